@@ -1,0 +1,476 @@
+"""Python restatement of the host-side half of MetaCherchant's environment-finder
+(everything in OneSequenceCalculator after the BFS, the seed reader, the read
+ingest policy and the writers).
+
+TEST INFRASTRUCTURE ONLY -- imported by tests/ and __graft_entry__.smoke(),
+never by the product package.  Plain Python loops: meant for environments of
+up to a few 10^5 k-mers.
+
+Citations: src/... = /root/reference/src/...; itmo!/x = ru/ifmo/genetics/x in
+/root/reference/lib/itmo-assembler-src.jar; JDK = java.util.HashMap of JDK 8
+(build.xml:36-37 targets 1.8).
+"""
+import os
+
+_COMP = {"A": "T", "C": "G", "G": "C", "T": "A"}
+
+
+def reverse_complement(s):
+    """itmo!/dna/DnaTools.java:139-145"""
+    return "".join(_COMP[c] for c in reversed(s))
+
+
+def normalize_dna(s):
+    """src/utils/StringUtils.java:34-41 (String.compareTo = ASCII order)"""
+    rc = reverse_complement(s)
+    return s if s < rc else rc
+
+
+def java_string_hash(s):
+    """JDK String.hashCode: h = 31*h + c, 32-bit wrap."""
+    h = 0
+    for ch in s:
+        h = (31 * h + ord(ch)) & 0xFFFFFFFF
+    return h
+
+
+class JavaHashMap:
+    """Iteration-order emulation of java.util.HashMap<String, V> (JDK 8), list bins.
+
+    put() appends new keys to the tail of their bin and keeps the position of
+    existing keys; resize() doubles at ++size > 0.75*cap and splits every bin
+    into lo/hi lists preserving relative order; iteration walks bins in index
+    order.  A bin that would be treeified (9th node appended while cap >= 64)
+    sets `treeified`: iteration order is then not guaranteed to match the JDK.
+    """
+
+    def __init__(self):
+        self.cap = 16
+        self.size = 0
+        self.bins = [[] for _ in range(16)]
+        self.index = {}
+        self.treeified = False
+
+    def put(self, key, val):
+        e = self.index.get(key)
+        if e is not None:
+            e[1] = val
+            return
+        h = java_string_hash(key)
+        h ^= h >> 16
+        e = [key, val, h, True]
+        self.index[key] = e
+        b = self.bins[h & (self.cap - 1)]
+        b.append(e)
+        if len(b) >= 9:  # binCount >= TREEIFY_THRESHOLD - 1 with 8 nodes already there
+            if self.cap >= 64:
+                self.treeified = True
+            else:
+                self._resize()  # treeifyBin resizes instead while tab.length < MIN_TREEIFY_CAPACITY
+        self.size += 1
+        if self.size > 0.75 * self.cap:
+            self._resize()
+
+    def _resize(self):
+        ncap = self.cap * 2
+        nb = [[] for _ in range(ncap)]
+        for b in self.bins:
+            for e in b:
+                if e[3]:
+                    nb[e[2] & (ncap - 1)].append(e)
+        self.cap = ncap
+        self.bins = nb
+
+    def get(self, key):
+        e = self.index.get(key)
+        return None if e is None else e[1]
+
+    def __contains__(self, key):
+        return key in self.index
+
+    def __len__(self):
+        return self.size
+
+    def remove(self, key):
+        e = self.index.pop(key, None)
+        if e is not None:
+            e[3] = False
+            self.bins[e[2] & (self.cap - 1)].remove(e)
+            self.size -= 1
+
+    def items(self):
+        for b in self.bins:
+            for e in b:
+                yield e[0], e[1]
+
+    def keys(self):
+        for k, _ in self.items():
+            yield k
+
+
+# --------------------------------------------------------------------------- readers
+
+def dnaq_to_string(s):
+    """itmo!/dna/DnaQ.java:21-30 + :227-229: N/n/. -> nuc 0 ('A'); ACGT case-insensitive."""
+    out = []
+    for ch in s:
+        if ch in "Nn.":
+            out.append("A")
+        elif ch in "ACGTacgt":
+            out.append(ch.upper())
+        else:
+            raise ValueError("Incorrect nucleotide char: \"%s\"" % ch)
+    return "".join(out)
+
+
+def rich_fasta_read(path):
+    """src/io/RichFastaReader.java:38-77 -> (dnas as strings, comments)"""
+    dnas, comments = [], []
+    last_comment = True
+    cur_comment, cur_dna = "", ""
+    with open(path, "r") as f:
+        data = f.read()
+    lines = data.split("\n")
+    if lines and lines[-1] == "":
+        lines.pop()
+    for line in lines:
+        if line.endswith("\r"):
+            line = line[:-1]
+        if line.startswith(">") or line.startswith(";"):
+            if not last_comment:
+                dnas.append(dnaq_to_string(cur_dna))
+                cur_dna, cur_comment = "", ""
+            cur_comment += line[1:]
+            last_comment = True
+        else:
+            if last_comment:
+                comments.append(cur_comment)
+                cur_dna, cur_comment = "", ""
+            cur_dna += line
+            last_comment = False
+    if len(cur_comment) > 0:
+        comments.append(cur_comment)
+    if len(cur_dna) > 0:
+        dnas.append(dnaq_to_string(cur_dna))
+    return dnas, comments
+
+
+def _lines(path):
+    with open(path, "r") as f:
+        for line in f:
+            line = line.rstrip("\n")
+            if line.endswith("\r"):
+                line = line[:-1]
+            yield line
+
+
+def read_fasta_reads(path):
+    """itmo!/io/readers/FastaReader.java:54-104: multi-line records concatenated,
+    records containing N/n dropped whole."""
+    out = []
+    sb = []
+
+    def flush():
+        if sb:
+            s = "".join(sb)
+            if len(s) > 0 and "N" not in s and "n" not in s:
+                out.append(s.upper())
+        sb.clear()
+
+    for line in _lines(path):
+        if line.startswith(">") or line.startswith(";"):
+            if len("".join(sb)) > 0:
+                flush()
+        else:
+            sb.append(line)
+    flush()
+    return out
+
+
+def read_fastq_reads(path):
+    """itmo!/io/readers/FastqReader.java:53-112 + FastaReaderFromXQSourceTrunc.java:61-95 +
+    itmo!/io/ReadersUtils.java:57-77: records split at every base with phred < 1 (the bad base
+    is dropped, every piece kept); quality offset Illumina+64 unless the first 1000 records hold
+    a char < 64, then Sanger+33."""
+    recs = []
+    it = iter(_lines(path))
+
+    def next_data():
+        for s in it:
+            if len(s) == 0:
+                continue
+            if not (s.startswith("@") or s.startswith("+")):
+                raise ValueError("Unknown structure of fastq file")
+            try:
+                return next(it)
+            except StopIteration:
+                raise ValueError("Unexpected end of file")
+        return None
+
+    while True:
+        d = next_data()
+        if d is None:
+            break
+        q = next_data()
+        if q is None or len(q) != len(d):
+            raise ValueError("Bad DnaQ record")
+        recs.append((d, q))
+    offset = 64
+    for d, q in recs[:1000]:
+        bad = False
+        for ch_d, ch_q in zip(d, q):
+            if ch_d in "Nn.":
+                continue
+            if ord(ch_q) < 64 or ord(ch_q) > 126:
+                bad = True
+                break
+        if bad:
+            offset = 33
+            break
+    out = []
+    for d, q in recs:
+        piece = []
+        for ch_d, ch_q in zip(d, q):
+            if ch_d in "Nn.":
+                ph = 0
+            else:
+                ph = ord(ch_q) - offset
+                if ph < 0 or ord(ch_q) > 126:
+                    raise ValueError("Invalid quality code char")
+            if ph < 1:
+                out.append("".join(piece))
+                piece = []
+            else:
+                piece.append(ch_d.upper())
+        out.append("".join(piece))
+    return [p for p in out if p]
+
+
+# --------------------------------------------------------------------------- calculator
+
+class SingleNode:
+    """src/algo/SingleNode.java:6-56"""
+    __slots__ = ("sequence", "id", "is_gene", "deleted", "rc", "neighbors", "color")
+
+    def __init__(self, sequence, id_, color, is_gene):
+        self.sequence = sequence
+        self.id = id_
+        self.is_gene = is_gene
+        self.color = color
+        self.deleted = False
+        self.rc = None
+        self.neighbors = []
+
+
+class Environment:
+    """State of one OneSequenceCalculator after buildEnvironment()."""
+
+    def __init__(self, k, seeds, merge):
+        self.k = k
+        self.seeds = seeds  # list of strings (--seq sequences only; Hi-C seeds excluded from isGeneNode)
+        self.merge = merge
+        self.subgraph = JavaHashMap()
+        self.nodes = None
+
+    # src/algo/OneSequenceCalculator.java:217-219 + :146-148
+    def add_pass(self, kmers, dists, covs, kept=None):
+        """One runBfs pass: oriented k-mer strings in discovery order."""
+        d = JavaHashMap()
+        for s, dist in zip(kmers, dists):
+            d.put(s, dist)
+        if kept is not None:  # :261 keySet().retainAll(visitedKmers)
+            for s, kp in zip(kmers, kept):
+                if not kp:
+                    d.remove(s)
+        cov = dict(zip(kmers, covs))
+        for s in d.keys():
+            self.subgraph.put(normalize_dna(s), int(cov[s]))
+        if d.treeified:
+            self.subgraph.treeified = True
+
+    # :297-310
+    def graph_txt(self):
+        return "".join("%s %d\n" % (s, c) for s, c in self.subgraph.items())
+
+    # :421-432
+    def _is_gene(self, seq, rc):
+        for s in self.seeds:
+            if seq in s or rc in s:
+                return True
+        return False
+
+    # :387-419
+    def initialize_structures(self):
+        k = self.k
+        nodes = []
+        for seq, _ in self.subgraph.items():
+            rc = reverse_complement(seq)
+            g = self._is_gene(seq, rc)
+            a = SingleNode(seq, len(nodes), "GREEN" if g else None, g)
+            b = SingleNode(rc, len(nodes) + 1, "GREEN" if g else None, g)
+            a.rc, b.rc = b, a
+            nodes += [a, b]
+        by_prefix = {}
+        for n in nodes:
+            by_prefix.setdefault(n.sequence[: k - 1], []).append(n)
+        for n in nodes:
+            lst = by_prefix.get(n.sequence[1:])
+            if lst is not None:
+                n.rc.neighbors.extend(lst)
+        self.nodes = nodes
+
+    # :312-324 + :453-462
+    def _merge_nodes(self, first_plus, second_minus):
+        k = self.k
+        first_minus, second_plus = first_plus.rc, second_minus.rc
+
+        def merge_labels(a, b):
+            if a[len(a) - (k - 1):] != b[: k - 1]:
+                raise AssertionError("Labels should be merged, but can not: %s and %s" % (a, b))
+            return a + b[k - 1:]
+
+        new_seq = merge_labels(second_plus.sequence, first_plus.sequence)
+        new_seq_rc = merge_labels(first_minus.sequence, second_minus.sequence)
+        second_plus.sequence = new_seq
+        first_minus.sequence = new_seq_rc
+        second_plus.rc = first_minus
+        first_minus.rc = second_plus
+        first_plus.deleted = True
+        second_minus.deleted = True
+
+    # :434-451
+    def do_merge(self):
+        nodes = self.nodes
+        while True:
+            acted = False
+            for n in nodes:
+                if not n.deleted and len(n.neighbors) == 1:
+                    other = n.neighbors[0]
+                    if len(other.neighbors) != 1 or n.is_gene != other.is_gene:
+                        continue
+                    self._merge_nodes(n, other)
+                    acted = True
+            if not acted:
+                break
+
+    @staticmethod
+    def _node_id(a):  # :464-466 / GFAWriter.java:84-86
+        return "%d%s" % (min(a.rc.id, a.id) + 1, "_start" if a.is_gene else "")
+
+    # :354-385
+    def seqs_fasta(self, chunk_length):
+        out = []
+        for n in self.nodes:
+            if not n.deleted and n.id < n.rc.id and len(n.sequence) >= chunk_length:
+                ids = set()
+                for nb in n.neighbors:
+                    ids.add(min(nb.id, nb.rc.id) + 1)
+                for nb in n.rc.neighbors:
+                    ids.add(min(nb.id, nb.rc.id) + 1)
+                ids.discard(min(n.id, n.rc.id) + 1)
+                out.append("> Id%s Length:%d Neighbors:[%s]\n%s\n" % (
+                    self._node_id(n), len(n.sequence), ", ".join(str(x) for x in sorted(ids)), n.sequence))
+        return "".join(out)
+
+    # src/io/writers/GFAWriter.java:47-99
+    def graph_gfa(self):
+        k = self.k
+        out = []
+        for n in self.nodes:
+            if not n.deleted and n.sequence <= n.rc.sequence:
+                cov = 0
+                s = n.sequence
+                for i in range(len(s) - k + 1):
+                    cov += self.subgraph.get(normalize_dna(s[i:i + k]))
+                cov += self.subgraph.get(normalize_dna(s[len(s) - k:])) * (k - 1)
+                out.append("S\t%s\t%s\tLN:i:%d\tKC:i:%d%s\n" % (
+                    self._node_id(n), s, len(s), cov, "" if n.color is None else "\tCL:Z:" + n.color))
+        for i in self.nodes:
+            if not i.deleted:
+                for j in i.neighbors:
+                    if not j.deleted:
+                        out.append("L\t%s\t%s\t%s\t%s\t%dM\n" % (
+                            self._node_id(i), "+" if i.sequence >= i.rc.sequence else "-",
+                            self._node_id(j), "+" if j.sequence <= j.rc.sequence else "-", k - 1))
+        return "".join(out)
+
+    # src/io/writers/TSVWriter.java:27-79
+    def tsv_nodes(self):
+        out = ["id\tlength\tseq\n"]
+        for i, n in enumerate(self.nodes):
+            if not n.deleted and n.sequence <= n.rc.sequence:
+                out.append("%d\t%d\t%s\n" % (i + 1, len(n.sequence), n.sequence))
+        return "".join(out)
+
+    def tsv_edges(self):
+        def nid(n):
+            base = str(n.id + 1) if n.sequence <= n.rc.sequence else "-" + str(n.rc.id + 1)
+            return base + ("_start" if n.is_gene else "")
+
+        out = ["source\ttarget\n"]
+        for i in self.nodes:
+            if not i.deleted:
+                for j in i.neighbors:
+                    if not j.deleted:
+                        out.append("%s\t%s\tpp\n" % (nid(i.rc), nid(j)))
+        return "".join(out)
+
+    # :326-339 createPicture
+    def files(self, chunk_length):
+        g = self.graph_txt()
+        self.initialize_structures()
+        self.do_merge()
+        return {
+            "graph.txt": g,
+            "seqs.fasta": self.seqs_fasta(chunk_length),
+            "graph.gfa": self.graph_gfa(),
+            "tsvs/nodes.tsv": self.tsv_nodes(),
+            "tsvs/edges.tsv": self.tsv_edges(),
+        }
+
+
+def write_files(files, out_dir):
+    for name, text in files.items():
+        p = os.path.join(out_dir, name)
+        os.makedirs(os.path.dirname(p), exist_ok=True)
+        with open(p, "w") as f:
+            f.write(text)
+
+
+# --------------------------------------------------------------------------- driver
+
+def environment_finder(table, k, mode, seqs, comments, out_dir, coverage=1, max_kmers=None, max_radius=None,
+                       bothdirs=False, chunk_length=1, trim=False, merge=False, hic_seqs=None):
+    """src/tools/EnvironmentFinderMain.java:185-243 runImpl + OneSequenceCalculator.run (:98-114),
+    on an already counted oracle table (oracle.pyoracle.Table).  Returns {output_prefix: files or None}."""
+    from . import pyoracle as po
+
+    if max_kmers is None and max_radius is None:
+        raise ValueError("At least one of --maxkmers and --maxradius parameters should be set")
+    mk = -1 if max_kmers is None else max_kmers
+    mr = -1 if max_radius is None else max_radius
+    jobs = []
+    if not merge:
+        for i, s in enumerate(seqs):
+            jobs.append((os.path.join(out_dir, comments[i]) + "/", [s], [s]))
+    else:
+        jobs.append((os.path.join(out_dir, "merged") + "/", list(seqs) + list(hic_seqs or []), list(seqs)))
+    results = {}
+    for prefix, bfs_seeds, gene_seqs in jobs:
+        env = Environment(k, gene_seqs, merge)
+        fail = False
+        for d in ([0] if bothdirs else [-1, 1]):  # :137-144
+            r = po.bfs(table, k, mode, [po.encode(s) for s in bfs_seeds], d, coverage, mk, mr, trim)
+            if r is None:
+                fail = True
+                break
+            kmers = [po.kmer_string(h, l, k) for h, l in zip(r["hi"], r["lo"])]
+            env.add_pass(kmers, r["dist"], r["cov"], r["kept"] if trim else None)
+        if fail:
+            results[prefix] = None  # "Could not find any k-mers of the target gene in the input, halting."
+            continue
+        files = env.files(chunk_length)
+        files["env.txt"] = files["graph.txt"]
+        write_files(files, prefix)
+        results[prefix] = files
+    return results
