@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- k-mers/s processed (count + BFS) at k=31 on MI355X, BASELINE.json's metric.
+
+One "step" = one full pass of the environment-finder hot path over one synthetic read set that is
+already resident in HBM: empty the table, count every k-mer occurrence (mc_add_reads_packed_dev),
+finalize, then the two BFS passes of --bothdirs False (runBfs(-1), runBfs(+1)) with
+--coverage 5 --maxkmers 100000.  Workload = BASELINE.json configs[1]: 10 M x 150 bp reads per GPU
+drawn from 10 x 5 Mb random contigs; for --gpus N > 1 every rank holds
+its own 10 M reads (weak scaling), keys are exchanged with one RCCL all-to-all bucketed by hash
+prefix, thresholded shards are all-gathered and rank 0 runs the BFS.
+
+Prints ONE JSON line on rank 0 (contract in the task brief) with `roofline` (dominant kernel =
+the counting kernel, algorithmic bytes per k-mer occurrence from SURVEY.md section 8(d)) and
+`cpu_baseline` (oracle/ multi-threaded restatement of the reference's design, timed on the host
+cores on a bounded sample; N=1, rank 0 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GENOME_SEED, READ_SEED = 20240531, 42
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--k", type=int, default=31)
+    ap.add_argument("--contigs", type=int, default=10)
+    ap.add_argument("--contig-len", type=int, default=5_000_000)
+    ap.add_argument("--err", type=int, default=100, help="substitution errors per 10000 bases (E1=100, E0=0)")
+    ap.add_argument("--coverage", type=int, default=5)
+    ap.add_argument("--maxkmers", type=int, default=100000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import metacherchant_amd as m
+    from metacherchant_amd.distributed import ShardedCounter
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    k, L, R = args.k, args.read_len, args.reads
+    mode = m.KEY_PACKED if k <= 31 else m.KEY_POLY
+    n_bases = R * L
+    windows = R * (L - k + 1)
+    genome_bases = args.contigs * args.contig_len
+    # expected distinct keys: the genome's k-mers + ~k novel k-mers per substitution error
+    est_distinct = int(min(world * windows, genome_bases + world * n_bases * (args.err / 10000.0) * k * 0.9))
+    hint_local = est_distinct // world + (1 << 20)
+
+    ctx = m.Context(k, mode, local_rank, hint_local)
+    solid = None
+    if world > 1 and rank == 0:
+        solid = m.Context(k, mode, local_rank, genome_bases + (1 << 20))
+
+    # ---- synthetic reads straight into HBM (not timed)
+    n_words = (n_bases + 31) // 32 + 1
+    d_words = torch.empty(n_words, dtype=torch.int64, device=dev)
+    d_off = torch.empty(R + 1, dtype=torch.int64, device=dev)
+    ctx.synth_reads_dev(GENOME_SEED, args.contigs, args.contig_len, READ_SEED, rank * R, R, L, args.err, d_words, d_off)
+    # seed gene: contig 0, bases [100000, 101000)
+    seed = m.native.synth_genome(GENOME_SEED, 100000, 1000)
+    sv = [0] * (len(seed) - k + 1)
+    for i in range(len(sv)):
+        v = 0
+        for c in seed[i:i + k]:
+            v = (v << 2) | int(c)
+        sv[i] = v
+    seed_hi = np.array([v >> 64 for v in sv], dtype=np.uint64)
+    seed_lo = np.array([v & 0xFFFFFFFFFFFFFFFF for v in sv], dtype=np.uint64)
+
+    sc = ShardedCounter(ctx, dev)
+    info = {}
+
+    def step():
+        ctx.clear()
+        sc.add_reads_dev(d_words, d_off, R, n_bases, windows)
+        info["distinct"] = sc.finalize()
+        bctx = ctx
+        if world > 1:
+            if solid is not None:
+                solid.clear()
+            info["solid"] = sc.gather_solid(solid, args.coverage, dst=0)
+            bctx = solid
+        if rank == 0:
+            bfs_ms, reached, levels, lookups = 0.0, 0, 0, 0
+            for d in (-1, 1):  # buildEnvironment with bothdirs=False
+                r = bctx.bfs(seed_hi, seed_lo, d, args.coverage, args.maxkmers, -1)
+                if r is None:
+                    raise SystemExit("BFS found no seed k-mer: synthetic workload broken")
+                bfs_ms += r["device_ms"]
+                reached += len(r["lo"])
+                levels += r["levels"]
+                lookups += r["lookups"]
+            info.update(bfs_ms=bfs_ms, reached=reached, levels=levels, lookups=lookups)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    ctx.reset_stats()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = ctx.stats()
+
+    out = None
+    if rank == 0:
+        total_windows = windows * world
+        value = total_windows * args.steps / elapsed
+        ms_per_step = 1e3 * elapsed / args.steps
+        distinct = info["distinct"]
+        # algorithmic bytes per k-mer occurrence: packed read bits + key read +
+        # count read + count write + key write on first insertion
+        A = L / (4.0 * (L - k + 1)) + 12.0 + 8.0 * distinct / float(total_windows)
+        launches = max(int(st.count_launches), 1)
+        avg_ms = st.count_ms / launches if st.count_launches else None
+        units_per_launch = st.windows / launches
+        roofline = None
+        if avg_ms:
+            achieved = units_per_launch * A / (avg_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "kernel": "k_count_reads" if world == 1 else "k_add_keys",
+                        "bytes_per_kmer": round(A, 3), "avg_launch_ms": round(avg_ms, 4),
+                        "launches_per_step": launches / args.steps,
+                        "count_ms_per_step": round(st.count_total_ms / args.steps, 3)}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args, k, mode, L)
+        out = {
+            "metric": "k-mers/s processed (count+BFS) at k=%d" % k, "value": value, "unit": "k-mers/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: %dx%dbp reads per GPU, %dx%d bp random contigs, k=%d, coverage=%d, "
+                                   "maxkmers=%d, bothdirs=False, %s" % (
+                                       R, L, args.contigs, args.contig_len, k, args.coverage, args.maxkmers,
+                                       "E1 1%% substitutions" if args.err == 100 else "err=%d/10000" % args.err),
+                       "reads_per_gpu": R, "read_len": L, "k": k, "err_per_10k": args.err,
+                       "parallelism": "reads sharded x%d, all-to-all by hash prefix" % world if world > 1 else "1 GPU"},
+            "distinct_kmers": distinct, "bfs": {"ms_per_step": round(info["bfs_ms"], 3), "reached": info["reached"],
+                                                 "levels": info["levels"], "lookups": info["lookups"]},
+            "table_bytes": int(st.table_bytes), "table_grows": int(st.grows),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        if world > 1:
+            out["solid_kmers"] = info.get("solid")
+            out["alltoall_bytes_sent_rank0_per_step"] = sc.bytes_sent // (args.steps + args.warmup)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+def cpu_baseline(args, k, mode, L):
+    """oracle/'s multi-threaded restatement of the reference's design (lock-striped sub-maps,
+    32768-read work items) on the host cores, on a bounded sample of the same workload."""
+    import numpy as np
+
+    from oracle import pyoracle as po
+    n = min(args.cpu_sample_reads, args.reads)
+    genome = po.synth_genome(GENOME_SEED, args.contigs * args.contig_len)
+    reads = po.synth_reads(genome, args.contigs, args.contig_len, READ_SEED, 0, n, L, args.err)
+    words = po.pack(reads)
+    off = np.arange(n + 1, dtype=np.uint64) * L
+    cores = os.cpu_count() or 1
+    w, nd, sec, _ = po.count_reads_packed_mt(words, off, k, 0 if mode == 0 else mode, cores)
+    return {"value": w / sec, "unit": "k-mers/s", "cores": cores, "kind": "port",
+            "sample": "count phase only, first %d reads of the same synthetic set (%d k-mer occurrences, %d distinct), "
+                      "%.2f s" % (n, w, nd, sec)}
+
+
+if __name__ == "__main__":
+    main()

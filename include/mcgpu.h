@@ -1,0 +1,187 @@
+/*
+ * mcgpu.h -- C ABI of libmcgpu.so: the MI355X (gfx950) implementation of MetaCherchant's
+ * environment-finder hot path (k-mer counting over the read set + coverage-thresholded
+ * de Bruijn BFS from the seed sequences).
+ *
+ * This is the drop-in boundary.  The reference has no FFI: the seam is ordinary Java calls
+ * inside one JVM, so each entry point below names the Java method whose body it replaces
+ * (src/... = the reference's src/ tree, itmo!/x = ru/ifmo/genetics/x in
+ * lib/itmo-assembler-src.jar).  INTEGRATION.md shows the JNI stub a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative MC_E* code; the message is available
+ *     from mc_last_error().  The library never calls exit() and no C++ exception crosses the ABI
+ *     (the reference throws ExecutionFailedException, itmo!/utils/tool/Tool.java:450-462).
+ *   - plain pointers and sizes only.  Functions ending in _dev take pointers to device (HBM)
+ *     memory of the context's device; all others take host pointers.
+ *   - a context is not re-entrant for mutation (mc_add_*, mc_finalize_counts).  After
+ *     mc_finalize_counts, mc_get* and mc_bfs are read-only on the table; calls on ONE context
+ *     are serialised internally, several contexts may be used from several threads.
+ *
+ * Data layout of reads ("2-bit packed"):
+ *   base code A=0 G=1 C=2 T=3 (itmo!/dna/DnaTools.java:31 -- note: not ACGT order);
+ *   base i of the concatenated read set lives in words[i >> 5], bits (63 - 2*(i & 31)) .. (62 - 2*(i & 31))
+ *   (first base = most significant, itmo!/utils/KmerUtils.java:24-39);
+ *   read r covers bases [read_offsets[r], read_offsets[r+1]); read_offsets has n_reads + 1 entries;
+ *   words[] must hold ceil(n_bases / 32) + 1 entries (one readable pad word).
+ *   Reads must be pure ACGT: the N policy of the readers (FASTA records with N dropped, FASTQ
+ *   split at phred < 1, itmo!/io/readers/FastaReader.java:54-76,
+ *   itmo!/io/readers/FastaReaderFromXQSourceTrunc.java:61-95) is applied by the caller
+ *   (metacherchant_amd's host reader does it) before packing.
+ */
+#ifndef MCGPU_H
+#define MCGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MC_ABI_VERSION 1
+
+/* error codes */
+#define MC_OK 0
+#define MC_EINVAL (-1)    /* bad argument */
+#define MC_ENOMEM (-2)    /* host or device allocation failed */
+#define MC_EHIP (-3)      /* HIP runtime error (message has the HIP error string) */
+#define MC_ESTATE (-4)    /* call not allowed in this state (e.g. mc_get before mc_finalize_counts) */
+#define MC_EOVERFLOW (-5) /* an internal capacity was exceeded and could not be grown */
+#define MC_ENOSEED (-6)   /* no seed k-mer reaches min_cov: the reference's "fail"
+                             (src/algo/OneSequenceCalculator.java:193-196) */
+
+/* Key modes, chosen exactly as src/tools/EnvironmentFinderMain.java:128-136,157-169:
+ * k <= 31 and !forcehash -> PACKED (key = min(fw, rc) of the 2-bit packed k-mer as signed long,
+ * itmo!/dna/kmers/ShortKmer.java:54-56); otherwise a 64-bit strand-symmetric hash of the k-mer
+ * (src/utils/PolynomialHash.java:19-28 default, src/utils/FNV1AHash.java:33-42 with --hash fnv1a);
+ * colliding k-mers share a counter, as in the reference. */
+enum { MC_KEY_PACKED = 0, MC_KEY_POLY = 1, MC_KEY_FNV1A = 2 };
+
+typedef struct mc_ctx mc_ctx;
+
+typedef struct {
+    int32_t k;              /* 1..31 for MC_KEY_PACKED, 1..63 for the hash modes */
+    int32_t key_mode;       /* MC_KEY_* */
+    int32_t device;         /* HIP device ordinal */
+    int32_t flags;          /* 0 */
+    uint64_t capacity_hint; /* expected number of distinct keys; 0 = start small and grow */
+} mc_config;
+
+/* Tool lifetime: one context = one k-mer table = the BigLong2ShortHashMap created by
+ * src/io/IOUtils.java:220-221 / src/io/LargeKIOUtils.java:60-61. */
+int mc_create(const mc_config *cfg, mc_ctx **out);
+void mc_destroy(mc_ctx *ctx);
+/* ctx may be NULL: returns the message of the last failed mc_create on this thread. */
+const char *mc_last_error(const mc_ctx *ctx);
+int mc_abi_version(void);
+
+/* Empties the table (keeps its allocation): a fresh BigLong2ShortHashMap without paying hipMalloc again. */
+int mc_clear(mc_ctx *ctx);
+
+/* Use the caller's HIP stream (a hipStream_t passed as void*) for all work of this context
+ * instead of the context's own stream.  NULL restores the own stream. */
+int mc_set_stream(mc_ctx *ctx, void *hip_stream);
+
+/* ---- counting: replaces ReadsLoadWorker.process (src/io/IOUtils.java:201-214,
+ * src/io/LargeKIOUtils.java:41-54): for every window of every read, addAndBound(key, 1).
+ * May be called repeatedly (one call per batch / file); the result does not depend on call or
+ * read order.  Reads shorter than k contribute nothing. */
+int mc_add_reads_packed(mc_ctx *ctx, const uint64_t *words, const uint64_t *read_offsets, uint64_t n_reads);
+int mc_add_reads_packed_dev(mc_ctx *ctx, const uint64_t *d_words, const uint64_t *d_read_offsets,
+                            uint64_t n_reads, uint64_t n_bases);
+
+/* End of loadReads (src/io/IOUtils.java:217-248): waits for all queued counting work;
+ * *n_distinct = hm.size() ("Hashtable size: N kmers", src/tools/EnvironmentFinderMain.java:137). */
+int mc_finalize_counts(mc_ctx *ctx, uint64_t *n_distinct);
+
+/* BigLong2ShortHashMap.get (itmo!/structures/map/BigLong2ShortHashMap.java:74-77 ->
+ * Long2ShortHashMap.java:160-175): out[i] = count saturated at 32767
+ * (itmo!/utils/NumUtils.java:21-26), or -1 when the key is absent.  Key 0 is legal. */
+int mc_get(mc_ctx *ctx, const int64_t *keys, uint64_t n, int16_t *out);
+int mc_get_dev(mc_ctx *ctx, const int64_t *d_keys, uint64_t n, int16_t *d_out);
+
+/* getKmerKey (src/algo/OneSequenceCalculator.java:89-96) for packed oriented k-mers:
+ * k-mer i is the 2k-bit number (hi[i] << 64 | lo[i]), first base most significant
+ * (hi may be NULL when k <= 32).  Host pointers. */
+int mc_kmer_keys(mc_ctx *ctx, const uint64_t *hi, const uint64_t *lo, uint64_t n, int64_t *out_keys);
+
+/* ---- BFS: replaces OneSequenceCalculator.runBfs up to (not including) runTrimPaths
+ * (src/algo/OneSequenceCalculator.java:154-214) with TerminationMode.allowsAddition
+ * (src/algo/TerminationMode.java:31-47).
+ *
+ * Seeds are the k-windows of the seed sequences in file order (then Hi-C seeds when merging),
+ * as oriented packed k-mers; the library looks their coverage up and queues those with
+ * count >= min_cov (:159-192).  dir: -1 left neighbours, +1 right, 0 all eight interleaved
+ * L(A) R(A) L(G) R(G) L(C) R(C) L(T) R(T) (src/utils/StringUtils.java:8-32).
+ * max_kmers / max_radius: < 0 = unset (at least one must be set, EnvironmentFinderMain.java:171-175).
+ *
+ * The result lists the entries of distanceToKmer in insertion order (= BFS discovery order, seeds
+ * first, duplicates once): the oriented k-mer, its distance, reads.get(key) and whether the vertex
+ * is in lastKmers (needed by runTrimPaths, :241-262, which the host applies).  Arrays are
+ * malloc()ed by the library; release with mc_bfs_result_free. */
+typedef struct {
+    uint64_t n;
+    uint64_t *hi, *lo; /* oriented k-mers (hi all zero when k <= 32) */
+    int32_t *dist;
+    int16_t *cov;
+    uint8_t *last;
+    uint64_t levels;     /* largest distance assigned */
+    uint64_t lookups;    /* table lookups issued (speculative ones included) */
+    double device_ms;    /* device time of the BFS kernels, HIP events */
+} mc_bfs_result;
+
+int mc_bfs(mc_ctx *ctx, const uint64_t *seed_hi, const uint64_t *seed_lo, uint64_t n_seeds, int dir,
+           int min_cov, int64_t max_kmers, int64_t max_radius, mc_bfs_result *out);
+void mc_bfs_result_free(mc_bfs_result *r);
+
+/* ---- table export / import: (key, count) pairs with count >= min_cov, unordered.
+ * Also the record content of the reference's .kmers.bin (src/io/KmersLoadWorker.java:9,20-23)
+ * and the payload of the multi-GPU gather.  With keys == NULL only *n_out is computed. */
+int mc_export(mc_ctx *ctx, int min_cov, int64_t *keys, int16_t *counts, uint64_t cap, uint64_t *n_out);
+int mc_export_dev(mc_ctx *ctx, int min_cov, int64_t *d_keys, int16_t *d_counts, uint64_t cap, uint64_t *n_out);
+/* table[key] = min(32767, table[key] + count) for each pair (saturating adds commute). */
+int mc_add_pairs_dev(mc_ctx *ctx, const int64_t *d_keys, const int16_t *d_counts, uint64_t n);
+
+/* ---- multi-GPU building blocks (device pointers).  The read set is split across ranks; each
+ * rank turns its reads into keys bucketed by owner rank, ranks exchange buckets (RCCL
+ * all-to-all, done by the caller), and each rank counts the keys it owns. */
+/* owner of a key among n_owners ranks; pure function, same on every rank */
+uint32_t mc_key_owner(int64_t key, uint32_t n_owners);
+/* Writes the keys of all windows grouped by owner into d_keys (capacity = total windows):
+ * owner o's keys are d_keys[owner_offsets[o] .. owner_offsets[o+1]); owner_offsets (host,
+ * n_owners + 1 entries) is filled on return. */
+int mc_extract_keys_dev(mc_ctx *ctx, const uint64_t *d_words, const uint64_t *d_read_offsets, uint64_t n_reads,
+                        uint64_t n_bases, uint32_t n_owners, int64_t *d_keys, uint64_t keys_cap,
+                        uint64_t *owner_offsets);
+/* addAndBound(key, 1) for each key */
+int mc_add_keys_dev(mc_ctx *ctx, const int64_t *d_keys, uint64_t n);
+
+/* ---- measurement */
+typedef struct {
+    uint64_t windows;        /* k-mer occurrences counted so far */
+    uint64_t count_launches; /* launches of the dominant counting kernel */
+    double count_ms;         /* their summed device time (HIP events on the context's stream) */
+    double count_total_ms;   /* device time of all counting-phase kernels */
+    uint64_t table_slots;    /* current table capacity (slots) */
+    uint64_t table_bytes;
+    uint64_t grows;          /* number of table rebuilds */
+} mc_stats;
+int mc_get_stats(mc_ctx *ctx, mc_stats *out);
+int mc_reset_stats(mc_ctx *ctx);
+
+/* ---- synthetic workload of SURVEY.md section 8(d) (spec: DESIGN.md "Synthetic workload"),
+ * generated straight into HBM so that benchmarks start with the reads resident.
+ * Reads r = first_read .. first_read + n_reads - 1 of fixed length read_len drawn from
+ * n_contigs contigs of contig_len bases; err_per_10k = substitution rate in 1/10000.
+ * d_words needs ceil(n_reads*read_len/32) + 1 words, d_read_offsets n_reads + 1. */
+int mc_synth_reads_dev(mc_ctx *ctx, uint64_t genome_seed, uint64_t n_contigs, uint64_t contig_len,
+                       uint64_t read_seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len,
+                       uint32_t err_per_10k, uint64_t *d_words, uint64_t *d_read_offsets);
+/* bases [start, start + n) of the synthetic genome as codes 0..3 (host buffer) */
+int mc_synth_genome(uint64_t genome_seed, uint64_t start, uint64_t n, uint8_t *codes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCGPU_H */

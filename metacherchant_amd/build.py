@@ -1,0 +1,74 @@
+"""Builds the native parts in-tree: libmcgpu.so (HIP, gfx950) and the C++ host tool.
+
+hipcc cross-compiles without a GPU.  Outputs land in metacherchant_amd/lib/ (git-ignored, but they
+travel to the GPU box with the gpurun snapshot).
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libmcgpu.so")
+CLI = os.path.join(LIBDIR, "metacherchant")
+
+HIP_SOURCES = ["mcgpu.hip"]
+HIP_DEPS = ["kmer_device.h", os.path.join(ROOT, "include", "mcgpu.h")]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm to build libmcgpu.so)")
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources if os.path.exists(s))
+
+
+def build_lib(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    deps = srcs + [d if os.path.isabs(d) else os.path.join(CSRC, d) for d in HIP_DEPS]
+    if not force and not _stale(LIB, deps):
+        return LIB
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra",
+           "-I", os.path.join(ROOT, "include"), "-o", LIB] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+def build_host(force=False, verbose=False):
+    """C++ host side (CLI + writers); see csrc/host/."""
+    hdir = os.path.join(CSRC, "host")
+    if not os.path.isdir(hdir):
+        return None
+    srcs = sorted(os.path.join(hdir, f) for f in os.listdir(hdir) if f.endswith(".cpp"))
+    hdrs = sorted(os.path.join(hdir, f) for f in os.listdir(hdir) if f.endswith(".h"))
+    if not srcs:
+        return None
+    if not force and not _stale(CLI, srcs + hdrs + [LIB]):
+        return CLI
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"), "-o", CLI] + srcs + [
+        "-L", LIBDIR, "-lmcgpu", "-Wl,-rpath,$ORIGIN", "-lpthread"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return CLI
+
+
+def build_all(force=False, verbose=False):
+    build_lib(force, verbose)
+    build_host(force, verbose)
+
+
+if __name__ == "__main__":
+    build_all(force=True, verbose=True)

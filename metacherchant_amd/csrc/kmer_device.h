@@ -1,0 +1,233 @@
+// Device-side k-mer arithmetic for gfx950 (wave64).  Every function names the reference code
+// whose result it must reproduce bit for bit (src/... = reference src/, itmo!/x =
+// ru/ifmo/genetics/x in lib/itmo-assembler-src.jar).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mc {
+
+constexpr int KEY_PACKED = 0, KEY_POLY = 1, KEY_FNV1A = 2;
+constexpr uint64_t EMPTY_KEY = 0xFFFFFFFFFFFFFFFFull;  // never a packed key (those are < 2^62)
+
+struct Kmer {  // oriented k-mer, 2k bits right-aligned in 128, first base most significant
+    uint64_t hi, lo;
+};
+
+__host__ __device__ __forceinline__ uint64_t fmix64(uint64_t x)
+{
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull;
+    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull;
+    x ^= x >> 33;
+    return x;
+}
+
+// SplitMix64, n-th output of the generator seeded with `seed` (DESIGN.md "Synthetic workload")
+__host__ __device__ __forceinline__ uint64_t splitmix(uint64_t seed, uint64_t n)
+{
+    uint64_t z = seed + (n + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// itmo!/utils/KmerUtils.java:12-22 reverseComplement(kmer, k): reverse the 2-bit groups,
+// complement, right-align.  v_bfrev reverses single bits, so swap the bits of each pair back.
+__host__ __device__ __forceinline__ uint64_t rc_packed(uint64_t x, int k)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t r = __brevll(x);
+#else
+    uint64_t r = x;
+    r = ((r & 0x5555555555555555ull) << 1) | ((r >> 1) & 0x5555555555555555ull);
+    r = ((r & 0x3333333333333333ull) << 2) | ((r >> 2) & 0x3333333333333333ull);
+    r = ((r & 0x0f0f0f0f0f0f0f0full) << 4) | ((r >> 4) & 0x0f0f0f0f0f0f0f0full);
+    r = ((r & 0x00ff00ff00ff00ffull) << 8) | ((r >> 8) & 0x00ff00ff00ff00ffull);
+    r = ((r & 0x0000ffff0000ffffull) << 16) | ((r >> 16) & 0x0000ffff0000ffffull);
+    r = (r << 32) | (r >> 32);
+#endif
+    r = ((r & 0x5555555555555555ull) << 1) | ((r >> 1) & 0x5555555555555555ull);
+    return (~r) >> (64 - 2 * k);
+}
+
+__host__ __device__ __forceinline__ uint32_t base_at(const Kmer &v, int k, int i)
+{  // i-th base, 0 = first
+    const int sh = 2 * (k - 1 - i);
+    return (uint32_t)((sh >= 64 ? (v.hi >> (sh - 64)) : (v.lo >> sh)) & 3);
+}
+
+// itmo!/dna/kmers/ShortKmer.java:54-56 toLong = Math.min(fwKmer, rcKmer) on signed longs
+// (both are < 2^62 for k <= 31, so the unsigned min is the same number)
+__host__ __device__ __forceinline__ int64_t key_packed(uint64_t fw, int k)
+{
+    const int64_t a = (int64_t)fw, b = (int64_t)rc_packed(fw, k);
+    return a < b ? a : b;
+}
+
+// src/utils/PolynomialHash.java:19-28
+__host__ __device__ inline int64_t key_poly(const Kmer &v, int k)
+{
+    uint64_t fw = 1, rc = 1;
+    for (int i = 0; i < k; i++) {
+        fw = fw * 5 + base_at(v, k, i);
+        rc = rc * 5 + (3u ^ base_at(v, k, k - 1 - i));
+    }
+    const int64_t a = (int64_t)fw, b = (int64_t)rc;
+    return a < b ? a : b;  // Math.min on signed longs
+}
+
+// src/utils/FNV1AHash.java:8-9,33-42
+__host__ __device__ inline int64_t key_fnv1a(const Kmer &v, int k)
+{
+    const uint64_t prime = 1099511628211ull;
+    uint64_t fw = 14695981039346656037ull, rc = 14695981039346656037ull;
+    for (int i = 0; i < k; i++) {
+        fw = (fw ^ (uint64_t)base_at(v, k, i)) * prime;
+        rc = (rc ^ (uint64_t)(3u ^ base_at(v, k, k - 1 - i))) * prime;
+    }
+    const int64_t a = (int64_t)fw, b = (int64_t)rc;
+    return a < b ? a : b;
+}
+
+// src/algo/OneSequenceCalculator.java:89-96 getKmerKey / src/tools/EnvironmentFinderMain.java:128
+template <int MODE>
+__host__ __device__ __forceinline__ int64_t key_of(const Kmer &v, int k)
+{
+    if (MODE == KEY_PACKED) return key_packed(v.lo, k);
+    if (MODE == KEY_POLY) return key_poly(v, k);
+    return key_fnv1a(v, k);
+}
+
+__host__ __device__ inline int64_t key_of_mode(const Kmer &v, int k, int mode)
+{
+    if (mode == KEY_PACKED) return key_of<KEY_PACKED>(v, k);
+    if (mode == KEY_POLY) return key_of<KEY_POLY>(v, k);
+    return key_of<KEY_FNV1A>(v, k);
+}
+
+// The k-mer starting at base p of the packed read set (layout: include/mcgpu.h).
+__device__ __forceinline__ Kmer extract_kmer(const uint64_t *__restrict__ words, uint64_t p, int k)
+{
+    const uint64_t wi = p >> 5;
+    const int off = 2 * (int)(p & 31);
+    const uint64_t w0 = words[wi], w1 = words[wi + 1];  // wi + 1 is at worst the pad word
+    const uint64_t a = off ? ((w0 << off) | (w1 >> (64 - off))) : w0;  // bases p .. p+31
+    Kmer r;
+    if (k <= 32) {
+        r.hi = 0;
+        r.lo = a >> (64 - 2 * k);
+        return r;
+    }
+    const uint64_t w2 = (off + 2 * k > 128) ? words[wi + 2] : 0;  // only touched when it holds real bases
+    const uint64_t b = off ? ((w1 << off) | (w2 >> (64 - off))) : w1;  // bases p+32 .. p+63
+    const int s = 128 - 2 * k;  // 2 .. 62
+    r.hi = a >> s;
+    r.lo = (a << (64 - s)) | (b >> s);
+    return r;
+}
+
+// Neighbours in the reference's order (src/utils/StringUtils.java:8-32, NUCLEOTIDES = A,G,C,T =
+// codes 0..3): dir -1: j-th left neighbour = code j + kmer[0..k-2]; dir +1: kmer[1..] + code j;
+// dir 0: index 2c = left(c), 2c+1 = right(c).
+__host__ __device__ __forceinline__ Kmer neighbour(const Kmer &v, int k, int dir, int j)
+{
+    const bool left = dir < 0 || (dir == 0 && !(j & 1));
+    const uint64_t c = (uint64_t)(dir == 0 ? (j >> 1) : j);
+    Kmer r;
+    if (left) {  // (v >> 2) | c << 2(k-1)
+        r.lo = (v.lo >> 2) | (v.hi << 62);
+        r.hi = v.hi >> 2;
+        const int sh = 2 * (k - 1);
+        if (sh >= 64) r.hi |= c << (sh - 64); else r.lo |= c << sh;
+    } else {  // ((v << 2) | c) & mask
+        r.hi = (v.hi << 2) | (v.lo >> 62);
+        r.lo = (v.lo << 2) | c;
+        if (k <= 32) {
+            r.hi = 0;
+            if (k < 32) r.lo &= (1ull << (2 * k)) - 1;
+        } else {
+            r.hi &= (1ull << (2 * k - 64)) - 1;
+        }
+    }
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The k-mer table in HBM (layout free: SURVEY.md F7).  2^rb regions of RS = 2^sb slots; a key
+// lives in region = top rb bits of fmix64(key), starting at offset = next sb bits, linear
+// probing that wraps inside the region.  A slot is 16 bytes {u64 key; u32 count; u32 aux} so one
+// dwordx4 load returns key and count together and a region is one contiguous run of lines.
+struct Slot {
+    uint64_t key;
+    uint32_t count;
+    uint32_t aux;
+};
+
+struct TableView {
+    Slot *slots;
+    uint32_t shift;   // 64 - (rb + sb)
+    uint32_t rmask;   // RS - 1
+    unsigned long long *n_used;     // distinct keys stored in slots
+    unsigned long long *empty_cnt;  // occurrences of the key that equals EMPTY_KEY (hash modes only)
+    uint32_t *fatal;                // set when a region is full
+};
+
+__device__ __forceinline__ uint64_t slot_of(const TableView &t, uint64_t key) { return fmix64(key) >> t.shift; }
+
+// addAndBound(key, inc) with the saturation deferred to read time (count is 32-bit here; a
+// counter that already reached 2^31 is left alone, launches add < 2^30 each, so it never wraps
+// and min(32767, count) equals the reference's saturating short, itmo!/utils/NumUtils.java:21-26).
+__device__ __forceinline__ void table_add(const TableView &t, uint64_t key, uint32_t inc)
+{
+    if (key == EMPTY_KEY) {
+        atomicAdd(t.empty_cnt, (unsigned long long)inc);
+        return;
+    }
+    uint64_t s = slot_of(t, key);
+    const uint64_t base = s & ~(uint64_t)t.rmask;
+    for (uint32_t probe = 0; probe <= t.rmask; probe++) {
+        Slot *p = t.slots + s;
+        const uint4 raw = *reinterpret_cast<const uint4 *>(p);
+        uint64_t cur = ((uint64_t)raw.y << 32) | raw.x;
+        if (cur == EMPTY_KEY) {
+            // a stale EMPTY is harmless: the CAS runs at the coherent memory side and decides
+            cur = atomicCAS(reinterpret_cast<unsigned long long *>(&p->key), (unsigned long long)EMPTY_KEY,
+                            (unsigned long long)key);
+            if (cur == EMPTY_KEY) {
+                atomicAdd(t.n_used, 1ull);
+                atomicAdd(&p->count, inc);
+                return;
+            }
+            if (cur == key) {
+                atomicAdd(&p->count, inc);
+                return;
+            }
+        } else if (cur == key) {
+            if (raw.z < 0x80000000u) atomicAdd(&p->count, inc);
+            return;
+        }
+        s = base | ((s + 1) & t.rmask);
+    }
+    atomicExch(t.fatal, 1u);
+}
+
+// BigLong2ShortHashMap.get: -1 when absent, else min(32767, count)
+__device__ __forceinline__ int table_get(const TableView &t, uint64_t key)
+{
+    if (key == EMPTY_KEY) {
+        const unsigned long long c = *t.empty_cnt;
+        return c == 0 ? -1 : (c > 32767ull ? 32767 : (int)c);
+    }
+    uint64_t s = slot_of(t, key);
+    const uint64_t base = s & ~(uint64_t)t.rmask;
+    for (uint32_t probe = 0; probe <= t.rmask; probe++) {
+        const uint4 raw = *reinterpret_cast<const uint4 *>(t.slots + s);
+        const uint64_t cur = ((uint64_t)raw.y << 32) | raw.x;
+        if (cur == key) return raw.z > 32767u ? 32767 : (int)raw.z;
+        if (cur == EMPTY_KEY) return -1;
+        s = base | ((s + 1) & t.rmask);
+    }
+    return -1;
+}
+
+}  // namespace mc

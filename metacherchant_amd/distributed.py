@@ -1,0 +1,98 @@
+"""Multi-GPU counting for the environment-finder path: one process per GPU, RCCL over xGMI.
+
+SURVEY.md section 8(e).  The reference has nothing distributed (one JVM, threads over one
+shared map, src/io/IOUtils.java:283-315); what shards here is its data-parallel work list
+(src/io/ReadsDispatcher.java:34-53): every rank takes a slice of the read set, turns it into keys
+bucketed by owner rank (owner = hash bits disjoint from the slot index, mc_key_owner), the ranks
+exchange the buckets with ONE all-to-all (all 7 xGMI links of a GPU busy at once -- unlike a ring),
+and each rank counts only the keys it owns.  Counting is then identical to the 1-GPU path.  For
+the BFS the thresholded shards (count >= coverage: everything the BFS can ever ask for, since
+absent and below-threshold are indistinguishable to `occs >= minOccurences`,
+src/algo/OneSequenceCalculator.java:203-204) are all-gathered and merged into one "solid" table
+on the rank(s) that run the BFS; a distributed per-level BFS is rejected because the frontier is
+typically one vertex wide.
+
+`backend` objects only need the Context methods used below, so the CPU (gloo) tests drive this
+file with a stand-in built on the oracle; the product always passes metacherchant_amd.Context.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class ShardedCounter:
+    def __init__(self, ctx, device, group=None):
+        self.ctx = ctx
+        self.device = device
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.bytes_sent = 0
+
+    def add_reads_dev(self, d_words, d_offsets, n_reads, n_bases, max_windows):
+        """Counts this rank's reads into the sharded table: extract -> all-to-all -> count owned keys.
+        max_windows bounds the number of k-mer occurrences of the local reads (n_bases is always enough)."""
+        ctx, W = self.ctx, self.world
+        if W == 1:
+            ctx.add_reads_packed_dev(d_words, d_offsets, n_reads, n_bases)
+            return
+        send = torch.empty(max(int(max_windows), 1), dtype=torch.int64, device=self.device)
+        off = ctx.extract_keys_dev(d_words, d_offsets, n_reads, n_bases, W, send, send.numel())
+        send_counts = [int(off[o + 1] - off[o]) for o in range(W)]
+        sc = torch.tensor(send_counts, dtype=torch.int64, device=self.device)
+        rc = torch.empty(W, dtype=torch.int64, device=self.device)
+        dist.all_to_all_single(rc, sc, group=self.group)
+        recv_counts = [int(x) for x in rc.cpu().tolist()]
+        recv = torch.empty(max(sum(recv_counts), 1), dtype=torch.int64, device=self.device)
+        n_send = int(off[W])
+        dist.all_to_all_single(recv[:sum(recv_counts)], send[:n_send], output_split_sizes=recv_counts,
+                               input_split_sizes=send_counts, group=self.group)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        self.bytes_sent += 8 * (n_send - send_counts[self.rank])
+        ctx.add_keys_dev(recv, sum(recv_counts))
+
+    def finalize(self):
+        """Local distinct keys; the sum over ranks is the table size (owners are disjoint)."""
+        n = self.ctx.finalize()
+        if self.world == 1:
+            return n
+        t = torch.tensor([n], dtype=torch.int64, device=self.device)
+        dist.all_reduce(t, group=self.group)
+        return int(t.item())
+
+    def gather_solid(self, solid_ctx, min_cov, dst=0):
+        """All-gather the (key, count >= min_cov) pairs of every shard and merge them into solid_ctx on
+        rank `dst` (pass dst=None to build it on every rank).  Returns the number of solid k-mers."""
+        ctx, W = self.ctx, self.world
+        if W == 1:
+            return None  # the caller BFSes on ctx itself
+        n_local = ctx.export_count(min_cov)
+        nt = torch.tensor([n_local], dtype=torch.int64, device=self.device)
+        sizes = [torch.empty(1, dtype=torch.int64, device=self.device) for _ in range(W)]
+        dist.all_gather(sizes, nt, group=self.group)
+        sizes = [int(s.item()) for s in sizes]
+        mx = max(max(sizes), 1)
+        keys = torch.zeros(mx, dtype=torch.int64, device=self.device)
+        cnts = torch.zeros(mx, dtype=torch.int16, device=self.device)
+        got = ctx.export_dev(min_cov, keys, cnts, mx)
+        assert got == n_local
+        all_k = torch.empty(W * mx, dtype=torch.int64, device=self.device)
+        all_c = torch.empty(W * mx, dtype=torch.int16, device=self.device)
+        dist.all_gather_into_tensor(all_k, keys, group=self.group)
+        dist.all_gather_into_tensor(all_c, cnts, group=self.group)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        if dst is None or self.rank == dst:
+            for r in range(W):
+                if sizes[r]:
+                    solid_ctx.add_pairs_dev(all_k[r * mx:r * mx + sizes[r]], all_c[r * mx:r * mx + sizes[r]], sizes[r])
+            solid_ctx.finalize()
+        return sum(sizes)
+
+
+def split_reads(n_reads_total, world, rank):
+    """Contiguous equal ranges of the read set, the GPU analogue of ReadsDispatcher's work list."""
+    base, rem = divmod(n_reads_total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)

@@ -1,0 +1,261 @@
+"""ctypes binding of libmcgpu.so (include/mcgpu.h).  Thin: argument marshalling and error
+translation only.  There is no CPU fallback: if the HIP library is missing or no MI355X is
+present, the calls raise."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+KEY_PACKED, KEY_POLY, KEY_FNV1A = 0, 1, 2
+MC_ENOSEED = -6
+
+
+class McError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libmcgpu error %d: %s" % (code, msg))
+        self.code = code
+
+
+class _Config(C.Structure):
+    _fields_ = [("k", C.c_int32), ("key_mode", C.c_int32), ("device", C.c_int32), ("flags", C.c_int32),
+                ("capacity_hint", C.c_uint64)]
+
+
+class _BfsResult(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("hi", C.POINTER(C.c_uint64)), ("lo", C.POINTER(C.c_uint64)),
+                ("dist", C.POINTER(C.c_int32)), ("cov", C.POINTER(C.c_int16)), ("last", C.POINTER(C.c_uint8)),
+                ("levels", C.c_uint64), ("lookups", C.c_uint64), ("device_ms", C.c_double)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("windows", C.c_uint64), ("count_launches", C.c_uint64), ("count_ms", C.c_double),
+                ("count_total_ms", C.c_double), ("table_slots", C.c_uint64), ("table_bytes", C.c_uint64),
+                ("grows", C.c_uint64)]
+
+
+# every symbol include/mcgpu.h declares; tests check that the library exports all of them
+EXPORTS = [
+    "mc_abi_version", "mc_create", "mc_destroy", "mc_clear", "mc_last_error", "mc_set_stream", "mc_add_reads_packed",
+    "mc_add_reads_packed_dev", "mc_finalize_counts", "mc_get", "mc_get_dev", "mc_kmer_keys", "mc_bfs",
+    "mc_bfs_result_free", "mc_export", "mc_export_dev", "mc_add_pairs_dev", "mc_key_owner", "mc_extract_keys_dev",
+    "mc_add_keys_dev", "mc_get_stats", "mc_reset_stats", "mc_synth_reads_dev", "mc_synth_genome",
+]
+
+_LIB = None
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    """Loads libmcgpu.so (does not touch the GPU).  Raises if it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(_build.LIB):
+        raise RuntimeError("libmcgpu.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(needs hipcc); there is no CPU fallback")
+    L = C.CDLL(_build.LIB)
+    vp, u64, i64, i32 = C.c_void_p, C.c_uint64, C.c_int64, C.c_int
+    u64p, i64p, i16p = C.POINTER(C.c_uint64), C.POINTER(C.c_int64), C.POINTER(C.c_int16)
+    L.mc_abi_version.restype = i32
+    L.mc_create.argtypes = [C.POINTER(_Config), C.POINTER(vp)]
+    L.mc_destroy.argtypes = [vp]
+    L.mc_destroy.restype = None
+    L.mc_last_error.argtypes = [vp]
+    L.mc_last_error.restype = C.c_char_p
+    L.mc_set_stream.argtypes = [vp, vp]
+    L.mc_clear.argtypes = [vp]
+    L.mc_add_reads_packed.argtypes = [vp, u64p, u64p, u64]
+    L.mc_add_reads_packed_dev.argtypes = [vp, vp, vp, u64, u64]
+    L.mc_finalize_counts.argtypes = [vp, u64p]
+    L.mc_get.argtypes = [vp, i64p, u64, i16p]
+    L.mc_get_dev.argtypes = [vp, vp, u64, vp]
+    L.mc_kmer_keys.argtypes = [vp, u64p, u64p, u64, i64p]
+    L.mc_bfs.argtypes = [vp, u64p, u64p, u64, i32, i32, i64, i64, C.POINTER(_BfsResult)]
+    L.mc_bfs_result_free.argtypes = [C.POINTER(_BfsResult)]
+    L.mc_bfs_result_free.restype = None
+    L.mc_export.argtypes = [vp, i32, i64p, i16p, u64, u64p]
+    L.mc_export_dev.argtypes = [vp, i32, vp, vp, u64, u64p]
+    L.mc_add_pairs_dev.argtypes = [vp, vp, vp, u64]
+    L.mc_key_owner.argtypes = [i64, C.c_uint32]
+    L.mc_key_owner.restype = C.c_uint32
+    L.mc_extract_keys_dev.argtypes = [vp, vp, vp, u64, u64, C.c_uint32, vp, u64, u64p]
+    L.mc_add_keys_dev.argtypes = [vp, vp, u64]
+    L.mc_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.mc_reset_stats.argtypes = [vp]
+    L.mc_synth_reads_dev.argtypes = [vp, u64, u64, u64, u64, u64, u64, C.c_uint32, C.c_uint32, vp, vp]
+    L.mc_synth_genome.argtypes = [u64, u64, u64, C.POINTER(C.c_uint8)]
+    _LIB = L
+    return L
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _dptr(x):
+    """device pointer of a torch tensor (or a raw int)"""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    return C.c_void_p(x.data_ptr())
+
+
+class Context:
+    """One k-mer table on one GPU = the BigLong2ShortHashMap of one tool run."""
+
+    def __init__(self, k, key_mode=KEY_PACKED, device=0, capacity_hint=0):
+        self._L = load()
+        self.k, self.key_mode, self.device = k, key_mode, device
+        cfg = _Config(k, key_mode, device, 0, capacity_hint)
+        h = C.c_void_p()
+        rc = self._L.mc_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise McError(rc, (self._L.mc_last_error(None) or b"").decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise McError(rc, (self._L.mc_last_error(self._h) or b"").decode())
+
+    def clear(self):
+        self._chk(self._L.mc_clear(self._h))
+
+    def set_stream(self, stream_ptr):
+        self._chk(self._L.mc_set_stream(self._h, C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    # ---- counting
+    def add_reads_packed(self, words, offsets):
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n_reads = len(offsets) - 1
+        if n_reads > 0 and len(words) < (int(offsets[-1]) + 31) // 32 + 1:
+            raise ValueError("words[] must hold ceil(n_bases/32) + 1 entries")
+        self._chk(self._L.mc_add_reads_packed(self._h, _p(words, C.c_uint64), _p(offsets, C.c_uint64), n_reads))
+
+    def add_reads_packed_dev(self, d_words, d_offsets, n_reads, n_bases):
+        self._chk(self._L.mc_add_reads_packed_dev(self._h, _dptr(d_words), _dptr(d_offsets), n_reads, n_bases))
+
+    def add_keys_dev(self, d_keys, n):
+        self._chk(self._L.mc_add_keys_dev(self._h, _dptr(d_keys), n))
+
+    def add_pairs_dev(self, d_keys, d_counts, n):
+        self._chk(self._L.mc_add_pairs_dev(self._h, _dptr(d_keys), _dptr(d_counts), n))
+
+    def finalize(self):
+        n = C.c_uint64(0)
+        self._chk(self._L.mc_finalize_counts(self._h, C.byref(n)))
+        return int(n.value)
+
+    # ---- lookups
+    def get(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.int64)
+        out = np.zeros(len(keys), dtype=np.int16)
+        self._chk(self._L.mc_get(self._h, _p(keys, C.c_int64), len(keys), _p(out, C.c_int16)))
+        return out
+
+    def get_dev(self, d_keys, n, d_out):
+        self._chk(self._L.mc_get_dev(self._h, _dptr(d_keys), n, _dptr(d_out)))
+
+    def kmer_keys(self, hi, lo):
+        lo = np.ascontiguousarray(lo, dtype=np.uint64)
+        hi = np.ascontiguousarray(hi, dtype=np.uint64) if hi is not None else None
+        out = np.zeros(len(lo), dtype=np.int64)
+        self._chk(self._L.mc_kmer_keys(self._h, _p(hi, C.c_uint64) if hi is not None else None,
+                                       _p(lo, C.c_uint64), len(lo), _p(out, C.c_int64)))
+        return out
+
+    # ---- BFS
+    def bfs(self, seed_hi, seed_lo, direction, min_cov, max_kmers=-1, max_radius=-1):
+        """Returns None when no seed k-mer reaches min_cov (the reference's 'fail'), else a dict of
+        numpy arrays in distanceToKmer insertion order."""
+        seed_lo = np.ascontiguousarray(seed_lo, dtype=np.uint64)
+        seed_hi = np.ascontiguousarray(seed_hi if seed_hi is not None else np.zeros(len(seed_lo)), dtype=np.uint64)
+        r = _BfsResult()
+        rc = self._L.mc_bfs(self._h, _p(seed_hi, C.c_uint64), _p(seed_lo, C.c_uint64), len(seed_lo), direction,
+                            min_cov, max_kmers, max_radius, C.byref(r))
+        if rc == MC_ENOSEED:
+            return None
+        self._chk(rc)
+        n = int(r.n)
+
+        def arr(ptr, dt):
+            return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt, copy=True)
+
+        out = dict(hi=arr(r.hi, np.uint64), lo=arr(r.lo, np.uint64), dist=arr(r.dist, np.int32),
+                   cov=arr(r.cov, np.int16), last=arr(r.last, np.uint8), levels=int(r.levels),
+                   lookups=int(r.lookups), device_ms=float(r.device_ms))
+        self._L.mc_bfs_result_free(C.byref(r))
+        return out
+
+    # ---- export
+    def export(self, min_cov=0):
+        n = C.c_uint64(0)
+        self._chk(self._L.mc_export(self._h, min_cov, None, None, 0, C.byref(n)))
+        cap = int(n.value)
+        keys = np.zeros(cap, dtype=np.int64)
+        cnt = np.zeros(cap, dtype=np.int16)
+        if cap:
+            self._chk(self._L.mc_export(self._h, min_cov, _p(keys, C.c_int64), _p(cnt, C.c_int16), cap, C.byref(n)))
+        o = np.argsort(keys, kind="stable")
+        return keys[o], cnt[o]
+
+    def export_count(self, min_cov=0):
+        n = C.c_uint64(0)
+        self._chk(self._L.mc_export_dev(self._h, min_cov, None, None, 0, C.byref(n)))
+        return int(n.value)
+
+    def export_dev(self, min_cov, d_keys, d_counts, cap):
+        n = C.c_uint64(0)
+        self._chk(self._L.mc_export_dev(self._h, min_cov, _dptr(d_keys), _dptr(d_counts), cap, C.byref(n)))
+        return int(n.value)
+
+    # ---- multi-GPU building blocks
+    def extract_keys_dev(self, d_words, d_offsets, n_reads, n_bases, n_owners, d_keys, cap):
+        off = np.zeros(n_owners + 1, dtype=np.uint64)
+        self._chk(self._L.mc_extract_keys_dev(self._h, _dptr(d_words), _dptr(d_offsets), n_reads, n_bases, n_owners,
+                                              _dptr(d_keys), cap, _p(off, C.c_uint64)))
+        return off
+
+    # ---- measurement / synthetic data
+    def stats(self):
+        s = Stats()
+        self._chk(self._L.mc_get_stats(self._h, C.byref(s)))
+        return s
+
+    def reset_stats(self):
+        self._chk(self._L.mc_reset_stats(self._h))
+
+    def synth_reads_dev(self, genome_seed, n_contigs, contig_len, read_seed, first_read, n_reads, read_len,
+                        err_per_10k, d_words, d_offsets):
+        self._chk(self._L.mc_synth_reads_dev(self._h, genome_seed, n_contigs, contig_len, read_seed, first_read,
+                                             n_reads, read_len, err_per_10k, _dptr(d_words), _dptr(d_offsets)))
+
+
+def key_owner(key, n_owners):
+    return int(load().mc_key_owner(int(key), n_owners))
+
+
+def synth_genome(genome_seed, start, n):
+    out = np.zeros(n, dtype=np.uint8)
+    load().mc_synth_genome(genome_seed, start, n, _p(out, C.c_uint8))
+    return out

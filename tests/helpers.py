@@ -1,0 +1,62 @@
+"""Shared input builders for the parity tests (seeded, small enough for the CPU oracle)."""
+import numpy as np
+
+from oracle import pyoracle as po
+
+GENOME_SEED = 20240531
+READ_SEED = 42
+
+
+def synth_case(n_contigs, contig_len, n_reads, L=150, err=100, first_read=0):
+    """Synthetic genome + fixed-length reads exactly as DESIGN.md 'Synthetic workload'."""
+    genome = po.synth_genome(GENOME_SEED, n_contigs * contig_len)
+    reads = po.synth_reads(genome, n_contigs, contig_len, READ_SEED, first_read, n_reads, L, err)
+    offsets = np.arange(n_reads + 1, dtype=np.uint64) * L
+    return genome, reads, offsets
+
+
+def ragged_case(rng, n_reads, max_len=220, genome_len=5000):
+    """Reads of random length 0..max_len cut from a small random genome (so k-mers repeat)."""
+    genome = rng.integers(0, 4, genome_len).astype(np.uint8)
+    lens = rng.integers(0, max_len + 1, n_reads)
+    lens[:4] = [0, 1, 30, 31]
+    starts = [int(rng.integers(0, genome_len - l + 1)) for l in lens]
+    reads = []
+    for s, l in zip(starts, lens):
+        r = genome[s:s + l]
+        if rng.integers(0, 2):
+            r = (3 - r[::-1]).astype(np.uint8)
+        reads.append(r)
+    codes = np.concatenate(reads) if reads else np.zeros(0, dtype=np.uint8)
+    offsets = np.zeros(n_reads + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(lens)
+    return genome, codes, offsets
+
+
+def oracle_table(codes, offsets, k, mode):
+    t = po.Table()
+    n = t.count_reads(codes, offsets, k, mode)
+    return t, n
+
+
+def seed_windows(codes, k):
+    """All k-windows of a seed sequence as packed oriented k-mers (hi, lo)."""
+    n = len(codes) - k + 1
+    hi = np.zeros(max(n, 0), dtype=np.uint64)
+    lo = np.zeros(max(n, 0), dtype=np.uint64)
+    for i in range(max(n, 0)):
+        v = 0
+        for c in codes[i:i + k]:
+            v = (v << 2) | int(c)
+        hi[i] = v >> 64
+        lo[i] = v & 0xFFFFFFFFFFFFFFFF
+    return hi, lo
+
+
+def assert_bfs_equal(got, want):
+    assert (got is None) == (want is None)
+    if got is None:
+        return
+    for f in ("hi", "lo", "dist", "cov", "last"):
+        assert np.array_equal(got[f], want[f]), f
+    assert got["levels"] == want["levels"]

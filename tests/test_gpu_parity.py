@@ -1,0 +1,263 @@
+"""Parity of the HIP path (through the C ABI of include/mcgpu.h) against the CPU oracle.
+Bit-exact: integer / byte / index work.  Needs a real MI355X: run with -m gpu."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from tests.helpers import (GENOME_SEED, READ_SEED, assert_bfs_equal, oracle_table, ragged_case, seed_windows,
+                           synth_case)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mc():
+    import metacherchant_amd as m
+    m.native.load()
+    return m
+
+
+def _gpu_table(mc, words, offsets, k, mode, hint=0):
+    ctx = mc.Context(k, mode, 0, hint)
+    ctx.add_reads_packed(words, offsets)
+    n = ctx.finalize()
+    return ctx, n
+
+
+def _assert_tables_equal(ctx, n_distinct, t):
+    assert n_distinct == t.size()
+    gk, gc = ctx.export(0)
+    ok, oc = t.dump()
+    assert np.array_equal(gk, ok)
+    assert np.array_equal(gc, oc)
+
+
+@pytest.mark.parametrize("err", [0, 100])
+def test_count_config1_k31(mc, err):
+    """BASELINE.json configs[0]: 10k x 150 bp, k=31 -- every (key, count) pair equal."""
+    _, reads, off = synth_case(1, 50000, 10000, 150, err)
+    t, n = oracle_table(reads, off, 31, po.KEY_PACKED)
+    ctx, nd = _gpu_table(mc, po.pack(reads), off, 31, mc.KEY_PACKED)
+    assert ctx.stats().windows == n == 10000 * 120
+    _assert_tables_equal(ctx, nd, t)
+    # get(): present, absent, key 0
+    gk, _ = ctx.export(0)
+    rng = np.random.default_rng(1)
+    q = np.concatenate([gk[:1000], rng.integers(1, 1 << 61, 1000), [0]]).astype(np.int64)
+    assert np.array_equal(ctx.get(q), t.get_many(q))
+    ctx.close()
+
+
+@pytest.mark.parametrize("k,mode", [(31, 0), (21, 0), (5, 0), (1, 0), (63, 1), (33, 1), (47, 2), (31, 1), (64 - 1, 2)])
+def test_count_ragged_reads_all_key_modes(mc, k, mode):
+    """Empty reads, reads shorter than k, k-1, k, ragged lengths; packed key, poly and fnv1a hashes."""
+    rng = np.random.default_rng(100 + k + mode)
+    _, codes, off = ragged_case(rng, 700)
+    t, n = oracle_table(codes, off, k, mode)
+    ctx, nd = _gpu_table(mc, po.pack(codes), off, k, mode)
+    assert ctx.stats().windows == n
+    _assert_tables_equal(ctx, nd, t)
+    ctx.close()
+
+
+def test_count_saturates_at_32767_and_key_zero(mc):
+    """poly-A / poly-T reads: key 0 (the reference's FREE marker) with > 32767 occurrences."""
+    L, n = 150, 400
+    codes = np.zeros(n * L, dtype=np.uint8)
+    codes[(n // 2) * L:] = 3  # second half poly-T: same canonical k-mer
+    off = np.arange(n + 1, dtype=np.uint64) * L
+    t, _ = oracle_table(codes, off, 31, po.KEY_PACKED)
+    ctx, nd = _gpu_table(mc, po.pack(codes), off, 31, mc.KEY_PACKED)
+    assert nd == 1 and t.get(0) == 32767
+    assert list(ctx.get(np.array([0, 1], dtype=np.int64))) == [32767, -1]
+    _assert_tables_equal(ctx, nd, t)
+    ctx.close()
+
+
+def test_empty_input_and_state_errors(mc):
+    ctx = mc.Context(31, mc.KEY_PACKED, 0, 0)
+    with pytest.raises(mc.McError):
+        ctx.get(np.array([1], dtype=np.int64))  # before finalize
+    ctx.add_reads_packed(np.zeros(1, dtype=np.uint64), np.zeros(1, dtype=np.uint64))
+    assert ctx.finalize() == 0
+    assert list(ctx.get(np.array([0, 5], dtype=np.int64))) == [-1, -1]
+    assert ctx.bfs(None, np.array([5], dtype=np.uint64), -1, 1, 10, -1) is None
+    with pytest.raises(mc.McError):
+        mc.Context(32, mc.KEY_PACKED)
+    with pytest.raises(mc.McError):
+        mc.Context(64, mc.KEY_POLY)
+    ctx.close()
+
+
+def test_table_grows_from_small(mc):
+    """No capacity hint: the table starts at 4 M slots and is rebuilt as it fills."""
+    _, reads, off = synth_case(4, 2_000_000, 120_000, 150, 100)
+    t, n = oracle_table(reads, off, 31, po.KEY_PACKED)
+    ctx, nd = _gpu_table(mc, po.pack(reads), off, 31, mc.KEY_PACKED, 0)
+    assert ctx.stats().grows >= 1
+    _assert_tables_equal(ctx, nd, t)
+    # batches in a different order and split over several calls give the same table
+    ctx2 = mc.Context(31, mc.KEY_PACKED, 0, t.size())
+    words = po.pack(reads)
+    half = 60_000
+    w2 = po.pack(reads[half * 150:])
+    ctx2.add_reads_packed(w2, off[: 120_000 - half + 1])
+    ctx2.add_reads_packed(words, off[: half + 1])
+    assert ctx2.stats().grows == 0
+    _assert_tables_equal(ctx2, ctx2.finalize(), t)
+    ctx.close()
+    ctx2.close()
+
+
+def _bfs_both(mc, ctx, t, k, mode, seed_codes, d, cov, mk, mr):
+    hi, lo = seed_windows(seed_codes, k)
+    got = ctx.bfs(hi, lo, d, cov, mk, mr)
+    want = po.bfs(t, k, mode, [seed_codes], d, cov, mk, mr)
+    assert_bfs_equal(got, want)
+    return got
+
+
+@pytest.fixture(scope="module")
+def bfs_case(mc):
+    genome, reads, off = synth_case(2, 30000, 12000, 150, 50)
+    t, _ = oracle_table(reads, off, 31, po.KEY_PACKED)
+    ctx, _ = _gpu_table(mc, po.pack(reads), off, 31, mc.KEY_PACKED)
+    yield genome, t, ctx
+    ctx.close()
+
+
+@pytest.mark.parametrize("d", [-1, 1, 0])
+@pytest.mark.parametrize("mk,mr", [(100000, -1), (777, -1), (-1, 50), (1500, 300), (3, -1)])
+def test_bfs_parity(mc, bfs_case, d, mk, mr):
+    """Discovery order, distances, coverages and lastKmers flags equal, incl. maxkmers biting mid-level."""
+    genome, t, ctx = bfs_case
+    seed = genome[10000:10500]
+    got = _bfs_both(mc, ctx, t, 31, po.KEY_PACKED, seed, d, 5, mk, mr)
+    assert got is not None and len(got["lo"]) >= 1
+
+
+def test_bfs_branching_graph_and_duplicate_seeds(mc):
+    """A repeat-rich genome (many branches, wide frontiers, cycles) + a seed whose windows repeat."""
+    rng = np.random.default_rng(5)
+    unit = rng.integers(0, 4, 400).astype(np.uint8)
+    parts = []
+    for i in range(60):
+        u = unit.copy()
+        pos = rng.integers(0, 400, 6)
+        u[pos] = rng.integers(0, 4, 6)
+        parts.append(u)
+    genome = np.concatenate(parts)
+    L, n = 100, 6000
+    starts = rng.integers(0, len(genome) - L, n)
+    reads = np.concatenate([genome[s:s + L] for s in starts])
+    off = np.arange(n + 1, dtype=np.uint64) * L
+    for k, mode in [(21, po.KEY_PACKED), (31, po.KEY_PACKED), (33, po.KEY_POLY)]:
+        t, _ = oracle_table(reads, off, k, mode)
+        ctx, nd = _gpu_table(mc, po.pack(reads), off, k, mode)
+        _assert_tables_equal(ctx, nd, t)
+        seed = np.concatenate([genome[100:200], genome[100:200], genome[500:560]])  # repeated windows
+        for d in (-1, 1, 0):
+            for mk, mr in [(-1, 40), (2000, -1), (5000, 25), (100000, -1)]:
+                _bfs_both(mc, ctx, t, k, mode, seed, d, 3, mk, mr)
+        ctx.close()
+
+
+def test_bfs_k63_hash_key(mc):
+    """BASELINE.json configs[2] at small scale: k=63, poly hash key, coverage 3, bothdirs."""
+    genome, reads, off = synth_case(1, 40000, 9000, 150, 30)
+    t, _ = oracle_table(reads, off, 63, po.KEY_POLY)
+    ctx, nd = _gpu_table(mc, po.pack(reads), off, 63, mc.KEY_POLY)
+    _assert_tables_equal(ctx, nd, t)
+    for d, mk, mr in [(0, 100000, -1), (0, 5000, -1), (-1, -1, 1000), (1, 300, 100)]:
+        _bfs_both(mc, ctx, t, 63, po.KEY_POLY, genome[20000:20400], d, 3, mk, mr)
+    ctx.close()
+
+
+def test_bfs_no_seed_passes(mc, bfs_case):
+    _, t, ctx = bfs_case
+    rng = np.random.default_rng(9)
+    seed = rng.integers(0, 4, 200).astype(np.uint8)  # random: not in the genome
+    hi, lo = seed_windows(seed, 31)
+    assert ctx.bfs(hi, lo, -1, 5, 1000, -1) is None
+    assert po.bfs(t, 31, po.KEY_PACKED, [seed], -1, 5, 1000, -1) is None
+
+
+def test_bfs_unbounded_radius_grows_buffers(mc):
+    """Only --maxradius: distanceToKmer is not bounded up front and has to grow on the device."""
+    genome, reads, off = synth_case(1, 1_300_000, 150_000, 150, 0)
+    t, _ = oracle_table(reads, off, 31, po.KEY_PACKED)
+    ctx, _ = _gpu_table(mc, po.pack(reads), off, 31, mc.KEY_PACKED, t.size())
+    got = _bfs_both(mc, ctx, t, 31, po.KEY_PACKED, genome[600000:600200], 0, 2, -1, 10_000_000)
+    assert len(got["lo"]) > (1 << 20)
+    ctx.close()
+
+
+def test_device_pointer_path_and_generator(mc):
+    """Reads generated straight into HBM == the oracle's generator; counting from device pointers."""
+    import torch
+    n_contigs, contig_len, n_reads, L = 3, 20000, 5000, 150
+    dev = torch.device("cuda:0")
+    for err in (0, 100):
+        ctx = mc.Context(31, mc.KEY_PACKED, 0, 0)
+        n_words = (n_reads * L + 31) // 32 + 1
+        d_words = torch.zeros(n_words, dtype=torch.int64, device=dev)
+        d_off = torch.zeros(n_reads + 1, dtype=torch.int64, device=dev)
+        ctx.synth_reads_dev(GENOME_SEED, n_contigs, contig_len, READ_SEED, 7, n_reads, L, err, d_words, d_off)
+        genome = po.synth_genome(GENOME_SEED, n_contigs * contig_len)
+        assert np.array_equal(genome, mc.native.synth_genome(GENOME_SEED, 0, n_contigs * contig_len))
+        reads = po.synth_reads(genome, n_contigs, contig_len, READ_SEED, 7, n_reads, L, err)
+        want_words = po.pack(reads)
+        assert np.array_equal(d_words.cpu().numpy().view(np.uint64)[:-1], want_words[:n_words - 1])
+        assert np.array_equal(d_off.cpu().numpy().view(np.uint64), np.arange(n_reads + 1, dtype=np.uint64) * L)
+        ctx.add_reads_packed_dev(d_words, d_off, n_reads, n_reads * L)
+        off = np.arange(n_reads + 1, dtype=np.uint64) * L
+        t, _ = oracle_table(reads, off, 31, po.KEY_PACKED)
+        _assert_tables_equal(ctx, ctx.finalize(), t)
+        # get_dev
+        gk, gc = ctx.export(0)
+        dk = torch.from_numpy(gk).to(dev)
+        dout = torch.zeros(len(gk), dtype=torch.int16, device=dev)
+        ctx.get_dev(dk, len(gk), dout)
+        assert np.array_equal(dout.cpu().numpy(), gc)
+        ctx.close()
+
+
+def test_extract_keys_by_owner_and_merge_pairs(mc):
+    """Multi-GPU building blocks on one GPU: keys bucketed by owner, counted per owner, gathered as
+    (key, count) pairs and merged == counting everything in one table."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(11)
+    _, codes, off = ragged_case(rng, 900)
+    for k, mode in [(31, po.KEY_PACKED), (41, po.KEY_POLY)]:
+        t, n = oracle_table(codes, off, k, mode)
+        words = po.pack(codes)
+        d_words = torch.from_numpy(words.view(np.int64)).to(dev)
+        d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+        G = 3
+        ex = mc.Context(k, mode, 0, 0)
+        d_keys = torch.zeros(n, dtype=torch.int64, device=dev)
+        ooff = ex.extract_keys_dev(d_words, d_off, len(off) - 1, int(off[-1]), G, d_keys, n)
+        assert int(ooff[-1]) == n
+        keys = d_keys.cpu().numpy()
+        for o in range(G):
+            seg = keys[int(ooff[o]):int(ooff[o + 1])]
+            assert all(mc.native.key_owner(int(x), G) == o for x in seg[:200])
+        merged = mc.Context(k, mode, 0, 0)
+        for o in range(G):
+            own = mc.Context(k, mode, 0, 0)
+            seg = d_keys[int(ooff[o]):int(ooff[o + 1])]
+            own.add_keys_dev(seg, len(seg))
+            nd = own.finalize()
+            pk = torch.zeros(nd, dtype=torch.int64, device=dev)
+            pc = torch.zeros(nd, dtype=torch.int16, device=dev)
+            assert own.export_dev(0, pk, pc, nd) == nd
+            merged.add_pairs_dev(pk, pc, nd)
+            own.close()
+        _assert_tables_equal(merged, merged.finalize(), t)
+        # thresholded export
+        gk, gc = merged.export(3)
+        ok, oc = t.dump()
+        assert np.array_equal(gk, ok[oc >= 3]) and np.array_equal(gc, oc[oc >= 3])
+        ex.close()
+        merged.close()
