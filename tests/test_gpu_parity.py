@@ -184,10 +184,10 @@ def test_bfs_no_seed_passes(mc, bfs_case):
 
 def test_bfs_unbounded_radius_grows_buffers(mc):
     """Only --maxradius: distanceToKmer is not bounded up front and has to grow on the device."""
-    genome, reads, off = synth_case(1, 1_300_000, 150_000, 150, 0)
+    genome, reads, off = synth_case(1, 1_200_000, 200_000, 150, 0)
     t, _ = oracle_table(reads, off, 31, po.KEY_PACKED)
     ctx, _ = _gpu_table(mc, po.pack(reads), off, 31, mc.KEY_PACKED, t.size())
-    got = _bfs_both(mc, ctx, t, 31, po.KEY_PACKED, genome[600000:600200], 0, 2, -1, 10_000_000)
+    got = _bfs_both(mc, ctx, t, 31, po.KEY_PACKED, genome[600000:600200], 0, 1, -1, 10_000_000)
     assert len(got["lo"]) > (1 << 20)
     ctx.close()
 
