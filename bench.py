@@ -110,14 +110,15 @@ def main():
             bctx = solid
         if rank == 0:
             bfs_ms, reached, levels, lookups = 0.0, 0, 0, 0
-            for d in (-1, 1):  # buildEnvironment with bothdirs=False
-                r = bctx.bfs(seed_hi, seed_lo, d, args.coverage, args.maxkmers, -1)
+            # buildEnvironment with bothdirs=False: runBfs(-1), runBfs(+1) -- independent passes, one launch
+            res = bctx.bfs_batch([(seed_hi, seed_lo, -1), (seed_hi, seed_lo, 1)], args.coverage, args.maxkmers, -1)
+            for r in res:
                 if r is None:
                     raise SystemExit("BFS found no seed k-mer: synthetic workload broken")
-                bfs_ms += r["device_ms"]
                 reached += len(r["lo"])
                 levels += r["levels"]
                 lookups += r["lookups"]
+            bfs_ms = res[0]["device_ms"]
             info.update(bfs_ms=bfs_ms, reached=reached, levels=levels, lookups=lookups)
 
     def sync():

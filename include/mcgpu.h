@@ -128,12 +128,27 @@ typedef struct {
     uint8_t *last;
     uint64_t levels;     /* largest distance assigned */
     uint64_t lookups;    /* table lookups issued (speculative ones included) */
-    double device_ms;    /* device time of the BFS kernels, HIP events */
+    uint64_t rounds;     /* memory round trips on the critical path (speculation rounds + wide chunks) */
+    double device_ms;    /* device time of the BFS kernels of the whole batch, HIP events */
 } mc_bfs_result;
 
 int mc_bfs(mc_ctx *ctx, const uint64_t *seed_hi, const uint64_t *seed_lo, uint64_t n_seeds, int dir,
            int min_cov, int64_t max_kmers, int64_t max_radius, mc_bfs_result *out);
 void mc_bfs_result_free(mc_bfs_result *r);
+
+/* Several independent BFS passes in ONE launch, one workgroup each: the two passes of
+ * buildEnvironment with --bothdirs False (runBfs(-1); runBfs(+1), OneSequenceCalculator.java:137-144)
+ * and the one-calculator-per-seed-sequence thread pool of EnvironmentFinderMain.java:218-225.
+ * out[] has n_jobs entries; a job whose seeds all fail the threshold returns out[j].n == 0
+ * (mc_bfs returns MC_ENOSEED for that). */
+typedef struct {
+    const uint64_t *seed_hi; /* may be NULL when k <= 32 */
+    const uint64_t *seed_lo;
+    uint64_t n_seeds;
+    int32_t dir;
+} mc_bfs_job;
+int mc_bfs_batch(mc_ctx *ctx, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov, int64_t max_kmers,
+                 int64_t max_radius, mc_bfs_result *out);
 
 /* ---- table export / import: (key, count) pairs with count >= min_cov, unordered.
  * Also the record content of the reference's .kmers.bin (src/io/KmersLoadWorker.java:9,20-23)

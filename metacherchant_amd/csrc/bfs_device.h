@@ -1,0 +1,846 @@
+// K5: the de Bruijn BFS of src/algo/OneSequenceCalculator.java:154-214 on one workgroup per
+// (seed set, direction) job.  All state lives in HBM, so a launch is resumable and the host can
+// grow distanceToKmer between launches.
+//
+// The reference's BFS is strictly sequential: vertex by vertex in queue order, neighbour by
+// neighbour in A,G,C,T order, and `maxkmers` is tested at each insertion
+// (src/algo/TerminationMode.java:31-47).  What is reproduced exactly is therefore the ORDER:
+// candidates get the rank (queue position of the parent, neighbour index); among equal k-mers the
+// smallest rank wins; survivors are appended in rank order; the cap cuts that order.
+//
+// Two ways through a BFS level:
+//   wide   -- the frontier has many vertices: chunks of BFS_THREADS candidates, one per thread,
+//             de-duplicated in an LDS hash, block scan for the ordered append.
+//   narrow -- the frontier is a handful of vertices (the usual case: metagenome graphs are mostly
+//             linear, so the BFS is ~10^5 dependent levels of width 1).  A level-per-round-trip
+//             walk is bound by HBM latency, so wave 0 looks several levels ahead in one round
+//             trip, guided by the read-context hints stored next to each k-mer, and falls back to
+//             an exact one-level replay wherever the graph is not a plain path (bfs_narrow).
+#pragma once
+#include "kmer_device.h"
+
+namespace mc {
+
+constexpr int BFS_THREADS = 512;          // 8 waves
+constexpr int NPL = 2;                    // speculative tree nodes per lane of the walking wave
+constexpr int MAX_NODES = 64 * NPL;       // neighbour sets looked up per round: levels x walkers x nb
+constexpr int MAX_DEPTH = 5;
+constexpr int NARROW_CAND = 64;           // candidates per replayed level = lanes of one wave
+constexpr int RH_SIZE = 1024;             // round-local LDS set (narrow, slow replay)
+constexpr int WH_SIZE = 2 * BFS_THREADS;  // chunk-local LDS set (wide)
+constexpr uint64_t VIS_EMPTY = ~0ull;
+constexpr uint32_t LH_EMPTY = 0xFFFFFFFFu;
+
+enum { BFS_RUNNING = 0, BFS_DONE = 1, BFS_NEED_GROW = 2 };
+
+struct BfsCtl {
+    unsigned long long n;       // |distanceToKmer|
+    unsigned long long lb, le;  // current frontier = entries [lb, le)
+    unsigned long long c0;      // next candidate rank inside the frontier (wide path)
+    unsigned long long lookups;
+    unsigned long long rounds_narrow, rounds_slow, chunks_wide;
+    unsigned long long tacc[8];  // MC_BFS_TIMING builds: 10 ns ticks per phase of a narrow round
+    long long level;            // distance of the frontier
+    int status;
+    int seeds_done;
+};
+
+struct BfsState {
+    uint64_t *hi, *lo;  // distanceToKmer keys in insertion order
+    int32_t *dist;
+    int16_t *cov;
+    uint32_t *flags;    // bit0: in lastKmers; bit1: seed window queued more than once.  Pre-zeroed.
+    uint64_t dcap;
+    uint64_t *vis;      // index of the arrays above: buckets of two (fingerprint << 32 | index) entries
+    uint64_t bmask;     // number of buckets - 1
+    BfsCtl *ctl;
+    const uint64_t *seed_hi, *seed_lo;
+    uint64_t n_seeds;
+    int dir;
+};
+
+__device__ __forceinline__ uint64_t ld_sc1(const uint64_t *p)
+{  // L1-bypassing load: data written earlier in this launch by an atomic or by another wave's store
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ uint32_t ld_flags(const uint32_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ uint64_t vis_hash(const Kmer &v) { return fmix64(v.lo ^ fmix64(v.hi + 0x9e3779b97f4a7c15ull)); }
+
+__device__ __forceinline__ bool vis_entry_is(const BfsState &S, uint64_t e, uint32_t fp, const Kmer &v)
+{
+    if ((uint32_t)(e >> 32) != fp) return false;
+    const uint32_t idx = (uint32_t)e;
+    return ld_sc1(&S.lo[idx]) == v.lo && ld_sc1(&S.hi[idx]) == v.hi;
+}
+
+// Is the oriented k-mer in distanceToKmer?  e0/e1 = the two entries of its home bucket (already loaded).
+__device__ __forceinline__ bool vis_contains(const BfsState &S, const Kmer &v, uint64_t h, uint64_t e0, uint64_t e1)
+{
+    const uint32_t fp = (uint32_t)(h >> 32);
+    uint64_t b = h & S.bmask;
+    for (uint64_t probe = 0; probe <= S.bmask; probe++) {
+        if (probe) {
+            e0 = ld_sc1(&S.vis[2 * b]);
+            e1 = ld_sc1(&S.vis[2 * b + 1]);
+        }
+        if (e0 == VIS_EMPTY) return false;
+        if (vis_entry_is(S, e0, fp, v)) return true;
+        if (e1 == VIS_EMPTY) return false;
+        if (vis_entry_is(S, e1, fp, v)) return true;
+        b = (b + 1) & S.bmask;
+    }
+    return false;
+}
+
+__device__ __forceinline__ bool vis_find(const BfsState &S, const Kmer &v)
+{
+    const uint64_t h = vis_hash(v);
+    const uint64_t b = h & S.bmask;
+    return vis_contains(S, v, h, ld_sc1(&S.vis[2 * b]), ld_sc1(&S.vis[2 * b + 1]));
+}
+
+// Index of a k-mer known to be present (seed bookkeeping only).
+__device__ __forceinline__ long long vis_index_of(const BfsState &S, const Kmer &v)
+{
+    const uint64_t h = vis_hash(v);
+    const uint32_t fp = (uint32_t)(h >> 32);
+    uint64_t b = h & S.bmask;
+    for (uint64_t probe = 0; probe <= S.bmask; probe++) {
+        for (int i = 0; i < 2; i++) {
+            const uint64_t e = ld_sc1(&S.vis[2 * b + i]);
+            if (e == VIS_EMPTY) return -1;
+            if (vis_entry_is(S, e, fp, v)) return (long long)(uint32_t)e;
+        }
+        b = (b + 1) & S.bmask;
+    }
+    return -1;
+}
+
+// Insert a k-mer known to be absent (callers de-duplicate first).  Entries are never removed, so a
+// bucket fills front to back and "first entry empty" means the whole bucket is empty.
+__device__ __forceinline__ void vis_insert(const BfsState &S, const Kmer &v, uint32_t idx)
+{
+    const uint64_t h = vis_hash(v);
+    const uint64_t e = (h & 0xFFFFFFFF00000000ull) | idx;
+    uint64_t b = h & S.bmask;
+    for (uint64_t probe = 0; probe <= S.bmask; probe++) {
+        for (int i = 0; i < 2; i++)
+            if (atomicCAS(reinterpret_cast<unsigned long long *>(&S.vis[2 * b + i]), (unsigned long long)VIS_EMPTY,
+                          (unsigned long long)e) == VIS_EMPTY)
+                return;
+        b = (b + 1) & S.bmask;
+    }
+}
+
+// LDS set of candidate ids keyed by their k-mer; the smallest id of each k-mer stays.
+// Returns the slot the caller's k-mer lives in.
+__device__ __forceinline__ uint32_t lds_set_min(uint32_t *tab, uint32_t mask, const Kmer *kmers, const Kmer &v,
+                                                uint32_t id)
+{
+    uint32_t s = (uint32_t)vis_hash(v) & mask;
+    for (;;) {
+        uint32_t cur = tab[s];
+        if (cur == LH_EMPTY) {
+            cur = atomicCAS(&tab[s], LH_EMPTY, id);
+            if (cur == LH_EMPTY) return s;
+        }
+        const Kmer o = kmers[cur];  // an occupant is only ever replaced by a smaller id of the SAME k-mer
+        if (o.lo == v.lo && o.hi == v.hi) {
+            atomicMin(&tab[s], id);
+            return s;
+        }
+        s = (s + 1) & mask;
+    }
+}
+
+// block-wide exclusive scan of one flag per thread; *total = number of set flags
+__device__ __forceinline__ uint32_t block_scan_flag(bool flag, uint32_t *lds_wave_tot, uint32_t *total)
+{
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(flag);
+    const uint32_t in_wave = (uint32_t)__popcll(m & ((1ull << lane) - 1));
+    if (lane == 0) lds_wave_tot[wv] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t before = 0, tot = 0;
+    const uint32_t n_waves = blockDim.x >> 6;
+    for (uint32_t i = 0; i < n_waves; i++) {
+        const uint32_t c = lds_wave_tot[i];
+        if (i < wv) before += c;
+        tot += c;
+    }
+    __syncthreads();
+    *total = tot;
+    return before + in_wave;
+}
+
+// table lookup with the first two probe slots already loaded
+__device__ __forceinline__ int table_get2(const TableView &t, uint64_t key, const uint4 &r0, const uint4 &r1)
+{
+    if (key == EMPTY_KEY) return table_get(t, key);
+    const uint64_t k0 = ((uint64_t)r0.y << 32) | r0.x;
+    if (k0 == key) return r0.z > 32767u ? 32767 : (int)r0.z;
+    if (k0 == EMPTY_KEY) return -1;
+    const uint64_t k1 = ((uint64_t)r1.y << 32) | r1.x;
+    if (k1 == key) return r1.z > 32767u ? 32767 : (int)r1.z;
+    if (k1 == EMPTY_KEY) return -1;
+    return table_get(t, key);  // both probes hit other keys: walk the region
+}
+
+struct WideLds {
+    Kmer kmer[BFS_THREADS];
+    uint32_t set[WH_SIZE];
+    uint32_t widx[BFS_THREADS];
+    uint32_t wave_tot[BFS_THREADS / 64];
+};
+
+struct NarrowLds {
+    Kmer kmer[MAX_NODES];
+    Kmer pk[MAX_NODES];               // the vertices the walkers are expected to visit, [(level-1)*F + walker]
+    Kmer root[NARROW_CAND];           // the walkers
+    Kmer pub_k[MAX_NODES];            // accepted in the last round, to be indexed
+    uint32_t pub_idx[MAX_NODES];
+    uint32_t rhint[NARROW_CAND], nhint[NARROW_CAND];  // their oriented hints (walker_hint)
+    int16_t cov[MAX_NODES];
+    uint32_t aux[MAX_NODES];
+    uint8_t vis[MAX_NODES];
+    uint8_t flip[MAX_NODES];
+    uint32_t set[RH_SIZE];
+    uint32_t fl_w[2][NARROW_CAND];    // frontier lists: index of the node inside its tree level
+    uint32_t fl_idx[2][NARROW_CAND];  //                 index in distanceToKmer (bit31: re-queued seed)
+    uint32_t new_id[NARROW_CAND * MAX_DEPTH];   // accepted this round: tree node
+    uint32_t new_idx[NARROW_CAND * MAX_DEPTH];  //                      index in distanceToKmer
+    // walk state, owned by wave 0, read by everyone after a barrier
+    unsigned long long n, lb, le, rounds_left;
+    long long level;
+    uint32_t F;
+    int cur, status, any_dup_root;
+};
+
+union BfsLds {
+    WideLds w;
+    NarrowLds n;
+};
+
+// ---- wide path: one chunk of <= BFS_THREADS candidates in rank order.  parent == UINT64_MAX marks a
+// seed window (src/algo/OneSequenceCalculator.java:159-192: queued when reads.get(key) >= minOccurences).
+template <int MODE>
+__device__ void bfs_chunk_wide(const BfsState &S, const TableView &t, WideLds &L, int k, int min_cov,
+                               long long max_kmers, bool radius_ok, bool have, const Kmer &cand, uint64_t parent,
+                               int32_t new_dist, unsigned long long &lookups)
+{
+    BfsCtl *ctl = S.ctl;
+    const uint32_t tid = threadIdx.x;
+    const bool is_seed = parent == UINT64_MAX;
+    L.kmer[tid] = cand;
+    L.set[tid] = LH_EMPTY;
+    L.set[tid + BFS_THREADS] = LH_EMPTY;
+    int cov = -1;
+    if (have) {
+        cov = table_get(t, (uint64_t)key_of<MODE>(cand, k));
+        lookups++;
+    }
+    const bool solid = have && cov >= min_cov;
+    const unsigned long long n_before = ctl->n;
+    const bool capped = max_kmers >= 0 && (long long)n_before >= max_kmers;
+    bool mark_last = false, contender = false;
+    if (solid) {
+        if (!is_seed && (ld_flags(&S.flags[parent]) & 2u)) mark_last = true;  // re-queued seed window: nothing is new to it
+        if (!is_seed && (capped || !radius_ok)) {
+            mark_last = true;  // allowsAddition() == false -> lastKmers.add(kmer)
+        } else if (vis_find(S, cand)) {
+            if (is_seed) {
+                const long long f = vis_index_of(S, cand);
+                if (f >= 0) atomicOr(&S.flags[f], 2u);
+            } else {
+                mark_last = true;
+            }
+        } else {
+            contender = true;
+        }
+    }
+    __syncthreads();
+    uint32_t slot = 0;
+    if (contender) slot = lds_set_min(L.set, WH_SIZE - 1, L.kmer, cand, tid);
+    __syncthreads();
+    const bool winner = contender && L.set[slot] == tid;
+    if (contender && !winner && !is_seed) mark_last = true;  // an earlier rank inserts it first
+    uint32_t total;
+    const uint32_t pos = block_scan_flag(winner, L.wave_tot, &total);
+    bool accepted = false;
+    uint64_t idx = 0;
+    if (winner) {
+        idx = n_before + pos;
+        accepted = is_seed || max_kmers < 0 || (long long)idx < max_kmers;  // distanceToKmer.size() >= threshold
+        if (accepted) {
+            S.hi[idx] = cand.hi;
+            S.lo[idx] = cand.lo;
+            S.dist[idx] = new_dist;
+            S.cov[idx] = (int16_t)cov;
+            vis_insert(S, cand, (uint32_t)idx);
+        } else {
+            mark_last = true;
+        }
+    }
+    if (mark_last && !is_seed) atomicOr(&S.flags[parent], 1u);
+    if (winner) L.widx[tid] = accepted ? (uint32_t)idx : LH_EMPTY;
+    uint32_t n_acc;
+    (void)block_scan_flag(accepted, L.wave_tot, &n_acc);  // (its barriers also publish widx)
+    if (is_seed && contender && !winner) {  // the same seed window twice inside this chunk: it is re-queued
+        const uint32_t wi = L.widx[L.set[slot]];
+        if (wi != LH_EMPTY) atomicOr(&S.flags[wi], 2u);
+    }
+    if (tid == 0) ctl->n = n_before + n_acc;
+    __syncthreads();
+}
+
+// number of tree nodes under ONE root down to depth d: nb + nb^2 + ... + nb^d
+__device__ __forceinline__ uint32_t tree_size(int nb, int d)
+{
+    uint32_t s = 0, p = 1;
+    for (int j = 1; j <= d; j++) { p *= (uint32_t)nb; s += p; }
+    return s;
+}
+
+#ifdef MC_BFS_TIMING
+#define MC_STAMP(i)                                                            \
+    do {                                                                       \
+        const unsigned long long now_ = __builtin_amdgcn_s_memrealtime();      \
+        if ((i) > 0) tacc[(i) > 0 ? (i)-1 : 0] += now_ - tlast;                \
+        tlast = now_;                                                          \
+    } while (0)
+#else
+#define MC_STAMP(i) do {} while (0)
+#endif
+
+// Exact level-by-level replay of one speculated round (wave 0).  Returns the number of accepted
+// vertices; updates n/lb/le/level/cur/F in L.
+__device__ inline uint32_t replay_slow(const BfsState &S, NarrowLds &L, int d, int min_cov, long long max_kmers,
+                                       long long max_radius, uint32_t lg, uint32_t flim, uint32_t *last_base)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t nb = 1u << lg;
+    unsigned long long n = L.n, lb = L.lb, le = L.le;
+    long long level = L.level;
+    int cur = L.cur;
+    const uint32_t F = L.F;
+    for (uint32_t i = lane; i < RH_SIZE; i += 64) L.set[i] = LH_EMPTY;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    uint32_t n_new = 0;  // accepted this round (uniform)
+    uint32_t Fj = F;     // frontier of the level being expanded
+    uint32_t base = 0, width = F << lg;
+    for (int j = 1; j <= d; j++) {
+        const uint32_t ncand = Fj << lg;  // <= 64
+        const bool have = lane < ncand;
+        const uint32_t p = lane >> lg, c = lane & (nb - 1);
+        uint32_t id = 0, pidx = 0;
+        bool pdup = false;
+        int cov = -1;
+        bool solid = false, gvis = false;
+        Kmer v{0, 0};
+        if (have) {
+            const uint32_t pw = L.fl_w[cur][p];
+            const uint32_t pi = L.fl_idx[cur][p];
+            pidx = pi & 0x3FFFFFFFu;
+            pdup = (pi & 0x80000000u) != 0;
+            id = base + (pw << lg) + c;
+            cov = L.cov[id];
+            gvis = L.vis[id] != 0;
+            v = L.kmer[id];
+            solid = cov >= min_cov;
+        }
+        const bool capped = max_kmers >= 0 && (long long)n >= max_kmers;
+        const bool radius_ok = max_radius < 0 || level + 1 <= max_radius;
+        bool mark_last = false, contender = false;
+        if (solid) {
+            if (pdup) mark_last = true;
+            if (capped || !radius_ok || gvis) mark_last = true;
+            else contender = true;
+        }
+        uint32_t slot = 0;
+        if (contender) slot = lds_set_min(L.set, RH_SIZE - 1, L.kmer, v, id);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        const bool winner = contender && L.set[slot] == id;  // ids grow with (level, rank): earlier levels win
+        if (contender && !winner) mark_last = true;
+        const unsigned long long wm = __ballot(winner);
+        const uint32_t pos = (uint32_t)__popcll(wm & ((1ull << lane) - 1));
+        bool accepted = false;
+        uint64_t idx = 0;
+        if (winner) {
+            idx = n + pos;
+            accepted = max_kmers < 0 || (long long)idx < max_kmers;
+            if (!accepted) mark_last = true;
+        }
+        const unsigned long long am = __ballot(accepted);
+        const uint32_t n_acc = (uint32_t)__popcll(am);
+        if (accepted) {
+            const uint32_t apos = (uint32_t)__popcll(am & ((1ull << lane) - 1));  // == pos: the cap cuts a prefix
+            S.hi[idx] = v.hi;
+            S.lo[idx] = v.lo;
+            S.dist[idx] = (int32_t)(level + 1);
+            S.cov[idx] = (int16_t)cov;
+            L.new_id[n_new + apos] = id;
+            L.new_idx[n_new + apos] = (uint32_t)idx;
+            L.fl_w[cur ^ 1][apos] = id - base;
+            L.fl_idx[cur ^ 1][apos] = (uint32_t)idx;
+        }
+        if (mark_last) atomicOr(&S.flags[pidx], 1u);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        n += n_acc;
+        n_new += n_acc;
+        lb = le;
+        le = n;
+        level++;
+        cur ^= 1;
+        Fj = n_acc;
+        base += width;
+        width <<= lg;
+        if (Fj == 0 || Fj > flim) break;
+    }
+    *last_base = base - (width >> lg);
+    if (lane == 0) {
+        L.n = n; L.lb = lb; L.le = le; L.level = level; L.cur = cur; L.F = Fj;
+    }
+    return n_new;
+}
+
+// oriented hint of a walker: the bases it expects next, nearest first (bits 0..13), bit 14 = valid,
+// bit 15 = the walker moves right
+__device__ __forceinline__ uint32_t walker_hint(uint32_t aux, bool flipped, bool right)
+{
+    const uint32_t R = aux & 0x3FFFu, L = (aux >> 16) & 0x3FFFu;
+    const bool RV = (aux & HINT_RV) != 0, LV = (aux & HINT_LV) != 0;
+    uint32_t f;
+    bool v;
+    if (right) { f = flipped ? (L ^ 0x3FFFu) : R; v = flipped ? LV : RV; }
+    else       { f = flipped ? (R ^ 0x3FFFu) : L; v = flipped ? RV : LV; }
+    return f | (v ? 0x4000u : 0u) | (right ? 0x8000u : 0u);
+}
+
+// table lookup with the first two probe slots already loaded; also returns the slot's hint word
+__device__ __forceinline__ int table_get2_aux(const TableView &t, uint64_t key, const uint4 &r0, const uint4 &r1,
+                                              uint32_t *aux)
+{
+    *aux = 0;
+    if (key == EMPTY_KEY) return table_get(t, key);
+    const uint64_t k0 = ((uint64_t)r0.y << 32) | r0.x;
+    if (k0 == key) { *aux = r0.w; return r0.z > 32767u ? 32767 : (int)r0.z; }
+    if (k0 == EMPTY_KEY) return -1;
+    const uint64_t k1 = ((uint64_t)r1.y << 32) | r1.x;
+    if (k1 == key) { *aux = r1.w; return r1.z > 32767u ? 32767 : (int)r1.z; }
+    if (k1 == EMPTY_KEY) return -1;
+    uint64_t s = slot_of(t, key);  // both probes hit other keys: walk the region
+    const uint64_t base = s & ~(uint64_t)t.rmask;
+    for (uint32_t probe = 0; probe <= t.rmask; probe++) {
+        const uint4 raw = *reinterpret_cast<const uint4 *>(t.slots + s);
+        const uint64_t cur = ((uint64_t)raw.y << 32) | raw.x;
+        if (cur == key) { *aux = raw.w; return raw.z > 32767u ? 32767 : (int)raw.z; }
+        if (cur == EMPTY_KEY) return -1;
+        s = base | ((s + 1) & t.rmask);
+    }
+    return -1;
+}
+
+// The narrow walk (wave 0 only, no workgroup barriers inside; the other waves wait at the barrier
+// behind it).  Entered at a level boundary with a frontier of F <= NARROW_CAND / nb vertices
+// ("walkers"); returns when the frontier is empty (done), too wide, distanceToKmer is nearly full,
+// or the round budget is used up.  The state is handed back in *ctl.
+//
+// A round looks up, in ONE memory round trip, the neighbours of every walker and of the next
+// H - 1 vertices each walker is EXPECTED to visit (the hint stored with the walker's k-mer says
+// which bases followed it in some read).  Then it counts the leading levels J in which every
+// walker's neighbourhood held exactly what the sequential BFS needs to add exactly the expected
+// vertex (anything else that is solid there is already in distanceToKmer): those F*J vertices are
+// appended in level-major order, which is the sequential discovery order.  The first level that
+// holds anything else (a branch, a dead end, a wrong hint, a cycle, the cap, the radius) is left
+// to the exact one-level replay with the LDS set (replay_slow).  Hints only steer the guess.
+template <int MODE>
+__device__ void bfs_narrow(const BfsState &S, const TableView &t, NarrowLds &L, int k, int min_cov,
+                           long long max_kmers, long long max_radius, unsigned long long &rounds_left,
+                           unsigned long long &lookups)
+{
+    BfsCtl *ctl = S.ctl;
+    const uint32_t lane = threadIdx.x & 63;
+    const int dir = S.dir;
+    const int nb = dir == 0 ? 8 : 4;
+    const uint32_t lg = dir == 0 ? 3 : 2;    // log2(nb)
+    const uint32_t flim = NARROW_CAND / nb;  // widest frontier one wave replays
+#ifdef MC_BFS_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+#endif
+    unsigned long long rounds = 0, slow_rounds = 0;
+    uint32_t pend = 0;  // accepted vertices of the previous round not yet in the index
+    {
+        const unsigned long long lb = ctl->lb, le = ctl->le;
+        const long long level = ctl->level;
+        const uint32_t F = (uint32_t)(le - lb);
+        bool dup = false;
+        if (lane < F) {
+            const uint64_t di = lb + lane;
+            if (level == 0) dup = (ld_flags(&S.flags[di]) & 2u) != 0;
+            L.fl_w[0][lane] = lane;
+            L.fl_idx[0][lane] = (uint32_t)di | (dup ? 0x80000000u : 0u);
+            Kmer r;
+            r.hi = S.hi[di];
+            r.lo = S.lo[di];
+            L.root[lane] = r;
+            L.rhint[lane] = dir > 0 ? 0x8000u : 0u;  // no hint yet: the first round is a plain one-level round
+        }
+        const bool any = __ballot(dup) != 0;
+        if (lane == 0) {
+            L.n = ctl->n; L.lb = lb; L.le = le; L.level = level; L.F = F; L.cur = 0;
+            L.status = BFS_RUNNING; L.any_dup_root = any ? 1 : 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    }
+
+    for (;;) {
+        const uint32_t F = L.F;
+        const unsigned long long n = L.n;
+        const long long level = L.level;
+        const int cur = L.cur;
+        if (F == 0) { if (lane == 0) L.status = BFS_DONE; break; }
+        if (F > flim) break;
+        if (n + (unsigned long long)MAX_NODES > S.dcap) { if (lane == 0) L.status = BFS_NEED_GROW; break; }
+        if (rounds_left == 0) break;
+        rounds_left--;
+        rounds++;
+
+        const bool capped0 = max_kmers >= 0 && (long long)n >= max_kmers;
+        const long long room = max_radius < 0 ? (long long)HINT_LEN : max_radius - level;  // levels that may still add
+        const uint32_t FN = F << lg;  // nodes per level
+        // every walker needs a valid hint for a multi-level round
+        const uint32_t myh = lane < F ? L.rhint[lane] : 0x4000u;
+        const bool hints_ok = __ballot(!(myh & 0x4000u)) == 0;
+        uint32_t H = 1;
+        if (hints_ok && !capped0 && room >= 1 && !L.any_dup_root) {
+            H = (uint32_t)MAX_NODES / FN;
+            if (H > (uint32_t)HINT_LEN) H = HINT_LEN;
+            if ((long long)H > room) H = (uint32_t)room;
+            if (max_kmers >= 0) {
+                const unsigned long long fit = ((unsigned long long)max_kmers - n) / F;  // whole levels under the cap
+                if (fit < H) H = fit < 1 ? 1 : (uint32_t)fit;
+            }
+        }
+        const uint32_t NT = H * FN;
+
+        // ---- speculate: node (i, a, c) = c-th neighbour of the vertex walker a is expected to reach after i-1 steps
+        MC_STAMP(0);
+        Kmer nk[NPL];
+        uint64_t tkey[NPL];
+        uint4 r0[NPL], r1[NPL];
+        uint32_t ni[NPL], na[NPL], nc[NPL];
+        bool npred[NPL], nflip[NPL];
+#pragma unroll
+        for (int u = 0; u < NPL; u++) {
+            const uint32_t id = lane + 64u * (uint32_t)u;
+            nk[u] = Kmer{0, 0};
+            tkey[u] = 0;
+            r0[u] = make_uint4(0, 0, 0, 0);
+            r1[u] = r0[u];
+            ni[u] = 0; na[u] = 0; nc[u] = 0;
+            npred[u] = false; nflip[u] = false;
+            if (id < NT) {
+                uint32_t i = 1, r = id;
+                while (r >= FN) { r -= FN; i++; }
+                const uint32_t a = r >> lg, c = r & (uint32_t)(nb - 1);
+                const uint32_t h = L.rhint[a];
+                const bool right = (h & 0x8000u) != 0;
+                Kmer v = L.root[a];
+                for (uint32_t st = 1; st < i; st++)  // the expected path so far
+                    v = neighbour(v, k, right ? 1 : -1, (int)((h >> (2 * (st - 1))) & 3u));
+                const uint32_t hb = (h >> (2 * (i - 1))) & 3u;  // expected step i
+                const uint32_t cstar = dir == 0 ? (2 * hb + (right ? 1u : 0u)) : hb;
+                nk[u] = neighbour(v, k, dir, (int)c);
+                ni[u] = i; na[u] = a; nc[u] = c;
+                npred[u] = H > 1 && c == cstar;
+                bool fl;
+                tkey[u] = (uint64_t)key_of<MODE>(nk[u], k, &fl);
+                nflip[u] = fl;
+                const uint64_t s0 = slot_of(t, tkey[u]);
+                const uint64_t s1 = (s0 & ~(uint64_t)t.rmask) | ((s0 + 1) & t.rmask);
+                r0[u] = *reinterpret_cast<const uint4 *>(t.slots + s0);
+                r1[u] = *reinterpret_cast<const uint4 *>(t.slots + s1);
+                lookups++;
+            }
+        }
+        // the previous round's vertices enter the index while this round's probes are in flight
+        // (they complete before any vis_find below: memory operations of a wave return in order)
+        for (uint32_t i = lane; i < pend; i += 64) vis_insert(S, L.pub_k[i], L.pub_idx[i]);
+        pend = 0;
+        MC_STAMP(1);
+        int cov[NPL];
+        uint32_t naux[NPL];
+#pragma unroll
+        for (int u = 0; u < NPL; u++) {
+            const uint32_t id = lane + 64u * (uint32_t)u;
+            cov[u] = -1;
+            naux[u] = 0;
+            if (id < NT) {
+                cov[u] = table_get2_aux(t, tkey[u], r0[u], r1[u], &naux[u]);
+                L.cov[id] = (int16_t)cov[u];
+                L.kmer[id] = nk[u];
+                if (npred[u]) L.pk[(ni[u] - 1) * F + na[u]] = nk[u];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        MC_STAMP(2);
+        // is a solid node already in distanceToKmer when the sequential BFS meets it?  = in the index,
+        // or one of the expected vertices that come earlier in level-major order
+        bool solid[NPL], ind[NPL];
+        uint32_t bad_lvl = 0xFFFFFFFFu;  // first level at which one of my nodes breaks the expectation
+#pragma unroll
+        for (int u = 0; u < NPL; u++) {
+            const uint32_t id = lane + 64u * (uint32_t)u;
+            solid[u] = id < NT && cov[u] >= min_cov;
+            ind[u] = false;
+            if (solid[u]) ind[u] = vis_find(S, nk[u]);
+        }
+        if (H > 1) {  // ... or equal to an expected vertex that comes earlier: broadcast each one, compare everywhere
+            const uint32_t np = H * F;  // <= MAX_NODES / nb <= 64
+            Kmer mypk{0, 0};
+            if (lane < np) mypk = L.pk[lane];
+            for (uint32_t e = 0; e < np; e++) {
+                const uint64_t blo = __shfl(mypk.lo, (int)e), bhi = __shfl(mypk.hi, (int)e);
+#pragma unroll
+                for (int u = 0; u < NPL; u++)
+                    if (solid[u] && e < (ni[u] - 1) * F + na[u] && nk[u].lo == blo && nk[u].hi == bhi) ind[u] = true;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NPL; u++) {
+            const uint32_t id = lane + 64u * (uint32_t)u;
+            if (id < NT) {
+                L.vis[id] = ind[u] ? 1 : 0;  // (level 1 only matters: the one-level replay reads it)
+                const bool ok = npred[u] ? (solid[u] && !ind[u]) : (!solid[u] || ind[u]);
+                if (!ok && ni[u] < bad_lvl) bad_lvl = ni[u];
+            }
+        }
+        MC_STAMP(3);
+        uint32_t J = 0;
+        if (H > 1) {
+            J = H;
+            for (uint32_t i = 1; i <= H; i++)
+                if (__ballot(bad_lvl == i) != 0) { J = i - 1; break; }
+        }
+
+        uint32_t n_new = 0, last_base = 0;
+        if (J >= 1) {
+            // ---- levels 1..J are exactly "every walker steps to its expected vertex"
+#pragma unroll
+            for (int u = 0; u < NPL; u++) {
+                const uint32_t id = lane + 64u * (uint32_t)u;
+                if (id < NT && ni[u] <= J) {
+                    const uint32_t i = ni[u], a = na[u];
+                    if (npred[u]) {
+                        const uint64_t idx = n + (unsigned long long)(i - 1) * F + a;
+                        S.hi[idx] = nk[u].hi;
+                        S.lo[idx] = nk[u].lo;
+                        S.dist[idx] = (int32_t)(level + i);
+                        S.cov[idx] = (int16_t)cov[u];
+                        L.pub_k[(i - 1) * F + a] = nk[u];
+                        L.pub_idx[(i - 1) * F + a] = (uint32_t)idx;
+                        if (i == J) {  // the walker's new position
+                            const bool right = (L.rhint[a] & 0x8000u) != 0;
+                            L.nhint[a] = walker_hint(naux[u], nflip[u], right);
+                            L.fl_idx[cur ^ 1][a] = (uint32_t)idx;
+                        }
+                    } else if (solid[u]) {  // solid but already there: lastKmers.add(parent)
+                        const uint32_t pidx = i == 1 ? (L.fl_idx[cur][a] & 0x3FFFFFFFu)
+                                                     : (uint32_t)(n + (unsigned long long)(i - 2) * F + a);
+                        atomicOr(&S.flags[pidx], 1u);
+                    }
+                }
+            }
+            n_new = F * J;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            if (lane < F) {
+                L.root[lane] = L.pk[(J - 1) * F + lane];
+                L.rhint[lane] = L.nhint[lane];
+                L.fl_w[cur ^ 1][lane] = lane;
+            }
+            if (lane == 0) {
+                L.n = n + n_new;
+                L.lb = n + (unsigned long long)(J - 1) * F;
+                L.le = n + n_new;
+                L.level = level + J;
+                L.cur = cur ^ 1;
+                L.any_dup_root = 0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            MC_STAMP(4);
+            pend = n_new;  // indexed while the next round's lookups are in flight
+        } else {
+            // ---- exact one-level replay of level 1 (ids [0, FN) are the plain neighbour sets of the walkers)
+            slow_rounds++;
+#pragma unroll
+            for (int u = 0; u < NPL; u++) {
+                const uint32_t id = lane + 64u * (uint32_t)u;
+                if (id < FN) L.aux[id] = naux[u] | 0u;
+                if (id < FN) L.flip[id] = nflip[u] ? 1 : 0;
+                if (id < FN && H > 1) L.vis[id] = (solid[u] && vis_find(S, nk[u])) ? 1 : 0;  // index only, no expectations
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            n_new = replay_slow(S, L, 1, min_cov, max_kmers, max_radius, lg, flim, &last_base);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            MC_STAMP(4);
+            for (uint32_t i = lane; i < n_new; i += 64) vis_insert(S, L.kmer[L.new_id[i]], L.new_idx[i]);
+            const uint32_t Fn = L.F;
+            const int c2 = L.cur;
+            Kmer nr{0, 0};
+            uint32_t nh = 0;
+            if (lane < Fn && Fn <= flim) {
+                const uint32_t id = last_base + L.fl_w[c2][lane];
+                nr = L.kmer[id];
+                const bool right = dir > 0 || (dir == 0 && (id & 1u));  // odd neighbour index = right neighbour
+                nh = walker_hint(L.aux[id], L.flip[id] != 0, right);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            if (lane < Fn && Fn <= flim) {
+                L.root[lane] = nr;
+                L.rhint[lane] = nh;
+                L.fl_w[c2][lane] = lane;  // walkers are numbered 0..F-1 in the next round
+            }
+            if (lane == 0) L.any_dup_root = 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        MC_STAMP(5);
+    }
+    for (uint32_t i = lane; i < pend; i += 64) vis_insert(S, L.pub_k[i], L.pub_idx[i]);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    if (lane == 0) {
+        ctl->n = L.n;
+        ctl->lb = L.lb;
+        ctl->le = L.le;
+        ctl->c0 = 0;
+        ctl->level = L.level;
+        ctl->rounds_narrow += rounds;
+        ctl->rounds_slow += slow_rounds;
+        if (L.status != BFS_RUNNING) ctl->status = L.status;
+        L.rounds_left = rounds_left;
+#ifdef MC_BFS_TIMING
+        for (int i = 0; i < 8; i++) ctl->tacc[i] += tacc[i];
+#endif
+    }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(BFS_THREADS) k_bfs(const BfsState *__restrict__ states, TableView t, int k,
+                                                     int min_cov, long long max_kmers, long long max_radius,
+                                                     unsigned long long max_rounds)
+{
+    __shared__ BfsLds lds;
+    const BfsState S = states[blockIdx.x];
+    BfsCtl *ctl = S.ctl;
+    if (ctl->status != BFS_RUNNING) return;  // finished (or waiting for the host) in an earlier launch
+    const uint32_t tid = threadIdx.x;
+    unsigned long long lookups = 0, rounds_left = max_rounds, chunks = 0;
+    const int dir = S.dir;
+    const int nb = dir == 0 ? 8 : 4;
+    const uint32_t flim = NARROW_CAND / nb;
+
+    // seeds: every window with reads.get(key) >= minOccurences, in order (:159-192)
+    if (!ctl->seeds_done) {
+        for (;;) {
+            const unsigned long long c0 = ctl->c0;
+            if (c0 >= S.n_seeds) break;
+            if (ctl->n + BFS_THREADS > S.dcap) {
+                if (tid == 0) ctl->status = BFS_NEED_GROW;
+                goto out;
+            }
+            if (rounds_left == 0) goto out;
+            rounds_left--;
+            chunks++;
+            const uint64_t r = c0 + tid;
+            const bool have = r < S.n_seeds;
+            Kmer cand{0, 0};
+            if (have) { cand.hi = S.seed_hi ? S.seed_hi[r] : 0; cand.lo = S.seed_lo[r]; }
+            __syncthreads();
+            bfs_chunk_wide<MODE>(S, t, lds.w, k, min_cov, -1, true, have, cand, UINT64_MAX, 0, lookups);
+            if (tid == 0) ctl->c0 = c0 + BFS_THREADS;
+            __syncthreads();
+        }
+        if (tid == 0) {
+            ctl->seeds_done = 1;
+            ctl->lb = 0;
+            ctl->le = ctl->n;
+            ctl->c0 = 0;
+            ctl->level = 0;
+        }
+        __syncthreads();
+    }
+
+    for (;;) {
+        const unsigned long long lb = ctl->lb, le = ctl->le;
+        if (le == lb) {
+            if (tid == 0) ctl->status = BFS_DONE;
+            break;
+        }
+        if (ctl->status != BFS_RUNNING) break;
+        if (rounds_left == 0) break;
+        if (ctl->c0 == 0 && le - lb <= flim) {
+            __syncthreads();
+            if (tid < 64) bfs_narrow<MODE>(S, t, lds.n, k, min_cov, max_kmers, max_radius, rounds_left, lookups);
+            __syncthreads();
+            rounds_left = lds.n.rounds_left;
+            __syncthreads();
+            if (ctl->status != BFS_RUNNING) break;  // done, or distanceToKmer must grow
+            if (ctl->le - ctl->lb <= flim && ctl->le != ctl->lb) break;  // round budget used up: relaunch
+            continue;
+        }
+        const long long level = ctl->level;
+        const bool radius_ok = max_radius < 0 || level + 1 <= max_radius;  // newDistance > threshold -> false
+        const unsigned long long ncand = (le - lb) * (unsigned long long)nb;
+        for (;;) {
+            const unsigned long long c0 = ctl->c0;
+            if (c0 >= ncand) break;
+            if (ctl->n + BFS_THREADS > S.dcap) {
+                if (tid == 0) ctl->status = BFS_NEED_GROW;
+                goto out;
+            }
+            if (rounds_left == 0) goto out;
+            rounds_left--;
+            chunks++;
+            const unsigned long long rank = c0 + tid;
+            const bool have = rank < ncand;
+            Kmer cand{0, 0};
+            uint64_t parent = 0;
+            if (have) {
+                parent = lb + rank / nb;
+                const Kmer pv{S.hi[parent], S.lo[parent]};
+                cand = neighbour(pv, k, dir, (int)(rank % nb));
+            }
+            __syncthreads();
+            bfs_chunk_wide<MODE>(S, t, lds.w, k, min_cov, max_kmers, radius_ok, have, cand, parent,
+                                 (int32_t)(level + 1), lookups);
+            if (tid == 0) ctl->c0 = c0 + BFS_THREADS;
+            __syncthreads();
+        }
+        if (tid == 0) {
+            ctl->lb = le;
+            ctl->le = ctl->n;
+            ctl->c0 = 0;
+            ctl->level = level + 1;
+        }
+        __syncthreads();
+    }
+out:
+    atomicAdd(&ctl->lookups, lookups);
+    if (tid == 0) atomicAdd(&ctl->chunks_wide, chunks);
+}
+
+// rebuild the index of distanceToKmer after the host enlarged it
+__global__ void k_vis_rebuild(BfsState S, uint64_t n)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const Kmer v{S.hi[i], S.lo[i]};
+        vis_insert(S, v, (uint32_t)i);
+    }
+}
+
+}  // namespace mc

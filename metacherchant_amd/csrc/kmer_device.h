@@ -56,16 +56,20 @@ __host__ __device__ __forceinline__ uint32_t base_at(const Kmer &v, int k, int i
     return (uint32_t)((sh >= 64 ? (v.hi >> (sh - 64)) : (v.lo >> sh)) & 3);
 }
 
+// All key functions also report `flipped`: whether the reverse-complement strand supplied the key
+// (only used to orient the speculation hints stored next to the key; never part of a result).
+
 // itmo!/dna/kmers/ShortKmer.java:54-56 toLong = Math.min(fwKmer, rcKmer) on signed longs
 // (both are < 2^62 for k <= 31, so the unsigned min is the same number)
-__host__ __device__ __forceinline__ int64_t key_packed(uint64_t fw, int k)
+__host__ __device__ __forceinline__ int64_t key_packed(uint64_t fw, int k, bool *flipped = nullptr)
 {
     const int64_t a = (int64_t)fw, b = (int64_t)rc_packed(fw, k);
+    if (flipped) *flipped = b < a;
     return a < b ? a : b;
 }
 
 // src/utils/PolynomialHash.java:19-28
-__host__ __device__ inline int64_t key_poly(const Kmer &v, int k)
+__host__ __device__ inline int64_t key_poly(const Kmer &v, int k, bool *flipped = nullptr)
 {
     uint64_t fw = 1, rc = 1;
     for (int i = 0; i < k; i++) {
@@ -73,11 +77,12 @@ __host__ __device__ inline int64_t key_poly(const Kmer &v, int k)
         rc = rc * 5 + (3u ^ base_at(v, k, k - 1 - i));
     }
     const int64_t a = (int64_t)fw, b = (int64_t)rc;
+    if (flipped) *flipped = b < a;
     return a < b ? a : b;  // Math.min on signed longs
 }
 
 // src/utils/FNV1AHash.java:8-9,33-42
-__host__ __device__ inline int64_t key_fnv1a(const Kmer &v, int k)
+__host__ __device__ inline int64_t key_fnv1a(const Kmer &v, int k, bool *flipped = nullptr)
 {
     const uint64_t prime = 1099511628211ull;
     uint64_t fw = 14695981039346656037ull, rc = 14695981039346656037ull;
@@ -86,16 +91,17 @@ __host__ __device__ inline int64_t key_fnv1a(const Kmer &v, int k)
         rc = (rc ^ (uint64_t)(3u ^ base_at(v, k, k - 1 - i))) * prime;
     }
     const int64_t a = (int64_t)fw, b = (int64_t)rc;
+    if (flipped) *flipped = b < a;
     return a < b ? a : b;
 }
 
 // src/algo/OneSequenceCalculator.java:89-96 getKmerKey / src/tools/EnvironmentFinderMain.java:128
 template <int MODE>
-__host__ __device__ __forceinline__ int64_t key_of(const Kmer &v, int k)
+__host__ __device__ __forceinline__ int64_t key_of(const Kmer &v, int k, bool *flipped = nullptr)
 {
-    if (MODE == KEY_PACKED) return key_packed(v.lo, k);
-    if (MODE == KEY_POLY) return key_poly(v, k);
-    return key_fnv1a(v, k);
+    if (MODE == KEY_PACKED) return key_packed(v.lo, k, flipped);
+    if (MODE == KEY_POLY) return key_poly(v, k, flipped);
+    return key_fnv1a(v, k, flipped);
 }
 
 __host__ __device__ inline int64_t key_of_mode(const Kmer &v, int k, int mode)
@@ -153,6 +159,60 @@ __host__ __device__ __forceinline__ Kmer neighbour(const Kmer &v, int k, int dir
 }
 
 // ---------------------------------------------------------------------------------------------
+// Speculation hints (Slot::aux).  While counting, a window also knows the bases around it in its
+// read; one occurrence's context is kept next to the key: the HINT_LEN bases that follow the key's
+// own strand (R) and the HINT_LEN bases that precede it (L), nearest base first, 2 bits each.
+// The BFS uses them only to GUESS the next vertices of a linear stretch and looks every guess up,
+// so a missing or wrong hint can cost time but never change a result.  The context is the one of
+// the occurrence that inserted the key (it rides on that thread's count update, no extra traffic).
+constexpr int HINT_LEN = 7;
+constexpr uint32_t HINT_RV = 1u << 14, HINT_LV = 1u << 30;  // R bits 0..13 + valid, L bits 16..29 + valid
+constexpr uint32_t HINT_RMASK = 0x00007FFFu, HINT_LMASK = 0x7FFF0000u;
+
+__host__ __device__ __forceinline__ uint32_t hint_merge(uint32_t have, uint32_t mine)
+{
+    uint32_t r = have;
+    if (!(have & HINT_RV) && (mine & HINT_RV)) r |= mine & HINT_RMASK;
+    if (!(have & HINT_LV) && (mine & HINT_LV)) r |= mine & HINT_LMASK;
+    return r;
+}
+
+// n <= 32 bases starting at base p, right-aligned, first base most significant
+__device__ __forceinline__ uint64_t extract_bases(const uint64_t *__restrict__ words, uint64_t p, int n)
+{
+    const uint64_t wi = p >> 5;
+    const int off = 2 * (int)(p & 31);
+    const uint64_t w0 = words[wi], w1 = words[wi + 1];
+    const uint64_t a = off ? ((w0 << off) | (w1 >> (64 - off))) : w0;
+    return a >> (64 - 2 * n);
+}
+
+// hint of the window at base q of the read [rb, re), for the strand that supplied the key
+__device__ __forceinline__ uint32_t hint_of(const uint64_t *__restrict__ words, uint64_t q, int k, uint64_t rb,
+                                            uint64_t re, bool flipped)
+{
+    uint32_t fr = 0, fl = 0;  // contexts of the forward window, nearest base in bits 1..0
+    bool rv = false, lv = false;
+    if (q + (uint64_t)k + HINT_LEN <= re) {
+        uint32_t x = (uint32_t)extract_bases(words, q + (uint64_t)k, HINT_LEN);  // first following base on top
+        x = __brev(x) >> (32 - 2 * HINT_LEN);                                      // reverse the bit order ...
+        fr = ((x & 0x1555u) << 1) | ((x >> 1) & 0x1555u);                          // ... and restore the pairs
+        rv = true;
+    }
+    if (q >= rb + HINT_LEN) {
+        fl = (uint32_t)extract_bases(words, q - HINT_LEN, HINT_LEN);  // nearest preceding base already lowest
+        lv = true;
+    }
+    uint32_t R = fr, L = fl;
+    bool RV = rv, LV = lv;
+    if (flipped) {  // the key's strand runs the other way: what followed now precedes, complemented
+        R = fl ^ 0x3FFFu; RV = lv;
+        L = fr ^ 0x3FFFu; LV = rv;
+    }
+    return (RV ? (R | HINT_RV) : 0u) | (LV ? ((L << 16) | HINT_LV) : 0u);
+}
+
+// ---------------------------------------------------------------------------------------------
 // The k-mer table in HBM (layout free: SURVEY.md F7).  2^rb regions of RS = 2^sb slots; a key
 // lives in region = top rb bits of fmix64(key), starting at offset = next sb bits, linear
 // probing that wraps inside the region.  A slot is 16 bytes {u64 key; u32 count; u32 aux} so one
@@ -177,7 +237,7 @@ __device__ __forceinline__ uint64_t slot_of(const TableView &t, uint64_t key) { 
 // addAndBound(key, inc) with the saturation deferred to read time (count is 32-bit here; a
 // counter that already reached 2^31 is left alone, launches add < 2^30 each, so it never wraps
 // and min(32767, count) equals the reference's saturating short, itmo!/utils/NumUtils.java:21-26).
-__device__ __forceinline__ void table_add(const TableView &t, uint64_t key, uint32_t inc)
+__device__ __forceinline__ void table_add(const TableView &t, uint64_t key, uint32_t inc, uint32_t hint = 0)
 {
     if (key == EMPTY_KEY) {
         atomicAdd(t.empty_cnt, (unsigned long long)inc);
@@ -195,7 +255,9 @@ __device__ __forceinline__ void table_add(const TableView &t, uint64_t key, uint
                             (unsigned long long)key);
             if (cur == EMPTY_KEY) {
                 atomicAdd(t.n_used, 1ull);
-                atomicAdd(&p->count, inc);
+                // the inserter alone also writes the hint: one 64-bit add on {count, aux} (aux was 0, and
+                // count never carries into it: counters stop growing at 2^31)
+                atomicAdd(reinterpret_cast<unsigned long long *>(&p->count), ((unsigned long long)hint << 32) | inc);
                 return;
             }
             if (cur == key) {

@@ -17,6 +17,7 @@
 
 #include "../../include/mcgpu.h"
 #include "kmer_device.h"
+#include "bfs_device.h"
 
 using namespace mc;
 
@@ -32,14 +33,29 @@ struct mc_ctx {
     // table
     Slot *slots = nullptr;
     uint32_t rb = 0, sb = 12;  // 2^rb regions of 2^sb slots
-    unsigned long long *d_ctr = nullptr;  // [0] n_used, [1] empty_cnt, [2] scratch counter
+    unsigned long long *d_ctr = nullptr;  // [0] n_used, [1] empty_cnt, [2] scratch counter, [3] solid n_used
     uint32_t *d_fatal = nullptr;
     uint64_t n_used_host = 0;
     bool finalized = false;
 
+    // "solid" table: only the keys with count >= solid_cov, at a load factor <= 1/8, so that the
+    // BFS's (mostly negative) lookups end at their first probe.  Built lazily by mc_bfs_batch.
+    Slot *solid = nullptr;
+    uint32_t solid_lg = 0;
+    int solid_cov = -1;  // -1: not built / stale
+    uint64_t n_solid = 0;
+
     mc_stats st{};
 
     uint64_t n_slots() const { return 1ull << (rb + sb); }
+    TableView solid_view() const
+    {
+        TableView t = view();
+        t.slots = solid;
+        t.shift = 64 - solid_lg;
+        t.n_used = d_ctr + 3;
+        return t;
+    }
     TableView view() const
     {
         TableView t;
@@ -110,7 +126,9 @@ __global__ void __launch_bounds__(256) k_count_reads(const uint64_t *__restrict_
         const uint64_t nwin = e - b - (uint64_t)k + 1;
         for (uint64_t w = lane; w < nwin; w += 64) {
             const Kmer v = extract_kmer(words, b + w, k);
-            table_add(t, (uint64_t)key_of<MODE>(v, k), 1u);
+            bool flipped;
+            const uint64_t key = (uint64_t)key_of<MODE>(v, k, &flipped);
+            table_add(t, key, 1u, hint_of(words, b + w, k, b, e, flipped));
         }
     }
 }
@@ -138,7 +156,20 @@ __global__ void k_rehash(const Slot *__restrict__ old_slots, uint64_t n_old, Tab
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_old; i += stride) {
         const uint4 raw = *reinterpret_cast<const uint4 *>(old_slots + i);
         const uint64_t key = ((uint64_t)raw.y << 32) | raw.x;
-        if (key != EMPTY_KEY) table_add(t, key, raw.z);
+        if (key != EMPTY_KEY) table_add(t, key, raw.z, raw.w);
+    }
+}
+
+// K6: copy the keys with count >= min_cov into the sparse "solid" table the BFS probes
+__global__ void k_build_solid(const Slot *__restrict__ slots, uint64_t n_slots, int min_cov, TableView solid)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += stride) {
+        const uint4 raw = *reinterpret_cast<const uint4 *>(slots + i);
+        const uint64_t key = ((uint64_t)raw.y << 32) | raw.x;
+        if (key == EMPTY_KEY) continue;
+        const int c = raw.z > 32767u ? 32767 : (int)raw.z;
+        if (c >= min_cov) table_add(solid, key, (uint32_t)c, raw.w);
     }
 }
 
@@ -258,261 +289,6 @@ __global__ void k_synth_reads(uint64_t gseed, uint64_t n_contigs, uint64_t conti
         words[w] = v;
     }
     for (uint64_t r = tid; r <= n_reads; r += stride) offsets[r] = r * (uint64_t)L;
-}
-
-// ------------------------------------------------------------------------------------------ kernels: BFS
-
-constexpr uint32_t V_EMPTY = 0xFFFFFFFFu, V_TOMB = 0xFFFFFFFEu, V_TEMP = 0x80000000u;
-constexpr int BFS_THREADS = 1024;
-
-enum { BFS_RUNNING = 0, BFS_DONE = 1, BFS_NEED_GROW = 2 };
-
-struct BfsCtl {
-    unsigned long long n;       // |distanceToKmer|
-    unsigned long long lb, le;  // current frontier = entries [lb, le)
-    unsigned long long c0;      // next candidate rank inside the frontier
-    unsigned long long lookups;
-    long long level;            // distance of the frontier
-    int status;
-    int seeds_done;
-};
-
-struct BfsState {
-    uint64_t *hi, *lo;  // distanceToKmer keys in insertion order
-    int32_t *dist;
-    int16_t *cov;
-    uint32_t *flags;    // bit0: in lastKmers; bit1: seed window queued more than once
-    uint64_t dcap;
-    uint32_t *vis;      // open-addressed set of indices into the arrays above
-    uint64_t vmask;
-    BfsCtl *ctl;
-};
-
-__device__ __forceinline__ uint32_t vis_load(const uint32_t *p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ __forceinline__ uint64_t vis_hash(const Kmer &v)
-{
-    return fmix64(v.lo ^ fmix64(v.hi + 0x9e3779b97f4a7c15ull));
-}
-
-// block-wide exclusive scan of one flag per thread; returns the block total in *total
-__device__ __forceinline__ uint32_t block_scan_flag(bool flag, uint32_t *lds_wave_tot, uint32_t *total)
-{
-    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const unsigned long long m = __ballot(flag);
-    const uint32_t in_wave = (uint32_t)__popcll(m & ((1ull << lane) - 1));
-    if (lane == 0) lds_wave_tot[wv] = (uint32_t)__popcll(m);
-    __syncthreads();
-    uint32_t before = 0, tot = 0;
-    const uint32_t n_waves = blockDim.x >> 6;
-    for (uint32_t i = 0; i < n_waves; i++) {
-        const uint32_t c = lds_wave_tot[i];
-        if (i < wv) before += c;
-        tot += c;
-    }
-    __syncthreads();
-    *total = tot;
-    return before + in_wave;
-}
-
-// One chunk of <= BFS_THREADS candidate vertices in rank order: look up, deduplicate against
-// distanceToKmer and among themselves (smallest rank wins, exactly the sequential order of
-// src/algo/OneSequenceCalculator.java:198-214), append the survivors in rank order, apply
-// TerminationMode.allowsAddition (src/algo/TerminationMode.java:31-47).
-// parent == UINT64_MAX marks a seed window (:159-192).
-template <int MODE>
-__device__ void bfs_chunk(const BfsState &S, const TableView &t, int k, int min_cov, long long max_kmers,
-                          bool radius_ok, bool have, const Kmer &cand, uint64_t parent, int32_t new_dist,
-                          Kmer *lds_kmer, uint32_t *lds_tot, uint64_t rank0, unsigned long long &lookups)
-{
-    BfsCtl *ctl = S.ctl;
-    const uint32_t tid = threadIdx.x;
-    int cov = -1;
-    if (have) {
-        cov = table_get(t, (uint64_t)key_of<MODE>(cand, k));
-        lookups++;
-    }
-    const bool solid = have && cov >= min_cov;
-    const bool is_seed = parent == UINT64_MAX;
-    const unsigned long long n_before = ctl->n;  // uniform: written only between barriers below
-    const bool capped = max_kmers >= 0 && (long long)n_before >= max_kmers;
-    lds_kmer[tid] = cand;
-    if (solid && !is_seed && S.flags[parent] & 2u) atomicOr(&S.flags[parent], 1u);  // re-queued seed window
-    __syncthreads();
-
-    // ---- claim phase
-    uint64_t slot = UINT64_MAX;
-    bool contender = false;
-    if (solid && !is_seed && (capped || !radius_ok)) {
-        atomicOr(&S.flags[parent], 1u);  // allowsAddition() == false -> lastKmers.add(kmer)
-    } else if (solid) {
-        const uint32_t my = V_TEMP | tid;
-        uint64_t s = vis_hash(cand) & S.vmask;
-        for (uint64_t probe = 0; probe <= S.vmask; probe++) {
-            uint32_t v = vis_load(&S.vis[s]);
-            if (v == V_EMPTY) {
-                v = atomicCAS(&S.vis[s], V_EMPTY, my);
-                if (v == V_EMPTY) { slot = s; contender = true; break; }
-            }
-            if (v == V_TOMB) { s = (s + 1) & S.vmask; continue; }
-            if (v & V_TEMP) {  // claimed in this chunk by candidate (v & ~V_TEMP); value only ever shrinks
-                const Kmer o = lds_kmer[v & ~V_TEMP];
-                if (o.lo == cand.lo && o.hi == cand.hi) {
-                    atomicMin(&S.vis[s], my);
-                    slot = s;
-                    contender = true;
-                    break;
-                }
-            } else if (S.lo[v] == cand.lo && S.hi[v] == cand.hi) {  // already in distanceToKmer
-                if (is_seed) atomicOr(&S.flags[v], 2u); else atomicOr(&S.flags[parent], 1u);
-                break;
-            }
-            s = (s + 1) & S.vmask;
-        }
-    }
-    __syncthreads();
-
-    // ---- resolve phase
-    bool winner = false;
-    if (contender) {
-        winner = vis_load(&S.vis[slot]) == (V_TEMP | tid);
-        if (!winner && !is_seed) atomicOr(&S.flags[parent], 1u);  // an earlier rank inserted it first
-    }
-    uint32_t total;
-    const uint32_t pos = block_scan_flag(winner, lds_tot, &total);
-    bool accepted = false;
-    uint64_t idx = 0;
-    if (winner) {
-        idx = n_before + pos;
-        accepted = is_seed || max_kmers < 0 || (long long)idx < max_kmers;  // distanceToKmer.size() < threshold
-        if (accepted) {
-            S.hi[idx] = cand.hi;
-            S.lo[idx] = cand.lo;
-            S.dist[idx] = new_dist;
-            S.cov[idx] = (int16_t)cov;
-            S.flags[idx] = 0;
-            __hip_atomic_store(&S.vis[slot], (uint32_t)idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            __hip_atomic_store(&S.vis[slot], V_TOMB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            atomicOr(&S.flags[parent], 1u);
-        }
-    }
-    // losers of a seed chunk: the winner's index is final now only after the stores above land
-    __syncthreads();
-    if (contender && !winner && is_seed) {
-        const uint32_t v = vis_load(&S.vis[slot]);
-        if (!(v & V_TEMP)) atomicOr(&S.flags[v], 2u);
-    }
-    uint32_t n_acc;
-    (void)block_scan_flag(accepted, lds_tot, &n_acc);
-    if (tid == 0) ctl->n = n_before + n_acc;
-    __syncthreads();
-    (void)rank0;
-}
-
-// K5: persistent single-workgroup BFS; all state lives in HBM so the launch is resumable
-// (bounded number of levels per launch; distanceToKmer can be grown by the host between launches).
-template <int MODE>
-__global__ void __launch_bounds__(BFS_THREADS) k_bfs(BfsState S, TableView t, int k, int dir, int min_cov,
-                                                     long long max_kmers, long long max_radius,
-                                                     const uint64_t *__restrict__ seed_hi,
-                                                     const uint64_t *__restrict__ seed_lo, uint64_t n_seeds,
-                                                     unsigned long long max_chunks)
-{
-    __shared__ Kmer lds_kmer[BFS_THREADS];
-    __shared__ uint32_t lds_tot[BFS_THREADS / 64];
-    BfsCtl *ctl = S.ctl;
-    const uint32_t tid = threadIdx.x;
-    unsigned long long lookups = 0, chunks = 0;
-    const int nb = dir == 0 ? 8 : 4;
-
-    // seeds: every window with reads.get(key) >= minOccurences, in order (:159-192)
-    if (!ctl->seeds_done) {
-        for (;;) {
-            const unsigned long long c0 = ctl->c0;
-            if (c0 >= n_seeds) break;
-            if (ctl->n + BFS_THREADS > S.dcap) {
-                if (tid == 0) ctl->status = BFS_NEED_GROW;
-                goto out;
-            }
-            if (chunks++ >= max_chunks) goto out;
-            const uint64_t r = c0 + tid;
-            const bool have = r < n_seeds;
-            Kmer cand{0, 0};
-            if (have) { cand.hi = seed_hi ? seed_hi[r] : 0; cand.lo = seed_lo[r]; }
-            __syncthreads();
-            bfs_chunk<MODE>(S, t, k, min_cov, -1, true, have, cand, UINT64_MAX, 0, lds_kmer, lds_tot, c0, lookups);
-            if (tid == 0) ctl->c0 = c0 + BFS_THREADS;
-            __syncthreads();
-        }
-        if (tid == 0) {
-            ctl->seeds_done = 1;
-            ctl->lb = 0;
-            ctl->le = ctl->n;
-            ctl->c0 = 0;
-            ctl->level = 0;
-        }
-        __syncthreads();
-    }
-
-    for (;;) {
-        const unsigned long long lb = ctl->lb, le = ctl->le;
-        if (le == lb) {
-            if (tid == 0) ctl->status = BFS_DONE;
-            break;
-        }
-        const long long level = ctl->level;
-        const bool radius_ok = max_radius < 0 || level + 1 <= max_radius;  // newDistance > threshold -> false
-        const unsigned long long ncand = (le - lb) * (unsigned long long)nb;
-        for (;;) {
-            const unsigned long long c0 = ctl->c0;
-            if (c0 >= ncand) break;
-            if (ctl->n + BFS_THREADS > S.dcap) {
-                if (tid == 0) ctl->status = BFS_NEED_GROW;
-                goto out;
-            }
-            if (chunks++ >= max_chunks) goto out;
-            const unsigned long long rank = c0 + tid;
-            const bool have = rank < ncand;
-            Kmer cand{0, 0};
-            uint64_t parent = 0;
-            if (have) {
-                parent = lb + rank / nb;
-                const Kmer pv{S.hi[parent], S.lo[parent]};
-                cand = neighbour(pv, k, dir, (int)(rank % nb));
-            }
-            __syncthreads();
-            bfs_chunk<MODE>(S, t, k, min_cov, max_kmers, radius_ok, have, cand, parent, (int32_t)(level + 1),
-                            lds_kmer, lds_tot, c0, lookups);
-            if (tid == 0) ctl->c0 = c0 + BFS_THREADS;
-            __syncthreads();
-        }
-        if (tid == 0) {
-            ctl->lb = le;
-            ctl->le = ctl->n;
-            ctl->c0 = 0;
-            ctl->level = level + 1;
-        }
-        __syncthreads();
-    }
-out:
-    atomicAdd(&ctl->lookups, lookups);
-}
-
-__global__ void k_vis_rebuild(BfsState S, uint64_t n)
-{
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const Kmer v{S.hi[i], S.lo[i]};
-        uint64_t s = vis_hash(v) & S.vmask;
-        for (uint64_t probe = 0; probe <= S.vmask; probe++) {
-            if (atomicCAS(&S.vis[s], V_EMPTY, (uint32_t)i) == V_EMPTY) break;
-            s = (s + 1) & S.vmask;
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------ host: table management
@@ -660,6 +436,7 @@ static int add_reads_impl(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_
         r = r1;
     }
     c->finalized = false;
+    c->solid_cov = -1;
     return MC_OK;
 }
 
@@ -705,9 +482,9 @@ int mc_create(const mc_config *cfg, mc_ctx **out)
     c->stream = c->own_stream;
     CREATE_CHK(hipEventCreate(&c->ev0));
     CREATE_CHK(hipEventCreate(&c->ev1));
-    CREATE_CHK(hipMalloc(reinterpret_cast<void **>(&c->d_ctr), 3 * sizeof(unsigned long long)));
+    CREATE_CHK(hipMalloc(reinterpret_cast<void **>(&c->d_ctr), 4 * sizeof(unsigned long long)));
     CREATE_CHK(hipMalloc(reinterpret_cast<void **>(&c->d_fatal), sizeof(uint32_t)));
-    CREATE_CHK(hipMemsetAsync(c->d_ctr, 0, 3 * sizeof(unsigned long long), c->stream));
+    CREATE_CHK(hipMemsetAsync(c->d_ctr, 0, 4 * sizeof(unsigned long long), c->stream));
     CREATE_CHK(hipMemsetAsync(c->d_fatal, 0, sizeof(uint32_t), c->stream));
 #undef CREATE_CHK
     uint32_t lg = 22;  // 4 M slots = 64 MB to start with
@@ -731,6 +508,7 @@ void mc_destroy(mc_ctx *c)
     (void)hipSetDevice(c->cfg.device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     if (c->slots) (void)hipFree(c->slots);
+    if (c->solid) (void)hipFree(c->solid);
     if (c->d_ctr) (void)hipFree(c->d_ctr);
     if (c->d_fatal) (void)hipFree(c->d_fatal);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -747,10 +525,11 @@ int mc_clear(mc_ctx *c)
     hipLaunchKernelGGL(k_fill_empty, dim3(grid_for(c->n_slots(), 256)), dim3(256), 0, c->stream, c->slots,
                        c->n_slots());
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, 3 * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, 4 * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_fatal, 0, sizeof(uint32_t), c->stream));
     c->n_used_host = 0;
     c->finalized = false;
+    c->solid_cov = -1;
     return MC_OK;
 }
 
@@ -832,6 +611,7 @@ int mc_add_keys_dev(mc_ctx *c, const int64_t *d_keys, uint64_t n)
         i += m;
     }
     c->finalized = false;
+    c->solid_cov = -1;
     return MC_OK;
 }
 
@@ -853,6 +633,7 @@ int mc_add_pairs_dev(mc_ctx *c, const int64_t *d_keys, const int16_t *d_counts, 
         i += m;
     }
     c->finalized = false;
+    c->solid_cov = -1;
     return MC_OK;
 }
 
@@ -1080,145 +861,263 @@ void mc_bfs_result_free(mc_bfs_result *r)
     memset(r, 0, sizeof *r);
 }
 
-struct BfsBuffers {
+namespace {
+
+struct BfsJobBuffers {
     BfsState S{};
-    ~BfsBuffers()
+    uint64_t *d_seed_hi = nullptr, *d_seed_lo = nullptr;
+    void free_arrays()
     {
         (void)hipFree(S.hi); (void)hipFree(S.lo); (void)hipFree(S.dist); (void)hipFree(S.cov);
-        (void)hipFree(S.flags); (void)hipFree(S.vis); (void)hipFree(S.ctl);
+        (void)hipFree(S.flags); (void)hipFree(S.vis);
+        S.hi = S.lo = nullptr; S.dist = nullptr; S.cov = nullptr; S.flags = nullptr; S.vis = nullptr;
+    }
+    ~BfsJobBuffers()
+    {
+        free_arrays();
+        (void)hipFree(S.ctl);
+        (void)hipFree(d_seed_hi);
+        (void)hipFree(d_seed_lo);
     }
 };
 
-static int bfs_alloc(mc_ctx *c, BfsState &S, uint64_t dcap)
+int bfs_alloc(mc_ctx *c, BfsState &S, uint64_t dcap)
 {
     S.dcap = dcap;
     uint64_t vcap = 1024;
     while (vcap < 4 * dcap) vcap <<= 1;
-    S.vmask = vcap - 1;
+    S.bmask = vcap / 2 - 1;
     HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&S.hi), dcap * 8));
     HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&S.lo), dcap * 8));
     HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&S.dist), dcap * 4));
     HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&S.cov), dcap * 2));
     HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&S.flags), dcap * 4));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&S.vis), vcap * 4));
-    HIPCHK(c, hipMemsetAsync(S.vis, 0xFF, vcap * 4, c->stream));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&S.vis), vcap * 8));
+    HIPCHK(c, hipMemsetAsync(S.vis, 0xFF, vcap * 8, c->stream));
     HIPCHK(c, hipMemsetAsync(S.flags, 0, dcap * 4, c->stream));
     return MC_OK;
+}
+
+// Builds (or reuses) the solid table for this threshold.  Falls back to the full table when the
+// sparse copy would not fit: the BFS is exact either way, only slower.
+int ensure_solid(mc_ctx *c, int min_cov, double *ms)
+{
+    if (c->solid_cov == min_cov) return MC_OK;
+    c->solid_cov = -1;
+    unsigned long long *cursor = c->d_ctr + 2;
+    HIPCHK(c, hipMemsetAsync(cursor, 0, sizeof(unsigned long long), c->stream));
+    int rc = timed(c, ms, [&] {
+        hipLaunchKernelGGL(k_export, dim3(grid_for(c->n_slots(), 256)), dim3(256), 0, c->stream, c->slots,
+                           c->n_slots(), min_cov, (int64_t *)nullptr, (int16_t *)nullptr, (uint64_t)0, cursor);
+    });
+    if (rc) return rc;
+    unsigned long long n = 0;
+    HIPCHK(c, hipMemcpy(&n, cursor, sizeof n, hipMemcpyDeviceToHost));
+    c->n_solid = n;
+    uint32_t lg = c->sb;
+    uint64_t factor = 8;  // slots per solid key (load factor <= 1/8)
+    if (const char *e = getenv("MC_SOLID_FACTOR")) factor = std::max<uint64_t>(2, strtoull(e, nullptr, 10));
+    while (lg < 31 && (1ull << lg) < factor * n) lg++;
+    if ((1ull << lg) < 2 * n || lg >= c->rb + c->sb) {  // no gain over the full table
+        if (c->solid) { (void)hipFree(c->solid); c->solid = nullptr; }
+        c->solid_lg = 0;
+        c->solid_cov = min_cov;
+        return MC_OK;
+    }
+    if (!c->solid || lg != c->solid_lg) {
+        if (c->solid) { (void)hipFree(c->solid); c->solid = nullptr; }
+        if (hipMalloc(reinterpret_cast<void **>(&c->solid), (sizeof(Slot)) << lg) != hipSuccess) {
+            (void)hipGetLastError();
+            c->solid = nullptr;
+            c->solid_lg = 0;
+            c->solid_cov = min_cov;
+            return MC_OK;
+        }
+        c->solid_lg = lg;
+    }
+    HIPCHK(c, hipMemsetAsync(c->d_ctr + 3, 0, sizeof(unsigned long long), c->stream));
+    rc = timed(c, ms, [&] {
+        hipLaunchKernelGGL(k_fill_empty, dim3(grid_for(1ull << lg, 256)), dim3(256), 0, c->stream, c->solid,
+                           (uint64_t)1 << lg);
+        hipLaunchKernelGGL(k_build_solid, dim3(grid_for(c->n_slots(), 256)), dim3(256), 0, c->stream, c->slots,
+                           c->n_slots(), min_cov, c->solid_view());
+    });
+    if (rc) return rc;
+    uint32_t fatal = 0;
+    HIPCHK(c, hipMemcpy(&fatal, c->d_fatal, sizeof fatal, hipMemcpyDeviceToHost));
+    if (fatal) return fail(c, MC_EOVERFLOW, "a region of the solid k-mer table filled up (hash skew)");
+    c->solid_cov = min_cov;
+    return MC_OK;
+}
+
+void launch_bfs(mc_ctx *c, const BfsState *d_states, uint32_t n_jobs, int min_cov, int64_t max_kmers,
+                int64_t max_radius, unsigned long long max_rounds)
+{
+    const TableView t = c->solid ? c->solid_view() : c->view();
+    switch (c->cfg.key_mode) {
+    case MC_KEY_PACKED:
+        hipLaunchKernelGGL(k_bfs<KEY_PACKED>, dim3(n_jobs), dim3(BFS_THREADS), 0, c->stream, d_states, t, c->cfg.k,
+                           min_cov, (long long)max_kmers, (long long)max_radius, max_rounds);
+        break;
+    case MC_KEY_POLY:
+        hipLaunchKernelGGL(k_bfs<KEY_POLY>, dim3(n_jobs), dim3(BFS_THREADS), 0, c->stream, d_states, t, c->cfg.k,
+                           min_cov, (long long)max_kmers, (long long)max_radius, max_rounds);
+        break;
+    default:
+        hipLaunchKernelGGL(k_bfs<KEY_FNV1A>, dim3(n_jobs), dim3(BFS_THREADS), 0, c->stream, d_states, t, c->cfg.k,
+                           min_cov, (long long)max_kmers, (long long)max_radius, max_rounds);
+    }
+}
+
+}  // namespace
+
+int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov, int64_t max_kmers,
+                 int64_t max_radius, mc_bfs_result *out)
+{
+    if (!c) return MC_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!out || !jobs || n_jobs == 0) return fail(c, MC_EINVAL, "mc_bfs: null argument");
+    memset(out, 0, sizeof(mc_bfs_result) * n_jobs);
+    if (!c->finalized) return fail(c, MC_ESTATE, "mc_bfs: call mc_finalize_counts first");
+    if (max_kmers < 0 && max_radius < 0)
+        return fail(c, MC_EINVAL, "At least one of --maxkmers and --maxradius parameters should be set");
+    if (min_cov < 0)
+        return fail(c, MC_EINVAL, "mc_bfs: negative coverage threshold (absent k-mers read as -1 and would pass)");
+    if (n_jobs > 4096) return fail(c, MC_EINVAL, "mc_bfs: too many jobs in one batch");
+    for (uint32_t j = 0; j < n_jobs; j++) {
+        if (jobs[j].dir < -1 || jobs[j].dir > 1) return fail(c, MC_EINVAL, "mc_bfs: dir must be -1, 0 or +1");
+        if (jobs[j].n_seeds && !jobs[j].seed_lo) return fail(c, MC_EINVAL, "mc_bfs: seed_lo is null");
+        if (c->cfg.k > 32 && jobs[j].n_seeds && !jobs[j].seed_hi)
+            return fail(c, MC_EINVAL, "mc_bfs: seed_hi is null with k > 32");
+        if (max_kmers >= (int64_t)0x3FFFF000ll || jobs[j].n_seeds >= 0x3FFFF000ull)
+            return fail(c, MC_EINVAL, "mc_bfs: more than 2^30 vertices requested");
+    }
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    double total_ms = 0;
+    {
+        int rc = ensure_solid(c, min_cov, &total_ms);
+        if (rc) return rc;
+    }
+
+    std::vector<BfsJobBuffers> B(n_jobs);
+    for (uint32_t j = 0; j < n_jobs; j++) {
+        BfsState &S = B[j].S;
+        const uint64_t ns = jobs[j].n_seeds;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&B[j].d_seed_lo), std::max<uint64_t>(ns, 1) * 8));
+        if (ns) HIPCHK(c, hipMemcpyAsync(B[j].d_seed_lo, jobs[j].seed_lo, ns * 8, hipMemcpyHostToDevice, c->stream));
+        if (jobs[j].seed_hi) {
+            HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&B[j].d_seed_hi), std::max<uint64_t>(ns, 1) * 8));
+            if (ns) HIPCHK(c, hipMemcpyAsync(B[j].d_seed_hi, jobs[j].seed_hi, ns * 8, hipMemcpyHostToDevice, c->stream));
+        }
+        const uint64_t dcap = max_kmers >= 0 ? std::max<uint64_t>((uint64_t)max_kmers, ns) + 2 * BFS_THREADS
+                                             : std::max<uint64_t>(1ull << 20, ns + 2 * BFS_THREADS);
+        int rc = bfs_alloc(c, S, dcap);
+        if (rc) return rc;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&S.ctl), sizeof(BfsCtl)));
+        HIPCHK(c, hipMemsetAsync(S.ctl, 0, sizeof(BfsCtl), c->stream));
+        S.seed_hi = B[j].d_seed_hi;
+        S.seed_lo = B[j].d_seed_lo;
+        S.n_seeds = ns;
+        S.dir = jobs[j].dir;
+    }
+    DevBuf<BfsState> d_states;
+    HIPCHK(c, d_states.alloc(n_jobs));
+    std::vector<BfsState> h_states(n_jobs);
+    std::vector<BfsCtl> ctl(n_jobs);
+    const unsigned long long max_rounds = 1ull << 17;  // bounds one launch; unfinished jobs are relaunched
+    for (;;) {
+        for (uint32_t j = 0; j < n_jobs; j++) h_states[j] = B[j].S;
+        HIPCHK(c, hipMemcpyAsync(d_states.p, h_states.data(), n_jobs * sizeof(BfsState), hipMemcpyHostToDevice,
+                                 c->stream));
+        int rc = timed(c, &total_ms,
+                       [&] { launch_bfs(c, d_states.p, n_jobs, min_cov, max_kmers, max_radius, max_rounds); });
+        if (rc) return rc;
+        bool all_done = true;
+        for (uint32_t j = 0; j < n_jobs; j++) {
+            HIPCHK(c, hipMemcpy(&ctl[j], B[j].S.ctl, sizeof(BfsCtl), hipMemcpyDeviceToHost));
+            if (ctl[j].status == BFS_DONE) continue;
+            all_done = false;
+            if (ctl[j].status != BFS_NEED_GROW) continue;
+            // grow distanceToKmer and its index (only reachable without --maxkmers)
+            BfsState &S = B[j].S;
+            BfsState N = S;
+            N.hi = N.lo = nullptr; N.dist = nullptr; N.cov = nullptr; N.flags = nullptr; N.vis = nullptr;
+            rc = bfs_alloc(c, N, S.dcap * 2);
+            if (rc) return rc;
+            const uint64_t n = ctl[j].n;
+            HIPCHK(c, hipMemcpyAsync(N.hi, S.hi, n * 8, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(N.lo, S.lo, n * 8, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(N.dist, S.dist, n * 4, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(N.cov, S.cov, n * 2, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(N.flags, S.flags, n * 4, hipMemcpyDeviceToDevice, c->stream));
+            if (n) {
+                hipLaunchKernelGGL(k_vis_rebuild, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, N, n);
+                HIPCHK(c, hipGetLastError());
+            }
+            const int running = BFS_RUNNING;
+            HIPCHK(c, hipMemcpyAsync(&S.ctl->status, &running, sizeof running, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            B[j].free_arrays();
+            S = N;
+        }
+        if (all_done) break;
+    }
+
+    int ret = MC_OK;
+    for (uint32_t j = 0; j < n_jobs; j++) {
+        const BfsState &S = B[j].S;
+        const uint64_t n = ctl[j].n;
+        mc_bfs_result *o = &out[j];
+        o->lookups = ctl[j].lookups;
+        o->rounds = ctl[j].rounds_narrow + ctl[j].chunks_wide;
+        o->device_ms = total_ms;
+#ifdef MC_BFS_TIMING
+        {
+            const double r_ = 0.01 / std::max(1ull, ctl[j].rounds_narrow);
+            fprintf(stderr, "[bfs job %u] rounds_narrow=%llu (slow %llu) chunks_wide=%llu levels~%lld  us/round: gen+issue %.2f table %.2f vis+check %.2f accept %.2f publish %.2f (%.2f %.2f)\n",
+                    j, ctl[j].rounds_narrow, ctl[j].rounds_slow, ctl[j].chunks_wide, ctl[j].level, ctl[j].tacc[0] * r_,
+                    ctl[j].tacc[1] * r_, ctl[j].tacc[2] * r_, ctl[j].tacc[3] * r_, ctl[j].tacc[4] * r_, ctl[j].tacc[5] * r_,
+                    ctl[j].tacc[6] * r_);
+        }
+#endif
+        if (n == 0) continue;  // the reference's "fail": no seed k-mer passes (out[j].n == 0)
+        o->n = n;
+        o->hi = static_cast<uint64_t *>(malloc(n * 8));
+        o->lo = static_cast<uint64_t *>(malloc(n * 8));
+        o->dist = static_cast<int32_t *>(malloc(n * 4));
+        o->cov = static_cast<int16_t *>(malloc(n * 2));
+        o->last = static_cast<uint8_t *>(malloc(n));
+        std::vector<uint32_t> flags(n);
+        if (!o->hi || !o->lo || !o->dist || !o->cov || !o->last) {
+            ret = fail(c, MC_ENOMEM, "mc_bfs: out of host memory");
+            break;
+        }
+        HIPCHK(c, hipMemcpy(o->hi, S.hi, n * 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(o->lo, S.lo, n * 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(o->dist, S.dist, n * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(o->cov, S.cov, n * 2, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(flags.data(), S.flags, n * 4, hipMemcpyDeviceToHost));
+        uint64_t levels = 0;
+        for (uint64_t i = 0; i < n; i++) {
+            o->last[i] = (uint8_t)(flags[i] & 1u);
+            if ((uint64_t)o->dist[i] > levels) levels = (uint64_t)o->dist[i];
+        }
+        o->levels = levels;
+    }
+    if (ret != MC_OK)
+        for (uint32_t j = 0; j < n_jobs; j++) mc_bfs_result_free(&out[j]);
+    return ret;
 }
 
 int mc_bfs(mc_ctx *c, const uint64_t *seed_hi, const uint64_t *seed_lo, uint64_t n_seeds, int dir, int min_cov,
            int64_t max_kmers, int64_t max_radius, mc_bfs_result *out)
 {
     if (!c) return MC_EINVAL;
-    std::lock_guard<std::mutex> g(c->mu);
     if (!out) return fail(c, MC_EINVAL, "mc_bfs: out is null");
-    memset(out, 0, sizeof *out);
-    if (!c->finalized) return fail(c, MC_ESTATE, "mc_bfs: call mc_finalize_counts first");
-    if (dir < -1 || dir > 1) return fail(c, MC_EINVAL, "mc_bfs: dir must be -1, 0 or +1");
-    if (max_kmers < 0 && max_radius < 0)
-        return fail(c, MC_EINVAL, "At least one of --maxkmers and --maxradius parameters should be set");
-    if (min_cov < 0)
-        return fail(c, MC_EINVAL, "mc_bfs: negative coverage threshold (absent k-mers read as -1 and would pass)");
-    if (n_seeds && !seed_lo) return fail(c, MC_EINVAL, "mc_bfs: seed_lo is null");
-    if (c->cfg.k > 32 && n_seeds && !seed_hi) return fail(c, MC_EINVAL, "mc_bfs: seed_hi is null with k > 32");
-    if (n_seeds == 0) return fail(c, MC_ENOSEED, "Could not find any k-mers of the target gene in the input");
-    if (max_kmers >= (int64_t)V_TEMP - 4096 || n_seeds >= (uint64_t)V_TEMP - 4096)
-        return fail(c, MC_EINVAL, "mc_bfs: more than 2^31 vertices requested");
-    HIPCHK(c, hipSetDevice(c->cfg.device));
-
-    DevBuf<uint64_t> d_shi, d_slo;
-    HIPCHK(c, d_slo.alloc(n_seeds));
-    HIPCHK(c, hipMemcpyAsync(d_slo.p, seed_lo, n_seeds * 8, hipMemcpyHostToDevice, c->stream));
-    if (seed_hi) {
-        HIPCHK(c, d_shi.alloc(n_seeds));
-        HIPCHK(c, hipMemcpyAsync(d_shi.p, seed_hi, n_seeds * 8, hipMemcpyHostToDevice, c->stream));
-    }
-
-    BfsBuffers B;
-    BfsState &S = B.S;
-    uint64_t dcap = max_kmers >= 0 ? std::max<uint64_t>((uint64_t)max_kmers, n_seeds) + 2 * BFS_THREADS
-                                   : std::max<uint64_t>(1ull << 20, n_seeds + 2 * BFS_THREADS);
-    int rc = bfs_alloc(c, S, dcap);
+    mc_bfs_job job{seed_hi, seed_lo, n_seeds, dir};
+    int rc = mc_bfs_batch(c, &job, 1, min_cov, max_kmers, max_radius, out);
     if (rc) return rc;
-    HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&S.ctl), sizeof(BfsCtl)));
-    HIPCHK(c, hipMemsetAsync(S.ctl, 0, sizeof(BfsCtl), c->stream));
-
-    BfsCtl h{};
-    double total_ms = 0;
-    const unsigned long long max_chunks = 1ull << 16;  // bounds one launch; the loop below relaunches
-    for (;;) {
-        const TableView t = c->view();
-        rc = timed(c, &total_ms, [&] {
-            switch (c->cfg.key_mode) {
-            case MC_KEY_PACKED:
-                hipLaunchKernelGGL(k_bfs<KEY_PACKED>, dim3(1), dim3(BFS_THREADS), 0, c->stream, S, t, c->cfg.k, dir,
-                                   min_cov, (long long)max_kmers, (long long)max_radius, d_shi.p, d_slo.p, n_seeds,
-                                   max_chunks);
-                break;
-            case MC_KEY_POLY:
-                hipLaunchKernelGGL(k_bfs<KEY_POLY>, dim3(1), dim3(BFS_THREADS), 0, c->stream, S, t, c->cfg.k, dir,
-                                   min_cov, (long long)max_kmers, (long long)max_radius, d_shi.p, d_slo.p, n_seeds,
-                                   max_chunks);
-                break;
-            default:
-                hipLaunchKernelGGL(k_bfs<KEY_FNV1A>, dim3(1), dim3(BFS_THREADS), 0, c->stream, S, t, c->cfg.k, dir,
-                                   min_cov, (long long)max_kmers, (long long)max_radius, d_shi.p, d_slo.p, n_seeds,
-                                   max_chunks);
-            }
-        });
-        if (rc) return rc;
-        HIPCHK(c, hipMemcpy(&h, S.ctl, sizeof h, hipMemcpyDeviceToHost));
-        if (h.status == BFS_DONE) break;
-        if (h.status == BFS_NEED_GROW) {
-            // grow distanceToKmer and its index; only reachable without --maxkmers
-            BfsState N{};
-            rc = bfs_alloc(c, N, S.dcap * 2);
-            if (rc) return rc;
-            N.ctl = S.ctl;
-            HIPCHK(c, hipMemcpyAsync(N.hi, S.hi, h.n * 8, hipMemcpyDeviceToDevice, c->stream));
-            HIPCHK(c, hipMemcpyAsync(N.lo, S.lo, h.n * 8, hipMemcpyDeviceToDevice, c->stream));
-            HIPCHK(c, hipMemcpyAsync(N.dist, S.dist, h.n * 4, hipMemcpyDeviceToDevice, c->stream));
-            HIPCHK(c, hipMemcpyAsync(N.cov, S.cov, h.n * 2, hipMemcpyDeviceToDevice, c->stream));
-            HIPCHK(c, hipMemcpyAsync(N.flags, S.flags, h.n * 4, hipMemcpyDeviceToDevice, c->stream));
-            if (h.n) {
-                hipLaunchKernelGGL(k_vis_rebuild, dim3(grid_for(h.n, 256)), dim3(256), 0, c->stream, N, (uint64_t)h.n);
-                HIPCHK(c, hipGetLastError());
-            }
-            const int zero = BFS_RUNNING;
-            HIPCHK(c, hipMemcpyAsync(&S.ctl->status, &zero, sizeof zero, hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            (void)hipFree(S.hi); (void)hipFree(S.lo); (void)hipFree(S.dist); (void)hipFree(S.cov);
-            (void)hipFree(S.flags); (void)hipFree(S.vis);
-            S = N;
-        }
-    }
-    if (h.n == 0) return fail(c, MC_ENOSEED, "Could not find any k-mers of the target gene in the input");
-
-    const uint64_t n = h.n;
-    out->n = n;
-    out->hi = static_cast<uint64_t *>(malloc(n * 8));
-    out->lo = static_cast<uint64_t *>(malloc(n * 8));
-    out->dist = static_cast<int32_t *>(malloc(n * 4));
-    out->cov = static_cast<int16_t *>(malloc(n * 2));
-    out->last = static_cast<uint8_t *>(malloc(n));
-    std::vector<uint32_t> flags(n);
-    if (!out->hi || !out->lo || !out->dist || !out->cov || !out->last) {
-        mc_bfs_result_free(out);
-        return fail(c, MC_ENOMEM, "mc_bfs: out of host memory");
-    }
-    HIPCHK(c, hipMemcpy(out->hi, S.hi, n * 8, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(out->lo, S.lo, n * 8, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(out->dist, S.dist, n * 4, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(out->cov, S.cov, n * 2, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(flags.data(), S.flags, n * 4, hipMemcpyDeviceToHost));
-    uint64_t levels = 0;
-    for (uint64_t i = 0; i < n; i++) {
-        out->last[i] = (uint8_t)(flags[i] & 1u);
-        if ((uint64_t)out->dist[i] > levels) levels = (uint64_t)out->dist[i];
-    }
-    out->levels = levels;
-    out->lookups = h.lookups;
-    out->device_ms = total_ms;
+    if (out->n == 0) return fail(c, MC_ENOSEED, "Could not find any k-mers of the target gene in the input");
     return MC_OK;
 }
 

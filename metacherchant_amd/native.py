@@ -26,7 +26,12 @@ class _Config(C.Structure):
 class _BfsResult(C.Structure):
     _fields_ = [("n", C.c_uint64), ("hi", C.POINTER(C.c_uint64)), ("lo", C.POINTER(C.c_uint64)),
                 ("dist", C.POINTER(C.c_int32)), ("cov", C.POINTER(C.c_int16)), ("last", C.POINTER(C.c_uint8)),
-                ("levels", C.c_uint64), ("lookups", C.c_uint64), ("device_ms", C.c_double)]
+                ("levels", C.c_uint64), ("lookups", C.c_uint64), ("rounds", C.c_uint64), ("device_ms", C.c_double)]
+
+
+class _BfsJob(C.Structure):
+    _fields_ = [("seed_hi", C.POINTER(C.c_uint64)), ("seed_lo", C.POINTER(C.c_uint64)), ("n_seeds", C.c_uint64),
+                ("dir", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -38,7 +43,7 @@ class Stats(C.Structure):
 # every symbol include/mcgpu.h declares; tests check that the library exports all of them
 EXPORTS = [
     "mc_abi_version", "mc_create", "mc_destroy", "mc_clear", "mc_last_error", "mc_set_stream", "mc_add_reads_packed",
-    "mc_add_reads_packed_dev", "mc_finalize_counts", "mc_get", "mc_get_dev", "mc_kmer_keys", "mc_bfs",
+    "mc_add_reads_packed_dev", "mc_finalize_counts", "mc_get", "mc_get_dev", "mc_kmer_keys", "mc_bfs", "mc_bfs_batch", "mc_bfs_batch",
     "mc_bfs_result_free", "mc_export", "mc_export_dev", "mc_add_pairs_dev", "mc_key_owner", "mc_extract_keys_dev",
     "mc_add_keys_dev", "mc_get_stats", "mc_reset_stats", "mc_synth_reads_dev", "mc_synth_genome",
 ]
@@ -58,6 +63,12 @@ def load():
     if not os.path.exists(_build.LIB):
         raise RuntimeError("libmcgpu.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(needs hipcc); there is no CPU fallback")
+    # PyTorch-ROCm ships its own HIP runtime; it must be the first one initialised in a process that
+    # uses both (the other order leaves torch with "No HIP GPUs are available").
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(_build.LIB)
     vp, u64, i64, i32 = C.c_void_p, C.c_uint64, C.c_int64, C.c_int
     u64p, i64p, i16p = C.POINTER(C.c_uint64), C.POINTER(C.c_int64), C.POINTER(C.c_int16)
@@ -76,6 +87,7 @@ def load():
     L.mc_get_dev.argtypes = [vp, vp, u64, vp]
     L.mc_kmer_keys.argtypes = [vp, u64p, u64p, u64, i64p]
     L.mc_bfs.argtypes = [vp, u64p, u64p, u64, i32, i32, i64, i64, C.POINTER(_BfsResult)]
+    L.mc_bfs_batch.argtypes = [vp, C.POINTER(_BfsJob), C.c_uint32, i32, i64, i64, C.POINTER(_BfsResult)]
     L.mc_bfs_result_free.argtypes = [C.POINTER(_BfsResult)]
     L.mc_bfs_result_free.restype = None
     L.mc_export.argtypes = [vp, i32, i64p, i16p, u64, u64p]
@@ -185,27 +197,40 @@ class Context:
         return out
 
     # ---- BFS
-    def bfs(self, seed_hi, seed_lo, direction, min_cov, max_kmers=-1, max_radius=-1):
-        """Returns None when no seed k-mer reaches min_cov (the reference's 'fail'), else a dict of
-        numpy arrays in distanceToKmer insertion order."""
-        seed_lo = np.ascontiguousarray(seed_lo, dtype=np.uint64)
-        seed_hi = np.ascontiguousarray(seed_hi if seed_hi is not None else np.zeros(len(seed_lo)), dtype=np.uint64)
-        r = _BfsResult()
-        rc = self._L.mc_bfs(self._h, _p(seed_hi, C.c_uint64), _p(seed_lo, C.c_uint64), len(seed_lo), direction,
-                            min_cov, max_kmers, max_radius, C.byref(r))
-        if rc == MC_ENOSEED:
-            return None
-        self._chk(rc)
-        n = int(r.n)
+    def bfs_batch(self, jobs, min_cov, max_kmers=-1, max_radius=-1):
+        """jobs: list of (seed_hi or None, seed_lo, direction).  All passes run in one launch, one
+        workgroup each.  Returns a list with, per job, None when no seed k-mer reaches min_cov (the
+        reference's 'fail'), else a dict of numpy arrays in distanceToKmer insertion order."""
+        n = len(jobs)
+        arr_jobs = (_BfsJob * n)()
+        keep = []
+        for i, (hi, lo, d) in enumerate(jobs):
+            lo = np.ascontiguousarray(lo, dtype=np.uint64)
+            hi = np.ascontiguousarray(hi if hi is not None else np.zeros(len(lo)), dtype=np.uint64)
+            keep.append((hi, lo))
+            arr_jobs[i] = _BfsJob(_p(hi, C.c_uint64), _p(lo, C.c_uint64), len(lo), d)
+        res = (_BfsResult * n)()
+        self._chk(self._L.mc_bfs_batch(self._h, arr_jobs, n, min_cov, max_kmers, max_radius, res))
+        out = []
+        for i in range(n):
+            r = res[i]
+            m = int(r.n)
+            if m == 0:
+                out.append(None)
+                continue
 
-        def arr(ptr, dt):
-            return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt, copy=True)
+            def arr(ptr, dt):
+                return np.ctypeslib.as_array(ptr, shape=(m,)).astype(dt, copy=True)
 
-        out = dict(hi=arr(r.hi, np.uint64), lo=arr(r.lo, np.uint64), dist=arr(r.dist, np.int32),
-                   cov=arr(r.cov, np.int16), last=arr(r.last, np.uint8), levels=int(r.levels),
-                   lookups=int(r.lookups), device_ms=float(r.device_ms))
-        self._L.mc_bfs_result_free(C.byref(r))
+            out.append(dict(hi=arr(r.hi, np.uint64), lo=arr(r.lo, np.uint64), dist=arr(r.dist, np.int32),
+                            cov=arr(r.cov, np.int16), last=arr(r.last, np.uint8), levels=int(r.levels),
+                            lookups=int(r.lookups), rounds=int(r.rounds), device_ms=float(r.device_ms)))
+            self._L.mc_bfs_result_free(C.byref(r))
         return out
+
+    def bfs(self, seed_hi, seed_lo, direction, min_cov, max_kmers=-1, max_radius=-1):
+        """One runBfs pass; None when no seed k-mer reaches min_cov."""
+        return self.bfs_batch([(seed_hi, seed_lo, direction)], min_cov, max_kmers, max_radius)[0]
 
     # ---- export
     def export(self, min_cov=0):

@@ -173,6 +173,23 @@ def test_bfs_k63_hash_key(mc):
     ctx.close()
 
 
+def test_bfs_batch_equals_single_passes(mc, bfs_case):
+    """Both passes of --bothdirs False (and a second seed) in one launch == one pass at a time."""
+    genome, t, ctx = bfs_case
+    rng = np.random.default_rng(2)
+    seeds = [genome[10000:10500], genome[40000:40100], rng.integers(0, 4, 100).astype(np.uint8)]
+    jobs, want = [], []
+    for s in seeds:
+        hi, lo = seed_windows(s, 31)
+        for d in (-1, 1, 0):
+            jobs.append((hi, lo, d))
+            want.append(po.bfs(t, 31, po.KEY_PACKED, [s], d, 5, 3000, 700))
+    got = ctx.bfs_batch(jobs, 5, 3000, 700)
+    assert got[-1] is None and want[-1] is None
+    for g, w in zip(got, want):
+        assert_bfs_equal(g, w)
+
+
 def test_bfs_no_seed_passes(mc, bfs_case):
     _, t, ctx = bfs_case
     rng = np.random.default_rng(9)
