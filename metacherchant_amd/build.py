@@ -46,22 +46,27 @@ def build_lib(force=False, verbose=False):
     return LIB
 
 
+HOSTTEST = os.path.join(LIBDIR, "mc_hosttest")
+
+
 def build_host(force=False, verbose=False):
-    """C++ host side (CLI + writers); see csrc/host/."""
+    """C++ host side: the `metacherchant` CLI (links libmcgpu.so) and the CPU-only `mc_hosttest`."""
     hdir = os.path.join(CSRC, "host")
-    if not os.path.isdir(hdir):
-        return None
-    srcs = sorted(os.path.join(hdir, f) for f in os.listdir(hdir) if f.endswith(".cpp"))
-    hdrs = sorted(os.path.join(hdir, f) for f in os.listdir(hdir) if f.endswith(".h"))
-    if not srcs:
-        return None
-    if not force and not _stale(CLI, srcs + hdrs + [LIB]):
-        return CLI
-    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"), "-o", CLI] + srcs + [
-        "-L", LIBDIR, "-lmcgpu", "-Wl,-rpath,$ORIGIN", "-lpthread"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    os.makedirs(LIBDIR, exist_ok=True)
+    common = [os.path.join(hdir, "envfinder.cpp")]
+    hdrs = [os.path.join(hdir, "envfinder.h"), os.path.join(ROOT, "include", "mcgpu.h")]
+    flags = ["-O2", "-std=c++17", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include")]
+    if force or _stale(HOSTTEST, common + hdrs + [os.path.join(hdir, "hosttest.cpp")]):
+        cmd = ["g++"] + flags + ["-o", HOSTTEST, os.path.join(hdir, "hosttest.cpp")] + common
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    if os.path.exists(LIB) and (force or _stale(CLI, common + hdrs + [os.path.join(hdir, "main.cpp"), LIB])):
+        cmd = ["g++"] + flags + ["-o", CLI, os.path.join(hdir, "main.cpp")] + common + [
+            "-L", LIBDIR, "-lmcgpu", "-Wl,-rpath,$ORIGIN", "-lpthread"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     return CLI
 
 

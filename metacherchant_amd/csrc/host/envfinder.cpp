@@ -1,0 +1,589 @@
+// See envfinder.h.  Every function restates the reference lines cited there.
+#include "envfinder.h"
+
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <functional>
+#include <set>
+#include <sstream>
+
+namespace mch {
+
+// ------------------------------------------------------------------------------------------ DNA strings
+
+int code_of(char c)
+{
+    switch (c) {
+    case 'A': case 'a': return 0;
+    case 'G': case 'g': return 1;
+    case 'C': case 'c': return 2;
+    case 'T': case 't': return 3;
+    default: return -1;
+    }
+}
+
+static inline char complement_char(char c)
+{
+    switch (c) {
+    case 'A': return 'T';
+    case 'C': return 'G';
+    case 'G': return 'C';
+    case 'T': return 'A';
+    default: throw Error(std::string("Incorrect nucleotide char: \"") + c + "\"");
+    }
+}
+
+std::string reverse_complement(const std::string &s)
+{
+    std::string r(s.size(), 'A');
+    for (size_t i = 0; i < s.size(); i++) r[i] = complement_char(s[s.size() - 1 - i]);
+    return r;
+}
+
+std::string normalize_dna(const std::string &s)
+{
+    std::string rc = reverse_complement(s);
+    return s.compare(rc) < 0 ? s : rc;  // String.compareTo on ASCII
+}
+
+std::vector<std::string> neighbors_by_dir(int dir, const std::string &kmer)
+{
+    static const char NUC[4] = {'A', 'G', 'C', 'T'};  // DnaTools.NUCLEOTIDES
+    std::vector<std::string> out;
+    const std::string head = kmer.substr(0, kmer.size() - 1), tail = kmer.substr(1);
+    if (dir == -1) {
+        for (char c : NUC) out.push_back(std::string(1, c) + head);
+    } else if (dir == 1) {
+        for (char c : NUC) out.push_back(tail + c);
+    } else {
+        for (char c : NUC) {
+            out.push_back(std::string(1, c) + head);
+            out.push_back(tail + c);
+        }
+    }
+    return out;
+}
+
+void pack_kmer(const std::string &s, uint64_t *hi, uint64_t *lo)
+{
+    unsigned __int128 v = 0;
+    for (char c : s) {
+        const int code = code_of(c);
+        if (code < 0) throw Error(std::string("Incorrect nucleotide char: \"") + c + "\"");
+        v = (v << 2) | (unsigned)code;
+    }
+    *hi = (uint64_t)(v >> 64);
+    *lo = (uint64_t)v;
+}
+
+std::string unpack_kmer(uint64_t hi, uint64_t lo, int k)
+{
+    const unsigned __int128 v = ((unsigned __int128)hi << 64) | lo;
+    std::string s((size_t)k, 'A');
+    for (int i = 0; i < k; i++) s[(size_t)i] = "AGCT"[(unsigned)(v >> (2 * (k - 1 - i))) & 3u];
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------ JavaHashMap
+
+static uint32_t java_string_hash(const std::string &s)
+{
+    uint32_t h = 0;
+    for (unsigned char c : s) h = 31u * h + c;
+    return h;
+}
+
+JavaHashMap::JavaHashMap() : bins_(16) {}
+
+void JavaHashMap::put(const std::string &key, int value)
+{
+    auto it = index_.find(key);
+    if (it != index_.end()) {
+        entries_[it->second].value = value;
+        return;
+    }
+    uint32_t h = java_string_hash(key);
+    h ^= h >> 16;
+    const uint32_t e = (uint32_t)entries_.size();
+    entries_.push_back(Entry{key, value, h});
+    index_.emplace(key, e);
+    auto &bin = bins_[h & (cap_ - 1)];
+    bin.push_back(e);
+    if (bin.size() >= 9) {  // a 9th node: treeifyBin (or a resize while the table is smaller than 64)
+        if (cap_ >= 64) treeified_ = true; else resize();
+    }
+    size_++;
+    if ((double)size_ > 0.75 * (double)cap_) resize();
+}
+
+void JavaHashMap::resize()
+{
+    const size_t ncap = cap_ * 2;
+    std::vector<std::vector<uint32_t>> nb(ncap);
+    for (const auto &bin : bins_)
+        for (uint32_t e : bin) nb[entries_[e].hash & (ncap - 1)].push_back(e);  // lo/hi split keeps relative order
+    cap_ = ncap;
+    bins_.swap(nb);
+}
+
+int JavaHashMap::get(const std::string &key) const
+{
+    auto it = index_.find(key);
+    if (it == index_.end()) throw Error("JavaHashMap::get: missing key " + key);
+    return entries_[it->second].value;
+}
+
+void JavaHashMap::remove(const std::string &key)
+{
+    auto it = index_.find(key);
+    if (it == index_.end()) return;
+    auto &bin = bins_[entries_[it->second].hash & (cap_ - 1)];
+    bin.erase(std::find(bin.begin(), bin.end(), it->second));
+    index_.erase(it);
+    size_--;
+}
+
+// ------------------------------------------------------------------------------------------ files
+
+static void mkdirs(const std::string &dir)
+{
+    if (dir.empty()) return;
+    std::string cur;
+    for (size_t i = 0; i <= dir.size(); i++) {
+        if (i == dir.size() || dir[i] == '/') {
+            if (!cur.empty() && cur != "/") {
+                if (mkdir(cur.c_str(), 0777) != 0 && errno != EEXIST)
+                    throw Error("Could not create directory " + cur + ": " + strerror(errno));
+            }
+        }
+        if (i < dir.size()) cur.push_back(dir[i]);
+    }
+}
+
+void write_file(const std::string &path, const std::string &text)
+{
+    const size_t slash = path.find_last_of('/');
+    if (slash != std::string::npos) mkdirs(path.substr(0, slash));
+    std::ofstream f(path, std::ios::binary);
+    if (!f) throw Error("Could not write " + path);
+    f << text;
+}
+
+static bool read_lines(const std::string &path, std::vector<std::string> *lines)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    std::string line;
+    while (std::getline(f, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        lines->push_back(line);
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------ seeds
+
+static std::string dnaq_string(const std::string &s)
+{
+    std::string r;
+    r.reserve(s.size());
+    for (char c : s) {
+        if (c == 'N' || c == 'n' || c == '.') {
+            r.push_back('A');  // DnaQ: unknown -> nuc 0
+        } else {
+            const int code = code_of(c);
+            if (code < 0) throw Error(std::string("Incorrect nucleotide char: \"") + c + "\"");
+            r.push_back("AGCT"[code]);
+        }
+    }
+    return r;
+}
+
+SeedFile read_seed_fasta(const std::string &path)
+{
+    std::vector<std::string> lines;
+    if (!read_lines(path, &lines)) throw Error("cannot open " + path);
+    SeedFile out;
+    bool last_comment = true;
+    std::string cur_comment, cur_dna;
+    for (const std::string &line : lines) {
+        if (!line.empty() && (line[0] == '>' || line[0] == ';')) {
+            if (!last_comment) {
+                out.dnas.push_back(dnaq_string(cur_dna));
+                cur_dna.clear();
+                cur_comment.clear();
+            }
+            cur_comment += line.substr(1);
+            last_comment = true;
+        } else {
+            if (last_comment) {
+                out.comments.push_back(cur_comment);
+                cur_dna.clear();
+                cur_comment.clear();
+            }
+            cur_dna += line;
+            last_comment = false;
+        }
+    }
+    if (!cur_comment.empty()) out.comments.push_back(cur_comment);
+    if (!cur_dna.empty()) out.dnas.push_back(dnaq_string(cur_dna));
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------ reads
+
+void PackedBatch::clear()
+{
+    words.clear();
+    offsets.assign(1, 0);
+}
+
+void PackedBatch::add_read(const char *s, size_t n)
+{
+    if (offsets.empty()) offsets.assign(1, 0);
+    uint64_t pos = offsets.back();
+    words.resize((pos + n + 31) / 32, 0);
+    for (size_t i = 0; i < n; i++, pos++) {
+        const int code = code_of(s[i]);
+        if (code < 0)
+            throw Error(std::string("read contains the character '") + s[i] +
+                        "': IUPAC codes other than N are replaced at random by the reference "
+                        "(itmo!/dna/DnaTools.java:66-117), which has no defined result; rejecting the input");
+        words[pos >> 5] |= (uint64_t)code << (62 - 2 * (pos & 31));
+    }
+    offsets.push_back(pos);
+}
+
+void PackedBatch::finish()
+{
+    if (offsets.empty()) offsets.assign(1, 0);
+    words.resize((offsets.back() + 31) / 32 + 1, 0);
+}
+
+static bool ends_with(const std::string &s, const char *suf)
+{
+    const size_t n = strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+static std::string lower(std::string s)
+{
+    for (char &c : s) c = (char)tolower((unsigned char)c);
+    return s;
+}
+
+uint64_t load_reads_file(const std::string &path, size_t max_reads, const std::function<void(PackedBatch &)> &sink)
+{
+    const size_t slash = path.find_last_of('/');
+    const std::string name = lower(slash == std::string::npos ? path : path.substr(slash + 1));
+    if (ends_with(name, ".gz") || ends_with(name, ".bz2") || ends_with(name, ".binq"))
+        throw Error("Can't read '" + name + "': compressed and BINQ inputs are not supported yet");
+    const bool fastq = ends_with(name, ".fastq") || ends_with(name, ".fq");
+    const bool fasta = ends_with(name, ".fasta") || ends_with(name, ".fa") || ends_with(name, ".fn") || ends_with(name, ".fna");
+    if (!fastq && !fasta) throw Error("Can't detect file format for file '" + name + "'");
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw Error("Failed to read from file " + path);
+
+    PackedBatch batch;
+    batch.clear();
+    uint64_t delivered = 0;
+    auto emit = [&](const char *s, size_t n) {
+        batch.add_read(s, n);
+        delivered++;
+        if (batch.n_reads() >= max_reads) {
+            batch.finish();
+            sink(batch);
+            batch.clear();
+        }
+    };
+    std::string line;
+    auto getline = [&](std::string &l) {
+        if (!std::getline(f, l)) return false;
+        if (!l.empty() && l.back() == '\r') l.pop_back();
+        return true;
+    };
+
+    if (fasta) {
+        std::string sb;
+        auto flush = [&] {
+            if (!sb.empty() && sb.find('N') == std::string::npos && sb.find('n') == std::string::npos)
+                emit(sb.data(), sb.size());
+            sb.clear();
+        };
+        while (getline(line)) {
+            if (!line.empty() && (line[0] == '>' || line[0] == ';')) {
+                if (!sb.empty()) flush();
+            } else {
+                sb += line;
+            }
+        }
+        flush();
+    } else {
+        // records: "@id" / data / "+id" / quality; empty lines between them are skipped
+        auto next_data = [&](std::string &out) -> bool {
+            std::string l;
+            for (;;) {
+                if (!getline(l)) return false;
+                if (!l.empty()) break;
+            }
+            if (l[0] != '@' && l[0] != '+') throw Error("Unknown structure of fastq file! Waiting \"@ID\" or \"+ID\" string");
+            if (!getline(out)) throw Error("Unexpected end of file. File is corrupted/Format mismatch.");
+            return true;
+        };
+        std::vector<std::pair<std::string, std::string>> head;  // the records the offset is sniffed on
+        int offset = -1;
+        auto process = [&](const std::string &d, const std::string &q) {
+            std::string piece;
+            for (size_t i = 0; i < d.size(); i++) {
+                int ph;
+                if (d[i] == 'N' || d[i] == 'n' || d[i] == '.') {
+                    ph = 0;
+                } else {
+                    const int qc = (unsigned char)q[i];
+                    if (qc < offset || qc > 126) throw Error("Invalid quality code char");
+                    ph = qc - offset;
+                }
+                if (ph < 1) {  // truncateByQuality(1): the piece ends here and the bad base is dropped
+                    if (!piece.empty()) emit(piece.data(), piece.size());
+                    piece.clear();
+                } else {
+                    piece.push_back(d[i]);
+                }
+            }
+            if (!piece.empty()) emit(piece.data(), piece.size());
+        };
+        auto sniff = [&] {
+            offset = 64;  // Illumina unless a char < 64 shows up in the first 1000 records
+            for (const auto &r : head)
+                for (size_t i = 0; i < r.first.size(); i++) {
+                    if (r.first[i] == 'N' || r.first[i] == 'n' || r.first[i] == '.') continue;
+                    const int qc = (unsigned char)r.second[i];
+                    if (qc < 64 || qc > 126) { offset = 33; return; }
+                }
+        };
+        std::string d, q;
+        while (next_data(d)) {
+            if (!next_data(q)) throw Error("Unexpected end of file. File is corrupted/Format mismatch.");
+            if (d.size() != q.size()) throw Error("Bad DnaQ record: length of chars and quality is not the same.");
+            if (offset < 0) {
+                head.emplace_back(d, q);
+                if (head.size() == 1000) {
+                    sniff();
+                    for (const auto &r : head) process(r.first, r.second);
+                    head.clear();
+                }
+            } else {
+                process(d, q);
+            }
+        }
+        if (offset < 0) {
+            sniff();
+            for (const auto &r : head) process(r.first, r.second);
+        }
+    }
+    if (batch.n_reads() > 0) {
+        batch.finish();
+        sink(batch);
+    }
+    return delivered;
+}
+
+// ------------------------------------------------------------------------------------------ Environment
+
+void Environment::add_pass(const BfsPass &p, bool trim)
+{
+    JavaHashMap d;  // distanceToKmer
+    for (size_t i = 0; i < p.kmers.size(); i++) d.put(p.kmers[i], p.dist[i]);
+    if (trim) {
+        // runTrimPaths: reverse BFS from lastKmers through getNeighborsByDir(-dir) inside distanceToKmer
+        std::vector<std::string> queue;
+        std::set<std::string> visited;
+        for (size_t i = 0; i < p.kmers.size(); i++)
+            if (p.last[i] && visited.insert(p.kmers[i]).second) queue.push_back(p.kmers[i]);
+        for (size_t head = 0; head < queue.size(); head++) {
+            const std::string kmer = queue[head];
+            for (const std::string &nb : neighbors_by_dir(-p.dir, kmer))
+                if (d.contains(nb) && visited.insert(nb).second) queue.push_back(nb);
+        }
+        for (const std::string &s : p.kmers)  // keySet().retainAll(visitedKmers): no reordering
+            if (!visited.count(s)) d.remove(s);
+    }
+    std::unordered_map<std::string, int> cov;
+    for (size_t i = 0; i < p.kmers.size(); i++) cov[p.kmers[i]] = p.cov[i];
+    d.for_each([&](const std::string &kmer, int) { subgraph_.put(normalize_dna(kmer), cov[kmer]); });
+    if (d.treeified()) d_treeified_ = true;
+}
+
+std::string Environment::graph_txt() const
+{
+    std::string out;
+    subgraph_.for_each([&](const std::string &k, int v) {
+        out += k;
+        out += ' ';
+        out += std::to_string(v);
+        out += '\n';
+    });
+    return out;
+}
+
+bool Environment::is_gene_node(const std::string &seq, const std::string &rc) const
+{
+    for (const std::string &g : genes_)
+        if (g.find(seq) != std::string::npos || g.find(rc) != std::string::npos) return true;
+    return false;
+}
+
+void Environment::merge_nodes(int first_plus, int second_minus)
+{
+    const int first_minus = nodes_[first_plus].rc, second_plus = nodes_[second_minus].rc;
+    auto merge_labels = [&](const std::string &a, const std::string &b) {
+        if (a.compare(a.size() - (size_t)(k_ - 1), (size_t)(k_ - 1), b, 0, (size_t)(k_ - 1)) != 0)
+            throw Error("Labels should be merged, but can not: " + a + " and " + b);
+        return a + b.substr((size_t)(k_ - 1));
+    };
+    const std::string new_seq = merge_labels(nodes_[second_plus].sequence, nodes_[first_plus].sequence);
+    const std::string new_seq_rc = merge_labels(nodes_[first_minus].sequence, nodes_[second_minus].sequence);
+    nodes_[second_plus].sequence = new_seq;
+    nodes_[first_minus].sequence = new_seq_rc;
+    nodes_[second_plus].rc = first_minus;
+    nodes_[first_minus].rc = second_plus;
+    nodes_[first_plus].deleted = true;
+    nodes_[second_minus].deleted = true;
+}
+
+void Environment::create_picture()
+{
+    // initializeStructures
+    nodes_.clear();
+    subgraph_.for_each([&](const std::string &seq, int) {
+        const std::string rc = reverse_complement(seq);
+        const bool g = is_gene_node(seq, rc);
+        const int id = (int)nodes_.size();
+        nodes_.push_back(Node{seq, id, g, false, id + 1, {}});
+        nodes_.push_back(Node{rc, id + 1, g, false, id, {}});
+    });
+    std::unordered_map<std::string, std::vector<int>> by_prefix;
+    for (const Node &n : nodes_) by_prefix[n.sequence.substr(0, (size_t)(k_ - 1))].push_back(n.id);
+    for (size_t i = 0; i < nodes_.size(); i++) {
+        auto it = by_prefix.find(nodes_[i].sequence.substr(1));
+        if (it != by_prefix.end()) {
+            auto &dst = nodes_[(size_t)nodes_[i].rc].neighbors;
+            dst.insert(dst.end(), it->second.begin(), it->second.end());
+        }
+    }
+    // doMerge
+    for (;;) {
+        bool acted = false;
+        for (size_t i = 0; i < nodes_.size(); i++) {
+            if (!nodes_[i].deleted && nodes_[i].neighbors.size() == 1) {
+                const int other = nodes_[i].neighbors[0];
+                if (nodes_[(size_t)other].neighbors.size() != 1 || nodes_[i].is_gene != nodes_[(size_t)other].is_gene)
+                    continue;
+                merge_nodes((int)i, other);
+                acted = true;
+            }
+        }
+        if (!acted) break;
+    }
+}
+
+std::string Environment::node_id(const Node &n) const
+{
+    return std::to_string(std::min(nodes_[(size_t)n.rc].id, n.id) + 1) + (n.is_gene ? "_start" : "");
+}
+
+std::string Environment::seqs_fasta(int chunk_length) const
+{
+    std::string out;
+    for (const Node &n : nodes_) {
+        const Node &rc = nodes_[(size_t)n.rc];
+        if (n.deleted || !(n.id < rc.id) || (int)n.sequence.size() < chunk_length) continue;
+        std::set<int> ids;
+        for (int j : n.neighbors) ids.insert(std::min(nodes_[(size_t)j].id, nodes_[(size_t)nodes_[(size_t)j].rc].id) + 1);
+        for (int j : rc.neighbors) ids.insert(std::min(nodes_[(size_t)j].id, nodes_[(size_t)nodes_[(size_t)j].rc].id) + 1);
+        ids.erase(std::min(n.id, rc.id) + 1);
+        out += "> Id" + node_id(n) + " Length:" + std::to_string(n.sequence.size()) + " Neighbors:[";
+        bool first = true;
+        for (int x : ids) {
+            if (!first) out += ", ";
+            out += std::to_string(x);
+            first = false;
+        }
+        out += "]\n" + n.sequence + "\n";
+    }
+    return out;
+}
+
+std::string Environment::graph_gfa() const
+{
+    std::string out;
+    for (const Node &n : nodes_) {
+        if (n.deleted || n.sequence.compare(nodes_[(size_t)n.rc].sequence) > 0) continue;
+        long long coverage = 0;
+        const std::string &s = n.sequence;
+        for (size_t i = 0; i + (size_t)k_ <= s.size(); i++) coverage += subgraph_.get(normalize_dna(s.substr(i, (size_t)k_)));
+        coverage += (long long)subgraph_.get(normalize_dna(s.substr(s.size() - (size_t)k_))) * (k_ - 1);
+        out += "S\t" + node_id(n) + "\t" + s + "\tLN:i:" + std::to_string(s.size()) + "\tKC:i:" + std::to_string(coverage) +
+               (n.is_gene ? "\tCL:Z:GREEN" : "") + "\n";
+    }
+    for (const Node &i : nodes_) {
+        if (i.deleted) continue;
+        for (int jx : i.neighbors) {
+            const Node &j = nodes_[(size_t)jx];
+            if (j.deleted) continue;
+            out += "L\t" + node_id(i) + "\t" + (i.sequence.compare(nodes_[(size_t)i.rc].sequence) >= 0 ? "+" : "-") + "\t" +
+                   node_id(j) + "\t" + (j.sequence.compare(nodes_[(size_t)j.rc].sequence) <= 0 ? "+" : "-") + "\t" +
+                   std::to_string(k_ - 1) + "M\n";
+        }
+    }
+    return out;
+}
+
+std::string Environment::tsv_nodes() const
+{
+    std::string out = "id\tlength\tseq\n";
+    for (size_t i = 0; i < nodes_.size(); i++) {
+        const Node &n = nodes_[i];
+        if (n.deleted || n.sequence.compare(nodes_[(size_t)n.rc].sequence) > 0) continue;
+        out += std::to_string(i + 1) + "\t" + std::to_string(n.sequence.size()) + "\t" + n.sequence + "\n";
+    }
+    return out;
+}
+
+std::string Environment::tsv_edges() const
+{
+    auto nid = [&](const Node &n) {
+        const Node &rc = nodes_[(size_t)n.rc];
+        return (n.sequence.compare(rc.sequence) <= 0 ? std::to_string(n.id + 1) : "-" + std::to_string(rc.id + 1)) +
+               (n.is_gene ? "_start" : "");
+    };
+    std::string out = "source\ttarget\n";
+    for (const Node &i : nodes_) {
+        if (i.deleted) continue;
+        for (int jx : i.neighbors) {
+            const Node &j = nodes_[(size_t)jx];
+            if (j.deleted) continue;
+            out += nid(nodes_[(size_t)i.rc]) + "\t" + nid(j) + "\tpp\n";
+        }
+    }
+    return out;
+}
+
+void Environment::write_all(const std::string &out_prefix, int chunk_length)
+{
+    const std::string g = graph_txt();
+    write_file(out_prefix + "/graph.txt", g);
+    write_file(out_prefix + "/env.txt", g);
+    create_picture();
+    write_file(out_prefix + "/seqs.fasta", seqs_fasta(chunk_length));
+    write_file(out_prefix + "/graph.gfa", graph_gfa());
+    write_file(out_prefix + "/tsvs/edges.tsv", tsv_edges());
+    write_file(out_prefix + "/tsvs/nodes.tsv", tsv_nodes());
+}
+
+}  // namespace mch

@@ -1,0 +1,126 @@
+// Host side of the environment-finder path above the C ABI: seed reading, read ingest (the
+// readers' N policy + 2-bit packing), runTrimPaths, the subgraph map, unitig compaction and the
+// writers.  It mirrors the reference's classes (names below) so that the output files are
+// byte-identical; the k-mer table and the BFS themselves live behind include/mcgpu.h.
+//
+// Citations: src/... = reference src/; itmo!/x = ru/ifmo/genetics/x in lib/itmo-assembler-src.jar.
+#pragma once
+#include <cstdint>
+#include <deque>
+#include <functional>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace mch {
+
+struct Error : std::runtime_error {  // plays ExecutionFailedException
+    using std::runtime_error::runtime_error;
+};
+
+// ---- DNA strings (itmo!/dna/DnaTools.java:31,46-64,131-145; src/utils/StringUtils.java:8-41)
+int code_of(char c);                       // A0 G1 C2 T3 (case-insensitive), -1 otherwise
+std::string reverse_complement(const std::string &s);
+std::string normalize_dna(const std::string &s);  // ASCII-lexicographic min of (s, rc(s))
+std::vector<std::string> neighbors_by_dir(int dir, const std::string &kmer);  // A,G,C,T order; dir 0 interleaves L,R
+void pack_kmer(const std::string &s, uint64_t *hi, uint64_t *lo);
+std::string unpack_kmer(uint64_t hi, uint64_t lo, int k);
+
+// ---- java.util.HashMap<String,Integer> iteration order (JDK 8)
+class JavaHashMap {
+public:
+    JavaHashMap();
+    void put(const std::string &key, int value);  // new keys go to the tail of their bin; existing keep their place
+    bool contains(const std::string &key) const { return index_.count(key) != 0; }
+    int get(const std::string &key) const;         // throws if absent
+    void remove(const std::string &key);
+    size_t size() const { return size_; }
+    bool treeified() const { return treeified_; }  // a bin would have been treeified: JDK order not guaranteed
+    template <typename F>
+    void for_each(F &&f) const
+    {
+        for (const auto &bin : bins_)
+            for (uint32_t e : bin) f(entries_[e].key, entries_[e].value);
+    }
+
+private:
+    struct Entry { std::string key; int value; uint32_t hash; };
+    void resize();
+    std::deque<Entry> entries_;
+    std::vector<std::vector<uint32_t>> bins_;
+    std::unordered_map<std::string, uint32_t> index_;
+    size_t cap_ = 16, size_ = 0;
+    bool treeified_ = false;
+};
+
+// ---- src/io/RichFastaReader.java:38-77 (+ DnaQ(String,0).toString(): N/n/. -> 'A', itmo!/dna/DnaQ.java:21-30)
+struct SeedFile {
+    std::vector<std::string> dnas, comments;
+};
+SeedFile read_seed_fasta(const std::string &path);  // throws Error when the file cannot be opened
+
+// ---- read ingest: itmo!/io/ReadersUtils.java:27-53,104-121 format by extension;
+// FASTA: records with N/n dropped whole (itmo!/io/readers/FastaReader.java:54-76);
+// FASTQ: split at phred < 1, offset sniffed on the first 1000 records
+// (itmo!/io/readers/FastqReader.java:53-112, FastaReaderFromXQSourceTrunc.java:61-95, ReadersUtils.java:57-77).
+struct PackedBatch {
+    std::vector<uint64_t> words;    // 2-bit packed, layout of include/mcgpu.h, with the pad word
+    std::vector<uint64_t> offsets;  // n_reads + 1
+    uint64_t n_reads() const { return offsets.empty() ? 0 : offsets.size() - 1; }
+    void clear();
+    void add_read(const char *s, size_t n);  // pure ACGT (any case); throws Error otherwise
+    void finish();                           // appends the pad word
+};
+// Calls sink(batch) for every max_reads reads; returns the number of reads (pieces) delivered.
+uint64_t load_reads_file(const std::string &path, size_t max_reads, const std::function<void(PackedBatch &)> &sink);
+
+// ---- one runBfs pass as delivered by mc_bfs_batch (or by a dump file in the CPU tests)
+struct BfsPass {
+    int dir = 0;
+    std::vector<std::string> kmers;  // distanceToKmer insertion order
+    std::vector<int32_t> dist;
+    std::vector<int16_t> cov;
+    std::vector<uint8_t> last;
+};
+
+// ---- src/algo/OneSequenceCalculator.java (after the BFS) + src/algo/SingleNode.java +
+// src/io/writers/GFAWriter.java + src/io/writers/TSVWriter.java
+class Environment {
+public:
+    Environment(int k, std::vector<std::string> gene_sequences) : k_(k), genes_(std::move(gene_sequences)) {}
+    // :217-219 (+ runTrimPaths :241-262 when trim): distanceToKmer -> subgraph
+    void add_pass(const BfsPass &p, bool trim);
+    size_t size() const { return subgraph_.size(); }
+    bool order_guaranteed() const { return !subgraph_.treeified() && !d_treeified_; }
+    std::string graph_txt() const;                    // printEnvironment :297-310
+    void create_picture();                            // initializeStructures + doMerge :387-451
+    std::string seqs_fasta(int chunk_length) const;   // outputNodeSequences :354-385
+    std::string graph_gfa() const;                    // GFAWriter.java:47-99
+    std::string tsv_nodes() const;                    // TSVWriter.java:35-49
+    std::string tsv_edges() const;                    // TSVWriter.java:51-79
+    // writes graph.txt (+ the identical env.txt README.md:98 names), seqs.fasta, graph.gfa, tsvs/*
+    void write_all(const std::string &out_prefix, int chunk_length);
+
+private:
+    struct Node {
+        std::string sequence;
+        int id;
+        bool is_gene, deleted = false;
+        int rc;                      // index of the reverse-complement node
+        std::vector<int> neighbors;  // successors of rc(this), in node-array order
+    };
+    bool is_gene_node(const std::string &seq, const std::string &rc) const;
+    void merge_nodes(int first_plus, int second_minus);
+    std::string node_id(const Node &n) const;
+    int k_;
+    std::vector<std::string> genes_;
+    JavaHashMap subgraph_;
+    bool d_treeified_ = false;
+    std::vector<Node> nodes_;
+};
+
+void write_file(const std::string &path, const std::string &text);  // mkdirs + write
+
+}  // namespace mch

@@ -1,0 +1,70 @@
+// mc_hosttest -- CPU-only driver of the host logic (no GPU, no libmcgpu): takes BFS passes from
+// a dump file instead of mc_bfs_batch and writes the environment files, so that tests/ can compare
+// the C++ host side with the Python restatement in oracle/host_oracle.py.
+//
+// dump format (text): k chunk_length trim n_genes / gene strings / n_passes / per pass: dir n /
+// n lines "kmer dist cov last".  Also: `mc_hosttest seeds <fasta>` and `mc_hosttest reads <file>`
+// print what the seed reader / read ingest deliver.
+#include <cstdio>
+#include <fstream>
+#include <functional>
+#include <iostream>
+
+#include "envfinder.h"
+
+using namespace mch;
+
+int main(int argc, char **argv)
+{
+    try {
+        if (argc == 3 && std::string(argv[1]) == "seeds") {
+            const SeedFile s = read_seed_fasta(argv[2]);
+            printf("%zu %zu\n", s.dnas.size(), s.comments.size());
+            for (const auto &d : s.dnas) printf("D %s\n", d.c_str());
+            for (const auto &c : s.comments) printf("C %s\n", c.c_str());
+            return 0;
+        }
+        if (argc == 3 && std::string(argv[1]) == "reads") {
+            const uint64_t n = load_reads_file(argv[2], 1000, [&](PackedBatch &b) {
+                for (uint64_t r = 0; r < b.n_reads(); r++) {
+                    std::string s;
+                    for (uint64_t p = b.offsets[r]; p < b.offsets[r + 1]; p++)
+                        s.push_back("AGCT"[(b.words[p >> 5] >> (62 - 2 * (p & 31))) & 3]);
+                    printf("%s\n", s.c_str());
+                }
+            });
+            fprintf(stderr, "%llu reads\n", (unsigned long long)n);
+            return 0;
+        }
+        if (argc != 4 || std::string(argv[1]) != "env") {
+            fprintf(stderr, "usage: mc_hosttest env <dump> <out_prefix> | seeds <fasta> | reads <file>\n");
+            return 2;
+        }
+        std::ifstream f(argv[2]);
+        if (!f) throw Error("cannot open dump");
+        int k, chunk, trim, n_genes;
+        f >> k >> chunk >> trim >> n_genes;
+        std::vector<std::string> genes((size_t)n_genes);
+        for (auto &g : genes) f >> g;
+        int n_passes;
+        f >> n_passes;
+        Environment env(k, genes);
+        for (int p = 0; p < n_passes; p++) {
+            BfsPass pass;
+            size_t n;
+            f >> pass.dir >> n;
+            pass.kmers.resize(n); pass.dist.resize(n); pass.cov.resize(n); pass.last.resize(n);
+            for (size_t i = 0; i < n; i++) {
+                int d, c, l;
+                f >> pass.kmers[i] >> d >> c >> l;
+                pass.dist[i] = d; pass.cov[i] = (int16_t)c; pass.last[i] = (uint8_t)l;
+            }
+            env.add_pass(pass, trim != 0);
+        }
+        env.write_all(argv[3], chunk);
+        return 0;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+}

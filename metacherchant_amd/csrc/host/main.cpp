@@ -1,0 +1,379 @@
+// metacherchant -- native launcher of the MI355X environment-finder path.  Mirrors the command line
+// of the reference (src/Runner.java + src/tools/EnvironmentFinderMain.java:32-105 + the launch
+// options of itmo!/utils/tool/Tool.java:59-143) and its output surface, and
+// drives libmcgpu.so through the C ABI of include/mcgpu.h exactly where the Java tool calls
+// IOUtils.loadReads / LargeKIOUtils.loadReads and OneSequenceCalculator.runBfs.
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "envfinder.h"
+#include "mcgpu.h"
+
+using namespace mch;
+
+namespace {
+
+FILE *g_log = nullptr, *g_log2 = nullptr;
+bool g_verbose = false;
+
+void logline(const char *level, const std::string &msg)
+{
+    char ts[32];
+    const time_t now = time(nullptr);
+    strftime(ts, sizeof ts, "%Y-%m-%d %H:%M:%S", localtime(&now));
+    const bool debug = strcmp(level, "DEBUG") == 0;
+    if (!debug || g_verbose) fprintf(stderr, "%s %s: %s\n", ts, level, msg.c_str());
+    for (FILE *f : {g_log, g_log2})
+        if (f) { fprintf(f, "%s %s: %s\n", ts, level, msg.c_str()); fflush(f); }
+}
+void info(const std::string &m) { logline("INFO", m); }
+
+std::string group_digits(unsigned long long v)  // itmo!/utils/NumUtils.java:163-174
+{
+    std::string vs = std::to_string(v), ans;
+    while (vs.size() > 3) {
+        ans = "'" + vs.substr(vs.size() - 3) + ans;
+        vs = vs.substr(0, vs.size() - 3);
+    }
+    return vs + ans;
+}
+
+std::string shorten_label(const std::string &label, int k)  // src/utils/StringUtils.java:43-49
+{
+    if ((int)label.size() >= 2 * k)
+        return label.substr(0, (size_t)k) + "..." + label.substr(label.size() - (size_t)k) + " (length=" +
+               std::to_string(label.size()) + ")";
+    return label;
+}
+
+struct Options {
+    int k = -1;
+    std::vector<std::string> reads;
+    std::string seq, hicseq, output, work_dir = "workDir", hash = "poly", tool = "environment-finder";
+    long long maxkmers = -1, maxradius = -1;
+    int coverage = 1, chunklength = 1, device = 0;
+    bool bothdirs = false, forcehash = false, trim = false, merge = false, cont = false, force = false, help = false;
+    unsigned long long capacity_hint = 0;
+};
+
+struct OptSpec { const char *name; const char *shortopt; int kind; };  // kind: 0 value, 1 bool (optional arg), 2 multi
+const OptSpec SPECS[] = {
+    {"k", "k", 0}, {"reads", "i", 2}, {"seq", nullptr, 0}, {"hicseq", nullptr, 0}, {"output", "o", 0},
+    {"maxkmers", nullptr, 0}, {"maxradius", nullptr, 0}, {"coverage", nullptr, 0}, {"bothdirs", nullptr, 1},
+    {"chunklength", nullptr, 0}, {"forcehash", nullptr, 1}, {"hash", nullptr, 0}, {"trim", nullptr, 1},
+    {"merge", nullptr, 1}, {"work-dir", "w", 0}, {"available-processors", "p", 0}, {"memory", "m", 0},
+    {"continue", "c", 1}, {"force", nullptr, 1}, {"verbose", "v", 1}, {"help", "h", 1}, {"tool", "t", 0},
+    {"device", nullptr, 0}, {"capacity-hint", nullptr, 0},
+};
+
+const OptSpec *find_spec(const std::string &tok)
+{
+    for (const OptSpec &s : SPECS) {
+        if (tok == std::string("--") + s.name) return &s;
+        if (s.shortopt && tok == std::string("-") + s.shortopt) return &s;
+    }
+    return nullptr;
+}
+
+bool java_bool(const std::string &s)  // new Boolean(String): true iff equalsIgnoreCase("true")
+{
+    return s.size() == 4 && tolower(s[0]) == 't' && tolower(s[1]) == 'r' && tolower(s[2]) == 'u' && tolower(s[3]) == 'e';
+}
+
+long long parse_int(const std::string &name, const std::string &v)
+{
+    char *end = nullptr;
+    errno = 0;
+    const long long x = strtoll(v.c_str(), &end, 10);
+    if (errno || end == v.c_str() || *end) throw Error("Can't convert value '" + v + "' of parameter '" + name + "' to type 'Integer'");
+    return x;
+}
+
+Options parse_args(int argc, char **argv)
+{
+    std::map<std::string, std::vector<std::string>> got;
+    for (int i = 1; i < argc; i++) {
+        std::string tok = argv[i], inline_val;
+        bool has_inline = false;
+        const size_t eq = tok.find('=');
+        if (tok.rfind("--", 0) == 0 && eq != std::string::npos) {  // --opt=value
+            inline_val = tok.substr(eq + 1);
+            tok = tok.substr(0, eq);
+            has_inline = true;
+        }
+        const OptSpec *s = find_spec(tok);
+        if (!s) throw Error("Cannot parse command line: Unrecognized option: " + tok);
+        auto &vals = got[s->name];
+        vals.clear();
+        if (has_inline) {
+            vals.push_back(inline_val);
+        } else if (s->kind == 2) {
+            while (i + 1 < argc && !find_spec(argv[i + 1]) && argv[i + 1][0] != '-') vals.push_back(argv[++i]);
+        } else if (s->kind == 1) {
+            if (i + 1 < argc && argv[i + 1][0] != '-') vals.push_back(argv[++i]);
+            else vals.push_back("true");  // option without an argument, itmo!/utils/tool/Tool.java:650-652
+        } else {
+            if (i + 1 >= argc) throw Error("Cannot parse command line: Missing argument for option: " + tok);
+            vals.push_back(argv[++i]);
+        }
+    }
+    Options o;
+    auto val = [&](const char *n) -> const std::string * { auto it = got.find(n); return it == got.end() || it->second.empty() ? nullptr : &it->second[0]; };
+    if (auto v = val("k")) o.k = (int)parse_int("k", *v);
+    if (got.count("reads"))
+        for (const std::string &v : got["reads"]) {  // arrays are re-tokenised on "[, ]" (Tool.java:888-895)
+            std::string cur;
+            for (char c : v + " ") {
+                if (c == '[' || c == ',' || c == ' ' || c == ']') { if (!cur.empty()) o.reads.push_back(cur); cur.clear(); }
+                else cur.push_back(c);
+            }
+        }
+    if (auto v = val("seq")) o.seq = *v;
+    if (auto v = val("hicseq")) o.hicseq = *v;
+    if (auto v = val("output")) o.output = *v;
+    if (auto v = val("maxkmers")) o.maxkmers = parse_int("maxkmers", *v);
+    if (auto v = val("maxradius")) o.maxradius = parse_int("maxradius", *v);
+    if (auto v = val("coverage")) o.coverage = (int)parse_int("coverage", *v);
+    if (auto v = val("chunklength")) o.chunklength = (int)parse_int("chunklength", *v);
+    if (auto v = val("bothdirs")) o.bothdirs = java_bool(*v);
+    if (auto v = val("forcehash")) o.forcehash = java_bool(*v);
+    if (auto v = val("trim")) o.trim = java_bool(*v);
+    if (auto v = val("merge")) o.merge = java_bool(*v);
+    if (auto v = val("continue")) o.cont = java_bool(*v);
+    if (auto v = val("force")) o.force = java_bool(*v);
+    if (auto v = val("verbose")) g_verbose = java_bool(*v);
+    if (auto v = val("help")) o.help = java_bool(*v);
+    if (auto v = val("hash")) o.hash = *v;
+    if (auto v = val("work-dir")) o.work_dir = *v;
+    if (auto v = val("tool")) o.tool = *v;
+    if (auto v = val("device")) o.device = (int)parse_int("device", *v);
+    if (auto v = val("capacity-hint")) o.capacity_hint = (unsigned long long)parse_int("capacity-hint", *v);
+    return o;
+}
+
+void usage()
+{
+    puts("MetaCherchant: genomic environment analysis tool (MI355X-native environment-finder path)\n");
+    puts("Usage:     metacherchant [<Launch options>] [<Input parameters>]\n");
+    puts("Input parameters of --tool environment-finder:");
+    puts("  -k, --k <arg>            k-mer size (MANDATORY)");
+    puts("  -i, --reads <args>       FASTQ, FASTA reads");
+    puts("      --seq <arg>          FASTA file with sequences (MANDATORY)");
+    puts("      --hicseq <arg>       FASTA file with Hi-C sequences");
+    puts("  -o, --output <arg>       output directory (MANDATORY)");
+    puts("      --maxkmers <arg>     maximum number of k-mers in created subgraph");
+    puts("      --maxradius <arg>    maximum distance in k-mers from starting gene");
+    puts("      --coverage <arg>     minimum depth of k-mers to consider (default 1)");
+    puts("      --bothdirs [<arg>]   run graph search in both directions from starting sequence (default false)");
+    puts("      --chunklength <arg>  minimum node length for BLAST search (default 1)");
+    puts("      --forcehash [<arg>]  force k-mer hashing (even for k <= 31) (default false)");
+    puts("      --hash <arg>         hash function to use: poly or fnv1a (default poly)");
+    puts("      --trim [<arg>]       trim all not maximal paths? (default false)");
+    puts("      --merge [<arg>]      draw single environment for multiple input sequences? (default false)");
+    puts("Launch options: -w/--work-dir <dir> (default workDir), -c/--continue, --force, -v/--verbose, -h/--help,");
+    puts("                -t/--tool <name>, -p/--available-processors <n> and -m/--memory <arg> (accepted, unused),");
+    puts("                --device <n> (GPU ordinal), --capacity-hint <distinct k-mers>");
+}
+
+#define MC_CHECK(ctx, call)                                                       \
+    do {                                                                          \
+        const int rc_ = (call);                                                   \
+        if (rc_ != MC_OK) throw Error(std::string(mc_last_error(ctx)));           \
+    } while (0)
+
+struct CtxGuard {
+    mc_ctx *c = nullptr;
+    ~CtxGuard() { mc_destroy(c); }
+};
+
+// buildEnvironment (src/algo/OneSequenceCalculator.java:137-144): the passes of one calculator
+std::vector<int> pass_dirs(bool bothdirs) { return bothdirs ? std::vector<int>{0} : std::vector<int>{-1, 1}; }
+
+int run(const Options &o)
+{
+    if (o.tool != "environment-finder")
+        throw Error("Tool '" + o.tool + "' is not part of this build: only --tool environment-finder runs on the GPU path");
+    if (o.k < 0) throw Error("Parameter 'k' is mandatory");
+    if (o.seq.empty()) throw Error("Parameter 'seq' is mandatory");
+    if (o.output.empty()) throw Error("Parameter 'output' is mandatory");
+    if (o.maxkmers < 0 && o.maxradius < 0)  // EnvironmentFinderMain.java:171-175
+        throw Error("At least one of --maxkmers and --maxradius parameters should be set");
+    if (o.coverage < 0) throw Error("--coverage must not be negative (absent k-mers read as -1 and would pass)");
+
+    // work dir: log files, in.properties / SUCCESS (itmo!/utils/tool/Tool.java:31-33,318-392,666-689)
+    const std::string wd = o.work_dir;
+    write_file(wd + "/logs/.keep", "");
+    char ts[32];
+    const time_t now = time(nullptr);
+    strftime(ts, sizeof ts, "%Y.%m.%d_%H.%M.%S", localtime(&now));
+    g_log = fopen((wd + "/log").c_str(), "w");
+    g_log2 = fopen((wd + "/logs/log_" + ts).c_str(), "w");
+    struct stat st;
+    if (stat((wd + "/in.properties").c_str(), &st) == 0 && !o.force && !o.cont)
+        logline("WARN", "Work directory " + wd + " holds a previous run; overwriting (the reference would prompt; pass --force to silence)");
+    if (o.cont && stat((wd + "/SUCCESS").c_str(), &st) == 0) {
+        info("Tool environment-finder already finished in " + wd + " (--continue), nothing to do");
+        return 0;
+    }
+    remove((wd + "/SUCCESS").c_str());
+    {
+        std::string p = "k=" + std::to_string(o.k) + "\nseq=" + o.seq + "\noutput=" + o.output + "\ncoverage=" +
+                        std::to_string(o.coverage) + "\nbothdirs=" + (o.bothdirs ? "true" : "false") + "\n";
+        write_file(wd + "/in.properties", p);
+    }
+
+    // loadInput (EnvironmentFinderMain.java:127-154)
+    const bool hashed = o.k > 31 || o.forcehash;
+    int mode = MC_KEY_PACKED;
+    if (hashed) {
+        info("Reading hashes of k-mers instead");
+        std::string h = o.hash;
+        for (char &c : h) c = (char)tolower((unsigned char)c);
+        if (h == "fnv1a") { info("Using FNV1a hash function"); mode = MC_KEY_FNV1A; }
+        else { info("Using default polynomial hash function"); mode = MC_KEY_POLY; }
+    }
+    mc_config cfg{};
+    cfg.k = o.k;
+    cfg.key_mode = mode;
+    cfg.device = o.device;
+    cfg.capacity_hint = o.capacity_hint;
+    CtxGuard G;
+    if (mc_create(&cfg, &G.c) != MC_OK) throw Error(std::string(mc_last_error(nullptr)));
+    mc_ctx *ctx = G.c;
+
+    const auto t0 = std::chrono::steady_clock::now();
+    for (const std::string &path : o.reads) {
+        const size_t slash = path.find_last_of('/');
+        info("Loading file " + (slash == std::string::npos ? path : path.substr(slash + 1)) + "...");
+        const uint64_t n = load_reads_file(path, 1u << 20, [&](PackedBatch &b) {
+            MC_CHECK(ctx, mc_add_reads_packed(ctx, b.words.data(), b.offsets.data(), b.n_reads()));
+        });
+        info(group_digits(n) + " reads added");
+    }
+    uint64_t n_distinct = 0;
+    MC_CHECK(ctx, mc_finalize_counts(ctx, &n_distinct));
+    info("Hashtable size: " + std::to_string(n_distinct) + " kmers");
+    logline("DEBUG", "k-mers HM size = " + group_digits(n_distinct));
+    const auto t1 = std::chrono::steady_clock::now();
+
+    SeedFile seeds;
+    try {
+        seeds = read_seed_fasta(o.seq);
+    } catch (const Error &) {
+        throw Error("Could not load sequences from " + o.seq);
+    }
+    SeedFile hic;
+    std::vector<std::string> comments = seeds.comments;
+    if (!o.hicseq.empty()) {
+        try {
+            hic = read_seed_fasta(o.hicseq);
+        } catch (const Error &) {
+            throw Error("Could not load Hi-C sequences from " + o.hicseq);
+        }
+        comments = hic.comments;  // the reference overwrites the comments (EnvironmentFinderMain.java:149)
+    }
+
+    // runImpl (:185-243): one calculator per sequence, or one for all with --merge
+    struct Calc { std::string out_prefix; std::vector<std::string> bfs_seqs, genes; };
+    std::vector<Calc> calcs;
+    if (!o.merge) {
+        for (size_t i = 0; i < seeds.dnas.size(); i++) {
+            if (i >= comments.size()) throw Error("sequence " + std::to_string(i) + " has no FASTA comment to name its output directory");
+            calcs.push_back(Calc{o.output + "/" + comments[i] + "/", {seeds.dnas[i]}, {seeds.dnas[i]}});
+        }
+    } else {
+        info("hicSequences = " + std::to_string(hic.dnas.size()));
+        Calc c{o.output + "/merged/", seeds.dnas, seeds.dnas};
+        c.bfs_seqs.insert(c.bfs_seqs.end(), hic.dnas.begin(), hic.dnas.end());
+        calcs.push_back(c);
+    }
+    const std::vector<int> dirs = pass_dirs(o.bothdirs);
+    // all passes of all calculators go to the GPU in one batch
+    std::vector<std::vector<uint64_t>> shi(calcs.size()), slo(calcs.size());
+    std::vector<mc_bfs_job> jobs;
+    for (size_t c = 0; c < calcs.size(); c++) {
+        if (!o.merge) info("Finding environment for sequence " + shorten_label(calcs[c].bfs_seqs[0], o.k));
+        else info("Finding single environment for " + std::to_string(seeds.dnas.size()) + " sequences");
+        for (const std::string &s : calcs[c].bfs_seqs)
+            for (size_t i = 0; i + (size_t)o.k <= s.size(); i++) {
+                uint64_t hi, lo;
+                pack_kmer(s.substr(i, (size_t)o.k), &hi, &lo);
+                shi[c].push_back(hi);
+                slo[c].push_back(lo);
+            }
+        for (int d : dirs) jobs.push_back(mc_bfs_job{shi[c].data(), slo[c].data(), shi[c].size(), d});
+    }
+    std::vector<mc_bfs_result> res(jobs.size());
+    if (!jobs.empty())
+        MC_CHECK(ctx, mc_bfs_batch(ctx, jobs.data(), (uint32_t)jobs.size(), o.coverage, o.maxkmers, o.maxradius, res.data()));
+    const auto t2 = std::chrono::steady_clock::now();
+
+    size_t j = 0;
+    for (size_t c = 0; c < calcs.size(); c++) {
+        Environment env(o.k, calcs[c].genes);
+        bool fail = false;
+        for (size_t d = 0; d < dirs.size(); d++, j++) {
+            mc_bfs_result &r = res[j];
+            if (r.n == 0) { fail = true; continue; }  // runBfs: queue.size() == 0 -> fail (:193-196)
+            if (fail) continue;
+            BfsPass p;
+            p.dir = dirs[d];
+            p.kmers.reserve(r.n);
+            for (uint64_t i = 0; i < r.n; i++) p.kmers.push_back(unpack_kmer(r.hi[i], r.lo[i], o.k));
+            p.dist.assign(r.dist, r.dist + r.n);
+            p.cov.assign(r.cov, r.cov + r.n);
+            p.last.assign(r.last, r.last + r.n);
+            env.add_pass(p, o.trim);
+        }
+        if (fail) {
+            info("Could not find any k-mers of the target gene in the input, halting.");
+            continue;
+        }
+        info("Extending endings by 0 kmers");  // extendEnvironment never adds anything
+        if (!env.order_guaranteed())
+            logline("WARN", "a java.util.HashMap bin would have been treeified: line order of " + calcs[c].out_prefix +
+                            " may differ from the JVM's inside that bin");
+        env.write_all(calcs[c].out_prefix, o.chunklength);
+    }
+    for (auto &r : res) mc_bfs_result_free(&r);
+    const auto t3 = std::chrono::steady_clock::now();
+    info("Finished processing all sequences!");
+
+    mc_stats stt{};
+    mc_get_stats(ctx, &stt);
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    char buf[512];
+    snprintf(buf, sizeof buf,
+             "{\"windows\": %llu, \"distinct_kmers\": %llu, \"load_and_count_ms\": %.3f, \"count_kernel_ms\": %.3f, "
+             "\"bfs_ms\": %.3f, \"output_ms\": %.3f, \"table_bytes\": %llu}\n",
+             (unsigned long long)stt.windows, (unsigned long long)n_distinct, ms(t0, t1), stt.count_total_ms, ms(t1, t2),
+             ms(t2, t3), (unsigned long long)stt.table_bytes);
+    write_file(wd + "/metrics.json", buf);
+    write_file(wd + "/SUCCESS", "");
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    try {
+        if (argc <= 1) { usage(); return 0; }
+        const Options o = parse_args(argc, argv);
+        if (o.help) { usage(); return 0; }
+        return run(o);
+    } catch (const std::exception &e) {
+        logline("ERROR", e.what());
+        return 1;  // System.exit(1) on ExecutionFailedException, itmo!/utils/tool/Tool.java:450-462
+    }
+}

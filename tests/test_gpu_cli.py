@@ -1,0 +1,152 @@
+"""End to end on the GPU: the native `metacherchant --tool environment-finder` CLI (C++ host + HIP
+library) against the oracle pipeline (oracle/ C counting + BFS, Python host restatement) on the
+same FASTA/FASTQ inputs: every output file byte-identical.  Needs a real MI355X: -m gpu."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import host_oracle as ho
+from oracle import pyoracle as po
+from tests.helpers import synth_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cli():
+    from metacherchant_amd import build
+    build.build_all()
+    assert os.path.exists(build.CLI)
+    return build.CLI
+
+
+def _write_fasta(path, reads, L, names=True, n_every=0):
+    with open(path, "w") as f:
+        for i in range(len(reads) // L):
+            s = po.decode(reads[i * L:(i + 1) * L])
+            if n_every and i % n_every == 3:
+                s = s[:40] + "N" + s[41:]  # FASTA records with N are dropped whole
+            f.write(">r%d\n%s\n%s\n" % (i, s[:70], s[70:]))  # multi-line records
+
+
+def _oracle_run(read_files, k, mode, seqs, comments, out_dir, **kw):
+    t = po.Table()
+    for p in read_files:
+        reads = ho.read_fastq_reads(p) if p.endswith((".fastq", ".fq")) else ho.read_fasta_reads(p)
+        codes = np.concatenate([po.encode(r) for r in reads])
+        off = np.zeros(len(reads) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(r) for r in reads])
+        t.count_reads(codes, off, k, mode)
+    return t, ho.environment_finder(t, k, mode, seqs, comments, out_dir, **kw)
+
+
+def _assert_same_tree(want_results, got_root, want_root):
+    for prefix, files in want_results.items():
+        rel = os.path.relpath(prefix, want_root)
+        gdir = os.path.join(got_root, rel)
+        if files is None:
+            assert not os.path.exists(os.path.join(gdir, "graph.txt"))
+            continue
+        for name, text in files.items():
+            with open(os.path.join(gdir, name)) as f:
+                assert f.read() == text, (rel, name)
+
+
+def test_cli_config1_both_passes_merge(cli, tmp_path):
+    """BASELINE.json configs[0]: 10k x 150 bp, k=31, coverage=5, maxkmers=100000, bothdirs=False."""
+    genome, reads, _ = synth_case(1, 50000, 10000, 150, 100)
+    r1, r2 = str(tmp_path / "reads_1.fasta"), str(tmp_path / "reads_2.fa")
+    _write_fasta(r1, reads[:6000 * 150], 150, n_every=50)
+    _write_fasta(r2, reads[6000 * 150:], 150)
+    seq = str(tmp_path / "seed.fasta")
+    with open(seq, "w") as f:
+        f.write(">seed\n%s\n" % po.decode(genome[10000:10500]))
+    out, want = str(tmp_path / "out"), str(tmp_path / "want")
+    cmd = [cli, "--tool", "environment-finder", "-k", "31", "--coverage", "5", "--reads", r1, r2, "--seq", seq,
+           "--output", out, "--work-dir", str(tmp_path / "wd"), "--maxkmers", "100000", "--bothdirs", "False",
+           "--chunklength", "10", "--merge", "true", "--force"]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    for line in ("Loading file reads_1.fasta...", "reads added", "Hashtable size: ", "Finding single environment for 1 sequences",
+                 "Extending endings by 0 kmers", "Finished processing all sequences!"):
+        assert line in p.stderr
+    seqs, comments = ho.rich_fasta_read(seq)
+    t, res = _oracle_run([r1, r2], 31, po.KEY_PACKED, seqs, comments, want, coverage=5, max_kmers=100000,
+                         bothdirs=False, chunk_length=10, merge=True)
+    assert "Hashtable size: %d kmers" % t.size() in p.stderr
+    _assert_same_tree(res, out, want)
+    assert os.path.exists(os.path.join(str(tmp_path / "wd"), "SUCCESS"))
+    assert len(res[os.path.join(want, "merged") + "/"]["graph.txt"].splitlines()) > 10000
+
+
+@pytest.mark.parametrize("extra,kw", [
+    (["--maxradius", "150", "--bothdirs", "--trim"], dict(max_radius=150, bothdirs=True, trim=True)),
+    (["--maxkmers=700", "--coverage=3", "--chunklength", "40"], dict(max_kmers=700, coverage=3, chunk_length=40)),
+    (["--maxkmers", "900", "--maxradius", "60", "--trim", "true", "--coverage", "2"],
+     dict(max_kmers=900, max_radius=60, trim=True, coverage=2)),
+])
+def test_cli_multi_sequence_dirs_and_flags(cli, tmp_path, extra, kw):
+    """One output directory per FASTA comment (no --merge), a sequence absent from the reads, FASTQ input."""
+    genome, reads, _ = synth_case(2, 20000, 6000, 150, 50)
+    fq = str(tmp_path / "reads.fastq")
+    with open(fq, "w") as f:
+        for i in range(6000):
+            s = po.decode(reads[i * 150:(i + 1) * 150])
+            q = ["I"] * 150
+            if i % 7 == 0:
+                q[60] = "!"  # phred 0: the read is split here and the base dropped
+            if i % 11 == 0:
+                s = s[:100] + "N" + s[101:]
+            f.write("@r%d\n%s\n+\n%s\n" % (i, s, "".join(q)))
+    seq = str(tmp_path / "genes.fasta")
+    rng = np.random.default_rng(4)
+    with open(seq, "w") as f:
+        f.write(">geneA\n%s\n>geneB some text\n%s\n>absent\n%s\n" % (
+            po.decode(genome[3000:3300]), po.decode(genome[25000:25200]), po.decode(rng.integers(0, 4, 120).astype(np.uint8))))
+    out, want = str(tmp_path / "out"), str(tmp_path / "want")
+    cmd = [cli, "-k", "25", "-i", fq, "--seq", seq, "-o", out, "-w", str(tmp_path / "wd"), "--force"] + extra
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert "Could not find any k-mers of the target gene in the input, halting." in p.stderr
+    seqs, comments = ho.rich_fasta_read(seq)
+    _, res = _oracle_run([fq], 25, po.KEY_PACKED, seqs, comments, want, **kw)
+    assert res[os.path.join(want, "absent") + "/"] is None
+    _assert_same_tree(res, out, want)
+
+
+@pytest.mark.parametrize("k,hash_name,mode", [(41, "poly", po.KEY_POLY), (63, "fnv1a", po.KEY_FNV1A), (21, "poly", po.KEY_POLY)])
+def test_cli_hash_key_modes(cli, tmp_path, k, hash_name, mode):
+    """k > 31 (or --forcehash): the table key is the reference's 64-bit hash (src/utils/*Hash.java)."""
+    genome, reads, _ = synth_case(1, 30000, 5000, 150, 30)
+    r1 = str(tmp_path / "reads.fna")
+    _write_fasta(r1, reads, 150)
+    seq = str(tmp_path / "seed.fasta")
+    with open(seq, "w") as f:
+        f.write(">s\n%s\n" % po.decode(genome[15000:15300]))
+    out, want = str(tmp_path / "out"), str(tmp_path / "want")
+    cmd = [cli, "-k", str(k), "-i", r1, "--seq", seq, "-o", out, "-w", str(tmp_path / "wd"), "--force", "--maxkmers", "3000",
+           "--coverage", "3", "--bothdirs", "True", "--hash", hash_name] + (["--forcehash"] if k <= 31 else [])
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert "Reading hashes of k-mers instead" in p.stderr
+    seqs, comments = ho.rich_fasta_read(seq)
+    _, res = _oracle_run([r1], k, mode, seqs, comments, want, coverage=3, max_kmers=3000, bothdirs=True)
+    _assert_same_tree(res, out, want)
+
+
+def test_cli_error_paths(cli, tmp_path):
+    """tests/EnvironmentFinderMainTest.java:47-94 pins the two messages."""
+    r1 = str(tmp_path / "reads.fasta")
+    open(r1, "w").write(">r\nACGTACGTACGTACGTACGTACGTACGTACGTACGT\n")
+    seq = str(tmp_path / "seed.fasta")
+    open(seq, "w").write(">s\nACGTACGTACGTACGTACGTACGTACGTACGTACGT\n")
+    base = [cli, "-k", "21", "-i", r1, "-o", str(tmp_path / "o"), "-w", str(tmp_path / "wd"), "--force"]
+    p = subprocess.run(base + ["--seq", str(tmp_path / "nope.fasta"), "--maxkmers", "10"], capture_output=True, text=True)
+    assert p.returncode == 1 and "Could not load sequences from " + str(tmp_path / "nope.fasta") in p.stderr
+    p = subprocess.run(base + ["--seq", seq, "--hicseq", str(tmp_path / "nohic.fasta"), "--maxkmers", "10"],
+                       capture_output=True, text=True)
+    assert p.returncode == 1 and "Could not load Hi-C sequences from " + str(tmp_path / "nohic.fasta") in p.stderr
+    p = subprocess.run(base + ["--seq", seq], capture_output=True, text=True)
+    assert p.returncode == 1 and "At least one of --maxkmers and --maxradius parameters should be set" in p.stderr

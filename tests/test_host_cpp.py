@@ -1,0 +1,137 @@
+"""The C++ host side (metacherchant_amd/csrc/host: seed reader, read ingest, trim, subgraph map,
+compaction, writers) against the Python restatement in oracle/host_oracle.py, byte for byte.
+CPU only: the BFS passes come from the oracle through a dump file (mc_hosttest)."""
+import lzma
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import host_oracle as ho
+from oracle import pyoracle as po
+
+
+@pytest.fixture(scope="module")
+def hosttest():
+    from metacherchant_amd import build
+    build.build_host()
+    assert os.path.exists(build.HOSTTEST)
+    return build.HOSTTEST
+
+
+def _dump(path, k, chunk, trim, genes, passes):
+    with open(path, "w") as f:
+        f.write("%d %d %d %d\n" % (k, chunk, 1 if trim else 0, len(genes)))
+        for g in genes:
+            f.write(g + "\n")
+        f.write("%d\n" % len(passes))
+        for d, r in passes:
+            f.write("%d %d\n" % (d, len(r["lo"])))
+            for h, l, dist, cov, last in zip(r["hi"], r["lo"], r["dist"], r["cov"], r["last"]):
+                f.write("%s %d %d %d\n" % (po.kmer_string(h, l, k), dist, cov, last))
+
+
+def _oracle_files(k, genes, passes, trim, chunk):
+    env = ho.Environment(k, genes, False)
+    for _, r in passes:
+        kmers = [po.kmer_string(h, l, k) for h, l in zip(r["hi"], r["lo"])]
+        env.add_pass(kmers, r["dist"], r["cov"], r["kept"] if trim else None)
+    files = env.files(chunk)
+    files["env.txt"] = files["graph.txt"]
+    return files
+
+
+def _compare(hosttest, tmp_path, k, genes, passes, trim, chunk):
+    dump = str(tmp_path / "dump.txt")
+    out = str(tmp_path / "out")
+    _dump(dump, k, chunk, trim, genes, passes)
+    subprocess.check_call([hosttest, "env", dump, out])
+    want = _oracle_files(k, genes, passes, trim, chunk)
+    for name, text in want.items():
+        with open(os.path.join(out, name)) as f:
+            assert f.read() == text, name
+    return want
+
+
+def test_fixture_example_all_files(hosttest, golden_dir, tmp_path):
+    """The shipped example (Hi-C_pipline/HiCEnvironmentFinder.sh:57): 93 572 k-mers, 2 passes, merge."""
+    g = os.path.join(golden_dir, "ref_example")
+    fix = [l.split(" ") for l in lzma.open(os.path.join(g, "graph.txt.xz"), "rt").read().splitlines()]
+    t = po.Table()
+    for s, c in fix:
+        t.add(po.key(po.encode(s), 31, po.KEY_PACKED), int(c))
+    seqs, _ = ho.rich_fasta_read(os.path.join(g, "seq.fasta"))
+    passes = [(d, po.bfs(t, 31, po.KEY_PACKED, [po.encode(s) for s in seqs], d, 5, -1, 100000)) for d in (-1, 1)]
+    want = _compare(hosttest, tmp_path, 31, seqs, passes, False, 10)
+    assert len(want["graph.txt"].splitlines()) == 93572
+
+
+@pytest.mark.parametrize("trim", [False, True])
+@pytest.mark.parametrize("bothdirs", [False, True])
+def test_branching_graph_trim_and_bothdirs(hosttest, tmp_path, trim, bothdirs):
+    rng = np.random.default_rng(17)
+    unit = rng.integers(0, 4, 300).astype(np.uint8)
+    parts = []
+    for _ in range(25):
+        u = unit.copy()
+        pos = rng.integers(0, 300, 5)
+        u[pos] = rng.integers(0, 4, 5)
+        parts.append(u)
+    genome = np.concatenate(parts)
+    L, n, k = 90, 2500, 21
+    starts = rng.integers(0, len(genome) - L, n)
+    reads = np.concatenate([genome[s:s + L] for s in starts])
+    off = np.arange(n + 1, dtype=np.uint64) * L
+    t = po.Table()
+    t.count_reads(reads, off, k, po.KEY_PACKED)
+    gene = po.decode(genome[650:760])
+    passes = []
+    for d in ([0] if bothdirs else [-1, 1]):
+        r = po.bfs(t, k, po.KEY_PACKED, [genome[650:760]], d, 2, 600, 80, trim)
+        assert r is not None
+        passes.append((d, r))
+    _compare(hosttest, tmp_path, k, [gene], passes, trim, 25)
+
+
+def test_seed_reader(hosttest, golden_dir, tmp_path):
+    def run(path):
+        out = subprocess.check_output([hosttest, "seeds", path]).decode().splitlines()
+        nd, nc = map(int, out[0].split())
+        return [l[2:] for l in out[1:1 + nd]], [l[2:] for l in out[1 + nd:1 + nd + nc]]
+
+    g = os.path.join(golden_dir, "ref_example")
+    for name in ("seq.fasta", "selected_reads.fasta"):
+        d, c = run(os.path.join(g, name))
+        wd, wc = ho.rich_fasta_read(os.path.join(g, name))
+        assert d == wd and c == wc
+    assert len(run(os.path.join(g, "selected_reads.fasta"))[0]) == 1047
+    p = tmp_path / "s.fasta"
+    p.write_text(">a b c\nACGTN\nnacg\n;second\n>more\nTTTT\r\nGG\n>only comment\n")
+    d, c = run(str(p))
+    wd, wc = ho.rich_fasta_read(str(p))
+    assert d == wd == ["ACGTAAACG", "TTTTGG"] and c == wc == ["a b c", "secondmore", "only comment"]
+    assert subprocess.call([hosttest, "seeds", str(tmp_path / "missing.fasta")], stderr=subprocess.DEVNULL) == 1
+
+
+def test_read_ingest_policies(hosttest, tmp_path):
+    def run(path):
+        return subprocess.check_output([hosttest, "reads", path], stderr=subprocess.DEVNULL).decode().splitlines()
+
+    fa = tmp_path / "r.fasta"
+    fa.write_text(">r1\nACGTACGT\nACGT\n>r2 has N\nACGNACGT\n>r3\nacgtTTGA\n;comment\n>r4\n\nGGGG\n>r5 n\nACGTn\n")
+    assert run(str(fa)) == ho.read_fasta_reads(str(fa)) == ["ACGTACGTACGT", "ACGTTTGA", "GGGG"]
+    fq = tmp_path / "r.fastq"
+    # Sanger offset (a char < 64 in the first record); '!' = phred 0 splits, N splits
+    fq.write_text("@a\nACGTACGTAC\n+\nIIII!IIII5\n@b\nACGNNACG\n+b\nIIIIIIII\n\n@c\nTTTT\n+\n!!!!\n@d\nGATTACA\n+\nIIIIII!\n")
+    assert run(str(fq)) == ho.read_fastq_reads(str(fq)) == ["ACGT", "CGTAC", "ACG", "ACG", "GATTAC"]
+    fq2 = tmp_path / "i.fq"
+    # all qualities >= '@' in the first 1000 records: read as Illumina+64, '@' = phred 0
+    fq2.write_text("@a\nACGTAC\n+\nhhh@hh\n")
+    assert run(str(fq2)) == ho.read_fastq_reads(str(fq2)) == ["ACG", "AC"]
+    bad = tmp_path / "r.txt"
+    bad.write_text(">x\nACGT\n")
+    assert subprocess.call([hosttest, "reads", str(bad)], stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL) == 1
+    iupac = tmp_path / "y.fa"
+    iupac.write_text(">x\nACGRT\n")
+    assert subprocess.call([hosttest, "reads", str(iupac)], stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL) == 1
