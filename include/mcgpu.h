@@ -175,12 +175,14 @@ int mc_add_keys_dev(mc_ctx *ctx, const int64_t *d_keys, uint64_t n);
 /* ---- measurement */
 typedef struct {
     uint64_t windows;        /* k-mer occurrences counted so far */
-    uint64_t count_launches; /* launches of the dominant counting kernel */
+    uint64_t count_launches; /* counting passes: launches of the direct kernel, or runs of the partitioned pipeline */
     double count_ms;         /* their summed device time (HIP events on the context's stream) */
     double count_total_ms;   /* device time of all counting-phase kernels */
     uint64_t table_slots;    /* current table capacity (slots) */
     uint64_t table_bytes;
     uint64_t grows;          /* number of table rebuilds */
+    double p1_ms, p2_ms, p3_ms; /* partitioned pipeline: extract+scatter / scatter / merge kernels */
+    uint64_t spill_keys;     /* keys that did not fit their bucket and took the direct kernel */
 } mc_stats;
 int mc_get_stats(mc_ctx *ctx, mc_stats *out);
 int mc_reset_stats(mc_ctx *ctx);

@@ -1,0 +1,364 @@
+// K2/K3, partitioned form: counting without one memory-side atomic per k-mer occurrence.
+//
+// The direct kernel (k_count_reads, mcgpu.hip) does what the reference does per occurrence
+// (src/io/IOUtils.java:207-208: hm.addAndBound(key, 1)): a probe plus an atomic on a random 16-byte
+// slot.  MI355X retires only ~2*10^10 scattered atomics per second chip-wide, far below what HBM
+// can stream, so large batches take this route instead:
+//
+//   P1  extract + scatter   reads -> keys (+ the read-context hint of the occurrence), grouped by the
+//                           top b1 bits of fmix64(key); tiles of 8192 windows staged in LDS and
+//                           written out as one contiguous run per bucket;
+//   P2  scatter             every level-1 bucket again by the next b2 bits: b1 + b2 = log2(#regions)
+//                           of the table, so a leaf bucket holds exactly the keys of one table region;
+//   P3  merge               one workgroup per region: the region (4096 slots, 64 KB) lives in LDS, the
+//                           leaf's keys are streamed in and counted with LDS atomics, the region goes
+//                           back to HBM with plain coalesced stores.
+//
+// Every byte moved is a coalesced stream; the only global atomics left are one per (tile, bucket).
+// Results are identical to the direct kernel: same slot placement rule (home slot from the hash,
+// linear probing inside the region), saturation as in kmer_device.h.
+#pragma once
+#include "kmer_device.h"
+
+namespace mc {
+
+constexpr int PT_THREADS = 1024;                    // workgroup of the scatter kernels
+constexpr int PT_ITEMS = 8;
+constexpr int PT_TILE = PT_THREADS * PT_ITEMS;      // 8192 windows / keys per tile
+constexpr int PT_MAX_BUCKETS = 512;                 // fan-out of one scatter level
+constexpr int P3_THREADS = 512;
+constexpr uint32_t REGION_SLOTS = 4096;             // == 1 << mc_ctx::sb
+
+struct ScatterLds {
+    uint64_t key[PT_TILE];
+    uint32_t hint[PT_TILE];
+    uint16_t dig[PT_TILE];
+    uint32_t cnt[PT_MAX_BUCKETS], off[PT_MAX_BUCKETS], gbase[PT_MAX_BUCKETS];
+    uint32_t starts[(PT_TILE + 256) / 32 + 2];  // P1: bit per base position = "a read starts here"
+    uint32_t wave_tot[PT_THREADS / 64];
+    uint32_t n_valid;
+};
+
+struct SpillView {
+    uint64_t *keys;
+    uint32_t *hints;
+    unsigned long long *count;
+    uint64_t cap;
+    uint32_t *lost;  // set when the spill list itself is full
+};
+
+__device__ __forceinline__ void spill_push(const SpillView &sp, uint64_t key, uint32_t hint)
+{
+    const unsigned long long i = atomicAdd(sp.count, 1ull);
+    if (i < sp.cap) {
+        sp.keys[i] = key;
+        sp.hints[i] = hint;
+    } else {
+        atomicExch(sp.lost, 1u);
+    }
+}
+
+// Shared tail of P1/P2: the tile's items are in registers; group them by digit in LDS and write one
+// contiguous run per bucket.  cursors[d] counts what bucket d holds so far; bucket d's storage is
+// out_*[d * cap .. (d+1) * cap); what does not fit goes to the spill list (drained by the direct kernel).
+__device__ __forceinline__ void scatter_tile(ScatterLds &L, const uint64_t (&key)[PT_ITEMS], const uint32_t (&hint)[PT_ITEMS],
+                                             const uint32_t (&dig)[PT_ITEMS], const bool (&valid)[PT_ITEMS],
+                                             uint32_t n_buckets, uint32_t *cursors, uint64_t cap, uint64_t *out_keys,
+                                             uint32_t *out_hints, uint64_t out_base, const SpillView &sp)
+{
+    const uint32_t tid = threadIdx.x;
+    uint32_t rank[PT_ITEMS];
+#pragma unroll
+    for (int j = 0; j < PT_ITEMS; j++) rank[j] = valid[j] ? atomicAdd(&L.cnt[dig[j]], 1u) : 0u;
+    __syncthreads();
+    // exclusive scan of cnt[0..n_buckets) (n_buckets <= 512 <= blockDim)
+    {
+        const uint32_t lane = tid & 63, wv = tid >> 6;
+        const uint32_t c = tid < n_buckets ? L.cnt[tid] : 0u;
+        uint32_t x = c;  // inclusive scan inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o);
+            if ((int)lane >= o) x += y;
+        }
+        if (lane == 63) L.wave_tot[wv] = x;
+        __syncthreads();
+        uint32_t before = 0;
+        for (uint32_t i = 0; i < wv; i++) before += L.wave_tot[i];
+        if (tid < n_buckets) {
+            L.off[tid] = before + x - c;
+            L.gbase[tid] = c ? atomicAdd(&cursors[tid], c) : 0u;  // one global atomic per (tile, bucket)
+        }
+        if (tid == PT_THREADS - 1) L.n_valid = before + x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PT_ITEMS; j++)
+        if (valid[j]) {
+            const uint32_t pos = L.off[dig[j]] + rank[j];
+            L.key[pos] = key[j];
+            L.hint[pos] = hint[j];
+            L.dig[pos] = (uint16_t)dig[j];
+        }
+    __syncthreads();
+    const uint32_t n = L.n_valid;
+    for (uint32_t i = tid; i < n; i += PT_THREADS) {
+        const uint32_t d = L.dig[i];
+        const uint64_t dst = (uint64_t)L.gbase[d] + (i - L.off[d]);
+        if (dst < cap) {
+            const uint64_t at = out_base + (uint64_t)d * cap + dst;
+            out_keys[at] = L.key[i];
+            out_hints[at] = L.hint[i];
+        } else {
+            spill_push(sp, L.key[i], L.hint[i]);
+        }
+    }
+    __syncthreads();
+}
+
+// first read that can matter for the tile starting at base `lo`: largest r with offsets[r] <= lo
+// (one thread per tile; the scatter kernel then walks forward from there)
+__global__ void k_tile_first_read(const uint64_t *__restrict__ offsets, uint64_t n_reads, uint64_t n_tiles,
+                                  uint32_t *__restrict__ first_read)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    const uint64_t lo = t * (uint64_t)PT_TILE;
+    const uint64_t back = lo >= 64 ? lo - 64 : 0;  // hints look a few bases to the left of the tile
+    uint64_t a = 0, b = n_reads;                    // invariant: offsets[a] <= back
+    while (b - a > 1) {
+        const uint64_t m = (a + b) >> 1;
+        if (offsets[m] <= back) a = m; else b = m;
+    }
+    first_read[t] = (uint32_t)a;
+}
+
+__device__ __forceinline__ uint64_t starts_window(const uint32_t *bits, uint32_t pos)
+{  // 64 bits of the bitmap starting at bit `pos`
+    const uint32_t w = pos >> 5, s = pos & 31;
+    const uint64_t lo = ((uint64_t)bits[w + 1] << 32) | bits[w];
+    const uint64_t hi = bits[w + 2];
+    return s ? ((lo >> s) | (hi << (64 - s))) : lo;
+}
+
+// P1: tiles of PT_TILE consecutive base positions of the packed read set.
+template <int MODE>
+__global__ void __launch_bounds__(PT_THREADS) k_p1_extract_scatter(
+    const uint64_t *__restrict__ words, const uint64_t *__restrict__ offsets, uint64_t n_reads, uint64_t base_lo,
+    uint64_t n_bases, uint64_t n_tiles, const uint32_t *__restrict__ first_read, int k, uint32_t b1, uint32_t *cursors, uint64_t cap,
+    uint64_t *out_keys, uint32_t *out_hints, unsigned long long *empty_cnt, SpillView sp)
+{
+    __shared__ ScatterLds L;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n_buckets = 1u << b1;
+    constexpr uint32_t MARGIN = 64;  // bitmap starts this many bases left of the tile
+    for (uint64_t tile = base_lo / PT_TILE + blockIdx.x; tile < n_tiles; tile += gridDim.x) {  // reads cover [base_lo, n_bases)
+        const uint64_t lo = tile * (uint64_t)PT_TILE;
+        const uint64_t bm_lo = lo >= MARGIN ? lo - MARGIN : 0;        // first position the bitmap covers
+        const uint64_t bm_hi = lo + PT_TILE + 128;                     // one past the last
+        for (uint32_t i = tid; i < sizeof(L.starts) / 4; i += PT_THREADS) L.starts[i] = 0;
+        if (tid < n_buckets) L.cnt[tid] = 0;
+        __syncthreads();
+        for (uint64_t r = (uint64_t)first_read[tile] + tid; r < n_reads; r += PT_THREADS) {
+            const uint64_t s = offsets[r];
+            if (s >= bm_hi) break;
+            if (s >= bm_lo) atomicOr(&L.starts[(uint32_t)(s - bm_lo) >> 5], 1u << ((uint32_t)(s - bm_lo) & 31));
+        }
+        __syncthreads();
+        uint64_t key[PT_ITEMS];
+        uint32_t hint[PT_ITEMS], dig[PT_ITEMS];
+        bool valid[PT_ITEMS];
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS; j++) {
+            const uint64_t p = lo + tid + (uint64_t)j * PT_THREADS;
+            key[j] = 0; hint[j] = 0; dig[j] = 0;
+            valid[j] = false;
+            if (p >= base_lo && p + (uint64_t)k <= n_bases) {
+                const uint32_t rel = (uint32_t)(p - bm_lo);
+                // the window [p, p+k) lies inside one read iff no read starts at p+1 .. p+k-1
+                const uint64_t inside = starts_window(L.starts, rel + 1);
+                const uint64_t m = k >= 2 ? (~0ull >> (64 - (k - 1))) : 0ull;
+                if ((inside & m) == 0) {
+                    const Kmer v = extract_kmer(words, p, k);
+                    bool flipped;
+                    key[j] = (uint64_t)key_of<MODE>(v, k, &flipped);
+                    // context: HINT_LEN bases to the right inside the read <=> no start in p+1 .. p+k+HINT_LEN-1 and in range;
+                    //          HINT_LEN bases to the left  <=> no start in p-HINT_LEN+1 .. p and p >= HINT_LEN
+                    const bool rv = p + (uint64_t)k + HINT_LEN <= n_bases &&
+                                    (starts_window(L.starts, rel + 1 + (uint32_t)(k - 1)) & ((1ull << HINT_LEN) - 1)) == 0;
+                    const bool lv = p >= (uint64_t)HINT_LEN && rel >= (uint32_t)HINT_LEN &&
+                                    (starts_window(L.starts, rel - HINT_LEN + 1) & ((1ull << HINT_LEN) - 1)) == 0;
+                    hint[j] = hint_of(words, p, k, lv ? 0 : p, rv ? n_bases : 0, flipped);
+                    if (key[j] == EMPTY_KEY) {
+                        atomicAdd(empty_cnt, 1ull);
+                    } else {
+                        valid[j] = true;
+                        dig[j] = (uint32_t)(fmix64(key[j]) >> (64 - b1));
+                    }
+                }
+            }
+        }
+        scatter_tile(L, key, hint, dig, valid, n_buckets, cursors, cap, out_keys, out_hints, 0, sp);
+    }
+}
+
+// P2: tiles of PT_TILE consecutive entries of one level-1 bucket; tile_map[t] = (bucket << 32 | first entry)
+__global__ void __launch_bounds__(PT_THREADS) k_p2_scatter(const uint64_t *__restrict__ in_keys,
+                                                           const uint32_t *__restrict__ in_hints, uint64_t cap1,
+                                                           const uint32_t *__restrict__ counts1,
+                                                           const uint64_t *__restrict__ tile_map, uint64_t n_tiles, uint32_t b1,
+                                                           uint32_t b2, uint32_t *cursors2, uint64_t cap2, uint64_t *out_keys,
+                                                           uint32_t *out_hints, SpillView sp)
+{
+    __shared__ ScatterLds L;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n_buckets = 1u << b2;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t tm = tile_map[tile];
+        const uint32_t bucket = (uint32_t)(tm >> 32), first = (uint32_t)tm;
+        const uint32_t have = min(counts1[bucket], (uint32_t)cap1);
+        if (tid < n_buckets) L.cnt[tid] = 0;
+        __syncthreads();
+        uint64_t key[PT_ITEMS];
+        uint32_t hint[PT_ITEMS], dig[PT_ITEMS];
+        bool valid[PT_ITEMS];
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS; j++) {
+            const uint32_t i = first + tid + (uint32_t)j * PT_THREADS;
+            valid[j] = i < have;
+            key[j] = 0; hint[j] = 0; dig[j] = 0;
+            if (valid[j]) {
+                const uint64_t at = (uint64_t)bucket * cap1 + i;
+                key[j] = in_keys[at];
+                hint[j] = in_hints[at];
+                dig[j] = (uint32_t)(fmix64(key[j]) >> (64 - b1 - b2)) & (n_buckets - 1);
+            }
+        }
+        scatter_tile(L, key, hint, dig, valid, n_buckets, cursors2 + (uint64_t)bucket * n_buckets, cap2, out_keys, out_hints,
+                     (uint64_t)bucket * n_buckets * cap2, sp);
+    }
+}
+
+// P3: one workgroup per leaf; a leaf covers 2^g consecutive table regions (g = 0 unless the table
+// has more regions than leaves).  `virgin`: the table holds nothing yet and is not read.
+// leaf_state[leaf]: 0 = to do, 1 = merged.  A leaf with a region that would overflow is left
+// untouched and stays at 0 for the retry after the host enlarged the table.
+struct MergeLds {
+    uint64_t key[REGION_SLOTS];
+    uint32_t cnt[REGION_SLOTS];
+    uint32_t aux[REGION_SLOTS];
+    uint32_t n_new, overflow;
+};
+
+__global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const uint64_t *__restrict__ leaf_keys,
+                                                         const uint32_t *__restrict__ leaf_hints,
+                                                         const uint32_t *__restrict__ leaf_counts, uint64_t cap2,
+                                                         uint32_t n_leaves, uint32_t g, TableView t, int virgin,
+                                                         uint32_t *leaf_state, uint32_t *leaf_new, uint32_t *any_failed)
+{
+    __shared__ MergeLds L;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t leaf = blockIdx.x; leaf < n_leaves; leaf += gridDim.x) {
+        if (leaf_state[leaf]) continue;  // uniform
+        const uint32_t n = min(leaf_counts[leaf], (uint32_t)cap2);
+        const uint64_t *keys = leaf_keys + (uint64_t)leaf * cap2;
+        const uint32_t *hints = leaf_hints + (uint64_t)leaf * cap2;
+        // g == 0: the leaf is one region: merge and commit unless it overflows.  g > 0 (after the host
+        // enlarged the table): a first sweep only checks that every sub-region fits, a second one commits,
+        // so a leaf is never merged partially.
+        bool leaf_ok = true;
+        uint32_t new_total = 0;  // (thread 0) keys this leaf added to the table
+        const int sweeps = g == 0 ? 1 : 2;
+        for (int sweep = 0; sweep < sweeps && leaf_ok; sweep++) {
+            const bool commit = g == 0 || sweep == 1;
+            for (uint32_t sub = 0; sub < (1u << g); sub++) {
+                const uint64_t region = ((uint64_t)leaf << g) | sub;
+                Slot *gs = t.slots + region * REGION_SLOTS;
+                for (uint32_t i = tid; i < REGION_SLOTS; i += P3_THREADS) {
+                    if (virgin) {
+                        L.key[i] = EMPTY_KEY; L.cnt[i] = 0; L.aux[i] = 0;
+                    } else {
+                        const uint4 raw = *reinterpret_cast<const uint4 *>(gs + i);
+                        L.key[i] = ((uint64_t)raw.y << 32) | raw.x;
+                        L.cnt[i] = raw.z;
+                        L.aux[i] = raw.w;
+                    }
+                }
+                if (tid == 0) { L.n_new = 0; L.overflow = 0; }
+                __syncthreads();
+                for (uint32_t i = tid; i < n; i += P3_THREADS) {
+                    const uint64_t key = keys[i];
+                    const uint64_t gslot = fmix64(key) >> t.shift;
+                    if (g && (gslot >> 12) != region) continue;
+                    const uint32_t hint = hints[i];
+                    uint32_t s = (uint32_t)gslot & (REGION_SLOTS - 1);
+                    bool done = false;
+                    for (uint32_t probe = 0; probe < REGION_SLOTS; probe++) {
+                        uint64_t cur = L.key[s];
+                        if (cur == EMPTY_KEY) {
+                            cur = atomicCAS(reinterpret_cast<unsigned long long *>(&L.key[s]), (unsigned long long)EMPTY_KEY,
+                                            (unsigned long long)key);
+                            if (cur == EMPTY_KEY) { atomicAdd(&L.n_new, 1u); cur = key; }
+                        }
+                        if (cur == key) {
+                            atomicAdd(&L.cnt[s], 1u);
+                            if (hint) {
+                                const uint32_t have = L.aux[s], m = hint_merge(have, hint);
+                                if (m != have) L.aux[s] = m;  // racy on purpose: any occurrence's context will do
+                            }
+                            done = true;
+                            break;
+                        }
+                        s = (s + 1) & (REGION_SLOTS - 1);
+                    }
+                    if (!done) atomicExch(&L.overflow, 1u);
+                }
+                __syncthreads();
+                const bool ovf = L.overflow != 0;
+                if (ovf) leaf_ok = false;
+                if (commit && !ovf) {
+                    for (uint32_t i = tid; i < REGION_SLOTS; i += P3_THREADS) {
+                        uint4 v;
+                        const uint64_t kk = L.key[i];
+                        v.x = (uint32_t)kk; v.y = (uint32_t)(kk >> 32);
+                        v.z = L.cnt[i] > 0x80000000u ? 0x80000000u : L.cnt[i];  // counters stop at 2^31 (kmer_device.h)
+                        v.w = L.aux[i];
+                        *reinterpret_cast<uint4 *>(gs + i) = v;
+                    }
+                    if (tid == 0) new_total += L.n_new;
+                } else if (commit && ovf && virgin) {  // (g == 0) nothing was there: leave a valid empty region behind
+                    for (uint32_t i = tid; i < REGION_SLOTS; i += P3_THREADS) {
+                        uint4 v; v.x = 0xFFFFFFFFu; v.y = 0xFFFFFFFFu; v.z = 0; v.w = 0;
+                        *reinterpret_cast<uint4 *>(gs + i) = v;
+                    }
+                }
+                __syncthreads();
+                if (ovf) break;
+            }
+        }
+        if (tid == 0) {
+            if (leaf_ok) { leaf_state[leaf] = 1; leaf_new[leaf] = new_total; } else atomicExch(any_failed, 1u);
+        }
+    }
+}
+
+// n_used += sum(leaf_new): one atomic per workgroup instead of one per region on a single hot address
+__global__ void k_sum_leaf_new(const uint32_t *__restrict__ leaf_new, uint32_t n, unsigned long long *n_used)
+{
+    unsigned long long v = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v += leaf_new[i];
+    wave_add_ull(n_used, v);
+}
+
+// drains the spill list (and serves as the direct path for key streams that carry a hint)
+__global__ void k_add_keys_hint(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ hints, uint64_t n,
+                                TableView t)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long n_new = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        n_new += table_add(t, keys[i], 1u, hints[i]);
+    wave_add_ull(t.n_used, n_new);
+}
+
+}  // namespace mc

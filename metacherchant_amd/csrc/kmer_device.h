@@ -237,11 +237,13 @@ __device__ __forceinline__ uint64_t slot_of(const TableView &t, uint64_t key) { 
 // addAndBound(key, inc) with the saturation deferred to read time (count is 32-bit here; a
 // counter that already reached 2^31 is left alone, launches add < 2^30 each, so it never wraps
 // and min(32767, count) equals the reference's saturating short, itmo!/utils/NumUtils.java:21-26).
-__device__ __forceinline__ void table_add(const TableView &t, uint64_t key, uint32_t inc, uint32_t hint = 0)
+// Returns 1 when the key was new: callers add these up and publish them with wave_add_ull once per
+// wave (one hot counter address hammered by every insert costs more than the inserts themselves).
+__device__ __forceinline__ uint32_t table_add(const TableView &t, uint64_t key, uint32_t inc, uint32_t hint = 0)
 {
     if (key == EMPTY_KEY) {
         atomicAdd(t.empty_cnt, (unsigned long long)inc);
-        return;
+        return 0;
     }
     uint64_t s = slot_of(t, key);
     const uint64_t base = s & ~(uint64_t)t.rmask;
@@ -254,23 +256,31 @@ __device__ __forceinline__ void table_add(const TableView &t, uint64_t key, uint
             cur = atomicCAS(reinterpret_cast<unsigned long long *>(&p->key), (unsigned long long)EMPTY_KEY,
                             (unsigned long long)key);
             if (cur == EMPTY_KEY) {
-                atomicAdd(t.n_used, 1ull);
                 // the inserter alone also writes the hint: one 64-bit add on {count, aux} (aux was 0, and
                 // count never carries into it: counters stop growing at 2^31)
                 atomicAdd(reinterpret_cast<unsigned long long *>(&p->count), ((unsigned long long)hint << 32) | inc);
-                return;
+                return 1;
             }
             if (cur == key) {
                 atomicAdd(&p->count, inc);
-                return;
+                return 0;
             }
         } else if (cur == key) {
             if (raw.z < 0x80000000u) atomicAdd(&p->count, inc);
-            return;
+            return 0;
         }
         s = base | ((s + 1) & t.rmask);
     }
     atomicExch(t.fatal, 1u);
+    return 0;
+}
+
+// sum over the wave, one atomic per wave.  Every lane of the wave must call it (convergent).
+__device__ __forceinline__ void wave_add_ull(unsigned long long *p, unsigned long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(p, v);
 }
 
 // BigLong2ShortHashMap.get: -1 when absent, else min(32767, count)

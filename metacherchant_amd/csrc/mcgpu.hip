@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -18,6 +19,7 @@
 #include "../../include/mcgpu.h"
 #include "kmer_device.h"
 #include "bfs_device.h"
+#include "count_pipeline.h"
 
 using namespace mc;
 
@@ -46,6 +48,25 @@ struct mc_ctx {
     uint64_t n_solid = 0;
 
     mc_stats st{};
+
+    bool virgin = true;  // the table holds no key and its memory is not initialised yet
+    int count_path = 0;  // 0 auto, 1 direct (atomics), 2 partitioned; MC_COUNT_PATH=direct|partition overrides
+    // scratch of the partitioned counting pipeline, kept between calls
+    struct Pipe {
+        uint64_t *a_keys = nullptr, *b_keys = nullptr, *spill_keys = nullptr, *tile_map = nullptr;
+        uint32_t *a_hints = nullptr, *b_hints = nullptr, *spill_hints = nullptr, *tile_first = nullptr;
+        uint32_t *cursors1 = nullptr, *cursors2 = nullptr, *leaf_state = nullptr, *leaf_new = nullptr, *flags = nullptr;  // flags: [0] spill lost, [1] any leaf failed
+        unsigned long long *spill_count = nullptr;
+        uint64_t a_cap = 0, b_cap = 0, spill_cap = 0, tiles1_cap = 0, tiles2_cap = 0, leaves_cap = 0;
+        void release()
+        {
+            (void)hipFree(a_keys); (void)hipFree(b_keys); (void)hipFree(spill_keys); (void)hipFree(tile_map);
+            (void)hipFree(a_hints); (void)hipFree(b_hints); (void)hipFree(spill_hints); (void)hipFree(tile_first);
+            (void)hipFree(cursors1); (void)hipFree(cursors2); (void)hipFree(leaf_state); (void)hipFree(leaf_new); (void)hipFree(flags);
+            (void)hipFree(spill_count);
+            *this = Pipe{};
+        }
+    } pipe;
 
     uint64_t n_slots() const { return 1ull << (rb + sb); }
     TableView solid_view() const
@@ -120,6 +141,7 @@ __global__ void __launch_bounds__(256) k_count_reads(const uint64_t *__restrict_
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    unsigned long long n_new = 0;
     for (uint64_t r = r_begin + wave; r < r_end; r += n_waves) {
         const uint64_t b = offsets[r], e = offsets[r + 1];
         if (e - b < (uint64_t)k) continue;
@@ -128,24 +150,29 @@ __global__ void __launch_bounds__(256) k_count_reads(const uint64_t *__restrict_
             const Kmer v = extract_kmer(words, b + w, k);
             bool flipped;
             const uint64_t key = (uint64_t)key_of<MODE>(v, k, &flipped);
-            table_add(t, key, 1u, hint_of(words, b + w, k, b, e, flipped));
+            n_new += table_add(t, key, 1u, hint_of(words, b + w, k, b, e, flipped));
         }
     }
+    wave_add_ull(t.n_used, n_new);
 }
 
 __global__ void k_add_keys(const int64_t *__restrict__ keys, uint64_t n, TableView t)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long n_new = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        table_add(t, (uint64_t)keys[i], 1u);
+        n_new += table_add(t, (uint64_t)keys[i], 1u);
+    wave_add_ull(t.n_used, n_new);
 }
 
 __global__ void k_add_pairs(const int64_t *__restrict__ keys, const int16_t *__restrict__ counts, uint64_t n,
                             TableView t)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long n_new = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        if (counts[i] > 0) table_add(t, (uint64_t)keys[i], (uint32_t)counts[i]);
+        if (counts[i] > 0) n_new += table_add(t, (uint64_t)keys[i], (uint32_t)counts[i]);
+    wave_add_ull(t.n_used, n_new);
 }
 
 // table rebuild into a larger table (the reference's enlargeAndRehash,
@@ -153,24 +180,28 @@ __global__ void k_add_pairs(const int64_t *__restrict__ keys, const int16_t *__r
 __global__ void k_rehash(const Slot *__restrict__ old_slots, uint64_t n_old, TableView t)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long n_new = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_old; i += stride) {
         const uint4 raw = *reinterpret_cast<const uint4 *>(old_slots + i);
         const uint64_t key = ((uint64_t)raw.y << 32) | raw.x;
-        if (key != EMPTY_KEY) table_add(t, key, raw.z, raw.w);
+        if (key != EMPTY_KEY) n_new += table_add(t, key, raw.z, raw.w);
     }
+    wave_add_ull(t.n_used, n_new);
 }
 
 // K6: copy the keys with count >= min_cov into the sparse "solid" table the BFS probes
 __global__ void k_build_solid(const Slot *__restrict__ slots, uint64_t n_slots, int min_cov, TableView solid)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long n_new = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += stride) {
         const uint4 raw = *reinterpret_cast<const uint4 *>(slots + i);
         const uint64_t key = ((uint64_t)raw.y << 32) | raw.x;
         if (key == EMPTY_KEY) continue;
         const int c = raw.z > 32767u ? 32767 : (int)raw.z;
-        if (c >= min_cov) table_add(solid, key, (uint32_t)c, raw.w);
+        if (c >= min_cov) n_new += table_add(solid, key, (uint32_t)c, raw.w);
     }
+    wave_add_ull(solid.n_used, n_new);
 }
 
 // K4: BigLong2ShortHashMap.get for a batch of keys
@@ -181,23 +212,44 @@ __global__ void k_get(const int64_t *__restrict__ keys, uint64_t n, int16_t *__r
         out[i] = (int16_t)table_get(t, (uint64_t)keys[i]);
 }
 
-// K6: (key, count) pairs with count >= min_cov; with keys == nullptr only counts them
+// K6: (key, count) pairs with count >= min_cov; with keys == nullptr only counts them.
+// One cursor update per wave and iteration (ballot), never one per slot.
 __global__ void k_export(const Slot *__restrict__ slots, uint64_t n_slots, int min_cov, int64_t *__restrict__ keys,
                          int16_t *__restrict__ counts, uint64_t cap, unsigned long long *cursor)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += stride) {
-        const uint4 raw = *reinterpret_cast<const uint4 *>(slots + i);
-        const uint64_t key = ((uint64_t)raw.y << 32) | raw.x;
-        if (key == EMPTY_KEY) continue;
-        const int c = raw.z > 32767u ? 32767 : (int)raw.z;
-        if (c < min_cov) continue;
-        const unsigned long long pos = atomicAdd(cursor, 1ull);  // hipcc merges this into one add per wave
-        if (keys && pos < cap) {
-            keys[pos] = (int64_t)key;
-            counts[pos] = (int16_t)c;
+    const uint32_t lane = threadIdx.x & 63;
+    unsigned long long counted = 0;
+    const uint64_t first = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint64_t i0 = first - lane; i0 < n_slots; i0 += stride) {  // wave-uniform trip count
+        const uint64_t i = i0 + lane;
+        uint64_t key = EMPTY_KEY;
+        int c = -1;
+        if (i < n_slots) {
+            const uint4 raw = *reinterpret_cast<const uint4 *>(slots + i);
+            key = ((uint64_t)raw.y << 32) | raw.x;
+            c = raw.z > 32767u ? 32767 : (int)raw.z;
+        }
+        const bool take = key != EMPTY_KEY && c >= min_cov;
+        if (!keys) {
+            counted += take ? 1u : 0u;
+            continue;
+        }
+        const unsigned long long m = __ballot(take);
+        if (!m) continue;
+        unsigned long long base = 0;
+        const int leader = __ffsll((long long)m) - 1;
+        if ((int)lane == leader) base = atomicAdd(cursor, (unsigned long long)__popcll(m));
+        base = __shfl(base, leader);
+        if (take) {
+            const unsigned long long pos = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1));
+            if (pos < cap) {
+                keys[pos] = (int64_t)key;
+                counts[pos] = (int16_t)c;
+            }
         }
     }
+    if (!keys) wave_add_ull(cursor, counted);
 }
 
 // ------------------------------------------------------------------------------------------ kernels: multi-GPU split
@@ -307,11 +359,20 @@ static int table_alloc(mc_ctx *c, uint32_t log2_slots)
     if (log2_slots > 36) return fail(c, MC_EOVERFLOW, "k-mer table would need 2^%u slots", log2_slots);
     c->rb = log2_slots - c->sb;
     HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->slots), c->n_slots() * sizeof(Slot)));
+    c->virgin = true;  // filled lazily: the partitioned pipeline writes every region itself
+    c->st.table_slots = c->n_slots();
+    c->st.table_bytes = c->n_slots() * sizeof(Slot);
+    return MC_OK;
+}
+
+// the direct kernels, lookups and exports need real (EMPTY-initialised) slots
+static int materialize(mc_ctx *c)
+{
+    if (!c->virgin) return MC_OK;
     hipLaunchKernelGGL(k_fill_empty, dim3(grid_for(c->n_slots(), 256)), dim3(256), 0, c->stream, c->slots,
                        c->n_slots());
     HIPCHK(c, hipGetLastError());
-    c->st.table_slots = c->n_slots();
-    c->st.table_bytes = c->n_slots() * sizeof(Slot);
+    c->virgin = false;
     return MC_OK;
 }
 
@@ -329,9 +390,18 @@ static int table_grow(mc_ctx *c, uint32_t new_log2)
 {
     Slot *old = c->slots;
     const uint64_t old_n = c->n_slots();
+    const bool old_virgin = c->virgin;
+    const uint32_t old_rb = c->rb;
     c->slots = nullptr;
     int rc = table_alloc(c, new_log2);
-    if (rc) { c->slots = old; return rc; }
+    if (rc) { c->slots = old; c->rb = old_rb; c->virgin = old_virgin; return rc; }
+    if (old_virgin) {  // nothing to move
+        HIPCHK(c, hipFree(old));
+        c->st.grows++;
+        return MC_OK;
+    }
+    rc = materialize(c);
+    if (rc) return rc;
     HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, sizeof(unsigned long long), c->stream));  // n_used is recounted
     hipLaunchKernelGGL(k_rehash, dim3(grid_for(old_n, 256)), dim3(256), 0, c->stream, old, old_n, c->view());
     HIPCHK(c, hipGetLastError());
@@ -345,6 +415,8 @@ static int table_grow(mc_ctx *c, uint32_t new_log2)
 // next launch without the load factor passing 0.85 even if every one is a new key.
 static int table_reserve(mc_ctx *c, uint64_t incoming, uint64_t *allowed)
 {
+    int mrc = materialize(c);
+    if (mrc) return mrc;
     unsigned long long used;
     uint32_t fatal;
     int rc = read_counters(c, &used, &fatal);
@@ -405,11 +477,214 @@ static void launch_count(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_o
     }
 }
 
+template <typename T>
+static int ensure_buf(mc_ctx *c, T **p, uint64_t *cap, uint64_t need)
+{
+    if (*cap >= need && *p) return MC_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void **>(p), std::max<uint64_t>(need, 1) * sizeof(T)));
+    *cap = need;
+    return MC_OK;
+}
+
+// One batch of reads [r0, r1) through the partitioned pipeline (count_pipeline.h).  wb = its windows.
+static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_off, const uint64_t *h_off,
+                                 uint64_t n_reads_total, uint64_t r0, uint64_t r1, uint64_t wb)
+{
+    (void)n_reads_total;
+    mc_ctx::Pipe &P = c->pipe;
+    const uint64_t base0 = h_off[r0], n_bases = h_off[r1] - base0;  // the kernels see reads r0.. with absolute offsets
+    // Make sure the table can take the batch: with a capacity hint the table was sized for it; without one
+    // assume every second occurrence is a new key at most (grown further below if a region still overflows).
+    {
+        unsigned long long used;
+        uint32_t fatal;
+        int rc = read_counters(c, &used, &fatal);
+        if (rc) return rc;
+        if (fatal) return fail(c, MC_EOVERFLOW, "a k-mer table region filled up (hash skew)");
+        c->n_used_host = used;
+        if (c->n_slots() < wb / 4) {
+            uint32_t lg = c->rb + c->sb;
+            while (lg < 34 && (double)(1ull << lg) * 0.5 < (double)used + (double)wb / 8.0) lg++;
+            if (lg > c->rb + c->sb) {
+                rc = table_grow(c, lg);
+                if (rc) return rc;
+            }
+        }
+    }
+    const uint32_t rb = c->rb;
+    if (rb < 2) return fail(c, MC_EINVAL, "internal: partitioned counting needs at least 4 table regions");
+    const uint32_t lb = std::min<uint32_t>(rb, 18);  // leaf bits; a leaf covers 2^(rb - lb) regions
+    const uint32_t b1 = (lb + 1) / 2, b2 = lb - b1;
+    uint32_t g = rb - lb;
+    const uint64_t np1 = 1ull << b1, n_leaves = 1ull << lb;
+    const uint64_t cap1 = (uint64_t)((double)wb / (double)np1 * 1.04) + 16384;
+    const double mean_leaf = (double)wb / (double)n_leaves;
+    const uint64_t cap2 = (uint64_t)(mean_leaf * 1.15 + 8.0 * std::sqrt(mean_leaf) + 64.0);
+    const uint64_t n_tiles1 = (n_bases + PT_TILE - 1) / PT_TILE;
+    const uint64_t tiles2_max = wb / PT_TILE + np1 + 1;
+    const uint64_t spill_cap = std::max<uint64_t>(wb / 64, 1u << 20);
+
+    int rc;
+    uint64_t dummy;
+#define ENSURE(ptr, capvar, need) do { rc = ensure_buf(c, &(ptr), &(capvar), (need)); if (rc) return rc; } while (0)
+    { uint64_t cap = P.a_cap; ENSURE(P.a_keys, cap, np1 * cap1); dummy = P.a_cap; ENSURE(P.a_hints, dummy, np1 * cap1); P.a_cap = cap; }
+    { uint64_t cap = P.b_cap; ENSURE(P.b_keys, cap, n_leaves * cap2); dummy = P.b_cap; ENSURE(P.b_hints, dummy, n_leaves * cap2); P.b_cap = cap; }
+    { uint64_t cap = P.spill_cap; ENSURE(P.spill_keys, cap, spill_cap); dummy = P.spill_cap; ENSURE(P.spill_hints, dummy, spill_cap); P.spill_cap = cap; }
+    ENSURE(P.tile_first, P.tiles1_cap, n_tiles1);
+    ENSURE(P.tile_map, P.tiles2_cap, tiles2_max);
+    { uint64_t cap = P.leaves_cap; ENSURE(P.cursors2, cap, n_leaves); dummy = P.leaves_cap; ENSURE(P.leaf_state, dummy, n_leaves); dummy = P.leaves_cap; ENSURE(P.leaf_new, dummy, n_leaves); P.leaves_cap = cap; }
+    if (!P.cursors1) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.cursors1), PT_MAX_BUCKETS * sizeof(uint32_t)));
+    if (!P.flags) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.flags), 2 * sizeof(uint32_t)));
+    if (!P.spill_count) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.spill_count), sizeof(unsigned long long)));
+#undef ENSURE
+    HIPCHK(c, hipMemsetAsync(P.cursors1, 0, PT_MAX_BUCKETS * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(P.cursors2, 0, n_leaves * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(P.leaf_state, 0, n_leaves * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(P.leaf_new, 0, n_leaves * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(P.flags, 0, 2 * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(P.spill_count, 0, sizeof(unsigned long long), c->stream));
+    const SpillView sp{P.spill_keys, P.spill_hints, P.spill_count, spill_cap, P.flags};
+    const int k = c->cfg.k;
+    const uint64_t *offs = d_off + r0;
+    const uint64_t nr = r1 - r0;
+    // tiles are cut over the absolute base positions [0, h_off[r1]); the ones before base0 hold no read of ours
+    const uint64_t n_bases_abs = h_off[r1];
+    const uint64_t n_tiles_abs = (n_bases_abs + PT_TILE - 1) / PT_TILE;
+    if (n_tiles_abs > P.tiles1_cap) { rc = ensure_buf(c, &P.tile_first, &P.tiles1_cap, n_tiles_abs); if (rc) return rc; }
+    (void)n_tiles1;
+
+    double ms1 = 0, ms2 = 0, ms3 = 0;
+    rc = timed(c, &ms1, [&] {
+        hipLaunchKernelGGL(k_tile_first_read, dim3((unsigned)((n_tiles_abs + 255) / 256)), dim3(256), 0, c->stream, offs, nr,
+                           n_tiles_abs, P.tile_first);
+        const int grid = (int)std::min<uint64_t>(n_tiles_abs, 256 * 1);
+        switch (c->cfg.key_mode) {
+        case MC_KEY_PACKED:
+            hipLaunchKernelGGL(k_p1_extract_scatter<KEY_PACKED>, dim3(grid), dim3(PT_THREADS), 0, c->stream, d_words, offs,
+                               nr, base0, n_bases_abs, n_tiles_abs, P.tile_first, k, b1, P.cursors1, cap1, P.a_keys, P.a_hints,
+                               c->d_ctr + 1, sp);
+            break;
+        case MC_KEY_POLY:
+            hipLaunchKernelGGL(k_p1_extract_scatter<KEY_POLY>, dim3(grid), dim3(PT_THREADS), 0, c->stream, d_words, offs, nr,
+                               base0, n_bases_abs, n_tiles_abs, P.tile_first, k, b1, P.cursors1, cap1, P.a_keys, P.a_hints,
+                               c->d_ctr + 1, sp);
+            break;
+        default:
+            hipLaunchKernelGGL(k_p1_extract_scatter<KEY_FNV1A>, dim3(grid), dim3(PT_THREADS), 0, c->stream, d_words, offs,
+                               nr, base0, n_bases_abs, n_tiles_abs, P.tile_first, k, b1, P.cursors1, cap1, P.a_keys, P.a_hints,
+                               c->d_ctr + 1, sp);
+        }
+    });
+    if (rc) return rc;
+    // tile map of P2 from the level-1 bucket sizes
+    std::vector<uint32_t> cnt1(np1);
+    HIPCHK(c, hipMemcpy(cnt1.data(), P.cursors1, np1 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::vector<uint64_t> tmap;
+    tmap.reserve(tiles2_max);
+    for (uint64_t b = 0; b < np1; b++) {
+        const uint64_t have = std::min<uint64_t>(cnt1[b], cap1);
+        for (uint64_t f = 0; f < have; f += PT_TILE) tmap.push_back((b << 32) | f);
+    }
+    if (tmap.size() > P.tiles2_cap) return fail(c, MC_EOVERFLOW, "internal: P2 tile map overflow");
+    if (!tmap.empty()) {
+        HIPCHK(c, hipMemcpyAsync(P.tile_map, tmap.data(), tmap.size() * 8, hipMemcpyHostToDevice, c->stream));
+        rc = timed(c, &ms2, [&] {
+            const int grid = (int)std::min<uint64_t>(tmap.size(), 256 * 1);
+            hipLaunchKernelGGL(k_p2_scatter, dim3(grid), dim3(PT_THREADS), 0, c->stream, P.a_keys, P.a_hints, cap1,
+                               P.cursors1, P.tile_map, (uint64_t)tmap.size(), b1, b2, P.cursors2, cap2, P.b_keys, P.b_hints, sp);
+        });
+        if (rc) return rc;
+    }
+    // P3, retried with a larger table when a region overflows
+    for (int attempt = 0;; attempt++) {
+        const int virgin = c->virgin ? 1 : 0;
+        rc = timed(c, &ms3, [&] {
+            const int grid = (int)std::min<uint64_t>(n_leaves, 256 * 2 * 4);
+            hipLaunchKernelGGL(k_p3_merge, dim3(grid), dim3(P3_THREADS), 0, c->stream, P.b_keys, P.b_hints, P.cursors2, cap2,
+                               (uint32_t)n_leaves, g, c->view(), virgin, P.leaf_state, P.leaf_new, P.flags + 1);
+        });
+        if (rc) return rc;
+        c->virgin = false;
+        uint32_t flags[2];
+        HIPCHK(c, hipMemcpy(flags, P.flags, sizeof flags, hipMemcpyDeviceToHost));
+        if (flags[0]) return fail(c, MC_EOVERFLOW, "internal: spill list of the partitioned counting pipeline overflowed");
+        if (!flags[1]) break;
+        if (attempt >= 6 || g >= 5)
+            return fail(c, MC_EOVERFLOW, "k-mer table regions keep overflowing; pass a capacity_hint (distinct k-mers)");
+        rc = table_grow(c, c->rb + c->sb + 1);
+        if (rc) return rc;
+        g++;
+        HIPCHK(c, hipMemsetAsync(P.flags + 1, 0, sizeof(uint32_t), c->stream));
+    }
+    hipLaunchKernelGGL(k_sum_leaf_new, dim3(64), dim3(256), 0, c->stream, P.leaf_new, (uint32_t)n_leaves, c->d_ctr);
+    HIPCHK(c, hipGetLastError());
+    // what did not fit its bucket goes through the direct kernel
+    unsigned long long n_spill = 0;
+    HIPCHK(c, hipMemcpy(&n_spill, P.spill_count, sizeof n_spill, hipMemcpyDeviceToHost));
+    double ms4 = 0;
+    if (n_spill) {
+        uint64_t i = 0;
+        while (i < n_spill) {
+            uint64_t allowed;
+            rc = table_reserve(c, n_spill - i, &allowed);
+            if (rc) return rc;
+            const uint64_t m = std::min<uint64_t>(allowed, n_spill - i);
+            rc = timed(c, &ms4, [&] {
+                hipLaunchKernelGGL(k_add_keys_hint, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, P.spill_keys + i,
+                                   P.spill_hints + i, m, c->view());
+            });
+            if (rc) return rc;
+            i += m;
+        }
+    }
+    c->st.p1_ms += ms1;
+    c->st.p2_ms += ms2;
+    c->st.p3_ms += ms3;
+    c->st.spill_keys += n_spill;
+    c->st.count_ms += ms1 + ms2 + ms3 + ms4;
+    c->st.count_total_ms += ms1 + ms2 + ms3 + ms4;
+    c->st.count_launches++;
+    c->st.windows += wb;
+    return MC_OK;
+}
+
 // counting with read offsets known on the host
 static int add_reads_impl(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_off, const uint64_t *h_off,
                           uint64_t n_reads)
 {
     const uint64_t k = (uint64_t)c->cfg.k;
+    auto windows_of = [&](uint64_t a, uint64_t b) {
+        uint64_t w = 0;
+        for (uint64_t i = a; i < b; i++) {
+            const uint64_t len = h_off[i + 1] - h_off[i];
+            if (len >= k) w += len - k + 1;
+        }
+        return w;
+    };
+    const uint64_t total = windows_of(0, n_reads);
+    const bool partition = c->count_path == 2 || (c->count_path == 0 && total >= (1ull << 22));
+    if (partition) {
+        // batches of at most ~2^31 windows (32-bit bucket cursors)
+        const uint64_t max_bases = (1ull << 31) - (1ull << 24);
+        uint64_t r = 0;
+        while (r < n_reads) {
+            uint64_t r1 = (uint64_t)(std::upper_bound(h_off + r, h_off + n_reads + 1, h_off[r] + max_bases) - h_off) - 1;
+            if (r1 <= r) return fail(c, MC_EINVAL, "a single read of more than 2^31 bases is not supported");
+            if (r1 > n_reads) r1 = n_reads;
+            const uint64_t wb = windows_of(r, r1);
+            if (wb) {
+                int rc = add_reads_partitioned(c, d_words, d_off, h_off, n_reads, r, r1, wb);
+                if (rc) return rc;
+            }
+            r = r1;
+        }
+        c->finalized = false;
+        c->solid_cov = -1;
+        return MC_OK;
+    }
     uint64_t r = 0;
     while (r < n_reads) {
         uint64_t allowed;
@@ -417,15 +692,12 @@ static int add_reads_impl(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_
         int rc = table_reserve(c, remaining_bases, &allowed);
         if (rc) return rc;
         // largest r1 with windows(r..r1) <= allowed (windows <= bases)
-        uint64_t r1 = r, win = 0;
+        uint64_t r1 = r;
         const uint64_t target = h_off[r] + allowed;
         r1 = (uint64_t)(std::upper_bound(h_off + r, h_off + n_reads + 1, target) - h_off) - 1;
         if (r1 <= r) r1 = r + 1;  // a single read longer than the allowance: fine, still < 0.85 + one read
         if (r1 > n_reads) r1 = n_reads;
-        for (uint64_t i = r; i < r1; i++) {
-            const uint64_t len = h_off[i + 1] - h_off[i];
-            if (len >= k) win += len - k + 1;
-        }
+        const uint64_t win = windows_of(r, r1);
         double ms = 0;
         rc = timed(c, &ms, [&] { launch_count(c, d_words, d_off, r, r1); });
         if (rc) return rc;
@@ -487,6 +759,7 @@ int mc_create(const mc_config *cfg, mc_ctx **out)
     CREATE_CHK(hipMemsetAsync(c->d_ctr, 0, 4 * sizeof(unsigned long long), c->stream));
     CREATE_CHK(hipMemsetAsync(c->d_fatal, 0, sizeof(uint32_t), c->stream));
 #undef CREATE_CHK
+    if (const char *e = getenv("MC_COUNT_PATH")) c->count_path = !strcmp(e, "direct") ? 1 : !strcmp(e, "partition") ? 2 : 0;
     uint32_t lg = 22;  // 4 M slots = 64 MB to start with
     if (cfg->capacity_hint) {
         const double want = (double)cfg->capacity_hint / 0.5;
@@ -509,6 +782,7 @@ void mc_destroy(mc_ctx *c)
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     if (c->slots) (void)hipFree(c->slots);
     if (c->solid) (void)hipFree(c->solid);
+    c->pipe.release();
     if (c->d_ctr) (void)hipFree(c->d_ctr);
     if (c->d_fatal) (void)hipFree(c->d_fatal);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -522,9 +796,7 @@ int mc_clear(mc_ctx *c)
     if (!c) return MC_EINVAL;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    hipLaunchKernelGGL(k_fill_empty, dim3(grid_for(c->n_slots(), 256)), dim3(256), 0, c->stream, c->slots,
-                       c->n_slots());
-    HIPCHK(c, hipGetLastError());
+    c->virgin = true;
     HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, 4 * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_fatal, 0, sizeof(uint32_t), c->stream));
     c->n_used_host = 0;
@@ -642,6 +914,10 @@ int mc_finalize_counts(mc_ctx *c, uint64_t *n_distinct)
     if (!c) return MC_EINVAL;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    {
+        int rc = materialize(c);
+        if (rc) return rc;
+    }
     unsigned long long h[3];
     uint32_t fatal;
     HIPCHK(c, hipMemcpyAsync(h, c->d_ctr, sizeof h, hipMemcpyDeviceToHost, c->stream));

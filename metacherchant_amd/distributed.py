@@ -80,7 +80,8 @@ class ShardedCounter:
         all_k = torch.empty(W * mx, dtype=torch.int64, device=self.device)
         all_c = torch.empty(W * mx, dtype=torch.int16, device=self.device)
         dist.all_gather_into_tensor(all_k, keys, group=self.group)
-        dist.all_gather_into_tensor(all_c, cnts, group=self.group)
+        # counts travel as bytes: neither RCCL nor gloo has a 16-bit integer type
+        dist.all_gather_into_tensor(all_c.view(torch.uint8), cnts.view(torch.uint8), group=self.group)
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
         if dst is None or self.rank == dst:

@@ -37,13 +37,14 @@ class _BfsJob(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("windows", C.c_uint64), ("count_launches", C.c_uint64), ("count_ms", C.c_double),
                 ("count_total_ms", C.c_double), ("table_slots", C.c_uint64), ("table_bytes", C.c_uint64),
-                ("grows", C.c_uint64)]
+                ("grows", C.c_uint64), ("p1_ms", C.c_double), ("p2_ms", C.c_double), ("p3_ms", C.c_double),
+                ("spill_keys", C.c_uint64)]
 
 
 # every symbol include/mcgpu.h declares; tests check that the library exports all of them
 EXPORTS = [
     "mc_abi_version", "mc_create", "mc_destroy", "mc_clear", "mc_last_error", "mc_set_stream", "mc_add_reads_packed",
-    "mc_add_reads_packed_dev", "mc_finalize_counts", "mc_get", "mc_get_dev", "mc_kmer_keys", "mc_bfs", "mc_bfs_batch", "mc_bfs_batch",
+    "mc_add_reads_packed_dev", "mc_finalize_counts", "mc_get", "mc_get_dev", "mc_kmer_keys", "mc_bfs", "mc_bfs_batch",
     "mc_bfs_result_free", "mc_export", "mc_export_dev", "mc_add_pairs_dev", "mc_key_owner", "mc_extract_keys_dev",
     "mc_add_keys_dev", "mc_get_stats", "mc_reset_stats", "mc_synth_reads_dev", "mc_synth_genome",
 ]

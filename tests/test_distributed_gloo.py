@@ -1,0 +1,144 @@
+"""The multi-GPU orchestration (metacherchant_amd/distributed.py) on CPU: world_size 2, gloo.
+The ranks run the real exchange logic (bucket by owner -> all-to-all -> count owned keys ->
+all-gather thresholded shards -> merge) over a stand-in for metacherchant_amd.Context built on the
+oracle, and the result must equal counting everything in one table."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleBackedContext:
+    """Implements the Context methods distributed.py uses, on CPU tensors, with oracle/ functions."""
+
+    def __init__(self, k, mode):
+        from oracle import pyoracle as po
+        self.po, self.k, self.mode = po, k, mode
+        self.t = po.Table()
+
+    def add_reads_packed_dev(self, d_words, d_off, n_reads, n_bases):
+        self.t.count_reads_packed(d_words.numpy().view(np.uint64), d_off.numpy().view(np.uint64), self.k, self.mode)
+
+    def _keys(self, d_words, d_off):
+        po = self.po
+        words, off = d_words.numpy().view(np.uint64), d_off.numpy().view(np.uint64)
+        keys = []
+        for r in range(len(off) - 1):
+            codes = np.array([(int(words[p >> 5]) >> (62 - 2 * (p & 31))) & 3 for p in range(int(off[r]), int(off[r + 1]))],
+                             dtype=np.uint8)
+            for i in range(len(codes) - self.k + 1):
+                keys.append(po.key(codes[i:i + self.k], self.k, self.mode))
+        return np.array(keys, dtype=np.int64)
+
+    def extract_keys_dev(self, d_words, d_off, n_reads, n_bases, n_owners, d_keys, cap):
+        from metacherchant_amd import native
+        keys = self._keys(d_words, d_off)
+        owners = np.array([native.key_owner(int(x), n_owners) for x in keys], dtype=np.int64)
+        order = np.argsort(owners, kind="stable")
+        out = np.zeros(n_owners + 1, dtype=np.uint64)
+        out[1:] = np.cumsum(np.bincount(owners, minlength=n_owners))
+        d_keys[:len(keys)] = torch.from_numpy(keys[order])
+        return out
+
+    def add_keys_dev(self, d_keys, n):
+        for x in d_keys[:n].tolist():
+            self.t.add(int(x), 1)
+
+    def add_pairs_dev(self, d_keys, d_counts, n):
+        for x, c in zip(d_keys[:n].tolist(), d_counts[:n].tolist()):
+            self.t.add(int(x), int(c))
+
+    def finalize(self):
+        return self.t.size()
+
+    def export_count(self, min_cov):
+        return int((self.t.dump()[1] >= min_cov).sum())
+
+    def export_dev(self, min_cov, d_keys, d_counts, cap):
+        k, c = self.t.dump()
+        m = c >= min_cov
+        n = int(m.sum())
+        d_keys[:n] = torch.from_numpy(k[m])
+        d_counts[:n] = torch.from_numpy(c[m])
+        return n
+
+
+def _worker(rank, world, port, k, mode, reads, L, n_reads, min_cov, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from metacherchant_amd.distributed import ShardedCounter, split_reads
+        from oracle import pyoracle as po
+        lo, hi = split_reads(n_reads, world, rank)
+        mine = reads[lo * L:hi * L]
+        words = torch.from_numpy(po.pack(mine).view(np.int64))
+        off = torch.from_numpy((np.arange(hi - lo + 1, dtype=np.uint64) * L).view(np.int64))
+        ctx = OracleBackedContext(k, mode)
+        sc = ShardedCounter(ctx, torch.device("cpu"))
+        sc.add_reads_dev(words, off, hi - lo, (hi - lo) * L, (hi - lo) * (L - k + 1))
+        total = sc.finalize()
+        solid = OracleBackedContext(k, mode)
+        n_solid = sc.gather_solid(solid, min_cov, dst=0)
+        own_keys = ctx.t.dump()[0]
+        from metacherchant_amd import native
+        assert all(native.key_owner(int(x), world) == rank for x in own_keys[:500])
+        if rank == 0:
+            sk, scnt = solid.t.dump()
+            q.put((total, n_solid, sk, scnt, sc.bytes_sent))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("k,mode", [(31, 0), (35, 1)])
+def test_sharded_count_equals_single_table(k, mode):
+    from metacherchant_amd import build
+    build.build_lib()  # key_owner comes from the C ABI (host function, no GPU needed)
+    from oracle import pyoracle as po
+    from tests.helpers import synth_case
+    L, n_reads, min_cov = 100, 300, 2
+    _, reads, off = synth_case(1, 3000, n_reads, L, 100)
+    t = po.Table()
+    t.count_reads(reads, off, k, mode)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, k, mode, reads, L, n_reads, min_cov, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    total, n_solid, sk, scnt, sent = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ok, oc = t.dump()
+    assert total == t.size()
+    m = oc >= min_cov
+    assert n_solid == int(m.sum())
+    assert np.array_equal(sk, ok[m]) and np.array_equal(scnt, oc[m])
+    assert sent > 0
+
+
+def test_split_reads_covers_everything():
+    from metacherchant_amd.distributed import split_reads
+    for n in (0, 1, 7, 100, 101):
+        for w in (1, 2, 3, 8):
+            spans = [split_reads(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1

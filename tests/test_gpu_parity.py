@@ -17,6 +17,14 @@ def mc():
     return m
 
 
+@pytest.fixture(params=["direct", "partition"])
+def count_path(request, monkeypatch):
+    """Both counting kernels must give the same table: the direct one (an atomic per occurrence) and the
+    partitioned pipeline (scatter by hash prefix, merge regions in LDS).  Read at mc_create."""
+    monkeypatch.setenv("MC_COUNT_PATH", request.param)
+    return request.param
+
+
 def _gpu_table(mc, words, offsets, k, mode, hint=0):
     ctx = mc.Context(k, mode, 0, hint)
     ctx.add_reads_packed(words, offsets)
@@ -33,7 +41,7 @@ def _assert_tables_equal(ctx, n_distinct, t):
 
 
 @pytest.mark.parametrize("err", [0, 100])
-def test_count_config1_k31(mc, err):
+def test_count_config1_k31(mc, err, count_path):
     """BASELINE.json configs[0]: 10k x 150 bp, k=31 -- every (key, count) pair equal."""
     _, reads, off = synth_case(1, 50000, 10000, 150, err)
     t, n = oracle_table(reads, off, 31, po.KEY_PACKED)
@@ -49,7 +57,7 @@ def test_count_config1_k31(mc, err):
 
 
 @pytest.mark.parametrize("k,mode", [(31, 0), (21, 0), (5, 0), (1, 0), (63, 1), (33, 1), (47, 2), (31, 1), (64 - 1, 2)])
-def test_count_ragged_reads_all_key_modes(mc, k, mode):
+def test_count_ragged_reads_all_key_modes(mc, k, mode, count_path):
     """Empty reads, reads shorter than k, k-1, k, ragged lengths; packed key, poly and fnv1a hashes."""
     rng = np.random.default_rng(100 + k + mode)
     _, codes, off = ragged_case(rng, 700)
@@ -60,7 +68,7 @@ def test_count_ragged_reads_all_key_modes(mc, k, mode):
     ctx.close()
 
 
-def test_count_saturates_at_32767_and_key_zero(mc):
+def test_count_saturates_at_32767_and_key_zero(mc, count_path):
     """poly-A / poly-T reads: key 0 (the reference's FREE marker) with > 32767 occurrences."""
     L, n = 150, 400
     codes = np.zeros(n * L, dtype=np.uint8)
@@ -89,12 +97,13 @@ def test_empty_input_and_state_errors(mc):
     ctx.close()
 
 
-def test_table_grows_from_small(mc):
+def test_table_grows_from_small(mc, count_path):
     """No capacity hint: the table starts at 4 M slots and is rebuilt as it fills."""
     _, reads, off = synth_case(4, 2_000_000, 120_000, 150, 100)
     t, n = oracle_table(reads, off, 31, po.KEY_PACKED)
     ctx, nd = _gpu_table(mc, po.pack(reads), off, 31, mc.KEY_PACKED, 0)
     assert ctx.stats().grows >= 1
+    assert (ctx.stats().p3_ms > 0) == (count_path == "partition")
     _assert_tables_equal(ctx, nd, t)
     # batches in a different order and split over several calls give the same table
     ctx2 = mc.Context(31, mc.KEY_PACKED, 0, t.size())
@@ -209,7 +218,7 @@ def test_bfs_unbounded_radius_grows_buffers(mc):
     ctx.close()
 
 
-def test_device_pointer_path_and_generator(mc):
+def test_device_pointer_path_and_generator(mc, count_path):
     """Reads generated straight into HBM == the oracle's generator; counting from device pointers."""
     import torch
     n_contigs, contig_len, n_reads, L = 3, 20000, 5000, 150
