@@ -69,6 +69,13 @@ __device__ __forceinline__ uint32_t ld_flags(const uint32_t *p)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, uint32_t l)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)l);
+    return ((uint64_t)hi << 32) | lo;
+}
+
 __device__ __forceinline__ uint64_t vis_hash(const Kmer &v) { return fmix64(v.lo ^ fmix64(v.hi + 0x9e3779b97f4a7c15ull)); }
 
 __device__ __forceinline__ bool vis_entry_is(const BfsState &S, uint64_t e, uint32_t fp, const Kmer &v)
@@ -604,8 +611,8 @@ __device__ void bfs_narrow(const BfsState &S, const TableView &t, NarrowLds &L, 
             const uint32_t np = H * F;  // <= MAX_NODES / nb <= 64
             Kmer mypk{0, 0};
             if (lane < np) mypk = L.pk[lane];
-            for (uint32_t e = 0; e < np; e++) {
-                const uint64_t blo = __shfl(mypk.lo, (int)e), bhi = __shfl(mypk.hi, (int)e);
+            for (uint32_t e = 0; e < np; e++) {  // e is wave-uniform: v_readlane, not an LDS permute
+                const uint64_t blo = readlane64(mypk.lo, e), bhi = k > 32 ? readlane64(mypk.hi, e) : 0;
 #pragma unroll
                 for (int u = 0; u < NPL; u++)
                     if (solid[u] && e < (ni[u] - 1) * F + na[u] && nk[u].lo == blo && nk[u].hi == bhi) ind[u] = true;

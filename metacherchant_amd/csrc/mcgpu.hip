@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -25,6 +26,31 @@ using namespace mc;
 
 // ------------------------------------------------------------------------------------------ ctx
 
+// device buffers of one BFS job, kept in the context between calls
+struct BfsJobBuffers {
+    BfsState S{};
+    uint64_t *d_seed_hi = nullptr, *d_seed_lo = nullptr;
+    uint64_t seed_cap = 0;
+    BfsJobBuffers() = default;
+    BfsJobBuffers(const BfsJobBuffers &) = delete;
+    BfsJobBuffers &operator=(const BfsJobBuffers &) = delete;
+    void free_arrays()
+    {
+        (void)hipFree(S.hi); (void)hipFree(S.lo); (void)hipFree(S.dist); (void)hipFree(S.cov);
+        (void)hipFree(S.flags); (void)hipFree(S.vis);
+        S.hi = S.lo = nullptr; S.dist = nullptr; S.cov = nullptr; S.flags = nullptr; S.vis = nullptr;
+    }
+    ~BfsJobBuffers()
+    {
+        free_arrays();
+        (void)hipFree(S.ctl);
+        (void)hipFree(d_seed_hi);
+        (void)hipFree(d_seed_lo);
+    }
+};
+
+
+
 struct mc_ctx {
     mc_config cfg{};
     std::mutex mu;
@@ -35,7 +61,7 @@ struct mc_ctx {
     // table
     Slot *slots = nullptr;
     uint32_t rb = 0, sb = 12;  // 2^rb regions of 2^sb slots
-    unsigned long long *d_ctr = nullptr;  // [0] n_used, [1] empty_cnt, [2] scratch counter, [3] solid n_used
+    unsigned long long *d_ctr = nullptr;  // [0] n_used, [1] empty_cnt, [2] scratch counter, [3] solid n_used, [4..5] read summary
     uint32_t *d_fatal = nullptr;
     uint64_t n_used_host = 0;
     bool finalized = false;
@@ -48,6 +74,7 @@ struct mc_ctx {
     uint64_t n_solid = 0;
 
     mc_stats st{};
+    std::vector<std::unique_ptr<BfsJobBuffers>> bfs_pool;
 
     bool virgin = true;  // the table holds no key and its memory is not initialised yet
     int count_path = 0;  // 0 auto, 1 direct (atomics), 2 partitioned; MC_COUNT_PATH=direct|partition overrides
@@ -202,6 +229,21 @@ __global__ void k_build_solid(const Slot *__restrict__ slots, uint64_t n_slots, 
         if (c >= min_cov) n_new += table_add(solid, key, (uint32_t)c, raw.w);
     }
     wave_add_ull(solid.n_used, n_new);
+}
+
+// windows = sum over reads of max(0, len - k + 1); also checks that the offsets never decrease
+__global__ void k_reads_summary(const uint64_t *__restrict__ offsets, uint64_t n_reads, uint64_t k,
+                                unsigned long long *out /* [0] windows, [1] violations */)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long w = 0, bad = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_reads; i += stride) {
+        const uint64_t a = offsets[i], b = offsets[i + 1];
+        if (b < a) bad++;
+        else if (b - a >= k) w += b - a - k + 1;
+    }
+    wave_add_ull(out, w);
+    wave_add_ull(out + 1, bad);
 }
 
 // K4: BigLong2ShortHashMap.get for a batch of keys
@@ -490,12 +532,12 @@ static int ensure_buf(mc_ctx *c, T **p, uint64_t *cap, uint64_t need)
 }
 
 // One batch of reads [r0, r1) through the partitioned pipeline (count_pipeline.h).  wb = its windows.
-static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_off, const uint64_t *h_off,
-                                 uint64_t n_reads_total, uint64_t r0, uint64_t r1, uint64_t wb)
+// base0 / end_abs = read_offsets[r0] / read_offsets[r1].
+static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_off, uint64_t r0, uint64_t r1,
+                                 uint64_t base0, uint64_t end_abs, uint64_t wb)
 {
-    (void)n_reads_total;
     mc_ctx::Pipe &P = c->pipe;
-    const uint64_t base0 = h_off[r0], n_bases = h_off[r1] - base0;  // the kernels see reads r0.. with absolute offsets
+    const uint64_t n_bases = end_abs - base0;  // the kernels see reads r0.. with absolute offsets
     // Make sure the table can take the batch: with a capacity hint the table was sized for it; without one
     // assume every second occurrence is a new key at most (grown further below if a region still overflows).
     {
@@ -551,7 +593,7 @@ static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint6
     const uint64_t *offs = d_off + r0;
     const uint64_t nr = r1 - r0;
     // tiles are cut over the absolute base positions [0, h_off[r1]); the ones before base0 hold no read of ours
-    const uint64_t n_bases_abs = h_off[r1];
+    const uint64_t n_bases_abs = end_abs;
     const uint64_t n_tiles_abs = (n_bases_abs + PT_TILE - 1) / PT_TILE;
     if (n_tiles_abs > P.tiles1_cap) { rc = ensure_buf(c, &P.tile_first, &P.tiles1_cap, n_tiles_abs); if (rc) return rc; }
     (void)n_tiles1;
@@ -676,7 +718,7 @@ static int add_reads_impl(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_
             if (r1 > n_reads) r1 = n_reads;
             const uint64_t wb = windows_of(r, r1);
             if (wb) {
-                int rc = add_reads_partitioned(c, d_words, d_off, h_off, n_reads, r, r1, wb);
+                int rc = add_reads_partitioned(c, d_words, d_off, r, r1, h_off[r], h_off[r1], wb);
                 if (rc) return rc;
             }
             r = r1;
@@ -754,9 +796,9 @@ int mc_create(const mc_config *cfg, mc_ctx **out)
     c->stream = c->own_stream;
     CREATE_CHK(hipEventCreate(&c->ev0));
     CREATE_CHK(hipEventCreate(&c->ev1));
-    CREATE_CHK(hipMalloc(reinterpret_cast<void **>(&c->d_ctr), 4 * sizeof(unsigned long long)));
+    CREATE_CHK(hipMalloc(reinterpret_cast<void **>(&c->d_ctr), 6 * sizeof(unsigned long long)));
     CREATE_CHK(hipMalloc(reinterpret_cast<void **>(&c->d_fatal), sizeof(uint32_t)));
-    CREATE_CHK(hipMemsetAsync(c->d_ctr, 0, 4 * sizeof(unsigned long long), c->stream));
+    CREATE_CHK(hipMemsetAsync(c->d_ctr, 0, 6 * sizeof(unsigned long long), c->stream));
     CREATE_CHK(hipMemsetAsync(c->d_fatal, 0, sizeof(uint32_t), c->stream));
 #undef CREATE_CHK
     if (const char *e = getenv("MC_COUNT_PATH")) c->count_path = !strcmp(e, "direct") ? 1 : !strcmp(e, "partition") ? 2 : 0;
@@ -783,6 +825,7 @@ void mc_destroy(mc_ctx *c)
     if (c->slots) (void)hipFree(c->slots);
     if (c->solid) (void)hipFree(c->solid);
     c->pipe.release();
+    c->bfs_pool.clear();
     if (c->d_ctr) (void)hipFree(c->d_ctr);
     if (c->d_fatal) (void)hipFree(c->d_fatal);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -847,17 +890,37 @@ int mc_add_reads_packed_dev(mc_ctx *c, const uint64_t *d_words, const uint64_t *
     if ((!d_words || !d_off) && n_reads) return fail(c, MC_EINVAL, "mc_add_reads_packed_dev: null pointer");
     if (n_reads == 0) return MC_OK;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    // the launch planner needs the offsets on the host (8 bytes per read, once per call)
+    // summary on the device: total windows, monotone offsets, first and last offset
+    unsigned long long *sum = c->d_ctr + 4;
+    HIPCHK(c, hipMemsetAsync(sum, 0, 2 * sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(k_reads_summary, dim3(grid_for(n_reads, 256)), dim3(256), 0, c->stream, d_off, n_reads,
+                       (uint64_t)c->cfg.k, sum);
+    HIPCHK(c, hipGetLastError());
+    unsigned long long hs[2];
+    uint64_t first_off = 0, last_off = 0;
+    HIPCHK(c, hipMemcpyAsync(hs, sum, sizeof hs, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&first_off, d_off, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&last_off, d_off + n_reads, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (hs[1]) return fail(c, MC_EINVAL, "mc_add_reads_packed_dev: read_offsets not monotone");
+    if (last_off != n_bases)
+        return fail(c, MC_EINVAL, "mc_add_reads_packed_dev: read_offsets[n_reads]=%llu but n_bases=%llu",
+                    (unsigned long long)last_off, (unsigned long long)n_bases);
+    const uint64_t total = hs[0];
+    const bool partition = c->count_path == 2 || (c->count_path == 0 && total >= (1ull << 22));
+    if (partition && last_off - first_off < (1ull << 31) - (1ull << 24)) {  // one batch: no need for the offsets on the host
+        if (total) {
+            int rc = add_reads_partitioned(c, d_words, d_off, 0, n_reads, first_off, last_off, total);
+            if (rc) return rc;
+        }
+        c->finalized = false;
+        c->solid_cov = -1;
+        return MC_OK;
+    }
+    // otherwise the launch planner needs the offsets on the host (8 bytes per read, once per call)
     std::vector<uint64_t> h_off(n_reads + 1);
     HIPCHK(c, hipMemcpyAsync(h_off.data(), d_off, (n_reads + 1) * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (h_off[n_reads] != n_bases)
-        return fail(c, MC_EINVAL, "mc_add_reads_packed_dev: read_offsets[n_reads]=%llu but n_bases=%llu",
-                    (unsigned long long)h_off[n_reads], (unsigned long long)n_bases);
-    for (uint64_t i = 0; i < n_reads; i++)
-        if (h_off[i + 1] < h_off[i])
-            return fail(c, MC_EINVAL, "mc_add_reads_packed_dev: read_offsets not monotone at %llu",
-                        (unsigned long long)i);
     return add_reads_impl(c, d_words, d_off, h_off.data(), n_reads);
 }
 
@@ -1139,24 +1202,6 @@ void mc_bfs_result_free(mc_bfs_result *r)
 
 namespace {
 
-struct BfsJobBuffers {
-    BfsState S{};
-    uint64_t *d_seed_hi = nullptr, *d_seed_lo = nullptr;
-    void free_arrays()
-    {
-        (void)hipFree(S.hi); (void)hipFree(S.lo); (void)hipFree(S.dist); (void)hipFree(S.cov);
-        (void)hipFree(S.flags); (void)hipFree(S.vis);
-        S.hi = S.lo = nullptr; S.dist = nullptr; S.cov = nullptr; S.flags = nullptr; S.vis = nullptr;
-    }
-    ~BfsJobBuffers()
-    {
-        free_arrays();
-        (void)hipFree(S.ctl);
-        (void)hipFree(d_seed_hi);
-        (void)hipFree(d_seed_lo);
-    }
-};
-
 int bfs_alloc(mc_ctx *c, BfsState &S, uint64_t dcap)
 {
     S.dcap = dcap;
@@ -1275,24 +1320,37 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
         if (rc) return rc;
     }
 
-    std::vector<BfsJobBuffers> B(n_jobs);
+    while (c->bfs_pool.size() < n_jobs) c->bfs_pool.emplace_back(new BfsJobBuffers);
+    auto &B = c->bfs_pool;
     for (uint32_t j = 0; j < n_jobs; j++) {
-        BfsState &S = B[j].S;
+        BfsJobBuffers &J = *B[j];
+        BfsState &S = J.S;
         const uint64_t ns = jobs[j].n_seeds;
-        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&B[j].d_seed_lo), std::max<uint64_t>(ns, 1) * 8));
-        if (ns) HIPCHK(c, hipMemcpyAsync(B[j].d_seed_lo, jobs[j].seed_lo, ns * 8, hipMemcpyHostToDevice, c->stream));
-        if (jobs[j].seed_hi) {
-            HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&B[j].d_seed_hi), std::max<uint64_t>(ns, 1) * 8));
-            if (ns) HIPCHK(c, hipMemcpyAsync(B[j].d_seed_hi, jobs[j].seed_hi, ns * 8, hipMemcpyHostToDevice, c->stream));
+        if (J.seed_cap < std::max<uint64_t>(ns, 1)) {
+            (void)hipFree(J.d_seed_lo); (void)hipFree(J.d_seed_hi);
+            J.d_seed_lo = J.d_seed_hi = nullptr;
+            J.seed_cap = 0;
+            HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&J.d_seed_lo), std::max<uint64_t>(ns, 1) * 8));
+            HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&J.d_seed_hi), std::max<uint64_t>(ns, 1) * 8));
+            J.seed_cap = std::max<uint64_t>(ns, 1);
         }
+        if (ns) HIPCHK(c, hipMemcpyAsync(J.d_seed_lo, jobs[j].seed_lo, ns * 8, hipMemcpyHostToDevice, c->stream));
+        if (ns && jobs[j].seed_hi)
+            HIPCHK(c, hipMemcpyAsync(J.d_seed_hi, jobs[j].seed_hi, ns * 8, hipMemcpyHostToDevice, c->stream));
         const uint64_t dcap = max_kmers >= 0 ? std::max<uint64_t>((uint64_t)max_kmers, ns) + 2 * BFS_THREADS
                                              : std::max<uint64_t>(1ull << 20, ns + 2 * BFS_THREADS);
-        int rc = bfs_alloc(c, S, dcap);
-        if (rc) return rc;
-        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&S.ctl), sizeof(BfsCtl)));
+        if (S.dcap < dcap || S.dcap > 4 * dcap || !S.hi) {
+            J.free_arrays();
+            int rc = bfs_alloc(c, S, dcap);
+            if (rc) return rc;
+        } else {  // reuse: only the index and the flags need clearing
+            HIPCHK(c, hipMemsetAsync(S.vis, 0xFF, (S.bmask + 1) * 16, c->stream));
+            HIPCHK(c, hipMemsetAsync(S.flags, 0, S.dcap * 4, c->stream));
+        }
+        if (!S.ctl) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&S.ctl), sizeof(BfsCtl)));
         HIPCHK(c, hipMemsetAsync(S.ctl, 0, sizeof(BfsCtl), c->stream));
-        S.seed_hi = B[j].d_seed_hi;
-        S.seed_lo = B[j].d_seed_lo;
+        S.seed_hi = jobs[j].seed_hi ? J.d_seed_hi : nullptr;
+        S.seed_lo = J.d_seed_lo;
         S.n_seeds = ns;
         S.dir = jobs[j].dir;
     }
@@ -1302,7 +1360,7 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
     std::vector<BfsCtl> ctl(n_jobs);
     const unsigned long long max_rounds = 1ull << 17;  // bounds one launch; unfinished jobs are relaunched
     for (;;) {
-        for (uint32_t j = 0; j < n_jobs; j++) h_states[j] = B[j].S;
+        for (uint32_t j = 0; j < n_jobs; j++) h_states[j] = B[j]->S;
         HIPCHK(c, hipMemcpyAsync(d_states.p, h_states.data(), n_jobs * sizeof(BfsState), hipMemcpyHostToDevice,
                                  c->stream));
         int rc = timed(c, &total_ms,
@@ -1310,12 +1368,12 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
         if (rc) return rc;
         bool all_done = true;
         for (uint32_t j = 0; j < n_jobs; j++) {
-            HIPCHK(c, hipMemcpy(&ctl[j], B[j].S.ctl, sizeof(BfsCtl), hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(&ctl[j], B[j]->S.ctl, sizeof(BfsCtl), hipMemcpyDeviceToHost));
             if (ctl[j].status == BFS_DONE) continue;
             all_done = false;
             if (ctl[j].status != BFS_NEED_GROW) continue;
             // grow distanceToKmer and its index (only reachable without --maxkmers)
-            BfsState &S = B[j].S;
+            BfsState &S = B[j]->S;
             BfsState N = S;
             N.hi = N.lo = nullptr; N.dist = nullptr; N.cov = nullptr; N.flags = nullptr; N.vis = nullptr;
             rc = bfs_alloc(c, N, S.dcap * 2);
@@ -1333,7 +1391,7 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
             const int running = BFS_RUNNING;
             HIPCHK(c, hipMemcpyAsync(&S.ctl->status, &running, sizeof running, hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            B[j].free_arrays();
+            B[j]->free_arrays();
             S = N;
         }
         if (all_done) break;
@@ -1341,7 +1399,7 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
 
     int ret = MC_OK;
     for (uint32_t j = 0; j < n_jobs; j++) {
-        const BfsState &S = B[j].S;
+        const BfsState &S = B[j]->S;
         const uint64_t n = ctl[j].n;
         mc_bfs_result *o = &out[j];
         o->lookups = ctl[j].lookups;
