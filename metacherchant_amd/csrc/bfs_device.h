@@ -185,19 +185,6 @@ __device__ __forceinline__ uint32_t block_scan_flag(bool flag, uint32_t *lds_wav
     return before + in_wave;
 }
 
-// table lookup with the first two probe slots already loaded
-__device__ __forceinline__ int table_get2(const TableView &t, uint64_t key, const uint4 &r0, const uint4 &r1)
-{
-    if (key == EMPTY_KEY) return table_get(t, key);
-    const uint64_t k0 = ((uint64_t)r0.y << 32) | r0.x;
-    if (k0 == key) return r0.z > 32767u ? 32767 : (int)r0.z;
-    if (k0 == EMPTY_KEY) return -1;
-    const uint64_t k1 = ((uint64_t)r1.y << 32) | r1.x;
-    if (k1 == key) return r1.z > 32767u ? 32767 : (int)r1.z;
-    if (k1 == EMPTY_KEY) return -1;
-    return table_get(t, key);  // both probes hit other keys: walk the region
-}
-
 struct WideLds {
     Kmer kmer[BFS_THREADS];
     uint32_t set[WH_SIZE];
@@ -211,9 +198,9 @@ struct NarrowLds {
     Kmer root[NARROW_CAND];           // the walkers
     Kmer pub_k[MAX_NODES];            // accepted in the last round, to be indexed
     uint32_t pub_idx[MAX_NODES];
-    uint32_t rhint[NARROW_CAND], nhint[NARROW_CAND];  // their oriented hints (walker_hint)
+    uint64_t rhint[NARROW_CAND], nhint[NARROW_CAND];  // their oriented hints (walker_hint)
+    uint64_t nslot[MAX_NODES];        // solid-table slot of each level-1 node (one-level replay)
     int16_t cov[MAX_NODES];
-    uint32_t aux[MAX_NODES];
     uint8_t vis[MAX_NODES];
     uint8_t flip[MAX_NODES];
     uint32_t set[RH_SIZE];
@@ -236,7 +223,7 @@ union BfsLds {
 // ---- wide path: one chunk of <= BFS_THREADS candidates in rank order.  parent == UINT64_MAX marks a
 // seed window (src/algo/OneSequenceCalculator.java:159-192: queued when reads.get(key) >= minOccurences).
 template <int MODE>
-__device__ void bfs_chunk_wide(const BfsState &S, const TableView &t, WideLds &L, int k, int min_cov,
+__device__ void bfs_chunk_wide(const BfsState &S, const SolidView &t, WideLds &L, int k, int min_cov,
                                long long max_kmers, bool radius_ok, bool have, const Kmer &cand, uint64_t parent,
                                int32_t new_dist, unsigned long long &lookups)
 {
@@ -248,7 +235,7 @@ __device__ void bfs_chunk_wide(const BfsState &S, const TableView &t, WideLds &L
     L.set[tid + BFS_THREADS] = LH_EMPTY;
     int cov = -1;
     if (have) {
-        cov = table_get(t, (uint64_t)key_of<MODE>(cand, k));
+        cov = solid_get(t, (uint64_t)key_of<MODE>(cand, k));
         lookups++;
     }
     const bool solid = have && cov >= min_cov;
@@ -415,37 +402,66 @@ __device__ inline uint32_t replay_slow(const BfsState &S, NarrowLds &L, int d, i
     return n_new;
 }
 
-// oriented hint of a walker: the bases it expects next, nearest first (bits 0..13), bit 14 = valid,
-// bit 15 = the walker moves right
-__device__ __forceinline__ uint32_t walker_hint(uint32_t aux, bool flipped, bool right)
+// oriented hint of a walker: the bases it expects next, nearest first (bits 0..55), how many
+// (bits 56..61), bit 62 = the walker moves right
+__device__ __forceinline__ uint64_t walker_hint(uint64_t hr, uint64_t hl, bool flipped, bool right)
 {
-    const uint32_t R = aux & 0x3FFFu, L = (aux >> 16) & 0x3FFFu;
-    const bool RV = (aux & HINT_RV) != 0, LV = (aux & HINT_LV) != 0;
-    uint32_t f;
-    bool v;
-    if (right) { f = flipped ? (L ^ 0x3FFFu) : R; v = flipped ? LV : RV; }
-    else       { f = flipped ? (R ^ 0x3FFFu) : L; v = flipped ? RV : LV; }
-    return f | (v ? 0x4000u : 0u) | (right ? 0x8000u : 0u);
+    uint64_t w = right ? (flipped ? hl : hr) : (flipped ? hr : hl);
+    if (flipped) w = lh_complement(w);
+    return (w & ~(3ull << 62)) | (right ? (1ull << 62) : 0);
 }
 
-// table lookup with the first two probe slots already loaded; also returns the slot's hint word
-__device__ __forceinline__ int table_get2_aux(const TableView &t, uint64_t key, const uint4 &r0, const uint4 &r1,
-                                              uint32_t *aux)
+// the vertex a walker reaches after i expected steps (i <= LHINT_MAX <= 28 < k is not required: i <= 28 and
+// the shifts below stay under 64 bits)
+__device__ __forceinline__ Kmer walker_at(const Kmer &root, int k, uint64_t hint, uint32_t i)
 {
-    *aux = 0;
-    if (key == EMPTY_KEY) return table_get(t, key);
-    const uint64_t k0 = ((uint64_t)r0.y << 32) | r0.x;
-    if (k0 == key) { *aux = r0.w; return r0.z > 32767u ? 32767 : (int)r0.z; }
+    if (i == 0) return root;
+    const bool right = (hint >> 62) & 1;
+    const uint32_t sh = 2 * i;  // 2 .. 56
+    Kmer r;
+    if (right) {  // ((root << 2i) | bases[0..i) with base 0 first) & mask
+        const uint64_t blk = lh_block_forward(hint, i);
+        r.hi = (root.hi << sh) | (root.lo >> (64 - sh));
+        r.lo = (root.lo << sh) | blk;
+        if (k <= 32) {
+            r.hi = 0;
+            if (k < 32) r.lo &= (1ull << (2 * k)) - 1;
+        } else {
+            r.hi &= (1ull << (2 * k - 64)) - 1;
+        }
+    } else {  // (root >> 2i) | (bases[i-1] ... bases[0]) << 2(k-i): the stored order already has base i-1 on top
+        const uint64_t blk = hint & lh_mask(i);
+        r.lo = (root.lo >> sh) | (root.hi << (64 - sh));
+        r.hi = root.hi >> sh;
+        const int pos = 2 * (k - (int)i);  // bit position of the block, >= 0 when i <= k
+        if (pos >= 64) {
+            r.hi |= blk << (pos - 64);
+        } else {
+            r.lo |= blk << pos;
+            if (pos > 0 && pos + (int)sh > 64) r.hi |= blk >> (64 - pos);
+        }
+    }
+    return r;
+}
+
+// lookup with the key/count halves of the first two probe slots already loaded
+__device__ __forceinline__ int solid_get2(const SolidView &t, uint64_t key, uint64_t s0, uint64_t s1, const uint4 &a0,
+                                          const uint4 &a1, uint64_t *found_slot)
+{
+    *found_slot = ~0ull;
+    if (key == EMPTY_KEY) return solid_get(t, key);
+    const uint64_t k0 = ((uint64_t)a0.y << 32) | a0.x;
+    if (k0 == key) { *found_slot = s0; return a0.z > 32767u ? 32767 : (int)a0.z; }
     if (k0 == EMPTY_KEY) return -1;
-    const uint64_t k1 = ((uint64_t)r1.y << 32) | r1.x;
-    if (k1 == key) { *aux = r1.w; return r1.z > 32767u ? 32767 : (int)r1.z; }
+    const uint64_t k1 = ((uint64_t)a1.y << 32) | a1.x;
+    if (k1 == key) { *found_slot = s1; return a1.z > 32767u ? 32767 : (int)a1.z; }
     if (k1 == EMPTY_KEY) return -1;
-    uint64_t s = slot_of(t, key);  // both probes hit other keys: walk the region
+    uint64_t s = s0;  // both probes hit other keys: walk the region
     const uint64_t base = s & ~(uint64_t)t.rmask;
     for (uint32_t probe = 0; probe <= t.rmask; probe++) {
         const uint4 raw = *reinterpret_cast<const uint4 *>(t.slots + s);
         const uint64_t cur = ((uint64_t)raw.y << 32) | raw.x;
-        if (cur == key) { *aux = raw.w; return raw.z > 32767u ? 32767 : (int)raw.z; }
+        if (cur == key) { *found_slot = s; return raw.z > 32767u ? 32767 : (int)raw.z; }
         if (cur == EMPTY_KEY) return -1;
         s = base | ((s + 1) & t.rmask);
     }
@@ -459,14 +475,14 @@ __device__ __forceinline__ int table_get2_aux(const TableView &t, uint64_t key, 
 //
 // A round looks up, in ONE memory round trip, the neighbours of every walker and of the next
 // H - 1 vertices each walker is EXPECTED to visit (the hint stored with the walker's k-mer says
-// which bases followed it in some read).  Then it counts the leading levels J in which every
+// which bases followed it in the reads).  Then it counts the leading levels J in which every
 // walker's neighbourhood held exactly what the sequential BFS needs to add exactly the expected
 // vertex (anything else that is solid there is already in distanceToKmer): those F*J vertices are
 // appended in level-major order, which is the sequential discovery order.  The first level that
 // holds anything else (a branch, a dead end, a wrong hint, a cycle, the cap, the radius) is left
 // to the exact one-level replay with the LDS set (replay_slow).  Hints only steer the guess.
 template <int MODE>
-__device__ void bfs_narrow(const BfsState &S, const TableView &t, NarrowLds &L, int k, int min_cov,
+__device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, int k, int min_cov,
                            long long max_kmers, long long max_radius, unsigned long long &rounds_left,
                            unsigned long long &lookups)
 {
@@ -495,7 +511,7 @@ __device__ void bfs_narrow(const BfsState &S, const TableView &t, NarrowLds &L, 
             r.hi = S.hi[di];
             r.lo = S.lo[di];
             L.root[lane] = r;
-            L.rhint[lane] = dir > 0 ? 0x8000u : 0u;  // no hint yet: the first round is a plain one-level round
+            L.rhint[lane] = dir > 0 ? (1ull << 62) : 0;  // no hint yet: the first round is a plain one-level round
         }
         const bool any = __ballot(dup) != 0;
         if (lane == 0) {
@@ -518,60 +534,60 @@ __device__ void bfs_narrow(const BfsState &S, const TableView &t, NarrowLds &L, 
         rounds++;
 
         const bool capped0 = max_kmers >= 0 && (long long)n >= max_kmers;
-        const long long room = max_radius < 0 ? (long long)HINT_LEN : max_radius - level;  // levels that may still add
+        const long long room = max_radius < 0 ? (long long)LHINT_MAX : max_radius - level;  // levels that may still add
         const uint32_t FN = F << lg;  // nodes per level
-        // every walker needs a valid hint for a multi-level round
-        const uint32_t myh = lane < F ? L.rhint[lane] : 0x4000u;
-        const bool hints_ok = __ballot(!(myh & 0x4000u)) == 0;
+        // the round is as deep as the shortest hint among the walkers
+        uint32_t myl = lane < F ? lh_len(L.rhint[lane]) : (uint32_t)LHINT_MAX;
+        if (myl > (uint32_t)k) myl = (uint32_t)k;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) myl = min(myl, (uint32_t)__shfl_xor((int)myl, o));
         uint32_t H = 1;
-        if (hints_ok && !capped0 && room >= 1 && !L.any_dup_root) {
-            H = (uint32_t)MAX_NODES / FN;
-            if (H > (uint32_t)HINT_LEN) H = HINT_LEN;
+        if (myl >= 2 && !capped0 && room >= 1 && !L.any_dup_root) {
+            H = min(myl, (uint32_t)MAX_NODES / FN);
             if ((long long)H > room) H = (uint32_t)room;
             if (max_kmers >= 0) {
                 const unsigned long long fit = ((unsigned long long)max_kmers - n) / F;  // whole levels under the cap
                 if (fit < H) H = fit < 1 ? 1 : (uint32_t)fit;
             }
+            if (H < 1) H = 1;
         }
         const uint32_t NT = H * FN;
 
         // ---- speculate: node (i, a, c) = c-th neighbour of the vertex walker a is expected to reach after i-1 steps
         MC_STAMP(0);
         Kmer nk[NPL];
-        uint64_t tkey[NPL];
-        uint4 r0[NPL], r1[NPL];
-        uint32_t ni[NPL], na[NPL], nc[NPL];
+        uint64_t tkey[NPL], ts0[NPL], ts1[NPL];
+        uint4 a0[NPL], a1[NPL];
+        uint32_t ni[NPL], na[NPL];
         bool npred[NPL], nflip[NPL];
 #pragma unroll
         for (int u = 0; u < NPL; u++) {
             const uint32_t id = lane + 64u * (uint32_t)u;
             nk[u] = Kmer{0, 0};
-            tkey[u] = 0;
-            r0[u] = make_uint4(0, 0, 0, 0);
-            r1[u] = r0[u];
-            ni[u] = 0; na[u] = 0; nc[u] = 0;
+            tkey[u] = 0; ts0[u] = 0; ts1[u] = 0;
+            a0[u] = make_uint4(0, 0, 0, 0);
+            a1[u] = a0[u];
+            ni[u] = 0; na[u] = 0;
             npred[u] = false; nflip[u] = false;
             if (id < NT) {
                 uint32_t i = 1, r = id;
                 while (r >= FN) { r -= FN; i++; }
                 const uint32_t a = r >> lg, c = r & (uint32_t)(nb - 1);
-                const uint32_t h = L.rhint[a];
-                const bool right = (h & 0x8000u) != 0;
-                Kmer v = L.root[a];
-                for (uint32_t st = 1; st < i; st++)  // the expected path so far
-                    v = neighbour(v, k, right ? 1 : -1, (int)((h >> (2 * (st - 1))) & 3u));
-                const uint32_t hb = (h >> (2 * (i - 1))) & 3u;  // expected step i
+                const uint64_t h = L.rhint[a];
+                const bool right = (h >> 62) & 1;
+                const Kmer v = walker_at(L.root[a], k, h, i - 1);  // the expected path so far
+                const uint32_t hb = (uint32_t)(h >> (2 * (i - 1))) & 3u;  // expected step i
                 const uint32_t cstar = dir == 0 ? (2 * hb + (right ? 1u : 0u)) : hb;
                 nk[u] = neighbour(v, k, dir, (int)c);
-                ni[u] = i; na[u] = a; nc[u] = c;
+                ni[u] = i; na[u] = a;
                 npred[u] = H > 1 && c == cstar;
                 bool fl;
                 tkey[u] = (uint64_t)key_of<MODE>(nk[u], k, &fl);
                 nflip[u] = fl;
-                const uint64_t s0 = slot_of(t, tkey[u]);
-                const uint64_t s1 = (s0 & ~(uint64_t)t.rmask) | ((s0 + 1) & t.rmask);
-                r0[u] = *reinterpret_cast<const uint4 *>(t.slots + s0);
-                r1[u] = *reinterpret_cast<const uint4 *>(t.slots + s1);
+                ts0[u] = solid_slot_of(t, tkey[u]);
+                ts1[u] = (ts0[u] & ~(uint64_t)t.rmask) | ((ts0[u] + 1) & t.rmask);
+                a0[u] = *reinterpret_cast<const uint4 *>(t.slots + ts0[u]);
+                a1[u] = *reinterpret_cast<const uint4 *>(t.slots + ts1[u]);
                 lookups++;
             }
         }
@@ -581,14 +597,14 @@ __device__ void bfs_narrow(const BfsState &S, const TableView &t, NarrowLds &L, 
         pend = 0;
         MC_STAMP(1);
         int cov[NPL];
-        uint32_t naux[NPL];
+        uint64_t nslot[NPL];
 #pragma unroll
         for (int u = 0; u < NPL; u++) {
             const uint32_t id = lane + 64u * (uint32_t)u;
             cov[u] = -1;
-            naux[u] = 0;
+            nslot[u] = ~0ull;
             if (id < NT) {
-                cov[u] = table_get2_aux(t, tkey[u], r0[u], r1[u], &naux[u]);
+                cov[u] = solid_get2(t, tkey[u], ts0[u], ts1[u], a0[u], a1[u], &nslot[u]);
                 L.cov[id] = (int16_t)cov[u];
                 L.kmer[id] = nk[u];
                 if (npred[u]) L.pk[(ni[u] - 1) * F + na[u]] = nk[u];
@@ -651,9 +667,10 @@ __device__ void bfs_narrow(const BfsState &S, const TableView &t, NarrowLds &L, 
                         S.cov[idx] = (int16_t)cov[u];
                         L.pub_k[(i - 1) * F + a] = nk[u];
                         L.pub_idx[(i - 1) * F + a] = (uint32_t)idx;
-                        if (i == J) {  // the walker's new position
-                            const bool right = (L.rhint[a] & 0x8000u) != 0;
-                            L.nhint[a] = walker_hint(naux[u], nflip[u], right);
+                        if (i == J) {  // the walker's new position and its own hint
+                            const bool right = (L.rhint[a] >> 62) & 1;
+                            const SolidSlot *sl = t.slots + nslot[u];
+                            L.nhint[a] = nslot[u] == ~0ull ? (right ? (1ull << 62) : 0) : walker_hint(sl->hr, sl->hl, nflip[u], right);
                             L.fl_idx[cur ^ 1][a] = (uint32_t)idx;
                         }
                     } else if (solid[u]) {  // solid but already there: lastKmers.add(parent)
@@ -687,9 +704,11 @@ __device__ void bfs_narrow(const BfsState &S, const TableView &t, NarrowLds &L, 
 #pragma unroll
             for (int u = 0; u < NPL; u++) {
                 const uint32_t id = lane + 64u * (uint32_t)u;
-                if (id < FN) L.aux[id] = naux[u] | 0u;
-                if (id < FN) L.flip[id] = nflip[u] ? 1 : 0;
-                if (id < FN && H > 1) L.vis[id] = (solid[u] && vis_find(S, nk[u])) ? 1 : 0;  // index only, no expectations
+                if (id < FN) {
+                    L.nslot[id] = nslot[u];
+                    L.flip[id] = nflip[u] ? 1 : 0;
+                    if (H > 1) L.vis[id] = (solid[u] && vis_find(S, nk[u])) ? 1 : 0;  // index only, no expectations
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             n_new = replay_slow(S, L, 1, min_cov, max_kmers, max_radius, lg, flim, &last_base);
@@ -699,12 +718,14 @@ __device__ void bfs_narrow(const BfsState &S, const TableView &t, NarrowLds &L, 
             const uint32_t Fn = L.F;
             const int c2 = L.cur;
             Kmer nr{0, 0};
-            uint32_t nh = 0;
+            uint64_t nh = 0;
             if (lane < Fn && Fn <= flim) {
                 const uint32_t id = last_base + L.fl_w[c2][lane];
                 nr = L.kmer[id];
                 const bool right = dir > 0 || (dir == 0 && (id & 1u));  // odd neighbour index = right neighbour
-                nh = walker_hint(L.aux[id], L.flip[id] != 0, right);
+                const uint64_t sl = L.nslot[id];
+                nh = sl == ~0ull ? (right ? (1ull << 62) : 0)
+                                 : walker_hint(t.slots[sl].hr, t.slots[sl].hl, L.flip[id] != 0, right);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             if (lane < Fn && Fn <= flim) {
@@ -736,7 +757,7 @@ __device__ void bfs_narrow(const BfsState &S, const TableView &t, NarrowLds &L, 
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(BFS_THREADS) k_bfs(const BfsState *__restrict__ states, TableView t, int k,
+__global__ void __launch_bounds__(BFS_THREADS) k_bfs(const BfsState *__restrict__ states, SolidView t, int k,
                                                      int min_cov, long long max_kmers, long long max_radius,
                                                      unsigned long long max_rounds)
 {

@@ -28,6 +28,7 @@ constexpr int PT_TILE = PT_THREADS * PT_ITEMS;      // 8192 windows / keys per t
 constexpr int PT_MAX_BUCKETS = 512;                 // fan-out of one scatter level
 constexpr int P3_THREADS = 512;
 constexpr uint32_t REGION_SLOTS = 4096;             // == 1 << mc_ctx::sb
+constexpr uint32_t CURSOR1_STRIDE = 32;             // level-1 bucket cursors sit on separate 128-byte lines
 
 struct ScatterLds {
     uint64_t key[PT_TILE];
@@ -63,7 +64,7 @@ __device__ __forceinline__ void spill_push(const SpillView &sp, uint64_t key, ui
 // out_*[d * cap .. (d+1) * cap); what does not fit goes to the spill list (drained by the direct kernel).
 __device__ __forceinline__ void scatter_tile(ScatterLds &L, const uint64_t (&key)[PT_ITEMS], const uint32_t (&hint)[PT_ITEMS],
                                              const uint32_t (&dig)[PT_ITEMS], const bool (&valid)[PT_ITEMS],
-                                             uint32_t n_buckets, uint32_t *cursors, uint64_t cap, uint64_t *out_keys,
+                                             uint32_t n_buckets, uint32_t *cursors, uint32_t cstride, uint64_t cap, uint64_t *out_keys,
                                              uint32_t *out_hints, uint64_t out_base, const SpillView &sp)
 {
     const uint32_t tid = threadIdx.x;
@@ -87,7 +88,7 @@ __device__ __forceinline__ void scatter_tile(ScatterLds &L, const uint64_t (&key
         for (uint32_t i = 0; i < wv; i++) before += L.wave_tot[i];
         if (tid < n_buckets) {
             L.off[tid] = before + x - c;
-            L.gbase[tid] = c ? atomicAdd(&cursors[tid], c) : 0u;  // one global atomic per (tile, bucket)
+            L.gbase[tid] = c ? atomicAdd(&cursors[(uint64_t)tid * cstride], c) : 0u;  // one global atomic per (tile, bucket)
         }
         if (tid == PT_THREADS - 1) L.n_valid = before + x;
     }
@@ -141,7 +142,23 @@ __device__ __forceinline__ uint64_t starts_window(const uint32_t *bits, uint32_t
     return s ? ((lo >> s) | (hi << (64 - s))) : lo;
 }
 
-// P1: tiles of PT_TILE consecutive base positions of the packed read set.
+__device__ __forceinline__ uint32_t base_or0(const uint64_t *__restrict__ words, uint64_t q, uint64_t n_bases)
+{
+    return q < n_bases ? (uint32_t)(words[q >> 5] >> (62 - 2 * (q & 31))) & 3u : 0u;
+}
+
+__device__ __forceinline__ uint64_t bits128(uint64_t lo, uint64_t hi, uint32_t from, uint32_t cnt)
+{  // cnt <= 63 bits of the 128-bit word hi:lo starting at bit `from`
+    if (cnt == 0) return 0;
+    uint64_t x;
+    if (from >= 64) x = hi >> (from - 64);
+    else x = from ? ((lo >> from) | (hi << (64 - from))) : lo;
+    return x & ((1ull << cnt) - 1);
+}
+
+// P1: tiles of PT_TILE consecutive base positions of the packed read set.  A thread owns PT_ITEMS
+// CONSECUTIVE positions and rolls the window along them (the reference's ShortKmer.shiftRight,
+// itmo!/dna/kmers/ShortKmer.java:68-71): one new base per step instead of a fresh extraction.
 template <int MODE>
 __global__ void __launch_bounds__(PT_THREADS) k_p1_extract_scatter(
     const uint64_t *__restrict__ words, const uint64_t *__restrict__ offsets, uint64_t n_reads, uint64_t base_lo,
@@ -151,44 +168,60 @@ __global__ void __launch_bounds__(PT_THREADS) k_p1_extract_scatter(
     __shared__ ScatterLds L;
     const uint32_t tid = threadIdx.x;
     const uint32_t n_buckets = 1u << b1;
-    constexpr uint32_t MARGIN = 64;  // bitmap starts this many bases left of the tile
+    constexpr int64_t MARGIN = 64;  // the bitmap starts this many bases left of the tile (virtually, for tile 0)
+    const uint64_t kmask = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1);
     for (uint64_t tile = base_lo / PT_TILE + blockIdx.x; tile < n_tiles; tile += gridDim.x) {  // reads cover [base_lo, n_bases)
         const uint64_t lo = tile * (uint64_t)PT_TILE;
-        const uint64_t bm_lo = lo >= MARGIN ? lo - MARGIN : 0;        // first position the bitmap covers
-        const uint64_t bm_hi = lo + PT_TILE + 128;                     // one past the last
+        const int64_t bm_lo = (int64_t)lo - MARGIN;                    // position of bit 0 of the bitmap
+        const uint64_t bm_hi = lo + PT_TILE + 128;                      // one past the last position it covers
         for (uint32_t i = tid; i < sizeof(L.starts) / 4; i += PT_THREADS) L.starts[i] = 0;
         if (tid < n_buckets) L.cnt[tid] = 0;
         __syncthreads();
         for (uint64_t r = (uint64_t)first_read[tile] + tid; r < n_reads; r += PT_THREADS) {
             const uint64_t s = offsets[r];
             if (s >= bm_hi) break;
-            if (s >= bm_lo) atomicOr(&L.starts[(uint32_t)(s - bm_lo) >> 5], 1u << ((uint32_t)(s - bm_lo) & 31));
+            const int64_t rel = (int64_t)s - bm_lo;
+            if (rel >= 0) atomicOr(&L.starts[(uint32_t)rel >> 5], 1u << ((uint32_t)rel & 31));
         }
         __syncthreads();
         uint64_t key[PT_ITEMS];
         uint32_t hint[PT_ITEMS], dig[PT_ITEMS];
         bool valid[PT_ITEMS];
 #pragma unroll
-        for (int j = 0; j < PT_ITEMS; j++) {
-            const uint64_t p = lo + tid + (uint64_t)j * PT_THREADS;
-            key[j] = 0; hint[j] = 0; dig[j] = 0;
-            valid[j] = false;
-            if (p >= base_lo && p + (uint64_t)k <= n_bases) {
-                const uint32_t rel = (uint32_t)(p - bm_lo);
+        for (int j = 0; j < PT_ITEMS; j++) { key[j] = 0; hint[j] = 0; dig[j] = 0; valid[j] = false; }
+        const uint64_t p0 = lo + (uint64_t)tid * PT_ITEMS;
+        if (p0 + (uint64_t)k <= n_bases) {
+            // read-start bits around my positions: position q <-> bit q - (p0 - 8)
+            const uint32_t wrel = (uint32_t)((int64_t)p0 - 8 - bm_lo);
+            const uint64_t w_lo = starts_window(L.starts, wrel), w_hi = starts_window(L.starts, wrel + 64);
+            Kmer v = extract_kmer(words, p0, k);
+            uint64_t rc = MODE == KEY_PACKED ? rc_packed(v.lo, k) : 0;
+            uint32_t r7 = 0, l7 = 0;  // the HINT_LEN bases after / before the window, nearest first
+#pragma unroll
+            for (int i = 0; i < HINT_LEN; i++) {
+                r7 |= base_or0(words, p0 + (uint64_t)k + (uint64_t)i, n_bases) << (2 * i);
+                if (p0 >= (uint64_t)(i + 1)) l7 |= base_or0(words, p0 - 1 - (uint64_t)i, n_bases) << (2 * i);
+            }
+#pragma unroll
+            for (int j = 0; j < PT_ITEMS; j++) {
+                const uint64_t p = p0 + (uint64_t)j;
+                if (p + (uint64_t)k > n_bases) break;
+                const uint32_t b = 8 + (uint32_t)j;
                 // the window [p, p+k) lies inside one read iff no read starts at p+1 .. p+k-1
-                const uint64_t inside = starts_window(L.starts, rel + 1);
-                const uint64_t m = k >= 2 ? (~0ull >> (64 - (k - 1))) : 0ull;
-                if ((inside & m) == 0) {
-                    const Kmer v = extract_kmer(words, p, k);
+                if (p >= base_lo && bits128(w_lo, w_hi, b + 1, (uint32_t)(k - 1)) == 0) {
                     bool flipped;
-                    key[j] = (uint64_t)key_of<MODE>(v, k, &flipped);
-                    // context: HINT_LEN bases to the right inside the read <=> no start in p+1 .. p+k+HINT_LEN-1 and in range;
-                    //          HINT_LEN bases to the left  <=> no start in p-HINT_LEN+1 .. p and p >= HINT_LEN
-                    const bool rv = p + (uint64_t)k + HINT_LEN <= n_bases &&
-                                    (starts_window(L.starts, rel + 1 + (uint32_t)(k - 1)) & ((1ull << HINT_LEN) - 1)) == 0;
-                    const bool lv = p >= (uint64_t)HINT_LEN && rel >= (uint32_t)HINT_LEN &&
-                                    (starts_window(L.starts, rel - HINT_LEN + 1) & ((1ull << HINT_LEN) - 1)) == 0;
-                    hint[j] = hint_of(words, p, k, lv ? 0 : p, rv ? n_bases : 0, flipped);
+                    if (MODE == KEY_PACKED) {
+                        flipped = rc < v.lo;
+                        key[j] = flipped ? rc : v.lo;
+                    } else {
+                        key[j] = (uint64_t)key_of<MODE>(v, k, &flipped);
+                    }
+                    // context inside the same read: no start at p+1 .. p+k+HINT_LEN-1 resp. p-HINT_LEN+1 .. p
+                    const bool rv = p + (uint64_t)k + HINT_LEN <= n_bases && bits128(w_lo, w_hi, b + (uint32_t)k, HINT_LEN) == 0;
+                    const bool lv = bits128(w_lo, w_hi, b - (HINT_LEN - 1), HINT_LEN) == 0;
+                    const uint32_t R = flipped ? (l7 ^ 0x3FFFu) : r7, Lc = flipped ? (r7 ^ 0x3FFFu) : l7;
+                    const bool RV = flipped ? lv : rv, LV = flipped ? rv : lv;
+                    hint[j] = (RV ? (R | HINT_RV) : 0u) | (LV ? ((Lc << 16) | HINT_LV) : 0u);
                     if (key[j] == EMPTY_KEY) {
                         atomicAdd(empty_cnt, 1ull);
                     } else {
@@ -196,9 +229,19 @@ __global__ void __launch_bounds__(PT_THREADS) k_p1_extract_scatter(
                         dig[j] = (uint32_t)(fmix64(key[j]) >> (64 - b1));
                     }
                 }
+                // roll to p + 1: the window takes the first base after it, loses its first base
+                const uint32_t in = r7 & 3u, out = base_at(v, k, 0);
+                if (MODE == KEY_PACKED) {
+                    v.lo = ((v.lo << 2) | in) & kmask;
+                    rc = (rc >> 2) | ((uint64_t)(3u - in) << (2 * (k - 1)));
+                } else {
+                    v = neighbour(v, k, 1, (int)in);
+                }
+                l7 = ((l7 << 2) | out) & 0x3FFFu;
+                r7 = (r7 >> 2) | (base_or0(words, p + (uint64_t)k + HINT_LEN, n_bases) << (2 * (HINT_LEN - 1)));
             }
         }
-        scatter_tile(L, key, hint, dig, valid, n_buckets, cursors, cap, out_keys, out_hints, 0, sp);
+        scatter_tile(L, key, hint, dig, valid, n_buckets, cursors, CURSOR1_STRIDE, cap, out_keys, out_hints, 0, sp);
     }
 }
 
@@ -216,7 +259,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_p2_scatter(const uint64_t *__res
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t tm = tile_map[tile];
         const uint32_t bucket = (uint32_t)(tm >> 32), first = (uint32_t)tm;
-        const uint32_t have = min(counts1[bucket], (uint32_t)cap1);
+        const uint32_t have = min(counts1[(uint64_t)bucket * CURSOR1_STRIDE], (uint32_t)cap1);
         if (tid < n_buckets) L.cnt[tid] = 0;
         __syncthreads();
         uint64_t key[PT_ITEMS];
@@ -234,7 +277,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_p2_scatter(const uint64_t *__res
                 dig[j] = (uint32_t)(fmix64(key[j]) >> (64 - b1 - b2)) & (n_buckets - 1);
             }
         }
-        scatter_tile(L, key, hint, dig, valid, n_buckets, cursors2 + (uint64_t)bucket * n_buckets, cap2, out_keys, out_hints,
+        scatter_tile(L, key, hint, dig, valid, n_buckets, cursors2 + (uint64_t)bucket * n_buckets, 1, cap2, out_keys, out_hints,
                      (uint64_t)bucket * n_buckets * cap2, sp);
     }
 }

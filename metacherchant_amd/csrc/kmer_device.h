@@ -275,6 +275,97 @@ __device__ __forceinline__ uint32_t table_add(const TableView &t, uint64_t key, 
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The "solid" table: the BFS's private copy of the keys with count >= --coverage, at a load factor
+// <= 1/4 so that its (mostly negative) lookups end at the first probe, with 32-byte slots that also
+// carry LONG speculation hints: up to LHINT_MAX bases of read context on either side.  They start
+// as the 7-base hints of the counting table and are doubled twice (7 -> 14 -> 28) by chaining:
+// the hint of x names the vertex y reached after following it, and y's own hint continues it.
+constexpr int LHINT_MAX = 28;
+constexpr uint64_t LH_BASES = (1ull << 56) - 1;
+
+struct SolidSlot {
+    uint64_t key;
+    uint32_t count;
+    uint32_t pad;
+    uint64_t hr, hl;  // bits 0..55: bases, nearest first, 2 bits each; bits 56..61: how many
+};
+
+struct SolidView {
+    SolidSlot *slots;
+    uint32_t shift;  // 64 - log2(#slots)
+    uint32_t rmask;  // region size - 1 (probing wraps inside a region, as in the counting table)
+    unsigned long long *empty_cnt;
+    uint32_t *fatal;
+};
+
+__host__ __device__ __forceinline__ uint32_t lh_len(uint64_t w) { return (uint32_t)(w >> 56) & 63u; }
+__host__ __device__ __forceinline__ uint64_t lh_mask(uint32_t n) { return n >= 32 ? ~0ull : ((1ull << (2 * n)) - 1); }
+__host__ __device__ __forceinline__ uint64_t lh_make(uint64_t bases, uint32_t n)
+{
+    if (n > (uint32_t)LHINT_MAX) n = LHINT_MAX;
+    return (bases & lh_mask(n)) | ((uint64_t)n << 56);
+}
+__host__ __device__ __forceinline__ uint64_t lh_complement(uint64_t w)
+{
+    const uint32_t n = lh_len(w);
+    return ((w ^ lh_mask(n)) & LH_BASES & lh_mask(n)) | ((uint64_t)n << 56);
+}
+// the first n bases of a nearest-first field as one block with base 0 most significant
+__device__ __forceinline__ uint64_t lh_block_forward(uint64_t w, uint32_t n)
+{
+    if (n == 0) return 0;
+    uint64_t x = __brevll(w & lh_mask(n));
+    x = ((x & 0x5555555555555555ull) << 1) | ((x >> 1) & 0x5555555555555555ull);
+    return x >> (64 - 2 * n);
+}
+
+__device__ __forceinline__ uint64_t solid_slot_of(const SolidView &t, uint64_t key) { return fmix64(key) >> t.shift; }
+
+// insert a key that is not in the table yet (the build visits every key once)
+__device__ __forceinline__ void solid_insert(const SolidView &t, uint64_t key, uint32_t count, uint32_t aux)
+{
+    uint64_t s = solid_slot_of(t, key);
+    const uint64_t base = s & ~(uint64_t)t.rmask;
+    for (uint32_t probe = 0; probe <= t.rmask; probe++) {
+        SolidSlot *p = t.slots + s;
+        if (atomicCAS(reinterpret_cast<unsigned long long *>(&p->key), (unsigned long long)EMPTY_KEY,
+                      (unsigned long long)key) == EMPTY_KEY) {
+            p->count = count;
+            p->hr = (aux & HINT_RV) ? lh_make(aux & 0x3FFFu, HINT_LEN) : 0;
+            p->hl = (aux & HINT_LV) ? lh_make((aux >> 16) & 0x3FFFu, HINT_LEN) : 0;
+            return;
+        }
+        s = base | ((s + 1) & t.rmask);
+    }
+    atomicExch(t.fatal, 1u);
+}
+
+// count (saturated) or -1; hr/hl may be null
+__device__ __forceinline__ int solid_get(const SolidView &t, uint64_t key, uint64_t *hr = nullptr, uint64_t *hl = nullptr)
+{
+    if (hr) *hr = 0;
+    if (hl) *hl = 0;
+    if (key == EMPTY_KEY) {
+        const unsigned long long c = *t.empty_cnt;
+        return c == 0 ? -1 : (c > 32767ull ? 32767 : (int)c);
+    }
+    uint64_t s = solid_slot_of(t, key);
+    const uint64_t base = s & ~(uint64_t)t.rmask;
+    for (uint32_t probe = 0; probe <= t.rmask; probe++) {
+        const uint4 raw = *reinterpret_cast<const uint4 *>(t.slots + s);
+        const uint64_t cur = ((uint64_t)raw.y << 32) | raw.x;
+        if (cur == key) {
+            if (hr) *hr = t.slots[s].hr;
+            if (hl) *hl = t.slots[s].hl;
+            return raw.z > 32767u ? 32767 : (int)raw.z;
+        }
+        if (cur == EMPTY_KEY) return -1;
+        s = base | ((s + 1) & t.rmask);
+    }
+    return -1;
+}
+
 // sum over the wave, one atomic per wave.  Every lane of the wave must call it (convergent).
 __device__ __forceinline__ void wave_add_ull(unsigned long long *p, unsigned long long v)
 {

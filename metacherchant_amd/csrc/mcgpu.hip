@@ -66,9 +66,9 @@ struct mc_ctx {
     uint64_t n_used_host = 0;
     bool finalized = false;
 
-    // "solid" table: only the keys with count >= solid_cov, at a load factor <= 1/8, so that the
-    // BFS's (mostly negative) lookups end at their first probe.  Built lazily by mc_bfs_batch.
-    Slot *solid = nullptr;
+    // "solid" table (kmer_device.h): only the keys with count >= solid_cov, sparse, with long hints.
+    // Built lazily by mc_bfs_batch; the BFS never touches the counting table.
+    SolidSlot *solid = nullptr;
     uint32_t solid_lg = 0;
     int solid_cov = -1;  // -1: not built / stale
     uint64_t n_solid = 0;
@@ -96,12 +96,14 @@ struct mc_ctx {
     } pipe;
 
     uint64_t n_slots() const { return 1ull << (rb + sb); }
-    TableView solid_view() const
+    SolidView solid_view() const
     {
-        TableView t = view();
+        SolidView t;
         t.slots = solid;
         t.shift = 64 - solid_lg;
-        t.n_used = d_ctr + 3;
+        t.rmask = (1u << sb) - 1;
+        t.empty_cnt = d_ctr + 1;
+        t.fatal = d_fatal;
         return t;
     }
     TableView view() const
@@ -217,18 +219,61 @@ __global__ void k_rehash(const Slot *__restrict__ old_slots, uint64_t n_old, Tab
 }
 
 // K6: copy the keys with count >= min_cov into the sparse "solid" table the BFS probes
-__global__ void k_build_solid(const Slot *__restrict__ slots, uint64_t n_slots, int min_cov, TableView solid)
+__global__ void k_solid_fill(SolidSlot *slots, uint64_t n)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    unsigned long long n_new = 0;
+    uint4 *p = reinterpret_cast<uint4 *>(slots);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * n; i += stride) {
+        uint4 v;
+        v.x = (i & 1) ? 0u : 0xFFFFFFFFu; v.y = v.x; v.z = 0; v.w = 0;  // first half of a slot: EMPTY key, count 0
+        p[i] = v;
+    }
+}
+
+__global__ void k_build_solid(const Slot *__restrict__ slots, uint64_t n_slots, int min_cov, SolidView solid)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += stride) {
         const uint4 raw = *reinterpret_cast<const uint4 *>(slots + i);
         const uint64_t key = ((uint64_t)raw.y << 32) | raw.x;
         if (key == EMPTY_KEY) continue;
         const int c = raw.z > 32767u ? 32767 : (int)raw.z;
-        if (c >= min_cov) n_new += table_add(solid, key, (uint32_t)c, raw.w);
+        if (c >= min_cov) solid_insert(solid, key, (uint32_t)c, raw.w);
     }
-    wave_add_ull(solid.n_used, n_new);
+}
+
+// Hint doubling (packed keys only: the key IS the k-mer).  The hint of x leads to the vertex y; y's own
+// hint, turned to x's strand, continues it.  In place: hr / hl are single 8-byte words, and a reader
+// that meets an already extended word just extends further -- any valid continuation will do.
+__global__ void k_solid_double(SolidView t, uint64_t n_slots, int k)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t kmask = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += stride) {
+        SolidSlot *p = t.slots + i;
+        const uint64_t x = p->key;
+        if (x == EMPTY_KEY) continue;
+        for (int side = 0; side < 2; side++) {
+            const uint64_t w = side == 0 ? p->hr : p->hl;
+            const uint32_t n = lh_len(w);
+            if (n == 0 || n >= (uint32_t)LHINT_MAX || n > (uint32_t)k) continue;
+            uint64_t y;
+            if (side == 0) y = ((x << (2 * n)) | lh_block_forward(w, n)) & kmask;            // x followed by its n bases
+            else y = (x >> (2 * n)) | ((w & lh_mask(n)) << (2 * (k - (int)n)));               // x preceded by them
+            const uint64_t ry = rc_packed(y, k);
+            const bool flipped = ry < y;
+            uint64_t hr, hl;
+            if (solid_get(t, flipped ? ry : y, &hr, &hl) < 0) continue;
+            // what follows (side 0) / precedes (side 1) y on x's strand
+            uint64_t cont = side == 0 ? (flipped ? lh_complement(hl) : hr) : (flipped ? lh_complement(hr) : hl);
+            const uint32_t m = lh_len(cont);
+            if (m == 0) continue;
+            const uint32_t total = n + m > (uint32_t)LHINT_MAX ? (uint32_t)LHINT_MAX : n + m;
+            const uint64_t bases = (w & lh_mask(n)) | ((cont & lh_mask(m)) << (2 * n));
+            const uint64_t nw = lh_make(bases, total);
+            if (side == 0) p->hr = nw; else p->hl = nw;
+        }
+    }
 }
 
 // windows = sum over reads of max(0, len - k + 1); also checks that the offsets never decrease
@@ -578,11 +623,11 @@ static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint6
     ENSURE(P.tile_first, P.tiles1_cap, n_tiles1);
     ENSURE(P.tile_map, P.tiles2_cap, tiles2_max);
     { uint64_t cap = P.leaves_cap; ENSURE(P.cursors2, cap, n_leaves); dummy = P.leaves_cap; ENSURE(P.leaf_state, dummy, n_leaves); dummy = P.leaves_cap; ENSURE(P.leaf_new, dummy, n_leaves); P.leaves_cap = cap; }
-    if (!P.cursors1) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.cursors1), PT_MAX_BUCKETS * sizeof(uint32_t)));
+    if (!P.cursors1) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.cursors1), PT_MAX_BUCKETS * CURSOR1_STRIDE * sizeof(uint32_t)));
     if (!P.flags) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.flags), 2 * sizeof(uint32_t)));
     if (!P.spill_count) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.spill_count), sizeof(unsigned long long)));
 #undef ENSURE
-    HIPCHK(c, hipMemsetAsync(P.cursors1, 0, PT_MAX_BUCKETS * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(P.cursors1, 0, PT_MAX_BUCKETS * CURSOR1_STRIDE * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(P.cursors2, 0, n_leaves * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(P.leaf_state, 0, n_leaves * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(P.leaf_new, 0, n_leaves * sizeof(uint32_t), c->stream));
@@ -622,8 +667,9 @@ static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint6
     });
     if (rc) return rc;
     // tile map of P2 from the level-1 bucket sizes
-    std::vector<uint32_t> cnt1(np1);
-    HIPCHK(c, hipMemcpy(cnt1.data(), P.cursors1, np1 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> cnt1raw(np1 * CURSOR1_STRIDE), cnt1(np1);
+    HIPCHK(c, hipMemcpy(cnt1raw.data(), P.cursors1, cnt1raw.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (uint64_t b = 0; b < np1; b++) cnt1[b] = cnt1raw[b * CURSOR1_STRIDE];
     std::vector<uint64_t> tmap;
     tmap.reserve(tiles2_max);
     for (uint64_t b = 0; b < np1; b++) {
@@ -1219,11 +1265,10 @@ int bfs_alloc(mc_ctx *c, BfsState &S, uint64_t dcap)
     return MC_OK;
 }
 
-// Builds (or reuses) the solid table for this threshold.  Falls back to the full table when the
-// sparse copy would not fit: the BFS is exact either way, only slower.
+// Builds (or reuses) the solid table for this threshold.
 int ensure_solid(mc_ctx *c, int min_cov, double *ms)
 {
-    if (c->solid_cov == min_cov) return MC_OK;
+    if (c->solid_cov == min_cov && c->solid) return MC_OK;
     c->solid_cov = -1;
     unsigned long long *cursor = c->d_ctr + 2;
     HIPCHK(c, hipMemsetAsync(cursor, 0, sizeof(unsigned long long), c->stream));
@@ -1235,33 +1280,24 @@ int ensure_solid(mc_ctx *c, int min_cov, double *ms)
     unsigned long long n = 0;
     HIPCHK(c, hipMemcpy(&n, cursor, sizeof n, hipMemcpyDeviceToHost));
     c->n_solid = n;
-    uint32_t lg = c->sb;
-    uint64_t factor = 8;  // slots per solid key (load factor <= 1/8)
+    uint64_t factor = 4;  // slots per solid key (load factor <= 1/4)
     if (const char *e = getenv("MC_SOLID_FACTOR")) factor = std::max<uint64_t>(2, strtoull(e, nullptr, 10));
-    while (lg < 31 && (1ull << lg) < factor * n) lg++;
-    if ((1ull << lg) < 2 * n || lg >= c->rb + c->sb) {  // no gain over the full table
-        if (c->solid) { (void)hipFree(c->solid); c->solid = nullptr; }
-        c->solid_lg = 0;
-        c->solid_cov = min_cov;
-        return MC_OK;
-    }
+    uint32_t lg = c->sb;
+    while (lg < 34 && (1ull << lg) < factor * n) lg++;
     if (!c->solid || lg != c->solid_lg) {
         if (c->solid) { (void)hipFree(c->solid); c->solid = nullptr; }
-        if (hipMalloc(reinterpret_cast<void **>(&c->solid), (sizeof(Slot)) << lg) != hipSuccess) {
-            (void)hipGetLastError();
-            c->solid = nullptr;
-            c->solid_lg = 0;
-            c->solid_cov = min_cov;
-            return MC_OK;
-        }
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->solid), sizeof(SolidSlot) << lg));
         c->solid_lg = lg;
     }
-    HIPCHK(c, hipMemsetAsync(c->d_ctr + 3, 0, sizeof(unsigned long long), c->stream));
+    const int doublings = c->cfg.key_mode == MC_KEY_PACKED ? 2 : 0;  // hash keys do not hold the k-mer
     rc = timed(c, ms, [&] {
-        hipLaunchKernelGGL(k_fill_empty, dim3(grid_for(1ull << lg, 256)), dim3(256), 0, c->stream, c->solid,
+        hipLaunchKernelGGL(k_solid_fill, dim3(grid_for(2ull << lg, 256)), dim3(256), 0, c->stream, c->solid,
                            (uint64_t)1 << lg);
         hipLaunchKernelGGL(k_build_solid, dim3(grid_for(c->n_slots(), 256)), dim3(256), 0, c->stream, c->slots,
                            c->n_slots(), min_cov, c->solid_view());
+        for (int d = 0; d < doublings; d++)
+            hipLaunchKernelGGL(k_solid_double, dim3(grid_for(1ull << lg, 256)), dim3(256), 0, c->stream, c->solid_view(),
+                               (uint64_t)1 << lg, c->cfg.k);
     });
     if (rc) return rc;
     uint32_t fatal = 0;
@@ -1274,7 +1310,7 @@ int ensure_solid(mc_ctx *c, int min_cov, double *ms)
 void launch_bfs(mc_ctx *c, const BfsState *d_states, uint32_t n_jobs, int min_cov, int64_t max_kmers,
                 int64_t max_radius, unsigned long long max_rounds)
 {
-    const TableView t = c->solid ? c->solid_view() : c->view();
+    const SolidView t = c->solid_view();
     switch (c->cfg.key_mode) {
     case MC_KEY_PACKED:
         hipLaunchKernelGGL(k_bfs<KEY_PACKED>, dim3(n_jobs), dim3(BFS_THREADS), 0, c->stream, d_states, t, c->cfg.k,
