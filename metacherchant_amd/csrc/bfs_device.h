@@ -22,8 +22,7 @@
 namespace mc {
 
 constexpr int BFS_THREADS = 512;          // 8 waves
-constexpr int NPL = 2;                    // speculative tree nodes per lane of the walking wave
-constexpr int MAX_NODES = 64 * NPL;       // neighbour sets looked up per round: levels x walkers x nb
+constexpr int MAX_NODES = BFS_THREADS;    // neighbour sets looked up per round (levels x walkers x nb): one per thread
 constexpr int MAX_DEPTH = 5;
 constexpr int NARROW_CAND = 64;           // candidates per replayed level = lanes of one wave
 constexpr int RH_SIZE = 1024;             // round-local LDS set (narrow, slow replay)
@@ -212,6 +211,7 @@ struct NarrowLds {
     unsigned long long n, lb, le, rounds_left;
     long long level;
     uint32_t F;
+    uint32_t bad_lvl, pend;
     int cur, status, any_dup_root;
 };
 
@@ -468,26 +468,26 @@ __device__ __forceinline__ int solid_get2(const SolidView &t, uint64_t key, uint
     return -1;
 }
 
-// The narrow walk (wave 0 only, no workgroup barriers inside; the other waves wait at the barrier
-// behind it).  Entered at a level boundary with a frontier of F <= NARROW_CAND / nb vertices
-// ("walkers"); returns when the frontier is empty (done), too wide, distanceToKmer is nearly full,
-// or the round budget is used up.  The state is handed back in *ctl.
+// The narrow walk.  All threads of the workgroup call it at a level boundary with a frontier of
+// F <= NARROW_CAND / nb vertices ("walkers"); it returns when the frontier is empty (done), too
+// wide, distanceToKmer is nearly full, or the round budget is used up, and hands the state back in *ctl.
 //
 // A round looks up, in ONE memory round trip, the neighbours of every walker and of the next
 // H - 1 vertices each walker is EXPECTED to visit (the hint stored with the walker's k-mer says
-// which bases followed it in the reads).  Then it counts the leading levels J in which every
-// walker's neighbourhood held exactly what the sequential BFS needs to add exactly the expected
-// vertex (anything else that is solid there is already in distanceToKmer): those F*J vertices are
-// appended in level-major order, which is the sequential discovery order.  The first level that
-// holds anything else (a branch, a dead end, a wrong hint, a cycle, the cap, the radius) is left
-// to the exact one-level replay with the LDS set (replay_slow).  Hints only steer the guess.
+// which bases followed it in the reads): one tree node per thread.  Then it finds the leading
+// levels J in which every walker's neighbourhood held exactly what the sequential BFS needs to add
+// exactly the expected vertex (anything else that is solid there is already in distanceToKmer):
+// those F*J vertices are appended in level-major order, which is the sequential discovery order.
+// The first level that holds anything else (a branch, a dead end, a wrong hint, a cycle, the cap,
+// the radius) is left to the exact one-level replay with the LDS set (replay_slow, wave 0).
+// Hints only steer the guess; every guess is checked against the table and the visited index.
 template <int MODE>
 __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, int k, int min_cov,
-                           long long max_kmers, long long max_radius, unsigned long long &rounds_left,
+                           long long max_kmers, long long max_radius, unsigned long long rounds_budget,
                            unsigned long long &lookups)
 {
     BfsCtl *ctl = S.ctl;
-    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
     const int dir = S.dir;
     const int nb = dir == 0 ? 8 : 4;
     const uint32_t lg = dir == 0 ? 3 : 2;    // log2(nb)
@@ -496,8 +496,7 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
 #endif
     unsigned long long rounds = 0, slow_rounds = 0;
-    uint32_t pend = 0;  // accepted vertices of the previous round not yet in the index
-    {
+    if (tid < 64) {
         const unsigned long long lb = ctl->lb, le = ctl->le;
         const long long level = ctl->level;
         const uint32_t F = (uint32_t)(le - lb);
@@ -516,34 +515,34 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
         const bool any = __ballot(dup) != 0;
         if (lane == 0) {
             L.n = ctl->n; L.lb = lb; L.le = le; L.level = level; L.F = F; L.cur = 0;
-            L.status = BFS_RUNNING; L.any_dup_root = any ? 1 : 0;
+            L.status = BFS_RUNNING; L.any_dup_root = any ? 1 : 0; L.rounds_left = rounds_budget; L.pend = 0;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     }
+    __syncthreads();
 
     for (;;) {
+        // ---- uniform decisions from the shared walk state
         const uint32_t F = L.F;
         const unsigned long long n = L.n;
         const long long level = L.level;
         const int cur = L.cur;
-        if (F == 0) { if (lane == 0) L.status = BFS_DONE; break; }
+        const uint32_t pend = L.pend;
+        if (F == 0) { if (tid == 0) L.status = BFS_DONE; break; }
         if (F > flim) break;
-        if (n + (unsigned long long)MAX_NODES > S.dcap) { if (lane == 0) L.status = BFS_NEED_GROW; break; }
-        if (rounds_left == 0) break;
-        rounds_left--;
+        if (n + (unsigned long long)MAX_NODES > S.dcap) { if (tid == 0) L.status = BFS_NEED_GROW; break; }
+        if (L.rounds_left == 0) break;
         rounds++;
 
         const bool capped0 = max_kmers >= 0 && (long long)n >= max_kmers;
         const long long room = max_radius < 0 ? (long long)LHINT_MAX : max_radius - level;  // levels that may still add
         const uint32_t FN = F << lg;  // nodes per level
         // the round is as deep as the shortest hint among the walkers
-        uint32_t myl = lane < F ? lh_len(L.rhint[lane]) : (uint32_t)LHINT_MAX;
-        if (myl > (uint32_t)k) myl = (uint32_t)k;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) myl = min(myl, (uint32_t)__shfl_xor((int)myl, o));
+        uint32_t hl_min = LHINT_MAX;
+        for (uint32_t a = 0; a < F; a++) hl_min = min(hl_min, lh_len(L.rhint[a]));
+        if (hl_min > (uint32_t)k) hl_min = (uint32_t)k;
         uint32_t H = 1;
-        if (myl >= 2 && !capped0 && room >= 1 && !L.any_dup_root) {
-            H = min(myl, (uint32_t)MAX_NODES / FN);
+        if (hl_min >= 2 && !capped0 && room >= 1 && !L.any_dup_root) {
+            H = min(hl_min, (uint32_t)MAX_NODES / FN);
             if ((long long)H > room) H = (uint32_t)room;
             if (max_kmers >= 0) {
                 const unsigned long long fit = ((unsigned long long)max_kmers - n) / F;  // whole levels under the cap
@@ -552,195 +551,177 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
             if (H < 1) H = 1;
         }
         const uint32_t NT = H * FN;
+        if (tid == 0) L.bad_lvl = 0xFFFFFFFFu;
 
         // ---- speculate: node (i, a, c) = c-th neighbour of the vertex walker a is expected to reach after i-1 steps
         MC_STAMP(0);
-        Kmer nk[NPL];
-        uint64_t tkey[NPL], ts0[NPL], ts1[NPL];
-        uint4 a0[NPL], a1[NPL];
-        uint32_t ni[NPL], na[NPL];
-        bool npred[NPL], nflip[NPL];
-#pragma unroll
-        for (int u = 0; u < NPL; u++) {
-            const uint32_t id = lane + 64u * (uint32_t)u;
-            nk[u] = Kmer{0, 0};
-            tkey[u] = 0; ts0[u] = 0; ts1[u] = 0;
-            a0[u] = make_uint4(0, 0, 0, 0);
-            a1[u] = a0[u];
-            ni[u] = 0; na[u] = 0;
-            npred[u] = false; nflip[u] = false;
-            if (id < NT) {
-                uint32_t i = 1, r = id;
-                while (r >= FN) { r -= FN; i++; }
-                const uint32_t a = r >> lg, c = r & (uint32_t)(nb - 1);
-                const uint64_t h = L.rhint[a];
-                const bool right = (h >> 62) & 1;
-                const Kmer v = walker_at(L.root[a], k, h, i - 1);  // the expected path so far
-                const uint32_t hb = (uint32_t)(h >> (2 * (i - 1))) & 3u;  // expected step i
-                const uint32_t cstar = dir == 0 ? (2 * hb + (right ? 1u : 0u)) : hb;
-                nk[u] = neighbour(v, k, dir, (int)c);
-                ni[u] = i; na[u] = a;
-                npred[u] = H > 1 && c == cstar;
-                bool fl;
-                tkey[u] = (uint64_t)key_of<MODE>(nk[u], k, &fl);
-                nflip[u] = fl;
-                ts0[u] = solid_slot_of(t, tkey[u]);
-                ts1[u] = (ts0[u] & ~(uint64_t)t.rmask) | ((ts0[u] + 1) & t.rmask);
-                a0[u] = *reinterpret_cast<const uint4 *>(t.slots + ts0[u]);
-                a1[u] = *reinterpret_cast<const uint4 *>(t.slots + ts1[u]);
-                lookups++;
-            }
+        const bool have = tid < NT;
+        Kmer nk{0, 0};
+        uint32_t ni = 0, na = 0;
+        bool npred = false, nflip = false;
+        int cov = -1;
+        uint64_t nslot = ~0ull;
+        uint64_t key = 0, s0 = 0, s1 = 0;
+        uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+        if (have) {
+            ni = tid / FN + 1;  // (FN <= 64: a cheap division)
+            const uint32_t r = tid - (ni - 1) * FN;
+            na = r >> lg;
+            const uint32_t c = r & (uint32_t)(nb - 1);
+            const uint64_t h = L.rhint[na];
+            const bool right = (h >> 62) & 1;
+            const Kmer v = walker_at(L.root[na], k, h, ni - 1);  // the expected path so far
+            const uint32_t hb = (uint32_t)(h >> (2 * (ni - 1))) & 3u;  // expected step
+            const uint32_t cstar = dir == 0 ? (2 * hb + (right ? 1u : 0u)) : hb;
+            nk = neighbour(v, k, dir, (int)c);
+            npred = H > 1 && c == cstar;
+            key = (uint64_t)key_of<MODE>(nk, k, &nflip);
+            s0 = solid_slot_of(t, key);
+            s1 = (s0 & ~(uint64_t)t.rmask) | ((s0 + 1) & t.rmask);
+            a0 = *reinterpret_cast<const uint4 *>(t.slots + s0);
+            a1 = *reinterpret_cast<const uint4 *>(t.slots + s1);
+            lookups++;
         }
-        // the previous round's vertices enter the index while this round's probes are in flight
-        // (they complete before any vis_find below: memory operations of a wave return in order)
-        for (uint32_t i = lane; i < pend; i += 64) vis_insert(S, L.pub_k[i], L.pub_idx[i]);
-        pend = 0;
+        // the previous round's vertices enter the index while this round's probes are in flight (taken
+        // from the top of the workgroup, where threads usually hold no node)
+        if (BFS_THREADS - 1 - tid < pend) vis_insert(S, L.pub_k[BFS_THREADS - 1 - tid], L.pub_idx[BFS_THREADS - 1 - tid]);
         MC_STAMP(1);
-        int cov[NPL];
-        uint64_t nslot[NPL];
-#pragma unroll
-        for (int u = 0; u < NPL; u++) {
-            const uint32_t id = lane + 64u * (uint32_t)u;
-            cov[u] = -1;
-            nslot[u] = ~0ull;
-            if (id < NT) {
-                cov[u] = solid_get2(t, tkey[u], ts0[u], ts1[u], a0[u], a1[u], &nslot[u]);
-                L.cov[id] = (int16_t)cov[u];
-                L.kmer[id] = nk[u];
-                if (npred[u]) L.pk[(ni[u] - 1) * F + na[u]] = nk[u];
-            }
+        if (have) {
+            cov = solid_get2(t, key, s0, s1, a0, a1, &nslot);
+            L.cov[tid] = (int16_t)cov;
+            L.kmer[tid] = nk;
+            if (npred) L.pk[(ni - 1) * F + na] = nk;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        L.set[tid] = LH_EMPTY;
+        L.set[tid + BFS_THREADS] = LH_EMPTY;
+        __syncthreads();
         MC_STAMP(2);
         // is a solid node already in distanceToKmer when the sequential BFS meets it?  = in the index,
-        // or one of the expected vertices that come earlier in level-major order
-        bool solid[NPL], ind[NPL];
-        uint32_t bad_lvl = 0xFFFFFFFFu;  // first level at which one of my nodes breaks the expectation
-#pragma unroll
-        for (int u = 0; u < NPL; u++) {
-            const uint32_t id = lane + 64u * (uint32_t)u;
-            solid[u] = id < NT && cov[u] >= min_cov;
-            ind[u] = false;
-            if (solid[u]) ind[u] = vis_find(S, nk[u]);
-        }
-        if (H > 1) {  // ... or equal to an expected vertex that comes earlier: broadcast each one, compare everywhere
-            const uint32_t np = H * F;  // <= MAX_NODES / nb <= 64
-            Kmer mypk{0, 0};
-            if (lane < np) mypk = L.pk[lane];
-            for (uint32_t e = 0; e < np; e++) {  // e is wave-uniform: v_readlane, not an LDS permute
-                const uint64_t blo = readlane64(mypk.lo, e), bhi = k > 32 ? readlane64(mypk.hi, e) : 0;
-#pragma unroll
-                for (int u = 0; u < NPL; u++)
-                    if (solid[u] && e < (ni[u] - 1) * F + na[u] && nk[u].lo == blo && nk[u].hi == bhi) ind[u] = true;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < NPL; u++) {
-            const uint32_t id = lane + 64u * (uint32_t)u;
-            if (id < NT) {
-                L.vis[id] = ind[u] ? 1 : 0;  // (level 1 only matters: the one-level replay reads it)
-                const bool ok = npred[u] ? (solid[u] && !ind[u]) : (!solid[u] || ind[u]);
-                if (!ok && ni[u] < bad_lvl) bad_lvl = ni[u];
-            }
-        }
-        MC_STAMP(3);
-        uint32_t J = 0;
-        if (H > 1) {
-            J = H;
-            for (uint32_t i = 1; i <= H; i++)
-                if (__ballot(bad_lvl == i) != 0) { J = i - 1; break; }
-        }
-
-        uint32_t n_new = 0, last_base = 0;
-        if (J >= 1) {
-            // ---- levels 1..J are exactly "every walker steps to its expected vertex"
-#pragma unroll
-            for (int u = 0; u < NPL; u++) {
-                const uint32_t id = lane + 64u * (uint32_t)u;
-                if (id < NT && ni[u] <= J) {
-                    const uint32_t i = ni[u], a = na[u];
-                    if (npred[u]) {
-                        const uint64_t idx = n + (unsigned long long)(i - 1) * F + a;
-                        S.hi[idx] = nk[u].hi;
-                        S.lo[idx] = nk[u].lo;
-                        S.dist[idx] = (int32_t)(level + i);
-                        S.cov[idx] = (int16_t)cov[u];
-                        L.pub_k[(i - 1) * F + a] = nk[u];
-                        L.pub_idx[(i - 1) * F + a] = (uint32_t)idx;
-                        if (i == J) {  // the walker's new position and its own hint
-                            const bool right = (L.rhint[a] >> 62) & 1;
-                            const SolidSlot *sl = t.slots + nslot[u];
-                            L.nhint[a] = nslot[u] == ~0ull ? (right ? (1ull << 62) : 0) : walker_hint(sl->hr, sl->hl, nflip[u], right);
-                            L.fl_idx[cur ^ 1][a] = (uint32_t)idx;
-                        }
-                    } else if (solid[u]) {  // solid but already there: lastKmers.add(parent)
-                        const uint32_t pidx = i == 1 ? (L.fl_idx[cur][a] & 0x3FFFFFFFu)
-                                                     : (uint32_t)(n + (unsigned long long)(i - 2) * F + a);
-                        atomicOr(&S.flags[pidx], 1u);
-                    }
+        // or one of the expected vertices that come earlier in level-major order.  The expected
+        // vertices go into an LDS set keyed by k-mer that keeps the earliest position of each.
+        const bool solid = have && cov >= min_cov;
+        const uint32_t pos = have ? (ni - 1) * F + na : 0;  // my walker's place in level-major order at my level
+        uint32_t myslot = 0;
+        if (npred) myslot = lds_set_min(L.set, RH_SIZE - 1, L.pk, nk, pos);
+        bool ind = false;
+        if (solid) ind = vis_find(S, nk);
+        __syncthreads();
+        if (solid && !ind && H > 1) {
+            if (npred) {
+                ind = L.set[myslot] != pos;  // the same k-mer is expected earlier on some walker's path
+            } else {  // a solid neighbour off the expected path: fine only if it is an expected vertex met earlier
+                uint32_t sl = (uint32_t)vis_hash(nk) & (RH_SIZE - 1);
+                for (;;) {
+                    const uint32_t e = L.set[sl];
+                    if (e == LH_EMPTY) break;
+                    const Kmer o = L.pk[e];
+                    if (o.lo == nk.lo && o.hi == nk.hi) { ind = e < pos; break; }
+                    sl = (sl + 1) & (RH_SIZE - 1);
                 }
             }
-            n_new = F * J;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            if (lane < F) {
-                L.root[lane] = L.pk[(J - 1) * F + lane];
-                L.rhint[lane] = L.nhint[lane];
-                L.fl_w[cur ^ 1][lane] = lane;
+        }
+        if (have) {
+            L.vis[tid] = ind ? 1 : 0;  // (level 1 only matters: the one-level replay reads it)
+            const bool ok = npred ? (solid && !ind) : (!solid || ind);
+            if (!ok && H > 1) atomicMin(&L.bad_lvl, ni);
+        }
+        __syncthreads();
+        MC_STAMP(3);
+        uint32_t J = 0;
+        if (H > 1) J = min(H, L.bad_lvl - 1);
+
+        if (J >= 1) {
+            // ---- levels 1..J are exactly "every walker steps to its expected vertex"
+            if (have && ni <= J) {
+                if (npred) {
+                    const uint64_t idx = n + (unsigned long long)(ni - 1) * F + na;
+                    S.hi[idx] = nk.hi;
+                    S.lo[idx] = nk.lo;
+                    S.dist[idx] = (int32_t)(level + ni);
+                    S.cov[idx] = (int16_t)cov;
+                    L.pub_k[(ni - 1) * F + na] = nk;
+                    L.pub_idx[(ni - 1) * F + na] = (uint32_t)idx;
+                    if (ni == J) {  // the walker's new position and its own hint
+                        const bool right = (L.rhint[na] >> 62) & 1;
+                        const SolidSlot *sl = t.slots + nslot;
+                        L.nhint[na] = nslot == ~0ull ? (right ? (1ull << 62) : 0) : walker_hint(sl->hr, sl->hl, nflip, right);
+                        L.fl_idx[cur ^ 1][na] = (uint32_t)idx;
+                    }
+                } else if (solid) {  // solid but already there: lastKmers.add(parent)
+                    const uint32_t pidx = ni == 1 ? (L.fl_idx[cur][na] & 0x3FFFFFFFu)
+                                                  : (uint32_t)(n + (unsigned long long)(ni - 2) * F + na);
+                    atomicOr(&S.flags[pidx], 1u);
+                }
             }
-            if (lane == 0) {
+            __syncthreads();
+            if (tid < F) {
+                L.root[tid] = L.pk[(J - 1) * F + tid];
+                L.rhint[tid] = L.nhint[tid];
+                L.fl_w[cur ^ 1][tid] = tid;
+            }
+            if (tid == 0) {
+                const uint32_t n_new = F * J;
                 L.n = n + n_new;
                 L.lb = n + (unsigned long long)(J - 1) * F;
                 L.le = n + n_new;
                 L.level = level + J;
                 L.cur = cur ^ 1;
                 L.any_dup_root = 0;
+                L.pend = n_new;  // indexed while the next round's lookups are in flight
+                L.rounds_left--;
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             MC_STAMP(4);
-            pend = n_new;  // indexed while the next round's lookups are in flight
         } else {
             // ---- exact one-level replay of level 1 (ids [0, FN) are the plain neighbour sets of the walkers)
             slow_rounds++;
-#pragma unroll
-            for (int u = 0; u < NPL; u++) {
-                const uint32_t id = lane + 64u * (uint32_t)u;
-                if (id < FN) {
-                    L.nslot[id] = nslot[u];
-                    L.flip[id] = nflip[u] ? 1 : 0;
-                    if (H > 1) L.vis[id] = (solid[u] && vis_find(S, nk[u])) ? 1 : 0;  // index only, no expectations
+            if (tid < FN) {
+                L.nslot[tid] = nslot;
+                L.flip[tid] = nflip ? 1 : 0;
+                if (H > 1) L.vis[tid] = (solid && vis_find(S, nk)) ? 1 : 0;  // index only, no expectations
+            }
+            __syncthreads();
+            if (tid < 64) {
+                uint32_t last_base = 0;
+                const uint32_t n_new = replay_slow(S, L, 1, min_cov, max_kmers, max_radius, lg, flim, &last_base);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                for (uint32_t i = lane; i < n_new; i += 64) vis_insert(S, L.kmer[L.new_id[i]], L.new_idx[i]);
+                const uint32_t Fn = L.F;
+                const int c2 = L.cur;
+                Kmer nr{0, 0};
+                uint64_t nh = 0;
+                if (lane < Fn && Fn <= flim) {
+                    const uint32_t id = last_base + L.fl_w[c2][lane];
+                    nr = L.kmer[id];
+                    const bool right = dir > 0 || (dir == 0 && (id & 1u));  // odd neighbour index = right neighbour
+                    const uint64_t sl = L.nslot[id];
+                    nh = sl == ~0ull ? (right ? (1ull << 62) : 0)
+                                     : walker_hint(t.slots[sl].hr, t.slots[sl].hl, L.flip[id] != 0, right);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                if (lane < Fn && Fn <= flim) {
+                    L.root[lane] = nr;
+                    L.rhint[lane] = nh;
+                    L.fl_w[c2][lane] = lane;  // walkers are numbered 0..F-1 in the next round
+                }
+                if (lane == 0) {
+                    L.any_dup_root = 0;
+                    L.pend = 0;
+                    L.rounds_left--;
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            n_new = replay_slow(S, L, 1, min_cov, max_kmers, max_radius, lg, flim, &last_base);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             MC_STAMP(4);
-            for (uint32_t i = lane; i < n_new; i += 64) vis_insert(S, L.kmer[L.new_id[i]], L.new_idx[i]);
-            const uint32_t Fn = L.F;
-            const int c2 = L.cur;
-            Kmer nr{0, 0};
-            uint64_t nh = 0;
-            if (lane < Fn && Fn <= flim) {
-                const uint32_t id = last_base + L.fl_w[c2][lane];
-                nr = L.kmer[id];
-                const bool right = dir > 0 || (dir == 0 && (id & 1u));  // odd neighbour index = right neighbour
-                const uint64_t sl = L.nslot[id];
-                nh = sl == ~0ull ? (right ? (1ull << 62) : 0)
-                                 : walker_hint(t.slots[sl].hr, t.slots[sl].hl, L.flip[id] != 0, right);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            if (lane < Fn && Fn <= flim) {
-                L.root[lane] = nr;
-                L.rhint[lane] = nh;
-                L.fl_w[c2][lane] = lane;  // walkers are numbered 0..F-1 in the next round
-            }
-            if (lane == 0) L.any_dup_root = 0;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __syncthreads();
         MC_STAMP(5);
     }
-    for (uint32_t i = lane; i < pend; i += 64) vis_insert(S, L.pub_k[i], L.pub_idx[i]);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    if (lane == 0) {
+    __syncthreads();
+    {   // vertices of the last fast round still waiting for the index
+        const uint32_t pend = L.pend;
+        if (tid < pend) vis_insert(S, L.pub_k[tid], L.pub_idx[tid]);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        L.pend = 0;
         ctl->n = L.n;
         ctl->lb = L.lb;
         ctl->le = L.le;
@@ -749,11 +730,11 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
         ctl->rounds_narrow += rounds;
         ctl->rounds_slow += slow_rounds;
         if (L.status != BFS_RUNNING) ctl->status = L.status;
-        L.rounds_left = rounds_left;
 #ifdef MC_BFS_TIMING
         for (int i = 0; i < 8; i++) ctl->tacc[i] += tacc[i];
 #endif
     }
+    __syncthreads();
 }
 
 template <int MODE>
@@ -812,8 +793,7 @@ __global__ void __launch_bounds__(BFS_THREADS) k_bfs(const BfsState *__restrict_
         if (rounds_left == 0) break;
         if (ctl->c0 == 0 && le - lb <= flim) {
             __syncthreads();
-            if (tid < 64) bfs_narrow<MODE>(S, t, lds.n, k, min_cov, max_kmers, max_radius, rounds_left, lookups);
-            __syncthreads();
+            bfs_narrow<MODE>(S, t, lds.n, k, min_cov, max_kmers, max_radius, rounds_left, lookups);
             rounds_left = lds.n.rounds_left;
             __syncthreads();
             if (ctl->status != BFS_RUNNING) break;  // done, or distanceToKmer must grow
