@@ -329,33 +329,47 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const uint64_t *__restr
                 }
                 if (tid == 0) { L.n_new = 0; L.overflow = 0; }
                 __syncthreads();
-                for (uint32_t i = tid; i < n; i += P3_THREADS) {
-                    const uint64_t key = keys[i];
-                    const uint64_t gslot = fmix64(key) >> t.shift;
-                    if (g && (gslot >> 12) != region) continue;
-                    const uint32_t hint = hints[i];
-                    uint32_t s = (uint32_t)gslot & (REGION_SLOTS - 1);
-                    bool done = false;
-                    for (uint32_t probe = 0; probe < REGION_SLOTS; probe++) {
-                        uint64_t cur = L.key[s];
-                        if (cur == EMPTY_KEY) {
-                            cur = atomicCAS(reinterpret_cast<unsigned long long *>(&L.key[s]), (unsigned long long)EMPTY_KEY,
-                                            (unsigned long long)key);
-                            if (cur == EMPTY_KEY) { atomicAdd(&L.n_new, 1u); cur = key; }
-                        }
-                        if (cur == key) {
-                            atomicAdd(&L.cnt[s], 1u);
-                            if (hint) {
-                                const uint32_t have = L.aux[s], m = hint_merge(have, hint);
-                                if (m != have) L.aux[s] = m;  // racy on purpose: any occurrence's context will do
-                            }
-                            done = true;
-                            break;
-                        }
-                        s = (s + 1) & (REGION_SLOTS - 1);
+                uint32_t my_new = 0;
+                for (uint32_t i0 = tid; i0 < n; i0 += 4 * P3_THREADS) {
+                    uint64_t kk[4];
+                    uint32_t hh[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {  // four independent loads in flight per thread
+                        const uint32_t i = i0 + (uint32_t)u * P3_THREADS;
+                        kk[u] = i < n ? keys[i] : EMPTY_KEY;  // (the streams never hold EMPTY_KEY)
+                        hh[u] = i < n ? hints[i] : 0u;
                     }
-                    if (!done) atomicExch(&L.overflow, 1u);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint64_t key = kk[u];
+                        if (key == EMPTY_KEY) continue;
+                        const uint64_t gslot = fmix64(key) >> t.shift;
+                        if (g && (gslot >> 12) != region) continue;
+                        const uint32_t hint = hh[u];
+                        uint32_t s = (uint32_t)gslot & (REGION_SLOTS - 1);
+                        bool done = false;
+                        for (uint32_t probe = 0; probe < REGION_SLOTS; probe++) {
+                            uint64_t cur = L.key[s];
+                            if (cur == EMPTY_KEY) {
+                                cur = atomicCAS(reinterpret_cast<unsigned long long *>(&L.key[s]), (unsigned long long)EMPTY_KEY,
+                                                (unsigned long long)key);
+                                if (cur == EMPTY_KEY) { my_new++; cur = key; }
+                            }
+                            if (cur == key) {
+                                atomicAdd(&L.cnt[s], 1u);
+                                if (hint) {
+                                    const uint32_t have = L.aux[s], m = hint_merge(have, hint);
+                                    if (m != have) L.aux[s] = m;  // racy on purpose: any occurrence's context will do
+                                }
+                                done = true;
+                                break;
+                            }
+                            s = (s + 1) & (REGION_SLOTS - 1);
+                        }
+                        if (!done) atomicExch(&L.overflow, 1u);
+                    }
                 }
+                if (my_new) atomicAdd(&L.n_new, my_new);
                 __syncthreads();
                 const bool ovf = L.overflow != 0;
                 if (ovf) leaf_ok = false;

@@ -322,25 +322,6 @@ __device__ __forceinline__ uint64_t lh_block_forward(uint64_t w, uint32_t n)
 
 __device__ __forceinline__ uint64_t solid_slot_of(const SolidView &t, uint64_t key) { return fmix64(key) >> t.shift; }
 
-// insert a key that is not in the table yet (the build visits every key once)
-__device__ __forceinline__ void solid_insert(const SolidView &t, uint64_t key, uint32_t count, uint32_t aux)
-{
-    uint64_t s = solid_slot_of(t, key);
-    const uint64_t base = s & ~(uint64_t)t.rmask;
-    for (uint32_t probe = 0; probe <= t.rmask; probe++) {
-        SolidSlot *p = t.slots + s;
-        if (atomicCAS(reinterpret_cast<unsigned long long *>(&p->key), (unsigned long long)EMPTY_KEY,
-                      (unsigned long long)key) == EMPTY_KEY) {
-            p->count = count;
-            p->hr = (aux & HINT_RV) ? lh_make(aux & 0x3FFFu, HINT_LEN) : 0;
-            p->hl = (aux & HINT_LV) ? lh_make((aux >> 16) & 0x3FFFu, HINT_LEN) : 0;
-            return;
-        }
-        s = base | ((s + 1) & t.rmask);
-    }
-    atomicExch(t.fatal, 1u);
-}
-
 // count (saturated) or -1; hr/hl may be null
 __device__ __forceinline__ int solid_get(const SolidView &t, uint64_t key, uint64_t *hr = nullptr, uint64_t *hl = nullptr)
 {

@@ -101,7 +101,7 @@ struct mc_ctx {
         SolidView t;
         t.slots = solid;
         t.shift = 64 - solid_lg;
-        t.rmask = (1u << sb) - 1;
+        t.rmask = (1u << 11) - 1;  // SOLID_REGION - 1
         t.empty_cnt = d_ctr + 1;
         t.fatal = d_fatal;
         return t;
@@ -218,27 +218,69 @@ __global__ void k_rehash(const Slot *__restrict__ old_slots, uint64_t n_old, Tab
     wave_add_ull(t.n_used, n_new);
 }
 
-// K6: copy the keys with count >= min_cov into the sparse "solid" table the BFS probes
-__global__ void k_solid_fill(SolidSlot *slots, uint64_t n)
-{
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    uint4 *p = reinterpret_cast<uint4 *>(slots);
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * n; i += stride) {
-        uint4 v;
-        v.x = (i & 1) ? 0u : 0xFFFFFFFFu; v.y = v.x; v.z = 0; v.w = 0;  // first half of a slot: EMPTY key, count 0
-        p[i] = v;
-    }
-}
+// K6, region-wise: one workgroup assembles one region of the solid table (SOLID_REGION slots, 64 KB)
+// in LDS from the counting-table region(s) that hash to it and writes it out with plain coalesced
+// stores: no fill pass, no atomics.  Both tables index by the top bits of the same hash, so the
+// counting regions of a solid region are consecutive (or it is a slice of one counting region).
+constexpr uint32_t SOLID_SB = 11, SOLID_REGION = 1u << SOLID_SB;
 
-__global__ void k_build_solid(const Slot *__restrict__ slots, uint64_t n_slots, int min_cov, SolidView solid)
+__global__ void __launch_bounds__(512) k_build_solid_regions(const Slot *__restrict__ slots, uint32_t main_lg,
+                                                             int min_cov, SolidView solid, uint32_t solid_lg)
 {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += stride) {
-        const uint4 raw = *reinterpret_cast<const uint4 *>(slots + i);
-        const uint64_t key = ((uint64_t)raw.y << 32) | raw.x;
-        if (key == EMPTY_KEY) continue;
-        const int c = raw.z > 32767u ? 32767 : (int)raw.z;
-        if (c >= min_cov) solid_insert(solid, key, (uint32_t)c, raw.w);
+    __shared__ SolidSlot R[SOLID_REGION];
+    __shared__ uint32_t overflow;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t q = solid_lg - SOLID_SB;  // log2(#solid regions)
+    const uint32_t rb = main_lg - 12;        // log2(#counting regions)
+    const uint64_t n_regions = 1ull << q;
+    for (uint64_t Q = blockIdx.x; Q < n_regions; Q += gridDim.x) {
+        for (uint32_t i = tid; i < SOLID_REGION; i += 512) {
+            R[i].key = EMPTY_KEY; R[i].count = 0; R[i].pad = 0; R[i].hr = 0; R[i].hl = 0;
+        }
+        if (tid == 0) overflow = 0;
+        __syncthreads();
+        // counting-table slots to scan
+        uint64_t first, count;
+        if (q <= rb) { first = (Q << (rb - q)) << 12; count = 1ull << (rb - q + 12); }
+        else { first = (Q >> (q - rb)) << 12; count = 4096; }
+        for (uint64_t i0 = tid; i0 < count; i0 += 4 * 512) {
+            uint4 raws[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {  // four independent loads in flight per thread
+                const uint64_t i = i0 + (uint64_t)u * 512;
+                raws[u] = i < count ? *reinterpret_cast<const uint4 *>(slots + first + i) : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint4 raw = raws[u];
+                const uint64_t key = ((uint64_t)raw.y << 32) | raw.x;
+                if (key == EMPTY_KEY) continue;
+                const int c = raw.z > 32767u ? 32767 : (int)raw.z;
+                if (c < min_cov) continue;
+                const uint64_t ss = fmix64(key) >> (64 - solid_lg);
+                if ((ss >> SOLID_SB) != Q) continue;  // (q > rb: the counting region feeds several solid regions)
+                uint32_t s = (uint32_t)ss & (SOLID_REGION - 1);
+                bool done = false;
+                for (uint32_t probe = 0; probe < SOLID_REGION; probe++) {
+                    if (atomicCAS(reinterpret_cast<unsigned long long *>(&R[s].key), (unsigned long long)EMPTY_KEY,
+                                  (unsigned long long)key) == EMPTY_KEY) {
+                        R[s].count = (uint32_t)c;
+                        R[s].hr = (raw.w & HINT_RV) ? lh_make(raw.w & 0x3FFFu, HINT_LEN) : 0;
+                        R[s].hl = (raw.w & HINT_LV) ? lh_make((raw.w >> 16) & 0x3FFFu, HINT_LEN) : 0;
+                        done = true;
+                        break;
+                    }
+                    s = (s + 1) & (SOLID_REGION - 1);
+                }
+                if (!done) atomicExch(&overflow, 1u);
+            }
+        }
+        __syncthreads();
+        if (overflow && tid == 0) atomicExch(solid.fatal, 1u);
+        uint4 *dst = reinterpret_cast<uint4 *>(solid.slots + Q * SOLID_REGION);
+        const uint4 *src = reinterpret_cast<const uint4 *>(R);
+        for (uint32_t i = tid; i < SOLID_REGION * 2; i += 512) dst[i] = src[i];
+        __syncthreads();
     }
 }
 
@@ -1284,6 +1326,7 @@ int ensure_solid(mc_ctx *c, int min_cov, double *ms)
     if (const char *e = getenv("MC_SOLID_FACTOR")) factor = std::max<uint64_t>(2, strtoull(e, nullptr, 10));
     uint32_t lg = c->sb;
     while (lg < 34 && (1ull << lg) < factor * n) lg++;
+    if (lg < SOLID_SB + 1) lg = SOLID_SB + 1;
     if (!c->solid || lg != c->solid_lg) {
         if (c->solid) { (void)hipFree(c->solid); c->solid = nullptr; }
         HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->solid), sizeof(SolidSlot) << lg));
@@ -1291,10 +1334,8 @@ int ensure_solid(mc_ctx *c, int min_cov, double *ms)
     }
     const int doublings = c->cfg.key_mode == MC_KEY_PACKED ? 2 : 0;  // hash keys do not hold the k-mer
     rc = timed(c, ms, [&] {
-        hipLaunchKernelGGL(k_solid_fill, dim3(grid_for(2ull << lg, 256)), dim3(256), 0, c->stream, c->solid,
-                           (uint64_t)1 << lg);
-        hipLaunchKernelGGL(k_build_solid, dim3(grid_for(c->n_slots(), 256)), dim3(256), 0, c->stream, c->slots,
-                           c->n_slots(), min_cov, c->solid_view());
+        hipLaunchKernelGGL(k_build_solid_regions, dim3((unsigned)std::min<uint64_t>(1ull << (lg - SOLID_SB), 256 * 2 * 8)), dim3(512), 0,
+                           c->stream, c->slots, c->rb + c->sb, min_cov, c->solid_view(), lg);
         for (int d = 0; d < doublings; d++)
             hipLaunchKernelGGL(k_solid_double, dim3(grid_for(1ull << lg, 256)), dim3(256), 0, c->stream, c->solid_view(),
                                (uint64_t)1 << lg, c->cfg.k);
