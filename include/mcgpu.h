@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MC_ABI_VERSION 1
+#define MC_ABI_VERSION 2
 
 /* error codes */
 #define MC_OK 0
@@ -154,9 +154,13 @@ int mc_bfs_batch(mc_ctx *ctx, const mc_bfs_job *jobs, uint32_t n_jobs, int min_c
  * Also the record content of the reference's .kmers.bin (src/io/KmersLoadWorker.java:9,20-23)
  * and the payload of the multi-GPU gather.  With keys == NULL only *n_out is computed. */
 int mc_export(mc_ctx *ctx, int min_cov, int64_t *keys, int16_t *counts, uint64_t cap, uint64_t *n_out);
-int mc_export_dev(mc_ctx *ctx, int min_cov, int64_t *d_keys, int16_t *d_counts, uint64_t cap, uint64_t *n_out);
+/* d_hints (may be NULL): the 32-bit speculation hint stored with each key -- 7 bases of read context on
+ * either side, used only to steer the BFS's look-ahead (never part of a result); carry it along with
+ * the pairs so that a table rebuilt elsewhere walks as fast as the one that counted the reads. */
+int mc_export_dev(mc_ctx *ctx, int min_cov, int64_t *d_keys, int16_t *d_counts, uint32_t *d_hints, uint64_t cap,
+                  uint64_t *n_out);
 /* table[key] = min(32767, table[key] + count) for each pair (saturating adds commute). */
-int mc_add_pairs_dev(mc_ctx *ctx, const int64_t *d_keys, const int16_t *d_counts, uint64_t n);
+int mc_add_pairs_dev(mc_ctx *ctx, const int64_t *d_keys, const int16_t *d_counts, const uint32_t *d_hints, uint64_t n);
 
 /* ---- multi-GPU building blocks (device pointers).  The read set is split across ranks; each
  * rank turns its reads into keys bucketed by owner rank, ranks exchange buckets (RCCL
@@ -165,12 +169,14 @@ int mc_add_pairs_dev(mc_ctx *ctx, const int64_t *d_keys, const int16_t *d_counts
 uint32_t mc_key_owner(int64_t key, uint32_t n_owners);
 /* Writes the keys of all windows grouped by owner into d_keys (capacity = total windows):
  * owner o's keys are d_keys[owner_offsets[o] .. owner_offsets[o+1]); owner_offsets (host,
- * n_owners + 1 entries) is filled on return. */
+ * n_owners + 1 entries) is filled on return.  d_hints (may be NULL, same capacity) receives the
+ * speculation hint of every occurrence at the same index.  With d_keys == NULL only the offsets are
+ * computed.  n_owners <= 512. */
 int mc_extract_keys_dev(mc_ctx *ctx, const uint64_t *d_words, const uint64_t *d_read_offsets, uint64_t n_reads,
-                        uint64_t n_bases, uint32_t n_owners, int64_t *d_keys, uint64_t keys_cap,
+                        uint64_t n_bases, uint32_t n_owners, int64_t *d_keys, uint32_t *d_hints, uint64_t keys_cap,
                         uint64_t *owner_offsets);
-/* addAndBound(key, 1) for each key */
-int mc_add_keys_dev(mc_ctx *ctx, const int64_t *d_keys, uint64_t n);
+/* addAndBound(key, 1) for each key; d_hints may be NULL */
+int mc_add_keys_dev(mc_ctx *ctx, const int64_t *d_keys, const uint32_t *d_hints, uint64_t n);
 
 /* ---- measurement */
 typedef struct {

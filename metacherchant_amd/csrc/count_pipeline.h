@@ -62,10 +62,15 @@ __device__ __forceinline__ void spill_push(const SpillView &sp, uint64_t key, ui
 // Shared tail of P1/P2: the tile's items are in registers; group them by digit in LDS and write one
 // contiguous run per bucket.  cursors[d] counts what bucket d holds so far; bucket d's storage is
 // out_*[d * cap .. (d+1) * cap); what does not fit goes to the spill list (drained by the direct kernel).
+// With `bases` (exact bucket start offsets from a counting pass, cursors then count from 0 inside each
+// bucket) the output is tightly packed and cannot overflow; out_hints may be null.
+// COUNT_ONLY: only add the tile's bucket sizes to the cursors (the counting pass).
+template <bool COUNT_ONLY = false>
 __device__ __forceinline__ void scatter_tile(ScatterLds &L, const uint64_t (&key)[PT_ITEMS], const uint32_t (&hint)[PT_ITEMS],
                                              const uint32_t (&dig)[PT_ITEMS], const bool (&valid)[PT_ITEMS],
                                              uint32_t n_buckets, uint32_t *cursors, uint32_t cstride, uint64_t cap, uint64_t *out_keys,
-                                             uint32_t *out_hints, uint64_t out_base, const SpillView &sp)
+                                             uint32_t *out_hints, uint64_t out_base, const SpillView &sp,
+                                             const uint64_t *bases = nullptr)
 {
     const uint32_t tid = threadIdx.x;
     uint32_t rank[PT_ITEMS];
@@ -93,6 +98,7 @@ __device__ __forceinline__ void scatter_tile(ScatterLds &L, const uint64_t (&key
         if (tid == PT_THREADS - 1) L.n_valid = before + x;
     }
     __syncthreads();
+    if (COUNT_ONLY) return;
 #pragma unroll
     for (int j = 0; j < PT_ITEMS; j++)
         if (valid[j]) {
@@ -106,7 +112,11 @@ __device__ __forceinline__ void scatter_tile(ScatterLds &L, const uint64_t (&key
     for (uint32_t i = tid; i < n; i += PT_THREADS) {
         const uint32_t d = L.dig[i];
         const uint64_t dst = (uint64_t)L.gbase[d] + (i - L.off[d]);
-        if (dst < cap) {
+        if (bases) {
+            const uint64_t at = bases[d] + dst;
+            out_keys[at] = L.key[i];
+            if (out_hints) out_hints[at] = L.hint[i];
+        } else if (dst < cap) {
             const uint64_t at = out_base + (uint64_t)d * cap + dst;
             out_keys[at] = L.key[i];
             out_hints[at] = L.hint[i];
@@ -159,15 +169,24 @@ __device__ __forceinline__ uint64_t bits128(uint64_t lo, uint64_t hi, uint32_t f
 // P1: tiles of PT_TILE consecutive base positions of the packed read set.  A thread owns PT_ITEMS
 // CONSECUTIVE positions and rolls the window along them (the reference's ShortKmer.shiftRight,
 // itmo!/dna/kmers/ShortKmer.java:68-71): one new base per step instead of a fresh extraction.
-template <int MODE>
+// bucket of a key: the top b1 bits of its hash (counting pipeline), or its owner rank (multi-GPU split;
+// low hash bits, disjoint from the bits that place it in the table)
+__device__ __forceinline__ uint32_t owner_of(uint64_t key, uint32_t n_owners)
+{
+    return (uint32_t)((fmix64(key) & 0xFFFFFFFFull) % n_owners);
+}
+
+// OWNERS: buckets are owner ranks (n_buckets = b1 owners) instead of 2^b1 hash prefixes, EMPTY_KEY is an
+// ordinary key, and the output is packed at `bases` (from a COUNT_ONLY run of the same kernel).
+template <int MODE, bool OWNERS = false, bool COUNT_ONLY = false>
 __global__ void __launch_bounds__(PT_THREADS) k_p1_extract_scatter(
     const uint64_t *__restrict__ words, const uint64_t *__restrict__ offsets, uint64_t n_reads, uint64_t base_lo,
     uint64_t n_bases, uint64_t n_tiles, const uint32_t *__restrict__ first_read, int k, uint32_t b1, uint32_t *cursors, uint64_t cap,
-    uint64_t *out_keys, uint32_t *out_hints, unsigned long long *empty_cnt, SpillView sp)
+    uint64_t *out_keys, uint32_t *out_hints, unsigned long long *empty_cnt, SpillView sp, const uint64_t *bases = nullptr)
 {
     __shared__ ScatterLds L;
     const uint32_t tid = threadIdx.x;
-    const uint32_t n_buckets = 1u << b1;
+    const uint32_t n_buckets = OWNERS ? b1 : (1u << b1);
     constexpr int64_t MARGIN = 64;  // the bitmap starts this many bases left of the tile (virtually, for tile 0)
     const uint64_t kmask = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1);
     for (uint64_t tile = base_lo / PT_TILE + blockIdx.x; tile < n_tiles; tile += gridDim.x) {  // reads cover [base_lo, n_bases)
@@ -222,7 +241,10 @@ __global__ void __launch_bounds__(PT_THREADS) k_p1_extract_scatter(
                     const uint32_t R = flipped ? (l7 ^ 0x3FFFu) : r7, Lc = flipped ? (r7 ^ 0x3FFFu) : l7;
                     const bool RV = flipped ? lv : rv, LV = flipped ? rv : lv;
                     hint[j] = (RV ? (R | HINT_RV) : 0u) | (LV ? ((Lc << 16) | HINT_LV) : 0u);
-                    if (key[j] == EMPTY_KEY) {
+                    if (OWNERS) {
+                        valid[j] = true;
+                        dig[j] = owner_of(key[j], n_buckets);
+                    } else if (key[j] == EMPTY_KEY) {
                         atomicAdd(empty_cnt, 1ull);
                     } else {
                         valid[j] = true;
@@ -239,6 +261,43 @@ __global__ void __launch_bounds__(PT_THREADS) k_p1_extract_scatter(
                 }
                 l7 = ((l7 << 2) | out) & 0x3FFFu;
                 r7 = (r7 >> 2) | (base_or0(words, p + (uint64_t)k + HINT_LEN, n_bases) << (2 * (HINT_LEN - 1)));
+            }
+        }
+        scatter_tile<COUNT_ONLY>(L, key, hint, dig, valid, n_buckets, cursors, CURSOR1_STRIDE, cap, out_keys, out_hints, 0, sp, bases);
+    }
+}
+
+// P1 for a flat stream of keys (+ optional hints) instead of reads: the receiving side of the
+// multi-GPU exchange.  Tiles of PT_TILE consecutive entries.
+__global__ void __launch_bounds__(PT_THREADS) k_p1_keys_scatter(const uint64_t *__restrict__ in_keys,
+                                                                const uint32_t *__restrict__ in_hints, uint64_t n, uint32_t b1,
+                                                                uint32_t *cursors, uint64_t cap, uint64_t *out_keys,
+                                                                uint32_t *out_hints, unsigned long long *empty_cnt, SpillView sp)
+{
+    __shared__ ScatterLds L;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n_buckets = 1u << b1;
+    const uint64_t n_tiles = (n + PT_TILE - 1) / PT_TILE;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        if (tid < n_buckets) L.cnt[tid] = 0;
+        __syncthreads();
+        uint64_t key[PT_ITEMS];
+        uint32_t hint[PT_ITEMS], dig[PT_ITEMS];
+        bool valid[PT_ITEMS];
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS; j++) {
+            const uint64_t i = tile * PT_TILE + tid + (uint64_t)j * PT_THREADS;
+            valid[j] = false;
+            key[j] = 0; hint[j] = 0; dig[j] = 0;
+            if (i < n) {
+                key[j] = in_keys[i];
+                hint[j] = in_hints ? in_hints[i] : 0u;
+                if (key[j] == EMPTY_KEY) {
+                    atomicAdd(empty_cnt, 1ull);
+                } else {
+                    valid[j] = true;
+                    dig[j] = (uint32_t)(fmix64(key[j]) >> (64 - b1));
+                }
             }
         }
         scatter_tile(L, key, hint, dig, valid, n_buckets, cursors, CURSOR1_STRIDE, cap, out_keys, out_hints, 0, sp);

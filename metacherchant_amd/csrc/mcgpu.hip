@@ -194,13 +194,13 @@ __global__ void k_add_keys(const int64_t *__restrict__ keys, uint64_t n, TableVi
     wave_add_ull(t.n_used, n_new);
 }
 
-__global__ void k_add_pairs(const int64_t *__restrict__ keys, const int16_t *__restrict__ counts, uint64_t n,
-                            TableView t)
+__global__ void k_add_pairs(const int64_t *__restrict__ keys, const int16_t *__restrict__ counts,
+                            const uint32_t *__restrict__ hints, uint64_t n, TableView t)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     unsigned long long n_new = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        if (counts[i] > 0) n_new += table_add(t, (uint64_t)keys[i], (uint32_t)counts[i]);
+        if (counts[i] > 0) n_new += table_add(t, (uint64_t)keys[i], (uint32_t)counts[i], hints ? hints[i] : 0u);
     wave_add_ull(t.n_used, n_new);
 }
 
@@ -344,7 +344,8 @@ __global__ void k_get(const int64_t *__restrict__ keys, uint64_t n, int16_t *__r
 // K6: (key, count) pairs with count >= min_cov; with keys == nullptr only counts them.
 // One cursor update per wave and iteration (ballot), never one per slot.
 __global__ void k_export(const Slot *__restrict__ slots, uint64_t n_slots, int min_cov, int64_t *__restrict__ keys,
-                         int16_t *__restrict__ counts, uint64_t cap, unsigned long long *cursor)
+                         int16_t *__restrict__ counts, uint32_t *__restrict__ hints, uint64_t cap,
+                         unsigned long long *cursor)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint32_t lane = threadIdx.x & 63;
@@ -354,10 +355,12 @@ __global__ void k_export(const Slot *__restrict__ slots, uint64_t n_slots, int m
         const uint64_t i = i0 + lane;
         uint64_t key = EMPTY_KEY;
         int c = -1;
+        uint32_t aux = 0;
         if (i < n_slots) {
             const uint4 raw = *reinterpret_cast<const uint4 *>(slots + i);
             key = ((uint64_t)raw.y << 32) | raw.x;
             c = raw.z > 32767u ? 32767 : (int)raw.z;
+            aux = raw.w;
         }
         const bool take = key != EMPTY_KEY && c >= min_cov;
         if (!keys) {
@@ -375,56 +378,11 @@ __global__ void k_export(const Slot *__restrict__ slots, uint64_t n_slots, int m
             if (pos < cap) {
                 keys[pos] = (int64_t)key;
                 counts[pos] = (int16_t)c;
+                if (hints) hints[pos] = aux;
             }
         }
     }
     if (!keys) wave_add_ull(cursor, counted);
-}
-
-// ------------------------------------------------------------------------------------------ kernels: multi-GPU split
-
-__device__ __forceinline__ uint32_t owner_of(uint64_t key, uint32_t n_owners)
-{
-    // bits disjoint from the slot index (which uses the TOP bits of fmix64(key))
-    return (uint32_t)((fmix64(key) & 0xFFFFFFFFull) % n_owners);
-}
-
-template <int MODE, bool SCATTER>
-__global__ void __launch_bounds__(256) k_extract_keys(const uint64_t *__restrict__ words,
-                                                      const uint64_t *__restrict__ offsets, uint64_t n_reads, int k,
-                                                      uint32_t n_owners, unsigned long long *cursors,
-                                                      int64_t *__restrict__ out, uint64_t cap)
-{
-    const uint32_t lane = threadIdx.x & 63;
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    for (uint64_t r = wave; r < n_reads; r += n_waves) {
-        const uint64_t b = offsets[r], e = offsets[r + 1];
-        if (e - b < (uint64_t)k) continue;
-        const uint64_t nwin = e - b - (uint64_t)k + 1;
-        for (uint64_t w0 = 0; w0 < nwin; w0 += 64) {
-            const bool act = w0 + lane < nwin;
-            uint64_t key = 0;
-            uint32_t own = 0xFFFFFFFFu;
-            if (act) {
-                key = (uint64_t)key_of<MODE>(extract_kmer(words, b + w0 + lane, k), k);
-                own = owner_of(key, n_owners);
-            }
-            for (uint32_t o = 0; o < n_owners; o++) {  // one atomic per (wave, owner)
-                const unsigned long long m = __ballot(act && own == o);
-                if (!m) continue;
-                const uint32_t cnt = (uint32_t)__popcll(m);
-                unsigned long long base = 0;
-                const int leader = __ffsll((long long)m) - 1;
-                if ((int)lane == leader) base = atomicAdd(&cursors[o], (unsigned long long)cnt);
-                base = __shfl(base, leader);
-                if (SCATTER && act && own == o) {
-                    const uint64_t pos = base + (uint64_t)__popcll(m & ((1ull << lane) - 1));
-                    if (pos < cap) out[pos] = (int64_t)key;
-                }
-            }
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------ kernels: synthetic reads
@@ -618,15 +576,19 @@ static int ensure_buf(mc_ctx *c, T **p, uint64_t *cap, uint64_t need)
     return MC_OK;
 }
 
-// One batch of reads [r0, r1) through the partitioned pipeline (count_pipeline.h).  wb = its windows.
-// base0 / end_abs = read_offsets[r0] / read_offsets[r1].
-static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_off, uint64_t r0, uint64_t r1,
-                                 uint64_t base0, uint64_t end_abs, uint64_t wb)
+struct PipePlan {
+    uint32_t b1 = 0, b2 = 0, g = 0;
+    uint64_t np1 = 0, n_leaves = 0, cap1 = 0, cap2 = 0, spill_cap = 0, tiles2_max = 0, wb = 0;
+    SpillView sp{};
+};
+
+// Table capacity check, scratch buffers and cursors for one run of the partitioned pipeline over
+// `wb` key occurrences.
+static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl)
 {
     mc_ctx::Pipe &P = c->pipe;
-    const uint64_t n_bases = end_abs - base0;  // the kernels see reads r0.. with absolute offsets
     // Make sure the table can take the batch: with a capacity hint the table was sized for it; without one
-    // assume every second occurrence is a new key at most (grown further below if a region still overflows).
+    // assume every eighth occurrence is a new key at most (grown further if a region still overflows).
     {
         unsigned long long used;
         uint32_t fatal;
@@ -646,76 +608,56 @@ static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint6
     const uint32_t rb = c->rb;
     if (rb < 2) return fail(c, MC_EINVAL, "internal: partitioned counting needs at least 4 table regions");
     const uint32_t lb = std::min<uint32_t>(rb, 18);  // leaf bits; a leaf covers 2^(rb - lb) regions
-    const uint32_t b1 = (lb + 1) / 2, b2 = lb - b1;
-    uint32_t g = rb - lb;
-    const uint64_t np1 = 1ull << b1, n_leaves = 1ull << lb;
-    const uint64_t cap1 = (uint64_t)((double)wb / (double)np1 * 1.04) + 16384;
-    const double mean_leaf = (double)wb / (double)n_leaves;
-    const uint64_t cap2 = (uint64_t)(mean_leaf * 1.15 + 8.0 * std::sqrt(mean_leaf) + 64.0);
-    const uint64_t n_tiles1 = (n_bases + PT_TILE - 1) / PT_TILE;
-    const uint64_t tiles2_max = wb / PT_TILE + np1 + 1;
-    const uint64_t spill_cap = std::max<uint64_t>(wb / 64, 1u << 20);
-
+    pl->b1 = (lb + 1) / 2;
+    pl->b2 = lb - pl->b1;
+    pl->g = rb - lb;
+    pl->wb = wb;
+    pl->np1 = 1ull << pl->b1;
+    pl->n_leaves = 1ull << lb;
+    pl->cap1 = (uint64_t)((double)wb / (double)pl->np1 * 1.04) + 16384;
+    const double mean_leaf = (double)wb / (double)pl->n_leaves;
+    pl->cap2 = (uint64_t)(mean_leaf * 1.15 + 8.0 * std::sqrt(mean_leaf) + 64.0);
+    pl->tiles2_max = wb / PT_TILE + pl->np1 + 1;
+    pl->spill_cap = std::max<uint64_t>(wb / 64, 1u << 20);
+    const uint64_t np1 = pl->np1, n_leaves = pl->n_leaves;
     int rc;
     uint64_t dummy;
 #define ENSURE(ptr, capvar, need) do { rc = ensure_buf(c, &(ptr), &(capvar), (need)); if (rc) return rc; } while (0)
-    { uint64_t cap = P.a_cap; ENSURE(P.a_keys, cap, np1 * cap1); dummy = P.a_cap; ENSURE(P.a_hints, dummy, np1 * cap1); P.a_cap = cap; }
-    { uint64_t cap = P.b_cap; ENSURE(P.b_keys, cap, n_leaves * cap2); dummy = P.b_cap; ENSURE(P.b_hints, dummy, n_leaves * cap2); P.b_cap = cap; }
-    { uint64_t cap = P.spill_cap; ENSURE(P.spill_keys, cap, spill_cap); dummy = P.spill_cap; ENSURE(P.spill_hints, dummy, spill_cap); P.spill_cap = cap; }
-    ENSURE(P.tile_first, P.tiles1_cap, n_tiles1);
-    ENSURE(P.tile_map, P.tiles2_cap, tiles2_max);
+    { uint64_t cap = P.a_cap; ENSURE(P.a_keys, cap, np1 * pl->cap1); dummy = P.a_cap; ENSURE(P.a_hints, dummy, np1 * pl->cap1); P.a_cap = cap; }
+    { uint64_t cap = P.b_cap; ENSURE(P.b_keys, cap, n_leaves * pl->cap2); dummy = P.b_cap; ENSURE(P.b_hints, dummy, n_leaves * pl->cap2); P.b_cap = cap; }
+    { uint64_t cap = P.spill_cap; ENSURE(P.spill_keys, cap, pl->spill_cap); dummy = P.spill_cap; ENSURE(P.spill_hints, dummy, pl->spill_cap); P.spill_cap = cap; }
+    ENSURE(P.tile_map, P.tiles2_cap, pl->tiles2_max);
     { uint64_t cap = P.leaves_cap; ENSURE(P.cursors2, cap, n_leaves); dummy = P.leaves_cap; ENSURE(P.leaf_state, dummy, n_leaves); dummy = P.leaves_cap; ENSURE(P.leaf_new, dummy, n_leaves); P.leaves_cap = cap; }
+#undef ENSURE
     if (!P.cursors1) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.cursors1), PT_MAX_BUCKETS * CURSOR1_STRIDE * sizeof(uint32_t)));
     if (!P.flags) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.flags), 2 * sizeof(uint32_t)));
     if (!P.spill_count) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.spill_count), sizeof(unsigned long long)));
-#undef ENSURE
     HIPCHK(c, hipMemsetAsync(P.cursors1, 0, PT_MAX_BUCKETS * CURSOR1_STRIDE * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(P.cursors2, 0, n_leaves * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(P.leaf_state, 0, n_leaves * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(P.leaf_new, 0, n_leaves * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(P.flags, 0, 2 * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(P.spill_count, 0, sizeof(unsigned long long), c->stream));
-    const SpillView sp{P.spill_keys, P.spill_hints, P.spill_count, spill_cap, P.flags};
-    const int k = c->cfg.k;
-    const uint64_t *offs = d_off + r0;
-    const uint64_t nr = r1 - r0;
-    // tiles are cut over the absolute base positions [0, h_off[r1]); the ones before base0 hold no read of ours
-    const uint64_t n_bases_abs = end_abs;
-    const uint64_t n_tiles_abs = (n_bases_abs + PT_TILE - 1) / PT_TILE;
-    if (n_tiles_abs > P.tiles1_cap) { rc = ensure_buf(c, &P.tile_first, &P.tiles1_cap, n_tiles_abs); if (rc) return rc; }
-    (void)n_tiles1;
+    pl->sp = SpillView{P.spill_keys, P.spill_hints, P.spill_count, pl->spill_cap, P.flags};
+    return MC_OK;
+}
 
-    double ms1 = 0, ms2 = 0, ms3 = 0;
-    rc = timed(c, &ms1, [&] {
-        hipLaunchKernelGGL(k_tile_first_read, dim3((unsigned)((n_tiles_abs + 255) / 256)), dim3(256), 0, c->stream, offs, nr,
-                           n_tiles_abs, P.tile_first);
-        const int grid = (int)std::min<uint64_t>(n_tiles_abs, 256 * 1);
-        switch (c->cfg.key_mode) {
-        case MC_KEY_PACKED:
-            hipLaunchKernelGGL(k_p1_extract_scatter<KEY_PACKED>, dim3(grid), dim3(PT_THREADS), 0, c->stream, d_words, offs,
-                               nr, base0, n_bases_abs, n_tiles_abs, P.tile_first, k, b1, P.cursors1, cap1, P.a_keys, P.a_hints,
-                               c->d_ctr + 1, sp);
-            break;
-        case MC_KEY_POLY:
-            hipLaunchKernelGGL(k_p1_extract_scatter<KEY_POLY>, dim3(grid), dim3(PT_THREADS), 0, c->stream, d_words, offs, nr,
-                               base0, n_bases_abs, n_tiles_abs, P.tile_first, k, b1, P.cursors1, cap1, P.a_keys, P.a_hints,
-                               c->d_ctr + 1, sp);
-            break;
-        default:
-            hipLaunchKernelGGL(k_p1_extract_scatter<KEY_FNV1A>, dim3(grid), dim3(PT_THREADS), 0, c->stream, d_words, offs,
-                               nr, base0, n_bases_abs, n_tiles_abs, P.tile_first, k, b1, P.cursors1, cap1, P.a_keys, P.a_hints,
-                               c->d_ctr + 1, sp);
-        }
-    });
-    if (rc) return rc;
+// P2, P3 (with the retry after growing the table), spill drain and bookkeeping; ms1 = time of the
+// level-1 scatter that filled the a_* buckets.
+static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1)
+{
+    mc_ctx::Pipe &P = c->pipe;
+    const uint64_t np1 = pl.np1, n_leaves = pl.n_leaves;
+    int rc;
+    double ms2 = 0, ms3 = 0;
     // tile map of P2 from the level-1 bucket sizes
     std::vector<uint32_t> cnt1raw(np1 * CURSOR1_STRIDE), cnt1(np1);
     HIPCHK(c, hipMemcpy(cnt1raw.data(), P.cursors1, cnt1raw.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (uint64_t b = 0; b < np1; b++) cnt1[b] = cnt1raw[b * CURSOR1_STRIDE];
     std::vector<uint64_t> tmap;
-    tmap.reserve(tiles2_max);
+    tmap.reserve(pl.tiles2_max);
     for (uint64_t b = 0; b < np1; b++) {
-        const uint64_t have = std::min<uint64_t>(cnt1[b], cap1);
+        const uint64_t have = std::min<uint64_t>(cnt1[b], pl.cap1);
         for (uint64_t f = 0; f < have; f += PT_TILE) tmap.push_back((b << 32) | f);
     }
     if (tmap.size() > P.tiles2_cap) return fail(c, MC_EOVERFLOW, "internal: P2 tile map overflow");
@@ -723,8 +665,9 @@ static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint6
         HIPCHK(c, hipMemcpyAsync(P.tile_map, tmap.data(), tmap.size() * 8, hipMemcpyHostToDevice, c->stream));
         rc = timed(c, &ms2, [&] {
             const int grid = (int)std::min<uint64_t>(tmap.size(), 256 * 1);
-            hipLaunchKernelGGL(k_p2_scatter, dim3(grid), dim3(PT_THREADS), 0, c->stream, P.a_keys, P.a_hints, cap1,
-                               P.cursors1, P.tile_map, (uint64_t)tmap.size(), b1, b2, P.cursors2, cap2, P.b_keys, P.b_hints, sp);
+            hipLaunchKernelGGL(k_p2_scatter, dim3(grid), dim3(PT_THREADS), 0, c->stream, P.a_keys, P.a_hints, pl.cap1,
+                               P.cursors1, P.tile_map, (uint64_t)tmap.size(), pl.b1, pl.b2, P.cursors2, pl.cap2, P.b_keys,
+                               P.b_hints, pl.sp);
         });
         if (rc) return rc;
     }
@@ -733,8 +676,8 @@ static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint6
         const int virgin = c->virgin ? 1 : 0;
         rc = timed(c, &ms3, [&] {
             const int grid = (int)std::min<uint64_t>(n_leaves, 256 * 2 * 4);
-            hipLaunchKernelGGL(k_p3_merge, dim3(grid), dim3(P3_THREADS), 0, c->stream, P.b_keys, P.b_hints, P.cursors2, cap2,
-                               (uint32_t)n_leaves, g, c->view(), virgin, P.leaf_state, P.leaf_new, P.flags + 1);
+            hipLaunchKernelGGL(k_p3_merge, dim3(grid), dim3(P3_THREADS), 0, c->stream, P.b_keys, P.b_hints, P.cursors2, pl.cap2,
+                               (uint32_t)n_leaves, pl.g, c->view(), virgin, P.leaf_state, P.leaf_new, P.flags + 1);
         });
         if (rc) return rc;
         c->virgin = false;
@@ -742,11 +685,11 @@ static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint6
         HIPCHK(c, hipMemcpy(flags, P.flags, sizeof flags, hipMemcpyDeviceToHost));
         if (flags[0]) return fail(c, MC_EOVERFLOW, "internal: spill list of the partitioned counting pipeline overflowed");
         if (!flags[1]) break;
-        if (attempt >= 6 || g >= 5)
+        if (attempt >= 6 || pl.g >= 5)
             return fail(c, MC_EOVERFLOW, "k-mer table regions keep overflowing; pass a capacity_hint (distinct k-mers)");
         rc = table_grow(c, c->rb + c->sb + 1);
         if (rc) return rc;
-        g++;
+        pl.g++;
         HIPCHK(c, hipMemsetAsync(P.flags + 1, 0, sizeof(uint32_t), c->stream));
     }
     hipLaunchKernelGGL(k_sum_leaf_new, dim3(64), dim3(256), 0, c->stream, P.leaf_new, (uint32_t)n_leaves, c->d_ctr);
@@ -777,8 +720,78 @@ static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint6
     c->st.count_ms += ms1 + ms2 + ms3 + ms4;
     c->st.count_total_ms += ms1 + ms2 + ms3 + ms4;
     c->st.count_launches++;
-    c->st.windows += wb;
+    c->st.windows += pl.wb;
     return MC_OK;
+}
+
+static void launch_p1_reads(mc_ctx *c, const uint64_t *d_words, const uint64_t *offs, uint64_t nr, uint64_t base0,
+                            uint64_t end_abs, uint64_t n_tiles_abs, const uint32_t *tile_first, uint32_t b1, uint32_t *cursors,
+                            uint64_t cap, uint64_t *out_keys, uint32_t *out_hints, const SpillView &sp, int owners_mode,
+                            const uint64_t *bases)
+{   // owners_mode: 0 = hash-prefix buckets (counting), 1 = count per owner, 2 = scatter per owner at `bases`
+    const int grid = (int)std::min<uint64_t>(std::max<uint64_t>(n_tiles_abs - base0 / PT_TILE, 1), 256 * 1);
+    const int k = c->cfg.k;
+#define P1_ARGS d_words, offs, nr, base0, end_abs, n_tiles_abs, tile_first, k, b1, cursors, cap, out_keys, out_hints, c->d_ctr + 1, sp, bases
+#define P1_LAUNCH(MODE)                                                                                                  \
+    do {                                                                                                                 \
+        if (owners_mode == 0)                                                                                            \
+            hipLaunchKernelGGL((k_p1_extract_scatter<MODE, false, false>), dim3(grid), dim3(PT_THREADS), 0, c->stream, P1_ARGS); \
+        else if (owners_mode == 1)                                                                                       \
+            hipLaunchKernelGGL((k_p1_extract_scatter<MODE, true, true>), dim3(grid), dim3(PT_THREADS), 0, c->stream, P1_ARGS);   \
+        else                                                                                                             \
+            hipLaunchKernelGGL((k_p1_extract_scatter<MODE, true, false>), dim3(grid), dim3(PT_THREADS), 0, c->stream, P1_ARGS);  \
+    } while (0)
+    switch (c->cfg.key_mode) {
+    case MC_KEY_PACKED: P1_LAUNCH(KEY_PACKED); break;
+    case MC_KEY_POLY: P1_LAUNCH(KEY_POLY); break;
+    default: P1_LAUNCH(KEY_FNV1A);
+    }
+#undef P1_LAUNCH
+#undef P1_ARGS
+}
+
+// One batch of reads [r0, r1) through the partitioned pipeline (count_pipeline.h).  wb = its windows,
+// base0 / end_abs = read_offsets[r0] / read_offsets[r1].
+static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_off, uint64_t r0, uint64_t r1,
+                                 uint64_t base0, uint64_t end_abs, uint64_t wb)
+{
+    mc_ctx::Pipe &P = c->pipe;
+    PipePlan pl;
+    int rc = pipe_prepare(c, wb, &pl);
+    if (rc) return rc;
+    const uint64_t *offs = d_off + r0;
+    const uint64_t nr = r1 - r0;
+    // tiles are cut over the absolute base positions [0, end_abs); the ones before base0 hold no read of ours
+    const uint64_t n_tiles_abs = (end_abs + PT_TILE - 1) / PT_TILE;
+    rc = ensure_buf(c, &P.tile_first, &P.tiles1_cap, n_tiles_abs);
+    if (rc) return rc;
+    double ms1 = 0;
+    rc = timed(c, &ms1, [&] {
+        hipLaunchKernelGGL(k_tile_first_read, dim3((unsigned)((n_tiles_abs + 255) / 256)), dim3(256), 0, c->stream, offs, nr,
+                           n_tiles_abs, P.tile_first);
+        launch_p1_reads(c, d_words, offs, nr, base0, end_abs, n_tiles_abs, P.tile_first, pl.b1, P.cursors1, pl.cap1, P.a_keys,
+                        P.a_hints, pl.sp, 0, nullptr);
+    });
+    if (rc) return rc;
+    return pipe_finish(c, pl, ms1);
+}
+
+// A flat stream of keys (+ optional hints) through the partitioned pipeline: the keys a rank owns
+// after the multi-GPU exchange.
+static int add_keys_partitioned(mc_ctx *c, const uint64_t *d_keys, const uint32_t *d_hints, uint64_t n)
+{
+    mc_ctx::Pipe &P = c->pipe;
+    PipePlan pl;
+    int rc = pipe_prepare(c, n, &pl);
+    if (rc) return rc;
+    double ms1 = 0;
+    rc = timed(c, &ms1, [&] {
+        const uint64_t n_tiles = (n + PT_TILE - 1) / PT_TILE;
+        hipLaunchKernelGGL(k_p1_keys_scatter, dim3((unsigned)std::min<uint64_t>(n_tiles, 256)), dim3(PT_THREADS), 0, c->stream,
+                           d_keys, d_hints, n, pl.b1, P.cursors1, pl.cap1, P.a_keys, P.a_hints, c->d_ctr + 1, pl.sp);
+    });
+    if (rc) return rc;
+    return pipe_finish(c, pl, ms1);
 }
 
 // counting with read offsets known on the host
@@ -1012,33 +1025,49 @@ int mc_add_reads_packed_dev(mc_ctx *c, const uint64_t *d_words, const uint64_t *
     return add_reads_impl(c, d_words, d_off, h_off.data(), n_reads);
 }
 
-int mc_add_keys_dev(mc_ctx *c, const int64_t *d_keys, uint64_t n)
+int mc_add_keys_dev(mc_ctx *c, const int64_t *d_keys, const uint32_t *d_hints, uint64_t n)
 {
     if (!c) return MC_EINVAL;
     std::lock_guard<std::mutex> g(c->mu);
     if (!d_keys && n) return fail(c, MC_EINVAL, "mc_add_keys_dev: null pointer");
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    uint64_t i = 0;
-    while (i < n) {
-        uint64_t allowed;
-        int rc = table_reserve(c, n - i, &allowed);
-        if (rc) return rc;
-        const uint64_t m = std::min<uint64_t>(allowed, n - i);
-        double ms = 0;
-        rc = timed(c, &ms, [&] {
-            hipLaunchKernelGGL(k_add_keys, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, d_keys + i, m, c->view());
-        });
-        if (rc) return rc;
-        c->st.count_total_ms += ms;
-        c->st.windows += m;
-        i += m;
+    const bool partition = c->count_path == 2 || (c->count_path == 0 && n >= (1ull << 22));
+    if (partition) {
+        const uint64_t max_batch = (1ull << 31) - (1ull << 24);
+        for (uint64_t i = 0; i < n; i += max_batch) {
+            const uint64_t m = std::min<uint64_t>(max_batch, n - i);
+            int rc = add_keys_partitioned(c, reinterpret_cast<const uint64_t *>(d_keys) + i, d_hints ? d_hints + i : nullptr, m);
+            if (rc) return rc;
+        }
+    } else {
+        uint64_t i = 0;
+        while (i < n) {
+            uint64_t allowed;
+            int rc = table_reserve(c, n - i, &allowed);
+            if (rc) return rc;
+            const uint64_t m = std::min<uint64_t>(allowed, n - i);
+            double ms = 0;
+            rc = timed(c, &ms, [&] {
+                if (d_hints)
+                    hipLaunchKernelGGL(k_add_keys_hint, dim3(grid_for(m, 256)), dim3(256), 0, c->stream,
+                                       reinterpret_cast<const uint64_t *>(d_keys) + i, d_hints + i, m, c->view());
+                else
+                    hipLaunchKernelGGL(k_add_keys, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, d_keys + i, m, c->view());
+            });
+            if (rc) return rc;
+            c->st.count_ms += ms;
+            c->st.count_total_ms += ms;
+            c->st.count_launches++;
+            c->st.windows += m;
+            i += m;
+        }
     }
     c->finalized = false;
     c->solid_cov = -1;
     return MC_OK;
 }
 
-int mc_add_pairs_dev(mc_ctx *c, const int64_t *d_keys, const int16_t *d_counts, uint64_t n)
+int mc_add_pairs_dev(mc_ctx *c, const int64_t *d_keys, const int16_t *d_counts, const uint32_t *d_hints, uint64_t n)
 {
     if (!c) return MC_EINVAL;
     std::lock_guard<std::mutex> g(c->mu);
@@ -1050,8 +1079,8 @@ int mc_add_pairs_dev(mc_ctx *c, const int64_t *d_keys, const int16_t *d_counts, 
         int rc = table_reserve(c, n - i, &allowed);
         if (rc) return rc;
         const uint64_t m = std::min<uint64_t>(allowed, n - i);
-        hipLaunchKernelGGL(k_add_pairs, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, d_keys + i, d_counts + i, m,
-                           c->view());
+        hipLaunchKernelGGL(k_add_pairs, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, d_keys + i, d_counts + i,
+                           d_hints ? d_hints + i : nullptr, m, c->view());
         HIPCHK(c, hipGetLastError());
         i += m;
     }
@@ -1134,56 +1163,61 @@ uint32_t mc_key_owner(int64_t key, uint32_t n_owners)
 }
 
 int mc_extract_keys_dev(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_off, uint64_t n_reads, uint64_t n_bases,
-                        uint32_t n_owners, int64_t *d_keys, uint64_t cap, uint64_t *owner_offsets)
+                        uint32_t n_owners, int64_t *d_keys, uint32_t *d_hints, uint64_t cap, uint64_t *owner_offsets)
 {
     if (!c) return MC_EINVAL;
     std::lock_guard<std::mutex> g(c->mu);
-    if (!owner_offsets || n_owners == 0 || n_owners > 1024)
+    if (!owner_offsets || n_owners == 0 || n_owners > PT_MAX_BUCKETS)
         return fail(c, MC_EINVAL, "mc_extract_keys_dev: bad n_owners / owner_offsets");
-    (void)n_bases;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    DevBuf<unsigned long long> cur;
-    HIPCHK(c, cur.alloc(n_owners));
-    std::vector<unsigned long long> h(n_owners, 0);
-    const int grid = grid_for(n_reads * 64, 256);
-    const int k = c->cfg.k;
-#define LAUNCH_EXTRACT(SC)                                                                                            \
-    switch (c->cfg.key_mode) {                                                                                        \
-    case MC_KEY_PACKED:                                                                                               \
-        hipLaunchKernelGGL((k_extract_keys<KEY_PACKED, SC>), dim3(grid), dim3(256), 0, c->stream, d_words, d_off,     \
-                           n_reads, k, n_owners, cur.p, d_keys, cap);                                                 \
-        break;                                                                                                        \
-    case MC_KEY_POLY:                                                                                                 \
-        hipLaunchKernelGGL((k_extract_keys<KEY_POLY, SC>), dim3(grid), dim3(256), 0, c->stream, d_words, d_off,       \
-                           n_reads, k, n_owners, cur.p, d_keys, cap);                                                 \
-        break;                                                                                                        \
-    default:                                                                                                          \
-        hipLaunchKernelGGL((k_extract_keys<KEY_FNV1A, SC>), dim3(grid), dim3(256), 0, c->stream, d_words, d_off,      \
-                           n_reads, k, n_owners, cur.p, d_keys, cap);                                                 \
-    }
-    // pass 1: histogram per owner
-    HIPCHK(c, hipMemsetAsync(cur.p, 0, n_owners * sizeof(unsigned long long), c->stream));
-    if (n_reads) { LAUNCH_EXTRACT(false) }
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(h.data(), cur.p, n_owners * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    for (uint32_t o = 0; o <= n_owners; o++) owner_offsets[o] = 0;
+    if (n_reads == 0) return MC_OK;
+    mc_ctx::Pipe &P = c->pipe;
+    uint64_t first_off = 0, last_off = 0;
+    HIPCHK(c, hipMemcpyAsync(&first_off, d_off, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&last_off, d_off + n_reads, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    owner_offsets[0] = 0;
-    for (uint32_t o = 0; o < n_owners; o++) owner_offsets[o + 1] = owner_offsets[o] + h[o];
+    if (last_off != n_bases)
+        return fail(c, MC_EINVAL, "mc_extract_keys_dev: read_offsets[n_reads]=%llu but n_bases=%llu",
+                    (unsigned long long)last_off, (unsigned long long)n_bases);
+    const uint64_t n_tiles_abs = (last_off + PT_TILE - 1) / PT_TILE;
+    int rc = ensure_buf(c, &P.tile_first, &P.tiles1_cap, n_tiles_abs);
+    if (rc) return rc;
+    if (!P.cursors1) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.cursors1), PT_MAX_BUCKETS * CURSOR1_STRIDE * sizeof(uint32_t)));
+    DevBuf<uint64_t> d_bases;
+    HIPCHK(c, d_bases.alloc(n_owners));
+    const SpillView nosp{nullptr, nullptr, nullptr, 0, nullptr};
+    // pass 1: how many keys every owner gets
+    HIPCHK(c, hipMemsetAsync(P.cursors1, 0, PT_MAX_BUCKETS * CURSOR1_STRIDE * sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(k_tile_first_read, dim3((unsigned)((n_tiles_abs + 255) / 256)), dim3(256), 0, c->stream, d_off, n_reads,
+                       n_tiles_abs, P.tile_first);
+    launch_p1_reads(c, d_words, d_off, n_reads, first_off, last_off, n_tiles_abs, P.tile_first, n_owners, P.cursors1, 0, nullptr,
+                    nullptr, nosp, 1, nullptr);
+    HIPCHK(c, hipGetLastError());
+    std::vector<uint32_t> raw((size_t)n_owners * CURSOR1_STRIDE);
+    HIPCHK(c, hipMemcpyAsync(raw.data(), P.cursors1, raw.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<uint64_t> bases(n_owners);
+    for (uint32_t o = 0; o < n_owners; o++) {
+        bases[o] = owner_offsets[o];
+        owner_offsets[o + 1] = owner_offsets[o] + raw[(size_t)o * CURSOR1_STRIDE];
+    }
+    if (!d_keys) return MC_OK;
     if (owner_offsets[n_owners] > cap)
         return fail(c, MC_EINVAL, "mc_extract_keys_dev: %llu keys but capacity %llu",
                     (unsigned long long)owner_offsets[n_owners], (unsigned long long)cap);
-    if (!d_keys) return MC_OK;
-    // pass 2: scatter with cursors starting at the bucket offsets
-    std::vector<unsigned long long> start(owner_offsets, owner_offsets + n_owners);
-    HIPCHK(c, hipMemcpyAsync(cur.p, start.data(), n_owners * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
-    if (n_reads) { LAUNCH_EXTRACT(true) }
-#undef LAUNCH_EXTRACT
+    // pass 2: the same tiles again, now writing every owner's keys (and hints) into its packed range
+    HIPCHK(c, hipMemcpyAsync(d_bases.p, bases.data(), n_owners * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(P.cursors1, 0, PT_MAX_BUCKETS * CURSOR1_STRIDE * sizeof(uint32_t), c->stream));
+    launch_p1_reads(c, d_words, d_off, n_reads, first_off, last_off, n_tiles_abs, P.tile_first, n_owners, P.cursors1, 0,
+                    reinterpret_cast<uint64_t *>(d_keys), d_hints, nosp, 2, d_bases.p);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MC_OK;
 }
 
-int mc_export_dev(mc_ctx *c, int min_cov, int64_t *d_keys, int16_t *d_counts, uint64_t cap, uint64_t *n_out)
+int mc_export_dev(mc_ctx *c, int min_cov, int64_t *d_keys, int16_t *d_counts, uint32_t *d_hints, uint64_t cap,
+                  uint64_t *n_out)
 {
     if (!c) return MC_EINVAL;
     std::lock_guard<std::mutex> g(c->mu);
@@ -1194,7 +1228,7 @@ int mc_export_dev(mc_ctx *c, int min_cov, int64_t *d_keys, int16_t *d_counts, ui
     unsigned long long *cursor = c->d_ctr + 2;
     HIPCHK(c, hipMemsetAsync(cursor, 0, sizeof(unsigned long long), c->stream));
     hipLaunchKernelGGL(k_export, dim3(grid_for(c->n_slots(), 256)), dim3(256), 0, c->stream, c->slots, c->n_slots(),
-                       min_cov, d_keys, d_counts, cap, cursor);
+                       min_cov, d_keys, d_counts, d_hints, cap, cursor);
     HIPCHK(c, hipGetLastError());
     unsigned long long n = 0, empty_cnt = 0;
     HIPCHK(c, hipMemcpyAsync(&n, cursor, sizeof n, hipMemcpyDeviceToHost, c->stream));
@@ -1208,6 +1242,7 @@ int mc_export_dev(mc_ctx *c, int min_cov, int64_t *d_keys, int16_t *d_counts, ui
             const int16_t cc = (int16_t)ec;
             HIPCHK(c, hipMemcpy(d_keys + n, &kk, 8, hipMemcpyHostToDevice));
             HIPCHK(c, hipMemcpy(d_counts + n, &cc, 2, hipMemcpyHostToDevice));
+            if (d_hints) HIPCHK(c, hipMemset(d_hints + n, 0, 4));
         }
         n++;
     }
@@ -1219,7 +1254,7 @@ int mc_export_dev(mc_ctx *c, int min_cov, int64_t *d_keys, int16_t *d_counts, ui
 int mc_export(mc_ctx *c, int min_cov, int64_t *keys, int16_t *counts, uint64_t cap, uint64_t *n_out)
 {
     if (!c) return MC_EINVAL;
-    if (!keys) return mc_export_dev(c, min_cov, nullptr, nullptr, 0, n_out);
+    if (!keys) return mc_export_dev(c, min_cov, nullptr, nullptr, nullptr, 0, n_out);
     DevBuf<int64_t> dk;
     DevBuf<int16_t> dc;
     {
@@ -1228,7 +1263,7 @@ int mc_export(mc_ctx *c, int min_cov, int64_t *keys, int16_t *counts, uint64_t c
         HIPCHK(c, dk.alloc(cap));
         HIPCHK(c, dc.alloc(cap));
     }
-    int rc = mc_export_dev(c, min_cov, dk.p, dc.p, cap, n_out);
+    int rc = mc_export_dev(c, min_cov, dk.p, dc.p, nullptr, cap, n_out);
     if (rc) return rc;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipMemcpy(keys, dk.p, *n_out * 8, hipMemcpyDeviceToHost));
@@ -1316,7 +1351,7 @@ int ensure_solid(mc_ctx *c, int min_cov, double *ms)
     HIPCHK(c, hipMemsetAsync(cursor, 0, sizeof(unsigned long long), c->stream));
     int rc = timed(c, ms, [&] {
         hipLaunchKernelGGL(k_export, dim3(grid_for(c->n_slots(), 256)), dim3(256), 0, c->stream, c->slots,
-                           c->n_slots(), min_cov, (int64_t *)nullptr, (int16_t *)nullptr, (uint64_t)0, cursor);
+                           c->n_slots(), min_cov, (int64_t *)nullptr, (int16_t *)nullptr, (uint32_t *)nullptr, (uint64_t)0, cursor);
     });
     if (rc) return rc;
     unsigned long long n = 0;

@@ -37,20 +37,26 @@ class ShardedCounter:
             ctx.add_reads_packed_dev(d_words, d_offsets, n_reads, n_bases)
             return
         send = torch.empty(max(int(max_windows), 1), dtype=torch.int64, device=self.device)
-        off = ctx.extract_keys_dev(d_words, d_offsets, n_reads, n_bases, W, send, send.numel())
+        send_h = torch.empty(max(int(max_windows), 1), dtype=torch.int32, device=self.device)  # speculation hints
+        off = ctx.extract_keys_dev(d_words, d_offsets, n_reads, n_bases, W, send, send.numel(), send_h)
         send_counts = [int(off[o + 1] - off[o]) for o in range(W)]
         sc = torch.tensor(send_counts, dtype=torch.int64, device=self.device)
         rc = torch.empty(W, dtype=torch.int64, device=self.device)
         dist.all_to_all_single(rc, sc, group=self.group)
         recv_counts = [int(x) for x in rc.cpu().tolist()]
-        recv = torch.empty(max(sum(recv_counts), 1), dtype=torch.int64, device=self.device)
+        n_recv = sum(recv_counts)
+        recv = torch.empty(max(n_recv, 1), dtype=torch.int64, device=self.device)
+        recv_h = torch.empty(max(n_recv, 1), dtype=torch.int32, device=self.device)
         n_send = int(off[W])
-        dist.all_to_all_single(recv[:sum(recv_counts)], send[:n_send], output_split_sizes=recv_counts,
+        dist.all_to_all_single(recv[:n_recv], send[:n_send], output_split_sizes=recv_counts,
+                               input_split_sizes=send_counts, group=self.group)
+        dist.all_to_all_single(recv_h[:n_recv], send_h[:n_send], output_split_sizes=recv_counts,
                                input_split_sizes=send_counts, group=self.group)
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
-        self.bytes_sent += 8 * (n_send - send_counts[self.rank])
-        ctx.add_keys_dev(recv, sum(recv_counts))
+        self.bytes_sent += 12 * (n_send - send_counts[self.rank])
+        del send, send_h
+        ctx.add_keys_dev(recv, n_recv, recv_h)
 
     def finalize(self):
         """Local distinct keys; the sum over ranks is the table size (owners are disjoint)."""
@@ -75,19 +81,23 @@ class ShardedCounter:
         mx = max(max(sizes), 1)
         keys = torch.zeros(mx, dtype=torch.int64, device=self.device)
         cnts = torch.zeros(mx, dtype=torch.int16, device=self.device)
-        got = ctx.export_dev(min_cov, keys, cnts, mx)
+        hints = torch.zeros(mx, dtype=torch.int32, device=self.device)
+        got = ctx.export_dev(min_cov, keys, cnts, mx, hints)
         assert got == n_local
         all_k = torch.empty(W * mx, dtype=torch.int64, device=self.device)
         all_c = torch.empty(W * mx, dtype=torch.int16, device=self.device)
+        all_h = torch.empty(W * mx, dtype=torch.int32, device=self.device)
         dist.all_gather_into_tensor(all_k, keys, group=self.group)
         # counts travel as bytes: neither RCCL nor gloo has a 16-bit integer type
         dist.all_gather_into_tensor(all_c.view(torch.uint8), cnts.view(torch.uint8), group=self.group)
+        dist.all_gather_into_tensor(all_h, hints, group=self.group)
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
         if dst is None or self.rank == dst:
             for r in range(W):
                 if sizes[r]:
-                    solid_ctx.add_pairs_dev(all_k[r * mx:r * mx + sizes[r]], all_c[r * mx:r * mx + sizes[r]], sizes[r])
+                    sl = slice(r * mx, r * mx + sizes[r])
+                    solid_ctx.add_pairs_dev(all_k[sl], all_c[sl], sizes[r], all_h[sl])
             solid_ctx.finalize()
         return sum(sizes)
 

@@ -92,12 +92,12 @@ def load():
     L.mc_bfs_result_free.argtypes = [C.POINTER(_BfsResult)]
     L.mc_bfs_result_free.restype = None
     L.mc_export.argtypes = [vp, i32, i64p, i16p, u64, u64p]
-    L.mc_export_dev.argtypes = [vp, i32, vp, vp, u64, u64p]
-    L.mc_add_pairs_dev.argtypes = [vp, vp, vp, u64]
+    L.mc_export_dev.argtypes = [vp, i32, vp, vp, vp, u64, u64p]
+    L.mc_add_pairs_dev.argtypes = [vp, vp, vp, vp, u64]
     L.mc_key_owner.argtypes = [i64, C.c_uint32]
     L.mc_key_owner.restype = C.c_uint32
-    L.mc_extract_keys_dev.argtypes = [vp, vp, vp, u64, u64, C.c_uint32, vp, u64, u64p]
-    L.mc_add_keys_dev.argtypes = [vp, vp, u64]
+    L.mc_extract_keys_dev.argtypes = [vp, vp, vp, u64, u64, C.c_uint32, vp, vp, u64, u64p]
+    L.mc_add_keys_dev.argtypes = [vp, vp, vp, u64]
     L.mc_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.mc_reset_stats.argtypes = [vp]
     L.mc_synth_reads_dev.argtypes = [vp, u64, u64, u64, u64, u64, u64, C.c_uint32, C.c_uint32, vp, vp]
@@ -168,11 +168,11 @@ class Context:
     def add_reads_packed_dev(self, d_words, d_offsets, n_reads, n_bases):
         self._chk(self._L.mc_add_reads_packed_dev(self._h, _dptr(d_words), _dptr(d_offsets), n_reads, n_bases))
 
-    def add_keys_dev(self, d_keys, n):
-        self._chk(self._L.mc_add_keys_dev(self._h, _dptr(d_keys), n))
+    def add_keys_dev(self, d_keys, n, d_hints=None):
+        self._chk(self._L.mc_add_keys_dev(self._h, _dptr(d_keys), _dptr(d_hints), n))
 
-    def add_pairs_dev(self, d_keys, d_counts, n):
-        self._chk(self._L.mc_add_pairs_dev(self._h, _dptr(d_keys), _dptr(d_counts), n))
+    def add_pairs_dev(self, d_keys, d_counts, n, d_hints=None):
+        self._chk(self._L.mc_add_pairs_dev(self._h, _dptr(d_keys), _dptr(d_counts), _dptr(d_hints), n))
 
     def finalize(self):
         n = C.c_uint64(0)
@@ -247,19 +247,19 @@ class Context:
 
     def export_count(self, min_cov=0):
         n = C.c_uint64(0)
-        self._chk(self._L.mc_export_dev(self._h, min_cov, None, None, 0, C.byref(n)))
+        self._chk(self._L.mc_export_dev(self._h, min_cov, None, None, None, 0, C.byref(n)))
         return int(n.value)
 
-    def export_dev(self, min_cov, d_keys, d_counts, cap):
+    def export_dev(self, min_cov, d_keys, d_counts, cap, d_hints=None):
         n = C.c_uint64(0)
-        self._chk(self._L.mc_export_dev(self._h, min_cov, _dptr(d_keys), _dptr(d_counts), cap, C.byref(n)))
+        self._chk(self._L.mc_export_dev(self._h, min_cov, _dptr(d_keys), _dptr(d_counts), _dptr(d_hints), cap, C.byref(n)))
         return int(n.value)
 
     # ---- multi-GPU building blocks
-    def extract_keys_dev(self, d_words, d_offsets, n_reads, n_bases, n_owners, d_keys, cap):
+    def extract_keys_dev(self, d_words, d_offsets, n_reads, n_bases, n_owners, d_keys, cap, d_hints=None):
         off = np.zeros(n_owners + 1, dtype=np.uint64)
         self._chk(self._L.mc_extract_keys_dev(self._h, _dptr(d_words), _dptr(d_offsets), n_reads, n_bases, n_owners,
-                                              _dptr(d_keys), cap, _p(off, C.c_uint64)))
+                                              _dptr(d_keys), _dptr(d_hints), cap, _p(off, C.c_uint64)))
         return off
 
     # ---- measurement / synthetic data

@@ -37,7 +37,7 @@ class OracleBackedContext:
                 keys.append(po.key(codes[i:i + self.k], self.k, self.mode))
         return np.array(keys, dtype=np.int64)
 
-    def extract_keys_dev(self, d_words, d_off, n_reads, n_bases, n_owners, d_keys, cap):
+    def extract_keys_dev(self, d_words, d_off, n_reads, n_bases, n_owners, d_keys, cap, d_hints=None):
         from metacherchant_amd import native
         keys = self._keys(d_words, d_off)
         owners = np.array([native.key_owner(int(x), n_owners) for x in keys], dtype=np.int64)
@@ -45,13 +45,15 @@ class OracleBackedContext:
         out = np.zeros(n_owners + 1, dtype=np.uint64)
         out[1:] = np.cumsum(np.bincount(owners, minlength=n_owners))
         d_keys[:len(keys)] = torch.from_numpy(keys[order])
+        if d_hints is not None:
+            d_hints[:len(keys)] = 0
         return out
 
-    def add_keys_dev(self, d_keys, n):
+    def add_keys_dev(self, d_keys, n, d_hints=None):
         for x in d_keys[:n].tolist():
             self.t.add(int(x), 1)
 
-    def add_pairs_dev(self, d_keys, d_counts, n):
+    def add_pairs_dev(self, d_keys, d_counts, n, d_hints=None):
         for x, c in zip(d_keys[:n].tolist(), d_counts[:n].tolist()):
             self.t.add(int(x), int(c))
 
@@ -61,7 +63,7 @@ class OracleBackedContext:
     def export_count(self, min_cov):
         return int((self.t.dump()[1] >= min_cov).sum())
 
-    def export_dev(self, min_cov, d_keys, d_counts, cap):
+    def export_dev(self, min_cov, d_keys, d_counts, cap, d_hints=None):
         k, c = self.t.dump()
         m = c >= min_cov
         n = int(m.sum())

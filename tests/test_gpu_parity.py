@@ -248,10 +248,13 @@ def test_device_pointer_path_and_generator(mc, count_path):
         ctx.close()
 
 
-def test_extract_keys_by_owner_and_merge_pairs(mc):
-    """Multi-GPU building blocks on one GPU: keys bucketed by owner, counted per owner, gathered as
-    (key, count) pairs and merged == counting everything in one table."""
+@pytest.mark.parametrize("count_path2", ["direct", "partition"])
+def test_extract_keys_by_owner_and_merge_pairs(mc, count_path2, monkeypatch):
+    """Multi-GPU building blocks on one GPU: keys (+ hints) bucketed by owner, counted per owner, gathered
+    as (key, count, hint) triples and merged == counting everything in one table; the merged table still
+    walks with long look-ahead (the hints survived the trip)."""
     import torch
+    monkeypatch.setenv("MC_COUNT_PATH", count_path2)
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(11)
     _, codes, off = ragged_case(rng, 900)
@@ -263,8 +266,11 @@ def test_extract_keys_by_owner_and_merge_pairs(mc):
         G = 3
         ex = mc.Context(k, mode, 0, 0)
         d_keys = torch.zeros(n, dtype=torch.int64, device=dev)
-        ooff = ex.extract_keys_dev(d_words, d_off, len(off) - 1, int(off[-1]), G, d_keys, n)
+        d_hints = torch.zeros(n, dtype=torch.int32, device=dev)
+        ooff = ex.extract_keys_dev(d_words, d_off, len(off) - 1, int(off[-1]), G, d_keys, n, d_hints)
         assert int(ooff[-1]) == n
+        only_offsets = ex.extract_keys_dev(d_words, d_off, len(off) - 1, int(off[-1]), G, None, 0)
+        assert np.array_equal(only_offsets, ooff)
         keys = d_keys.cpu().numpy()
         for o in range(G):
             seg = keys[int(ooff[o]):int(ooff[o + 1])]
@@ -272,13 +278,14 @@ def test_extract_keys_by_owner_and_merge_pairs(mc):
         merged = mc.Context(k, mode, 0, 0)
         for o in range(G):
             own = mc.Context(k, mode, 0, 0)
-            seg = d_keys[int(ooff[o]):int(ooff[o + 1])]
-            own.add_keys_dev(seg, len(seg))
+            a, b = int(ooff[o]), int(ooff[o + 1])
+            own.add_keys_dev(d_keys[a:b], b - a, d_hints[a:b])
             nd = own.finalize()
             pk = torch.zeros(nd, dtype=torch.int64, device=dev)
             pc = torch.zeros(nd, dtype=torch.int16, device=dev)
-            assert own.export_dev(0, pk, pc, nd) == nd
-            merged.add_pairs_dev(pk, pc, nd)
+            ph = torch.zeros(nd, dtype=torch.int32, device=dev)
+            assert own.export_dev(0, pk, pc, nd, ph) == nd
+            merged.add_pairs_dev(pk, pc, nd, ph)
             own.close()
         _assert_tables_equal(merged, merged.finalize(), t)
         # thresholded export
@@ -287,3 +294,32 @@ def test_extract_keys_by_owner_and_merge_pairs(mc):
         assert np.array_equal(gk, ok[oc >= 3]) and np.array_equal(gc, oc[oc >= 3])
         ex.close()
         merged.close()
+
+
+def test_hints_survive_exchange_and_speed_up_the_walk(mc):
+    """Same results with and without hints; with them the BFS needs far fewer memory round trips."""
+    import torch
+    dev = torch.device("cuda:0")
+    genome, reads, off = synth_case(1, 60000, 20000, 150, 0)
+    n = 20000 * 120
+    words = po.pack(reads)
+    d_words = torch.from_numpy(words.view(np.int64)).to(dev)
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    ex = mc.Context(31, mc.KEY_PACKED, 0, 0)
+    d_keys = torch.zeros(n, dtype=torch.int64, device=dev)
+    d_hints = torch.zeros(n, dtype=torch.int32, device=dev)
+    ooff = ex.extract_keys_dev(d_words, d_off, 20000, 20000 * 150, 1, d_keys, n, d_hints)
+    assert int(ooff[1]) == n
+    hi, lo = seed_windows(genome[30000:30200], 31)
+    rounds = {}
+    res = {}
+    for name, h in (("with", d_hints), ("without", None)):
+        c = mc.Context(31, mc.KEY_PACKED, 0, 200000)
+        c.add_keys_dev(d_keys, n, h)
+        c.finalize()
+        r = c.bfs(hi, lo, -1, 3, 20000, -1)
+        rounds[name], res[name] = r["rounds"], r
+        c.close()
+    assert_bfs_equal(res["with"], res["without"])
+    assert rounds["with"] * 4 < rounds["without"]
+    ex.close()
