@@ -152,17 +152,36 @@ def main():
         # algorithmic bytes per k-mer occurrence: packed read bits + key read +
         # count read + count write + key write on first insertion
         A = L / (4.0 * (L - k + 1)) + 12.0 + 8.0 * distinct / float(total_windows)
+        # One "launch" = one pass of the counting pipeline over the whole batch (k_p1_extract_scatter ->
+        # k_p2_scatter -> k_p3_merge); its duration = the summed HIP-event times of
+        # those kernels on the context's stream.  For a direct-kernel run it is k_count_reads alone.
         launches = max(int(st.count_launches), 1)
         avg_ms = st.count_ms / launches if st.count_launches else None
         units_per_launch = st.windows / launches
         roofline = None
         if avg_ms:
             achieved = units_per_launch * A / (avg_ms * 1e-3) / 1e9
+            parts = {"k_p1_extract_scatter" if world == 1 else "k_p1_keys_scatter": st.p1_ms / launches,
+                     "k_p2_scatter": st.p2_ms / launches, "k_p3_merge": st.p3_ms / launches}
+            pipeline = st.p3_ms > 0
+            dominant = max(parts, key=parts.get) if pipeline else "k_count_reads"
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "r01_v3_pmc_hbm_traffic_e1.csv")
+            if pipeline and world == 1 and args.err == 100 and R == 10_000_000 and k == 31 and os.path.exists(pmc):
+                # HBM bytes per pipeline run from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes,
+                # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes), collected by scripts/gpu_pmc.sh
+                import csv
+                gb = 0.0
+                for row in csv.DictReader(open(pmc)):
+                    if row["kernel"].startswith(("mc::k_p1_extract_scatter", "mc::k_p2_scatter", "mc::k_p3_merge")):
+                        gb += float(row["fetch_GB_corrected_x2"]) + float(row["write_GB"])
+                traffic = round(gb * 1e9)
             roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                        "kernel": "k_count_reads" if world == 1 else "k_add_keys",
-                        "bytes_per_kmer": round(A, 3), "avg_launch_ms": round(avg_ms, 4),
-                        "launches_per_step": launches / args.steps,
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                        "kernel": dominant, "launch": "counting pipeline p1+p2+p3" if pipeline else "k_count_reads",
+                        "kernel_ms": {kk: round(v, 3) for kk, v in parts.items()} if pipeline else None,
+                        "bytes_per_kmer": round(A, 3), "algorithmic_bytes_per_launch": round(units_per_launch * A),
+                        "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches / args.steps,
                         "count_ms_per_step": round(st.count_total_ms / args.steps, 3)}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
