@@ -22,6 +22,6 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
 with open("gpurun_out/pmc_summary.csv", "w") as f:
     f.write("kernel,dispatches,FETCH_SIZE_KB_sum,WRITE_SIZE_KB_sum,fetch_GB_corrected_x2,write_GB\n")
     for k, d in out.items():
-        f.write("%s,%d,%.0f,%.0f,%.3f,%.3f\n" % (k, d["n"], d["FETCH_SIZE"], d["WRITE_SIZE"], 2 * d["FETCH_SIZE"] * 1024 / 1e9, d["WRITE_SIZE"] * 1024 / 1e9))
+        f.write("\"%s\",%d,%.0f,%.0f,%.3f,%.3f\n" % (k, d["n"], d["FETCH_SIZE"], d["WRITE_SIZE"], 2 * d["FETCH_SIZE"] * 1024 / 1e9, d["WRITE_SIZE"] * 1024 / 1e9))
 print(open("gpurun_out/pmc_summary.csv").read())
 PY
