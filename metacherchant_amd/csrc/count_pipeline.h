@@ -7,14 +7,18 @@
 //
 //   P1  extract + scatter   reads -> keys (+ the read-context hint of the occurrence), grouped by the
 //                           top b1 bits of fmix64(key); tiles of 8192 windows staged in LDS and
-//                           written out as one contiguous run per bucket;
-//   P2  scatter             every level-1 bucket again by the next b2 bits: b1 + b2 = log2(#regions)
-//                           of the table, so a leaf bucket holds exactly the keys of one table region;
+//                           written out as one contiguous run per bucket.  Each of the 256 workgroups
+//                           owns one segment of every bucket: fill levels live in LDS, no atomics,
+//                           and a run's cache lines are completed by the workgroup that started them;
+//   P2  scatter             one workgroup per level-1 bucket scatters it again by the next b2 bits:
+//                           b1 + b2 = log2(#regions) of the table, so a leaf bucket holds exactly the
+//                           keys of one table region;
 //   P3  merge               one workgroup per region: the region (4096 slots, 64 KB) lives in LDS, the
 //                           leaf's keys are streamed in and counted with LDS atomics, the region goes
 //                           back to HBM with plain coalesced stores.
 //
-// Every byte moved is a coalesced stream; the only global atomics left are one per (tile, bucket).
+// Every byte moved is a coalesced stream and the counting pipeline issues no global atomics at all
+// (only the multi-GPU owner split reserves its packed output ranges with one atomic per tile and owner).
 // Results are identical to the direct kernel: same slot placement rule (home slot from the hash,
 // linear probing inside the region), saturation as in kmer_device.h.
 #pragma once
@@ -28,16 +32,20 @@ constexpr int PT_TILE = PT_THREADS * PT_ITEMS;      // 8192 windows / keys per t
 constexpr int PT_MAX_BUCKETS = 512;                 // fan-out of one scatter level
 constexpr int P3_THREADS = 512;
 constexpr uint32_t REGION_SLOTS = 4096;             // == 1 << mc_ctx::sb
-constexpr uint32_t CURSOR1_STRIDE = 32;             // level-1 bucket cursors sit on separate 128-byte lines
+constexpr uint32_t CURSOR1_STRIDE = 32;             // owner cursors of the multi-GPU split sit on separate 128-byte lines
+constexpr int PT_SEGMENTS = 256;                    // workgroups of P1 (one per CU) = segments of every level-1 bucket
 
 struct ScatterLds {
     uint64_t key[PT_TILE];
     uint32_t hint[PT_TILE];
-    uint16_t dig[PT_TILE];
+    uint32_t rel[PT_TILE];                       // where the staged record goes, relative to out_base (~0 = spill)
     uint32_t cnt[PT_MAX_BUCKETS], off[PT_MAX_BUCKETS], gbase[PT_MAX_BUCKETS];
+    uint32_t wcur[PT_MAX_BUCKETS];               // this workgroup's own fill level of every bucket
+    uint32_t seg_prefix[PT_SEGMENTS + 1];        // P2: where each input segment starts in the bucket's stream
     uint32_t starts[(PT_TILE + 256) / 32 + 2];  // P1: bit per base position = "a read starts here"
     uint32_t wave_tot[PT_THREADS / 64];
-    uint32_t n_valid;
+    uint32_t n_valid, tile_seg;
+    unsigned long long dbg[4];
 };
 
 struct SpillView {
@@ -60,23 +68,33 @@ __device__ __forceinline__ void spill_push(const SpillView &sp, uint64_t key, ui
 }
 
 // Shared tail of P1/P2: the tile's items are in registers; group them by digit in LDS and write one
-// contiguous run per bucket.  cursors[d] counts what bucket d holds so far; bucket d's storage is
-// out_*[d * cap .. (d+1) * cap); what does not fit goes to the spill list (drained by the direct kernel).
-// With `bases` (exact bucket start offsets from a counting pass, cursors then count from 0 inside each
-// bucket) the output is tightly packed and cannot overflow; out_hints may be null.
-// COUNT_ONLY: only add the tile's bucket sizes to the cursors (the counting pass).
+// contiguous run per bucket.
+//   counting pipeline (cursors == nullptr): every workgroup owns one SEGMENT of every bucket and
+//     appends to it alone -- fill levels live in LDS (L.wcur), no global atomics, and the cache lines
+//     of a run are completed by the same workgroup, so L2 writes whole lines.  Bucket d's piece for
+//     this workgroup is out_*[out_base + d * bucket_stride ..] with room for `cap` records; what
+//     does not fit goes to the spill list (drained by the direct kernel).
+//   multi-GPU split (cursors + bases): exact bucket offsets from a COUNT_ONLY run of the same tiles,
+//     global cursors count from 0 inside each bucket, output tightly packed; out_hints may be null.
 template <bool COUNT_ONLY = false>
 __device__ __forceinline__ void scatter_tile(ScatterLds &L, const uint64_t (&key)[PT_ITEMS], const uint32_t (&hint)[PT_ITEMS],
                                              const uint32_t (&dig)[PT_ITEMS], const bool (&valid)[PT_ITEMS],
-                                             uint32_t n_buckets, uint32_t *cursors, uint32_t cstride, uint64_t cap, uint64_t *out_keys,
-                                             uint32_t *out_hints, uint64_t out_base, const SpillView &sp,
+                                             uint32_t n_buckets, uint32_t *cursors, uint64_t cap, uint64_t bucket_stride,
+                                             uint64_t *out_keys, uint32_t *out_hints, uint64_t out_base, const SpillView &sp,
                                              const uint64_t *bases = nullptr)
 {
     const uint32_t tid = threadIdx.x;
+#ifdef MC_P1_TIMING
+    unsigned long long ts_[5];
+    ts_[0] = __builtin_amdgcn_s_memrealtime();
+#endif
     uint32_t rank[PT_ITEMS];
 #pragma unroll
     for (int j = 0; j < PT_ITEMS; j++) rank[j] = valid[j] ? atomicAdd(&L.cnt[dig[j]], 1u) : 0u;
     __syncthreads();
+#ifdef MC_P1_TIMING
+    ts_[1] = __builtin_amdgcn_s_memrealtime();
+#endif
     // exclusive scan of cnt[0..n_buckets) (n_buckets <= 512 <= blockDim)
     {
         const uint32_t lane = tid & 63, wv = tid >> 6;
@@ -93,31 +111,46 @@ __device__ __forceinline__ void scatter_tile(ScatterLds &L, const uint64_t (&key
         for (uint32_t i = 0; i < wv; i++) before += L.wave_tot[i];
         if (tid < n_buckets) {
             L.off[tid] = before + x - c;
-            L.gbase[tid] = c ? atomicAdd(&cursors[(uint64_t)tid * cstride], c) : 0u;  // one global atomic per (tile, bucket)
+            if (cursors) {
+                L.gbase[tid] = c ? atomicAdd(&cursors[(uint64_t)tid * CURSOR1_STRIDE], c) : 0u;  // one atomic per (tile, owner)
+            } else {
+                L.gbase[tid] = L.wcur[tid];
+                L.wcur[tid] += c;
+            }
         }
         if (tid == PT_THREADS - 1) L.n_valid = before + x;
     }
     __syncthreads();
     if (COUNT_ONLY) return;
+#ifdef MC_P1_TIMING
+    ts_[2] = __builtin_amdgcn_s_memrealtime();
+#endif
+    // stage by bucket; the destination of every record is computed here (while its bucket number is in a
+    // register) so that the write-out below is three independent LDS reads and two stores per record
 #pragma unroll
     for (int j = 0; j < PT_ITEMS; j++)
         if (valid[j]) {
-            const uint32_t pos = L.off[dig[j]] + rank[j];
+            const uint32_t d = dig[j];
+            const uint32_t pos = L.off[d] + rank[j];
+            const uint64_t dst = (uint64_t)L.gbase[d] + rank[j];
             L.key[pos] = key[j];
             L.hint[pos] = hint[j];
-            L.dig[pos] = (uint16_t)dig[j];
+            if (bases) L.rel[pos] = d;  // (multi-GPU split: 64-bit bases, resolved at write-out; rank recomputed)
+            else L.rel[pos] = dst < cap ? (uint32_t)((uint64_t)d * bucket_stride + dst) : 0xFFFFFFFFu;
         }
     __syncthreads();
+#ifdef MC_P1_TIMING
+    ts_[3] = __builtin_amdgcn_s_memrealtime();
+#endif
     const uint32_t n = L.n_valid;
     for (uint32_t i = tid; i < n; i += PT_THREADS) {
-        const uint32_t d = L.dig[i];
-        const uint64_t dst = (uint64_t)L.gbase[d] + (i - L.off[d]);
+        const uint32_t r = L.rel[i];
         if (bases) {
-            const uint64_t at = bases[d] + dst;
+            const uint64_t at = bases[r] + L.gbase[r] + (i - L.off[r]);
             out_keys[at] = L.key[i];
             if (out_hints) out_hints[at] = L.hint[i];
-        } else if (dst < cap) {
-            const uint64_t at = out_base + (uint64_t)d * cap + dst;
+        } else if (r != 0xFFFFFFFFu) {
+            const uint64_t at = out_base + r;
             out_keys[at] = L.key[i];
             out_hints[at] = L.hint[i];
         } else {
@@ -125,6 +158,10 @@ __device__ __forceinline__ void scatter_tile(ScatterLds &L, const uint64_t (&key
         }
     }
     __syncthreads();
+#ifdef MC_P1_TIMING
+    ts_[4] = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) for (int q = 0; q < 4; q++) L.dbg[q] += ts_[q + 1] - ts_[q];
+#endif
 }
 
 // first read that can matter for the tile starting at base `lo`: largest r with offsets[r] <= lo
@@ -187,12 +224,21 @@ __global__ void __launch_bounds__(PT_THREADS) k_p1_extract_scatter(
     __shared__ ScatterLds L;
     const uint32_t tid = threadIdx.x;
     const uint32_t n_buckets = OWNERS ? b1 : (1u << b1);
+    if (tid < PT_MAX_BUCKETS) L.wcur[tid] = 0;  // (counting pipeline: gridDim.x == PT_SEGMENTS, segment = blockIdx.x)
+#ifdef MC_P1_TIMING
+    if (tid < 4) L.dbg[tid] = 0;
+    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tl = 0;
+#define P1_STAMP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); if (i) tph[(i) > 0 ? (i)-1 : 0] += n_ - tl; tl = n_; } while (0)
+#else
+#define P1_STAMP(i) do {} while (0)
+#endif
     constexpr int64_t MARGIN = 64;  // the bitmap starts this many bases left of the tile (virtually, for tile 0)
     const uint64_t kmask = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1);
     for (uint64_t tile = base_lo / PT_TILE + blockIdx.x; tile < n_tiles; tile += gridDim.x) {  // reads cover [base_lo, n_bases)
         const uint64_t lo = tile * (uint64_t)PT_TILE;
         const int64_t bm_lo = (int64_t)lo - MARGIN;                    // position of bit 0 of the bitmap
         const uint64_t bm_hi = lo + PT_TILE + 128;                      // one past the last position it covers
+        P1_STAMP(0);
         for (uint32_t i = tid; i < sizeof(L.starts) / 4; i += PT_THREADS) L.starts[i] = 0;
         if (tid < n_buckets) L.cnt[tid] = 0;
         __syncthreads();
@@ -203,6 +249,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_p1_extract_scatter(
             if (rel >= 0) atomicOr(&L.starts[(uint32_t)rel >> 5], 1u << ((uint32_t)rel & 31));
         }
         __syncthreads();
+        P1_STAMP(1);
         uint64_t key[PT_ITEMS];
         uint32_t hint[PT_ITEMS], dig[PT_ITEMS];
         bool valid[PT_ITEMS];
@@ -263,8 +310,19 @@ __global__ void __launch_bounds__(PT_THREADS) k_p1_extract_scatter(
                 r7 = (r7 >> 2) | (base_or0(words, p + (uint64_t)k + HINT_LEN, n_bases) << (2 * (HINT_LEN - 1)));
             }
         }
-        scatter_tile<COUNT_ONLY>(L, key, hint, dig, valid, n_buckets, cursors, CURSOR1_STRIDE, cap, out_keys, out_hints, 0, sp, bases);
+        P1_STAMP(2);
+        if (OWNERS)
+            scatter_tile<COUNT_ONLY>(L, key, hint, dig, valid, n_buckets, cursors, 0, 0, out_keys, out_hints, 0, sp, bases);
+        else
+            scatter_tile(L, key, hint, dig, valid, n_buckets, nullptr, cap, (uint64_t)PT_SEGMENTS * cap, out_keys, out_hints,
+                         (uint64_t)blockIdx.x * cap, sp);
+        P1_STAMP(3);
     }
+#ifdef MC_P1_TIMING
+    if (!OWNERS && blockIdx.x == 7 && tid == 0) printf("[p1 block 7] us: bitmap %.1f items %.1f scatter %.1f  (rank %.1f scan %.1f stage %.1f writeout %.1f)\n", tph[0] * 0.01, tph[1] * 0.01, tph[2] * 0.01, L.dbg[0] * 0.01, L.dbg[1] * 0.01, L.dbg[2] * 0.01, L.dbg[3] * 0.01);
+#endif
+    if (!OWNERS && tid < n_buckets)  // how much of its segment of every bucket this workgroup filled
+        cursors[(uint64_t)tid * PT_SEGMENTS + blockIdx.x] = min(L.wcur[tid], (uint32_t)cap);
 }
 
 // P1 for a flat stream of keys (+ optional hints) instead of reads: the receiving side of the
@@ -278,6 +336,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_p1_keys_scatter(const uint64_t *
     const uint32_t tid = threadIdx.x;
     const uint32_t n_buckets = 1u << b1;
     const uint64_t n_tiles = (n + PT_TILE - 1) / PT_TILE;
+    if (tid < PT_MAX_BUCKETS) L.wcur[tid] = 0;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         if (tid < n_buckets) L.cnt[tid] = 0;
         __syncthreads();
@@ -300,44 +359,70 @@ __global__ void __launch_bounds__(PT_THREADS) k_p1_keys_scatter(const uint64_t *
                 }
             }
         }
-        scatter_tile(L, key, hint, dig, valid, n_buckets, cursors, CURSOR1_STRIDE, cap, out_keys, out_hints, 0, sp);
+        scatter_tile(L, key, hint, dig, valid, n_buckets, nullptr, cap, (uint64_t)PT_SEGMENTS * cap, out_keys, out_hints,
+                     (uint64_t)blockIdx.x * cap, sp);
     }
+    if (tid < n_buckets) cursors[(uint64_t)tid * PT_SEGMENTS + blockIdx.x] = min(L.wcur[tid], (uint32_t)cap);
 }
 
-// P2: tiles of PT_TILE consecutive entries of one level-1 bucket; tile_map[t] = (bucket << 32 | first entry)
+// P2: one workgroup per level-1 bucket (it owns all of the bucket's leaves, so again no global
+// atomics and whole-line writes).  The bucket's PT_SEGMENTS input segments are read as one stream,
+// PT_TILE records per tile, and scattered by the next b2 hash bits.
 __global__ void __launch_bounds__(PT_THREADS) k_p2_scatter(const uint64_t *__restrict__ in_keys,
-                                                           const uint32_t *__restrict__ in_hints, uint64_t cap1,
-                                                           const uint32_t *__restrict__ counts1,
-                                                           const uint64_t *__restrict__ tile_map, uint64_t n_tiles, uint32_t b1,
-                                                           uint32_t b2, uint32_t *cursors2, uint64_t cap2, uint64_t *out_keys,
-                                                           uint32_t *out_hints, SpillView sp)
+                                                           const uint32_t *__restrict__ in_hints, uint64_t seg_cap1,
+                                                           const uint32_t *__restrict__ seg_counts1, uint32_t n_buckets1,
+                                                           uint32_t b1, uint32_t b2, uint32_t *leaf_counts, uint64_t cap2,
+                                                           uint64_t *out_keys, uint32_t *out_hints, SpillView sp)
 {
     __shared__ ScatterLds L;
     const uint32_t tid = threadIdx.x;
     const uint32_t n_buckets = 1u << b2;
-    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint64_t tm = tile_map[tile];
-        const uint32_t bucket = (uint32_t)(tm >> 32), first = (uint32_t)tm;
-        const uint32_t have = min(counts1[(uint64_t)bucket * CURSOR1_STRIDE], (uint32_t)cap1);
-        if (tid < n_buckets) L.cnt[tid] = 0;
+    for (uint32_t bucket = blockIdx.x; bucket < n_buckets1; bucket += gridDim.x) {
         __syncthreads();
-        uint64_t key[PT_ITEMS];
-        uint32_t hint[PT_ITEMS], dig[PT_ITEMS];
-        bool valid[PT_ITEMS];
-#pragma unroll
-        for (int j = 0; j < PT_ITEMS; j++) {
-            const uint32_t i = first + tid + (uint32_t)j * PT_THREADS;
-            valid[j] = i < have;
-            key[j] = 0; hint[j] = 0; dig[j] = 0;
-            if (valid[j]) {
-                const uint64_t at = (uint64_t)bucket * cap1 + i;
-                key[j] = in_keys[at];
-                hint[j] = in_hints[at];
-                dig[j] = (uint32_t)(fmix64(key[j]) >> (64 - b1 - b2)) & (n_buckets - 1);
+        if (tid < PT_MAX_BUCKETS) L.wcur[tid] = 0;
+        if (tid == 0) {  // (257 additions: not worth a parallel scan)
+            uint32_t acc = 0;
+            for (int sgm = 0; sgm < PT_SEGMENTS; sgm++) {
+                L.seg_prefix[sgm] = acc;
+                acc += seg_counts1[(uint64_t)bucket * PT_SEGMENTS + sgm];
             }
+            L.seg_prefix[PT_SEGMENTS] = acc;
         }
-        scatter_tile(L, key, hint, dig, valid, n_buckets, cursors2 + (uint64_t)bucket * n_buckets, 1, cap2, out_keys, out_hints,
-                     (uint64_t)bucket * n_buckets * cap2, sp);
+        __syncthreads();
+        const uint32_t total = L.seg_prefix[PT_SEGMENTS];
+        for (uint32_t first = 0; first < total; first += PT_TILE) {
+            if (tid < n_buckets) L.cnt[tid] = 0;
+            if (tid == 0) {  // segment of the tile's first record: largest sg with seg_prefix[sg] <= first
+                uint32_t lo_s = 0, hi_s = PT_SEGMENTS;
+                while (hi_s - lo_s > 1) {
+                    const uint32_t mid = (lo_s + hi_s) >> 1;
+                    if (L.seg_prefix[mid] <= first) lo_s = mid; else hi_s = mid;
+                }
+                L.tile_seg = lo_s;
+            }
+            __syncthreads();
+            uint64_t key[PT_ITEMS];
+            uint32_t hint[PT_ITEMS], dig[PT_ITEMS];
+            bool valid[PT_ITEMS];
+#pragma unroll
+            for (int j = 0; j < PT_ITEMS; j++) {  // record first + j*PT_THREADS + tid: consecutive lanes, consecutive records
+                const uint32_t e = first + (uint32_t)j * PT_THREADS + tid;
+                valid[j] = e < total;
+                key[j] = 0; hint[j] = 0; dig[j] = 0;
+                if (valid[j]) {
+                    uint32_t sg = L.tile_seg;
+                    while (e >= L.seg_prefix[sg + 1]) sg++;  // a tile spans a few segments at most; empty ones are skipped
+                    const uint64_t at = ((uint64_t)bucket * PT_SEGMENTS + sg) * seg_cap1 + (e - L.seg_prefix[sg]);
+                    key[j] = in_keys[at];
+                    hint[j] = in_hints[at];
+                    dig[j] = (uint32_t)(fmix64(key[j]) >> (64 - b1 - b2)) & (n_buckets - 1);
+                }
+            }
+            scatter_tile(L, key, hint, dig, valid, n_buckets, nullptr, cap2, cap2, out_keys, out_hints,
+                         (uint64_t)bucket * n_buckets * cap2, sp);
+        }
+        __syncthreads();
+        if (tid < n_buckets) leaf_counts[(uint64_t)bucket * n_buckets + tid] = min(L.wcur[tid], (uint32_t)cap2);
     }
 }
 
@@ -352,19 +437,19 @@ struct MergeLds {
     uint32_t n_new, overflow;
 };
 
+// A leaf's records sit in `nseg` segments of capacity seg_cap: 1 after P2, PT_SEGMENTS when the table
+// is so small that P1's buckets already are the leaves.
 __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const uint64_t *__restrict__ leaf_keys,
                                                          const uint32_t *__restrict__ leaf_hints,
-                                                         const uint32_t *__restrict__ leaf_counts, uint64_t cap2,
-                                                         uint32_t n_leaves, uint32_t g, TableView t, int virgin,
+                                                         const uint32_t *__restrict__ seg_counts, uint64_t seg_cap,
+                                                         uint32_t nseg, uint32_t n_leaves, uint32_t g, TableView t, int virgin,
                                                          uint32_t *leaf_state, uint32_t *leaf_new, uint32_t *any_failed)
 {
     __shared__ MergeLds L;
     const uint32_t tid = threadIdx.x;
     for (uint32_t leaf = blockIdx.x; leaf < n_leaves; leaf += gridDim.x) {
         if (leaf_state[leaf]) continue;  // uniform
-        const uint32_t n = min(leaf_counts[leaf], (uint32_t)cap2);
-        const uint64_t *keys = leaf_keys + (uint64_t)leaf * cap2;
-        const uint32_t *hints = leaf_hints + (uint64_t)leaf * cap2;
+
         // g == 0: the leaf is one region: merge and commit unless it overflows.  g > 0 (after the host
         // enlarged the table): a first sweep only checks that every sub-region fits, a second one commits,
         // so a leaf is never merged partially.
@@ -389,6 +474,10 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const uint64_t *__restr
                 if (tid == 0) { L.n_new = 0; L.overflow = 0; }
                 __syncthreads();
                 uint32_t my_new = 0;
+                for (uint32_t sgm = 0; sgm < nseg; sgm++) {
+                const uint32_t n = min(seg_counts[(uint64_t)leaf * nseg + sgm], (uint32_t)seg_cap);
+                const uint64_t *keys = leaf_keys + ((uint64_t)leaf * nseg + sgm) * seg_cap;
+                const uint32_t *hints = leaf_hints + ((uint64_t)leaf * nseg + sgm) * seg_cap;
                 for (uint32_t i0 = tid; i0 < n; i0 += 4 * P3_THREADS) {
                     uint64_t kk[4];
                     uint32_t hh[4];
@@ -427,6 +516,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const uint64_t *__restr
                         }
                         if (!done) atomicExch(&L.overflow, 1u);
                     }
+                }
                 }
                 if (my_new) atomicAdd(&L.n_new, my_new);
                 __syncthreads();

@@ -80,16 +80,16 @@ struct mc_ctx {
     int count_path = 0;  // 0 auto, 1 direct (atomics), 2 partitioned; MC_COUNT_PATH=direct|partition overrides
     // scratch of the partitioned counting pipeline, kept between calls
     struct Pipe {
-        uint64_t *a_keys = nullptr, *b_keys = nullptr, *spill_keys = nullptr, *tile_map = nullptr;
+        uint64_t *a_keys = nullptr, *b_keys = nullptr, *spill_keys = nullptr;
         uint32_t *a_hints = nullptr, *b_hints = nullptr, *spill_hints = nullptr, *tile_first = nullptr;
-        uint32_t *cursors1 = nullptr, *cursors2 = nullptr, *leaf_state = nullptr, *leaf_new = nullptr, *flags = nullptr;  // flags: [0] spill lost, [1] any leaf failed
+        uint32_t *cursors1 = nullptr, *seg_counts1 = nullptr, *cursors2 = nullptr, *leaf_state = nullptr, *leaf_new = nullptr, *flags = nullptr;  // cursors1: owner cursors (multi-GPU split); cursors2: leaf fill levels; flags: [0] spill lost, [1] any leaf failed
         unsigned long long *spill_count = nullptr;
-        uint64_t a_cap = 0, b_cap = 0, spill_cap = 0, tiles1_cap = 0, tiles2_cap = 0, leaves_cap = 0;
+        uint64_t a_cap = 0, b_cap = 0, spill_cap = 0, tiles1_cap = 0, leaves_cap = 0, segs1_cap = 0;
         void release()
         {
-            (void)hipFree(a_keys); (void)hipFree(b_keys); (void)hipFree(spill_keys); (void)hipFree(tile_map);
+            (void)hipFree(a_keys); (void)hipFree(b_keys); (void)hipFree(spill_keys);
             (void)hipFree(a_hints); (void)hipFree(b_hints); (void)hipFree(spill_hints); (void)hipFree(tile_first);
-            (void)hipFree(cursors1); (void)hipFree(cursors2); (void)hipFree(leaf_state); (void)hipFree(leaf_new); (void)hipFree(flags);
+            (void)hipFree(cursors1); (void)hipFree(seg_counts1); (void)hipFree(cursors2); (void)hipFree(leaf_state); (void)hipFree(leaf_new); (void)hipFree(flags);
             (void)hipFree(spill_count);
             *this = Pipe{};
         }
@@ -578,7 +578,7 @@ static int ensure_buf(mc_ctx *c, T **p, uint64_t *cap, uint64_t need)
 
 struct PipePlan {
     uint32_t b1 = 0, b2 = 0, g = 0;
-    uint64_t np1 = 0, n_leaves = 0, cap1 = 0, cap2 = 0, spill_cap = 0, tiles2_max = 0, wb = 0;
+    uint64_t np1 = 0, n_leaves = 0, cap1 = 0, cap2 = 0, spill_cap = 0, wb = 0;
     SpillView sp{};
 };
 
@@ -608,31 +608,31 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl)
     const uint32_t rb = c->rb;
     if (rb < 2) return fail(c, MC_EINVAL, "internal: partitioned counting needs at least 4 table regions");
     const uint32_t lb = std::min<uint32_t>(rb, 18);  // leaf bits; a leaf covers 2^(rb - lb) regions
-    pl->b1 = (lb + 1) / 2;
-    pl->b2 = lb - pl->b1;
+    pl->b1 = std::min<uint32_t>(lb, 9);              // P1 always fans out as wide as it can
+    pl->b2 = lb - pl->b1;                            // 0: the level-1 buckets already are the leaves, no P2
     pl->g = rb - lb;
     pl->wb = wb;
     pl->np1 = 1ull << pl->b1;
     pl->n_leaves = 1ull << lb;
-    pl->cap1 = (uint64_t)((double)wb / (double)pl->np1 * 1.04) + 16384;
+    pl->cap1 = (uint64_t)((double)wb / (double)pl->np1 / (double)PT_SEGMENTS * 1.25) + 256;  // per segment
     const double mean_leaf = (double)wb / (double)pl->n_leaves;
     pl->cap2 = (uint64_t)(mean_leaf * 1.15 + 8.0 * std::sqrt(mean_leaf) + 64.0);
-    pl->tiles2_max = wb / PT_TILE + pl->np1 + 1;
     pl->spill_cap = std::max<uint64_t>(wb / 64, 1u << 20);
+    if (pl->np1 * PT_SEGMENTS * pl->cap1 >= 0xFFFFFFFFull || (1ull << pl->b2) * pl->cap2 >= 0xFFFFFFFFull)
+        return fail(c, MC_EINVAL, "internal: partitioned batch too large for 32-bit bucket indices");
     const uint64_t np1 = pl->np1, n_leaves = pl->n_leaves;
     int rc;
     uint64_t dummy;
 #define ENSURE(ptr, capvar, need) do { rc = ensure_buf(c, &(ptr), &(capvar), (need)); if (rc) return rc; } while (0)
-    { uint64_t cap = P.a_cap; ENSURE(P.a_keys, cap, np1 * pl->cap1); dummy = P.a_cap; ENSURE(P.a_hints, dummy, np1 * pl->cap1); P.a_cap = cap; }
+    { uint64_t cap = P.a_cap; ENSURE(P.a_keys, cap, np1 * PT_SEGMENTS * pl->cap1); dummy = P.a_cap; ENSURE(P.a_hints, dummy, np1 * PT_SEGMENTS * pl->cap1); P.a_cap = cap; }
     { uint64_t cap = P.b_cap; ENSURE(P.b_keys, cap, n_leaves * pl->cap2); dummy = P.b_cap; ENSURE(P.b_hints, dummy, n_leaves * pl->cap2); P.b_cap = cap; }
     { uint64_t cap = P.spill_cap; ENSURE(P.spill_keys, cap, pl->spill_cap); dummy = P.spill_cap; ENSURE(P.spill_hints, dummy, pl->spill_cap); P.spill_cap = cap; }
-    ENSURE(P.tile_map, P.tiles2_cap, pl->tiles2_max);
+    ENSURE(P.seg_counts1, P.segs1_cap, np1 * PT_SEGMENTS);
     { uint64_t cap = P.leaves_cap; ENSURE(P.cursors2, cap, n_leaves); dummy = P.leaves_cap; ENSURE(P.leaf_state, dummy, n_leaves); dummy = P.leaves_cap; ENSURE(P.leaf_new, dummy, n_leaves); P.leaves_cap = cap; }
 #undef ENSURE
-    if (!P.cursors1) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.cursors1), PT_MAX_BUCKETS * CURSOR1_STRIDE * sizeof(uint32_t)));
     if (!P.flags) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.flags), 2 * sizeof(uint32_t)));
     if (!P.spill_count) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.spill_count), sizeof(unsigned long long)));
-    HIPCHK(c, hipMemsetAsync(P.cursors1, 0, PT_MAX_BUCKETS * CURSOR1_STRIDE * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(P.seg_counts1, 0, np1 * PT_SEGMENTS * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(P.cursors2, 0, n_leaves * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(P.leaf_state, 0, n_leaves * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(P.leaf_new, 0, n_leaves * sizeof(uint32_t), c->stream));
@@ -650,33 +650,25 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1)
     const uint64_t np1 = pl.np1, n_leaves = pl.n_leaves;
     int rc;
     double ms2 = 0, ms3 = 0;
-    // tile map of P2 from the level-1 bucket sizes
-    std::vector<uint32_t> cnt1raw(np1 * CURSOR1_STRIDE), cnt1(np1);
-    HIPCHK(c, hipMemcpy(cnt1raw.data(), P.cursors1, cnt1raw.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    for (uint64_t b = 0; b < np1; b++) cnt1[b] = cnt1raw[b * CURSOR1_STRIDE];
-    std::vector<uint64_t> tmap;
-    tmap.reserve(pl.tiles2_max);
-    for (uint64_t b = 0; b < np1; b++) {
-        const uint64_t have = std::min<uint64_t>(cnt1[b], pl.cap1);
-        for (uint64_t f = 0; f < have; f += PT_TILE) tmap.push_back((b << 32) | f);
-    }
-    if (tmap.size() > P.tiles2_cap) return fail(c, MC_EOVERFLOW, "internal: P2 tile map overflow");
-    if (!tmap.empty()) {
-        HIPCHK(c, hipMemcpyAsync(P.tile_map, tmap.data(), tmap.size() * 8, hipMemcpyHostToDevice, c->stream));
+    if (pl.b2 > 0) {
         rc = timed(c, &ms2, [&] {
-            const int grid = (int)std::min<uint64_t>(tmap.size(), 256 * 1);
-            hipLaunchKernelGGL(k_p2_scatter, dim3(grid), dim3(PT_THREADS), 0, c->stream, P.a_keys, P.a_hints, pl.cap1,
-                               P.cursors1, P.tile_map, (uint64_t)tmap.size(), pl.b1, pl.b2, P.cursors2, pl.cap2, P.b_keys,
-                               P.b_hints, pl.sp);
+            hipLaunchKernelGGL(k_p2_scatter, dim3((unsigned)np1), dim3(PT_THREADS), 0, c->stream, P.a_keys, P.a_hints, pl.cap1,
+                               P.seg_counts1, (uint32_t)np1, pl.b1, pl.b2, P.cursors2, pl.cap2, P.b_keys, P.b_hints, pl.sp);
         });
         if (rc) return rc;
     }
+    // P3 reads the leaves: P2's output (one segment each), or P1's buckets directly when there is no second level
+    const uint64_t *lk = pl.b2 > 0 ? P.b_keys : P.a_keys;
+    const uint32_t *lh = pl.b2 > 0 ? P.b_hints : P.a_hints;
+    const uint32_t *lc = pl.b2 > 0 ? P.cursors2 : P.seg_counts1;
+    const uint64_t lcap = pl.b2 > 0 ? pl.cap2 : pl.cap1;
+    const uint32_t lseg = pl.b2 > 0 ? 1u : (uint32_t)PT_SEGMENTS;
     // P3, retried with a larger table when a region overflows
     for (int attempt = 0;; attempt++) {
         const int virgin = c->virgin ? 1 : 0;
         rc = timed(c, &ms3, [&] {
             const int grid = (int)std::min<uint64_t>(n_leaves, 256 * 2 * 4);
-            hipLaunchKernelGGL(k_p3_merge, dim3(grid), dim3(P3_THREADS), 0, c->stream, P.b_keys, P.b_hints, P.cursors2, pl.cap2,
+            hipLaunchKernelGGL(k_p3_merge, dim3(grid), dim3(P3_THREADS), 0, c->stream, lk, lh, lc, lcap, lseg,
                                (uint32_t)n_leaves, pl.g, c->view(), virgin, P.leaf_state, P.leaf_new, P.flags + 1);
         });
         if (rc) return rc;
@@ -729,7 +721,9 @@ static void launch_p1_reads(mc_ctx *c, const uint64_t *d_words, const uint64_t *
                             uint64_t cap, uint64_t *out_keys, uint32_t *out_hints, const SpillView &sp, int owners_mode,
                             const uint64_t *bases)
 {   // owners_mode: 0 = hash-prefix buckets (counting), 1 = count per owner, 2 = scatter per owner at `bases`
-    const int grid = (int)std::min<uint64_t>(std::max<uint64_t>(n_tiles_abs - base0 / PT_TILE, 1), 256 * 1);
+    // counting mode: exactly PT_SEGMENTS workgroups, each owns one segment of every bucket
+    const int grid = owners_mode == 0 ? PT_SEGMENTS
+                                      : (int)std::min<uint64_t>(std::max<uint64_t>(n_tiles_abs - base0 / PT_TILE, 1), 256);
     const int k = c->cfg.k;
 #define P1_ARGS d_words, offs, nr, base0, end_abs, n_tiles_abs, tile_first, k, b1, cursors, cap, out_keys, out_hints, c->d_ctr + 1, sp, bases
 #define P1_LAUNCH(MODE)                                                                                                  \
@@ -769,7 +763,7 @@ static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint6
     rc = timed(c, &ms1, [&] {
         hipLaunchKernelGGL(k_tile_first_read, dim3((unsigned)((n_tiles_abs + 255) / 256)), dim3(256), 0, c->stream, offs, nr,
                            n_tiles_abs, P.tile_first);
-        launch_p1_reads(c, d_words, offs, nr, base0, end_abs, n_tiles_abs, P.tile_first, pl.b1, P.cursors1, pl.cap1, P.a_keys,
+        launch_p1_reads(c, d_words, offs, nr, base0, end_abs, n_tiles_abs, P.tile_first, pl.b1, P.seg_counts1, pl.cap1, P.a_keys,
                         P.a_hints, pl.sp, 0, nullptr);
     });
     if (rc) return rc;
@@ -787,8 +781,9 @@ static int add_keys_partitioned(mc_ctx *c, const uint64_t *d_keys, const uint32_
     double ms1 = 0;
     rc = timed(c, &ms1, [&] {
         const uint64_t n_tiles = (n + PT_TILE - 1) / PT_TILE;
-        hipLaunchKernelGGL(k_p1_keys_scatter, dim3((unsigned)std::min<uint64_t>(n_tiles, 256)), dim3(PT_THREADS), 0, c->stream,
-                           d_keys, d_hints, n, pl.b1, P.cursors1, pl.cap1, P.a_keys, P.a_hints, c->d_ctr + 1, pl.sp);
+        (void)n_tiles;
+        hipLaunchKernelGGL(k_p1_keys_scatter, dim3(PT_SEGMENTS), dim3(PT_THREADS), 0, c->stream,
+                           d_keys, d_hints, n, pl.b1, P.seg_counts1, pl.cap1, P.a_keys, P.a_hints, c->d_ctr + 1, pl.sp);
     });
     if (rc) return rc;
     return pipe_finish(c, pl, ms1);
