@@ -75,6 +75,7 @@ def main():
     hint_local = est_distinct // world + (1 << 20)
 
     ctx = m.Context(k, mode, local_rank, hint_local)
+    ctx.set_coverage_hint(args.coverage)  # --coverage is known before the reads are loaded (the CLI does the same)
     solid = None
     if world > 1 and rank == 0:
         solid = m.Context(k, mode, local_rank, genome_bases + (1 << 20))

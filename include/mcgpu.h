@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MC_ABI_VERSION 2
+#define MC_ABI_VERSION 3
 
 /* error codes */
 #define MC_OK 0
@@ -78,6 +78,12 @@ int mc_abi_version(void);
 
 /* Empties the table (keeps its allocation): a fresh BigLong2ShortHashMap without paying hipMalloc again. */
 int mc_clear(mc_ctx *ctx);
+
+/* Optional: tells the context which --coverage the BFS will use (minOccurences,
+ * src/tools/EnvironmentFinderMain.java:61-65, known before the reads are loaded).  Counting then
+ * keeps the number of k-mers with count >= min_cov up to date as it goes, which saves mc_bfs* one
+ * sweep over the table.  Results never depend on it; 0 turns it off. */
+int mc_set_coverage_hint(mc_ctx *ctx, int min_cov);
 
 /* Use the caller's HIP stream (a hipStream_t passed as void*) for all work of this context
  * instead of the context's own stream.  NULL restores the own stream. */
@@ -189,6 +195,8 @@ typedef struct {
     uint64_t grows;          /* number of table rebuilds */
     double p1_ms, p2_ms, p3_ms; /* partitioned pipeline: extract+scatter / scatter / merge kernels */
     uint64_t spill_keys;     /* keys that did not fit their bucket and took the direct kernel */
+    uint64_t solid_kmers;    /* k-mers with count >= min_cov found by the last BFS set-up */
+    uint64_t solid_sweeps;   /* table sweeps BFS set-ups needed to count them (0 with mc_set_coverage_hint) */
 } mc_stats;
 int mc_get_stats(mc_ctx *ctx, mc_stats *out);
 int mc_reset_stats(mc_ctx *ctx);

@@ -443,10 +443,14 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const uint64_t *__restr
                                                          const uint32_t *__restrict__ leaf_hints,
                                                          const uint32_t *__restrict__ seg_counts, uint64_t seg_cap,
                                                          uint32_t nseg, uint32_t n_leaves, uint32_t g, TableView t, int virgin,
-                                                         uint32_t *leaf_state, uint32_t *leaf_new, uint32_t *any_failed)
+                                                         uint32_t *leaf_state, uint32_t *leaf_new, uint32_t *any_failed,
+                                                         uint32_t solid_thr, unsigned long long *n_solid)
 {
     __shared__ MergeLds L;
     const uint32_t tid = threadIdx.x;
+    // solid_thr != 0: keep *n_solid = number of keys with count >= solid_thr up to date (the coverage
+    // threshold the BFS will ask for, mc_set_coverage_hint), which saves the BFS set-up a table sweep
+    long long solid_delta = 0;
     for (uint32_t leaf = blockIdx.x; leaf < n_leaves; leaf += gridDim.x) {
         if (leaf_state[leaf]) continue;  // uniform
 
@@ -461,6 +465,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const uint64_t *__restr
             for (uint32_t sub = 0; sub < (1u << g); sub++) {
                 const uint64_t region = ((uint64_t)leaf << g) | sub;
                 Slot *gs = t.slots + region * REGION_SLOTS;
+                int solid_before = 0;
                 for (uint32_t i = tid; i < REGION_SLOTS; i += P3_THREADS) {
                     if (virgin) {
                         L.key[i] = EMPTY_KEY; L.cnt[i] = 0; L.aux[i] = 0;
@@ -469,6 +474,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const uint64_t *__restr
                         L.key[i] = ((uint64_t)raw.y << 32) | raw.x;
                         L.cnt[i] = raw.z;
                         L.aux[i] = raw.w;
+                        solid_before += solid_thr && raw.z >= solid_thr;  // (empty slots hold count 0)
                     }
                 }
                 if (tid == 0) { L.n_new = 0; L.overflow = 0; }
@@ -530,7 +536,9 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const uint64_t *__restr
                         v.z = L.cnt[i] > 0x80000000u ? 0x80000000u : L.cnt[i];  // counters stop at 2^31 (kmer_device.h)
                         v.w = L.aux[i];
                         *reinterpret_cast<uint4 *>(gs + i) = v;
+                        solid_delta += solid_thr && v.z >= solid_thr;
                     }
+                    solid_delta -= solid_before;
                     if (tid == 0) new_total += L.n_new;
                 } else if (commit && ovf && virgin) {  // (g == 0) nothing was there: leave a valid empty region behind
                     for (uint32_t i = tid; i < REGION_SLOTS; i += P3_THREADS) {
@@ -546,6 +554,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const uint64_t *__restr
             if (leaf_ok) { leaf_state[leaf] = 1; leaf_new[leaf] = new_total; } else atomicExch(any_failed, 1u);
         }
     }
+    if (solid_thr) wave_add_ull(n_solid, (unsigned long long)solid_delta);  // (two's complement: deltas may be negative)
 }
 
 // n_used += sum(leaf_new): one atomic per workgroup instead of one per region on a single hot address

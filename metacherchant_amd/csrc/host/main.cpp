@@ -250,6 +250,7 @@ int run(const Options &o)
     CtxGuard G;
     if (mc_create(&cfg, &G.c) != MC_OK) throw Error(std::string(mc_last_error(nullptr)));
     mc_ctx *ctx = G.c;
+    MC_CHECK(ctx, mc_set_coverage_hint(ctx, o.coverage));
 
     const auto t0 = std::chrono::steady_clock::now();
     for (const std::string &path : o.reads) {

@@ -61,7 +61,7 @@ struct mc_ctx {
     // table
     Slot *slots = nullptr;
     uint32_t rb = 0, sb = 12;  // 2^rb regions of 2^sb slots
-    unsigned long long *d_ctr = nullptr;  // [0] n_used, [1] empty_cnt, [2] scratch counter, [3] solid n_used, [4..5] read summary
+    unsigned long long *d_ctr = nullptr;  // [0] n_used, [1] empty_cnt, [2] scratch counter, [3] solid n_used, [4..5] read summary, [6] keys with count >= cov_hint
     uint32_t *d_fatal = nullptr;
     uint64_t n_used_host = 0;
     bool finalized = false;
@@ -72,6 +72,11 @@ struct mc_ctx {
     uint32_t solid_lg = 0;
     int solid_cov = -1;  // -1: not built / stale
     uint64_t n_solid = 0;
+    // mc_set_coverage_hint: the merge kernel of the counting pipeline keeps d_ctr[6] = #keys with
+    // count >= cov_hint, so ensure_solid needs no counting sweep.  Only additions that go through that
+    // kernel maintain it; any other kind of addition clears solid_tracked until mc_clear.
+    int cov_hint = 0;
+    bool solid_tracked = true;
 
     mc_stats st{};
     std::vector<std::unique_ptr<BfsJobBuffers>> bfs_pool;
@@ -549,6 +554,7 @@ static void launch_count(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_o
     const int block = 256;
     const int grid = grid_for((r1 - r0) * 64, block, 256 * 8);
     const TableView t = c->view();
+    c->solid_tracked = false;
     switch (c->cfg.key_mode) {
     case MC_KEY_PACKED:
         hipLaunchKernelGGL(k_count_reads<KEY_PACKED>, dim3(grid), dim3(block), 0, c->stream, d_words, d_off, r0, r1,
@@ -669,7 +675,8 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1)
         rc = timed(c, &ms3, [&] {
             const int grid = (int)std::min<uint64_t>(n_leaves, 256 * 2 * 4);
             hipLaunchKernelGGL(k_p3_merge, dim3(grid), dim3(P3_THREADS), 0, c->stream, lk, lh, lc, lcap, lseg,
-                               (uint32_t)n_leaves, pl.g, c->view(), virgin, P.leaf_state, P.leaf_new, P.flags + 1);
+                               (uint32_t)n_leaves, pl.g, c->view(), virgin, P.leaf_state, P.leaf_new, P.flags + 1,
+                               (uint32_t)(c->solid_tracked ? c->cov_hint : 0), c->d_ctr + 6);
         });
         if (rc) return rc;
         c->virgin = false;
@@ -691,6 +698,7 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1)
     HIPCHK(c, hipMemcpy(&n_spill, P.spill_count, sizeof n_spill, hipMemcpyDeviceToHost));
     double ms4 = 0;
     if (n_spill) {
+        c->solid_tracked = false;
         uint64_t i = 0;
         while (i < n_spill) {
             uint64_t allowed;
@@ -892,9 +900,9 @@ int mc_create(const mc_config *cfg, mc_ctx **out)
     c->stream = c->own_stream;
     CREATE_CHK(hipEventCreate(&c->ev0));
     CREATE_CHK(hipEventCreate(&c->ev1));
-    CREATE_CHK(hipMalloc(reinterpret_cast<void **>(&c->d_ctr), 6 * sizeof(unsigned long long)));
+    CREATE_CHK(hipMalloc(reinterpret_cast<void **>(&c->d_ctr), 8 * sizeof(unsigned long long)));
     CREATE_CHK(hipMalloc(reinterpret_cast<void **>(&c->d_fatal), sizeof(uint32_t)));
-    CREATE_CHK(hipMemsetAsync(c->d_ctr, 0, 6 * sizeof(unsigned long long), c->stream));
+    CREATE_CHK(hipMemsetAsync(c->d_ctr, 0, 8 * sizeof(unsigned long long), c->stream));
     CREATE_CHK(hipMemsetAsync(c->d_fatal, 0, sizeof(uint32_t), c->stream));
 #undef CREATE_CHK
     if (const char *e = getenv("MC_COUNT_PATH")) c->count_path = !strcmp(e, "direct") ? 1 : !strcmp(e, "partition") ? 2 : 0;
@@ -937,10 +945,22 @@ int mc_clear(mc_ctx *c)
     HIPCHK(c, hipSetDevice(c->cfg.device));
     c->virgin = true;
     HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, 4 * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_ctr + 6, 0, sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_fatal, 0, sizeof(uint32_t), c->stream));
     c->n_used_host = 0;
     c->finalized = false;
     c->solid_cov = -1;
+    c->solid_tracked = true;
+    return MC_OK;
+}
+
+int mc_set_coverage_hint(mc_ctx *c, int min_cov)
+{
+    if (!c) return MC_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (min_cov < 0 || min_cov > 32767) return fail(c, MC_EINVAL, "mc_set_coverage_hint: min_cov must be in 0..32767");
+    if (min_cov != c->cov_hint && !c->virgin) c->solid_tracked = false;  // keys already counted were not tracked at this threshold
+    c->cov_hint = min_cov;
     return MC_OK;
 }
 
@@ -1035,6 +1055,7 @@ int mc_add_keys_dev(mc_ctx *c, const int64_t *d_keys, const uint32_t *d_hints, u
             if (rc) return rc;
         }
     } else {
+        c->solid_tracked = false;
         uint64_t i = 0;
         while (i < n) {
             uint64_t allowed;
@@ -1068,6 +1089,7 @@ int mc_add_pairs_dev(mc_ctx *c, const int64_t *d_keys, const int16_t *d_counts, 
     std::lock_guard<std::mutex> g(c->mu);
     if ((!d_keys || !d_counts) && n) return fail(c, MC_EINVAL, "mc_add_pairs_dev: null pointer");
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    c->solid_tracked = false;
     uint64_t i = 0;
     while (i < n) {
         uint64_t allowed;
@@ -1343,15 +1365,22 @@ int ensure_solid(mc_ctx *c, int min_cov, double *ms)
     if (c->solid_cov == min_cov && c->solid) return MC_OK;
     c->solid_cov = -1;
     unsigned long long *cursor = c->d_ctr + 2;
-    HIPCHK(c, hipMemsetAsync(cursor, 0, sizeof(unsigned long long), c->stream));
-    int rc = timed(c, ms, [&] {
-        hipLaunchKernelGGL(k_export, dim3(grid_for(c->n_slots(), 256)), dim3(256), 0, c->stream, c->slots,
-                           c->n_slots(), min_cov, (int64_t *)nullptr, (int16_t *)nullptr, (uint32_t *)nullptr, (uint64_t)0, cursor);
-    });
-    if (rc) return rc;
+    int rc;
+    if (c->solid_tracked && c->cov_hint == min_cov && min_cov > 0 && !c->virgin) {
+        cursor = c->d_ctr + 6;  // kept up to date by k_p3_merge
+    } else {
+        HIPCHK(c, hipMemsetAsync(cursor, 0, sizeof(unsigned long long), c->stream));
+        rc = timed(c, ms, [&] {
+            hipLaunchKernelGGL(k_export, dim3(grid_for(c->n_slots(), 256)), dim3(256), 0, c->stream, c->slots,
+                               c->n_slots(), min_cov, (int64_t *)nullptr, (int16_t *)nullptr, (uint32_t *)nullptr, (uint64_t)0, cursor);
+        });
+        if (rc) return rc;
+        c->st.solid_sweeps++;
+    }
     unsigned long long n = 0;
     HIPCHK(c, hipMemcpy(&n, cursor, sizeof n, hipMemcpyDeviceToHost));
     c->n_solid = n;
+    c->st.solid_kmers = n;
     uint64_t factor = 4;  // slots per solid key (load factor <= 1/4)
     if (const char *e = getenv("MC_SOLID_FACTOR")) factor = std::max<uint64_t>(2, strtoull(e, nullptr, 10));
     uint32_t lg = c->sb;

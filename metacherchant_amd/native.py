@@ -38,12 +38,12 @@ class Stats(C.Structure):
     _fields_ = [("windows", C.c_uint64), ("count_launches", C.c_uint64), ("count_ms", C.c_double),
                 ("count_total_ms", C.c_double), ("table_slots", C.c_uint64), ("table_bytes", C.c_uint64),
                 ("grows", C.c_uint64), ("p1_ms", C.c_double), ("p2_ms", C.c_double), ("p3_ms", C.c_double),
-                ("spill_keys", C.c_uint64)]
+                ("spill_keys", C.c_uint64), ("solid_kmers", C.c_uint64), ("solid_sweeps", C.c_uint64)]
 
 
 # every symbol include/mcgpu.h declares; tests check that the library exports all of them
 EXPORTS = [
-    "mc_abi_version", "mc_create", "mc_destroy", "mc_clear", "mc_last_error", "mc_set_stream", "mc_add_reads_packed",
+    "mc_abi_version", "mc_create", "mc_destroy", "mc_clear", "mc_set_coverage_hint", "mc_last_error", "mc_set_stream", "mc_add_reads_packed",
     "mc_add_reads_packed_dev", "mc_finalize_counts", "mc_get", "mc_get_dev", "mc_kmer_keys", "mc_bfs", "mc_bfs_batch",
     "mc_bfs_result_free", "mc_export", "mc_export_dev", "mc_add_pairs_dev", "mc_key_owner", "mc_extract_keys_dev",
     "mc_add_keys_dev", "mc_get_stats", "mc_reset_stats", "mc_synth_reads_dev", "mc_synth_genome",
@@ -81,6 +81,7 @@ def load():
     L.mc_last_error.restype = C.c_char_p
     L.mc_set_stream.argtypes = [vp, vp]
     L.mc_clear.argtypes = [vp]
+    L.mc_set_coverage_hint.argtypes = [vp, i32]
     L.mc_add_reads_packed.argtypes = [vp, u64p, u64p, u64]
     L.mc_add_reads_packed_dev.argtypes = [vp, vp, vp, u64, u64]
     L.mc_finalize_counts.argtypes = [vp, u64p]
@@ -152,6 +153,10 @@ class Context:
 
     def clear(self):
         self._chk(self._L.mc_clear(self._h))
+
+    def set_coverage_hint(self, min_cov):
+        """mc_set_coverage_hint: counting keeps #(count >= min_cov) current, BFS set-up skips a table sweep."""
+        self._chk(self._L.mc_set_coverage_hint(self._h, int(min_cov)))
 
     def set_stream(self, stream_ptr):
         self._chk(self._L.mc_set_stream(self._h, C.c_void_p(stream_ptr) if stream_ptr else None))

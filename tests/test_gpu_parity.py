@@ -199,6 +199,36 @@ def test_bfs_batch_equals_single_passes(mc, bfs_case):
         assert_bfs_equal(g, w)
 
 
+def test_coverage_hint_tracks_solid_count_over_batches(mc, monkeypatch):
+    """mc_set_coverage_hint: the merge kernel keeps #(count >= min_cov) current over several batches (the
+    second batch lifts keys over the threshold that the first one left below it); the BFS set-up then
+    needs no counting sweep, and the walk is the same as without the hint.  A different threshold, or an
+    addition through another kernel, falls back to the sweep."""
+    monkeypatch.setenv("MC_COUNT_PATH", "partition")
+    genome, reads, off = synth_case(2, 30000, 12000, 150, 50)
+    t, _ = oracle_table(reads, off, 31, po.KEY_PACKED)
+    half = 6000
+    seed = genome[10000:10500]
+    hi, lo = seed_windows(seed, 31)
+    want = po.bfs(t, 31, po.KEY_PACKED, [seed], 1, 5, 3000, -1)
+    ctx = mc.Context(31, mc.KEY_PACKED, 0, 0)
+    ctx.set_coverage_hint(5)
+    for rep in range(2):  # the second round checks mc_clear keeps the hint working
+        ctx.add_reads_packed(po.pack(reads[:off[half]]), off[:half + 1])
+        ctx.add_reads_packed(po.pack(reads[off[half]:]), off[half:] - off[half])
+        assert ctx.finalize() == t.size()
+        ctx.reset_stats()
+        assert_bfs_equal(ctx.bfs(hi, lo, 1, 5, 3000, -1), want)
+        st = ctx.stats()
+        assert st.solid_sweeps == 0
+        assert st.solid_kmers == ctx.export_count(5) == int((t.dump()[1] >= 5).sum())
+        assert_bfs_equal(ctx.bfs(hi, lo, 1, 3, 3000, -1), po.bfs(t, 31, po.KEY_PACKED, [seed], 1, 3, 3000, -1))
+        st = ctx.stats()
+        assert st.solid_sweeps == 1 and st.solid_kmers == int((t.dump()[1] >= 3).sum())
+        ctx.clear()
+    ctx.close()
+
+
 def test_bfs_no_seed_passes(mc, bfs_case):
     _, t, ctx = bfs_case
     rng = np.random.default_rng(9)
