@@ -593,8 +593,9 @@ struct PipePlan {
 static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl)
 {
     mc_ctx::Pipe &P = c->pipe;
-    // Make sure the table can take the batch: with a capacity hint the table was sized for it; without one
-    // assume every eighth occurrence is a new key at most (grown further if a region still overflows).
+    // Make sure the table can take the batch: with a capacity hint that still holds the table was sized for
+    // it; without one assume every eighth occurrence is a new key at most.  Either way the merge kernel
+    // reports regions that would overflow and the table is grown then.
     {
         unsigned long long used;
         uint32_t fatal;
@@ -602,7 +603,8 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl)
         if (rc) return rc;
         if (fatal) return fail(c, MC_EOVERFLOW, "a k-mer table region filled up (hash skew)");
         c->n_used_host = used;
-        if (c->n_slots() < wb / 4) {
+        const bool hint_holds = c->cfg.capacity_hint && used < c->cfg.capacity_hint;
+        if (!hint_holds && c->n_slots() < wb / 4) {
             uint32_t lg = c->rb + c->sb;
             while (lg < 34 && (double)(1ull << lg) * 0.5 < (double)used + (double)wb / 8.0) lg++;
             if (lg > c->rb + c->sb) {
@@ -908,7 +910,7 @@ int mc_create(const mc_config *cfg, mc_ctx **out)
     if (const char *e = getenv("MC_COUNT_PATH")) c->count_path = !strcmp(e, "direct") ? 1 : !strcmp(e, "partition") ? 2 : 0;
     uint32_t lg = 22;  // 4 M slots = 64 MB to start with
     if (cfg->capacity_hint) {
-        const double want = (double)cfg->capacity_hint / 0.5;
+        const double want = (double)cfg->capacity_hint / 0.7;  // regions are probed in LDS: a fuller table costs little
         while (lg < 36 && (double)(1ull << lg) < want) lg++;
     }
     int rc = table_alloc(c, lg);
