@@ -219,7 +219,8 @@ template <int MODE, bool OWNERS = false, bool COUNT_ONLY = false>
 __global__ void __launch_bounds__(PT_THREADS) k_p1_extract_scatter(
     const uint64_t *__restrict__ words, const uint64_t *__restrict__ offsets, uint64_t n_reads, uint64_t base_lo,
     uint64_t n_bases, uint64_t n_tiles, const uint32_t *__restrict__ first_read, int k, uint32_t b1, uint32_t *cursors, uint64_t cap,
-    uint64_t *out_keys, uint32_t *out_hints, unsigned long long *empty_cnt, SpillView sp, const uint64_t *bases = nullptr)
+    uint64_t *out_keys, uint32_t *out_hints, unsigned long long *empty_cnt, SpillView sp, const uint64_t *bases = nullptr,
+    int mm_k = 0)
 {
     __shared__ ScatterLds L;
     const uint32_t tid = threadIdx.x;
@@ -295,7 +296,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_p1_extract_scatter(
                         atomicAdd(empty_cnt, 1ull);
                     } else {
                         valid[j] = true;
-                        dig[j] = (uint32_t)(fmix64(key[j]) >> (64 - b1));
+                        dig[j] = bin32_of(key[j], mm_k) >> (32 - b1);
                     }
                 }
                 // roll to p + 1: the window takes the first base after it, loses its first base
@@ -330,7 +331,8 @@ __global__ void __launch_bounds__(PT_THREADS) k_p1_extract_scatter(
 __global__ void __launch_bounds__(PT_THREADS) k_p1_keys_scatter(const uint64_t *__restrict__ in_keys,
                                                                 const uint32_t *__restrict__ in_hints, uint64_t n, uint32_t b1,
                                                                 uint32_t *cursors, uint64_t cap, uint64_t *out_keys,
-                                                                uint32_t *out_hints, unsigned long long *empty_cnt, SpillView sp)
+                                                                uint32_t *out_hints, unsigned long long *empty_cnt, SpillView sp,
+                                                                int mm_k)
 {
     __shared__ ScatterLds L;
     const uint32_t tid = threadIdx.x;
@@ -355,7 +357,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_p1_keys_scatter(const uint64_t *
                     atomicAdd(empty_cnt, 1ull);
                 } else {
                     valid[j] = true;
-                    dig[j] = (uint32_t)(fmix64(key[j]) >> (64 - b1));
+                    dig[j] = bin32_of(key[j], mm_k) >> (32 - b1);
                 }
             }
         }
@@ -372,7 +374,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_p2_scatter(const uint64_t *__res
                                                            const uint32_t *__restrict__ in_hints, uint64_t seg_cap1,
                                                            const uint32_t *__restrict__ seg_counts1, uint32_t n_buckets1,
                                                            uint32_t b1, uint32_t b2, uint32_t *leaf_counts, uint64_t cap2,
-                                                           uint64_t *out_keys, uint32_t *out_hints, SpillView sp)
+                                                           uint64_t *out_keys, uint32_t *out_hints, SpillView sp, int mm_k)
 {
     __shared__ ScatterLds L;
     const uint32_t tid = threadIdx.x;
@@ -415,7 +417,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_p2_scatter(const uint64_t *__res
                     const uint64_t at = ((uint64_t)bucket * PT_SEGMENTS + sg) * seg_cap1 + (e - L.seg_prefix[sg]);
                     key[j] = in_keys[at];
                     hint[j] = in_hints[at];
-                    dig[j] = (uint32_t)(fmix64(key[j]) >> (64 - b1 - b2)) & (n_buckets - 1);
+                    dig[j] = (bin32_of(key[j], mm_k) >> (32 - b1 - b2)) & (n_buckets - 1);
                 }
             }
             scatter_tile(L, key, hint, dig, valid, n_buckets, nullptr, cap2, cap2, out_keys, out_hints,
@@ -424,6 +426,401 @@ __global__ void __launch_bounds__(PT_THREADS) k_p2_scatter(const uint64_t *__res
         __syncthreads();
         if (tid < n_buckets) leaf_counts[(uint64_t)bucket * n_buckets + tid] = min(L.wcur[tid], (uint32_t)cap2);
     }
+}
+
+
+// =============================================================================================
+// Super-k-mer form of the pipeline (packed keys, k >= SK_MIN_K: TableView::mm_k != 0).
+//
+// Regions of the table are minimizer bins (kmer_device.h), so all windows of a read that share their
+// minimizer go to the same region, and consecutive windows mostly do.  P1 therefore emits one 16-byte
+// RECORD per run of up to SK_MAX_WINDOWS such windows -- the run's bases plus, where the read has
+// them, the HINT_LEN bases of context on either side -- instead of one 12-byte (key, hint) record per
+// window: about 9 windows per record at k = 31, so the streams through P1/P2/P3 shrink ~7-fold.  P3
+// expands the records back into keys and hints right before it counts them in LDS.
+//
+// Record, as the 128-bit number hi:lo --
+//   bits 127..122  unused        bits 125..122  windows - 1
+//   bit  121       the HINT_LEN bases before the first window are included (hasL)
+//   bit  120       the HINT_LEN bases after the last window are included (hasR)
+//   bits 119..106  the HINT_LEN bases before the first window (zero without hasL)
+//   bits 105..0    the windows' bases, then (hasR) the HINT_LEN bases after the last window; unused tail zero
+// A second stream carries the record's bin word (sk_bin of its minimizer): P2 and, after the table
+// grew, P3 take their bucket digits from it.
+constexpr uint32_t SK_MAX_WINDOWS = 16;  // 16 + (31 - 1) + 2*7 = 60 bases
+
+__device__ __forceinline__ uint32_t sk_windows(uint64_t hi) { return (uint32_t)((hi >> 58) & 15u) + 1u; }
+
+// bases [first, first + nb) of a record, right-aligned (nb <= 31)
+__device__ __forceinline__ uint64_t sk_bases(uint64_t lo, uint64_t hi, uint32_t first, uint32_t nb)
+{
+    return bits128(lo, hi, 120 - 2 * (first + nb), 2 * nb);
+}
+
+// window j of a record -> (key, hint), exactly what the per-window pipeline computes from the read
+__device__ __forceinline__ void sk_expand(uint64_t lo, uint64_t hi, uint32_t j, int k, uint64_t *key, uint32_t *hint)
+{
+    const uint32_t n = sk_windows(hi), has_l = (uint32_t)(hi >> 57) & 1u, has_r = (uint32_t)(hi >> 56) & 1u;
+    const uint32_t at = HINT_LEN + j;  // first base of the window
+    const uint64_t fw = sk_bases(lo, hi, at, (uint32_t)k), rc = rc_packed(fw, k);
+    const bool flipped = rc < fw;
+    *key = flipped ? rc : fw;
+    uint32_t fr = 0, fl = 0;
+    const bool rv = j + HINT_LEN <= n - 1 + HINT_LEN * has_r, lv = has_l || j >= (uint32_t)HINT_LEN;
+    if (rv) {
+        uint32_t x = (uint32_t)sk_bases(lo, hi, at + (uint32_t)k, HINT_LEN);  // first following base on top
+        x = __brev(x) >> (32 - 2 * HINT_LEN);
+        fr = ((x & 0x1555u) << 1) | ((x >> 1) & 0x1555u);                     // nearest base lowest
+    }
+    if (lv) fl = (uint32_t)sk_bases(lo, hi, at - HINT_LEN, HINT_LEN);        // nearest preceding base already lowest
+    const uint32_t R = flipped ? (fl ^ 0x3FFFu) : fr, Lc = flipped ? (fr ^ 0x3FFFu) : fl;
+    const bool RV = flipped ? lv : rv, LV = flipped ? rv : lv;
+    *hint = (RV ? (R | HINT_RV) : 0u) | (LV ? ((Lc << 16) | HINT_LV) : 0u);
+}
+
+struct SkSpill {
+    uint4 *recs;
+    unsigned long long *count;
+    uint64_t cap;
+    uint32_t *lost;
+};
+
+__device__ __forceinline__ void sk_spill_push(const SkSpill &sp, const uint4 &rec)
+{
+    const unsigned long long i = atomicAdd(sp.count, 1ull);
+    if (i < sp.cap) sp.recs[i] = rec; else atomicExch(sp.lost, 1u);
+}
+
+// append one record to this workgroup's piece of bucket d (fill levels in LDS: wcur = before this
+// tile, cnt = within it); runs of a bucket are short here, so the store is not staged through LDS
+struct SkCursors {
+    uint32_t cnt[PT_MAX_BUCKETS], wcur[PT_MAX_BUCKETS];
+};
+__device__ __forceinline__ void sk_emit(SkCursors &C, uint32_t d, const uint4 &rec, uint32_t bin, uint64_t cap, uint64_t base,
+                                        uint64_t bucket_stride, uint4 *out_recs, uint32_t *out_bins, const SkSpill &sp)
+{
+    const uint64_t dst = (uint64_t)C.wcur[d] + atomicAdd(&C.cnt[d], 1u);
+    if (dst < cap) {
+        const uint64_t at = base + (uint64_t)d * bucket_stride + dst;
+        out_recs[at] = rec;
+        out_bins[at] = bin;
+    } else {
+        sk_spill_push(sp, rec);
+    }
+}
+
+struct Sk1Lds {
+    SkCursors C;
+    uint64_t bases[PT_TILE / 32 + 8];           // the tile's packed bases, from word `wfirst`
+    uint32_t starts[(PT_TILE + 256) / 32 + 2];  // bit per base position = "a read starts here"
+    alignas(16) uint32_t hs[PT_TILE + 32];      // sk_order of the canonical SK_M-mer starting at each position of the tile (+ overhang)
+    uint32_t last[PT_THREADS];                  // minimizer hash of each thread's last window (SK_NONE: no window)
+    uint32_t brk[PT_TILE / 32 + 4];             // from word 1 on, bit per window: "not a window, or its minimizer differs from
+                                                // the previous window's"; word 0 = 0, the words after the tile = all ones
+};
+
+// bases q .. q+31 of the tile's LDS copy (q relative to word `wfirst`)
+__device__ __forceinline__ uint64_t sk_lds_bases(const uint64_t *bases, uint32_t q)
+{
+    const uint32_t wi = q >> 5, off = 2 * (q & 31);
+    const uint64_t w0 = bases[wi], w1 = bases[wi + 1];
+    return off ? ((w0 << off) | (w1 >> (64 - off))) : w0;
+}
+
+// sk_order of the 8 SK_M-mers starting at tile-relative base q .. q+7
+__device__ __forceinline__ void sk_hash8(const uint64_t *bases, uint32_t q, uint32_t *out)
+{
+    const uint64_t A = sk_lds_bases(bases, q);
+    uint32_t f = (uint32_t)(A >> (64 - 2 * SK_M)), r = sk_rc_mmer(f);
+    out[0] = sk_order(f < r ? f : r);
+#pragma unroll
+    for (int i = 1; i < 8; i++) {
+        const uint32_t nb = (uint32_t)(A >> (62 - 2 * (i + SK_M - 1))) & 3u;  // the base that enters
+        f = ((f << 2) | nb) & SK_MMASK;
+        r = (r >> 2) | ((3u - nb) << (2 * (SK_M - 1)));
+        out[i] = sk_order(f < r ? f : r);
+    }
+}
+
+// SK-P1: tiles of PT_TILE consecutive base positions, PT_ITEMS (8) consecutive positions per thread.
+__global__ void __launch_bounds__(PT_THREADS) k_sk1_extract(
+    const uint64_t *__restrict__ words, const uint64_t *__restrict__ offsets, uint64_t n_reads, uint64_t base_lo,
+    uint64_t n_bases, uint64_t n_tiles, const uint32_t *__restrict__ first_read, int k, uint32_t b1, uint32_t *seg_counts,
+    uint64_t cap, uint4 *out_recs, uint32_t *out_bins, SkSpill sp)
+{
+    static_assert(PT_ITEMS == 8, "one byte of the break bitmap per thread");
+    __shared__ Sk1Lds L;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n_buckets = 1u << b1;
+    const int w = k - SK_M + 1;  // SK_M-mers per window (9 .. 17)
+    const uint64_t last_word = (n_bases + 31) / 32;  // the pad word
+    if (tid < PT_MAX_BUCKETS) { L.C.wcur[tid] = 0; L.C.cnt[tid] = 0; }
+    if (tid == 0) { L.brk[0] = 0; L.brk[PT_TILE / 32 + 1] = 0xFFFFFFFFu; L.brk[PT_TILE / 32 + 2] = 0xFFFFFFFFu; L.brk[PT_TILE / 32 + 3] = 0xFFFFFFFFu; }
+    constexpr int64_t MARGIN = 64;
+    // the global loads a tile starts with (its bases, the read offsets around it) are issued one tile ahead
+    uint64_t pf_word = 0, pf_off = ~0ull;
+    uint32_t pf_first = 0;
+    auto prefetch = [&](uint64_t tile) {
+        if (tile >= n_tiles) return;
+        const uint64_t lo = tile * (uint64_t)PT_TILE, wfirst = lo >= 32 ? lo / 32 - 1 : 0;
+        if (tid < PT_TILE / 32 + 8) pf_word = words[min(wfirst + tid, last_word)];
+        pf_first = first_read[tile];
+        const uint64_t r = (uint64_t)pf_first + tid;
+        pf_off = r < n_reads ? offsets[r] : ~0ull;
+    };
+    prefetch(base_lo / PT_TILE + blockIdx.x);
+    for (uint64_t tile = base_lo / PT_TILE + blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t lo = tile * (uint64_t)PT_TILE;
+        const int64_t bm_lo = (int64_t)lo - MARGIN;
+        const uint64_t bm_hi = lo + PT_TILE + 128;
+        const uint64_t wfirst = lo >= 32 ? lo / 32 - 1 : 0;
+        const uint32_t rel0 = (uint32_t)(lo - wfirst * 32);  // tile-relative base 0 in the LDS copy
+        __syncthreads();  // (previous tile done with the LDS arrays)
+        for (uint32_t i = tid; i < sizeof(L.starts) / 4; i += PT_THREADS) L.starts[i] = 0;
+        if (tid < PT_TILE / 32 + 8) L.bases[tid] = pf_word;
+        const uint64_t my_off = pf_off;
+        const uint32_t my_first = pf_first;
+        prefetch(tile + gridDim.x);
+        __syncthreads();
+        {
+            uint64_t s = my_off;  // offsets[my_first + tid], or ~0 past the last read
+            for (uint64_t r = (uint64_t)my_first + tid; r < n_reads; r += PT_THREADS) {
+                if (r != (uint64_t)my_first + tid) s = offsets[r];
+                if (s >= bm_hi) break;
+                const int64_t rel = (int64_t)s - bm_lo;
+                if (rel >= 0) atomicOr(&L.starts[(uint32_t)rel >> 5], 1u << ((uint32_t)rel & 31));
+            }
+        }
+        {   // every SK_M-mer of the tile is hashed once
+            uint32_t h8[8];
+            sk_hash8(L.bases, rel0 + tid * 8, h8);
+            *reinterpret_cast<uint4 *>(&L.hs[tid * 8]) = make_uint4(h8[0], h8[1], h8[2], h8[3]);
+            *reinterpret_cast<uint4 *>(&L.hs[tid * 8 + 4]) = make_uint4(h8[4], h8[5], h8[6], h8[7]);
+            if (tid < 3) {  // the overhang the last windows need
+                sk_hash8(L.bases, rel0 + PT_TILE + tid * 8, h8);
+                *reinterpret_cast<uint4 *>(&L.hs[PT_TILE + tid * 8]) = make_uint4(h8[0], h8[1], h8[2], h8[3]);
+                *reinterpret_cast<uint4 *>(&L.hs[PT_TILE + tid * 8 + 4]) = make_uint4(h8[4], h8[5], h8[6], h8[7]);
+            }
+        }
+        __syncthreads();
+
+        // ---- minimizer hash of my 8 windows: min over w consecutive entries of hs
+        const uint64_t p0 = lo + (uint64_t)tid * PT_ITEMS;
+        const uint32_t wrel = (uint32_t)((int64_t)p0 - 8 - bm_lo);
+        const uint64_t w_lo = starts_window(L.starts, wrel), w_hi = starts_window(L.starts, wrel + 64);
+        uint32_t hmin[PT_ITEMS];
+        uint32_t valid_bits = 0;
+        {
+            uint32_t hh[24], o[16];
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(&L.hs[tid * 8 + 4 * i]);
+                hh[4 * i] = v.x; hh[4 * i + 1] = v.y; hh[4 * i + 2] = v.z; hh[4 * i + 3] = v.w;
+            }
+            {   // o[i] = min hh[i .. i+7]
+                uint32_t p2[23], p4[21];
+#pragma unroll
+                for (int i = 0; i < 23; i++) p2[i] = min(hh[i], hh[i + 1]);
+#pragma unroll
+                for (int i = 0; i < 21; i++) p4[i] = min(p2[i], p2[i + 2]);
+#pragma unroll
+                for (int i = 0; i < 16; i++) o[i] = min(p4[i], p4[i + 4]);
+            }
+            // min hh[j .. j+w-1] from two overlapping runs of 8 (w = 9 .. 16), or two runs and one more (w = 17)
+#define SK_CASE(W)                                                                                              \
+    case W:                                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < PT_ITEMS; j++)                                                    \
+            hmin[j] = W == 17 ? min(min(o[j], o[j + 8]), hh[j + 16]) : min(o[j], o[j + (W == 17 ? 8 : W - 8)]); \
+        break;
+            switch (w) {
+                SK_CASE(9) SK_CASE(10) SK_CASE(11) SK_CASE(12) SK_CASE(13) SK_CASE(14) SK_CASE(15) SK_CASE(16)
+            default:
+                SK_CASE(17)
+            }
+#undef SK_CASE
+#pragma unroll
+            for (int j = 0; j < PT_ITEMS; j++) {
+                const uint64_t p = p0 + (uint64_t)j;
+                // the window [p, p+k) lies inside one read iff no read starts at p+1 .. p+k-1
+                if (p >= base_lo && p + (uint64_t)k <= n_bases && bits128(w_lo, w_hi, 8 + (uint32_t)j + 1, (uint32_t)(k - 1)) == 0)
+                    valid_bits |= 1u << j;
+            }
+        }
+        L.last[tid] = (valid_bits >> (PT_ITEMS - 1)) & 1u ? hmin[PT_ITEMS - 1] : SK_NONE;
+        __syncthreads();
+        {
+            uint32_t prev = tid ? L.last[tid - 1] : SK_NONE;  // a tile always starts a run
+            uint32_t bits = 0;
+#pragma unroll
+            for (int j = 0; j < PT_ITEMS; j++) {
+                const bool v = (valid_bits >> j) & 1u;
+                if (!v || prev == SK_NONE || prev != hmin[j]) bits |= 1u << j;
+                prev = v ? hmin[j] : SK_NONE;
+            }
+            reinterpret_cast<uint8_t *>(L.brk + 1)[tid] = (uint8_t)bits;  // window i of the tile <-> bit i of the words from L.brk[1]
+        }
+        __syncthreads();
+
+        // ---- records: a run is cut every SK_MAX_WINDOWS windows, counted from its first window.
+        // 64 break bits around my windows: bit b <-> window tid*8 - 16 + b
+        uint64_t bw;
+        {
+            const uint32_t pos = 32 + tid * 8 - 16, wd = pos >> 5, sh = pos & 31;  // (bit 32 of L.brk = window 0)
+            const uint64_t x0 = ((uint64_t)L.brk[wd + 1] << 32) | L.brk[wd];
+            bw = sh ? ((x0 >> sh) | ((uint64_t)L.brk[wd + 2] << (64 - sh))) : x0;
+        }
+        uint32_t start_bits = 0;
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS; j++) {
+            if (!((valid_bits >> j) & 1u)) continue;
+            if ((bw >> (16 + j)) & 1ull) { start_bits |= 1u << j; continue; }           // first window of its run
+            if ((bw >> (1 + j)) & 0x7FFFull) continue;                                   // the run started < 16 windows ago
+            uint32_t i = tid * PT_ITEMS + j, wd = (i >> 5) + 1, bit = i & 31;            // rare: a run of 16 or more
+            uint32_t x = L.brk[wd] & ((2u << bit) - 1u);
+            while (x == 0) x = L.brk[--wd];  // (window 0 of the tile always breaks)
+            const uint32_t run_start = (wd - 1) * 32 + 31 - (uint32_t)__builtin_clz(x);
+            if ((i - run_start) % SK_MAX_WINDOWS == 0) start_bits |= 1u << j;
+        }
+        for (uint32_t todo = start_bits; todo; todo &= todo - 1) {
+            const uint32_t j = (uint32_t)__builtin_ctz(todo), i = tid * PT_ITEMS + j;
+            const uint32_t ahead = (uint32_t)(bw >> (17 + j)) & 0x7FFFu;  // breaks among the next 15 windows
+            const uint32_t n = ahead ? (uint32_t)__builtin_ctz(ahead) + 1u : SK_MAX_WINDOWS;
+            const uint64_t a = lo + i, e = a + n - 1;
+            // context inside the same read: no start at a-HINT_LEN+1 .. a resp. e+1 .. e+k+HINT_LEN-1
+            const bool has_l = bits128(w_lo, w_hi, 8 + j - (HINT_LEN - 1), HINT_LEN) == 0;
+            const bool has_r = e + (uint64_t)k + HINT_LEN <= n_bases && bits128(w_lo, w_hi, 8 + j + n - 1 + (uint32_t)k, HINT_LEN) == 0;
+            const uint32_t len = n + (uint32_t)k - 1 + (has_r ? HINT_LEN : 0);  // bases from the first window on
+            const uint32_t qa = rel0 + i;
+            const uint64_t A = sk_lds_bases(L.bases, qa), B = sk_lds_bases(L.bases, qa + 32);  // bases a .. a+31, a+32 .. a+63
+            const uint64_t ctx_l = has_l ? sk_lds_bases(L.bases, qa - HINT_LEN) >> (64 - 2 * HINT_LEN) : 0;  // bases a-HINT_LEN .. a-1
+            uint64_t hi = (ctx_l << 42) | (A >> 22), rl = (A << 42) | (B >> 22);
+            const uint32_t keep = 2 * (HINT_LEN + len);  // bits of the 120-bit base field in use
+            if (keep <= 56) { hi &= ~0ull << (56 - keep); rl = 0; }
+            else rl &= ~0ull << (120 - keep);
+            hi |= ((uint64_t)(n - 1) << 58) | ((uint64_t)has_l << 57) | ((uint64_t)has_r << 56);
+            uint32_t hsel = hmin[0];
+#pragma unroll
+            for (int q = 1; q < PT_ITEMS; q++) hsel = j == (uint32_t)q ? hmin[q] : hsel;
+            const uint32_t bin = sk_bin(hsel);
+            uint4 rec;
+            rec.x = (uint32_t)rl; rec.y = (uint32_t)(rl >> 32); rec.z = (uint32_t)hi; rec.w = (uint32_t)(hi >> 32);
+            sk_emit(L.C, bin >> (32 - b1), rec, bin, cap, (uint64_t)blockIdx.x * cap, (uint64_t)PT_SEGMENTS * cap, out_recs, out_bins, sp);
+        }
+        __syncthreads();
+        if (tid < n_buckets) { L.C.wcur[tid] += L.C.cnt[tid]; L.C.cnt[tid] = 0; }
+    }
+    __syncthreads();
+    if (tid < n_buckets) seg_counts[(uint64_t)tid * PT_SEGMENTS + blockIdx.x] = min(L.C.wcur[tid], (uint32_t)cap);
+}
+
+// SK-P1 for a flat stream of records (+ bin words): the receiving side of a multi-GPU exchange.
+__global__ void __launch_bounds__(PT_THREADS) k_sk1_records(const uint4 *__restrict__ in_recs, const uint32_t *__restrict__ in_bins,
+                                                            uint64_t n, uint32_t b1, uint32_t *seg_counts, uint64_t cap,
+                                                            uint4 *out_recs, uint32_t *out_bins, SkSpill sp)
+{
+    __shared__ SkCursors C;
+    const uint32_t tid = threadIdx.x, n_buckets = 1u << b1;
+    if (tid < PT_MAX_BUCKETS) { C.wcur[tid] = 0; C.cnt[tid] = 0; }
+    __syncthreads();
+    const uint64_t n_tiles = (n + PT_TILE - 1) / PT_TILE;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS; j++) {
+            const uint64_t i = tile * PT_TILE + tid + (uint64_t)j * PT_THREADS;
+            if (i < n) {
+                const uint32_t bin = in_bins[i];
+                sk_emit(C, bin >> (32 - b1), in_recs[i], bin, cap, (uint64_t)blockIdx.x * cap, (uint64_t)PT_SEGMENTS * cap, out_recs, out_bins, sp);
+            }
+        }
+        __syncthreads();
+        if (tid < n_buckets) { C.wcur[tid] += C.cnt[tid]; C.cnt[tid] = 0; }
+        __syncthreads();
+    }
+    if (tid < n_buckets) seg_counts[(uint64_t)tid * PT_SEGMENTS + blockIdx.x] = min(C.wcur[tid], (uint32_t)cap);
+}
+
+// SK-P2: one workgroup per level-1 bucket; its PT_SEGMENTS segments are read as one stream and
+// scattered by the next b2 bits of the bin word into the bucket's leaves.
+struct Sk2Lds {
+    SkCursors C;
+    uint32_t seg_prefix[PT_SEGMENTS + 1];
+    uint32_t tile_seg;
+};
+__global__ void __launch_bounds__(PT_THREADS) k_sk2_scatter(const uint4 *__restrict__ in_recs, const uint32_t *__restrict__ in_bins,
+                                                            uint64_t seg_cap1, const uint32_t *__restrict__ seg_counts1,
+                                                            uint32_t n_buckets1, uint32_t b1, uint32_t b2, uint32_t *leaf_counts,
+                                                            uint64_t cap2, uint4 *out_recs, uint32_t *out_bins, SkSpill sp)
+{
+    __shared__ Sk2Lds L;
+    const uint32_t tid = threadIdx.x, n_buckets = 1u << b2;
+    constexpr uint32_t TILE2 = PT_THREADS * 4;
+    for (uint32_t bucket = blockIdx.x; bucket < n_buckets1; bucket += gridDim.x) {
+        __syncthreads();
+        if (tid < PT_MAX_BUCKETS) { L.C.wcur[tid] = 0; L.C.cnt[tid] = 0; }
+        if (tid == 0) {
+            uint32_t acc = 0;
+            for (int sgm = 0; sgm < PT_SEGMENTS; sgm++) {
+                L.seg_prefix[sgm] = acc;
+                acc += seg_counts1[(uint64_t)bucket * PT_SEGMENTS + sgm];
+            }
+            L.seg_prefix[PT_SEGMENTS] = acc;
+        }
+        __syncthreads();
+        const uint32_t total = L.seg_prefix[PT_SEGMENTS];
+        for (uint32_t first = 0; first < total; first += TILE2) {
+            if (tid == 0) {  // segment of the tile's first record: largest sg with seg_prefix[sg] <= first
+                uint32_t lo_s = 0, hi_s = PT_SEGMENTS;
+                while (hi_s - lo_s > 1) {
+                    const uint32_t mid = (lo_s + hi_s) >> 1;
+                    if (L.seg_prefix[mid] <= first) lo_s = mid; else hi_s = mid;
+                }
+                L.tile_seg = lo_s;
+            }
+            __syncthreads();
+            uint4 rec[4];
+            uint32_t bin[4];
+            bool have[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {  // loads first, then the scattered stores
+                const uint32_t e = first + (uint32_t)j * PT_THREADS + tid;
+                have[j] = e < total;
+                if (have[j]) {
+                    uint32_t sg = L.tile_seg;
+                    while (e >= L.seg_prefix[sg + 1]) sg++;
+                    const uint64_t at = ((uint64_t)bucket * PT_SEGMENTS + sg) * seg_cap1 + (e - L.seg_prefix[sg]);
+                    rec[j] = in_recs[at];
+                    bin[j] = in_bins[at];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (have[j])
+                    sk_emit(L.C, (bin[j] >> (32 - b1 - b2)) & (n_buckets - 1), rec[j], bin[j], cap2, (uint64_t)bucket * n_buckets * cap2,
+                            cap2, out_recs, out_bins, sp);
+            __syncthreads();
+            if (tid < n_buckets) { L.C.wcur[tid] += L.C.cnt[tid]; L.C.cnt[tid] = 0; }
+        }
+        __syncthreads();
+        if (tid < n_buckets) leaf_counts[(uint64_t)bucket * n_buckets + tid] = min(L.C.wcur[tid], (uint32_t)cap2);
+    }
+}
+
+// drains the record spill list through the direct path
+__global__ void k_sk_add_records(const uint4 *__restrict__ recs, uint64_t n, int k, TableView t)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long n_new = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint4 rec = recs[i];
+        const uint64_t lo = ((uint64_t)rec.y << 32) | rec.x, hi = ((uint64_t)rec.w << 32) | rec.z;
+        for (uint32_t j = 0; j < sk_windows(hi); j++) {
+            uint64_t key;
+            uint32_t hint;
+            sk_expand(lo, hi, j, k, &key, &hint);
+            n_new += table_add(t, key, 1u, hint);
+        }
+    }
+    wave_add_ull(t.n_used, n_new);
 }
 
 // P3: one workgroup per leaf; a leaf covers 2^g consecutive table regions (g = 0 unless the table
@@ -437,14 +834,41 @@ struct MergeLds {
     uint32_t n_new, overflow;
 };
 
+
+// one occurrence of `key` into the region held in LDS; false when the region is full
+__device__ __forceinline__ bool lds_region_add(MergeLds &L, uint64_t key, uint32_t hint, uint32_t home, uint32_t &my_new)
+{
+    uint32_t s = home;
+    for (uint32_t probe = 0; probe < REGION_SLOTS; probe++) {
+        uint64_t cur = L.key[s];
+        if (cur == EMPTY_KEY) {
+            cur = atomicCAS(reinterpret_cast<unsigned long long *>(&L.key[s]), (unsigned long long)EMPTY_KEY,
+                            (unsigned long long)key);
+            if (cur == EMPTY_KEY) { my_new++; cur = key; }
+        }
+        if (cur == key) {
+            atomicAdd(&L.cnt[s], 1u);
+            if (hint) {
+                const uint32_t have = L.aux[s], m = hint_merge(have, hint);
+                if (m != have) L.aux[s] = m;  // racy on purpose: any occurrence's context will do
+            }
+            return true;
+        }
+        s = (s + 1) & (REGION_SLOTS - 1);
+    }
+    return false;
+}
+
 // A leaf's records sit in `nseg` segments of capacity seg_cap: 1 after P2, PT_SEGMENTS when the table
 // is so small that P1's buckets already are the leaves.
-__global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const uint64_t *__restrict__ leaf_keys,
+// SK: the streams hold super-k-mer records (leaf_keys = uint4 records, leaf_hints = their bin words, see below).
+template <bool SK>
+__global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict__ leaf_keys,
                                                          const uint32_t *__restrict__ leaf_hints,
                                                          const uint32_t *__restrict__ seg_counts, uint64_t seg_cap,
                                                          uint32_t nseg, uint32_t n_leaves, uint32_t g, TableView t, int virgin,
                                                          uint32_t *leaf_state, uint32_t *leaf_new, uint32_t *any_failed,
-                                                         uint32_t solid_thr, unsigned long long *n_solid)
+                                                         uint32_t solid_thr, unsigned long long *n_solid, int k)
 {
     __shared__ MergeLds L;
     const uint32_t tid = threadIdx.x;
@@ -482,7 +906,78 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const uint64_t *__restr
                 uint32_t my_new = 0;
                 for (uint32_t sgm = 0; sgm < nseg; sgm++) {
                 const uint32_t n = min(seg_counts[(uint64_t)leaf * nseg + sgm], (uint32_t)seg_cap);
-                const uint64_t *keys = leaf_keys + ((uint64_t)leaf * nseg + sgm) * seg_cap;
+                if constexpr (SK) {
+                    // one record per thread: the window is rolled along the record (ShortKmer.shiftRight again),
+                    // the next record's load is in flight meanwhile
+                    const uint4 *recs = static_cast<const uint4 *>(leaf_keys) + ((uint64_t)leaf * nseg + sgm) * seg_cap;
+                    const uint32_t *bins = leaf_hints + ((uint64_t)leaf * nseg + sgm) * seg_cap;
+                    const uint64_t kmask = (1ull << (2 * k)) - 1;  // (k <= 31)
+                    uint4 nxt = tid < n ? recs[tid] : make_uint4(0, 0, 0, 0);
+                    uint32_t nxt_bin = (g && tid < n) ? bins[tid] : 0u;
+                    for (uint32_t r = tid; r < n; r += P3_THREADS) {
+                        const uint4 rec = nxt;
+                        const uint32_t bin = nxt_bin;
+                        if (r + P3_THREADS < n) {
+                            nxt = recs[r + P3_THREADS];
+                            if (g) nxt_bin = bins[r + P3_THREADS];
+                        }
+                        if (g && (bin >> (32 - t.rb)) != region) continue;  // (t.rb >= g > 0)
+                        const uint64_t lo = ((uint64_t)rec.y << 32) | rec.x, hi = ((uint64_t)rec.w << 32) | rec.z;
+                        const uint32_t nw = sk_windows(hi);
+                        const bool has_l = (hi >> 57) & 1u, has_r = (hi >> 56) & 1u;
+                        // F = the 120-bit base field, top-aligned; T = what follows the current window
+                        const uint64_t f_hi = (hi << 8) | (lo >> 56), f_lo = lo << 8;
+                        uint32_t l7 = (uint32_t)(f_hi >> (64 - 2 * HINT_LEN));                 // bases before the window, nearest lowest
+                        const uint64_t g_hi = (f_hi << (2 * HINT_LEN)) | (f_lo >> (64 - 2 * HINT_LEN)), g_lo = f_lo << (2 * HINT_LEN);
+                        uint64_t fw = g_hi >> (64 - 2 * k), rc = rc_packed(fw, k);
+                        uint64_t t_hi = (g_hi << (2 * k)) | (g_lo >> (64 - 2 * k)), t_lo = g_lo << (2 * k);
+                        uint32_t r7;  // bases after the window, nearest lowest
+                        {
+                            const uint32_t x = __brev((uint32_t)(t_hi >> (64 - 2 * HINT_LEN))) >> (32 - 2 * HINT_LEN);
+                            r7 = ((x & 0x1555u) << 1) | ((x >> 1) & 0x1555u);
+                        }
+                        for (uint32_t j = 0; j < nw; j++) {
+                            const bool flipped = rc < fw;
+                            const uint64_t key = flipped ? rc : fw;
+                            uint32_t s = sk_home(key);
+                            bool done = false;
+                            for (uint32_t probe = 0; probe < REGION_SLOTS; probe++) {
+                                uint64_t cur = L.key[s];
+                                if (cur == EMPTY_KEY) {
+                                    cur = atomicCAS(reinterpret_cast<unsigned long long *>(&L.key[s]), (unsigned long long)EMPTY_KEY,
+                                                    (unsigned long long)key);
+                                    if (cur == EMPTY_KEY) { my_new++; cur = key; }
+                                }
+                                if (cur == key) { done = true; break; }
+                                s = (s + 1) & (REGION_SLOTS - 1);
+                            }
+                            if (done) {
+                                atomicAdd(&L.cnt[s], 1u);
+                                const uint32_t have = L.aux[s];
+                                if ((have & (HINT_RV | HINT_LV)) != (HINT_RV | HINT_LV)) {  // the slot still lacks context
+                                    const bool lv = has_l || j >= (uint32_t)HINT_LEN, rv = j + HINT_LEN <= nw - 1 + (has_r ? HINT_LEN : 0);
+                                    const uint32_t R = flipped ? (l7 ^ 0x3FFFu) : r7, Lc = flipped ? (r7 ^ 0x3FFFu) : l7;
+                                    const bool RV = flipped ? lv : rv, LV = flipped ? rv : lv;
+                                    const uint32_t hint = (RV ? (R | HINT_RV) : 0u) | (LV ? ((Lc << 16) | HINT_LV) : 0u);
+                                    const uint32_t m = hint_merge(have, hint);
+                                    if (m != have) L.aux[s] = m;  // racy on purpose: any occurrence's context will do
+                                }
+                            } else {
+                                atomicExch(&L.overflow, 1u);
+                            }
+                            // roll to window j + 1
+                            const uint32_t in = (uint32_t)(t_hi >> 62), out = (uint32_t)(fw >> (2 * (k - 1))) & 3u;
+                            const uint32_t far = (uint32_t)(t_hi >> (62 - 2 * HINT_LEN)) & 3u;  // the base HINT_LEN beyond `in`
+                            fw = ((fw << 2) | in) & kmask;
+                            rc = (rc >> 2) | ((uint64_t)(3u - in) << (2 * (k - 1)));
+                            l7 = ((l7 << 2) | out) & 0x3FFFu;
+                            r7 = (r7 >> 2) | (far << (2 * (HINT_LEN - 1)));
+                            t_hi = (t_hi << 2) | (t_lo >> 62);
+                            t_lo <<= 2;
+                        }
+                    }
+                } else {
+                const uint64_t *keys = static_cast<const uint64_t *>(leaf_keys) + ((uint64_t)leaf * nseg + sgm) * seg_cap;
                 const uint32_t *hints = leaf_hints + ((uint64_t)leaf * nseg + sgm) * seg_cap;
                 for (uint32_t i0 = tid; i0 < n; i0 += 4 * P3_THREADS) {
                     uint64_t kk[4];
@@ -497,31 +992,12 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const uint64_t *__restr
                     for (int u = 0; u < 4; u++) {
                         const uint64_t key = kk[u];
                         if (key == EMPTY_KEY) continue;
-                        const uint64_t gslot = fmix64(key) >> t.shift;
+                        const uint64_t gslot = slot_of(t, key);
                         if (g && (gslot >> 12) != region) continue;
-                        const uint32_t hint = hh[u];
-                        uint32_t s = (uint32_t)gslot & (REGION_SLOTS - 1);
-                        bool done = false;
-                        for (uint32_t probe = 0; probe < REGION_SLOTS; probe++) {
-                            uint64_t cur = L.key[s];
-                            if (cur == EMPTY_KEY) {
-                                cur = atomicCAS(reinterpret_cast<unsigned long long *>(&L.key[s]), (unsigned long long)EMPTY_KEY,
-                                                (unsigned long long)key);
-                                if (cur == EMPTY_KEY) { my_new++; cur = key; }
-                            }
-                            if (cur == key) {
-                                atomicAdd(&L.cnt[s], 1u);
-                                if (hint) {
-                                    const uint32_t have = L.aux[s], m = hint_merge(have, hint);
-                                    if (m != have) L.aux[s] = m;  // racy on purpose: any occurrence's context will do
-                                }
-                                done = true;
-                                break;
-                            }
-                            s = (s + 1) & (REGION_SLOTS - 1);
-                        }
+                        const bool done = lds_region_add(L, key, hh[u], (uint32_t)gslot & (REGION_SLOTS - 1), my_new);
                         if (!done) atomicExch(&L.overflow, 1u);
                     }
+                }
                 }
                 }
                 if (my_new) atomicAdd(&L.n_new, my_new);

@@ -223,16 +223,81 @@ struct Slot {
     uint32_t aux;
 };
 
+// ---------------------------------------------------------------------------------------------
+// Minimizer bins.  With packed keys and k >= SK_MIN_K the REGION of a key is not taken from the
+// key's own hash but from its canonical minimizer: the SK_M-mer x inside the k-mer whose
+// sk_order(min(x, rc(x))) is smallest.  Both strands of a k-mer hold the same canonical SK_M-mers,
+// so the bin is a function of the key; and consecutive windows of a read mostly share their
+// minimizer, which is what lets the counting pipeline move "super-k-mers" (a run of windows in one
+// 16-byte record) instead of one record per window (count_pipeline.h).  Nothing of this reaches a
+// result: it only decides where in the table a key lives.
+constexpr int SK_M = 15;
+constexpr int SK_MIN_K = 23;  // shorter k-mers: runs too short to pay; regions from fmix64(key) as for hash keys
+constexpr uint32_t SK_MMASK = (1u << (2 * SK_M)) - 1;
+constexpr uint32_t SK_NONE = 0xFFFFFFFFu;  // "no window here" in arrays of minimizer hashes
+
+__host__ __device__ __forceinline__ uint32_t sk_order(uint32_t canon_mmer)
+{  // a bijection of 32-bit words: random-looking total order of the SK_M-mers (ties impossible below 2^30)
+    uint32_t x = canon_mmer * 0x9E3779B1u;
+    x ^= x >> 15;
+    return x == SK_NONE ? SK_NONE - 1 : x;
+}
+__host__ __device__ __forceinline__ uint32_t sk_bin(uint32_t hmin)
+{  // the minimum of many hashes is small: mix again before taking top bits as a bin number
+    uint32_t x = hmin;
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x ^= x >> 15; x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
+__host__ __device__ __forceinline__ uint32_t sk_rc_mmer(uint32_t x)
+{
+    return (uint32_t)rc_packed((uint64_t)x, SK_M);
+}
+// smallest sk_order over the canonical SK_M-mers of a k-mer (either strand gives the same value)
+__host__ __device__ inline uint32_t sk_hmin_of_kmer(uint64_t fw, int k)
+{
+    uint32_t best = SK_NONE;
+    for (int i = 0; i + SK_M <= k; i++) {
+        const uint32_t f = (uint32_t)(fw >> (2 * (k - SK_M - i))) & SK_MMASK, r = sk_rc_mmer(f);
+        const uint32_t h = sk_order(f < r ? f : r);
+        best = h < best ? h : best;
+    }
+    return best;
+}
+
 struct TableView {
     Slot *slots;
     uint32_t shift;   // 64 - (rb + sb)
     uint32_t rmask;   // RS - 1
+    uint32_t rb;      // log2(#regions)
+    int mm_k;         // 0: region from fmix64(key); else k: region from the key's minimizer bin
     unsigned long long *n_used;     // distinct keys stored in slots
     unsigned long long *empty_cnt;  // occurrences of the key that equals EMPTY_KEY (hash modes only)
     uint32_t *fatal;                // set when a region is full
 };
 
-__device__ __forceinline__ uint64_t slot_of(const TableView &t, uint64_t key) { return fmix64(key) >> t.shift; }
+// home slot inside a minimizer-bin region: 12 well-mixed bits of the key, cheaper than fmix64 (the
+// merge kernel of the counting pipeline computes it once per k-mer occurrence)
+__host__ __device__ __forceinline__ uint32_t sk_home(uint64_t key)
+{
+    uint32_t x = (uint32_t)key * 0x9E3779B1u + (uint32_t)(key >> 32) * 0x85EBCA6Bu;
+    x ^= x >> 15; x *= 0xC2B2AE35u;
+    return x >> 20;
+}
+
+// 32 bits whose TOP bits number the region of a key (and, in the counting pipeline, its buckets)
+__host__ __device__ __forceinline__ uint32_t bin32_of(uint64_t key, int mm_k)
+{
+    return mm_k ? sk_bin(sk_hmin_of_kmer(key, mm_k)) : (uint32_t)(fmix64(key) >> 32);
+}
+
+__host__ __device__ __forceinline__ uint64_t slot_of(const TableView &t, uint64_t key)
+{
+    if (t.mm_k == 0) return fmix64(key) >> t.shift;
+    const uint64_t region = t.rb ? (uint64_t)(sk_bin(sk_hmin_of_kmer(key, t.mm_k)) >> (32 - t.rb)) : 0;
+    return (region << 12) | sk_home(key);  // (regions are 4096 slots: count_pipeline.h REGION_SLOTS)
+}
 
 // addAndBound(key, inc) with the saturation deferred to read time (count is 32-bit here; a
 // counter that already reached 2^31 is left alone, launches add < 2^30 each, so it never wraps
@@ -320,6 +385,8 @@ __device__ __forceinline__ uint64_t lh_block_forward(uint64_t w, uint32_t n)
     return x >> (64 - 2 * n);
 }
 
+// (always the key's own hash, also when the counting table is organised by minimizer bins: the BFS
+// must not pay for a minimizer per lookup)
 __device__ __forceinline__ uint64_t solid_slot_of(const SolidView &t, uint64_t key) { return fmix64(key) >> t.shift; }
 
 // count (saturated) or -1; hr/hl may be null

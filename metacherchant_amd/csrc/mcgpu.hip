@@ -81,18 +81,24 @@ struct mc_ctx {
     mc_stats st{};
     std::vector<std::unique_ptr<BfsJobBuffers>> bfs_pool;
 
+    int mm_k = 0;        // != 0 (= k): regions are minimizer bins and reads are counted as super-k-mers (kmer_device.h)
     bool virgin = true;  // the table holds no key and its memory is not initialised yet
     int count_path = 0;  // 0 auto, 1 direct (atomics), 2 partitioned; MC_COUNT_PATH=direct|partition overrides
     // scratch of the partitioned counting pipeline, kept between calls
     struct Pipe {
         uint64_t *a_keys = nullptr, *b_keys = nullptr, *spill_keys = nullptr;
         uint32_t *a_hints = nullptr, *b_hints = nullptr, *spill_hints = nullptr, *tile_first = nullptr;
+        uint4 *a_recs = nullptr, *b_recs = nullptr, *spill_recs = nullptr;  // super-k-mer form (their bin words use a_hints / b_hints)
+        uint64_t a_recs_cap = 0, b_recs_cap = 0, spill_recs_cap = 0;
+        uint32_t *solid_cursors = nullptr;  // leaf fill levels of the solid-table build (minimizer-bin tables)
+        uint64_t solid_cursors_cap = 0;
         uint32_t *cursors1 = nullptr, *seg_counts1 = nullptr, *cursors2 = nullptr, *leaf_state = nullptr, *leaf_new = nullptr, *flags = nullptr;  // cursors1: owner cursors (multi-GPU split); cursors2: leaf fill levels; flags: [0] spill lost, [1] any leaf failed
         unsigned long long *spill_count = nullptr;
-        uint64_t a_cap = 0, b_cap = 0, spill_cap = 0, tiles1_cap = 0, leaves_cap = 0, segs1_cap = 0;
+        uint64_t a_cap = 0, b_cap = 0, spill_cap = 0, tiles1_cap = 0, leaves_cap = 0, segs1_cap = 0, a_hints_cap = 0, b_hints_cap = 0;
         void release()
         {
             (void)hipFree(a_keys); (void)hipFree(b_keys); (void)hipFree(spill_keys);
+            (void)hipFree(a_recs); (void)hipFree(b_recs); (void)hipFree(spill_recs); (void)hipFree(solid_cursors);
             (void)hipFree(a_hints); (void)hipFree(b_hints); (void)hipFree(spill_hints); (void)hipFree(tile_first);
             (void)hipFree(cursors1); (void)hipFree(seg_counts1); (void)hipFree(cursors2); (void)hipFree(leaf_state); (void)hipFree(leaf_new); (void)hipFree(flags);
             (void)hipFree(spill_count);
@@ -117,6 +123,8 @@ struct mc_ctx {
         t.slots = slots;
         t.shift = 64 - (rb + sb);
         t.rmask = (1u << sb) - 1;
+        t.rb = rb;
+        t.mm_k = mm_k;
         t.n_used = d_ctr;
         t.empty_cnt = d_ctr + 1;
         t.fatal = d_fatal;
@@ -227,6 +235,7 @@ __global__ void k_rehash(const Slot *__restrict__ old_slots, uint64_t n_old, Tab
 // in LDS from the counting-table region(s) that hash to it and writes it out with plain coalesced
 // stores: no fill pass, no atomics.  Both tables index by the top bits of the same hash, so the
 // counting regions of a solid region are consecutive (or it is a slice of one counting region).
+// (Counting table organised by minimizer bins: see k_solid_emit / k_solid_from_leaves instead.)
 constexpr uint32_t SOLID_SB = 11, SOLID_REGION = 1u << SOLID_SB;
 
 __global__ void __launch_bounds__(512) k_build_solid_regions(const Slot *__restrict__ slots, uint32_t main_lg,
@@ -270,6 +279,92 @@ __global__ void __launch_bounds__(512) k_build_solid_regions(const Slot *__restr
                     if (atomicCAS(reinterpret_cast<unsigned long long *>(&R[s].key), (unsigned long long)EMPTY_KEY,
                                   (unsigned long long)key) == EMPTY_KEY) {
                         R[s].count = (uint32_t)c;
+                        R[s].hr = (raw.w & HINT_RV) ? lh_make(raw.w & 0x3FFFu, HINT_LEN) : 0;
+                        R[s].hl = (raw.w & HINT_LV) ? lh_make((raw.w >> 16) & 0x3FFFu, HINT_LEN) : 0;
+                        done = true;
+                        break;
+                    }
+                    s = (s + 1) & (SOLID_REGION - 1);
+                }
+                if (!done) atomicExch(&overflow, 1u);
+            }
+        }
+        __syncthreads();
+        if (overflow && tid == 0) atomicExch(solid.fatal, 1u);
+        uint4 *dst = reinterpret_cast<uint4 *>(solid.slots + Q * SOLID_REGION);
+        const uint4 *src = reinterpret_cast<const uint4 *>(R);
+        for (uint32_t i = tid; i < SOLID_REGION * 2; i += 512) dst[i] = src[i];
+        __syncthreads();
+    }
+}
+
+
+// K6 when the counting table is organised by minimizer bins (mc_ctx::mm_k): the solid table still
+// indexes by the key's own hash, so its regions draw from all over the counting table.  The solid
+// entries (a few % of the occurrences) therefore take the same route as the counting records:
+// k_solid_emit sweeps the counting table and appends every entry with count >= min_cov to the level-1
+// bucket of its solid slot (256 workgroups, each its own segment of every bucket), k_sk2_scatter
+// splits the buckets into one leaf per solid region, k_solid_from_leaves assembles each region in
+// LDS.  No fill pass, no global atomics.
+__global__ void __launch_bounds__(PT_THREADS) k_solid_emit(const Slot *__restrict__ slots, uint64_t n_slots, int min_cov, uint32_t b1,
+                                                            uint32_t *seg_counts, uint64_t cap, uint4 *out_recs, uint32_t *out_bins,
+                                                            SkSpill sp)
+{
+    __shared__ SkCursors C;
+    const uint32_t tid = threadIdx.x, n_buckets = 1u << b1;
+    if (tid < PT_MAX_BUCKETS) { C.wcur[tid] = 0; C.cnt[tid] = 0; }
+    __syncthreads();
+    const uint64_t n_tiles = (n_slots + PT_TILE - 1) / PT_TILE;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        uint4 raws[PT_ITEMS];
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS; j++) {
+            const uint64_t i = tile * PT_TILE + tid + (uint64_t)j * PT_THREADS;
+            raws[j] = i < n_slots ? *reinterpret_cast<const uint4 *>(slots + i) : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS; j++) {
+            const uint64_t key = ((uint64_t)raws[j].y << 32) | raws[j].x;
+            if (key == EMPTY_KEY) continue;
+            const uint32_t c = raws[j].z > 32767u ? 32767u : raws[j].z;
+            if ((int)c < min_cov) continue;
+            raws[j].z = c;
+            const uint32_t bin = (uint32_t)(fmix64(key) >> 32);
+            sk_emit(C, bin >> (32 - b1), raws[j], bin, cap, (uint64_t)blockIdx.x * cap, (uint64_t)PT_SEGMENTS * cap, out_recs, out_bins, sp);
+        }
+        __syncthreads();
+        if (tid < n_buckets) { C.wcur[tid] += C.cnt[tid]; C.cnt[tid] = 0; }
+        __syncthreads();
+    }
+    if (tid < n_buckets) seg_counts[(uint64_t)tid * PT_SEGMENTS + blockIdx.x] = min(C.wcur[tid], (uint32_t)cap);
+}
+
+// one workgroup per solid region = one leaf (nseg segments of capacity seg_cap, as for k_p3_merge)
+__global__ void __launch_bounds__(512) k_solid_from_leaves(const uint4 *__restrict__ leaf_recs, const uint32_t *__restrict__ seg_counts,
+                                                           uint64_t seg_cap, uint32_t nseg, SolidView solid, uint32_t solid_lg)
+{
+    __shared__ SolidSlot R[SOLID_REGION];
+    __shared__ uint32_t overflow;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t n_regions = 1ull << (solid_lg - SOLID_SB);
+    for (uint64_t Q = blockIdx.x; Q < n_regions; Q += gridDim.x) {
+        for (uint32_t i = tid; i < SOLID_REGION; i += 512) {
+            R[i].key = EMPTY_KEY; R[i].count = 0; R[i].pad = 0; R[i].hr = 0; R[i].hl = 0;
+        }
+        if (tid == 0) overflow = 0;
+        __syncthreads();
+        for (uint32_t sgm = 0; sgm < nseg; sgm++) {
+            const uint32_t n = min(seg_counts[Q * nseg + sgm], (uint32_t)seg_cap);
+            const uint4 *recs = leaf_recs + (Q * nseg + sgm) * seg_cap;
+            for (uint32_t i = tid; i < n; i += 512) {
+                const uint4 raw = recs[i];
+                const uint64_t key = ((uint64_t)raw.y << 32) | raw.x;
+                uint32_t s = (uint32_t)(fmix64(key) >> (64 - solid_lg)) & (SOLID_REGION - 1);
+                bool done = false;
+                for (uint32_t probe = 0; probe < SOLID_REGION; probe++) {
+                    if (atomicCAS(reinterpret_cast<unsigned long long *>(&R[s].key), (unsigned long long)EMPTY_KEY,
+                                  (unsigned long long)key) == EMPTY_KEY) {
+                        R[s].count = raw.z;
                         R[s].hr = (raw.w & HINT_RV) ? lh_make(raw.w & 0x3FFFu, HINT_LEN) : 0;
                         R[s].hl = (raw.w & HINT_LV) ? lh_make((raw.w >> 16) & 0x3FFFu, HINT_LEN) : 0;
                         done = true;
@@ -585,12 +680,14 @@ static int ensure_buf(mc_ctx *c, T **p, uint64_t *cap, uint64_t need)
 struct PipePlan {
     uint32_t b1 = 0, b2 = 0, g = 0;
     uint64_t np1 = 0, n_leaves = 0, cap1 = 0, cap2 = 0, spill_cap = 0, wb = 0;
+    bool sk = false;  // the streams hold super-k-mer records; capacities are in records
     SpillView sp{};
+    SkSpill sks{};
 };
 
 // Table capacity check, scratch buffers and cursors for one run of the partitioned pipeline over
-// `wb` key occurrences.
-static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl)
+// `wb` key occurrences.  n_records != 0: they travel as (an estimated) n_records super-k-mer records.
+static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records = 0)
 {
     mc_ctx::Pipe &P = c->pipe;
     // Make sure the table can take the batch: with a capacity hint that still holds the table was sized for
@@ -622,19 +719,29 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl)
     pl->wb = wb;
     pl->np1 = 1ull << pl->b1;
     pl->n_leaves = 1ull << lb;
-    pl->cap1 = (uint64_t)((double)wb / (double)pl->np1 / (double)PT_SEGMENTS * 1.25) + 256;  // per segment
-    const double mean_leaf = (double)wb / (double)pl->n_leaves;
+    pl->sk = n_records != 0;
+    const uint64_t units = pl->sk ? n_records : wb;  // records in the streams
+    pl->cap1 = (uint64_t)((double)units / (double)pl->np1 / (double)PT_SEGMENTS * 1.25) + (pl->sk ? 64 : 256);  // per segment
+    const double mean_leaf = (double)units / (double)pl->n_leaves;
     pl->cap2 = (uint64_t)(mean_leaf * 1.15 + 8.0 * std::sqrt(mean_leaf) + 64.0);
-    pl->spill_cap = std::max<uint64_t>(wb / 64, 1u << 20);
+    pl->spill_cap = pl->sk ? std::max<uint64_t>(units / 16, 1u << 16) : std::max<uint64_t>(wb / 64, 1u << 20);
     if (pl->np1 * PT_SEGMENTS * pl->cap1 >= 0xFFFFFFFFull || (1ull << pl->b2) * pl->cap2 >= 0xFFFFFFFFull)
         return fail(c, MC_EINVAL, "internal: partitioned batch too large for 32-bit bucket indices");
     const uint64_t np1 = pl->np1, n_leaves = pl->n_leaves;
     int rc;
     uint64_t dummy;
 #define ENSURE(ptr, capvar, need) do { rc = ensure_buf(c, &(ptr), &(capvar), (need)); if (rc) return rc; } while (0)
-    { uint64_t cap = P.a_cap; ENSURE(P.a_keys, cap, np1 * PT_SEGMENTS * pl->cap1); dummy = P.a_cap; ENSURE(P.a_hints, dummy, np1 * PT_SEGMENTS * pl->cap1); P.a_cap = cap; }
-    { uint64_t cap = P.b_cap; ENSURE(P.b_keys, cap, n_leaves * pl->cap2); dummy = P.b_cap; ENSURE(P.b_hints, dummy, n_leaves * pl->cap2); P.b_cap = cap; }
-    { uint64_t cap = P.spill_cap; ENSURE(P.spill_keys, cap, pl->spill_cap); dummy = P.spill_cap; ENSURE(P.spill_hints, dummy, pl->spill_cap); P.spill_cap = cap; }
+    if (pl->sk) {
+        ENSURE(P.a_recs, P.a_recs_cap, np1 * PT_SEGMENTS * pl->cap1);
+        if (pl->b2) ENSURE(P.b_recs, P.b_recs_cap, n_leaves * pl->cap2);
+        ENSURE(P.spill_recs, P.spill_recs_cap, pl->spill_cap);
+    } else {
+        { uint64_t cap = P.a_cap; ENSURE(P.a_keys, cap, np1 * PT_SEGMENTS * pl->cap1); P.a_cap = cap; }
+        { uint64_t cap = P.b_cap; ENSURE(P.b_keys, cap, n_leaves * pl->cap2); P.b_cap = cap; }
+        { uint64_t cap = P.spill_cap; ENSURE(P.spill_keys, cap, pl->spill_cap); dummy = P.spill_cap; ENSURE(P.spill_hints, dummy, pl->spill_cap); P.spill_cap = cap; }
+    }
+    ENSURE(P.a_hints, P.a_hints_cap, np1 * PT_SEGMENTS * pl->cap1);
+    ENSURE(P.b_hints, P.b_hints_cap, n_leaves * pl->cap2);
     ENSURE(P.seg_counts1, P.segs1_cap, np1 * PT_SEGMENTS);
     { uint64_t cap = P.leaves_cap; ENSURE(P.cursors2, cap, n_leaves); dummy = P.leaves_cap; ENSURE(P.leaf_state, dummy, n_leaves); dummy = P.leaves_cap; ENSURE(P.leaf_new, dummy, n_leaves); P.leaves_cap = cap; }
 #undef ENSURE
@@ -647,26 +754,39 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl)
     HIPCHK(c, hipMemsetAsync(P.flags, 0, 2 * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(P.spill_count, 0, sizeof(unsigned long long), c->stream));
     pl->sp = SpillView{P.spill_keys, P.spill_hints, P.spill_count, pl->spill_cap, P.flags};
+    pl->sks = SkSpill{P.spill_recs, P.spill_count, pl->spill_cap, P.flags};
     return MC_OK;
 }
 
 // P2, P3 (with the retry after growing the table), spill drain and bookkeeping; ms1 = time of the
-// level-1 scatter that filled the a_* buckets.
+// level-1 scatter that filled the a_* buckets.  Returns 1 (nothing merged yet) when the super-k-mer
+// streams overflowed even their spill list: the caller then counts the batch with the direct kernel.
 static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1)
 {
     mc_ctx::Pipe &P = c->pipe;
     const uint64_t np1 = pl.np1, n_leaves = pl.n_leaves;
+    const int k = c->cfg.k;
     int rc;
     double ms2 = 0, ms3 = 0;
     if (pl.b2 > 0) {
         rc = timed(c, &ms2, [&] {
-            hipLaunchKernelGGL(k_p2_scatter, dim3((unsigned)np1), dim3(PT_THREADS), 0, c->stream, P.a_keys, P.a_hints, pl.cap1,
-                               P.seg_counts1, (uint32_t)np1, pl.b1, pl.b2, P.cursors2, pl.cap2, P.b_keys, P.b_hints, pl.sp);
+            if (pl.sk)
+                hipLaunchKernelGGL(k_sk2_scatter, dim3((unsigned)np1), dim3(PT_THREADS), 0, c->stream, P.a_recs, P.a_hints, pl.cap1,
+                                   P.seg_counts1, (uint32_t)np1, pl.b1, pl.b2, P.cursors2, pl.cap2, P.b_recs, P.b_hints, pl.sks);
+            else
+                hipLaunchKernelGGL(k_p2_scatter, dim3((unsigned)np1), dim3(PT_THREADS), 0, c->stream, P.a_keys, P.a_hints, pl.cap1,
+                                   P.seg_counts1, (uint32_t)np1, pl.b1, pl.b2, P.cursors2, pl.cap2, P.b_keys, P.b_hints, pl.sp, c->mm_k);
         });
         if (rc) return rc;
     }
+    if (pl.sk) {  // the record capacities are estimates: check before anything is merged
+        uint32_t lost = 0;
+        HIPCHK(c, hipMemcpy(&lost, P.flags, sizeof lost, hipMemcpyDeviceToHost));
+        if (lost) return 1;
+    }
     // P3 reads the leaves: P2's output (one segment each), or P1's buckets directly when there is no second level
-    const uint64_t *lk = pl.b2 > 0 ? P.b_keys : P.a_keys;
+    const void *lk = pl.sk ? (pl.b2 > 0 ? (const void *)P.b_recs : (const void *)P.a_recs)
+                           : (pl.b2 > 0 ? (const void *)P.b_keys : (const void *)P.a_keys);
     const uint32_t *lh = pl.b2 > 0 ? P.b_hints : P.a_hints;
     const uint32_t *lc = pl.b2 > 0 ? P.cursors2 : P.seg_counts1;
     const uint64_t lcap = pl.b2 > 0 ? pl.cap2 : pl.cap1;
@@ -676,9 +796,11 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1)
         const int virgin = c->virgin ? 1 : 0;
         rc = timed(c, &ms3, [&] {
             const int grid = (int)std::min<uint64_t>(n_leaves, 256 * 2 * 4);
-            hipLaunchKernelGGL(k_p3_merge, dim3(grid), dim3(P3_THREADS), 0, c->stream, lk, lh, lc, lcap, lseg,
-                               (uint32_t)n_leaves, pl.g, c->view(), virgin, P.leaf_state, P.leaf_new, P.flags + 1,
-                               (uint32_t)(c->solid_tracked ? c->cov_hint : 0), c->d_ctr + 6);
+#define P3_ARGS lk, lh, lc, lcap, lseg, (uint32_t)n_leaves, pl.g, c->view(), virgin, P.leaf_state, P.leaf_new, P.flags + 1, \
+                (uint32_t)(c->solid_tracked ? c->cov_hint : 0), c->d_ctr + 6, k
+            if (pl.sk) hipLaunchKernelGGL(k_p3_merge<true>, dim3(grid), dim3(P3_THREADS), 0, c->stream, P3_ARGS);
+            else hipLaunchKernelGGL(k_p3_merge<false>, dim3(grid), dim3(P3_THREADS), 0, c->stream, P3_ARGS);
+#undef P3_ARGS
         });
         if (rc) return rc;
         c->virgin = false;
@@ -692,6 +814,8 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1)
         if (rc) return rc;
         pl.g++;
         HIPCHK(c, hipMemsetAsync(P.flags + 1, 0, sizeof(uint32_t), c->stream));
+        // the rebuild recounted n_used, keys of the leaves merged so far included
+        HIPCHK(c, hipMemsetAsync(P.leaf_new, 0, n_leaves * sizeof(uint32_t), c->stream));
     }
     hipLaunchKernelGGL(k_sum_leaf_new, dim3(64), dim3(256), 0, c->stream, P.leaf_new, (uint32_t)n_leaves, c->d_ctr);
     HIPCHK(c, hipGetLastError());
@@ -704,12 +828,15 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1)
         uint64_t i = 0;
         while (i < n_spill) {
             uint64_t allowed;
-            rc = table_reserve(c, n_spill - i, &allowed);
+            rc = table_reserve(c, (n_spill - i) * (pl.sk ? SK_MAX_WINDOWS : 1), &allowed);
             if (rc) return rc;
-            const uint64_t m = std::min<uint64_t>(allowed, n_spill - i);
+            const uint64_t m = std::min<uint64_t>(pl.sk ? std::max<uint64_t>(allowed / SK_MAX_WINDOWS, 1) : allowed, n_spill - i);
             rc = timed(c, &ms4, [&] {
-                hipLaunchKernelGGL(k_add_keys_hint, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, P.spill_keys + i,
-                                   P.spill_hints + i, m, c->view());
+                if (pl.sk)
+                    hipLaunchKernelGGL(k_sk_add_records, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, P.spill_recs + i, m, k, c->view());
+                else
+                    hipLaunchKernelGGL(k_add_keys_hint, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, P.spill_keys + i,
+                                       P.spill_hints + i, m, c->view());
             });
             if (rc) return rc;
             i += m;
@@ -735,7 +862,7 @@ static void launch_p1_reads(mc_ctx *c, const uint64_t *d_words, const uint64_t *
     const int grid = owners_mode == 0 ? PT_SEGMENTS
                                       : (int)std::min<uint64_t>(std::max<uint64_t>(n_tiles_abs - base0 / PT_TILE, 1), 256);
     const int k = c->cfg.k;
-#define P1_ARGS d_words, offs, nr, base0, end_abs, n_tiles_abs, tile_first, k, b1, cursors, cap, out_keys, out_hints, c->d_ctr + 1, sp, bases
+#define P1_ARGS d_words, offs, nr, base0, end_abs, n_tiles_abs, tile_first, k, b1, cursors, cap, out_keys, out_hints, c->d_ctr + 1, sp, bases, c->mm_k
 #define P1_LAUNCH(MODE)                                                                                                  \
     do {                                                                                                                 \
         if (owners_mode == 0)                                                                                            \
@@ -761,10 +888,13 @@ static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint6
 {
     mc_ctx::Pipe &P = c->pipe;
     PipePlan pl;
-    int rc = pipe_prepare(c, wb, &pl);
+    const uint64_t nr = r1 - r0;
+    // super-k-mer records expected: runs of windows sharing a minimizer average (w + 1) / 2 windows
+    // (w = k - SK_M + 1 minimizer candidates per window), and every read ends one
+    const uint64_t n_records = c->mm_k ? (uint64_t)((double)wb * 2.0 / (double)(c->cfg.k - SK_M + 2) * 1.2) + nr + 1024 : 0;
+    int rc = pipe_prepare(c, wb, &pl, n_records);
     if (rc) return rc;
     const uint64_t *offs = d_off + r0;
-    const uint64_t nr = r1 - r0;
     // tiles are cut over the absolute base positions [0, end_abs); the ones before base0 hold no read of ours
     const uint64_t n_tiles_abs = (end_abs + PT_TILE - 1) / PT_TILE;
     rc = ensure_buf(c, &P.tile_first, &P.tiles1_cap, n_tiles_abs);
@@ -773,11 +903,33 @@ static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint6
     rc = timed(c, &ms1, [&] {
         hipLaunchKernelGGL(k_tile_first_read, dim3((unsigned)((n_tiles_abs + 255) / 256)), dim3(256), 0, c->stream, offs, nr,
                            n_tiles_abs, P.tile_first);
-        launch_p1_reads(c, d_words, offs, nr, base0, end_abs, n_tiles_abs, P.tile_first, pl.b1, P.seg_counts1, pl.cap1, P.a_keys,
-                        P.a_hints, pl.sp, 0, nullptr);
+        if (pl.sk)
+            hipLaunchKernelGGL(k_sk1_extract, dim3(PT_SEGMENTS), dim3(PT_THREADS), 0, c->stream, d_words, offs, nr, base0, end_abs,
+                               n_tiles_abs, P.tile_first, c->cfg.k, pl.b1, P.seg_counts1, pl.cap1, P.a_recs, P.a_hints, pl.sks);
+        else
+            launch_p1_reads(c, d_words, offs, nr, base0, end_abs, n_tiles_abs, P.tile_first, pl.b1, P.seg_counts1, pl.cap1, P.a_keys,
+                            P.a_hints, pl.sp, 0, nullptr);
     });
     if (rc) return rc;
-    return pipe_finish(c, pl, ms1);
+    rc = pipe_finish(c, pl, ms1);
+    if (rc != 1) return rc;
+    // (super-k-mer streams overflowed: unusually short runs) count this batch with the direct kernel instead
+    uint64_t r = r0;
+    while (r < r1) {
+        uint64_t allowed;
+        rc = table_reserve(c, wb, &allowed);
+        if (rc) return rc;
+        const uint64_t step = std::max<uint64_t>(1, std::min<uint64_t>(r1 - r, allowed / std::max<uint64_t>(1, (end_abs - base0) / nr + 1)));
+        double ms = 0;
+        rc = timed(c, &ms, [&] { launch_count(c, d_words, d_off, r, r + step); });
+        if (rc) return rc;
+        c->st.count_ms += ms;
+        c->st.count_total_ms += ms;
+        c->st.count_launches++;
+        r += step;
+    }
+    c->st.windows += wb;
+    return MC_OK;
 }
 
 // A flat stream of keys (+ optional hints) through the partitioned pipeline: the keys a rank owns
@@ -793,7 +945,7 @@ static int add_keys_partitioned(mc_ctx *c, const uint64_t *d_keys, const uint32_
         const uint64_t n_tiles = (n + PT_TILE - 1) / PT_TILE;
         (void)n_tiles;
         hipLaunchKernelGGL(k_p1_keys_scatter, dim3(PT_SEGMENTS), dim3(PT_THREADS), 0, c->stream,
-                           d_keys, d_hints, n, pl.b1, P.seg_counts1, pl.cap1, P.a_keys, P.a_hints, c->d_ctr + 1, pl.sp);
+                           d_keys, d_hints, n, pl.b1, P.seg_counts1, pl.cap1, P.a_keys, P.a_hints, c->d_ctr + 1, pl.sp, c->mm_k);
     });
     if (rc) return rc;
     return pipe_finish(c, pl, ms1);
@@ -908,6 +1060,10 @@ int mc_create(const mc_config *cfg, mc_ctx **out)
     CREATE_CHK(hipMemsetAsync(c->d_fatal, 0, sizeof(uint32_t), c->stream));
 #undef CREATE_CHK
     if (const char *e = getenv("MC_COUNT_PATH")) c->count_path = !strcmp(e, "direct") ? 1 : !strcmp(e, "partition") ? 2 : 0;
+    // packed keys of at least SK_MIN_K bases: table regions = minimizer bins, reads counted as super-k-mers
+    // (MC_SUPERKMERS=0 keeps the per-window pipeline: for A/B measurements)
+    if (cfg->key_mode == MC_KEY_PACKED && cfg->k >= SK_MIN_K) c->mm_k = cfg->k;
+    if (const char *e = getenv("MC_SUPERKMERS")) if (!strcmp(e, "0")) c->mm_k = 0;
     uint32_t lg = 22;  // 4 M slots = 64 MB to start with
     if (cfg->capacity_hint) {
         const double want = (double)cfg->capacity_hint / 0.7;  // regions are probed in LDS: a fuller table costs little
@@ -1394,9 +1550,42 @@ int ensure_solid(mc_ctx *c, int min_cov, double *ms)
         c->solid_lg = lg;
     }
     const int doublings = c->cfg.key_mode == MC_KEY_PACKED ? 2 : 0;  // hash keys do not hold the k-mer
+    // counting table organised by minimizer bins: the solid entries are partitioned by their own hash first
+    mc_ctx::Pipe &P = c->pipe;
+    const uint32_t q = lg - SOLID_SB, sb1 = std::min<uint32_t>(q, 9), sb2 = q - sb1;
+    uint64_t scap1 = 0, scap2 = 0;
+    if (c->mm_k) {
+        const double m1 = (double)n / (double)(1ull << sb1) / (double)PT_SEGMENTS, m2 = (double)n / (double)(1ull << q);
+        scap1 = (uint64_t)(m1 * 1.25 + 10.0 * std::sqrt(m1) + 64.0);
+        scap2 = (uint64_t)(m2 * 1.15 + 10.0 * std::sqrt(m2) + 64.0);
+        rc = ensure_buf(c, &P.a_recs, &P.a_recs_cap, (uint64_t)(1ull << sb1) * PT_SEGMENTS * scap1);
+        if (!rc) rc = ensure_buf(c, &P.a_hints, &P.a_hints_cap, (uint64_t)(1ull << sb1) * PT_SEGMENTS * scap1);
+        if (!rc) rc = ensure_buf(c, &P.seg_counts1, &P.segs1_cap, (uint64_t)(1ull << sb1) * PT_SEGMENTS);
+        if (!rc && sb2) rc = ensure_buf(c, &P.b_recs, &P.b_recs_cap, (uint64_t)(1ull << q) * scap2);
+        if (!rc && sb2) rc = ensure_buf(c, &P.b_hints, &P.b_hints_cap, (uint64_t)(1ull << q) * scap2);
+        if (!rc && sb2) rc = ensure_buf(c, &P.solid_cursors, &P.solid_cursors_cap, 1ull << q);
+        if (rc) return rc;
+        if (!P.flags) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.flags), 2 * sizeof(uint32_t)));
+        if (!P.spill_count) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.spill_count), sizeof(unsigned long long)));
+        HIPCHK(c, hipMemsetAsync(P.flags, 0, 2 * sizeof(uint32_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(P.spill_count, 0, sizeof(unsigned long long), c->stream));
+    }
     rc = timed(c, ms, [&] {
-        hipLaunchKernelGGL(k_build_solid_regions, dim3((unsigned)std::min<uint64_t>(1ull << (lg - SOLID_SB), 256 * 2 * 8)), dim3(512), 0,
-                           c->stream, c->slots, c->rb + c->sb, min_cov, c->solid_view(), lg);
+        if (c->mm_k) {
+            uint32_t *leaf_counts = P.solid_cursors;
+            const SkSpill none{nullptr, P.spill_count, 0, P.flags};  // no spill list: an overflow is reported
+            hipLaunchKernelGGL(k_solid_emit, dim3(PT_SEGMENTS), dim3(PT_THREADS), 0, c->stream, c->slots, c->n_slots(), min_cov, sb1,
+                               P.seg_counts1, scap1, P.a_recs, P.a_hints, none);
+            if (sb2)
+                hipLaunchKernelGGL(k_sk2_scatter, dim3(1u << sb1), dim3(PT_THREADS), 0, c->stream, P.a_recs, P.a_hints, scap1,
+                                   P.seg_counts1, 1u << sb1, sb1, sb2, leaf_counts, scap2, P.b_recs, P.b_hints, none);
+            hipLaunchKernelGGL(k_solid_from_leaves, dim3((unsigned)std::min<uint64_t>(1ull << q, 256 * 2 * 8)), dim3(512), 0, c->stream,
+                               sb2 ? P.b_recs : P.a_recs, sb2 ? leaf_counts : P.seg_counts1, sb2 ? scap2 : scap1,
+                               sb2 ? 1u : (uint32_t)PT_SEGMENTS, c->solid_view(), lg);
+        } else {
+            hipLaunchKernelGGL(k_build_solid_regions, dim3((unsigned)std::min<uint64_t>(1ull << (lg - SOLID_SB), 256 * 2 * 8)), dim3(512), 0,
+                               c->stream, c->slots, c->rb + c->sb, min_cov, c->solid_view(), lg);
+        }
         for (int d = 0; d < doublings; d++)
             hipLaunchKernelGGL(k_solid_double, dim3(grid_for(1ull << lg, 256)), dim3(256), 0, c->stream, c->solid_view(),
                                (uint64_t)1 << lg, c->cfg.k);
@@ -1405,6 +1594,11 @@ int ensure_solid(mc_ctx *c, int min_cov, double *ms)
     uint32_t fatal = 0;
     HIPCHK(c, hipMemcpy(&fatal, c->d_fatal, sizeof fatal, hipMemcpyDeviceToHost));
     if (fatal) return fail(c, MC_EOVERFLOW, "a region of the solid k-mer table filled up (hash skew)");
+    if (c->mm_k) {
+        uint32_t lost = 0;
+        HIPCHK(c, hipMemcpy(&lost, P.flags, sizeof lost, hipMemcpyDeviceToHost));
+        if (lost) return fail(c, MC_EOVERFLOW, "internal: a bucket of the solid-table build overflowed (hash skew)");
+    }
     c->solid_cov = min_cov;
     return MC_OK;
 }

@@ -56,7 +56,7 @@ def test_count_config1_k31(mc, err, count_path):
     ctx.close()
 
 
-@pytest.mark.parametrize("k,mode", [(31, 0), (21, 0), (5, 0), (1, 0), (63, 1), (33, 1), (47, 2), (31, 1), (64 - 1, 2)])
+@pytest.mark.parametrize("k,mode", [(31, 0), (23, 0), (27, 0), (30, 0), (21, 0), (5, 0), (1, 0), (63, 1), (33, 1), (47, 2), (31, 1), (64 - 1, 2)])
 def test_count_ragged_reads_all_key_modes(mc, k, mode, count_path):
     """Empty reads, reads shorter than k, k-1, k, ragged lengths; packed key, poly and fnv1a hashes."""
     rng = np.random.default_rng(100 + k + mode)
