@@ -162,19 +162,21 @@ def main():
         roofline = None
         if avg_ms:
             achieved = units_per_launch * A / (avg_ms * 1e-3) / 1e9
-            parts = {"k_p1_extract_scatter" if world == 1 else "k_p1_keys_scatter": st.p1_ms / launches,
-                     "k_p2_scatter": st.p2_ms / launches, "k_p3_merge": st.p3_ms / launches}
+            # super-k-mer form of the pipeline (packed keys, k >= 23) unless the reads arrive as keys from other ranks
+            sk = world == 1 and mode == m.KEY_PACKED and k >= 23 and os.environ.get("MC_SUPERKMERS") != "0"
+            parts = {("k_sk1_extract" if sk else "k_p1_extract_scatter") if world == 1 else "k_p1_keys_scatter": st.p1_ms / launches,
+                     "k_sk2_scatter" if sk else "k_p2_scatter": st.p2_ms / launches, "k_p3_merge": st.p3_ms / launches}
             pipeline = st.p3_ms > 0
             dominant = max(parts, key=parts.get) if pipeline else "k_count_reads"
             traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_v3_pmc_hbm_traffic_e1.csv")
+            pmc = os.path.join(ROOT, "profiles", "r01_v4_pmc_hbm_traffic_e1.csv")
             if pipeline and world == 1 and args.err == 100 and R == 10_000_000 and k == 31 and os.path.exists(pmc):
                 # HBM bytes per pipeline run from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes,
                 # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes), collected by scripts/gpu_pmc.sh
                 import csv
                 gb = 0.0
                 for row in csv.DictReader(open(pmc)):
-                    if row["kernel"].startswith(("mc::k_p1_extract_scatter", "mc::k_p2_scatter", "mc::k_p3_merge")):
+                    if row["kernel"].startswith(("mc::k_sk1_extract", "mc::k_sk2_scatter", "mc::k_p3_merge")):
                         gb += float(row["fetch_GB_corrected_x2"]) + float(row["write_GB"])
                 traffic = round(gb * 1e9)
             roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -201,6 +203,7 @@ def main():
             "distinct_kmers": distinct, "bfs": {"ms_per_step": round(info["bfs_ms"], 3), "reached": info["reached"],
                                                  "levels": info["levels"], "lookups": info["lookups"]},
             "table_bytes": int(st.table_bytes), "table_grows": int(st.grows),
+            "spilled_records_per_step": int(st.spill_keys) // args.steps, "solid_sweeps_per_step": int(st.solid_sweeps) / args.steps,
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if world > 1:

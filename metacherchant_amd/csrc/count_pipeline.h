@@ -805,11 +805,12 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk2_scatter(const uint4 *__restr
     }
 }
 
-// drains the record spill list through the direct path
-__global__ void k_sk_add_records(const uint4 *__restrict__ recs, uint64_t n, int k, TableView t)
+// drains the record spill list through the direct path (solid_thr / n_solid as in k_p3_merge)
+__global__ void k_sk_add_records(const uint4 *__restrict__ recs, uint64_t n, int k, TableView t, uint32_t solid_thr,
+                                 unsigned long long *n_solid)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    unsigned long long n_new = 0;
+    unsigned long long n_new = 0, n_cross = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint4 rec = recs[i];
         const uint64_t lo = ((uint64_t)rec.y << 32) | rec.x, hi = ((uint64_t)rec.w << 32) | rec.z;
@@ -817,10 +818,13 @@ __global__ void k_sk_add_records(const uint4 *__restrict__ recs, uint64_t n, int
             uint64_t key;
             uint32_t hint;
             sk_expand(lo, hi, j, k, &key, &hint);
-            n_new += table_add(t, key, 1u, hint);
+            uint32_t before;
+            n_new += table_add(t, key, 1u, hint, &before);
+            n_cross += crosses(before, 1u, solid_thr);
         }
     }
     wave_add_ull(t.n_used, n_new);
+    if (solid_thr) wave_add_ull(n_solid, n_cross);
 }
 
 // P3: one workgroup per leaf; a leaf covers 2^g consecutive table regions (g = 0 unless the table
@@ -1043,13 +1047,17 @@ __global__ void k_sum_leaf_new(const uint32_t *__restrict__ leaf_new, uint32_t n
 
 // drains the spill list (and serves as the direct path for key streams that carry a hint)
 __global__ void k_add_keys_hint(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ hints, uint64_t n,
-                                TableView t)
+                                TableView t, uint32_t solid_thr = 0, unsigned long long *n_solid = nullptr)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    unsigned long long n_new = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        n_new += table_add(t, keys[i], 1u, hints[i]);
+    unsigned long long n_new = 0, n_cross = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint32_t before;
+        n_new += table_add(t, keys[i], 1u, hints[i], &before);
+        n_cross += crosses(before, 1u, solid_thr);
+    }
     wave_add_ull(t.n_used, n_new);
+    if (solid_thr) wave_add_ull(n_solid, n_cross);
 }
 
 }  // namespace mc

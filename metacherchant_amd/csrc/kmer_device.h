@@ -304,10 +304,14 @@ __host__ __device__ __forceinline__ uint64_t slot_of(const TableView &t, uint64_
 // and min(32767, count) equals the reference's saturating short, itmo!/utils/NumUtils.java:21-26).
 // Returns 1 when the key was new: callers add these up and publish them with wave_add_ull once per
 // wave (one hot counter address hammered by every insert costs more than the inserts themselves).
-__device__ __forceinline__ uint32_t table_add(const TableView &t, uint64_t key, uint32_t inc, uint32_t hint = 0)
+// *before (optional): the key's count before this addition (0 for a new key).
+__device__ __forceinline__ uint32_t table_add(const TableView &t, uint64_t key, uint32_t inc, uint32_t hint = 0,
+                                              uint32_t *before = nullptr)
 {
+    if (before) *before = 0;
     if (key == EMPTY_KEY) {
-        atomicAdd(t.empty_cnt, (unsigned long long)inc);
+        const unsigned long long old = atomicAdd(t.empty_cnt, (unsigned long long)inc);
+        if (before) *before = old > 0x80000000ull ? 0x80000000u : (uint32_t)old;
         return 0;
     }
     uint64_t s = slot_of(t, key);
@@ -323,21 +327,35 @@ __device__ __forceinline__ uint32_t table_add(const TableView &t, uint64_t key, 
             if (cur == EMPTY_KEY) {
                 // the inserter alone also writes the hint: one 64-bit add on {count, aux} (aux was 0, and
                 // count never carries into it: counters stop growing at 2^31)
-                atomicAdd(reinterpret_cast<unsigned long long *>(&p->count), ((unsigned long long)hint << 32) | inc);
+                const unsigned long long old =
+                    atomicAdd(reinterpret_cast<unsigned long long *>(&p->count), ((unsigned long long)hint << 32) | inc);
+                if (before) *before = (uint32_t)old;  // (another thread may have counted this key in between)
                 return 1;
             }
             if (cur == key) {
-                atomicAdd(&p->count, inc);
+                const uint32_t old = atomicAdd(&p->count, inc);
+                if (before) *before = old;
                 return 0;
             }
         } else if (cur == key) {
-            if (raw.z < 0x80000000u) atomicAdd(&p->count, inc);
+            if (raw.z < 0x80000000u) {
+                const uint32_t old = atomicAdd(&p->count, inc);
+                if (before) *before = old;
+            } else if (before) {
+                *before = raw.z;
+            }
             return 0;
         }
         s = base | ((s + 1) & t.rmask);
     }
     atomicExch(t.fatal, 1u);
     return 0;
+}
+
+// does an addition of `inc` to a count that was `before` carry it over the threshold? (both clamp at 32767 when read)
+__device__ __forceinline__ uint32_t crosses(uint32_t before, uint32_t inc, uint32_t thr)
+{
+    return thr && before < thr && (uint64_t)before + inc >= thr;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -723,7 +723,8 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
     const uint64_t units = pl->sk ? n_records : wb;  // records in the streams
     pl->cap1 = (uint64_t)((double)units / (double)pl->np1 / (double)PT_SEGMENTS * 1.25) + (pl->sk ? 64 : 256);  // per segment
     const double mean_leaf = (double)units / (double)pl->n_leaves;
-    pl->cap2 = (uint64_t)(mean_leaf * 1.15 + 8.0 * std::sqrt(mean_leaf) + 64.0);
+    // (records of one locus come in clumps -- one per read covering it -- so leaves vary more than Poisson)
+    pl->cap2 = (uint64_t)(mean_leaf * 1.15 + (pl->sk ? 24.0 : 8.0) * std::sqrt(mean_leaf) + 64.0);
     pl->spill_cap = pl->sk ? std::max<uint64_t>(units / 16, 1u << 16) : std::max<uint64_t>(wb / 64, 1u << 20);
     if (pl->np1 * PT_SEGMENTS * pl->cap1 >= 0xFFFFFFFFull || (1ull << pl->b2) * pl->cap2 >= 0xFFFFFFFFull)
         return fail(c, MC_EINVAL, "internal: partitioned batch too large for 32-bit bucket indices");
@@ -824,7 +825,7 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1)
     HIPCHK(c, hipMemcpy(&n_spill, P.spill_count, sizeof n_spill, hipMemcpyDeviceToHost));
     double ms4 = 0;
     if (n_spill) {
-        c->solid_tracked = false;
+        const uint32_t thr = (uint32_t)(c->solid_tracked ? c->cov_hint : 0);
         uint64_t i = 0;
         while (i < n_spill) {
             uint64_t allowed;
@@ -833,10 +834,11 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1)
             const uint64_t m = std::min<uint64_t>(pl.sk ? std::max<uint64_t>(allowed / SK_MAX_WINDOWS, 1) : allowed, n_spill - i);
             rc = timed(c, &ms4, [&] {
                 if (pl.sk)
-                    hipLaunchKernelGGL(k_sk_add_records, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, P.spill_recs + i, m, k, c->view());
+                    hipLaunchKernelGGL(k_sk_add_records, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, P.spill_recs + i, m, k, c->view(),
+                                       thr, c->d_ctr + 6);
                 else
                     hipLaunchKernelGGL(k_add_keys_hint, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, P.spill_keys + i,
-                                       P.spill_hints + i, m, c->view());
+                                       P.spill_hints + i, m, c->view(), thr, c->d_ctr + 6);
             });
             if (rc) return rc;
             i += m;
