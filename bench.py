@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--maxkmers", type=int, default=100000)
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--capacity-hint", type=int, default=0, help="distinct k-mers per GPU expected (0: estimate from the error rate)")
     args = ap.parse_args()
 
     import numpy as np
@@ -72,7 +73,7 @@ def main():
     genome_bases = args.contigs * args.contig_len
     # expected distinct keys: the genome's k-mers + ~k novel k-mers per substitution error
     est_distinct = int(min(world * windows, genome_bases + world * n_bases * (args.err / 10000.0) * k * 0.9))
-    hint_local = est_distinct // world + (1 << 20)
+    hint_local = args.capacity_hint or est_distinct // world + (1 << 20)
 
     ctx = m.Context(k, mode, local_rank, hint_local)
     ctx.set_coverage_hint(args.coverage)  # --coverage is known before the reads are loaded (the CLI does the same)

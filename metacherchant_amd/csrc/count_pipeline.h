@@ -894,6 +894,16 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                 const uint64_t region = ((uint64_t)leaf << g) | sub;
                 Slot *gs = t.slots + region * REGION_SLOTS;
                 int solid_before = 0;
+                // (SK) the first records are requested before the region is set up in LDS
+                uint4 pre = make_uint4(0, 0, 0, 0);
+                uint32_t pre_bin = 0;
+                if constexpr (SK) {
+                    const uint32_t n0 = min(seg_counts[(uint64_t)leaf * nseg], (uint32_t)seg_cap);
+                    if (tid < n0) {
+                        pre = static_cast<const uint4 *>(leaf_keys)[(uint64_t)leaf * nseg * seg_cap + tid];
+                        if (g) pre_bin = leaf_hints[(uint64_t)leaf * nseg * seg_cap + tid];
+                    }
+                }
                 for (uint32_t i = tid; i < REGION_SLOTS; i += P3_THREADS) {
                     if (virgin) {
                         L.key[i] = EMPTY_KEY; L.cnt[i] = 0; L.aux[i] = 0;
@@ -916,8 +926,8 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                     const uint4 *recs = static_cast<const uint4 *>(leaf_keys) + ((uint64_t)leaf * nseg + sgm) * seg_cap;
                     const uint32_t *bins = leaf_hints + ((uint64_t)leaf * nseg + sgm) * seg_cap;
                     const uint64_t kmask = (1ull << (2 * k)) - 1;  // (k <= 31)
-                    uint4 nxt = tid < n ? recs[tid] : make_uint4(0, 0, 0, 0);
-                    uint32_t nxt_bin = (g && tid < n) ? bins[tid] : 0u;
+                    uint4 nxt = sgm == 0 ? pre : (tid < n ? recs[tid] : make_uint4(0, 0, 0, 0));
+                    uint32_t nxt_bin = sgm == 0 ? pre_bin : ((g && tid < n) ? bins[tid] : 0u);
                     for (uint32_t r = tid; r < n; r += P3_THREADS) {
                         const uint4 rec = nxt;
                         const uint32_t bin = nxt_bin;

@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(512) k_solid_from_leaves(const uint4 *__restri
 // Hint doubling (packed keys only: the key IS the k-mer).  The hint of x leads to the vertex y; y's own
 // hint, turned to x's strand, continues it.  In place: hr / hl are single 8-byte words, and a reader
 // that meets an already extended word just extends further -- any valid continuation will do.
-__global__ void k_solid_double(SolidView t, uint64_t n_slots, int k)
+__global__ void k_solid_double(SolidView t, uint64_t n_slots, int k, int max_steps)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t kmask = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1);
@@ -396,24 +396,28 @@ __global__ void k_solid_double(SolidView t, uint64_t n_slots, int k)
         const uint64_t x = p->key;
         if (x == EMPTY_KEY) continue;
         for (int side = 0; side < 2; side++) {
-            const uint64_t w = side == 0 ? p->hr : p->hl;
-            const uint32_t n = lh_len(w);
-            if (n == 0 || n >= (uint32_t)LHINT_MAX || n > (uint32_t)k) continue;
-            uint64_t y;
-            if (side == 0) y = ((x << (2 * n)) | lh_block_forward(w, n)) & kmask;            // x followed by its n bases
-            else y = (x >> (2 * n)) | ((w & lh_mask(n)) << (2 * (k - (int)n)));               // x preceded by them
-            const uint64_t ry = rc_packed(y, k);
-            const bool flipped = ry < y;
-            uint64_t hr, hl;
-            if (solid_get(t, flipped ? ry : y, &hr, &hl) < 0) continue;
-            // what follows (side 0) / precedes (side 1) y on x's strand
-            uint64_t cont = side == 0 ? (flipped ? lh_complement(hl) : hr) : (flipped ? lh_complement(hr) : hl);
-            const uint32_t m = lh_len(cont);
-            if (m == 0) continue;
-            const uint32_t total = n + m > (uint32_t)LHINT_MAX ? (uint32_t)LHINT_MAX : n + m;
-            const uint64_t bases = (w & lh_mask(n)) | ((cont & lh_mask(m)) << (2 * n));
-            const uint64_t nw = lh_make(bases, total);
-            if (side == 0) p->hr = nw; else p->hl = nw;
+            uint64_t w = side == 0 ? p->hr : p->hl;
+            bool changed = false;
+            for (int step = 0; step < max_steps; step++) {  // 7 -> 14 -> 21 -> 28, or faster when y was extended already
+                const uint32_t n = lh_len(w);
+                if (n == 0 || n >= (uint32_t)LHINT_MAX || n > (uint32_t)k) break;
+                uint64_t y;
+                if (side == 0) y = ((x << (2 * n)) | lh_block_forward(w, n)) & kmask;            // x followed by its n bases
+                else y = (x >> (2 * n)) | ((w & lh_mask(n)) << (2 * (k - (int)n)));               // x preceded by them
+                const uint64_t ry = rc_packed(y, k);
+                const bool flipped = ry < y;
+                uint64_t hr, hl;
+                if (solid_get(t, flipped ? ry : y, &hr, &hl) < 0) break;
+                // what follows (side 0) / precedes (side 1) y on x's strand
+                uint64_t cont = side == 0 ? (flipped ? lh_complement(hl) : hr) : (flipped ? lh_complement(hr) : hl);
+                const uint32_t m = lh_len(cont);
+                if (m == 0) break;
+                const uint32_t total = n + m > (uint32_t)LHINT_MAX ? (uint32_t)LHINT_MAX : n + m;
+                const uint64_t bases = (w & lh_mask(n)) | ((cont & lh_mask(m)) << (2 * n));
+                w = lh_make(bases, total);
+                changed = true;
+            }
+            if (changed) { if (side == 0) p->hr = w; else p->hl = w; }
         }
     }
 }
@@ -1068,7 +1072,9 @@ int mc_create(const mc_config *cfg, mc_ctx **out)
     if (const char *e = getenv("MC_SUPERKMERS")) if (!strcmp(e, "0")) c->mm_k = 0;
     uint32_t lg = 22;  // 4 M slots = 64 MB to start with
     if (cfg->capacity_hint) {
-        const double want = (double)cfg->capacity_hint / 0.7;  // regions are probed in LDS: a fuller table costs little
+        // regions are probed in LDS: a fuller table costs little.  Minimizer bins fill less evenly than hash
+        // prefixes (the k-mers of one locus share a bin), so they get more headroom.
+        const double want = (double)cfg->capacity_hint / (c->mm_k ? 0.6 : 0.7);
         while (lg < 36 && (double)(1ull << lg) < want) lg++;
     }
     int rc = table_alloc(c, lg);
@@ -1588,9 +1594,9 @@ int ensure_solid(mc_ctx *c, int min_cov, double *ms)
             hipLaunchKernelGGL(k_build_solid_regions, dim3((unsigned)std::min<uint64_t>(1ull << (lg - SOLID_SB), 256 * 2 * 8)), dim3(512), 0,
                                c->stream, c->slots, c->rb + c->sb, min_cov, c->solid_view(), lg);
         }
-        for (int d = 0; d < doublings; d++)
+        if (doublings)  // one sweep: each slot chases its own chain (up to 3 dependent lookups per side)
             hipLaunchKernelGGL(k_solid_double, dim3(grid_for(1ull << lg, 256)), dim3(256), 0, c->stream, c->solid_view(),
-                               (uint64_t)1 << lg, c->cfg.k);
+                               (uint64_t)1 << lg, c->cfg.k, 3);
     });
     if (rc) return rc;
     uint32_t fatal = 0;
