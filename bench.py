@@ -163,10 +163,12 @@ def main():
         roofline = None
         if avg_ms:
             achieved = units_per_launch * A / (avg_ms * 1e-3) / 1e9
-            # super-k-mer form of the pipeline (packed keys, k >= 23) unless the reads arrive as keys from other ranks
-            sk = world == 1 and mode == m.KEY_PACKED and k >= 23 and os.environ.get("MC_SUPERKMERS") != "0"
-            parts = {("k_sk1_extract" if sk else "k_p1_extract_scatter") if world == 1 else "k_p1_keys_scatter": st.p1_ms / launches,
-                     "k_sk2_scatter" if sk else "k_p2_scatter": st.p2_ms / launches, "k_p3_merge": st.p3_ms / launches}
+            # super-k-mer form of the pipeline (packed keys, k >= 23); with several ranks the level-1 kernel
+            # scatters the records (or keys) received from the other ranks instead of extracting them from reads
+            sk = mode == m.KEY_PACKED and k >= 23 and os.environ.get("MC_SUPERKMERS") != "0"
+            p1 = ("k_sk1_extract" if world == 1 else "k_sk1_records") if sk else ("k_p1_extract_scatter" if world == 1 else "k_p1_keys_scatter")
+            parts = {p1: st.p1_ms / launches, "k_sk2_scatter" if sk else "k_p2_scatter": st.p2_ms / launches,
+                     "k_p3_merge": st.p3_ms / launches}
             pipeline = st.p3_ms > 0
             dominant = max(parts, key=parts.get) if pipeline else "k_count_reads"
             traffic = None
@@ -200,7 +202,7 @@ def main():
                                        R, L, args.contigs, args.contig_len, k, args.coverage, args.maxkmers,
                                        "E1 1%% substitutions" if args.err == 100 else "err=%d/10000" % args.err),
                        "reads_per_gpu": R, "read_len": L, "k": k, "err_per_10k": args.err,
-                       "parallelism": "reads sharded x%d, all-to-all by hash prefix" % world if world > 1 else "1 GPU"},
+                       "parallelism": "reads sharded x%d, all-to-all of super-k-mer records (keys for k < 23 / hash keys) by owner" % world if world > 1 else "1 GPU"},
             "distinct_kmers": distinct, "bfs": {"ms_per_step": round(info["bfs_ms"], 3), "reached": info["reached"],
                                                  "levels": info["levels"], "lookups": info["lookups"]},
             "table_bytes": int(st.table_bytes), "table_grows": int(st.grows),

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MC_ABI_VERSION 3
+#define MC_ABI_VERSION 4
 
 /* error codes */
 #define MC_OK 0
@@ -183,6 +183,22 @@ int mc_extract_keys_dev(mc_ctx *ctx, const uint64_t *d_words, const uint64_t *d_
                         uint64_t *owner_offsets);
 /* addAndBound(key, 1) for each key; d_hints may be NULL */
 int mc_add_keys_dev(mc_ctx *ctx, const int64_t *d_keys, const uint32_t *d_hints, uint64_t n);
+
+/* The same split in the compact form the counting pipeline uses itself when keys are packed k-mers
+ * of at least 23 bases: one 16-byte "super-k-mer" record per run of up to 16 consecutive windows of a
+ * read that share their minimizer (two uint64 per record; layout in csrc/count_pipeline.h) plus one
+ * 32-bit bin word per record -- about a seventh of the bytes of the key form.  All windows of a record
+ * have the same owner.
+ *   mc_superkmer_capacity   records to provide room for, given the windows and reads of a batch;
+ *                           0 when this context does not use the form (then use the key form above)
+ *   mc_extract_superkmers_dev  as mc_extract_keys_dev; MC_EOVERFLOW when the reads yield more records
+ *                           than mc_superkmer_capacity allows for (fall back to the key form)
+ *   mc_add_superkmers_dev   addAndBound(key, 1) for every window of every record */
+uint64_t mc_superkmer_capacity(mc_ctx *ctx, uint64_t n_windows, uint64_t n_reads);
+int mc_extract_superkmers_dev(mc_ctx *ctx, const uint64_t *d_words, const uint64_t *d_read_offsets, uint64_t n_reads,
+                              uint64_t n_bases, uint32_t n_owners, uint64_t *d_records, uint32_t *d_bins,
+                              uint64_t records_cap, uint64_t *owner_offsets);
+int mc_add_superkmers_dev(mc_ctx *ctx, const uint64_t *d_records, const uint32_t *d_bins, uint64_t n);
 
 /* ---- measurement */
 typedef struct {

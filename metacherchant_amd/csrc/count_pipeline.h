@@ -543,6 +543,8 @@ __device__ __forceinline__ void sk_hash8(const uint64_t *bases, uint32_t q, uint
 }
 
 // SK-P1: tiles of PT_TILE consecutive base positions, PT_ITEMS (8) consecutive positions per thread.
+// OWNERS: the buckets are the b1 (!) owner ranks of a multi-GPU split instead of 2^b1 bin prefixes.
+template <bool OWNERS>
 __global__ void __launch_bounds__(PT_THREADS) k_sk1_extract(
     const uint64_t *__restrict__ words, const uint64_t *__restrict__ offsets, uint64_t n_reads, uint64_t base_lo,
     uint64_t n_bases, uint64_t n_tiles, const uint32_t *__restrict__ first_read, int k, uint32_t b1, uint32_t *seg_counts,
@@ -551,7 +553,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk1_extract(
     static_assert(PT_ITEMS == 8, "one byte of the break bitmap per thread");
     __shared__ Sk1Lds L;
     const uint32_t tid = threadIdx.x;
-    const uint32_t n_buckets = 1u << b1;
+    const uint32_t n_buckets = OWNERS ? b1 : (1u << b1);
     const int w = k - SK_M + 1;  // SK_M-mers per window (9 .. 17)
     const uint64_t last_word = (n_bases + 31) / 32;  // the pad word
     if (tid < PT_MAX_BUCKETS) { L.C.wcur[tid] = 0; L.C.cnt[tid] = 0; }
@@ -704,13 +706,65 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk1_extract(
             const uint32_t bin = sk_bin(hsel);
             uint4 rec;
             rec.x = (uint32_t)rl; rec.y = (uint32_t)(rl >> 32); rec.z = (uint32_t)hi; rec.w = (uint32_t)(hi >> 32);
-            sk_emit(L.C, bin >> (32 - b1), rec, bin, cap, (uint64_t)blockIdx.x * cap, (uint64_t)PT_SEGMENTS * cap, out_recs, out_bins, sp);
+            sk_emit(L.C, OWNERS ? sk_owner(hsel, b1) : bin >> (32 - b1), rec, bin, cap, (uint64_t)blockIdx.x * cap,
+                    (uint64_t)PT_SEGMENTS * cap, out_recs, out_bins, sp);
         }
         __syncthreads();
         if (tid < n_buckets) { L.C.wcur[tid] += L.C.cnt[tid]; L.C.cnt[tid] = 0; }
     }
     __syncthreads();
     if (tid < n_buckets) seg_counts[(uint64_t)tid * PT_SEGMENTS + blockIdx.x] = min(L.C.wcur[tid], (uint32_t)cap);
+}
+
+// Multi-GPU split: packs the (owner, segment) pieces k_sk1_extract<true> filled into one stream ordered by
+// owner.  k_sk_pack_offsets (one workgroup): piece_off[i] = records before piece i = owner * PT_SEGMENTS + seg,
+// owner_off[o] = records before owner o, owner_off[n_owners] = all.  k_sk_pack: one workgroup per piece.
+__global__ void __launch_bounds__(1024) k_sk_pack_offsets(const uint32_t *__restrict__ seg_counts, uint32_t n_owners,
+                                                          unsigned long long *piece_off, unsigned long long *owner_off)
+{
+    __shared__ unsigned long long part[1024];
+    const uint32_t tid = threadIdx.x, n = n_owners * PT_SEGMENTS;
+    const uint32_t per = (n + 1023) / 1024, lo = tid * per, hi = min(n, lo + per);
+    unsigned long long sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += seg_counts[i];
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long acc = 0;
+        for (uint32_t i = 0; i < 1024; i++) { const unsigned long long v = part[i]; part[i] = acc; acc += v; }
+        owner_off[n_owners] = acc;
+    }
+    __syncthreads();
+    unsigned long long acc = part[tid];
+    for (uint32_t i = lo; i < hi; i++) {
+        piece_off[i] = acc;
+        if (i % PT_SEGMENTS == 0) owner_off[i / PT_SEGMENTS] = acc;
+        acc += seg_counts[i];
+    }
+}
+__global__ void __launch_bounds__(256) k_sk_pack(const uint4 *__restrict__ recs, const uint32_t *__restrict__ bins,
+                                                 const uint32_t *__restrict__ seg_counts, uint64_t seg_cap,
+                                                 const unsigned long long *__restrict__ piece_off, uint32_t n_pieces,
+                                                 uint4 *out_recs, uint32_t *out_bins, uint64_t out_cap)
+{
+    for (uint32_t p = blockIdx.x; p < n_pieces; p += gridDim.x) {
+        const uint32_t n = seg_counts[p];
+        const uint64_t src = (uint64_t)p * seg_cap, dst = piece_off[p];
+        if (dst + n > out_cap) continue;  // (the host reports the overflow from owner_off)
+        for (uint32_t i = threadIdx.x; i < n; i += 256) {
+            out_recs[dst + i] = recs[src + i];
+            out_bins[dst + i] = bins[src + i];
+        }
+    }
+}
+
+// windows of a stream of records
+__global__ void k_sk_count_windows(const uint4 *__restrict__ recs, uint64_t n, unsigned long long *out)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long w = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) w += sk_windows(((uint64_t)recs[i].w << 32) | recs[i].z);
+    wave_add_ull(out, w);
 }
 
 // SK-P1 for a flat stream of records (+ bin words): the receiving side of a multi-GPU exchange.

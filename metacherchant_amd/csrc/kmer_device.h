@@ -250,6 +250,12 @@ __host__ __device__ __forceinline__ uint32_t sk_bin(uint32_t hmin)
     x ^= x >> 16;
     return x;
 }
+// owner rank of everything that shares a minimizer (multi-GPU split): mixed differently from sk_bin, so that
+// the keys one rank owns still spread over all regions of its table
+__host__ __device__ __forceinline__ uint32_t sk_owner(uint32_t hmin, uint32_t n_owners)
+{
+    return sk_bin(hmin ^ 0x5BD1E995u) % n_owners;
+}
 __host__ __device__ __forceinline__ uint32_t sk_rc_mmer(uint32_t x)
 {
     return (uint32_t)rc_packed((uint64_t)x, SK_M);

@@ -887,6 +887,14 @@ static void launch_p1_reads(mc_ctx *c, const uint64_t *d_words, const uint64_t *
 #undef P1_ARGS
 }
 
+// super-k-mer records expected from `nr` reads with `wb` windows: runs of windows sharing a minimizer average
+// (w + 1) / 2 windows in random sequence (w = k - SK_M + 1 minimizer candidates per window); sequencing errors
+// and the 16-window limit cut some short (x 1.5 covers 1-2 % errors), and every read ends one
+static uint64_t sk_records_bound(const mc_ctx *c, uint64_t wb, uint64_t nr)
+{
+    return (uint64_t)((double)wb * 2.0 / (double)(c->cfg.k - SK_M + 2) * 1.5) + 2 * nr + 1024;
+}
+
 // One batch of reads [r0, r1) through the partitioned pipeline (count_pipeline.h).  wb = its windows,
 // base0 / end_abs = read_offsets[r0] / read_offsets[r1].
 static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_off, uint64_t r0, uint64_t r1,
@@ -895,9 +903,7 @@ static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint6
     mc_ctx::Pipe &P = c->pipe;
     PipePlan pl;
     const uint64_t nr = r1 - r0;
-    // super-k-mer records expected: runs of windows sharing a minimizer average (w + 1) / 2 windows
-    // (w = k - SK_M + 1 minimizer candidates per window), and every read ends one
-    const uint64_t n_records = c->mm_k ? (uint64_t)((double)wb * 2.0 / (double)(c->cfg.k - SK_M + 2) * 1.2) + nr + 1024 : 0;
+    const uint64_t n_records = c->mm_k ? sk_records_bound(c, wb, nr) : 0;
     int rc = pipe_prepare(c, wb, &pl, n_records);
     if (rc) return rc;
     const uint64_t *offs = d_off + r0;
@@ -910,7 +916,7 @@ static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint6
         hipLaunchKernelGGL(k_tile_first_read, dim3((unsigned)((n_tiles_abs + 255) / 256)), dim3(256), 0, c->stream, offs, nr,
                            n_tiles_abs, P.tile_first);
         if (pl.sk)
-            hipLaunchKernelGGL(k_sk1_extract, dim3(PT_SEGMENTS), dim3(PT_THREADS), 0, c->stream, d_words, offs, nr, base0, end_abs,
+            hipLaunchKernelGGL(k_sk1_extract<false>, dim3(PT_SEGMENTS), dim3(PT_THREADS), 0, c->stream, d_words, offs, nr, base0, end_abs,
                                n_tiles_abs, P.tile_first, c->cfg.k, pl.b1, P.seg_counts1, pl.cap1, P.a_recs, P.a_hints, pl.sks);
         else
             launch_p1_reads(c, d_words, offs, nr, base0, end_abs, n_tiles_abs, P.tile_first, pl.b1, P.seg_counts1, pl.cap1, P.a_keys,
@@ -955,6 +961,30 @@ static int add_keys_partitioned(mc_ctx *c, const uint64_t *d_keys, const uint32_
     });
     if (rc) return rc;
     return pipe_finish(c, pl, ms1);
+}
+
+// A flat stream of super-k-mer records (+ bin words): what a rank owns after the multi-GPU exchange.
+static int add_records_partitioned(mc_ctx *c, const uint4 *d_recs, const uint32_t *d_bins, uint64_t n)
+{
+    mc_ctx::Pipe &P = c->pipe;
+    unsigned long long *sum = c->d_ctr + 2;
+    HIPCHK(c, hipMemsetAsync(sum, 0, sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(k_sk_count_windows, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, d_recs, n, sum);
+    HIPCHK(c, hipGetLastError());
+    unsigned long long wb = 0;
+    HIPCHK(c, hipMemcpy(&wb, sum, sizeof wb, hipMemcpyDeviceToHost));
+    PipePlan pl;
+    int rc = pipe_prepare(c, wb, &pl, n);
+    if (rc) return rc;
+    double ms1 = 0;
+    rc = timed(c, &ms1, [&] {
+        hipLaunchKernelGGL(k_sk1_records, dim3(PT_SEGMENTS), dim3(PT_THREADS), 0, c->stream, d_recs, d_bins, n, pl.b1, P.seg_counts1,
+                           pl.cap1, P.a_recs, P.a_hints, pl.sks);
+    });
+    if (rc) return rc;
+    rc = pipe_finish(c, pl, ms1);
+    if (rc == 1) return fail(c, MC_EOVERFLOW, "internal: super-k-mer buckets overflowed while adding a record stream");
+    return rc;
 }
 
 // counting with read offsets known on the host
@@ -1396,6 +1426,88 @@ int mc_extract_keys_dev(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_of
                     reinterpret_cast<uint64_t *>(d_keys), d_hints, nosp, 2, d_bases.p);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MC_OK;
+}
+
+uint64_t mc_superkmer_capacity(mc_ctx *c, uint64_t n_windows, uint64_t n_reads)
+{
+    if (!c || !c->mm_k) return 0;
+    return sk_records_bound(c, n_windows, n_reads);
+}
+
+int mc_extract_superkmers_dev(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_off, uint64_t n_reads, uint64_t n_bases,
+                              uint32_t n_owners, uint64_t *d_recs, uint32_t *d_bins, uint64_t cap, uint64_t *owner_offsets)
+{
+    if (!c) return MC_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->mm_k) return fail(c, MC_ESTATE, "mc_extract_superkmers_dev: this context does not count through super-k-mers (mc_superkmer_capacity() == 0)");
+    if (!owner_offsets || !d_recs || !d_bins || n_owners == 0 || n_owners > PT_MAX_BUCKETS)
+        return fail(c, MC_EINVAL, "mc_extract_superkmers_dev: bad argument");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    for (uint32_t o = 0; o <= n_owners; o++) owner_offsets[o] = 0;
+    if (n_reads == 0) return MC_OK;
+    mc_ctx::Pipe &P = c->pipe;
+    uint64_t first_off = 0, last_off = 0;
+    HIPCHK(c, hipMemcpyAsync(&first_off, d_off, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&last_off, d_off + n_reads, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (last_off != n_bases)
+        return fail(c, MC_EINVAL, "mc_extract_superkmers_dev: read_offsets[n_reads]=%llu but n_bases=%llu",
+                    (unsigned long long)last_off, (unsigned long long)n_bases);
+    // windows <= bases: capacity of the (owner, segment) pieces from the same bound the caller sized its buffer with
+    const uint64_t bound = sk_records_bound(c, n_bases - first_off, n_reads);
+    const uint64_t seg_cap = (uint64_t)((double)bound / (double)n_owners / (double)PT_SEGMENTS * 1.25) + 64;
+    if ((uint64_t)n_owners * PT_SEGMENTS * seg_cap >= 0xFFFFFFFFull)
+        return fail(c, MC_EINVAL, "mc_extract_superkmers_dev: batch too large (split the reads)");
+    const uint64_t n_tiles_abs = (last_off + PT_TILE - 1) / PT_TILE;
+    int rc = ensure_buf(c, &P.tile_first, &P.tiles1_cap, n_tiles_abs);
+    if (!rc) rc = ensure_buf(c, &P.a_recs, &P.a_recs_cap, (uint64_t)n_owners * PT_SEGMENTS * seg_cap);
+    if (!rc) rc = ensure_buf(c, &P.a_hints, &P.a_hints_cap, (uint64_t)n_owners * PT_SEGMENTS * seg_cap);
+    if (!rc) rc = ensure_buf(c, &P.seg_counts1, &P.segs1_cap, (uint64_t)n_owners * PT_SEGMENTS);
+    if (rc) return rc;
+    if (!P.flags) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.flags), 2 * sizeof(uint32_t)));
+    if (!P.spill_count) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.spill_count), sizeof(unsigned long long)));
+    HIPCHK(c, hipMemsetAsync(P.flags, 0, 2 * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(P.spill_count, 0, sizeof(unsigned long long), c->stream));
+    DevBuf<unsigned long long> d_piece, d_owner;
+    HIPCHK(c, d_piece.alloc((uint64_t)n_owners * PT_SEGMENTS));
+    HIPCHK(c, d_owner.alloc(n_owners + 1));
+    const SkSpill none{nullptr, P.spill_count, 0, P.flags};  // no spill list: an overflow is reported
+    hipLaunchKernelGGL(k_tile_first_read, dim3((unsigned)((n_tiles_abs + 255) / 256)), dim3(256), 0, c->stream, d_off, n_reads,
+                       n_tiles_abs, P.tile_first);
+    hipLaunchKernelGGL(k_sk1_extract<true>, dim3(PT_SEGMENTS), dim3(PT_THREADS), 0, c->stream, d_words, d_off, n_reads, first_off,
+                       last_off, n_tiles_abs, P.tile_first, c->cfg.k, n_owners, P.seg_counts1, seg_cap, P.a_recs, P.a_hints, none);
+    hipLaunchKernelGGL(k_sk_pack_offsets, dim3(1), dim3(1024), 0, c->stream, P.seg_counts1, n_owners, d_piece.p, d_owner.p);
+    hipLaunchKernelGGL(k_sk_pack, dim3(std::min<uint32_t>(n_owners * PT_SEGMENTS, 4096)), dim3(256), 0, c->stream, P.a_recs, P.a_hints,
+                       P.seg_counts1, seg_cap, d_piece.p, n_owners * PT_SEGMENTS, reinterpret_cast<uint4 *>(d_recs), d_bins, cap);
+    HIPCHK(c, hipGetLastError());
+    std::vector<unsigned long long> h_owner(n_owners + 1);
+    uint32_t lost = 0;
+    HIPCHK(c, hipMemcpyAsync(h_owner.data(), d_owner.p, (n_owners + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&lost, P.flags, sizeof lost, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (lost) return fail(c, MC_EOVERFLOW, "mc_extract_superkmers_dev: more super-k-mers than expected (unusually short runs); use mc_extract_keys_dev");
+    if (h_owner[n_owners] > cap)
+        return fail(c, MC_EINVAL, "mc_extract_superkmers_dev: %llu records but capacity %llu", h_owner[n_owners], (unsigned long long)cap);
+    for (uint32_t o = 0; o <= n_owners; o++) owner_offsets[o] = h_owner[o];
+    return MC_OK;
+}
+
+int mc_add_superkmers_dev(mc_ctx *c, const uint64_t *d_recs, const uint32_t *d_bins, uint64_t n)
+{
+    if (!c) return MC_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->mm_k) return fail(c, MC_ESTATE, "mc_add_superkmers_dev: this context does not count through super-k-mers");
+    if ((!d_recs || !d_bins) && n) return fail(c, MC_EINVAL, "mc_add_superkmers_dev: null pointer");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const uint64_t max_batch = 1ull << 28;  // records per pipeline run (32-bit bucket indices)
+    for (uint64_t i = 0; i < n; i += max_batch) {
+        const uint64_t m = std::min<uint64_t>(max_batch, n - i);
+        int rc = add_records_partitioned(c, reinterpret_cast<const uint4 *>(d_recs) + i, d_bins + i, m);
+        if (rc) return rc;
+    }
+    c->finalized = false;
+    c->solid_cov = -1;
     return MC_OK;
 }
 

@@ -36,6 +36,10 @@ class ShardedCounter:
         if W == 1:
             ctx.add_reads_packed_dev(d_words, d_offsets, n_reads, n_bases)
             return
+        cap = ctx.superkmer_capacity(max_windows, n_reads) if hasattr(ctx, "superkmer_capacity") else 0
+        if cap:  # packed keys, k >= 23: the reads travel as super-k-mer records, a seventh of the bytes
+            self._exchange_superkmers(d_words, d_offsets, n_reads, n_bases, cap)
+            return
         send = torch.empty(max(int(max_windows), 1), dtype=torch.int64, device=self.device)
         send_h = torch.empty(max(int(max_windows), 1), dtype=torch.int32, device=self.device)  # speculation hints
         off = ctx.extract_keys_dev(d_words, d_offsets, n_reads, n_bases, W, send, send.numel(), send_h)
@@ -57,6 +61,29 @@ class ShardedCounter:
         self.bytes_sent += 12 * (n_send - send_counts[self.rank])
         del send, send_h
         ctx.add_keys_dev(recv, n_recv, recv_h)
+
+    def _exchange_superkmers(self, d_words, d_offsets, n_reads, n_bases, cap):
+        ctx, W = self.ctx, self.world
+        send = torch.empty((cap, 2), dtype=torch.int64, device=self.device)   # 16-byte records
+        send_b = torch.empty(cap, dtype=torch.int32, device=self.device)      # their bin words
+        off = ctx.extract_superkmers_dev(d_words, d_offsets, n_reads, n_bases, W, send, send_b, cap)
+        send_counts = [int(off[o + 1] - off[o]) for o in range(W)]
+        sc = torch.tensor(send_counts, dtype=torch.int64, device=self.device)
+        rc = torch.empty(W, dtype=torch.int64, device=self.device)
+        dist.all_to_all_single(rc, sc, group=self.group)
+        recv_counts = [int(x) for x in rc.cpu().tolist()]
+        n_recv, n_send = sum(recv_counts), int(off[W])
+        recv = torch.empty((max(n_recv, 1), 2), dtype=torch.int64, device=self.device)
+        recv_b = torch.empty(max(n_recv, 1), dtype=torch.int32, device=self.device)
+        dist.all_to_all_single(recv[:n_recv], send[:n_send], output_split_sizes=recv_counts,
+                               input_split_sizes=send_counts, group=self.group)
+        dist.all_to_all_single(recv_b[:n_recv], send_b[:n_send], output_split_sizes=recv_counts,
+                               input_split_sizes=send_counts, group=self.group)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        self.bytes_sent += 20 * (n_send - send_counts[self.rank])
+        del send, send_b
+        ctx.add_superkmers_dev(recv, recv_b, n_recv)
 
     def finalize(self):
         """Local distinct keys; the sum over ranks is the table size (owners are disjoint)."""

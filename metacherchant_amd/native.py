@@ -46,7 +46,7 @@ EXPORTS = [
     "mc_abi_version", "mc_create", "mc_destroy", "mc_clear", "mc_set_coverage_hint", "mc_last_error", "mc_set_stream", "mc_add_reads_packed",
     "mc_add_reads_packed_dev", "mc_finalize_counts", "mc_get", "mc_get_dev", "mc_kmer_keys", "mc_bfs", "mc_bfs_batch",
     "mc_bfs_result_free", "mc_export", "mc_export_dev", "mc_add_pairs_dev", "mc_key_owner", "mc_extract_keys_dev",
-    "mc_add_keys_dev", "mc_get_stats", "mc_reset_stats", "mc_synth_reads_dev", "mc_synth_genome",
+    "mc_add_keys_dev", "mc_superkmer_capacity", "mc_extract_superkmers_dev", "mc_add_superkmers_dev", "mc_get_stats", "mc_reset_stats", "mc_synth_reads_dev", "mc_synth_genome",
 ]
 
 _LIB = None
@@ -99,6 +99,10 @@ def load():
     L.mc_key_owner.restype = C.c_uint32
     L.mc_extract_keys_dev.argtypes = [vp, vp, vp, u64, u64, C.c_uint32, vp, vp, u64, u64p]
     L.mc_add_keys_dev.argtypes = [vp, vp, vp, u64]
+    L.mc_superkmer_capacity.argtypes = [vp, u64, u64]
+    L.mc_superkmer_capacity.restype = u64
+    L.mc_extract_superkmers_dev.argtypes = [vp, vp, vp, u64, u64, C.c_uint32, vp, vp, u64, u64p]
+    L.mc_add_superkmers_dev.argtypes = [vp, vp, vp, u64]
     L.mc_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.mc_reset_stats.argtypes = [vp]
     L.mc_synth_reads_dev.argtypes = [vp, u64, u64, u64, u64, u64, u64, C.c_uint32, C.c_uint32, vp, vp]
@@ -266,6 +270,21 @@ class Context:
         self._chk(self._L.mc_extract_keys_dev(self._h, _dptr(d_words), _dptr(d_offsets), n_reads, n_bases, n_owners,
                                               _dptr(d_keys), _dptr(d_hints), cap, _p(off, C.c_uint64)))
         return off
+
+    def superkmer_capacity(self, n_windows, n_reads):
+        """Records to make room for when a batch of reads is split with extract_superkmers_dev; 0 when this
+        context counts window by window (hash keys, k < 23): use extract_keys_dev then."""
+        return int(self._L.mc_superkmer_capacity(self._h, int(n_windows), int(n_reads)))
+
+    def extract_superkmers_dev(self, d_words, d_offsets, n_reads, n_bases, n_owners, d_recs, d_bins, cap):
+        """d_recs: int64 tensor of shape (cap, 2); d_bins: int32 tensor of cap entries.  Returns the owner offsets."""
+        off = np.zeros(n_owners + 1, dtype=np.uint64)
+        self._chk(self._L.mc_extract_superkmers_dev(self._h, _dptr(d_words), _dptr(d_offsets), n_reads, n_bases, n_owners,
+                                                    _dptr(d_recs), _dptr(d_bins), cap, _p(off, C.c_uint64)))
+        return off
+
+    def add_superkmers_dev(self, d_recs, d_bins, n):
+        self._chk(self._L.mc_add_superkmers_dev(self._h, _dptr(d_recs), _dptr(d_bins), n))
 
     # ---- measurement / synthetic data
     def stats(self):

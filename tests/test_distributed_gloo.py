@@ -18,10 +18,28 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 class OracleBackedContext:
     """Implements the Context methods distributed.py uses, on CPU tensors, with oracle/ functions."""
 
-    def __init__(self, k, mode):
+    def __init__(self, k, mode, records=False):
         from oracle import pyoracle as po
         self.po, self.k, self.mode = po, k, mode
         self.t = po.Table()
+        self.records = records  # stand in for a context that splits reads into super-k-mer records
+
+    # the record form of the split, degenerate here: one window per record, the key in the record's first word
+    def superkmer_capacity(self, n_windows, n_reads):
+        return n_windows + 1 if self.records else 0
+
+    def extract_superkmers_dev(self, d_words, d_off, n_reads, n_bases, n_owners, d_recs, d_bins, cap):
+        assert d_recs.shape == (cap, 2) and d_bins.shape == (cap,)
+        keys = torch.zeros(cap, dtype=torch.int64)
+        out = self.extract_keys_dev(d_words, d_off, n_reads, n_bases, n_owners, keys, cap)
+        d_recs[:, 0] = keys
+        d_recs[:, 1] = 7
+        d_bins[:] = 5
+        return out
+
+    def add_superkmers_dev(self, d_recs, d_bins, n):
+        assert bool((d_recs[:n, 1] == 7).all()) and bool((d_bins[:n] == 5).all())
+        self.add_keys_dev(d_recs[:n, 0].contiguous(), n)
 
     def add_reads_packed_dev(self, d_words, d_off, n_reads, n_bases):
         self.t.count_reads_packed(d_words.numpy().view(np.uint64), d_off.numpy().view(np.uint64), self.k, self.mode)
@@ -72,7 +90,7 @@ class OracleBackedContext:
         return n
 
 
-def _worker(rank, world, port, k, mode, reads, L, n_reads, min_cov, q):
+def _worker(rank, world, port, k, mode, reads, L, n_reads, min_cov, q, records=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -84,7 +102,7 @@ def _worker(rank, world, port, k, mode, reads, L, n_reads, min_cov, q):
         mine = reads[lo * L:hi * L]
         words = torch.from_numpy(po.pack(mine).view(np.int64))
         off = torch.from_numpy((np.arange(hi - lo + 1, dtype=np.uint64) * L).view(np.int64))
-        ctx = OracleBackedContext(k, mode)
+        ctx = OracleBackedContext(k, mode, records)
         sc = ShardedCounter(ctx, torch.device("cpu"))
         sc.add_reads_dev(words, off, hi - lo, (hi - lo) * L, (hi - lo) * (L - k + 1))
         total = sc.finalize()
@@ -108,8 +126,8 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("k,mode", [(31, 0), (35, 1)])
-def test_sharded_count_equals_single_table(k, mode):
+@pytest.mark.parametrize("k,mode,records", [(31, 0, False), (35, 1, False), (31, 0, True)])
+def test_sharded_count_equals_single_table(k, mode, records):
     from metacherchant_amd import build
     build.build_lib()  # key_owner comes from the C ABI (host function, no GPU needed)
     from oracle import pyoracle as po
@@ -121,7 +139,7 @@ def test_sharded_count_equals_single_table(k, mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, k, mode, reads, L, n_reads, min_cov, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, k, mode, reads, L, n_reads, min_cov, q, records)) for r in range(2)]
     for p in procs:
         p.start()
     total, n_solid, sk, scnt, sent = q.get(timeout=120)

@@ -326,6 +326,59 @@ def test_extract_keys_by_owner_and_merge_pairs(mc, count_path2, monkeypatch):
         merged.close()
 
 
+@pytest.mark.parametrize("k", [31, 23, 28])
+def test_superkmer_records_by_owner(mc, k):
+    """The compact form of the multi-GPU split: reads -> super-k-mer records bucketed by owner -> every owner
+    counts its records; owners hold disjoint key sets whose union is the table of all reads, and the walk over
+    the merged solid k-mers still has its read-context hints."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    genome, reads, off = synth_case(2, 40000, 9000, 150, 60)
+    _, rcodes, roff = ragged_case(rng, 600)  # short and ragged reads too
+    codes = np.concatenate([reads, rcodes])
+    offs = np.concatenate([off, roff[1:] + off[-1]])
+    t, n = oracle_table(codes, offs, k, po.KEY_PACKED)
+    d_words = torch.from_numpy(po.pack(codes).view(np.int64)).to(dev)
+    d_off = torch.from_numpy(offs.view(np.int64)).to(dev)
+    n_reads = len(offs) - 1
+    ex = mc.Context(k, mc.KEY_PACKED, 0, 0)
+    assert mc.Context(21, mc.KEY_PACKED, 0, 0).superkmer_capacity(1000, 10) == 0  # short k-mers: key form only
+    cap = ex.superkmer_capacity(n, n_reads)
+    assert 0 < cap < n
+    G = 3
+    recs = torch.zeros((cap, 2), dtype=torch.int64, device=dev)
+    bins = torch.zeros(cap, dtype=torch.int32, device=dev)
+    ooff = ex.extract_superkmers_dev(d_words, d_off, n_reads, int(offs[-1]), G, recs, bins, cap)
+    n_rec = int(ooff[-1])
+    assert n_rec * 4 < n  # many windows per record
+    seen = []
+    merged = mc.Context(k, mc.KEY_PACKED, 0, 0)
+    for o in range(G):
+        own = mc.Context(k, mc.KEY_PACKED, 0, 0)
+        a, b = int(ooff[o]), int(ooff[o + 1])
+        own.add_superkmers_dev(recs[a:b], bins[a:b], b - a)
+        nd = own.finalize()
+        pk = torch.zeros(nd, dtype=torch.int64, device=dev)
+        pc = torch.zeros(nd, dtype=torch.int16, device=dev)
+        ph = torch.zeros(nd, dtype=torch.int32, device=dev)
+        assert own.export_dev(0, pk, pc, nd, ph) == nd
+        seen.append(pk.cpu().numpy())
+        merged.add_pairs_dev(pk, pc, nd, ph)
+        own.close()
+    allk = np.concatenate(seen)
+    assert len(np.unique(allk)) == len(allk) == t.size()  # owners are disjoint
+    _assert_tables_equal(merged, merged.finalize(), t)
+    if k == 31:
+        seed = genome[5000:5300]
+        hi, lo = seed_windows(seed, k)
+        got = merged.bfs(hi, lo, 1, 3, 4000, -1)
+        assert_bfs_equal(got, po.bfs(t, k, po.KEY_PACKED, [seed], 1, 3, 4000, -1))
+        assert got["rounds"] * 6 < got["levels"]  # long look-ahead: the hints made the trip
+    ex.close()
+    merged.close()
+
+
 def test_hints_survive_exchange_and_speed_up_the_walk(mc):
     """Same results with and without hints; with them the BFS needs far fewer memory round trips."""
     import torch
