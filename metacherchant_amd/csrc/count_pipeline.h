@@ -980,6 +980,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                     const uint4 *recs = static_cast<const uint4 *>(leaf_keys) + ((uint64_t)leaf * nseg + sgm) * seg_cap;
                     const uint32_t *bins = leaf_hints + ((uint64_t)leaf * nseg + sgm) * seg_cap;
                     const uint64_t kmask = (1ull << (2 * k)) - 1;  // (k <= 31)
+                    const uint32_t hint_from = solid_thr >= 2 ? 1u : 0u;
                     uint4 nxt = sgm == 0 ? pre : (tid < n ? recs[tid] : make_uint4(0, 0, 0, 0));
                     uint32_t nxt_bin = sgm == 0 ? pre_bin : ((g && tid < n) ? bins[tid] : 0u);
                     for (uint32_t r = tid; r < n; r += P3_THREADS) {
@@ -1020,8 +1021,10 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                                 s = (s + 1) & (REGION_SLOTS - 1);
                             }
                             if (done) {
-                                atomicAdd(&L.cnt[s], 1u);
-                                const uint32_t have = L.aux[s];
+                                // context is only collected from the second occurrence on when the coverage threshold is
+                                // known to be above 1: sequencing errors (most distinct k-mers, seen once) never reach the BFS
+                                const uint32_t seen = atomicAdd(&L.cnt[s], 1u);
+                                const uint32_t have = seen >= hint_from ? L.aux[s] : (HINT_RV | HINT_LV);
                                 if ((have & (HINT_RV | HINT_LV)) != (HINT_RV | HINT_LV)) {  // the slot still lacks context
                                     const bool lv = has_l || j >= (uint32_t)HINT_LEN, rv = j + HINT_LEN <= nw - 1 + (has_r ? HINT_LEN : 0);
                                     const uint32_t R = flipped ? (l7 ^ 0x3FFFu) : r7, Lc = flipped ? (r7 ^ 0x3FFFu) : l7;

@@ -8,20 +8,27 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
 done
 python3 - <<'PY'
 import csv, glob, collections
+# one row per kernel and ordinal of its dispatch in the run (a kernel used by two phases stays separable)
 out = collections.OrderedDict()
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    seen = collections.Counter()
+    rows = []
     for f in glob.glob("gpurun_out/pmc_%s/*/*counter_collection.csv" % ctr):
-        for row in csv.DictReader(open(f)):
-            name = row["Kernel_Name"].split("(")[0].replace("void ", "")
-            if row["Counter_Name"] != ctr:
-                continue
-            d = out.setdefault(name, {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "n": 0})
-            d[ctr] += float(row["Counter_Value"])
-            if ctr == "FETCH_SIZE":
-                d["n"] += 1
+        rows += [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == ctr]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    per_dispatch = collections.OrderedDict()
+    for r in rows:  # counters of one dispatch may come in several rows (one per XCD / dimension): sum them
+        per_dispatch.setdefault((int(r["Dispatch_Id"]), r["Kernel_Name"]), 0.0)
+        per_dispatch[(int(r["Dispatch_Id"]), r["Kernel_Name"])] += float(r["Counter_Value"])
+    for (did, kname), v in per_dispatch.items():
+        name = kname.split("(")[0].replace("void ", "")
+        seen[name] += 1
+        d = out.setdefault("%s#%d" % (name, seen[name]), {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0})
+        d[ctr] += v
 with open("gpurun_out/pmc_summary.csv", "w") as f:
-    f.write("kernel,dispatches,FETCH_SIZE_KB_sum,WRITE_SIZE_KB_sum,fetch_GB_corrected_x2,write_GB\n")
+    f.write("kernel,dispatch,FETCH_SIZE_KB,WRITE_SIZE_KB,fetch_GB_corrected_x2,write_GB\n")
     for k, d in out.items():
-        f.write("\"%s\",%d,%.0f,%.0f,%.3f,%.3f\n" % (k, d["n"], d["FETCH_SIZE"], d["WRITE_SIZE"], 2 * d["FETCH_SIZE"] * 1024 / 1e9, d["WRITE_SIZE"] * 1024 / 1e9))
+        name, n = k.rsplit("#", 1)
+        f.write("\"%s\",%s,%.0f,%.0f,%.3f,%.3f\n" % (name, n, d["FETCH_SIZE"], d["WRITE_SIZE"], 2 * d["FETCH_SIZE"] * 1024 / 1e9, d["WRITE_SIZE"] * 1024 / 1e9))
 print(open("gpurun_out/pmc_summary.csv").read())
 PY
