@@ -179,7 +179,9 @@ def main():
                 import csv
                 gb = 0.0
                 for row in csv.DictReader(open(pmc)):
-                    if row["kernel"].startswith(("mc::k_sk1_extract", "mc::k_sk2_scatter", "mc::k_p3_merge")):
+                    # (the second dispatch of k_sk2_scatter belongs to the BFS set-up, not to the counting pipeline)
+                    if row["kernel"].startswith(("mc::k_sk1_extract", "mc::k_p3_merge")) or (
+                            row["kernel"].startswith("mc::k_sk2_scatter") and row["dispatch"] == "1"):
                         gb += float(row["fetch_GB_corrected_x2"]) + float(row["write_GB"])
                 traffic = round(gb * 1e9)
             roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
