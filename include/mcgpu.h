@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MC_ABI_VERSION 4
+#define MC_ABI_VERSION 5
 
 /* error codes */
 #define MC_OK 0
@@ -96,6 +96,13 @@ int mc_set_stream(mc_ctx *ctx, void *hip_stream);
 int mc_add_reads_packed(mc_ctx *ctx, const uint64_t *words, const uint64_t *read_offsets, uint64_t n_reads);
 int mc_add_reads_packed_dev(mc_ctx *ctx, const uint64_t *d_words, const uint64_t *d_read_offsets,
                             uint64_t n_reads, uint64_t n_bases);
+
+/* One input file of --reads: ReadsWorker.run / ReadersUtils.readDnaLazyTrunc (src/io/ReadsWorker.java:29-41,
+ * itmo!/io/ReadersUtils.java:27-53,104-121): format by extension (.fasta .fa .fn .fna / .fastq .fq, optionally
+ * .gz), FASTA records with N dropped whole, FASTQ reads split where phred < 1 (quality offset sniffed on the
+ * first 1000 records); every read (piece) is counted as by mc_add_reads_packed.  *n_reads (may be NULL) = reads
+ * added ("N reads added").  Errors carry the reference's messages ("Can't detect file format for file ..."). */
+int mc_add_reads_file(mc_ctx *ctx, const char *path, uint64_t *n_reads);
 
 /* End of loadReads (src/io/IOUtils.java:217-248): waits for all queued counting work;
  * *n_distinct = hm.size() ("Hashtable size: N kmers", src/tools/EnvironmentFinderMain.java:137). */

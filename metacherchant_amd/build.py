@@ -14,8 +14,9 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmcgpu.so")
 CLI = os.path.join(LIBDIR, "metacherchant")
 
-HIP_SOURCES = ["mcgpu.hip"]
-HIP_DEPS = ["kmer_device.h", os.path.join(ROOT, "include", "mcgpu.h")]
+HIP_SOURCES = ["mcgpu.hip", os.path.join("host", "envfinder.cpp")]  # (the read-file entry point uses the host reader)
+HIP_DEPS = ["kmer_device.h", "bfs_device.h", "count_pipeline.h", os.path.join("host", "envfinder.h"),
+            os.path.join(ROOT, "include", "mcgpu.h")]
 
 
 def _hipcc():
@@ -39,7 +40,7 @@ def build_lib(force=False, verbose=False):
     if not force and not _stale(LIB, deps):
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra",
-           "-I", os.path.join(ROOT, "include"), "-o", LIB] + srcs
+           "-I", os.path.join(ROOT, "include"), "-o", LIB] + srcs + ["-lz"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -57,13 +58,13 @@ def build_host(force=False, verbose=False):
     hdrs = [os.path.join(hdir, "envfinder.h"), os.path.join(ROOT, "include", "mcgpu.h")]
     flags = ["-O2", "-std=c++17", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include")]
     if force or _stale(HOSTTEST, common + hdrs + [os.path.join(hdir, "hosttest.cpp")]):
-        cmd = ["g++"] + flags + ["-o", HOSTTEST, os.path.join(hdir, "hosttest.cpp")] + common
+        cmd = ["g++"] + flags + ["-o", HOSTTEST, os.path.join(hdir, "hosttest.cpp")] + common + ["-lz"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
     if os.path.exists(LIB) and (force or _stale(CLI, common + hdrs + [os.path.join(hdir, "main.cpp"), LIB])):
         cmd = ["g++"] + flags + ["-o", CLI, os.path.join(hdir, "main.cpp")] + common + [
-            "-L", LIBDIR, "-lmcgpu", "-Wl,-rpath,$ORIGIN", "-lpthread"]
+            "-L", LIBDIR, "-lmcgpu", "-Wl,-rpath,$ORIGIN", "-lpthread", "-lz"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -1,6 +1,8 @@
 // See envfinder.h.  Every function restates the reference lines cited there.
 #include "envfinder.h"
 
+#include <zlib.h>
+
 #include <sys/stat.h>
 
 #include <algorithm>
@@ -277,17 +279,72 @@ static std::string lower(std::string s)
     return s;
 }
 
+// Lines of a text file, plain or gzip (itmo!/io/readers/FastaGZReader.java, FastqGZReader.java: the same
+// readers over a java.util.zip.GZIPInputStream; concatenated gzip members read on, as there).
+namespace {
+class LineSource {
+public:
+    LineSource(const std::string &path, bool gz) : gz_(gz)
+    {
+        if (gz_) {
+            g_ = gzopen(path.c_str(), "rb");
+            if (!g_) throw Error("Failed to read from file " + path);
+            gzbuffer(g_, 1u << 20);
+        } else {
+            f_.open(path, std::ios::binary);
+            if (!f_) throw Error("Failed to read from file " + path);
+        }
+    }
+    ~LineSource() { if (g_) gzclose(g_); }
+    LineSource(const LineSource &) = delete;
+    LineSource &operator=(const LineSource &) = delete;
+    bool getline(std::string &l)
+    {
+        if (!gz_) {
+            if (!std::getline(f_, l)) return false;
+        } else {
+            l.clear();
+            char buf[1 << 16];
+            bool any = false;
+            for (;;) {
+                if (!gzgets(g_, buf, (int)sizeof buf)) {
+                    int err = 0;
+                    (void)gzerror(g_, &err);
+                    if (err != Z_OK && err != Z_STREAM_END) throw Error("Failed to decompress the input (corrupt gzip stream)");
+                    if (!any) return false;
+                    break;
+                }
+                any = true;
+                const size_t n = strlen(buf);
+                l.append(buf, n);
+                if (n && buf[n - 1] == '\n') { l.pop_back(); break; }
+            }
+        }
+        if (!l.empty() && l.back() == '\r') l.pop_back();
+        return true;
+    }
+
+private:
+    bool gz_;
+    gzFile g_ = nullptr;
+    std::ifstream f_;
+};
+}  // namespace
+
 uint64_t load_reads_file(const std::string &path, size_t max_reads, const std::function<void(PackedBatch &)> &sink)
 {
+    // itmo!/io/ReadersUtils.java:27-53 detectFileFormat: a .gz / .bz2 suffix comes off first, then the format
     const size_t slash = path.find_last_of('/');
-    const std::string name = lower(slash == std::string::npos ? path : path.substr(slash + 1));
-    if (ends_with(name, ".gz") || ends_with(name, ".bz2") || ends_with(name, ".binq"))
-        throw Error("Can't read '" + name + "': compressed and BINQ inputs are not supported yet");
+    const std::string full_name = lower(slash == std::string::npos ? path : path.substr(slash + 1));
+    std::string name = full_name;
+    const bool gz = ends_with(name, ".gz");
+    if (gz) name.resize(name.size() - 3);
+    if (ends_with(name, ".bz2") || ends_with(name, ".binq"))
+        throw Error("Can't read '" + full_name + "': bzip2 and BINQ inputs are not supported");
     const bool fastq = ends_with(name, ".fastq") || ends_with(name, ".fq");
     const bool fasta = ends_with(name, ".fasta") || ends_with(name, ".fa") || ends_with(name, ".fn") || ends_with(name, ".fna");
     if (!fastq && !fasta) throw Error("Can't detect file format for file '" + name + "'");
-    std::ifstream f(path, std::ios::binary);
-    if (!f) throw Error("Failed to read from file " + path);
+    LineSource src(path, gz);
 
     PackedBatch batch;
     batch.clear();
@@ -302,11 +359,7 @@ uint64_t load_reads_file(const std::string &path, size_t max_reads, const std::f
         }
     };
     std::string line;
-    auto getline = [&](std::string &l) {
-        if (!std::getline(f, l)) return false;
-        if (!l.empty() && l.back() == '\r') l.pop_back();
-        return true;
-    };
+    auto getline = [&](std::string &l) { return src.getline(l); };
 
     if (fasta) {
         std::string sb;

@@ -256,9 +256,8 @@ int run(const Options &o)
     for (const std::string &path : o.reads) {
         const size_t slash = path.find_last_of('/');
         info("Loading file " + (slash == std::string::npos ? path : path.substr(slash + 1)) + "...");
-        const uint64_t n = load_reads_file(path, 1u << 20, [&](PackedBatch &b) {
-            MC_CHECK(ctx, mc_add_reads_packed(ctx, b.words.data(), b.offsets.data(), b.n_reads()));
-        });
+        uint64_t n = 0;
+        MC_CHECK(ctx, mc_add_reads_file(ctx, path.c_str(), &n));
         info(group_digits(n) + " reads added");
     }
     uint64_t n_distinct = 0;

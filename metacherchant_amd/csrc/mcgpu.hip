@@ -21,6 +21,7 @@
 #include "kmer_device.h"
 #include "bfs_device.h"
 #include "count_pipeline.h"
+#include "host/envfinder.h"
 
 using namespace mc;
 
@@ -1300,6 +1301,30 @@ int mc_add_pairs_dev(mc_ctx *c, const int64_t *d_keys, const int16_t *d_counts, 
     c->finalized = false;
     c->solid_cov = -1;
     return MC_OK;
+}
+
+int mc_add_reads_file(mc_ctx *c, const char *path, uint64_t *n_reads)
+{
+    if (!c) return MC_EINVAL;
+    if (n_reads) *n_reads = 0;
+    if (!path) return fail(c, MC_EINVAL, "mc_add_reads_file: null path");
+    // batches of 2^20 reads: parsed and packed on the host (csrc/host/envfinder.cpp: the reference's readers and
+    // their N / quality policy), counted on the device; the context's lock is taken per batch
+    try {
+        int rc = MC_OK;
+        const uint64_t n = mch::load_reads_file(path, 1u << 20, [&](mch::PackedBatch &b) {
+            if (rc == MC_OK) rc = mc_add_reads_packed(c, b.words.data(), b.offsets.data(), b.n_reads());
+        });
+        if (rc != MC_OK) return rc;
+        if (n_reads) *n_reads = n;
+        return MC_OK;
+    } catch (const mch::Error &e) {
+        std::lock_guard<std::mutex> g(c->mu);
+        return fail(c, MC_EINVAL, "%s", e.what());
+    } catch (const std::bad_alloc &) {
+        std::lock_guard<std::mutex> g(c->mu);
+        return fail(c, MC_ENOMEM, "mc_add_reads_file: out of host memory");
+    }
 }
 
 int mc_finalize_counts(mc_ctx *c, uint64_t *n_distinct)

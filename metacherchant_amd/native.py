@@ -44,7 +44,7 @@ class Stats(C.Structure):
 # every symbol include/mcgpu.h declares; tests check that the library exports all of them
 EXPORTS = [
     "mc_abi_version", "mc_create", "mc_destroy", "mc_clear", "mc_set_coverage_hint", "mc_last_error", "mc_set_stream", "mc_add_reads_packed",
-    "mc_add_reads_packed_dev", "mc_finalize_counts", "mc_get", "mc_get_dev", "mc_kmer_keys", "mc_bfs", "mc_bfs_batch",
+    "mc_add_reads_packed_dev", "mc_add_reads_file", "mc_finalize_counts", "mc_get", "mc_get_dev", "mc_kmer_keys", "mc_bfs", "mc_bfs_batch",
     "mc_bfs_result_free", "mc_export", "mc_export_dev", "mc_add_pairs_dev", "mc_key_owner", "mc_extract_keys_dev",
     "mc_add_keys_dev", "mc_superkmer_capacity", "mc_extract_superkmers_dev", "mc_add_superkmers_dev", "mc_get_stats", "mc_reset_stats", "mc_synth_reads_dev", "mc_synth_genome",
 ]
@@ -84,6 +84,7 @@ def load():
     L.mc_set_coverage_hint.argtypes = [vp, i32]
     L.mc_add_reads_packed.argtypes = [vp, u64p, u64p, u64]
     L.mc_add_reads_packed_dev.argtypes = [vp, vp, vp, u64, u64]
+    L.mc_add_reads_file.argtypes = [vp, C.c_char_p, u64p]
     L.mc_finalize_counts.argtypes = [vp, u64p]
     L.mc_get.argtypes = [vp, i64p, u64, i16p]
     L.mc_get_dev.argtypes = [vp, vp, u64, vp]
@@ -270,6 +271,12 @@ class Context:
         self._chk(self._L.mc_extract_keys_dev(self._h, _dptr(d_words), _dptr(d_offsets), n_reads, n_bases, n_owners,
                                               _dptr(d_keys), _dptr(d_hints), cap, _p(off, C.c_uint64)))
         return off
+
+    def add_reads_file(self, path):
+        """One --reads file (FASTA / FASTQ, optionally .gz) with the reference's reader policies; returns the reads added."""
+        n = C.c_uint64(0)
+        self._chk(self._L.mc_add_reads_file(self._h, os.fsencode(path), C.byref(n)))
+        return int(n.value)
 
     def superkmer_capacity(self, n_windows, n_reads):
         """Records to make room for when a batch of reads is split with extract_superkmers_dev; 0 when this

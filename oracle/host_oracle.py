@@ -156,7 +156,9 @@ def rich_fasta_read(path):
 
 
 def _lines(path):
-    with open(path, "r") as f:
+    # .gz: the same readers over a GZIPInputStream (itmo!/io/readers/FastaGZReader.java, FastqGZReader.java)
+    import gzip
+    with (gzip.open(path, "rt") if path.lower().endswith(".gz") else open(path, "r")) as f:
         for line in f:
             line = line.rstrip("\n")
             if line.endswith("\r"):

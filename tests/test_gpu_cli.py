@@ -34,7 +34,8 @@ def _write_fasta(path, reads, L, names=True, n_every=0):
 def _oracle_run(read_files, k, mode, seqs, comments, out_dir, **kw):
     t = po.Table()
     for p in read_files:
-        reads = ho.read_fastq_reads(p) if p.endswith((".fastq", ".fq")) else ho.read_fasta_reads(p)
+        inner = p[:-3] if p.endswith(".gz") else p
+        reads = ho.read_fastq_reads(p) if inner.endswith((".fastq", ".fq")) else ho.read_fasta_reads(p)
         codes = np.concatenate([po.encode(r) for r in reads])
         off = np.zeros(len(reads) + 1, dtype=np.uint64)
         off[1:] = np.cumsum([len(r) for r in reads])
@@ -57,9 +58,13 @@ def _assert_same_tree(want_results, got_root, want_root):
 def test_cli_config1_both_passes_merge(cli, tmp_path):
     """BASELINE.json configs[0]: 10k x 150 bp, k=31, coverage=5, maxkmers=100000, bothdirs=False."""
     genome, reads, _ = synth_case(1, 50000, 10000, 150, 100)
-    r1, r2 = str(tmp_path / "reads_1.fasta"), str(tmp_path / "reads_2.fa")
+    r1, r2 = str(tmp_path / "reads_1.fasta"), str(tmp_path / "reads_2.fa.gz")
     _write_fasta(r1, reads[:6000 * 150], 150, n_every=50)
-    _write_fasta(r2, reads[6000 * 150:], 150)
+    _write_fasta(r2[:-3], reads[6000 * 150:], 150)
+    import gzip
+    with open(r2[:-3], "rb") as f, open(r2, "wb") as z:  # the second file gzip-compressed (read through zlib)
+        z.write(gzip.compress(f.read()))
+    os.remove(r2[:-3])
     seq = str(tmp_path / "seed.fasta")
     with open(seq, "w") as f:
         f.write(">seed\n%s\n" % po.decode(genome[10000:10500]))

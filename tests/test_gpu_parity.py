@@ -82,6 +82,35 @@ def test_count_saturates_at_32767_and_key_zero(mc, count_path):
     ctx.close()
 
 
+def test_add_reads_file(mc, tmp_path):
+    """mc_add_reads_file: FASTQ.gz through the library's own reader == the oracle reader + oracle table."""
+    import gzip
+    from oracle import host_oracle as ho
+    _, reads, _ = synth_case(1, 20000, 3000, 100, 100)
+    fq = tmp_path / "x.fq.gz"
+    lines = []
+    for i in range(3000):
+        s = po.decode(reads[i * 100:(i + 1) * 100])
+        q = ["I"] * 100
+        if i % 5 == 0:
+            q[37] = "!"
+        lines.append("@r%d\n%s\n+\n%s\n" % (i, s, "".join(q)))
+    fq.write_bytes(gzip.compress("".join(lines).encode()))
+    want_reads = ho.read_fastq_reads(str(fq))
+    codes = np.concatenate([po.encode(r) for r in want_reads])
+    off = np.zeros(len(want_reads) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(r) for r in want_reads])
+    t, _ = oracle_table(codes, off, 27, po.KEY_PACKED)
+    ctx = mc.Context(27, mc.KEY_PACKED, 0, 0)
+    assert ctx.add_reads_file(str(fq)) == len(want_reads) == 3600
+    _assert_tables_equal(ctx, ctx.finalize(), t)
+    with pytest.raises(mc.native.McError, match="Can't detect file format"):
+        ctx.add_reads_file(str(tmp_path / "reads.txt"))
+    with pytest.raises(mc.native.McError, match="Failed to read from file"):
+        ctx.add_reads_file(str(tmp_path / "missing.fasta"))
+    ctx.close()
+
+
 def test_empty_input_and_state_errors(mc):
     ctx = mc.Context(31, mc.KEY_PACKED, 0, 0)
     with pytest.raises(mc.McError):

@@ -129,6 +129,19 @@ def test_read_ingest_policies(hosttest, tmp_path):
     # all qualities >= '@' in the first 1000 records: read as Illumina+64, '@' = phred 0
     fq2.write_text("@a\nACGTAC\n+\nhhh@hh\n")
     assert run(str(fq2)) == ho.read_fastq_reads(str(fq2)) == ["ACG", "AC"]
+    # gzip: format by the inner extension, same policies on the decompressed text (two members, no final newline)
+    import gzip
+    fqz = tmp_path / "R.FQ.gz"
+    with open(fqz, "wb") as f:
+        f.write(gzip.compress(fq.read_bytes()))
+        f.write(gzip.compress(b"@e\nGGCC\n+\nIIII"))
+    assert run(str(fqz)) == ho.read_fastq_reads(str(fqz)) == ["ACGT", "CGTAC", "ACG", "ACG", "GATTAC", "GGCC"]
+    faz = tmp_path / "r.fna.gz"
+    faz.write_bytes(gzip.compress(fa.read_bytes()))
+    assert run(str(faz)) == ho.read_fasta_reads(str(faz)) == ["ACGTACGTACGT", "ACGTTTGA", "GGGG"]
+    for unsupported in ("r.fasta.bz2", "r.binq", "r.txt.gz"):
+        (tmp_path / unsupported).write_bytes(b"x")
+        assert subprocess.call([hosttest, "reads", str(tmp_path / unsupported)], stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL) == 1
     bad = tmp_path / "r.txt"
     bad.write_text(">x\nACGT\n")
     assert subprocess.call([hosttest, "reads", str(bad)], stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL) == 1
