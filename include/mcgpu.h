@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MC_ABI_VERSION 5
+#define MC_ABI_VERSION 6
 
 /* error codes */
 #define MC_OK 0
@@ -206,6 +206,18 @@ int mc_extract_superkmers_dev(mc_ctx *ctx, const uint64_t *d_words, const uint64
                               uint64_t n_bases, uint32_t n_owners, uint64_t *d_records, uint32_t *d_bins,
                               uint64_t records_cap, uint64_t *owner_offsets);
 int mc_add_superkmers_dev(mc_ctx *ctx, const uint64_t *d_records, const uint32_t *d_bins, uint64_t n);
+
+/* ---- the table as a file: `kmer-counter`'s <name>.kmers.bin and <name>.stat.txt (src/tools/KmersCounter.java:87-121).
+ * mc_save_kmers = IOUtils.printKmers (src/io/IOUtils.java:39-65): one 10-byte record per key with count >
+ * threshold -- big-endian int64 key, big-endian int16 count (saturated) -- in table order (the reference's order
+ * is its map's iteration order; nothing reads it), and the frequency histogram of ALL keys
+ * ("# k-mer frequency<TAB>number of such k-mers", ascending, a blank line at the end); stat_path may be NULL.
+ * Call after mc_finalize_counts.  *n_total = keys in the table, *n_written = records written.
+ * mc_load_kmers = IOUtils.loadKmers (:94-126, src/io/KmersLoadWorker.java:9-23): addAndBound(key, count) for
+ * every record with count > freq_threshold; *n_records = records read, *n_added = records added. */
+int mc_save_kmers(mc_ctx *ctx, const char *bin_path, const char *stat_path, int threshold, uint64_t *n_total,
+                  uint64_t *n_written);
+int mc_load_kmers(mc_ctx *ctx, const char *path, int freq_threshold, uint64_t *n_records, uint64_t *n_added);
 
 /* ---- measurement */
 typedef struct {

@@ -59,7 +59,7 @@ std::string shorten_label(const std::string &label, int k)  // src/utils/StringU
 struct Options {
     int k = -1;
     std::vector<std::string> reads;
-    std::string seq, hicseq, output, work_dir = "workDir", hash = "poly", tool = "environment-finder";
+    std::string seq, hicseq, output, output_dir, work_dir = "workDir", hash = "poly", tool = "environment-finder";
     long long maxkmers = -1, maxradius = -1;
     int coverage = 1, chunklength = 1, device = 0;
     bool bothdirs = false, forcehash = false, trim = false, merge = false, cont = false, force = false, help = false;
@@ -73,7 +73,7 @@ const OptSpec SPECS[] = {
     {"chunklength", nullptr, 0}, {"forcehash", nullptr, 1}, {"hash", nullptr, 0}, {"trim", nullptr, 1},
     {"merge", nullptr, 1}, {"work-dir", "w", 0}, {"available-processors", "p", 0}, {"memory", "m", 0},
     {"continue", "c", 1}, {"force", nullptr, 1}, {"verbose", "v", 1}, {"help", "h", 1}, {"tool", "t", 0},
-    {"device", nullptr, 0}, {"capacity-hint", nullptr, 0},
+    {"device", nullptr, 0}, {"capacity-hint", nullptr, 0}, {"output-dir", nullptr, 0},
 };
 
 const OptSpec *find_spec(const std::string &tok)
@@ -156,6 +156,7 @@ Options parse_args(int argc, char **argv)
     if (auto v = val("hash")) o.hash = *v;
     if (auto v = val("work-dir")) o.work_dir = *v;
     if (auto v = val("tool")) o.tool = *v;
+    if (auto v = val("output-dir")) o.output_dir = *v;
     if (auto v = val("device")) o.device = (int)parse_int("device", *v);
     if (auto v = val("capacity-hint")) o.capacity_hint = (unsigned long long)parse_int("capacity-hint", *v);
     return o;
@@ -180,6 +181,7 @@ void usage()
     puts("      --hash <arg>         hash function to use: poly or fnv1a (default poly)");
     puts("      --trim [<arg>]       trim all not maximal paths? (default false)");
     puts("      --merge [<arg>]      draw single environment for multiple input sequences? (default false)");
+    puts("Input parameters of --tool kmer-counter: -k, -i/--reads, --hash, --output-dir <dir> (default <work-dir>/kmers)");
     puts("Launch options: -w/--work-dir <dir> (default workDir), -c/--continue, --force, -v/--verbose, -h/--help,");
     puts("                -t/--tool <name>, -p/--available-processors <n> and -m/--memory <arg> (accepted, unused),");
     puts("                --device <n> (GPU ordinal), --capacity-hint <distinct k-mers>");
@@ -199,18 +201,10 @@ struct CtxGuard {
 // buildEnvironment (src/algo/OneSequenceCalculator.java:137-144): the passes of one calculator
 std::vector<int> pass_dirs(bool bothdirs) { return bothdirs ? std::vector<int>{0} : std::vector<int>{-1, 1}; }
 
-int run(const Options &o)
+// work dir: log files, in.properties / SUCCESS (itmo!/utils/tool/Tool.java:31-33,318-392,666-689).
+// Returns false when --continue finds the tool finished already.
+bool open_work_dir(const Options &o, const std::string &props)
 {
-    if (o.tool != "environment-finder")
-        throw Error("Tool '" + o.tool + "' is not part of this build: only --tool environment-finder runs on the GPU path");
-    if (o.k < 0) throw Error("Parameter 'k' is mandatory");
-    if (o.seq.empty()) throw Error("Parameter 'seq' is mandatory");
-    if (o.output.empty()) throw Error("Parameter 'output' is mandatory");
-    if (o.maxkmers < 0 && o.maxradius < 0)  // EnvironmentFinderMain.java:171-175
-        throw Error("At least one of --maxkmers and --maxradius parameters should be set");
-    if (o.coverage < 0) throw Error("--coverage must not be negative (absent k-mers read as -1 and would pass)");
-
-    // work dir: log files, in.properties / SUCCESS (itmo!/utils/tool/Tool.java:31-33,318-392,666-689)
     const std::string wd = o.work_dir;
     write_file(wd + "/logs/.keep", "");
     char ts[32];
@@ -222,15 +216,106 @@ int run(const Options &o)
     if (stat((wd + "/in.properties").c_str(), &st) == 0 && !o.force && !o.cont)
         logline("WARN", "Work directory " + wd + " holds a previous run; overwriting (the reference would prompt; pass --force to silence)");
     if (o.cont && stat((wd + "/SUCCESS").c_str(), &st) == 0) {
-        info("Tool environment-finder already finished in " + wd + " (--continue), nothing to do");
-        return 0;
+        info("Tool " + o.tool + " already finished in " + wd + " (--continue), nothing to do");
+        return false;
     }
     remove((wd + "/SUCCESS").c_str());
-    {
-        std::string p = "k=" + std::to_string(o.k) + "\nseq=" + o.seq + "\noutput=" + o.output + "\ncoverage=" +
-                        std::to_string(o.coverage) + "\nbothdirs=" + (o.bothdirs ? "true" : "false") + "\n";
-        write_file(wd + "/in.properties", p);
+    write_file(wd + "/in.properties", props);
+    return true;
+}
+
+// the reads of all --reads files into the table; returns hm.size()
+uint64_t load_reads(const Options &o, mc_ctx *ctx)
+{
+    for (const std::string &path : o.reads) {
+        const size_t slash = path.find_last_of('/');
+        info("Loading file " + (slash == std::string::npos ? path : path.substr(slash + 1)) + "...");
+        uint64_t n = 0;
+        MC_CHECK(ctx, mc_add_reads_file(ctx, path.c_str(), &n));
+        info(group_digits(n) + " reads added");
     }
+    uint64_t n_distinct = 0;
+    MC_CHECK(ctx, mc_finalize_counts(ctx, &n_distinct));
+    info("Hashtable size: " + std::to_string(n_distinct) + " kmers");
+    return n_distinct;
+}
+
+// --tool kmer-counter (src/tools/KmersCounter.java:56-121): count, then <name>.kmers.bin + <name>.stat.txt
+int run_kmer_counter(const Options &o)
+{
+    if (o.k < 0) throw Error("Parameter 'k' is mandatory");
+    if (o.reads.empty()) throw Error("Parameter 'reads' is mandatory");
+    if (!open_work_dir(o, "k=" + std::to_string(o.k) + "\n")) return 0;
+    const std::string out_dir = o.output_dir.empty() ? o.work_dir + "/kmers" : o.output_dir;
+    int mode = MC_KEY_PACKED;
+    if (o.k > 31) {  // (no --forcehash here: KmersCounter.java:59-69)
+        info("Reading hashes of k-mers instead");
+        std::string h = o.hash;
+        for (char &c : h) c = (char)tolower((unsigned char)c);
+        if (h == "fnv1a") { info("Using FNV1a hash function"); mode = MC_KEY_FNV1A; }
+        else { info("Using default polynomial hash function"); mode = MC_KEY_POLY; }
+    }
+    mc_config cfg{};
+    cfg.k = o.k;
+    cfg.key_mode = mode;
+    cfg.device = o.device;
+    cfg.capacity_hint = o.capacity_hint;
+    CtxGuard G;
+    if (mc_create(&cfg, &G.c) != MC_OK) throw Error(std::string(mc_last_error(nullptr)));
+    mc_ctx *ctx = G.c;
+    const uint64_t size = load_reads(o, ctx);
+    // ReadersUtils.readDnaLazy(file).name(): the first file's name without its format extension
+    std::string name = o.reads[0];
+    const size_t slash = name.find_last_of('/');
+    if (slash != std::string::npos) name = name.substr(slash + 1);
+    {
+        std::string low = name;
+        for (char &c : low) c = (char)tolower((unsigned char)c);
+        for (const char *ext : {".fasta.gz", ".fa.gz", ".fn.gz", ".fna.gz", ".fastq.gz", ".fq.gz", ".fasta", ".fa", ".fn", ".fna", ".fastq", ".fq"}) {
+            const size_t n = strlen(ext);
+            if (low.size() >= n && low.compare(low.size() - n, n, ext) == 0) { name.resize(name.size() - n); break; }
+        }
+    }
+    const std::string bin = out_dir + "/" + name + ".kmers.bin", st = out_dir + "/" + name + ".stat.txt";
+    write_file(out_dir + "/.keep", "");
+    remove((out_dir + "/.keep").c_str());
+    logline("DEBUG", "Starting to print k-mers to " + bin);
+    uint64_t total = 0, good = 0;
+    MC_CHECK(ctx, mc_save_kmers(ctx, bin.c_str(), st.c_str(), 0, &total, &good));
+    char pct[32];
+    if (size) snprintf(pct, sizeof pct, "%.1f", good * 100.0 / (double)size);
+    else snprintf(pct, sizeof pct, "NaN");  // (Java's String.format of 0.0 / 0)
+    info(group_digits(size) + " k-mers found, " + group_digits(good) + " (" + pct + "%) of them is good (not erroneous)");
+    if (size == 0) logline("WARN", "No k-mers found in reads! Perhaps you reads file is empty or k-mer size is too big");
+    else if (good == 0 || good < (uint64_t)((double)size * 0.03))
+        logline("WARN", "Too few good k-mers were found! Perhaps you should decrease k-mer size or --maximal-bad-frequency value");
+    if (o.k <= 31) {
+        const uint64_t all = (1ull << (2 * o.k)) / 2;  // (4^k)/2
+        if (size == all) logline("WARN", "All possible k-mers were found in reads! Perhaps you should increase k-mer size");
+        else if (size >= (uint64_t)((double)all * 0.99))
+            logline("WARN", "Almost all possible k-mers were found in reads! Perhaps you should increase k-mer size");
+    }
+    info("k-mers printed to " + bin);
+    write_file(o.work_dir + "/SUCCESS", "");
+    return 0;
+}
+
+int run(const Options &o)
+{
+    if (o.tool == "kmer-counter") return run_kmer_counter(o);
+    if (o.tool != "environment-finder")
+        throw Error("Tool '" + o.tool + "' is not part of this build: only --tool environment-finder and --tool kmer-counter run on the GPU path");
+    if (o.k < 0) throw Error("Parameter 'k' is mandatory");
+    if (o.seq.empty()) throw Error("Parameter 'seq' is mandatory");
+    if (o.output.empty()) throw Error("Parameter 'output' is mandatory");
+    if (o.maxkmers < 0 && o.maxradius < 0)  // EnvironmentFinderMain.java:171-175
+        throw Error("At least one of --maxkmers and --maxradius parameters should be set");
+    if (o.coverage < 0) throw Error("--coverage must not be negative (absent k-mers read as -1 and would pass)");
+
+    const std::string wd = o.work_dir;
+    if (!open_work_dir(o, "k=" + std::to_string(o.k) + "\nseq=" + o.seq + "\noutput=" + o.output + "\ncoverage=" +
+                              std::to_string(o.coverage) + "\nbothdirs=" + (o.bothdirs ? "true" : "false") + "\n"))
+        return 0;
 
     // loadInput (EnvironmentFinderMain.java:127-154)
     const bool hashed = o.k > 31 || o.forcehash;
@@ -253,16 +338,7 @@ int run(const Options &o)
     MC_CHECK(ctx, mc_set_coverage_hint(ctx, o.coverage));
 
     const auto t0 = std::chrono::steady_clock::now();
-    for (const std::string &path : o.reads) {
-        const size_t slash = path.find_last_of('/');
-        info("Loading file " + (slash == std::string::npos ? path : path.substr(slash + 1)) + "...");
-        uint64_t n = 0;
-        MC_CHECK(ctx, mc_add_reads_file(ctx, path.c_str(), &n));
-        info(group_digits(n) + " reads added");
-    }
-    uint64_t n_distinct = 0;
-    MC_CHECK(ctx, mc_finalize_counts(ctx, &n_distinct));
-    info("Hashtable size: " + std::to_string(n_distinct) + " kmers");
+    const uint64_t n_distinct = load_reads(o, ctx);
     logline("DEBUG", "k-mers HM size = " + group_digits(n_distinct));
     const auto t1 = std::chrono::steady_clock::now();
 

@@ -1591,6 +1591,115 @@ int mc_export(mc_ctx *c, int min_cov, int64_t *keys, int16_t *counts, uint64_t c
     return MC_OK;
 }
 
+// ---- .kmers.bin (src/io/IOUtils.java:39-65 printKmers, :94-126 loadKmers, src/io/KmersLoadWorker.java:9-23)
+
+int mc_save_kmers(mc_ctx *c, const char *bin_path, const char *stat_path, int threshold, uint64_t *n_total, uint64_t *n_written)
+{
+    if (!c) return MC_EINVAL;
+    if (n_total) *n_total = 0;
+    if (n_written) *n_written = 0;
+    if (!bin_path) return fail(c, MC_EINVAL, "mc_save_kmers: null path");
+    uint64_t n = 0;
+    int rc = mc_export(c, 0, nullptr, nullptr, 0, &n);
+    if (rc) return rc;
+    std::vector<int64_t> keys(std::max<uint64_t>(n, 1));
+    std::vector<int16_t> counts(std::max<uint64_t>(n, 1));
+    if (n) {
+        rc = mc_export(c, 0, keys.data(), counts.data(), n, &n);
+        if (rc) return rc;
+    }
+    FILE *f = fopen(bin_path, "wb");
+    if (!f) return fail(c, MC_EINVAL, "mc_save_kmers: cannot write %s", bin_path);
+    std::vector<unsigned char> buf;
+    buf.reserve(10u << 20);
+    std::vector<uint64_t> hist(32768, 0);  // QuickQuantitativeStatistics<Short>: frequency -> number of such k-mers
+    uint64_t good = 0;
+    bool io_ok = true;
+    for (uint64_t i = 0; i < n; i++) {
+        const int16_t v = counts[i];
+        hist[(size_t)v]++;
+        if (v > threshold) {  // DataOutputStream.writeLong / writeShort: big-endian
+            const uint64_t kk = (uint64_t)keys[i];
+            for (int b = 7; b >= 0; b--) buf.push_back((unsigned char)(kk >> (8 * b)));
+            buf.push_back((unsigned char)((uint16_t)v >> 8));
+            buf.push_back((unsigned char)((uint16_t)v & 0xFF));
+            good++;
+            if (buf.size() >= (10u << 20)) { io_ok = io_ok && fwrite(buf.data(), 1, buf.size(), f) == buf.size(); buf.clear(); }
+        }
+    }
+    if (!buf.empty()) io_ok = io_ok && fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+    io_ok = (fclose(f) == 0) && io_ok;
+    if (!io_ok) return fail(c, MC_EINVAL, "mc_save_kmers: error writing %s", bin_path);
+    if (stat_path) {
+        FILE *sf = fopen(stat_path, "w");
+        if (!sf) return fail(c, MC_EINVAL, "mc_save_kmers: cannot write %s", stat_path);
+        fputs("# k-mer frequency\tnumber of such k-mers\n", sf);
+        for (size_t v = 0; v < hist.size(); v++)
+            if (hist[v]) fprintf(sf, "%zu\t%llu\n", v, (unsigned long long)hist[v]);
+        fputs("\n", sf);  // (println of a string that already ends with a newline)
+        if (fclose(sf) != 0) return fail(c, MC_EINVAL, "mc_save_kmers: error writing %s", stat_path);
+    }
+    if (n_total) *n_total = n;
+    if (n_written) *n_written = good;
+    return MC_OK;
+}
+
+int mc_load_kmers(mc_ctx *c, const char *path, int freq_threshold, uint64_t *n_records, uint64_t *n_added)
+{
+    if (!c) return MC_EINVAL;
+    if (n_records) *n_records = 0;
+    if (n_added) *n_added = 0;
+    if (!path) return fail(c, MC_EINVAL, "mc_load_kmers: null path");
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(c, MC_EINVAL, "Failed to read from file %s", path);
+    const size_t batch = 8u << 20;  // records per upload
+    std::vector<unsigned char> raw(batch * 10);
+    std::vector<int64_t> keys(batch);
+    std::vector<int16_t> counts(batch);
+    DevBuf<int64_t> dk;
+    DevBuf<int16_t> dc;
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        if (hipSetDevice(c->cfg.device) != hipSuccess || dk.alloc(batch) != hipSuccess || dc.alloc(batch) != hipSuccess) {
+            fclose(f);
+            return fail(c, MC_ENOMEM, "mc_load_kmers: device allocation failed");
+        }
+    }
+    uint64_t total = 0, added = 0;
+    int rc = MC_OK;
+    for (;;) {
+        const size_t got = fread(raw.data(), 1, raw.size(), f);
+        if (got == 0) break;
+        if (got % 10 != 0) { rc = fail(c, MC_EINVAL, "Can't load kmers from file %s: its length is not a multiple of the 10-byte record", path); break; }
+        size_t m = 0;
+        for (size_t i = 0; i < got; i += 10) {
+            uint64_t kk = 0;
+            for (int b = 0; b < 8; b++) kk = (kk << 8) | raw[i + b];
+            const int16_t v = (int16_t)(((uint16_t)raw[i + 8] << 8) | raw[i + 9]);
+            total++;
+            if (v > freq_threshold) { keys[m] = (int64_t)kk; counts[m] = v; m++; }
+        }
+        if (m) {
+            {
+                std::lock_guard<std::mutex> g(c->mu);
+                if (hipMemcpy(dk.p, keys.data(), m * 8, hipMemcpyHostToDevice) != hipSuccess ||
+                    hipMemcpy(dc.p, counts.data(), m * 2, hipMemcpyHostToDevice) != hipSuccess) {
+                    rc = fail(c, MC_EHIP, "mc_load_kmers: upload failed");
+                    break;
+                }
+            }
+            rc = mc_add_pairs_dev(c, dk.p, dc.p, nullptr, m);
+            if (rc) break;
+            added += m;
+        }
+    }
+    fclose(f);
+    if (rc) return rc;
+    if (n_records) *n_records = total;
+    if (n_added) *n_added = added;
+    return MC_OK;
+}
+
 int mc_get_stats(mc_ctx *c, mc_stats *out)
 {
     if (!c || !out) return MC_EINVAL;

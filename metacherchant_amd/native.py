@@ -45,7 +45,7 @@ class Stats(C.Structure):
 EXPORTS = [
     "mc_abi_version", "mc_create", "mc_destroy", "mc_clear", "mc_set_coverage_hint", "mc_last_error", "mc_set_stream", "mc_add_reads_packed",
     "mc_add_reads_packed_dev", "mc_add_reads_file", "mc_finalize_counts", "mc_get", "mc_get_dev", "mc_kmer_keys", "mc_bfs", "mc_bfs_batch",
-    "mc_bfs_result_free", "mc_export", "mc_export_dev", "mc_add_pairs_dev", "mc_key_owner", "mc_extract_keys_dev",
+    "mc_bfs_result_free", "mc_export", "mc_export_dev", "mc_add_pairs_dev", "mc_save_kmers", "mc_load_kmers", "mc_key_owner", "mc_extract_keys_dev",
     "mc_add_keys_dev", "mc_superkmer_capacity", "mc_extract_superkmers_dev", "mc_add_superkmers_dev", "mc_get_stats", "mc_reset_stats", "mc_synth_reads_dev", "mc_synth_genome",
 ]
 
@@ -86,6 +86,8 @@ def load():
     L.mc_add_reads_packed_dev.argtypes = [vp, vp, vp, u64, u64]
     L.mc_add_reads_file.argtypes = [vp, C.c_char_p, u64p]
     L.mc_finalize_counts.argtypes = [vp, u64p]
+    L.mc_save_kmers.argtypes = [vp, C.c_char_p, C.c_char_p, i32, u64p, u64p]
+    L.mc_load_kmers.argtypes = [vp, C.c_char_p, i32, u64p, u64p]
     L.mc_get.argtypes = [vp, i64p, u64, i16p]
     L.mc_get_dev.argtypes = [vp, vp, u64, vp]
     L.mc_kmer_keys.argtypes = [vp, u64p, u64p, u64, i64p]
@@ -277,6 +279,19 @@ class Context:
         n = C.c_uint64(0)
         self._chk(self._L.mc_add_reads_file(self._h, os.fsencode(path), C.byref(n)))
         return int(n.value)
+
+    def save_kmers(self, bin_path, stat_path=None, threshold=0):
+        """<name>.kmers.bin (+ <name>.stat.txt): returns (keys in the table, records written)."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._chk(self._L.mc_save_kmers(self._h, os.fsencode(bin_path), os.fsencode(stat_path) if stat_path else None,
+                                        threshold, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def load_kmers(self, path, freq_threshold=0):
+        """Adds the records of a .kmers.bin file; returns (records read, records added)."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._chk(self._L.mc_load_kmers(self._h, os.fsencode(path), freq_threshold, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def superkmer_capacity(self, n_windows, n_reads):
         """Records to make room for when a batch of reads is split with extract_superkmers_dev; 0 when this

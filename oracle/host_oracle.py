@@ -476,3 +476,37 @@ def environment_finder(table, k, mode, seqs, comments, out_dir, coverage=1, max_
         write_files(files, prefix)
         results[prefix] = files
     return results
+
+
+# ---- --tool kmer-counter (src/tools/KmersCounter.java:87-121, src/io/IOUtils.java:39-65,
+# itmo!/statistics/QuickQuantitativeStatistics.java:37-72)
+
+def library_name(path):
+    """ReadersUtils.readDnaLazy(file).name(): file name without its format extension."""
+    name = os.path.basename(path)
+    low = name.lower()
+    for ext in (".fasta.gz", ".fa.gz", ".fn.gz", ".fna.gz", ".fastq.gz", ".fq.gz", ".fasta", ".fa", ".fn", ".fna", ".fastq", ".fq"):
+        if low.endswith(ext):
+            return name[:len(name) - len(ext)]
+    return name
+
+
+def kmer_counter_files(table, threshold=0):
+    """(records of <name>.kmers.bin as a sorted list of (key, count), text of <name>.stat.txt).
+    Record order in the reference is its map's iteration order (unpinned: fastutil hash), so records
+    are compared as a set; the statistics file is sorted by frequency and must match byte for byte."""
+    keys, counts = table.dump()
+    recs = sorted((int(k), int(c)) for k, c in zip(keys, counts) if c > threshold)
+    hist = {}
+    for c in counts:
+        hist[int(c)] = hist.get(int(c), 0) + 1
+    text = "# k-mer frequency\tnumber of such k-mers\n" + "".join("%d\t%d\n" % (v, hist[v]) for v in sorted(hist)) + "\n"
+    return recs, text
+
+
+def read_kmers_bin(path):
+    """10-byte records: big-endian int64 key, big-endian int16 count (src/io/KmersLoadWorker.java:9-23)."""
+    import struct
+    data = open(path, "rb").read()
+    assert len(data) % 10 == 0
+    return sorted(struct.unpack(">qh", data[i:i + 10]) for i in range(0, len(data), 10))

@@ -155,3 +155,50 @@ def test_cli_error_paths(cli, tmp_path):
     assert p.returncode == 1 and "Could not load Hi-C sequences from " + str(tmp_path / "nohic.fasta") in p.stderr
     p = subprocess.run(base + ["--seq", seq], capture_output=True, text=True)
     assert p.returncode == 1 and "At least one of --maxkmers and --maxradius parameters should be set" in p.stderr
+
+
+@pytest.mark.parametrize("k,mode", [(25, po.KEY_PACKED), (40, po.KEY_POLY)])
+def test_cli_kmer_counter_and_reload(cli, tmp_path, k, mode):
+    """--tool kmer-counter: <name>.stat.txt byte-identical with the oracle, <name>.kmers.bin the same records;
+    a table reloaded from the file (mc_load_kmers) equals the original and walks to the same environment."""
+    import metacherchant_amd as m
+    from tests.helpers import assert_bfs_equal, seed_windows
+    genome, reads, off = synth_case(1, 30000, 4000, 150, 80)
+    fa = str(tmp_path / "Sample_A.fasta")
+    _write_fasta(fa, reads, 150, n_every=40)
+    wd = str(tmp_path / "wd")
+    p = subprocess.run([cli, "-t", "kmer-counter", "-k", str(k), "-i", fa, "-w", wd, "--force"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    t = po.Table()
+    rr = ho.read_fasta_reads(fa)
+    codes = np.concatenate([po.encode(r) for r in rr])
+    roff = np.zeros(len(rr) + 1, dtype=np.uint64)
+    roff[1:] = np.cumsum([len(r) for r in rr])
+    t.count_reads(codes, roff, k, mode)
+    want_recs, want_stat = ho.kmer_counter_files(t)
+    assert ho.library_name(fa) == "Sample_A"
+    bin_path = os.path.join(wd, "kmers", "Sample_A.kmers.bin")
+    assert open(os.path.join(wd, "kmers", "Sample_A.stat.txt")).read() == want_stat
+    assert ho.read_kmers_bin(bin_path) == want_recs
+    assert "Hashtable size: %d kmers" % t.size() in p.stderr
+    assert "k-mers found, " in p.stderr and "(100.0%) of them is good (not erroneous)" in p.stderr
+    assert "k-mers printed to " + bin_path in p.stderr
+    # reload: every record (threshold 0), then only the solid ones
+    ctx = m.Context(k, mode, 0, 0)
+    assert ctx.load_kmers(bin_path) == (len(want_recs), len(want_recs))
+    assert ctx.finalize() == t.size()
+    gk, gc = ctx.export(0)
+    ok, oc = t.dump()
+    assert np.array_equal(gk, ok) and np.array_equal(gc, oc)
+    seed = genome[8000:8200]
+    hi, lo = seed_windows(seed, k)
+    assert_bfs_equal(ctx.bfs(hi, lo, 0, 4, 3000, -1), po.bfs(t, k, mode, [seed], 0, 4, 3000, -1))
+    ctx.close()
+    ctx = m.Context(k, mode, 0, 0)
+    n_rec, n_add = ctx.load_kmers(bin_path, 3)
+    assert n_rec == len(want_recs) and n_add == sum(1 for _, c in want_recs if c > 3) == ctx.finalize()
+    bad = tmp_path / "bad.kmers.bin"
+    bad.write_bytes(b"123456789012345")
+    with pytest.raises(m.native.McError, match="multiple of the 10-byte record"):
+        ctx.load_kmers(str(bad))
+    ctx.close()
