@@ -10,7 +10,9 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <cmath>
 #include <functional>
+#include <limits>
 #include <set>
 #include <sstream>
 
@@ -138,6 +140,14 @@ int JavaHashMap::get(const std::string &key) const
     auto it = index_.find(key);
     if (it == index_.end()) throw Error("JavaHashMap::get: missing key " + key);
     return entries_[it->second].value;
+}
+
+bool JavaHashMap::find(const std::string &key, int *value) const
+{
+    auto it = index_.find(key);
+    if (it == index_.end()) return false;
+    *value = entries_[it->second].value;
+    return true;
 }
 
 void JavaHashMap::remove(const std::string &key)
@@ -637,6 +647,256 @@ void Environment::write_all(const std::string &out_prefix, int chunk_length)
     write_file(out_prefix + "/graph.gfa", graph_gfa());
     write_file(out_prefix + "/tsvs/edges.tsv", tsv_edges());
     write_file(out_prefix + "/tsvs/nodes.tsv", tsv_nodes());
+}
+
+// ------------------------------------------------------------------------------------------ environment-finder-multi
+
+std::string java_format_6_2f(float x)
+{
+    std::string body;
+    if (x != x) {
+        body = "NaN";
+    } else if (x == std::numeric_limits<float>::infinity() || x == -std::numeric_limits<float>::infinity()) {
+        body = x > 0 ? "Infinity" : "-Infinity";
+    } else {
+        // the exact decimal value of the float, rounded HALF_UP to two places
+        char buf[512];
+        snprintf(buf, sizeof buf, "%.160f", (double)(x < 0 ? -x : x));
+        std::string d = buf;
+        const size_t dot = d.find('.');
+        std::string ip = d.substr(0, dot), fp = d.substr(dot + 1);
+        bool up = fp[2] >= '5';
+        std::string digits = ip + fp.substr(0, 2);
+        if (up) {
+            int i = (int)digits.size() - 1;
+            while (i >= 0 && digits[(size_t)i] == '9') digits[(size_t)i--] = '0';
+            if (i >= 0) digits[(size_t)i]++; else digits.insert(digits.begin(), '1');
+        }
+        body = digits.substr(0, digits.size() - 2) + "." + digits.substr(digits.size() - 2);
+        if (std::signbit(x)) body = "-" + body;  // (Java prints -0.00 for negative values that round to zero)
+    }
+    if (body.size() < 6) body.insert(0, 6 - body.size(), ' ');
+    return body;
+}
+
+namespace {
+// DeBruijnGraphUtils.loadGraph (:13-27)
+JavaHashMap load_graph(const std::string &path)
+{
+    std::vector<std::string> lines;
+    if (!read_lines(path, &lines)) throw Error("Couldn't load graph from file " + path);
+    JavaHashMap g;
+    for (const std::string &line : lines) {
+        if (line.empty()) continue;
+        const size_t sp = line.find(' ');
+        if (sp == std::string::npos || sp + 1 >= line.size()) throw Error("Couldn't load graph from file " + path + ": bad line '" + line + "'");
+        size_t end = line.find(' ', sp + 1);
+        const std::string num = line.substr(sp + 1, end == std::string::npos ? std::string::npos : end - sp - 1);
+        char *stop = nullptr;
+        const long v = strtol(num.c_str(), &stop, 10);
+        if (num.empty() || *stop) throw Error("Couldn't load graph from file " + path + ": bad depth '" + num + "'");
+        g.put(line.substr(0, sp), (int)v);
+    }
+    return g;
+}
+
+struct MultiNode {  // src/algo/MultiNode.java:9-29 (rc and neighbours as indices into the node array)
+    std::string sequence;
+    int id;
+    bool is_gene, deleted = false;
+    int rc;
+    std::vector<int> neighbors;
+    std::set<int> graphs;
+};
+}  // namespace
+
+MultiResult environment_finder_multi(const std::vector<std::string> &env_paths, const std::string &seq_path, int gene_id)
+{
+    MultiResult R;
+    std::vector<JavaHashMap> graphs;
+    for (const std::string &p : env_paths) graphs.push_back(load_graph(p));
+    if (graphs.empty()) throw Error("Zero environments given");
+    if (graphs.size() > 256) R.log.push_back("WARN Found more than 256 environments. Grayscale graph may be not accurate.");
+    int k = -1;
+    graphs[0].for_each([&](const std::string &kmer, int) { if (k < 0) k = (int)kmer.size(); });
+    if (k < 0) throw Error("The first environment is empty");  // (the reference fails with NoSuchElementException)
+    for (const JavaHashMap &g : graphs)
+        g.for_each([&](const std::string &kmer, int) {
+            if ((int)kmer.size() != k)
+                throw Error("K-mers of different lengths encountered: " + std::to_string(k) + " and " + std::to_string(kmer.size()));
+        });
+    SeedFile sf;
+    try {
+        sf = read_seed_fasta(seq_path);
+    } catch (const Error &) {
+        throw Error("Could not load sequence file");
+    }
+    if (gene_id < 1 || (size_t)gene_id > sf.dnas.size() || (size_t)gene_id > sf.comments.size())
+        throw Error("--geneid " + std::to_string(gene_id) + " is outside the sequences of " + seq_path);
+    const std::string sequence = sf.dnas[(size_t)gene_id - 1], comment = sf.comments[(size_t)gene_id - 1];
+    R.log.push_back("INFO Combining environments for sequence " +
+                    ((int)sequence.size() >= 2 * k ? sequence.substr(0, (size_t)k) + "..." + sequence.substr(sequence.size() - (size_t)k) +
+                                                         " (length=" + std::to_string(sequence.size()) + ")"
+                                                   : sequence));
+
+    // initializeStructures (MultiSequenceCalculator.java:51-100)
+    JavaHashMap by_kmer;  // value: node index, -1 = null
+    for (const JavaHashMap &g : graphs)
+        g.for_each([&](const std::string &kmer, int) {
+            by_kmer.put(kmer, -1);
+            by_kmer.put(reverse_complement(kmer), -1);
+        });
+    const size_t size = by_kmer.size();
+    std::vector<MultiNode> nodes;
+    nodes.reserve(size);
+    {
+        std::vector<std::string> order;
+        by_kmer.for_each([&](const std::string &kmer, int) { order.push_back(kmer); });
+        for (const std::string &kmer : order) {
+            const std::string rc = reverse_complement(kmer);
+            if (kmer.compare(rc) > 0) continue;
+            if (nodes.size() + 2 > size)
+                throw Error("palindromic k-mer " + kmer + ": the reference fails here (ArrayIndexOutOfBoundsException)");
+            const bool is_gene = sequence.find(kmer) != std::string::npos || sequence.find(rc) != std::string::npos;
+            const int a = (int)nodes.size();
+            MultiNode na, nb;
+            na.sequence = kmer; na.id = a; na.is_gene = is_gene; na.rc = a + 1;
+            nb.sequence = rc; nb.id = a + 1; nb.is_gene = is_gene; nb.rc = a;
+            nodes.push_back(na);
+            nodes.push_back(nb);
+            by_kmer.put(kmer, a);
+            by_kmer.put(rc, a + 1);
+        }
+    }
+    for (size_t i = 0; i < graphs.size(); i++)
+        graphs[i].for_each([&](const std::string &kmer, int) {
+            const int n = by_kmer.get(kmer);
+            nodes[(size_t)n].graphs.insert((int)i);
+            nodes[(size_t)nodes[(size_t)n].rc].graphs.insert((int)i);
+        });
+    for (size_t i = 0; i < nodes.size(); i++)
+        for (const char c : {'A', 'G', 'C', 'T'}) {
+            int nb;
+            if (by_kmer.find(nodes[i].sequence.substr(1) + c, &nb) && nb >= 0) nodes[(size_t)nodes[i].rc].neighbors.push_back(nb);
+        }
+
+    // doMerge (:102-139)
+    auto merge_labels = [&](const std::string &a, const std::string &b) {
+        if (a.substr(a.size() - (size_t)(k - 1)) != b.substr(0, (size_t)(k - 1)))
+            throw Error("Labels should be merged, but can not: " + a + " and " + b);
+        return a + b.substr((size_t)(k - 1));
+    };
+    for (;;) {
+        bool acted = false;
+        for (size_t i = 0; i < nodes.size(); i++) {
+            if (nodes[i].deleted || nodes[i].neighbors.size() != 1) continue;
+            const size_t o = (size_t)nodes[i].neighbors[0];
+            if (nodes[o].neighbors.size() != 1 || nodes[i].is_gene != nodes[o].is_gene || nodes[i].graphs != nodes[o].graphs) continue;
+            const size_t first_minus = (size_t)nodes[i].rc, second_plus = (size_t)nodes[o].rc;
+            const std::string new_seq = merge_labels(nodes[second_plus].sequence, nodes[i].sequence);
+            const std::string new_rc = merge_labels(nodes[first_minus].sequence, nodes[o].sequence);
+            nodes[second_plus].sequence = new_seq;
+            nodes[first_minus].sequence = new_rc;
+            nodes[second_plus].rc = (int)first_minus;
+            nodes[first_minus].rc = (int)second_plus;
+            nodes[i].deleted = nodes[o].deleted = true;
+            acted = true;
+        }
+        if (!acted) break;
+    }
+    auto min_id = [&](const MultiNode &n) { return std::min(n.id, nodes[(size_t)n.rc].id) + 1; };
+    auto label = [&](const MultiNode &n) { return std::to_string(min_id(n)) + (n.is_gene ? "_start" : ""); };
+
+    // outputNodeSequences (:141-160)
+    for (const MultiNode &n : nodes) {
+        const MultiNode &rc = nodes[(size_t)n.rc];
+        if (n.deleted || !(n.id < rc.id)) continue;
+        std::set<int> ids;
+        for (int j : n.neighbors) ids.insert(min_id(nodes[(size_t)j]));
+        for (int j : rc.neighbors) ids.insert(min_id(nodes[(size_t)j]));
+        ids.erase(min_id(n));
+        R.seqs_fasta += "> Id" + label(n) + " Length:" + std::to_string(n.sequence.size()) + " Neighbors:[";
+        bool first = true;
+        for (int x : ids) {
+            if (!first) R.seqs_fasta += ", ";
+            R.seqs_fasta += std::to_string(x);
+            first = false;
+        }
+        R.seqs_fasta += "]\n" + n.sequence + "\n";
+    }
+
+    // GFAWriterMulti (:37-146)
+    const size_t G = graphs.size();
+    auto color = [&](const MultiNode &n) -> std::string {
+        if (n.is_gene) return "#00ff00";
+        const size_t s = n.graphs.size();
+        if (G == 2) return s == 1 ? "#ff0000" : s == 2 ? "#0000ff" : "#000000";
+        if (G == 3) {
+            static const char *c3[] = {"#000000", "#ff0000", "#0000ff", "#ff00ff", "#ffff00", "#ffaa00", "#00ffff"};
+            return s <= 6 ? c3[s] : "#000000";
+        }
+        const int v = (int)(256 * s / G);
+        char buf[32];
+        snprintf(buf, sizeof buf, "#%02X%02X%02X", v, v, v);
+        return buf;
+    };
+    for (const MultiNode &n : nodes) {
+        if (n.deleted || !(n.id < nodes[(size_t)n.rc].id)) continue;
+        long long coverage = 0;
+        for (const JavaHashMap &g : graphs)
+            for (size_t i = 0; i + (size_t)k <= n.sequence.size(); i++) {
+                int c;
+                if (g.find(normalize_dna(n.sequence.substr(i, (size_t)k)), &c)) coverage += c;
+            }
+        const std::string col = color(n);
+        R.graph_gfa += "S\t" + label(n) + "\t" + n.sequence + "\tLN:i:" + std::to_string(n.sequence.size()) + "\tKC:i:" +
+                       std::to_string(coverage) + "\tCL:Z:" + col + "\tC2:Z:" + col + "\n";
+    }
+    for (const MultiNode &a : nodes) {
+        if (a.deleted) continue;
+        for (int j : a.neighbors) {
+            const MultiNode &b = nodes[(size_t)j];
+            R.graph_gfa += "L\t" + label(a) + "\t" + (a.id < nodes[(size_t)a.rc].id ? "+" : "-") + "\t" + label(b) + "\t" +
+                           (b.id > nodes[(size_t)b.rc].id ? "+" : "-") + "\t" + std::to_string(k - 1) + "M\n";
+        }
+    }
+    R.gene_fasta = ">" + comment + "\n" + sequence + "\n";
+
+    // printProbability (EnvironmentFinderMultiMain.java:104-170): 32-bit sums (wrapping like Java's int), float division
+    R.jacard_sym = "The[31mWarning! symmetric <<Jaccard distance>> (1 - AB/AUB):\n\n";
+    R.jacard_alt = "The[31mWarning! alternative <<Jaccard distance>> (1 - AB/A):\n\n";
+    for (size_t i = 0; i < G; i++) {
+        R.jacard_sym += env_paths[i];
+        R.jacard_alt += env_paths[i];
+        for (size_t j = 0; j < G; j++) {
+            uint32_t diff = 0, diff_alt = 0, uni = 0;  // (unsigned: wraps like Java's int without undefined behaviour)
+            graphs[i].for_each([&](const std::string &kmer, int v) {
+                int w;
+                if (!graphs[j].find(kmer, &w)) { diff += (uint32_t)v; diff_alt += (uint32_t)v; uni += (uint32_t)v; }
+                else { diff += (uint32_t)std::abs(v - w); diff_alt += (uint32_t)std::abs(v - w); uni += (uint32_t)std::max(v, w); }
+            });
+            graphs[j].for_each([&](const std::string &kmer, int v) {
+                int w;
+                if (!graphs[i].find(kmer, &w)) { diff += (uint32_t)v; uni += (uint32_t)v; }
+            });
+            const int inter = (int)(uni - diff), u = (int)uni, ua = (int)(uni - diff_alt);
+            R.jacard_sym += java_format_6_2f(1.0f - (float)inter / (float)u) + " ";
+            R.jacard_alt += java_format_6_2f(1.0f - (float)inter / (float)ua) + " ";
+        }
+        R.jacard_sym += "\n";
+        R.jacard_alt += "\n";
+    }
+    R.log.push_back("INFO Finished processing!");
+    return R;
+}
+
+void write_multi(const MultiResult &r, const std::string &output_dir)
+{
+    write_file(output_dir + "/seqs.fasta", r.seqs_fasta);
+    write_file(output_dir + "/graph.gfa", r.graph_gfa);
+    write_file(output_dir + "/gene.fasta", r.gene_fasta);
+    write_file(output_dir + "/Jacard_sym.txt", r.jacard_sym);
+    write_file(output_dir + "/Jacard_alt.txt", r.jacard_alt);
 }
 
 }  // namespace mch

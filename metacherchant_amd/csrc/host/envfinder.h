@@ -35,6 +35,7 @@ public:
     void put(const std::string &key, int value);  // new keys go to the tail of their bin; existing keep their place
     bool contains(const std::string &key) const { return index_.count(key) != 0; }
     int get(const std::string &key) const;         // throws if absent
+    bool find(const std::string &key, int *value) const;
     void remove(const std::string &key);
     size_t size() const { return size_; }
     bool treeified() const { return treeified_; }  // a bin would have been treeified: JDK order not guaranteed
@@ -122,5 +123,17 @@ private:
 };
 
 void write_file(const std::string &path, const std::string &text);  // mkdirs + write
+
+// ---- --tool environment-finder-multi: src/tools/EnvironmentFinderMultiMain.java,
+// src/algo/MultiSequenceCalculator.java, src/algo/MultiNode.java, src/io/writers/GFAWriterMulti.java,
+// src/io/graph/DeBruijnGraphUtils.java.  CPU only: joins the graph.txt / env.txt files of several
+// environment-finder runs into one coloured graph and two distance tables.
+struct MultiResult {
+    std::string seqs_fasta, graph_gfa, gene_fasta, jacard_sym, jacard_alt;  // <output>/seqs.fasta, graph.gfa, gene.fasta, Jacard_*.txt
+    std::vector<std::string> log;                                            // "INFO ..." / "WARN ..." lines, in order
+};
+MultiResult environment_finder_multi(const std::vector<std::string> &env_paths, const std::string &seq_path, int gene_id);
+void write_multi(const MultiResult &r, const std::string &output_dir);
+std::string java_format_6_2f(float x);  // String.format("%6.2f", x)
 
 }  // namespace mch

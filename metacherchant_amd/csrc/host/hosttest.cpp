@@ -36,8 +36,18 @@ int main(int argc, char **argv)
             fprintf(stderr, "%llu reads\n", (unsigned long long)n);
             return 0;
         }
+        if (argc == 3 && std::string(argv[1]) == "fmt") {  // String.format("%6.2f", (float) x)
+            fputs(java_format_6_2f(strtof(argv[2], nullptr)).c_str(), stdout);
+            return 0;
+        }
+        if (argc >= 6 && std::string(argv[1]) == "multi") {  // multi <out_dir> <seq.fasta> <gene_id> <env>...
+            const MultiResult r = environment_finder_multi(std::vector<std::string>(argv + 5, argv + argc), argv[3], atoi(argv[4]));
+            write_multi(r, argv[2]);
+            for (const auto &l : r.log) printf("%s\n", l.c_str());
+            return 0;
+        }
         if (argc != 4 || std::string(argv[1]) != "env") {
-            fprintf(stderr, "usage: mc_hosttest env <dump> <out_prefix> | seeds <fasta> | reads <file>\n");
+            fprintf(stderr, "usage: mc_hosttest env <dump> <out_prefix> | seeds <fasta> | reads <file> | multi <out_dir> <seq> <gene_id> <env>...\n");
             return 2;
         }
         std::ifstream f(argv[2]);

@@ -61,7 +61,8 @@ struct Options {
     std::vector<std::string> reads;
     std::string seq, hicseq, output, output_dir, work_dir = "workDir", hash = "poly", tool = "environment-finder";
     long long maxkmers = -1, maxradius = -1;
-    int coverage = 1, chunklength = 1, device = 0;
+    int coverage = 1, chunklength = 1, device = 0, geneid = 1;
+    std::vector<std::string> env;
     bool bothdirs = false, forcehash = false, trim = false, merge = false, cont = false, force = false, help = false;
     unsigned long long capacity_hint = 0;
 };
@@ -73,7 +74,7 @@ const OptSpec SPECS[] = {
     {"chunklength", nullptr, 0}, {"forcehash", nullptr, 1}, {"hash", nullptr, 0}, {"trim", nullptr, 1},
     {"merge", nullptr, 1}, {"work-dir", "w", 0}, {"available-processors", "p", 0}, {"memory", "m", 0},
     {"continue", "c", 1}, {"force", nullptr, 1}, {"verbose", "v", 1}, {"help", "h", 1}, {"tool", "t", 0},
-    {"device", nullptr, 0}, {"capacity-hint", nullptr, 0}, {"output-dir", nullptr, 0},
+    {"device", nullptr, 0}, {"capacity-hint", nullptr, 0}, {"output-dir", nullptr, 0}, {"env", "e", 2}, {"geneid", "g", 0},
 };
 
 const OptSpec *find_spec(const std::string &tok)
@@ -130,14 +131,18 @@ Options parse_args(int argc, char **argv)
     Options o;
     auto val = [&](const char *n) -> const std::string * { auto it = got.find(n); return it == got.end() || it->second.empty() ? nullptr : &it->second[0]; };
     if (auto v = val("k")) o.k = (int)parse_int("k", *v);
-    if (got.count("reads"))
-        for (const std::string &v : got["reads"]) {  // arrays are re-tokenised on "[, ]" (Tool.java:888-895)
+    auto multi = [&](const char *name, std::vector<std::string> &dst) {
+        if (!got.count(name)) return;
+        for (const std::string &v : got[name]) {  // arrays are re-tokenised on "[, ]" (Tool.java:888-895)
             std::string cur;
             for (char c : v + " ") {
-                if (c == '[' || c == ',' || c == ' ' || c == ']') { if (!cur.empty()) o.reads.push_back(cur); cur.clear(); }
+                if (c == '[' || c == ',' || c == ' ' || c == ']') { if (!cur.empty()) dst.push_back(cur); cur.clear(); }
                 else cur.push_back(c);
             }
         }
+    };
+    multi("reads", o.reads);
+    multi("env", o.env);
     if (auto v = val("seq")) o.seq = *v;
     if (auto v = val("hicseq")) o.hicseq = *v;
     if (auto v = val("output")) o.output = *v;
@@ -157,6 +162,7 @@ Options parse_args(int argc, char **argv)
     if (auto v = val("work-dir")) o.work_dir = *v;
     if (auto v = val("tool")) o.tool = *v;
     if (auto v = val("output-dir")) o.output_dir = *v;
+    if (auto v = val("geneid")) o.geneid = (int)parse_int("geneid", *v);
     if (auto v = val("device")) o.device = (int)parse_int("device", *v);
     if (auto v = val("capacity-hint")) o.capacity_hint = (unsigned long long)parse_int("capacity-hint", *v);
     return o;
@@ -181,6 +187,7 @@ void usage()
     puts("      --hash <arg>         hash function to use: poly or fnv1a (default poly)");
     puts("      --trim [<arg>]       trim all not maximal paths? (default false)");
     puts("      --merge [<arg>]      draw single environment for multiple input sequences? (default false)");
+    puts("Input parameters of --tool environment-finder-multi (CPU only): -e/--env <graph.txt files>, --seq, -o/--output, -g/--geneid (default 1)");
     puts("Input parameters of --tool kmer-counter: -k, -i/--reads, --hash, --output-dir <dir> (default <work-dir>/kmers)");
     puts("Launch options: -w/--work-dir <dir> (default workDir), -c/--continue, --force, -v/--verbose, -h/--help,");
     puts("                -t/--tool <name>, -p/--available-processors <n> and -m/--memory <arg> (accepted, unused),");
@@ -300,11 +307,26 @@ int run_kmer_counter(const Options &o)
     return 0;
 }
 
+// --tool environment-finder-multi (src/tools/EnvironmentFinderMultiMain.java): no GPU involved
+int run_multi(const Options &o)
+{
+    if (o.env.empty()) throw Error("Parameter 'env' is mandatory");
+    if (o.seq.empty()) throw Error("Parameter 'seq' is mandatory");
+    if (o.output.empty()) throw Error("Parameter 'output' is mandatory");
+    if (!open_work_dir(o, "seq=" + o.seq + "\noutput=" + o.output + "\n")) return 0;
+    const MultiResult r = environment_finder_multi(o.env, o.seq, o.geneid);
+    write_multi(r, o.output);
+    for (const std::string &l : r.log) logline(l.substr(0, 4).c_str(), l.substr(5));
+    write_file(o.work_dir + "/SUCCESS", "");
+    return 0;
+}
+
 int run(const Options &o)
 {
     if (o.tool == "kmer-counter") return run_kmer_counter(o);
+    if (o.tool == "environment-finder-multi") return run_multi(o);
     if (o.tool != "environment-finder")
-        throw Error("Tool '" + o.tool + "' is not part of this build: only --tool environment-finder and --tool kmer-counter run on the GPU path");
+        throw Error("Tool '" + o.tool + "' is not part of this build: only environment-finder, kmer-counter and environment-finder-multi are");
     if (o.k < 0) throw Error("Parameter 'k' is mandatory");
     if (o.seq.empty()) throw Error("Parameter 'seq' is mandatory");
     if (o.output.empty()) throw Error("Parameter 'output' is mandatory");

@@ -510,3 +510,191 @@ def read_kmers_bin(path):
     data = open(path, "rb").read()
     assert len(data) % 10 == 0
     return sorted(struct.unpack(">qh", data[i:i + 10]) for i in range(0, len(data), 10))
+
+
+# ---- --tool environment-finder-multi (src/tools/EnvironmentFinderMultiMain.java, src/algo/MultiSequenceCalculator.java,
+# src/algo/MultiNode.java, src/io/writers/GFAWriterMulti.java, src/io/graph/DeBruijnGraphUtils.java)
+
+def load_graph(path):
+    """DeBruijnGraphUtils.loadGraph (:13-27): "<kmer> <depth>" lines into a java.util.HashMap, in file order."""
+    g = JavaHashMap()
+    with open(path, "r") as f:
+        for line in f.read().split("\n"):
+            if line == "" :
+                continue  # (BufferedReader.ready() is false at the end of the file; a blank line would crash the reference)
+            tokens = line.rstrip("\r").split(" ")
+            g.put(tokens[0], int(tokens[1]))
+    return g
+
+
+class MultiNode:
+    """src/algo/MultiNode.java:9-29"""
+    __slots__ = ("sequence", "id", "is_gene", "deleted", "rc", "neighbors", "graphs")
+
+    def __init__(self, sequence, id_, is_gene):
+        self.sequence, self.id, self.is_gene = sequence, id_, is_gene
+        self.deleted = False
+        self.rc = None
+        self.neighbors = []
+        self.graphs = set()
+
+
+def java_format_6_2f(x):
+    """String.format("%6.2f", (float) x): the exact decimal value of the float, rounded HALF_UP to two places."""
+    import decimal
+    import math
+    x = float(x)
+    if math.isnan(x):
+        s = "NaN"
+    elif math.isinf(x):
+        s = "Infinity" if x > 0 else "-Infinity"
+    else:
+        d = decimal.Decimal(x).quantize(decimal.Decimal("0.01"), rounding=decimal.ROUND_HALF_UP)
+        s = "%.2f" % d if d != 0 else ("-0.00" if math.copysign(1.0, x) < 0 else "0.00")
+    return s.rjust(6)
+
+
+def environment_finder_multi(env_paths, seq_path, out_dir, gene_id=1):
+    """Returns ({file name: text}, log lines); writes nothing.  Raises ValueError where the reference fails."""
+    import numpy as np
+    graphs = [load_graph(p) for p in env_paths]
+    if not graphs:
+        raise ValueError("Zero environments given")
+    log = []
+    if len(graphs) > 256:
+        log.append("WARN Found more than 256 environments. Grayscale graph may be not accurate.")
+    k = len(next(iter(graphs[0].keys())))
+    for g in graphs:
+        for kmer in g.keys():
+            if len(kmer) != k:
+                raise ValueError("K-mers of different lengths encountered: %d and %d" % (k, len(kmer)))
+    dnas, comments = rich_fasta_read(seq_path)
+    sequence, comment = dnas[gene_id - 1], comments[gene_id - 1]
+    log.append("INFO Combining environments for sequence " +
+               (sequence[:k] + "..." + sequence[len(sequence) - k:] + " (length=%d)" % len(sequence) if len(sequence) >= 2 * k else sequence))
+
+    # initializeStructures (MultiSequenceCalculator.java:51-100)
+    by_kmer = JavaHashMap()
+    for g in graphs:
+        for kmer in g.keys():
+            by_kmer.put(kmer, None)
+            by_kmer.put(reverse_complement(kmer), None)
+    size = len(by_kmer)
+    nodes = []
+    for kmer in list(by_kmer.keys()):
+        rc = reverse_complement(kmer)
+        if kmer > rc:
+            continue
+        if len(nodes) + 2 > size:  # a palindromic k-mer (even k) takes two nodes but one key: nodes[] is too short
+            raise ValueError("palindromic k-mer %s: the reference fails here (ArrayIndexOutOfBoundsException)" % kmer)
+        is_gene = kmer in sequence or rc in sequence
+        a, b = MultiNode(kmer, len(nodes), is_gene), MultiNode(rc, len(nodes) + 1, is_gene)
+        a.rc, b.rc = b, a
+        nodes += [a, b]
+        by_kmer.put(a.sequence, a)
+        by_kmer.put(b.sequence, b)
+    for i, g in enumerate(graphs):
+        for kmer in g.keys():
+            n = by_kmer.get(kmer)
+            n.graphs.add(i)
+            n.rc.graphs.add(i)
+    for n in nodes:
+        for c in "AGCT":
+            nb = by_kmer.get(n.sequence[1:] + c)
+            if nb is not None:
+                n.rc.neighbors.append(nb)
+
+    # doMerge (:102-122, 124-139)
+    def merge_labels(a, b):
+        if a[len(a) - (k - 1):] != b[: k - 1]:
+            raise AssertionError("Labels should be merged, but can not: %s and %s" % (a, b))
+        return a + b[k - 1:]
+
+    while True:
+        acted = False
+        for n in nodes:
+            if not n.deleted and len(n.neighbors) == 1:
+                o = n.neighbors[0]
+                if len(o.neighbors) == 1 and n.is_gene == o.is_gene and n.graphs == o.graphs:
+                    first_minus, second_plus = n.rc, o.rc
+                    new_seq = merge_labels(second_plus.sequence, n.sequence)
+                    new_rc = merge_labels(first_minus.sequence, o.sequence)
+                    second_plus.sequence, first_minus.sequence = new_seq, new_rc
+                    second_plus.rc, first_minus.rc = first_minus, second_plus
+                    n.deleted = o.deleted = True
+                    acted = True
+        if not acted:
+            break
+
+    def min_id(n):
+        return min(n.id, n.rc.id) + 1
+
+    # outputNodeSequences (:141-160)
+    seqs = []
+    for n in nodes:
+        if not n.deleted and n.id < n.rc.id:
+            ids = set(min_id(x) for x in n.neighbors) | set(min_id(x) for x in n.rc.neighbors)
+            ids.discard(min_id(n))
+            seqs.append("> Id%d%s Length:%d Neighbors:[%s]\n%s\n" % (
+                min_id(n), "_start" if n.is_gene else "", len(n.sequence), ", ".join(str(x) for x in sorted(ids)), n.sequence))
+
+    # GFAWriterMulti (:37-146)
+    def color(n):
+        G = len(graphs)
+        if n.is_gene:
+            return "#00ff00"
+        s = len(n.graphs)
+        if G == 2:
+            return {1: "#ff0000", 2: "#0000ff"}.get(s, "#000000")
+        if G == 3:
+            return {1: "#ff0000", 2: "#0000ff", 3: "#ff00ff", 4: "#ffff00", 5: "#ffaa00", 6: "#00ffff"}.get(s, "#000000")
+        v = 256 * s // G
+        return "#%02X%02X%02X" % (v, v, v)
+
+    gfa = []
+    for n in nodes:
+        if not n.deleted and n.id < n.rc.id:
+            cov = 0
+            for g in graphs:
+                for i in range(len(n.sequence) - k + 1):
+                    c = g.get(normalize_dna(n.sequence[i:i + k]))
+                    cov += 0 if c is None else c
+            col = color(n)
+            gfa.append("S\t%d%s\t%s\tLN:i:%d\tKC:i:%d\tCL:Z:%s\tC2:Z:%s\n" % (
+                min_id(n), "_start" if n.is_gene else "", n.sequence, len(n.sequence), cov, col, col))
+    for a in nodes:
+        if not a.deleted:
+            for b in a.neighbors:
+                gfa.append("L\t%d%s\t%s\t%d%s\t%s\t%dM\n" % (
+                    min_id(a), "_start" if a.is_gene else "", "+" if a.id < a.rc.id else "-",
+                    min_id(b), "_start" if b.is_gene else "", "+" if b.id > b.rc.id else "-", k - 1))
+
+    # printProbability (EnvironmentFinderMultiMain.java:104-170): 32-bit int sums, float division
+    G = len(graphs)
+    dicts = [dict(g.items()) for g in graphs]
+    sym = ["The[31mWarning! symmetric <<Jaccard distance>> (1 - AB/AUB):\n", "\n"]
+    alt = ["The[31mWarning! alternative <<Jaccard distance>> (1 - AB/A):\n", "\n"]
+    for i in range(G):
+        sym.append(str(env_paths[i]))
+        alt.append(str(env_paths[i]))
+        for j in range(G):
+            F, S = dicts[i], dicts[j]
+            diff = diff_alt = union = 0
+            for kmer, v in F.items():
+                if kmer not in S:
+                    diff += v; diff_alt += v; union += v
+                else:
+                    diff += abs(v - S[kmer]); diff_alt += abs(v - S[kmer]); union += max(v, S[kmer])
+            for kmer, v in S.items():
+                if kmer not in F:
+                    diff += v; union += v
+            inter = union - diff
+            with np.errstate(divide="ignore", invalid="ignore"):
+                sym.append(java_format_6_2f(np.float32(1) - np.float32(inter) / np.float32(union)) + " ")
+                alt.append(java_format_6_2f(np.float32(1) - np.float32(inter) / np.float32(union - diff_alt)) + " ")
+        sym.append("\n")
+        alt.append("\n")
+    log.append("INFO Finished processing!")
+    files = {"seqs.fasta": "".join(seqs), "graph.gfa": "".join(gfa), "gene.fasta": ">%s\n%s\n" % (comment, sequence),
+             "Jacard_sym.txt": "".join(sym), "Jacard_alt.txt": "".join(alt)}
+    return files, log

@@ -148,3 +148,69 @@ def test_read_ingest_policies(hosttest, tmp_path):
     iupac = tmp_path / "y.fa"
     iupac.write_text(">x\nACGRT\n")
     assert subprocess.call([hosttest, "reads", str(iupac)], stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL) == 1
+
+
+def _env_text(rng, genome, k, start, length, cov_lo, cov_hi, drop=0.0):
+    """graph.txt of a pretend environment: the canonical k-mers of genome[start:start+length] (some dropped), random depths."""
+    seq = "".join("AGCT"[c] for c in genome[start:start + length])
+    seen, lines = set(), []
+    for i in range(len(seq) - k + 1):
+        s = ho.normalize_dna(seq[i:i + k])
+        if s in seen or rng.random() < drop:
+            continue
+        seen.add(s)
+        lines.append("%s %d\n" % (s, int(rng.integers(cov_lo, cov_hi))))
+    order = rng.permutation(len(lines))  # file order decides java.util.HashMap bin order
+    return "".join(lines[i] for i in order)
+
+
+@pytest.mark.parametrize("n_env,k,gene_id", [(2, 21, 1), (3, 15, 2), (5, 31, 1), (1, 9, 1)])
+def test_environment_finder_multi_cpp_equals_oracle(hosttest, tmp_path, n_env, k, gene_id):
+    """--tool environment-finder-multi: the C++ host and the Python restatement of
+    MultiSequenceCalculator / GFAWriterMulti / printProbability write the same five files, byte for byte."""
+    rng = np.random.default_rng(100 + n_env)
+    genome = rng.integers(0, 4, 3000).astype(np.uint8)
+    # a variant with a few substitutions: environments that share most of a region and differ in bubbles
+    variant = genome.copy()
+    for p in rng.integers(200, 2800, 12):
+        variant[p] = (variant[p] + 1) & 3
+    envs = []
+    for e in range(n_env):
+        src = variant if e % 2 else genome
+        p = tmp_path / ("env%d.txt" % e)
+        p.write_text(_env_text(rng, src, k, 100 + 150 * e, 1800, 1, 40, drop=0.02 * e))
+        envs.append(str(p))
+    seq = tmp_path / "genes.fasta"
+    g1 = "".join("AGCT"[c] for c in genome[700:760])
+    g2 = "".join("AGCT"[c] for c in genome[900:990])
+    seq.write_text(">first gene\n%s\n>second\n%s\n" % (g1, g2))
+    out = tmp_path / "out"
+    log = subprocess.check_output([hosttest, "multi", str(out), str(seq), str(gene_id)] + envs).decode().splitlines()
+    want, want_log = ho.environment_finder_multi(envs, str(seq), str(out), gene_id)
+    assert log == want_log
+    for name, text in want.items():
+        assert (out / name).read_text() == text, name
+    assert want["graph.gfa"].count("\nS\t") > 5 and "CL:Z:#" in want["graph.gfa"]
+    if n_env >= 2:
+        assert "#00ff00" in want["graph.gfa"]  # the gene's unitigs
+
+
+def test_environment_finder_multi_edge_cases(hosttest, tmp_path):
+    def fmt(x):
+        return subprocess.check_output([hosttest, "fmt", repr(float(x))]).decode()
+    # String.format("%6.2f"): HALF_UP on the float's exact value, NaN / infinities as Java prints them
+    for x in (0.125, 0.375, 0.005, 0.63, 1.0, 0.995, -0.004, float("nan"), float("-inf"), 12345.678):
+        assert fmt(np.float32(x)) == ho.java_format_6_2f(np.float32(x)), x
+    assert ho.java_format_6_2f(np.float32(0.125)) == "  0.13" and ho.java_format_6_2f(float("nan")) == "   NaN"
+    # even k with a palindromic k-mer: the reference dies with an ArrayIndexOutOfBoundsException; both restatements refuse
+    e = tmp_path / "pal.txt"
+    e.write_text("ACGT 3\nAAAA 2\n")
+    s = tmp_path / "s.fa"
+    s.write_text(">g\nAAAACGT\n")
+    assert subprocess.call([hosttest, "multi", str(tmp_path / "o"), str(s), "1", str(e)], stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL) == 1
+    with pytest.raises(ValueError, match="palindromic"):
+        ho.environment_finder_multi([str(e)], str(s), str(tmp_path / "o"))
+    # k-mers of different lengths
+    e2 = tmp_path / "mixed.txt"
+    e2.write_text("ACGTA 3\nAAAC 2\n")
+    assert subprocess.call([hosttest, "multi", str(tmp_path / "o"), str(s), "1", str(e2)], stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL) == 1
