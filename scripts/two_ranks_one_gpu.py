@@ -1,0 +1,69 @@
+"""Both ranks of a world-2 job on ONE GPU (gloo carries the collectives, staging CUDA tensors through
+the host): exercises ShardedCounter with real Contexts where only one GPU is available.
+Usage: python scripts/two_ranks_one_gpu.py [k]"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def worker(rank, world, port, k, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import metacherchant_amd as m
+    from metacherchant_amd.distributed import ShardedCounter, split_reads
+    from oracle import pyoracle as po
+    from tests.helpers import synth_case, seed_windows
+    dev = torch.device("cuda:0")
+    L, n_reads = 150, 40000
+    genome, reads, off = synth_case(2, 100000, n_reads, L, 80)
+    lo, hi = split_reads(n_reads, world, rank)
+    mine = reads[lo * L:hi * L]
+    words = torch.from_numpy(po.pack(mine).view(np.int64)).to(dev)
+    offs = torch.from_numpy((np.arange(hi - lo + 1, dtype=np.uint64) * L).view(np.int64)).to(dev)
+    mode = m.KEY_PACKED if k <= 31 else m.KEY_POLY
+    ctx = m.Context(k, mode, 0, 0)
+    sc = ShardedCounter(ctx, dev)
+    sc.add_reads_dev(words, offs, hi - lo, (hi - lo) * L, (hi - lo) * (L - k + 1))
+    total = sc.finalize()
+    solid = m.Context(k, mode, 0, 0) if rank == 0 else None
+    n_solid = sc.gather_solid(solid, 4, dst=0)
+    if rank == 0:
+        t = po.Table()
+        t.count_reads(reads, off, k, mode)
+        ok, oc = t.dump()
+        sk, scnt = solid.export(0)
+        assert total == t.size(), (total, t.size())
+        assert n_solid == int((oc >= 4).sum())
+        assert np.array_equal(sk, ok[oc >= 4]) and np.array_equal(scnt, oc[oc >= 4])
+        seed = genome[30000:30300]
+        shi, slo = seed_windows(seed, k)
+        got = solid.bfs(shi, slo, 1, 4, 5000, -1)
+        want = po.bfs(t, k, mode, [seed], 1, 4, 5000, -1)
+        assert np.array_equal(got["lo"], want["lo"]) and np.array_equal(got["dist"], want["dist"])
+        q.put(("ok", total, n_solid, sc.bytes_sent, ctx.superkmer_capacity(1000, 10) > 0))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    k = int(sys.argv[1]) if len(sys.argv) > 1 else 31
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, 2, port, k, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0, p.exitcode
+    print("two ranks on one GPU, k=%d:" % k, res)
