@@ -13,7 +13,10 @@
  *     from mc_last_error().  The library never calls exit() and no C++ exception crosses the ABI
  *     (the reference throws ExecutionFailedException, itmo!/utils/tool/Tool.java:450-462).
  *   - plain pointers and sizes only.  Functions ending in _dev take pointers to device (HBM)
- *     memory of the context's device; all others take host pointers.
+ *     memory of the context's device; all others take host pointers.  Work runs on the context's own
+ *     HIP stream (or the one given to mc_set_stream) and every call returns with its results complete;
+ *     device buffers a caller passes in must not have writes pending on OTHER streams (a memset, a
+ *     copy, a collective's result): synchronise those first, or share the stream.
  *   - a context is not re-entrant for mutation (mc_add_*, mc_finalize_counts).  After
  *     mc_finalize_counts, mc_get* and mc_bfs are read-only on the table; calls on ONE context
  *     are serialised internally, several contexts may be used from several threads.

@@ -119,11 +119,16 @@ def _p(a, t):
 
 
 def _dptr(x):
-    """device pointer of a torch tensor (or a raw int)"""
+    """device pointer of a torch tensor (or a raw int).  The library works on its own HIP stream, so whatever
+    torch still has queued for the tensor (the fill of a torch.zeros, a copy, a collective's result) must be
+    done before the pointer is handed over: the tensor's current stream is synchronised here."""
     if x is None:
         return None
     if isinstance(x, int):
         return C.c_void_p(x)
+    if getattr(x, "is_cuda", False):
+        import torch
+        torch.cuda.current_stream(x.device).synchronize()
     return C.c_void_p(x.data_ptr())
 
 

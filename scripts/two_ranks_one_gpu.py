@@ -42,7 +42,13 @@ def worker(rank, world, port, k, q):
         sk, scnt = solid.export(0)
         assert total == t.size(), (total, t.size())
         assert n_solid == int((oc >= 4).sum())
-        assert np.array_equal(sk, ok[oc >= 4]) and np.array_equal(scnt, oc[oc >= 4])
+        wk, wc = ok[oc >= 4], oc[oc >= 4]
+        if not (np.array_equal(sk, wk) and np.array_equal(scnt, wc)):
+            msg = "solid table differs: n %d want %d, missing %d extra %d" % (len(sk), len(wk), len(np.setdiff1d(wk, sk)), len(np.setdiff1d(sk, wk)))
+            if np.array_equal(sk, wk):
+                bad = np.nonzero(scnt != wc)[0]
+                msg += ", %d counts differ, e.g. %s" % (len(bad), [(int(sk[i]), int(scnt[i]), int(wc[i])) for i in bad[:5]])
+            raise AssertionError(msg)
         seed = genome[30000:30300]
         shi, slo = seed_windows(seed, k)
         got = solid.bfs(shi, slo, 1, 4, 5000, -1)
@@ -62,7 +68,7 @@ if __name__ == "__main__":
     procs = [ctx.Process(target=worker, args=(r, 2, port, k, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = q.get(timeout=600)
+    res = q.get(timeout=120)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0, p.exitcode
