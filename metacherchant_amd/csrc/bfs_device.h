@@ -75,7 +75,12 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, uint32_t l)
     return ((uint64_t)hi << 32) | lo;
 }
 
-__device__ __forceinline__ uint64_t vis_hash(const Kmer &v) { return fmix64(v.lo ^ fmix64(v.hi + 0x9e3779b97f4a7c15ull)); }
+// (hi == 0, every k <= 32: the inner hash is a constant)
+__device__ __forceinline__ uint64_t vis_hash(const Kmer &v)
+{
+    constexpr uint64_t H0 = fmix64(0x9e3779b97f4a7c15ull);
+    return fmix64(v.lo ^ (v.hi == 0 ? H0 : fmix64(v.hi + 0x9e3779b97f4a7c15ull)));
+}
 
 __device__ __forceinline__ bool vis_entry_is(const BfsState &S, uint64_t e, uint32_t fp, const Kmer &v)
 {
@@ -496,6 +501,7 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
 #endif
     unsigned long long rounds = 0, slow_rounds = 0;
+    uint32_t div_f = 0, div_m = 0;  // div_m = ceil(2^16 / div_f)
     if (tid < 64) {
         const unsigned long long lb = ctl->lb, le = ctl->le;
         const long long level = ctl->level;
@@ -540,13 +546,16 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
         uint32_t hl_min = LHINT_MAX;
         for (uint32_t a = 0; a < F; a++) hl_min = min(hl_min, lh_len(L.rhint[a]));
         if (hl_min > (uint32_t)k) hl_min = (uint32_t)k;
+        // x / F for x <= 512 and F <= 16 is (x * ceil(2^16 / F)) >> 16: integer divisions cost a lone wave ~30 instructions
+        // each, and this loop is bound by how fast one wave issues instructions.  F rarely changes.
+        if (F != div_f) { div_f = F; div_m = (65536u + F - 1) / F; }
         uint32_t H = 1;
         if (hl_min >= 2 && !capped0 && room >= 1 && !L.any_dup_root) {
-            H = min(hl_min, (uint32_t)MAX_NODES / FN);
+            H = min(hl_min, (((uint32_t)MAX_NODES >> lg) * div_m) >> 16);  // MAX_NODES / FN
             if ((long long)H > room) H = (uint32_t)room;
-            if (max_kmers >= 0) {
-                const unsigned long long fit = ((unsigned long long)max_kmers - n) / F;  // whole levels under the cap
-                if (fit < H) H = fit < 1 ? 1 : (uint32_t)fit;
+            if (max_kmers >= 0) {  // whole levels under the cap: H <= (max_kmers - n) / F
+                const unsigned long long rem = (unsigned long long)max_kmers - n;
+                if (rem < (unsigned long long)H * F) H = (uint32_t)(((uint32_t)rem * div_m) >> 16);  // (rem < 512 here)
             }
             if (H < 1) H = 1;
         }
@@ -564,18 +573,36 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
         uint64_t key = 0, s0 = 0, s1 = 0;
         uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
         if (have) {
-            ni = tid / FN + 1;  // (FN <= 64: a cheap division)
-            const uint32_t r = tid - (ni - 1) * FN;
+            const uint32_t lvl = ((tid >> lg) * div_m) >> 16;  // tid / FN
+            ni = lvl + 1;
+            const uint32_t r = tid - lvl * FN;
             na = r >> lg;
             const uint32_t c = r & (uint32_t)(nb - 1);
             const uint64_t h = L.rhint[na];
             const bool right = (h >> 62) & 1;
-            const Kmer v = walker_at(L.root[na], k, h, ni - 1);  // the expected path so far
-            const uint32_t hb = (uint32_t)(h >> (2 * (ni - 1))) & 3u;  // expected step
+            const uint32_t hb = (uint32_t)(h >> (2 * lvl)) & 3u;  // expected step
             const uint32_t cstar = dir == 0 ? (2 * hb + (right ? 1u : 0u)) : hb;
-            nk = neighbour(v, k, dir, (int)c);
             npred = H > 1 && c == cstar;
-            key = (uint64_t)key_of<MODE>(nk, k, &nflip);
+            if (MODE == KEY_PACKED) {
+                // k <= 31: everything in one 64-bit word, no branches (walker_at + neighbour + key_of, specialised)
+                const uint64_t root = L.root[na].lo, kmask = (1ull << (2 * k)) - 1;
+                const uint32_t sh = 2 * lvl;  // 0 .. 54
+                const uint64_t fwd = ((root << sh) | lh_block_forward(h, lvl)) & kmask;                       // root followed by lvl bases
+                const uint64_t bwd = (root >> sh) | ((h & lh_mask(lvl)) << (2 * ((uint32_t)k - lvl)));        // root preceded by them
+                const uint64_t v = lvl == 0 ? root : (right ? fwd : bwd);
+                const bool left = dir < 0 || (dir == 0 && !(c & 1));
+                const uint64_t cc = dir == 0 ? (c >> 1) : c;
+                const uint64_t x = left ? ((v >> 2) | (cc << (2 * (k - 1)))) : (((v << 2) | cc) & kmask);
+                nk.hi = 0;
+                nk.lo = x;
+                const uint64_t rcx = rc_packed(x, k);
+                nflip = rcx < x;
+                key = nflip ? rcx : x;
+            } else {
+                const Kmer v = walker_at(L.root[na], k, h, lvl);  // the expected path so far
+                nk = neighbour(v, k, dir, (int)c);
+                key = (uint64_t)key_of<MODE>(nk, k, &nflip);
+            }
             s0 = solid_slot_of(t, key);
             s1 = (s0 & ~(uint64_t)t.rmask) | ((s0 + 1) & t.rmask);
             a0 = *reinterpret_cast<const uint4 *>(t.slots + s0);

@@ -14,7 +14,7 @@ struct Kmer {  // oriented k-mer, 2k bits right-aligned in 128, first base most 
     uint64_t hi, lo;
 };
 
-__host__ __device__ __forceinline__ uint64_t fmix64(uint64_t x)
+__host__ __device__ constexpr __forceinline__ uint64_t fmix64(uint64_t x)
 {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdull;
     x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull;
