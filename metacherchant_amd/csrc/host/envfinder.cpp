@@ -1,6 +1,9 @@
 // See envfinder.h.  Every function restates the reference lines cited there.
 #include "envfinder.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <sys/stat.h>
@@ -15,6 +18,7 @@
 #include <limits>
 #include <set>
 #include <sstream>
+#include <thread>
 
 namespace mch {
 
@@ -341,6 +345,235 @@ private:
 };
 }  // namespace
 
+namespace {
+
+// lines of a memory range (a chunk of a memory-mapped file)
+class MemLines {
+public:
+    MemLines(const char *b, const char *e) : p_(b), end_(e) {}
+    bool getline(std::string &l)
+    {
+        if (p_ >= end_) return false;
+        const char *nl = static_cast<const char *>(memchr(p_, '\n', (size_t)(end_ - p_)));
+        const char *stop = nl ? nl : end_;
+        l.assign(p_, (size_t)(stop - p_));
+        p_ = nl ? nl + 1 : end_;
+        if (!l.empty() && l.back() == '\r') l.pop_back();
+        return true;
+    }
+
+private:
+    const char *p_, *end_;
+};
+
+// itmo!/io/readers/FastaReader.java:54-104: multi-line records concatenated, records with N / n dropped whole
+template <class Src, class Emit>
+void parse_fasta(Src &src, Emit &&emit)
+{
+    std::string line, sb;
+    auto flush = [&] {
+        if (!sb.empty() && sb.find('N') == std::string::npos && sb.find('n') == std::string::npos) emit(sb.data(), sb.size());
+        sb.clear();
+    };
+    while (src.getline(line)) {
+        if (!line.empty() && (line[0] == '>' || line[0] == ';')) {
+            if (!sb.empty()) flush();
+        } else {
+            sb += line;
+        }
+    }
+    flush();
+}
+
+// itmo!/io/readers/FastqReader.java:53-112 + FastaReaderFromXQSourceTrunc.java:61-95 + itmo!/io/ReadersUtils.java:57-77.
+// Records: marker line ("@id" / "+id") + content line, twice; empty lines before a marker are skipped.
+// offset < 0: the quality offset is sniffed on the first 1000 records (Illumina+64 unless a char < 64 shows up).
+// strict: the first marker must be '@' and the second '+' (what the parallel reader relies on); returns false otherwise.
+template <class Src, class Emit>
+bool parse_fastq(Src &src, Emit &&emit, int offset, bool strict, int *sniffed = nullptr, size_t sniff_only = 0)
+{
+    char marker = 0;
+    auto next_data = [&](std::string &out) -> bool {
+        std::string l;
+        for (;;) {
+            if (!src.getline(l)) return false;
+            if (!l.empty()) break;
+        }
+        if (l[0] != '@' && l[0] != '+') throw Error("Unknown structure of fastq file! Waiting \"@ID\" or \"+ID\" string");
+        marker = l[0];
+        if (!src.getline(out)) throw Error("Unexpected end of file. File is corrupted/Format mismatch.");
+        return true;
+    };
+    std::vector<std::pair<std::string, std::string>> head;  // the records the offset is sniffed on
+    auto process = [&](const std::string &d, const std::string &q) {
+        std::string piece;
+        for (size_t i = 0; i < d.size(); i++) {
+            int ph;
+            if (d[i] == 'N' || d[i] == 'n' || d[i] == '.') {
+                ph = 0;
+            } else {
+                const int qc = (unsigned char)q[i];
+                if (qc < offset || qc > 126) throw Error("Invalid quality code char");
+                ph = qc - offset;
+            }
+            if (ph < 1) {  // truncateByQuality(1): the piece ends here and the bad base is dropped
+                if (!piece.empty()) emit(piece.data(), piece.size());
+                piece.clear();
+            } else {
+                piece.push_back(d[i]);
+            }
+        }
+        if (!piece.empty()) emit(piece.data(), piece.size());
+    };
+    auto sniff = [&] {
+        offset = 64;
+        for (const auto &r : head)
+            for (size_t i = 0; i < r.first.size(); i++) {
+                if (r.first[i] == 'N' || r.first[i] == 'n' || r.first[i] == '.') continue;
+                const int qc = (unsigned char)r.second[i];
+                if (qc < 64 || qc > 126) { offset = 33; return; }
+            }
+    };
+    std::string d, q;
+    while (next_data(d)) {
+        if (strict && marker != '@') return false;
+        if (!next_data(q)) throw Error("Unexpected end of file. File is corrupted/Format mismatch.");
+        if (strict && marker != '+') return false;
+        if (d.size() != q.size()) throw Error("Bad DnaQ record: length of chars and quality is not the same.");
+        if (offset < 0) {
+            head.emplace_back(d, q);
+            if (head.size() == 1000) {
+                sniff();
+                if (sniff_only) { *sniffed = offset; return true; }
+                for (const auto &r : head) process(r.first, r.second);
+                head.clear();
+            }
+        } else {
+            process(d, q);
+        }
+    }
+    if (offset < 0) {
+        sniff();
+        if (sniff_only) { *sniffed = offset; return true; }
+        for (const auto &r : head) process(r.first, r.second);
+    }
+    return true;
+}
+
+struct Mapped {  // a read-only memory map of a whole file
+    const char *p = nullptr;
+    size_t n = 0;
+    int fd = -1;
+    ~Mapped()
+    {
+        if (p && n) munmap(const_cast<char *>(p), n);
+        if (fd >= 0) close(fd);
+    }
+};
+
+size_t env_size(const char *name, size_t dflt)
+{
+    const char *e = getenv(name);
+    return e && *e ? (size_t)strtoull(e, nullptr, 10) : dflt;
+}
+
+// Parallel ingest of an uncompressed file: cut at record starts, parse the chunks on all cores, hand the batches over
+// in file order.  Returns false (nothing delivered) when the file is small, cannot be mapped, or does not have the
+// plain structure the cutting relies on -- the caller then reads it serially, which defines the behaviour.
+bool load_reads_parallel(const std::string &path, bool fastq, size_t max_reads, const std::function<void(PackedBatch &)> &sink,
+                         uint64_t *delivered)
+{
+    size_t n_threads = env_size("MC_INGEST_THREADS", std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 64));
+    const size_t min_chunk = std::max<size_t>(env_size("MC_INGEST_CHUNK_BYTES", 4u << 20), 64);
+    if (n_threads < 2) return false;
+    Mapped m;
+    m.fd = open(path.c_str(), O_RDONLY);
+    if (m.fd < 0) return false;
+    struct stat st;
+    if (fstat(m.fd, &st) != 0 || st.st_size < (off_t)(2 * min_chunk)) return false;
+    m.n = (size_t)st.st_size;
+    void *mp = mmap(nullptr, m.n, PROT_READ, MAP_PRIVATE, m.fd, 0);
+    if (mp == MAP_FAILED) { m.n = 0; return false; }
+    m.p = static_cast<const char *>(mp);
+    n_threads = std::min(n_threads, m.n / min_chunk);
+    const char *begin = m.p, *end = m.p + m.n;
+    auto line_start_after = [&](const char *q) -> const char * {  // first line start at or after q
+        if (q <= begin) return begin;
+        const char *nl = static_cast<const char *>(memchr(q - 1, '\n', (size_t)(end - (q - 1))));
+        return nl ? nl + 1 : end;
+    };
+    auto line_end = [&](const char *q) { const char *nl = static_cast<const char *>(memchr(q, '\n', (size_t)(end - q))); return nl ? nl : end; };
+    auto next_line = [&](const char *q) { const char *e = line_end(q); return e < end ? e + 1 : end; };
+    auto len_of = [&](const char *q) { const char *e = line_end(q); size_t l = (size_t)(e - q); if (l && q[l - 1] == '\r') l--; return l; };
+    // record start at or after q: FASTA a header line; FASTQ '@' line whose third line starts with '+' and whose second
+    // and fourth lines have the same length (a quality line that starts with '@' fails the '+' test)
+    auto record_start = [&](const char *q) -> const char * {
+        const char *l = line_start_after(q);
+        for (int guard = 0; l < end && guard < 100000; guard++, l = next_line(l)) {
+            if (!fastq) {
+                if (*l == '>' || *l == ';') return l;
+                continue;
+            }
+            if (*l != '@') continue;
+            const char *l2 = next_line(l), *l3 = l2 < end ? next_line(l2) : end;
+            if (l3 >= end || *l3 != '+') continue;
+            const char *l4 = next_line(l3);
+            if (l4 < end && len_of(l2) == len_of(l4)) return l;
+        }
+        return end;
+    };
+    std::vector<const char *> cut(n_threads + 1);
+    cut[0] = begin;
+    cut[n_threads] = end;
+    for (size_t t = 1; t < n_threads; t++) cut[t] = std::max(cut[t - 1], record_start(begin + m.n / n_threads * t));
+    int offset = -1;
+    if (fastq) {  // the quality offset comes from the first 1000 records of the file
+        MemLines src(begin, end);
+        if (!parse_fastq(src, [](const char *, size_t) {}, -1, true, &offset, 1) || offset < 0) return false;
+    }
+    struct Part { std::vector<PackedBatch> batches; uint64_t reads = 0; bool ok = true; };
+    std::vector<Part> parts(n_threads);
+    std::vector<std::thread> threads;
+    for (size_t t = 0; t < n_threads; t++)
+        threads.emplace_back([&, t] {
+            Part &P = parts[t];
+            try {
+                PackedBatch batch;
+                batch.clear();
+                auto emit = [&](const char *s, size_t n) {
+                    batch.add_read(s, n);
+                    P.reads++;
+                    if (batch.n_reads() >= max_reads) {
+                        batch.finish();
+                        P.batches.push_back(std::move(batch));
+                        batch = PackedBatch();
+                        batch.clear();
+                    }
+                };
+                MemLines src(cut[t], cut[t + 1]);
+                if (fastq) P.ok = parse_fastq(src, emit, offset, true);
+                else parse_fasta(src, emit);
+                if (batch.n_reads() > 0) {
+                    batch.finish();
+                    P.batches.push_back(std::move(batch));
+                }
+            } catch (...) {
+                P.ok = false;  // the serial reader will meet the same problem and report it
+            }
+        });
+    for (auto &th : threads) th.join();
+    for (const Part &P : parts)
+        if (!P.ok) return false;
+    *delivered = 0;
+    for (Part &P : parts) {
+        for (PackedBatch &b : P.batches) sink(b);
+        *delivered += P.reads;
+    }
+    return true;
+}
+
+}  // namespace
+
 uint64_t load_reads_file(const std::string &path, size_t max_reads, const std::function<void(PackedBatch &)> &sink)
 {
     // itmo!/io/ReadersUtils.java:27-53 detectFileFormat: a .gz / .bz2 suffix comes off first, then the format
@@ -354,11 +587,14 @@ uint64_t load_reads_file(const std::string &path, size_t max_reads, const std::f
     const bool fastq = ends_with(name, ".fastq") || ends_with(name, ".fq");
     const bool fasta = ends_with(name, ".fasta") || ends_with(name, ".fa") || ends_with(name, ".fn") || ends_with(name, ".fna");
     if (!fastq && !fasta) throw Error("Can't detect file format for file '" + name + "'");
-    LineSource src(path, gz);
 
+    uint64_t delivered = 0;
+    if (!gz && load_reads_parallel(path, fastq, max_reads, sink, &delivered)) return delivered;
+
+    // the reference's readers are serial (one synchronized source per file, src/io/ReadsDispatcher.java:34-53)
+    LineSource src(path, gz);
     PackedBatch batch;
     batch.clear();
-    uint64_t delivered = 0;
     auto emit = [&](const char *s, size_t n) {
         batch.add_read(s, n);
         delivered++;
@@ -368,87 +604,8 @@ uint64_t load_reads_file(const std::string &path, size_t max_reads, const std::f
             batch.clear();
         }
     };
-    std::string line;
-    auto getline = [&](std::string &l) { return src.getline(l); };
-
-    if (fasta) {
-        std::string sb;
-        auto flush = [&] {
-            if (!sb.empty() && sb.find('N') == std::string::npos && sb.find('n') == std::string::npos)
-                emit(sb.data(), sb.size());
-            sb.clear();
-        };
-        while (getline(line)) {
-            if (!line.empty() && (line[0] == '>' || line[0] == ';')) {
-                if (!sb.empty()) flush();
-            } else {
-                sb += line;
-            }
-        }
-        flush();
-    } else {
-        // records: "@id" / data / "+id" / quality; empty lines between them are skipped
-        auto next_data = [&](std::string &out) -> bool {
-            std::string l;
-            for (;;) {
-                if (!getline(l)) return false;
-                if (!l.empty()) break;
-            }
-            if (l[0] != '@' && l[0] != '+') throw Error("Unknown structure of fastq file! Waiting \"@ID\" or \"+ID\" string");
-            if (!getline(out)) throw Error("Unexpected end of file. File is corrupted/Format mismatch.");
-            return true;
-        };
-        std::vector<std::pair<std::string, std::string>> head;  // the records the offset is sniffed on
-        int offset = -1;
-        auto process = [&](const std::string &d, const std::string &q) {
-            std::string piece;
-            for (size_t i = 0; i < d.size(); i++) {
-                int ph;
-                if (d[i] == 'N' || d[i] == 'n' || d[i] == '.') {
-                    ph = 0;
-                } else {
-                    const int qc = (unsigned char)q[i];
-                    if (qc < offset || qc > 126) throw Error("Invalid quality code char");
-                    ph = qc - offset;
-                }
-                if (ph < 1) {  // truncateByQuality(1): the piece ends here and the bad base is dropped
-                    if (!piece.empty()) emit(piece.data(), piece.size());
-                    piece.clear();
-                } else {
-                    piece.push_back(d[i]);
-                }
-            }
-            if (!piece.empty()) emit(piece.data(), piece.size());
-        };
-        auto sniff = [&] {
-            offset = 64;  // Illumina unless a char < 64 shows up in the first 1000 records
-            for (const auto &r : head)
-                for (size_t i = 0; i < r.first.size(); i++) {
-                    if (r.first[i] == 'N' || r.first[i] == 'n' || r.first[i] == '.') continue;
-                    const int qc = (unsigned char)r.second[i];
-                    if (qc < 64 || qc > 126) { offset = 33; return; }
-                }
-        };
-        std::string d, q;
-        while (next_data(d)) {
-            if (!next_data(q)) throw Error("Unexpected end of file. File is corrupted/Format mismatch.");
-            if (d.size() != q.size()) throw Error("Bad DnaQ record: length of chars and quality is not the same.");
-            if (offset < 0) {
-                head.emplace_back(d, q);
-                if (head.size() == 1000) {
-                    sniff();
-                    for (const auto &r : head) process(r.first, r.second);
-                    head.clear();
-                }
-            } else {
-                process(d, q);
-            }
-        }
-        if (offset < 0) {
-            sniff();
-            for (const auto &r : head) process(r.first, r.second);
-        }
-    }
+    if (fasta) parse_fasta(src, emit);
+    else parse_fastq(src, emit, -1, false);
     if (batch.n_reads() > 0) {
         batch.finish();
         sink(batch);

@@ -214,3 +214,66 @@ def test_environment_finder_multi_edge_cases(hosttest, tmp_path):
     e2 = tmp_path / "mixed.txt"
     e2.write_text("ACGTA 3\nAAAC 2\n")
     assert subprocess.call([hosttest, "multi", str(tmp_path / "o"), str(s), "1", str(e2)], stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL) == 1
+
+
+def test_parallel_ingest_equals_serial(hosttest, tmp_path):
+    """Uncompressed files are cut at record starts and parsed on several threads; the reads, and their order, must
+    be those of the serial reader (which restates the reference's readers) -- also for quality lines that start with
+    '@', blank lines, CRLF, multi-line FASTA records, and files the cutting rejects (then the serial reader runs)."""
+    rng = np.random.default_rng(9)
+
+    def run(path, threads):
+        env = dict(os.environ, MC_INGEST_THREADS=str(threads), MC_INGEST_CHUNK_BYTES="700")
+        return subprocess.check_output([hosttest, "reads", str(path)], stderr=subprocess.DEVNULL, env=env).decode().splitlines()
+
+    def dna(n):
+        return "".join("ACGT"[c] for c in rng.integers(0, 4, n))
+
+    fa = tmp_path / "p.fasta"
+    with open(fa, "w") as f:
+        for i in range(400):
+            s = dna(int(rng.integers(1, 200)))
+            if i % 17 == 0:
+                s = s[: len(s) // 2] + "N" + s[len(s) // 2:]
+            nl = "\r\n" if i % 5 == 0 else "\n"
+            f.write(">r%d some text%s" % (i, nl))
+            for j in range(0, len(s), 60):
+                f.write(s[j:j + 60] + nl)
+            if i % 23 == 0:
+                f.write(";a comment line\n")
+    want = ho.read_fasta_reads(str(fa))
+    assert run(fa, 1) == want
+    assert run(fa, 4) == want and run(fa, 7) == want
+
+    fq = tmp_path / "p.fastq"
+    with open(fq, "w") as f:
+        for i in range(600):
+            n = int(rng.integers(1, 120))
+            s, q = dna(n), ["I"] * n
+            if i % 3 == 0:
+                q[0] = "@"  # a quality line that starts like a header (phred 31 at offset 33)
+            if i % 7 == 0 and n > 5:
+                q[n // 2] = "!"
+            if i % 13 == 0 and n > 3:
+                s = s[:2] + "N" + s[3:]
+            f.write("@r%d\n%s\n+%s\n%s\n%s" % (i, s, "r%d" % i if i % 2 else "", "".join(q), "\n" if i % 29 == 0 else ""))
+    want = ho.read_fastq_reads(str(fq))
+    assert run(fq, 1) == want
+    assert run(fq, 4) == want and run(fq, 6) == want
+
+    # all qualities >= '@' in the first 1000 records: Illumina+64 for the whole file, also in the chunks that come later
+    fq64 = tmp_path / "i.fq"
+    with open(fq64, "w") as f:
+        for i in range(1500):
+            n = int(rng.integers(5, 80))
+            q = ["h"] * n
+            q[n // 3] = "@"  # phred 0 at offset 64
+            f.write("@x%d\n%s\n+\n%s\n" % (i, dna(n), "".join(q)))
+    want = ho.read_fastq_reads(str(fq64))
+    assert run(fq64, 5) == want == run(fq64, 1)
+
+    # "+" and "@" markers swapped in one record: the reference's reader does not care, the cutting does -> serial result
+    odd = tmp_path / "odd.fastq"
+    text = open(fq).read().replace("@r300\n", "+r300\n", 1)
+    odd.write_text(text)
+    assert run(odd, 4) == ho.read_fastq_reads(str(odd))
