@@ -235,6 +235,10 @@ __global__ void __launch_bounds__(PT_THREADS) k_p1_extract_scatter(
 #endif
     constexpr int64_t MARGIN = 64;  // the bitmap starts this many bases left of the tile (virtually, for tile 0)
     const uint64_t kmask = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+    constexpr uint64_t INV5 = 0xCCCCCCCCCCCCCCCDull;  // 5 * INV5 == 1 (mod 2^64)
+    uint64_t pow5_km1 = 1;
+    for (int i = 1; i < k; i++) pow5_km1 *= 5;
+    const uint64_t pow5_k = pow5_km1 * 5;
     for (uint64_t tile = base_lo / PT_TILE + blockIdx.x; tile < n_tiles; tile += gridDim.x) {  // reads cover [base_lo, n_bases)
         const uint64_t lo = tile * (uint64_t)PT_TILE;
         const int64_t bm_lo = (int64_t)lo - MARGIN;                    // position of bit 0 of the bitmap
@@ -263,6 +267,15 @@ __global__ void __launch_bounds__(PT_THREADS) k_p1_extract_scatter(
             const uint64_t w_lo = starts_window(L.starts, wrel), w_hi = starts_window(L.starts, wrel + 64);
             Kmer v = extract_kmer(words, p0, k);
             uint64_t rc = MODE == KEY_PACKED ? rc_packed(v.lo, k) : 0;
+            // polynomial keys roll too: src/utils/PolynomialHash.java:19-28 is h = 5^k + sum b_i 5^(k-1-i) in the ring
+            // of 64-bit integers (and 5^k + sum (3 - b_i) 5^i for the other strand), so sliding the window by one
+            // base is a handful of operations instead of 2k multiply-adds, with the same value bit for bit
+            uint64_t hf = 1, hr = 1;
+            if (MODE == KEY_POLY)
+                for (int i = 0; i < k; i++) {
+                    hf = hf * 5 + base_at(v, k, i);
+                    hr = hr * 5 + (3u ^ base_at(v, k, k - 1 - i));
+                }
             uint32_t r7 = 0, l7 = 0;  // the HINT_LEN bases after / before the window, nearest first
 #pragma unroll
             for (int i = 0; i < HINT_LEN; i++) {
@@ -280,6 +293,9 @@ __global__ void __launch_bounds__(PT_THREADS) k_p1_extract_scatter(
                     if (MODE == KEY_PACKED) {
                         flipped = rc < v.lo;
                         key[j] = flipped ? rc : v.lo;
+                    } else if (MODE == KEY_POLY) {
+                        flipped = (int64_t)hr < (int64_t)hf;  // Math.min on signed longs
+                        key[j] = flipped ? hr : hf;
                     } else {
                         key[j] = (uint64_t)key_of<MODE>(v, k, &flipped);
                     }
@@ -306,6 +322,10 @@ __global__ void __launch_bounds__(PT_THREADS) k_p1_extract_scatter(
                     rc = (rc >> 2) | ((uint64_t)(3u - in) << (2 * (k - 1)));
                 } else {
                     v = neighbour(v, k, 1, (int)in);
+                    if (MODE == KEY_POLY) {
+                        hf = hf * 5 + in - (uint64_t)(out + 4u) * pow5_k;  // drop out * 5^(k-1) * 5 and the leading 5^(k+1), add 5^k
+                        hr = pow5_k + (hr - pow5_k - (3u - out)) * INV5 + (uint64_t)(3u - in) * pow5_km1;
+                    }
                 }
                 l7 = ((l7 << 2) | out) & 0x3FFFu;
                 r7 = (r7 >> 2) | (base_or0(words, p + (uint64_t)k + HINT_LEN, n_bases) << (2 * (HINT_LEN - 1)));
