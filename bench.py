@@ -60,11 +60,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    # MC_BENCH_ONE_GPU=1 (tests only): every rank uses cuda:0 and gloo carries the collectives, so that the
+    # multi-rank path of this file can be exercised on a 1-GPU box; its numbers mean nothing.
+    one_gpu = os.environ.get("MC_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     k, L, R = args.k, args.read_len, args.reads
     mode = m.KEY_PACKED if k <= 31 else m.KEY_POLY

@@ -20,3 +20,21 @@ def test_two_ranks_on_one_gpu(k, records):
     line = [l for l in p.stdout.splitlines() if l.startswith("two ranks on one GPU")][-1]
     assert "'ok'" in line
     assert line.rstrip(")").endswith("True" if records else "False")  # which form of the exchange ran
+
+
+def test_bench_multi_rank_path_on_one_gpu():
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run), both ranks on the one GPU over gloo:
+    the sharded step runs and rank 0 prints one JSON line with the whole-job numbers."""
+    import json
+    env = dict(os.environ, MC_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29617", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--reads", "300000", "--contigs", "2", "--contig-len", "1000000", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["bfs"]["reached"] > 1000 and out["solid_kmers"] > 100000
+    assert out["roofline"]["kernel_ms"]["k_sk1_records"] > 0  # the super-k-mer form of the exchange ran
