@@ -5,14 +5,14 @@
 // slot.  MI355X retires only ~2*10^10 scattered atomics per second chip-wide, far below what HBM
 // can stream, so large batches take this route instead:
 //
-//   P1  extract + scatter   reads -> keys (+ the read-context hint of the occurrence), grouped by the
-//                           top b1 bits of fmix64(key); tiles of 8192 windows staged in LDS and
-//                           written out as one contiguous run per bucket.  Each of the 256 workgroups
+//   P1  extract + scatter   reads -> keys (+ the read-context hint of the occurrence), grouped into np1
+//                           level-1 buckets by their bin word (mulhi32 below); tiles of 8192 windows staged
+//                           in LDS and written out as one contiguous run per bucket.  Each of the 256 workgroups
 //                           owns one segment of every bucket: fill levels live in LDS, no atomics,
 //                           and a run's cache lines are completed by the workgroup that started them;
-//   P2  scatter             one workgroup per level-1 bucket scatters it again by the next b2 bits:
-//                           b1 + b2 = log2(#regions) of the table, so a leaf bucket holds exactly the
-//                           keys of one table region;
+//   P2  scatter             one workgroup per level-1 bucket scatters it again into the bucket's m2 leaves:
+//                           np1 * m2 = #leaves = #regions of the table (x 2^g for very large tables), so a
+//                           leaf holds exactly the keys of one table region;
 //   P3  merge               one workgroup per region: the region (4096 slots, 64 KB) lives in LDS, the
 //                           leaf's keys are streamed in and counted with LDS atomics, the region goes
 //                           back to HBM with plain coalesced stores.
@@ -34,6 +34,12 @@ constexpr int P3_THREADS = 512;
 constexpr uint32_t REGION_SLOTS = 4096;             // == 1 << mc_ctx::sb
 constexpr uint32_t CURSOR1_STRIDE = 32;             // owner cursors of the multi-GPU split sit on separate 128-byte lines
 constexpr int PT_SEGMENTS = 256;                    // workgroups of P1 (one per CU) = segments of every level-1 bucket
+
+// Bucket digits.  A key's (or record's) 32-bit bin word places it by multiplication, not by bit prefix:
+// region = (bin * n_regions) >> 32, so a table may have any number of regions; with np1 level-1 buckets of
+// m2 leaves each (np1 * m2 leaves in all) bucket = (bin * np1) >> 32 and leaf = (bin * np1 * m2) >> 32 =
+// bucket * m2 + leaf-in-bucket (floor(floor(x * np1 * m2) / m2) == floor(x * np1)).  Powers of two give bit prefixes.
+__host__ __device__ __forceinline__ uint32_t mulhi32(uint32_t bin, uint32_t n) { return (uint32_t)(((uint64_t)bin * n) >> 32); }
 
 struct ScatterLds {
     uint64_t key[PT_TILE];
@@ -206,25 +212,25 @@ __device__ __forceinline__ uint64_t bits128(uint64_t lo, uint64_t hi, uint32_t f
 // P1: tiles of PT_TILE consecutive base positions of the packed read set.  A thread owns PT_ITEMS
 // CONSECUTIVE positions and rolls the window along them (the reference's ShortKmer.shiftRight,
 // itmo!/dna/kmers/ShortKmer.java:68-71): one new base per step instead of a fresh extraction.
-// bucket of a key: the top b1 bits of its hash (counting pipeline), or its owner rank (multi-GPU split;
+// bucket of a key: mulhi32(its bin word, np1) (counting pipeline), or its owner rank (multi-GPU split;
 // low hash bits, disjoint from the bits that place it in the table)
 __device__ __forceinline__ uint32_t owner_of(uint64_t key, uint32_t n_owners)
 {
     return (uint32_t)((fmix64(key) & 0xFFFFFFFFull) % n_owners);
 }
 
-// OWNERS: buckets are owner ranks (n_buckets = b1 owners) instead of 2^b1 hash prefixes, EMPTY_KEY is an
+// OWNERS: the np1 buckets are owner ranks instead of ranges of the bin word, EMPTY_KEY is an
 // ordinary key, and the output is packed at `bases` (from a COUNT_ONLY run of the same kernel).
 template <int MODE, bool OWNERS = false, bool COUNT_ONLY = false>
 __global__ void __launch_bounds__(PT_THREADS) k_p1_extract_scatter(
     const uint64_t *__restrict__ words, const uint64_t *__restrict__ offsets, uint64_t n_reads, uint64_t base_lo,
-    uint64_t n_bases, uint64_t n_tiles, const uint32_t *__restrict__ first_read, int k, uint32_t b1, uint32_t *cursors, uint64_t cap,
+    uint64_t n_bases, uint64_t n_tiles, const uint32_t *__restrict__ first_read, int k, uint32_t np1, uint32_t *cursors, uint64_t cap,
     uint64_t *out_keys, uint32_t *out_hints, unsigned long long *empty_cnt, SpillView sp, const uint64_t *bases = nullptr,
     int mm_k = 0)
 {
     __shared__ ScatterLds L;
     const uint32_t tid = threadIdx.x;
-    const uint32_t n_buckets = OWNERS ? b1 : (1u << b1);
+    const uint32_t n_buckets = np1;  // (owner ranks, or level-1 buckets)
     if (tid < PT_MAX_BUCKETS) L.wcur[tid] = 0;  // (counting pipeline: gridDim.x == PT_SEGMENTS, segment = blockIdx.x)
 #ifdef MC_P1_TIMING
     if (tid < 4) L.dbg[tid] = 0;
@@ -312,7 +318,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_p1_extract_scatter(
                         atomicAdd(empty_cnt, 1ull);
                     } else {
                         valid[j] = true;
-                        dig[j] = bin32_of(key[j], mm_k) >> (32 - b1);
+                        dig[j] = mulhi32(bin32_of(key[j], mm_k), np1);
                     }
                 }
                 // roll to p + 1: the window takes the first base after it, loses its first base
@@ -349,14 +355,14 @@ __global__ void __launch_bounds__(PT_THREADS) k_p1_extract_scatter(
 // P1 for a flat stream of keys (+ optional hints) instead of reads: the receiving side of the
 // multi-GPU exchange.  Tiles of PT_TILE consecutive entries.
 __global__ void __launch_bounds__(PT_THREADS) k_p1_keys_scatter(const uint64_t *__restrict__ in_keys,
-                                                                const uint32_t *__restrict__ in_hints, uint64_t n, uint32_t b1,
+                                                                const uint32_t *__restrict__ in_hints, uint64_t n, uint32_t np1,
                                                                 uint32_t *cursors, uint64_t cap, uint64_t *out_keys,
                                                                 uint32_t *out_hints, unsigned long long *empty_cnt, SpillView sp,
                                                                 int mm_k)
 {
     __shared__ ScatterLds L;
     const uint32_t tid = threadIdx.x;
-    const uint32_t n_buckets = 1u << b1;
+    const uint32_t n_buckets = np1;
     const uint64_t n_tiles = (n + PT_TILE - 1) / PT_TILE;
     if (tid < PT_MAX_BUCKETS) L.wcur[tid] = 0;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -377,7 +383,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_p1_keys_scatter(const uint64_t *
                     atomicAdd(empty_cnt, 1ull);
                 } else {
                     valid[j] = true;
-                    dig[j] = bin32_of(key[j], mm_k) >> (32 - b1);
+                    dig[j] = mulhi32(bin32_of(key[j], mm_k), np1);
                 }
             }
         }
@@ -389,16 +395,16 @@ __global__ void __launch_bounds__(PT_THREADS) k_p1_keys_scatter(const uint64_t *
 
 // P2: one workgroup per level-1 bucket (it owns all of the bucket's leaves, so again no global
 // atomics and whole-line writes).  The bucket's PT_SEGMENTS input segments are read as one stream,
-// PT_TILE records per tile, and scattered by the next b2 hash bits.
+// PT_TILE records per tile, and scattered into the bucket's m2 leaves.
 __global__ void __launch_bounds__(PT_THREADS) k_p2_scatter(const uint64_t *__restrict__ in_keys,
                                                            const uint32_t *__restrict__ in_hints, uint64_t seg_cap1,
                                                            const uint32_t *__restrict__ seg_counts1, uint32_t n_buckets1,
-                                                           uint32_t b1, uint32_t b2, uint32_t *leaf_counts, uint64_t cap2,
+                                                           uint32_t np1, uint32_t m2, uint32_t *leaf_counts, uint64_t cap2,
                                                            uint64_t *out_keys, uint32_t *out_hints, SpillView sp, int mm_k)
 {
     __shared__ ScatterLds L;
     const uint32_t tid = threadIdx.x;
-    const uint32_t n_buckets = 1u << b2;
+    const uint32_t n_buckets = m2;  // leaves per level-1 bucket
     for (uint32_t bucket = blockIdx.x; bucket < n_buckets1; bucket += gridDim.x) {
         __syncthreads();
         if (tid < PT_MAX_BUCKETS) L.wcur[tid] = 0;
@@ -437,7 +443,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_p2_scatter(const uint64_t *__res
                     const uint64_t at = ((uint64_t)bucket * PT_SEGMENTS + sg) * seg_cap1 + (e - L.seg_prefix[sg]);
                     key[j] = in_keys[at];
                     hint[j] = in_hints[at];
-                    dig[j] = (bin32_of(key[j], mm_k) >> (32 - b1 - b2)) & (n_buckets - 1);
+                    dig[j] = mulhi32(bin32_of(key[j], mm_k), np1 * m2) - bucket * m2;
                 }
             }
             scatter_tile(L, key, hint, dig, valid, n_buckets, nullptr, cap2, cap2, out_keys, out_hints,
@@ -563,17 +569,17 @@ __device__ __forceinline__ void sk_hash8(const uint64_t *bases, uint32_t q, uint
 }
 
 // SK-P1: tiles of PT_TILE consecutive base positions, PT_ITEMS (8) consecutive positions per thread.
-// OWNERS: the buckets are the b1 (!) owner ranks of a multi-GPU split instead of 2^b1 bin prefixes.
+// OWNERS: the np1 buckets are the owner ranks of a multi-GPU split instead of ranges of the bin word.
 template <bool OWNERS>
 __global__ void __launch_bounds__(PT_THREADS) k_sk1_extract(
     const uint64_t *__restrict__ words, const uint64_t *__restrict__ offsets, uint64_t n_reads, uint64_t base_lo,
-    uint64_t n_bases, uint64_t n_tiles, const uint32_t *__restrict__ first_read, int k, uint32_t b1, uint32_t *seg_counts,
+    uint64_t n_bases, uint64_t n_tiles, const uint32_t *__restrict__ first_read, int k, uint32_t np1, uint32_t *seg_counts,
     uint64_t cap, uint4 *out_recs, uint32_t *out_bins, SkSpill sp)
 {
     static_assert(PT_ITEMS == 8, "one byte of the break bitmap per thread");
     __shared__ Sk1Lds L;
     const uint32_t tid = threadIdx.x;
-    const uint32_t n_buckets = OWNERS ? b1 : (1u << b1);
+    const uint32_t n_buckets = np1;  // (owner ranks, or level-1 buckets)
     const int w = k - SK_M + 1;  // SK_M-mers per window (9 .. 17)
     const uint64_t last_word = (n_bases + 31) / 32;  // the pad word
     if (tid < PT_MAX_BUCKETS) { L.C.wcur[tid] = 0; L.C.cnt[tid] = 0; }
@@ -726,7 +732,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk1_extract(
             const uint32_t bin = sk_bin(hsel);
             uint4 rec;
             rec.x = (uint32_t)rl; rec.y = (uint32_t)(rl >> 32); rec.z = (uint32_t)hi; rec.w = (uint32_t)(hi >> 32);
-            sk_emit(L.C, OWNERS ? sk_owner(hsel, b1) : bin >> (32 - b1), rec, bin, cap, (uint64_t)blockIdx.x * cap,
+            sk_emit(L.C, OWNERS ? sk_owner(hsel, np1) : mulhi32(bin, np1), rec, bin, cap, (uint64_t)blockIdx.x * cap,
                     (uint64_t)PT_SEGMENTS * cap, out_recs, out_bins, sp);
         }
         __syncthreads();
@@ -789,11 +795,11 @@ __global__ void k_sk_count_windows(const uint4 *__restrict__ recs, uint64_t n, u
 
 // SK-P1 for a flat stream of records (+ bin words): the receiving side of a multi-GPU exchange.
 __global__ void __launch_bounds__(PT_THREADS) k_sk1_records(const uint4 *__restrict__ in_recs, const uint32_t *__restrict__ in_bins,
-                                                            uint64_t n, uint32_t b1, uint32_t *seg_counts, uint64_t cap,
+                                                            uint64_t n, uint32_t np1, uint32_t *seg_counts, uint64_t cap,
                                                             uint4 *out_recs, uint32_t *out_bins, SkSpill sp)
 {
     __shared__ SkCursors C;
-    const uint32_t tid = threadIdx.x, n_buckets = 1u << b1;
+    const uint32_t tid = threadIdx.x, n_buckets = np1;
     if (tid < PT_MAX_BUCKETS) { C.wcur[tid] = 0; C.cnt[tid] = 0; }
     __syncthreads();
     const uint64_t n_tiles = (n + PT_TILE - 1) / PT_TILE;
@@ -803,7 +809,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk1_records(const uint4 *__restr
             const uint64_t i = tile * PT_TILE + tid + (uint64_t)j * PT_THREADS;
             if (i < n) {
                 const uint32_t bin = in_bins[i];
-                sk_emit(C, bin >> (32 - b1), in_recs[i], bin, cap, (uint64_t)blockIdx.x * cap, (uint64_t)PT_SEGMENTS * cap, out_recs, out_bins, sp);
+                sk_emit(C, mulhi32(bin, np1), in_recs[i], bin, cap, (uint64_t)blockIdx.x * cap, (uint64_t)PT_SEGMENTS * cap, out_recs, out_bins, sp);
             }
         }
         __syncthreads();
@@ -814,7 +820,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk1_records(const uint4 *__restr
 }
 
 // SK-P2: one workgroup per level-1 bucket; its PT_SEGMENTS segments are read as one stream and
-// scattered by the next b2 bits of the bin word into the bucket's leaves.
+// scattered by the next m2 bits of the bin word into the bucket's leaves.
 struct Sk2Lds {
     SkCursors C;
     uint32_t seg_prefix[PT_SEGMENTS + 1];
@@ -822,11 +828,11 @@ struct Sk2Lds {
 };
 __global__ void __launch_bounds__(PT_THREADS) k_sk2_scatter(const uint4 *__restrict__ in_recs, const uint32_t *__restrict__ in_bins,
                                                             uint64_t seg_cap1, const uint32_t *__restrict__ seg_counts1,
-                                                            uint32_t n_buckets1, uint32_t b1, uint32_t b2, uint32_t *leaf_counts,
+                                                            uint32_t n_buckets1, uint32_t np1, uint32_t m2, uint32_t *leaf_counts,
                                                             uint64_t cap2, uint4 *out_recs, uint32_t *out_bins, SkSpill sp)
 {
     __shared__ Sk2Lds L;
-    const uint32_t tid = threadIdx.x, n_buckets = 1u << b2;
+    const uint32_t tid = threadIdx.x, n_buckets = m2;  // leaves per level-1 bucket
     constexpr uint32_t TILE2 = PT_THREADS * 4;
     for (uint32_t bucket = blockIdx.x; bucket < n_buckets1; bucket += gridDim.x) {
         __syncthreads();
@@ -869,7 +875,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk2_scatter(const uint4 *__restr
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 if (have[j])
-                    sk_emit(L.C, (bin[j] >> (32 - b1 - b2)) & (n_buckets - 1), rec[j], bin[j], cap2, (uint64_t)bucket * n_buckets * cap2,
+                    sk_emit(L.C, mulhi32(bin[j], np1 * m2) - bucket * m2, rec[j], bin[j], cap2, (uint64_t)bucket * n_buckets * cap2,
                             cap2, out_recs, out_bins, sp);
             __syncthreads();
             if (tid < n_buckets) { L.C.wcur[tid] += L.C.cnt[tid]; L.C.cnt[tid] = 0; }
@@ -1010,7 +1016,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                             nxt = recs[r + P3_THREADS];
                             if (g) nxt_bin = bins[r + P3_THREADS];
                         }
-                        if (g && (bin >> (32 - t.rb)) != region) continue;  // (t.rb >= g > 0)
+                        if (g && mulhi32(bin, t.n_regions) != region) continue;
                         const uint64_t lo = ((uint64_t)rec.y << 32) | rec.x, hi = ((uint64_t)rec.w << 32) | rec.z;
                         const uint32_t nw = sk_windows(hi);
                         const bool has_l = (hi >> 57) & 1u, has_r = (hi >> 56) & 1u;

@@ -276,7 +276,7 @@ struct TableView {
     Slot *slots;
     uint32_t shift;   // 64 - (rb + sb)
     uint32_t rmask;   // RS - 1
-    uint32_t rb;      // log2(#regions)
+    uint32_t n_regions;  // any number when regions are minimizer bins, a power of two otherwise
     int mm_k;         // 0: region from fmix64(key); else k: region from the key's minimizer bin
     unsigned long long *n_used;     // distinct keys stored in slots
     unsigned long long *empty_cnt;  // occurrences of the key that equals EMPTY_KEY (hash modes only)
@@ -301,7 +301,7 @@ __host__ __device__ __forceinline__ uint32_t bin32_of(uint64_t key, int mm_k)
 __host__ __device__ __forceinline__ uint64_t slot_of(const TableView &t, uint64_t key)
 {
     if (t.mm_k == 0) return fmix64(key) >> t.shift;
-    const uint64_t region = t.rb ? (uint64_t)(sk_bin(sk_hmin_of_kmer(key, t.mm_k)) >> (32 - t.rb)) : 0;
+    const uint64_t region = ((uint64_t)sk_bin(sk_hmin_of_kmer(key, t.mm_k)) * t.n_regions) >> 32;
     return (region << 12) | sk_home(key);  // (regions are 4096 slots: count_pipeline.h REGION_SLOTS)
 }
 

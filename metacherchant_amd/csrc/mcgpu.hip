@@ -61,7 +61,8 @@ struct mc_ctx {
 
     // table
     Slot *slots = nullptr;
-    uint32_t rb = 0, sb = 12;  // 2^rb regions of 2^sb slots
+    uint64_t n_regions = 0;    // regions of 2^sb slots: a power of two, or (minimizer-bin tables of >= 512 regions) any multiple of 512
+    uint32_t rb = 0, sb = 12;  // rb = log2(n_regions) when that is a power of two (else its floor)
     unsigned long long *d_ctr = nullptr;  // [0] n_used, [1] empty_cnt, [2] scratch counter, [3] solid n_used, [4..5] read summary, [6] keys with count >= cov_hint
     uint32_t *d_fatal = nullptr;
     uint64_t n_used_host = 0;
@@ -107,7 +108,7 @@ struct mc_ctx {
         }
     } pipe;
 
-    uint64_t n_slots() const { return 1ull << (rb + sb); }
+    uint64_t n_slots() const { return n_regions << sb; }
     SolidView solid_view() const
     {
         SolidView t;
@@ -122,9 +123,9 @@ struct mc_ctx {
     {
         TableView t;
         t.slots = slots;
-        t.shift = 64 - (rb + sb);
+        t.shift = 64 - (rb + sb);  // (hash-prefix regions: n_regions is a power of two)
         t.rmask = (1u << sb) - 1;
-        t.rb = rb;
+        t.n_regions = (uint32_t)n_regions;
         t.mm_k = mm_k;
         t.n_used = d_ctr;
         t.empty_cnt = d_ctr + 1;
@@ -307,12 +308,12 @@ __global__ void __launch_bounds__(512) k_build_solid_regions(const Slot *__restr
 // bucket of its solid slot (256 workgroups, each its own segment of every bucket), k_sk2_scatter
 // splits the buckets into one leaf per solid region, k_solid_from_leaves assembles each region in
 // LDS.  No fill pass, no global atomics.
-__global__ void __launch_bounds__(PT_THREADS) k_solid_emit(const Slot *__restrict__ slots, uint64_t n_slots, int min_cov, uint32_t b1,
+__global__ void __launch_bounds__(PT_THREADS) k_solid_emit(const Slot *__restrict__ slots, uint64_t n_slots, int min_cov, uint32_t np1,
                                                             uint32_t *seg_counts, uint64_t cap, uint4 *out_recs, uint32_t *out_bins,
                                                             SkSpill sp)
 {
     __shared__ SkCursors C;
-    const uint32_t tid = threadIdx.x, n_buckets = 1u << b1;
+    const uint32_t tid = threadIdx.x, n_buckets = np1;
     if (tid < PT_MAX_BUCKETS) { C.wcur[tid] = 0; C.cnt[tid] = 0; }
     __syncthreads();
     const uint64_t n_tiles = (n_slots + PT_TILE - 1) / PT_TILE;
@@ -331,7 +332,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_solid_emit(const Slot *__restric
             if ((int)c < min_cov) continue;
             raws[j].z = c;
             const uint32_t bin = (uint32_t)(fmix64(key) >> 32);
-            sk_emit(C, bin >> (32 - b1), raws[j], bin, cap, (uint64_t)blockIdx.x * cap, (uint64_t)PT_SEGMENTS * cap, out_recs, out_bins, sp);
+            sk_emit(C, mulhi32(bin, np1), raws[j], bin, cap, (uint64_t)blockIdx.x * cap, (uint64_t)PT_SEGMENTS * cap, out_recs, out_bins, sp);
         }
         __syncthreads();
         if (tid < n_buckets) { C.wcur[tid] += C.cnt[tid]; C.cnt[tid] = 0; }
@@ -545,11 +546,27 @@ static int grid_for(uint64_t work_items, int block, int max_blocks = 256 * 8)
     return (int)g;
 }
 
-static int table_alloc(mc_ctx *c, uint32_t log2_slots)
+// Number of regions for a table of at least `slots` slots.  Hash-prefix regions need a power of two; minimizer bins
+// are numbered by multiplication (count_pipeline.h mulhi32), so those tables come in steps of 512 regions (2 M slots,
+// 32 MB) -- times 2^g beyond 2^18 regions, where a leaf of the counting pipeline covers 2^g regions.
+static uint64_t regions_for(const mc_ctx *c, uint64_t slots)
 {
-    if (log2_slots < c->sb) log2_slots = c->sb;
-    if (log2_slots > 36) return fail(c, MC_EOVERFLOW, "k-mer table would need 2^%u slots", log2_slots);
-    c->rb = log2_slots - c->sb;
+    uint64_t want = std::max<uint64_t>((slots + (1ull << c->sb) - 1) >> c->sb, 1);
+    uint64_t p2 = 1;
+    while (p2 < want) p2 <<= 1;
+    if (!c->mm_k || want <= 512) return p2;
+    uint64_t step = 512;
+    while (((want + step - 1) / step) * step > (step << 9)) step <<= 1;  // keep <= 2^18 leaves of `step`-aligned size
+    return ((want + step - 1) / step) * step;
+}
+
+static int table_alloc(mc_ctx *c, uint64_t n_regions)
+{
+    if (n_regions < 1) n_regions = 1;
+    if (n_regions > (1ull << 24)) return fail(c, MC_EOVERFLOW, "k-mer table would need %llu regions", (unsigned long long)n_regions);
+    c->n_regions = n_regions;
+    c->rb = 0;
+    while ((2ull << c->rb) <= n_regions) c->rb++;
     HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->slots), c->n_slots() * sizeof(Slot)));
     c->virgin = true;  // filled lazily: the partitioned pipeline writes every region itself
     c->st.table_slots = c->n_slots();
@@ -578,15 +595,15 @@ static int read_counters(mc_ctx *c, unsigned long long *n_used, uint32_t *fatal)
     return MC_OK;
 }
 
-static int table_grow(mc_ctx *c, uint32_t new_log2)
+static int table_grow(mc_ctx *c, uint64_t new_regions)
 {
     Slot *old = c->slots;
-    const uint64_t old_n = c->n_slots();
+    const uint64_t old_n = c->n_slots(), old_regions = c->n_regions;
     const bool old_virgin = c->virgin;
     const uint32_t old_rb = c->rb;
     c->slots = nullptr;
-    int rc = table_alloc(c, new_log2);
-    if (rc) { c->slots = old; c->rb = old_rb; c->virgin = old_virgin; return rc; }
+    int rc = table_alloc(c, new_regions);
+    if (rc) { c->slots = old; c->n_regions = old_regions; c->rb = old_rb; c->virgin = old_virgin; return rc; }
     if (old_virgin) {  // nothing to move
         HIPCHK(c, hipFree(old));
         c->st.grows++;
@@ -630,7 +647,7 @@ static int table_reserve(mc_ctx *c, uint64_t incoming, uint64_t *allowed)
             *allowed = room;
             return MC_OK;
         }
-        rc = table_grow(c, c->rb + c->sb + 1);
+        rc = table_grow(c, c->n_regions * 2);
         if (rc) return rc;
     }
 }
@@ -683,7 +700,7 @@ static int ensure_buf(mc_ctx *c, T **p, uint64_t *cap, uint64_t need)
 }
 
 struct PipePlan {
-    uint32_t b1 = 0, b2 = 0, g = 0;
+    uint32_t b1 = 0, b2 = 1, g = 0;  // b1 level-1 buckets of b2 leaves each (counts, not bits); a leaf covers 2^g regions
     uint64_t np1 = 0, n_leaves = 0, cap1 = 0, cap2 = 0, spill_cap = 0, wb = 0;
     bool sk = false;  // the streams hold super-k-mer records; capacities are in records
     SpillView sp{};
@@ -707,23 +724,29 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
         c->n_used_host = used;
         const bool hint_holds = c->cfg.capacity_hint && used < c->cfg.capacity_hint;
         if (!hint_holds && c->n_slots() < wb / 4) {
-            uint32_t lg = c->rb + c->sb;
-            while (lg < 34 && (double)(1ull << lg) * 0.5 < (double)used + (double)wb / 8.0) lg++;
-            if (lg > c->rb + c->sb) {
-                rc = table_grow(c, lg);
+            const uint64_t want = regions_for(c, (uint64_t)(((double)used + (double)wb / 8.0) / 0.5));
+            if (want > c->n_regions) {
+                rc = table_grow(c, want);
                 if (rc) return rc;
             }
         }
     }
-    const uint32_t rb = c->rb;
-    if (rb < 2) return fail(c, MC_EINVAL, "internal: partitioned counting needs at least 4 table regions");
-    const uint32_t lb = std::min<uint32_t>(rb, 18);  // leaf bits; a leaf covers 2^(rb - lb) regions
-    pl->b1 = std::min<uint32_t>(lb, 9);              // P1 always fans out as wide as it can
-    pl->b2 = lb - pl->b1;                            // 0: the level-1 buckets already are the leaves, no P2
-    pl->g = rb - lb;
+    // leaves: the regions themselves up to 2^18 of them, else 2^g regions per leaf; level-1 buckets: up to 512, each
+    // of m2 <= 512 leaves (regions_for made the numbers divide)
+    uint64_t n_leaves = c->n_regions;
+    uint32_t g = 0;
+    while (n_leaves > (1ull << 18)) { n_leaves >>= 1; g++; }
+    if ((n_leaves << g) != c->n_regions) return fail(c, MC_EINVAL, "internal: %llu table regions do not split into leaves", (unsigned long long)c->n_regions);
+    if (n_leaves < 4) return fail(c, MC_EINVAL, "internal: partitioned counting needs at least 4 table regions");
+    uint64_t np1 = std::min<uint64_t>(n_leaves, PT_MAX_BUCKETS);
+    while (n_leaves % np1) np1--;  // (a power of two, or 512 dividing a multiple of 512)
+    if (n_leaves / np1 > PT_MAX_BUCKETS) return fail(c, MC_EINVAL, "internal: %llu leaves do not fit two scatter levels", (unsigned long long)n_leaves);
+    pl->b1 = (uint32_t)np1;               // level-1 buckets
+    pl->b2 = (uint32_t)(n_leaves / np1);  // leaves per bucket; 1: the level-1 buckets already are the leaves, no P2
+    pl->g = g;
     pl->wb = wb;
-    pl->np1 = 1ull << pl->b1;
-    pl->n_leaves = 1ull << lb;
+    pl->np1 = np1;
+    pl->n_leaves = n_leaves;
     pl->sk = n_records != 0;
     const uint64_t units = pl->sk ? n_records : wb;  // records in the streams
     pl->cap1 = (uint64_t)((double)units / (double)pl->np1 / (double)PT_SEGMENTS * 1.25) + (pl->sk ? 64 : 256);  // per segment
@@ -731,15 +754,15 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
     // (records of one locus come in clumps -- one per read covering it -- so leaves vary more than Poisson)
     pl->cap2 = (uint64_t)(mean_leaf * 1.15 + (pl->sk ? 24.0 : 8.0) * std::sqrt(mean_leaf) + 64.0);
     pl->spill_cap = pl->sk ? std::max<uint64_t>(units / 16, 1u << 16) : std::max<uint64_t>(wb / 64, 1u << 20);
-    if (pl->np1 * PT_SEGMENTS * pl->cap1 >= 0xFFFFFFFFull || (1ull << pl->b2) * pl->cap2 >= 0xFFFFFFFFull)
+    if (pl->np1 * PT_SEGMENTS * pl->cap1 >= 0xFFFFFFFFull || (uint64_t)pl->b2 * pl->cap2 >= 0xFFFFFFFFull)
         return fail(c, MC_EINVAL, "internal: partitioned batch too large for 32-bit bucket indices");
-    const uint64_t np1 = pl->np1, n_leaves = pl->n_leaves;
+    // (np1, n_leaves as computed above)
     int rc;
     uint64_t dummy;
 #define ENSURE(ptr, capvar, need) do { rc = ensure_buf(c, &(ptr), &(capvar), (need)); if (rc) return rc; } while (0)
     if (pl->sk) {
         ENSURE(P.a_recs, P.a_recs_cap, np1 * PT_SEGMENTS * pl->cap1);
-        if (pl->b2) ENSURE(P.b_recs, P.b_recs_cap, n_leaves * pl->cap2);
+        if (pl->b2 > 1) ENSURE(P.b_recs, P.b_recs_cap, n_leaves * pl->cap2);
         ENSURE(P.spill_recs, P.spill_recs_cap, pl->spill_cap);
     } else {
         { uint64_t cap = P.a_cap; ENSURE(P.a_keys, cap, np1 * PT_SEGMENTS * pl->cap1); P.a_cap = cap; }
@@ -774,7 +797,7 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1)
     const int k = c->cfg.k;
     int rc;
     double ms2 = 0, ms3 = 0;
-    if (pl.b2 > 0) {
+    if (pl.b2 > 1) {
         rc = timed(c, &ms2, [&] {
             if (pl.sk)
                 hipLaunchKernelGGL(k_sk2_scatter, dim3((unsigned)np1), dim3(PT_THREADS), 0, c->stream, P.a_recs, P.a_hints, pl.cap1,
@@ -791,12 +814,12 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1)
         if (lost) return 1;
     }
     // P3 reads the leaves: P2's output (one segment each), or P1's buckets directly when there is no second level
-    const void *lk = pl.sk ? (pl.b2 > 0 ? (const void *)P.b_recs : (const void *)P.a_recs)
-                           : (pl.b2 > 0 ? (const void *)P.b_keys : (const void *)P.a_keys);
-    const uint32_t *lh = pl.b2 > 0 ? P.b_hints : P.a_hints;
-    const uint32_t *lc = pl.b2 > 0 ? P.cursors2 : P.seg_counts1;
-    const uint64_t lcap = pl.b2 > 0 ? pl.cap2 : pl.cap1;
-    const uint32_t lseg = pl.b2 > 0 ? 1u : (uint32_t)PT_SEGMENTS;
+    const void *lk = pl.sk ? (pl.b2 > 1 ? (const void *)P.b_recs : (const void *)P.a_recs)
+                           : (pl.b2 > 1 ? (const void *)P.b_keys : (const void *)P.a_keys);
+    const uint32_t *lh = pl.b2 > 1 ? P.b_hints : P.a_hints;
+    const uint32_t *lc = pl.b2 > 1 ? P.cursors2 : P.seg_counts1;
+    const uint64_t lcap = pl.b2 > 1 ? pl.cap2 : pl.cap1;
+    const uint32_t lseg = pl.b2 > 1 ? 1u : (uint32_t)PT_SEGMENTS;
     // P3, retried with a larger table when a region overflows
     for (int attempt = 0;; attempt++) {
         const int virgin = c->virgin ? 1 : 0;
@@ -816,7 +839,7 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1)
         if (!flags[1]) break;
         if (attempt >= 6 || pl.g >= 5)
             return fail(c, MC_EOVERFLOW, "k-mer table regions keep overflowing; pass a capacity_hint (distinct k-mers)");
-        rc = table_grow(c, c->rb + c->sb + 1);
+        rc = table_grow(c, c->n_regions * 2);
         if (rc) return rc;
         pl.g++;
         HIPCHK(c, hipMemsetAsync(P.flags + 1, 0, sizeof(uint32_t), c->stream));
@@ -1101,14 +1124,13 @@ int mc_create(const mc_config *cfg, mc_ctx **out)
     // (MC_SUPERKMERS=0 keeps the per-window pipeline: for A/B measurements)
     if (cfg->key_mode == MC_KEY_PACKED && cfg->k >= SK_MIN_K) c->mm_k = cfg->k;
     if (const char *e = getenv("MC_SUPERKMERS")) if (!strcmp(e, "0")) c->mm_k = 0;
-    uint32_t lg = 22;  // 4 M slots = 64 MB to start with
+    uint64_t want_slots = 1ull << 22;  // 4 M slots = 64 MB to start with
     if (cfg->capacity_hint) {
         // regions are probed in LDS: a fuller table costs little.  Minimizer bins fill less evenly than hash
         // prefixes (the k-mers of one locus share a bin), so they get more headroom.
-        const double want = (double)cfg->capacity_hint / (c->mm_k ? 0.6 : 0.7);
-        while (lg < 36 && (double)(1ull << lg) < want) lg++;
+        want_slots = std::max<uint64_t>(want_slots, (uint64_t)((double)cfg->capacity_hint / (c->mm_k ? 0.45 : 0.7)));
     }
-    int rc = table_alloc(c, lg);
+    int rc = table_alloc(c, regions_for(c, want_slots));
     if (rc) {
         g_create_err = c->err;
         mc_destroy(c);
@@ -1828,17 +1850,17 @@ int ensure_solid(mc_ctx *c, int min_cov, double *ms)
         if (c->mm_k) {
             uint32_t *leaf_counts = P.solid_cursors;
             const SkSpill none{nullptr, P.spill_count, 0, P.flags};  // no spill list: an overflow is reported
-            hipLaunchKernelGGL(k_solid_emit, dim3(PT_SEGMENTS), dim3(PT_THREADS), 0, c->stream, c->slots, c->n_slots(), min_cov, sb1,
+            hipLaunchKernelGGL(k_solid_emit, dim3(PT_SEGMENTS), dim3(PT_THREADS), 0, c->stream, c->slots, c->n_slots(), min_cov, 1u << sb1,
                                P.seg_counts1, scap1, P.a_recs, P.a_hints, none);
             if (sb2)
                 hipLaunchKernelGGL(k_sk2_scatter, dim3(1u << sb1), dim3(PT_THREADS), 0, c->stream, P.a_recs, P.a_hints, scap1,
-                                   P.seg_counts1, 1u << sb1, sb1, sb2, leaf_counts, scap2, P.b_recs, P.b_hints, none);
+                                   P.seg_counts1, 1u << sb1, 1u << sb1, 1u << sb2, leaf_counts, scap2, P.b_recs, P.b_hints, none);
             hipLaunchKernelGGL(k_solid_from_leaves, dim3((unsigned)std::min<uint64_t>(1ull << q, 256 * 2 * 8)), dim3(512), 0, c->stream,
                                sb2 ? P.b_recs : P.a_recs, sb2 ? leaf_counts : P.seg_counts1, sb2 ? scap2 : scap1,
                                sb2 ? 1u : (uint32_t)PT_SEGMENTS, c->solid_view(), lg);
         } else {
             hipLaunchKernelGGL(k_build_solid_regions, dim3((unsigned)std::min<uint64_t>(1ull << (lg - SOLID_SB), 256 * 2 * 8)), dim3(512), 0,
-                               c->stream, c->slots, c->rb + c->sb, min_cov, c->solid_view(), lg);
+                               c->stream, c->slots, c->rb + c->sb, min_cov, c->solid_view(), lg);  // (hash-prefix regions: a power of two)
         }
         if (doublings)  // one sweep: each slot chases its own chain (up to 3 dependent lookups per side)
             hipLaunchKernelGGL(k_solid_double, dim3(grid_for(1ull << lg, 256)), dim3(256), 0, c->stream, c->solid_view(),
