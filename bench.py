@@ -180,7 +180,7 @@ def main():
             pipeline = st.p3_ms > 0
             dominant = max(parts, key=parts.get) if pipeline else "k_count_reads"
             traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_v4_pmc_hbm_traffic_e1.csv")
+            pmc = os.path.join(ROOT, "profiles", "r01_v5_pmc_hbm_traffic_e1.csv")
             if pipeline and world == 1 and args.err == 100 and R == 10_000_000 and k == 31 and os.path.exists(pmc):
                 # HBM bytes per pipeline run from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes,
                 # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes), collected by scripts/gpu_pmc.sh
