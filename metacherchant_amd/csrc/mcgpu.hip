@@ -15,6 +15,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mcgpu.h"
@@ -83,6 +84,8 @@ struct mc_ctx {
     mc_stats st{};
     std::vector<std::unique_ptr<BfsJobBuffers>> bfs_pool;
 
+    char *pin[8] = {};                 // pinned staging buffers of h2d_fast, made on first use
+    hipStream_t pin_stream[4] = {};
     int mm_k = 0;        // != 0 (= k): regions are minimizer bins and reads are counted as super-k-mers (kmer_device.h)
     bool virgin = true;  // the table holds no key and its memory is not initialised yet
     int count_path = 0;  // 0 auto, 1 direct (atomics), 2 partitioned; MC_COUNT_PATH=direct|partition overrides
@@ -1158,6 +1161,8 @@ void mc_destroy(mc_ctx *c)
     if (c->d_fatal) (void)hipFree(c->d_fatal);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (char *p : c->pin) if (p) (void)hipHostFree(p);
+    for (hipStream_t st : c->pin_stream) if (st) (void)hipStreamDestroy(st);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -1197,39 +1202,89 @@ int mc_set_stream(mc_ctx *c, void *hip_stream)
     return MC_OK;
 }
 
+static int add_reads_dev_locked(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_off, uint64_t n_reads, uint64_t n_bases);
+
+// Host (pageable) memory to the device.  A plain hipMemcpy of pageable memory stages through one thread; a few
+// threads each staging 8 MB pieces through their own pinned buffers and stream reach the link rate
+// (scripts/microbench/hostreg.hip: 360 MB in 7-14 ms instead of 19 ms, or 176 ms for memory touched first here).
+static int h2d_fast(mc_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    constexpr size_t CHUNK = 8u << 20;
+    constexpr int T = 4;
+    if (bytes < 4 * CHUNK) {
+        HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return MC_OK;
+    }
+    if (!c->pin[0]) {
+        for (int i = 0; i < 2 * T; i++) HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->pin[i]), CHUNK));
+        for (int i = 0; i < T; i++) HIPCHK(c, hipStreamCreateWithFlags(&c->pin_stream[i], hipStreamNonBlocking));
+    }
+    const size_t n_chunks = (bytes + CHUNK - 1) / CHUNK;
+    bool failed[T] = {false, false, false, false};
+    const int device = c->cfg.device;
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++)
+        th.emplace_back([&, t] {
+            if (hipSetDevice(device) != hipSuccess) { failed[t] = true; return; }
+            hipEvent_t ev[2];
+            if (hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) != hipSuccess) { failed[t] = true; return; }
+            bool used[2] = {false, false};
+            int flip = 0;
+            for (size_t ch = (size_t)t; ch < n_chunks; ch += T) {
+                const size_t off = ch * CHUNK, len = std::min(CHUNK, bytes - off);
+                if (used[flip] && hipEventSynchronize(ev[flip]) != hipSuccess) failed[t] = true;
+                memcpy(c->pin[2 * t + flip], static_cast<const char *>(src) + off, len);
+                if (hipMemcpyAsync(static_cast<char *>(dst) + off, c->pin[2 * t + flip], len, hipMemcpyHostToDevice, c->pin_stream[t]) != hipSuccess ||
+                    hipEventRecord(ev[flip], c->pin_stream[t]) != hipSuccess)
+                    failed[t] = true;
+                used[flip] = true;
+                flip ^= 1;
+            }
+            if (hipStreamSynchronize(c->pin_stream[t]) != hipSuccess) failed[t] = true;
+            (void)hipEventDestroy(ev[0]);
+            (void)hipEventDestroy(ev[1]);
+        });
+    for (auto &x : th) x.join();
+    for (bool f : failed)
+        if (f) return fail(c, MC_EHIP, "host-to-device copy failed");
+    return MC_OK;
+}
+
 int mc_add_reads_packed(mc_ctx *c, const uint64_t *words, const uint64_t *off, uint64_t n_reads)
 {
     if (!c) return MC_EINVAL;
     std::lock_guard<std::mutex> g(c->mu);
     if ((!words || !off) && n_reads) return fail(c, MC_EINVAL, "mc_add_reads_packed: null pointer");
     if (n_reads == 0) return MC_OK;
-    for (uint64_t i = 0; i < n_reads; i++)
-        if (off[i + 1] < off[i]) return fail(c, MC_EINVAL, "mc_add_reads_packed: read_offsets not monotone at %llu",
-                                             (unsigned long long)i);
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const uint64_t n_bases = off[n_reads];
+    if (n_bases < off[0]) return fail(c, MC_EINVAL, "mc_add_reads_packed: read_offsets not monotone");
     const uint64_t n_words = (n_bases + 31) / 32 + 1;
     const uint64_t w_begin = off[0] / 32;  // offsets need not start at 0
     DevBuf<uint64_t> dw, doff;
     HIPCHK(c, dw.alloc(n_words - w_begin));
     HIPCHK(c, doff.alloc(n_reads + 1));
-    std::vector<uint64_t> rel(off, off + n_reads + 1);
-    for (auto &x : rel) x -= w_begin * 32;
-    HIPCHK(c, hipMemcpyAsync(dw.p, words + w_begin, (n_words - w_begin) * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(doff.p, rel.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    int rc = add_reads_impl(c, dw.p, doff.p, rel.data(), n_reads);
+    int rc = h2d_fast(c, dw.p, words + w_begin, (n_words - w_begin) * 8);
+    if (rc) return rc;
+    if (w_begin == 0) {
+        rc = h2d_fast(c, doff.p, off, (n_reads + 1) * 8);
+    } else {
+        std::vector<uint64_t> rel(off, off + n_reads + 1);
+        for (auto &x : rel) x -= w_begin * 32;
+        rc = h2d_fast(c, doff.p, rel.data(), (n_reads + 1) * 8);
+    }
+    if (rc) return rc;
+    // (monotone offsets are checked on the device, with the window count: k_reads_summary)
+    rc = add_reads_dev_locked(c, dw.p, doff.p, n_reads, n_bases - w_begin * 32);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return rc;
 }
 
-int mc_add_reads_packed_dev(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_off, uint64_t n_reads,
-                            uint64_t n_bases)
+// reads resident in HBM (the context's lock is held)
+static int add_reads_dev_locked(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_off, uint64_t n_reads, uint64_t n_bases)
 {
-    if (!c) return MC_EINVAL;
-    std::lock_guard<std::mutex> g(c->mu);
-    if ((!d_words || !d_off) && n_reads) return fail(c, MC_EINVAL, "mc_add_reads_packed_dev: null pointer");
-    if (n_reads == 0) return MC_OK;
-    HIPCHK(c, hipSetDevice(c->cfg.device));
     // summary on the device: total windows, monotone offsets, first and last offset
     unsigned long long *sum = c->d_ctr + 4;
     HIPCHK(c, hipMemsetAsync(sum, 0, 2 * sizeof(unsigned long long), c->stream));
@@ -1262,6 +1317,17 @@ int mc_add_reads_packed_dev(mc_ctx *c, const uint64_t *d_words, const uint64_t *
     HIPCHK(c, hipMemcpyAsync(h_off.data(), d_off, (n_reads + 1) * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return add_reads_impl(c, d_words, d_off, h_off.data(), n_reads);
+}
+
+int mc_add_reads_packed_dev(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_off, uint64_t n_reads,
+                            uint64_t n_bases)
+{
+    if (!c) return MC_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    if ((!d_words || !d_off) && n_reads) return fail(c, MC_EINVAL, "mc_add_reads_packed_dev: null pointer");
+    if (n_reads == 0) return MC_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    return add_reads_dev_locked(c, d_words, d_off, n_reads, n_bases);
 }
 
 int mc_add_keys_dev(mc_ctx *c, const int64_t *d_keys, const uint32_t *d_hints, uint64_t n)
