@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cerrno>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -483,7 +484,10 @@ size_t env_size(const char *name, size_t dflt)
 bool load_reads_parallel(const std::string &path, bool fastq, size_t max_reads, const std::function<void(PackedBatch &)> &sink,
                          uint64_t *delivered)
 {
-    size_t n_threads = env_size("MC_INGEST_THREADS", std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 64));
+    const bool dbg = getenv("MC_INGEST_DEBUG") != nullptr;
+    auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = tnow();
+    size_t n_threads = env_size("MC_INGEST_THREADS", std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 128));
     const size_t min_chunk = std::max<size_t>(env_size("MC_INGEST_CHUNK_BYTES", 4u << 20), 64);
     if (n_threads < 2) return false;
     Mapped m;
@@ -531,6 +535,7 @@ bool load_reads_parallel(const std::string &path, bool fastq, size_t max_reads, 
         MemLines src(begin, end);
         if (!parse_fastq(src, [](const char *, size_t) {}, -1, true, &offset, 1) || offset < 0) return false;
     }
+    const double t_cut = tnow();
     struct Part { std::vector<PackedBatch> batches; uint64_t reads = 0; bool ok = true; };
     std::vector<Part> parts(n_threads);
     std::vector<std::thread> threads;
@@ -540,6 +545,10 @@ bool load_reads_parallel(const std::string &path, bool fastq, size_t max_reads, 
             try {
                 PackedBatch batch;
                 batch.clear();
+                // room for the whole chunk up front: growing vectors map and unmap memory, which serialises the threads
+                const size_t chunk_bytes = (size_t)(cut[t + 1] - cut[t]);
+                batch.words.reserve(chunk_bytes / 32 + 16);
+                batch.offsets.reserve(std::min<size_t>(max_reads, chunk_bytes / 64) + 16);
                 auto emit = [&](const char *s, size_t n) {
                     batch.add_read(s, n);
                     P.reads++;
@@ -562,13 +571,74 @@ bool load_reads_parallel(const std::string &path, bool fastq, size_t max_reads, 
             }
         });
     for (auto &th : threads) th.join();
+    const double t_parse = tnow();
     for (const Part &P : parts)
         if (!P.ok) return false;
     *delivered = 0;
-    for (Part &P : parts) {
-        for (PackedBatch &b : P.batches) sink(b);
-        *delivered += P.reads;
+    for (const Part &P : parts) *delivered += P.reads;
+    // Every thread leaves a small batch; handing them over one by one would cost a device launch each.  They are
+    // joined, in file order, into batches of up to max_reads reads: the pieces' words are shifted into place in
+    // parallel (a piece starts wherever the previous one ended, not at a word boundary).
+    std::vector<PackedBatch *> pieces;
+    for (Part &P : parts)
+        for (PackedBatch &b : P.batches)
+            if (b.n_reads()) pieces.push_back(&b);
+    size_t first = 0;
+    while (first < pieces.size()) {
+        size_t last = first;
+        uint64_t reads = 0, bases = 0;
+        std::vector<uint64_t> base_at;  // where each piece starts, in bases
+        while (last < pieces.size() && (last == first || reads + pieces[last]->n_reads() <= max_reads)) {
+            base_at.push_back(bases);
+            reads += pieces[last]->n_reads();
+            bases += pieces[last]->offsets.back();
+            last++;
+        }
+        if (last - first == 1) {
+            sink(*pieces[first]);
+            first = last;
+            continue;
+        }
+        const double t_m0 = tnow();
+        PackedBatch out;
+        out.words.assign((bases + 31) / 32 + 1, 0);
+        out.offsets.resize(reads + 1);
+        out.offsets[0] = 0;
+        std::vector<uint64_t> read_at(last - first);
+        {
+            uint64_t r = 0;
+            for (size_t i = first; i < last; i++) { read_at[i - first] = r; r += pieces[i]->n_reads(); }
+        }
+        std::vector<std::thread> mergers;
+        const size_t n_merge = std::min<size_t>(last - first, n_threads);
+        for (size_t w = 0; w < n_merge; w++)
+            mergers.emplace_back([&, w] {
+                for (size_t i = first + w; i < last; i += n_merge) {
+                    const PackedBatch &b = *pieces[i];
+                    const uint64_t at = base_at[i - first], n_src = (b.offsets.back() + 31) / 32;
+                    const uint64_t dw = at / 32, sh = 2 * (at % 32);
+                    // only the first and the last destination words of a piece can be shared with a neighbour
+                    auto put = [&](uint64_t idx, uint64_t v) {
+                        if (!v) return;
+                        if (idx == dw || idx + 1 >= dw + n_src) __atomic_fetch_or(&out.words[idx], v, __ATOMIC_RELAXED);
+                        else out.words[idx] |= v;
+                    };
+                    for (uint64_t j = 0; j < n_src; j++) {
+                        const uint64_t v = b.words[j];
+                        put(dw + j, sh ? (v >> sh) : v);
+                        if (sh) put(dw + j + 1, v << (64 - sh));
+                    }
+                    const uint64_t r0 = read_at[i - first];
+                    for (uint64_t r = 0; r < b.n_reads(); r++) out.offsets[r0 + r + 1] = at + b.offsets[r + 1];
+                }
+            });
+        for (auto &th : mergers) th.join();
+        const double t_m = tnow();
+        sink(out);
+        if (dbg) fprintf(stderr, "[ingest] merged %zu pieces (%llu reads) in %.3f s, sink %.3f s\n", last - first, (unsigned long long)reads, t_m - t_m0, tnow() - t_m);
+        first = last;
     }
+    if (dbg) fprintf(stderr, "[ingest] %zu threads: map+cut+sniff %.3f s, parse %.3f s, merge+sink %.3f s\n", n_threads, t_cut - t_begin, t_parse - t_cut, tnow() - t_parse);
     return true;
 }
 
