@@ -260,18 +260,48 @@ void PackedBatch::clear()
     offsets.assign(1, 0);
 }
 
+namespace {
+struct CodeLut {  // A0 G1 C2 T3 (either case), 0xFF otherwise
+    uint8_t v[256];
+    CodeLut()
+    {
+        memset(v, 0xFF, sizeof v);
+        v[(unsigned char)'A'] = v[(unsigned char)'a'] = 0;
+        v[(unsigned char)'G'] = v[(unsigned char)'g'] = 1;
+        v[(unsigned char)'C'] = v[(unsigned char)'c'] = 2;
+        v[(unsigned char)'T'] = v[(unsigned char)'t'] = 3;
+    }
+};
+const CodeLut CODE_LUT;
+}  // namespace
+
 void PackedBatch::add_read(const char *s, size_t n)
 {
     if (offsets.empty()) offsets.assign(1, 0);
     uint64_t pos = offsets.back();
     words.resize((pos + n + 31) / 32, 0);
-    for (size_t i = 0; i < n; i++, pos++) {
-        const int code = code_of(s[i]);
-        if (code < 0)
-            throw Error(std::string("read contains the character '") + s[i] +
-                        "': IUPAC codes other than N are replaced at random by the reference "
-                        "(itmo!/dna/DnaTools.java:66-117), which has no defined result; rejecting the input");
-        words[pos >> 5] |= (uint64_t)code << (62 - 2 * (pos & 31));
+    // a word at a time: the open word is completed, then whole words of 32 bases, then the tail
+    size_t i = 0;
+    uint32_t bad = 0;
+    uint64_t *w = words.data();
+    while (i < n) {
+        const uint32_t in_word = (uint32_t)(pos & 31), take = (uint32_t)std::min<size_t>(32 - in_word, n - i);
+        uint64_t acc = 0;
+        for (uint32_t j = 0; j < take; j++) {
+            const uint8_t c = CODE_LUT.v[(unsigned char)s[i + j]];
+            bad |= c;
+            acc = (acc << 2) | (c & 3u);
+        }
+        w[pos >> 5] |= acc << (2 * (32 - in_word - take));
+        pos += take;
+        i += take;
+    }
+    if (bad & 0x80) {
+        for (size_t q = 0; q < n; q++)
+            if (code_of(s[q]) < 0)
+                throw Error(std::string("read contains the character '") + s[q] +
+                            "': IUPAC codes other than N are replaced at random by the reference "
+                            "(itmo!/dna/DnaTools.java:66-117), which has no defined result; rejecting the input");
     }
     offsets.push_back(pos);
 }
@@ -379,6 +409,8 @@ void parse_fasta(Src &src, Emit &&emit)
     while (src.getline(line)) {
         if (!line.empty() && (line[0] == '>' || line[0] == ';')) {
             if (!sb.empty()) flush();
+        } else if (sb.empty()) {
+            sb.swap(line);  // (the usual single-line record is not copied again)
         } else {
             sb += line;
         }
