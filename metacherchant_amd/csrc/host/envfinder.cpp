@@ -439,24 +439,24 @@ bool parse_fastq(Src &src, Emit &&emit, int offset, bool strict, int *sniffed = 
     };
     std::vector<std::pair<std::string, std::string>> head;  // the records the offset is sniffed on
     auto process = [&](const std::string &d, const std::string &q) {
-        std::string piece;
-        for (size_t i = 0; i < d.size(); i++) {
-            int ph;
-            if (d[i] == 'N' || d[i] == 'n' || d[i] == '.') {
-                ph = 0;
-            } else {
+        // truncateByQuality(1): a base with phred < 1 (or N n .) ends the piece and is dropped; pieces go out straight
+        // from the line
+        size_t start = 0;
+        const size_t n = d.size();
+        for (size_t i = 0; i < n; i++) {
+            const unsigned char c = (unsigned char)d[i];
+            bool bad = c == 'N' || c == 'n' || c == '.';
+            if (!bad) {
                 const int qc = (unsigned char)q[i];
                 if (qc < offset || qc > 126) throw Error("Invalid quality code char");
-                ph = qc - offset;
+                bad = qc - offset < 1;
             }
-            if (ph < 1) {  // truncateByQuality(1): the piece ends here and the bad base is dropped
-                if (!piece.empty()) emit(piece.data(), piece.size());
-                piece.clear();
-            } else {
-                piece.push_back(d[i]);
+            if (bad) {
+                if (i > start) emit(d.data() + start, i - start);
+                start = i + 1;
             }
         }
-        if (!piece.empty()) emit(piece.data(), piece.size());
+        if (n > start) emit(d.data() + start, n - start);
     };
     auto sniff = [&] {
         offset = 64;
