@@ -717,47 +717,207 @@ uint64_t load_reads_file(const std::string &path, size_t max_reads, const std::f
 
 // ------------------------------------------------------------------------------------------ Environment
 
+// ---- packed k-mers
+
+kmer_t pack_kmer128(const std::string &s)
+{
+    uint64_t hi, lo;
+    pack_kmer(s, &hi, &lo);
+    return ((kmer_t)hi << 64) | lo;
+}
+
+static inline uint64_t reverse_pairs64(uint64_t x)
+{
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+    return __builtin_bswap64(x);
+}
+
+kmer_t reverse_complement128(kmer_t v, int k)
+{
+    // complement is 3 - code (A0<->T3, G1<->C2); then the 2-bit groups in reverse order
+    const kmer_t c = ~v;
+    const kmer_t r = ((kmer_t)reverse_pairs64((uint64_t)c) << 64) | reverse_pairs64((uint64_t)(c >> 64));
+    return r >> (128 - 2 * k);
+}
+
+// ASCII order is A < C < G < T, the codes are A0 G1 C2 T3: swapping the two bits of every code gives ranks
+// whose numeric order is String.compareTo's
+static inline kmer_t ascii_rank(kmer_t v)
+{
+    const kmer_t m = ((kmer_t)0x5555555555555555ull << 64) | 0x5555555555555555ull;
+    return ((v & m) << 1) | ((v >> 1) & m);
+}
+
+kmer_t normalize128(kmer_t v, int k)
+{
+    const kmer_t rc = reverse_complement128(v, k);
+    return ascii_rank(v) < ascii_rank(rc) ? v : rc;
+}
+
+static inline kmer_t kmer_mask(int bases) { return bases >= 64 ? ~(kmer_t)0 : (((kmer_t)1 << (2 * bases)) - 1); }
+
+// ---- JavaKmerMap
+
+JavaKmerMap::JavaKmerMap(int k) : k_(k), head_(16, NIL), tail_(16, NIL) {}
+
+uint32_t JavaKmerMap::hash_of(kmer_t key) const
+{
+    uint32_t h = 0;  // String.hashCode() of the k characters, then HashMap.hash()'s spread
+    for (int i = k_ - 1; i >= 0; i--) h = 31u * h + (uint32_t)(unsigned char)"AGCT"[(unsigned)(key >> (2 * i)) & 3u];
+    return h ^ (h >> 16);
+}
+
+int JavaKmerMap::find_entry(kmer_t key) const
+{
+    const uint32_t h = hash_of(key);
+    for (uint32_t e = head_[h & (cap_ - 1)]; e != NIL; e = entries_[e].next)
+        if (entries_[e].key == key) return (int)e;
+    return -1;
+}
+
+int JavaKmerMap::put(kmer_t key, int value)
+{
+    const uint32_t h = hash_of(key);
+    const size_t b = h & (cap_ - 1);
+    size_t len = 0;
+    for (uint32_t e = head_[b]; e != NIL; e = entries_[e].next, len++)
+        if (entries_[e].key == key) {
+            entries_[e].value = value;
+            return (int)e;
+        }
+    const uint32_t e = (uint32_t)entries_.size();
+    entries_.push_back(Entry{key, value, h, NIL});
+    if (tail_[b] == NIL) head_[b] = e; else entries_[tail_[b]].next = e;
+    tail_[b] = e;
+    if (len + 1 >= 9) {  // a 9th node: treeifyBin (or a resize while the table is smaller than 64)
+        if (cap_ >= 64) treeified_ = true; else resize();
+    }
+    size_++;
+    if ((double)size_ > 0.75 * (double)cap_) resize();
+    return (int)e;
+}
+
+void JavaKmerMap::resize()
+{
+    const size_t ncap = cap_ * 2;
+    std::vector<uint32_t> nh(ncap, NIL), nt(ncap, NIL);
+    for (uint32_t h : head_)
+        for (uint32_t e = h, nx; e != NIL; e = nx) {  // lo/hi split keeps relative order
+            nx = entries_[e].next;
+            const size_t b = entries_[e].hash & (ncap - 1);
+            entries_[e].next = NIL;
+            if (nt[b] == NIL) nh[b] = e; else entries_[nt[b]].next = e;
+            nt[b] = e;
+        }
+    cap_ = ncap;
+    head_.swap(nh);
+    tail_.swap(nt);
+}
+
+void JavaKmerMap::remove(kmer_t key)
+{
+    const size_t b = hash_of(key) & (cap_ - 1);
+    uint32_t prev = NIL;
+    for (uint32_t e = head_[b]; e != NIL; prev = e, e = entries_[e].next)
+        if (entries_[e].key == key) {
+            if (prev == NIL) head_[b] = entries_[e].next; else entries_[prev].next = entries_[e].next;
+            if (tail_[b] == e) tail_[b] = prev;
+            size_--;
+            return;
+        }
+}
+
+// ---- Environment
+
+Environment::Environment(int k, std::vector<std::string> gene_sequences) : k_(k), genes_(std::move(gene_sequences)), subgraph_(k)
+{
+    if (k < 1 || k > 63) throw Error("Environment: k must be in 1..63");
+    // isGeneNode (:313-320) is `gene.contains(seq) || gene.contains(rc)` on k-long node labels: a lookup in the
+    // set of the genes' k-windows.  Labels are upper-case ACGT, so windows holding anything else never match.
+    for (const std::string &g : genes_) {
+        kmer_t v = 0;
+        int valid = 0;
+        for (char c : g) {
+            int code;
+            switch (c) {
+            case 'A': code = 0; break;
+            case 'G': code = 1; break;
+            case 'C': code = 2; break;
+            case 'T': code = 3; break;
+            default: code = -1;
+            }
+            if (code < 0) { valid = 0; continue; }
+            v = ((v << 2) | (unsigned)code) & kmer_mask(k_);
+            if (++valid >= k_) gene_kmers_.push_back(v);
+        }
+    }
+    std::sort(gene_kmers_.begin(), gene_kmers_.end());
+    gene_kmers_.erase(std::unique(gene_kmers_.begin(), gene_kmers_.end()), gene_kmers_.end());
+}
+
 void Environment::add_pass(const BfsPass &p, bool trim)
 {
-    JavaHashMap d;  // distanceToKmer
-    for (size_t i = 0; i < p.kmers.size(); i++) d.put(p.kmers[i], p.dist[i]);
+    JavaKmerMap d(k_);  // distanceToKmer
+    std::vector<int16_t> cov;  // by entry of d
+    cov.reserve(p.kmers.size());
+    for (size_t i = 0; i < p.kmers.size(); i++) {
+        const size_t e = (size_t)d.put(p.kmers[i], p.dist[i]);
+        if (e >= cov.size()) cov.resize(e + 1);
+        cov[e] = p.cov[i];
+    }
     if (trim) {
         // runTrimPaths: reverse BFS from lastKmers through getNeighborsByDir(-dir) inside distanceToKmer
-        std::vector<std::string> queue;
-        std::set<std::string> visited;
-        for (size_t i = 0; i < p.kmers.size(); i++)
-            if (p.last[i] && visited.insert(p.kmers[i]).second) queue.push_back(p.kmers[i]);
-        for (size_t head = 0; head < queue.size(); head++) {
-            const std::string kmer = queue[head];
-            for (const std::string &nb : neighbors_by_dir(-p.dir, kmer))
-                if (d.contains(nb) && visited.insert(nb).second) queue.push_back(nb);
+        std::vector<kmer_t> queue;
+        std::vector<uint8_t> visited(d.n_entries(), 0);
+        for (size_t i = 0; i < p.kmers.size(); i++) {
+            const int e = d.find_entry(p.kmers[i]);
+            if (p.last[i] && !visited[(size_t)e]) { visited[(size_t)e] = 1; queue.push_back(p.kmers[i]); }
         }
-        for (const std::string &s : p.kmers)  // keySet().retainAll(visitedKmers): no reordering
-            if (!visited.count(s)) d.remove(s);
+        const int dir = -p.dir;
+        const int top = 2 * (k_ - 1);
+        for (size_t head = 0; head < queue.size(); head++) {
+            const kmer_t kmer = queue[head];
+            for (unsigned c = 0; c < 4; c++) {  // A, G, C, T; dir 0 interleaves left and right
+                kmer_t nb[2];
+                int n = 0;
+                if (dir != 1) nb[n++] = ((kmer_t)c << top) | (kmer >> 2);
+                if (dir != -1) nb[n++] = ((kmer << 2) & kmer_mask(k_)) | c;
+                for (int j = 0; j < n; j++) {
+                    const int e = d.find_entry(nb[j]);
+                    if (e >= 0 && !visited[(size_t)e]) { visited[(size_t)e] = 1; queue.push_back(nb[j]); }
+                }
+            }
+        }
+        for (const kmer_t s : p.kmers) {  // keySet().retainAll(visitedKmers): no reordering
+            const int e = d.find_entry(s);
+            if (e >= 0 && !visited[(size_t)e]) d.remove(s);
+        }
     }
-    std::unordered_map<std::string, int> cov;
-    for (size_t i = 0; i < p.kmers.size(); i++) cov[p.kmers[i]] = p.cov[i];
-    d.for_each([&](const std::string &kmer, int) { subgraph_.put(normalize_dna(kmer), cov[kmer]); });
+    d.for_each([&](kmer_t kmer, int, int e) { subgraph_.put(normalize128(kmer, k_), cov[(size_t)e]); });
     if (d.treeified()) d_treeified_ = true;
+}
+
+static inline void append_uint(std::string &out, unsigned long long v)
+{
+    char buf[24];
+    int n = 0;
+    do { buf[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) out.push_back(buf[--n]);
 }
 
 std::string Environment::graph_txt() const
 {
     std::string out;
-    subgraph_.for_each([&](const std::string &k, int v) {
-        out += k;
-        out += ' ';
-        out += std::to_string(v);
-        out += '\n';
+    out.reserve(subgraph_.size() * (size_t)(k_ + 8));
+    subgraph_.for_each([&](kmer_t key, int v, int) {
+        for (int i = k_ - 1; i >= 0; i--) out.push_back("AGCT"[(unsigned)(key >> (2 * i)) & 3u]);
+        out.push_back(' ');
+        if (v < 0) { out.push_back('-'); append_uint(out, (unsigned long long)(-(long long)v)); }
+        else append_uint(out, (unsigned long long)v);
+        out.push_back('\n');
     });
     return out;
-}
-
-bool Environment::is_gene_node(const std::string &seq, const std::string &rc) const
-{
-    for (const std::string &g : genes_)
-        if (g.find(seq) != std::string::npos || g.find(rc) != std::string::npos) return true;
-    return false;
 }
 
 void Environment::merge_nodes(int first_plus, int second_minus)
@@ -782,21 +942,42 @@ void Environment::create_picture()
 {
     // initializeStructures
     nodes_.clear();
-    subgraph_.for_each([&](const std::string &seq, int) {
-        const std::string rc = reverse_complement(seq);
-        const bool g = is_gene_node(seq, rc);
+    nodes_.reserve(2 * subgraph_.size());
+    std::vector<kmer_t> packed;  // by node id
+    packed.reserve(2 * subgraph_.size());
+    subgraph_.for_each([&](kmer_t seq, int, int) {
+        const kmer_t rc = reverse_complement128(seq, k_);
+        const bool g = std::binary_search(gene_kmers_.begin(), gene_kmers_.end(), seq) ||
+                       std::binary_search(gene_kmers_.begin(), gene_kmers_.end(), rc);
         const int id = (int)nodes_.size();
-        nodes_.push_back(Node{seq, id, g, false, id + 1, {}});
-        nodes_.push_back(Node{rc, id + 1, g, false, id, {}});
+        nodes_.push_back(Node{unpack_kmer128(seq, k_), id, g, false, id + 1, {}});
+        nodes_.push_back(Node{unpack_kmer128(rc, k_), id + 1, g, false, id, {}});
+        packed.push_back(seq);
+        packed.push_back(rc);
     });
-    std::unordered_map<std::string, std::vector<int>> by_prefix;
-    for (const Node &n : nodes_) by_prefix[n.sequence.substr(0, (size_t)(k_ - 1))].push_back(n.id);
-    for (size_t i = 0; i < nodes_.size(); i++) {
-        auto it = by_prefix.find(nodes_[i].sequence.substr(1));
-        if (it != by_prefix.end()) {
-            auto &dst = nodes_[(size_t)nodes_[i].rc].neighbors;
-            dst.insert(dst.end(), it->second.begin(), it->second.end());
-        }
+    // node ids by (k-1)-prefix, in node order: an open-addressing table of chains threaded through next[]
+    const size_t n = nodes_.size();
+    size_t cap = 16;
+    while (cap < 2 * n) cap *= 2;
+    struct Slot { kmer_t key; int head, tail; };
+    std::vector<Slot> slots(cap, Slot{0, -1, -1});
+    std::vector<int> next(n, -1);
+    auto slot_of = [&](kmer_t key) {
+        uint64_t h = (uint64_t)key ^ ((uint64_t)(key >> 64) * 0x9E3779B97F4A7C15ull);
+        h ^= h >> 33; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 33; h *= 0xC4CEB9FE1A85EC53ull; h ^= h >> 33;
+        size_t i = (size_t)h & (cap - 1);
+        while (slots[i].head >= 0 && slots[i].key != key) i = (i + 1) & (cap - 1);
+        return i;
+    };
+    for (size_t i = 0; i < n; i++) {
+        Slot &sl = slots[slot_of(packed[i] >> 2)];
+        if (sl.head < 0) { sl.key = packed[i] >> 2; sl.head = (int)i; } else next[(size_t)sl.tail] = (int)i;
+        sl.tail = (int)i;
+    }
+    const kmer_t suffix_mask = kmer_mask(k_ - 1);
+    for (size_t i = 0; i < n; i++) {
+        auto &dst = nodes_[(size_t)nodes_[i].rc].neighbors;
+        for (int j = slots[slot_of(packed[i] & suffix_mask)].head; j >= 0; j = next[(size_t)j]) dst.push_back(j);
     }
     // doMerge
     for (;;) {
@@ -848,8 +1029,19 @@ std::string Environment::graph_gfa() const
         if (n.deleted || n.sequence.compare(nodes_[(size_t)n.rc].sequence) > 0) continue;
         long long coverage = 0;
         const std::string &s = n.sequence;
-        for (size_t i = 0; i + (size_t)k_ <= s.size(); i++) coverage += subgraph_.get(normalize_dna(s.substr(i, (size_t)k_)));
-        coverage += (long long)subgraph_.get(normalize_dna(s.substr(s.size() - (size_t)k_))) * (k_ - 1);
+        kmer_t fw = 0, rc = 0;  // the window and its reverse complement, rolled along the label
+        int last = 0;
+        for (size_t i = 0; i < s.size(); i++) {
+            const unsigned code = (unsigned)code_of(s[i]);
+            fw = ((fw << 2) | code) & kmer_mask(k_);
+            rc = (rc >> 2) | ((kmer_t)(3u - code) << (2 * (k_ - 1)));
+            if (i + 1 < (size_t)k_) continue;
+            const int e = subgraph_.find_entry(ascii_rank(fw) < ascii_rank(rc) ? fw : rc);
+            if (e < 0) throw Error("graph_gfa: k-mer of a node label is not in the subgraph: " + s.substr(i + 1 - (size_t)k_, (size_t)k_));
+            last = subgraph_.value_at(e);
+            coverage += last;
+        }
+        coverage += (long long)last * (k_ - 1);
         out += "S\t" + node_id(n) + "\t" + s + "\tLN:i:" + std::to_string(s.size()) + "\tKC:i:" + std::to_string(coverage) +
                (n.is_gene ? "\tCL:Z:GREEN" : "") + "\n";
     }

@@ -77,10 +77,50 @@ struct PackedBatch {
 // Calls sink(batch) for every max_reads reads; returns the number of reads (pieces) delivered.
 uint64_t load_reads_file(const std::string &path, size_t max_reads, const std::function<void(PackedBatch &)> &sink);
 
+// ---- 2-bit packed k-mers (k <= 63): base i of the string is bits 2(k-1-i)+1..2(k-1-i), codes A0 G1 C2 T3,
+// the layout of mc_bfs_result's hi/lo words (include/mcgpu.h)
+typedef unsigned __int128 kmer_t;
+kmer_t pack_kmer128(const std::string &s);
+inline std::string unpack_kmer128(kmer_t v, int k) { return unpack_kmer((uint64_t)(v >> 64), (uint64_t)v, k); }
+kmer_t reverse_complement128(kmer_t v, int k);
+kmer_t normalize128(kmer_t v, int k);  // the packed form of normalize_dna(string)
+
+// java.util.HashMap<String, Integer> over k-mer strings held packed: the same bins, resize points, in-bin
+// order and treeify detection as JavaHashMap, with String.hashCode() evaluated on the characters the
+// packed key stands for.  Entries are chained per bin the way the JDK chains them.
+class JavaKmerMap {
+public:
+    explicit JavaKmerMap(int k);
+    int put(kmer_t key, int value);   // entry index; an existing key keeps its place and gets the value
+    int find_entry(kmer_t key) const;  // -1 when absent
+    int value_at(int e) const { return entries_[(size_t)e].value; }
+    void remove(kmer_t key);
+    size_t size() const { return size_; }
+    size_t n_entries() const { return entries_.size(); }  // removed ones included: bound of the entry indices
+    bool treeified() const { return treeified_; }
+    template <typename F>
+    void for_each(F &&f) const  // f(key, value, entry index) in HashMap iteration order
+    {
+        for (uint32_t h : head_)
+            for (uint32_t e = h; e != NIL; e = entries_[e].next) f(entries_[e].key, entries_[e].value, (int)e);
+    }
+
+private:
+    static constexpr uint32_t NIL = 0xFFFFFFFFu;
+    struct Entry { kmer_t key; int value; uint32_t hash, next; };
+    uint32_t hash_of(kmer_t key) const;
+    void resize();
+    int k_;
+    std::vector<Entry> entries_;
+    std::vector<uint32_t> head_, tail_;
+    size_t cap_ = 16, size_ = 0;
+    bool treeified_ = false;
+};
+
 // ---- one runBfs pass as delivered by mc_bfs_batch (or by a dump file in the CPU tests)
 struct BfsPass {
     int dir = 0;
-    std::vector<std::string> kmers;  // distanceToKmer insertion order
+    std::vector<kmer_t> kmers;  // distanceToKmer insertion order
     std::vector<int32_t> dist;
     std::vector<int16_t> cov;
     std::vector<uint8_t> last;
@@ -90,7 +130,7 @@ struct BfsPass {
 // src/io/writers/GFAWriter.java + src/io/writers/TSVWriter.java
 class Environment {
 public:
-    Environment(int k, std::vector<std::string> gene_sequences) : k_(k), genes_(std::move(gene_sequences)) {}
+    Environment(int k, std::vector<std::string> gene_sequences);
     // :217-219 (+ runTrimPaths :241-262 when trim): distanceToKmer -> subgraph
     void add_pass(const BfsPass &p, bool trim);
     size_t size() const { return subgraph_.size(); }
@@ -112,12 +152,12 @@ private:
         int rc;                      // index of the reverse-complement node
         std::vector<int> neighbors;  // successors of rc(this), in node-array order
     };
-    bool is_gene_node(const std::string &seq, const std::string &rc) const;
     void merge_nodes(int first_plus, int second_minus);
     std::string node_id(const Node &n) const;
     int k_;
     std::vector<std::string> genes_;
-    JavaHashMap subgraph_;
+    std::vector<kmer_t> gene_kmers_;  // sorted: every k-window of the gene sequences, for isGeneNode
+    JavaKmerMap subgraph_;
     bool d_treeified_ = false;
     std::vector<Node> nodes_;
 };

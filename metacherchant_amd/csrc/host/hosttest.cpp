@@ -66,7 +66,9 @@ int main(int argc, char **argv)
             pass.kmers.resize(n); pass.dist.resize(n); pass.cov.resize(n); pass.last.resize(n);
             for (size_t i = 0; i < n; i++) {
                 int d, c, l;
-                f >> pass.kmers[i] >> d >> c >> l;
+                std::string kmer;
+                f >> kmer >> d >> c >> l;
+                pass.kmers[i] = pack_kmer128(kmer);
                 pass.dist[i] = d; pass.cov[i] = (int16_t)c; pass.last[i] = (uint8_t)l;
             }
             env.add_pass(pass, trim != 0);

@@ -427,7 +427,7 @@ int run(const Options &o)
             BfsPass p;
             p.dir = dirs[d];
             p.kmers.reserve(r.n);
-            for (uint64_t i = 0; i < r.n; i++) p.kmers.push_back(unpack_kmer(r.hi[i], r.lo[i], o.k));
+            for (uint64_t i = 0; i < r.n; i++) p.kmers.push_back(((kmer_t)r.hi[i] << 64) | r.lo[i]);
             p.dist.assign(r.dist, r.dist + r.n);
             p.cov.assign(r.cov, r.cov + r.n);
             p.last.assign(r.last, r.last + r.n);

@@ -94,6 +94,29 @@ def test_branching_graph_trim_and_bothdirs(hosttest, tmp_path, trim, bothdirs):
     _compare(hosttest, tmp_path, k, [gene], passes, trim, 25)
 
 
+@pytest.mark.parametrize("k,mode", [(5, po.KEY_PACKED), (32, po.KEY_POLY), (47, po.KEY_FNV1A), (63, po.KEY_POLY)])
+def test_packed_labels_at_k_extremes(hosttest, tmp_path, k, mode):
+    """The host keeps node labels 2-bit packed in 128 bits: shortest labels (every bin of the subgraph map
+    crowded), the first k past one word, and the longest k the ABI takes."""
+    rng = np.random.default_rng(k)
+    genome = rng.integers(0, 4, 1500).astype(np.uint8)
+    genome[700:760] = genome[200:260]  # a repeat, so the graph branches
+    L, n = 100, 600
+    starts = rng.integers(0, len(genome) - L, n)
+    reads = np.concatenate([genome[s:s + L] for s in starts])
+    off = np.arange(n + 1, dtype=np.uint64) * L
+    t = po.Table()
+    t.count_reads(reads, off, k, mode)
+    seed = genome[400:520]
+    for trim in (False, True):
+        passes = []
+        for d in (-1, 1):
+            r = po.bfs(t, k, mode, [seed], d, 2, 500, 200, trim)
+            assert r is not None
+            passes.append((d, r))
+        _compare(hosttest, tmp_path, k, [po.decode(seed)], passes, trim, 1)
+
+
 def test_seed_reader(hosttest, golden_dir, tmp_path):
     def run(path):
         out = subprocess.check_output([hosttest, "seeds", path]).decode().splitlines()
