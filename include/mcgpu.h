@@ -102,8 +102,8 @@ int mc_add_reads_packed_dev(mc_ctx *ctx, const uint64_t *d_words, const uint64_t
 
 /* One input file of --reads: ReadsWorker.run / ReadersUtils.readDnaLazyTrunc (src/io/ReadsWorker.java:29-41,
  * itmo!/io/ReadersUtils.java:27-53,104-121): format by extension (.fasta .fa .fn .fna / .fastq .fq, optionally
- * .gz), FASTA records with N dropped whole, FASTQ reads split where phred < 1 (quality offset sniffed on the
- * first 1000 records); every read (piece) is counted as by mc_add_reads_packed.  *n_reads (may be NULL) = reads
+ * .gz or .bz2; .binq), FASTA records with N dropped whole, FASTQ and BINQ reads split where phred < 1 (quality
+ * offset sniffed on the first 1000 records); every read (piece) is counted as by mc_add_reads_packed.  *n_reads (may be NULL) = reads
  * added ("N reads added").  Errors carry the reference's messages ("Can't detect file format for file ..."). */
 int mc_add_reads_file(mc_ctx *ctx, const char *path, uint64_t *n_reads);
 

@@ -40,7 +40,7 @@ def build_lib(force=False, verbose=False):
     if not force and not _stale(LIB, deps):
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra",
-           "-I", os.path.join(ROOT, "include"), "-o", LIB] + srcs + ["-lz"]
+           "-I", os.path.join(ROOT, "include"), "-o", LIB] + srcs + ["-lz", "-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -58,13 +58,13 @@ def build_host(force=False, verbose=False):
     hdrs = [os.path.join(hdir, "envfinder.h"), os.path.join(ROOT, "include", "mcgpu.h")]
     flags = ["-O2", "-std=c++17", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include")]
     if force or _stale(HOSTTEST, common + hdrs + [os.path.join(hdir, "hosttest.cpp")]):
-        cmd = ["g++"] + flags + ["-o", HOSTTEST, os.path.join(hdir, "hosttest.cpp")] + common + ["-lz"]
+        cmd = ["g++"] + flags + ["-o", HOSTTEST, os.path.join(hdir, "hosttest.cpp")] + common + ["-lz", "-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
     if os.path.exists(LIB) and (force or _stale(CLI, common + hdrs + [os.path.join(hdir, "main.cpp"), LIB])):
         cmd = ["g++"] + flags + ["-o", CLI, os.path.join(hdir, "main.cpp")] + common + [
-            "-L", LIBDIR, "-lmcgpu", "-Wl,-rpath,$ORIGIN", "-lpthread", "-lz"]
+            "-L", LIBDIR, "-lmcgpu", "-Wl,-rpath,$ORIGIN", "-lpthread", "-lz", "-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

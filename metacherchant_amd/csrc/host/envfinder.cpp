@@ -1,6 +1,7 @@
 // See envfinder.h.  Every function restates the reference lines cited there.
 #include "envfinder.h"
 
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <unistd.h>
@@ -324,55 +325,155 @@ static std::string lower(std::string s)
     return s;
 }
 
-// Lines of a text file, plain or gzip (itmo!/io/readers/FastaGZReader.java, FastqGZReader.java: the same
-// readers over a java.util.zip.GZIPInputStream; concatenated gzip members read on, as there).
+// Bytes of a file, plain, gzip or bzip2 (itmo!/io/readers/FastaGZReader.java, FastqGZReader.java: the same readers
+// over a java.util.zip.GZIPInputStream; FastaBZ2Reader.java:27, FastqBZ2Reader.java: over Hadoop's BZip2Codec
+// stream; concatenated members / streams read on, as there).  bzip2 goes through the system's libbz2.so.1.0, loaded
+// when the first .bz2 file is opened: its 1.0 ABI (bz_stream + BZ2_bzDecompress*) is declared here because the
+// image ships the library without its header.
 namespace {
-class LineSource {
-public:
-    LineSource(const std::string &path, bool gz) : gz_(gz)
+enum Compression { COMP_NONE, COMP_GZ, COMP_BZ2 };
+
+struct Bz2Api {
+    struct Stream {
+        char *next_in; unsigned avail_in, total_in_lo32, total_in_hi32;
+        char *next_out; unsigned avail_out, total_out_lo32, total_out_hi32;
+        void *state;
+        void *(*bzalloc)(void *, int, int);
+        void (*bzfree)(void *, void *);
+        void *opaque;
+    };
+    int (*init)(Stream *, int, int) = nullptr;
+    int (*run)(Stream *) = nullptr;
+    int (*end)(Stream *) = nullptr;
+    static const Bz2Api &get()
     {
-        if (gz_) {
+        static const Bz2Api api = [] {
+            Bz2Api a;
+            void *h = dlopen("libbz2.so.1.0", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("libbz2.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (h) {
+                a.init = (int (*)(Stream *, int, int))dlsym(h, "BZ2_bzDecompressInit");
+                a.run = (int (*)(Stream *))dlsym(h, "BZ2_bzDecompress");
+                a.end = (int (*)(Stream *))dlsym(h, "BZ2_bzDecompressEnd");
+            }
+            return a;
+        }();
+        if (!api.init || !api.run || !api.end) throw Error("bzip2 input needs libbz2.so.1.0, which could not be loaded");
+        return api;
+    }
+};
+
+class ByteSource {
+public:
+    ByteSource(const std::string &path, Compression comp) : comp_(comp)
+    {
+        if (comp_ == COMP_GZ) {
             g_ = gzopen(path.c_str(), "rb");
             if (!g_) throw Error("Failed to read from file " + path);
             gzbuffer(g_, 1u << 20);
         } else {
-            f_.open(path, std::ios::binary);
+            f_ = fopen(path.c_str(), "rb");
             if (!f_) throw Error("Failed to read from file " + path);
+            if (comp_ == COMP_BZ2) {
+                bz_ = &Bz2Api::get();
+                in_.resize(1u << 20);
+                memset(&bs_, 0, sizeof bs_);
+            }
         }
     }
-    ~LineSource() { if (g_) gzclose(g_); }
-    LineSource(const LineSource &) = delete;
-    LineSource &operator=(const LineSource &) = delete;
+    ~ByteSource()
+    {
+        if (g_) gzclose(g_);
+        if (bz_open_) bz_->end(&bs_);
+        if (f_) fclose(f_);
+    }
+    ByteSource(const ByteSource &) = delete;
+    ByteSource &operator=(const ByteSource &) = delete;
+    // up to n bytes; 0 at the end of the data
+    size_t read(char *dst, size_t n)
+    {
+        if (comp_ == COMP_NONE) return fread(dst, 1, n, f_);
+        if (comp_ == COMP_GZ) {
+            const int got = gzread(g_, dst, (unsigned)std::min<size_t>(n, 1u << 30));
+            if (got < 0) throw Error("Failed to decompress the input (corrupt gzip stream)");
+            return (size_t)got;
+        }
+        size_t done = 0;
+        while (done < n && !bz_eof_) {
+            if (bs_.avail_in == 0) {
+                bs_.next_in = in_.data();
+                bs_.avail_in = (unsigned)fread(in_.data(), 1, in_.size(), f_);
+                if (bs_.avail_in == 0) {
+                    if (bz_open_) throw Error("Failed to decompress the input (truncated bzip2 stream)");
+                    bz_eof_ = true;  // the file ends between two streams
+                    break;
+                }
+            }
+            if (!bz_open_) {
+                if (bz_->init(&bs_, 0, 0) != 0) throw Error("Failed to decompress the input (bzip2 initialisation)");
+                bz_open_ = true;
+            }
+            bs_.next_out = dst + done;
+            bs_.avail_out = (unsigned)std::min<size_t>(n - done, 1u << 30);
+            const unsigned before = bs_.avail_out;
+            const int rc = bz_->run(&bs_);
+            done += before - bs_.avail_out;
+            if (rc == 4) {  // BZ_STREAM_END: another stream may follow
+                bz_->end(&bs_);
+                bz_open_ = false;
+            } else if (rc != 0) {
+                throw Error("Failed to decompress the input (corrupt bzip2 stream)");
+            }
+        }
+        return done;
+    }
+
+private:
+    Compression comp_;
+    gzFile g_ = nullptr;
+    FILE *f_ = nullptr;
+    const Bz2Api *bz_ = nullptr;
+    Bz2Api::Stream bs_;
+    std::vector<char> in_;
+    bool bz_open_ = false, bz_eof_ = false;
+};
+
+// Lines of such a file ('\n' ends a line, one trailing '\r' comes off)
+class LineSource {
+public:
+    LineSource(const std::string &path, Compression comp) : src_(path, comp), buf_(1u << 20) {}
     bool getline(std::string &l)
     {
-        if (!gz_) {
-            if (!std::getline(f_, l)) return false;
-        } else {
-            l.clear();
-            char buf[1 << 16];
-            bool any = false;
-            for (;;) {
-                if (!gzgets(g_, buf, (int)sizeof buf)) {
-                    int err = 0;
-                    (void)gzerror(g_, &err);
-                    if (err != Z_OK && err != Z_STREAM_END) throw Error("Failed to decompress the input (corrupt gzip stream)");
+        l.clear();
+        bool any = false;
+        for (;;) {
+            if (pos_ == len_) {
+                len_ = src_.read(buf_.data(), buf_.size());
+                pos_ = 0;
+                if (len_ == 0) {
                     if (!any) return false;
                     break;
                 }
-                any = true;
-                const size_t n = strlen(buf);
-                l.append(buf, n);
-                if (n && buf[n - 1] == '\n') { l.pop_back(); break; }
             }
+            any = true;
+            const char *b = buf_.data() + pos_;
+            const char *nl = (const char *)memchr(b, '\n', len_ - pos_);
+            if (nl) {
+                l.append(b, (size_t)(nl - b));
+                pos_ += (size_t)(nl - b) + 1;
+                break;
+            }
+            l.append(b, len_ - pos_);
+            pos_ = len_;
         }
         if (!l.empty() && l.back() == '\r') l.pop_back();
         return true;
     }
 
 private:
-    bool gz_;
-    gzFile g_ = nullptr;
-    std::ifstream f_;
+    ByteSource src_;
+    std::vector<char> buf_;
+    size_t pos_ = 0, len_ = 0;
 };
 }  // namespace
 
@@ -449,7 +550,7 @@ bool parse_fastq(Src &src, Emit &&emit, int offset, bool strict, int *sniffed = 
             if (!bad) {
                 const int qc = (unsigned char)q[i];
                 if (qc < offset || qc > 126) throw Error("Invalid quality code char");
-                bad = qc - offset < 1;
+                bad = ((qc - offset) & 63) < 1;  // the phred lives in 6 bits of a byte (DnaQBuilder.java:32-35): 64 wraps to 0
             }
             if (bad) {
                 if (i > start) emit(d.data() + start, i - start);
@@ -491,6 +592,55 @@ bool parse_fastq(Src &src, Emit &&emit, int offset, bool strict, int *sniffed = 
         for (const auto &r : head) process(r.first, r.second);
     }
     return true;
+}
+
+// itmo!/io/readers/BinqReader.java:52-86: records of a 4-byte big-endian length and that many bytes (phred << 2 | nuc);
+// 0xFF bytes in front of a record are padding.  Pieces as in parse_fastq (FastaReaderFromXQSourceTrunc.java:61-95).
+template <class Src, class Emit>
+void parse_binq(Src &src, Emit &&emit, const std::string &file_name)
+{
+    std::vector<char> buf(1u << 20);
+    size_t pos = 0, len = 0;
+    auto next_byte = [&]() -> int {
+        if (pos == len) {
+            len = src.read(buf.data(), buf.size());
+            pos = 0;
+            if (len == 0) return -1;
+        }
+        return (unsigned char)buf[pos++];
+    };
+    std::string rec, piece;
+    for (;;) {
+        int b0 = next_byte();
+        while (b0 == 255) b0 = next_byte();
+        if (b0 < 0) return;
+        const int b1 = next_byte(), b2 = next_byte(), b3 = next_byte();
+        if (b1 < 0 || b2 < 0 || b3 < 0) throw Error("Unexpected end of file " + file_name);
+        const size_t n = ((size_t)b0 << 24) + ((size_t)b1 << 16) + ((size_t)b2 << 8) + (size_t)b3;
+        rec.resize(n);
+        for (size_t got = 0; got < n;) {
+            if (pos == len) {
+                len = src.read(buf.data(), buf.size());
+                pos = 0;
+                if (len == 0) throw Error("Unexpected end of file " + file_name);
+            }
+            const size_t take = std::min(n - got, len - pos);
+            memcpy(&rec[got], buf.data() + pos, take);
+            got += take;
+            pos += take;
+        }
+        piece.clear();
+        for (size_t i = 0; i < n; i++) {
+            const unsigned v = (unsigned char)rec[i];
+            if ((v >> 2) < 1) {  // truncateByQuality(1)
+                if (!piece.empty()) emit(piece.data(), piece.size());
+                piece.clear();
+            } else {
+                piece.push_back("AGCT"[v & 3]);
+            }
+        }
+        if (!piece.empty()) emit(piece.data(), piece.size());
+    }
 }
 
 struct Mapped {  // a read-only memory map of a whole file
@@ -678,23 +828,23 @@ bool load_reads_parallel(const std::string &path, bool fastq, size_t max_reads, 
 
 uint64_t load_reads_file(const std::string &path, size_t max_reads, const std::function<void(PackedBatch &)> &sink)
 {
-    // itmo!/io/ReadersUtils.java:27-53 detectFileFormat: a .gz / .bz2 suffix comes off first, then the format
+    // itmo!/io/ReadersUtils.java:27-53 detectFileFormat: a .gz and then a .bz2 suffix come off, then the format
     const size_t slash = path.find_last_of('/');
     const std::string full_name = lower(slash == std::string::npos ? path : path.substr(slash + 1));
-    std::string name = full_name;
-    const bool gz = ends_with(name, ".gz");
-    if (gz) name.resize(name.size() - 3);
-    if (ends_with(name, ".bz2") || ends_with(name, ".binq"))
-        throw Error("Can't read '" + full_name + "': bzip2 and BINQ inputs are not supported");
+    std::string name = full_name, suffix;
+    Compression comp = COMP_NONE;
+    if (ends_with(name, ".gz")) { comp = COMP_GZ; suffix = ".gz"; name.resize(name.size() - 3); }
+    if (ends_with(name, ".bz2")) { comp = COMP_BZ2; suffix = ".bz2"; name.resize(name.size() - 4); }
+    const bool binq = ends_with(name, ".binq");
     const bool fastq = ends_with(name, ".fastq") || ends_with(name, ".fq");
     const bool fasta = ends_with(name, ".fasta") || ends_with(name, ".fa") || ends_with(name, ".fn") || ends_with(name, ".fna");
-    if (!fastq && !fasta) throw Error("Can't detect file format for file '" + name + "'");
+    if (!binq && !fastq && !fasta) throw Error("Can't detect file format for file '" + name + "'");
+    if (binq && comp != COMP_NONE) throw Error("Illegal format binq" + suffix);  // ReadersUtils.java:210-214
 
     uint64_t delivered = 0;
-    if (!gz && load_reads_parallel(path, fastq, max_reads, sink, &delivered)) return delivered;
+    if (comp == COMP_NONE && !binq && load_reads_parallel(path, fastq, max_reads, sink, &delivered)) return delivered;
 
     // the reference's readers are serial (one synchronized source per file, src/io/ReadsDispatcher.java:34-53)
-    LineSource src(path, gz);
     PackedBatch batch;
     batch.clear();
     auto emit = [&](const char *s, size_t n) {
@@ -706,8 +856,14 @@ uint64_t load_reads_file(const std::string &path, size_t max_reads, const std::f
             batch.clear();
         }
     };
-    if (fasta) parse_fasta(src, emit);
-    else parse_fastq(src, emit, -1, false);
+    if (binq) {
+        ByteSource src(path, COMP_NONE);
+        parse_binq(src, emit, full_name);
+    } else {
+        LineSource src(path, comp);
+        if (fasta) parse_fasta(src, emit);
+        else parse_fastq(src, emit, -1, false);
+    }
     if (batch.n_reads() > 0) {
         batch.finish();
         sink(batch);

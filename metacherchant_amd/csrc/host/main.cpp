@@ -278,7 +278,8 @@ int run_kmer_counter(const Options &o)
     {
         std::string low = name;
         for (char &c : low) c = (char)tolower((unsigned char)c);
-        for (const char *ext : {".fasta.gz", ".fa.gz", ".fn.gz", ".fna.gz", ".fastq.gz", ".fq.gz", ".fasta", ".fa", ".fn", ".fna", ".fastq", ".fq"}) {
+        for (const char *ext : {".fasta.gz", ".fa.gz", ".fn.gz", ".fna.gz", ".fastq.gz", ".fq.gz", ".fasta.bz2", ".fa.bz2", ".fn.bz2", ".fna.bz2",
+                                ".fastq.bz2", ".fq.bz2", ".fasta", ".fa", ".fn", ".fna", ".fastq", ".fq", ".binq"}) {
             const size_t n = strlen(ext);
             if (low.size() >= n && low.compare(low.size() - n, n, ext) == 0) { name.resize(name.size() - n); break; }
         }

@@ -156,9 +156,12 @@ def rich_fasta_read(path):
 
 
 def _lines(path):
-    # .gz: the same readers over a GZIPInputStream (itmo!/io/readers/FastaGZReader.java, FastqGZReader.java)
+    # .gz / .bz2: the same readers over a GZIPInputStream (itmo!/io/readers/FastaGZReader.java, FastqGZReader.java)
+    # or Hadoop's BZip2Codec stream (FastaBZ2Reader.java:27, FastqBZ2Reader.java)
+    import bz2
     import gzip
-    with (gzip.open(path, "rt") if path.lower().endswith(".gz") else open(path, "r")) as f:
+    low = path.lower()
+    with (gzip.open(path, "rt") if low.endswith(".gz") else bz2.open(path, "rt") if low.endswith(".bz2") else open(path, "r")) as f:
         for line in f:
             line = line.rstrip("\n")
             if line.endswith("\r"):
@@ -239,12 +242,42 @@ def read_fastq_reads(path):
                 ph = ord(ch_q) - offset
                 if ph < 0 or ord(ch_q) > 126:
                     raise ValueError("Invalid quality code char")
+                ph &= 63  # itmo!/dna/DnaQBuilder.java:32-35 keeps the phred in 6 bits of a byte: 64 reads back as 0
             if ph < 1:
                 out.append("".join(piece))
                 piece = []
             else:
                 piece.append(ch_d.upper())
         out.append("".join(piece))
+    return [p for p in out if p]
+
+
+def read_binq_reads(path):
+    """itmo!/io/readers/BinqReader.java:52-86 (records: 4-byte big-endian length, then bytes phred << 2 | nuc;
+    0xFF bytes in front of a record are padding) + FastaReaderFromXQSourceTrunc.java:61-95 (pieces)."""
+    data = open(path, "rb").read()
+    out = []
+    pos = 0
+    while True:
+        while pos < len(data) and data[pos] == 255:
+            pos += 1
+        if pos >= len(data):
+            break
+        if pos + 4 > len(data):
+            raise ValueError("Unexpected end of file")
+        n = int.from_bytes(data[pos:pos + 4], "big")
+        pos += 4
+        if pos + n > len(data):
+            raise ValueError("Unexpected end of file")
+        piece = []
+        for v in data[pos:pos + n]:
+            if (v >> 2) < 1:
+                out.append("".join(piece))
+                piece = []
+            else:
+                piece.append("AGCT"[v & 3])
+        out.append("".join(piece))
+        pos += n
     return [p for p in out if p]
 
 
@@ -485,7 +518,8 @@ def library_name(path):
     """ReadersUtils.readDnaLazy(file).name(): file name without its format extension."""
     name = os.path.basename(path)
     low = name.lower()
-    for ext in (".fasta.gz", ".fa.gz", ".fn.gz", ".fna.gz", ".fastq.gz", ".fq.gz", ".fasta", ".fa", ".fn", ".fna", ".fastq", ".fq"):
+    for ext in (".fasta.gz", ".fa.gz", ".fn.gz", ".fna.gz", ".fastq.gz", ".fq.gz", ".fasta.bz2", ".fa.bz2", ".fn.bz2", ".fna.bz2",
+                ".fastq.bz2", ".fq.bz2", ".fasta", ".fa", ".fn", ".fna", ".fastq", ".fq", ".binq"):
         if low.endswith(ext):
             return name[:len(name) - len(ext)]
     return name

@@ -162,7 +162,30 @@ def test_read_ingest_policies(hosttest, tmp_path):
     faz = tmp_path / "r.fna.gz"
     faz.write_bytes(gzip.compress(fa.read_bytes()))
     assert run(str(faz)) == ho.read_fasta_reads(str(faz)) == ["ACGTACGTACGT", "ACGTTTGA", "GGGG"]
-    for unsupported in ("r.fasta.bz2", "r.binq", "r.txt.gz"):
+    # bzip2: two streams back to back (Hadoop's codec reads on), FASTA and FASTQ
+    import bz2
+    fab = tmp_path / "r.fa.bz2"
+    fab.write_bytes(bz2.compress(fa.read_bytes()) + bz2.compress(b">r6\nTTGACA"))
+    assert run(str(fab)) == ho.read_fasta_reads(str(fab)) == ["ACGTACGTACGT", "ACGTTTGA", "GGGG", "TTGACA"]
+    fqb = tmp_path / "r.fastq.bz2"
+    fqb.write_bytes(bz2.compress(fq.read_bytes()))
+    assert run(str(fqb)) == ho.read_fastq_reads(str(fqb)) == ["ACGT", "CGTAC", "ACG", "ACG", "GATTAC"]
+    (tmp_path / "cut.fa.bz2").write_bytes(bz2.compress(fa.read_bytes() * 50)[:-20])
+    assert subprocess.call([hosttest, "reads", str(tmp_path / "cut.fa.bz2")], stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL) == 1
+    # Sanger phred 64 ('a'): the reference keeps the phred in 6 bits, so it reads back as 0 and splits the read
+    fq3 = tmp_path / "wrap.fastq"
+    fq3.write_text("@a\nACGTACGT\n+\n5III~aIb\n")
+    assert run(str(fq3)) == ho.read_fastq_reads(str(fq3)) == ["ACGTA", "GT"]
+    # BINQ: 4-byte big-endian length + bytes (phred << 2 | nuc), 0xFF padding between records, phred 0 splits
+    def rec(seq, quals):
+        body = bytes((q << 2) | "AGCT".index(c) for c, q in zip(seq, quals))
+        return len(body).to_bytes(4, "big") + body
+    bq = tmp_path / "lib.binq"
+    bq.write_bytes(rec("ACGTAC", [30, 30, 0, 30, 30, 63]) + b"\xff\xff" + rec("GGTT", [1, 2, 3, 4]) + rec("", []) + rec("AAAA", [0, 0, 0, 0]) + b"\xff")
+    assert run(str(bq)) == ho.read_binq_reads(str(bq)) == ["AC", "TAC", "GGTT"]
+    (tmp_path / "cut.binq").write_bytes(rec("ACGTAC", [30] * 6)[:-2])
+    assert subprocess.call([hosttest, "reads", str(tmp_path / "cut.binq")], stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL) == 1
+    for unsupported in ("r.binq.gz", "r.binq.bz2", "r.txt.gz"):
         (tmp_path / unsupported).write_bytes(b"x")
         assert subprocess.call([hosttest, "reads", str(tmp_path / unsupported)], stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL) == 1
     bad = tmp_path / "r.txt"
