@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define MC_ABI_VERSION 6
+#define MC_ABI_VERSION 7
 
 /* error codes */
 #define MC_OK 0
@@ -177,6 +177,14 @@ int mc_export_dev(mc_ctx *ctx, int min_cov, int64_t *d_keys, int16_t *d_counts, 
                   uint64_t *n_out);
 /* table[key] = min(32767, table[key] + count) for each pair (saturating adds commute). */
 int mc_add_pairs_dev(mc_ctx *ctx, const int64_t *d_keys, const int16_t *d_counts, const uint32_t *d_hints, uint64_t n);
+/* The BFS side of the multi-GPU gather: turns an empty (new or cleared) context into a BFS-only one whose graph
+ * is the given pairs with count >= min_cov -- the concatenated mc_export_dev output of every rank, owners being
+ * disjoint so no key comes twice; entries with a smaller (or negative: padding) count are skipped.  The pairs go
+ * straight into the BFS's own table; the counting table stays empty, so mc_get / mc_export on this context see
+ * nothing and mc_bfs* accepts this min_cov only, until mc_clear.  *n_solid (may be NULL) = vertices kept.
+ * What the reference does instead: the BFS reads the one shared map (src/algo/OneSequenceCalculator.java:203-204). */
+int mc_solid_from_pairs_dev(mc_ctx *ctx, const int64_t *d_keys, const int16_t *d_counts, const uint32_t *d_hints, uint64_t n,
+                            int min_cov, uint64_t *n_solid);
 
 /* ---- multi-GPU building blocks (device pointers).  The read set is split across ranks; each
  * rank turns its reads into keys bucketed by owner rank, ranks exchange buckets (RCCL

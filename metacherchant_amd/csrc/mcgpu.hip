@@ -74,6 +74,9 @@ struct mc_ctx {
     SolidSlot *solid = nullptr;
     uint32_t solid_lg = 0;
     int solid_cov = -1;  // -1: not built / stale
+    bool solid_external = false;  // built by mc_solid_from_pairs_dev, not from this context's counting table
+    int solid_external_cov = -1;
+    double pending_solid_ms = 0;
     uint64_t n_solid = 0;
     // mc_set_coverage_hint: the merge kernel of the counting pipeline keeps d_ctr[6] = #keys with
     // count >= cov_hint, so ensure_solid needs no counting sweep.  Only additions that go through that
@@ -344,6 +347,55 @@ __global__ void __launch_bounds__(PT_THREADS) k_solid_emit(const Slot *__restric
     if (tid < n_buckets) seg_counts[(uint64_t)tid * PT_SEGMENTS + blockIdx.x] = min(C.wcur[tid], (uint32_t)cap);
 }
 
+// The same first step for solid entries that arrive as (key, count, hint) arrays -- the thresholded shards of the
+// other ranks (mc_solid_from_pairs_dev) -- instead of sitting in this context's counting table.
+__global__ void __launch_bounds__(PT_THREADS) k_solid_emit_pairs(const int64_t *__restrict__ keys, const int16_t *__restrict__ counts,
+                                                                  const uint32_t *__restrict__ hints, uint64_t n, int min_cov, uint32_t np1,
+                                                                  uint32_t *seg_counts, uint64_t cap, uint4 *out_recs, uint32_t *out_bins,
+                                                                  SkSpill sp, unsigned long long *empty_cnt)
+{
+    __shared__ SkCursors C;
+    const uint32_t tid = threadIdx.x, n_buckets = np1;
+    if (tid < PT_MAX_BUCKETS) { C.wcur[tid] = 0; C.cnt[tid] = 0; }
+    __syncthreads();
+    // Rows of 64 entries (one wave, one coalesced load) are dealt to the workgroups (= segments) round-robin: an
+    // export comes in table order, which for hash-prefix tables is the order of the very hash that picks the
+    // bucket, and short arrays must not land in a few segments either -- the segment capacities count on each
+    // segment getting its share of every bucket (to within one row).
+    constexpr uint32_t WAVES = PT_THREADS / 64;
+    const uint64_t n_rows = (n + 63) / 64;
+    const uint32_t wave = tid >> 6, lane = tid & 63;
+    for (uint64_t t0 = 0; t0 * WAVES * gridDim.x < n_rows; t0 += PT_ITEMS) {
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS; j++) {
+            const uint64_t row = ((t0 + (uint64_t)j) * WAVES + wave) * gridDim.x + blockIdx.x;
+            const uint64_t i = row * 64 + lane;
+            if (i >= n) continue;
+            const int c = counts[i];
+            if (c < min_cov || c < 0) continue;
+            const uint64_t key = (uint64_t)keys[i];
+            if (key == EMPTY_KEY) { atomicAdd(empty_cnt, (unsigned long long)c); continue; }  // kept out of band, as in the counting table
+            const uint4 rec = make_uint4((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)c, hints ? hints[i] : 0u);
+            const uint32_t bin = (uint32_t)(fmix64(key) >> 32);
+            sk_emit(C, mulhi32(bin, np1), rec, bin, cap, (uint64_t)blockIdx.x * cap, (uint64_t)PT_SEGMENTS * cap, out_recs, out_bins, sp);
+        }
+        __syncthreads();
+        if (tid < n_buckets) { C.wcur[tid] += C.cnt[tid]; C.cnt[tid] = 0; }
+        __syncthreads();
+    }
+    if (tid < n_buckets) seg_counts[(uint64_t)tid * PT_SEGMENTS + blockIdx.x] = min(C.wcur[tid], (uint32_t)cap);
+}
+
+__global__ void k_count_pairs(const int16_t *__restrict__ counts, const int64_t *__restrict__ keys, uint64_t n, int min_cov,
+                              unsigned long long *out)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long m = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        m += counts[i] >= min_cov && counts[i] >= 0 && (uint64_t)keys[i] != EMPTY_KEY;
+    wave_add_ull(out, m);
+}
+
 // one workgroup per solid region = one leaf (nseg segments of capacity seg_cap, as for k_p3_merge)
 __global__ void __launch_bounds__(512) k_solid_from_leaves(const uint4 *__restrict__ leaf_recs, const uint32_t *__restrict__ seg_counts,
                                                            uint64_t seg_cap, uint32_t nseg, SolidView solid, uint32_t solid_lg)
@@ -451,45 +503,66 @@ __global__ void k_get(const int64_t *__restrict__ keys, uint64_t n, int16_t *__r
 }
 
 // K6: (key, count) pairs with count >= min_cov; with keys == nullptr only counts them.
-// One cursor update per wave and iteration (ballot), never one per slot.
-__global__ void k_export(const Slot *__restrict__ slots, uint64_t n_slots, int min_cov, int64_t *__restrict__ keys,
-                         int16_t *__restrict__ counts, uint32_t *__restrict__ hints, uint64_t cap,
-                         unsigned long long *cursor)
+constexpr int EXP_THREADS = 256, EXP_ITEMS = 8, EXP_TILE = EXP_THREADS * EXP_ITEMS;
+
+__global__ void __launch_bounds__(EXP_THREADS) k_export(const Slot *__restrict__ slots, uint64_t n_slots, int min_cov,
+                                                        int64_t *__restrict__ keys, int16_t *__restrict__ counts,
+                                                        uint32_t *__restrict__ hints, uint64_t cap, unsigned long long *cursor)
 {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint32_t lane = threadIdx.x & 63;
+    // A tile of slots is compacted in LDS (one LDS cursor update per wave and row), takes ONE slice of the output
+    // with a single global atomic and leaves in coalesced stores: a global atomic per wave and row would put
+    // n_slots / 64 updates on one address, which alone costs ~10 ns each.
+    __shared__ uint4 buf[EXP_TILE];
+    __shared__ uint32_t lcur;
+    __shared__ unsigned long long gbase;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
     unsigned long long counted = 0;
-    const uint64_t first = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (uint64_t i0 = first - lane; i0 < n_slots; i0 += stride) {  // wave-uniform trip count
-        const uint64_t i = i0 + lane;
-        uint64_t key = EMPTY_KEY;
-        int c = -1;
-        uint32_t aux = 0;
-        if (i < n_slots) {
-            const uint4 raw = *reinterpret_cast<const uint4 *>(slots + i);
-            key = ((uint64_t)raw.y << 32) | raw.x;
-            c = raw.z > 32767u ? 32767 : (int)raw.z;
-            aux = raw.w;
+    const uint64_t n_tiles = (n_slots + EXP_TILE - 1) / EXP_TILE;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        uint4 raws[EXP_ITEMS];
+#pragma unroll
+        for (int j = 0; j < EXP_ITEMS; j++) {
+            const uint64_t i = tile * EXP_TILE + (uint64_t)j * EXP_THREADS + tid;
+            raws[j] = i < n_slots ? *reinterpret_cast<const uint4 *>(slots + i) : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0);
         }
-        const bool take = key != EMPTY_KEY && c >= min_cov;
         if (!keys) {
-            counted += take ? 1u : 0u;
+#pragma unroll
+            for (int j = 0; j < EXP_ITEMS; j++) {
+                const uint64_t key = ((uint64_t)raws[j].y << 32) | raws[j].x;
+                const int c = raws[j].z > 32767u ? 32767 : (int)raws[j].z;
+                counted += key != EMPTY_KEY && c >= min_cov ? 1u : 0u;
+            }
             continue;
         }
-        const unsigned long long m = __ballot(take);
-        if (!m) continue;
-        unsigned long long base = 0;
-        const int leader = __ffsll((long long)m) - 1;
-        if ((int)lane == leader) base = atomicAdd(cursor, (unsigned long long)__popcll(m));
-        base = __shfl(base, leader);
-        if (take) {
-            const unsigned long long pos = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1));
+        if (tid == 0) lcur = 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < EXP_ITEMS; j++) {
+            const uint64_t key = ((uint64_t)raws[j].y << 32) | raws[j].x;
+            const int c = raws[j].z > 32767u ? 32767 : (int)raws[j].z;
+            const bool take = key != EMPTY_KEY && c >= min_cov;
+            const unsigned long long m = __ballot(take);
+            if (!m) continue;
+            uint32_t base = 0;
+            const int leader = __ffsll((long long)m) - 1;
+            if ((int)lane == leader) base = atomicAdd(&lcur, (uint32_t)__popcll(m));
+            base = __shfl(base, leader);
+            if (take) buf[base + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = make_uint4(raws[j].x, raws[j].y, (uint32_t)c, raws[j].w);
+        }
+        __syncthreads();
+        const uint32_t n_out = lcur;
+        if (tid == 0 && n_out) gbase = atomicAdd(cursor, (unsigned long long)n_out);
+        __syncthreads();
+        for (uint32_t i = tid; i < n_out; i += EXP_THREADS) {
+            const unsigned long long pos = gbase + i;
             if (pos < cap) {
-                keys[pos] = (int64_t)key;
-                counts[pos] = (int16_t)c;
-                if (hints) hints[pos] = aux;
+                const uint4 e = buf[i];
+                keys[pos] = (int64_t)(((uint64_t)e.y << 32) | e.x);
+                counts[pos] = (int16_t)e.z;
+                if (hints) hints[pos] = e.w;
             }
         }
+        __syncthreads();
     }
     if (!keys) wave_add_ull(cursor, counted);
 }
@@ -1045,7 +1118,7 @@ static int add_reads_impl(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_
             r = r1;
         }
         c->finalized = false;
-        c->solid_cov = -1;
+        c->solid_cov = -1; c->solid_external = false;
         return MC_OK;
     }
     uint64_t r = 0;
@@ -1071,7 +1144,7 @@ static int add_reads_impl(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_
         r = r1;
     }
     c->finalized = false;
-    c->solid_cov = -1;
+    c->solid_cov = -1; c->solid_external = false;
     return MC_OK;
 }
 
@@ -1178,7 +1251,7 @@ int mc_clear(mc_ctx *c)
     HIPCHK(c, hipMemsetAsync(c->d_fatal, 0, sizeof(uint32_t), c->stream));
     c->n_used_host = 0;
     c->finalized = false;
-    c->solid_cov = -1;
+    c->solid_cov = -1; c->solid_external = false;
     c->solid_tracked = true;
     return MC_OK;
 }
@@ -1309,7 +1382,7 @@ static int add_reads_dev_locked(mc_ctx *c, const uint64_t *d_words, const uint64
             if (rc) return rc;
         }
         c->finalized = false;
-        c->solid_cov = -1;
+        c->solid_cov = -1; c->solid_external = false;
         return MC_OK;
     }
     // otherwise the launch planner needs the offsets on the host (8 bytes per read, once per call)
@@ -1369,7 +1442,7 @@ int mc_add_keys_dev(mc_ctx *c, const int64_t *d_keys, const uint32_t *d_hints, u
         }
     }
     c->finalized = false;
-    c->solid_cov = -1;
+    c->solid_cov = -1; c->solid_external = false;
     return MC_OK;
 }
 
@@ -1392,7 +1465,7 @@ int mc_add_pairs_dev(mc_ctx *c, const int64_t *d_keys, const int16_t *d_counts, 
         i += m;
     }
     c->finalized = false;
-    c->solid_cov = -1;
+    c->solid_cov = -1; c->solid_external = false;
     return MC_OK;
 }
 
@@ -1625,7 +1698,7 @@ int mc_add_superkmers_dev(mc_ctx *c, const uint64_t *d_recs, const uint32_t *d_b
         if (rc) return rc;
     }
     c->finalized = false;
-    c->solid_cov = -1;
+    c->solid_cov = -1; c->solid_external = false;
     return MC_OK;
 }
 
@@ -1639,10 +1712,14 @@ int mc_export_dev(mc_ctx *c, int min_cov, int64_t *d_keys, int16_t *d_counts, ui
     if (d_keys && !d_counts) return fail(c, MC_EINVAL, "mc_export: counts is null");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     unsigned long long *cursor = c->d_ctr + 2;
-    HIPCHK(c, hipMemsetAsync(cursor, 0, sizeof(unsigned long long), c->stream));
-    hipLaunchKernelGGL(k_export, dim3(grid_for(c->n_slots(), 256)), dim3(256), 0, c->stream, c->slots, c->n_slots(),
-                       min_cov, d_keys, d_counts, d_hints, cap, cursor);
-    HIPCHK(c, hipGetLastError());
+    if (!d_keys && c->solid_tracked && c->cov_hint == min_cov && min_cov > 0 && !c->virgin) {
+        cursor = c->d_ctr + 6;  // counting only, and k_p3_merge kept the number of keys at this threshold up to date
+    } else {
+        HIPCHK(c, hipMemsetAsync(cursor, 0, sizeof(unsigned long long), c->stream));
+        hipLaunchKernelGGL(k_export, dim3(grid_for(c->n_slots(), 256)), dim3(256), 0, c->stream, c->slots, c->n_slots(),
+                           min_cov, d_keys, d_counts, d_hints, cap, cursor);
+        HIPCHK(c, hipGetLastError());
+    }
     unsigned long long n = 0, empty_cnt = 0;
     HIPCHK(c, hipMemcpyAsync(&n, cursor, sizeof n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(&empty_cnt, c->d_ctr + 1, sizeof empty_cnt, hipMemcpyDeviceToHost, c->stream));
@@ -1864,26 +1941,12 @@ int bfs_alloc(mc_ctx *c, BfsState &S, uint64_t dcap)
     return MC_OK;
 }
 
-// Builds (or reuses) the solid table for this threshold.
-int ensure_solid(mc_ctx *c, int min_cov, double *ms)
+struct PairSource { const int64_t *keys; const int16_t *counts; const uint32_t *hints; uint64_t n; };
+
+// Builds the solid table for n entries with count >= min_cov, taken from the counting table or (pairs != nullptr)
+// from arrays of (key, count, hint).
+int solid_build(mc_ctx *c, uint64_t n, int min_cov, double *ms, const PairSource *pairs)
 {
-    if (c->solid_cov == min_cov && c->solid) return MC_OK;
-    c->solid_cov = -1;
-    unsigned long long *cursor = c->d_ctr + 2;
-    int rc;
-    if (c->solid_tracked && c->cov_hint == min_cov && min_cov > 0 && !c->virgin) {
-        cursor = c->d_ctr + 6;  // kept up to date by k_p3_merge
-    } else {
-        HIPCHK(c, hipMemsetAsync(cursor, 0, sizeof(unsigned long long), c->stream));
-        rc = timed(c, ms, [&] {
-            hipLaunchKernelGGL(k_export, dim3(grid_for(c->n_slots(), 256)), dim3(256), 0, c->stream, c->slots,
-                               c->n_slots(), min_cov, (int64_t *)nullptr, (int16_t *)nullptr, (uint32_t *)nullptr, (uint64_t)0, cursor);
-        });
-        if (rc) return rc;
-        c->st.solid_sweeps++;
-    }
-    unsigned long long n = 0;
-    HIPCHK(c, hipMemcpy(&n, cursor, sizeof n, hipMemcpyDeviceToHost));
     c->n_solid = n;
     c->st.solid_kmers = n;
     uint64_t factor = 4;  // slots per solid key (load factor <= 1/4)
@@ -1897,13 +1960,18 @@ int ensure_solid(mc_ctx *c, int min_cov, double *ms)
         c->solid_lg = lg;
     }
     const int doublings = c->cfg.key_mode == MC_KEY_PACKED ? 2 : 0;  // hash keys do not hold the k-mer
-    // counting table organised by minimizer bins: the solid entries are partitioned by their own hash first
+    // counting table organised by minimizer bins, or entries from outside: the solid entries are partitioned by
+    // their own hash first
+    const bool partitioned = c->mm_k || pairs;
     mc_ctx::Pipe &P = c->pipe;
     const uint32_t q = lg - SOLID_SB, sb1 = std::min<uint32_t>(q, 9), sb2 = q - sb1;
     uint64_t scap1 = 0, scap2 = 0;
-    if (c->mm_k) {
-        const double m1 = (double)n / (double)(1ull << sb1) / (double)PT_SEGMENTS, m2 = (double)n / (double)(1ull << q);
+    int rc;
+    if (partitioned) {
+        const double m1 = (double)n / (double)(1ull << sb1) / (double)PT_SEGMENTS;
+        const double m2 = (double)n / (double)(1ull << q);
         scap1 = (uint64_t)(m1 * 1.25 + 10.0 * std::sqrt(m1) + 64.0);
+        if (pairs) scap1 += 64;  // rows of 64 entries are dealt to the segments: one of them may bring a whole row more
         scap2 = (uint64_t)(m2 * 1.15 + 10.0 * std::sqrt(m2) + 64.0);
         rc = ensure_buf(c, &P.a_recs, &P.a_recs_cap, (uint64_t)(1ull << sb1) * PT_SEGMENTS * scap1);
         if (!rc) rc = ensure_buf(c, &P.a_hints, &P.a_hints_cap, (uint64_t)(1ull << sb1) * PT_SEGMENTS * scap1);
@@ -1918,11 +1986,15 @@ int ensure_solid(mc_ctx *c, int min_cov, double *ms)
         HIPCHK(c, hipMemsetAsync(P.spill_count, 0, sizeof(unsigned long long), c->stream));
     }
     rc = timed(c, ms, [&] {
-        if (c->mm_k) {
+        if (partitioned) {
             uint32_t *leaf_counts = P.solid_cursors;
             const SkSpill none{nullptr, P.spill_count, 0, P.flags};  // no spill list: an overflow is reported
-            hipLaunchKernelGGL(k_solid_emit, dim3(PT_SEGMENTS), dim3(PT_THREADS), 0, c->stream, c->slots, c->n_slots(), min_cov, 1u << sb1,
-                               P.seg_counts1, scap1, P.a_recs, P.a_hints, none);
+            if (pairs)
+                hipLaunchKernelGGL(k_solid_emit_pairs, dim3(PT_SEGMENTS), dim3(PT_THREADS), 0, c->stream, pairs->keys, pairs->counts,
+                                   pairs->hints, pairs->n, min_cov, 1u << sb1, P.seg_counts1, scap1, P.a_recs, P.a_hints, none, c->d_ctr + 1);
+            else
+                hipLaunchKernelGGL(k_solid_emit, dim3(PT_SEGMENTS), dim3(PT_THREADS), 0, c->stream, c->slots, c->n_slots(), min_cov, 1u << sb1,
+                                   P.seg_counts1, scap1, P.a_recs, P.a_hints, none);
             if (sb2)
                 hipLaunchKernelGGL(k_sk2_scatter, dim3(1u << sb1), dim3(PT_THREADS), 0, c->stream, P.a_recs, P.a_hints, scap1,
                                    P.seg_counts1, 1u << sb1, 1u << sb1, 1u << sb2, leaf_counts, scap2, P.b_recs, P.b_hints, none);
@@ -1941,13 +2013,39 @@ int ensure_solid(mc_ctx *c, int min_cov, double *ms)
     uint32_t fatal = 0;
     HIPCHK(c, hipMemcpy(&fatal, c->d_fatal, sizeof fatal, hipMemcpyDeviceToHost));
     if (fatal) return fail(c, MC_EOVERFLOW, "a region of the solid k-mer table filled up (hash skew)");
-    if (c->mm_k) {
+    if (partitioned) {
         uint32_t lost = 0;
         HIPCHK(c, hipMemcpy(&lost, P.flags, sizeof lost, hipMemcpyDeviceToHost));
         if (lost) return fail(c, MC_EOVERFLOW, "internal: a bucket of the solid-table build overflowed (hash skew)");
     }
     c->solid_cov = min_cov;
     return MC_OK;
+}
+
+// Builds (or reuses) the solid table for this threshold.
+int ensure_solid(mc_ctx *c, int min_cov, double *ms)
+{
+    if (c->solid_cov == min_cov && c->solid) return MC_OK;
+    if (c->solid_external)
+        return fail(c, MC_ESTATE, "this context's solid table came from mc_solid_from_pairs_dev at coverage %d; it serves that threshold only",
+                    c->solid_external_cov);
+    c->solid_cov = -1; c->solid_external = false;
+    unsigned long long *cursor = c->d_ctr + 2;
+    int rc;
+    if (c->solid_tracked && c->cov_hint == min_cov && min_cov > 0 && !c->virgin) {
+        cursor = c->d_ctr + 6;  // kept up to date by k_p3_merge
+    } else {
+        HIPCHK(c, hipMemsetAsync(cursor, 0, sizeof(unsigned long long), c->stream));
+        rc = timed(c, ms, [&] {
+            hipLaunchKernelGGL(k_export, dim3(grid_for(c->n_slots(), 256)), dim3(256), 0, c->stream, c->slots,
+                               c->n_slots(), min_cov, (int64_t *)nullptr, (int16_t *)nullptr, (uint32_t *)nullptr, (uint64_t)0, cursor);
+        });
+        if (rc) return rc;
+        c->st.solid_sweeps++;
+    }
+    unsigned long long n = 0;
+    HIPCHK(c, hipMemcpy(&n, cursor, sizeof n, hipMemcpyDeviceToHost));
+    return solid_build(c, n, min_cov, ms, nullptr);
 }
 
 void launch_bfs(mc_ctx *c, const BfsState *d_states, uint32_t n_jobs, int min_cov, int64_t max_kmers,
@@ -1971,6 +2069,38 @@ void launch_bfs(mc_ctx *c, const BfsState *d_states, uint32_t n_jobs, int min_co
 
 }  // namespace
 
+int mc_solid_from_pairs_dev(mc_ctx *c, const int64_t *d_keys, const int16_t *d_counts, const uint32_t *d_hints, uint64_t n,
+                            int min_cov, uint64_t *n_solid)
+{
+    if (!c) return MC_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (n_solid) *n_solid = 0;
+    if ((!d_keys || !d_counts) && n) return fail(c, MC_EINVAL, "mc_solid_from_pairs_dev: null pointer");
+    if (min_cov < 0) return fail(c, MC_EINVAL, "mc_solid_from_pairs_dev: negative coverage threshold");
+    if (!c->virgin) return fail(c, MC_ESTATE, "mc_solid_from_pairs_dev: the context holds counts; call mc_clear first");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    c->solid_cov = -1;
+    c->solid_external = false;
+    unsigned long long *cursor = c->d_ctr + 2;
+    HIPCHK(c, hipMemsetAsync(cursor, 0, sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_ctr + 1, 0, sizeof(unsigned long long), c->stream));  // the out-of-band count of EMPTY_KEY
+    if (n) hipLaunchKernelGGL(k_count_pairs, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, d_counts, d_keys, n, min_cov, cursor);
+    HIPCHK(c, hipGetLastError());
+    unsigned long long m = 0;
+    HIPCHK(c, hipMemcpyAsync(&m, cursor, sizeof m, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const PairSource src{d_keys, d_counts, d_hints, n};
+    double ms = 0;
+    int rc = solid_build(c, m, min_cov, &ms, &src);
+    if (rc) return rc;
+    c->pending_solid_ms = ms;  // reported with the next BFS
+    c->solid_external = true;
+    c->solid_external_cov = min_cov;
+    c->finalized = true;
+    if (n_solid) *n_solid = m;
+    return MC_OK;
+}
+
 int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov, int64_t max_kmers,
                  int64_t max_radius, mc_bfs_result *out)
 {
@@ -1993,7 +2123,8 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
             return fail(c, MC_EINVAL, "mc_bfs: more than 2^30 vertices requested");
     }
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    double total_ms = 0;
+    double total_ms = c->pending_solid_ms;
+    c->pending_solid_ms = 0;
     {
         int rc = ensure_solid(c, min_cov, &total_ms);
         if (rc) return rc;

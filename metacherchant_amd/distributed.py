@@ -95,19 +95,19 @@ class ShardedCounter:
         return int(t.item())
 
     def gather_solid(self, solid_ctx, min_cov, dst=0):
-        """All-gather the (key, count >= min_cov) pairs of every shard and merge them into solid_ctx on
-        rank `dst` (pass dst=None to build it on every rank).  Returns the number of solid k-mers."""
+        """All-gather the (key, count >= min_cov, hint) entries of every shard and build solid_ctx's BFS table from
+        them on rank `dst` (pass dst=None to build it on every rank).  Returns the number of solid k-mers."""
         ctx, W = self.ctx, self.world
         if W == 1:
             return None  # the caller BFSes on ctx itself
-        n_local = ctx.export_count(min_cov)
+        n_local = ctx.export_count(min_cov)  # no sweep when the context tracked this threshold (set_coverage_hint)
         nt = torch.tensor([n_local], dtype=torch.int64, device=self.device)
         sizes = [torch.empty(1, dtype=torch.int64, device=self.device) for _ in range(W)]
         dist.all_gather(sizes, nt, group=self.group)
         sizes = [int(s.item()) for s in sizes]
         mx = max(max(sizes), 1)
         keys = torch.zeros(mx, dtype=torch.int64, device=self.device)
-        cnts = torch.zeros(mx, dtype=torch.int16, device=self.device)
+        cnts = torch.full((mx,), -1, dtype=torch.int16, device=self.device)  # -1 marks the padding behind a short shard
         hints = torch.zeros(mx, dtype=torch.int32, device=self.device)
         got = ctx.export_dev(min_cov, keys, cnts, mx, hints)
         assert got == n_local
@@ -121,11 +121,10 @@ class ShardedCounter:
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
         if dst is None or self.rank == dst:
-            for r in range(W):
-                if sizes[r]:
-                    sl = slice(r * mx, r * mx + sizes[r])
-                    solid_ctx.add_pairs_dev(all_k[sl], all_c[sl], sizes[r], all_h[sl])
-            solid_ctx.finalize()
+            # owners are disjoint, so the shards simply sit side by side: one pass over the gathered arrays puts
+            # them into the BFS table (padding skipped by its count)
+            kept = solid_ctx.solid_from_pairs_dev(all_k, all_c, W * mx, min_cov, all_h)
+            assert kept == sum(sizes), (kept, sizes)
         return sum(sizes)
 
 

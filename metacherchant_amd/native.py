@@ -45,7 +45,7 @@ class Stats(C.Structure):
 EXPORTS = [
     "mc_abi_version", "mc_create", "mc_destroy", "mc_clear", "mc_set_coverage_hint", "mc_last_error", "mc_set_stream", "mc_add_reads_packed",
     "mc_add_reads_packed_dev", "mc_add_reads_file", "mc_finalize_counts", "mc_get", "mc_get_dev", "mc_kmer_keys", "mc_bfs", "mc_bfs_batch",
-    "mc_bfs_result_free", "mc_export", "mc_export_dev", "mc_add_pairs_dev", "mc_save_kmers", "mc_load_kmers", "mc_key_owner", "mc_extract_keys_dev",
+    "mc_bfs_result_free", "mc_export", "mc_export_dev", "mc_add_pairs_dev", "mc_solid_from_pairs_dev", "mc_save_kmers", "mc_load_kmers", "mc_key_owner", "mc_extract_keys_dev",
     "mc_add_keys_dev", "mc_superkmer_capacity", "mc_extract_superkmers_dev", "mc_add_superkmers_dev", "mc_get_stats", "mc_reset_stats", "mc_synth_reads_dev", "mc_synth_genome",
 ]
 
@@ -98,6 +98,7 @@ def load():
     L.mc_export.argtypes = [vp, i32, i64p, i16p, u64, u64p]
     L.mc_export_dev.argtypes = [vp, i32, vp, vp, vp, u64, u64p]
     L.mc_add_pairs_dev.argtypes = [vp, vp, vp, vp, u64]
+    L.mc_solid_from_pairs_dev.argtypes = [vp, vp, vp, vp, u64, i32, u64p]
     L.mc_key_owner.argtypes = [i64, C.c_uint32]
     L.mc_key_owner.restype = C.c_uint32
     L.mc_extract_keys_dev.argtypes = [vp, vp, vp, u64, u64, C.c_uint32, vp, vp, u64, u64p]
@@ -190,6 +191,12 @@ class Context:
 
     def add_pairs_dev(self, d_keys, d_counts, n, d_hints=None):
         self._chk(self._L.mc_add_pairs_dev(self._h, _dptr(d_keys), _dptr(d_counts), _dptr(d_hints), n))
+
+    def solid_from_pairs_dev(self, d_keys, d_counts, n, min_cov, d_hints=None):
+        """BFS-only context from the gathered (key, count, hint) pairs with count >= min_cov; returns how many."""
+        m = C.c_uint64(0)
+        self._chk(self._L.mc_solid_from_pairs_dev(self._h, _dptr(d_keys), _dptr(d_counts), _dptr(d_hints), n, min_cov, C.byref(m)))
+        return int(m.value)
 
     def finalize(self):
         n = C.c_uint64(0)

@@ -39,21 +39,16 @@ def worker(rank, world, port, k, q):
         t = po.Table()
         t.count_reads(reads, off, k, mode)
         ok, oc = t.dump()
-        sk, scnt = solid.export(0)
         assert total == t.size(), (total, t.size())
         assert n_solid == int((oc >= 4).sum())
-        wk, wc = ok[oc >= 4], oc[oc >= 4]
-        if not (np.array_equal(sk, wk) and np.array_equal(scnt, wc)):
-            msg = "solid table differs: n %d want %d, missing %d extra %d" % (len(sk), len(wk), len(np.setdiff1d(wk, sk)), len(np.setdiff1d(sk, wk)))
-            if np.array_equal(sk, wk):
-                bad = np.nonzero(scnt != wc)[0]
-                msg += ", %d counts differ, e.g. %s" % (len(bad), [(int(sk[i]), int(scnt[i]), int(wc[i])) for i in bad[:5]])
-            raise AssertionError(msg)
+        # the BFS-only context holds no counts of its own (mc_solid_from_pairs_dev): what it knows shows in the walks
         seed = genome[30000:30300]
         shi, slo = seed_windows(seed, k)
-        got = solid.bfs(shi, slo, 1, 4, 5000, -1)
-        want = po.bfs(t, k, mode, [seed], 1, 4, 5000, -1)
-        assert np.array_equal(got["lo"], want["lo"]) and np.array_equal(got["dist"], want["dist"])
+        for d in (1, -1, 0):
+            got = solid.bfs(shi, slo, d, 4, 20000, -1)
+            want = po.bfs(t, k, mode, [seed], d, 4, 20000, -1)
+            assert np.array_equal(got["lo"], want["lo"]) and np.array_equal(got["dist"], want["dist"])
+            assert np.array_equal(got["cov"], want["cov"]) and np.array_equal(got["hi"], want["hi"])
         q.put(("ok", total, n_solid, sc.bytes_sent, ctx.superkmer_capacity(1000, 10) > 0))
     dist.barrier()
     dist.destroy_process_group()

@@ -75,6 +75,14 @@ class OracleBackedContext:
         for x, c in zip(d_keys[:n].tolist(), d_counts[:n].tolist()):
             self.t.add(int(x), int(c))
 
+    def solid_from_pairs_dev(self, d_keys, d_counts, n, min_cov, d_hints=None):
+        kept = 0
+        for x, c in zip(d_keys[:n].tolist(), d_counts[:n].tolist()):
+            if c >= min_cov and c >= 0:
+                self.t.add(int(x), int(c))
+                kept += 1
+        return kept
+
     def finalize(self):
         return self.t.size()
 

@@ -408,6 +408,61 @@ def test_superkmer_records_by_owner(mc, k):
     merged.close()
 
 
+@pytest.mark.parametrize("k,mode_name", [(31, "KEY_PACKED"), (25, "KEY_PACKED"), (21, "KEY_PACKED"), (45, "KEY_POLY"), (31, "KEY_FNV1A")])
+def test_bfs_table_straight_from_gathered_pairs(mc, k, mode_name):
+    """Rank 0's side of the gather: the exported shards, side by side with padding between them, go straight into a
+    BFS-only context; the walk equals the oracle's on the table of all reads and still has its hints."""
+    import torch
+    dev = torch.device("cuda:0")
+    mode, omode = getattr(mc, mode_name), getattr(po, mode_name)
+    genome, reads, off = synth_case(2, 30000, 8000, 150, 50)
+    t, n = oracle_table(reads, off, k, omode)
+    d_words = torch.from_numpy(po.pack(reads).view(np.int64)).to(dev)
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    full = mc.Context(k, mode, 0, 0)
+    full.set_coverage_hint(3)
+    full.add_reads_packed_dev(d_words, d_off, len(off) - 1, int(off[-1]))
+    nd = full.finalize()
+    n3 = full.export_count(3)
+    ok, oc = t.dump()
+    assert n3 == int((oc >= 3).sum())  # (the tracked number when the pipeline counted, a sweep otherwise)
+    # two "shards" (below / from the median key), each padded to a common length like all_gather_into_tensor's input
+    pk = torch.zeros(nd, dtype=torch.int64, device=dev)
+    pc = torch.zeros(nd, dtype=torch.int16, device=dev)
+    ph = torch.zeros(nd, dtype=torch.int32, device=dev)
+    assert full.export_dev(2, pk, pc, nd, ph) <= nd  # a lower threshold than the walk's: filtered on the way in
+    m = full.export_count(2)
+    med = pk[:m].median()
+    parts = [pk[:m] < med, pk[:m] >= med]
+    mx = int(max(int(p.sum()) for p in parts)) + 5
+    all_k = torch.zeros(2 * mx, dtype=torch.int64, device=dev)
+    all_c = torch.full((2 * mx,), -1, dtype=torch.int16, device=dev)
+    all_h = torch.zeros(2 * mx, dtype=torch.int32, device=dev)
+    for r, p in enumerate(parts):
+        cnt = int(p.sum())
+        all_k[r * mx:r * mx + cnt] = pk[:m][p]
+        all_c[r * mx:r * mx + cnt] = pc[:m][p]
+        all_h[r * mx:r * mx + cnt] = ph[:m][p]
+    solid = mc.Context(k, mode, 0, 0)
+    assert solid.solid_from_pairs_dev(all_k, all_c, 2 * mx, 3, all_h) == n3
+    seed = genome[4000:4300]
+    hi, lo = seed_windows(seed, k)
+    for d in (-1, 0, 1):
+        got = solid.bfs(hi, lo, d, 3, 3000, -1)
+        assert_bfs_equal(got, po.bfs(t, k, omode, [seed], d, 3, 3000, -1))
+        ref = full.bfs(hi, lo, d, 3, 3000, -1)
+        assert got["rounds"] == ref["rounds"]  # same hints, same look-ahead
+    with pytest.raises(Exception):
+        solid.bfs(hi, lo, 1, 4, 3000, -1)  # built for coverage 3 only
+    solid.clear()
+    assert solid.solid_from_pairs_dev(all_k, all_c, 0, 3, all_h) == 0  # nothing gathered: an empty graph
+    assert solid.bfs(hi, lo, 1, 3, 3000, -1) is None
+    with pytest.raises(Exception):
+        full.solid_from_pairs_dev(all_k, all_c, 2 * mx, 3, all_h)  # holds counts
+    full.close()
+    solid.close()
+
+
 def test_hints_survive_exchange_and_speed_up_the_walk(mc):
     """Same results with and without hints; with them the BFS needs far fewer memory round trips."""
     import torch
