@@ -87,7 +87,7 @@ def main():
     ctx.set_coverage_hint(args.coverage)  # --coverage is known before the reads are loaded (the CLI does the same)
     solid = None
     if world > 1 and rank == 0:
-        solid = m.Context(k, mode, local_rank, genome_bases + (1 << 20))
+        solid = m.Context(k, mode, local_rank, 1 << 20)  # BFS-only (mc_solid_from_pairs_dev): its counting table stays empty
 
     # ---- synthetic reads straight into HBM (not timed)
     n_words = (n_bases + 31) // 32 + 1
