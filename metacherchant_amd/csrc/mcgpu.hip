@@ -58,7 +58,11 @@ struct mc_ctx {
     std::mutex mu;
     std::string err;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_side = nullptr, ev_walk = nullptr;
+    hipStream_t walk_stream = nullptr;  // the walk's own CUs while the sweep runs (CU-masked), or null
+    int walk_cus = 0;
+    hipStream_t side_stream = nullptr;  // the hint-doubling sweep runs here, next to the walk (mc_bfs_batch)
+    bool double_deferred = false;       // the solid table is built but its hints are not doubled yet
 
     // table
     Slot *slots = nullptr;
@@ -1190,6 +1194,9 @@ int mc_create(const mc_config *cfg, mc_ctx **out)
     c->stream = c->own_stream;
     CREATE_CHK(hipEventCreate(&c->ev0));
     CREATE_CHK(hipEventCreate(&c->ev1));
+    CREATE_CHK(hipEventCreate(&c->ev_side));
+    CREATE_CHK(hipEventCreate(&c->ev_walk));
+    CREATE_CHK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
     CREATE_CHK(hipMalloc(reinterpret_cast<void **>(&c->d_ctr), 8 * sizeof(unsigned long long)));
     CREATE_CHK(hipMalloc(reinterpret_cast<void **>(&c->d_fatal), sizeof(uint32_t)));
     CREATE_CHK(hipMemsetAsync(c->d_ctr, 0, 8 * sizeof(unsigned long long), c->stream));
@@ -1234,6 +1241,10 @@ void mc_destroy(mc_ctx *c)
     if (c->d_fatal) (void)hipFree(c->d_fatal);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_side) (void)hipEventDestroy(c->ev_side);
+    if (c->ev_walk) (void)hipEventDestroy(c->ev_walk);
+    if (c->walk_stream) (void)hipStreamDestroy(c->walk_stream);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     for (char *p : c->pin) if (p) (void)hipHostFree(p);
     for (hipStream_t st : c->pin_stream) if (st) (void)hipStreamDestroy(st);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1945,7 +1956,7 @@ struct PairSource { const int64_t *keys; const int16_t *counts; const uint32_t *
 
 // Builds the solid table for n entries with count >= min_cov, taken from the counting table or (pairs != nullptr)
 // from arrays of (key, count, hint).
-int solid_build(mc_ctx *c, uint64_t n, int min_cov, double *ms, const PairSource *pairs)
+int solid_build(mc_ctx *c, uint64_t n, int min_cov, double *ms, const PairSource *pairs, bool defer_double = false)
 {
     c->n_solid = n;
     c->st.solid_kmers = n;
@@ -2005,11 +2016,14 @@ int solid_build(mc_ctx *c, uint64_t n, int min_cov, double *ms, const PairSource
             hipLaunchKernelGGL(k_build_solid_regions, dim3((unsigned)std::min<uint64_t>(1ull << (lg - SOLID_SB), 256 * 2 * 8)), dim3(512), 0,
                                c->stream, c->slots, c->rb + c->sb, min_cov, c->solid_view(), lg);  // (hash-prefix regions: a power of two)
         }
-        if (doublings)  // one sweep: each slot chases its own chain (up to 3 dependent lookups per side)
+        // one sweep: each slot chases its own chain (up to 3 dependent lookups per side).  A caller that walks right
+        // away launches it itself, next to the walk (launch_double): any mix of short and doubled hints is valid.
+        if (doublings && !defer_double)
             hipLaunchKernelGGL(k_solid_double, dim3(grid_for(1ull << lg, 256)), dim3(256), 0, c->stream, c->solid_view(),
                                (uint64_t)1 << lg, c->cfg.k, 3);
     });
     if (rc) return rc;
+    c->double_deferred = doublings && defer_double;
     uint32_t fatal = 0;
     HIPCHK(c, hipMemcpy(&fatal, c->d_fatal, sizeof fatal, hipMemcpyDeviceToHost));
     if (fatal) return fail(c, MC_EOVERFLOW, "a region of the solid k-mer table filled up (hash skew)");
@@ -2023,7 +2037,7 @@ int solid_build(mc_ctx *c, uint64_t n, int min_cov, double *ms, const PairSource
 }
 
 // Builds (or reuses) the solid table for this threshold.
-int ensure_solid(mc_ctx *c, int min_cov, double *ms)
+int ensure_solid(mc_ctx *c, int min_cov, double *ms, bool defer_double = false)
 {
     if (c->solid_cov == min_cov && c->solid) return MC_OK;
     if (c->solid_external)
@@ -2045,24 +2059,24 @@ int ensure_solid(mc_ctx *c, int min_cov, double *ms)
     }
     unsigned long long n = 0;
     HIPCHK(c, hipMemcpy(&n, cursor, sizeof n, hipMemcpyDeviceToHost));
-    return solid_build(c, n, min_cov, ms, nullptr);
+    return solid_build(c, n, min_cov, ms, nullptr, defer_double);
 }
 
-void launch_bfs(mc_ctx *c, const BfsState *d_states, uint32_t n_jobs, int min_cov, int64_t max_kmers,
+void launch_bfs(mc_ctx *c, hipStream_t stream, const BfsState *d_states, uint32_t n_jobs, int min_cov, int64_t max_kmers,
                 int64_t max_radius, unsigned long long max_rounds)
 {
     const SolidView t = c->solid_view();
     switch (c->cfg.key_mode) {
     case MC_KEY_PACKED:
-        hipLaunchKernelGGL(k_bfs<KEY_PACKED>, dim3(n_jobs), dim3(BFS_THREADS), 0, c->stream, d_states, t, c->cfg.k,
+        hipLaunchKernelGGL(k_bfs<KEY_PACKED>, dim3(n_jobs), dim3(BFS_THREADS), 0, stream, d_states, t, c->cfg.k,
                            min_cov, (long long)max_kmers, (long long)max_radius, max_rounds);
         break;
     case MC_KEY_POLY:
-        hipLaunchKernelGGL(k_bfs<KEY_POLY>, dim3(n_jobs), dim3(BFS_THREADS), 0, c->stream, d_states, t, c->cfg.k,
+        hipLaunchKernelGGL(k_bfs<KEY_POLY>, dim3(n_jobs), dim3(BFS_THREADS), 0, stream, d_states, t, c->cfg.k,
                            min_cov, (long long)max_kmers, (long long)max_radius, max_rounds);
         break;
     default:
-        hipLaunchKernelGGL(k_bfs<KEY_FNV1A>, dim3(n_jobs), dim3(BFS_THREADS), 0, c->stream, d_states, t, c->cfg.k,
+        hipLaunchKernelGGL(k_bfs<KEY_FNV1A>, dim3(n_jobs), dim3(BFS_THREADS), 0, stream, d_states, t, c->cfg.k,
                            min_cov, (long long)max_kmers, (long long)max_radius, max_rounds);
     }
 }
@@ -2091,7 +2105,8 @@ int mc_solid_from_pairs_dev(mc_ctx *c, const int64_t *d_keys, const int16_t *d_c
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const PairSource src{d_keys, d_counts, d_hints, n};
     double ms = 0;
-    int rc = solid_build(c, m, min_cov, &ms, &src);
+    static const bool overlap = getenv("MC_NO_DOUBLE_OVERLAP") == nullptr;
+    int rc = solid_build(c, m, min_cov, &ms, &src, overlap);  // the hints are doubled next to the first walk
     if (rc) return rc;
     c->pending_solid_ms = ms;  // reported with the next BFS
     c->solid_external = true;
@@ -2126,9 +2141,16 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
     double total_ms = c->pending_solid_ms;
     c->pending_solid_ms = 0;
     {
-        int rc = ensure_solid(c, min_cov, &total_ms);
+        static const bool overlap = getenv("MC_NO_DOUBLE_OVERLAP") == nullptr;
+        int rc = ensure_solid(c, min_cov, &total_ms, overlap);
         if (rc) return rc;
     }
+    // whatever happens below, the sweep on the side stream has ended before this call returns
+    struct SideGuard {
+        mc_ctx *c;
+        bool launched = false;
+        ~SideGuard() { if (launched) (void)hipStreamSynchronize(c->side_stream); }
+    } side{c};
 
     while (c->bfs_pool.size() < n_jobs) c->bfs_pool.emplace_back(new BfsJobBuffers);
     auto &B = c->bfs_pool;
@@ -2173,9 +2195,55 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
         for (uint32_t j = 0; j < n_jobs; j++) h_states[j] = B[j]->S;
         HIPCHK(c, hipMemcpyAsync(d_states.p, h_states.data(), n_jobs * sizeof(BfsState), hipMemcpyHostToDevice,
                                  c->stream));
-        int rc = timed(c, &total_ms,
-                       [&] { launch_bfs(c, d_states.p, n_jobs, min_cov, max_kmers, max_radius, max_rounds); });
+        int rc = timed(c, &total_ms, [&] {
+            // The walk's few workgroups get CUs of their own (a stream with a CU mask) and the sweep the others: on
+            // shared CUs the sweep's waves take issue slots from the walk, whose rounds are issue-bound (2 ms of 31).
+            const int walk_cus = n_jobs <= 32 ? std::max(8, 2 * (int)n_jobs) : 0;  // many jobs: the walk needs the chip
+            if (c->double_deferred && walk_cus != c->walk_cus) {
+                if (c->walk_stream) { (void)hipStreamDestroy(c->walk_stream); c->walk_stream = nullptr; }
+                (void)hipStreamDestroy(c->side_stream);
+                c->side_stream = nullptr;
+                c->walk_cus = walk_cus;
+                if (walk_cus) {
+                    uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, r[8];
+                    for (int i = 0; i < walk_cus; i++) a[i >> 5] |= 1u << (i & 31);
+                    for (int i = 0; i < 8; i++) r[i] = ~a[i];
+                    if (hipExtStreamCreateWithCUMask(&c->walk_stream, 8, a) != hipSuccess) c->walk_stream = nullptr;
+                    if (c->walk_stream && hipExtStreamCreateWithCUMask(&c->side_stream, 8, r) != hipSuccess) {
+                        (void)hipStreamDestroy(c->walk_stream);
+                        c->walk_stream = c->side_stream = nullptr;
+                    }
+                    (void)hipGetLastError();
+                }
+                if (!c->side_stream) (void)hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking);
+            }
+            if (c->double_deferred && c->walk_stream) {
+                (void)hipEventRecord(c->ev_side, c->stream);
+                (void)hipStreamWaitEvent(c->walk_stream, c->ev_side, 0);
+                launch_bfs(c, c->walk_stream, d_states.p, n_jobs, min_cov, max_kmers, max_radius, max_rounds);
+                (void)hipEventRecord(c->ev_walk, c->walk_stream);
+                (void)hipStreamWaitEvent(c->stream, c->ev_walk, 0);
+            } else {
+                launch_bfs(c, c->stream, d_states.p, n_jobs, min_cov, max_kmers, max_radius, max_rounds);
+            }
+            if (c->double_deferred) {
+                // The walk's few workgroups are placed first; the sweep fills the rest of the chip and lengthens the
+                // hints under the walk's feet (8-byte words, replaced whole: the walk reads either version, and a
+                // hint only steers its look-ahead).  The table was complete and the stream idle when it was built.
+                c->double_deferred = false;
+                side.launched = true;
+                hipLaunchKernelGGL(k_solid_double, dim3(grid_for(1ull << c->solid_lg, 256)), dim3(256), 0, c->side_stream,
+                                   c->solid_view(), (uint64_t)1 << c->solid_lg, c->cfg.k, 3);
+                (void)hipEventRecord(c->ev_side, c->side_stream);
+            }
+        });
         if (rc) return rc;
+        if (side.launched) {
+            HIPCHK(c, hipEventSynchronize(c->ev_side));
+            float tail = 0;  // the part of the sweep that outlasted the walk, if any
+            if (hipEventElapsedTime(&tail, c->ev1, c->ev_side) == hipSuccess && tail > 0) total_ms += tail;
+            side.launched = false;
+        }
         bool all_done = true;
         for (uint32_t j = 0; j < n_jobs; j++) {
             HIPCHK(c, hipMemcpy(&ctl[j], B[j]->S.ctl, sizeof(BfsCtl), hipMemcpyDeviceToHost));
