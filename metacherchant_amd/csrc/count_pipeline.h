@@ -915,6 +915,7 @@ struct MergeLds {
     uint64_t key[REGION_SLOTS];
     uint32_t cnt[REGION_SLOTS];
     uint32_t aux[REGION_SLOTS];
+    uint8_t dq[P3_THREADS / 64][64 * SK_MAX_WINDOWS];  // per wave: window -> lane holding its record (k_p3_merge<true>)
     uint32_t n_new, overflow;
 };
 
@@ -1001,39 +1002,52 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                 for (uint32_t sgm = 0; sgm < nseg; sgm++) {
                 const uint32_t n = min(seg_counts[(uint64_t)leaf * nseg + sgm], (uint32_t)seg_cap);
                 if constexpr (SK) {
-                    // one record per thread: the window is rolled along the record (ShortKmer.shiftRight again),
-                    // the next record's load is in flight meanwhile
+                    // A wave takes 64 records at a time and spreads their WINDOWS over its lanes: records hold 1-16
+                    // windows, and a lane that walked its own record left the wave waiting for the longest one (lane
+                    // use ~40 %).  Each lane writes its lane number into the wave's queue once per window of its
+                    // record; window w of the batch then belongs to the record of lane dq[w], whose words come over
+                    // by ds_bpermute, and is cut out of the record directly (no rolling state).  The next batch's
+                    // records are in flight meanwhile.
                     const uint4 *recs = static_cast<const uint4 *>(leaf_keys) + ((uint64_t)leaf * nseg + sgm) * seg_cap;
                     const uint32_t *bins = leaf_hints + ((uint64_t)leaf * nseg + sgm) * seg_cap;
-                    const uint64_t kmask = (1ull << (2 * k)) - 1;  // (k <= 31)
                     const uint32_t hint_from = solid_thr >= 2 ? 1u : 0u;
+                    const uint32_t lane = tid & 63u;
+                    uint8_t *dq = L.dq[tid >> 6];
                     uint4 nxt = sgm == 0 ? pre : (tid < n ? recs[tid] : make_uint4(0, 0, 0, 0));
                     uint32_t nxt_bin = sgm == 0 ? pre_bin : ((g && tid < n) ? bins[tid] : 0u);
-                    for (uint32_t r = tid; r < n; r += P3_THREADS) {
+                    for (uint32_t b0 = tid - lane; b0 < n; b0 += P3_THREADS) {  // wave-uniform
+                        const uint32_t r = b0 + lane;
                         const uint4 rec = nxt;
                         const uint32_t bin = nxt_bin;
                         if (r + P3_THREADS < n) {
                             nxt = recs[r + P3_THREADS];
                             if (g) nxt_bin = bins[r + P3_THREADS];
                         }
-                        if (g && mulhi32(bin, t.n_regions) != region) continue;
-                        const uint64_t lo = ((uint64_t)rec.y << 32) | rec.x, hi = ((uint64_t)rec.w << 32) | rec.z;
-                        const uint32_t nw = sk_windows(hi);
-                        const bool has_l = (hi >> 57) & 1u, has_r = (hi >> 56) & 1u;
-                        // F = the 120-bit base field, top-aligned; T = what follows the current window
-                        const uint64_t f_hi = (hi << 8) | (lo >> 56), f_lo = lo << 8;
-                        uint32_t l7 = (uint32_t)(f_hi >> (64 - 2 * HINT_LEN));                 // bases before the window, nearest lowest
-                        const uint64_t g_hi = (f_hi << (2 * HINT_LEN)) | (f_lo >> (64 - 2 * HINT_LEN)), g_lo = f_lo << (2 * HINT_LEN);
-                        uint64_t fw = g_hi >> (64 - 2 * k), rc = rc_packed(fw, k);
-                        uint64_t t_hi = (g_hi << (2 * k)) | (g_lo >> (64 - 2 * k)), t_lo = g_lo << (2 * k);
-                        uint32_t r7;  // bases after the window, nearest lowest
-                        {
-                            const uint32_t x = __brev((uint32_t)(t_hi >> (64 - 2 * HINT_LEN))) >> (32 - 2 * HINT_LEN);
-                            r7 = ((x & 0x1555u) << 1) | ((x >> 1) & 0x1555u);
+                        const bool mine = r < n && !(g && mulhi32(bin, t.n_regions) != region);
+                        const uint32_t nw = mine ? sk_windows(((uint64_t)rec.w << 32) | rec.z) : 0u;
+                        uint32_t incl = nw;  // inclusive scan of the window counts
+#pragma unroll
+                        for (uint32_t o = 1; o < 64; o <<= 1) {
+                            const uint32_t y = __shfl_up(incl, o);
+                            if (lane >= o) incl += y;
                         }
-                        for (uint32_t j = 0; j < nw; j++) {
-                            const bool flipped = rc < fw;
-                            const uint64_t key = flipped ? rc : fw;
+                        const uint32_t excl = incl - nw, total = __shfl(incl, 63);
+                        for (uint32_t i = 0; i < nw; i++) dq[excl + i] = (uint8_t)lane;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        for (uint32_t base = 0; base < total; base += 64) {
+                            const uint32_t w = base + lane;
+                            const bool act = w < total;
+                            const uint32_t src = act ? dq[w] : lane;
+                            const uint32_t rx = __shfl(rec.x, src), ry = __shfl(rec.y, src), rz = __shfl(rec.z, src), rw = __shfl(rec.w, src);
+                            const uint32_t j = w - __shfl(excl, src);
+                            if (!act) continue;
+                            const uint64_t lo = ((uint64_t)ry << 32) | rx, hi = ((uint64_t)rw << 32) | rz;
+                            // G = core + right context, top-aligned (the record's base field is 120 bits, 7 context bases first)
+                            const uint64_t g_hi = (hi << (8 + 2 * HINT_LEN)) | (lo >> (56 - 2 * HINT_LEN)), g_lo = lo << (8 + 2 * HINT_LEN);
+                            const uint32_t sh = 2 * j;  // (j <= 15)
+                            const uint64_t fw = ((g_hi << sh) | ((g_lo >> 1) >> (63 - sh))) >> (64 - 2 * k), rc = rc_packed(fw, k);
+                            const uint64_t key = rc < fw ? rc : fw;
                             uint32_t s = sk_home(key);
                             bool done = false;
                             for (uint32_t probe = 0; probe < REGION_SLOTS; probe++) {
@@ -1052,26 +1066,17 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                                 const uint32_t seen = atomicAdd(&L.cnt[s], 1u);
                                 const uint32_t have = seen >= hint_from ? L.aux[s] : (HINT_RV | HINT_LV);
                                 if ((have & (HINT_RV | HINT_LV)) != (HINT_RV | HINT_LV)) {  // the slot still lacks context
-                                    const bool lv = has_l || j >= (uint32_t)HINT_LEN, rv = j + HINT_LEN <= nw - 1 + (has_r ? HINT_LEN : 0);
-                                    const uint32_t R = flipped ? (l7 ^ 0x3FFFu) : r7, Lc = flipped ? (r7 ^ 0x3FFFu) : l7;
-                                    const bool RV = flipped ? lv : rv, LV = flipped ? rv : lv;
-                                    const uint32_t hint = (RV ? (R | HINT_RV) : 0u) | (LV ? ((Lc << 16) | HINT_LV) : 0u);
+                                    uint64_t key2;
+                                    uint32_t hint;
+                                    sk_expand(lo, hi, j, k, &key2, &hint);
                                     const uint32_t m = hint_merge(have, hint);
                                     if (m != have) L.aux[s] = m;  // racy on purpose: any occurrence's context will do
                                 }
                             } else {
                                 atomicExch(&L.overflow, 1u);
                             }
-                            // roll to window j + 1
-                            const uint32_t in = (uint32_t)(t_hi >> 62), out = (uint32_t)(fw >> (2 * (k - 1))) & 3u;
-                            const uint32_t far = (uint32_t)(t_hi >> (62 - 2 * HINT_LEN)) & 3u;  // the base HINT_LEN beyond `in`
-                            fw = ((fw << 2) | in) & kmask;
-                            rc = (rc >> 2) | ((uint64_t)(3u - in) << (2 * (k - 1)));
-                            l7 = ((l7 << 2) | out) & 0x3FFFu;
-                            r7 = (r7 >> 2) | (far << (2 * (HINT_LEN - 1)));
-                            t_hi = (t_hi << 2) | (t_lo >> 62);
-                            t_lo <<= 2;
                         }
+                        __builtin_amdgcn_wave_barrier();  // (the queue is rewritten by the next batch)
                     }
                 } else {
                 const uint64_t *keys = static_cast<const uint64_t *>(leaf_keys) + ((uint64_t)leaf * nseg + sgm) * seg_cap;
