@@ -911,6 +911,11 @@ __global__ void k_sk_add_records(const uint4 *__restrict__ recs, uint64_t n, int
 // has more regions than leaves).  `virgin`: the table holds nothing yet and is not read.
 // leaf_state[leaf]: 0 = to do, 1 = merged.  A leaf with a region that would overflow is left
 // untouched and stays at 0 for the retry after the host enlarged the table.
+// In LDS the top bit of a slot's count says "context known on both sides": the atomic add that counts an occurrence
+// then also tells whether the hint word needs a look at all (one LDS round trip less for most occurrences).  Counts
+// are held to 2^30 when a region comes in and goes out; a launch adds < 2^30, so bit 31 is never reached by counting.
+constexpr uint32_t P3_CTX_DONE = 1u << 31, P3_COUNT_CAP = 1u << 30;
+
 struct MergeLds {
     uint64_t key[REGION_SLOTS];
     uint32_t cnt[REGION_SLOTS];
@@ -960,8 +965,43 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
     // solid_thr != 0: keep *n_solid = number of keys with count >= solid_thr up to date (the coverage
     // threshold the BFS will ask for, mc_set_coverage_hint), which saves the BFS set-up a table sweep
     long long solid_delta = 0;
+    // A leaf starts with three dependent global reads (its state, its record count, its first records).  State and
+    // count of the NEXT leaf are requested when this one starts, its first records once this one's are merged (their
+    // addresses depend on the count: the waves share a leaf's records evenly), so that none of them costs waiting.
+    const uint32_t wv = tid >> 6, lane = tid & 63u;
+    constexpr uint32_t N_WAVES = P3_THREADS / 64;
+    uint32_t st_nxt = blockIdx.x < n_leaves ? leaf_state[blockIdx.x] : 1u;
+    uint32_t n0_nxt = 0;
+    uint4 pre_nxt = make_uint4(0, 0, 0, 0);
+    uint32_t pre_bin_nxt = 0;
+    auto fetch_first = [&](uint32_t lf, uint32_t n0) {  // lane's record of the wave's first batch in leaf lf
+        if constexpr (SK) {
+            const uint32_t per = (n0 + N_WAVES - 1) / N_WAVES, r = wv * per + lane, end = (wv + 1) * per < n0 ? (wv + 1) * per : n0;
+            if (r < end) {
+                pre_nxt = static_cast<const uint4 *>(leaf_keys)[(uint64_t)lf * nseg * seg_cap + r];
+                if (g) pre_bin_nxt = leaf_hints[(uint64_t)lf * nseg * seg_cap + r];
+            }
+        }
+    };
+    if constexpr (SK) {
+        if (blockIdx.x < n_leaves) {
+            n0_nxt = min(seg_counts[(uint64_t)blockIdx.x * nseg], (uint32_t)seg_cap);
+            fetch_first(blockIdx.x, n0_nxt);
+        }
+    }
     for (uint32_t leaf = blockIdx.x; leaf < n_leaves; leaf += gridDim.x) {
-        if (leaf_state[leaf]) continue;  // uniform
+        const uint32_t st_cur = st_nxt, n0_cur = n0_nxt, pre_bin_cur = pre_bin_nxt;
+        const uint4 pre_cur = pre_nxt;
+        const uint32_t nl = leaf + gridDim.x;
+        if (nl < n_leaves) {
+            st_nxt = leaf_state[nl];
+            if constexpr (SK) n0_nxt = min(seg_counts[(uint64_t)nl * nseg], (uint32_t)seg_cap);
+        }
+        bool first_fetched = false;
+        if (st_cur) {  // uniform
+            if (nl < n_leaves) fetch_first(nl, n0_nxt);
+            continue;
+        }
 
         // g == 0: the leaf is one region: merge and commit unless it overflows.  g > 0 (after the host
         // enlarged the table): a first sweep only checks that every sub-region fits, a second one commits,
@@ -975,23 +1015,15 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                 const uint64_t region = ((uint64_t)leaf << g) | sub;
                 Slot *gs = t.slots + region * REGION_SLOTS;
                 int solid_before = 0;
-                // (SK) the first records are requested before the region is set up in LDS
-                uint4 pre = make_uint4(0, 0, 0, 0);
-                uint32_t pre_bin = 0;
-                if constexpr (SK) {
-                    const uint32_t n0 = min(seg_counts[(uint64_t)leaf * nseg], (uint32_t)seg_cap);
-                    if (tid < n0) {
-                        pre = static_cast<const uint4 *>(leaf_keys)[(uint64_t)leaf * nseg * seg_cap + tid];
-                        if (g) pre_bin = leaf_hints[(uint64_t)leaf * nseg * seg_cap + tid];
-                    }
-                }
+                const uint4 pre = pre_cur;
+                const uint32_t pre_bin = pre_bin_cur;
                 for (uint32_t i = tid; i < REGION_SLOTS; i += P3_THREADS) {
                     if (virgin) {
                         L.key[i] = EMPTY_KEY; L.cnt[i] = 0; L.aux[i] = 0;
                     } else {
                         const uint4 raw = *reinterpret_cast<const uint4 *>(gs + i);
                         L.key[i] = ((uint64_t)raw.y << 32) | raw.x;
-                        L.cnt[i] = raw.z;
+                        L.cnt[i] = min(raw.z, P3_COUNT_CAP) | ((raw.w & (HINT_RV | HINT_LV)) == (HINT_RV | HINT_LV) ? P3_CTX_DONE : 0u);
                         L.aux[i] = raw.w;
                         solid_before += solid_thr && raw.z >= solid_thr;  // (empty slots hold count 0)
                     }
@@ -1000,7 +1032,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                 __syncthreads();
                 uint32_t my_new = 0;
                 for (uint32_t sgm = 0; sgm < nseg; sgm++) {
-                const uint32_t n = min(seg_counts[(uint64_t)leaf * nseg + sgm], (uint32_t)seg_cap);
+                const uint32_t n = (SK && sgm == 0) ? n0_cur : min(seg_counts[(uint64_t)leaf * nseg + sgm], (uint32_t)seg_cap);
                 if constexpr (SK) {
                     // A wave takes 64 records at a time and spreads their WINDOWS over its lanes: records hold 1-16
                     // windows, and a lane that walked its own record left the wave waiting for the longest one (lane
@@ -1011,19 +1043,21 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                     const uint4 *recs = static_cast<const uint4 *>(leaf_keys) + ((uint64_t)leaf * nseg + sgm) * seg_cap;
                     const uint32_t *bins = leaf_hints + ((uint64_t)leaf * nseg + sgm) * seg_cap;
                     const uint32_t hint_from = solid_thr >= 2 ? 1u : 0u;
-                    const uint32_t lane = tid & 63u;
-                    uint8_t *dq = L.dq[tid >> 6];
-                    uint4 nxt = sgm == 0 ? pre : (tid < n ? recs[tid] : make_uint4(0, 0, 0, 0));
-                    uint32_t nxt_bin = sgm == 0 ? pre_bin : ((g && tid < n) ? bins[tid] : 0u);
-                    for (uint32_t b0 = tid - lane; b0 < n; b0 += P3_THREADS) {  // wave-uniform
+                    uint8_t *dq = L.dq[wv];
+                    // the waves share the segment's records evenly (in batches of 64): the barrier behind the merge
+                    // waits for the slowest wave
+                    const uint32_t per = (n + N_WAVES - 1) / N_WAVES, r_lo = wv * per, r_hi = r_lo + per < n ? r_lo + per : n;
+                    uint4 nxt = sgm == 0 ? pre : (r_lo + lane < r_hi ? recs[r_lo + lane] : make_uint4(0, 0, 0, 0));
+                    uint32_t nxt_bin = sgm == 0 ? pre_bin : ((g && r_lo + lane < r_hi) ? bins[r_lo + lane] : 0u);
+                    for (uint32_t b0 = r_lo; b0 < r_hi; b0 += 64) {  // wave-uniform
                         const uint32_t r = b0 + lane;
                         const uint4 rec = nxt;
                         const uint32_t bin = nxt_bin;
-                        if (r + P3_THREADS < n) {
-                            nxt = recs[r + P3_THREADS];
-                            if (g) nxt_bin = bins[r + P3_THREADS];
+                        if (r + 64 < r_hi) {
+                            nxt = recs[r + 64];
+                            if (g) nxt_bin = bins[r + 64];
                         }
-                        const bool mine = r < n && !(g && mulhi32(bin, t.n_regions) != region);
+                        const bool mine = r < r_hi && !(g && mulhi32(bin, t.n_regions) != region);
                         const uint32_t nw = mine ? sk_windows(((uint64_t)rec.w << 32) | rec.z) : 0u;
                         uint32_t incl = nw;  // inclusive scan of the window counts
 #pragma unroll
@@ -1035,12 +1069,20 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                         for (uint32_t i = 0; i < nw; i++) dq[excl + i] = (uint8_t)lane;
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
+                        // the record words of chunk c + 1 are on their way while chunk c probes the region
+                        uint32_t src_n = lane < total ? dq[lane] : lane;
+                        uint32_t nx = __shfl(rec.x, src_n), ny = __shfl(rec.y, src_n), nz = __shfl(rec.z, src_n), nw4 = __shfl(rec.w, src_n);
+                        uint32_t ne = __shfl(excl, src_n);
                         for (uint32_t base = 0; base < total; base += 64) {
                             const uint32_t w = base + lane;
                             const bool act = w < total;
-                            const uint32_t src = act ? dq[w] : lane;
-                            const uint32_t rx = __shfl(rec.x, src), ry = __shfl(rec.y, src), rz = __shfl(rec.z, src), rw = __shfl(rec.w, src);
-                            const uint32_t j = w - __shfl(excl, src);
+                            const uint32_t rx = nx, ry = ny, rz = nz, rw = nw4;
+                            const uint32_t j = w - ne;
+                            if (base + 64 < total) {
+                                src_n = w + 64 < total ? dq[w + 64] : lane;
+                                nx = __shfl(rec.x, src_n); ny = __shfl(rec.y, src_n); nz = __shfl(rec.z, src_n); nw4 = __shfl(rec.w, src_n);
+                                ne = __shfl(excl, src_n);
+                            }
                             if (!act) continue;
                             const uint64_t lo = ((uint64_t)ry << 32) | rx, hi = ((uint64_t)rw << 32) | rz;
                             // G = core + right context, top-aligned (the record's base field is 120 bits, 7 context bases first)
@@ -1064,13 +1106,22 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                                 // context is only collected from the second occurrence on when the coverage threshold is
                                 // known to be above 1: sequencing errors (most distinct k-mers, seen once) never reach the BFS
                                 const uint32_t seen = atomicAdd(&L.cnt[s], 1u);
-                                const uint32_t have = seen >= hint_from ? L.aux[s] : (HINT_RV | HINT_LV);
-                                if ((have & (HINT_RV | HINT_LV)) != (HINT_RV | HINT_LV)) {  // the slot still lacks context
+                                if (seen >= hint_from && seen < P3_CTX_DONE) {  // counted before, and the slot still lacks context
                                     uint64_t key2;
                                     uint32_t hint;
                                     sk_expand(lo, hi, j, k, &key2, &hint);
-                                    const uint32_t m = hint_merge(have, hint);
-                                    if (m != have) L.aux[s] = m;  // racy on purpose: any occurrence's context will do
+                                    // Several occurrences of a key often sit in one chunk (a region holds ~30 copies of
+                                    // each of its super-k-mers): a side once known is never replaced, so the flag below
+                                    // is only raised over a hint word that really has both.
+                                    uint32_t have = L.aux[s], m;
+                                    for (;;) {
+                                        m = hint_merge(have, hint);
+                                        if (m == have) break;
+                                        const uint32_t old = atomicCAS(&L.aux[s], have, m);
+                                        if (old == have) break;
+                                        have = old;
+                                    }
+                                    if ((m & (HINT_RV | HINT_LV)) == (HINT_RV | HINT_LV)) atomicOr(&L.cnt[s], P3_CTX_DONE);
                                 }
                             } else {
                                 atomicExch(&L.overflow, 1u);
@@ -1102,6 +1153,10 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                 }
                 }
                 }
+                if (!first_fetched && nl < n_leaves) {  // the next leaf's first records: its count has long arrived
+                    fetch_first(nl, n0_nxt);
+                    first_fetched = true;
+                }
                 if (my_new) atomicAdd(&L.n_new, my_new);
                 __syncthreads();
                 const bool ovf = L.overflow != 0;
@@ -1111,7 +1166,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                         uint4 v;
                         const uint64_t kk = L.key[i];
                         v.x = (uint32_t)kk; v.y = (uint32_t)(kk >> 32);
-                        v.z = L.cnt[i] > 0x80000000u ? 0x80000000u : L.cnt[i];  // counters stop at 2^31 (kmer_device.h)
+                        v.z = min(L.cnt[i] & ~P3_CTX_DONE, P3_COUNT_CAP);  // counters stop at 2^30 here (anything above 32767 reads the same)
                         v.w = L.aux[i];
                         *reinterpret_cast<uint4 *>(gs + i) = v;
                         solid_delta += solid_thr && v.z >= solid_thr;
