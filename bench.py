@@ -79,8 +79,9 @@ def main():
     n_bases = R * L
     windows = R * (L - k + 1)
     genome_bases = args.contigs * args.contig_len
-    # expected distinct keys: the genome's k-mers + ~k novel k-mers per substitution error
-    est_distinct = int(min(world * windows, genome_bases + world * n_bases * (args.err / 10000.0) * k * 0.9))
+    # expected distinct keys: the genome's k-mers + ~0.7 k novel k-mers per substitution error (fewer than k near read
+    # ends and where two errors share a window; measured 0.67 k at k = 31, 1 % errors)
+    est_distinct = int(min(world * windows, genome_bases + world * n_bases * (args.err / 10000.0) * k * 0.7))
     hint_local = args.capacity_hint or est_distinct // world + (1 << 20)
 
     ctx = m.Context(k, mode, local_rank, hint_local)
@@ -180,7 +181,7 @@ def main():
             pipeline = st.p3_ms > 0
             dominant = max(parts, key=parts.get) if pipeline else "k_count_reads"
             traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_v5_pmc_hbm_traffic_e1.csv")
+            pmc = os.path.join(ROOT, "profiles", "r01_v6_pmc_hbm_traffic_e1.csv")
             if pipeline and world == 1 and args.err == 100 and R == 10_000_000 and k == 31 and os.path.exists(pmc):
                 # HBM bytes per pipeline run from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes,
                 # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes), collected by scripts/gpu_pmc.sh
