@@ -14,6 +14,15 @@ sys.path.insert(0, ROOT)
 
 
 def worker(rank, world, port, k, q):
+    try:
+        _worker(rank, world, port, k, q)
+    except BaseException:
+        import traceback
+        q.put(("error", rank, traceback.format_exc()))  # the parent reports it at once instead of timing out
+        raise
+
+
+def _worker(rank, world, port, k, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -63,7 +72,13 @@ if __name__ == "__main__":
     procs = [ctx.Process(target=worker, args=(r, 2, port, k, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = q.get(timeout=120)
+    res = q.get(timeout=300)
+    if res[0] != "ok":
+        for p in procs:
+            p.join(timeout=20)
+            if p.is_alive():
+                p.terminate()
+        raise SystemExit("rank %d failed:\n%s" % (res[1], res[2]))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0, p.exitcode
