@@ -217,7 +217,7 @@ def main():
             "distinct_kmers": distinct, "bfs": {"ms_per_step": round(info["bfs_ms"], 3), "reached": info["reached"],
                                                  "levels": info["levels"], "lookups": info["lookups"]},
             "table_bytes": int(st.table_bytes), "table_grows": int(st.grows),
-            "spilled_records_per_step": int(st.spill_keys) // args.steps, "solid_sweeps_per_step": int(st.solid_sweeps) / args.steps,
+            "spilled_records_per_step": int(st.spill_keys) // args.steps, "solid_sweeps_per_step": int(st.solid_sweeps) / args.steps, "solid_list_builds_per_step": int(st.solid_list_builds) / args.steps,
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if world > 1:

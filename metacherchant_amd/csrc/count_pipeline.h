@@ -922,6 +922,18 @@ struct MergeLds {
     uint32_t aux[REGION_SLOTS];
     uint8_t dq[P3_THREADS / 64][64 * SK_MAX_WINDOWS];  // per wave: window -> lane holding its record (k_p3_merge<true>)
     uint32_t n_new, overflow;
+    uint32_t emit_cur;  // fill level of this workgroup's segment of the solid list (P3Emit)
+};
+
+// The solid list: while a merged region goes back to HBM, its entries with count >= solid_thr are also appended,
+// as (key, min(count, 32767), hint), to the workgroup's own segment of a list -- every batch rewrites every region, so
+// after the last batch the list holds exactly what the BFS table is built from and the counting table need not be
+// swept for it.  counts[wg] = the segment's fill level (kept across the retry launches of one batch).
+struct P3Emit {
+    uint4 *recs;       // nullptr: no list
+    uint32_t *counts;  // one per workgroup of the launch
+    uint64_t seg_cap;
+    uint32_t *lost;    // set when a segment overflows: the list is then not used
 };
 
 
@@ -958,10 +970,12 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                                                          const uint32_t *__restrict__ seg_counts, uint64_t seg_cap,
                                                          uint32_t nseg, uint32_t n_leaves, uint32_t g, TableView t, int virgin,
                                                          uint32_t *leaf_state, uint32_t *leaf_new, uint32_t *any_failed,
-                                                         uint32_t solid_thr, unsigned long long *n_solid, int k)
+                                                         uint32_t solid_thr, unsigned long long *n_solid, int k, P3Emit emit)
 {
     __shared__ MergeLds L;
     const uint32_t tid = threadIdx.x;
+    const bool emitting = emit.recs != nullptr && solid_thr != 0;
+    if (tid == 0) L.emit_cur = emitting ? emit.counts[blockIdx.x] : 0u;  // (published by the first barrier below)
     // solid_thr != 0: keep *n_solid = number of keys with count >= solid_thr up to date (the coverage
     // threshold the BFS will ask for, mc_set_coverage_hint), which saves the BFS set-up a table sweep
     long long solid_delta = 0;
@@ -1169,7 +1183,26 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                         v.z = min(L.cnt[i] & ~P3_CTX_DONE, P3_COUNT_CAP);  // counters stop at 2^30 here (anything above 32767 reads the same)
                         v.w = L.aux[i];
                         *reinterpret_cast<uint4 *>(gs + i) = v;
-                        solid_delta += solid_thr && v.z >= solid_thr;
+                        const bool solid = solid_thr && v.z >= solid_thr;
+                        solid_delta += solid;
+                        if (emitting) {  // (uniform; the loop's trip count is the same for every lane)
+                            const unsigned long long m = __ballot(solid);
+                            if (m) {
+                                uint32_t base = 0;
+                                const int leader = __ffsll((long long)m) - 1;
+                                if ((int)(tid & 63u) == leader) base = atomicAdd(&L.emit_cur, (uint32_t)__popcll(m));
+                                base = __shfl(base, leader);
+                                if (solid) {
+                                    const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << (tid & 63u)) - 1));
+                                    if (pos < emit.seg_cap) {
+                                        v.z = min(v.z, 32767u);
+                                        emit.recs[(uint64_t)blockIdx.x * emit.seg_cap + pos] = v;
+                                    } else {
+                                        atomicExch(emit.lost, 1u);
+                                    }
+                                }
+                            }
+                        }
                     }
                     solid_delta -= solid_before;
                     if (tid == 0) new_total += L.n_new;
@@ -1188,6 +1221,10 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
         }
     }
     if (solid_thr) wave_add_ull(n_solid, (unsigned long long)solid_delta);  // (two's complement: deltas may be negative)
+    if (emitting) {
+        __syncthreads();
+        if (tid == 0) emit.counts[blockIdx.x] = (uint64_t)L.emit_cur < emit.seg_cap ? L.emit_cur : (uint32_t)emit.seg_cap;  // (seg_cap < 2^32)
+    }
 }
 
 // n_used += sum(leaf_new): one atomic per workgroup instead of one per region on a single hot address

@@ -63,6 +63,11 @@ struct mc_ctx {
     int walk_cus = 0;
     hipStream_t side_stream = nullptr;  // the hint-doubling sweep runs here, next to the walk (mc_bfs_batch)
     bool double_deferred = false;       // the solid table is built but its hints are not doubled yet
+    // The solid list P3 left in pipe.a_recs (count_pipeline.h P3Emit): valid for threshold cov_hint until anything
+    // else touches the table or the pipeline buffers.
+    bool solid_list_fresh = false;
+    uint32_t solid_list_segs = 0;
+    uint64_t solid_list_segcap = 0;
 
     // table
     Slot *slots = nullptr;
@@ -104,13 +109,14 @@ struct mc_ctx {
         uint64_t a_recs_cap = 0, b_recs_cap = 0, spill_recs_cap = 0;
         uint32_t *solid_cursors = nullptr;  // leaf fill levels of the solid-table build (minimizer-bin tables)
         uint64_t solid_cursors_cap = 0;
-        uint32_t *cursors1 = nullptr, *seg_counts1 = nullptr, *cursors2 = nullptr, *leaf_state = nullptr, *leaf_new = nullptr, *flags = nullptr;  // cursors1: owner cursors (multi-GPU split); cursors2: leaf fill levels; flags: [0] spill lost, [1] any leaf failed
+        uint32_t *emit_counts = nullptr;  // fill levels of the solid list's segments (one per P3 workgroup)
+        uint32_t *cursors1 = nullptr, *seg_counts1 = nullptr, *cursors2 = nullptr, *leaf_state = nullptr, *leaf_new = nullptr, *flags = nullptr;  // cursors1: owner cursors (multi-GPU split); cursors2: leaf fill levels; flags: [0] spill lost, [1] any leaf failed, [2] a segment of the solid list overflowed
         unsigned long long *spill_count = nullptr;
         uint64_t a_cap = 0, b_cap = 0, spill_cap = 0, tiles1_cap = 0, leaves_cap = 0, segs1_cap = 0, a_hints_cap = 0, b_hints_cap = 0;
         void release()
         {
             (void)hipFree(a_keys); (void)hipFree(b_keys); (void)hipFree(spill_keys);
-            (void)hipFree(a_recs); (void)hipFree(b_recs); (void)hipFree(spill_recs); (void)hipFree(solid_cursors);
+            (void)hipFree(a_recs); (void)hipFree(b_recs); (void)hipFree(spill_recs); (void)hipFree(solid_cursors); (void)hipFree(emit_counts);
             (void)hipFree(a_hints); (void)hipFree(b_hints); (void)hipFree(spill_hints); (void)hipFree(tile_first);
             (void)hipFree(cursors1); (void)hipFree(seg_counts1); (void)hipFree(cursors2); (void)hipFree(leaf_state); (void)hipFree(leaf_new); (void)hipFree(flags);
             (void)hipFree(spill_count);
@@ -386,6 +392,42 @@ __global__ void __launch_bounds__(PT_THREADS) k_solid_emit_pairs(const int64_t *
         __syncthreads();
         if (tid < n_buckets) { C.wcur[tid] += C.cnt[tid]; C.cnt[tid] = 0; }
         __syncthreads();
+    }
+    if (tid < n_buckets) seg_counts[(uint64_t)tid * PT_SEGMENTS + blockIdx.x] = min(C.wcur[tid], (uint32_t)cap);
+}
+
+// ... and for the solid list P3 left behind (count_pipeline.h P3Emit): nseg segments of (key, count, hint) records.
+// Workgroup b takes segments b, b + gridDim.x, ...: a segment holds what one P3 workgroup saw, regions from all over
+// the table, so every workgroup here feeds all buckets evenly.
+__global__ void __launch_bounds__(PT_THREADS) k_solid_emit_list(const uint4 *__restrict__ list, const uint32_t *__restrict__ list_counts,
+                                                                 uint32_t nseg, uint64_t list_segcap, uint32_t np1, uint32_t *seg_counts,
+                                                                 uint64_t cap, uint4 *out_recs, uint32_t *out_bins, SkSpill sp)
+{
+    __shared__ SkCursors C;
+    const uint32_t tid = threadIdx.x, n_buckets = np1;
+    if (tid < PT_MAX_BUCKETS) { C.wcur[tid] = 0; C.cnt[tid] = 0; }
+    __syncthreads();
+    for (uint32_t sg = blockIdx.x; sg < nseg; sg += gridDim.x) {
+        const uint32_t n = list_counts[sg];
+        const uint4 *src = list + (uint64_t)sg * list_segcap;
+        for (uint32_t i0 = 0; i0 < n; i0 += PT_TILE) {
+            uint4 raws[PT_ITEMS];
+#pragma unroll
+            for (int j = 0; j < PT_ITEMS; j++) {
+                const uint32_t i = i0 + tid + (uint32_t)j * PT_THREADS;
+                raws[j] = i < n ? src[i] : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < PT_ITEMS; j++) {
+                const uint64_t key = ((uint64_t)raws[j].y << 32) | raws[j].x;
+                if (key == EMPTY_KEY) continue;  // (padding of the last tile; the table never holds this key)
+                const uint32_t bin = (uint32_t)(fmix64(key) >> 32);
+                sk_emit(C, mulhi32(bin, np1), raws[j], bin, cap, (uint64_t)blockIdx.x * cap, (uint64_t)PT_SEGMENTS * cap, out_recs, out_bins, sp);
+            }
+            __syncthreads();
+            if (tid < n_buckets) { C.wcur[tid] += C.cnt[tid]; C.cnt[tid] = 0; }
+            __syncthreads();
+        }
     }
     if (tid < n_buckets) seg_counts[(uint64_t)tid * PT_SEGMENTS + blockIdx.x] = min(C.wcur[tid], (uint32_t)cap);
 }
@@ -752,6 +794,7 @@ static void launch_count(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_o
     const int grid = grid_for((r1 - r0) * 64, block, 256 * 8);
     const TableView t = c->view();
     c->solid_tracked = false;
+    c->solid_list_fresh = false;
     switch (c->cfg.key_mode) {
     case MC_KEY_PACKED:
         hipLaunchKernelGGL(k_count_reads<KEY_PACKED>, dim3(grid), dim3(block), 0, c->stream, d_words, d_off, r0, r1,
@@ -792,6 +835,7 @@ struct PipePlan {
 static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records = 0)
 {
     mc_ctx::Pipe &P = c->pipe;
+    c->solid_list_fresh = false;  // the pipeline buffers are about to be reused
     // Make sure the table can take the batch: with a capacity hint that still holds the table was sized for
     // it; without one assume every eighth occurrence is a new key at most.  Either way the merge kernel
     // reports regions that would overflow and the table is grown then.
@@ -854,13 +898,13 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
     ENSURE(P.seg_counts1, P.segs1_cap, np1 * PT_SEGMENTS);
     { uint64_t cap = P.leaves_cap; ENSURE(P.cursors2, cap, n_leaves); dummy = P.leaves_cap; ENSURE(P.leaf_state, dummy, n_leaves); dummy = P.leaves_cap; ENSURE(P.leaf_new, dummy, n_leaves); P.leaves_cap = cap; }
 #undef ENSURE
-    if (!P.flags) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.flags), 2 * sizeof(uint32_t)));
+    if (!P.flags) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.flags), 4 * sizeof(uint32_t)));
     if (!P.spill_count) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.spill_count), sizeof(unsigned long long)));
     HIPCHK(c, hipMemsetAsync(P.seg_counts1, 0, np1 * PT_SEGMENTS * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(P.cursors2, 0, n_leaves * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(P.leaf_state, 0, n_leaves * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(P.leaf_new, 0, n_leaves * sizeof(uint32_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(P.flags, 0, 2 * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(P.flags, 0, 4 * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(P.spill_count, 0, sizeof(unsigned long long), c->stream));
     pl->sp = SpillView{P.spill_keys, P.spill_hints, P.spill_count, pl->spill_cap, P.flags};
     pl->sks = SkSpill{P.spill_recs, P.spill_count, pl->spill_cap, P.flags};
@@ -900,22 +944,35 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1)
     const uint32_t *lc = pl.b2 > 1 ? P.cursors2 : P.seg_counts1;
     const uint64_t lcap = pl.b2 > 1 ? pl.cap2 : pl.cap1;
     const uint32_t lseg = pl.b2 > 1 ? 1u : (uint32_t)PT_SEGMENTS;
+    // The solid list (P3Emit): super-k-mer form with the leaves in b_recs, so that a_recs is free to take it, and a
+    // threshold to track.  Each P3 workgroup owns a segment.
+    const int p3_grid = (int)std::min<uint64_t>(n_leaves, 256 * 2 * 4);
+    P3Emit emit{nullptr, nullptr, 0, P.flags + 2};
+    static const bool no_list = getenv("MC_NO_SOLID_LIST") != nullptr;
+    if (pl.sk && pl.b2 > 1 && c->mm_k && c->solid_tracked && c->cov_hint > 0 && !no_list) {
+        if (!P.emit_counts) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.emit_counts), 256 * 2 * 4 * sizeof(uint32_t)));
+        HIPCHK(c, hipMemsetAsync(P.emit_counts, 0, 256 * 2 * 4 * sizeof(uint32_t), c->stream));
+        emit.recs = P.a_recs;
+        emit.counts = P.emit_counts;
+        emit.seg_cap = std::min<uint64_t>(P.a_recs_cap / (uint64_t)p3_grid, 0xFFFFFFF0ull);
+    }
     // P3, retried with a larger table when a region overflows
     for (int attempt = 0;; attempt++) {
         const int virgin = c->virgin ? 1 : 0;
         rc = timed(c, &ms3, [&] {
-            const int grid = (int)std::min<uint64_t>(n_leaves, 256 * 2 * 4);
+            const int grid = p3_grid;
 #define P3_ARGS lk, lh, lc, lcap, lseg, (uint32_t)n_leaves, pl.g, c->view(), virgin, P.leaf_state, P.leaf_new, P.flags + 1, \
-                (uint32_t)(c->solid_tracked ? c->cov_hint : 0), c->d_ctr + 6, k
+                (uint32_t)(c->solid_tracked ? c->cov_hint : 0), c->d_ctr + 6, k, emit
             if (pl.sk) hipLaunchKernelGGL(k_p3_merge<true>, dim3(grid), dim3(P3_THREADS), 0, c->stream, P3_ARGS);
             else hipLaunchKernelGGL(k_p3_merge<false>, dim3(grid), dim3(P3_THREADS), 0, c->stream, P3_ARGS);
 #undef P3_ARGS
         });
         if (rc) return rc;
         c->virgin = false;
-        uint32_t flags[2];
+        uint32_t flags[3];
         HIPCHK(c, hipMemcpy(flags, P.flags, sizeof flags, hipMemcpyDeviceToHost));
         if (flags[0]) return fail(c, MC_EOVERFLOW, "internal: spill list of the partitioned counting pipeline overflowed");
+        if (flags[2]) emit.recs = nullptr;  // a segment of the solid list overflowed: the BFS set-up sweeps the table instead
         if (!flags[1]) break;
         if (attempt >= 6 || pl.g >= 5)
             return fail(c, MC_EOVERFLOW, "k-mer table regions keep overflowing; pass a capacity_hint (distinct k-mers)");
@@ -951,6 +1008,11 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1)
             if (rc) return rc;
             i += m;
         }
+    }
+    if (emit.recs && !n_spill) {  // (spilled records went into the table behind P3's back)
+        c->solid_list_fresh = true;
+        c->solid_list_segs = (uint32_t)p3_grid;
+        c->solid_list_segcap = emit.seg_cap;
     }
     c->st.p1_ms += ms1;
     c->st.p2_ms += ms2;
@@ -1264,6 +1326,7 @@ int mc_clear(mc_ctx *c)
     c->finalized = false;
     c->solid_cov = -1; c->solid_external = false;
     c->solid_tracked = true;
+    c->solid_list_fresh = false;
     return MC_OK;
 }
 
@@ -1273,6 +1336,7 @@ int mc_set_coverage_hint(mc_ctx *c, int min_cov)
     std::lock_guard<std::mutex> g(c->mu);
     if (min_cov < 0 || min_cov > 32767) return fail(c, MC_EINVAL, "mc_set_coverage_hint: min_cov must be in 0..32767");
     if (min_cov != c->cov_hint && !c->virgin) c->solid_tracked = false;  // keys already counted were not tracked at this threshold
+    if (min_cov != c->cov_hint) c->solid_list_fresh = false;
     c->cov_hint = min_cov;
     return MC_OK;
 }
@@ -1430,6 +1494,7 @@ int mc_add_keys_dev(mc_ctx *c, const int64_t *d_keys, const uint32_t *d_hints, u
         }
     } else {
         c->solid_tracked = false;
+        c->solid_list_fresh = false;
         uint64_t i = 0;
         while (i < n) {
             uint64_t allowed;
@@ -1464,6 +1529,7 @@ int mc_add_pairs_dev(mc_ctx *c, const int64_t *d_keys, const int16_t *d_counts, 
     if ((!d_keys || !d_counts) && n) return fail(c, MC_EINVAL, "mc_add_pairs_dev: null pointer");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     c->solid_tracked = false;
+    c->solid_list_fresh = false;
     uint64_t i = 0;
     while (i < n) {
         uint64_t allowed;
@@ -1667,9 +1733,9 @@ int mc_extract_superkmers_dev(mc_ctx *c, const uint64_t *d_words, const uint64_t
     if (!rc) rc = ensure_buf(c, &P.a_hints, &P.a_hints_cap, (uint64_t)n_owners * PT_SEGMENTS * seg_cap);
     if (!rc) rc = ensure_buf(c, &P.seg_counts1, &P.segs1_cap, (uint64_t)n_owners * PT_SEGMENTS);
     if (rc) return rc;
-    if (!P.flags) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.flags), 2 * sizeof(uint32_t)));
+    if (!P.flags) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.flags), 4 * sizeof(uint32_t)));
     if (!P.spill_count) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.spill_count), sizeof(unsigned long long)));
-    HIPCHK(c, hipMemsetAsync(P.flags, 0, 2 * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(P.flags, 0, 4 * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(P.spill_count, 0, sizeof(unsigned long long), c->stream));
     DevBuf<unsigned long long> d_piece, d_owner;
     HIPCHK(c, d_piece.alloc((uint64_t)n_owners * PT_SEGMENTS));
@@ -1956,7 +2022,7 @@ struct PairSource { const int64_t *keys; const int16_t *counts; const uint32_t *
 
 // Builds the solid table for n entries with count >= min_cov, taken from the counting table or (pairs != nullptr)
 // from arrays of (key, count, hint).
-int solid_build(mc_ctx *c, uint64_t n, int min_cov, double *ms, const PairSource *pairs, bool defer_double = false)
+int solid_build(mc_ctx *c, uint64_t n, int min_cov, double *ms, const PairSource *pairs, bool defer_double = false, bool from_list = false)
 {
     c->n_solid = n;
     c->st.solid_kmers = n;
@@ -1984,33 +2050,50 @@ int solid_build(mc_ctx *c, uint64_t n, int min_cov, double *ms, const PairSource
         scap1 = (uint64_t)(m1 * 1.25 + 10.0 * std::sqrt(m1) + 64.0);
         if (pairs) scap1 += 64;  // rows of 64 entries are dealt to the segments: one of them may bring a whole row more
         scap2 = (uint64_t)(m2 * 1.15 + 10.0 * std::sqrt(m2) + 64.0);
-        rc = ensure_buf(c, &P.a_recs, &P.a_recs_cap, (uint64_t)(1ull << sb1) * PT_SEGMENTS * scap1);
-        if (!rc) rc = ensure_buf(c, &P.a_hints, &P.a_hints_cap, (uint64_t)(1ull << sb1) * PT_SEGMENTS * scap1);
+        const uint64_t need1 = (uint64_t)(1ull << sb1) * PT_SEGMENTS * scap1, need2 = sb2 ? (uint64_t)(1ull << q) * scap2 : 0;
+        // The solid list sits in a_recs: the level-1 buckets then go to b_recs and the leaves, once the list has been
+        // read, to a_recs -- which must not be reallocated for it (and a one-level build would have to read and
+        // write a_recs at once): otherwise the table is swept as usual.
+        if (from_list && (!sb2 || need2 > P.a_recs_cap || need2 > P.a_hints_cap)) from_list = false;
+        uint4 **l1_recs = from_list ? &P.b_recs : &P.a_recs, **l2_recs = from_list ? &P.a_recs : &P.b_recs;
+        uint32_t **l1_bins = from_list ? &P.b_hints : &P.a_hints, **l2_bins = from_list ? &P.a_hints : &P.b_hints;
+        uint64_t *l1_recs_cap = from_list ? &P.b_recs_cap : &P.a_recs_cap, *l2_recs_cap = from_list ? &P.a_recs_cap : &P.b_recs_cap;
+        uint64_t *l1_bins_cap = from_list ? &P.b_hints_cap : &P.a_hints_cap, *l2_bins_cap = from_list ? &P.a_hints_cap : &P.b_hints_cap;
+        rc = ensure_buf(c, l1_recs, l1_recs_cap, need1);
+        if (!rc) rc = ensure_buf(c, l1_bins, l1_bins_cap, need1);
         if (!rc) rc = ensure_buf(c, &P.seg_counts1, &P.segs1_cap, (uint64_t)(1ull << sb1) * PT_SEGMENTS);
-        if (!rc && sb2) rc = ensure_buf(c, &P.b_recs, &P.b_recs_cap, (uint64_t)(1ull << q) * scap2);
-        if (!rc && sb2) rc = ensure_buf(c, &P.b_hints, &P.b_hints_cap, (uint64_t)(1ull << q) * scap2);
+        if (!rc && sb2) rc = ensure_buf(c, l2_recs, l2_recs_cap, need2);
+        if (!rc && sb2) rc = ensure_buf(c, l2_bins, l2_bins_cap, need2);
         if (!rc && sb2) rc = ensure_buf(c, &P.solid_cursors, &P.solid_cursors_cap, 1ull << q);
         if (rc) return rc;
-        if (!P.flags) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.flags), 2 * sizeof(uint32_t)));
+        if (!P.flags) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.flags), 4 * sizeof(uint32_t)));
         if (!P.spill_count) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.spill_count), sizeof(unsigned long long)));
-        HIPCHK(c, hipMemsetAsync(P.flags, 0, 2 * sizeof(uint32_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(P.flags, 0, 4 * sizeof(uint32_t), c->stream));
         HIPCHK(c, hipMemsetAsync(P.spill_count, 0, sizeof(unsigned long long), c->stream));
     }
+    const bool list = partitioned && from_list && !pairs;
+    uint4 *const r1 = list ? P.b_recs : P.a_recs, *const r2 = list ? P.a_recs : P.b_recs;
+    uint32_t *const h1 = list ? P.b_hints : P.a_hints, *const h2 = list ? P.a_hints : P.b_hints;
+    c->solid_list_fresh = false;  // (read below, then overwritten by the leaves)
+    if (list) c->st.solid_list_builds++;
     rc = timed(c, ms, [&] {
         if (partitioned) {
             uint32_t *leaf_counts = P.solid_cursors;
             const SkSpill none{nullptr, P.spill_count, 0, P.flags};  // no spill list: an overflow is reported
             if (pairs)
                 hipLaunchKernelGGL(k_solid_emit_pairs, dim3(PT_SEGMENTS), dim3(PT_THREADS), 0, c->stream, pairs->keys, pairs->counts,
-                                   pairs->hints, pairs->n, min_cov, 1u << sb1, P.seg_counts1, scap1, P.a_recs, P.a_hints, none, c->d_ctr + 1);
+                                   pairs->hints, pairs->n, min_cov, 1u << sb1, P.seg_counts1, scap1, r1, h1, none, c->d_ctr + 1);
+            else if (list)
+                hipLaunchKernelGGL(k_solid_emit_list, dim3(PT_SEGMENTS), dim3(PT_THREADS), 0, c->stream, P.a_recs, P.emit_counts,
+                                   c->solid_list_segs, c->solid_list_segcap, 1u << sb1, P.seg_counts1, scap1, r1, h1, none);
             else
                 hipLaunchKernelGGL(k_solid_emit, dim3(PT_SEGMENTS), dim3(PT_THREADS), 0, c->stream, c->slots, c->n_slots(), min_cov, 1u << sb1,
-                                   P.seg_counts1, scap1, P.a_recs, P.a_hints, none);
+                                   P.seg_counts1, scap1, r1, h1, none);
             if (sb2)
-                hipLaunchKernelGGL(k_sk2_scatter, dim3(1u << sb1), dim3(PT_THREADS), 0, c->stream, P.a_recs, P.a_hints, scap1,
-                                   P.seg_counts1, 1u << sb1, 1u << sb1, 1u << sb2, leaf_counts, scap2, P.b_recs, P.b_hints, none);
+                hipLaunchKernelGGL(k_sk2_scatter, dim3(1u << sb1), dim3(PT_THREADS), 0, c->stream, r1, h1, scap1,
+                                   P.seg_counts1, 1u << sb1, 1u << sb1, 1u << sb2, leaf_counts, scap2, r2, h2, none);
             hipLaunchKernelGGL(k_solid_from_leaves, dim3((unsigned)std::min<uint64_t>(1ull << q, 256 * 2 * 8)), dim3(512), 0, c->stream,
-                               sb2 ? P.b_recs : P.a_recs, sb2 ? leaf_counts : P.seg_counts1, sb2 ? scap2 : scap1,
+                               sb2 ? r2 : r1, sb2 ? leaf_counts : P.seg_counts1, sb2 ? scap2 : scap1,
                                sb2 ? 1u : (uint32_t)PT_SEGMENTS, c->solid_view(), lg);
         } else {
             hipLaunchKernelGGL(k_build_solid_regions, dim3((unsigned)std::min<uint64_t>(1ull << (lg - SOLID_SB), 256 * 2 * 8)), dim3(512), 0,
@@ -2046,8 +2129,10 @@ int ensure_solid(mc_ctx *c, int min_cov, double *ms, bool defer_double = false)
     c->solid_cov = -1; c->solid_external = false;
     unsigned long long *cursor = c->d_ctr + 2;
     int rc;
+    bool from_list = false;
     if (c->solid_tracked && c->cov_hint == min_cov && min_cov > 0 && !c->virgin) {
         cursor = c->d_ctr + 6;  // kept up to date by k_p3_merge
+        from_list = c->solid_list_fresh && c->mm_k;  // ... which also listed those keys
     } else {
         HIPCHK(c, hipMemsetAsync(cursor, 0, sizeof(unsigned long long), c->stream));
         rc = timed(c, ms, [&] {
@@ -2059,7 +2144,7 @@ int ensure_solid(mc_ctx *c, int min_cov, double *ms, bool defer_double = false)
     }
     unsigned long long n = 0;
     HIPCHK(c, hipMemcpy(&n, cursor, sizeof n, hipMemcpyDeviceToHost));
-    return solid_build(c, n, min_cov, ms, nullptr, defer_double);
+    return solid_build(c, n, min_cov, ms, nullptr, defer_double, from_list);
 }
 
 void launch_bfs(mc_ctx *c, hipStream_t stream, const BfsState *d_states, uint32_t n_jobs, int min_cov, int64_t max_kmers,

@@ -258,6 +258,46 @@ def test_coverage_hint_tracks_solid_count_over_batches(mc, monkeypatch):
     ctx.close()
 
 
+def test_solid_list_from_the_merge_kernel(mc, monkeypatch):
+    """With the threshold known while counting, the merge kernel lists the keys at or above it as it writes each
+    region back (tables of more than 512 regions), and the BFS set-up builds its table from that list instead of
+    sweeping the counting table: same walks; the list is rebuilt by every batch, dropped when another kernel adds
+    keys, and not used for another threshold."""
+    monkeypatch.delenv("MC_COUNT_PATH", raising=False)  # batches of 4.8 M windows take the pipeline by themselves
+    genome, reads, off = synth_case(2, 200000, 80000, 150, 50)  # > 2^18 solid k-mers: a two-level build of the BFS table
+    t, _ = oracle_table(reads, off, 31, po.KEY_PACKED)
+    half = 40000
+    seed = genome[10000:10500]
+    hi, lo = seed_windows(seed, 31)
+    ctx = mc.Context(31, mc.KEY_PACKED, 0, 3_000_000)  # ~3000 regions
+    ctx.set_coverage_hint(5)
+    ctx.add_reads_packed(po.pack(reads[:off[half]]), off[:half + 1])
+    ctx.finalize()
+    t1, _ = oracle_table(reads[:off[half]], off[:half + 1], 31, po.KEY_PACKED)
+    for d in (-1, 1):
+        assert_bfs_equal(ctx.bfs(hi, lo, d, 5, 3000, -1), po.bfs(t1, 31, po.KEY_PACKED, [seed], d, 5, 3000, -1))
+    st = ctx.stats()
+    assert st.solid_list_builds == 1 and st.solid_sweeps == 0  # (the second walk reuses the table)
+    ctx.add_reads_packed(po.pack(reads[off[half]:]), off[half:] - off[half])  # every region is rewritten: a new list
+    assert ctx.finalize() == t.size()
+    want = po.bfs(t, 31, po.KEY_PACKED, [seed], 1, 5, 3000, -1)
+    assert_bfs_equal(ctx.bfs(hi, lo, 1, 5, 3000, -1), want)
+    st = ctx.stats()
+    assert st.solid_list_builds == 2 and st.solid_sweeps == 0 and st.solid_kmers == int((t.dump()[1] >= 5).sum())
+    assert_bfs_equal(ctx.bfs(hi, lo, 1, 3, 3000, -1), po.bfs(t, 31, po.KEY_PACKED, [seed], 1, 3, 3000, -1))
+    assert ctx.stats().solid_list_builds == 2  # another threshold: swept
+    assert_bfs_equal(ctx.bfs(hi, lo, 1, 5, 3000, -1), want)  # the list was consumed by the first build: swept too
+    assert ctx.stats().solid_list_builds == 2
+    # keys added by another kernel (a small batch goes through the direct path) end the list's validity
+    extra = reads[:off[10]]
+    ctx.add_reads_packed(po.pack(extra), off[:11])
+    ctx.finalize()
+    t.count_reads(extra, off[:11], 31, po.KEY_PACKED)
+    assert_bfs_equal(ctx.bfs(hi, lo, 1, 5, 3000, -1), po.bfs(t, 31, po.KEY_PACKED, [seed], 1, 5, 3000, -1))
+    assert ctx.stats().solid_list_builds == 2
+    ctx.close()
+
+
 def test_bfs_no_seed_passes(mc, bfs_case):
     _, t, ctx = bfs_case
     rng = np.random.default_rng(9)
