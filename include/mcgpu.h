@@ -243,7 +243,7 @@ typedef struct {
     uint64_t spill_keys;     /* keys that did not fit their bucket and took the direct kernel */
     uint64_t solid_kmers;    /* k-mers with count >= min_cov found by the last BFS set-up */
     uint64_t solid_sweeps;   /* table sweeps BFS set-ups needed to count them (0 with mc_set_coverage_hint) */
-    uint64_t solid_list_builds; /* BFS set-ups that took their entries from the list the merge kernel left, without sweeping the table */
+    uint64_t solid_list_builds; /* BFS set-ups and exports that took their entries from the list the merge kernel left, without sweeping the table */
 } mc_stats;
 int mc_get_stats(mc_ctx *ctx, mc_stats *out);
 int mc_reset_stats(mc_ctx *ctx);

@@ -613,6 +613,31 @@ __global__ void __launch_bounds__(EXP_THREADS) k_export(const Slot *__restrict__
     if (!keys) wave_add_ull(cursor, counted);
 }
 
+// K6 from the solid list the merge kernel left (count_pipeline.h P3Emit): a segment takes its slice of the output
+// with one atomic and is copied over -- 0.8 GB read instead of a sweep of the table.
+__global__ void __launch_bounds__(256) k_export_list(const uint4 *__restrict__ list, const uint32_t *__restrict__ list_counts, uint32_t nseg,
+                                                     uint64_t list_segcap, int64_t *__restrict__ keys, int16_t *__restrict__ counts,
+                                                     uint32_t *__restrict__ hints, uint64_t cap, unsigned long long *cursor)
+{
+    __shared__ unsigned long long gbase;
+    for (uint32_t sg = blockIdx.x; sg < nseg; sg += gridDim.x) {
+        const uint32_t n = list_counts[sg];
+        if (threadIdx.x == 0 && n) gbase = atomicAdd(cursor, (unsigned long long)n);
+        __syncthreads();
+        const uint4 *src = list + (uint64_t)sg * list_segcap;
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+            const unsigned long long pos = gbase + i;
+            if (pos < cap) {
+                const uint4 e = src[i];
+                keys[pos] = (int64_t)(((uint64_t)e.y << 32) | e.x);
+                counts[pos] = (int16_t)e.z;
+                if (hints) hints[pos] = e.w;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------ kernels: synthetic reads
 
 constexpr uint64_t ERR_STREAM = 0xE44044E44044E440ull;
@@ -876,7 +901,7 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
     pl->cap1 = (uint64_t)((double)units / (double)pl->np1 / (double)PT_SEGMENTS * 1.25) + (pl->sk ? 64 : 256);  // per segment
     const double mean_leaf = (double)units / (double)pl->n_leaves;
     // (records of one locus come in clumps -- one per read covering it -- so leaves vary more than Poisson)
-    pl->cap2 = (uint64_t)(mean_leaf * 1.15 + (pl->sk ? 24.0 : 8.0) * std::sqrt(mean_leaf) + 64.0);
+    pl->cap2 = (uint64_t)(mean_leaf * 1.15 + (pl->sk ? 32.0 : 8.0) * std::sqrt(mean_leaf) + 64.0);  // (a spilled record also costs the solid list, P3Emit)
     pl->spill_cap = pl->sk ? std::max<uint64_t>(units / 16, 1u << 16) : std::max<uint64_t>(wb / 64, 1u << 20);
     if (pl->np1 * PT_SEGMENTS * pl->cap1 >= 0xFFFFFFFFull || (uint64_t)pl->b2 * pl->cap2 >= 0xFFFFFFFFull)
         return fail(c, MC_EINVAL, "internal: partitioned batch too large for 32-bit bucket indices");
@@ -1791,6 +1816,13 @@ int mc_export_dev(mc_ctx *c, int min_cov, int64_t *d_keys, int16_t *d_counts, ui
     unsigned long long *cursor = c->d_ctr + 2;
     if (!d_keys && c->solid_tracked && c->cov_hint == min_cov && min_cov > 0 && !c->virgin) {
         cursor = c->d_ctr + 6;  // counting only, and k_p3_merge kept the number of keys at this threshold up to date
+    } else if (d_keys && c->solid_list_fresh && c->solid_tracked && c->cov_hint == min_cov && min_cov > 0 && !c->virgin && c->mm_k) {
+        // ... and listed them (the list stays: a BFS set-up on this context can still use it)
+        HIPCHK(c, hipMemsetAsync(cursor, 0, sizeof(unsigned long long), c->stream));
+        hipLaunchKernelGGL(k_export_list, dim3(std::min<uint32_t>(c->solid_list_segs, 2048u)), dim3(256), 0, c->stream, c->pipe.a_recs,
+                           c->pipe.emit_counts, c->solid_list_segs, c->solid_list_segcap, d_keys, d_counts, d_hints, cap, cursor);
+        HIPCHK(c, hipGetLastError());
+        c->st.solid_list_builds++;
     } else {
         HIPCHK(c, hipMemsetAsync(cursor, 0, sizeof(unsigned long long), c->stream));
         hipLaunchKernelGGL(k_export, dim3(grid_for(c->n_slots(), 256)), dim3(256), 0, c->stream, c->slots, c->n_slots(),

@@ -56,6 +56,8 @@ for rep in range(3):
     _, ms_solid = t(lambda: solid.solid_from_pairs_dev(keys, cnts, n, cov, hints))
     res, ms_bfs = t(lambda: solid.bfs_batch(jobs, cov, 100000, -1))
     tot = ms_ext + ms_add + ms_fin + ms_cnt + ms_exp + ms_solid + ms_bfs
+    st = ctx.stats()
+    print("  (exports from the merge kernel's list so far: %d, table sweeps for counting: %d, spilled records: %d)" % (st.solid_list_builds, st.solid_sweeps, st.spill_keys))
     print("owners %d: extract %.2f (%d records, %.2f GB) | add %.2f | finalize %.2f (%d distinct) | export_count %.2f export %.2f (%d solid) | "
           "solid table %.2f | walk %.2f (%d reached) | sum %.2f ms" % (W, ms_ext, n_rec, n_rec * 20 / 1e9, ms_add, ms_fin, nd, ms_cnt, ms_exp, n,
                                                                       ms_solid, ms_bfs, sum(len(r["lo"]) for r in res), tot))

@@ -280,21 +280,25 @@ def test_solid_list_from_the_merge_kernel(mc, monkeypatch):
     assert st.solid_list_builds == 1 and st.solid_sweeps == 0  # (the second walk reuses the table)
     ctx.add_reads_packed(po.pack(reads[off[half]:]), off[half:] - off[half])  # every region is rewritten: a new list
     assert ctx.finalize() == t.size()
+    ok, oc = t.dump()
+    gk, gc = ctx.export(5)  # the multi-GPU gather's export reads the list too (and leaves it in place)
+    assert np.array_equal(gk, ok[oc >= 5]) and np.array_equal(gc, oc[oc >= 5])
+    assert ctx.stats().solid_list_builds == 2
     want = po.bfs(t, 31, po.KEY_PACKED, [seed], 1, 5, 3000, -1)
     assert_bfs_equal(ctx.bfs(hi, lo, 1, 5, 3000, -1), want)
     st = ctx.stats()
-    assert st.solid_list_builds == 2 and st.solid_sweeps == 0 and st.solid_kmers == int((t.dump()[1] >= 5).sum())
+    assert st.solid_list_builds == 3 and st.solid_sweeps == 0 and st.solid_kmers == int((t.dump()[1] >= 5).sum())
     assert_bfs_equal(ctx.bfs(hi, lo, 1, 3, 3000, -1), po.bfs(t, 31, po.KEY_PACKED, [seed], 1, 3, 3000, -1))
-    assert ctx.stats().solid_list_builds == 2  # another threshold: swept
+    assert ctx.stats().solid_list_builds == 3  # another threshold: swept
     assert_bfs_equal(ctx.bfs(hi, lo, 1, 5, 3000, -1), want)  # the list was consumed by the first build: swept too
-    assert ctx.stats().solid_list_builds == 2
+    assert ctx.stats().solid_list_builds == 3
     # keys added by another kernel (a small batch goes through the direct path) end the list's validity
     extra = reads[:off[10]]
     ctx.add_reads_packed(po.pack(extra), off[:11])
     ctx.finalize()
     t.count_reads(extra, off[:11], 31, po.KEY_PACKED)
     assert_bfs_equal(ctx.bfs(hi, lo, 1, 5, 3000, -1), po.bfs(t, 31, po.KEY_PACKED, [seed], 1, 5, 3000, -1))
-    assert ctx.stats().solid_list_builds == 2
+    assert ctx.stats().solid_list_builds == 3
     ctx.close()
 
 
