@@ -28,6 +28,7 @@ class ShardedCounter:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.bytes_sent = 0
+        self.parts, self.parts_min_reads = 2, 1 << 20  # see _exchange_superkmers
 
     def add_reads_dev(self, d_words, d_offsets, n_reads, n_bases, max_windows):
         """Counts this rank's reads into the sharded table: extract -> all-to-all -> count owned keys.
@@ -63,27 +64,59 @@ class ShardedCounter:
         ctx.add_keys_dev(recv, n_recv, recv_h)
 
     def _exchange_superkmers(self, d_words, d_offsets, n_reads, n_bases, cap):
+        """The reads go in `parts` consecutive pieces: the all-to-all of piece p (asynchronous: RCCL has its own
+        stream) runs while piece p + 1 is being extracted.  All pieces land in ONE receive buffer and are counted by
+        one call: every counting pass rewrites the whole table, so one pass per piece would cost more than the
+        overlap gains."""
         ctx, W = self.ctx, self.world
-        send = torch.empty((cap, 2), dtype=torch.int64, device=self.device)   # 16-byte records
-        send_b = torch.empty(cap, dtype=torch.int32, device=self.device)      # their bin words
-        off = ctx.extract_superkmers_dev(d_words, d_offsets, n_reads, n_bases, W, send, send_b, cap)
-        send_counts = [int(off[o + 1] - off[o]) for o in range(W)]
-        sc = torch.tensor(send_counts, dtype=torch.int64, device=self.device)
-        rc = torch.empty(W, dtype=torch.int64, device=self.device)
-        dist.all_to_all_single(rc, sc, group=self.group)
-        recv_counts = [int(x) for x in rc.cpu().tolist()]
-        n_recv, n_send = sum(recv_counts), int(off[W])
-        recv = torch.empty((max(n_recv, 1), 2), dtype=torch.int64, device=self.device)
-        recv_b = torch.empty(max(n_recv, 1), dtype=torch.int32, device=self.device)
-        dist.all_to_all_single(recv[:n_recv], send[:n_send], output_split_sizes=recv_counts,
-                               input_split_sizes=send_counts, group=self.group)
-        dist.all_to_all_single(recv_b[:n_recv], send_b[:n_send], output_split_sizes=recv_counts,
-                               input_split_sizes=send_counts, group=self.group)
+        parts = self.parts if n_reads >= self.parts_min_reads else 1
+        bounds = [n_reads * p // parts for p in range(parts + 1)]
+        base_at = [0] + [int(d_offsets[b].item()) for b in bounds[1:-1]] + [int(n_bases)]
+        recv = recv_b = None
+        filled = 0
+        inflight = []   # (work, work, send buffers kept alive)
+        leftovers = []  # a piece that did not fit the shared buffer: counted by a call of its own
+        for p in range(parts):
+            a, b = bounds[p], bounds[p + 1]
+            if a == b:
+                continue
+            cap_p = cap if parts == 1 else ctx.superkmer_capacity(base_at[p + 1] - base_at[p], b - a)
+            send = torch.empty((cap_p, 2), dtype=torch.int64, device=self.device)   # 16-byte records
+            send_b = torch.empty(cap_p, dtype=torch.int32, device=self.device)      # their bin words
+            off = ctx.extract_superkmers_dev(d_words, d_offsets[a:], b - a, base_at[p + 1], W, send, send_b, cap_p)
+            send_counts = [int(off[o + 1] - off[o]) for o in range(W)]
+            sc = torch.tensor(send_counts, dtype=torch.int64, device=self.device)
+            rc = torch.empty(W, dtype=torch.int64, device=self.device)
+            dist.all_to_all_single(rc, sc, group=self.group)
+            recv_counts = [int(x) for x in rc.cpu().tolist()]
+            n_recv, n_send = sum(recv_counts), int(off[W])
+            if recv is None:  # room for all pieces, sized from the first (the pieces are equal shares of the reads)
+                room = max(int(n_recv * (parts - p) * 1.1) + 1024, 1) if parts > 1 else max(n_recv, 1)
+                recv = torch.empty((room, 2), dtype=torch.int64, device=self.device)
+                recv_b = torch.empty(room, dtype=torch.int32, device=self.device)
+            if filled + n_recv <= recv.shape[0]:
+                dst, dst_b = recv[filled:filled + n_recv], recv_b[filled:filled + n_recv]
+                filled += n_recv
+            else:
+                dst = torch.empty((max(n_recv, 1), 2), dtype=torch.int64, device=self.device)[:n_recv]
+                dst_b = torch.empty(max(n_recv, 1), dtype=torch.int32, device=self.device)[:n_recv]
+                leftovers.append((dst, dst_b, n_recv))
+            w1 = dist.all_to_all_single(dst, send[:n_send], output_split_sizes=recv_counts, input_split_sizes=send_counts,
+                                        group=self.group, async_op=True)
+            w2 = dist.all_to_all_single(dst_b, send_b[:n_send], output_split_sizes=recv_counts, input_split_sizes=send_counts,
+                                        group=self.group, async_op=True)
+            inflight.append((w1, w2, send, send_b))
+            self.bytes_sent += 20 * (n_send - send_counts[self.rank])
+        for w1, w2, _, _ in inflight:
+            w1.wait()
+            w2.wait()
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
-        self.bytes_sent += 20 * (n_send - send_counts[self.rank])
-        del send, send_b
-        ctx.add_superkmers_dev(recv, recv_b, n_recv)
+        del inflight
+        if recv is not None:
+            ctx.add_superkmers_dev(recv, recv_b, filled)
+        for dst, dst_b, n in leftovers:
+            ctx.add_superkmers_dev(dst, dst_b, n)
 
     def finalize(self):
         """Local distinct keys; the sum over ranks is the table size (owners are disjoint)."""

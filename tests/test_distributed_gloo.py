@@ -44,9 +44,11 @@ class OracleBackedContext:
     def add_reads_packed_dev(self, d_words, d_off, n_reads, n_bases):
         self.t.count_reads_packed(d_words.numpy().view(np.uint64), d_off.numpy().view(np.uint64), self.k, self.mode)
 
-    def _keys(self, d_words, d_off):
+    def _keys(self, d_words, d_off, n_reads=None):
         po = self.po
         words, off = d_words.numpy().view(np.uint64), d_off.numpy().view(np.uint64)
+        if n_reads is not None:
+            off = off[:n_reads + 1]  # (d_off may be a view into a longer offsets array: a piece of the reads)
         keys = []
         for r in range(len(off) - 1):
             codes = np.array([(int(words[p >> 5]) >> (62 - 2 * (p & 31))) & 3 for p in range(int(off[r]), int(off[r + 1]))],
@@ -57,7 +59,8 @@ class OracleBackedContext:
 
     def extract_keys_dev(self, d_words, d_off, n_reads, n_bases, n_owners, d_keys, cap, d_hints=None):
         from metacherchant_amd import native
-        keys = self._keys(d_words, d_off)
+        keys = self._keys(d_words, d_off, n_reads)
+        assert int(d_off.numpy().view(np.uint64)[n_reads]) == n_bases
         owners = np.array([native.key_owner(int(x), n_owners) for x in keys], dtype=np.int64)
         order = np.argsort(owners, kind="stable")
         out = np.zeros(n_owners + 1, dtype=np.uint64)
@@ -98,7 +101,7 @@ class OracleBackedContext:
         return n
 
 
-def _worker(rank, world, port, k, mode, reads, L, n_reads, min_cov, q, records=False):
+def _worker(rank, world, port, k, mode, reads, L, n_reads, min_cov, q, records=False, pieces=1):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -112,6 +115,7 @@ def _worker(rank, world, port, k, mode, reads, L, n_reads, min_cov, q, records=F
         off = torch.from_numpy((np.arange(hi - lo + 1, dtype=np.uint64) * L).view(np.int64))
         ctx = OracleBackedContext(k, mode, records)
         sc = ShardedCounter(ctx, torch.device("cpu"))
+        sc.parts, sc.parts_min_reads = pieces, 0  # pieces > 1: the exchange of a piece overlaps the extraction of the next
         sc.add_reads_dev(words, off, hi - lo, (hi - lo) * L, (hi - lo) * (L - k + 1))
         total = sc.finalize()
         solid = OracleBackedContext(k, mode)
@@ -134,8 +138,8 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("k,mode,records", [(31, 0, False), (35, 1, False), (31, 0, True)])
-def test_sharded_count_equals_single_table(k, mode, records):
+@pytest.mark.parametrize("k,mode,records,pieces", [(31, 0, False, 1), (35, 1, False, 1), (31, 0, True, 1), (31, 0, True, 2), (27, 0, True, 3)])
+def test_sharded_count_equals_single_table(k, mode, records, pieces):
     from metacherchant_amd import build
     build.build_lib()  # key_owner comes from the C ABI (host function, no GPU needed)
     from oracle import pyoracle as po
@@ -147,7 +151,7 @@ def test_sharded_count_equals_single_table(k, mode, records):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, k, mode, reads, L, n_reads, min_cov, q, records)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, k, mode, reads, L, n_reads, min_cov, q, records, pieces)) for r in range(2)]
     for p in procs:
         p.start()
     total, n_solid, sk, scnt, sent = q.get(timeout=120)
