@@ -15,6 +15,8 @@ typically one vertex wide.
 `backend` objects only need the Context methods used below, so the CPU (gloo) tests drive this
 file with a stand-in built on the oracle; the product always passes metacherchant_amd.Context.
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -28,7 +30,8 @@ class ShardedCounter:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.bytes_sent = 0
-        self.parts, self.parts_min_reads = 2, 1 << 20  # see _exchange_superkmers
+        # see _exchange_superkmers (MC_EXCHANGE_MIN_READS: read sets from this size on go in two pieces)
+        self.parts, self.parts_min_reads = 2, int(os.environ.get("MC_EXCHANGE_MIN_READS", 1 << 20))
 
     def add_reads_dev(self, d_words, d_offsets, n_reads, n_bases, max_windows):
         """Counts this rank's reads into the sharded table: extract -> all-to-all -> count owned keys.

@@ -26,7 +26,7 @@ def test_bench_multi_rank_path_on_one_gpu():
     """bench.py --gpus 2 as the driver launches it (torch.distributed.run), both ranks on the one GPU over gloo:
     the sharded step runs and rank 0 prints one JSON line with the whole-job numbers."""
     import json
-    env = dict(os.environ, MC_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MC_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MC_EXCHANGE_MIN_READS="0")  # two pieces, as at full size
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29617", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--reads", "300000", "--contigs", "2", "--contig-len", "1000000", "--no-cpu-baseline"]
