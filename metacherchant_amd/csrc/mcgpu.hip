@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -59,8 +60,12 @@ struct mc_ctx {
     std::string err;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_side = nullptr, ev_walk = nullptr;
-    hipStream_t walk_stream = nullptr;  // the walk's own CUs while the sweep runs (CU-masked), or null
-    int walk_cus = 0;
+    // While the hint sweep runs next to a walk of few jobs, the walk has WALK_CUS CUs of its own and the sweep the others:
+    // two CU-masked streams.  Creating them takes ~10 ms each, so a thread does it aside (started once a BFS is in
+    // sight: mc_set_coverage_hint or the first BFS); until they are ready the sweep uses side_stream and shares CUs.
+    hipStream_t walk_stream = nullptr, sweep_stream = nullptr;
+    std::thread mask_thread;
+    std::atomic<bool> mask_started{false}, mask_ready{false};
     hipStream_t side_stream = nullptr;  // the hint-doubling sweep runs here, next to the walk (mc_bfs_batch)
     bool double_deferred = false;       // the solid table is built but its hints are not doubled yet
     // The solid list P3 left in pipe.a_recs (count_pipeline.h P3Emit): valid for threshold cov_hint until anything
@@ -1330,12 +1335,33 @@ void mc_destroy(mc_ctx *c)
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_side) (void)hipEventDestroy(c->ev_side);
     if (c->ev_walk) (void)hipEventDestroy(c->ev_walk);
+    if (c->mask_thread.joinable()) c->mask_thread.join();
     if (c->walk_stream) (void)hipStreamDestroy(c->walk_stream);
+    if (c->sweep_stream) (void)hipStreamDestroy(c->sweep_stream);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     for (char *p : c->pin) if (p) (void)hipHostFree(p);
     for (hipStream_t st : c->pin_stream) if (st) (void)hipStreamDestroy(st);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
+}
+
+// see mc_ctx::walk_stream
+constexpr int WALK_CUS = 16;
+static void start_mask_streams(mc_ctx *c)
+{
+    if (c->mask_started.exchange(true)) return;
+    c->mask_thread = std::thread([c] {
+        if (hipSetDevice(c->cfg.device) != hipSuccess) return;
+        uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, r[8];
+        for (int i = 0; i < WALK_CUS; i++) a[i >> 5] |= 1u << (i & 31);
+        for (int i = 0; i < 8; i++) r[i] = ~a[i];
+        hipStream_t w = nullptr, s = nullptr;
+        if (hipExtStreamCreateWithCUMask(&w, 8, a) != hipSuccess) return;
+        if (hipExtStreamCreateWithCUMask(&s, 8, r) != hipSuccess) { (void)hipStreamDestroy(w); return; }
+        c->walk_stream = w;
+        c->sweep_stream = s;
+        c->mask_ready.store(true, std::memory_order_release);
+    });
 }
 
 int mc_clear(mc_ctx *c)
@@ -1362,6 +1388,7 @@ int mc_set_coverage_hint(mc_ctx *c, int min_cov)
     if (min_cov < 0 || min_cov > 32767) return fail(c, MC_EINVAL, "mc_set_coverage_hint: min_cov must be in 0..32767");
     if (min_cov != c->cov_hint && !c->virgin) c->solid_tracked = false;  // keys already counted were not tracked at this threshold
     if (min_cov != c->cov_hint) c->solid_list_fresh = false;
+    if (min_cov > 0) start_mask_streams(c);
     c->cov_hint = min_cov;
     return MC_OK;
 }
@@ -2263,11 +2290,13 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
         if (rc) return rc;
     }
     // whatever happens below, the sweep on the side stream has ended before this call returns
+    hipStream_t sweep_on = c->side_stream;
     struct SideGuard {
-        mc_ctx *c;
+        hipStream_t *on;
         bool launched = false;
-        ~SideGuard() { if (launched) (void)hipStreamSynchronize(c->side_stream); }
-    } side{c};
+        ~SideGuard() { if (launched) (void)hipStreamSynchronize(*on); }
+    } side{&sweep_on};
+    start_mask_streams(c);  // (if mc_set_coverage_hint did not: ready for the next BFS)
 
     while (c->bfs_pool.size() < n_jobs) c->bfs_pool.emplace_back(new BfsJobBuffers);
     auto &B = c->bfs_pool;
@@ -2315,26 +2344,9 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
         int rc = timed(c, &total_ms, [&] {
             // The walk's few workgroups get CUs of their own (a stream with a CU mask) and the sweep the others: on
             // shared CUs the sweep's waves take issue slots from the walk, whose rounds are issue-bound (2 ms of 31).
-            const int walk_cus = n_jobs <= 32 ? std::max(8, 2 * (int)n_jobs) : 0;  // many jobs: the walk needs the chip
-            if (c->double_deferred && walk_cus != c->walk_cus) {
-                if (c->walk_stream) { (void)hipStreamDestroy(c->walk_stream); c->walk_stream = nullptr; }
-                (void)hipStreamDestroy(c->side_stream);
-                c->side_stream = nullptr;
-                c->walk_cus = walk_cus;
-                if (walk_cus) {
-                    uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, r[8];
-                    for (int i = 0; i < walk_cus; i++) a[i >> 5] |= 1u << (i & 31);
-                    for (int i = 0; i < 8; i++) r[i] = ~a[i];
-                    if (hipExtStreamCreateWithCUMask(&c->walk_stream, 8, a) != hipSuccess) c->walk_stream = nullptr;
-                    if (c->walk_stream && hipExtStreamCreateWithCUMask(&c->side_stream, 8, r) != hipSuccess) {
-                        (void)hipStreamDestroy(c->walk_stream);
-                        c->walk_stream = c->side_stream = nullptr;
-                    }
-                    (void)hipGetLastError();
-                }
-                if (!c->side_stream) (void)hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking);
-            }
-            if (c->double_deferred && c->walk_stream) {
+            const bool masked = c->double_deferred && n_jobs <= (uint32_t)WALK_CUS && c->mask_ready.load(std::memory_order_acquire);
+            sweep_on = masked ? c->sweep_stream : c->side_stream;
+            if (masked) {
                 (void)hipEventRecord(c->ev_side, c->stream);
                 (void)hipStreamWaitEvent(c->walk_stream, c->ev_side, 0);
                 launch_bfs(c, c->walk_stream, d_states.p, n_jobs, min_cov, max_kmers, max_radius, max_rounds);
@@ -2349,9 +2361,9 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
                 // hint only steers its look-ahead).  The table was complete and the stream idle when it was built.
                 c->double_deferred = false;
                 side.launched = true;
-                hipLaunchKernelGGL(k_solid_double, dim3(grid_for(1ull << c->solid_lg, 256)), dim3(256), 0, c->side_stream,
+                hipLaunchKernelGGL(k_solid_double, dim3(grid_for(1ull << c->solid_lg, 256)), dim3(256), 0, sweep_on,
                                    c->solid_view(), (uint64_t)1 << c->solid_lg, c->cfg.k, 3);
-                (void)hipEventRecord(c->ev_side, c->side_stream);
+                (void)hipEventRecord(c->ev_side, sweep_on);
             }
         });
         if (rc) return rc;
