@@ -911,7 +911,7 @@ __global__ void k_sk_add_records(const uint4 *__restrict__ recs, uint64_t n, int
 // has more regions than leaves).  `virgin`: the table holds nothing yet and is not read.
 // leaf_state[leaf]: 0 = to do, 1 = merged.  A leaf with a region that would overflow is left
 // untouched and stays at 0 for the retry after the host enlarged the table.
-// In LDS the top bit of a slot's count says "context known on both sides": the atomic add that counts an occurrence
+// In LDS the top bit of a slot's count says "context confirmed on both sides" (hint_confirm): the atomic add that counts an occurrence
 // then also tells whether the hint word needs a look at all (one LDS round trip less for most occurrences).  Counts
 // are held to 2^30 when a region comes in and goes out; a launch adds < 2^30, so bit 31 is never reached by counting.
 constexpr uint32_t P3_CTX_DONE = 1u << 31, P3_COUNT_CAP = 1u << 30;
@@ -1037,7 +1037,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                     } else {
                         const uint4 raw = *reinterpret_cast<const uint4 *>(gs + i);
                         L.key[i] = ((uint64_t)raw.y << 32) | raw.x;
-                        L.cnt[i] = min(raw.z, P3_COUNT_CAP) | ((raw.w & (HINT_RV | HINT_LV)) == (HINT_RV | HINT_LV) ? P3_CTX_DONE : 0u);
+                        L.cnt[i] = min(raw.z, P3_COUNT_CAP) | ((raw.w & (HINT_RC | HINT_LC)) == (HINT_RC | HINT_LC) ? P3_CTX_DONE : 0u);
                         L.aux[i] = raw.w;
                         solid_before += solid_thr && raw.z >= solid_thr;  // (empty slots hold count 0)
                     }
@@ -1129,13 +1129,13 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                                     // is only raised over a hint word that really has both.
                                     uint32_t have = L.aux[s], m;
                                     for (;;) {
-                                        m = hint_merge(have, hint);
+                                        m = hint_confirm(have, hint);
                                         if (m == have) break;
                                         const uint32_t old = atomicCAS(&L.aux[s], have, m);
                                         if (old == have) break;
                                         have = old;
                                     }
-                                    if ((m & (HINT_RV | HINT_LV)) == (HINT_RV | HINT_LV)) atomicOr(&L.cnt[s], P3_CTX_DONE);
+                                    if ((m & (HINT_RC | HINT_LC)) == (HINT_RC | HINT_LC)) atomicOr(&L.cnt[s], P3_CTX_DONE);
                                 }
                             } else {
                                 atomicExch(&L.overflow, 1u);

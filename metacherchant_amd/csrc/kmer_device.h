@@ -169,6 +169,25 @@ constexpr int HINT_LEN = 7;
 constexpr uint32_t HINT_RV = 1u << 14, HINT_LV = 1u << 30;  // R bits 0..13 + valid, L bits 16..29 + valid
 constexpr uint32_t HINT_RMASK = 0x00007FFFu, HINT_LMASK = 0x7FFF0000u;
 
+// The merge kernel of the super-k-mer pipeline is pickier (hint_confirm): with sequencing errors in 1 % of the bases
+// every 14th 7-base context is wrong, and a wrong hint costs the walk a truncated round plus a one-level replay.  A
+// side's context counts as known once two occurrences in a row agree on it (bits 15 / 31); until then a differing
+// occurrence replaces the candidate.  Other writers leave the two bits clear: their contexts stay candidates.
+constexpr uint32_t HINT_RC = 1u << 15, HINT_LC = 1u << 31;
+__host__ __device__ __forceinline__ uint32_t hint_confirm(uint32_t have, uint32_t mine)
+{
+    uint32_t r = have;
+    if (mine & HINT_RV) {
+        if (!(have & HINT_RV)) r |= mine & HINT_RMASK;
+        else if (!(have & HINT_RC)) r = ((have ^ mine) & 0x3FFFu) ? ((r & ~0x3FFFu) | (mine & 0x3FFFu)) : (r | HINT_RC);
+    }
+    if (mine & HINT_LV) {
+        if (!(have & HINT_LV)) r |= mine & HINT_LMASK;
+        else if (!(have & HINT_LC)) r = ((have ^ mine) & 0x3FFF0000u) ? ((r & ~0x3FFF0000u) | (mine & 0x3FFF0000u)) : (r | HINT_LC);
+    }
+    return r;
+}
+
 __host__ __device__ __forceinline__ uint32_t hint_merge(uint32_t have, uint32_t mine)
 {
     uint32_t r = have;
