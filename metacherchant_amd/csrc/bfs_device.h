@@ -203,8 +203,8 @@ struct NarrowLds {
     Kmer pub_k[MAX_NODES];            // accepted in the last round, to be indexed
     uint32_t pub_idx[MAX_NODES];
     uint64_t rhint[NARROW_CAND], nhint[NARROW_CAND];  // their oriented hints (walker_hint)
-    Kmer root2[NARROW_CAND];          // second stage of a round: where each walker is expected to be when its hint runs out,
-    uint64_t rhint2[NARROW_CAND];     // and that vertex's own hint (length 0: no second stage)
+    Kmer sroot[2][NARROW_CAND];       // later stages of a round: where each walker is expected to be when its hint runs out,
+    uint64_t shint[2][NARROW_CAND];   // and that vertex's own hint (length 0: no further stage); [stage & 1]
     uint64_t nslot[MAX_NODES];        // solid-table slot of each level-1 node (one-level replay)
     int16_t cov[MAX_NODES];
     uint8_t vis[MAX_NODES];
@@ -555,7 +555,7 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
         uint32_t H = 1, Hcap = 1;
         if (hl_min >= 2 && !capped0 && room >= 1 && !L.any_dup_root) {
             Hcap = (((uint32_t)MAX_NODES >> lg) * div_m) >> 16;  // MAX_NODES / FN
-            const long long room2 = max_radius < 0 ? (long long)(2 * LHINT_MAX) : room;
+            const long long room2 = max_radius < 0 ? (long long)(4 * LHINT_MAX) : room;
             if ((long long)Hcap > room2) Hcap = (uint32_t)room2;
             if (max_kmers >= 0) {  // whole levels under the cap: H <= (max_kmers - n) / F
                 const unsigned long long rem = (unsigned long long)max_kmers - n;
@@ -564,17 +564,15 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
             if (Hcap < 1) Hcap = 1;
             H = min(hl_min, Hcap);
         }
-        // Second stage: when a walker's hint is used up before Hcap, the vertex it is expected to reach then brings
-        // its own hint (its slot is among this round's lookups), and the levels behind it are looked up in a second
-        // round trip of the same round -- the index work, checks and appends of a round are paid once for both.
-        const uint32_t HA = H;
-        const bool two = HA >= 2 && HA == hl_min && HA < Hcap;
-        const uint32_t NTA = HA * FN;
+        // Further stages: when a walker's hint is used up before Hcap, the vertex it is expected to reach then brings
+        // its own hint (its slot is among this stage's lookups), and the levels behind it are looked up in another
+        // round trip of the same round -- the index work, checks and appends of a round are paid once for all stages.
+        const bool spec = H >= 2;
         if (tid == 0) L.bad_lvl = 0xFFFFFFFFu;
 
         // ---- speculate: node (i, a, c) = c-th neighbour of the vertex walker a is expected to reach after i-1 steps
         MC_STAMP(0);
-        bool have = tid < NTA;
+        bool have = false;
         Kmer nk{0, 0};
         uint32_t ni = 0, na = 0;
         bool npred = false, nflip = false;
@@ -582,10 +580,10 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
         uint64_t nslot = ~0ull;
         uint64_t key = 0, s0 = 0, s1 = 0;
         uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
-        uint4 g0 = a0, g1 = a0;  // (stage-one nodes that seed the second stage: the hint words of both probed slots)
-        bool seeds2 = false;
-        // node tl of a stage: levels lvl0 + 1 .. of the walkers standing at roots[] with hints[]
-        auto generate = [&](uint32_t tl, uint32_t lvl0, const Kmer *roots, const uint64_t *hints, bool last_seeds) {
+        uint4 g0 = a0, g1 = a0;  // (nodes that seed the next stage: the hint words of both probed slots)
+        bool seeds = false;
+        // node tl of a stage of Hs levels: levels lvl0 + 1 .. of the walkers standing at roots[] with hints[]
+        auto generate = [&](uint32_t tl, uint32_t lvl0, uint32_t Hs, const Kmer *roots, const uint64_t *hints, bool more) {
             const uint32_t lvl = ((tl >> lg) * div_m) >> 16;  // tl / FN
             ni = lvl0 + lvl + 1;
             const uint32_t r = tl - lvl * FN;
@@ -595,7 +593,7 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
             const bool right = (h >> 62) & 1;
             const uint32_t hb = (uint32_t)(h >> (2 * lvl)) & 3u;  // expected step
             const uint32_t cstar = dir == 0 ? (2 * hb + (right ? 1u : 0u)) : hb;
-            npred = HA > 1 && c == cstar;
+            npred = spec && c == cstar;
             if (MODE == KEY_PACKED) {
                 // k <= 31: everything in one 64-bit word, no branches (walker_at + neighbour + key_of, specialised)
                 const uint64_t root = roots[na].lo, kmask = (1ull << (2 * k)) - 1;
@@ -620,55 +618,61 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
             s1 = (s0 & ~(uint64_t)t.rmask) | ((s0 + 1) & t.rmask);
             a0 = *reinterpret_cast<const uint4 *>(t.slots + s0);
             a1 = *reinterpret_cast<const uint4 *>(t.slots + s1);
-            seeds2 = last_seeds && npred && lvl + 1 == HA;
-            if (seeds2) {
+            seeds = more && npred && lvl + 1 == Hs;
+            if (seeds) {
                 g0 = reinterpret_cast<const uint4 *>(t.slots + s0)[1];
                 g1 = reinterpret_cast<const uint4 *>(t.slots + s1)[1];
             }
             lookups++;
         };
-        if (have) generate(tid, 0, L.root, L.rhint, two);
-        // the previous round's vertices enter the index while this round's probes are in flight (taken
-        // from the top of the workgroup, where threads usually hold no node)
-        if (BFS_THREADS - 1 - tid < pend) vis_insert(S, L.pub_k[BFS_THREADS - 1 - tid], L.pub_idx[BFS_THREADS - 1 - tid]);
-        MC_STAMP(1);
-        if (have) {
-            cov = solid_get2(t, key, s0, s1, a0, a1, &nslot);
-            L.cov[tid] = (int16_t)cov;
-            L.kmer[tid] = nk;
-            if (npred) L.pk[(ni - 1) * F + na] = nk;
-            if (seeds2) {  // the walker's expected position after HA steps, and the hint stored there
-                uint64_t h2 = 0;
-                if (cov >= min_cov && nslot != ~0ull) {
-                    const bool right = (L.rhint[na] >> 62) & 1;
-                    uint64_t hr, hl;
-                    if (nslot == s0) { hr = ((uint64_t)g0.y << 32) | g0.x; hl = ((uint64_t)g0.w << 32) | g0.z; }
-                    else if (nslot == s1) { hr = ((uint64_t)g1.y << 32) | g1.x; hl = ((uint64_t)g1.w << 32) | g1.z; }
-                    else { const SolidSlot *sl = t.slots + nslot; hr = sl->hr; hl = sl->hl; }
-                    h2 = walker_hint(hr, hl, nflip, right);
+        {
+            const Kmer *roots = L.root;
+            const uint64_t *hints = L.rhint;
+            uint32_t Hs = H, h_min = hl_min, lvl_done = 0, nt_done = 0;
+            for (uint32_t st = 0;; st++) {
+                // another stage follows when this one runs to the end of the walkers' hints and the budget is not used up
+                const bool more = spec && Hs == h_min && lvl_done + Hs < Hcap;
+                const bool mine = tid >= nt_done && tid < nt_done + Hs * FN;
+                if (mine) generate(tid - nt_done, lvl_done, Hs, roots, hints, more);
+                if (st == 0) {
+                    // the previous round's vertices enter the index while this round's probes are in flight (taken
+                    // from the top of the workgroup, where threads usually hold no node)
+                    if (BFS_THREADS - 1 - tid < pend) vis_insert(S, L.pub_k[BFS_THREADS - 1 - tid], L.pub_idx[BFS_THREADS - 1 - tid]);
+                    MC_STAMP(1);
                 }
-                L.root2[na] = nk;
-                L.rhint2[na] = h2;
-            }
-        }
-        if (two) {
-            __syncthreads();
-            uint32_t h2_min = LHINT_MAX;
-            for (uint32_t a = 0; a < F; a++) h2_min = min(h2_min, lh_len(L.rhint2[a]));
-            if (h2_min > (uint32_t)k) h2_min = (uint32_t)k;
-            const uint32_t HB = min(h2_min, Hcap - HA);
-            if (HB >= 1) {
-                const bool have2 = tid >= NTA && tid < NTA + HB * FN;
-                if (have2) {
-                    generate(tid - NTA, HA, L.root2, L.rhint2, false);
+                if (mine) {
+                    have = true;
                     cov = solid_get2(t, key, s0, s1, a0, a1, &nslot);
                     L.cov[tid] = (int16_t)cov;
                     L.kmer[tid] = nk;
                     if (npred) L.pk[(ni - 1) * F + na] = nk;
-                    have = true;
+                    if (seeds) {  // the walker's expected position at the end of this stage, and the hint stored there
+                        uint64_t h2 = 0;
+                        if (cov >= min_cov && nslot != ~0ull) {
+                            const bool right = (hints[na] >> 62) & 1;
+                            uint64_t hr, hl;
+                            if (nslot == s0) { hr = ((uint64_t)g0.y << 32) | g0.x; hl = ((uint64_t)g0.w << 32) | g0.z; }
+                            else if (nslot == s1) { hr = ((uint64_t)g1.y << 32) | g1.x; hl = ((uint64_t)g1.w << 32) | g1.z; }
+                            else { const SolidSlot *sl = t.slots + nslot; hr = sl->hr; hl = sl->hl; }
+                            h2 = walker_hint(hr, hl, nflip, right);
+                        }
+                        L.sroot[(st + 1) & 1][na] = nk;
+                        L.shint[(st + 1) & 1][na] = h2;
+                    }
                 }
-                H = HA + HB;
+                lvl_done += Hs;
+                nt_done += Hs * FN;
+                if (!more) break;
+                __syncthreads();
+                roots = L.sroot[(st + 1) & 1];
+                hints = L.shint[(st + 1) & 1];
+                h_min = LHINT_MAX;
+                for (uint32_t a = 0; a < F; a++) h_min = min(h_min, lh_len(hints[a]));
+                if (h_min > (uint32_t)k) h_min = (uint32_t)k;
+                Hs = min(h_min, Hcap - lvl_done);
+                if (Hs == 0) break;
             }
+            H = lvl_done;
         }
         L.set[tid] = LH_EMPTY;
         L.set[tid + BFS_THREADS] = LH_EMPTY;
