@@ -951,8 +951,8 @@ __device__ __forceinline__ bool lds_region_add(MergeLds &L, uint64_t key, uint32
         if (cur == key) {
             atomicAdd(&L.cnt[s], 1u);
             if (hint) {
-                const uint32_t have = L.aux[s], m = hint_merge(have, hint);
-                if (m != have) L.aux[s] = m;  // racy on purpose: any occurrence's context will do
+                const uint32_t have = L.aux[s], m = hint_confirm(have, hint);
+                if (m != have) L.aux[s] = m;  // racy on purpose: a lost update only delays the confirmation
             }
             return true;
         }
