@@ -1,0 +1,63 @@
+"""Randomised parity soak on the GPU: random k, error rate, read count, genome size and coverage threshold; the
+partitioned pipeline (forced) counts the reads in one or two batches, and the table and three BFS walks are compared
+with the oracle each time.  Usage: python scripts/soak.py [iterations] [seed]"""
+import os
+import sys
+import time
+
+os.environ["MC_COUNT_PATH"] = "partition"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+import metacherchant_amd as mc
+from oracle import pyoracle as po
+from tests.helpers import GENOME_SEED, assert_bfs_equal, seed_windows
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+t0 = time.time()
+for it in range(iters):
+    k = int(rng.choice([21, 23, 24, 25, 27, 28, 29, 30, 31, 31, 31, 41]))
+    mode, omode = (mc.KEY_PACKED, po.KEY_PACKED) if k <= 31 else (mc.KEY_POLY, po.KEY_POLY)
+    err = int(rng.choice([0, 50, 100, 200]))
+    L = int(rng.choice([100, 150, 250]))
+    n_reads = int(rng.integers(30_000, 250_000))
+    contigs = int(rng.integers(1, 4))
+    clen = int(rng.integers(20_000, 400_000))
+    cov = int(rng.integers(2, 7))
+    hint = bool(rng.integers(0, 2))
+    cap = int(rng.choice([0, 0, 2_000_000, 6_000_000]))
+    rseed = int(rng.integers(1, 1 << 30))
+    genome = po.synth_genome(GENOME_SEED + it, contigs * clen)
+    reads = po.synth_reads(genome, contigs, clen, rseed, 0, n_reads, L, err)
+    off = np.arange(n_reads + 1, dtype=np.uint64) * L
+    t = po.Table()
+    t.count_reads(reads, off, k, omode)
+    ctx = mc.Context(k, mode, 0, cap)
+    if hint:
+        ctx.set_coverage_hint(cov)
+    two = bool(rng.integers(0, 2))
+    if two:
+        h = n_reads // 2
+        ctx.add_reads_packed(po.pack(reads[:off[h]]), off[:h + 1])
+        ctx.add_reads_packed(po.pack(reads[off[h]:]), off[h:] - off[h])
+    else:
+        ctx.add_reads_packed(po.pack(reads), off)
+    nd = ctx.finalize()
+    assert nd == t.size(), (it, nd, t.size())
+    gk, gc = ctx.export(0)
+    ok, oc = t.dump()
+    assert np.array_equal(gk, ok) and np.array_equal(gc, oc), it
+    a = int(rng.integers(0, max(1, clen - 600)))
+    seed = genome[a:a + 400]
+    hi, lo = seed_windows(seed, k)
+    for d in (1, -1, 0):
+        got = ctx.bfs(hi, lo, d, cov, 20000, -1)
+        want = po.bfs(t, k, omode, [seed], d, cov, 20000, -1)
+        assert_bfs_equal(got, want)
+    st = ctx.stats()
+    ctx.close()
+    print("it %d ok: k=%d err=%d L=%d reads=%d genome=%dx%d cov=%d hint=%d cap=%d batches=%d distinct=%d list=%d sweeps=%d spills=%d (%.0f s)" % (
+        it, k, err, L, n_reads, contigs, clen, cov, hint, cap, 2 if two else 1, nd, st.solid_list_builds, st.solid_sweeps, st.spill_keys, time.time() - t0), flush=True)
+print("soak ok: %d iterations" % iters)
