@@ -299,7 +299,12 @@ struct TableView {
     int mm_k;         // 0: region from fmix64(key); else k: region from the key's minimizer bin
     unsigned long long *n_used;     // distinct keys stored in slots
     unsigned long long *empty_cnt;  // occurrences of the key that equals EMPTY_KEY (hash modes only)
-    uint32_t *fatal;                // set when a region is full
+    uint32_t *fatal;                // set when a region is full and the overflow list cannot take the addition either
+    // Additions that found their region full (minimizer bins fill unevenly: the error variants of a deeply covered
+    // locus share its bin) wait here as (key, inc, hint) until the host has enlarged the table (mc_finalize_counts).
+    uint4 *ovf;
+    unsigned long long *ovf_n;
+    uint64_t ovf_cap;
 };
 
 // home slot inside a minimizer-bin region: 12 well-mixed bits of the key, cheaper than fmix64 (the
@@ -372,6 +377,13 @@ __device__ __forceinline__ uint32_t table_add(const TableView &t, uint64_t key, 
             return 0;
         }
         s = base | ((s + 1) & t.rmask);
+    }
+    if (t.ovf) {  // the region is full: park the addition
+        const unsigned long long i = atomicAdd(t.ovf_n, 1ull);
+        if (i < t.ovf_cap) {
+            t.ovf[i] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), inc, hint);
+            return 0;
+        }
     }
     atomicExch(t.fatal, 1u);
     return 0;

@@ -151,8 +151,13 @@ struct mc_ctx {
         t.n_used = d_ctr;
         t.empty_cnt = d_ctr + 1;
         t.fatal = d_fatal;
+        t.ovf = d_ovf;
+        t.ovf_n = d_ctr + 7;
+        t.ovf_cap = d_ovf ? OVF_CAP : 0;
         return t;
     }
+    static constexpr uint64_t OVF_CAP = 1ull << 20;
+    uint4 *d_ovf = nullptr;  // TableView::ovf
 };
 
 static thread_local std::string g_create_err;
@@ -237,6 +242,18 @@ __global__ void k_add_pairs(const int64_t *__restrict__ keys, const int16_t *__r
     unsigned long long n_new = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
         if (counts[i] > 0) n_new += table_add(t, (uint64_t)keys[i], (uint32_t)counts[i], hints ? hints[i] : 0u);
+    wave_add_ull(t.n_used, n_new);
+}
+
+// the parked additions of TableView::ovf, once the table has been enlarged
+__global__ void k_add_parked(const uint4 *__restrict__ list, uint64_t n, TableView t)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long n_new = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint4 e = list[i];
+        n_new += table_add(t, ((uint64_t)e.y << 32) | e.x, e.z, e.w);
+    }
     wave_add_ull(t.n_used, n_new);
 }
 
@@ -772,6 +789,31 @@ static int table_grow(mc_ctx *c, uint64_t new_regions)
     return MC_OK;
 }
 
+// Additions that found their region full were parked (TableView::ovf): enlarge the table -- twice as many regions
+// split the bins that were crowded together -- and add them again, until none is left.
+static int drain_parked(mc_ctx *c)
+{
+    for (int attempt = 0;; attempt++) {
+        unsigned long long n = 0;
+        HIPCHK(c, hipMemcpyAsync(&n, c->d_ctr + 7, sizeof n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (n == 0) return MC_OK;
+        if (n > mc_ctx::OVF_CAP || attempt >= 8)
+            return fail(c, MC_EOVERFLOW, "k-mer table regions keep overflowing (%llu additions parked); pass a capacity_hint (distinct k-mers)", n);
+        DevBuf<uint4> tmp;
+        HIPCHK(c, tmp.alloc(n));
+        HIPCHK(c, hipMemcpyAsync(tmp.p, c->d_ovf, n * sizeof(uint4), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_ctr + 7, 0, sizeof(unsigned long long), c->stream));
+        int rc = table_grow(c, c->n_regions * 2);
+        if (rc) return rc;
+        c->solid_tracked = false;  // (these additions were not watched for crossing the coverage threshold)
+        c->solid_list_fresh = false;
+        hipLaunchKernelGGL(k_add_parked, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, tmp.p, (uint64_t)n, c->view());
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+}
+
 // Make room for `incoming` more key occurrences: returns how many of them may be inserted by the
 // next launch without the load factor passing 0.85 even if every one is a new key.
 static int table_reserve(mc_ctx *c, uint64_t incoming, uint64_t *allowed)
@@ -1291,6 +1333,7 @@ int mc_create(const mc_config *cfg, mc_ctx **out)
     CREATE_CHK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
     CREATE_CHK(hipMalloc(reinterpret_cast<void **>(&c->d_ctr), 8 * sizeof(unsigned long long)));
     CREATE_CHK(hipMalloc(reinterpret_cast<void **>(&c->d_fatal), sizeof(uint32_t)));
+    CREATE_CHK(hipMalloc(reinterpret_cast<void **>(&c->d_ovf), mc_ctx::OVF_CAP * sizeof(uint4)));
     CREATE_CHK(hipMemsetAsync(c->d_ctr, 0, 8 * sizeof(unsigned long long), c->stream));
     CREATE_CHK(hipMemsetAsync(c->d_fatal, 0, sizeof(uint32_t), c->stream));
 #undef CREATE_CHK
@@ -1331,6 +1374,7 @@ void mc_destroy(mc_ctx *c)
     c->bfs_pool.clear();
     if (c->d_ctr) (void)hipFree(c->d_ctr);
     if (c->d_fatal) (void)hipFree(c->d_fatal);
+    if (c->d_ovf) (void)hipFree(c->d_ovf);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_side) (void)hipEventDestroy(c->ev_side);
@@ -1371,7 +1415,7 @@ int mc_clear(mc_ctx *c)
     HIPCHK(c, hipSetDevice(c->cfg.device));
     c->virgin = true;
     HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, 4 * sizeof(unsigned long long), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_ctr + 6, 0, sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_ctr + 6, 0, 2 * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_fatal, 0, sizeof(uint32_t), c->stream));
     c->n_used_host = 0;
     c->finalized = false;
@@ -1629,6 +1673,7 @@ int mc_finalize_counts(mc_ctx *c, uint64_t *n_distinct)
     HIPCHK(c, hipSetDevice(c->cfg.device));
     {
         int rc = materialize(c);
+        if (!rc) rc = drain_parked(c);
         if (rc) return rc;
     }
     unsigned long long h[3];

@@ -29,6 +29,7 @@ for it in range(iters):
     hint = bool(rng.integers(0, 2))
     cap = int(rng.choice([0, 0, 2_000_000, 6_000_000]))
     rseed = int(rng.integers(1, 1 << 30))
+    print("it %d: k=%d err=%d L=%d reads=%d genome=%dx%d cov=%d hint=%d cap=%d rseed=%d" % (it, k, err, L, n_reads, contigs, clen, cov, hint, cap, rseed), flush=True)
     genome = po.synth_genome(GENOME_SEED + it, contigs * clen)
     reads = po.synth_reads(genome, contigs, clen, rseed, 0, n_reads, L, err)
     off = np.arange(n_reads + 1, dtype=np.uint64) * L

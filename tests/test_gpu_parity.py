@@ -302,6 +302,34 @@ def test_solid_list_from_the_merge_kernel(mc, monkeypatch):
     ctx.close()
 
 
+def test_deep_coverage_of_a_small_genome(mc, monkeypatch):
+    """450-fold coverage of a 69 kb genome with 2 % errors (found by scripts/soak.py): the error variants of a locus
+    share its minimizer bin, so the table's regions and the pipeline's leaves fill very unevenly.  Records that do
+    not fit their leaf go through the direct kernel, additions that find their region full are parked until the
+    table has been enlarged (mc_finalize_counts) -- nothing is lost, nothing fails."""
+    monkeypatch.setenv("MC_COUNT_PATH", "partition")
+    k, L, n_reads, clen, rseed = 30, 150, 205367, 69072, 947706781
+    genome = po.synth_genome(GENOME_SEED + 36, clen)
+    reads = po.synth_reads(genome, 1, clen, rseed, 0, n_reads, L, 200)
+    off = np.arange(n_reads + 1, dtype=np.uint64) * L
+    t, _ = oracle_table(reads, off, k, po.KEY_PACKED)
+    for batches in (1, 2):
+        ctx = mc.Context(k, mc.KEY_PACKED, 0, 6_000_000)  # (12 M distinct k-mers come)
+        ctx.set_coverage_hint(6)
+        if batches == 1:
+            ctx.add_reads_packed(po.pack(reads), off)
+        else:
+            h = n_reads // 2
+            ctx.add_reads_packed(po.pack(reads[:off[h]]), off[:h + 1])
+            ctx.add_reads_packed(po.pack(reads[off[h]:]), off[h:] - off[h])
+        _assert_tables_equal(ctx, ctx.finalize(), t)
+        seed = genome[30000:30400]
+        hi, lo = seed_windows(seed, k)
+        for d in (1, -1):
+            assert_bfs_equal(ctx.bfs(hi, lo, d, 6, 20000, -1), po.bfs(t, k, po.KEY_PACKED, [seed], d, 6, 20000, -1))
+        ctx.close()
+
+
 def test_bfs_no_seed_passes(mc, bfs_case):
     _, t, ctx = bfs_case
     rng = np.random.default_rng(9)
