@@ -907,6 +907,33 @@ __global__ void k_sk_add_records(const uint4 *__restrict__ recs, uint64_t n, int
     if (solid_thr) wave_add_ull(n_solid, n_cross);
 }
 
+// the records of the leaves [leaf_lo, leaf_hi) that k_p3_merge left unmerged, through the direct path (after the
+// table has given up minimizer bins, mcgpu.hip to_hash_regions)
+__global__ void k_sk_add_unmerged(const uint4 *__restrict__ leaf_recs, const uint32_t *__restrict__ seg_counts, uint64_t seg_cap,
+                                  uint32_t nseg, uint32_t leaf_lo, uint32_t leaf_hi, const uint32_t *__restrict__ leaf_state, int k,
+                                  TableView t)
+{
+    unsigned long long n_new = 0;
+    for (uint32_t leaf = leaf_lo + blockIdx.x; leaf < leaf_hi; leaf += gridDim.x) {
+        if (leaf_state[leaf]) continue;
+        for (uint32_t sgm = 0; sgm < nseg; sgm++) {
+            const uint64_t n = min((uint64_t)seg_counts[(uint64_t)leaf * nseg + sgm], seg_cap);
+            const uint4 *recs = leaf_recs + ((uint64_t)leaf * nseg + sgm) * seg_cap;
+            for (uint64_t r = threadIdx.x; r < n; r += blockDim.x) {
+                const uint4 rec = recs[r];
+                const uint64_t lo = ((uint64_t)rec.y << 32) | rec.x, hi = ((uint64_t)rec.w << 32) | rec.z;
+                for (uint32_t j = 0; j < sk_windows(hi); j++) {
+                    uint64_t key;
+                    uint32_t hint;
+                    sk_expand(lo, hi, j, k, &key, &hint);
+                    n_new += table_add(t, key, 1u, hint);
+                }
+            }
+        }
+    }
+    wave_add_ull(t.n_used, n_new);
+}
+
 // P3: one workgroup per leaf; a leaf covers 2^g consecutive table regions (g = 0 unless the table
 // has more regions than leaves).  `virgin`: the table holds nothing yet and is not read.
 // leaf_state[leaf]: 0 = to do, 1 = merged.  A leaf with a region that would overflow is left

@@ -106,6 +106,7 @@ struct mc_ctx {
     int mm_k = 0;        // != 0 (= k): regions are minimizer bins and reads are counted as super-k-mers (kmer_device.h)
     bool virgin = true;  // the table holds no key and its memory is not initialised yet
     int count_path = 0;  // 0 auto, 1 direct (atomics), 2 partitioned; MC_COUNT_PATH=direct|partition overrides
+    bool sk_form = false;  // reads of this context can travel as super-k-mer records (set once; mm_k may be given up later)
     // scratch of the partitioned counting pipeline, kept between calls
     struct Pipe {
         uint64_t *a_keys = nullptr, *b_keys = nullptr, *spill_keys = nullptr;
@@ -156,7 +157,7 @@ struct mc_ctx {
         t.ovf_cap = d_ovf ? OVF_CAP : 0;
         return t;
     }
-    static constexpr uint64_t OVF_CAP = 1ull << 20;
+    static constexpr uint64_t OVF_CAP = 1ull << 22;
     uint4 *d_ovf = nullptr;  // TableView::ovf
 };
 
@@ -789,6 +790,43 @@ static int table_grow(mc_ctx *c, uint64_t new_regions)
     return MC_OK;
 }
 
+// When the k-mers of a read set crowd into single minimizer bins -- a genome covered more than ~1500-fold: the error
+// variants of one locus share its minimizer and outnumber a region's 4096 slots -- no number of regions helps.  The
+// context then gives up minimizer bins for good: regions by the key's own hash, as for hash keys and short k-mers
+// (reads take the per-window pipeline from here on), with everything counted so far moved over.
+static int to_hash_regions(mc_ctx *c)
+{
+    if (!c->mm_k) return MC_OK;
+    unsigned long long used = 0;
+    HIPCHK(c, hipMemcpyAsync(&used, c->d_ctr, sizeof used, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    Slot *old = c->slots;
+    const uint64_t old_n = c->n_slots(), old_regions = c->n_regions;
+    const bool old_virgin = c->virgin;
+    const uint32_t old_rb = c->rb;
+    const int old_mm = c->mm_k;
+    c->mm_k = 0;
+    c->slots = nullptr;
+    int rc = table_alloc(c, regions_for(c, std::max<uint64_t>(old_n, 2 * used)));
+    if (rc) { c->slots = old; c->n_regions = old_regions; c->rb = old_rb; c->virgin = old_virgin; c->mm_k = old_mm; return rc; }
+    c->solid_tracked = false;
+    c->solid_list_fresh = false;
+    c->solid_cov = -1;
+    c->st.grows++;
+    if (old_virgin) {
+        HIPCHK(c, hipFree(old));
+        return MC_OK;
+    }
+    rc = materialize(c);
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, sizeof(unsigned long long), c->stream));  // n_used is recounted
+    hipLaunchKernelGGL(k_rehash, dim3(grid_for(old_n, 256)), dim3(256), 0, c->stream, old, old_n, c->view());
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(old));
+    return MC_OK;
+}
+
 // Additions that found their region full were parked (TableView::ovf): enlarge the table -- twice as many regions
 // split the bins that were crowded together -- and add them again, until none is left.
 static int drain_parked(mc_ctx *c)
@@ -799,12 +837,14 @@ static int drain_parked(mc_ctx *c)
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (n == 0) return MC_OK;
         if (n > mc_ctx::OVF_CAP || attempt >= 8)
-            return fail(c, MC_EOVERFLOW, "k-mer table regions keep overflowing (%llu additions parked); pass a capacity_hint (distinct k-mers)", n);
+            return fail(c, MC_EOVERFLOW, "k-mer table regions keep overflowing (%llu additions parked); pass a capacity_hint "
+                        "(distinct k-mers), or set MC_SUPERKMERS=0 for read sets that cover a genome thousands of times", n);
         DevBuf<uint4> tmp;
         HIPCHK(c, tmp.alloc(n));
         HIPCHK(c, hipMemcpyAsync(tmp.p, c->d_ovf, n * sizeof(uint4), hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_ctr + 7, 0, sizeof(unsigned long long), c->stream));
-        int rc = table_grow(c, c->n_regions * 2);
+        // (minimizer bins: if two doublings did not make room, the crowd shares one bin)
+        int rc = (c->mm_k && attempt >= 2) ? to_hash_regions(c) : table_grow(c, c->n_regions * 2);
         if (rc) return rc;
         c->solid_tracked = false;  // (these additions were not watched for crossing the coverage threshold)
         c->solid_list_fresh = false;
@@ -819,13 +859,14 @@ static int drain_parked(mc_ctx *c)
 static int table_reserve(mc_ctx *c, uint64_t incoming, uint64_t *allowed)
 {
     int mrc = materialize(c);
+    if (!mrc) mrc = drain_parked(c);  // (what the previous launch could not place)
     if (mrc) return mrc;
     unsigned long long used;
     uint32_t fatal;
     int rc = read_counters(c, &used, &fatal);
     if (rc) return rc;
-    if (fatal) return fail(c, MC_EOVERFLOW, "a k-mer table region filled up (hash skew); table of %llu slots",
-                           (unsigned long long)c->n_slots());
+    if (fatal) return fail(c, MC_EOVERFLOW, "a k-mer table region filled up (hash skew); table of %llu slots%s",
+                           (unsigned long long)c->n_slots(), c->mm_k ? "; MC_SUPERKMERS=0 copes with read sets that cover a genome thousands of times" : "");
     c->n_used_host = used;
     const uint64_t max_launch = 1ull << 26;
     for (;;) {
@@ -984,8 +1025,8 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
 }
 
 // P2, P3 (with the retry after growing the table), spill drain and bookkeeping; ms1 = time of the
-// level-1 scatter that filled the a_* buckets.  Returns 1 (nothing merged yet) when the super-k-mer
-// streams overflowed even their spill list: the caller then counts the batch with the direct kernel.
+// level-1 scatter that filled the a_* buckets.  Returns 1 (nothing merged yet) when the streams
+// overflowed even their spill list: the caller then counts the batch with the direct kernel.
 static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1)
 {
     mc_ctx::Pipe &P = c->pipe;
@@ -1004,7 +1045,8 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1)
         });
         if (rc) return rc;
     }
-    if (pl.sk) {  // the record capacities are estimates: check before anything is merged
+    {   // the capacities are estimates (and a few heavy keys can fill a bucket's spill list alone): check before
+        // anything is merged, so that the caller can still count the batch another way
         uint32_t lost = 0;
         HIPCHK(c, hipMemcpy(&lost, P.flags, sizeof lost, hipMemcpyDeviceToHost));
         if (lost) return 1;
@@ -1046,8 +1088,45 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1)
         if (flags[0]) return fail(c, MC_EOVERFLOW, "internal: spill list of the partitioned counting pipeline overflowed");
         if (flags[2]) emit.recs = nullptr;  // a segment of the solid list overflowed: the BFS set-up sweeps the table instead
         if (!flags[1]) break;
-        if (attempt >= 6 || pl.g >= 5)
-            return fail(c, MC_EOVERFLOW, "k-mer table regions keep overflowing; pass a capacity_hint (distinct k-mers)");
+        if (attempt >= 6 || pl.g >= 5) {
+            if (!(pl.sk && c->mm_k))
+                return fail(c, MC_EOVERFLOW, "k-mer table regions keep overflowing; pass a capacity_hint (distinct k-mers)");
+            // minimizer bins that no number of regions can hold: regions by the key's hash from here on, and the leaves
+            // that were not merged go through the direct kernel, as many at a time as the table has room for
+            rc = to_hash_regions(c);
+            if (rc) return rc;
+            HIPCHK(c, hipMemsetAsync(P.leaf_new, 0, n_leaves * sizeof(uint32_t), c->stream));  // (n_used was recounted)
+            std::vector<uint32_t> st(n_leaves), cnt(n_leaves * (uint64_t)lseg);
+            HIPCHK(c, hipMemcpy(st.data(), P.leaf_state, n_leaves * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(cnt.data(), lc, cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            uint32_t lo_leaf = 0;
+            while (lo_leaf < n_leaves) {
+                uint64_t allowed, need = 0;
+                uint32_t hi_leaf = lo_leaf;
+                rc = table_reserve(c, 1ull << 26, &allowed);
+                if (rc) return rc;
+                while (hi_leaf < n_leaves) {
+                    uint64_t w = 0;
+                    if (!st[hi_leaf])
+                        for (uint32_t sg = 0; sg < lseg; sg++) w += std::min<uint64_t>(cnt[(uint64_t)hi_leaf * lseg + sg], lcap) * SK_MAX_WINDOWS;
+                    if (hi_leaf > lo_leaf && need + w > allowed) break;
+                    need += w;
+                    hi_leaf++;
+                }
+                if (need > allowed) {  // a single leaf above what one launch may add: make room for it
+                    rc = table_reserve(c, need, &allowed);
+                    if (rc) return rc;
+                    if (need > allowed) return fail(c, MC_EOVERFLOW, "internal: a leaf of %llu k-mer occurrences does not fit one launch", (unsigned long long)need);
+                }
+                if (need)
+                    hipLaunchKernelGGL(k_sk_add_unmerged, dim3(std::min<uint32_t>(hi_leaf - lo_leaf, 4096u)), dim3(256), 0, c->stream,
+                                       static_cast<const uint4 *>(lk), lc, lcap, lseg, lo_leaf, hi_leaf, P.leaf_state, k, c->view());
+                HIPCHK(c, hipGetLastError());
+                lo_leaf = hi_leaf;
+            }
+            emit.recs = nullptr;
+            break;
+        }
         rc = table_grow(c, c->n_regions * 2);
         if (rc) return rc;
         pl.g++;
@@ -1198,7 +1277,24 @@ static int add_keys_partitioned(mc_ctx *c, const uint64_t *d_keys, const uint32_
                            d_keys, d_hints, n, pl.b1, P.seg_counts1, pl.cap1, P.a_keys, P.a_hints, c->d_ctr + 1, pl.sp, c->mm_k);
     });
     if (rc) return rc;
-    return pipe_finish(c, pl, ms1);
+    rc = pipe_finish(c, pl, ms1);
+    if (rc != 1) return rc;
+    // (the streams overflowed: a few keys make up most of the batch) the direct kernel instead
+    c->solid_tracked = false;
+    c->solid_list_fresh = false;
+    for (uint64_t i = 0; i < n;) {
+        uint64_t allowed;
+        rc = table_reserve(c, n - i, &allowed);
+        if (rc) return rc;
+        const uint64_t m = std::min<uint64_t>(allowed, n - i);
+        if (d_hints)
+            hipLaunchKernelGGL(k_add_keys_hint, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, d_keys + i, d_hints + i, m, c->view());
+        else
+            hipLaunchKernelGGL(k_add_keys, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, reinterpret_cast<const int64_t *>(d_keys) + i, m, c->view());
+        HIPCHK(c, hipGetLastError());
+        i += m;
+    }
+    return MC_OK;
 }
 
 // A flat stream of super-k-mer records (+ bin words): what a rank owns after the multi-GPU exchange.
@@ -1221,8 +1317,20 @@ static int add_records_partitioned(mc_ctx *c, const uint4 *d_recs, const uint32_
     });
     if (rc) return rc;
     rc = pipe_finish(c, pl, ms1);
-    if (rc == 1) return fail(c, MC_EOVERFLOW, "internal: super-k-mer buckets overflowed while adding a record stream");
-    return rc;
+    if (rc != 1) return rc;
+    // (the buckets overflowed) the direct kernel instead
+    c->solid_tracked = false;
+    c->solid_list_fresh = false;
+    for (uint64_t i = 0; i < n;) {
+        uint64_t allowed;
+        rc = table_reserve(c, (n - i) * SK_MAX_WINDOWS, &allowed);
+        if (rc) return rc;
+        const uint64_t m = std::min<uint64_t>(std::max<uint64_t>(allowed / SK_MAX_WINDOWS, 1), n - i);
+        hipLaunchKernelGGL(k_sk_add_records, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, d_recs + i, m, c->cfg.k, c->view(), 0u, c->d_ctr + 6);
+        HIPCHK(c, hipGetLastError());
+        i += m;
+    }
+    return MC_OK;
 }
 
 // counting with read offsets known on the host
@@ -1342,6 +1450,7 @@ int mc_create(const mc_config *cfg, mc_ctx **out)
     // (MC_SUPERKMERS=0 keeps the per-window pipeline: for A/B measurements)
     if (cfg->key_mode == MC_KEY_PACKED && cfg->k >= SK_MIN_K) c->mm_k = cfg->k;
     if (const char *e = getenv("MC_SUPERKMERS")) if (!strcmp(e, "0")) c->mm_k = 0;
+    c->sk_form = c->mm_k != 0;
     uint64_t want_slots = 1ull << 22;  // 4 M slots = 64 MB to start with
     if (cfg->capacity_hint) {
         // Load factor the hint is turned into.  Hash-prefix tables: 0.7 (regions are probed in LDS, a fuller table
@@ -1796,7 +1905,7 @@ int mc_extract_keys_dev(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_of
 
 uint64_t mc_superkmer_capacity(mc_ctx *c, uint64_t n_windows, uint64_t n_reads)
 {
-    if (!c || !c->mm_k) return 0;
+    if (!c || !c->sk_form) return 0;
     return sk_records_bound(c, n_windows, n_reads);
 }
 
@@ -1805,7 +1914,7 @@ int mc_extract_superkmers_dev(mc_ctx *c, const uint64_t *d_words, const uint64_t
 {
     if (!c) return MC_EINVAL;
     std::lock_guard<std::mutex> g(c->mu);
-    if (!c->mm_k) return fail(c, MC_ESTATE, "mc_extract_superkmers_dev: this context does not count through super-k-mers (mc_superkmer_capacity() == 0)");
+    if (!c->sk_form) return fail(c, MC_ESTATE, "mc_extract_superkmers_dev: this context does not count through super-k-mers (mc_superkmer_capacity() == 0)");
     if (!owner_offsets || !d_recs || !d_bins || n_owners == 0 || n_owners > PT_MAX_BUCKETS)
         return fail(c, MC_EINVAL, "mc_extract_superkmers_dev: bad argument");
     HIPCHK(c, hipSetDevice(c->cfg.device));
@@ -1862,9 +1971,27 @@ int mc_add_superkmers_dev(mc_ctx *c, const uint64_t *d_recs, const uint32_t *d_b
 {
     if (!c) return MC_EINVAL;
     std::lock_guard<std::mutex> g(c->mu);
-    if (!c->mm_k) return fail(c, MC_ESTATE, "mc_add_superkmers_dev: this context does not count through super-k-mers");
+    if (!c->sk_form) return fail(c, MC_ESTATE, "mc_add_superkmers_dev: this context does not count through super-k-mers");
     if ((!d_recs || !d_bins) && n) return fail(c, MC_EINVAL, "mc_add_superkmers_dev: null pointer");
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (!c->mm_k) {  // the context gave up minimizer bins (to_hash_regions): the records are expanded by the direct kernel
+        c->solid_tracked = false;
+        c->solid_list_fresh = false;
+        uint64_t i = 0;
+        while (i < n) {
+            uint64_t allowed;
+            int rc = table_reserve(c, (n - i) * SK_MAX_WINDOWS, &allowed);
+            if (rc) return rc;
+            const uint64_t m = std::min<uint64_t>(std::max<uint64_t>(allowed / SK_MAX_WINDOWS, 1), n - i);
+            hipLaunchKernelGGL(k_sk_add_records, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, reinterpret_cast<const uint4 *>(d_recs) + i, m,
+                               c->cfg.k, c->view(), 0u, c->d_ctr + 6);
+            HIPCHK(c, hipGetLastError());
+            i += m;
+        }
+        c->finalized = false;
+        c->solid_cov = -1; c->solid_external = false;
+        return MC_OK;
+    }
     const uint64_t max_batch = 1ull << 28;  // records per pipeline run (32-bit bucket indices)
     for (uint64_t i = 0; i < n; i += max_batch) {
         const uint64_t m = std::min<uint64_t>(max_batch, n - i);

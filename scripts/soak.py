@@ -20,12 +20,12 @@ t0 = time.time()
 for it in range(iters):
     k = int(rng.choice([21, 23, 24, 25, 27, 28, 29, 30, 31, 31, 31, 41]))
     mode, omode = (mc.KEY_PACKED, po.KEY_PACKED) if k <= 31 else (mc.KEY_POLY, po.KEY_POLY)
-    err = int(rng.choice([0, 50, 100, 200]))
-    L = int(rng.choice([100, 150, 250]))
+    err = int(rng.choice([0, 50, 100, 200, 500]))
+    L = int(rng.choice([45, 70, 100, 150, 250]))
     n_reads = int(rng.integers(30_000, 250_000))
     contigs = int(rng.integers(1, 4))
-    clen = int(rng.integers(20_000, 400_000))
-    cov = int(rng.integers(2, 7))
+    clen = int(rng.choice([3_000, 20_000, 60_000, 150_000, 400_000]))
+    cov = int(rng.integers(1, 7))
     hint = bool(rng.integers(0, 2))
     cap = int(rng.choice([0, 0, 2_000_000, 6_000_000]))
     rseed = int(rng.integers(1, 1 << 30))

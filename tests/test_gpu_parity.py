@@ -330,6 +330,33 @@ def test_deep_coverage_of_a_small_genome(mc, monkeypatch):
         ctx.close()
 
 
+@pytest.mark.parametrize("k,err,L,n_reads,contigs,clen,cap,rseed", [
+    (31, 500, 250, 180342, 2, 3000, 6_000_000, 52959798),  # ~47 000 distinct k-mers per minimizer: no region holds that
+    (21, 100, 150, 242878, 3, 3000, 0, 171492290),         # 9 000 k-mers make up most of 32 M occurrences
+])
+def test_thousandfold_coverage(mc, monkeypatch, k, err, L, n_reads, contigs, clen, cap, rseed):
+    """Read sets that cover a few kilobases thousands of times (scripts/soak.py found both).  Minimizer-bin regions
+    cannot hold what shares one minimizer, however many regions there are: the context falls back to regions by the
+    key's own hash, for good, and what the merge kernel had not merged goes through the direct kernel.  With hash-prefix
+    regions a few heavy keys overflow their buckets' spill lists: the batch is counted by the direct kernel instead."""
+    monkeypatch.setenv("MC_COUNT_PATH", "partition")
+    genome = po.synth_genome(GENOME_SEED + 1, contigs * clen)
+    reads = po.synth_reads(genome, contigs, clen, rseed, 0, n_reads, L, err)
+    off = np.arange(n_reads + 1, dtype=np.uint64) * L
+    t, _ = oracle_table(reads, off, k, po.KEY_PACKED)
+    ctx = mc.Context(k, mc.KEY_PACKED, 0, cap)
+    ctx.add_reads_packed(po.pack(reads), off)
+    _assert_tables_equal(ctx, ctx.finalize(), t)
+    h = n_reads // 3
+    ctx.add_reads_packed(po.pack(reads[:off[h]]), off[:h + 1])  # and it keeps counting afterwards
+    t.count_reads(reads[:off[h]], off[:h + 1], k, po.KEY_PACKED)
+    _assert_tables_equal(ctx, ctx.finalize(), t)
+    seed = genome[1000:1400]
+    hi, lo = seed_windows(seed, k)
+    assert_bfs_equal(ctx.bfs(hi, lo, 1, 5, 20000, -1), po.bfs(t, k, po.KEY_PACKED, [seed], 1, 5, 20000, -1))
+    ctx.close()
+
+
 def test_bfs_no_seed_passes(mc, bfs_case):
     _, t, ctx = bfs_case
     rng = np.random.default_rng(9)
