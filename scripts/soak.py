@@ -33,6 +33,12 @@ for it in range(iters):
     genome = po.synth_genome(GENOME_SEED + it, contigs * clen)
     reads = po.synth_reads(genome, contigs, clen, rseed, 0, n_reads, L, err)
     off = np.arange(n_reads + 1, dtype=np.uint64) * L
+    ragged = bool(rng.integers(0, 4) == 0)
+    if ragged:  # reads cut to random lengths 0..L (some shorter than k, some empty)
+        lens = rng.integers(0, L + 1, n_reads)
+        keep = (np.arange(L)[None, :] < lens[:, None]).ravel()
+        reads = reads[keep]
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
     t = po.Table()
     t.count_reads(reads, off, k, omode)
     ctx = mc.Context(k, mode, 0, cap)
@@ -59,6 +65,6 @@ for it in range(iters):
         assert_bfs_equal(got, want)
     st = ctx.stats()
     ctx.close()
-    print("it %d ok: k=%d err=%d L=%d reads=%d genome=%dx%d cov=%d hint=%d cap=%d batches=%d distinct=%d list=%d sweeps=%d spills=%d (%.0f s)" % (
-        it, k, err, L, n_reads, contigs, clen, cov, hint, cap, 2 if two else 1, nd, st.solid_list_builds, st.solid_sweeps, st.spill_keys, time.time() - t0), flush=True)
+    print("it %d ok%s: k=%d err=%d L=%d reads=%d genome=%dx%d cov=%d hint=%d cap=%d batches=%d distinct=%d list=%d sweeps=%d spills=%d (%.0f s)" % (
+        it, " (ragged)" if ragged else "", k, err, L, n_reads, contigs, clen, cov, hint, cap, 2 if two else 1, nd, st.solid_list_builds, st.solid_sweeps, st.spill_keys, time.time() - t0), flush=True)
 print("soak ok: %d iterations" % iters)
