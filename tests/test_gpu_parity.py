@@ -354,6 +354,22 @@ def test_thousandfold_coverage(mc, monkeypatch, k, err, L, n_reads, contigs, cle
     seed = genome[1000:1400]
     hi, lo = seed_windows(seed, k)
     assert_bfs_equal(ctx.bfs(hi, lo, 1, 5, 20000, -1), po.bfs(t, k, po.KEY_PACKED, [seed], 1, 5, 20000, -1))
+    if k >= 23:
+        # a rank that gave up minimizer bins still takes part in the multi-GPU exchange: it cuts its reads into
+        # super-k-mer records like the others and counts the records it receives (directly)
+        import torch
+        dev = torch.device("cuda:0")
+        m = 5000
+        d_words = torch.from_numpy(po.pack(reads[:off[m]]).view(np.int64)).to(dev)
+        d_off = torch.from_numpy(off[:m + 1].view(np.int64)).to(dev)
+        cap2 = ctx.superkmer_capacity(int(off[m]), m)
+        assert cap2 > 0
+        recs = torch.zeros((cap2, 2), dtype=torch.int64, device=dev)
+        bins = torch.zeros(cap2, dtype=torch.int32, device=dev)
+        ooff = ctx.extract_superkmers_dev(d_words, d_off, m, int(off[m]), 1, recs, bins, cap2)
+        ctx.add_superkmers_dev(recs, bins, int(ooff[1]))
+        t.count_reads(reads[:off[m]], off[:m + 1], k, po.KEY_PACKED)
+        _assert_tables_equal(ctx, ctx.finalize(), t)
     ctx.close()
 
 
