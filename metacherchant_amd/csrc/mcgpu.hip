@@ -391,18 +391,18 @@ __global__ void __launch_bounds__(PT_THREADS) k_solid_emit_pairs(const int64_t *
     const uint32_t tid = threadIdx.x, n_buckets = np1;
     if (tid < PT_MAX_BUCKETS) { C.wcur[tid] = 0; C.cnt[tid] = 0; }
     __syncthreads();
-    // Rows of 64 entries (one wave, one coalesced load) are dealt to the workgroups (= segments) round-robin: an
-    // export comes in table order, which for hash-prefix tables is the order of the very hash that picks the
-    // bucket, and short arrays must not land in a few segments either -- the segment capacities count on each
-    // segment getting its share of every bucket (to within one row).
-    constexpr uint32_t WAVES = PT_THREADS / 64;
-    const uint64_t n_rows = (n + 63) / 64;
+    // Rows of 8 entries (64 bytes of keys: one memory sector) are dealt to the workgroups (= segments) round-robin.  An
+    // export comes in table order, which for hash-prefix tables is the order of the very hash that picks the bucket
+    // -- one sorted run per gathered shard -- and short arrays must not land in a few segments either: the segment
+    // capacities count on each segment getting its share of every bucket, to within a row per shard.
+    constexpr uint32_t WAVES = PT_THREADS / 64, ROW = 8, ROWS_PER_WAVE = 64 / ROW;
+    const uint64_t n_rows = (n + ROW - 1) / ROW;
     const uint32_t wave = tid >> 6, lane = tid & 63;
-    for (uint64_t t0 = 0; t0 * WAVES * gridDim.x < n_rows; t0 += PT_ITEMS) {
+    for (uint64_t t0 = 0; t0 * WAVES * ROWS_PER_WAVE * gridDim.x < n_rows; t0 += PT_ITEMS) {
 #pragma unroll
         for (int j = 0; j < PT_ITEMS; j++) {
-            const uint64_t row = ((t0 + (uint64_t)j) * WAVES + wave) * gridDim.x + blockIdx.x;
-            const uint64_t i = row * 64 + lane;
+            const uint64_t local = ((t0 + (uint64_t)j) * WAVES + wave) * ROWS_PER_WAVE + lane / ROW;  // this workgroup's row number
+            const uint64_t i = (local * gridDim.x + blockIdx.x) * ROW + lane % ROW;
             if (i >= n) continue;
             const int c = counts[i];
             if (c < min_cov || c < 0) continue;

@@ -10,6 +10,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VARIANT = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 sys.path.insert(0, ROOT)
 
 
@@ -31,32 +32,43 @@ def _worker(rank, world, port, k, q):
     from oracle import pyoracle as po
     from tests.helpers import synth_case, seed_windows
     dev = torch.device("cuda:0")
-    L, n_reads = 150, 40000
-    genome, reads, off = synth_case(2, 100000, n_reads, L, 80)
+    L, n_reads, contigs, clen, err, cov, hint = 150, 40000, 2, 100000, 80, 4, False
+    if VARIANT:  # (soak: python scripts/two_ranks_one_gpu.py <k> <variant>)
+        rng = np.random.default_rng(VARIANT)
+        L = int(rng.choice([70, 100, 150, 250]))
+        n_reads = int(rng.integers(20000, 90000))
+        contigs, clen = int(rng.integers(1, 4)), int(rng.choice([3000, 30000, 100000, 300000]))
+        err, cov, hint = int(rng.choice([0, 50, 100, 300])), int(rng.integers(2, 6)), bool(rng.integers(0, 2))
+    genome, reads, off = synth_case(contigs, clen, n_reads, L, err)
     lo, hi = split_reads(n_reads, world, rank)
     mine = reads[lo * L:hi * L]
     words = torch.from_numpy(po.pack(mine).view(np.int64)).to(dev)
     offs = torch.from_numpy((np.arange(hi - lo + 1, dtype=np.uint64) * L).view(np.int64)).to(dev)
     mode = m.KEY_PACKED if k <= 31 else m.KEY_POLY
     ctx = m.Context(k, mode, 0, 0)
+    if hint:
+        ctx.set_coverage_hint(cov)
     sc = ShardedCounter(ctx, dev)
     sc.parts_min_reads = 0  # two pieces even for this small read set: the pipelined exchange is what runs at scale
     sc.add_reads_dev(words, offs, hi - lo, (hi - lo) * L, (hi - lo) * (L - k + 1))
     total = sc.finalize()
     solid = m.Context(k, mode, 0, 0) if rank == 0 else None
-    n_solid = sc.gather_solid(solid, 4, dst=0)
+    n_solid = sc.gather_solid(solid, cov, dst=0)
     if rank == 0:
         t = po.Table()
         t.count_reads(reads, off, k, mode)
         ok, oc = t.dump()
         assert total == t.size(), (total, t.size())
-        assert n_solid == int((oc >= 4).sum())
+        assert n_solid == int((oc >= cov).sum())
         # the BFS-only context holds no counts of its own (mc_solid_from_pairs_dev): what it knows shows in the walks
-        seed = genome[30000:30300]
+        seed = genome[min(30000, clen // 3):min(30000, clen // 3) + 300]
         shi, slo = seed_windows(seed, k)
         for d in (1, -1, 0):
-            got = solid.bfs(shi, slo, d, 4, 20000, -1)
-            want = po.bfs(t, k, mode, [seed], d, 4, 20000, -1)
+            got = solid.bfs(shi, slo, d, cov, 20000, -1)
+            want = po.bfs(t, k, mode, [seed], d, cov, 20000, -1)
+            assert (got is None) == (want is None)
+            if got is None:
+                continue
             assert np.array_equal(got["lo"], want["lo"]) and np.array_equal(got["dist"], want["dist"])
             assert np.array_equal(got["cov"], want["cov"]) and np.array_equal(got["hi"], want["hi"])
         q.put(("ok", total, n_solid, sc.bytes_sent, ctx.superkmer_capacity(1000, 10) > 0))
