@@ -1930,7 +1930,12 @@ int mc_extract_superkmers_dev(mc_ctx *c, const uint64_t *d_words, const uint64_t
                     (unsigned long long)last_off, (unsigned long long)n_bases);
     // windows <= bases: capacity of the (owner, segment) pieces from the same bound the caller sized its buffer with
     const uint64_t bound = sk_records_bound(c, n_bases - first_off, n_reads);
-    const uint64_t seg_cap = (uint64_t)((double)bound / (double)n_owners / (double)PT_SEGMENTS * 1.25) + 64;
+    uint64_t seg_cap = (uint64_t)((double)bound / (double)n_owners / (double)PT_SEGMENTS * 1.25) + 64;
+    {   // a workgroup (= segment) takes whole tiles: with few tiles some segments get one more than others, or one at all
+        const uint64_t tiles = (last_off - first_off + PT_TILE - 1) / PT_TILE + 1, per_wg = (tiles + PT_SEGMENTS - 1) / PT_SEGMENTS;
+        const double per_tile = (double)bound / (double)std::max<uint64_t>(tiles - 1, 1);
+        seg_cap = std::max<uint64_t>(seg_cap, (uint64_t)((double)per_wg * per_tile / (double)n_owners * 1.3) + 64);
+    }
     if ((uint64_t)n_owners * PT_SEGMENTS * seg_cap >= 0xFFFFFFFFull)
         return fail(c, MC_EINVAL, "mc_extract_superkmers_dev: batch too large (split the reads)");
     const uint64_t n_tiles_abs = (last_off + PT_TILE - 1) / PT_TILE;
