@@ -61,10 +61,9 @@ struct mc_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_side = nullptr, ev_walk = nullptr;
     // While the hint sweep runs next to a walk of few jobs, the walk has WALK_CUS CUs of its own and the sweep the others:
-    // two CU-masked streams.  Creating them takes ~10 ms each, so a thread does it aside (started once a BFS is in
-    // sight: mc_set_coverage_hint or the first BFS); until they are ready the sweep uses side_stream and shares CUs.
+    // two CU-masked streams, created (~10 ms each) once a BFS is in sight: by mc_set_coverage_hint, or by the first BFS
+    // for the next one; without them the sweep uses side_stream and shares CUs.
     hipStream_t walk_stream = nullptr, sweep_stream = nullptr;
-    std::thread mask_thread;
     std::atomic<bool> mask_started{false}, mask_ready{false};
     hipStream_t side_stream = nullptr;  // the hint-doubling sweep runs here, next to the walk (mc_bfs_batch)
     bool double_deferred = false;       // the solid table is built but its hints are not doubled yet
@@ -1488,7 +1487,6 @@ void mc_destroy(mc_ctx *c)
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_side) (void)hipEventDestroy(c->ev_side);
     if (c->ev_walk) (void)hipEventDestroy(c->ev_walk);
-    if (c->mask_thread.joinable()) c->mask_thread.join();
     if (c->walk_stream) (void)hipStreamDestroy(c->walk_stream);
     if (c->sweep_stream) (void)hipStreamDestroy(c->sweep_stream);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
@@ -1503,18 +1501,17 @@ constexpr int WALK_CUS = 16;
 static void start_mask_streams(mc_ctx *c)
 {
     if (c->mask_started.exchange(true)) return;
-    c->mask_thread = std::thread([c] {
-        if (hipSetDevice(c->cfg.device) != hipSuccess) return;
-        uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, r[8];
-        for (int i = 0; i < WALK_CUS; i++) a[i >> 5] |= 1u << (i & 31);
-        for (int i = 0; i < 8; i++) r[i] = ~a[i];
-        hipStream_t w = nullptr, s = nullptr;
-        if (hipExtStreamCreateWithCUMask(&w, 8, a) != hipSuccess) return;
-        if (hipExtStreamCreateWithCUMask(&s, 8, r) != hipSuccess) { (void)hipStreamDestroy(w); return; }
-        c->walk_stream = w;
-        c->sweep_stream = s;
-        c->mask_ready.store(true, std::memory_order_release);
-    });
+    // (on the calling thread: a helper thread creating queues while the caller launches kernels saved 20 ms of a
+    // one-shot run, but is the one piece of concurrent runtime initialisation a hang in a long CLI soak could be traced to)
+    uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, r[8];
+    for (int i = 0; i < WALK_CUS; i++) a[i >> 5] |= 1u << (i & 31);
+    for (int i = 0; i < 8; i++) r[i] = ~a[i];
+    hipStream_t w = nullptr, s = nullptr;
+    if (hipExtStreamCreateWithCUMask(&w, 8, a) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (hipExtStreamCreateWithCUMask(&s, 8, r) != hipSuccess) { (void)hipStreamDestroy(w); (void)hipGetLastError(); return; }
+    c->walk_stream = w;
+    c->sweep_stream = s;
+    c->mask_ready.store(true, std::memory_order_release);
 }
 
 int mc_clear(mc_ctx *c)

@@ -99,7 +99,24 @@ for it in range(iters):
             extra += ["--hash", hname] + ([] if k > 31 else ["--forcehash"])
         out, want = os.path.join(tmp, "out"), os.path.join(tmp, "want")
         cmd = [build.CLI, "-k", str(k), "--reads"] + files + ["--seq", seq, "-o", out, "-w", os.path.join(tmp, "wd"), "--force"] + extra
-        p = subprocess.run(cmd, capture_output=True, text=True)
+        print("it %d: %s" % (it, " ".join(cmd[1:])), flush=True)
+        if os.environ.get("SOAK_ORACLE_ONLY"):
+            import time
+            t0 = time.time()
+            seqs, comments = ho.rich_fasta_read(seq)
+            t, res = oracle_run(files, k, mode, seqs, comments, want, **kw)
+            print("   oracle alone: %.1f s, table %d" % (time.time() - t0, t.size()), flush=True)
+            for fpath in files:  # the host reader alone (no GPU)
+                r = subprocess.run([build.HOSTTEST, "reads", fpath], capture_output=True, text=True, timeout=60)
+                print("   host reader %s: rc %d, %d reads" % (os.path.basename(fpath), r.returncode, len(r.stdout.splitlines())), flush=True)
+            continue
+        if it < int(os.environ.get("SOAK_FROM", "0")):
+            continue
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=int(os.environ.get("SOAK_CLI_TIMEOUT", "120")))
+        except subprocess.TimeoutExpired as e:
+            err = e.stderr.decode() if isinstance(e.stderr, bytes) else (e.stderr or "")
+            raise SystemExit("it %d: the CLI did not finish; its log ends:\n%s" % (it, err[-1500:]))
         assert p.returncode == 0, (it, cmd, p.stderr[-2000:])
         seqs, comments = ho.rich_fasta_read(seq)
         t, res = oracle_run(files, k, mode, seqs, comments, want, **kw)
