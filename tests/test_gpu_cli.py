@@ -72,7 +72,7 @@ def test_cli_config1_both_passes_merge(cli, tmp_path):
     cmd = [cli, "--tool", "environment-finder", "-k", "31", "--coverage", "5", "--reads", r1, r2, "--seq", seq,
            "--output", out, "--work-dir", str(tmp_path / "wd"), "--maxkmers", "100000", "--bothdirs", "False",
            "--chunklength", "10", "--merge", "true", "--force"]
-    p = subprocess.run(cmd, capture_output=True, text=True)
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr
     for line in ("Loading file reads_1.fasta...", "reads added", "Hashtable size: ", "Finding single environment for 1 sequences",
                  "Extending endings by 0 kmers", "Finished processing all sequences!"):
@@ -112,7 +112,7 @@ def test_cli_multi_sequence_dirs_and_flags(cli, tmp_path, extra, kw):
             po.decode(genome[3000:3300]), po.decode(genome[25000:25200]), po.decode(rng.integers(0, 4, 120).astype(np.uint8))))
     out, want = str(tmp_path / "out"), str(tmp_path / "want")
     cmd = [cli, "-k", "25", "-i", fq, "--seq", seq, "-o", out, "-w", str(tmp_path / "wd"), "--force"] + extra
-    p = subprocess.run(cmd, capture_output=True, text=True)
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr
     assert "Could not find any k-mers of the target gene in the input, halting." in p.stderr
     seqs, comments = ho.rich_fasta_read(seq)
@@ -133,7 +133,7 @@ def test_cli_hash_key_modes(cli, tmp_path, k, hash_name, mode):
     out, want = str(tmp_path / "out"), str(tmp_path / "want")
     cmd = [cli, "-k", str(k), "-i", r1, "--seq", seq, "-o", out, "-w", str(tmp_path / "wd"), "--force", "--maxkmers", "3000",
            "--coverage", "3", "--bothdirs", "True", "--hash", hash_name] + (["--forcehash"] if k <= 31 else [])
-    p = subprocess.run(cmd, capture_output=True, text=True)
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr
     assert "Reading hashes of k-mers instead" in p.stderr
     seqs, comments = ho.rich_fasta_read(seq)
