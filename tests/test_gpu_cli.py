@@ -148,12 +148,12 @@ def test_cli_error_paths(cli, tmp_path):
     seq = str(tmp_path / "seed.fasta")
     open(seq, "w").write(">s\nACGTACGTACGTACGTACGTACGTACGTACGTACGT\n")
     base = [cli, "-k", "21", "-i", r1, "-o", str(tmp_path / "o"), "-w", str(tmp_path / "wd"), "--force"]
-    p = subprocess.run(base + ["--seq", str(tmp_path / "nope.fasta"), "--maxkmers", "10"], capture_output=True, text=True)
+    p = subprocess.run(base + ["--seq", str(tmp_path / "nope.fasta"), "--maxkmers", "10"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 1 and "Could not load sequences from " + str(tmp_path / "nope.fasta") in p.stderr
     p = subprocess.run(base + ["--seq", seq, "--hicseq", str(tmp_path / "nohic.fasta"), "--maxkmers", "10"],
-                       capture_output=True, text=True)
+                       capture_output=True, text=True, timeout=600)
     assert p.returncode == 1 and "Could not load Hi-C sequences from " + str(tmp_path / "nohic.fasta") in p.stderr
-    p = subprocess.run(base + ["--seq", seq], capture_output=True, text=True)
+    p = subprocess.run(base + ["--seq", seq], capture_output=True, text=True, timeout=600)
     assert p.returncode == 1 and "At least one of --maxkmers and --maxradius parameters should be set" in p.stderr
 
 
@@ -167,7 +167,7 @@ def test_cli_kmer_counter_and_reload(cli, tmp_path, k, mode):
     fa = str(tmp_path / "Sample_A.fasta")
     _write_fasta(fa, reads, 150, n_every=40)
     wd = str(tmp_path / "wd")
-    p = subprocess.run([cli, "-t", "kmer-counter", "-k", str(k), "-i", fa, "-w", wd, "--force"], capture_output=True, text=True)
+    p = subprocess.run([cli, "-t", "kmer-counter", "-k", str(k), "-i", fa, "-w", wd, "--force"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr
     t = po.Table()
     rr = ho.read_fasta_reads(fa)
