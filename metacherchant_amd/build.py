@@ -33,18 +33,21 @@ def _stale(target, sources):
     return any(os.path.getmtime(s) > t for s in sources if os.path.exists(s))
 
 
-def build_lib(force=False, verbose=False):
+def build_lib(force=False, verbose=False, variant=None, defines=()):
+    """variant/defines: a tuning build next to the product library (lib/libmcgpu_<variant>.so, compiled with the given
+    -D flags); MC_LIB=<path> makes native.load() use it (scripts/variants.py)."""
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
     deps = srcs + [d if os.path.isabs(d) else os.path.join(CSRC, d) for d in HIP_DEPS]
-    if not force and not _stale(LIB, deps):
-        return LIB
+    out = LIB if not variant else os.path.join(LIBDIR, "libmcgpu_%s.so" % variant)
+    if not force and not _stale(out, deps):
+        return out
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra",
-           "-I", os.path.join(ROOT, "include"), "-o", LIB] + srcs + ["-lz", "-ldl"]
+           "-I", os.path.join(ROOT, "include"), "-o", out] + ["-D" + d for d in defines] + srcs + ["-lz", "-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return out
 
 
 HOSTTEST = os.path.join(LIBDIR, "mc_hosttest")

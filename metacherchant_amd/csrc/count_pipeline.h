@@ -173,11 +173,11 @@ __device__ __forceinline__ void scatter_tile(ScatterLds &L, const uint64_t (&key
 // first read that can matter for the tile starting at base `lo`: largest r with offsets[r] <= lo
 // (one thread per tile; the scatter kernel then walks forward from there)
 __global__ void k_tile_first_read(const uint64_t *__restrict__ offsets, uint64_t n_reads, uint64_t n_tiles,
-                                  uint32_t *__restrict__ first_read)
+                                  uint32_t *__restrict__ first_read, uint32_t tile_size = PT_TILE)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tiles) return;
-    const uint64_t lo = t * (uint64_t)PT_TILE;
+    const uint64_t lo = t * (uint64_t)tile_size;
     const uint64_t back = lo >= 64 ? lo - 64 : 0;  // hints look a few bases to the left of the tile
     uint64_t a = 0, b = n_reads;                    // invariant: offsets[a] <= back
     while (b - a > 1) {
@@ -742,14 +742,261 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk1_extract(
     if (tid < n_buckets) seg_counts[(uint64_t)tid * PT_SEGMENTS + blockIdx.x] = min(L.C.wcur[tid], (uint32_t)cap);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// SK-P1, wave-autonomous form (the one the host launches).  The kernel above synchronises 16 waves six times per tile
+// of 8192 positions and ran at 4 waves per SIMD with half its wave-cycles parked on barriers; here a WAVE owns a tile
+// of P1W_TILE = 62 x 8 positions and nothing but the bucket fill levels is shared by the workgroup:
+//   * a lane loads the three 64-bit words that hold bases p0-7 .. p0+59 around its 8 positions straight from global
+//     memory (the next tile's words, read offsets and first read are requested one tile ahead);
+//   * every 15-mer is hashed once: a lane hashes the 8 that start at its positions and takes the 16 that follow from the
+//     next two lanes (lanes 62 and 63 own no window: they only supply those hashes, so a tile needs nothing from outside
+//     its wave);
+//   * read starts and run breaks live in a 176-byte piece of LDS per wave, ordered by wave-level fences only;
+//   * a record goes out with one LDS atomic on the workgroup's fill level of its bucket and two scattered stores.
+// Same records, bin words and segment layout as k_sk1_extract (segments = workgroups = P1W_SEGMENTS).
+#ifndef MC_P1W_MIN_WAVES
+#define MC_P1W_MIN_WAVES 4   // waves per SIMD the register allocator must leave room for (tuning builds override it)
+#endif
+#ifndef MC_P1W_PREFETCH_WORDS
+#define MC_P1W_PREFETCH_WORDS 1
+#endif
+constexpr int P1W_THREADS = 512;
+constexpr int P1W_WAVES = P1W_THREADS / 64;
+constexpr uint32_t P1W_TILE = 62 * PT_ITEMS;   // base positions per wave tile
+constexpr int P1W_SEGMENTS = 1024;             // workgroups of the launch = segments of every level-1 bucket
+static_assert(P1W_SEGMENTS <= PT_THREADS && P1W_SEGMENTS >= PT_SEGMENTS, "k_sk2_scatter scans one segment count per thread");
+
+struct Sk1wLds {
+    uint32_t wcur[PT_MAX_BUCKETS];     // this workgroup's fill level of every bucket
+    uint32_t starts[P1W_WAVES][24];    // per wave: bit b <-> "a read starts at position lo - 64 + b" (704 bits used)
+    uint32_t brk[P1W_WAVES][20];       // per wave, as bytes: byte 2 + lane = that lane's 8 break bits; bytes 0,1 = 0; bytes 66.. = 0xFF
+};
+
+__device__ __forceinline__ uint32_t wave_from_next(uint32_t x)
+{  // lane i <- lane i + 1 (lane 63: unspecified)
+    return __shfl_down(x, 1);
+}
+
+// 64 bits starting at bit 2*q of the 192-bit string W0:W1:W2 (q <= 64); bits past W2 read as zero
+__device__ __forceinline__ uint64_t p1w_bits(uint64_t W0, uint64_t W1, uint64_t W2, uint32_t q)
+{
+    const bool up = q >= 32;
+    const uint64_t a = up ? W1 : W0, b = up ? W2 : W1;
+    const uint32_t sh = 2 * (q & 31);
+    return (a << sh) | ((b >> 1) >> (63 - sh));
+}
+
+template <bool OWNERS>
+__global__ void __launch_bounds__(P1W_THREADS, MC_P1W_MIN_WAVES) k_sk1w_extract(
+    const uint64_t *__restrict__ words, const uint64_t *__restrict__ offsets, uint64_t n_reads, uint64_t base_lo,
+    uint64_t n_bases, uint64_t n_tiles, const uint32_t *__restrict__ first_read, int k, uint32_t np1, uint32_t *seg_counts,
+    uint64_t cap, uint4 *out_recs, uint32_t *out_bins, SkSpill sp)
+{
+    __shared__ Sk1wLds L;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    for (uint32_t i = tid; i < PT_MAX_BUCKETS; i += P1W_THREADS) L.wcur[i] = 0;
+    uint32_t *starts = L.starts[wv];
+    uint32_t *brkw = L.brk[wv];
+    uint8_t *brkb = reinterpret_cast<uint8_t *>(brkw);
+    if (lane < 20) brkw[lane] = lane == 0 ? 0u : 0xFFFFFFFFu;  // (bytes 2 .. 65 are rewritten by every tile)
+    __syncthreads();
+    const int w = k - SK_M + 1;                       // SK_M-mers per window (9 .. 17)
+    const uint64_t last_word = (n_bases + 31) / 32;   // the pad word
+    const uint32_t kmask1 = (1u << (k - 1)) - 1u;     // k - 1 <= 30 positions after a window's first base
+    const uint64_t seg_base = (uint64_t)blockIdx.x * cap, bucket_stride = (uint64_t)gridDim.x * cap;
+    const uint64_t wave_id = (uint64_t)blockIdx.x * P1W_WAVES + wv, n_waves = (uint64_t)gridDim.x * P1W_WAVES;
+
+    uint64_t pfW0 = 0, pfW1 = 0, pfW2 = 0, pf_off = ~0ull;
+    uint32_t pf_first = 0;
+    auto load_words = [&](uint64_t tile) {
+        const int64_t p0 = (int64_t)(tile * P1W_TILE) + (int64_t)lane * PT_ITEMS;
+        const int64_t wi0 = (p0 - 7) >> 5;  // (-1 for the first lane of tile 0: that word reads as zero)
+        pfW0 = wi0 >= 0 ? words[min((uint64_t)wi0, last_word)] : 0ull;
+        pfW1 = words[min((uint64_t)(wi0 + 1), last_word)];
+        pfW2 = words[min((uint64_t)(wi0 + 2), last_word)];
+    };
+    auto prefetch = [&](uint64_t tile) {
+        if (tile >= n_tiles) return;
+        if (MC_P1W_PREFETCH_WORDS) load_words(tile);
+        pf_first = first_read[tile];
+        const uint64_t r = (uint64_t)pf_first + lane;
+        pf_off = r < n_reads ? offsets[r] : ~0ull;
+    };
+    const uint64_t tile0 = base_lo / P1W_TILE + wave_id;
+    prefetch(tile0);
+    for (uint64_t tile = tile0; tile < n_tiles; tile += n_waves) {
+        const uint64_t lo = tile * (uint64_t)P1W_TILE;
+        const int64_t bm_lo = (int64_t)lo - 64;
+        const uint64_t bm_hi = lo + 640;
+        if (!MC_P1W_PREFETCH_WORDS) load_words(tile);
+        const uint64_t W0 = pfW0, W1 = pfW1, W2 = pfW2;
+        uint64_t s = pf_off;
+        const uint32_t my_first = pf_first;
+        prefetch(tile + n_waves);
+        const uint64_t p0 = lo + (uint64_t)lane * PT_ITEMS;
+        const uint32_t off0 = (uint32_t)((int64_t)p0 - 32 * (((int64_t)p0 - 7) >> 5));  // base p0 inside W0:W1:W2 (8, 16, 24 or 32)
+
+        // ---- read starts of this tile's neighbourhood
+        if (lane < 24) starts[lane] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint64_t r = (uint64_t)my_first + lane;; r += 64) {
+            const bool in = r < n_reads && s < bm_hi;
+            if (in) {
+                const int64_t rel = (int64_t)s - bm_lo;
+                if (rel >= 0) atomicOr(&starts[(uint32_t)rel >> 5], 1u << ((uint32_t)rel & 31));
+            }
+            if (__ballot(!in)) break;  // offsets ascend: the first lane past the range ends the walk
+            s = r + 64 < n_reads ? offsets[r + 64] : ~0ull;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t ws[4];  // bit b of ws[0..3] <-> a read starts at position p0 - 8 + b
+        {
+            const uint32_t bit0 = lane * 8 + 56, wd = bit0 >> 5, sh = bit0 & 31;
+            const uint32_t d0 = starts[wd], d1 = starts[wd + 1], d2 = starts[wd + 2], d3 = starts[wd + 3], d4 = starts[wd + 4];
+            ws[0] = __builtin_amdgcn_alignbit(d1, d0, sh);
+            ws[1] = __builtin_amdgcn_alignbit(d2, d1, sh);
+            ws[2] = __builtin_amdgcn_alignbit(d3, d2, sh);
+            ws[3] = __builtin_amdgcn_alignbit(d4, d3, sh);
+        }
+
+        // ---- sk_order of the canonical SK_M-mers at my 8 positions, then of the 16 after them
+        uint32_t hh[24];
+        {
+            const uint64_t A = p1w_bits(W0, W1, W2, off0);
+            uint32_t f = (uint32_t)(A >> (64 - 2 * SK_M)), r = sk_rc_mmer(f);
+            hh[0] = sk_order(f < r ? f : r);
+#pragma unroll
+            for (int i = 1; i < 8; i++) {
+                const uint32_t nb = (uint32_t)(A >> (62 - 2 * (i + SK_M - 1))) & 3u;  // the base that enters
+                f = ((f << 2) | nb) & SK_MMASK;
+                r = (r >> 2) | ((3u - nb) << (2 * (SK_M - 1)));
+                hh[i] = sk_order(f < r ? f : r);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) hh[8 + i] = wave_from_next(hh[i]);
+#pragma unroll
+            for (int i = 0; i < 8; i++) hh[16 + i] = wave_from_next(hh[8 + i]);
+        }
+        // minimizer hash of my 8 windows: window j = min hh[j .. j+w-1].  All eight ranges hold hh[7 .. w-1]; what differs
+        // is a suffix of hh[0 .. 6] and a prefix of hh[w .. w+6].
+        uint32_t hmin[PT_ITEMS];
+#define SK_CASE(W)                                                                             \
+    case W: {                                                                                  \
+        uint32_t core = hh[7];                                                                 \
+        _Pragma("unroll") for (int i = 8; i < W; i++) core = min(core, hh[i]);                 \
+        uint32_t suf = SK_NONE;                                                                \
+        hmin[7] = core;                                                                        \
+        _Pragma("unroll") for (int j = 6; j >= 0; j--) { suf = min(suf, hh[j]); hmin[j] = min(suf, core); } \
+        uint32_t pre = SK_NONE;                                                                \
+        _Pragma("unroll") for (int j = 1; j < PT_ITEMS; j++) { pre = min(pre, hh[W + j - 1]); hmin[j] = min(hmin[j], pre); } \
+    } break;
+        switch (w) {
+            SK_CASE(9) SK_CASE(10) SK_CASE(11) SK_CASE(12) SK_CASE(13) SK_CASE(14) SK_CASE(15) SK_CASE(16)
+        default:
+            SK_CASE(17)
+        }
+#undef SK_CASE
+
+        // ---- which of my positions start a window, and where runs of equal minimizers break
+        uint32_t valid_bits = 0;
+        if (lane < 62 && p0 + (uint64_t)k <= n_bases) {
+            const uint64_t jmax = n_bases - (uint64_t)k - p0;  // last j with p0 + j + k <= n_bases
+#pragma unroll
+            for (int j = 0; j < PT_ITEMS; j++)  // the window [p, p+k) lies inside one read iff no read starts at p+1 .. p+k-1
+                if ((uint64_t)j <= jmax && p0 + (uint64_t)j >= base_lo && (__builtin_amdgcn_alignbit(ws[1], ws[0], 9 + j) & kmask1) == 0)
+                    valid_bits |= 1u << j;
+        }
+        {
+            const uint32_t last = (valid_bits >> (PT_ITEMS - 1)) & 1u ? hmin[PT_ITEMS - 1] : SK_NONE;
+            uint32_t prev = __shfl_up(last, 1);
+            if (lane == 0) prev = SK_NONE;  // a tile always starts a run
+            uint32_t bits = 0;
+#pragma unroll
+            for (int j = 0; j < PT_ITEMS; j++) {
+                const bool v = (valid_bits >> j) & 1u;
+                if (!v || prev == SK_NONE || prev != hmin[j]) bits |= 1u << j;
+                prev = v ? hmin[j] : SK_NONE;
+            }
+            brkb[2 + lane] = (uint8_t)bits;  // window i of the tile <-> bit 16 + i of the wave's break bitmap
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint64_t bw;  // bit b <-> window lane*8 - 16 + b
+        {
+            const uint32_t wd = lane >> 2, sh = 8 * (lane & 3);
+            const uint32_t d0 = brkw[wd], d1 = brkw[wd + 1], d2 = brkw[wd + 2];
+            bw = ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32) | __builtin_amdgcn_alignbit(d1, d0, sh);
+        }
+        uint32_t start_bits = 0;
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS; j++) {
+            if (!((valid_bits >> j) & 1u)) continue;
+            if ((bw >> (16 + j)) & 1ull) { start_bits |= 1u << j; continue; }           // first window of its run
+            if ((bw >> (1 + j)) & 0x7FFFull) continue;                                   // the run started < 16 windows ago
+            const uint32_t i = 16 + lane * PT_ITEMS + j;                                 // a run of 16 or more: find its start
+            uint32_t wd = i >> 5;
+            uint32_t x = brkw[wd] & ((2u << (i & 31)) - 1u);
+            while (x == 0) x = brkw[--wd];  // (window 0 of the tile always breaks)
+            const uint32_t run_start = wd * 32 + 31 - (uint32_t)__builtin_clz(x);
+            if ((i - run_start) % SK_MAX_WINDOWS == 0) start_bits |= 1u << j;
+        }
+
+        // ---- records: a run is cut every SK_MAX_WINDOWS windows, counted from its first window
+        for (uint32_t todo = start_bits; todo; todo &= todo - 1) {
+            const uint32_t j = (uint32_t)__builtin_ctz(todo);
+            const uint32_t ahead = (uint32_t)(bw >> (17 + j)) & 0x7FFFu;  // breaks among the next 15 windows
+            const uint32_t n = ahead ? (uint32_t)__builtin_ctz(ahead) + 1u : SK_MAX_WINDOWS;
+            const uint64_t e = p0 + j + n - 1;  // the run's last window
+            // context inside the same read: no start at a-HINT_LEN+1 .. a resp. e+k .. e+k+HINT_LEN-1
+            const bool has_l = ((ws[0] >> (2 + j)) & 0x7Fu) == 0;
+            bool has_r = e + (uint64_t)k + HINT_LEN <= n_bases;
+            {
+                const uint32_t b = 8 + j + n - 1 + (uint32_t)k;  // 31 .. 61
+                const uint32_t x = b >= 32 ? __builtin_amdgcn_alignbit(ws[2], ws[1], b) : __builtin_amdgcn_alignbit(ws[1], ws[0], b);
+                has_r = has_r && (x & 0x7Fu) == 0;
+            }
+            const uint32_t len = n + (uint32_t)k - 1 + (has_r ? HINT_LEN : 0);  // bases from the first window on
+            // X0:X1 = the 64 bases from a - HINT_LEN on; the record's 120-bit base field is their top 60
+            const uint32_t q = off0 + j - HINT_LEN;  // 1 .. 32
+            const uint64_t X0 = p1w_bits(W0, W1, W2, q), X1 = p1w_bits(W1, W2, 0ull, q);
+            uint64_t hi = X0 >> 8, rl = (X0 << 56) | (X1 >> 8);
+            if (!has_l) hi &= (1ull << 42) - 1;
+            const uint32_t keep = 2 * (HINT_LEN + len);  // bits of the 120-bit base field in use
+            if (keep <= 56) { hi &= ~0ull << (56 - keep); rl = 0; }
+            else rl &= ~0ull << (120 - keep);
+            hi |= ((uint64_t)(n - 1) << 58) | ((uint64_t)has_l << 57) | ((uint64_t)has_r << 56);
+            uint32_t hsel = hmin[0];
+#pragma unroll
+            for (int qq = 1; qq < PT_ITEMS; qq++) hsel = j == (uint32_t)qq ? hmin[qq] : hsel;
+            const uint32_t bin = sk_bin(hsel);
+            const uint32_t d = OWNERS ? sk_owner(hsel, np1) : mulhi32(bin, np1);
+            uint4 rec;
+            rec.x = (uint32_t)rl; rec.y = (uint32_t)(rl >> 32); rec.z = (uint32_t)hi; rec.w = (uint32_t)(hi >> 32);
+            const uint64_t dst = atomicAdd(&L.wcur[d], 1u);
+            if (dst < cap) {
+                const uint64_t at = seg_base + (uint64_t)d * bucket_stride + dst;
+                out_recs[at] = rec;
+                out_bins[at] = bin;
+            } else {
+                sk_spill_push(sp, rec);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t d = tid; d < np1; d += P1W_THREADS)  // how much of its segment of every bucket this workgroup filled
+        seg_counts[(uint64_t)d * gridDim.x + blockIdx.x] = (uint32_t)min((uint64_t)L.wcur[d], cap);
+}
+
 // Multi-GPU split: packs the (owner, segment) pieces k_sk1_extract<true> filled into one stream ordered by
 // owner.  k_sk_pack_offsets (one workgroup): piece_off[i] = records before piece i = owner * PT_SEGMENTS + seg,
 // owner_off[o] = records before owner o, owner_off[n_owners] = all.  k_sk_pack: one workgroup per piece.
 __global__ void __launch_bounds__(1024) k_sk_pack_offsets(const uint32_t *__restrict__ seg_counts, uint32_t n_owners,
-                                                          unsigned long long *piece_off, unsigned long long *owner_off)
+                                                          unsigned long long *piece_off, unsigned long long *owner_off, uint32_t nseg)
 {
     __shared__ unsigned long long part[1024];
-    const uint32_t tid = threadIdx.x, n = n_owners * PT_SEGMENTS;
+    const uint32_t tid = threadIdx.x, n = n_owners * nseg;
     const uint32_t per = (n + 1023) / 1024, lo = tid * per, hi = min(n, lo + per);
     unsigned long long sum = 0;
     for (uint32_t i = lo; i < hi; i++) sum += seg_counts[i];
@@ -764,7 +1011,7 @@ __global__ void __launch_bounds__(1024) k_sk_pack_offsets(const uint32_t *__rest
     unsigned long long acc = part[tid];
     for (uint32_t i = lo; i < hi; i++) {
         piece_off[i] = acc;
-        if (i % PT_SEGMENTS == 0) owner_off[i / PT_SEGMENTS] = acc;
+        if (i % nseg == 0) owner_off[i / nseg] = acc;
         acc += seg_counts[i];
     }
 }
@@ -823,13 +1070,14 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk1_records(const uint4 *__restr
 // scattered by the next m2 bits of the bin word into the bucket's leaves.
 struct Sk2Lds {
     SkCursors C;
-    uint32_t seg_prefix[PT_SEGMENTS + 1];
+    uint32_t seg_prefix[P1W_SEGMENTS + 1];  // (P1W_SEGMENTS >= PT_SEGMENTS)
+    uint32_t wave_tot[PT_THREADS / 64];
     uint32_t tile_seg;
 };
 __global__ void __launch_bounds__(PT_THREADS) k_sk2_scatter(const uint4 *__restrict__ in_recs, const uint32_t *__restrict__ in_bins,
                                                             uint64_t seg_cap1, const uint32_t *__restrict__ seg_counts1,
                                                             uint32_t n_buckets1, uint32_t np1, uint32_t m2, uint32_t *leaf_counts,
-                                                            uint64_t cap2, uint4 *out_recs, uint32_t *out_bins, SkSpill sp)
+                                                            uint64_t cap2, uint4 *out_recs, uint32_t *out_bins, SkSpill sp, uint32_t nseg_in = PT_SEGMENTS)
 {
     __shared__ Sk2Lds L;
     const uint32_t tid = threadIdx.x, n_buckets = m2;  // leaves per level-1 bucket
@@ -837,19 +1085,26 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk2_scatter(const uint4 *__restr
     for (uint32_t bucket = blockIdx.x; bucket < n_buckets1; bucket += gridDim.x) {
         __syncthreads();
         if (tid < PT_MAX_BUCKETS) { L.C.wcur[tid] = 0; L.C.cnt[tid] = 0; }
-        if (tid == 0) {
-            uint32_t acc = 0;
-            for (int sgm = 0; sgm < PT_SEGMENTS; sgm++) {
-                L.seg_prefix[sgm] = acc;
-                acc += seg_counts1[(uint64_t)bucket * PT_SEGMENTS + sgm];
+        {   // exclusive prefix of the bucket's segment fill levels (nseg_in <= PT_THREADS: one per thread)
+            const uint32_t c = tid < nseg_in ? seg_counts1[(uint64_t)bucket * nseg_in + tid] : 0u;
+            uint32_t x = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t y = __shfl_up(x, o);
+                if ((int)(tid & 63u) >= o) x += y;
             }
-            L.seg_prefix[PT_SEGMENTS] = acc;
+            if ((tid & 63u) == 63u) L.wave_tot[tid >> 6] = x;
+            __syncthreads();
+            uint32_t before = 0;
+            for (uint32_t i = 0; i < (tid >> 6); i++) before += L.wave_tot[i];
+            if (tid < nseg_in) L.seg_prefix[tid] = before + x - c;
+            if (tid == PT_THREADS - 1) L.seg_prefix[nseg_in] = before + x;
         }
         __syncthreads();
-        const uint32_t total = L.seg_prefix[PT_SEGMENTS];
+        const uint32_t total = L.seg_prefix[nseg_in];
         for (uint32_t first = 0; first < total; first += TILE2) {
             if (tid == 0) {  // segment of the tile's first record: largest sg with seg_prefix[sg] <= first
-                uint32_t lo_s = 0, hi_s = PT_SEGMENTS;
+                uint32_t lo_s = 0, hi_s = nseg_in;
                 while (hi_s - lo_s > 1) {
                     const uint32_t mid = (lo_s + hi_s) >> 1;
                     if (L.seg_prefix[mid] <= first) lo_s = mid; else hi_s = mid;
@@ -860,14 +1115,14 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk2_scatter(const uint4 *__restr
             uint4 rec[4];
             uint32_t bin[4];
             bool have[4];
+            uint32_t sg = L.tile_seg;  // (a thread's records ascend: the walk carries on from the previous one's segment)
 #pragma unroll
             for (int j = 0; j < 4; j++) {  // loads first, then the scattered stores
                 const uint32_t e = first + (uint32_t)j * PT_THREADS + tid;
                 have[j] = e < total;
                 if (have[j]) {
-                    uint32_t sg = L.tile_seg;
                     while (e >= L.seg_prefix[sg + 1]) sg++;
-                    const uint64_t at = ((uint64_t)bucket * PT_SEGMENTS + sg) * seg_cap1 + (e - L.seg_prefix[sg]);
+                    const uint64_t at = ((uint64_t)bucket * nseg_in + sg) * seg_cap1 + (e - L.seg_prefix[sg]);
                     rec[j] = in_recs[at];
                     bin[j] = in_bins[at];
                 }

@@ -937,6 +937,7 @@ static int ensure_buf(mc_ctx *c, T **p, uint64_t *cap, uint64_t need)
 struct PipePlan {
     uint32_t b1 = 0, b2 = 1, g = 0;  // b1 level-1 buckets of b2 leaves each (counts, not bits); a leaf covers 2^g regions
     uint64_t np1 = 0, n_leaves = 0, cap1 = 0, cap2 = 0, spill_cap = 0, wb = 0;
+    uint32_t nseg1 = PT_SEGMENTS;  // segments of every level-1 bucket = workgroups of the level-1 kernel
     bool sk = false;  // the streams hold super-k-mer records; capacities are in records
     SpillView sp{};
     SkSpill sks{};
@@ -944,8 +945,9 @@ struct PipePlan {
 
 // Table capacity check, scratch buffers and cursors for one run of the partitioned pipeline over
 // `wb` key occurrences.  n_records != 0: they travel as (an estimated) n_records super-k-mer records.
-static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records = 0)
+static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records = 0, uint32_t nseg1 = PT_SEGMENTS)
 {
+    pl->nseg1 = nseg1;
     mc_ctx::Pipe &P = c->pipe;
     c->solid_list_fresh = false;  // the pipeline buffers are about to be reused
     // Make sure the table can take the batch: with a capacity hint that still holds the table was sized for
@@ -985,34 +987,34 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
     pl->n_leaves = n_leaves;
     pl->sk = n_records != 0;
     const uint64_t units = pl->sk ? n_records : wb;  // records in the streams
-    pl->cap1 = (uint64_t)((double)units / (double)pl->np1 / (double)PT_SEGMENTS * 1.25) + (pl->sk ? 64 : 256);  // per segment
+    pl->cap1 = (uint64_t)((double)units / (double)pl->np1 / (double)nseg1 * 1.25) + (pl->sk ? 64 : 256);  // per segment
     const double mean_leaf = (double)units / (double)pl->n_leaves;
     // (records of one locus come in clumps -- one per read covering it -- so leaves vary more than Poisson)
     pl->cap2 = (uint64_t)(mean_leaf * 1.15 + (pl->sk ? 32.0 : 8.0) * std::sqrt(mean_leaf) + 64.0);  // (a spilled record also costs the solid list, P3Emit)
     pl->spill_cap = pl->sk ? std::max<uint64_t>(units / 16, 1u << 16) : std::max<uint64_t>(wb / 64, 1u << 20);
-    if (pl->np1 * PT_SEGMENTS * pl->cap1 >= 0xFFFFFFFFull || (uint64_t)pl->b2 * pl->cap2 >= 0xFFFFFFFFull)
+    if (pl->np1 * nseg1 * pl->cap1 >= 0xFFFFFFFFull || (uint64_t)pl->b2 * pl->cap2 >= 0xFFFFFFFFull)
         return fail(c, MC_EINVAL, "internal: partitioned batch too large for 32-bit bucket indices");
     // (np1, n_leaves as computed above)
     int rc;
     uint64_t dummy;
 #define ENSURE(ptr, capvar, need) do { rc = ensure_buf(c, &(ptr), &(capvar), (need)); if (rc) return rc; } while (0)
     if (pl->sk) {
-        ENSURE(P.a_recs, P.a_recs_cap, np1 * PT_SEGMENTS * pl->cap1);
+        ENSURE(P.a_recs, P.a_recs_cap, np1 * nseg1 * pl->cap1);
         if (pl->b2 > 1) ENSURE(P.b_recs, P.b_recs_cap, n_leaves * pl->cap2);
         ENSURE(P.spill_recs, P.spill_recs_cap, pl->spill_cap);
     } else {
-        { uint64_t cap = P.a_cap; ENSURE(P.a_keys, cap, np1 * PT_SEGMENTS * pl->cap1); P.a_cap = cap; }
+        { uint64_t cap = P.a_cap; ENSURE(P.a_keys, cap, np1 * nseg1 * pl->cap1); P.a_cap = cap; }
         { uint64_t cap = P.b_cap; ENSURE(P.b_keys, cap, n_leaves * pl->cap2); P.b_cap = cap; }
         { uint64_t cap = P.spill_cap; ENSURE(P.spill_keys, cap, pl->spill_cap); dummy = P.spill_cap; ENSURE(P.spill_hints, dummy, pl->spill_cap); P.spill_cap = cap; }
     }
-    ENSURE(P.a_hints, P.a_hints_cap, np1 * PT_SEGMENTS * pl->cap1);
+    ENSURE(P.a_hints, P.a_hints_cap, np1 * nseg1 * pl->cap1);
     ENSURE(P.b_hints, P.b_hints_cap, n_leaves * pl->cap2);
-    ENSURE(P.seg_counts1, P.segs1_cap, np1 * PT_SEGMENTS);
+    ENSURE(P.seg_counts1, P.segs1_cap, np1 * nseg1);
     { uint64_t cap = P.leaves_cap; ENSURE(P.cursors2, cap, n_leaves); dummy = P.leaves_cap; ENSURE(P.leaf_state, dummy, n_leaves); dummy = P.leaves_cap; ENSURE(P.leaf_new, dummy, n_leaves); P.leaves_cap = cap; }
 #undef ENSURE
     if (!P.flags) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.flags), 4 * sizeof(uint32_t)));
     if (!P.spill_count) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.spill_count), sizeof(unsigned long long)));
-    HIPCHK(c, hipMemsetAsync(P.seg_counts1, 0, np1 * PT_SEGMENTS * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(P.seg_counts1, 0, np1 * nseg1 * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(P.cursors2, 0, n_leaves * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(P.leaf_state, 0, n_leaves * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(P.leaf_new, 0, n_leaves * sizeof(uint32_t), c->stream));
@@ -1037,7 +1039,7 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1)
         rc = timed(c, &ms2, [&] {
             if (pl.sk)
                 hipLaunchKernelGGL(k_sk2_scatter, dim3((unsigned)np1), dim3(PT_THREADS), 0, c->stream, P.a_recs, P.a_hints, pl.cap1,
-                                   P.seg_counts1, (uint32_t)np1, pl.b1, pl.b2, P.cursors2, pl.cap2, P.b_recs, P.b_hints, pl.sks);
+                                   P.seg_counts1, (uint32_t)np1, pl.b1, pl.b2, P.cursors2, pl.cap2, P.b_recs, P.b_hints, pl.sks, pl.nseg1);
             else
                 hipLaunchKernelGGL(k_p2_scatter, dim3((unsigned)np1), dim3(PT_THREADS), 0, c->stream, P.a_keys, P.a_hints, pl.cap1,
                                    P.seg_counts1, (uint32_t)np1, pl.b1, pl.b2, P.cursors2, pl.cap2, P.b_keys, P.b_hints, pl.sp, c->mm_k);
@@ -1056,7 +1058,7 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1)
     const uint32_t *lh = pl.b2 > 1 ? P.b_hints : P.a_hints;
     const uint32_t *lc = pl.b2 > 1 ? P.cursors2 : P.seg_counts1;
     const uint64_t lcap = pl.b2 > 1 ? pl.cap2 : pl.cap1;
-    const uint32_t lseg = pl.b2 > 1 ? 1u : (uint32_t)PT_SEGMENTS;
+    const uint32_t lseg = pl.b2 > 1 ? 1u : pl.nseg1;
     // The solid list (P3Emit): super-k-mer form with the leaves in b_recs, so that a_recs is free to take it, and a
     // threshold to track.  Each P3 workgroup owns a segment.
     const int p3_grid = (int)std::min<uint64_t>(n_leaves, 256 * 2 * 4);
@@ -1220,19 +1222,20 @@ static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint6
     PipePlan pl;
     const uint64_t nr = r1 - r0;
     const uint64_t n_records = c->mm_k ? sk_records_bound(c, wb, nr) : 0;
-    int rc = pipe_prepare(c, wb, &pl, n_records);
+    int rc = pipe_prepare(c, wb, &pl, n_records, n_records ? (uint32_t)P1W_SEGMENTS : (uint32_t)PT_SEGMENTS);
     if (rc) return rc;
     const uint64_t *offs = d_off + r0;
     // tiles are cut over the absolute base positions [0, end_abs); the ones before base0 hold no read of ours
-    const uint64_t n_tiles_abs = (end_abs + PT_TILE - 1) / PT_TILE;
+    const uint32_t tile_size = pl.sk ? P1W_TILE : (uint32_t)PT_TILE;
+    const uint64_t n_tiles_abs = (end_abs + tile_size - 1) / tile_size;
     rc = ensure_buf(c, &P.tile_first, &P.tiles1_cap, n_tiles_abs);
     if (rc) return rc;
     double ms1 = 0;
     rc = timed(c, &ms1, [&] {
         hipLaunchKernelGGL(k_tile_first_read, dim3((unsigned)((n_tiles_abs + 255) / 256)), dim3(256), 0, c->stream, offs, nr,
-                           n_tiles_abs, P.tile_first);
+                           n_tiles_abs, P.tile_first, tile_size);
         if (pl.sk)
-            hipLaunchKernelGGL(k_sk1_extract<false>, dim3(PT_SEGMENTS), dim3(PT_THREADS), 0, c->stream, d_words, offs, nr, base0, end_abs,
+            hipLaunchKernelGGL(k_sk1w_extract<false>, dim3(P1W_SEGMENTS), dim3(P1W_THREADS), 0, c->stream, d_words, offs, nr, base0, end_abs,
                                n_tiles_abs, P.tile_first, c->cfg.k, pl.b1, P.seg_counts1, pl.cap1, P.a_recs, P.a_hints, pl.sks);
         else
             launch_p1_reads(c, d_words, offs, nr, base0, end_abs, n_tiles_abs, P.tile_first, pl.b1, P.seg_counts1, pl.cap1, P.a_keys,
@@ -1927,35 +1930,37 @@ int mc_extract_superkmers_dev(mc_ctx *c, const uint64_t *d_words, const uint64_t
                     (unsigned long long)last_off, (unsigned long long)n_bases);
     // windows <= bases: capacity of the (owner, segment) pieces from the same bound the caller sized its buffer with
     const uint64_t bound = sk_records_bound(c, n_bases - first_off, n_reads);
-    uint64_t seg_cap = (uint64_t)((double)bound / (double)n_owners / (double)PT_SEGMENTS * 1.25) + 64;
-    {   // a workgroup (= segment) takes whole tiles: with few tiles some segments get one more than others, or one at all
-        const uint64_t tiles = (last_off - first_off + PT_TILE - 1) / PT_TILE + 1, per_wg = (tiles + PT_SEGMENTS - 1) / PT_SEGMENTS;
+    const uint32_t nseg = P1W_SEGMENTS;
+    uint64_t seg_cap = (uint64_t)((double)bound / (double)n_owners / (double)nseg * 1.25) + 64;
+    {   // a workgroup (= segment) takes whole tiles, one per wave and round: with few tiles some segments get more than others, or any at all
+        const uint64_t n_waves = (uint64_t)nseg * P1W_WAVES;
+        const uint64_t tiles = (last_off - first_off + P1W_TILE - 1) / P1W_TILE + 1, per_wg = (tiles + n_waves - 1) / n_waves * P1W_WAVES;
         const double per_tile = (double)bound / (double)std::max<uint64_t>(tiles - 1, 1);
         seg_cap = std::max<uint64_t>(seg_cap, (uint64_t)((double)per_wg * per_tile / (double)n_owners * 1.3) + 64);
     }
-    if ((uint64_t)n_owners * PT_SEGMENTS * seg_cap >= 0xFFFFFFFFull)
+    if ((uint64_t)n_owners * nseg * seg_cap >= 0xFFFFFFFFull)
         return fail(c, MC_EINVAL, "mc_extract_superkmers_dev: batch too large (split the reads)");
-    const uint64_t n_tiles_abs = (last_off + PT_TILE - 1) / PT_TILE;
+    const uint64_t n_tiles_abs = (last_off + P1W_TILE - 1) / P1W_TILE;
     int rc = ensure_buf(c, &P.tile_first, &P.tiles1_cap, n_tiles_abs);
-    if (!rc) rc = ensure_buf(c, &P.a_recs, &P.a_recs_cap, (uint64_t)n_owners * PT_SEGMENTS * seg_cap);
-    if (!rc) rc = ensure_buf(c, &P.a_hints, &P.a_hints_cap, (uint64_t)n_owners * PT_SEGMENTS * seg_cap);
-    if (!rc) rc = ensure_buf(c, &P.seg_counts1, &P.segs1_cap, (uint64_t)n_owners * PT_SEGMENTS);
+    if (!rc) rc = ensure_buf(c, &P.a_recs, &P.a_recs_cap, (uint64_t)n_owners * nseg * seg_cap);
+    if (!rc) rc = ensure_buf(c, &P.a_hints, &P.a_hints_cap, (uint64_t)n_owners * nseg * seg_cap);
+    if (!rc) rc = ensure_buf(c, &P.seg_counts1, &P.segs1_cap, (uint64_t)n_owners * nseg);
     if (rc) return rc;
     if (!P.flags) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.flags), 4 * sizeof(uint32_t)));
     if (!P.spill_count) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.spill_count), sizeof(unsigned long long)));
     HIPCHK(c, hipMemsetAsync(P.flags, 0, 4 * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(P.spill_count, 0, sizeof(unsigned long long), c->stream));
     DevBuf<unsigned long long> d_piece, d_owner;
-    HIPCHK(c, d_piece.alloc((uint64_t)n_owners * PT_SEGMENTS));
+    HIPCHK(c, d_piece.alloc((uint64_t)n_owners * nseg));
     HIPCHK(c, d_owner.alloc(n_owners + 1));
     const SkSpill none{nullptr, P.spill_count, 0, P.flags};  // no spill list: an overflow is reported
     hipLaunchKernelGGL(k_tile_first_read, dim3((unsigned)((n_tiles_abs + 255) / 256)), dim3(256), 0, c->stream, d_off, n_reads,
-                       n_tiles_abs, P.tile_first);
-    hipLaunchKernelGGL(k_sk1_extract<true>, dim3(PT_SEGMENTS), dim3(PT_THREADS), 0, c->stream, d_words, d_off, n_reads, first_off,
+                       n_tiles_abs, P.tile_first, P1W_TILE);
+    hipLaunchKernelGGL(k_sk1w_extract<true>, dim3(nseg), dim3(P1W_THREADS), 0, c->stream, d_words, d_off, n_reads, first_off,
                        last_off, n_tiles_abs, P.tile_first, c->cfg.k, n_owners, P.seg_counts1, seg_cap, P.a_recs, P.a_hints, none);
-    hipLaunchKernelGGL(k_sk_pack_offsets, dim3(1), dim3(1024), 0, c->stream, P.seg_counts1, n_owners, d_piece.p, d_owner.p);
-    hipLaunchKernelGGL(k_sk_pack, dim3(std::min<uint32_t>(n_owners * PT_SEGMENTS, 4096)), dim3(256), 0, c->stream, P.a_recs, P.a_hints,
-                       P.seg_counts1, seg_cap, d_piece.p, n_owners * PT_SEGMENTS, reinterpret_cast<uint4 *>(d_recs), d_bins, cap);
+    hipLaunchKernelGGL(k_sk_pack_offsets, dim3(1), dim3(1024), 0, c->stream, P.seg_counts1, n_owners, d_piece.p, d_owner.p, nseg);
+    hipLaunchKernelGGL(k_sk_pack, dim3(std::min<uint32_t>(n_owners * nseg, 4096)), dim3(256), 0, c->stream, P.a_recs, P.a_hints,
+                       P.seg_counts1, seg_cap, d_piece.p, n_owners * nseg, reinterpret_cast<uint4 *>(d_recs), d_bins, cap);
     HIPCHK(c, hipGetLastError());
     std::vector<unsigned long long> h_owner(n_owners + 1);
     uint32_t lost = 0;

@@ -54,7 +54,8 @@ _LIB = None
 
 
 def lib_path():
-    return _build.LIB
+    """The product library; MC_LIB=<path> selects a tuning build instead (metacherchant_amd/build.py build_lib(variant=...))."""
+    return os.environ.get("MC_LIB") or _build.LIB
 
 
 def load():
@@ -62,7 +63,8 @@ def load():
     global _LIB
     if _LIB is not None:
         return _LIB
-    if not os.path.exists(_build.LIB):
+    path = lib_path()
+    if not os.path.exists(path):
         raise RuntimeError("libmcgpu.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(needs hipcc); there is no CPU fallback")
     # PyTorch-ROCm ships its own HIP runtime; it must be the first one initialised in a process that
@@ -71,7 +73,7 @@ def load():
         import torch  # noqa: F401
     except ImportError:
         pass
-    L = C.CDLL(_build.LIB)
+    L = C.CDLL(path)
     vp, u64, i64, i32 = C.c_void_p, C.c_uint64, C.c_int64, C.c_int
     u64p, i64p, i16p = C.POINTER(C.c_uint64), C.POINTER(C.c_int64), C.POINTER(C.c_int16)
     L.mc_abi_version.restype = i32
