@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define MC_ABI_VERSION 7
+#define MC_ABI_VERSION 8
 
 /* error codes */
 #define MC_OK 0
@@ -87,6 +87,16 @@ int mc_clear(mc_ctx *ctx);
  * keeps the number of k-mers with count >= min_cov up to date as it goes, which saves mc_bfs* one
  * sweep over the table.  Results never depend on it; 0 turns it off. */
 int mc_set_coverage_hint(mc_ctx *ctx, int min_cov);
+
+/* Read pointers.  A context keeps the packed bases of every read it counts (its "read store", until mc_clear) and each
+ * table slot remembers where one occurrence of its k-mer sits in it: the BFS reads its look-ahead from there (the bases
+ * that follow an occurrence are the path the walk will most likely take; every guess is looked up, so results never
+ * depend on it).  mc_set_read_pointers(ctx, 0) turns both off for the reads added from then on -- for the ranks of a
+ * sharded run whose reads the BFS rank cannot see.  mc_share_read_store(ctx, from): a BFS-only context built by
+ * mc_solid_from_pairs_dev reads the store of `from`, the context of the same device that counted (or extracted) this
+ * rank's reads and whose pointers the pairs carry; `from` must outlive the BFS calls on ctx (NULL detaches). */
+int mc_set_read_pointers(mc_ctx *ctx, int enable);
+int mc_share_read_store(mc_ctx *ctx, mc_ctx *from);
 
 /* Use the caller's HIP stream (a hipStream_t passed as void*) for all work of this context
  * instead of the context's own stream.  NULL restores the own stream. */
@@ -170,9 +180,10 @@ int mc_bfs_batch(mc_ctx *ctx, const mc_bfs_job *jobs, uint32_t n_jobs, int min_c
  * Also the record content of the reference's .kmers.bin (src/io/KmersLoadWorker.java:9,20-23)
  * and the payload of the multi-GPU gather.  With keys == NULL only *n_out is computed. */
 int mc_export(mc_ctx *ctx, int min_cov, int64_t *keys, int16_t *counts, uint64_t cap, uint64_t *n_out);
-/* d_hints (may be NULL): the 32-bit speculation hint stored with each key -- 7 bases of read context on
- * either side, used only to steer the BFS's look-ahead (never part of a result); carry it along with
- * the pairs so that a table rebuilt elsewhere walks as fast as the one that counted the reads. */
+/* d_hints (may be NULL): the 32-bit read pointer stored with each key -- where one of its occurrences sits in the
+ * read store of the context that extracted it, used only to steer the BFS's look-ahead (never part of a result);
+ * carry it along with the pairs so that a table rebuilt elsewhere walks as fast as the one that counted the reads
+ * (mc_share_read_store). */
 int mc_export_dev(mc_ctx *ctx, int min_cov, int64_t *d_keys, int16_t *d_counts, uint32_t *d_hints, uint64_t cap,
                   uint64_t *n_out);
 /* table[key] = min(32767, table[key] + count) for each pair (saturating adds commute). */
@@ -205,8 +216,8 @@ int mc_add_keys_dev(mc_ctx *ctx, const int64_t *d_keys, const uint32_t *d_hints,
 /* The same split in the compact form the counting pipeline uses itself when keys are packed k-mers
  * of at least 23 bases: one 16-byte "super-k-mer" record per run of up to 16 consecutive windows of a
  * read that share their minimizer (two uint64 per record; layout in csrc/count_pipeline.h) plus one
- * 32-bit bin word per record -- about a seventh of the bytes of the key form.  All windows of a record
- * have the same owner.
+ * 32-bit word per record (d_bins: the read pointer of the record's first window, 0 when the context keeps no read
+ * store) -- about a seventh of the bytes of the key form.  All windows of a record have the same owner.
  *   mc_superkmer_capacity   records to provide room for, given the windows and reads of a batch;
  *                           0 when this context does not use the form (then use the key form above)
  *   mc_extract_superkmers_dev  as mc_extract_keys_dev; MC_EOVERFLOW when the reads yield more records

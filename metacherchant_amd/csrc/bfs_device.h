@@ -13,9 +13,13 @@
 //             de-duplicated in an LDS hash, block scan for the ordered append.
 //   narrow -- the frontier is a handful of vertices (the usual case: metagenome graphs are mostly
 //             linear, so the BFS is ~10^5 dependent levels of width 1).  A level-per-round-trip
-//             walk is bound by HBM latency, so wave 0 looks several levels ahead in one round
-//             trip, guided by the read-context hints stored next to each k-mer, and falls back to
-//             an exact one-level replay wherever the graph is not a plain path (bfs_narrow).
+//             walk is bound by HBM latency.  Every k-mer's slot points at one of its occurrences in
+//             the read store, and the bases that follow it in that read are the path the walk will
+//             most likely take: a SCOUT (one wave per walker) hops from read to read and writes the
+//             predicted path down -- ~40-110 levels per two memory round trips -- and the rounds
+//             then look up the neighbour sets of up to 128 predicted levels at once and append the
+//             leading levels that are exactly what the sequential BFS would have found; anything
+//             else falls back to an exact one-level replay (bfs_narrow).
 #pragma once
 #include "kmer_device.h"
 
@@ -24,6 +28,12 @@ namespace mc {
 constexpr int BFS_THREADS = 512;          // 8 waves
 constexpr int MAX_NODES = BFS_THREADS;    // neighbour sets looked up per round (levels x walkers x nb): one per thread
 constexpr int MAX_DEPTH = 5;
+constexpr int SCOUT_MAX_F = 8;                        // walkers that get a scout (one wave each)
+constexpr uint32_t PATH_CAP = 1u << 15;               // levels one scout run may predict
+constexpr uint32_t PATH_WORDS = (PATH_CAP + 64 + 96) / 32 + 4;  // the walker's own k bases + the levels, 32 bases per word
+constexpr uint32_t PSEG_WORDS = 12;                   // path words a round needs: (31 + MAX_NODES / 4 + 63 + 1) bases and one to spare
+constexpr uint32_t SCOUT_WORDS = 16;                  // read-store words a hop looks at
+constexpr uint32_t SCOUT_BUDGET0 = 1024;              // levels of the first scout run; doubled after every run the rounds used up
 constexpr int NARROW_CAND = 64;           // candidates per replayed level = lanes of one wave
 constexpr int RH_SIZE = 1024;             // round-local LDS set (narrow, slow replay)
 constexpr int WH_SIZE = 2 * BFS_THREADS;  // chunk-local LDS set (wide)
@@ -37,7 +47,7 @@ struct BfsCtl {
     unsigned long long lb, le;  // current frontier = entries [lb, le)
     unsigned long long c0;      // next candidate rank inside the frontier (wide path)
     unsigned long long lookups;
-    unsigned long long rounds_narrow, rounds_slow, chunks_wide;
+    unsigned long long rounds_narrow, rounds_slow, chunks_wide, scout_hops, scout_levels, scout_calls, scout_nf, scout_m0;
     unsigned long long tacc[8];  // MC_BFS_TIMING builds: 10 ns ticks per phase of a narrow round
     long long level;            // distance of the frontier
     int status;
@@ -53,6 +63,7 @@ struct BfsState {
     uint64_t *vis;      // index of the arrays above: buckets of two (fingerprint << 32 | index) entries
     uint64_t bmask;     // number of buckets - 1
     BfsCtl *ctl;
+    uint64_t *path;     // SCOUT_MAX_F * PATH_WORDS words: the predicted paths of the walkers (scout_run)
     const uint64_t *seed_hi, *seed_lo;
     uint64_t n_seeds;
     int dir;
@@ -202,13 +213,14 @@ struct NarrowLds {
     Kmer root[NARROW_CAND];           // the walkers
     Kmer pub_k[MAX_NODES];            // accepted in the last round, to be indexed
     uint32_t pub_idx[MAX_NODES];
-    uint64_t rhint[NARROW_CAND], nhint[NARROW_CAND];  // their oriented hints (walker_hint)
-    Kmer sroot[2][NARROW_CAND];       // later stages of a round: where each walker is expected to be when its hint runs out,
-    uint64_t shint[2][NARROW_CAND];   // and that vertex's own hint (length 0: no further stage); [stage & 1]
-    uint64_t nslot[MAX_NODES];        // solid-table slot of each level-1 node (one-level replay)
+    uint32_t wptr[NARROW_CAND];       // read pointer stored with each walker's k-mer (0: none / not looked up yet)
+    uint8_t wright[NARROW_CAND];      // the walker moves right (1) or left (0)
+    uint32_t plen[SCOUT_MAX_F], ppos[SCOUT_MAX_F];  // predicted path of walker a: levels written / levels used up
+    uint64_t pseg[SCOUT_MAX_F][PSEG_WORDS];         // the path words this round reads, from word ppos / 32 on
+    uint64_t sw[SCOUT_MAX_F][SCOUT_WORDS];          // scout: the piece of the read store a hop looks at
+    uint32_t naux[MAX_NODES];         // read pointer found with each node's k-mer
     int16_t cov[MAX_NODES];
     uint8_t vis[MAX_NODES];
-    uint8_t flip[MAX_NODES];
     uint32_t set[RH_SIZE];
     uint32_t fl_w[2][NARROW_CAND];    // frontier lists: index of the node inside its tree level
     uint32_t fl_idx[2][NARROW_CAND];  //                 index in distanceToKmer (bit31: re-queued seed)
@@ -219,6 +231,8 @@ struct NarrowLds {
     long long level;
     uint32_t F;
     uint32_t bad_lvl, pend;
+    uint32_t scout_budget, scout_skip, scout_wait, force_slow;
+    unsigned long long hops, hop_levels, s_calls, s_nf, s_m0;
     int cur, status, any_dup_root;
 };
 
@@ -409,70 +423,269 @@ __device__ inline uint32_t replay_slow(const BfsState &S, NarrowLds &L, int d, i
     return n_new;
 }
 
-// oriented hint of a walker: the bases it expects next, nearest first (bits 0..55), how many
-// (bits 56..61), bit 62 = the walker moves right
-__device__ __forceinline__ uint64_t walker_hint(uint64_t hr, uint64_t hl, bool flipped, bool right)
+// lookup with the first two probe slots already loaded; *aux = the read pointer stored with the key (0 when absent)
+__device__ __forceinline__ int solid_get2(const SolidView &t, uint64_t key, uint64_t s0, const uint4 &a0, const uint4 &a1,
+                                          uint32_t *aux)
 {
-    uint64_t w = right ? (flipped ? hl : hr) : (flipped ? hr : hl);
-    if (flipped) w = lh_complement(w);
-    return (w & ~(3ull << 62)) | (right ? (1ull << 62) : 0);
-}
-
-// the vertex a walker reaches after i expected steps (i <= LHINT_MAX <= 28 < k is not required: i <= 28 and
-// the shifts below stay under 64 bits)
-__device__ __forceinline__ Kmer walker_at(const Kmer &root, int k, uint64_t hint, uint32_t i)
-{
-    if (i == 0) return root;
-    const bool right = (hint >> 62) & 1;
-    const uint32_t sh = 2 * i;  // 2 .. 56
-    Kmer r;
-    if (right) {  // ((root << 2i) | bases[0..i) with base 0 first) & mask
-        const uint64_t blk = lh_block_forward(hint, i);
-        r.hi = (root.hi << sh) | (root.lo >> (64 - sh));
-        r.lo = (root.lo << sh) | blk;
-        if (k <= 32) {
-            r.hi = 0;
-            if (k < 32) r.lo &= (1ull << (2 * k)) - 1;
-        } else {
-            r.hi &= (1ull << (2 * k - 64)) - 1;
-        }
-    } else {  // (root >> 2i) | (bases[i-1] ... bases[0]) << 2(k-i): the stored order already has base i-1 on top
-        const uint64_t blk = hint & lh_mask(i);
-        r.lo = (root.lo >> sh) | (root.hi << (64 - sh));
-        r.hi = root.hi >> sh;
-        const int pos = 2 * (k - (int)i);  // bit position of the block, >= 0 when i <= k
-        if (pos >= 64) {
-            r.hi |= blk << (pos - 64);
-        } else {
-            r.lo |= blk << pos;
-            if (pos > 0 && pos + (int)sh > 64) r.hi |= blk >> (64 - pos);
-        }
-    }
-    return r;
-}
-
-// lookup with the key/count halves of the first two probe slots already loaded
-__device__ __forceinline__ int solid_get2(const SolidView &t, uint64_t key, uint64_t s0, uint64_t s1, const uint4 &a0,
-                                          const uint4 &a1, uint64_t *found_slot)
-{
-    *found_slot = ~0ull;
+    *aux = 0;
     if (key == EMPTY_KEY) return solid_get(t, key);
     const uint64_t k0 = ((uint64_t)a0.y << 32) | a0.x;
-    if (k0 == key) { *found_slot = s0; return a0.z > 32767u ? 32767 : (int)a0.z; }
+    if (k0 == key) { *aux = a0.w; return a0.z > 32767u ? 32767 : (int)a0.z; }
     if (k0 == EMPTY_KEY) return -1;
     const uint64_t k1 = ((uint64_t)a1.y << 32) | a1.x;
-    if (k1 == key) { *found_slot = s1; return a1.z > 32767u ? 32767 : (int)a1.z; }
+    if (k1 == key) { *aux = a1.w; return a1.z > 32767u ? 32767 : (int)a1.z; }
     if (k1 == EMPTY_KEY) return -1;
     uint64_t s = s0;  // both probes hit other keys: walk the region
     const uint64_t base = s & ~(uint64_t)t.rmask;
     for (uint32_t probe = 0; probe <= t.rmask; probe++) {
         const uint4 raw = *reinterpret_cast<const uint4 *>(t.slots + s);
         const uint64_t cur = ((uint64_t)raw.y << 32) | raw.x;
-        if (cur == key) { *found_slot = s; return raw.z > 32767u ? 32767 : (int)raw.z; }
+        if (cur == key) { *aux = raw.w; return raw.z > 32767u ? 32767 : (int)raw.z; }
         if (cur == EMPTY_KEY) return -1;
         s = base | ((s + 1) & t.rmask);
     }
     return -1;
+}
+
+// 32 bases from base q of a packed word array on, first base on top (reads one word past the last one it needs)
+__device__ __forceinline__ uint64_t bases32(const uint64_t *w, uint32_t q)
+{
+    const uint32_t wi = q >> 5, off = 2 * (q & 31);
+    const uint64_t w0 = w[wi], w1 = w[wi + 1];
+    return off ? ((w0 << off) | (w1 >> (64 - off))) : w0;
+}
+
+// The 32 bases that END right before base q (q may be < 32: the missing ones read as garbage), reverse-complemented:
+// the complement of base q-1 on top, then q-2, ...
+__device__ __forceinline__ uint64_t bases32_before_rc(const uint64_t *w, uint32_t q)
+{
+    const uint64_t x = q >= 32 ? bases32(w, q - 32) : (q ? bases32(w, 0) >> (2 * (32 - q)) : 0ull);
+    return rc64_pairs(x);
+}
+
+__device__ __forceinline__ bool kmer_eq(const Kmer &a, const Kmer &b) { return a.lo == b.lo && a.hi == b.hi; }
+
+// a value every lane holds alike, moved to scalar registers
+__device__ __forceinline__ uint64_t uni64(uint64_t v)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// the k-mer at base q of a packed word array / its reverse complement; packed keys (k <= 31) live in one word
+template <int MODE>
+__device__ __forceinline__ Kmer kmer_at(const uint64_t *w, uint64_t q, int k)
+{
+    if (MODE == KEY_PACKED) return Kmer{0, bases32(w, (uint32_t)q) >> (64 - 2 * k)};
+    return extract_kmer(w, q, k);
+}
+template <int MODE>
+__device__ __forceinline__ Kmer kmer_rc(const Kmer &v, int k)
+{
+    if (MODE == KEY_PACKED) return Kmer{0, rc_packed(v.lo, k)};
+    return rc_kmer(v, k);
+}
+
+// lookup with the first four probe slots requested at once: the lanes of a wave look different keys up, and the
+// slowest one decides -- at load 1/4 one in ~8 lookups needs a second probe, nearly none a fifth
+__device__ __forceinline__ int solid_get4(const SolidView &t, uint64_t key, uint32_t *aux)
+{
+    *aux = 0;
+    if (key == EMPTY_KEY) return solid_get(t, key);
+    const uint64_t s0 = solid_slot_of(t, key), base = s0 & ~(uint64_t)t.rmask;
+    uint4 a[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) a[i] = *reinterpret_cast<const uint4 *>(t.slots + (base | ((s0 + i) & t.rmask)));
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint64_t cur = ((uint64_t)a[i].y << 32) | a[i].x;
+        if (cur == key) { *aux = a[i].w; return a[i].z > 32767u ? 32767 : (int)a[i].z; }
+        if (cur == EMPTY_KEY) return -1;
+    }
+    uint64_t s = base | ((s0 + 4) & t.rmask);
+    for (uint32_t probe = 4; probe <= t.rmask; probe++) {
+        const uint4 raw = *reinterpret_cast<const uint4 *>(t.slots + s);
+        const uint64_t cur = ((uint64_t)raw.y << 32) | raw.x;
+        if (cur == key) { *aux = raw.w; return raw.z > 32767u ? 32767 : (int)raw.z; }
+        if (cur == EMPTY_KEY) return -1;
+        s = base | ((s + 1) & t.rmask);
+    }
+    return -1;
+}
+
+// The scout of walker `a` (one wave; every lane calls it).  From the walker's vertex it follows the reads: the slot of
+// a k-mer points at one of its occurrences in the read store, the bases behind that occurrence (before it, when the read
+// runs the other way) spell the next vertices, and lane i looks the i-th of them up -- two dependent memory round trips
+// per hop of up to 64 levels.  The hop ends at the first k-mer that is not solid (a sequencing error, the end of the
+// read); the next one starts from the last solid vertex with the read pointers found on the way (the nearest ones to
+// the tip first, up to four tried).  The path is written, on the walker's own strand (for a walker that moves left: the
+// reverse complement, so that the walk always appends), 32 bases per word into S.path: first the k bases of the
+// walker's vertex, then one base per predicted level.  Only `solid` is checked here; whether each level is what the
+// sequential BFS would find is the rounds' business.
+template <int MODE>
+__device__ void scout_run(const BfsState &S, const SolidView &t, NarrowLds &L, uint32_t a, int k, int min_cov, uint32_t budget,
+                          unsigned long long &lookups)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    uint64_t *P = S.path + (uint64_t)a * PATH_WORDS;
+    uint64_t *sw = L.sw[a];
+    const bool right = L.wright[a] != 0;
+    Kmer X = right ? L.root[a] : kmer_rc<MODE>(L.root[a], k);  // the walk strand: the scout always appends
+    // the walker's own bases open the path
+    uint64_t tailw;
+    uint32_t tail_n, wi = 0;
+    if (k <= 32) {
+        tailw = X.lo << (64 - 2 * k);
+        tail_n = (uint32_t)k;
+        if (k == 32) { if (lane == 0) P[0] = tailw; tailw = 0; tail_n = 0; wi = 1; }
+    } else {
+        const uint64_t top = (X.hi << (128 - 2 * k)) | (X.lo >> (2 * k - 64));
+        if (lane == 0) P[0] = top;
+        tailw = X.lo << (128 - 2 * k);
+        tail_n = (uint32_t)k - 32;
+        wi = 1;
+    }
+    uint32_t cptr[4] = {0, 0, 0, 0}, cdelta[4] = {0, 0, 0, 0}, nc = 0;
+    {
+        uint32_t p0 = L.wptr[a];
+        if (p0 == 0) {  // the walker's k-mer has not been looked up with its pointer yet
+            (void)solid_get(t, (uint64_t)key_of<MODE>(L.root[a], k), &p0);
+            lookups++;
+        }
+        if (p0) { cptr[0] = p0; nc = 1; }
+    }
+    uint32_t levels = 0, hops = 0, n_nf = 0, n_m0 = 0;
+#ifdef MC_BFS_TIMING
+    unsigned long long sacc[4] = {0, 0, 0, 0}, slast = __builtin_amdgcn_s_memrealtime();
+#define SC_STAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); sacc[i] += now_ - slast; slast = now_; } while (0)
+#else
+#define SC_STAMP(i) do {} while (0)
+#endif
+    const uint64_t last_word = (t.reads_bases + 31) / 32;  // the pad word
+    while (levels < budget && nc) {
+        bool progressed = false;
+        for (uint32_t ci = 0; ci < nc && !progressed; ci++) {
+            uint32_t span;
+            const uint64_t lo = ptr_decode(cptr[ci], &span);
+            const uint32_t delta = cdelta[ci];  // the candidate's k-mer sits `delta` levels before the tip
+            if (lo >= t.reads_bases) continue;  // (a pointer from elsewhere)
+            // the piece of the read store around the occurrence
+            const uint64_t wlo = (lo > 128 ? lo - 128 : 0) >> 5;
+            __builtin_amdgcn_wave_barrier();
+            SC_STAMP(3);
+            if (lane < SCOUT_WORDS) sw[lane] = t.reads[min(wlo + lane, last_word)];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            SC_STAMP(0);
+            const uint64_t base = wlo * 32;
+            const Kmer Xr = kmer_rc<MODE>(X, k);
+            // where is the tip?  `delta` bases after the pointer's k-mer in a read that runs our way, before it otherwise
+            long long Q = -1;
+            bool fwd = true;
+            for (uint32_t o0 = 0; o0 < span && Q < 0; o0 += 64) {
+                const uint32_t o = o0 + lane;
+                const uint64_t qf = lo + delta + o, qr = lo + o - delta;
+                const bool of = o < span && qf + (uint64_t)k <= t.reads_bases, orv = o < span && lo + o >= delta && qr + (uint64_t)k <= t.reads_bases;
+                const bool mf = of && kmer_eq(kmer_at<MODE>(sw, qf - base, k), X);
+                const bool mr = orv && kmer_eq(kmer_at<MODE>(sw, qr - base, k), Xr);
+                const unsigned long long bf = __ballot(mf), br = __ballot(mr);
+                if (bf) { Q = (long long)(lo + delta + o0 + (uint32_t)__builtin_ctzll(bf)); fwd = true; }
+                else if (br) { Q = (long long)(lo + o0 + (uint32_t)__builtin_ctzll(br)) - (long long)delta; fwd = false; }
+            }
+            if (Q < 0) { n_nf++; continue; }
+            Q = (long long)uni64((uint64_t)Q);  // (wave-uniform: what follows from it can run on the scalar unit)
+            hops++;
+            // lane i: the vertex i + 1 levels past the tip
+            const uint32_t want = min(64u, budget - levels);
+            Kmer K{0, 0};
+            bool ok = lane < want;
+            if (fwd) {
+                const uint64_t pi = (uint64_t)Q + 1 + lane;
+                ok = ok && pi + (uint64_t)k <= t.reads_bases;
+                if (ok) K = kmer_at<MODE>(sw, pi - base, k);
+            } else {
+                ok = ok && (uint64_t)Q >= (uint64_t)lane + 1;
+                if (ok) K = kmer_rc<MODE>(kmer_at<MODE>(sw, (uint64_t)Q - 1 - lane - base, k), k);
+            }
+            uint32_t aux = 0;
+            int cov = -1;
+            SC_STAMP(1);
+            if (ok) {
+                cov = solid_get4(t, (uint64_t)key_of<MODE>(K, k), &aux);
+                lookups++;
+            }
+            SC_STAMP(2);
+            const unsigned long long solid_m = __ballot(ok && cov >= min_cov);
+            const uint32_t m = solid_m == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~solid_m);
+            if (m == 0) { n_m0++; continue; }
+            // the m new bases, first on top: what follows the occurrence (precedes it, complemented)
+            uint64_t e_hi, e_lo;
+            if (fwd) {
+                e_hi = bases32(sw, (uint32_t)((uint64_t)Q + (uint64_t)k - base));
+                e_lo = m > 32 ? bases32(sw, (uint32_t)((uint64_t)Q + (uint64_t)k + 32 - base)) : 0;
+            } else {
+                e_hi = bases32_before_rc(sw, (uint32_t)((uint64_t)Q - base));
+                e_lo = m > 32 ? bases32_before_rc(sw, (uint32_t)((uint64_t)Q - 32 - base)) : 0;
+            }
+            e_hi = uni64(e_hi);
+            e_lo = uni64(e_lo);
+            if (m < 32) e_hi &= ~0ull << (64 - 2 * m);
+            if (m <= 32) e_lo = 0; else if (m < 64) e_lo &= ~0ull << (128 - 2 * m);
+            {
+                const uint32_t sh = 2 * tail_n;  // tail_n < 32
+                const uint64_t w0 = tailw | (sh ? e_hi >> sh : e_hi);
+                const uint64_t w1 = sh ? ((e_hi << (64 - sh)) | (e_lo >> sh)) : e_lo;
+                const uint64_t w2 = sh ? (e_lo << (64 - sh)) : 0;
+                const uint32_t total = tail_n + m, nfull = total >> 5;
+                if (lane == 0) {
+                    if (nfull >= 1) P[wi] = w0;
+                    if (nfull >= 2) P[wi + 1] = w1;
+                }
+                tailw = nfull == 0 ? w0 : (nfull == 1 ? w1 : w2);
+                wi += nfull;
+                tail_n = total & 31;
+            }
+            X.lo = readlane64(K.lo, m - 1);
+            X.hi = readlane64(K.hi, m - 1);
+            levels += m;
+            // the next hop's candidates: the read pointers nearest to the tip that lead into OTHER reads than this one
+            bool other = aux != 0;
+            if (other) {
+                uint32_t sp;
+                const uint64_t at = ptr_decode(aux, &sp);
+                const uint64_t here = fwd ? (uint64_t)Q + 1 + lane : (uint64_t)Q - 1 - lane;  // where this read holds lane's k-mer
+                other = !(at <= here && here < at + sp);
+            }
+            unsigned long long cm = __ballot(lane < m && lane + 48 >= m && other);
+            nc = 0;
+            while (cm && nc < 4) {
+                const uint32_t j = 63u - (uint32_t)__builtin_clzll(cm);
+                cm &= ~(1ull << j);
+                cptr[nc] = (uint32_t)__builtin_amdgcn_readlane((int)aux, (int)j);
+                cdelta[nc] = m - 1 - j;
+                nc++;
+            }
+            progressed = true;
+        }
+        if (!progressed) break;
+    }
+    if (lane == 0) {
+        P[wi] = tailw;
+        P[wi + 1] = 0;
+        P[wi + 2] = 0;
+        L.plen[a] = levels;
+        L.ppos[a] = 0;
+        atomicAdd(&L.hops, (unsigned long long)hops);
+        atomicAdd(&L.hop_levels, (unsigned long long)levels);
+        atomicAdd(&L.s_calls, 1ull);
+        atomicAdd(&L.s_nf, (unsigned long long)n_nf);
+        atomicAdd(&L.s_m0, (unsigned long long)n_m0);
+#ifdef MC_BFS_TIMING
+        if (a == 0) printf("[scout a=0 job %u] hops %u levels %u  us: read fetch %.1f  match+extract %.1f  lookup %.1f  rest %.1f\n", blockIdx.x, hops, levels, sacc[0] * 0.01, sacc[1] * 0.01, sacc[2] * 0.01, sacc[3] * 0.01);
+#endif
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (the rounds read the path with L1-bypassing loads)
 }
 
 // The narrow walk.  All threads of the workgroup call it at a level boundary with a frontier of
@@ -480,21 +693,20 @@ __device__ __forceinline__ int solid_get2(const SolidView &t, uint64_t key, uint
 // wide, distanceToKmer is nearly full, or the round budget is used up, and hands the state back in *ctl.
 //
 // A round looks up, in ONE memory round trip, the neighbours of every walker and of the next
-// H - 1 vertices each walker is EXPECTED to visit (the hint stored with the walker's k-mer says
-// which bases followed it in the reads): one tree node per thread.  Then it finds the leading
-// levels J in which every walker's neighbourhood held exactly what the sequential BFS needs to add
-// exactly the expected vertex (anything else that is solid there is already in distanceToKmer):
-// those F*J vertices are appended in level-major order, which is the sequential discovery order.
-// The first level that holds anything else (a branch, a dead end, a wrong hint, a cycle, the cap,
-// the radius) is left to the exact one-level replay with the LDS set (replay_slow, wave 0).
-// Hints only steer the guess; every guess is checked against the table and the visited index.
+// H - 1 vertices each walker is EXPECTED to visit (its scout's predicted path): one tree node per
+// thread.  Then it finds the leading levels J in which every walker's neighbourhood held exactly what
+// the sequential BFS needs to add exactly the expected vertex (anything else that is solid there is
+// already in distanceToKmer): those F*J vertices are appended in level-major order, which is the
+// sequential discovery order.  The first level that holds anything else (a branch, a dead end, a cycle,
+// the cap, the radius) is left to the exact one-level replay with the LDS set (replay_slow, wave 0).
+// Predictions only steer the guess; every guess is checked against the table and the visited index.
 template <int MODE>
 __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, int k, int min_cov,
                            long long max_kmers, long long max_radius, unsigned long long rounds_budget,
                            unsigned long long &lookups)
 {
     BfsCtl *ctl = S.ctl;
-    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int dir = S.dir;
     const int nb = dir == 0 ? 8 : 4;
     const uint32_t lg = dir == 0 ? 3 : 2;    // log2(nb)
@@ -518,15 +730,28 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
             r.hi = S.hi[di];
             r.lo = S.lo[di];
             L.root[lane] = r;
-            L.rhint[lane] = dir > 0 ? (1ull << 62) : 0;  // no hint yet: the first round is a plain one-level round
+            L.wptr[lane] = 0;
+            L.wright[lane] = dir > 0 ? 1 : 0;
         }
+        if (lane < SCOUT_MAX_F) { L.plen[lane] = 0; L.ppos[lane] = 0; }
         const bool any = __ballot(dup) != 0;
         if (lane == 0) {
             L.n = ctl->n; L.lb = lb; L.le = le; L.level = level; L.F = F; L.cur = 0;
             L.status = BFS_RUNNING; L.any_dup_root = any ? 1 : 0; L.rounds_left = rounds_budget; L.pend = 0;
+            L.scout_budget = SCOUT_BUDGET0; L.scout_skip = 0; L.scout_wait = 1; L.hops = 0; L.hop_levels = 0; L.s_calls = 0; L.s_nf = 0; L.s_m0 = 0;
+            L.force_slow = dir == 0 ? 1 : 0;  // (both directions: which way a walker moves is known once it has stepped)
         }
     }
     __syncthreads();
+
+    // the path words the next round reads, for every walker (requested while the previous round still appends)
+    auto load_pseg = [&](uint32_t F) {
+        if (tid < F * PSEG_WORDS && F <= (uint32_t)SCOUT_MAX_F) {
+            const uint32_t a = tid / PSEG_WORDS, w = tid - a * PSEG_WORDS;
+            const uint32_t wd = (L.ppos[a] >> 5) + w;
+            L.pseg[a][w] = wd < PATH_WORDS ? ld_sc1(&S.path[(uint64_t)a * PATH_WORDS + wd]) : 0ull;
+        }
+    };
 
     for (;;) {
         // ---- uniform decisions from the shared walk state
@@ -535,6 +760,8 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
         const long long level = L.level;
         const int cur = L.cur;
         const uint32_t pend = L.pend;
+        const uint32_t skip0 = L.scout_skip, budget0 = L.scout_budget, fslow0 = L.force_slow;  // (tid 0 changes them mid-round)
+        bool dec_skip = false;
         if (F == 0) { if (tid == 0) L.status = BFS_DONE; break; }
         if (F > flim) break;
         if (n + (unsigned long long)MAX_NODES > S.dcap) { if (tid == 0) L.status = BFS_NEED_GROW; break; }
@@ -542,31 +769,44 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
         rounds++;
 
         const bool capped0 = max_kmers >= 0 && (long long)n >= max_kmers;
-        const long long room = max_radius < 0 ? (long long)LHINT_MAX : max_radius - level;  // levels that may still add
+        const long long room = max_radius < 0 ? (long long)PATH_CAP : max_radius - level;  // levels that may still add
         const uint32_t FN = F << lg;  // nodes per level
-        // the round is as deep as the shortest hint among the walkers
-        uint32_t hl_min = LHINT_MAX;
-        for (uint32_t a = 0; a < F; a++) hl_min = min(hl_min, lh_len(L.rhint[a]));
-        if (hl_min > (uint32_t)k) hl_min = (uint32_t)k;
         // x / F for x <= 512 and F <= 16 is (x * ceil(2^16 / F)) >> 16: integer divisions cost a lone wave ~30 instructions
-        // each, and this loop is bound by how fast one wave issues instructions.  F rarely changes.
+        // each.  F rarely changes.
         if (F != div_f) { div_f = F; div_m = (65536u + F - 1) / F; }
         // Hcap: how many levels a round may speculate at all (nodes, radius, whole levels under the cap)
         uint32_t H = 1, Hcap = 1;
-        if (hl_min >= 2 && !capped0 && room >= 1 && !L.any_dup_root) {
+        long long lv_left = 0;  // whole levels that may still be added
+        const bool may_spec = !capped0 && room >= 2 && !L.any_dup_root && !fslow0 && F <= (uint32_t)SCOUT_MAX_F && t.reads != nullptr;
+        if (may_spec) {
             Hcap = (((uint32_t)MAX_NODES >> lg) * div_m) >> 16;  // MAX_NODES / FN
-            const long long room2 = max_radius < 0 ? (long long)(4 * LHINT_MAX) : room;
-            if ((long long)Hcap > room2) Hcap = (uint32_t)room2;
-            if (max_kmers >= 0) {  // whole levels under the cap: H <= (max_kmers - n) / F
-                const unsigned long long rem = (unsigned long long)max_kmers - n;
-                if (rem < (unsigned long long)Hcap * F) Hcap = (uint32_t)(((uint32_t)rem * div_m) >> 16);  // (rem < 512 here)
-            }
-            if (Hcap < 1) Hcap = 1;
-            H = min(hl_min, Hcap);
+            lv_left = room;
+            if (max_kmers >= 0) lv_left = min(lv_left, (long long)(((unsigned long long)max_kmers - n) / F));
+            if ((long long)Hcap > lv_left) Hcap = (uint32_t)lv_left;
         }
-        // Further stages: when a walker's hint is used up before Hcap, the vertex it is expected to reach then brings
-        // its own hint (its slot is among this stage's lookups), and the levels behind it are looked up in another
-        // round trip of the same round -- the index work, checks and appends of a round are paid once for all stages.
+        // ---- the scouts: when a walker's predicted path is used up
+        uint32_t avail = 0;
+        if (may_spec && Hcap >= 2) {
+            avail = 0xFFFFFFFFu;
+            for (uint32_t a = 0; a < F; a++) avail = min(avail, L.plen[a] - L.ppos[a]);
+            if (avail == 0 && skip0 == 0) {
+                const uint32_t budget = (uint32_t)min((long long)min(budget0, PATH_CAP), lv_left);
+                if (wv < F) scout_run<MODE>(S, t, L, wv, k, min_cov, budget, lookups);
+                __syncthreads();
+                avail = 0xFFFFFFFFu;
+                for (uint32_t a = 0; a < F; a++) avail = min(avail, L.plen[a]);
+                load_pseg(F);
+                __syncthreads();
+                if (tid == 0) {
+                    if (avail >= budget && budget0 < PATH_CAP) L.scout_budget = budget0 * 2;
+                    // a walker nobody can predict (no pointer, a dead end ahead): plain levels for a while, longer every time
+                    if (avail == 0) { L.scout_skip = L.scout_wait; L.scout_wait = min(L.scout_wait * 2, 64u); } else L.scout_wait = 1;
+                }
+            } else if (avail == 0) {
+                dec_skip = true;  // (applied at the end of the round, behind its barriers)
+            }
+            H = max(1u, min(avail, Hcap));
+        }
         const bool spec = H >= 2;
         if (tid == 0) L.bad_lvl = 0xFFFFFFFFu;
 
@@ -577,102 +817,66 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
         uint32_t ni = 0, na = 0;
         bool npred = false, nflip = false;
         int cov = -1;
-        uint64_t nslot = ~0ull;
-        uint64_t key = 0, s0 = 0, s1 = 0;
+        uint32_t naux = 0;
+        uint64_t key = 0, s0 = 0;
         uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
-        uint4 g0 = a0, g1 = a0;  // (nodes that seed the next stage: the hint words of both probed slots)
-        bool seeds = false;
-        // node tl of a stage of Hs levels: levels lvl0 + 1 .. of the walkers standing at roots[] with hints[]
-        auto generate = [&](uint32_t tl, uint32_t lvl0, uint32_t Hs, const Kmer *roots, const uint64_t *hints, bool more) {
+        if (tid < H * FN) {
+            const uint32_t tl = tid;
             const uint32_t lvl = ((tl >> lg) * div_m) >> 16;  // tl / FN
-            ni = lvl0 + lvl + 1;
+            ni = lvl + 1;
             const uint32_t r = tl - lvl * FN;
             na = r >> lg;
             const uint32_t c = r & (uint32_t)(nb - 1);
-            const uint64_t h = hints[na];
-            const bool right = (h >> 62) & 1;
-            const uint32_t hb = (uint32_t)(h >> (2 * lvl)) & 3u;  // expected step
-            const uint32_t cstar = dir == 0 ? (2 * hb + (right ? 1u : 0u)) : hb;
-            npred = spec && c == cstar;
-            if (MODE == KEY_PACKED) {
-                // k <= 31: everything in one 64-bit word, no branches (walker_at + neighbour + key_of, specialised)
-                const uint64_t root = roots[na].lo, kmask = (1ull << (2 * k)) - 1;
-                const uint32_t sh = 2 * lvl;  // 0 .. 54
-                const uint64_t fwd = ((root << sh) | lh_block_forward(h, lvl)) & kmask;                       // root followed by lvl bases
-                const uint64_t bwd = (root >> sh) | ((h & lh_mask(lvl)) << (2 * ((uint32_t)k - lvl)));        // root preceded by them
-                const uint64_t v = lvl == 0 ? root : (right ? fwd : bwd);
+            Kmer v = L.root[na];
+            if (spec) {
+                const bool right = L.wright[na] != 0;
+                const uint32_t q = (L.ppos[na] & 31u) + lvl;
+                uint32_t hb;  // the base the walker's next step appends (walk strand)
+                Kmer x;       // the walker's vertex after lvl steps, on its walk strand
+                if (MODE == KEY_PACKED) {  // k <= 31: the vertex and the base behind it come out of one 32-base window
+                    const uint64_t A = bases32(L.pseg[na], q);
+                    x = Kmer{0, A >> (64 - 2 * k)};
+                    hb = (uint32_t)(A >> (62 - 2 * k)) & 3u;
+                } else {
+                    x = extract_kmer(L.pseg[na], q, k);
+                    const uint32_t qn = q + (uint32_t)k;
+                    hb = (uint32_t)(L.pseg[na][qn >> 5] >> (62 - 2 * (qn & 31))) & 3u;
+                }
+                v = right ? x : kmer_rc<MODE>(x, k);
+                const uint32_t ob = right ? hb : (3u ^ hb);  // ... as seen from the vertex itself
+                const uint32_t cstar = dir == 0 ? (2 * ob + (right ? 1u : 0u)) : ob;
+                npred = c == cstar;
+            }
+            if (MODE == KEY_PACKED) {  // everything in one 64-bit word, no branches (neighbour + key_of, specialised)
+                const uint64_t kmask = (1ull << (2 * k)) - 1;
                 const bool left = dir < 0 || (dir == 0 && !(c & 1));
                 const uint64_t cc = dir == 0 ? (c >> 1) : c;
-                const uint64_t x = left ? ((v >> 2) | (cc << (2 * (k - 1)))) : (((v << 2) | cc) & kmask);
-                nk.hi = 0;
-                nk.lo = x;
-                const uint64_t rcx = rc_packed(x, k);
-                nflip = rcx < x;
-                key = nflip ? rcx : x;
+                const uint64_t xx = left ? ((v.lo >> 2) | (cc << (2 * (k - 1)))) : (((v.lo << 2) | cc) & kmask);
+                nk = Kmer{0, xx};
+                const uint64_t rcx = rc_packed(xx, k);
+                nflip = rcx < xx;
+                key = nflip ? rcx : xx;
             } else {
-                const Kmer v = walker_at(roots[na], k, h, lvl);  // the expected path so far
                 nk = neighbour(v, k, dir, (int)c);
                 key = (uint64_t)key_of<MODE>(nk, k, &nflip);
             }
             s0 = solid_slot_of(t, key);
-            s1 = (s0 & ~(uint64_t)t.rmask) | ((s0 + 1) & t.rmask);
+            const uint64_t s1 = (s0 & ~(uint64_t)t.rmask) | ((s0 + 1) & t.rmask);
             a0 = *reinterpret_cast<const uint4 *>(t.slots + s0);
             a1 = *reinterpret_cast<const uint4 *>(t.slots + s1);
-            seeds = more && npred && lvl + 1 == Hs;
-            if (seeds) {
-                g0 = reinterpret_cast<const uint4 *>(t.slots + s0)[1];
-                g1 = reinterpret_cast<const uint4 *>(t.slots + s1)[1];
-            }
             lookups++;
-        };
-        {
-            const Kmer *roots = L.root;
-            const uint64_t *hints = L.rhint;
-            uint32_t Hs = H, h_min = hl_min, lvl_done = 0, nt_done = 0;
-            for (uint32_t st = 0;; st++) {
-                // another stage follows when this one runs to the end of the walkers' hints and the budget is not used up
-                const bool more = spec && Hs == h_min && lvl_done + Hs < Hcap;
-                const bool mine = tid >= nt_done && tid < nt_done + Hs * FN;
-                if (mine) generate(tid - nt_done, lvl_done, Hs, roots, hints, more);
-                if (st == 0) {
-                    // the previous round's vertices enter the index while this round's probes are in flight (taken
-                    // from the top of the workgroup, where threads usually hold no node)
-                    if (BFS_THREADS - 1 - tid < pend) vis_insert(S, L.pub_k[BFS_THREADS - 1 - tid], L.pub_idx[BFS_THREADS - 1 - tid]);
-                    MC_STAMP(1);
-                }
-                if (mine) {
-                    have = true;
-                    cov = solid_get2(t, key, s0, s1, a0, a1, &nslot);
-                    L.cov[tid] = (int16_t)cov;
-                    L.kmer[tid] = nk;
-                    if (npred) L.pk[(ni - 1) * F + na] = nk;
-                    if (seeds) {  // the walker's expected position at the end of this stage, and the hint stored there
-                        uint64_t h2 = 0;
-                        if (cov >= min_cov && nslot != ~0ull) {
-                            const bool right = (hints[na] >> 62) & 1;
-                            uint64_t hr, hl;
-                            if (nslot == s0) { hr = ((uint64_t)g0.y << 32) | g0.x; hl = ((uint64_t)g0.w << 32) | g0.z; }
-                            else if (nslot == s1) { hr = ((uint64_t)g1.y << 32) | g1.x; hl = ((uint64_t)g1.w << 32) | g1.z; }
-                            else { const SolidSlot *sl = t.slots + nslot; hr = sl->hr; hl = sl->hl; }
-                            h2 = walker_hint(hr, hl, nflip, right);
-                        }
-                        L.sroot[(st + 1) & 1][na] = nk;
-                        L.shint[(st + 1) & 1][na] = h2;
-                    }
-                }
-                lvl_done += Hs;
-                nt_done += Hs * FN;
-                if (!more) break;
-                __syncthreads();
-                roots = L.sroot[(st + 1) & 1];
-                hints = L.shint[(st + 1) & 1];
-                h_min = LHINT_MAX;
-                for (uint32_t a = 0; a < F; a++) h_min = min(h_min, lh_len(hints[a]));
-                if (h_min > (uint32_t)k) h_min = (uint32_t)k;
-                Hs = min(h_min, Hcap - lvl_done);
-                if (Hs == 0) break;
-            }
-            H = lvl_done;
+            have = true;
+        }
+        // the previous round's vertices enter the index while this round's probes are in flight (taken from the top of
+        // the workgroup, where threads usually hold no node)
+        if (BFS_THREADS - 1 - tid < pend) vis_insert(S, L.pub_k[BFS_THREADS - 1 - tid], L.pub_idx[BFS_THREADS - 1 - tid]);
+        MC_STAMP(1);
+        if (have) {
+            cov = solid_get2(t, key, s0, a0, a1, &naux);
+            L.cov[tid] = (int16_t)cov;
+            L.kmer[tid] = nk;
+            L.naux[tid] = naux;
+            if (npred) L.pk[(ni - 1) * F + na] = nk;
         }
         L.set[tid] = LH_EMPTY;
         L.set[tid + BFS_THREADS] = LH_EMPTY;
@@ -723,10 +927,8 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
                     S.cov[idx] = (int16_t)cov;
                     L.pub_k[(ni - 1) * F + na] = nk;
                     L.pub_idx[(ni - 1) * F + na] = (uint32_t)idx;
-                    if (ni == J) {  // the walker's new position and its own hint
-                        const bool right = (L.rhint[na] >> 62) & 1;
-                        const SolidSlot *sl = t.slots + nslot;
-                        L.nhint[na] = nslot == ~0ull ? (right ? (1ull << 62) : 0) : walker_hint(sl->hr, sl->hl, nflip, right);
+                    if (ni == J) {  // the walker's new position and the read pointer stored there
+                        L.wptr[na] = naux;
                         L.fl_idx[cur ^ 1][na] = (uint32_t)idx;
                     }
                 } else if (solid) {  // solid but already there: lastKmers.add(parent)
@@ -738,7 +940,7 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
             __syncthreads();
             if (tid < F) {
                 L.root[tid] = L.pk[(J - 1) * F + tid];
-                L.rhint[tid] = L.nhint[tid];
+                L.ppos[tid] += J;
                 L.fl_w[cur ^ 1][tid] = tid;
             }
             if (tid == 0) {
@@ -751,16 +953,16 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
                 L.any_dup_root = 0;
                 L.pend = n_new;  // indexed while the next round's lookups are in flight
                 L.rounds_left--;
+                if (J < H) L.force_slow = 1;  // the level behind them is something else: replayed exactly by the next round
+                if (dec_skip) L.scout_skip = skip0 - 1;
             }
+            __syncthreads();
+            load_pseg(F);
             MC_STAMP(4);
         } else {
             // ---- exact one-level replay of level 1 (ids [0, FN) are the plain neighbour sets of the walkers)
             slow_rounds++;
-            if (tid < FN) {
-                L.nslot[tid] = nslot;
-                L.flip[tid] = nflip ? 1 : 0;
-                if (H > 1) L.vis[tid] = (solid && vis_find(S, nk)) ? 1 : 0;  // index only, no expectations
-            }
+            if (tid < FN && H > 1) L.vis[tid] = (solid && vis_find(S, nk)) ? 1 : 0;  // index only, no expectations
             __syncthreads();
             if (tid < 64) {
                 uint32_t last_base = 0;
@@ -770,25 +972,29 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
                 const uint32_t Fn = L.F;
                 const int c2 = L.cur;
                 Kmer nr{0, 0};
-                uint64_t nh = 0;
+                uint32_t np = 0;
+                bool right = dir > 0;
                 if (lane < Fn && Fn <= flim) {
                     const uint32_t id = last_base + L.fl_w[c2][lane];
                     nr = L.kmer[id];
-                    const bool right = dir > 0 || (dir == 0 && (id & 1u));  // odd neighbour index = right neighbour
-                    const uint64_t sl = L.nslot[id];
-                    nh = sl == ~0ull ? (right ? (1ull << 62) : 0)
-                                     : walker_hint(t.slots[sl].hr, t.slots[sl].hl, L.flip[id] != 0, right);
+                    if (dir == 0) right = (id & 1u) != 0;  // odd neighbour index = right neighbour
+                    np = L.naux[id];
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                 if (lane < Fn && Fn <= flim) {
                     L.root[lane] = nr;
-                    L.rhint[lane] = nh;
+                    L.wptr[lane] = np;
+                    L.wright[lane] = right ? 1 : 0;
                     L.fl_w[c2][lane] = lane;  // walkers are numbered 0..F-1 in the next round
                 }
+                if (lane < SCOUT_MAX_F) { L.plen[lane] = 0; L.ppos[lane] = 0; }  // the walkers changed: their paths are void
                 if (lane == 0) {
                     L.any_dup_root = 0;
                     L.pend = 0;
                     L.rounds_left--;
+                    if (fslow0) L.scout_budget = SCOUT_BUDGET0;
+                    L.force_slow = 0;
+                    if (dec_skip) L.scout_skip = skip0 - 1;
                 }
             }
             MC_STAMP(4);
@@ -811,6 +1017,11 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
         ctl->level = L.level;
         ctl->rounds_narrow += rounds;
         ctl->rounds_slow += slow_rounds;
+        ctl->scout_hops += L.hops;
+        ctl->scout_levels += L.hop_levels;
+        ctl->scout_calls += L.s_calls;
+        ctl->scout_nf += L.s_nf;
+        ctl->scout_m0 += L.s_m0;
         if (L.status != BFS_RUNNING) ctl->status = L.status;
 #ifdef MC_BFS_TIMING
         for (int i = 0; i < 8; i++) ctl->tacc[i] += tacc[i];

@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_p1_extract_scatter(
     const uint64_t *__restrict__ words, const uint64_t *__restrict__ offsets, uint64_t n_reads, uint64_t base_lo,
     uint64_t n_bases, uint64_t n_tiles, const uint32_t *__restrict__ first_read, int k, uint32_t np1, uint32_t *cursors, uint64_t cap,
     uint64_t *out_keys, uint32_t *out_hints, unsigned long long *empty_cnt, SpillView sp, const uint64_t *bases = nullptr,
-    int mm_k = 0)
+    int mm_k = 0, uint64_t ptr_base = ~0ull)
 {
     __shared__ ScatterLds L;
     const uint32_t tid = threadIdx.x;
@@ -282,12 +282,6 @@ __global__ void __launch_bounds__(PT_THREADS) k_p1_extract_scatter(
                     hf = hf * 5 + base_at(v, k, i);
                     hr = hr * 5 + (3u ^ base_at(v, k, k - 1 - i));
                 }
-            uint32_t r7 = 0, l7 = 0;  // the HINT_LEN bases after / before the window, nearest first
-#pragma unroll
-            for (int i = 0; i < HINT_LEN; i++) {
-                r7 |= base_or0(words, p0 + (uint64_t)k + (uint64_t)i, n_bases) << (2 * i);
-                if (p0 >= (uint64_t)(i + 1)) l7 |= base_or0(words, p0 - 1 - (uint64_t)i, n_bases) << (2 * i);
-            }
 #pragma unroll
             for (int j = 0; j < PT_ITEMS; j++) {
                 const uint64_t p = p0 + (uint64_t)j;
@@ -305,12 +299,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_p1_extract_scatter(
                     } else {
                         key[j] = (uint64_t)key_of<MODE>(v, k, &flipped);
                     }
-                    // context inside the same read: no start at p+1 .. p+k+HINT_LEN-1 resp. p-HINT_LEN+1 .. p
-                    const bool rv = p + (uint64_t)k + HINT_LEN <= n_bases && bits128(w_lo, w_hi, b + (uint32_t)k, HINT_LEN) == 0;
-                    const bool lv = bits128(w_lo, w_hi, b - (HINT_LEN - 1), HINT_LEN) == 0;
-                    const uint32_t R = flipped ? (l7 ^ 0x3FFFu) : r7, Lc = flipped ? (r7 ^ 0x3FFFu) : l7;
-                    const bool RV = flipped ? lv : rv, LV = flipped ? rv : lv;
-                    hint[j] = (RV ? (R | HINT_RV) : 0u) | (LV ? ((Lc << 16) | HINT_LV) : 0u);
+                    hint[j] = ptr_base == ~0ull ? 0u : ptr_encode(ptr_base + p);  // the occurrence's place in the read store
                     if (OWNERS) {
                         valid[j] = true;
                         dig[j] = owner_of(key[j], n_buckets);
@@ -322,7 +311,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_p1_extract_scatter(
                     }
                 }
                 // roll to p + 1: the window takes the first base after it, loses its first base
-                const uint32_t in = r7 & 3u, out = base_at(v, k, 0);
+                const uint32_t in = base_or0(words, p + (uint64_t)k, n_bases), out = base_at(v, k, 0);
                 if (MODE == KEY_PACKED) {
                     v.lo = ((v.lo << 2) | in) & kmask;
                     rc = (rc >> 2) | ((uint64_t)(3u - in) << (2 * (k - 1)));
@@ -333,8 +322,6 @@ __global__ void __launch_bounds__(PT_THREADS) k_p1_extract_scatter(
                         hr = pow5_k + (hr - pow5_k - (3u - out)) * INV5 + (uint64_t)(3u - in) * pow5_km1;
                     }
                 }
-                l7 = ((l7 << 2) | out) & 0x3FFFu;
-                r7 = (r7 >> 2) | (base_or0(words, p + (uint64_t)k + HINT_LEN, n_bases) << (2 * (HINT_LEN - 1)));
             }
         }
         P1_STAMP(2);
@@ -461,47 +448,29 @@ __global__ void __launch_bounds__(PT_THREADS) k_p2_scatter(const uint64_t *__res
 // Regions of the table are minimizer bins (kmer_device.h), so all windows of a read that share their
 // minimizer go to the same region, and consecutive windows mostly do.  P1 therefore emits one 16-byte
 // RECORD per run of up to SK_MAX_WINDOWS such windows -- the run's bases plus, where the read has
-// them, the HINT_LEN bases of context on either side -- instead of one 12-byte (key, hint) record per
+// them -- instead of one 12-byte (key, read pointer) record per
 // window: about 9 windows per record at k = 31, so the streams through P1/P2/P3 shrink ~7-fold.  P3
 // expands the records back into keys and hints right before it counts them in LDS.
 //
 // Record, as the 128-bit number hi:lo --
-//   bits 127..122  unused        bits 125..122  windows - 1
-//   bit  121       the HINT_LEN bases before the first window are included (hasL)
-//   bit  120       the HINT_LEN bases after the last window are included (hasR)
-//   bits 119..106  the HINT_LEN bases before the first window (zero without hasL)
-//   bits 105..0    the windows' bases, then (hasR) the HINT_LEN bases after the last window; unused tail zero
-// A second stream carries the record's bin word (sk_bin of its minimizer): P2 and, after the table
-// grew, P3 take their bucket digits from it.
-constexpr uint32_t SK_MAX_WINDOWS = 16;  // 16 + (31 - 1) + 2*7 = 60 bases
+//   hi bits 63..60  windows - 1
+//   hi bits 59..0   the first 30 bases of the run (first base on top)
+//   lo bits 63..32  bases 30 .. 45 (windows + k - 1 <= 16 + 30 bases in all; unused tail zero)
+//   lo bits 31..0   the record's bin word (sk_bin of its minimizer): P2 and, after the table grew, P3 take their
+//                   bucket digits from it
+// A second stream carries the read pointer (kmer_device.h ptr_encode) of the record's first window, or 0.
+constexpr uint32_t SK_MAX_WINDOWS = 16;  // 16 + (31 - 1) = 46 bases
 
-__device__ __forceinline__ uint32_t sk_windows(uint64_t hi) { return (uint32_t)((hi >> 58) & 15u) + 1u; }
+__device__ __forceinline__ uint32_t sk_windows(uint64_t hi) { return (uint32_t)(hi >> 60) + 1u; }
 
-// bases [first, first + nb) of a record, right-aligned (nb <= 31)
-__device__ __forceinline__ uint64_t sk_bases(uint64_t lo, uint64_t hi, uint32_t first, uint32_t nb)
+// window j of a record -> its canonical key (j < sk_windows(hi), k <= 31)
+__device__ __forceinline__ uint64_t sk_window_key(uint64_t lo, uint64_t hi, uint32_t j, int k)
 {
-    return bits128(lo, hi, 120 - 2 * (first + nb), 2 * nb);
-}
-
-// window j of a record -> (key, hint), exactly what the per-window pipeline computes from the read
-__device__ __forceinline__ void sk_expand(uint64_t lo, uint64_t hi, uint32_t j, int k, uint64_t *key, uint32_t *hint)
-{
-    const uint32_t n = sk_windows(hi), has_l = (uint32_t)(hi >> 57) & 1u, has_r = (uint32_t)(hi >> 56) & 1u;
-    const uint32_t at = HINT_LEN + j;  // first base of the window
-    const uint64_t fw = sk_bases(lo, hi, at, (uint32_t)k), rc = rc_packed(fw, k);
-    const bool flipped = rc < fw;
-    *key = flipped ? rc : fw;
-    uint32_t fr = 0, fl = 0;
-    const bool rv = j + HINT_LEN <= n - 1 + HINT_LEN * has_r, lv = has_l || j >= (uint32_t)HINT_LEN;
-    if (rv) {
-        uint32_t x = (uint32_t)sk_bases(lo, hi, at + (uint32_t)k, HINT_LEN);  // first following base on top
-        x = __brev(x) >> (32 - 2 * HINT_LEN);
-        fr = ((x & 0x1555u) << 1) | ((x >> 1) & 0x1555u);                     // nearest base lowest
-    }
-    if (lv) fl = (uint32_t)sk_bases(lo, hi, at - HINT_LEN, HINT_LEN);        // nearest preceding base already lowest
-    const uint32_t R = flipped ? (fl ^ 0x3FFFu) : fr, Lc = flipped ? (fr ^ 0x3FFFu) : fl;
-    const bool RV = flipped ? lv : rv, LV = flipped ? rv : lv;
-    *hint = (RV ? (R | HINT_RV) : 0u) | (LV ? ((Lc << 16) | HINT_LV) : 0u);
+    // T = the 46 bases top-aligned in 128 bits
+    const uint64_t t_hi = (hi << 4) | (lo >> 60), t_lo = (lo >> 32) << 36;
+    const uint32_t sh = 2 * j;  // <= 30
+    const uint64_t fw = ((t_hi << sh) | ((t_lo >> 1) >> (63 - sh))) >> (64 - 2 * k), rc = rc_packed(fw, k);
+    return rc < fw ? rc : fw;
 }
 
 struct SkSpill {
@@ -535,213 +504,6 @@ __device__ __forceinline__ void sk_emit(SkCursors &C, uint32_t d, const uint4 &r
     }
 }
 
-struct Sk1Lds {
-    SkCursors C;
-    uint64_t bases[PT_TILE / 32 + 8];           // the tile's packed bases, from word `wfirst`
-    uint32_t starts[(PT_TILE + 256) / 32 + 2];  // bit per base position = "a read starts here"
-    alignas(16) uint32_t hs[PT_TILE + 32];      // sk_order of the canonical SK_M-mer starting at each position of the tile (+ overhang)
-    uint32_t last[PT_THREADS];                  // minimizer hash of each thread's last window (SK_NONE: no window)
-    uint32_t brk[PT_TILE / 32 + 4];             // from word 1 on, bit per window: "not a window, or its minimizer differs from
-                                                // the previous window's"; word 0 = 0, the words after the tile = all ones
-};
-
-// bases q .. q+31 of the tile's LDS copy (q relative to word `wfirst`)
-__device__ __forceinline__ uint64_t sk_lds_bases(const uint64_t *bases, uint32_t q)
-{
-    const uint32_t wi = q >> 5, off = 2 * (q & 31);
-    const uint64_t w0 = bases[wi], w1 = bases[wi + 1];
-    return off ? ((w0 << off) | (w1 >> (64 - off))) : w0;
-}
-
-// sk_order of the 8 SK_M-mers starting at tile-relative base q .. q+7
-__device__ __forceinline__ void sk_hash8(const uint64_t *bases, uint32_t q, uint32_t *out)
-{
-    const uint64_t A = sk_lds_bases(bases, q);
-    uint32_t f = (uint32_t)(A >> (64 - 2 * SK_M)), r = sk_rc_mmer(f);
-    out[0] = sk_order(f < r ? f : r);
-#pragma unroll
-    for (int i = 1; i < 8; i++) {
-        const uint32_t nb = (uint32_t)(A >> (62 - 2 * (i + SK_M - 1))) & 3u;  // the base that enters
-        f = ((f << 2) | nb) & SK_MMASK;
-        r = (r >> 2) | ((3u - nb) << (2 * (SK_M - 1)));
-        out[i] = sk_order(f < r ? f : r);
-    }
-}
-
-// SK-P1: tiles of PT_TILE consecutive base positions, PT_ITEMS (8) consecutive positions per thread.
-// OWNERS: the np1 buckets are the owner ranks of a multi-GPU split instead of ranges of the bin word.
-template <bool OWNERS>
-__global__ void __launch_bounds__(PT_THREADS) k_sk1_extract(
-    const uint64_t *__restrict__ words, const uint64_t *__restrict__ offsets, uint64_t n_reads, uint64_t base_lo,
-    uint64_t n_bases, uint64_t n_tiles, const uint32_t *__restrict__ first_read, int k, uint32_t np1, uint32_t *seg_counts,
-    uint64_t cap, uint4 *out_recs, uint32_t *out_bins, SkSpill sp)
-{
-    static_assert(PT_ITEMS == 8, "one byte of the break bitmap per thread");
-    __shared__ Sk1Lds L;
-    const uint32_t tid = threadIdx.x;
-    const uint32_t n_buckets = np1;  // (owner ranks, or level-1 buckets)
-    const int w = k - SK_M + 1;  // SK_M-mers per window (9 .. 17)
-    const uint64_t last_word = (n_bases + 31) / 32;  // the pad word
-    if (tid < PT_MAX_BUCKETS) { L.C.wcur[tid] = 0; L.C.cnt[tid] = 0; }
-    if (tid == 0) { L.brk[0] = 0; L.brk[PT_TILE / 32 + 1] = 0xFFFFFFFFu; L.brk[PT_TILE / 32 + 2] = 0xFFFFFFFFu; L.brk[PT_TILE / 32 + 3] = 0xFFFFFFFFu; }
-    constexpr int64_t MARGIN = 64;
-    // the global loads a tile starts with (its bases, the read offsets around it) are issued one tile ahead
-    uint64_t pf_word = 0, pf_off = ~0ull;
-    uint32_t pf_first = 0;
-    auto prefetch = [&](uint64_t tile) {
-        if (tile >= n_tiles) return;
-        const uint64_t lo = tile * (uint64_t)PT_TILE, wfirst = lo >= 32 ? lo / 32 - 1 : 0;
-        if (tid < PT_TILE / 32 + 8) pf_word = words[min(wfirst + tid, last_word)];
-        pf_first = first_read[tile];
-        const uint64_t r = (uint64_t)pf_first + tid;
-        pf_off = r < n_reads ? offsets[r] : ~0ull;
-    };
-    prefetch(base_lo / PT_TILE + blockIdx.x);
-    for (uint64_t tile = base_lo / PT_TILE + blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint64_t lo = tile * (uint64_t)PT_TILE;
-        const int64_t bm_lo = (int64_t)lo - MARGIN;
-        const uint64_t bm_hi = lo + PT_TILE + 128;
-        const uint64_t wfirst = lo >= 32 ? lo / 32 - 1 : 0;
-        const uint32_t rel0 = (uint32_t)(lo - wfirst * 32);  // tile-relative base 0 in the LDS copy
-        __syncthreads();  // (previous tile done with the LDS arrays)
-        for (uint32_t i = tid; i < sizeof(L.starts) / 4; i += PT_THREADS) L.starts[i] = 0;
-        if (tid < PT_TILE / 32 + 8) L.bases[tid] = pf_word;
-        const uint64_t my_off = pf_off;
-        const uint32_t my_first = pf_first;
-        prefetch(tile + gridDim.x);
-        __syncthreads();
-        {
-            uint64_t s = my_off;  // offsets[my_first + tid], or ~0 past the last read
-            for (uint64_t r = (uint64_t)my_first + tid; r < n_reads; r += PT_THREADS) {
-                if (r != (uint64_t)my_first + tid) s = offsets[r];
-                if (s >= bm_hi) break;
-                const int64_t rel = (int64_t)s - bm_lo;
-                if (rel >= 0) atomicOr(&L.starts[(uint32_t)rel >> 5], 1u << ((uint32_t)rel & 31));
-            }
-        }
-        {   // every SK_M-mer of the tile is hashed once
-            uint32_t h8[8];
-            sk_hash8(L.bases, rel0 + tid * 8, h8);
-            *reinterpret_cast<uint4 *>(&L.hs[tid * 8]) = make_uint4(h8[0], h8[1], h8[2], h8[3]);
-            *reinterpret_cast<uint4 *>(&L.hs[tid * 8 + 4]) = make_uint4(h8[4], h8[5], h8[6], h8[7]);
-            if (tid < 3) {  // the overhang the last windows need
-                sk_hash8(L.bases, rel0 + PT_TILE + tid * 8, h8);
-                *reinterpret_cast<uint4 *>(&L.hs[PT_TILE + tid * 8]) = make_uint4(h8[0], h8[1], h8[2], h8[3]);
-                *reinterpret_cast<uint4 *>(&L.hs[PT_TILE + tid * 8 + 4]) = make_uint4(h8[4], h8[5], h8[6], h8[7]);
-            }
-        }
-        __syncthreads();
-
-        // ---- minimizer hash of my 8 windows: min over w consecutive entries of hs
-        const uint64_t p0 = lo + (uint64_t)tid * PT_ITEMS;
-        const uint32_t wrel = (uint32_t)((int64_t)p0 - 8 - bm_lo);
-        const uint64_t w_lo = starts_window(L.starts, wrel), w_hi = starts_window(L.starts, wrel + 64);
-        uint32_t hmin[PT_ITEMS];
-        uint32_t valid_bits = 0;
-        {
-            uint32_t hh[24], o[16];
-#pragma unroll
-            for (int i = 0; i < 6; i++) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(&L.hs[tid * 8 + 4 * i]);
-                hh[4 * i] = v.x; hh[4 * i + 1] = v.y; hh[4 * i + 2] = v.z; hh[4 * i + 3] = v.w;
-            }
-            {   // o[i] = min hh[i .. i+7]
-                uint32_t p2[23], p4[21];
-#pragma unroll
-                for (int i = 0; i < 23; i++) p2[i] = min(hh[i], hh[i + 1]);
-#pragma unroll
-                for (int i = 0; i < 21; i++) p4[i] = min(p2[i], p2[i + 2]);
-#pragma unroll
-                for (int i = 0; i < 16; i++) o[i] = min(p4[i], p4[i + 4]);
-            }
-            // min hh[j .. j+w-1] from two overlapping runs of 8 (w = 9 .. 16), or two runs and one more (w = 17)
-#define SK_CASE(W)                                                                                              \
-    case W:                                                                                                     \
-        _Pragma("unroll") for (int j = 0; j < PT_ITEMS; j++)                                                    \
-            hmin[j] = W == 17 ? min(min(o[j], o[j + 8]), hh[j + 16]) : min(o[j], o[j + (W == 17 ? 8 : W - 8)]); \
-        break;
-            switch (w) {
-                SK_CASE(9) SK_CASE(10) SK_CASE(11) SK_CASE(12) SK_CASE(13) SK_CASE(14) SK_CASE(15) SK_CASE(16)
-            default:
-                SK_CASE(17)
-            }
-#undef SK_CASE
-#pragma unroll
-            for (int j = 0; j < PT_ITEMS; j++) {
-                const uint64_t p = p0 + (uint64_t)j;
-                // the window [p, p+k) lies inside one read iff no read starts at p+1 .. p+k-1
-                if (p >= base_lo && p + (uint64_t)k <= n_bases && bits128(w_lo, w_hi, 8 + (uint32_t)j + 1, (uint32_t)(k - 1)) == 0)
-                    valid_bits |= 1u << j;
-            }
-        }
-        L.last[tid] = (valid_bits >> (PT_ITEMS - 1)) & 1u ? hmin[PT_ITEMS - 1] : SK_NONE;
-        __syncthreads();
-        {
-            uint32_t prev = tid ? L.last[tid - 1] : SK_NONE;  // a tile always starts a run
-            uint32_t bits = 0;
-#pragma unroll
-            for (int j = 0; j < PT_ITEMS; j++) {
-                const bool v = (valid_bits >> j) & 1u;
-                if (!v || prev == SK_NONE || prev != hmin[j]) bits |= 1u << j;
-                prev = v ? hmin[j] : SK_NONE;
-            }
-            reinterpret_cast<uint8_t *>(L.brk + 1)[tid] = (uint8_t)bits;  // window i of the tile <-> bit i of the words from L.brk[1]
-        }
-        __syncthreads();
-
-        // ---- records: a run is cut every SK_MAX_WINDOWS windows, counted from its first window.
-        // 64 break bits around my windows: bit b <-> window tid*8 - 16 + b
-        uint64_t bw;
-        {
-            const uint32_t pos = 32 + tid * 8 - 16, wd = pos >> 5, sh = pos & 31;  // (bit 32 of L.brk = window 0)
-            const uint64_t x0 = ((uint64_t)L.brk[wd + 1] << 32) | L.brk[wd];
-            bw = sh ? ((x0 >> sh) | ((uint64_t)L.brk[wd + 2] << (64 - sh))) : x0;
-        }
-        uint32_t start_bits = 0;
-#pragma unroll
-        for (int j = 0; j < PT_ITEMS; j++) {
-            if (!((valid_bits >> j) & 1u)) continue;
-            if ((bw >> (16 + j)) & 1ull) { start_bits |= 1u << j; continue; }           // first window of its run
-            if ((bw >> (1 + j)) & 0x7FFFull) continue;                                   // the run started < 16 windows ago
-            uint32_t i = tid * PT_ITEMS + j, wd = (i >> 5) + 1, bit = i & 31;            // rare: a run of 16 or more
-            uint32_t x = L.brk[wd] & ((2u << bit) - 1u);
-            while (x == 0) x = L.brk[--wd];  // (window 0 of the tile always breaks)
-            const uint32_t run_start = (wd - 1) * 32 + 31 - (uint32_t)__builtin_clz(x);
-            if ((i - run_start) % SK_MAX_WINDOWS == 0) start_bits |= 1u << j;
-        }
-        for (uint32_t todo = start_bits; todo; todo &= todo - 1) {
-            const uint32_t j = (uint32_t)__builtin_ctz(todo), i = tid * PT_ITEMS + j;
-            const uint32_t ahead = (uint32_t)(bw >> (17 + j)) & 0x7FFFu;  // breaks among the next 15 windows
-            const uint32_t n = ahead ? (uint32_t)__builtin_ctz(ahead) + 1u : SK_MAX_WINDOWS;
-            const uint64_t a = lo + i, e = a + n - 1;
-            // context inside the same read: no start at a-HINT_LEN+1 .. a resp. e+1 .. e+k+HINT_LEN-1
-            const bool has_l = bits128(w_lo, w_hi, 8 + j - (HINT_LEN - 1), HINT_LEN) == 0;
-            const bool has_r = e + (uint64_t)k + HINT_LEN <= n_bases && bits128(w_lo, w_hi, 8 + j + n - 1 + (uint32_t)k, HINT_LEN) == 0;
-            const uint32_t len = n + (uint32_t)k - 1 + (has_r ? HINT_LEN : 0);  // bases from the first window on
-            const uint32_t qa = rel0 + i;
-            const uint64_t A = sk_lds_bases(L.bases, qa), B = sk_lds_bases(L.bases, qa + 32);  // bases a .. a+31, a+32 .. a+63
-            const uint64_t ctx_l = has_l ? sk_lds_bases(L.bases, qa - HINT_LEN) >> (64 - 2 * HINT_LEN) : 0;  // bases a-HINT_LEN .. a-1
-            uint64_t hi = (ctx_l << 42) | (A >> 22), rl = (A << 42) | (B >> 22);
-            const uint32_t keep = 2 * (HINT_LEN + len);  // bits of the 120-bit base field in use
-            if (keep <= 56) { hi &= ~0ull << (56 - keep); rl = 0; }
-            else rl &= ~0ull << (120 - keep);
-            hi |= ((uint64_t)(n - 1) << 58) | ((uint64_t)has_l << 57) | ((uint64_t)has_r << 56);
-            uint32_t hsel = hmin[0];
-#pragma unroll
-            for (int q = 1; q < PT_ITEMS; q++) hsel = j == (uint32_t)q ? hmin[q] : hsel;
-            const uint32_t bin = sk_bin(hsel);
-            uint4 rec;
-            rec.x = (uint32_t)rl; rec.y = (uint32_t)(rl >> 32); rec.z = (uint32_t)hi; rec.w = (uint32_t)(hi >> 32);
-            sk_emit(L.C, OWNERS ? sk_owner(hsel, np1) : mulhi32(bin, np1), rec, bin, cap, (uint64_t)blockIdx.x * cap,
-                    (uint64_t)PT_SEGMENTS * cap, out_recs, out_bins, sp);
-        }
-        __syncthreads();
-        if (tid < n_buckets) { L.C.wcur[tid] += L.C.cnt[tid]; L.C.cnt[tid] = 0; }
-    }
-    __syncthreads();
-    if (tid < n_buckets) seg_counts[(uint64_t)tid * PT_SEGMENTS + blockIdx.x] = min(L.C.wcur[tid], (uint32_t)cap);
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // SK-P1, wave-autonomous form (the one the host launches).  The kernel above synchronises 16 waves six times per tile
 // of 8192 positions and ran at 4 waves per SIMD with half its wave-cycles parked on barriers; here a WAVE owns a tile
@@ -752,8 +514,10 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk1_extract(
 //     next two lanes (lanes 62 and 63 own no window: they only supply those hashes, so a tile needs nothing from outside
 //     its wave);
 //   * read starts and run breaks live in a 176-byte piece of LDS per wave, ordered by wave-level fences only;
-//   * a record goes out with one LDS atomic on the workgroup's fill level of its bucket and two scattered stores.
-// Same records, bin words and segment layout as k_sk1_extract (segments = workgroups = P1W_SEGMENTS).
+//   * a record goes out with one LDS atomic on the workgroup's fill level of its bucket and two scattered stores
+//     (the record, and the read pointer of its first window: base ptr_base + position in the read store; ptr_base
+//     == ~0: the context keeps no read store and the pointers are 0).
+// Segments = workgroups = P1W_SEGMENTS.
 #ifndef MC_P1W_MIN_WAVES
 #define MC_P1W_MIN_WAVES 4   // waves per SIMD the register allocator must leave room for (tuning builds override it)
 #endif
@@ -790,7 +554,7 @@ template <bool OWNERS>
 __global__ void __launch_bounds__(P1W_THREADS, MC_P1W_MIN_WAVES) k_sk1w_extract(
     const uint64_t *__restrict__ words, const uint64_t *__restrict__ offsets, uint64_t n_reads, uint64_t base_lo,
     uint64_t n_bases, uint64_t n_tiles, const uint32_t *__restrict__ first_read, int k, uint32_t np1, uint32_t *seg_counts,
-    uint64_t cap, uint4 *out_recs, uint32_t *out_bins, SkSpill sp)
+    uint64_t cap, uint4 *out_recs, uint32_t *out_ptrs, SkSpill sp, uint64_t ptr_base)
 {
     __shared__ Sk1wLds L;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
@@ -948,37 +712,27 @@ __global__ void __launch_bounds__(P1W_THREADS, MC_P1W_MIN_WAVES) k_sk1w_extract(
             const uint32_t j = (uint32_t)__builtin_ctz(todo);
             const uint32_t ahead = (uint32_t)(bw >> (17 + j)) & 0x7FFFu;  // breaks among the next 15 windows
             const uint32_t n = ahead ? (uint32_t)__builtin_ctz(ahead) + 1u : SK_MAX_WINDOWS;
-            const uint64_t e = p0 + j + n - 1;  // the run's last window
-            // context inside the same read: no start at a-HINT_LEN+1 .. a resp. e+k .. e+k+HINT_LEN-1
-            const bool has_l = ((ws[0] >> (2 + j)) & 0x7Fu) == 0;
-            bool has_r = e + (uint64_t)k + HINT_LEN <= n_bases;
-            {
-                const uint32_t b = 8 + j + n - 1 + (uint32_t)k;  // 31 .. 61
-                const uint32_t x = b >= 32 ? __builtin_amdgcn_alignbit(ws[2], ws[1], b) : __builtin_amdgcn_alignbit(ws[1], ws[0], b);
-                has_r = has_r && (x & 0x7Fu) == 0;
-            }
-            const uint32_t len = n + (uint32_t)k - 1 + (has_r ? HINT_LEN : 0);  // bases from the first window on
-            // X0:X1 = the 64 bases from a - HINT_LEN on; the record's 120-bit base field is their top 60
-            const uint32_t q = off0 + j - HINT_LEN;  // 1 .. 32
+            const uint32_t len = n + (uint32_t)k - 1;  // bases of the run (<= 46)
+            // X0:X1 = the 64 bases from the run's first base on; the record keeps the first `len`
+            const uint32_t q = off0 + j;  // 8 .. 39
             const uint64_t X0 = p1w_bits(W0, W1, W2, q), X1 = p1w_bits(W1, W2, 0ull, q);
-            uint64_t hi = X0 >> 8, rl = (X0 << 56) | (X1 >> 8);
-            if (!has_l) hi &= (1ull << 42) - 1;
-            const uint32_t keep = 2 * (HINT_LEN + len);  // bits of the 120-bit base field in use
-            if (keep <= 56) { hi &= ~0ull << (56 - keep); rl = 0; }
-            else rl &= ~0ull << (120 - keep);
-            hi |= ((uint64_t)(n - 1) << 58) | ((uint64_t)has_l << 57) | ((uint64_t)has_r << 56);
+            uint64_t hi = X0 >> 4;                                                  // bases 0 .. 29
+            uint32_t tail = (uint32_t)(((X0 & 0xFull) << 28) | (X1 >> 36));         // bases 30 .. 45
+            if (len <= 30) { hi &= ~0ull << (60 - 2 * len); tail = 0; }
+            else tail &= len >= 46 ? ~0u : ~0u << (2 * (46 - len));
+            hi |= (uint64_t)(n - 1) << 60;
             uint32_t hsel = hmin[0];
 #pragma unroll
             for (int qq = 1; qq < PT_ITEMS; qq++) hsel = j == (uint32_t)qq ? hmin[qq] : hsel;
             const uint32_t bin = sk_bin(hsel);
             const uint32_t d = OWNERS ? sk_owner(hsel, np1) : mulhi32(bin, np1);
             uint4 rec;
-            rec.x = (uint32_t)rl; rec.y = (uint32_t)(rl >> 32); rec.z = (uint32_t)hi; rec.w = (uint32_t)(hi >> 32);
+            rec.x = bin; rec.y = tail; rec.z = (uint32_t)hi; rec.w = (uint32_t)(hi >> 32);
             const uint64_t dst = atomicAdd(&L.wcur[d], 1u);
             if (dst < cap) {
                 const uint64_t at = seg_base + (uint64_t)d * bucket_stride + dst;
                 out_recs[at] = rec;
-                out_bins[at] = bin;
+                out_ptrs[at] = ptr_base == ~0ull ? 0u : ptr_encode(ptr_base + p0 + j);
             } else {
                 sk_spill_push(sp, rec);
             }
@@ -1055,8 +809,8 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk1_records(const uint4 *__restr
         for (int j = 0; j < PT_ITEMS; j++) {
             const uint64_t i = tile * PT_TILE + tid + (uint64_t)j * PT_THREADS;
             if (i < n) {
-                const uint32_t bin = in_bins[i];
-                sk_emit(C, mulhi32(bin, np1), in_recs[i], bin, cap, (uint64_t)blockIdx.x * cap, (uint64_t)PT_SEGMENTS * cap, out_recs, out_bins, sp);
+                const uint4 rec = in_recs[i];  // (its bin word rides in rec.x; in_bins / out_bins carry the read pointers)
+                sk_emit(C, mulhi32(rec.x, np1), rec, in_bins[i], cap, (uint64_t)blockIdx.x * cap, (uint64_t)PT_SEGMENTS * cap, out_recs, out_bins, sp);
             }
         }
         __syncthreads();
@@ -1066,7 +820,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk1_records(const uint4 *__restr
     if (tid < n_buckets) seg_counts[(uint64_t)tid * PT_SEGMENTS + blockIdx.x] = min(C.wcur[tid], (uint32_t)cap);
 }
 
-// SK-P2: one workgroup per level-1 bucket; its PT_SEGMENTS segments are read as one stream and
+// SK-P2: one workgroup per level-1 bucket; its segments are read as one stream and
 // scattered by the next m2 bits of the bin word into the bucket's leaves.
 struct Sk2Lds {
     SkCursors C;
@@ -1077,8 +831,12 @@ struct Sk2Lds {
 __global__ void __launch_bounds__(PT_THREADS) k_sk2_scatter(const uint4 *__restrict__ in_recs, const uint32_t *__restrict__ in_bins,
                                                             uint64_t seg_cap1, const uint32_t *__restrict__ seg_counts1,
                                                             uint32_t n_buckets1, uint32_t np1, uint32_t m2, uint32_t *leaf_counts,
-                                                            uint64_t cap2, uint4 *out_recs, uint32_t *out_bins, SkSpill sp, uint32_t nseg_in = PT_SEGMENTS)
+                                                            uint64_t cap2, uint4 *out_recs, uint32_t *out_bins, SkSpill sp, uint32_t nseg_in = PT_SEGMENTS,
+                                                            int bin_of = 0)
 {
+    // bin_of == 0: super-k-mer records -- the bucket digits come from the bin word inside the record (rec.x) and the
+    // second stream (in_bins / out_bins) is the records' read pointers; != 0: other 16-byte payloads (the entries of the
+    // solid-table build) whose bin word IS the second stream.
     __shared__ Sk2Lds L;
     const uint32_t tid = threadIdx.x, n_buckets = m2;  // leaves per level-1 bucket
     constexpr uint32_t TILE2 = PT_THREADS * 4;
@@ -1130,7 +888,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk2_scatter(const uint4 *__restr
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 if (have[j])
-                    sk_emit(L.C, mulhi32(bin[j], np1 * m2) - bucket * m2, rec[j], bin[j], cap2, (uint64_t)bucket * n_buckets * cap2,
+                    sk_emit(L.C, mulhi32(bin_of ? bin[j] : rec[j].x, np1 * m2) - bucket * m2, rec[j], bin[j], cap2, (uint64_t)bucket * n_buckets * cap2,
                             cap2, out_recs, out_bins, sp);
             __syncthreads();
             if (tid < n_buckets) { L.C.wcur[tid] += L.C.cnt[tid]; L.C.cnt[tid] = 0; }
@@ -1141,20 +899,19 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk2_scatter(const uint4 *__restr
 }
 
 // drains the record spill list through the direct path (solid_thr / n_solid as in k_p3_merge)
-__global__ void k_sk_add_records(const uint4 *__restrict__ recs, uint64_t n, int k, TableView t, uint32_t solid_thr,
-                                 unsigned long long *n_solid)
-{
+__global__ void k_sk_add_records(const uint4 *__restrict__ recs, const uint32_t *__restrict__ ptrs, uint64_t n, int k, TableView t,
+                                 uint32_t solid_thr, unsigned long long *n_solid)
+{   // ptrs (may be null): the read pointer of each record's first window
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     unsigned long long n_new = 0, n_cross = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint4 rec = recs[i];
+        const uint32_t p0 = ptrs ? ptrs[i] : 0u;
         const uint64_t lo = ((uint64_t)rec.y << 32) | rec.x, hi = ((uint64_t)rec.w << 32) | rec.z;
         for (uint32_t j = 0; j < sk_windows(hi); j++) {
-            uint64_t key;
-            uint32_t hint;
-            sk_expand(lo, hi, j, k, &key, &hint);
+            const uint64_t key = sk_window_key(lo, hi, j, k);
             uint32_t before;
-            n_new += table_add(t, key, 1u, hint, &before);
+            n_new += table_add(t, key, 1u, ptr_advance(p0, j), &before);
             n_cross += crosses(before, 1u, solid_thr);
         }
     }
@@ -1164,7 +921,8 @@ __global__ void k_sk_add_records(const uint4 *__restrict__ recs, uint64_t n, int
 
 // the records of the leaves [leaf_lo, leaf_hi) that k_p3_merge left unmerged, through the direct path (after the
 // table has given up minimizer bins, mcgpu.hip to_hash_regions)
-__global__ void k_sk_add_unmerged(const uint4 *__restrict__ leaf_recs, const uint32_t *__restrict__ seg_counts, uint64_t seg_cap,
+__global__ void k_sk_add_unmerged(const uint4 *__restrict__ leaf_recs, const uint32_t *__restrict__ leaf_ptrs,
+                                  const uint32_t *__restrict__ seg_counts, uint64_t seg_cap,
                                   uint32_t nseg, uint32_t leaf_lo, uint32_t leaf_hi, const uint32_t *__restrict__ leaf_state, int k,
                                   TableView t)
 {
@@ -1174,15 +932,12 @@ __global__ void k_sk_add_unmerged(const uint4 *__restrict__ leaf_recs, const uin
         for (uint32_t sgm = 0; sgm < nseg; sgm++) {
             const uint64_t n = min((uint64_t)seg_counts[(uint64_t)leaf * nseg + sgm], seg_cap);
             const uint4 *recs = leaf_recs + ((uint64_t)leaf * nseg + sgm) * seg_cap;
+            const uint32_t *ptrs = leaf_ptrs + ((uint64_t)leaf * nseg + sgm) * seg_cap;
             for (uint64_t r = threadIdx.x; r < n; r += blockDim.x) {
                 const uint4 rec = recs[r];
+                const uint32_t p0 = ptrs[r];
                 const uint64_t lo = ((uint64_t)rec.y << 32) | rec.x, hi = ((uint64_t)rec.w << 32) | rec.z;
-                for (uint32_t j = 0; j < sk_windows(hi); j++) {
-                    uint64_t key;
-                    uint32_t hint;
-                    sk_expand(lo, hi, j, k, &key, &hint);
-                    n_new += table_add(t, key, 1u, hint);
-                }
+                for (uint32_t j = 0; j < sk_windows(hi); j++) n_new += table_add(t, sk_window_key(lo, hi, j, k), 1u, ptr_advance(p0, j));
             }
         }
     }
@@ -1193,16 +948,22 @@ __global__ void k_sk_add_unmerged(const uint4 *__restrict__ leaf_recs, const uin
 // has more regions than leaves).  `virgin`: the table holds nothing yet and is not read.
 // leaf_state[leaf]: 0 = to do, 1 = merged.  A leaf with a region that would overflow is left
 // untouched and stays at 0 for the retry after the host enlarged the table.
-// In LDS the top bit of a slot's count says "context confirmed on both sides" (hint_confirm): the atomic add that counts an occurrence
-// then also tells whether the hint word needs a look at all (one LDS round trip less for most occurrences).  Counts
-// are held to 2^30 when a region comes in and goes out; a launch adds < 2^30, so bit 31 is never reached by counting.
-constexpr uint32_t P3_CTX_DONE = 1u << 31, P3_COUNT_CAP = 1u << 30;
+// Counts are held to 2^30 when a region comes in and goes out; a launch adds < 2^30, so a counter never wraps.
+// The read pointer of a slot (kmer_device.h) is written by ONE occurrence: the atomic add that counts an occurrence
+// returns how many came before it, and the occurrence that finds ptr_from + r before it stores its own position --
+// ptr_from = 0, or 1 when the coverage threshold is known to be above 1 (sequencing errors, most distinct k-mers, are
+// seen once and never reach the BFS); r = a few bits of the key, below the threshold: the occurrences of neighbouring
+// k-mers arrive in the same order (read by read), and if all took, say, their second one, the pointers along a stretch
+// of the graph would all lead into the same read, which is no help once the walk has used that read up (ptr_pick).
+// ptr_tries > 1 (records of other ranks carry no pointer): the next occurrences try too while the slot has none.
+constexpr uint32_t P3_COUNT_CAP = 1u << 30;
 
 struct MergeLds {
     uint64_t key[REGION_SLOTS];
     uint32_t cnt[REGION_SLOTS];
     uint32_t aux[REGION_SLOTS];
     uint8_t dq[P3_THREADS / 64][64 * SK_MAX_WINDOWS];  // per wave: window -> lane holding its record (k_p3_merge<true>)
+    uint32_t sq[P3_THREADS / 64][64];                  // per wave: lane -> read pointer of its record's first window
     uint32_t n_new, overflow;
     uint32_t emit_cur;  // fill level of this workgroup's segment of the solid list (P3Emit)
 };
@@ -1220,7 +981,7 @@ struct P3Emit {
 
 
 // one occurrence of `key` into the region held in LDS; false when the region is full
-__device__ __forceinline__ bool lds_region_add(MergeLds &L, uint64_t key, uint32_t hint, uint32_t home, uint32_t &my_new)
+__device__ __forceinline__ bool lds_region_add(MergeLds &L, uint64_t key, uint32_t hint, uint32_t home, uint32_t &my_new, uint32_t pick)
 {
     uint32_t s = home;
     for (uint32_t probe = 0; probe < REGION_SLOTS; probe++) {
@@ -1231,11 +992,8 @@ __device__ __forceinline__ bool lds_region_add(MergeLds &L, uint64_t key, uint32
             if (cur == EMPTY_KEY) { my_new++; cur = key; }
         }
         if (cur == key) {
-            atomicAdd(&L.cnt[s], 1u);
-            if (hint) {
-                const uint32_t have = L.aux[s], m = hint_confirm(have, hint);
-                if (m != have) L.aux[s] = m;  // racy on purpose: a lost update only delays the confirmation
-            }
+            const uint32_t seen = atomicAdd(&L.cnt[s], 1u);
+            if (hint && (seen == pick || L.aux[s] == 0)) L.aux[s] = hint;  // (racy on purpose: any occurrence's pointer will do)
             return true;
         }
         s = (s + 1) & (REGION_SLOTS - 1);
@@ -1252,7 +1010,8 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                                                          const uint32_t *__restrict__ seg_counts, uint64_t seg_cap,
                                                          uint32_t nseg, uint32_t n_leaves, uint32_t g, TableView t, int virgin,
                                                          uint32_t *leaf_state, uint32_t *leaf_new, uint32_t *any_failed,
-                                                         uint32_t solid_thr, unsigned long long *n_solid, int k, P3Emit emit)
+                                                         uint32_t solid_thr, unsigned long long *n_solid, int k, P3Emit emit,
+                                                         uint32_t ptr_tries)
 {
     __shared__ MergeLds L;
     const uint32_t tid = threadIdx.x;
@@ -1275,7 +1034,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
             const uint32_t per = (n0 + N_WAVES - 1) / N_WAVES, r = wv * per + lane, end = (wv + 1) * per < n0 ? (wv + 1) * per : n0;
             if (r < end) {
                 pre_nxt = static_cast<const uint4 *>(leaf_keys)[(uint64_t)lf * nseg * seg_cap + r];
-                if (g) pre_bin_nxt = leaf_hints[(uint64_t)lf * nseg * seg_cap + r];
+                pre_bin_nxt = leaf_hints[(uint64_t)lf * nseg * seg_cap + r];  // (the record's read pointer)
             }
         }
     };
@@ -1319,7 +1078,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                     } else {
                         const uint4 raw = *reinterpret_cast<const uint4 *>(gs + i);
                         L.key[i] = ((uint64_t)raw.y << 32) | raw.x;
-                        L.cnt[i] = min(raw.z, P3_COUNT_CAP) | ((raw.w & (HINT_RC | HINT_LC)) == (HINT_RC | HINT_LC) ? P3_CTX_DONE : 0u);
+                        L.cnt[i] = min(raw.z, P3_COUNT_CAP);
                         L.aux[i] = raw.w;
                         solid_before += solid_thr && raw.z >= solid_thr;  // (empty slots hold count 0)
                     }
@@ -1337,23 +1096,24 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                     // by ds_bpermute, and is cut out of the record directly (no rolling state).  The next batch's
                     // records are in flight meanwhile.
                     const uint4 *recs = static_cast<const uint4 *>(leaf_keys) + ((uint64_t)leaf * nseg + sgm) * seg_cap;
-                    const uint32_t *bins = leaf_hints + ((uint64_t)leaf * nseg + sgm) * seg_cap;
-                    const uint32_t hint_from = solid_thr >= 2 ? 1u : 0u;
+                    const uint32_t *ptrs = leaf_hints + ((uint64_t)leaf * nseg + sgm) * seg_cap;
+                    const uint32_t ptr_from = solid_thr >= 2 ? 1u : 0u, ptr_last = ptr_from + 3 + ptr_tries - 1;
                     uint8_t *dq = L.dq[wv];
+                    uint32_t *sq = L.sq[wv];
                     // the waves share the segment's records evenly (in batches of 64): the barrier behind the merge
                     // waits for the slowest wave
                     const uint32_t per = (n + N_WAVES - 1) / N_WAVES, r_lo = wv * per, r_hi = r_lo + per < n ? r_lo + per : n;
                     uint4 nxt = sgm == 0 ? pre : (r_lo + lane < r_hi ? recs[r_lo + lane] : make_uint4(0, 0, 0, 0));
-                    uint32_t nxt_bin = sgm == 0 ? pre_bin : ((g && r_lo + lane < r_hi) ? bins[r_lo + lane] : 0u);
+                    uint32_t nxt_ptr = sgm == 0 ? pre_bin : (r_lo + lane < r_hi ? ptrs[r_lo + lane] : 0u);
                     for (uint32_t b0 = r_lo; b0 < r_hi; b0 += 64) {  // wave-uniform
                         const uint32_t r = b0 + lane;
                         const uint4 rec = nxt;
-                        const uint32_t bin = nxt_bin;
+                        const uint32_t rptr = nxt_ptr;
                         if (r + 64 < r_hi) {
                             nxt = recs[r + 64];
-                            if (g) nxt_bin = bins[r + 64];
+                            nxt_ptr = ptrs[r + 64];
                         }
-                        const bool mine = r < r_hi && !(g && mulhi32(bin, t.n_regions) != region);
+                        const bool mine = r < r_hi && !(g && mulhi32(rec.x, t.n_regions) != region);
                         const uint32_t nw = mine ? sk_windows(((uint64_t)rec.w << 32) | rec.z) : 0u;
                         uint32_t incl = nw;  // inclusive scan of the window counts
 #pragma unroll
@@ -1363,28 +1123,29 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                         }
                         const uint32_t excl = incl - nw, total = __shfl(incl, 63);
                         for (uint32_t i = 0; i < nw; i++) dq[excl + i] = (uint8_t)lane;
+                        sq[lane] = rptr;
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         // the record words of chunk c + 1 are on their way while chunk c probes the region
                         uint32_t src_n = lane < total ? dq[lane] : lane;
-                        uint32_t nx = __shfl(rec.x, src_n), ny = __shfl(rec.y, src_n), nz = __shfl(rec.z, src_n), nw4 = __shfl(rec.w, src_n);
+                        uint32_t ny = __shfl(rec.y, src_n), nz = __shfl(rec.z, src_n), nw4 = __shfl(rec.w, src_n);
                         uint32_t ne = __shfl(excl, src_n);
                         for (uint32_t base = 0; base < total; base += 64) {
                             const uint32_t w = base + lane;
                             const bool act = w < total;
-                            const uint32_t rx = nx, ry = ny, rz = nz, rw = nw4;
+                            const uint32_t ry = ny, rz = nz, rw = nw4, src_c = src_n;
                             const uint32_t j = w - ne;
                             if (base + 64 < total) {
                                 src_n = w + 64 < total ? dq[w + 64] : lane;
-                                nx = __shfl(rec.x, src_n); ny = __shfl(rec.y, src_n); nz = __shfl(rec.z, src_n); nw4 = __shfl(rec.w, src_n);
+                                ny = __shfl(rec.y, src_n); nz = __shfl(rec.z, src_n); nw4 = __shfl(rec.w, src_n);
                                 ne = __shfl(excl, src_n);
                             }
                             if (!act) continue;
-                            const uint64_t lo = ((uint64_t)ry << 32) | rx, hi = ((uint64_t)rw << 32) | rz;
-                            // G = core + right context, top-aligned (the record's base field is 120 bits, 7 context bases first)
-                            const uint64_t g_hi = (hi << (8 + 2 * HINT_LEN)) | (lo >> (56 - 2 * HINT_LEN)), g_lo = lo << (8 + 2 * HINT_LEN);
+                            // T = the record's 46 bases top-aligned in 128 bits (sk_window_key, with the bin word never moved)
+                            const uint64_t hi = ((uint64_t)rw << 32) | rz;
+                            const uint64_t t_hi = (hi << 4) | (ry >> 28), t_lo = (uint64_t)ry << 36;
                             const uint32_t sh = 2 * j;  // (j <= 15)
-                            const uint64_t fw = ((g_hi << sh) | ((g_lo >> 1) >> (63 - sh))) >> (64 - 2 * k), rc = rc_packed(fw, k);
+                            const uint64_t fw = ((t_hi << sh) | ((t_lo >> 1) >> (63 - sh))) >> (64 - 2 * k), rc = rc_packed(fw, k);
                             const uint64_t key = rc < fw ? rc : fw;
                             uint32_t s = sk_home(key);
                             bool done = false;
@@ -1399,25 +1160,13 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                                 s = (s + 1) & (REGION_SLOTS - 1);
                             }
                             if (done) {
-                                // context is only collected from the second occurrence on when the coverage threshold is
-                                // known to be above 1: sequencing errors (most distinct k-mers, seen once) never reach the BFS
                                 const uint32_t seen = atomicAdd(&L.cnt[s], 1u);
-                                if (seen >= hint_from && seen < P3_CTX_DONE) {  // counted before, and the slot still lacks context
-                                    uint64_t key2;
-                                    uint32_t hint;
-                                    sk_expand(lo, hi, j, k, &key2, &hint);
-                                    // Several occurrences of a key often sit in one chunk (a region holds ~30 copies of
-                                    // each of its super-k-mers): a side once known is never replaced, so the flag below
-                                    // is only raised over a hint word that really has both.
-                                    uint32_t have = L.aux[s], m;
-                                    for (;;) {
-                                        m = hint_confirm(have, hint);
-                                        if (m == have) break;
-                                        const uint32_t old = atomicCAS(&L.aux[s], have, m);
-                                        if (old == have) break;
-                                        have = old;
+                                if (seen >= ptr_from && seen <= ptr_last) {
+                                    const uint32_t first = ptr_pick(key, ptr_from, solid_thr);
+                                    if (seen >= first && seen < first + ptr_tries) {
+                                        const uint32_t p0 = sq[src_c];
+                                        if (p0 && (seen == first || L.aux[s] == 0)) L.aux[s] = ptr_advance(p0, j);
                                     }
-                                    if ((m & (HINT_RC | HINT_LC)) == (HINT_RC | HINT_LC)) atomicOr(&L.cnt[s], P3_CTX_DONE);
                                 }
                             } else {
                                 atomicExch(&L.overflow, 1u);
@@ -1443,7 +1192,8 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                         if (key == EMPTY_KEY) continue;
                         const uint64_t gslot = slot_of(t, key);
                         if (g && (gslot >> 12) != region) continue;
-                        const bool done = lds_region_add(L, key, hh[u], (uint32_t)gslot & (REGION_SLOTS - 1), my_new);
+                        const bool done = lds_region_add(L, key, hh[u], (uint32_t)gslot & (REGION_SLOTS - 1), my_new,
+                                                         ptr_pick(key, solid_thr >= 2 ? 1u : 0u, solid_thr));
                         if (!done) atomicExch(&L.overflow, 1u);
                     }
                 }
@@ -1462,7 +1212,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                         uint4 v;
                         const uint64_t kk = L.key[i];
                         v.x = (uint32_t)kk; v.y = (uint32_t)(kk >> 32);
-                        v.z = min(L.cnt[i] & ~P3_CTX_DONE, P3_COUNT_CAP);  // counters stop at 2^30 here (anything above 32767 reads the same)
+                        v.z = min(L.cnt[i], P3_COUNT_CAP);  // counters stop at 2^30 here (anything above 32767 reads the same)
                         v.w = L.aux[i];
                         *reinterpret_cast<uint4 *>(gs + i) = v;
                         const bool solid = solid_thr && v.z >= solid_thr;

@@ -159,83 +159,85 @@ __host__ __device__ __forceinline__ Kmer neighbour(const Kmer &v, int k, int dir
 }
 
 // ---------------------------------------------------------------------------------------------
-// Speculation hints (Slot::aux).  While counting, a window also knows the bases around it in its
-// read; one occurrence's context is kept next to the key: the HINT_LEN bases that follow the key's
-// own strand (R) and the HINT_LEN bases that precede it (L), nearest base first, 2 bits each.
-// The BFS uses them only to GUESS the next vertices of a linear stretch and looks every guess up,
-// so a missing or wrong hint can cost time but never change a result.  The context is the one of
-// the occurrence that inserted the key (it rides on that thread's count update, no extra traffic).
-constexpr int HINT_LEN = 7;
-constexpr uint32_t HINT_RV = 1u << 14, HINT_LV = 1u << 30;  // R bits 0..13 + valid, L bits 16..29 + valid
-constexpr uint32_t HINT_RMASK = 0x00007FFFu, HINT_LMASK = 0x7FFF0000u;
-
-// The merge kernel of the super-k-mer pipeline is pickier (hint_confirm): with sequencing errors in 1 % of the bases
-// every 14th 7-base context is wrong, and a wrong hint costs the walk a truncated round plus a one-level replay.  A
-// side's context counts as known once two occurrences in a row agree on it (bits 15 / 31); until then a differing
-// occurrence replaces the candidate.  Other writers leave the two bits clear: their contexts stay candidates.
-constexpr uint32_t HINT_RC = 1u << 15, HINT_LC = 1u << 31;
-__host__ __device__ __forceinline__ uint32_t hint_confirm(uint32_t have, uint32_t mine)
+// Read pointers (Slot::aux).  The context keeps the packed bases of every read it was given (the "read store",
+// mcgpu.hip) and a slot remembers WHERE one occurrence of its key sits in it.  The BFS uses that only to GUESS the
+// next vertices of a linear stretch -- the bases that follow the occurrence in its read are the path a walker will
+// most likely take -- and looks every guess up, so a missing, stale or wrong pointer can cost time but never change a
+// result.  32 bits: 0 = none; v = aux - 1 < 2^31: the occurrence starts at base v of the store, exactly; otherwise
+// somewhere in the PTR_COARSE + PTR_SLACK bases from 2^31 + ((v - 2^31) << 6) on (the reader matches the k-mer against
+// every offset of that range).  Exact for the first 2.1 G bases (14 M reads of 150), 6-bit granules up to 139 G.
+constexpr uint64_t PTR_EXACT_END = 1ull << 31;
+constexpr uint32_t PTR_COARSE_LG = 6, PTR_COARSE = 1u << PTR_COARSE_LG, PTR_SLACK = 16;
+__host__ __device__ __forceinline__ uint32_t ptr_encode(uint64_t pos)
 {
-    uint32_t r = have;
-    if (mine & HINT_RV) {
-        if (!(have & HINT_RV)) r |= mine & HINT_RMASK;
-        else if (!(have & HINT_RC)) r = ((have ^ mine) & 0x3FFFu) ? ((r & ~0x3FFFu) | (mine & 0x3FFFu)) : (r | HINT_RC);
+    if (pos < PTR_EXACT_END) return (uint32_t)pos + 1u;
+    const uint64_t v = PTR_EXACT_END + ((pos - PTR_EXACT_END) >> PTR_COARSE_LG);
+    return v < 0xFFFFFFFEull ? (uint32_t)v + 1u : 0u;
+}
+// first base of the range the occurrence starts in; *span = number of candidate offsets
+__host__ __device__ __forceinline__ uint64_t ptr_decode(uint32_t aux, uint32_t *span)
+{
+    const uint64_t v = (uint64_t)aux - 1;
+    if (v < PTR_EXACT_END) { *span = 1; return v; }
+    *span = PTR_COARSE + PTR_SLACK;
+    return PTR_EXACT_END + ((v - PTR_EXACT_END) << PTR_COARSE_LG);
+}
+// pointer of the window j bases after the window a pointer names (windows of one super-k-mer record)
+__host__ __device__ __forceinline__ uint32_t ptr_advance(uint32_t aux, uint32_t j)
+{
+    if (aux == 0) return 0;
+    return ((uint64_t)aux - 1 < PTR_EXACT_END - 64) ? aux + j : aux;  // (coarse granules: the reader's range has PTR_SLACK to spare)
+}
+
+// Which occurrence of a key (counted from 0 in the order the counting kernels meet them) leaves its pointer:
+// ptr_from + r with r = a few bits of the key, r < min(4, thr - ptr_from) so that every key that reaches the coverage
+// threshold thr has one.  The occurrences of neighbouring k-mers arrive in the same order (read by read): if all took
+// the same one, the pointers along a stretch of the graph would all lead into one read.
+__host__ __device__ __forceinline__ uint32_t ptr_pick(uint64_t key, uint32_t ptr_from, uint32_t solid_thr)
+{   // which occurrence (counted from 0) leaves its pointer: ptr_from + r, r < min(4, thr - ptr_from) so that every key that reaches the threshold has one
+    const uint32_t room = solid_thr > ptr_from ? solid_thr - ptr_from : 1u;
+    const uint32_t r = (uint32_t)(key ^ (key >> 9) ^ (key >> 23)) & 3u;
+    return ptr_from + (room >= 4 ? r : r % room);
+}
+
+// reverse complement of an oriented k-mer of up to 64 bases (two words, right-aligned)
+__host__ __device__ __forceinline__ uint64_t rc64_pairs(uint64_t x)
+{  // reverses the 32 2-bit groups of a word and complements them
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t r = __brevll(x);
+#else
+    uint64_t r = x;
+    r = ((r & 0x5555555555555555ull) << 1) | ((r >> 1) & 0x5555555555555555ull);
+    r = ((r & 0x3333333333333333ull) << 2) | ((r >> 2) & 0x3333333333333333ull);
+    r = ((r & 0x0f0f0f0f0f0f0f0full) << 4) | ((r >> 4) & 0x0f0f0f0f0f0f0f0full);
+    r = ((r & 0x00ff00ff00ff00ffull) << 8) | ((r >> 8) & 0x00ff00ff00ff00ffull);
+    r = ((r & 0x0000ffff0000ffffull) << 16) | ((r >> 16) & 0x0000ffff0000ffffull);
+    r = (r << 32) | (r >> 32);
+#endif
+    r = ((r & 0x5555555555555555ull) << 1) | ((r >> 1) & 0x5555555555555555ull);
+    return ~r;
+}
+__host__ __device__ __forceinline__ Kmer rc_kmer(const Kmer &v, int k)
+{
+    Kmer r;
+    if (k <= 32) {
+        r.hi = 0;
+        r.lo = rc64_pairs(v.lo) >> (64 - 2 * k);
+        return r;
     }
-    if (mine & HINT_LV) {
-        if (!(have & HINT_LV)) r |= mine & HINT_LMASK;
-        else if (!(have & HINT_LC)) r = ((have ^ mine) & 0x3FFF0000u) ? ((r & ~0x3FFF0000u) | (mine & 0x3FFF0000u)) : (r | HINT_LC);
-    }
+    // 128-bit value hi:lo reversed pairwise = rc(lo):rc(hi); right-align by 128 - 2k (0 .. 62)
+    const uint64_t a = rc64_pairs(v.lo), b = rc64_pairs(v.hi);
+    const int s = 128 - 2 * k;
+    if (s == 0) { r.hi = a; r.lo = b; }
+    else { r.hi = a >> s; r.lo = (b >> s) | (a << (64 - s)); }
     return r;
-}
-
-__host__ __device__ __forceinline__ uint32_t hint_merge(uint32_t have, uint32_t mine)
-{
-    uint32_t r = have;
-    if (!(have & HINT_RV) && (mine & HINT_RV)) r |= mine & HINT_RMASK;
-    if (!(have & HINT_LV) && (mine & HINT_LV)) r |= mine & HINT_LMASK;
-    return r;
-}
-
-// n <= 32 bases starting at base p, right-aligned, first base most significant
-__device__ __forceinline__ uint64_t extract_bases(const uint64_t *__restrict__ words, uint64_t p, int n)
-{
-    const uint64_t wi = p >> 5;
-    const int off = 2 * (int)(p & 31);
-    const uint64_t w0 = words[wi], w1 = words[wi + 1];
-    const uint64_t a = off ? ((w0 << off) | (w1 >> (64 - off))) : w0;
-    return a >> (64 - 2 * n);
-}
-
-// hint of the window at base q of the read [rb, re), for the strand that supplied the key
-__device__ __forceinline__ uint32_t hint_of(const uint64_t *__restrict__ words, uint64_t q, int k, uint64_t rb,
-                                            uint64_t re, bool flipped)
-{
-    uint32_t fr = 0, fl = 0;  // contexts of the forward window, nearest base in bits 1..0
-    bool rv = false, lv = false;
-    if (q + (uint64_t)k + HINT_LEN <= re) {
-        uint32_t x = (uint32_t)extract_bases(words, q + (uint64_t)k, HINT_LEN);  // first following base on top
-        x = __brev(x) >> (32 - 2 * HINT_LEN);                                      // reverse the bit order ...
-        fr = ((x & 0x1555u) << 1) | ((x >> 1) & 0x1555u);                          // ... and restore the pairs
-        rv = true;
-    }
-    if (q >= rb + HINT_LEN) {
-        fl = (uint32_t)extract_bases(words, q - HINT_LEN, HINT_LEN);  // nearest preceding base already lowest
-        lv = true;
-    }
-    uint32_t R = fr, L = fl;
-    bool RV = rv, LV = lv;
-    if (flipped) {  // the key's strand runs the other way: what followed now precedes, complemented
-        R = fl ^ 0x3FFFu; RV = lv;
-        L = fr ^ 0x3FFFu; LV = rv;
-    }
-    return (RV ? (R | HINT_RV) : 0u) | (LV ? ((L << 16) | HINT_LV) : 0u);
 }
 
 // ---------------------------------------------------------------------------------------------
 // The k-mer table in HBM (layout free: SURVEY.md F7).  2^rb regions of RS = 2^sb slots; a key
 // lives in region = top rb bits of fmix64(key), starting at offset = next sb bits, linear
 // probing that wraps inside the region.  A slot is 16 bytes {u64 key; u32 count; u32 aux} so one
-// dwordx4 load returns key and count together and a region is one contiguous run of lines.
+// dwordx4 load returns key, count and read pointer together and a region is one contiguous run of lines.
 struct Slot {
     uint64_t key;
     uint32_t count;
@@ -336,8 +338,8 @@ __host__ __device__ __forceinline__ uint64_t slot_of(const TableView &t, uint64_
 // wave (one hot counter address hammered by every insert costs more than the inserts themselves).
 // *before (optional): the key's count before this addition (0 for a new key).
 __device__ __forceinline__ uint32_t table_add(const TableView &t, uint64_t key, uint32_t inc, uint32_t hint = 0,
-                                              uint32_t *before = nullptr)
-{
+                                              uint32_t *before = nullptr, uint32_t pick = 0)
+{   // pick != 0: the occurrence that finds `pick` before it replaces the inserter's read pointer with its own (ptr_pick)
     if (before) *before = 0;
     if (key == EMPTY_KEY) {
         const unsigned long long old = atomicAdd(t.empty_cnt, (unsigned long long)inc);
@@ -365,12 +367,14 @@ __device__ __forceinline__ uint32_t table_add(const TableView &t, uint64_t key, 
             if (cur == key) {
                 const uint32_t old = atomicAdd(&p->count, inc);
                 if (before) *before = old;
+                if (pick && hint && old == pick) p->aux = hint;
                 return 0;
             }
         } else if (cur == key) {
             if (raw.z < 0x80000000u) {
                 const uint32_t old = atomicAdd(&p->count, inc);
                 if (before) *before = old;
+                if (pick && hint && old == pick) p->aux = hint;
             } else if (before) {
                 *before = raw.z;
             }
@@ -397,58 +401,25 @@ __device__ __forceinline__ uint32_t crosses(uint32_t before, uint32_t inc, uint3
 
 // ---------------------------------------------------------------------------------------------
 // The "solid" table: the BFS's private copy of the keys with count >= --coverage, at a load factor
-// <= 1/4 so that its (mostly negative) lookups end at the first probe, with 32-byte slots that also
-// carry LONG speculation hints: up to LHINT_MAX bases of read context on either side.  They start
-// as the 7-base hints of the counting table and are doubled twice (7 -> 14 -> 28) by chaining:
-// the hint of x names the vertex y reached after following it, and y's own hint continues it.
-constexpr int LHINT_MAX = 28;
-constexpr uint64_t LH_BASES = (1ull << 56) - 1;
-
-struct SolidSlot {
-    uint64_t key;
-    uint32_t count;
-    uint32_t pad;
-    uint64_t hr, hl;  // bits 0..55: bases, nearest first, 2 bits each; bits 56..61: how many
-};
-
+// <= 1/4 so that its (mostly negative) lookups end at the first probe.  Same 16-byte slots as the counting table
+// {key, count (already saturated), read pointer}, regions of SOLID_REGION slots, always indexed by the key's own
+// hash (a BFS lookup must not pay for a minimizer).  The view also carries the read store the pointers refer to.
 struct SolidView {
-    SolidSlot *slots;
+    Slot *slots;
     uint32_t shift;  // 64 - log2(#slots)
     uint32_t rmask;  // region size - 1 (probing wraps inside a region, as in the counting table)
     unsigned long long *empty_cnt;
     uint32_t *fatal;
+    const uint64_t *reads;  // packed bases of the read store (nullptr: none), one readable pad word behind them
+    uint64_t reads_bases;
 };
 
-__host__ __device__ __forceinline__ uint32_t lh_len(uint64_t w) { return (uint32_t)(w >> 56) & 63u; }
-__host__ __device__ __forceinline__ uint64_t lh_mask(uint32_t n) { return n >= 32 ? ~0ull : ((1ull << (2 * n)) - 1); }
-__host__ __device__ __forceinline__ uint64_t lh_make(uint64_t bases, uint32_t n)
-{
-    if (n > (uint32_t)LHINT_MAX) n = LHINT_MAX;
-    return (bases & lh_mask(n)) | ((uint64_t)n << 56);
-}
-__host__ __device__ __forceinline__ uint64_t lh_complement(uint64_t w)
-{
-    const uint32_t n = lh_len(w);
-    return ((w ^ lh_mask(n)) & LH_BASES & lh_mask(n)) | ((uint64_t)n << 56);
-}
-// the first n bases of a nearest-first field as one block with base 0 most significant
-__device__ __forceinline__ uint64_t lh_block_forward(uint64_t w, uint32_t n)
-{
-    if (n == 0) return 0;
-    uint64_t x = __brevll(w & lh_mask(n));
-    x = ((x & 0x5555555555555555ull) << 1) | ((x >> 1) & 0x5555555555555555ull);
-    return x >> (64 - 2 * n);
-}
-
-// (always the key's own hash, also when the counting table is organised by minimizer bins: the BFS
-// must not pay for a minimizer per lookup)
 __device__ __forceinline__ uint64_t solid_slot_of(const SolidView &t, uint64_t key) { return fmix64(key) >> t.shift; }
 
-// count (saturated) or -1; hr/hl may be null
-__device__ __forceinline__ int solid_get(const SolidView &t, uint64_t key, uint64_t *hr = nullptr, uint64_t *hl = nullptr)
+// count (saturated) or -1; *aux (may be null) = the slot's read pointer
+__device__ __forceinline__ int solid_get(const SolidView &t, uint64_t key, uint32_t *aux = nullptr)
 {
-    if (hr) *hr = 0;
-    if (hl) *hl = 0;
+    if (aux) *aux = 0;
     if (key == EMPTY_KEY) {
         const unsigned long long c = *t.empty_cnt;
         return c == 0 ? -1 : (c > 32767ull ? 32767 : (int)c);
@@ -459,8 +430,7 @@ __device__ __forceinline__ int solid_get(const SolidView &t, uint64_t key, uint6
         const uint4 raw = *reinterpret_cast<const uint4 *>(t.slots + s);
         const uint64_t cur = ((uint64_t)raw.y << 32) | raw.x;
         if (cur == key) {
-            if (hr) *hr = t.slots[s].hr;
-            if (hl) *hl = t.slots[s].hl;
+            if (aux) *aux = raw.w;
             return raw.z > 32767u ? 32767 : (int)raw.z;
         }
         if (cur == EMPTY_KEY) return -1;

@@ -47,6 +47,7 @@ struct BfsJobBuffers {
     {
         free_arrays();
         (void)hipFree(S.ctl);
+        (void)hipFree(S.path);
         (void)hipFree(d_seed_hi);
         (void)hipFree(d_seed_lo);
     }
@@ -59,14 +60,17 @@ struct mc_ctx {
     std::mutex mu;
     std::string err;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_side = nullptr, ev_walk = nullptr;
-    // While the hint sweep runs next to a walk of few jobs, the walk has WALK_CUS CUs of its own and the sweep the others:
-    // two CU-masked streams, created (~10 ms each) once a BFS is in sight: by mc_set_coverage_hint, or by the first BFS
-    // for the next one; without them the sweep uses side_stream and shares CUs.
-    hipStream_t walk_stream = nullptr, sweep_stream = nullptr;
-    std::atomic<bool> mask_started{false}, mask_ready{false};
-    hipStream_t side_stream = nullptr;  // the hint-doubling sweep runs here, next to the walk (mc_bfs_batch)
-    bool double_deferred = false;       // the solid table is built but its hints are not doubled yet
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // The read store: the packed bases of every read this context was given since the last mc_clear, batch after
+    // batch (each starting on a word boundary).  Table slots point into it (kmer_device.h ptr_encode) and the BFS
+    // reads its look-ahead from it.  rs_from: a BFS-only context (mc_solid_from_pairs_dev) borrows the store of the
+    // context that counted this rank's reads (mc_share_read_store).
+    uint64_t *rs_words = nullptr;
+    uint64_t rs_cap_words = 0, rs_bases = 0;
+    bool rs_enabled = true;
+    mc_ctx *rs_from = nullptr;
+    uint64_t cur_ptr_base = ~0ull;  // store position of base 0 of the batch being counted (~0: no pointers for it)
+    uint32_t ptr_tries = 1;         // count_pipeline.h k_p3_merge: 16 while the records of other ranks (no pointers) are merged
     // The solid list P3 left in pipe.a_recs (count_pipeline.h P3Emit): valid for threshold cov_hint until anything
     // else touches the table or the pipeline buffers.
     bool solid_list_fresh = false;
@@ -82,9 +86,9 @@ struct mc_ctx {
     uint64_t n_used_host = 0;
     bool finalized = false;
 
-    // "solid" table (kmer_device.h): only the keys with count >= solid_cov, sparse, with long hints.
+    // "solid" table (kmer_device.h): only the keys with count >= solid_cov, sparse.
     // Built lazily by mc_bfs_batch; the BFS never touches the counting table.
-    SolidSlot *solid = nullptr;
+    Slot *solid = nullptr;
     uint32_t solid_lg = 0;
     int solid_cov = -1;  // -1: not built / stale
     bool solid_external = false;  // built by mc_solid_from_pairs_dev, not from this context's counting table
@@ -138,6 +142,9 @@ struct mc_ctx {
         t.rmask = (1u << 11) - 1;  // SOLID_REGION - 1
         t.empty_cnt = d_ctr + 1;
         t.fatal = d_fatal;
+        const mc_ctx *rs = rs_from ? rs_from : this;
+        t.reads = rs->rs_bases ? rs->rs_words : nullptr;
+        t.reads_bases = rs->rs_bases;
         return t;
     }
     TableView view() const
@@ -206,7 +213,7 @@ __global__ void k_fill_empty(Slot *slots, uint64_t n)
 template <int MODE>
 __global__ void __launch_bounds__(256) k_count_reads(const uint64_t *__restrict__ words,
                                                      const uint64_t *__restrict__ offsets, uint64_t r_begin,
-                                                     uint64_t r_end, int k, TableView t)
+                                                     uint64_t r_end, int k, TableView t, uint64_t ptr_base, uint32_t thr)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -218,9 +225,9 @@ __global__ void __launch_bounds__(256) k_count_reads(const uint64_t *__restrict_
         const uint64_t nwin = e - b - (uint64_t)k + 1;
         for (uint64_t w = lane; w < nwin; w += 64) {
             const Kmer v = extract_kmer(words, b + w, k);
-            bool flipped;
-            const uint64_t key = (uint64_t)key_of<MODE>(v, k, &flipped);
-            n_new += table_add(t, key, 1u, hint_of(words, b + w, k, b, e, flipped));
+            const uint64_t key = (uint64_t)key_of<MODE>(v, k);
+            // (the inserter leaves its place in the read store; the occurrence ptr_pick names replaces it)
+            n_new += table_add(t, key, 1u, ptr_base == ~0ull ? 0u : ptr_encode(ptr_base + b + w), nullptr, ptr_pick(key, thr >= 2 ? 1u : 0u, thr));
         }
     }
     wave_add_ull(t.n_used, n_new);
@@ -271,7 +278,7 @@ __global__ void k_rehash(const Slot *__restrict__ old_slots, uint64_t n_old, Tab
     wave_add_ull(t.n_used, n_new);
 }
 
-// K6, region-wise: one workgroup assembles one region of the solid table (SOLID_REGION slots, 64 KB)
+// K6, region-wise: one workgroup assembles one region of the solid table (SOLID_REGION slots, 32 KB)
 // in LDS from the counting-table region(s) that hash to it and writes it out with plain coalesced
 // stores: no fill pass, no atomics.  Both tables index by the top bits of the same hash, so the
 // counting regions of a solid region are consecutive (or it is a slice of one counting region).
@@ -281,7 +288,7 @@ constexpr uint32_t SOLID_SB = 11, SOLID_REGION = 1u << SOLID_SB;
 __global__ void __launch_bounds__(512) k_build_solid_regions(const Slot *__restrict__ slots, uint32_t main_lg,
                                                              int min_cov, SolidView solid, uint32_t solid_lg)
 {
-    __shared__ SolidSlot R[SOLID_REGION];
+    __shared__ Slot R[SOLID_REGION];
     __shared__ uint32_t overflow;
     const uint32_t tid = threadIdx.x;
     const uint32_t q = solid_lg - SOLID_SB;  // log2(#solid regions)
@@ -289,7 +296,7 @@ __global__ void __launch_bounds__(512) k_build_solid_regions(const Slot *__restr
     const uint64_t n_regions = 1ull << q;
     for (uint64_t Q = blockIdx.x; Q < n_regions; Q += gridDim.x) {
         for (uint32_t i = tid; i < SOLID_REGION; i += 512) {
-            R[i].key = EMPTY_KEY; R[i].count = 0; R[i].pad = 0; R[i].hr = 0; R[i].hl = 0;
+            R[i].key = EMPTY_KEY; R[i].count = 0; R[i].aux = 0;
         }
         if (tid == 0) overflow = 0;
         __syncthreads();
@@ -319,8 +326,7 @@ __global__ void __launch_bounds__(512) k_build_solid_regions(const Slot *__restr
                     if (atomicCAS(reinterpret_cast<unsigned long long *>(&R[s].key), (unsigned long long)EMPTY_KEY,
                                   (unsigned long long)key) == EMPTY_KEY) {
                         R[s].count = (uint32_t)c;
-                        R[s].hr = (raw.w & HINT_RV) ? lh_make(raw.w & 0x3FFFu, HINT_LEN) : 0;
-                        R[s].hl = (raw.w & HINT_LV) ? lh_make((raw.w >> 16) & 0x3FFFu, HINT_LEN) : 0;
+                        R[s].aux = raw.w;
                         done = true;
                         break;
                     }
@@ -333,7 +339,7 @@ __global__ void __launch_bounds__(512) k_build_solid_regions(const Slot *__restr
         if (overflow && tid == 0) atomicExch(solid.fatal, 1u);
         uint4 *dst = reinterpret_cast<uint4 *>(solid.slots + Q * SOLID_REGION);
         const uint4 *src = reinterpret_cast<const uint4 *>(R);
-        for (uint32_t i = tid; i < SOLID_REGION * 2; i += 512) dst[i] = src[i];
+        for (uint32_t i = tid; i < SOLID_REGION; i += 512) dst[i] = src[i];
         __syncthreads();
     }
 }
@@ -468,13 +474,13 @@ __global__ void k_count_pairs(const int16_t *__restrict__ counts, const int64_t 
 __global__ void __launch_bounds__(512) k_solid_from_leaves(const uint4 *__restrict__ leaf_recs, const uint32_t *__restrict__ seg_counts,
                                                            uint64_t seg_cap, uint32_t nseg, SolidView solid, uint32_t solid_lg)
 {
-    __shared__ SolidSlot R[SOLID_REGION];
+    __shared__ Slot R[SOLID_REGION];
     __shared__ uint32_t overflow;
     const uint32_t tid = threadIdx.x;
     const uint64_t n_regions = 1ull << (solid_lg - SOLID_SB);
     for (uint64_t Q = blockIdx.x; Q < n_regions; Q += gridDim.x) {
         for (uint32_t i = tid; i < SOLID_REGION; i += 512) {
-            R[i].key = EMPTY_KEY; R[i].count = 0; R[i].pad = 0; R[i].hr = 0; R[i].hl = 0;
+            R[i].key = EMPTY_KEY; R[i].count = 0; R[i].aux = 0;
         }
         if (tid == 0) overflow = 0;
         __syncthreads();
@@ -490,8 +496,7 @@ __global__ void __launch_bounds__(512) k_solid_from_leaves(const uint4 *__restri
                     if (atomicCAS(reinterpret_cast<unsigned long long *>(&R[s].key), (unsigned long long)EMPTY_KEY,
                                   (unsigned long long)key) == EMPTY_KEY) {
                         R[s].count = raw.z;
-                        R[s].hr = (raw.w & HINT_RV) ? lh_make(raw.w & 0x3FFFu, HINT_LEN) : 0;
-                        R[s].hl = (raw.w & HINT_LV) ? lh_make((raw.w >> 16) & 0x3FFFu, HINT_LEN) : 0;
+                        R[s].aux = raw.w;
                         done = true;
                         break;
                     }
@@ -504,46 +509,8 @@ __global__ void __launch_bounds__(512) k_solid_from_leaves(const uint4 *__restri
         if (overflow && tid == 0) atomicExch(solid.fatal, 1u);
         uint4 *dst = reinterpret_cast<uint4 *>(solid.slots + Q * SOLID_REGION);
         const uint4 *src = reinterpret_cast<const uint4 *>(R);
-        for (uint32_t i = tid; i < SOLID_REGION * 2; i += 512) dst[i] = src[i];
+        for (uint32_t i = tid; i < SOLID_REGION; i += 512) dst[i] = src[i];
         __syncthreads();
-    }
-}
-
-// Hint doubling (packed keys only: the key IS the k-mer).  The hint of x leads to the vertex y; y's own
-// hint, turned to x's strand, continues it.  In place: hr / hl are single 8-byte words, and a reader
-// that meets an already extended word just extends further -- any valid continuation will do.
-__global__ void k_solid_double(SolidView t, uint64_t n_slots, int k, int max_steps)
-{
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t kmask = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1);
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += stride) {
-        SolidSlot *p = t.slots + i;
-        const uint64_t x = p->key;
-        if (x == EMPTY_KEY) continue;
-        for (int side = 0; side < 2; side++) {
-            uint64_t w = side == 0 ? p->hr : p->hl;
-            bool changed = false;
-            for (int step = 0; step < max_steps; step++) {  // 7 -> 14 -> 21 -> 28, or faster when y was extended already
-                const uint32_t n = lh_len(w);
-                if (n == 0 || n >= (uint32_t)LHINT_MAX || n > (uint32_t)k) break;
-                uint64_t y;
-                if (side == 0) y = ((x << (2 * n)) | lh_block_forward(w, n)) & kmask;            // x followed by its n bases
-                else y = (x >> (2 * n)) | ((w & lh_mask(n)) << (2 * (k - (int)n)));               // x preceded by them
-                const uint64_t ry = rc_packed(y, k);
-                const bool flipped = ry < y;
-                uint64_t hr, hl;
-                if (solid_get(t, flipped ? ry : y, &hr, &hl) < 0) break;
-                // what follows (side 0) / precedes (side 1) y on x's strand
-                uint64_t cont = side == 0 ? (flipped ? lh_complement(hl) : hr) : (flipped ? lh_complement(hr) : hl);
-                const uint32_t m = lh_len(cont);
-                if (m == 0) break;
-                const uint32_t total = n + m > (uint32_t)LHINT_MAX ? (uint32_t)LHINT_MAX : n + m;
-                const uint64_t bases = (w & lh_mask(n)) | ((cont & lh_mask(m)) << (2 * n));
-                w = lh_make(bases, total);
-                changed = true;
-            }
-            if (changed) { if (side == 0) p->hr = w; else p->hl = w; }
-        }
     }
 }
 
@@ -910,15 +877,15 @@ static void launch_count(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_o
     switch (c->cfg.key_mode) {
     case MC_KEY_PACKED:
         hipLaunchKernelGGL(k_count_reads<KEY_PACKED>, dim3(grid), dim3(block), 0, c->stream, d_words, d_off, r0, r1,
-                           c->cfg.k, t);
+                           c->cfg.k, t, c->cur_ptr_base, (uint32_t)c->cov_hint);
         break;
     case MC_KEY_POLY:
         hipLaunchKernelGGL(k_count_reads<KEY_POLY>, dim3(grid), dim3(block), 0, c->stream, d_words, d_off, r0, r1,
-                           c->cfg.k, t);
+                           c->cfg.k, t, c->cur_ptr_base, (uint32_t)c->cov_hint);
         break;
     default:
         hipLaunchKernelGGL(k_count_reads<KEY_FNV1A>, dim3(grid), dim3(block), 0, c->stream, d_words, d_off, r0, r1,
-                           c->cfg.k, t);
+                           c->cfg.k, t, c->cur_ptr_base, (uint32_t)c->cov_hint);
     }
 }
 
@@ -1077,7 +1044,7 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1)
         rc = timed(c, &ms3, [&] {
             const int grid = p3_grid;
 #define P3_ARGS lk, lh, lc, lcap, lseg, (uint32_t)n_leaves, pl.g, c->view(), virgin, P.leaf_state, P.leaf_new, P.flags + 1, \
-                (uint32_t)(c->solid_tracked ? c->cov_hint : 0), c->d_ctr + 6, k, emit
+                (uint32_t)(c->solid_tracked ? c->cov_hint : 0), c->d_ctr + 6, k, emit, c->ptr_tries
             if (pl.sk) hipLaunchKernelGGL(k_p3_merge<true>, dim3(grid), dim3(P3_THREADS), 0, c->stream, P3_ARGS);
             else hipLaunchKernelGGL(k_p3_merge<false>, dim3(grid), dim3(P3_THREADS), 0, c->stream, P3_ARGS);
 #undef P3_ARGS
@@ -1121,7 +1088,7 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1)
                 }
                 if (need)
                     hipLaunchKernelGGL(k_sk_add_unmerged, dim3(std::min<uint32_t>(hi_leaf - lo_leaf, 4096u)), dim3(256), 0, c->stream,
-                                       static_cast<const uint4 *>(lk), lc, lcap, lseg, lo_leaf, hi_leaf, P.leaf_state, k, c->view());
+                                       static_cast<const uint4 *>(lk), lh, lc, lcap, lseg, lo_leaf, hi_leaf, P.leaf_state, k, c->view());
                 HIPCHK(c, hipGetLastError());
                 lo_leaf = hi_leaf;
             }
@@ -1151,8 +1118,8 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1)
             const uint64_t m = std::min<uint64_t>(pl.sk ? std::max<uint64_t>(allowed / SK_MAX_WINDOWS, 1) : allowed, n_spill - i);
             rc = timed(c, &ms4, [&] {
                 if (pl.sk)
-                    hipLaunchKernelGGL(k_sk_add_records, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, P.spill_recs + i, m, k, c->view(),
-                                       thr, c->d_ctr + 6);
+                    hipLaunchKernelGGL(k_sk_add_records, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, P.spill_recs + i, (const uint32_t *)nullptr, m, k,
+                                       c->view(), thr, c->d_ctr + 6);
                 else
                     hipLaunchKernelGGL(k_add_keys_hint, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, P.spill_keys + i,
                                        P.spill_hints + i, m, c->view(), thr, c->d_ctr + 6);
@@ -1186,7 +1153,7 @@ static void launch_p1_reads(mc_ctx *c, const uint64_t *d_words, const uint64_t *
     const int grid = owners_mode == 0 ? PT_SEGMENTS
                                       : (int)std::min<uint64_t>(std::max<uint64_t>(n_tiles_abs - base0 / PT_TILE, 1), 256);
     const int k = c->cfg.k;
-#define P1_ARGS d_words, offs, nr, base0, end_abs, n_tiles_abs, tile_first, k, b1, cursors, cap, out_keys, out_hints, c->d_ctr + 1, sp, bases, c->mm_k
+#define P1_ARGS d_words, offs, nr, base0, end_abs, n_tiles_abs, tile_first, k, b1, cursors, cap, out_keys, out_hints, c->d_ctr + 1, sp, bases, c->mm_k, c->cur_ptr_base
 #define P1_LAUNCH(MODE)                                                                                                  \
     do {                                                                                                                 \
         if (owners_mode == 0)                                                                                            \
@@ -1236,7 +1203,7 @@ static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint6
                            n_tiles_abs, P.tile_first, tile_size);
         if (pl.sk)
             hipLaunchKernelGGL(k_sk1w_extract<false>, dim3(P1W_SEGMENTS), dim3(P1W_THREADS), 0, c->stream, d_words, offs, nr, base0, end_abs,
-                               n_tiles_abs, P.tile_first, c->cfg.k, pl.b1, P.seg_counts1, pl.cap1, P.a_recs, P.a_hints, pl.sks);
+                               n_tiles_abs, P.tile_first, c->cfg.k, pl.b1, P.seg_counts1, pl.cap1, P.a_recs, P.a_hints, pl.sks, c->cur_ptr_base);
         else
             launch_p1_reads(c, d_words, offs, nr, base0, end_abs, n_tiles_abs, P.tile_first, pl.b1, P.seg_counts1, pl.cap1, P.a_keys,
                             P.a_hints, pl.sp, 0, nullptr);
@@ -1328,10 +1295,45 @@ static int add_records_partitioned(mc_ctx *c, const uint4 *d_recs, const uint32_
         rc = table_reserve(c, (n - i) * SK_MAX_WINDOWS, &allowed);
         if (rc) return rc;
         const uint64_t m = std::min<uint64_t>(std::max<uint64_t>(allowed / SK_MAX_WINDOWS, 1), n - i);
-        hipLaunchKernelGGL(k_sk_add_records, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, d_recs + i, m, c->cfg.k, c->view(), 0u, c->d_ctr + 6);
+        hipLaunchKernelGGL(k_sk_add_records, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, d_recs + i, d_bins + i, m, c->cfg.k, c->view(), 0u, c->d_ctr + 6);
         HIPCHK(c, hipGetLastError());
         i += m;
     }
+    return MC_OK;
+}
+
+// Appends the packed bases [first_off, last_off) of a batch (word-aligned copy from the batch's own buffer) to the read
+// store and sets cur_ptr_base so that store position = cur_ptr_base + position in the batch.  in_place >= 0: the batch
+// already sits in the store from word `in_place` on (mc_add_reads_packed uploads straight into it).
+static int rs_reserve(mc_ctx *c, uint64_t more_words)
+{
+    const uint64_t used = c->rs_bases / 32, need = used + more_words + 2;
+    if (need <= c->rs_cap_words) return MC_OK;
+    uint64_t cap = std::max<uint64_t>(c->rs_cap_words * 2, std::max<uint64_t>(need, 1ull << 20));
+    uint64_t *nw = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&nw), cap * 8));
+    if (used) HIPCHK(c, hipMemcpyAsync(nw, c->rs_words, used * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->rs_words) (void)hipFree(c->rs_words);
+    c->rs_words = nw;
+    c->rs_cap_words = cap;
+    return MC_OK;
+}
+static int rs_append(mc_ctx *c, const uint64_t *d_words, uint64_t first_off, uint64_t last_off, int64_t in_place = -1)
+{
+    c->cur_ptr_base = ~0ull;
+    if (!c->rs_enabled || last_off <= first_off) return MC_OK;
+    const uint64_t w0 = first_off / 32, w1 = (last_off + 31) / 32;  // words [w0, w1) hold the batch (+ a pad word behind)
+    uint64_t at = c->rs_bases / 32;
+    if (in_place >= 0) {
+        at = (uint64_t)in_place;
+    } else {
+        int rc = rs_reserve(c, w1 - w0 + 1);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->rs_words + at, d_words + w0, (w1 - w0 + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
+    }
+    c->cur_ptr_base = at * 32 - w0 * 32;  // (mod 2^64: the kernels add a batch position >= w0 * 32)
+    c->rs_bases = (at + (w1 - w0)) * 32;
     return MC_OK;
 }
 
@@ -1438,9 +1440,6 @@ int mc_create(const mc_config *cfg, mc_ctx **out)
     c->stream = c->own_stream;
     CREATE_CHK(hipEventCreate(&c->ev0));
     CREATE_CHK(hipEventCreate(&c->ev1));
-    CREATE_CHK(hipEventCreate(&c->ev_side));
-    CREATE_CHK(hipEventCreate(&c->ev_walk));
-    CREATE_CHK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
     CREATE_CHK(hipMalloc(reinterpret_cast<void **>(&c->d_ctr), 8 * sizeof(unsigned long long)));
     CREATE_CHK(hipMalloc(reinterpret_cast<void **>(&c->d_fatal), sizeof(uint32_t)));
     CREATE_CHK(hipMalloc(reinterpret_cast<void **>(&c->d_ovf), mc_ctx::OVF_CAP * sizeof(uint4)));
@@ -1488,33 +1487,11 @@ void mc_destroy(mc_ctx *c)
     if (c->d_ovf) (void)hipFree(c->d_ovf);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
-    if (c->ev_side) (void)hipEventDestroy(c->ev_side);
-    if (c->ev_walk) (void)hipEventDestroy(c->ev_walk);
-    if (c->walk_stream) (void)hipStreamDestroy(c->walk_stream);
-    if (c->sweep_stream) (void)hipStreamDestroy(c->sweep_stream);
-    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+    if (c->rs_words) (void)hipFree(c->rs_words);
     for (char *p : c->pin) if (p) (void)hipHostFree(p);
     for (hipStream_t st : c->pin_stream) if (st) (void)hipStreamDestroy(st);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
-}
-
-// see mc_ctx::walk_stream
-constexpr int WALK_CUS = 16;
-static void start_mask_streams(mc_ctx *c)
-{
-    if (c->mask_started.exchange(true)) return;
-    // (on the calling thread: a helper thread creating queues while the caller launches kernels saved 20 ms of a
-    // one-shot run, but is the one piece of concurrent runtime initialisation a hang in a long CLI soak could be traced to)
-    uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, r[8];
-    for (int i = 0; i < WALK_CUS; i++) a[i >> 5] |= 1u << (i & 31);
-    for (int i = 0; i < 8; i++) r[i] = ~a[i];
-    hipStream_t w = nullptr, s = nullptr;
-    if (hipExtStreamCreateWithCUMask(&w, 8, a) != hipSuccess) { (void)hipGetLastError(); return; }
-    if (hipExtStreamCreateWithCUMask(&s, 8, r) != hipSuccess) { (void)hipStreamDestroy(w); (void)hipGetLastError(); return; }
-    c->walk_stream = w;
-    c->sweep_stream = s;
-    c->mask_ready.store(true, std::memory_order_release);
 }
 
 int mc_clear(mc_ctx *c)
@@ -1523,6 +1500,7 @@ int mc_clear(mc_ctx *c)
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->cfg.device));
     c->virgin = true;
+    c->rs_bases = 0;  // (slots that pointed into the read store go with the table)
     HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, 4 * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_ctr + 6, 0, 2 * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_fatal, 0, sizeof(uint32_t), c->stream));
@@ -1541,8 +1519,25 @@ int mc_set_coverage_hint(mc_ctx *c, int min_cov)
     if (min_cov < 0 || min_cov > 32767) return fail(c, MC_EINVAL, "mc_set_coverage_hint: min_cov must be in 0..32767");
     if (min_cov != c->cov_hint && !c->virgin) c->solid_tracked = false;  // keys already counted were not tracked at this threshold
     if (min_cov != c->cov_hint) c->solid_list_fresh = false;
-    if (min_cov > 0) start_mask_streams(c);
     c->cov_hint = min_cov;
+    return MC_OK;
+}
+
+int mc_set_read_pointers(mc_ctx *c, int enable)
+{
+    if (!c) return MC_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    c->rs_enabled = enable != 0;
+    return MC_OK;
+}
+
+int mc_share_read_store(mc_ctx *c, mc_ctx *from)
+{
+    if (!c) return MC_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (from == c) from = nullptr;
+    if (from && from->cfg.device != c->cfg.device) return fail(c, MC_EINVAL, "mc_share_read_store: the contexts are on different devices");
+    c->rs_from = from;
     return MC_OK;
 }
 
@@ -1555,7 +1550,8 @@ int mc_set_stream(mc_ctx *c, void *hip_stream)
     return MC_OK;
 }
 
-static int add_reads_dev_locked(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_off, uint64_t n_reads, uint64_t n_bases);
+static int add_reads_dev_locked(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_off, uint64_t n_reads, uint64_t n_bases,
+                                int64_t in_store = -1);
 
 // Host (pageable) memory to the device.  A plain hipMemcpy of pageable memory stages through one thread; a few
 // threads each staging 8 MB pieces through their own pinned buffers and stream reach the link rate
@@ -1617,9 +1613,20 @@ int mc_add_reads_packed(mc_ctx *c, const uint64_t *words, const uint64_t *off, u
     const uint64_t n_words = (n_bases + 31) / 32 + 1;
     const uint64_t w_begin = off[0] / 32;  // offsets need not start at 0
     DevBuf<uint64_t> dw, doff;
-    HIPCHK(c, dw.alloc(n_words - w_begin));
+    uint64_t *dst = nullptr;
+    int64_t in_store = -1;
+    int rc;
+    if (c->rs_enabled) {  // straight into the read store: the kernels read the batch from there
+        rc = rs_reserve(c, n_words - w_begin);
+        if (rc) return rc;
+        in_store = (int64_t)(c->rs_bases / 32);
+        dst = c->rs_words + in_store;
+    } else {
+        HIPCHK(c, dw.alloc(n_words - w_begin));
+        dst = dw.p;
+    }
     HIPCHK(c, doff.alloc(n_reads + 1));
-    int rc = h2d_fast(c, dw.p, words + w_begin, (n_words - w_begin) * 8);
+    rc = h2d_fast(c, dst, words + w_begin, (n_words - w_begin) * 8);
     if (rc) return rc;
     if (w_begin == 0) {
         rc = h2d_fast(c, doff.p, off, (n_reads + 1) * 8);
@@ -1630,13 +1637,14 @@ int mc_add_reads_packed(mc_ctx *c, const uint64_t *words, const uint64_t *off, u
     }
     if (rc) return rc;
     // (monotone offsets are checked on the device, with the window count: k_reads_summary)
-    rc = add_reads_dev_locked(c, dw.p, doff.p, n_reads, n_bases - w_begin * 32);
+    rc = add_reads_dev_locked(c, dst, doff.p, n_reads, n_bases - w_begin * 32, in_store);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return rc;
 }
 
 // reads resident in HBM (the context's lock is held)
-static int add_reads_dev_locked(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_off, uint64_t n_reads, uint64_t n_bases)
+static int add_reads_dev_locked(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_off, uint64_t n_reads, uint64_t n_bases,
+                                int64_t in_store)
 {
     // summary on the device: total windows, monotone offsets, first and last offset
     unsigned long long *sum = c->d_ctr + 4;
@@ -1655,6 +1663,11 @@ static int add_reads_dev_locked(mc_ctx *c, const uint64_t *d_words, const uint64
         return fail(c, MC_EINVAL, "mc_add_reads_packed_dev: read_offsets[n_reads]=%llu but n_bases=%llu",
                     (unsigned long long)last_off, (unsigned long long)n_bases);
     const uint64_t total = hs[0];
+    {   // the batch joins the read store (the slots of its k-mers will point there)
+        int rc = rs_append(c, d_words, first_off, last_off, in_store);
+        if (rc) return rc;
+        c->ptr_tries = 1;
+    }
     const bool partition = c->count_path == 2 || (c->count_path == 0 && total >= (1ull << 22));
     if (partition && last_off - first_off < (1ull << 31) - (1ull << 24)) {  // one batch: no need for the offsets on the host
         if (total) {
@@ -1867,6 +1880,12 @@ int mc_extract_keys_dev(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_of
     if (last_off != n_bases)
         return fail(c, MC_EINVAL, "mc_extract_keys_dev: read_offsets[n_reads]=%llu but n_bases=%llu",
                     (unsigned long long)last_off, (unsigned long long)n_bases);
+    if (d_keys) {  // (the pass that writes the keys: their read pointers refer to this context's read store)
+        int rrc = rs_append(c, d_words, first_off, last_off);
+        if (rrc) return rrc;
+    } else {
+        c->cur_ptr_base = ~0ull;
+    }
     const uint64_t n_tiles_abs = (last_off + PT_TILE - 1) / PT_TILE;
     int rc = ensure_buf(c, &P.tile_first, &P.tiles1_cap, n_tiles_abs);
     if (rc) return rc;
@@ -1928,6 +1947,10 @@ int mc_extract_superkmers_dev(mc_ctx *c, const uint64_t *d_words, const uint64_t
     if (last_off != n_bases)
         return fail(c, MC_EINVAL, "mc_extract_superkmers_dev: read_offsets[n_reads]=%llu but n_bases=%llu",
                     (unsigned long long)last_off, (unsigned long long)n_bases);
+    {
+        int rrc = rs_append(c, d_words, first_off, last_off);
+        if (rrc) return rrc;
+    }
     // windows <= bases: capacity of the (owner, segment) pieces from the same bound the caller sized its buffer with
     const uint64_t bound = sk_records_bound(c, n_bases - first_off, n_reads);
     const uint32_t nseg = P1W_SEGMENTS;
@@ -1957,7 +1980,7 @@ int mc_extract_superkmers_dev(mc_ctx *c, const uint64_t *d_words, const uint64_t
     hipLaunchKernelGGL(k_tile_first_read, dim3((unsigned)((n_tiles_abs + 255) / 256)), dim3(256), 0, c->stream, d_off, n_reads,
                        n_tiles_abs, P.tile_first, P1W_TILE);
     hipLaunchKernelGGL(k_sk1w_extract<true>, dim3(nseg), dim3(P1W_THREADS), 0, c->stream, d_words, d_off, n_reads, first_off,
-                       last_off, n_tiles_abs, P.tile_first, c->cfg.k, n_owners, P.seg_counts1, seg_cap, P.a_recs, P.a_hints, none);
+                       last_off, n_tiles_abs, P.tile_first, c->cfg.k, n_owners, P.seg_counts1, seg_cap, P.a_recs, P.a_hints, none, c->cur_ptr_base);
     hipLaunchKernelGGL(k_sk_pack_offsets, dim3(1), dim3(1024), 0, c->stream, P.seg_counts1, n_owners, d_piece.p, d_owner.p, nseg);
     hipLaunchKernelGGL(k_sk_pack, dim3(std::min<uint32_t>(n_owners * nseg, 4096)), dim3(256), 0, c->stream, P.a_recs, P.a_hints,
                        P.seg_counts1, seg_cap, d_piece.p, n_owners * nseg, reinterpret_cast<uint4 *>(d_recs), d_bins, cap);
@@ -1981,6 +2004,7 @@ int mc_add_superkmers_dev(mc_ctx *c, const uint64_t *d_recs, const uint32_t *d_b
     if (!c->sk_form) return fail(c, MC_ESTATE, "mc_add_superkmers_dev: this context does not count through super-k-mers");
     if ((!d_recs || !d_bins) && n) return fail(c, MC_EINVAL, "mc_add_superkmers_dev: null pointer");
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    c->ptr_tries = 16;  // (records of ranks that keep no read store carry no pointer)
     if (!c->mm_k) {  // the context gave up minimizer bins (to_hash_regions): the records are expanded by the direct kernel
         c->solid_tracked = false;
         c->solid_list_fresh = false;
@@ -1990,7 +2014,7 @@ int mc_add_superkmers_dev(mc_ctx *c, const uint64_t *d_recs, const uint32_t *d_b
             int rc = table_reserve(c, (n - i) * SK_MAX_WINDOWS, &allowed);
             if (rc) return rc;
             const uint64_t m = std::min<uint64_t>(std::max<uint64_t>(allowed / SK_MAX_WINDOWS, 1), n - i);
-            hipLaunchKernelGGL(k_sk_add_records, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, reinterpret_cast<const uint4 *>(d_recs) + i, m,
+            hipLaunchKernelGGL(k_sk_add_records, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, reinterpret_cast<const uint4 *>(d_recs) + i, d_bins + i, m,
                                c->cfg.k, c->view(), 0u, c->d_ctr + 6);
             HIPCHK(c, hipGetLastError());
             i += m;
@@ -2260,7 +2284,7 @@ struct PairSource { const int64_t *keys; const int16_t *counts; const uint32_t *
 
 // Builds the solid table for n entries with count >= min_cov, taken from the counting table or (pairs != nullptr)
 // from arrays of (key, count, hint).
-int solid_build(mc_ctx *c, uint64_t n, int min_cov, double *ms, const PairSource *pairs, bool defer_double = false, bool from_list = false)
+int solid_build(mc_ctx *c, uint64_t n, int min_cov, double *ms, const PairSource *pairs, bool from_list = false)
 {
     c->n_solid = n;
     c->st.solid_kmers = n;
@@ -2271,10 +2295,9 @@ int solid_build(mc_ctx *c, uint64_t n, int min_cov, double *ms, const PairSource
     if (lg < SOLID_SB + 1) lg = SOLID_SB + 1;
     if (!c->solid || lg != c->solid_lg) {
         if (c->solid) { (void)hipFree(c->solid); c->solid = nullptr; }
-        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->solid), sizeof(SolidSlot) << lg));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->solid), sizeof(Slot) << lg));
         c->solid_lg = lg;
     }
-    const int doublings = c->cfg.key_mode == MC_KEY_PACKED ? 2 : 0;  // hash keys do not hold the k-mer
     // counting table organised by minimizer bins, or entries from outside: the solid entries are partitioned by
     // their own hash first
     const bool partitioned = c->mm_k || pairs;
@@ -2329,7 +2352,7 @@ int solid_build(mc_ctx *c, uint64_t n, int min_cov, double *ms, const PairSource
                                    P.seg_counts1, scap1, r1, h1, none);
             if (sb2)
                 hipLaunchKernelGGL(k_sk2_scatter, dim3(1u << sb1), dim3(PT_THREADS), 0, c->stream, r1, h1, scap1,
-                                   P.seg_counts1, 1u << sb1, 1u << sb1, 1u << sb2, leaf_counts, scap2, r2, h2, none);
+                                   P.seg_counts1, 1u << sb1, 1u << sb1, 1u << sb2, leaf_counts, scap2, r2, h2, none, (uint32_t)PT_SEGMENTS, 1);
             hipLaunchKernelGGL(k_solid_from_leaves, dim3((unsigned)std::min<uint64_t>(1ull << q, 256 * 2 * 8)), dim3(512), 0, c->stream,
                                sb2 ? r2 : r1, sb2 ? leaf_counts : P.seg_counts1, sb2 ? scap2 : scap1,
                                sb2 ? 1u : (uint32_t)PT_SEGMENTS, c->solid_view(), lg);
@@ -2337,14 +2360,8 @@ int solid_build(mc_ctx *c, uint64_t n, int min_cov, double *ms, const PairSource
             hipLaunchKernelGGL(k_build_solid_regions, dim3((unsigned)std::min<uint64_t>(1ull << (lg - SOLID_SB), 256 * 2 * 8)), dim3(512), 0,
                                c->stream, c->slots, c->rb + c->sb, min_cov, c->solid_view(), lg);  // (hash-prefix regions: a power of two)
         }
-        // one sweep: each slot chases its own chain (up to 3 dependent lookups per side).  A caller that walks right
-        // away launches it itself, next to the walk (launch_double): any mix of short and doubled hints is valid.
-        if (doublings && !defer_double)
-            hipLaunchKernelGGL(k_solid_double, dim3(grid_for(1ull << lg, 256)), dim3(256), 0, c->stream, c->solid_view(),
-                               (uint64_t)1 << lg, c->cfg.k, 3);
     });
     if (rc) return rc;
-    c->double_deferred = doublings && defer_double;
     uint32_t fatal = 0;
     HIPCHK(c, hipMemcpy(&fatal, c->d_fatal, sizeof fatal, hipMemcpyDeviceToHost));
     if (fatal) return fail(c, MC_EOVERFLOW, "a region of the solid k-mer table filled up (hash skew)");
@@ -2358,7 +2375,7 @@ int solid_build(mc_ctx *c, uint64_t n, int min_cov, double *ms, const PairSource
 }
 
 // Builds (or reuses) the solid table for this threshold.
-int ensure_solid(mc_ctx *c, int min_cov, double *ms, bool defer_double = false)
+int ensure_solid(mc_ctx *c, int min_cov, double *ms)
 {
     if (c->solid_cov == min_cov && c->solid) return MC_OK;
     if (c->solid_external)
@@ -2382,7 +2399,7 @@ int ensure_solid(mc_ctx *c, int min_cov, double *ms, bool defer_double = false)
     }
     unsigned long long n = 0;
     HIPCHK(c, hipMemcpy(&n, cursor, sizeof n, hipMemcpyDeviceToHost));
-    return solid_build(c, n, min_cov, ms, nullptr, defer_double, from_list);
+    return solid_build(c, n, min_cov, ms, nullptr, from_list);
 }
 
 void launch_bfs(mc_ctx *c, hipStream_t stream, const BfsState *d_states, uint32_t n_jobs, int min_cov, int64_t max_kmers,
@@ -2428,8 +2445,7 @@ int mc_solid_from_pairs_dev(mc_ctx *c, const int64_t *d_keys, const int16_t *d_c
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const PairSource src{d_keys, d_counts, d_hints, n};
     double ms = 0;
-    static const bool overlap = getenv("MC_NO_DOUBLE_OVERLAP") == nullptr;
-    int rc = solid_build(c, m, min_cov, &ms, &src, overlap);  // the hints are doubled next to the first walk
+    int rc = solid_build(c, m, min_cov, &ms, &src);
     if (rc) return rc;
     c->pending_solid_ms = ms;  // reported with the next BFS
     c->solid_external = true;
@@ -2464,18 +2480,9 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
     double total_ms = c->pending_solid_ms;
     c->pending_solid_ms = 0;
     {
-        static const bool overlap = getenv("MC_NO_DOUBLE_OVERLAP") == nullptr;
-        int rc = ensure_solid(c, min_cov, &total_ms, overlap);
+        int rc = ensure_solid(c, min_cov, &total_ms);
         if (rc) return rc;
     }
-    // whatever happens below, the sweep on the side stream has ended before this call returns
-    hipStream_t sweep_on = c->side_stream;
-    struct SideGuard {
-        hipStream_t *on;
-        bool launched = false;
-        ~SideGuard() { if (launched) (void)hipStreamSynchronize(*on); }
-    } side{&sweep_on};
-    start_mask_streams(c);  // (if mc_set_coverage_hint did not: ready for the next BFS)
 
     while (c->bfs_pool.size() < n_jobs) c->bfs_pool.emplace_back(new BfsJobBuffers);
     auto &B = c->bfs_pool;
@@ -2505,6 +2512,7 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
             HIPCHK(c, hipMemsetAsync(S.flags, 0, S.dcap * 4, c->stream));
         }
         if (!S.ctl) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&S.ctl), sizeof(BfsCtl)));
+        if (!S.path) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&S.path), (size_t)SCOUT_MAX_F * PATH_WORDS * 8));
         HIPCHK(c, hipMemsetAsync(S.ctl, 0, sizeof(BfsCtl), c->stream));
         S.seed_hi = jobs[j].seed_hi ? J.d_seed_hi : nullptr;
         S.seed_lo = J.d_seed_lo;
@@ -2520,38 +2528,8 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
         for (uint32_t j = 0; j < n_jobs; j++) h_states[j] = B[j]->S;
         HIPCHK(c, hipMemcpyAsync(d_states.p, h_states.data(), n_jobs * sizeof(BfsState), hipMemcpyHostToDevice,
                                  c->stream));
-        int rc = timed(c, &total_ms, [&] {
-            // The walk's few workgroups get CUs of their own (a stream with a CU mask) and the sweep the others: on
-            // shared CUs the sweep's waves take issue slots from the walk, whose rounds are issue-bound (2 ms of 31).
-            const bool masked = c->double_deferred && n_jobs <= (uint32_t)WALK_CUS && c->mask_ready.load(std::memory_order_acquire);
-            sweep_on = masked ? c->sweep_stream : c->side_stream;
-            if (masked) {
-                (void)hipEventRecord(c->ev_side, c->stream);
-                (void)hipStreamWaitEvent(c->walk_stream, c->ev_side, 0);
-                launch_bfs(c, c->walk_stream, d_states.p, n_jobs, min_cov, max_kmers, max_radius, max_rounds);
-                (void)hipEventRecord(c->ev_walk, c->walk_stream);
-                (void)hipStreamWaitEvent(c->stream, c->ev_walk, 0);
-            } else {
-                launch_bfs(c, c->stream, d_states.p, n_jobs, min_cov, max_kmers, max_radius, max_rounds);
-            }
-            if (c->double_deferred) {
-                // The walk's few workgroups are placed first; the sweep fills the rest of the chip and lengthens the
-                // hints under the walk's feet (8-byte words, replaced whole: the walk reads either version, and a
-                // hint only steers its look-ahead).  The table was complete and the stream idle when it was built.
-                c->double_deferred = false;
-                side.launched = true;
-                hipLaunchKernelGGL(k_solid_double, dim3(grid_for(1ull << c->solid_lg, 256)), dim3(256), 0, sweep_on,
-                                   c->solid_view(), (uint64_t)1 << c->solid_lg, c->cfg.k, 3);
-                (void)hipEventRecord(c->ev_side, sweep_on);
-            }
-        });
+        int rc = timed(c, &total_ms, [&] { launch_bfs(c, c->stream, d_states.p, n_jobs, min_cov, max_kmers, max_radius, max_rounds); });
         if (rc) return rc;
-        if (side.launched) {
-            HIPCHK(c, hipEventSynchronize(c->ev_side));
-            float tail = 0;  // the part of the sweep that outlasted the walk, if any
-            if (hipEventElapsedTime(&tail, c->ev1, c->ev_side) == hipSuccess && tail > 0) total_ms += tail;
-            side.launched = false;
-        }
         bool all_done = true;
         for (uint32_t j = 0; j < n_jobs; j++) {
             HIPCHK(c, hipMemcpy(&ctl[j], B[j]->S.ctl, sizeof(BfsCtl), hipMemcpyDeviceToHost));
@@ -2561,7 +2539,7 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
             // grow distanceToKmer and its index (only reachable without --maxkmers)
             BfsState &S = B[j]->S;
             BfsState N = S;
-            N.hi = N.lo = nullptr; N.dist = nullptr; N.cov = nullptr; N.flags = nullptr; N.vis = nullptr;
+            N.hi = N.lo = nullptr; N.dist = nullptr; N.cov = nullptr; N.flags = nullptr; N.vis = nullptr;  // (ctl and path stay)
             rc = bfs_alloc(c, N, S.dcap * 2);
             if (rc) return rc;
             const uint64_t n = ctl[j].n;
@@ -2589,8 +2567,15 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
         const uint64_t n = ctl[j].n;
         mc_bfs_result *o = &out[j];
         o->lookups = ctl[j].lookups;
-        o->rounds = ctl[j].rounds_narrow + ctl[j].chunks_wide;
+        o->rounds = ctl[j].rounds_narrow + ctl[j].chunks_wide + 2 * ctl[j].scout_hops;  // (a scout hop: the read, then its k-mers)
         o->device_ms = total_ms;
+        {
+            static const bool stats = getenv("MC_BFS_STATS") != nullptr;
+            if (stats)
+                fprintf(stderr, "[bfs job %u] n=%llu level=%lld rounds_narrow=%llu (slow %llu) chunks_wide=%llu scout calls=%llu hops=%llu levels=%llu notfound=%llu m0=%llu lookups=%llu\n", j,
+                        ctl[j].n, ctl[j].level, ctl[j].rounds_narrow, ctl[j].rounds_slow, ctl[j].chunks_wide, ctl[j].scout_calls, ctl[j].scout_hops, ctl[j].scout_levels,
+                        ctl[j].scout_nf, ctl[j].scout_m0, ctl[j].lookups);
+        }
 #ifdef MC_BFS_TIMING
         {
             const double r_ = 0.01 / std::max(1ull, ctl[j].rounds_narrow);

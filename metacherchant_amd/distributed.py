@@ -23,13 +23,18 @@ import torch.distributed as dist
 
 
 class ShardedCounter:
-    def __init__(self, ctx, device, group=None):
+    def __init__(self, ctx, device, group=None, bfs_rank=0):
         self.ctx = ctx
         self.device = device
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.bytes_sent = 0
+        # Read pointers (include/mcgpu.h mc_set_read_pointers): the BFS rank walks with look-ahead read from ITS OWN
+        # reads, so only its records carry pointers; the other ranks keep no read store and send zeros.
+        self.bfs_rank = bfs_rank
+        if self.world > 1 and bfs_rank is not None and self.rank != bfs_rank and hasattr(ctx, "set_read_pointers"):
+            ctx.set_read_pointers(False)
         # see _exchange_superkmers (MC_EXCHANGE_MIN_READS: read sets from this size on go in two pieces)
         self.parts, self.parts_min_reads = 2, int(os.environ.get("MC_EXCHANGE_MIN_READS", 1 << 20))
 
@@ -72,7 +77,11 @@ class ShardedCounter:
         one call: every counting pass rewrites the whole table, so one pass per piece would cost more than the
         overlap gains."""
         ctx, W = self.ctx, self.world
-        parts = self.parts if n_reads >= self.parts_min_reads else 1
+        # every rank must issue the same collectives: the number of pieces is decided by the smallest share, and a rank
+        # without reads in a piece still takes part in its exchange (with zero counts)
+        nmin = torch.tensor([int(n_reads)], dtype=torch.int64, device=self.device)
+        dist.all_reduce(nmin, op=dist.ReduceOp.MIN, group=self.group)
+        parts = self.parts if int(nmin.item()) >= self.parts_min_reads else 1
         bounds = [n_reads * p // parts for p in range(parts + 1)]
         base_at = [0] + [int(d_offsets[b].item()) for b in bounds[1:-1]] + [int(n_bases)]
         recv = recv_b = None
@@ -81,12 +90,13 @@ class ShardedCounter:
         leftovers = []  # a piece that did not fit the shared buffer: counted by a call of its own
         for p in range(parts):
             a, b = bounds[p], bounds[p + 1]
-            if a == b:
-                continue
-            cap_p = cap if parts == 1 else ctx.superkmer_capacity(base_at[p + 1] - base_at[p], b - a)
+            cap_p = max(cap if parts == 1 else ctx.superkmer_capacity(base_at[p + 1] - base_at[p], b - a), 1)
             send = torch.empty((cap_p, 2), dtype=torch.int64, device=self.device)   # 16-byte records
-            send_b = torch.empty(cap_p, dtype=torch.int32, device=self.device)      # their bin words
-            off = ctx.extract_superkmers_dev(d_words, d_offsets[a:], b - a, base_at[p + 1], W, send, send_b, cap_p)
+            send_b = torch.empty(cap_p, dtype=torch.int32, device=self.device)      # the read pointers of their first windows
+            if b > a:
+                off = ctx.extract_superkmers_dev(d_words, d_offsets[a:], b - a, base_at[p + 1], W, send, send_b, cap_p)
+            else:
+                off = np.zeros(W + 1, dtype=np.uint64)
             send_counts = [int(off[o + 1] - off[o]) for o in range(W)]
             sc = torch.tensor(send_counts, dtype=torch.int64, device=self.device)
             rc = torch.empty(W, dtype=torch.int64, device=self.device)
@@ -158,7 +168,9 @@ class ShardedCounter:
             torch.cuda.synchronize(self.device)
         if dst is None or self.rank == dst:
             # owners are disjoint, so the shards simply sit side by side: one pass over the gathered arrays puts
-            # them into the BFS table (padding skipped by its count)
+            # them into the BFS table (padding skipped by its count); the pointers refer to this rank's reads
+            if hasattr(solid_ctx, "share_read_store"):
+                solid_ctx.share_read_store(ctx)
             kept = solid_ctx.solid_from_pairs_dev(all_k, all_c, W * mx, min_cov, all_h)
             assert kept == sum(sizes), (kept, sizes)
         return sum(sizes)

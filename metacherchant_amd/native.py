@@ -44,7 +44,7 @@ class Stats(C.Structure):
 
 # every symbol include/mcgpu.h declares; tests check that the library exports all of them
 EXPORTS = [
-    "mc_abi_version", "mc_create", "mc_destroy", "mc_clear", "mc_set_coverage_hint", "mc_last_error", "mc_set_stream", "mc_add_reads_packed",
+    "mc_abi_version", "mc_create", "mc_destroy", "mc_clear", "mc_set_coverage_hint", "mc_set_read_pointers", "mc_share_read_store", "mc_last_error", "mc_set_stream", "mc_add_reads_packed",
     "mc_add_reads_packed_dev", "mc_add_reads_file", "mc_finalize_counts", "mc_get", "mc_get_dev", "mc_kmer_keys", "mc_bfs", "mc_bfs_batch",
     "mc_bfs_result_free", "mc_export", "mc_export_dev", "mc_add_pairs_dev", "mc_solid_from_pairs_dev", "mc_save_kmers", "mc_load_kmers", "mc_key_owner", "mc_extract_keys_dev",
     "mc_add_keys_dev", "mc_superkmer_capacity", "mc_extract_superkmers_dev", "mc_add_superkmers_dev", "mc_get_stats", "mc_reset_stats", "mc_synth_reads_dev", "mc_synth_genome",
@@ -85,6 +85,8 @@ def load():
     L.mc_set_stream.argtypes = [vp, vp]
     L.mc_clear.argtypes = [vp]
     L.mc_set_coverage_hint.argtypes = [vp, i32]
+    L.mc_set_read_pointers.argtypes = [vp, i32]
+    L.mc_share_read_store.argtypes = [vp, vp]
     L.mc_add_reads_packed.argtypes = [vp, u64p, u64p, u64]
     L.mc_add_reads_packed_dev.argtypes = [vp, vp, vp, u64, u64]
     L.mc_add_reads_file.argtypes = [vp, C.c_char_p, u64p]
@@ -173,6 +175,14 @@ class Context:
     def set_coverage_hint(self, min_cov):
         """mc_set_coverage_hint: counting keeps #(count >= min_cov) current, BFS set-up skips a table sweep."""
         self._chk(self._L.mc_set_coverage_hint(self._h, int(min_cov)))
+
+    def set_read_pointers(self, enable):
+        """mc_set_read_pointers: keep (1) or stop keeping (0) the reads and the slots' pointers into them."""
+        self._chk(self._L.mc_set_read_pointers(self._h, 1 if enable else 0))
+
+    def share_read_store(self, other):
+        """mc_share_read_store: this (BFS-only) context reads its look-ahead from `other`'s read store."""
+        self._chk(self._L.mc_share_read_store(self._h, other._h if other is not None else None))
 
     def set_stream(self, stream_ptr):
         self._chk(self._L.mc_set_stream(self._h, C.c_void_p(stream_ptr) if stream_ptr else None))

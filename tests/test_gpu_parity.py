@@ -513,12 +513,13 @@ def test_superkmer_records_by_owner(mc, k):
     allk = np.concatenate(seen)
     assert len(np.unique(allk)) == len(allk) == t.size()  # owners are disjoint
     _assert_tables_equal(merged, merged.finalize(), t)
+    merged.share_read_store(ex)  # the read pointers of the records refer to the extracting context's reads
     if k == 31:
         seed = genome[5000:5300]
         hi, lo = seed_windows(seed, k)
         got = merged.bfs(hi, lo, 1, 3, 4000, -1)
         assert_bfs_equal(got, po.bfs(t, k, po.KEY_PACKED, [seed], 1, 3, 4000, -1))
-        assert got["rounds"] * 4 < got["levels"]  # long look-ahead: the hints made the trip
+        assert got["rounds"] * 4 < got["levels"]  # long look-ahead: the read pointers made the trip
     ex.close()
     merged.close()
 
@@ -559,14 +560,16 @@ def test_bfs_table_straight_from_gathered_pairs(mc, k, mode_name):
         all_c[r * mx:r * mx + cnt] = pc[:m][p]
         all_h[r * mx:r * mx + cnt] = ph[:m][p]
     solid = mc.Context(k, mode, 0, 0)
+    solid.share_read_store(full)  # the pairs' read pointers refer to the reads `full` counted
     assert solid.solid_from_pairs_dev(all_k, all_c, 2 * mx, 3, all_h) == n3
     seed = genome[4000:4300]
     hi, lo = seed_windows(seed, k)
     for d in (-1, 0, 1):
         got = solid.bfs(hi, lo, d, 3, 3000, -1)
         assert_bfs_equal(got, po.bfs(t, k, omode, [seed], d, 3, 3000, -1))
-        # the hints made the trip (their doubling runs next to the first walk, so the exact number of rounds varies)
-        assert d == 0 or mode != mc.KEY_PACKED or got["rounds"] * 4 < got["levels"]
+        # the read pointers made the trip: long look-ahead in every key mode (both directions at once: two walkers,
+        # each with a scout whose hops count as round trips)
+        assert got["rounds"] * (2 if d == 0 else 4) < got["levels"]
     with pytest.raises(Exception):
         solid.bfs(hi, lo, 1, 4, 3000, -1)  # built for coverage 3 only
     solid.clear()
@@ -597,6 +600,7 @@ def test_hints_survive_exchange_and_speed_up_the_walk(mc):
     res = {}
     for name, h in (("with", d_hints), ("without", None)):
         c = mc.Context(31, mc.KEY_PACKED, 0, 200000)
+        c.share_read_store(ex)
         c.add_keys_dev(d_keys, n, h)
         c.finalize()
         r = c.bfs(hi, lo, -1, 3, 20000, -1)
