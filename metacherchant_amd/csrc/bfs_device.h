@@ -34,6 +34,13 @@ constexpr uint32_t PATH_WORDS = (PATH_CAP + 64 + 96) / 32 + 4;  // the walker's 
 constexpr uint32_t PSEG_WORDS = 12;                   // path words a round needs: (31 + MAX_NODES / 4 + 63 + 1) bases and one to spare
 constexpr uint32_t SCOUT_WORDS = 16;                  // read-store words a hop looks at
 constexpr uint32_t SCOUT_BUDGET0 = 1024;              // levels of the first scout run; doubled after every run the rounds used up
+#ifndef MC_TEAM_MAX
+#define MC_TEAM_MAX 2   // waves that follow different candidate reads of one walker's hop (measured on configs[1], BFS phase: 1 wave 14.0 ms,
+                        // 2 waves 11.2, 4 waves 11.8, 8 waves 14.3: the longer hops of a larger team cost more in lookups issued by one CU than they save)
+#endif
+#ifndef MC_SCOUT_PROBES
+#define MC_SCOUT_PROBES 4   // slots a scout's lookup requests at once
+#endif
 constexpr int NARROW_CAND = 64;           // candidates per replayed level = lanes of one wave
 constexpr int RH_SIZE = 1024;             // round-local LDS set (narrow, slow replay)
 constexpr int WH_SIZE = 2 * BFS_THREADS;  // chunk-local LDS set (wide)
@@ -47,13 +54,14 @@ struct BfsCtl {
     unsigned long long lb, le;  // current frontier = entries [lb, le)
     unsigned long long c0;      // next candidate rank inside the frontier (wide path)
     unsigned long long lookups;
-    unsigned long long rounds_narrow, rounds_slow, chunks_wide, scout_hops, scout_levels, scout_calls, scout_nf, scout_m0;
+    unsigned long long rounds_narrow, rounds_slow, chunks_wide, scout_hops, scout_levels, scout_calls, scout_nf, scout_m0, slow_mismatch, slow_starved, slow_forced;
     unsigned long long tacc[8];  // MC_BFS_TIMING builds: 10 ns ticks per phase of a narrow round
     long long level;            // distance of the frontier
     int status;
     int seeds_done;
 };
 
+struct ScoutBox;
 struct BfsState {
     uint64_t *hi, *lo;  // distanceToKmer keys in insertion order
     int32_t *dist;
@@ -64,10 +72,20 @@ struct BfsState {
     uint64_t bmask;     // number of buckets - 1
     BfsCtl *ctl;
     uint64_t *path;     // SCOUT_MAX_F * PATH_WORDS words: the predicted paths of the walkers (scout_run)
+    ScoutBox *box;      // mailbox between this job's workgroup and its scouting companion (nullptr: none)
     const uint64_t *seed_hi, *seed_lo;
     uint64_t n_seeds;
     int dir;
 };
+
+// The walk state in BfsCtl is written by thread 0 and read by every thread behind a barrier.  Those reads decide what the
+// whole workgroup does next, so every wave must see the same value: they are L1-bypassing loads (a wave that read a
+// stale `c0` -- seen once the struct had grown over more cache lines -- expands other parents than its neighbours and,
+// were it `lb` / `le`, would wait at a different barrier for good), and the stores write through.
+template <typename T>
+__device__ __forceinline__ T ctl_ld(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T, typename V>
+__device__ __forceinline__ void ctl_st(T *p, V v) { __hip_atomic_store(p, (T)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __device__ __forceinline__ uint64_t ld_sc1(const uint64_t *p)
 {  // L1-bypassing load: data written earlier in this launch by an atomic or by another wave's store
@@ -232,14 +250,12 @@ struct NarrowLds {
     uint32_t F;
     uint32_t bad_lvl, pend;
     uint32_t scout_budget, scout_skip, scout_wait, force_slow;
+    uint32_t comp, req_seq, req_open, ready;  // the companion (ScoutBox): usable, the last request, one is outstanding, its answer is in
+    uint32_t pdone[SCOUT_MAX_F];              // the companion finished walker a's path
     unsigned long long hops, hop_levels, s_calls, s_nf, s_m0;
     int cur, status, any_dup_root;
 };
 
-union BfsLds {
-    WideLds w;
-    NarrowLds n;
-};
 
 // ---- wide path: one chunk of <= BFS_THREADS candidates in rank order.  parent == UINT64_MAX marks a
 // seed window (src/algo/OneSequenceCalculator.java:159-192: queued when reads.get(key) >= minOccurences).
@@ -260,7 +276,7 @@ __device__ void bfs_chunk_wide(const BfsState &S, const SolidView &t, WideLds &L
         lookups++;
     }
     const bool solid = have && cov >= min_cov;
-    const unsigned long long n_before = ctl->n;
+    const unsigned long long n_before = ctl_ld(&ctl->n);
     const bool capped = max_kmers >= 0 && (long long)n_before >= max_kmers;
     bool mark_last = false, contender = false;
     if (solid) {
@@ -309,7 +325,7 @@ __device__ void bfs_chunk_wide(const BfsState &S, const SolidView &t, WideLds &L
         const uint32_t wi = L.widx[L.set[slot]];
         if (wi != LH_EMPTY) atomicOr(&S.flags[wi], 2u);
     }
-    if (tid == 0) ctl->n = n_before + n_acc;
+    if (tid == 0) ctl_st(&ctl->n, n_before + n_acc);
     __syncthreads();
 }
 
@@ -494,17 +510,18 @@ __device__ __forceinline__ int solid_get4(const SolidView &t, uint64_t key, uint
     *aux = 0;
     if (key == EMPTY_KEY) return solid_get(t, key);
     const uint64_t s0 = solid_slot_of(t, key), base = s0 & ~(uint64_t)t.rmask;
-    uint4 a[4];
+    constexpr int NP = MC_SCOUT_PROBES;
+    uint4 a[NP];
 #pragma unroll
-    for (int i = 0; i < 4; i++) a[i] = *reinterpret_cast<const uint4 *>(t.slots + (base | ((s0 + i) & t.rmask)));
+    for (int i = 0; i < NP; i++) a[i] = *reinterpret_cast<const uint4 *>(t.slots + (base | ((s0 + i) & t.rmask)));
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < NP; i++) {
         const uint64_t cur = ((uint64_t)a[i].y << 32) | a[i].x;
         if (cur == key) { *aux = a[i].w; return a[i].z > 32767u ? 32767 : (int)a[i].z; }
         if (cur == EMPTY_KEY) return -1;
     }
-    uint64_t s = base | ((s0 + 4) & t.rmask);
-    for (uint32_t probe = 4; probe <= t.rmask; probe++) {
+    uint64_t s = base | ((s0 + NP) & t.rmask);
+    for (uint32_t probe = NP; probe <= t.rmask; probe++) {
         const uint4 raw = *reinterpret_cast<const uint4 *>(t.slots + s);
         const uint64_t cur = ((uint64_t)raw.y << 32) | raw.x;
         if (cur == key) { *aux = raw.w; return raw.z > 32767u ? 32767 : (int)raw.z; }
@@ -512,6 +529,139 @@ __device__ __forceinline__ int solid_get4(const SolidView &t, uint64_t key, uint
         s = base | ((s + 1) & t.rmask);
     }
     return -1;
+}
+
+// ---- one hop of a scout -------------------------------------------------------------------------------------------
+// What one candidate read adds to a walker's predicted path (one wave; every lane calls it).
+struct HopEval {
+    uint32_t m;           // (uniform) levels added; 0: the candidate failed
+    int why;              // (uniform) 0 ok, 1 the tip is not where the pointer says, 2 nothing solid behind it
+    bool fwd;             // (uniform) the read runs the walker's way
+    long long Q;          // (uniform) where the tip sits in the read store
+    uint64_t e_hi, e_lo;  // (uniform) the m new bases, first on top
+    Kmer K;               // (lane) the vertex lane + 1 levels past the tip, walk strand
+    uint32_t aux;         // (lane) its read pointer
+    bool other;           // (lane) ... which leads into another read than this one
+};
+
+template <int MODE>
+__device__ __forceinline__ void scout_eval(const SolidView &t, uint64_t *sw, const Kmer &X, int k, int min_cov, uint32_t cptr,
+                                           uint32_t delta, uint32_t want, HopEval &R, unsigned long long &lookups)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    R.m = 0; R.why = 1; R.fwd = true; R.Q = -1; R.e_hi = R.e_lo = 0; R.K = Kmer{0, 0}; R.aux = 0; R.other = false;
+    uint32_t span;
+    const uint64_t lo = ptr_decode(cptr, &span);
+    if (lo >= t.reads_bases) return;  // (a pointer from elsewhere)
+    const uint64_t last_word = (t.reads_bases + 31) / 32;  // the pad word
+    // the piece of the read store around the occurrence
+    const uint64_t wlo = (lo > 128 ? lo - 128 : 0) >> 5;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < SCOUT_WORDS) sw[lane] = t.reads[min(wlo + lane, last_word)];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint64_t base = wlo * 32;
+    const Kmer Xr = kmer_rc<MODE>(X, k);
+    // where is the tip?  `delta` bases after the pointer's k-mer in a read that runs our way, before it otherwise
+    long long Q = -1;
+    bool fwd = true;
+    for (uint32_t o0 = 0; o0 < span && Q < 0; o0 += 64) {
+        const uint32_t o = o0 + lane;
+        const uint64_t qf = lo + delta + o, qr = lo + o - delta;
+        const bool of = o < span && qf + (uint64_t)k <= t.reads_bases, orv = o < span && lo + o >= delta && qr + (uint64_t)k <= t.reads_bases;
+        const bool mf = of && kmer_eq(kmer_at<MODE>(sw, qf - base, k), X);
+        const bool mr = orv && kmer_eq(kmer_at<MODE>(sw, qr - base, k), Xr);
+        const unsigned long long bf = __ballot(mf), br = __ballot(mr);
+        if (bf) { Q = (long long)(lo + delta + o0 + (uint32_t)__builtin_ctzll(bf)); fwd = true; }
+        else if (br) { Q = (long long)(lo + o0 + (uint32_t)__builtin_ctzll(br)) - (long long)delta; fwd = false; }
+    }
+    if (Q < 0) return;
+    Q = (long long)uni64((uint64_t)Q);  // (wave-uniform: what follows from it can run on the scalar unit)
+    R.Q = Q; R.fwd = fwd; R.why = 2;
+    // lane i: the vertex i + 1 levels past the tip
+    Kmer K{0, 0};
+    bool ok = lane < want;
+    if (fwd) {
+        const uint64_t pi = (uint64_t)Q + 1 + lane;
+        ok = ok && pi + (uint64_t)k <= t.reads_bases;
+        if (ok) K = kmer_at<MODE>(sw, pi - base, k);
+    } else {
+        ok = ok && (uint64_t)Q >= (uint64_t)lane + 1;
+        if (ok) K = kmer_rc<MODE>(kmer_at<MODE>(sw, (uint64_t)Q - 1 - lane - base, k), k);
+    }
+    uint32_t aux = 0;
+    int cov = -1;
+    if (ok) {
+        cov = solid_get4(t, (uint64_t)key_of<MODE>(K, k), &aux);
+        lookups++;
+    }
+    const unsigned long long solid_m = __ballot(ok && cov >= min_cov);
+    const uint32_t m = solid_m == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~solid_m);
+    if (m == 0) return;
+    // the m new bases, first on top: what follows the occurrence (precedes it, complemented)
+    uint64_t e_hi, e_lo;
+    if (fwd) {
+        e_hi = bases32(sw, (uint32_t)((uint64_t)Q + (uint64_t)k - base));
+        e_lo = m > 32 ? bases32(sw, (uint32_t)((uint64_t)Q + (uint64_t)k + 32 - base)) : 0;
+    } else {
+        e_hi = bases32_before_rc(sw, (uint32_t)((uint64_t)Q - base));
+        e_lo = m > 32 ? bases32_before_rc(sw, (uint32_t)((uint64_t)Q - 32 - base)) : 0;
+    }
+    e_hi = uni64(e_hi);
+    e_lo = uni64(e_lo);
+    if (m < 32) e_hi &= ~0ull << (64 - 2 * m);
+    if (m <= 32) e_lo = 0; else if (m < 64) e_lo &= ~0ull << (128 - 2 * m);
+    bool other = aux != 0 && lane < m;
+    if (other) {  // does the pointer lead back into this very read?
+        uint32_t sp;
+        const uint64_t at = ptr_decode(aux, &sp);
+        const uint64_t here = fwd ? (uint64_t)Q + 1 + lane : (uint64_t)Q - 1 - lane;  // where this read holds lane's k-mer
+        other = !(at <= here && here < at + sp);
+    }
+    R.m = m; R.why = 0; R.e_hi = e_hi; R.e_lo = e_lo; R.K = K; R.aux = aux; R.other = other;
+}
+
+__device__ __forceinline__ void st_u64(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// the tail of a path under construction: words P[0 .. wi) are complete, `tailw` holds the next tail_n < 32 bases
+struct PathTail {
+    uint64_t tailw;
+    uint32_t tail_n, wi;
+};
+__device__ __forceinline__ PathTail path_open(uint64_t *P, const Kmer &X, int k, bool writer)
+{   // the walker's own k bases open the path
+    PathTail T;
+    T.wi = 0;
+    if (k <= 32) {
+        T.tailw = X.lo << (64 - 2 * k);
+        T.tail_n = (uint32_t)k;
+        if (k == 32) { if (writer) P[0] = T.tailw; T.tailw = 0; T.tail_n = 0; T.wi = 1; }
+    } else {
+        const uint64_t top = (X.hi << (128 - 2 * k)) | (X.lo >> (2 * k - 64));
+        if (writer) P[0] = top;
+        T.tailw = X.lo << (128 - 2 * k);
+        T.tail_n = (uint32_t)k - 32;
+        T.wi = 1;
+    }
+    return T;
+}
+// appends the m <= 64 bases e_hi:e_lo (first on top, unused bits zero); the partial tail word is stored too, so that a
+// reader may use every base appended so far
+__device__ __forceinline__ void path_append(uint64_t *P, PathTail &T, uint64_t e_hi, uint64_t e_lo, uint32_t m, bool writer)
+{
+    const uint32_t sh = 2 * T.tail_n;  // tail_n < 32
+    const uint64_t w0 = T.tailw | (sh ? e_hi >> sh : e_hi);
+    const uint64_t w1 = sh ? ((e_hi << (64 - sh)) | (e_lo >> sh)) : e_lo;
+    const uint64_t w2 = sh ? (e_lo << (64 - sh)) : 0;
+    const uint32_t total = T.tail_n + m, nfull = total >> 5;
+    if (writer) {  // (write-through stores: the reader may be a workgroup behind another L2)
+        st_u64(&P[T.wi], w0);
+        st_u64(&P[T.wi + 1], w1);
+        st_u64(&P[T.wi + 2], w2);
+        st_u64(&P[T.wi + 3], 0);
+    }
+    T.tailw = nfull == 0 ? w0 : (nfull == 1 ? w1 : w2);
+    T.wi += nfull;
+    T.tail_n = total & 31;
 }
 
 // The scout of walker `a` (one wave; every lane calls it).  From the walker's vertex it follows the reads: the slot of
@@ -529,23 +679,9 @@ __device__ void scout_run(const BfsState &S, const SolidView &t, NarrowLds &L, u
 {
     const uint32_t lane = threadIdx.x & 63;
     uint64_t *P = S.path + (uint64_t)a * PATH_WORDS;
-    uint64_t *sw = L.sw[a];
     const bool right = L.wright[a] != 0;
     Kmer X = right ? L.root[a] : kmer_rc<MODE>(L.root[a], k);  // the walk strand: the scout always appends
-    // the walker's own bases open the path
-    uint64_t tailw;
-    uint32_t tail_n, wi = 0;
-    if (k <= 32) {
-        tailw = X.lo << (64 - 2 * k);
-        tail_n = (uint32_t)k;
-        if (k == 32) { if (lane == 0) P[0] = tailw; tailw = 0; tail_n = 0; wi = 1; }
-    } else {
-        const uint64_t top = (X.hi << (128 - 2 * k)) | (X.lo >> (2 * k - 64));
-        if (lane == 0) P[0] = top;
-        tailw = X.lo << (128 - 2 * k);
-        tail_n = (uint32_t)k - 32;
-        wi = 1;
-    }
+    PathTail T = path_open(P, X, k, lane == 0);
     uint32_t cptr[4] = {0, 0, 0, 0}, cdelta[4] = {0, 0, 0, 0}, nc = 0;
     {
         uint32_t p0 = L.wptr[a];
@@ -556,113 +692,26 @@ __device__ void scout_run(const BfsState &S, const SolidView &t, NarrowLds &L, u
         if (p0) { cptr[0] = p0; nc = 1; }
     }
     uint32_t levels = 0, hops = 0, n_nf = 0, n_m0 = 0;
-#ifdef MC_BFS_TIMING
-    unsigned long long sacc[4] = {0, 0, 0, 0}, slast = __builtin_amdgcn_s_memrealtime();
-#define SC_STAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); sacc[i] += now_ - slast; slast = now_; } while (0)
-#else
-#define SC_STAMP(i) do {} while (0)
-#endif
-    const uint64_t last_word = (t.reads_bases + 31) / 32;  // the pad word
+    HopEval R;
     while (levels < budget && nc) {
         bool progressed = false;
         for (uint32_t ci = 0; ci < nc && !progressed; ci++) {
-            uint32_t span;
-            const uint64_t lo = ptr_decode(cptr[ci], &span);
-            const uint32_t delta = cdelta[ci];  // the candidate's k-mer sits `delta` levels before the tip
-            if (lo >= t.reads_bases) continue;  // (a pointer from elsewhere)
-            // the piece of the read store around the occurrence
-            const uint64_t wlo = (lo > 128 ? lo - 128 : 0) >> 5;
-            __builtin_amdgcn_wave_barrier();
-            SC_STAMP(3);
-            if (lane < SCOUT_WORDS) sw[lane] = t.reads[min(wlo + lane, last_word)];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            SC_STAMP(0);
-            const uint64_t base = wlo * 32;
-            const Kmer Xr = kmer_rc<MODE>(X, k);
-            // where is the tip?  `delta` bases after the pointer's k-mer in a read that runs our way, before it otherwise
-            long long Q = -1;
-            bool fwd = true;
-            for (uint32_t o0 = 0; o0 < span && Q < 0; o0 += 64) {
-                const uint32_t o = o0 + lane;
-                const uint64_t qf = lo + delta + o, qr = lo + o - delta;
-                const bool of = o < span && qf + (uint64_t)k <= t.reads_bases, orv = o < span && lo + o >= delta && qr + (uint64_t)k <= t.reads_bases;
-                const bool mf = of && kmer_eq(kmer_at<MODE>(sw, qf - base, k), X);
-                const bool mr = orv && kmer_eq(kmer_at<MODE>(sw, qr - base, k), Xr);
-                const unsigned long long bf = __ballot(mf), br = __ballot(mr);
-                if (bf) { Q = (long long)(lo + delta + o0 + (uint32_t)__builtin_ctzll(bf)); fwd = true; }
-                else if (br) { Q = (long long)(lo + o0 + (uint32_t)__builtin_ctzll(br)) - (long long)delta; fwd = false; }
-            }
-            if (Q < 0) { n_nf++; continue; }
-            Q = (long long)uni64((uint64_t)Q);  // (wave-uniform: what follows from it can run on the scalar unit)
+            scout_eval<MODE>(t, L.sw[a], X, k, min_cov, cptr[ci], cdelta[ci], min(64u, budget - levels), R, lookups);
+            if (R.why == 1) { n_nf++; continue; }
             hops++;
-            // lane i: the vertex i + 1 levels past the tip
-            const uint32_t want = min(64u, budget - levels);
-            Kmer K{0, 0};
-            bool ok = lane < want;
-            if (fwd) {
-                const uint64_t pi = (uint64_t)Q + 1 + lane;
-                ok = ok && pi + (uint64_t)k <= t.reads_bases;
-                if (ok) K = kmer_at<MODE>(sw, pi - base, k);
-            } else {
-                ok = ok && (uint64_t)Q >= (uint64_t)lane + 1;
-                if (ok) K = kmer_rc<MODE>(kmer_at<MODE>(sw, (uint64_t)Q - 1 - lane - base, k), k);
-            }
-            uint32_t aux = 0;
-            int cov = -1;
-            SC_STAMP(1);
-            if (ok) {
-                cov = solid_get4(t, (uint64_t)key_of<MODE>(K, k), &aux);
-                lookups++;
-            }
-            SC_STAMP(2);
-            const unsigned long long solid_m = __ballot(ok && cov >= min_cov);
-            const uint32_t m = solid_m == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~solid_m);
-            if (m == 0) { n_m0++; continue; }
-            // the m new bases, first on top: what follows the occurrence (precedes it, complemented)
-            uint64_t e_hi, e_lo;
-            if (fwd) {
-                e_hi = bases32(sw, (uint32_t)((uint64_t)Q + (uint64_t)k - base));
-                e_lo = m > 32 ? bases32(sw, (uint32_t)((uint64_t)Q + (uint64_t)k + 32 - base)) : 0;
-            } else {
-                e_hi = bases32_before_rc(sw, (uint32_t)((uint64_t)Q - base));
-                e_lo = m > 32 ? bases32_before_rc(sw, (uint32_t)((uint64_t)Q - 32 - base)) : 0;
-            }
-            e_hi = uni64(e_hi);
-            e_lo = uni64(e_lo);
-            if (m < 32) e_hi &= ~0ull << (64 - 2 * m);
-            if (m <= 32) e_lo = 0; else if (m < 64) e_lo &= ~0ull << (128 - 2 * m);
-            {
-                const uint32_t sh = 2 * tail_n;  // tail_n < 32
-                const uint64_t w0 = tailw | (sh ? e_hi >> sh : e_hi);
-                const uint64_t w1 = sh ? ((e_hi << (64 - sh)) | (e_lo >> sh)) : e_lo;
-                const uint64_t w2 = sh ? (e_lo << (64 - sh)) : 0;
-                const uint32_t total = tail_n + m, nfull = total >> 5;
-                if (lane == 0) {
-                    if (nfull >= 1) P[wi] = w0;
-                    if (nfull >= 2) P[wi + 1] = w1;
-                }
-                tailw = nfull == 0 ? w0 : (nfull == 1 ? w1 : w2);
-                wi += nfull;
-                tail_n = total & 31;
-            }
-            X.lo = readlane64(K.lo, m - 1);
-            X.hi = readlane64(K.hi, m - 1);
+            if (R.m == 0) { n_m0++; continue; }
+            const uint32_t m = R.m;
+            path_append(P, T, R.e_hi, R.e_lo, m, lane == 0);
+            X.lo = readlane64(R.K.lo, m - 1);
+            X.hi = readlane64(R.K.hi, m - 1);
             levels += m;
             // the next hop's candidates: the read pointers nearest to the tip that lead into OTHER reads than this one
-            bool other = aux != 0;
-            if (other) {
-                uint32_t sp;
-                const uint64_t at = ptr_decode(aux, &sp);
-                const uint64_t here = fwd ? (uint64_t)Q + 1 + lane : (uint64_t)Q - 1 - lane;  // where this read holds lane's k-mer
-                other = !(at <= here && here < at + sp);
-            }
-            unsigned long long cm = __ballot(lane < m && lane + 48 >= m && other);
+            unsigned long long cm = __ballot(lane < m && lane + 48 >= m && R.other);
             nc = 0;
             while (cm && nc < 4) {
                 const uint32_t j = 63u - (uint32_t)__builtin_clzll(cm);
                 cm &= ~(1ull << j);
-                cptr[nc] = (uint32_t)__builtin_amdgcn_readlane((int)aux, (int)j);
+                cptr[nc] = (uint32_t)__builtin_amdgcn_readlane((int)R.aux, (int)j);
                 cdelta[nc] = m - 1 - j;
                 nc++;
             }
@@ -671,9 +720,6 @@ __device__ void scout_run(const BfsState &S, const SolidView &t, NarrowLds &L, u
         if (!progressed) break;
     }
     if (lane == 0) {
-        P[wi] = tailw;
-        P[wi + 1] = 0;
-        P[wi + 2] = 0;
         L.plen[a] = levels;
         L.ppos[a] = 0;
         atomicAdd(&L.hops, (unsigned long long)hops);
@@ -681,11 +727,161 @@ __device__ void scout_run(const BfsState &S, const SolidView &t, NarrowLds &L, u
         atomicAdd(&L.s_calls, 1ull);
         atomicAdd(&L.s_nf, (unsigned long long)n_nf);
         atomicAdd(&L.s_m0, (unsigned long long)n_m0);
-#ifdef MC_BFS_TIMING
-        if (a == 0) printf("[scout a=0 job %u] hops %u levels %u  us: read fetch %.1f  match+extract %.1f  lookup %.1f  rest %.1f\n", blockIdx.x, hops, levels, sacc[0] * 0.01, sacc[1] * 0.01, sacc[2] * 0.01, sacc[3] * 0.01);
-#endif
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (the rounds read the path with L1-bypassing loads)
+}
+
+// ---- the companion: a second workgroup per job that scouts WHILE the first one verifies ------------------------------
+// The two talk through the job's ScoutBox in global memory.  The verifying workgroup posts a request -- its walkers,
+// their read pointers, a budget -- under a new sequence number; the companion's waves form one TEAM per walker (all
+// eight for a single walker): every member follows a different candidate read of the hop, the one that gets furthest
+// extends the path, publishes the new length (resp[a]: request number, a "finished" bit, levels so far) and names the
+// next candidates.  The verifier appends behind it and never waits for long: when no answer comes (the companion is
+// not running: grids larger than the chip holds at once) it scouts for itself as above, and a companion nobody talks
+// to leaves after a while.  A new request (the walk met something the prediction did not foresee) aborts the run.
+struct ScoutBox {
+    uint32_t req_seq, quit, F, budget;
+    uint64_t root_hi[SCOUT_MAX_F], root_lo[SCOUT_MAX_F];
+    uint32_t ptr[SCOUT_MAX_F], right[SCOUT_MAX_F];
+    uint32_t resp[SCOUT_MAX_F];  // (seq & 0x7FFF) << 17 | finished << 16 | levels
+    unsigned long long hops, levels, calls, nf, m0, iters, e_stuck, e_nc0, e_budget, e_stop;  // statistics (iters: team hops = round trips on the critical path / 2)
+};
+constexpr uint32_t BOX_WAIT_POLLS = 400;       // verifier: polls (~0.5 us each) before it gives the companion up
+constexpr uint32_t BOX_IDLE_POLLS = 40000;     // companion: polls without a request before it leaves
+__device__ __forceinline__ uint32_t ld_u32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_u32(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t box_resp(uint32_t seq, bool finished, uint32_t levels) { return ((seq & 0x7FFFu) << 17) | (finished ? 1u << 16 : 0u) | levels; }
+
+struct TeamLds {
+    Kmer X[SCOUT_MAX_F];  // tips, walk strand
+    PathTail T[SCOUT_MAX_F];
+    uint32_t levels[SCOUT_MAX_F], nc[SCOUT_MAX_F], stuck[SCOUT_MAX_F], right[SCOUT_MAX_F];
+    uint32_t cptr[SCOUT_MAX_F][8], cdelta[SCOUT_MAX_F][8];
+    uint32_t reach[BFS_THREADS / 64];
+    uint64_t sw[BFS_THREADS / 64][SCOUT_WORDS];
+    uint32_t seq, quit, F, budget, stop;
+};
+
+template <int MODE>
+__device__ void scout_companion(const BfsState &S, const SolidView &t, TeamLds &L, int k, int min_cov)
+{
+    ScoutBox *box = S.box;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr uint32_t W = BFS_THREADS / 64;
+    uint32_t last_seq = 0, idle = 0;
+    unsigned long long lookups = 0, hops = 0, n_nf = 0, n_m0 = 0, iters = 0;
+    for (;;) {
+        if (tid == 0) { L.seq = ld_u32(&box->req_seq); L.quit = ld_u32(&box->quit); }
+        __syncthreads();
+        const uint32_t seq = L.seq, quit = L.quit;
+        __syncthreads();
+        if (quit) break;
+        if (seq == last_seq) {
+            if (++idle > BOX_IDLE_POLLS) break;
+            __builtin_amdgcn_s_sleep(8);
+            continue;
+        }
+        idle = 0;
+        last_seq = seq;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // ---- the request
+        if (tid == 0) { L.F = ld_u32(&box->F); L.budget = ld_u32(&box->budget); L.stop = 0; }
+        if (tid < SCOUT_MAX_F) {
+            const Kmer root{ld_sc1(&box->root_hi[tid]), ld_sc1(&box->root_lo[tid])};
+            const uint32_t right = ld_u32(&box->right[tid]), p0 = ld_u32(&box->ptr[tid]);
+            L.right[tid] = right;
+            L.X[tid] = right ? root : kmer_rc<MODE>(root, k);
+            L.levels[tid] = 0;
+            L.stuck[tid] = p0 == 0;  // (the verifier looks the pointer up before it asks)
+            L.cptr[tid][0] = p0;
+            L.cdelta[tid][0] = 0;
+            L.nc[tid] = p0 ? 1 : 0;
+        }
+        __syncthreads();
+        const uint32_t F = min(L.F, (uint32_t)SCOUT_MAX_F), budget = min(L.budget, PATH_CAP);
+        if (F == 0) continue;
+        uint32_t Tm = min(W, (uint32_t)MC_TEAM_MAX);  // team size: the largest power of two with F * Tm <= W
+        while (Tm > 1 && F * Tm > W) Tm >>= 1;
+        const uint32_t g = wv / Tm, u = wv - g * Tm;
+        const bool member = g < F;
+        uint64_t *P = S.path + (uint64_t)g * PATH_WORDS;
+        if (member && u == 0) {
+            const PathTail T0 = path_open(P, L.X[g], k, lane == 0);
+            if (lane == 0) { L.T[g] = T0; P[T0.wi] = T0.tailw; P[T0.wi + 1] = 0; }
+        }
+        __syncthreads();
+        // ---- hops, all teams in step
+        HopEval R;
+        for (;;) {
+            uint32_t probe = seq;
+            if (tid == 0) probe = ld_u32(&box->req_seq) | (ld_u32(&box->quit) << 31);  // (used at the end of the hop)
+            R.m = 0;
+            const bool busy = member && !L.stuck[g] && L.levels[g] < budget;
+            if (busy && u < L.nc[g]) {
+                scout_eval<MODE>(t, L.sw[wv], L.X[g], k, min_cov, L.cptr[g][u], L.cdelta[g][u], min(64u, budget - L.levels[g]), R, lookups);
+                if (R.why == 1) n_nf += lane == 0; else { hops += lane == 0; if (R.m == 0) n_m0 += lane == 0; }
+            }
+            if (lane == 0) L.reach[wv] = R.m;
+            __syncthreads();
+            if (busy) {
+                uint32_t best = 0, best_u = 0;
+                for (uint32_t i = 0; i < Tm; i++) {
+                    const uint32_t r = L.reach[g * Tm + i];
+                    if (r > best) { best = r; best_u = i; }
+                }
+                if (best == 0) {
+                    if (u == 0 && lane == 0) { L.stuck[g] = 1; atomicAdd(&box->e_stuck, 1ull); }
+                } else if (u == best_u) {  // this wave's read got furthest: it extends the path and names the next candidates
+                    const uint32_t m = R.m;
+                    // the path words of the hops before this one have long arrived: the length that covers them goes out now
+                    // (a release fence right behind the stores would wait a microsecond for them on every hop)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    if (lane == 0 && L.levels[g]) st_u32(&box->resp[g], box_resp(seq, false, L.levels[g]));
+                    PathTail T = L.T[g];
+                    path_append(P, T, R.e_hi, R.e_lo, m, lane == 0);
+                    Kmer X;
+                    X.lo = readlane64(R.K.lo, m - 1);
+                    X.hi = readlane64(R.K.hi, m - 1);
+                    const uint32_t levels = L.levels[g] + m;
+                    // candidates: the pointers nearest to the tip that lead into other reads, one per read
+                    uint32_t sp;
+                    const uint64_t apos = R.aux ? ptr_decode(R.aux, &sp) : 0;
+                    unsigned long long cm = __ballot(lane < m && lane + 48 >= m && R.other);
+                    uint32_t nc = 0;
+                    while (cm && nc < Tm) {
+                        const uint32_t j = 63u - (uint32_t)__builtin_clzll(cm);
+                        const uint32_t cp = (uint32_t)__builtin_amdgcn_readlane((int)R.aux, (int)j);
+                        const uint64_t cpos = readlane64(apos, j);
+                        if (lane == 0) { L.cptr[g][nc] = cp; L.cdelta[g][nc] = m - 1 - j; }
+                        nc++;
+                        // lanes whose pointer sits in the same read at the matching distance add nothing
+                        const uint64_t d = (uint64_t)j - lane;  // (lanes above j are out of the mask already)
+                        cm &= ~__ballot(lane <= j && (apos + d == cpos || apos == cpos + d));
+                    }
+                    if (lane == 0) { L.T[g] = T; L.X[g] = X; L.levels[g] = levels; L.nc[g] = nc; if (nc == 0) { L.stuck[g] = 1; atomicAdd(&box->e_nc0, 1ull); } }
+                }
+            }
+            if (tid == 0 && probe != seq) L.stop = 1;
+            if (tid == 0) iters++;
+            __syncthreads();
+            bool any = false;
+            for (uint32_t a = 0; a < F; a++) any = any || (!L.stuck[a] && L.levels[a] < budget);
+            if (!any || L.stop) break;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (!L.stop && tid < F) st_u32(&box->resp[tid], box_resp(seq, true, L.levels[tid]));
+        if (tid == 0) { atomicAdd(&box->calls, 1ull); if (L.stop) atomicAdd(&box->e_stop, 1ull); else if (L.levels[0] >= budget) atomicAdd(&box->e_budget, 1ull); }
+        if (tid < F) atomicAdd(&box->levels, (unsigned long long)L.levels[tid]);
+        __syncthreads();
+    }
+    if (lane == 0) {
+        atomicAdd(&box->hops, hops);
+        atomicAdd(&box->nf, n_nf);
+        atomicAdd(&box->m0, n_m0);
+        if (tid == 0) atomicAdd(&box->iters, iters);
+    }
+    (void)lookups;
 }
 
 // The narrow walk.  All threads of the workgroup call it at a level boundary with a frontier of
@@ -703,9 +899,10 @@ __device__ void scout_run(const BfsState &S, const SolidView &t, NarrowLds &L, u
 template <int MODE>
 __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, int k, int min_cov,
                            long long max_kmers, long long max_radius, unsigned long long rounds_budget,
-                           unsigned long long &lookups)
+                           unsigned long long &lookups, bool companion)
 {
     BfsCtl *ctl = S.ctl;
+    ScoutBox *box = S.box;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int dir = S.dir;
     const int nb = dir == 0 ? 8 : 4;
@@ -717,8 +914,8 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
     unsigned long long rounds = 0, slow_rounds = 0;
     uint32_t div_f = 0, div_m = 0;  // div_m = ceil(2^16 / div_f)
     if (tid < 64) {
-        const unsigned long long lb = ctl->lb, le = ctl->le;
-        const long long level = ctl->level;
+        const unsigned long long lb = ctl_ld(&ctl->lb), le = ctl_ld(&ctl->le);
+        const long long level = ctl_ld(&ctl->level);
         const uint32_t F = (uint32_t)(le - lb);
         bool dup = false;
         if (lane < F) {
@@ -733,13 +930,16 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
             L.wptr[lane] = 0;
             L.wright[lane] = dir > 0 ? 1 : 0;
         }
-        if (lane < SCOUT_MAX_F) { L.plen[lane] = 0; L.ppos[lane] = 0; }
+        if (lane < SCOUT_MAX_F) { L.plen[lane] = 0; L.ppos[lane] = 0; L.pdone[lane] = 0; }
         const bool any = __ballot(dup) != 0;
         if (lane == 0) {
-            L.n = ctl->n; L.lb = lb; L.le = le; L.level = level; L.F = F; L.cur = 0;
+            L.n = ctl_ld(&ctl->n); L.lb = lb; L.le = le; L.level = level; L.F = F; L.cur = 0;
             L.status = BFS_RUNNING; L.any_dup_root = any ? 1 : 0; L.rounds_left = rounds_budget; L.pend = 0;
             L.scout_budget = SCOUT_BUDGET0; L.scout_skip = 0; L.scout_wait = 1; L.hops = 0; L.hop_levels = 0; L.s_calls = 0; L.s_nf = 0; L.s_m0 = 0;
             L.force_slow = dir == 0 ? 1 : 0;  // (both directions: which way a walker moves is known once it has stepped)
+            L.comp = companion && box != nullptr ? 1 : 0;
+            L.req_seq = L.comp ? ld_u32(&box->req_seq) : 0;
+            L.req_open = 0;
         }
     }
     __syncthreads();
@@ -761,6 +961,10 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
         const int cur = L.cur;
         const uint32_t pend = L.pend;
         const uint32_t skip0 = L.scout_skip, budget0 = L.scout_budget, fslow0 = L.force_slow;  // (tid 0 changes them mid-round)
+        const uint32_t comp0 = L.comp, open0 = L.req_open, seq0 = L.req_seq;
+        // what the companion has published meanwhile (applied at the end of the round; a little stale is fine)
+        uint32_t resp_now = 0;
+        if (comp0 && open0 && tid < F) resp_now = ld_u32(&box->resp[tid]);
         bool dec_skip = false;
         if (F == 0) { if (tid == 0) L.status = BFS_DONE; break; }
         if (F > flim) break;
@@ -789,7 +993,63 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
         if (may_spec && Hcap >= 2) {
             avail = 0xFFFFFFFFu;
             for (uint32_t a = 0; a < F; a++) avail = min(avail, L.plen[a] - L.ppos[a]);
-            if (avail == 0 && skip0 == 0) {
+            if (avail == 0 && skip0 != 0) dec_skip = true;  // (applied at the end of the round, behind its barriers)
+            bool inline_scout = avail == 0 && skip0 == 0 && !comp0;
+            if (avail == 0 && skip0 == 0 && comp0) {
+                // ---- the companion scouts: ask it (a new request when there is none, or the last one is used up), then
+                // wait until every walker has something ahead of it (or is known to have nothing)
+                bool used_up = true;
+                for (uint32_t a = 0; a < F; a++) used_up = used_up && L.pdone[a] != 0;
+                uint32_t seq = seq0;
+                if (!open0 || used_up) {
+                    seq = seq0 + 1;
+                    if (tid < F) {
+                        uint32_t p0 = L.wptr[tid];
+                        if (p0 == 0) {  // the walker's k-mer has not been looked up with its pointer yet
+                            (void)solid_get(t, (uint64_t)key_of<MODE>(L.root[tid], k), &p0);
+                            lookups++;
+                            L.wptr[tid] = p0;
+                        }
+                        box->root_hi[tid] = L.root[tid].hi;
+                        box->root_lo[tid] = L.root[tid].lo;
+                        box->ptr[tid] = p0;
+                        box->right[tid] = L.wright[tid];
+                    }
+                    if (tid == 0) { box->F = F; box->budget = (uint32_t)min((long long)PATH_CAP, lv_left); }
+                    if (tid < SCOUT_MAX_F) { L.plen[tid] = 0; L.ppos[tid] = 0; L.pdone[tid] = 0; }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    __syncthreads();
+                    if (tid == 0) { st_u32(&box->req_seq, seq); L.req_seq = seq; L.req_open = 1; }
+                }
+                bool ready = false;
+                for (uint32_t polls = 0; polls <= BOX_WAIT_POLLS && !ready; polls++) {
+                    if (tid < F) {
+                        const uint32_t r = ld_u32(&box->resp[tid]);
+                        if ((r >> 17) == (seq & 0x7FFFu)) { L.plen[tid] = r & 0xFFFFu; L.pdone[tid] = (r >> 16) & 1u; }
+                    }
+                    __syncthreads();
+                    ready = true;
+                    for (uint32_t a = 0; a < F; a++) ready = ready && (L.plen[a] > L.ppos[a] || L.pdone[a]);
+                    __syncthreads();
+                    if (!ready) __builtin_amdgcn_s_sleep(4);
+                }
+                if (ready) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    avail = 0xFFFFFFFFu;
+                    for (uint32_t a = 0; a < F; a++) avail = min(avail, L.plen[a] - L.ppos[a]);
+                    load_pseg(F);
+                    __syncthreads();
+                    if (tid == 0) {
+                        if (avail == 0) { L.scout_skip = L.scout_wait; L.scout_wait = min(L.scout_wait * 2, 64u); L.req_open = 0; } else L.scout_wait = 1;
+                    }
+                } else {  // no answer: the companion is not there; this workgroup scouts for itself from now on
+                    if (tid == 0) { L.comp = 0; L.req_open = 0; }
+                    if (tid < SCOUT_MAX_F) { L.plen[tid] = 0; L.ppos[tid] = 0; L.pdone[tid] = 0; }
+                    __syncthreads();
+                    inline_scout = true;
+                }
+            }
+            if (inline_scout) {
                 const uint32_t budget = (uint32_t)min((long long)min(budget0, PATH_CAP), lv_left);
                 if (wv < F) scout_run<MODE>(S, t, L, wv, k, min_cov, budget, lookups);
                 __syncthreads();
@@ -802,8 +1062,6 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
                     // a walker nobody can predict (no pointer, a dead end ahead): plain levels for a while, longer every time
                     if (avail == 0) { L.scout_skip = L.scout_wait; L.scout_wait = min(L.scout_wait * 2, 64u); } else L.scout_wait = 1;
                 }
-            } else if (avail == 0) {
-                dec_skip = true;  // (applied at the end of the round, behind its barriers)
             }
             H = max(1u, min(avail, Hcap));
         }
@@ -956,6 +1214,12 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
                 if (J < H) L.force_slow = 1;  // the level behind them is something else: replayed exactly by the next round
                 if (dec_skip) L.scout_skip = skip0 - 1;
             }
+            if (comp0 && open0 && tid < F && L.req_seq == seq0 && (resp_now >> 17) == (seq0 & 0x7FFFu)) {  // how far the companion has got meanwhile (same request)
+                if ((resp_now & 0xFFFFu) >= L.plen[tid]) {  // (the wait above may have seen a later answer already)
+                    L.plen[tid] = resp_now & 0xFFFFu;
+                    L.pdone[tid] = (resp_now >> 16) & 1u;
+                }
+            }
             __syncthreads();
             load_pseg(F);
             MC_STAMP(4);
@@ -987,13 +1251,15 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
                     L.wright[lane] = right ? 1 : 0;
                     L.fl_w[c2][lane] = lane;  // walkers are numbered 0..F-1 in the next round
                 }
-                if (lane < SCOUT_MAX_F) { L.plen[lane] = 0; L.ppos[lane] = 0; }  // the walkers changed: their paths are void
+                if (lane < SCOUT_MAX_F) { L.plen[lane] = 0; L.ppos[lane] = 0; L.pdone[lane] = 0; }  // the walkers changed: their paths are void
                 if (lane == 0) {
                     L.any_dup_root = 0;
                     L.pend = 0;
                     L.rounds_left--;
                     if (fslow0) L.scout_budget = SCOUT_BUDGET0;
+                    if (fslow0) atomicAdd(&ctl->slow_forced, 1ull); else if (H > 1) atomicAdd(&ctl->slow_mismatch, 1ull); else atomicAdd(&ctl->slow_starved, 1ull);
                     L.force_slow = 0;
+                    L.req_open = 0;  // (the companion's run, if any, is for walkers that no longer exist)
                     if (dec_skip) L.scout_skip = skip0 - 1;
                 }
             }
@@ -1010,11 +1276,11 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
     __syncthreads();
     if (tid == 0) {
         L.pend = 0;
-        ctl->n = L.n;
-        ctl->lb = L.lb;
-        ctl->le = L.le;
-        ctl->c0 = 0;
-        ctl->level = L.level;
+        ctl_st(&ctl->n, L.n);
+        ctl_st(&ctl->lb, L.lb);
+        ctl_st(&ctl->le, L.le);
+        ctl_st(&ctl->c0, 0);
+        ctl_st(&ctl->level, L.level);
         ctl->rounds_narrow += rounds;
         ctl->rounds_slow += slow_rounds;
         ctl->scout_hops += L.hops;
@@ -1022,7 +1288,7 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
         ctl->scout_calls += L.s_calls;
         ctl->scout_nf += L.s_nf;
         ctl->scout_m0 += L.s_m0;
-        if (L.status != BFS_RUNNING) ctl->status = L.status;
+        if (L.status != BFS_RUNNING) ctl_st(&ctl->status, L.status);
 #ifdef MC_BFS_TIMING
         for (int i = 0; i < 8; i++) ctl->tacc[i] += tacc[i];
 #endif
@@ -1030,28 +1296,42 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
     __syncthreads();
 }
 
+union BfsLds {
+    WideLds w;
+    NarrowLds n;
+    TeamLds t;
+};
+
 template <int MODE>
 __global__ void __launch_bounds__(BFS_THREADS) k_bfs(const BfsState *__restrict__ states, SolidView t, int k,
                                                      int min_cov, long long max_kmers, long long max_radius,
-                                                     unsigned long long max_rounds)
+                                                     unsigned long long max_rounds, int companions)
 {
+    // companions: two workgroups per job -- 2j walks (this function), 2j + 1 scouts for it (scout_companion)
     __shared__ BfsLds lds;
-    const BfsState S = states[blockIdx.x];
+    const BfsState S = states[companions ? blockIdx.x >> 1 : blockIdx.x];
     BfsCtl *ctl = S.ctl;
-    if (ctl->status != BFS_RUNNING) return;  // finished (or waiting for the host) in an earlier launch
     const uint32_t tid = threadIdx.x;
+    if (companions && (blockIdx.x & 1u)) {
+        if (S.box && t.reads) scout_companion<MODE>(S, t, lds.t, k, min_cov);
+        return;
+    }
+    if (ctl_ld(&ctl->status) != BFS_RUNNING) {  // finished (or waiting for the host) in an earlier launch
+        if (companions && S.box && tid == 0) st_u32(&S.box->quit, 1u);
+        return;
+    }
     unsigned long long lookups = 0, rounds_left = max_rounds, chunks = 0;
     const int dir = S.dir;
     const int nb = dir == 0 ? 8 : 4;
     const uint32_t flim = NARROW_CAND / nb;
 
     // seeds: every window with reads.get(key) >= minOccurences, in order (:159-192)
-    if (!ctl->seeds_done) {
+    if (!ctl_ld(&ctl->seeds_done)) {
         for (;;) {
-            const unsigned long long c0 = ctl->c0;
+            const unsigned long long c0 = ctl_ld(&ctl->c0);
             if (c0 >= S.n_seeds) break;
-            if (ctl->n + BFS_THREADS > S.dcap) {
-                if (tid == 0) ctl->status = BFS_NEED_GROW;
+            if (ctl_ld(&ctl->n) + BFS_THREADS > S.dcap) {
+                if (tid == 0) ctl_st(&ctl->status, BFS_NEED_GROW);
                 goto out;
             }
             if (rounds_left == 0) goto out;
@@ -1063,44 +1343,44 @@ __global__ void __launch_bounds__(BFS_THREADS) k_bfs(const BfsState *__restrict_
             if (have) { cand.hi = S.seed_hi ? S.seed_hi[r] : 0; cand.lo = S.seed_lo[r]; }
             __syncthreads();
             bfs_chunk_wide<MODE>(S, t, lds.w, k, min_cov, -1, true, have, cand, UINT64_MAX, 0, lookups);
-            if (tid == 0) ctl->c0 = c0 + BFS_THREADS;
+            if (tid == 0) ctl_st(&ctl->c0, c0 + BFS_THREADS);
             __syncthreads();
         }
         if (tid == 0) {
-            ctl->seeds_done = 1;
-            ctl->lb = 0;
-            ctl->le = ctl->n;
-            ctl->c0 = 0;
-            ctl->level = 0;
+            ctl_st(&ctl->seeds_done, 1);
+            ctl_st(&ctl->lb, 0);
+            ctl_st(&ctl->le, ctl_ld(&ctl->n));
+            ctl_st(&ctl->c0, 0);
+            ctl_st(&ctl->level, 0);
         }
         __syncthreads();
     }
 
     for (;;) {
-        const unsigned long long lb = ctl->lb, le = ctl->le;
+        const unsigned long long lb = ctl_ld(&ctl->lb), le = ctl_ld(&ctl->le);
         if (le == lb) {
-            if (tid == 0) ctl->status = BFS_DONE;
+            if (tid == 0) ctl_st(&ctl->status, BFS_DONE);
             break;
         }
-        if (ctl->status != BFS_RUNNING) break;
+        if (ctl_ld(&ctl->status) != BFS_RUNNING) break;
         if (rounds_left == 0) break;
-        if (ctl->c0 == 0 && le - lb <= flim) {
+        if (ctl_ld(&ctl->c0) == 0 && le - lb <= flim) {
             __syncthreads();
-            bfs_narrow<MODE>(S, t, lds.n, k, min_cov, max_kmers, max_radius, rounds_left, lookups);
+            bfs_narrow<MODE>(S, t, lds.n, k, min_cov, max_kmers, max_radius, rounds_left, lookups, companions != 0);
             rounds_left = lds.n.rounds_left;
             __syncthreads();
-            if (ctl->status != BFS_RUNNING) break;  // done, or distanceToKmer must grow
-            if (ctl->le - ctl->lb <= flim && ctl->le != ctl->lb) break;  // round budget used up: relaunch
+            if (ctl_ld(&ctl->status) != BFS_RUNNING) break;  // done, or distanceToKmer must grow
+            if (ctl_ld(&ctl->le) - ctl_ld(&ctl->lb) <= flim && ctl_ld(&ctl->le) != ctl_ld(&ctl->lb)) break;  // round budget used up: relaunch
             continue;
         }
-        const long long level = ctl->level;
+        const long long level = ctl_ld(&ctl->level);
         const bool radius_ok = max_radius < 0 || level + 1 <= max_radius;  // newDistance > threshold -> false
         const unsigned long long ncand = (le - lb) * (unsigned long long)nb;
         for (;;) {
-            const unsigned long long c0 = ctl->c0;
+            const unsigned long long c0 = ctl_ld(&ctl->c0);
             if (c0 >= ncand) break;
-            if (ctl->n + BFS_THREADS > S.dcap) {
-                if (tid == 0) ctl->status = BFS_NEED_GROW;
+            if (ctl_ld(&ctl->n) + BFS_THREADS > S.dcap) {
+                if (tid == 0) ctl_st(&ctl->status, BFS_NEED_GROW);
                 goto out;
             }
             if (rounds_left == 0) goto out;
@@ -1118,20 +1398,21 @@ __global__ void __launch_bounds__(BFS_THREADS) k_bfs(const BfsState *__restrict_
             __syncthreads();
             bfs_chunk_wide<MODE>(S, t, lds.w, k, min_cov, max_kmers, radius_ok, have, cand, parent,
                                  (int32_t)(level + 1), lookups);
-            if (tid == 0) ctl->c0 = c0 + BFS_THREADS;
+            if (tid == 0) ctl_st(&ctl->c0, c0 + BFS_THREADS);
             __syncthreads();
         }
         if (tid == 0) {
-            ctl->lb = le;
-            ctl->le = ctl->n;
-            ctl->c0 = 0;
-            ctl->level = level + 1;
+            ctl_st(&ctl->lb, le);
+            ctl_st(&ctl->le, ctl_ld(&ctl->n));
+            ctl_st(&ctl->c0, 0);
+            ctl_st(&ctl->level, level + 1);
         }
         __syncthreads();
     }
 out:
     atomicAdd(&ctl->lookups, lookups);
     if (tid == 0) atomicAdd(&ctl->chunks_wide, chunks);
+    if (companions && S.box && tid == 0) st_u32(&S.box->quit, 1u);  // (on every way out: the companion leaves with us)
 }
 
 // rebuild the index of distanceToKmer after the host enlarged it

@@ -957,6 +957,10 @@ __global__ void k_sk_add_unmerged(const uint4 *__restrict__ leaf_recs, const uin
 // of the graph would all lead into the same read, which is no help once the walk has used that read up (ptr_pick).
 // ptr_tries > 1 (records of other ranks carry no pointer): the next occurrences try too while the slot has none.
 constexpr uint32_t P3_COUNT_CAP = 1u << 30;
+#ifndef MC_PTR_LATE
+#define MC_PTR_LATE 0   // 1: a later occurrence (one of sixteen) replaces the early pointer (kmer_device.h ptr_pick_late): more different reads
+                        // near a scout's tip, but + 0.6 ms in this kernel for 0.1 ms of walk on configs[1]
+#endif
 
 struct MergeLds {
     uint64_t key[REGION_SLOTS];
@@ -981,7 +985,8 @@ struct P3Emit {
 
 
 // one occurrence of `key` into the region held in LDS; false when the region is full
-__device__ __forceinline__ bool lds_region_add(MergeLds &L, uint64_t key, uint32_t hint, uint32_t home, uint32_t &my_new, uint32_t pick)
+__device__ __forceinline__ bool lds_region_add(MergeLds &L, uint64_t key, uint32_t hint, uint32_t home, uint32_t &my_new, uint32_t pick,
+                                               uint32_t pick2)
 {
     uint32_t s = home;
     for (uint32_t probe = 0; probe < REGION_SLOTS; probe++) {
@@ -993,7 +998,7 @@ __device__ __forceinline__ bool lds_region_add(MergeLds &L, uint64_t key, uint32
         }
         if (cur == key) {
             const uint32_t seen = atomicAdd(&L.cnt[s], 1u);
-            if (hint && (seen == pick || L.aux[s] == 0)) L.aux[s] = hint;  // (racy on purpose: any occurrence's pointer will do)
+            if (hint && (seen == pick || seen == pick2 || L.aux[s] == 0)) L.aux[s] = hint;  // (racy on purpose: any occurrence's pointer will do)
             return true;
         }
         s = (s + 1) & (REGION_SLOTS - 1);
@@ -1097,7 +1102,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                     // records are in flight meanwhile.
                     const uint4 *recs = static_cast<const uint4 *>(leaf_keys) + ((uint64_t)leaf * nseg + sgm) * seg_cap;
                     const uint32_t *ptrs = leaf_hints + ((uint64_t)leaf * nseg + sgm) * seg_cap;
-                    const uint32_t ptr_from = solid_thr >= 2 ? 1u : 0u, ptr_last = ptr_from + 3 + ptr_tries - 1;
+                    const uint32_t ptr_from = solid_thr >= 2 ? 1u : 0u, ptr_last = ptr_from + (MC_PTR_LATE ? 19 : 3) + ptr_tries - 1;
                     uint8_t *dq = L.dq[wv];
                     uint32_t *sq = L.sq[wv];
                     // the waves share the segment's records evenly (in batches of 64): the barrier behind the merge
@@ -1162,10 +1167,14 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                             if (done) {
                                 const uint32_t seen = atomicAdd(&L.cnt[s], 1u);
                                 if (seen >= ptr_from && seen <= ptr_last) {
-                                    const uint32_t first = ptr_pick(key, ptr_from, solid_thr);
-                                    if (seen >= first && seen < first + ptr_tries) {
+#if MC_PTR_LATE
+                                    const uint32_t first = ptr_pick(key, ptr_from, solid_thr), late = ptr_pick_late(key, ptr_from);
+#else
+                                    const uint32_t first = ptr_pick(key, ptr_from, solid_thr), late = first;
+#endif
+                                    if ((seen >= first && seen < first + ptr_tries) || seen == late) {
                                         const uint32_t p0 = sq[src_c];
-                                        if (p0 && (seen == first || L.aux[s] == 0)) L.aux[s] = ptr_advance(p0, j);
+                                        if (p0 && (seen == first || seen == late || L.aux[s] == 0)) L.aux[s] = ptr_advance(p0, j);
                                     }
                                 }
                             } else {
@@ -1193,7 +1202,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                         const uint64_t gslot = slot_of(t, key);
                         if (g && (gslot >> 12) != region) continue;
                         const bool done = lds_region_add(L, key, hh[u], (uint32_t)gslot & (REGION_SLOTS - 1), my_new,
-                                                         ptr_pick(key, solid_thr >= 2 ? 1u : 0u, solid_thr));
+                                                         ptr_pick(key, solid_thr >= 2 ? 1u : 0u, solid_thr), ptr_pick_late(key, solid_thr >= 2 ? 1u : 0u));
                         if (!done) atomicExch(&L.overflow, 1u);
                     }
                 }

@@ -200,6 +200,13 @@ __host__ __device__ __forceinline__ uint32_t ptr_pick(uint64_t key, uint32_t ptr
     return ptr_from + (room >= 4 ? r : r % room);
 }
 
+// ... and a later occurrence, one of sixteen, replaces it when the key has that many: the early arrivals of all the
+// k-mers of a stretch are the same few reads, and a scout that has just used those up wants pointers into others.
+__host__ __device__ __forceinline__ uint32_t ptr_pick_late(uint64_t key, uint32_t ptr_from)
+{
+    return ptr_from + 4 + ((uint32_t)((key >> 3) ^ (key >> 17) ^ (key >> 41)) & 15u);
+}
+
 // reverse complement of an oriented k-mer of up to 64 bases (two words, right-aligned)
 __host__ __device__ __forceinline__ uint64_t rc64_pairs(uint64_t x)
 {  // reverses the 32 2-bit groups of a word and complements them
@@ -338,8 +345,8 @@ __host__ __device__ __forceinline__ uint64_t slot_of(const TableView &t, uint64_
 // wave (one hot counter address hammered by every insert costs more than the inserts themselves).
 // *before (optional): the key's count before this addition (0 for a new key).
 __device__ __forceinline__ uint32_t table_add(const TableView &t, uint64_t key, uint32_t inc, uint32_t hint = 0,
-                                              uint32_t *before = nullptr, uint32_t pick = 0)
-{   // pick != 0: the occurrence that finds `pick` before it replaces the inserter's read pointer with its own (ptr_pick)
+                                              uint32_t *before = nullptr, uint32_t pick = 0, uint32_t pick2 = 0)
+{   // pick != 0: the occurrences that find `pick` / `pick2` before them replace the inserter's read pointer with their own (ptr_pick)
     if (before) *before = 0;
     if (key == EMPTY_KEY) {
         const unsigned long long old = atomicAdd(t.empty_cnt, (unsigned long long)inc);
@@ -367,14 +374,14 @@ __device__ __forceinline__ uint32_t table_add(const TableView &t, uint64_t key, 
             if (cur == key) {
                 const uint32_t old = atomicAdd(&p->count, inc);
                 if (before) *before = old;
-                if (pick && hint && old == pick) p->aux = hint;
+                if (pick && hint && (old == pick || old == pick2)) p->aux = hint;
                 return 0;
             }
         } else if (cur == key) {
             if (raw.z < 0x80000000u) {
                 const uint32_t old = atomicAdd(&p->count, inc);
                 if (before) *before = old;
-                if (pick && hint && old == pick) p->aux = hint;
+                if (pick && hint && (old == pick || old == pick2)) p->aux = hint;
             } else if (before) {
                 *before = raw.z;
             }

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
@@ -48,6 +49,7 @@ struct BfsJobBuffers {
         free_arrays();
         (void)hipFree(S.ctl);
         (void)hipFree(S.path);
+        (void)hipFree(S.box);
         (void)hipFree(d_seed_hi);
         (void)hipFree(d_seed_lo);
     }
@@ -227,7 +229,7 @@ __global__ void __launch_bounds__(256) k_count_reads(const uint64_t *__restrict_
             const Kmer v = extract_kmer(words, b + w, k);
             const uint64_t key = (uint64_t)key_of<MODE>(v, k);
             // (the inserter leaves its place in the read store; the occurrence ptr_pick names replaces it)
-            n_new += table_add(t, key, 1u, ptr_base == ~0ull ? 0u : ptr_encode(ptr_base + b + w), nullptr, ptr_pick(key, thr >= 2 ? 1u : 0u, thr));
+            n_new += table_add(t, key, 1u, ptr_base == ~0ull ? 0u : ptr_encode(ptr_base + b + w), nullptr, ptr_pick(key, thr >= 2 ? 1u : 0u, thr), ptr_pick_late(key, thr >= 2 ? 1u : 0u));
         }
     }
     wave_add_ull(t.n_used, n_new);
@@ -2403,21 +2405,22 @@ int ensure_solid(mc_ctx *c, int min_cov, double *ms)
 }
 
 void launch_bfs(mc_ctx *c, hipStream_t stream, const BfsState *d_states, uint32_t n_jobs, int min_cov, int64_t max_kmers,
-                int64_t max_radius, unsigned long long max_rounds)
+                int64_t max_radius, unsigned long long max_rounds, int companions)
 {
     const SolidView t = c->solid_view();
+    if (companions) n_jobs *= 2;
     switch (c->cfg.key_mode) {
     case MC_KEY_PACKED:
         hipLaunchKernelGGL(k_bfs<KEY_PACKED>, dim3(n_jobs), dim3(BFS_THREADS), 0, stream, d_states, t, c->cfg.k,
-                           min_cov, (long long)max_kmers, (long long)max_radius, max_rounds);
+                           min_cov, (long long)max_kmers, (long long)max_radius, max_rounds, companions);
         break;
     case MC_KEY_POLY:
         hipLaunchKernelGGL(k_bfs<KEY_POLY>, dim3(n_jobs), dim3(BFS_THREADS), 0, stream, d_states, t, c->cfg.k,
-                           min_cov, (long long)max_kmers, (long long)max_radius, max_rounds);
+                           min_cov, (long long)max_kmers, (long long)max_radius, max_rounds, companions);
         break;
     default:
         hipLaunchKernelGGL(k_bfs<KEY_FNV1A>, dim3(n_jobs), dim3(BFS_THREADS), 0, stream, d_states, t, c->cfg.k,
-                           min_cov, (long long)max_kmers, (long long)max_radius, max_rounds);
+                           min_cov, (long long)max_kmers, (long long)max_radius, max_rounds, companions);
     }
 }
 
@@ -2513,6 +2516,7 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
         }
         if (!S.ctl) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&S.ctl), sizeof(BfsCtl)));
         if (!S.path) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&S.path), (size_t)SCOUT_MAX_F * PATH_WORDS * 8));
+        if (!S.box) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&S.box), sizeof(ScoutBox)));
         HIPCHK(c, hipMemsetAsync(S.ctl, 0, sizeof(BfsCtl), c->stream));
         S.seed_hi = jobs[j].seed_hi ? J.d_seed_hi : nullptr;
         S.seed_lo = J.d_seed_lo;
@@ -2524,12 +2528,24 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
     std::vector<BfsState> h_states(n_jobs);
     std::vector<BfsCtl> ctl(n_jobs);
     const unsigned long long max_rounds = 1ull << 17;  // bounds one launch; unfinished jobs are relaunched
+    std::vector<std::array<unsigned long long, 4>> box_e(n_jobs, std::array<unsigned long long, 4>{0, 0, 0, 0});
+    std::vector<unsigned long long> box_iters(n_jobs, 0), box_hops(n_jobs, 0), box_levels(n_jobs, 0), box_calls(n_jobs, 0), box_nf(n_jobs, 0), box_m0(n_jobs, 0);
     for (;;) {
         for (uint32_t j = 0; j < n_jobs; j++) h_states[j] = B[j]->S;
         HIPCHK(c, hipMemcpyAsync(d_states.p, h_states.data(), n_jobs * sizeof(BfsState), hipMemcpyHostToDevice,
                                  c->stream));
-        int rc = timed(c, &total_ms, [&] { launch_bfs(c, c->stream, d_states.p, n_jobs, min_cov, max_kmers, max_radius, max_rounds); });
+        // Few jobs: each gets a second workgroup that scouts ahead while the first verifies (bfs_device.h ScoutBox).  The
+        // pair must be on the chip together to gain anything (it is correct either way), so not for large batches.
+        static const bool no_comp = getenv("MC_BFS_COMPANION") && !strcmp(getenv("MC_BFS_COMPANION"), "0");
+        const int companions = !no_comp && n_jobs <= 64 && c->solid_view().reads != nullptr ? 1 : 0;
+        for (uint32_t j = 0; j < n_jobs; j++) HIPCHK(c, hipMemsetAsync(B[j]->S.box, 0, sizeof(ScoutBox), c->stream));
+        int rc = timed(c, &total_ms, [&] { launch_bfs(c, c->stream, d_states.p, n_jobs, min_cov, max_kmers, max_radius, max_rounds, companions); });
         if (rc) return rc;
+        for (uint32_t j = 0; j < n_jobs && companions; j++) {
+            ScoutBox hb;
+            HIPCHK(c, hipMemcpy(&hb, B[j]->S.box, sizeof hb, hipMemcpyDeviceToHost));
+            box_iters[j] += hb.iters; box_e[j][0] += hb.e_stuck; box_e[j][1] += hb.e_nc0; box_e[j][2] += hb.e_budget; box_e[j][3] += hb.e_stop; box_hops[j] += hb.hops; box_levels[j] += hb.levels; box_calls[j] += hb.calls; box_nf[j] += hb.nf; box_m0[j] += hb.m0;
+        }
         bool all_done = true;
         for (uint32_t j = 0; j < n_jobs; j++) {
             HIPCHK(c, hipMemcpy(&ctl[j], B[j]->S.ctl, sizeof(BfsCtl), hipMemcpyDeviceToHost));
@@ -2567,14 +2583,17 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
         const uint64_t n = ctl[j].n;
         mc_bfs_result *o = &out[j];
         o->lookups = ctl[j].lookups;
-        o->rounds = ctl[j].rounds_narrow + ctl[j].chunks_wide + 2 * ctl[j].scout_hops;  // (a scout hop: the read, then its k-mers)
+        // (a scout hop: the read, then its k-mers; the members of a companion's team hop side by side)
+        o->rounds = ctl[j].rounds_narrow + ctl[j].chunks_wide + 2 * (ctl[j].scout_hops + box_iters[j]);
         o->device_ms = total_ms;
         {
             static const bool stats = getenv("MC_BFS_STATS") != nullptr;
+            if (stats) fprintf(stderr, "[bfs job %u] slow rounds: after a partly verified round %llu, first level mismatch %llu, nothing predicted %llu; companion runs ended: stuck %llu, no candidates %llu, budget %llu, aborted %llu\n",
+                               j, ctl[j].slow_forced, ctl[j].slow_mismatch, ctl[j].slow_starved, box_e[j][0], box_e[j][1], box_e[j][2], box_e[j][3]);
             if (stats)
-                fprintf(stderr, "[bfs job %u] n=%llu level=%lld rounds_narrow=%llu (slow %llu) chunks_wide=%llu scout calls=%llu hops=%llu levels=%llu notfound=%llu m0=%llu lookups=%llu\n", j,
-                        ctl[j].n, ctl[j].level, ctl[j].rounds_narrow, ctl[j].rounds_slow, ctl[j].chunks_wide, ctl[j].scout_calls, ctl[j].scout_hops, ctl[j].scout_levels,
-                        ctl[j].scout_nf, ctl[j].scout_m0, ctl[j].lookups);
+                fprintf(stderr, "[bfs job %u] n=%llu level=%lld rounds_narrow=%llu (slow %llu) chunks_wide=%llu scout calls=%llu hops=%llu (team hops %llu) levels=%llu notfound=%llu m0=%llu lookups=%llu\n", j,
+                        ctl[j].n, ctl[j].level, ctl[j].rounds_narrow, ctl[j].rounds_slow, ctl[j].chunks_wide, ctl[j].scout_calls + box_calls[j], ctl[j].scout_hops + box_hops[j], box_iters[j],
+                        ctl[j].scout_levels + box_levels[j], ctl[j].scout_nf + box_nf[j], ctl[j].scout_m0 + box_m0[j], ctl[j].lookups);
         }
 #ifdef MC_BFS_TIMING
         {

@@ -58,5 +58,10 @@ def assert_bfs_equal(got, want):
     if got is None:
         return
     for f in ("hi", "lo", "dist", "cov", "last"):
-        assert np.array_equal(got[f], want[f]), f
+        if not np.array_equal(got[f], want[f]):  # say where: the first entries that differ, with their distances
+            g, w = np.asarray(got[f]), np.asarray(want[f])
+            m = min(len(g), len(w))
+            idx = np.nonzero(g[:m] != w[:m])[0][:8]
+            raise AssertionError("%s: %d vs %d entries, first differences at %s: got %s want %s (dist %s, n=%d)" % (
+                f, len(g), len(w), idx, g[idx], w[idx], np.asarray(want["dist"])[idx], len(w)))
     assert got["levels"] == want["levels"]
