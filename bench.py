@@ -84,7 +84,7 @@ def main():
     est_distinct = int(min(world * windows, genome_bases + world * n_bases * (args.err / 10000.0) * k * 0.7))
     hint_local = args.capacity_hint or est_distinct // world + (1 << 20)
 
-    ctx = m.Context(k, mode, local_rank, hint_local)
+    ctx = m.Context(k, mode, local_rank, hint_local, m.native.FLAG_SOLID_LIST if world > 1 else 0)
     ctx.set_coverage_hint(args.coverage)  # --coverage is known before the reads are loaded (the CLI does the same)
     solid = None
     if world > 1 and rank == 0:

@@ -61,13 +61,17 @@ extern "C" {
  * colliding k-mers share a counter, as in the reference. */
 enum { MC_KEY_PACKED = 0, MC_KEY_POLY = 1, MC_KEY_FNV1A = 2 };
 
+/* mc_config.flags.  MC_FLAG_SOLID_LIST: the k-mers at or above the coverage hint will be exported (a shard of a
+ * multi-GPU run, mc_export_dev): the counting pass then lists them as it goes, which saves the export a table sweep. */
+#define MC_FLAG_SOLID_LIST 1
+
 typedef struct mc_ctx mc_ctx;
 
 typedef struct {
     int32_t k;              /* 1..31 for MC_KEY_PACKED, 1..63 for the hash modes */
     int32_t key_mode;       /* MC_KEY_* */
     int32_t device;         /* HIP device ordinal */
-    int32_t flags;          /* 0 */
+    int32_t flags;          /* MC_FLAG_* */
     uint64_t capacity_hint; /* expected number of distinct keys; 0 = start small and grow */
 } mc_config;
 

@@ -33,6 +33,7 @@ constexpr uint32_t PATH_CAP = 1u << 15;               // levels one scout run ma
 constexpr uint32_t PATH_WORDS = (PATH_CAP + 64 + 96) / 32 + 4;  // the walker's own k bases + the levels, 32 bases per word
 constexpr uint32_t PSEG_WORDS = 12;                   // path words a round needs: (31 + MAX_NODES / 4 + 63 + 1) bases and one to spare
 constexpr uint32_t SCOUT_WORDS = 16;                  // read-store words a hop looks at
+constexpr uint32_t SCOUT_MH = 64 + SK_M + 2;          // minimizer hashes a hop looks at (64 new vertices + the tip's own)
 constexpr uint32_t SCOUT_BUDGET0 = 1024;              // levels of the first scout run; doubled after every run the rounds used up
 #ifndef MC_TEAM_MAX
 #define MC_TEAM_MAX 2   // waves that follow different candidate reads of one walker's hop (measured on configs[1], BFS phase: 1 wave 14.0 ms,
@@ -236,6 +237,7 @@ struct NarrowLds {
     uint32_t plen[SCOUT_MAX_F], ppos[SCOUT_MAX_F];  // predicted path of walker a: levels written / levels used up
     uint64_t pseg[SCOUT_MAX_F][PSEG_WORDS];         // the path words this round reads, from word ppos / 32 on
     uint64_t sw[SCOUT_MAX_F][SCOUT_WORDS];          // scout: the piece of the read store a hop looks at
+    uint32_t mh[SCOUT_MAX_F][SCOUT_MH];             //        and the minimizer hashes along it
     uint32_t naux[MAX_NODES];         // read pointer found with each node's k-mer
     int16_t cov[MAX_NODES];
     uint8_t vis[MAX_NODES];
@@ -250,7 +252,7 @@ struct NarrowLds {
     uint32_t F;
     uint32_t bad_lvl, pend;
     uint32_t scout_budget, scout_skip, scout_wait, force_slow;
-    uint32_t comp, req_seq, req_open, ready;  // the companion (ScoutBox): usable, the last request, one is outstanding, its answer is in
+    uint32_t comp, req_seq, req_open, ready, root_bad;  // the companion (ScoutBox): usable, the last request, one is outstanding, its answer is in
     uint32_t pdone[SCOUT_MAX_F];              // the companion finished walker a's path
     unsigned long long hops, hop_levels, s_calls, s_nf, s_m0;
     int cur, status, any_dup_root;
@@ -505,11 +507,11 @@ __device__ __forceinline__ Kmer kmer_rc(const Kmer &v, int k)
 
 // lookup with the first four probe slots requested at once: the lanes of a wave look different keys up, and the
 // slowest one decides -- at load 1/4 one in ~8 lookups needs a second probe, nearly none a fifth
-__device__ __forceinline__ int solid_get4(const SolidView &t, uint64_t key, uint32_t *aux)
-{
+__device__ __forceinline__ int solid_get4(const SolidView &t, uint64_t key, uint32_t *aux, uint64_t s0)
+{   // s0 = solid_slot_of(t, key)
     *aux = 0;
     if (key == EMPTY_KEY) return solid_get(t, key);
-    const uint64_t s0 = solid_slot_of(t, key), base = s0 & ~(uint64_t)t.rmask;
+    const uint64_t base = s0 & ~(uint64_t)t.rmask;
     constexpr int NP = MC_SCOUT_PROBES;
     uint4 a[NP];
 #pragma unroll
@@ -544,8 +546,9 @@ struct HopEval {
     bool other;           // (lane) ... which leads into another read than this one
 };
 
+// sw, mh: this wave's LDS scratch (SCOUT_WORDS words of the read store; SCOUT_MH minimizer hashes)
 template <int MODE>
-__device__ __forceinline__ void scout_eval(const SolidView &t, uint64_t *sw, const Kmer &X, int k, int min_cov, uint32_t cptr,
+__device__ __forceinline__ void scout_eval(const SolidView &t, uint64_t *sw, uint32_t *mh, const Kmer &X, int k, int min_cov, uint32_t cptr,
                                            uint32_t delta, uint32_t want, HopEval &R, unsigned long long &lookups)
 {
     const uint32_t lane = threadIdx.x & 63;
@@ -591,8 +594,27 @@ __device__ __forceinline__ void scout_eval(const SolidView &t, uint64_t *sw, con
     }
     uint32_t aux = 0;
     int cov = -1;
+    const uint64_t key = ok ? (uint64_t)key_of<MODE>(K, k) : 0;
+    uint64_t s0;
+    if (MODE == KEY_PACKED && t.mm_k) {
+        // The counting table's regions are minimizer bins (kmer_device.h).  The vertices of consecutive lanes overlap in
+        // all but one base, so every SK_M-mer is hashed once -- a lane hashes the last one of its own vertex, the first
+        // lanes also the ones inside the tip -- and a lane takes the minimum over its w of them (w = k - SK_M + 1).
+        const uint32_t w = (uint32_t)k - SK_M + 1;
+        auto mm_hash = [](uint32_t f) { const uint32_t r = sk_rc_mmer(f); return sk_order(f < r ? f : r); };
+        __builtin_amdgcn_wave_barrier();
+        if (lane + 1 < w) mh[lane] = mm_hash((uint32_t)(X.lo >> (2 * (w - 2 - lane))) & SK_MMASK);  // the tip's SK_M-mers from base lane + 1 on
+        mh[w - 1 + lane] = ok ? mm_hash((uint32_t)K.lo & SK_MMASK) : SK_NONE;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t hmin = SK_NONE;
+        for (uint32_t i = 0; i < w; i++) hmin = min(hmin, mh[lane + i]);
+        s0 = ((((uint64_t)sk_bin(hmin) * t.n_regions) >> 32) << 12) | sk_home(key);
+    } else {
+        s0 = solid_slot_of(t, key);
+    }
     if (ok) {
-        cov = solid_get4(t, (uint64_t)key_of<MODE>(K, k), &aux);
+        cov = solid_get4(t, key, &aux, s0);
         lookups++;
     }
     const unsigned long long solid_m = __ballot(ok && cov >= min_cov);
@@ -696,7 +718,7 @@ __device__ void scout_run(const BfsState &S, const SolidView &t, NarrowLds &L, u
     while (levels < budget && nc) {
         bool progressed = false;
         for (uint32_t ci = 0; ci < nc && !progressed; ci++) {
-            scout_eval<MODE>(t, L.sw[a], X, k, min_cov, cptr[ci], cdelta[ci], min(64u, budget - levels), R, lookups);
+            scout_eval<MODE>(t, L.sw[a], L.mh[a], X, k, min_cov, cptr[ci], cdelta[ci], min(64u, budget - levels), R, lookups);
             if (R.why == 1) { n_nf++; continue; }
             hops++;
             if (R.m == 0) { n_m0++; continue; }
@@ -759,7 +781,9 @@ struct TeamLds {
     uint32_t cptr[SCOUT_MAX_F][8], cdelta[SCOUT_MAX_F][8];
     uint32_t reach[BFS_THREADS / 64];
     uint64_t sw[BFS_THREADS / 64][SCOUT_WORDS];
+    uint32_t mh[BFS_THREADS / 64][SCOUT_MH];
     uint32_t seq, quit, F, budget, stop;
+    uint32_t published[SCOUT_MAX_F];  // levels whose path words are known to have arrived
 };
 
 template <int MODE>
@@ -792,6 +816,7 @@ __device__ void scout_companion(const BfsState &S, const SolidView &t, TeamLds &
             L.right[tid] = right;
             L.X[tid] = right ? root : kmer_rc<MODE>(root, k);
             L.levels[tid] = 0;
+            L.published[tid] = 0;
             L.stuck[tid] = p0 == 0;  // (the verifier looks the pointer up before it asks)
             L.cptr[tid][0] = p0;
             L.cdelta[tid][0] = 0;
@@ -818,11 +843,20 @@ __device__ void scout_companion(const BfsState &S, const SolidView &t, TeamLds &
             R.m = 0;
             const bool busy = member && !L.stuck[g] && L.levels[g] < budget;
             if (busy && u < L.nc[g]) {
-                scout_eval<MODE>(t, L.sw[wv], L.X[g], k, min_cov, L.cptr[g][u], L.cdelta[g][u], min(64u, budget - L.levels[g]), R, lookups);
+                scout_eval<MODE>(t, L.sw[wv], L.mh[wv], L.X[g], k, min_cov, L.cptr[g][u], L.cdelta[g][u], min(64u, budget - L.levels[g]), R, lookups);
                 if (R.why == 1) n_nf += lane == 0; else { hops += lane == 0; if (R.m == 0) n_m0 += lane == 0; }
             }
             if (lane == 0) L.reach[wv] = R.m;
+            // The length the previous hop added is published now: its path words (write-through stores) were issued before
+            // this hop's two round trips and every wave waits here for the stores it has outstanding, so they have arrived
+            // -- a release fence at agent scope right behind the stores would cost a cache write-back on every hop.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            const uint32_t lv_done = tid < F ? L.levels[tid] : 0;  // (read before the barrier: this hop's winner changes it behind it)
             __syncthreads();
+            if (tid < F && lv_done != L.published[tid]) {
+                st_u32(&box->resp[tid], box_resp(seq, false, lv_done));
+                L.published[tid] = lv_done;
+            }
             if (busy) {
                 uint32_t best = 0, best_u = 0;
                 for (uint32_t i = 0; i < Tm; i++) {
@@ -833,10 +867,6 @@ __device__ void scout_companion(const BfsState &S, const SolidView &t, TeamLds &
                     if (u == 0 && lane == 0) { L.stuck[g] = 1; atomicAdd(&box->e_stuck, 1ull); }
                 } else if (u == best_u) {  // this wave's read got furthest: it extends the path and names the next candidates
                     const uint32_t m = R.m;
-                    // the path words of the hops before this one have long arrived: the length that covers them goes out now
-                    // (a release fence right behind the stores would wait a microsecond for them on every hop)
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    if (lane == 0 && L.levels[g]) st_u32(&box->resp[g], box_resp(seq, false, L.levels[g]));
                     PathTail T = L.T[g];
                     path_append(P, T, R.e_hi, R.e_lo, m, lane == 0);
                     Kmer X;
@@ -940,6 +970,7 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
             L.comp = companion && box != nullptr ? 1 : 0;
             L.req_seq = L.comp ? ld_u32(&box->req_seq) : 0;
             L.req_open = 0;
+            L.root_bad = 0;
         }
     }
     __syncthreads();
@@ -1078,6 +1109,7 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
         uint32_t naux = 0;
         uint64_t key = 0, s0 = 0;
         uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+        bool root_bad = false;
         if (tid < H * FN) {
             const uint32_t tl = tid;
             const uint32_t lvl = ((tl >> lg) * div_m) >> 16;  // tl / FN
@@ -1101,6 +1133,10 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
                     hb = (uint32_t)(L.pseg[na][qn >> 5] >> (62 - 2 * (qn & 31))) & 3u;
                 }
                 v = right ? x : kmer_rc<MODE>(x, k);
+                // The path must start at the walker itself.  It does whenever the scout's words arrived in order; but a
+                // path is only ever a guess, and a stale one -- another walker's, an earlier request's -- is a chain of the
+                // graph that would pass every check below: the walker's own k-mer is the one thing they cannot share.
+                root_bad = lvl == 0 && !kmer_eq(v, L.root[na]);  // (applied with the other checks, behind the barrier)
                 const uint32_t ob = right ? hb : (3u ^ hb);  // ... as seen from the vertex itself
                 const uint32_t cstar = dir == 0 ? (2 * ob + (right ? 1u : 0u)) : ob;
                 npred = c == cstar;
@@ -1168,11 +1204,28 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
             L.vis[tid] = ind ? 1 : 0;  // (level 1 only matters: the one-level replay reads it)
             const bool ok = npred ? (solid && !ind) : (!solid || ind);
             if (!ok && H > 1) atomicMin(&L.bad_lvl, ni);
+            if (root_bad) L.root_bad = 1;
         }
         __syncthreads();
         MC_STAMP(3);
         uint32_t J = 0;
         if (H > 1) J = min(H, L.bad_lvl - 1);
+        if (L.root_bad) {
+            // the path does not start at the walker: none of this round's nodes means anything (the one-level replay below
+            // takes level 1 to be the walkers' own neighbours).  The paths are dropped and the next round is a plain one.
+            __syncthreads();
+            if (tid < SCOUT_MAX_F) { L.plen[tid] = 0; L.ppos[tid] = 0; L.pdone[tid] = 0; }
+            if (tid == 0) {
+                L.root_bad = 0;
+                L.force_slow = 1;
+                L.req_open = 0;
+                L.rounds_left--;
+                if (dec_skip) L.scout_skip = skip0 - 1;
+                atomicAdd(&ctl->slow_mismatch, 1ull);
+            }
+            __syncthreads();
+            continue;
+        }
 
         if (J >= 1) {
             // ---- levels 1..J are exactly "every walker steps to its expected vertex"

@@ -407,7 +407,8 @@ __device__ __forceinline__ uint32_t crosses(uint32_t before, uint32_t inc, uint3
 }
 
 // ---------------------------------------------------------------------------------------------
-// The "solid" table: the BFS's private copy of the keys with count >= --coverage, at a load factor
+// The "solid" table: a BFS-only context's copy of the keys with count >= --coverage (the gathered shards of a
+// multi-GPU run; MC_BFS_DIRECT=0 builds it on one GPU too), at a load factor
 // <= 1/4 so that its (mostly negative) lookups end at the first probe.  Same 16-byte slots as the counting table
 // {key, count (already saturated), read pointer}, regions of SOLID_REGION slots, always indexed by the key's own
 // hash (a BFS lookup must not pay for a minimizer).  The view also carries the read store the pointers refer to.
@@ -419,9 +420,18 @@ struct SolidView {
     uint32_t *fatal;
     const uint64_t *reads;  // packed bases of the read store (nullptr: none), one readable pad word behind them
     uint64_t reads_bases;
+    // The BFS of the context that counted the reads walks the counting table itself (no copy to build): then regions
+    // are those of the TableView -- minimizer bins when mm_k != 0 -- and counts are clamped when read, as by table_get.
+    int mm_k;
+    uint32_t n_regions;
 };
 
-__device__ __forceinline__ uint64_t solid_slot_of(const SolidView &t, uint64_t key) { return fmix64(key) >> t.shift; }
+__device__ __forceinline__ uint64_t solid_slot_of(const SolidView &t, uint64_t key)
+{
+    if (t.mm_k == 0) return fmix64(key) >> t.shift;
+    const uint64_t region = ((uint64_t)sk_bin(sk_hmin_of_kmer(key, t.mm_k)) * t.n_regions) >> 32;
+    return (region << 12) | sk_home(key);
+}
 
 // count (saturated) or -1; *aux (may be null) = the slot's read pointer
 __device__ __forceinline__ int solid_get(const SolidView &t, uint64_t key, uint32_t *aux = nullptr)

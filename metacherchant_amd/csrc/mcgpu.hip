@@ -94,6 +94,9 @@ struct mc_ctx {
     uint32_t solid_lg = 0;
     int solid_cov = -1;  // -1: not built / stale
     bool solid_external = false;  // built by mc_solid_from_pairs_dev, not from this context's counting table
+    bool bfs_direct = true;       // the BFS walks the counting table itself instead of a solid copy (MC_BFS_DIRECT=0: copy)
+    bool solid_is_table = false;  // ... and does so now (solid_view)
+    bool want_list = false;       // the merge kernel lists the solid keys (count_pipeline.h P3Emit): for exports, and for the copy
     int solid_external_cov = -1;
     double pending_solid_ms = 0;
     uint64_t n_solid = 0;
@@ -142,6 +145,15 @@ struct mc_ctx {
         t.slots = solid;
         t.shift = 64 - solid_lg;
         t.rmask = (1u << 11) - 1;  // SOLID_REGION - 1
+        t.mm_k = 0;
+        t.n_regions = 0;
+        if (solid_is_table) {  // the counting table itself
+            t.slots = slots;
+            t.shift = 64 - (rb + sb);
+            t.rmask = (1u << sb) - 1;
+            t.mm_k = mm_k;
+            t.n_regions = (uint32_t)n_regions;
+        }
         t.empty_cnt = d_ctr + 1;
         t.fatal = d_fatal;
         const mc_ctx *rs = rs_from ? rs_from : this;
@@ -1033,7 +1045,7 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1)
     const int p3_grid = (int)std::min<uint64_t>(n_leaves, 256 * 2 * 4);
     P3Emit emit{nullptr, nullptr, 0, P.flags + 2};
     static const bool no_list = getenv("MC_NO_SOLID_LIST") != nullptr;
-    if (pl.sk && pl.b2 > 1 && c->mm_k && c->solid_tracked && c->cov_hint > 0 && !no_list) {
+    if (pl.sk && pl.b2 > 1 && c->mm_k && c->solid_tracked && c->cov_hint > 0 && !no_list && c->want_list) {
         if (!P.emit_counts) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.emit_counts), 256 * 2 * 4 * sizeof(uint32_t)));
         HIPCHK(c, hipMemsetAsync(P.emit_counts, 0, 256 * 2 * 4 * sizeof(uint32_t), c->stream));
         emit.recs = P.a_recs;
@@ -1449,6 +1461,8 @@ int mc_create(const mc_config *cfg, mc_ctx **out)
     CREATE_CHK(hipMemsetAsync(c->d_fatal, 0, sizeof(uint32_t), c->stream));
 #undef CREATE_CHK
     if (const char *e = getenv("MC_COUNT_PATH")) c->count_path = !strcmp(e, "direct") ? 1 : !strcmp(e, "partition") ? 2 : 0;
+    if (const char *e = getenv("MC_BFS_DIRECT")) c->bfs_direct = strcmp(e, "0") != 0;
+    c->want_list = (cfg->flags & MC_FLAG_SOLID_LIST) != 0 || !c->bfs_direct;
     // packed keys of at least SK_MIN_K bases: table regions = minimizer bins, reads counted as super-k-mers
     // (MC_SUPERKMERS=0 keeps the per-window pipeline: for A/B measurements)
     if (cfg->key_mode == MC_KEY_PACKED && cfg->k >= SK_MIN_K) c->mm_k = cfg->k;
@@ -2379,6 +2393,12 @@ int solid_build(mc_ctx *c, uint64_t n, int min_cov, double *ms, const PairSource
 // Builds (or reuses) the solid table for this threshold.
 int ensure_solid(mc_ctx *c, int min_cov, double *ms)
 {
+    if (c->bfs_direct && !c->solid_external) {  // the walk looks its k-mers up in the counting table: nothing to build
+        c->solid_is_table = true;
+        c->solid_cov = min_cov;
+        return MC_OK;
+    }
+    c->solid_is_table = false;
     if (c->solid_cov == min_cov && c->solid) return MC_OK;
     if (c->solid_external)
         return fail(c, MC_ESTATE, "this context's solid table came from mc_solid_from_pairs_dev at coverage %d; it serves that threshold only",
@@ -2438,6 +2458,7 @@ int mc_solid_from_pairs_dev(mc_ctx *c, const int64_t *d_keys, const int16_t *d_c
     HIPCHK(c, hipSetDevice(c->cfg.device));
     c->solid_cov = -1;
     c->solid_external = false;
+    c->solid_is_table = false;
     unsigned long long *cursor = c->d_ctr + 2;
     HIPCHK(c, hipMemsetAsync(cursor, 0, sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_ctr + 1, 0, sizeof(unsigned long long), c->stream));  // the out-of-band count of EMPTY_KEY

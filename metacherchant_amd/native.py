@@ -9,6 +9,7 @@ import numpy as np
 from . import build as _build
 
 KEY_PACKED, KEY_POLY, KEY_FNV1A = 0, 1, 2
+FLAG_SOLID_LIST = 1  # mc_config.flags: this context is a shard whose solid k-mers will be exported
 MC_ENOSEED = -6
 
 
@@ -141,10 +142,10 @@ def _dptr(x):
 class Context:
     """One k-mer table on one GPU = the BigLong2ShortHashMap of one tool run."""
 
-    def __init__(self, k, key_mode=KEY_PACKED, device=0, capacity_hint=0):
+    def __init__(self, k, key_mode=KEY_PACKED, device=0, capacity_hint=0, flags=0):
         self._L = load()
         self.k, self.key_mode, self.device = k, key_mode, device
-        cfg = _Config(k, key_mode, device, 0, capacity_hint)
+        cfg = _Config(k, key_mode, device, flags, capacity_hint)
         h = C.c_void_p()
         rc = self._L.mc_create(C.byref(cfg), C.byref(h))
         if rc != 0:

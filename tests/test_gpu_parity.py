@@ -234,6 +234,7 @@ def test_coverage_hint_tracks_solid_count_over_batches(mc, monkeypatch):
     needs no counting sweep, and the walk is the same as without the hint.  A different threshold, or an
     addition through another kernel, falls back to the sweep."""
     monkeypatch.setenv("MC_COUNT_PATH", "partition")
+    monkeypatch.setenv("MC_BFS_DIRECT", "0")  # (the walk on a copy of the solid k-mers; by default it reads the counting table itself)
     genome, reads, off = synth_case(2, 30000, 12000, 150, 50)
     t, _ = oracle_table(reads, off, 31, po.KEY_PACKED)
     half = 6000
@@ -264,6 +265,7 @@ def test_solid_list_from_the_merge_kernel(mc, monkeypatch):
     sweeping the counting table: same walks; the list is rebuilt by every batch, dropped when another kernel adds
     keys, and not used for another threshold."""
     monkeypatch.delenv("MC_COUNT_PATH", raising=False)  # batches of 4.8 M windows take the pipeline by themselves
+    monkeypatch.setenv("MC_BFS_DIRECT", "0")  # (the BFS table as a copy built from the list; by default the walk reads the counting table itself)
     genome, reads, off = synth_case(2, 200000, 80000, 150, 50)  # > 2^18 solid k-mers: a two-level build of the BFS table
     t, _ = oracle_table(reads, off, 31, po.KEY_PACKED)
     half = 40000
