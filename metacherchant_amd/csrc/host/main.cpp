@@ -397,55 +397,70 @@ int run(const Options &o)
         calcs.push_back(c);
     }
     const std::vector<int> dirs = pass_dirs(o.bothdirs);
-    // all passes of all calculators go to the GPU in one batch
-    std::vector<std::vector<uint64_t>> shi(calcs.size()), slo(calcs.size());
-    std::vector<mc_bfs_job> jobs;
-    for (size_t c = 0; c < calcs.size(); c++) {
-        if (!o.merge) info("Finding environment for sequence " + shorten_label(calcs[c].bfs_seqs[0], o.k));
-        else info("Finding single environment for " + std::to_string(seeds.dnas.size()) + " sequences");
-        for (const std::string &s : calcs[c].bfs_seqs)
-            for (size_t i = 0; i + (size_t)o.k <= s.size(); i++) {
-                uint64_t hi, lo;
-                pack_kmer(s.substr(i, (size_t)o.k), &hi, &lo);
-                shi[c].push_back(hi);
-                slo[c].push_back(lo);
-            }
-        for (int d : dirs) jobs.push_back(mc_bfs_job{shi[c].data(), slo[c].data(), shi[c].size(), d});
-    }
-    std::vector<mc_bfs_result> res(jobs.size());
-    if (!jobs.empty())
-        MC_CHECK(ctx, mc_bfs_batch(ctx, jobs.data(), (uint32_t)jobs.size(), o.coverage, o.maxkmers, o.maxradius, res.data()));
-    const auto t2 = std::chrono::steady_clock::now();
+    // The passes of up to CHUNK_JOBS / dirs calculators go to the GPU in one batch (the reference runs one
+    // OneSequenceCalculator per sequence on a thread pool, EnvironmentFinderMain.java:218-225, without a limit on their
+    // number): a chunk's environments are written and its results freed before the next one starts, so neither the job
+    // count of mc_bfs_batch nor the memory of the per-job arrays grows with the number of seed sequences.
+    constexpr size_t CHUNK_JOBS = 256;
+    const size_t calcs_per_chunk = std::max<size_t>(1, CHUNK_JOBS / dirs.size());
+    double bfs_ms = 0, out_ms = 0;
+    auto ms_between = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    for (size_t c0 = 0; c0 < calcs.size(); c0 += calcs_per_chunk) {
+        const size_t c1 = std::min(calcs.size(), c0 + calcs_per_chunk);
+        const auto tb0 = std::chrono::steady_clock::now();
+        std::vector<std::vector<uint64_t>> shi(c1 - c0), slo(c1 - c0);
+        std::vector<mc_bfs_job> jobs;
+        for (size_t c = c0; c < c1; c++) {
+            if (!o.merge) info("Finding environment for sequence " + shorten_label(calcs[c].bfs_seqs[0], o.k));
+            else info("Finding single environment for " + std::to_string(seeds.dnas.size()) + " sequences");
+            for (const std::string &s : calcs[c].bfs_seqs)
+                for (size_t i = 0; i + (size_t)o.k <= s.size(); i++) {
+                    uint64_t hi, lo;
+                    pack_kmer(s.substr(i, (size_t)o.k), &hi, &lo);
+                    shi[c - c0].push_back(hi);
+                    slo[c - c0].push_back(lo);
+                }
+            for (int d : dirs) jobs.push_back(mc_bfs_job{shi[c - c0].data(), slo[c - c0].data(), shi[c - c0].size(), d});
+        }
+        std::vector<mc_bfs_result> res(jobs.size());
+        struct ResGuard {  // (an exception below must not leak the library's result arrays)
+            std::vector<mc_bfs_result> &r;
+            ~ResGuard() { for (auto &x : r) mc_bfs_result_free(&x); }
+        } guard{res};
+        if (!jobs.empty())
+            MC_CHECK(ctx, mc_bfs_batch(ctx, jobs.data(), (uint32_t)jobs.size(), o.coverage, o.maxkmers, o.maxradius, res.data()));
+        const auto tb1 = std::chrono::steady_clock::now();
+        bfs_ms += ms_between(tb0, tb1);
 
-    size_t j = 0;
-    for (size_t c = 0; c < calcs.size(); c++) {
-        Environment env(o.k, calcs[c].genes);
-        bool fail = false;
-        for (size_t d = 0; d < dirs.size(); d++, j++) {
-            mc_bfs_result &r = res[j];
-            if (r.n == 0) { fail = true; continue; }  // runBfs: queue.size() == 0 -> fail (:193-196)
-            if (fail) continue;
-            BfsPass p;
-            p.dir = dirs[d];
-            p.kmers.reserve(r.n);
-            for (uint64_t i = 0; i < r.n; i++) p.kmers.push_back(((kmer_t)r.hi[i] << 64) | r.lo[i]);
-            p.dist.assign(r.dist, r.dist + r.n);
-            p.cov.assign(r.cov, r.cov + r.n);
-            p.last.assign(r.last, r.last + r.n);
-            env.add_pass(p, o.trim);
+        size_t j = 0;
+        for (size_t c = c0; c < c1; c++) {
+            Environment env(o.k, calcs[c].genes);
+            bool fail = false;
+            for (size_t d = 0; d < dirs.size(); d++, j++) {
+                mc_bfs_result &r = res[j];
+                if (r.n == 0) { fail = true; continue; }  // runBfs: queue.size() == 0 -> fail (:193-196)
+                if (fail) continue;
+                BfsPass p;
+                p.dir = dirs[d];
+                p.kmers.reserve(r.n);
+                for (uint64_t i = 0; i < r.n; i++) p.kmers.push_back(((kmer_t)r.hi[i] << 64) | r.lo[i]);
+                p.dist.assign(r.dist, r.dist + r.n);
+                p.cov.assign(r.cov, r.cov + r.n);
+                p.last.assign(r.last, r.last + r.n);
+                env.add_pass(p, o.trim);
+            }
+            if (fail) {
+                info("Could not find any k-mers of the target gene in the input, halting.");
+                continue;
+            }
+            info("Extending endings by 0 kmers");  // extendEnvironment never adds anything
+            if (!env.order_guaranteed())
+                logline("WARN", "a java.util.HashMap bin would have been treeified: line order of " + calcs[c].out_prefix +
+                                " may differ from the JVM's inside that bin");
+            env.write_all(calcs[c].out_prefix, o.chunklength);
         }
-        if (fail) {
-            info("Could not find any k-mers of the target gene in the input, halting.");
-            continue;
-        }
-        info("Extending endings by 0 kmers");  // extendEnvironment never adds anything
-        if (!env.order_guaranteed())
-            logline("WARN", "a java.util.HashMap bin would have been treeified: line order of " + calcs[c].out_prefix +
-                            " may differ from the JVM's inside that bin");
-        env.write_all(calcs[c].out_prefix, o.chunklength);
+        out_ms += ms_between(tb1, std::chrono::steady_clock::now());
     }
-    for (auto &r : res) mc_bfs_result_free(&r);
-    const auto t3 = std::chrono::steady_clock::now();
     info("Finished processing all sequences!");
 
     mc_stats stt{};
@@ -455,8 +470,8 @@ int run(const Options &o)
     snprintf(buf, sizeof buf,
              "{\"windows\": %llu, \"distinct_kmers\": %llu, \"load_and_count_ms\": %.3f, \"count_kernel_ms\": %.3f, "
              "\"bfs_ms\": %.3f, \"output_ms\": %.3f, \"table_bytes\": %llu}\n",
-             (unsigned long long)stt.windows, (unsigned long long)n_distinct, ms(t0, t1), stt.count_total_ms, ms(t1, t2),
-             ms(t2, t3), (unsigned long long)stt.table_bytes);
+             (unsigned long long)stt.windows, (unsigned long long)n_distinct, ms(t0, t1), stt.count_total_ms, bfs_ms,
+             out_ms, (unsigned long long)stt.table_bytes);
     write_file(wd + "/metrics.json", buf);
     write_file(wd + "/SUCCESS", "");
     return 0;

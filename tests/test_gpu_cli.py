@@ -202,3 +202,81 @@ def test_cli_kmer_counter_and_reload(cli, tmp_path, k, mode):
     with pytest.raises(m.native.McError, match="multiple of the 10-byte record"):
         ctx.load_kmers(str(bad))
     ctx.close()
+
+
+def test_cli_more_seed_sequences_than_one_bfs_batch(cli, tmp_path):
+    """300 seed sequences without --merge: the reference runs one OneSequenceCalculator per sequence with no limit on
+    their number (EnvironmentFinderMain.java:218-225); the CLI sends their 600 passes to the GPU in chunks."""
+    genome, reads, _ = synth_case(2, 40000, 9000, 150, 40)
+    fa = str(tmp_path / "reads.fasta")
+    _write_fasta(fa, reads, 150)
+    seq = str(tmp_path / "genes.fasta")
+    with open(seq, "w") as f:
+        for i in range(300):
+            f.write(">gene%03d\n%s\n" % (i, po.decode(genome[200 + 250 * i:200 + 250 * i + 90])))
+    out, want = str(tmp_path / "out"), str(tmp_path / "want")
+    cmd = [cli, "-k", "31", "-i", fa, "--seq", seq, "-o", out, "-w", str(tmp_path / "wd"), "--force", "--maxkmers", "400",
+           "--coverage", "3"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    seqs, comments = ho.rich_fasta_read(seq)
+    _, res = _oracle_run([fa], 31, po.KEY_PACKED, seqs, comments, want, coverage=3, max_kmers=400)
+    assert len(res) == 300
+    _assert_same_tree(res, out, want)
+
+
+def test_cli_config5_four_environments_then_multi_join(cli, tmp_path):
+    """BASELINE.json configs[4] at small scale: four read sets drawn from overlapping subsets of the genomes (all hold
+    the contig with the seed gene) -> four environments built by the HIP path -> `--tool environment-finder-multi` joins
+    their graph.txt files (src/tools/EnvironmentFinderMultiMain.java:84-170).  Every file of every stage equals the oracle
+    pipeline's.  (Parity of the join itself is unpinned: the reference ships no output of that tool.)"""
+    rng = np.random.default_rng(77)
+    contigs = [rng.integers(0, 4, 30000).astype(np.uint8) for _ in range(4)]
+    variant = contigs[0].copy()  # two of the four samples carry a variant of the gene's neighbourhood: coloured bubbles
+    for pos in (9800, 10650, 11200):
+        variant[pos] = (variant[pos] + 1) & 3
+    gene = po.decode(contigs[0][10000:10300])
+    seq = str(tmp_path / "gene.fasta")
+    with open(seq, "w") as f:
+        f.write(">thegene\n%s\n" % gene)  # (no blank in the name: array options are re-tokenised on [, ], Tool.java:888-895)
+    envs_got, envs_want = [], []
+    for s in range(4):
+        src = [variant if s % 2 else contigs[0], contigs[1 + s % 3]]
+        L, n = 150, 4000
+        reads = []
+        for i in range(n):
+            g = src[int(rng.integers(0, 2))]
+            a = int(rng.integers(0, len(g) - L))
+            r = g[a:a + L].copy()
+            if rng.integers(0, 2):
+                r = (3 - r[::-1]).astype(np.uint8)  # the other strand (complement = 3 - code)
+            reads.append(r)
+        fa = str(tmp_path / ("sample%d.fasta" % s))
+        _write_fasta(fa, np.concatenate(reads), L)
+        out, want = str(tmp_path / ("out%d" % s)), str(tmp_path / ("want%d" % s))
+        cmd = [cli, "-k", "31", "-i", fa, "--seq", seq, "-o", out, "-w", str(tmp_path / ("wd%d" % s)), "--force", "--maxradius", "400",
+               "--coverage", "3", "--bothdirs", "true"]
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        seqs, comments = ho.rich_fasta_read(seq)
+        _, res = _oracle_run([fa], 31, po.KEY_PACKED, seqs, comments, want, coverage=3, max_radius=400, bothdirs=True)
+        _assert_same_tree(res, out, want)
+        envs_got.append(os.path.join(out, "thegene", "graph.txt"))
+        envs_want.append(os.path.join(want, "thegene", "graph.txt"))
+        os.makedirs(os.path.dirname(envs_want[-1]), exist_ok=True)
+        with open(envs_want[-1], "w") as f:
+            f.write(res[os.path.join(want, "thegene") + "/"]["graph.txt"])
+    joined = str(tmp_path / "joined")
+    p = subprocess.run([cli, "--tool", "environment-finder-multi", "--env"] + envs_got + ["--seq", seq, "-o", joined, "-w",
+                       str(tmp_path / "wdj"), "--force"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    # (the Jaccard tables print the environments' paths: the oracle joins the very files the CLI wrote, which the
+    # comparison above found byte-identical with its own)
+    for g, w in zip(envs_got, envs_want):
+        assert open(g).read() == open(w).read()
+    want_files, _ = ho.environment_finder_multi(envs_got, seq, joined, 1)
+    for name, text in want_files.items():
+        with open(os.path.join(joined, name)) as f:
+            assert f.read() == text, name
+    gfa = want_files["graph.gfa"]
+    assert gfa.count("\nS\t") > 3 and "#00ff00" in gfa  # the gene's unitigs are marked, the samples' bubbles coloured
