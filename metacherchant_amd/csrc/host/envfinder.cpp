@@ -99,6 +99,132 @@ std::string unpack_kmer(uint64_t hi, uint64_t lo, int k)
     return s;
 }
 
+// ------------------------------------------------------------------------------------------ JavaTreeOrder
+// java.util.HashMap.TreeNode (JDK 8): treeify, putTreeVal, balanceInsertion, rotateLeft / rotateRight, moveRootToFront.
+
+uint32_t JavaTreeOrder::rotate_left(uint32_t root, uint32_t p)
+{
+    if (p == NIL) return root;
+    const uint32_t r = t_[p].right;
+    if (r == NIL) return root;
+    const uint32_t rl = t_[p].right = t_[r].left;
+    if (rl != NIL) t_[rl].parent = p;
+    const uint32_t pp = t_[r].parent = t_[p].parent;
+    if (pp == NIL) { root = r; t_[r].red = false; }
+    else if (t_[pp].left == p) t_[pp].left = r;
+    else t_[pp].right = r;
+    t_[r].left = p;
+    t_[p].parent = r;
+    return root;
+}
+
+uint32_t JavaTreeOrder::rotate_right(uint32_t root, uint32_t p)
+{
+    if (p == NIL) return root;
+    const uint32_t l = t_[p].left;
+    if (l == NIL) return root;
+    const uint32_t lr = t_[p].left = t_[l].right;
+    if (lr != NIL) t_[lr].parent = p;
+    const uint32_t pp = t_[l].parent = t_[p].parent;
+    if (pp == NIL) { root = l; t_[l].red = false; }
+    else if (t_[pp].right == p) t_[pp].right = l;
+    else t_[pp].left = l;
+    t_[l].right = p;
+    t_[p].parent = l;
+    return root;
+}
+
+uint32_t JavaTreeOrder::balance_insertion(uint32_t root, uint32_t x)
+{
+    t_[x].red = true;
+    for (;;) {
+        uint32_t xp = t_[x].parent;
+        if (xp == NIL) { t_[x].red = false; return x; }
+        uint32_t xpp = t_[xp].parent;
+        if (!t_[xp].red || xpp == NIL) return root;
+        const uint32_t xppl = t_[xpp].left;
+        if (xp == xppl) {
+            const uint32_t xppr = t_[xpp].right;
+            if (xppr != NIL && t_[xppr].red) {
+                t_[xppr].red = false; t_[xp].red = false; t_[xpp].red = true; x = xpp;
+            } else {
+                if (x == t_[xp].right) {
+                    x = xp;
+                    root = rotate_left(root, x);
+                    xp = t_[x].parent;
+                    xpp = xp == NIL ? NIL : t_[xp].parent;
+                }
+                if (xp != NIL) {
+                    t_[xp].red = false;
+                    if (xpp != NIL) { t_[xpp].red = true; root = rotate_right(root, xpp); }
+                }
+            }
+        } else {
+            if (xppl != NIL && t_[xppl].red) {
+                t_[xppl].red = false; t_[xp].red = false; t_[xpp].red = true; x = xpp;
+            } else {
+                if (x == t_[xp].left) {
+                    x = xp;
+                    root = rotate_right(root, x);
+                    xp = t_[x].parent;
+                    xpp = xp == NIL ? NIL : t_[xp].parent;
+                }
+                if (xp != NIL) {
+                    t_[xp].red = false;
+                    if (xpp != NIL) { t_[xpp].red = true; root = rotate_left(root, xpp); }
+                }
+            }
+        }
+    }
+}
+
+void JavaTreeOrder::root_to_front(std::vector<uint32_t> &chain, uint32_t root)
+{   // moveRootToFront: the root leaves its place in the chain and becomes its head
+    if (chain.empty() || chain[0] == root) return;
+    chain.erase(std::find(chain.begin(), chain.end(), root));
+    chain.insert(chain.begin(), root);
+}
+
+void JavaTreeOrder::treeify(std::vector<uint32_t> &chain)
+{
+    uint32_t root = NIL;
+    for (uint32_t x : chain) {
+        t_[x] = Node{};
+        if (root == NIL) { root = x; continue; }
+        for (uint32_t p = root;;) {
+            const int d = dir_(x, p);
+            const uint32_t xp = p;
+            p = d <= 0 ? t_[p].left : t_[p].right;
+            if (p == NIL) {
+                t_[x].parent = xp;
+                if (d <= 0) t_[xp].left = x; else t_[xp].right = x;
+                root = balance_insertion(root, x);
+                break;
+            }
+        }
+    }
+    root_to_front(chain, root);
+}
+
+void JavaTreeOrder::put(std::vector<uint32_t> &chain, uint32_t id)
+{   // putTreeVal for a key known to be absent
+    uint32_t root = chain[0];
+    while (t_[root].parent != NIL) root = t_[root].parent;
+    for (uint32_t p = root;;) {
+        const int d = dir_(id, p);
+        const uint32_t xp = p;
+        p = d <= 0 ? t_[p].left : t_[p].right;
+        if (p == NIL) {
+            t_[id] = Node{};
+            t_[id].parent = xp;
+            if (d <= 0) t_[xp].left = id; else t_[xp].right = id;
+            chain.insert(std::find(chain.begin(), chain.end(), xp) + 1, id);  // xp.next = x
+            root_to_front(chain, balance_insertion(root, id));
+            return;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ JavaHashMap
 
 static uint32_t java_string_hash(const std::string &s)
@@ -108,7 +234,15 @@ static uint32_t java_string_hash(const std::string &s)
     return h;
 }
 
-JavaHashMap::JavaHashMap() : bins_(16) {}
+JavaHashMap::JavaHashMap() : bins_(16), is_tree_(16, 0), tree_([this](uint32_t x, uint32_t p) { return tree_dir(x, p); }) {}
+
+int JavaHashMap::tree_dir(uint32_t x, uint32_t p) const
+{   // TreeNode order: the (signed) spread hash, then String.compareTo (distinct keys never compare equal)
+    const int32_t h = (int32_t)entries_[x].hash, ph = (int32_t)entries_[p].hash;
+    if (ph > h) return -1;
+    if (ph < h) return 1;
+    return entries_[x].key < entries_[p].key ? -1 : 1;
+}
 
 void JavaHashMap::put(const std::string &key, int value)
 {
@@ -122,10 +256,15 @@ void JavaHashMap::put(const std::string &key, int value)
     const uint32_t e = (uint32_t)entries_.size();
     entries_.push_back(Entry{key, value, h});
     index_.emplace(key, e);
-    auto &bin = bins_[h & (cap_ - 1)];
-    bin.push_back(e);
-    if (bin.size() >= 9) {  // a 9th node: treeifyBin (or a resize while the table is smaller than 64)
-        if (cap_ >= 64) treeified_ = true; else resize();
+    const size_t b = h & (cap_ - 1);
+    auto &bin = bins_[b];
+    if (is_tree_[b]) {
+        tree_.put(bin, e);
+    } else {
+        bin.push_back(e);
+        if (bin.size() >= 9) {  // a 9th node: treeifyBin (or a resize while the table is smaller than 64)
+            if (cap_ >= 64) { tree_.treeify(bin); is_tree_[b] = 1; n_treeified_++; } else resize();
+        }
     }
     size_++;
     if ((double)size_ > 0.75 * (double)cap_) resize();
@@ -133,12 +272,27 @@ void JavaHashMap::put(const std::string &key, int value)
 
 void JavaHashMap::resize()
 {
-    const size_t ncap = cap_ * 2;
+    const size_t ocap = cap_, ncap = cap_ * 2;
     std::vector<std::vector<uint32_t>> nb(ncap);
-    for (const auto &bin : bins_)
+    std::vector<char> nt(ncap, 0);
+    for (size_t j = 0; j < ocap; j++) {
+        const auto &bin = bins_[j];
         for (uint32_t e : bin) nb[entries_[e].hash & (ncap - 1)].push_back(e);  // lo/hi split keeps relative order
+        if (!is_tree_[j]) continue;
+        // TreeNode.split: halves of <= 6 nodes become plain lists again; the others stay trees, rebuilt (treeify: the
+        // root moves to the front) only when the bin really split
+        auto &lo = nb[j], &hi = nb[j + ocap];
+        const bool both = !lo.empty() && !hi.empty();
+        for (auto *half : {&lo, &hi}) {
+            if (half->empty()) continue;
+            const size_t at = half == &lo ? j : j + ocap;
+            if (half->size() <= 6) tree_.forget(*half);
+            else { nt[at] = 1; if (both) tree_.treeify(*half); }
+        }
+    }
     cap_ = ncap;
     bins_.swap(nb);
+    is_tree_.swap(nt);
 }
 
 int JavaHashMap::get(const std::string &key) const
@@ -160,8 +314,15 @@ void JavaHashMap::remove(const std::string &key)
 {
     auto it = index_.find(key);
     if (it == index_.end()) return;
-    auto &bin = bins_[entries_[it->second].hash & (cap_ - 1)];
+    const size_t b = entries_[it->second].hash & (cap_ - 1);
+    auto &bin = bins_[b];
     bin.erase(std::find(bin.begin(), bin.end(), it->second));
+    if (is_tree_[b]) {  // removeTreeNode is not replayed: the order inside this bin is no longer the JVM's for sure
+        order_unknown_ = true;
+        tree_.forget(bin);
+        tree_.forget({it->second});
+        if (bin.size() > 6) tree_.treeify(bin); else is_tree_[b] = 0;
+    }
     index_.erase(it);
     size_--;
 }
@@ -915,7 +1076,22 @@ static inline kmer_t kmer_mask(int bases) { return bases >= 64 ? ~(kmer_t)0 : ((
 
 // ---- JavaKmerMap
 
-JavaKmerMap::JavaKmerMap(int k) : k_(k), head_(16, NIL), tail_(16, NIL) {}
+JavaKmerMap::JavaKmerMap(int k) : k_(k), head_(16, NIL), tail_(16, NIL), tree_([this](uint32_t x, uint32_t p) { return tree_dir(x, p); }) {}
+
+int JavaKmerMap::tree_dir(uint32_t x, uint32_t p) const
+{   // TreeNode order: the (signed) spread hash, then String.compareTo on the characters the packed keys stand for
+    const int32_t h = (int32_t)entries_[x].hash, ph = (int32_t)entries_[p].hash;
+    if (ph > h) return -1;
+    if (ph < h) return 1;
+    return unpack_kmer128(entries_[x].key, k_) < unpack_kmer128(entries_[p].key, k_) ? -1 : 1;
+}
+
+void JavaKmerMap::relink(size_t b, const std::vector<uint32_t> &chain)
+{
+    head_[b] = chain.empty() ? NIL : chain.front();
+    tail_[b] = chain.empty() ? NIL : chain.back();
+    for (size_t i = 0; i < chain.size(); i++) entries_[chain[i]].next = i + 1 < chain.size() ? chain[i + 1] : NIL;
+}
 
 uint32_t JavaKmerMap::hash_of(kmer_t key) const
 {
@@ -944,10 +1120,25 @@ int JavaKmerMap::put(kmer_t key, int value)
         }
     const uint32_t e = (uint32_t)entries_.size();
     entries_.push_back(Entry{key, value, h, NIL});
-    if (tail_[b] == NIL) head_[b] = e; else entries_[tail_[b]].next = e;
-    tail_[b] = e;
-    if (len + 1 >= 9) {  // a 9th node: treeifyBin (or a resize while the table is smaller than 64)
-        if (cap_ >= 64) treeified_ = true; else resize();
+    auto tb = tree_bins_.find(b);
+    if (tb != tree_bins_.end()) {  // a treeified bin: putTreeVal decides where the node goes
+        tree_.put(tb->second, e);
+        relink(b, tb->second);
+    } else {
+        if (tail_[b] == NIL) head_[b] = e; else entries_[tail_[b]].next = e;
+        tail_[b] = e;
+        if (len + 1 >= 9) {  // a 9th node: treeifyBin (or a resize while the table is smaller than 64)
+            if (cap_ >= 64) {
+                std::vector<uint32_t> chain;
+                for (uint32_t x = head_[b]; x != NIL; x = entries_[x].next) chain.push_back(x);
+                tree_.treeify(chain);
+                relink(b, chain);
+                tree_bins_.emplace(b, std::move(chain));
+                n_treeified_++;
+            } else {
+                resize();
+            }
+        }
     }
     size_++;
     if ((double)size_ > 0.75 * (double)cap_) resize();
@@ -966,14 +1157,47 @@ void JavaKmerMap::resize()
             if (nt[b] == NIL) nh[b] = e; else entries_[nt[b]].next = e;
             nt[b] = e;
         }
+    const size_t ocap = cap_;
     cap_ = ncap;
     head_.swap(nh);
     tail_.swap(nt);
+    // TreeNode.split for the bins that were trees: halves of <= 6 nodes are plain lists again (in chain order, as linked
+    // above); the others stay trees, rebuilt (the root moves to the front) only when the bin really split
+    std::unordered_map<size_t, std::vector<uint32_t>> old;
+    old.swap(tree_bins_);
+    for (auto &kv : old) {
+        std::vector<uint32_t> lo, hi;
+        for (uint32_t e : kv.second) ((entries_[e].hash & ocap) ? hi : lo).push_back(e);
+        const bool both = !lo.empty() && !hi.empty();
+        for (int side = 0; side < 2; side++) {
+            std::vector<uint32_t> &half = side ? hi : lo;
+            if (half.empty()) continue;
+            const size_t at = kv.first + (side ? ocap : 0);
+            if (half.size() <= 6) { tree_.forget(half); continue; }
+            if (both) { tree_.treeify(half); relink(at, half); }
+            tree_bins_.emplace(at, std::move(half));
+        }
+    }
 }
 
 void JavaKmerMap::remove(kmer_t key)
 {
     const size_t b = hash_of(key) & (cap_ - 1);
+    auto tb = tree_bins_.find(b);
+    if (tb != tree_bins_.end()) {  // removeTreeNode is not replayed: the order inside this bin is no longer the JVM's for sure
+        std::vector<uint32_t> &chain = tb->second;
+        for (size_t i = 0; i < chain.size(); i++)
+            if (entries_[chain[i]].key == key) {
+                order_unknown_ = true;
+                tree_.forget(chain);
+                chain.erase(chain.begin() + (long)i);
+                if (chain.size() > 6) { tree_.treeify(chain); relink(b, chain); }
+                else { relink(b, chain); tree_bins_.erase(tb); }
+                size_--;
+                return;
+            }
+        return;
+    }
     uint32_t prev = NIL;
     for (uint32_t e = head_[b]; e != NIL; prev = e, e = entries_[e].next)
         if (entries_[e].key == key) {
@@ -1051,7 +1275,7 @@ void Environment::add_pass(const BfsPass &p, bool trim)
         }
     }
     d.for_each([&](kmer_t kmer, int, int e) { subgraph_.put(normalize128(kmer, k_), cov[(size_t)e]); });
-    if (d.treeified()) d_treeified_ = true;
+    if (d.treeified()) d_treeified_ = true;  // (a removal from a treeified bin of distanceToKmer: runTrimPaths)
 }
 
 static inline void append_uint(std::string &out, unsigned long long v)

@@ -28,6 +28,29 @@ std::vector<std::string> neighbors_by_dir(int dir, const std::string &kmer);  //
 void pack_kmer(const std::string &s, uint64_t *hi, uint64_t *lo);
 std::string unpack_kmer(uint64_t hi, uint64_t lo, int k);
 
+// ---- treeified bins of java.util.HashMap (JDK 8 HashMap.TreeNode).  A bin's iteration order is
+// its nodes' next-chain, kept here as a vector of entry ids; the red-black tree over the same nodes decides where a new
+// node is linked in: treeify() builds the tree in chain order and moves its root to the front (moveRootToFront),
+// put() is putTreeVal (the new node goes right behind its tree parent, then balanceInsertion, then the root to the front).
+// dir(x, p) = which way x goes below p: by the (signed) spread hash, then String.compareTo -- < 0 left, > 0 right.
+class JavaTreeOrder {
+public:
+    explicit JavaTreeOrder(std::function<int(uint32_t, uint32_t)> dir) : dir_(std::move(dir)) {}
+    void treeify(std::vector<uint32_t> &chain);
+    void put(std::vector<uint32_t> &chain, uint32_t id);
+    void forget(const std::vector<uint32_t> &chain) { for (uint32_t id : chain) t_.erase(id); }
+
+private:
+    static constexpr uint32_t NIL = 0xFFFFFFFFu;
+    struct Node { uint32_t parent = NIL, left = NIL, right = NIL; bool red = false; };
+    uint32_t rotate_left(uint32_t root, uint32_t p);
+    uint32_t rotate_right(uint32_t root, uint32_t p);
+    uint32_t balance_insertion(uint32_t root, uint32_t x);
+    static void root_to_front(std::vector<uint32_t> &chain, uint32_t root);
+    std::function<int(uint32_t, uint32_t)> dir_;
+    std::unordered_map<uint32_t, Node> t_;
+};
+
 // ---- java.util.HashMap<String,Integer> iteration order (JDK 8)
 class JavaHashMap {
 public:
@@ -38,7 +61,10 @@ public:
     bool find(const std::string &key, int *value) const;
     void remove(const std::string &key);
     size_t size() const { return size_; }
-    bool treeified() const { return treeified_; }  // a bin would have been treeified: JDK order not guaranteed
+    // The order of a treeified bin is replayed node for node (JavaTreeOrder) except for a REMOVAL from such a bin
+    // (removeTreeNode: only runTrimPaths' retainAll removes): then the JDK's order is no longer guaranteed.
+    bool treeified() const { return order_unknown_; }
+    size_t bins_treeified() const { return n_treeified_; }  // bins that were treeified at some point (tests)
     template <typename F>
     void for_each(F &&f) const
     {
@@ -49,11 +75,14 @@ public:
 private:
     struct Entry { std::string key; int value; uint32_t hash; };
     void resize();
+    int tree_dir(uint32_t x, uint32_t p) const;
     std::deque<Entry> entries_;
-    std::vector<std::vector<uint32_t>> bins_;
+    std::vector<std::vector<uint32_t>> bins_;  // (a treeified bin's vector is its next-chain)
+    std::vector<char> is_tree_;
     std::unordered_map<std::string, uint32_t> index_;
-    size_t cap_ = 16, size_ = 0;
-    bool treeified_ = false;
+    JavaTreeOrder tree_;
+    size_t cap_ = 16, size_ = 0, n_treeified_ = 0;
+    bool order_unknown_ = false;
 };
 
 // ---- src/io/RichFastaReader.java:38-77 (+ DnaQ(String,0).toString(): N/n/. -> 'A', itmo!/dna/DnaQ.java:21-30)
@@ -97,7 +126,8 @@ public:
     void remove(kmer_t key);
     size_t size() const { return size_; }
     size_t n_entries() const { return entries_.size(); }  // removed ones included: bound of the entry indices
-    bool treeified() const { return treeified_; }
+    bool treeified() const { return order_unknown_; }  // (see JavaHashMap::treeified)
+    size_t bins_treeified() const { return n_treeified_; }
     template <typename F>
     void for_each(F &&f) const  // f(key, value, entry index) in HashMap iteration order
     {
@@ -110,11 +140,15 @@ private:
     struct Entry { kmer_t key; int value; uint32_t hash, next; };
     uint32_t hash_of(kmer_t key) const;
     void resize();
+    int tree_dir(uint32_t x, uint32_t p) const;
+    void relink(size_t bin, const std::vector<uint32_t> &chain);  // head_/tail_/next of a bin from its chain
     int k_;
     std::vector<Entry> entries_;
     std::vector<uint32_t> head_, tail_;
-    size_t cap_ = 16, size_ = 0;
-    bool treeified_ = false;
+    std::unordered_map<size_t, std::vector<uint32_t>> tree_bins_;  // treeified bins: their next-chains
+    JavaTreeOrder tree_;
+    size_t cap_ = 16, size_ = 0, n_treeified_ = 0;
+    bool order_unknown_ = false;
 };
 
 // ---- one runBfs pass as delivered by mc_bfs_batch (or by a dump file in the CPU tests)

@@ -40,6 +40,25 @@ int main(int argc, char **argv)
             fputs(java_format_6_2f(strtof(argv[2], nullptr)).c_str(), stdout);
             return 0;
         }
+        if (argc == 3 && std::string(argv[1]) == "hashmap") {  // put every k-mer string of the file ("-kmer": remove it), print both maps' orders
+            std::ifstream f(argv[2]);
+            if (!f) throw Error("cannot open key file");
+            std::vector<std::string> ops;
+            for (std::string line; std::getline(f, line);) if (!line.empty()) ops.push_back(line);
+            const int k = (int)(ops.empty() ? 1 : ops[0].size() - (ops[0][0] == '-'));
+            JavaHashMap hm;
+            JavaKmerMap km(k);
+            int v = 0;
+            for (const std::string &op : ops) {
+                if (op[0] == '-') { hm.remove(op.substr(1)); km.remove(pack_kmer128(op.substr(1))); }
+                else { hm.put(op, v); km.put(pack_kmer128(op), v); v++; }
+            }
+            printf("S %zu %zu %d\n", hm.size(), hm.bins_treeified(), hm.treeified() ? 1 : 0);
+            hm.for_each([](const std::string &key, int val) { printf("s %s %d\n", key.c_str(), val); });
+            printf("K %zu %zu %d\n", km.size(), km.bins_treeified(), km.treeified() ? 1 : 0);
+            km.for_each([&](kmer_t key, int val, int) { printf("k %s %d\n", unpack_kmer128(key, k).c_str(), val); });
+            return 0;
+        }
         if (argc >= 6 && std::string(argv[1]) == "multi") {  // multi <out_dir> <seq.fasta> <gene_id> <env>...
             const MultiResult r = environment_finder_multi(std::vector<std::string>(argv + 5, argv + argc), argv[3], atoi(argv[4]));
             write_multi(r, argv[2]);
@@ -47,7 +66,7 @@ int main(int argc, char **argv)
             return 0;
         }
         if (argc != 4 || std::string(argv[1]) != "env") {
-            fprintf(stderr, "usage: mc_hosttest env <dump> <out_prefix> | seeds <fasta> | reads <file> | multi <out_dir> <seq> <gene_id> <env>...\n");
+            fprintf(stderr, "usage: mc_hosttest env <dump> <out_prefix> | seeds <fasta> | reads <file> | hashmap <keys> | multi <out_dir> <seq> <gene_id> <env>...\n");
             return 2;
         }
         std::ifstream f(argv[2]);

@@ -455,7 +455,7 @@ int run(const Options &o)
             }
             info("Extending endings by 0 kmers");  // extendEnvironment never adds anything
             if (!env.order_guaranteed())
-                logline("WARN", "a java.util.HashMap bin would have been treeified: line order of " + calcs[c].out_prefix +
+                logline("WARN", "--trim removed k-mers from a treeified java.util.HashMap bin: line order of " + calcs[c].out_prefix +
                                 " may differ from the JVM's inside that bin");
             env.write_all(calcs[c].out_prefix, o.chunklength);
         }

@@ -34,22 +34,252 @@ def java_string_hash(s):
     return h
 
 
+class _TNode:
+    """A TreeNode of a treeified bin: the bin's iteration order is the `next` chain, the red-black tree decides where
+    a new node is linked into it (java.util.HashMap.TreeNode, JDK 8)."""
+    __slots__ = ("e", "hash", "next", "prev", "parent", "left", "right", "red")
+
+    def __init__(self, e, h):
+        self.e, self.hash = e, h
+        self.next = self.prev = self.parent = self.left = self.right = None
+        self.red = False
+
+
+def _sint(h):
+    return h - (1 << 32) if h & 0x80000000 else h
+
+
+def _tree_dir(h, key, p):
+    """HashMap.TreeNode.treeify / putTreeVal: by (signed int) hash, then String.compareTo."""
+    ph = p.hash
+    if ph > h:
+        return -1
+    if ph < h:
+        return 1
+    pk = p.e[0]
+    return -1 if key < pk else 1  # (distinct Strings never compare equal; tieBreakOrder is not reached)
+
+
+def _rotate_left(root, p):
+    r = p.right if p is not None else None
+    if r is not None:
+        rl = p.right = r.left
+        if rl is not None:
+            rl.parent = p
+        pp = r.parent = p.parent
+        if pp is None:
+            root = r
+            r.red = False
+        elif pp.left is p:
+            pp.left = r
+        else:
+            pp.right = r
+        r.left = p
+        p.parent = r
+    return root
+
+
+def _rotate_right(root, p):
+    l = p.left if p is not None else None
+    if l is not None:
+        lr = p.left = l.right
+        if lr is not None:
+            lr.parent = p
+        pp = l.parent = p.parent
+        if pp is None:
+            root = l
+            l.red = False
+        elif pp.right is p:
+            pp.right = l
+        else:
+            pp.left = l
+        l.right = p
+        p.parent = l
+    return root
+
+
+def _balance_insertion(root, x):
+    x.red = True
+    while True:
+        xp = x.parent
+        if xp is None:
+            x.red = False
+            return x
+        xpp = xp.parent
+        if not xp.red or xpp is None:
+            return root
+        xppl = xpp.left
+        if xp is xppl:
+            xppr = xpp.right
+            if xppr is not None and xppr.red:
+                xppr.red = False
+                xp.red = False
+                xpp.red = True
+                x = xpp
+            else:
+                if x is xp.right:
+                    x = xp
+                    root = _rotate_left(root, x)
+                    xp = x.parent
+                    xpp = None if xp is None else xp.parent
+                if xp is not None:
+                    xp.red = False
+                    if xpp is not None:
+                        xpp.red = True
+                        root = _rotate_right(root, xpp)
+        else:
+            if xppl is not None and xppl.red:
+                xppl.red = False
+                xp.red = False
+                xpp.red = True
+                x = xpp
+            else:
+                if x is xp.left:
+                    x = xp
+                    root = _rotate_right(root, x)
+                    xp = x.parent
+                    xpp = None if xp is None else xp.parent
+                if xp is not None:
+                    xp.red = False
+                    if xpp is not None:
+                        xpp.red = True
+                        root = _rotate_left(root, xpp)
+
+
+class _TreeBin:
+    """One treeified bin: `first` heads the next-chain (always the tree's root: moveRootToFront)."""
+
+    def __init__(self, entries):  # treeifyBin: TreeNodes in list order, then treeify
+        self.first = None
+        tl = None
+        for e in entries:
+            p = _TNode(e, _sint(e[2]))
+            if tl is None:
+                self.first = p
+            else:
+                p.prev = tl
+                tl.next = p
+            tl = p
+        self.treeify()
+
+    @classmethod
+    def from_chain(cls, head, retreeify):
+        b = cls.__new__(cls)
+        b.first = head
+        if retreeify:
+            b.treeify()
+        return b
+
+    def treeify(self):
+        root = None
+        x = self.first
+        while x is not None:
+            nxt = x.next
+            x.left = x.right = None
+            if root is None:
+                x.parent = None
+                x.red = False
+                root = x
+            else:
+                p = root
+                while True:
+                    d = _tree_dir(x.hash, x.e[0], p)
+                    xp = p
+                    p = p.left if d <= 0 else p.right
+                    if p is None:
+                        x.parent = xp
+                        if d <= 0:
+                            xp.left = x
+                        else:
+                            xp.right = x
+                        root = _balance_insertion(root, x)
+                        break
+            x = nxt
+        self._move_root_to_front(root)
+
+    def _root(self):
+        r = self.first
+        while r.parent is not None:
+            r = r.parent
+        return r
+
+    def _move_root_to_front(self, root):
+        first = self.first
+        if root is not None and root is not first:
+            rn, rp = root.next, root.prev
+            if rn is not None:
+                rn.prev = rp
+            if rp is not None:
+                rp.next = rn
+            if first is not None:
+                first.prev = root
+            root.next = first
+            root.prev = None
+            self.first = root
+
+    def put(self, e):  # putTreeVal for a key known to be absent
+        h, key = _sint(e[2]), e[0]
+        root = self._root()
+        p = root
+        while True:
+            d = _tree_dir(h, key, p)
+            xp = p
+            p = p.left if d <= 0 else p.right
+            if p is None:
+                xpn = xp.next
+                x = _TNode(e, h)
+                x.next = xpn
+                if d <= 0:
+                    xp.left = x
+                else:
+                    xp.right = x
+                xp.next = x
+                x.parent = x.prev = xp
+                if xpn is not None:
+                    xpn.prev = x
+                self._move_root_to_front(_balance_insertion(root, x))
+                return
+
+    def entries(self):
+        x = self.first
+        while x is not None:
+            yield x.e
+            x = x.next
+
+    def __len__(self):
+        return sum(1 for _ in self.entries())
+
+
 class JavaHashMap:
-    """Iteration-order emulation of java.util.HashMap<String, V> (JDK 8), list bins.
+    """Iteration-order emulation of java.util.HashMap<String, V> (JDK 8).
 
     put() appends new keys to the tail of their bin and keeps the position of
     existing keys; resize() doubles at ++size > 0.75*cap and splits every bin
     into lo/hi lists preserving relative order; iteration walks bins in index
-    order.  A bin that would be treeified (9th node appended while cap >= 64)
-    sets `treeified`: iteration order is then not guaranteed to match the JDK.
+    order.  A bin whose 9th node arrives while cap >= 64 is treeified (below 64 the
+    table is resized instead): its iteration order is the TreeNodes' next-chain --
+    treeify() moves the tree's root to the front, putTreeVal() links a new node right
+    behind its tree parent, split() keeps the chain order, untreeifies halves of <= 6
+    nodes and re-treeifies the others when the bin really split.  Only a REMOVAL from a
+    treeified bin (runTrimPaths' retainAll) is not replayed node for node: it sets
+    `order_unknown`, the one case left in which the order may differ from the JVM's.
     """
 
     def __init__(self):
         self.cap = 16
         self.size = 0
-        self.bins = [[] for _ in range(16)]
+        self.bins = [[] for _ in range(16)]  # a list of entries, or a _TreeBin
         self.index = {}
-        self.treeified = False
+        self.order_unknown = False
+        self.n_treeified = 0  # bins that were treeified at some point (tests)
+
+    @property
+    def treeified(self):  # (older name: "the order is not guaranteed")
+        return self.order_unknown
+
+    @treeified.setter
+    def treeified(self, v):
+        self.order_unknown = bool(v)
 
     def put(self, key, val):
         e = self.index.get(key)
@@ -60,23 +290,64 @@ class JavaHashMap:
         h ^= h >> 16
         e = [key, val, h, True]
         self.index[key] = e
-        b = self.bins[h & (self.cap - 1)]
-        b.append(e)
-        if len(b) >= 9:  # binCount >= TREEIFY_THRESHOLD - 1 with 8 nodes already there
-            if self.cap >= 64:
-                self.treeified = True
-            else:
-                self._resize()  # treeifyBin resizes instead while tab.length < MIN_TREEIFY_CAPACITY
+        i = h & (self.cap - 1)
+        b = self.bins[i]
+        if isinstance(b, _TreeBin):
+            b.put(e)
+        else:
+            b.append(e)
+            if len(b) >= 9:  # binCount >= TREEIFY_THRESHOLD - 1 with 8 nodes already there
+                if self.cap >= 64:
+                    self.bins[i] = _TreeBin(b)
+                    self.n_treeified += 1
+                else:
+                    self._resize()  # treeifyBin resizes instead while tab.length < MIN_TREEIFY_CAPACITY
         self.size += 1
         if self.size > 0.75 * self.cap:
             self._resize()
 
     def _resize(self):
-        ncap = self.cap * 2
+        ocap, ncap = self.cap, self.cap * 2
         nb = [[] for _ in range(ncap)]
-        for b in self.bins:
-            for e in b:
-                if e[3]:
+        for j, b in enumerate(self.bins):
+            if isinstance(b, _TreeBin):  # TreeNode.split
+                lo_h = lo_t = hi_h = hi_t = None
+                lc = hc = 0
+                x = b.first
+                while x is not None:
+                    nxt = x.next
+                    x.next = None
+                    if (x.e[2] & ocap) == 0:
+                        x.prev = lo_t
+                        if lo_t is None:
+                            lo_h = x
+                        else:
+                            lo_t.next = x
+                        lo_t = x
+                        lc += 1
+                    else:
+                        x.prev = hi_t
+                        if hi_t is None:
+                            hi_h = x
+                        else:
+                            hi_t.next = x
+                        hi_t = x
+                        hc += 1
+                    x = nxt
+                for head, cnt, other, at in ((lo_h, lc, hi_h, j), (hi_h, hc, lo_h, j + ocap)):
+                    if head is None:
+                        continue
+                    if cnt <= 6:  # UNTREEIFY_THRESHOLD: back to a plain list, in chain order
+                        lst = []
+                        x = head
+                        while x is not None:
+                            lst.append(x.e)
+                            x = x.next
+                        nb[at] = lst
+                    else:  # (re-treeified only when the bin really split; else the tree stands as it is)
+                        nb[at] = _TreeBin.from_chain(head, other is not None)
+            else:
+                for e in b:
                     nb[e[2] & (ncap - 1)].append(e)
         self.cap = ncap
         self.bins = nb
@@ -95,12 +366,19 @@ class JavaHashMap:
         e = self.index.pop(key, None)
         if e is not None:
             e[3] = False
-            self.bins[e[2] & (self.cap - 1)].remove(e)
+            i = e[2] & (self.cap - 1)
+            b = self.bins[i]
+            if isinstance(b, _TreeBin):  # (removeTreeNode is not replayed: order of this bin no longer guaranteed)
+                self.order_unknown = True
+                rest = [x for x in b.entries() if x is not e]
+                self.bins[i] = _TreeBin(rest) if len(rest) > 6 else rest
+            else:
+                b.remove(e)
             self.size -= 1
 
     def items(self):
         for b in self.bins:
-            for e in b:
+            for e in (b.entries() if isinstance(b, _TreeBin) else b):
                 yield e[0], e[1]
 
     def keys(self):

@@ -323,3 +323,76 @@ def test_parallel_ingest_equals_serial(hosttest, tmp_path):
     text = open(fq).read().replace("@r300\n", "+r300\n", 1)
     odd.write_text(text)
     assert run(odd, 4) == ho.read_fastq_reads(str(odd))
+
+
+def _spread(s):
+    h = ho.java_string_hash(s)
+    return h ^ (h >> 16)
+
+
+def test_treeified_bins_same_order_in_all_three_maps(hosttest, tmp_path):
+    """java.util.HashMap bins of 9 and more colliding keys: the treeified bin's order -- root moved to
+    the front, a new node linked behind its tree parent, split / untreeify at resizes -- comes out the same from the Python
+    restatement, the C++ string map and the C++ packed-k-mer map, and differs from plain insertion order.  (The three are
+    restatements of the JDK 8 sources; no JVM here to run the real class.)"""
+    rng = np.random.default_rng(2024)
+
+    def rand_kmer(k):
+        return "".join("ACGT"[c] for c in rng.integers(0, 4, k))
+
+    for k, n_fill in ((31, 30), (21, 700), (45, 3000)):
+        keys = []
+        # three crowded buckets (index taken at a large table, so they stay together through several resizes; two of them
+        # differ only in a high bit and part ways at a later split), filled one by one between other keys
+        crowd = {5: [], 5 + 4096: [], 77: []}
+        while min(len(v) for v in crowd.values()) < 14:
+            s = rand_kmer(k)
+            b = _spread(s) & 8191
+            if b in crowd and len(crowd[b]) < 14:
+                crowd[b].append(s)
+        filler = [rand_kmer(k) for _ in range(n_fill)]
+        order = []
+        for i in range(14):
+            for b in crowd:
+                order.append(crowd[b][i])
+            order.extend(filler[i * len(filler) // 14:(i + 1) * len(filler) // 14])
+        seen = set()
+        keys = [s for s in order if not (s in seen or seen.add(s))]
+        m = ho.JavaHashMap()
+        for i, s in enumerate(keys):
+            m.put(s, i)
+        assert m.n_treeified >= 2 and not m.order_unknown
+        want = list(m.items())
+        by_bucket = {}
+        for s, v in want:
+            by_bucket.setdefault(_spread(s) & (m.cap - 1), []).append(v)
+        assert any(vs != sorted(vs) for vs in by_bucket.values())  # some bin is not in insertion order: a tree bin
+        path = tmp_path / ("keys%d.txt" % k)
+        path.write_text("\n".join(keys) + "\n")
+        out = subprocess.check_output([hosttest, "hashmap", str(path)]).decode().splitlines()
+        s_hdr = out[0].split()
+        n = int(s_hdr[1])
+        assert n == len(keys) and int(s_hdr[2]) == m.n_treeified and s_hdr[3] == "0"
+        got_s = [(l.split()[1], int(l.split()[2])) for l in out[1:1 + n]]
+        k_hdr = out[1 + n].split()
+        assert int(k_hdr[1]) == n and int(k_hdr[2]) == m.n_treeified and k_hdr[3] == "0"
+        got_k = [(l.split()[1], int(l.split()[2])) for l in out[2 + n:2 + 2 * n]]
+        assert got_s == want and got_k == want
+
+    # a removal from a treeified bin is the one thing not replayed: all three say so, and still agree on the order
+    keys = []
+    while len(keys) < 12:
+        s = rand_kmer(25)
+        if _spread(s) & 63 == 9:
+            keys.append(s)
+    ops = keys + ["-" + keys[4]]
+    m = ho.JavaHashMap()
+    for i, s in enumerate(keys):
+        m.put(s, i)
+    m.remove(keys[4])
+    assert m.order_unknown
+    path = tmp_path / "ops.txt"
+    path.write_text("\n".join(ops) + "\n")
+    out = subprocess.check_output([hosttest, "hashmap", str(path)]).decode().splitlines()
+    assert out[0].split()[3] == "1" and out[12].split()[3] == "1"
+    assert [(l.split()[1], int(l.split()[2])) for l in out[1:12]] == list(m.items())
