@@ -44,6 +44,10 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--capacity-hint", type=int, default=0, help="distinct k-mers per GPU expected (0: estimate from the error rate)")
+    ap.add_argument("--config", type=int, default=1, choices=[1, 2],
+                    help="BASELINE.json configs[N]: 1 = the headline (10 M reads, k=31, coverage 5, bothdirs False); 2 = k=63 poly-hash "
+                         "keys, coverage 3, bothdirs True on 100 x 5 Mb contigs (100 M reads at full size: give --reads to scale down)")
+    ap.add_argument("--total-reads", type=int, default=0, help="reads of the whole job, split evenly over the ranks (configs[3]: 1000000000 on 8 GPUs)")
     args = ap.parse_args()
 
     import numpy as np
@@ -74,6 +78,14 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
+    if args.config == 2:  # BASELINE.json configs[2]
+        if args.k == 31: args.k = 63
+        if args.contigs == 10: args.contigs = 100
+        if args.coverage == 5: args.coverage = 3
+        if args.reads == 10_000_000: args.reads = 100_000_000
+    if args.total_reads:
+        args.reads = args.total_reads // world
+    bothdirs = args.config == 2
     k, L, R = args.k, args.read_len, args.reads
     mode = m.KEY_PACKED if k <= 31 else m.KEY_POLY
     n_bases = R * L
@@ -122,7 +134,8 @@ def main():
         if rank == 0:
             bfs_ms, reached, levels, lookups = 0.0, 0, 0, 0
             # buildEnvironment with bothdirs=False: runBfs(-1), runBfs(+1) -- independent passes, one launch
-            res = bctx.bfs_batch([(seed_hi, seed_lo, -1), (seed_hi, seed_lo, 1)], args.coverage, args.maxkmers, -1)
+            jobs = [(seed_hi, seed_lo, 0)] if bothdirs else [(seed_hi, seed_lo, -1), (seed_hi, seed_lo, 1)]
+            res = bctx.bfs_batch(jobs, args.coverage, args.maxkmers, -1)
             for r in res:
                 if r is None:
                     raise SystemExit("BFS found no seed k-mer: synthetic workload broken")
@@ -175,26 +188,39 @@ def main():
             # super-k-mer form of the pipeline (packed keys, k >= 23); with several ranks the level-1 kernel
             # scatters the records (or keys) received from the other ranks instead of extracting them from reads
             sk = mode == m.KEY_PACKED and k >= 23 and os.environ.get("MC_SUPERKMERS") != "0"
-            p1 = ("k_sk1_extract" if world == 1 else "k_sk1_records") if sk else ("k_p1_extract_scatter" if world == 1 else "k_p1_keys_scatter")
+            p1 = ("k_sk1w_extract" if world == 1 else "k_sk1_records") if sk else ("k_p1_extract_scatter" if world == 1 else "k_p1_keys_scatter")
             parts = {p1: st.p1_ms / launches, "k_sk2_scatter" if sk else "k_p2_scatter": st.p2_ms / launches,
                      "k_p3_merge": st.p3_ms / launches}
             pipeline = st.p3_ms > 0
             dominant = max(parts, key=parts.get) if pipeline else "k_count_reads"
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_v6_pmc_hbm_traffic_e1.csv")
+            # HBM bytes per pipeline run from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH_SIZE doubled
+            # as MI355X_MICROARCH.md prescribes), collected by scripts/gpu_pmc.sh for THIS build: the file names the commit
+            # its kernels were built from, and the number is only reported while the counting kernels are unchanged since
+            # (git diff of csrc/count_pipeline.h and csrc/kmer_device.h against that commit is empty), else null.
+            traffic, traffic_source = None, None
+            pmc = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic_e1.csv")
             if pipeline and world == 1 and args.err == 100 and R == 10_000_000 and k == 31 and os.path.exists(pmc):
-                # HBM bytes per pipeline run from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes,
-                # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes), collected by scripts/gpu_pmc.sh
                 import csv
-                gb = 0.0
-                for row in csv.DictReader(open(pmc)):
-                    # (the second dispatch of k_sk2_scatter belongs to the BFS set-up, not to the counting pipeline)
-                    if row["kernel"].startswith(("mc::k_sk1_extract", "mc::k_p3_merge")) or (
-                            row["kernel"].startswith("mc::k_sk2_scatter") and row["dispatch"] == "1"):
-                        gb += float(row["fetch_GB_corrected_x2"]) + float(row["write_GB"])
-                traffic = round(gb * 1e9)
+                import subprocess
+                rows = [r for r in csv.DictReader(l for l in open(pmc) if not l.startswith("#"))]
+                commit = next((l.split()[-1] for l in open(pmc) if l.startswith("# commit")), None)
+                fresh = None
+                if commit and os.path.isdir(os.path.join(ROOT, ".git")):
+                    try:
+                        fresh = subprocess.run(["git", "-C", ROOT, "diff", "--quiet", commit, "--", "metacherchant_amd/csrc/count_pipeline.h",
+                                                "metacherchant_amd/csrc/kmer_device.h"], timeout=20).returncode == 0
+                    except Exception:
+                        fresh = None
+                if fresh is not False:  # (no git on the box: the file travels with the build it was measured on)
+                    gb = 0.0
+                    for row in rows:
+                        # (k_sk2_scatter is also used by the BFS-table build of a sharded run; on one GPU only by the pipeline)
+                        if row["kernel"].startswith(("mc::k_sk1w_extract", "mc::k_p3_merge", "mc::k_sk2_scatter", "void mc::k_sk1w_extract", "void mc::k_p3_merge")):
+                            gb += float(row["fetch_GB_corrected_x2"]) + float(row["write_GB"])
+                    traffic = round(gb * 1e9)
+                    traffic_source = "profiles/r02_pmc_hbm_traffic_e1.csv (commit %s)" % commit
             roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                         "kernel": dominant, "launch": "counting pipeline p1+p2+p3" if pipeline else "k_count_reads",
                         "kernel_ms": {kk: round(v, 3) for kk, v in parts.items()} if pipeline else None,
                         "bytes_per_kmer": round(A, 3), "algorithmic_bytes_per_launch": round(units_per_launch * A),
@@ -208,9 +234,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: %dx%dbp reads per GPU, %dx%d bp random contigs, k=%d, coverage=%d, "
-                                   "maxkmers=%d, bothdirs=False, %s" % (
-                                       R, L, args.contigs, args.contig_len, k, args.coverage, args.maxkmers,
+            "config": {"workload": "configs[%d]%s: %dx%dbp reads per GPU, %dx%d bp random contigs, k=%d%s, coverage=%d, "
+                                   "maxkmers=%d, bothdirs=%s, %s" % (
+                                       args.config if world == 1 or args.config != 1 else 3,
+                                       "" if (args.config == 1 and R == 10_000_000) or (args.config == 2 and R == 100_000_000) else " scaled",
+                                       R, L, args.contigs, args.contig_len, k, " (poly hash keys)" if mode == m.KEY_POLY else "", args.coverage, args.maxkmers, bothdirs,
                                        "E1 1%% substitutions" if args.err == 100 else "err=%d/10000" % args.err),
                        "reads_per_gpu": R, "read_len": L, "k": k, "err_per_10k": args.err,
                        "parallelism": "reads sharded x%d, all-to-all of super-k-mer records (keys for k < 23 / hash keys) by owner" % world if world > 1 else "1 GPU"},
@@ -231,21 +259,88 @@ def main():
 
 
 def cpu_baseline(args, k, mode, L):
-    """oracle/'s multi-threaded restatement of the reference's design (lock-striped sub-maps,
-    32768-read work items) on the host cores, on a bounded sample of the same workload."""
+    """The reference's CPU path beside the GPU number, on a bounded sample of the same workload.
+
+    With a JVM and the reference's jar on the box ($MC_REFERENCE_JAR) that is the reference itself:
+    `java -jar ... --tool environment-finder -p <cores>` on the sample written as FASTA, timed from its own log
+    ("Loading file" .. "Hashtable size" = counting; .. "Finished processing all sequences!" = BFS and output).  This image
+    has neither, so normally it is oracle/'s multi-threaded restatement of the reference's design (lock-striped
+    sub-maps, 32768-read work items) for the counting phase plus the oracle's BFS: "kind": "port"."""
+    import shutil
+
     import numpy as np
 
     from oracle import pyoracle as po
+    # The sample keeps what decides the reference's cost per k-mer -- read length, depth of coverage, error rate, k,
+    # thresholds -- and scales the genome with the reads: n reads over ONE contig of n * L / depth bases (the first n reads
+    # of the full set would cover its genome n / reads times as thinly: hardly a k-mer would reach the coverage threshold
+    # and the BFS leg would time nothing).
     n = min(args.cpu_sample_reads, args.reads)
-    genome = po.synth_genome(GENOME_SEED, args.contigs * args.contig_len)
-    reads = po.synth_reads(genome, args.contigs, args.contig_len, READ_SEED, 0, n, L, args.err)
+    depth = args.reads * L / float(args.contigs * args.contig_len)
+    glen = max(int(n * L / depth), 400000)
+    genome = po.synth_genome(GENOME_SEED, glen)
+    reads = po.synth_reads(genome, 1, glen, READ_SEED, 0, n, L, args.err)
+    cores = os.cpu_count() or 1
+    jar = os.environ.get("MC_REFERENCE_JAR")
+    if jar and os.path.exists(jar) and shutil.which("java"):
+        try:
+            return java_baseline(args, k, L, n, genome, reads, cores, jar)
+        except Exception as e:  # (fall through to the port, and say why)
+            sys.stderr.write("reference jar run failed (%s): timing the port instead\n" % e)
     words = po.pack(reads)
     off = np.arange(n + 1, dtype=np.uint64) * L
-    cores = os.cpu_count() or 1
-    w, nd, sec, _ = po.count_reads_packed_mt(words, off, k, 0 if mode == 0 else mode, cores)
-    return {"value": w / sec, "unit": "k-mers/s", "cores": cores, "kind": "port",
-            "sample": "count phase only, first %d reads of the same synthetic set (%d k-mer occurrences, %d distinct), "
-                      "%.2f s" % (n, w, nd, sec)}
+    w, nd, sec, table = po.count_reads_packed_mt(words, off, k, 0 if mode == 0 else mode, cores, want_table=True)
+    # the BFS leg on the sample's table (the reference runs one calculator thread per seed: single-threaded per pass)
+    seed = genome[100000:101000]
+    t0 = time.perf_counter()
+    dirs = [0] if args.config == 2 else [-1, 1]
+    reached = 0
+    for d in dirs:
+        r = po.bfs(table, k, 0 if mode == 0 else mode, [seed], d, args.coverage, args.maxkmers, -1)
+        reached += 0 if r is None else len(r["lo"])
+    bfs_sec = time.perf_counter() - t0
+    return {"value": w / (sec + bfs_sec), "unit": "k-mers/s", "cores": cores, "kind": "port",
+            "sample": "count + BFS on %d reads of the same kind over one %d-base contig (the workload's %.0f-fold depth; %d k-mer "
+                      "occurrences, %d distinct): counting %.2f s on %d threads (%.1f M k-mers/s), BFS %.3f s on one thread "
+                      "(%d vertices)" % (n, glen, depth, w, nd, sec, cores, w / sec / 1e6, bfs_sec, reached)}
+
+
+def java_baseline(args, k, L, n, genome, reads, cores, jar):
+    import re
+    import subprocess
+    import tempfile
+    from datetime import datetime
+
+    from oracle import pyoracle as po
+    with tempfile.TemporaryDirectory() as w:
+        with open(os.path.join(w, "reads.fasta"), "w") as f:
+            for i in range(n):
+                f.write(">r%d\n%s\n" % (i, po.decode(reads[i * L:(i + 1) * L])))
+        with open(os.path.join(w, "seed.fasta"), "w") as f:
+            f.write(">seed\n%s\n" % po.decode(genome[100000:101000]))
+        cmd = ["java", "-jar", jar, "--tool", "environment-finder", "-k", str(k), "--reads", os.path.join(w, "reads.fasta"),
+               "--seq", os.path.join(w, "seed.fasta"), "--output", os.path.join(w, "out"), "--work-dir", os.path.join(w, "wd"),
+               "-p", str(cores), "--force", "--coverage", str(args.coverage), "--maxkmers", str(args.maxkmers),
+               "--bothdirs", "True" if args.config == 2 else "False"]
+        t0 = time.perf_counter()
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=3600)
+        wall = time.perf_counter() - t0
+        stamps = {}
+        for line in open(os.path.join(w, "wd", "log"), errors="replace"):
+            mt = re.match(r"(\d{4}[.-]\d\d[.-]\d\d[ _]\d\d[:.]\d\d[:.]\d\d)", line)
+            if not mt:
+                continue
+            ts = datetime.strptime(re.sub(r"[._-]", " ", mt.group(1)).replace(":", " "), "%Y %m %d %H %M %S")
+            for key in ("Loading file", "Hashtable size", "Finished processing"):
+                if key in line and key not in stamps:
+                    stamps[key] = ts
+        windows = n * (L - k + 1)
+        sec = wall
+        if "Loading file" in stamps and "Finished processing" in stamps:
+            sec = max((stamps["Finished processing"] - stamps["Loading file"]).total_seconds(), 1.0)
+        return {"value": windows / sec, "unit": "k-mers/s", "cores": cores, "kind": "reference",
+                "sample": "the reference jar (%s) on %d reads of the same kind over one contig at the workload's depth, as FASTA: %.1f s from 'Loading file' to "
+                          "'Finished processing all sequences!' (log timestamps, 1 s resolution), %.1f s wall" % (os.path.basename(jar), n, sec, wall)}
 
 
 if __name__ == "__main__":
