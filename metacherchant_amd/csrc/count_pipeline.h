@@ -832,8 +832,10 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk2_scatter(const uint4 *__restr
                                                             uint64_t seg_cap1, const uint32_t *__restrict__ seg_counts1,
                                                             uint32_t n_buckets1, uint32_t np1, uint32_t m2, uint32_t *leaf_counts,
                                                             uint64_t cap2, uint4 *out_recs, uint32_t *out_bins, SkSpill sp, uint32_t nseg_in = PT_SEGMENTS,
-                                                            int bin_of = 0)
+                                                            int bin_of = 0, uint32_t piece = 0, uint32_t n_pieces = 1)
 {
+    // piece / n_pieces: the batch travels in n_pieces pieces (the level-1 pass of one runs next to this pass of the
+    // one before it); every leaf then has n_pieces segments of capacity cap2 and this launch fills segment `piece`.
     // bin_of == 0: super-k-mer records -- the bucket digits come from the bin word inside the record (rec.x) and the
     // second stream (in_bins / out_bins) is the records' read pointers; != 0: other 16-byte payloads (the entries of the
     // solid-table build) whose bin word IS the second stream.
@@ -888,13 +890,13 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk2_scatter(const uint4 *__restr
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 if (have[j])
-                    sk_emit(L.C, mulhi32(bin_of ? bin[j] : rec[j].x, np1 * m2) - bucket * m2, rec[j], bin[j], cap2, (uint64_t)bucket * n_buckets * cap2,
-                            cap2, out_recs, out_bins, sp);
+                    sk_emit(L.C, mulhi32(bin_of ? bin[j] : rec[j].x, np1 * m2) - bucket * m2, rec[j], bin[j], cap2,
+                            ((uint64_t)bucket * n_buckets * n_pieces + piece) * cap2, (uint64_t)n_pieces * cap2, out_recs, out_bins, sp);
             __syncthreads();
             if (tid < n_buckets) { L.C.wcur[tid] += L.C.cnt[tid]; L.C.cnt[tid] = 0; }
         }
         __syncthreads();
-        if (tid < n_buckets) leaf_counts[(uint64_t)bucket * n_buckets + tid] = min(L.C.wcur[tid], (uint32_t)cap2);
+        if (tid < n_buckets) leaf_counts[((uint64_t)bucket * n_buckets + tid) * n_pieces + piece] = min(L.C.wcur[tid], (uint32_t)cap2);
     }
 }
 

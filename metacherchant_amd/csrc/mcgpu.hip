@@ -63,6 +63,9 @@ struct mc_ctx {
     std::string err;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // the second scatter level of one piece of a batch runs here, next to the first level of the next piece (add_reads_partitioned)
+    hipStream_t pipe_stream = nullptr;
+    hipEvent_t ev_piece[8] = {}, ev_p2 = nullptr;
     // The read store: the packed bases of every read this context was given since the last mc_clear, batch after
     // batch (each starting on a word boundary).  Table slots point into it (kmer_device.h ptr_encode) and the BFS
     // reads its look-ahead from it.  rs_from: a BFS-only context (mc_solid_from_pairs_dev) borrows the store of the
@@ -126,7 +129,7 @@ struct mc_ctx {
         uint32_t *emit_counts = nullptr;  // fill levels of the solid list's segments (one per P3 workgroup)
         uint32_t *cursors1 = nullptr, *seg_counts1 = nullptr, *cursors2 = nullptr, *leaf_state = nullptr, *leaf_new = nullptr, *flags = nullptr;  // cursors1: owner cursors (multi-GPU split); cursors2: leaf fill levels; flags: [0] spill lost, [1] any leaf failed, [2] a segment of the solid list overflowed
         unsigned long long *spill_count = nullptr;
-        uint64_t a_cap = 0, b_cap = 0, spill_cap = 0, tiles1_cap = 0, leaves_cap = 0, segs1_cap = 0, a_hints_cap = 0, b_hints_cap = 0;
+        uint64_t a_cap = 0, b_cap = 0, spill_cap = 0, tiles1_cap = 0, leaves_cap = 0, segs1_cap = 0, a_hints_cap = 0, b_hints_cap = 0, cursors2_cap = 0;
         void release()
         {
             (void)hipFree(a_keys); (void)hipFree(b_keys); (void)hipFree(spill_keys);
@@ -919,6 +922,7 @@ struct PipePlan {
     uint32_t b1 = 0, b2 = 1, g = 0;  // b1 level-1 buckets of b2 leaves each (counts, not bits); a leaf covers 2^g regions
     uint64_t np1 = 0, n_leaves = 0, cap1 = 0, cap2 = 0, spill_cap = 0, wb = 0;
     uint32_t nseg1 = PT_SEGMENTS;  // segments of every level-1 bucket = workgroups of the level-1 kernel
+    uint32_t pieces = 1;           // the reads go through P1 / P2 in this many pieces (cap1, cap2: per piece); P3 sees `pieces` segments per leaf
     bool sk = false;  // the streams hold super-k-mer records; capacities are in records
     SpillView sp{};
     SkSpill sks{};
@@ -926,9 +930,10 @@ struct PipePlan {
 
 // Table capacity check, scratch buffers and cursors for one run of the partitioned pipeline over
 // `wb` key occurrences.  n_records != 0: they travel as (an estimated) n_records super-k-mer records.
-static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records = 0, uint32_t nseg1 = PT_SEGMENTS)
+static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records = 0, uint32_t nseg1 = PT_SEGMENTS, uint32_t pieces = 1)
 {
     pl->nseg1 = nseg1;
+    pl->pieces = pieces;
     mc_ctx::Pipe &P = c->pipe;
     c->solid_list_fresh = false;  // the pipeline buffers are about to be reused
     // Make sure the table can take the batch: with a capacity hint that still holds the table was sized for
@@ -967,36 +972,38 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
     pl->np1 = np1;
     pl->n_leaves = n_leaves;
     pl->sk = n_records != 0;
-    const uint64_t units = pl->sk ? n_records : wb;  // records in the streams
+    if (pl->b2 <= 1) pl->pieces = pieces = 1;  // (no second level to overlap with)
+    const uint64_t units = (pl->sk ? n_records : wb) / pieces + (pieces > 1 ? 1024 : 0);  // records in the streams (of one piece)
     pl->cap1 = (uint64_t)((double)units / (double)pl->np1 / (double)nseg1 * 1.25) + (pl->sk ? 64 : 256);  // per segment
     const double mean_leaf = (double)units / (double)pl->n_leaves;
     // (records of one locus come in clumps -- one per read covering it -- so leaves vary more than Poisson)
     pl->cap2 = (uint64_t)(mean_leaf * 1.15 + (pl->sk ? 32.0 : 8.0) * std::sqrt(mean_leaf) + 64.0);  // (a spilled record also costs the solid list, P3Emit)
-    pl->spill_cap = pl->sk ? std::max<uint64_t>(units / 16, 1u << 16) : std::max<uint64_t>(wb / 64, 1u << 20);
-    if (pl->np1 * nseg1 * pl->cap1 >= 0xFFFFFFFFull || (uint64_t)pl->b2 * pl->cap2 >= 0xFFFFFFFFull)
+    pl->spill_cap = pl->sk ? std::max<uint64_t>(units * pieces / 16, 1u << 16) : std::max<uint64_t>(wb / 64, 1u << 20);
+    if (pl->np1 * nseg1 * pl->cap1 >= 0xFFFFFFFFull || (uint64_t)pl->b2 * pl->cap2 * pieces >= 0xFFFFFFFFull)
         return fail(c, MC_EINVAL, "internal: partitioned batch too large for 32-bit bucket indices");
     // (np1, n_leaves as computed above)
     int rc;
     uint64_t dummy;
 #define ENSURE(ptr, capvar, need) do { rc = ensure_buf(c, &(ptr), &(capvar), (need)); if (rc) return rc; } while (0)
     if (pl->sk) {
-        ENSURE(P.a_recs, P.a_recs_cap, np1 * nseg1 * pl->cap1);
-        if (pl->b2 > 1) ENSURE(P.b_recs, P.b_recs_cap, n_leaves * pl->cap2);
+        ENSURE(P.a_recs, P.a_recs_cap, np1 * nseg1 * pl->cap1 * pieces);
+        if (pl->b2 > 1) ENSURE(P.b_recs, P.b_recs_cap, n_leaves * pl->cap2 * pieces);
         ENSURE(P.spill_recs, P.spill_recs_cap, pl->spill_cap);
     } else {
         { uint64_t cap = P.a_cap; ENSURE(P.a_keys, cap, np1 * nseg1 * pl->cap1); P.a_cap = cap; }
         { uint64_t cap = P.b_cap; ENSURE(P.b_keys, cap, n_leaves * pl->cap2); P.b_cap = cap; }
         { uint64_t cap = P.spill_cap; ENSURE(P.spill_keys, cap, pl->spill_cap); dummy = P.spill_cap; ENSURE(P.spill_hints, dummy, pl->spill_cap); P.spill_cap = cap; }
     }
-    ENSURE(P.a_hints, P.a_hints_cap, np1 * nseg1 * pl->cap1);
-    ENSURE(P.b_hints, P.b_hints_cap, n_leaves * pl->cap2);
-    ENSURE(P.seg_counts1, P.segs1_cap, np1 * nseg1);
-    { uint64_t cap = P.leaves_cap; ENSURE(P.cursors2, cap, n_leaves); dummy = P.leaves_cap; ENSURE(P.leaf_state, dummy, n_leaves); dummy = P.leaves_cap; ENSURE(P.leaf_new, dummy, n_leaves); P.leaves_cap = cap; }
+    ENSURE(P.a_hints, P.a_hints_cap, np1 * nseg1 * pl->cap1 * pieces);
+    ENSURE(P.b_hints, P.b_hints_cap, n_leaves * pl->cap2 * pieces);
+    ENSURE(P.seg_counts1, P.segs1_cap, np1 * nseg1 * pieces);
+    ENSURE(P.cursors2, P.cursors2_cap, n_leaves * pieces);
+    { uint64_t cap = P.leaves_cap; ENSURE(P.leaf_state, cap, n_leaves); dummy = P.leaves_cap; ENSURE(P.leaf_new, dummy, n_leaves); P.leaves_cap = cap; }
 #undef ENSURE
     if (!P.flags) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.flags), 4 * sizeof(uint32_t)));
     if (!P.spill_count) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.spill_count), sizeof(unsigned long long)));
-    HIPCHK(c, hipMemsetAsync(P.seg_counts1, 0, np1 * nseg1 * sizeof(uint32_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(P.cursors2, 0, n_leaves * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(P.seg_counts1, 0, np1 * nseg1 * pieces * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(P.cursors2, 0, n_leaves * pieces * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(P.leaf_state, 0, n_leaves * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(P.leaf_new, 0, n_leaves * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(P.flags, 0, 4 * sizeof(uint32_t), c->stream));
@@ -1009,14 +1016,14 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
 // P2, P3 (with the retry after growing the table), spill drain and bookkeeping; ms1 = time of the
 // level-1 scatter that filled the a_* buckets.  Returns 1 (nothing merged yet) when the streams
 // overflowed even their spill list: the caller then counts the batch with the direct kernel.
-static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1)
-{
+static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false, double ms2_exposed = 0)
+{   // p2_done: the caller ran P2 itself, piece by piece next to P1 (ms2_exposed = what of it outlasted P1)
     mc_ctx::Pipe &P = c->pipe;
     const uint64_t np1 = pl.np1, n_leaves = pl.n_leaves;
     const int k = c->cfg.k;
     int rc;
-    double ms2 = 0, ms3 = 0;
-    if (pl.b2 > 1) {
+    double ms2 = ms2_exposed, ms3 = 0;
+    if (pl.b2 > 1 && !p2_done) {
         rc = timed(c, &ms2, [&] {
             if (pl.sk)
                 hipLaunchKernelGGL(k_sk2_scatter, dim3((unsigned)np1), dim3(PT_THREADS), 0, c->stream, P.a_recs, P.a_hints, pl.cap1,
@@ -1039,7 +1046,7 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1)
     const uint32_t *lh = pl.b2 > 1 ? P.b_hints : P.a_hints;
     const uint32_t *lc = pl.b2 > 1 ? P.cursors2 : P.seg_counts1;
     const uint64_t lcap = pl.b2 > 1 ? pl.cap2 : pl.cap1;
-    const uint32_t lseg = pl.b2 > 1 ? 1u : pl.nseg1;
+    const uint32_t lseg = pl.b2 > 1 ? pl.pieces : pl.nseg1;
     // The solid list (P3Emit): super-k-mer form with the leaves in b_recs, so that a_recs is free to take it, and a
     // threshold to track.  Each P3 workgroup owns a segment.
     const int p3_grid = (int)std::min<uint64_t>(n_leaves, 256 * 2 * 4);
@@ -1203,8 +1210,17 @@ static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint6
     PipePlan pl;
     const uint64_t nr = r1 - r0;
     const uint64_t n_records = c->mm_k ? sk_records_bound(c, wb, nr) : 0;
-    int rc = pipe_prepare(c, wb, &pl, n_records, n_records ? (uint32_t)P1W_SEGMENTS : (uint32_t)PT_SEGMENTS);
+    // MC_PIPE_PIECES=n (an experiment, off by default): the reads go through the two scatter levels in n pieces, the
+    // second level of piece p on a side stream next to the first level of piece p + 1; the merge kernel then finds n
+    // segments per leaf.  Measured on configs[1] (P1 + exposed P2 + P3): 1 piece 6.1 + 2.7 + 9.3 = 18.2 ms, 2 pieces
+    // 7.0 + 1.4 + 9.5 = 17.9, 4 pieces 7.6 + 0.7 + 10.9 = 19.2 -- the two levels slow each other down by nearly what
+    // the overlap hides, and the merge pays for the shorter segments.
+    uint32_t pieces = 1;
+    if (const char *e = getenv("MC_PIPE_PIECES")) pieces = (uint32_t)std::min<unsigned long>(8, std::max<unsigned long>(1, strtoul(e, nullptr, 10)));
+    if (!n_records) pieces = 1;
+    int rc = pipe_prepare(c, wb, &pl, n_records, n_records ? (uint32_t)P1W_SEGMENTS : (uint32_t)PT_SEGMENTS, pieces);
     if (rc) return rc;
+    pieces = pl.pieces;
     const uint64_t *offs = d_off + r0;
     // tiles are cut over the absolute base positions [0, end_abs); the ones before base0 hold no read of ours
     const uint32_t tile_size = pl.sk ? P1W_TILE : (uint32_t)PT_TILE;
@@ -1212,18 +1228,50 @@ static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint6
     rc = ensure_buf(c, &P.tile_first, &P.tiles1_cap, n_tiles_abs);
     if (rc) return rc;
     double ms1 = 0;
-    rc = timed(c, &ms1, [&] {
+    if (pieces > 1) {
+        const uint64_t t_first = base0 / tile_size, per = (n_tiles_abs - t_first + pieces - 1) / pieces;
+        const uint64_t a_stride = pl.np1 * pl.nseg1 * pl.cap1, c_stride = pl.np1 * pl.nseg1;
+        HIPCHK(c, hipEventRecord(c->ev0, c->stream));
         hipLaunchKernelGGL(k_tile_first_read, dim3((unsigned)((n_tiles_abs + 255) / 256)), dim3(256), 0, c->stream, offs, nr,
                            n_tiles_abs, P.tile_first, tile_size);
-        if (pl.sk)
-            hipLaunchKernelGGL(k_sk1w_extract<false>, dim3(P1W_SEGMENTS), dim3(P1W_THREADS), 0, c->stream, d_words, offs, nr, base0, end_abs,
-                               n_tiles_abs, P.tile_first, c->cfg.k, pl.b1, P.seg_counts1, pl.cap1, P.a_recs, P.a_hints, pl.sks, c->cur_ptr_base);
-        else
-            launch_p1_reads(c, d_words, offs, nr, base0, end_abs, n_tiles_abs, P.tile_first, pl.b1, P.seg_counts1, pl.cap1, P.a_keys,
-                            P.a_hints, pl.sp, 0, nullptr);
-    });
-    if (rc) return rc;
-    rc = pipe_finish(c, pl, ms1);
+        for (uint32_t pc = 0; pc < pieces; pc++) {
+            const uint64_t lo_t = t_first + pc * per, hi_t = std::min<uint64_t>(n_tiles_abs, lo_t + per);
+            if (lo_t < hi_t)
+                hipLaunchKernelGGL(k_sk1w_extract<false>, dim3(P1W_SEGMENTS), dim3(P1W_THREADS), 0, c->stream, d_words, offs, nr,
+                                   pc == 0 ? base0 : lo_t * tile_size, end_abs, hi_t, P.tile_first, c->cfg.k, pl.b1, P.seg_counts1 + pc * c_stride,
+                                   pl.cap1, P.a_recs + pc * a_stride, P.a_hints + pc * a_stride, pl.sks, c->cur_ptr_base);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipEventRecord(c->ev_piece[pc], c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->pipe_stream, c->ev_piece[pc], 0));
+            hipLaunchKernelGGL(k_sk2_scatter, dim3((unsigned)pl.np1), dim3(PT_THREADS), 0, c->pipe_stream, P.a_recs + pc * a_stride,
+                               P.a_hints + pc * a_stride, pl.cap1, P.seg_counts1 + pc * c_stride, (uint32_t)pl.np1, pl.b1, pl.b2, P.cursors2,
+                               pl.cap2, P.b_recs, P.b_hints, pl.sks, pl.nseg1, 0, pc, pieces);
+            HIPCHK(c, hipGetLastError());
+        }
+        HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+        HIPCHK(c, hipEventRecord(c->ev_p2, c->pipe_stream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_p2, 0));
+        HIPCHK(c, hipEventSynchronize(c->ev_p2));
+        HIPCHK(c, hipEventSynchronize(c->ev1));
+        float f1 = 0, f2 = 0;
+        HIPCHK(c, hipEventElapsedTime(&f1, c->ev0, c->ev1));
+        HIPCHK(c, hipEventElapsedTime(&f2, c->ev1, c->ev_p2));  // what the last piece's second level adds behind the first levels
+        ms1 = f1;
+        rc = pipe_finish(c, pl, ms1, true, f2 > 0 ? f2 : 0);
+    } else {
+        rc = timed(c, &ms1, [&] {
+            hipLaunchKernelGGL(k_tile_first_read, dim3((unsigned)((n_tiles_abs + 255) / 256)), dim3(256), 0, c->stream, offs, nr,
+                               n_tiles_abs, P.tile_first, tile_size);
+            if (pl.sk)
+                hipLaunchKernelGGL(k_sk1w_extract<false>, dim3(P1W_SEGMENTS), dim3(P1W_THREADS), 0, c->stream, d_words, offs, nr, base0, end_abs,
+                                   n_tiles_abs, P.tile_first, c->cfg.k, pl.b1, P.seg_counts1, pl.cap1, P.a_recs, P.a_hints, pl.sks, c->cur_ptr_base);
+            else
+                launch_p1_reads(c, d_words, offs, nr, base0, end_abs, n_tiles_abs, P.tile_first, pl.b1, P.seg_counts1, pl.cap1, P.a_keys,
+                                P.a_hints, pl.sp, 0, nullptr);
+        });
+        if (rc) return rc;
+        rc = pipe_finish(c, pl, ms1);
+    }
     if (rc != 1) return rc;
     // (super-k-mer streams overflowed: unusually short runs) count this batch with the direct kernel instead
     uint64_t r = r0;
@@ -1454,6 +1502,9 @@ int mc_create(const mc_config *cfg, mc_ctx **out)
     c->stream = c->own_stream;
     CREATE_CHK(hipEventCreate(&c->ev0));
     CREATE_CHK(hipEventCreate(&c->ev1));
+    CREATE_CHK(hipStreamCreateWithFlags(&c->pipe_stream, hipStreamNonBlocking));
+    for (auto &e : c->ev_piece) CREATE_CHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    CREATE_CHK(hipEventCreate(&c->ev_p2));
     CREATE_CHK(hipMalloc(reinterpret_cast<void **>(&c->d_ctr), 8 * sizeof(unsigned long long)));
     CREATE_CHK(hipMalloc(reinterpret_cast<void **>(&c->d_fatal), sizeof(uint32_t)));
     CREATE_CHK(hipMalloc(reinterpret_cast<void **>(&c->d_ovf), mc_ctx::OVF_CAP * sizeof(uint4)));
@@ -1504,6 +1555,9 @@ void mc_destroy(mc_ctx *c)
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->rs_words) (void)hipFree(c->rs_words);
+    for (auto &e : c->ev_piece) if (e) (void)hipEventDestroy(e);
+    if (c->ev_p2) (void)hipEventDestroy(c->ev_p2);
+    if (c->pipe_stream) { (void)hipStreamSynchronize(c->pipe_stream); (void)hipStreamDestroy(c->pipe_stream); }
     for (char *p : c->pin) if (p) (void)hipHostFree(p);
     for (hipStream_t st : c->pin_stream) if (st) (void)hipStreamDestroy(st);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
