@@ -233,6 +233,26 @@ int mc_extract_superkmers_dev(mc_ctx *ctx, const uint64_t *d_words, const uint64
                               uint64_t records_cap, uint64_t *owner_offsets);
 int mc_add_superkmers_dev(mc_ctx *ctx, const uint64_t *d_records, const uint32_t *d_bins, uint64_t n);
 
+/* ---- several GPUs of one node as ONE table, for a host that is one process (the native `metacherchant --devices 0,1,...`).
+ * A context per device and one host thread per device; reads are dealt to the devices in equal contiguous shares, every
+ * device buckets its share by owner (mc_extract_superkmers_dev / mc_extract_keys_dev), the buckets travel as peer-to-peer
+ * copies over xGMI -- every (source, destination) pair at once -- and every device counts what it owns
+ * (mc_add_superkmers_dev / mc_add_keys_dev); for the BFS the k-mers at or above the threshold are gathered on the first
+ * device (mc_export_dev -> mc_solid_from_pairs_dev) and the walk runs there.  Results equal a single context's.
+ * `cfg->device` is ignored; capacity_hint is the whole job's.  A device may be named more than once (shares of one GPU).
+ * Replaces the same Java as the single-context calls: the P threads over one shared map of src/io/IOUtils.java:283-315 and
+ * the work list of src/io/ReadsDispatcher.java:34-53.  ctx may be NULL in mc_group_last_error after a failed create. */
+typedef struct mc_group mc_group;
+int mc_group_create(const mc_config *cfg, const int32_t *devices, uint32_t n_devices, mc_group **out);
+void mc_group_destroy(mc_group *g);
+const char *mc_group_last_error(const mc_group *g);
+int mc_group_set_coverage_hint(mc_group *g, int min_cov);
+int mc_group_add_reads_packed(mc_group *g, const uint64_t *words, const uint64_t *read_offsets, uint64_t n_reads);
+int mc_group_add_reads_file(mc_group *g, const char *path, uint64_t *n_reads);
+int mc_group_finalize_counts(mc_group *g, uint64_t *n_distinct);
+int mc_group_bfs_batch(mc_group *g, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov, int64_t max_kmers,
+                       int64_t max_radius, mc_bfs_result *out);
+
 /* ---- the table as a file: `kmer-counter`'s <name>.kmers.bin and <name>.stat.txt (src/tools/KmersCounter.java:87-121).
  * mc_save_kmers = IOUtils.printKmers (src/io/IOUtils.java:39-65): one 10-byte record per key with count >
  * threshold -- big-endian int64 key, big-endian int16 count (saturated) -- in table order (the reference's order

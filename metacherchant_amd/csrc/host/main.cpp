@@ -65,6 +65,7 @@ struct Options {
     std::vector<std::string> env;
     bool bothdirs = false, forcehash = false, trim = false, merge = false, cont = false, force = false, help = false;
     unsigned long long capacity_hint = 0;
+    std::vector<int> devices;  // --devices 0,1,...: several GPUs as one table (mc_group_*); empty: --device alone
 };
 
 struct OptSpec { const char *name; const char *shortopt; int kind; };  // kind: 0 value, 1 bool (optional arg), 2 multi
@@ -74,7 +75,7 @@ const OptSpec SPECS[] = {
     {"chunklength", nullptr, 0}, {"forcehash", nullptr, 1}, {"hash", nullptr, 0}, {"trim", nullptr, 1},
     {"merge", nullptr, 1}, {"work-dir", "w", 0}, {"available-processors", "p", 0}, {"memory", "m", 0},
     {"continue", "c", 1}, {"force", nullptr, 1}, {"verbose", "v", 1}, {"help", "h", 1}, {"tool", "t", 0},
-    {"device", nullptr, 0}, {"capacity-hint", nullptr, 0}, {"output-dir", nullptr, 0}, {"env", "e", 2}, {"geneid", "g", 0},
+    {"device", nullptr, 0}, {"devices", nullptr, 0}, {"capacity-hint", nullptr, 0}, {"output-dir", nullptr, 0}, {"env", "e", 2}, {"geneid", "g", 0},
 };
 
 const OptSpec *find_spec(const std::string &tok)
@@ -165,6 +166,24 @@ Options parse_args(int argc, char **argv)
     if (auto v = val("geneid")) o.geneid = (int)parse_int("geneid", *v);
     if (auto v = val("device")) o.device = (int)parse_int("device", *v);
     if (auto v = val("capacity-hint")) o.capacity_hint = (unsigned long long)parse_int("capacity-hint", *v);
+    if (auto v = val("devices")) {  // "0,1,2" or "0-7"
+        const std::string &d = *v;
+        const size_t dash = d.find('-');
+        if (dash != std::string::npos && d.find(',') == std::string::npos) {
+            const long long a = parse_int("devices", d.substr(0, dash)), b = parse_int("devices", d.substr(dash + 1));
+            for (long long i = a; i <= b; i++) o.devices.push_back((int)i);
+        } else {
+            size_t at = 0;
+            while (at <= d.size()) {
+                const size_t comma = d.find(',', at);
+                const std::string tok = d.substr(at, comma == std::string::npos ? std::string::npos : comma - at);
+                if (!tok.empty()) o.devices.push_back((int)parse_int("devices", tok));
+                if (comma == std::string::npos) break;
+                at = comma + 1;
+            }
+        }
+        if (o.devices.empty() || o.devices.size() > 64) throw Error("--devices: give 1 to 64 GPU ordinals, e.g. 0,1,2,3 or 0-7");
+    }
     return o;
 }
 
@@ -191,7 +210,8 @@ void usage()
     puts("Input parameters of --tool kmer-counter: -k, -i/--reads, --hash, --output-dir <dir> (default <work-dir>/kmers)");
     puts("Launch options: -w/--work-dir <dir> (default workDir), -c/--continue, --force, -v/--verbose, -h/--help,");
     puts("                -t/--tool <name>, -p/--available-processors <n> and -m/--memory <arg> (accepted, unused),");
-    puts("                --device <n> (GPU ordinal), --capacity-hint <distinct k-mers>");
+    puts("                --device <n> (GPU ordinal), --devices <a,b,...|a-b> (several GPUs as one table: reads dealt to them,");
+    puts("                k-mers exchanged by owner over xGMI, BFS on the first), --capacity-hint <distinct k-mers>");
 }
 
 #define MC_CHECK(ctx, call)                                                       \
@@ -231,18 +251,42 @@ bool open_work_dir(const Options &o, const std::string &props)
     return true;
 }
 
+// One table on one GPU (mc_*), or on several (mc_group_*: --devices): the calls environment-finder makes
+struct Engine {
+    mc_ctx *c = nullptr;
+    mc_group *g = nullptr;
+    ~Engine() { if (g) mc_group_destroy(g); else mc_destroy(c); }
+    void open(const mc_config &cfg, const std::vector<int> &devices)
+    {
+        if (devices.empty()) {
+            if (mc_create(&cfg, &c) != MC_OK) throw Error(std::string(mc_last_error(nullptr)));
+        } else {
+            std::vector<int32_t> d(devices.begin(), devices.end());
+            if (mc_group_create(&cfg, d.data(), (uint32_t)d.size(), &g) != MC_OK) throw Error(std::string(mc_group_last_error(nullptr)));
+        }
+    }
+    void check(int rc) const { if (rc != MC_OK) throw Error(std::string(g ? mc_group_last_error(g) : mc_last_error(c))); }
+    void set_coverage_hint(int cov) { check(g ? mc_group_set_coverage_hint(g, cov) : mc_set_coverage_hint(c, cov)); }
+    void add_reads_file(const std::string &path, uint64_t *n) { check(g ? mc_group_add_reads_file(g, path.c_str(), n) : mc_add_reads_file(c, path.c_str(), n)); }
+    void finalize(uint64_t *n) { check(g ? mc_group_finalize_counts(g, n) : mc_finalize_counts(c, n)); }
+    void bfs_batch(const mc_bfs_job *jobs, uint32_t n, int cov, int64_t mk, int64_t mr, mc_bfs_result *out)
+    {
+        check(g ? mc_group_bfs_batch(g, jobs, n, cov, mk, mr, out) : mc_bfs_batch(c, jobs, n, cov, mk, mr, out));
+    }
+};
+
 // the reads of all --reads files into the table; returns hm.size()
-uint64_t load_reads(const Options &o, mc_ctx *ctx)
+uint64_t load_reads(const Options &o, Engine &e)
 {
     for (const std::string &path : o.reads) {
         const size_t slash = path.find_last_of('/');
         info("Loading file " + (slash == std::string::npos ? path : path.substr(slash + 1)) + "...");
         uint64_t n = 0;
-        MC_CHECK(ctx, mc_add_reads_file(ctx, path.c_str(), &n));
+        e.add_reads_file(path, &n);
         info(group_digits(n) + " reads added");
     }
     uint64_t n_distinct = 0;
-    MC_CHECK(ctx, mc_finalize_counts(ctx, &n_distinct));
+    e.finalize(&n_distinct);
     info("Hashtable size: " + std::to_string(n_distinct) + " kmers");
     return n_distinct;
 }
@@ -267,10 +311,11 @@ int run_kmer_counter(const Options &o)
     cfg.key_mode = mode;
     cfg.device = o.device;
     cfg.capacity_hint = o.capacity_hint;
-    CtxGuard G;
-    if (mc_create(&cfg, &G.c) != MC_OK) throw Error(std::string(mc_last_error(nullptr)));
-    mc_ctx *ctx = G.c;
-    const uint64_t size = load_reads(o, ctx);
+    if (!o.devices.empty()) throw Error("--devices is for --tool environment-finder: kmer-counter writes one device's table (--device)");
+    Engine E;
+    E.open(cfg, {});
+    mc_ctx *ctx = E.c;
+    const uint64_t size = load_reads(o, E);
     // ReadersUtils.readDnaLazy(file).name(): the first file's name without its format extension
     std::string name = o.reads[0];
     const size_t slash = name.find_last_of('/');
@@ -355,13 +400,13 @@ int run(const Options &o)
     cfg.key_mode = mode;
     cfg.device = o.device;
     cfg.capacity_hint = o.capacity_hint;
-    CtxGuard G;
-    if (mc_create(&cfg, &G.c) != MC_OK) throw Error(std::string(mc_last_error(nullptr)));
-    mc_ctx *ctx = G.c;
-    MC_CHECK(ctx, mc_set_coverage_hint(ctx, o.coverage));
+    Engine E;
+    E.open(cfg, o.devices);
+    if (!o.devices.empty()) info("Counting on " + std::to_string(o.devices.size()) + " devices");
+    E.set_coverage_hint(o.coverage);
 
     const auto t0 = std::chrono::steady_clock::now();
-    const uint64_t n_distinct = load_reads(o, ctx);
+    const uint64_t n_distinct = load_reads(o, E);
     logline("DEBUG", "k-mers HM size = " + group_digits(n_distinct));
     const auto t1 = std::chrono::steady_clock::now();
 
@@ -427,8 +472,7 @@ int run(const Options &o)
             std::vector<mc_bfs_result> &r;
             ~ResGuard() { for (auto &x : r) mc_bfs_result_free(&x); }
         } guard{res};
-        if (!jobs.empty())
-            MC_CHECK(ctx, mc_bfs_batch(ctx, jobs.data(), (uint32_t)jobs.size(), o.coverage, o.maxkmers, o.maxradius, res.data()));
+        if (!jobs.empty()) E.bfs_batch(jobs.data(), (uint32_t)jobs.size(), o.coverage, o.maxkmers, o.maxradius, res.data());
         const auto tb1 = std::chrono::steady_clock::now();
         bfs_ms += ms_between(tb0, tb1);
 
@@ -464,7 +508,7 @@ int run(const Options &o)
     info("Finished processing all sequences!");
 
     mc_stats stt{};
-    mc_get_stats(ctx, &stt);
+    if (E.c) mc_get_stats(E.c, &stt);  // (several devices: per-device statistics are not summed up here)
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     char buf[512];
     snprintf(buf, sizeof buf,

@@ -2721,3 +2721,297 @@ int mc_bfs(mc_ctx *c, const uint64_t *seed_hi, const uint64_t *seed_lo, uint64_t
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------ several GPUs as one table
+// mc_group: the native counterpart of metacherchant_amd/distributed.py, for a host that is one
+// process: a context per device, one host thread per device for the work, and the exchange as peer-to-peer copies --
+// every (source, destination) pair at once, so that all xGMI links of a GPU are busy together, which is what an
+// all-to-all over RCCL's grouped send / recv does too.  Reads are dealt to the devices in equal contiguous shares, every
+// device turns its share into super-k-mer records (keys for k < 23 / hash keys) bucketed by owner, the buckets travel,
+// every device counts what it owns (disjoint key sets).  For the BFS the shards' k-mers at or above the threshold are
+// gathered on the first device into a BFS-only context that borrows that device's read store (read pointers refer to the
+// first device's reads: the others keep none).  What the reference does instead: P threads over one shared map
+// (src/io/IOUtils.java:283-315, src/io/ReadsDispatcher.java:34-53).
+
+struct mc_group {
+    std::vector<mc_ctx *> ctx;  // one per device, in the order given
+    mc_ctx *solid = nullptr;    // BFS-only context on the first device (n > 1)
+    int solid_cov = -1;
+    bool dirty = true;          // counts changed since the shards were gathered
+    mc_config cfg{};
+    std::string err;
+    std::mutex mu;
+};
+
+namespace {
+
+int gfail(mc_group *g, int code, const std::string &msg)
+{
+    if (g) g->err = msg;
+    return code;
+}
+
+// runs f(rank) on one thread per rank; returns the first non-zero result
+template <typename F>
+int per_rank(size_t n, F &&f)
+{
+    std::vector<int> rc(n, 0);
+    std::vector<std::thread> th;
+    for (size_t r = 1; r < n; r++) th.emplace_back([&, r] { rc[r] = f(r); });
+    rc[0] = f(0);
+    for (auto &t : th) t.join();
+    for (int x : rc) if (x) return x;
+    return MC_OK;
+}
+
+// bytes from a buffer of src's device to one of dst's (the same device: a plain device copy)
+hipError_t peer_copy(void *d, const mc_ctx *dst, const void *s, const mc_ctx *src, size_t bytes, hipStream_t st)
+{
+    if (bytes == 0) return hipSuccess;
+    if (dst->cfg.device == src->cfg.device) return hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, st);
+    return hipMemcpyPeerAsync(d, dst->cfg.device, s, src->cfg.device, bytes, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mc_group_last_error(const mc_group *g) { return g ? g->err.c_str() : g_create_err.c_str(); }
+
+void mc_group_destroy(mc_group *g)
+{
+    if (!g) return;
+    if (g->solid) mc_destroy(g->solid);
+    for (mc_ctx *c : g->ctx) mc_destroy(c);
+    delete g;
+}
+
+int mc_group_create(const mc_config *cfg, const int32_t *devices, uint32_t n_devices, mc_group **out)
+{
+    if (!cfg || !devices || !out || n_devices == 0 || n_devices > 64) return fail(nullptr, MC_EINVAL, "mc_group_create: bad argument");
+    *out = nullptr;
+    mc_group *g = new (std::nothrow) mc_group;
+    if (!g) return fail(nullptr, MC_ENOMEM, "mc_group_create: out of host memory");
+    g->cfg = *cfg;
+    for (uint32_t r = 0; r < n_devices; r++) {
+        mc_config c = *cfg;
+        c.device = devices[r];
+        c.capacity_hint = cfg->capacity_hint ? cfg->capacity_hint / n_devices + (1u << 20) : 0;  // owners hold equal shares of the keys
+        if (n_devices > 1) c.flags |= MC_FLAG_SOLID_LIST;                                           // its solid k-mers will be exported
+        mc_ctx *x = nullptr;
+        const int rc = mc_create(&c, &x);
+        if (rc) { mc_group_destroy(g); return rc; }
+        g->ctx.push_back(x);
+        if (r > 0) (void)mc_set_read_pointers(x, 0);  // (the BFS device cannot see this one's reads)
+    }
+    // peer access between every pair of different devices (already enabled: fine)
+    for (uint32_t a = 0; a < n_devices; a++)
+        for (uint32_t b = 0; b < n_devices; b++) {
+            if (devices[a] == devices[b]) continue;
+            if (hipSetDevice(devices[a]) == hipSuccess) { (void)hipDeviceEnablePeerAccess(devices[b], 0); (void)hipGetLastError(); }
+        }
+    if (n_devices > 1) {
+        mc_config c = *cfg;
+        c.device = devices[0];
+        c.capacity_hint = 1u << 20;
+        c.flags = 0;
+        const int rc = mc_create(&c, &g->solid);
+        if (rc) { mc_group_destroy(g); return rc; }
+    }
+    *out = g;
+    return MC_OK;
+}
+
+int mc_group_set_coverage_hint(mc_group *g, int min_cov)
+{
+    if (!g) return MC_EINVAL;
+    for (mc_ctx *c : g->ctx) {
+        const int rc = mc_set_coverage_hint(c, min_cov);
+        if (rc) return gfail(g, rc, mc_last_error(c));
+    }
+    return MC_OK;
+}
+
+int mc_group_add_reads_packed(mc_group *g, const uint64_t *words, const uint64_t *off, uint64_t n_reads)
+{
+    if (!g) return MC_EINVAL;
+    std::lock_guard<std::mutex> lk(g->mu);
+    if ((!words || !off) && n_reads) return gfail(g, MC_EINVAL, "mc_group_add_reads_packed: null pointer");
+    if (n_reads == 0) return MC_OK;
+    g->dirty = true;
+    const size_t W = g->ctx.size();
+    if (W == 1) {
+        const int rc = mc_add_reads_packed(g->ctx[0], words, off, n_reads);
+        return rc ? gfail(g, rc, mc_last_error(g->ctx[0])) : MC_OK;
+    }
+    const int k = g->cfg.k;
+    const bool sk = g->ctx[0]->sk_form;
+    struct Rank {
+        DevBuf<uint64_t> dw, doff, send, recv;   // reads; what goes out (records: 2 words each, or keys) and what came in
+        DevBuf<uint32_t> send_p, recv_p;         // the read pointers that travel with them
+        std::vector<uint64_t> owner_off;         // owner o's piece of `send` = [owner_off[o], owner_off[o + 1])
+        uint64_t n_recv = 0;
+    };
+    std::vector<Rank> R(W);
+    // ---- every device: its share of the reads -> records (keys) bucketed by owner
+    int rc = per_rank(W, [&](size_t r) -> int {
+        mc_ctx *c = g->ctx[r];
+        const uint64_t a = n_reads * r / W, b = n_reads * (r + 1) / W;
+        R[r].owner_off.assign(W + 1, 0);
+        if (a == b) return MC_OK;
+        if (hipSetDevice(c->cfg.device) != hipSuccess) return MC_EHIP;
+        const uint64_t w0 = off[a] / 32, w1 = (off[b] + 31) / 32 + 1, nb = off[b] - w0 * 32;
+        std::vector<uint64_t> rel(off + a, off + b + 1);
+        uint64_t windows = 0;
+        for (uint64_t i = 0; i < b - a; i++) {
+            const uint64_t len = rel[i + 1] - rel[i];
+            if (len >= (uint64_t)k) windows += len - (uint64_t)k + 1;
+        }
+        for (auto &x : rel) x -= w0 * 32;
+        if (R[r].dw.alloc(w1 - w0) != hipSuccess || R[r].doff.alloc(b - a + 1) != hipSuccess) return MC_ENOMEM;
+        if (hipMemcpy(R[r].dw.p, words + w0, (w1 - w0) * 8, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(R[r].doff.p, rel.data(), (b - a + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) return MC_EHIP;
+        if (windows == 0) return MC_OK;
+        if (sk) {
+            const uint64_t cap = mc_superkmer_capacity(c, windows, b - a);
+            if (R[r].send.alloc(cap * 2) != hipSuccess || R[r].send_p.alloc(cap) != hipSuccess) return MC_ENOMEM;
+            return mc_extract_superkmers_dev(c, R[r].dw.p, R[r].doff.p, b - a, nb, (uint32_t)W, R[r].send.p, R[r].send_p.p, cap, R[r].owner_off.data());
+        }
+        if (R[r].send.alloc(windows) != hipSuccess || R[r].send_p.alloc(windows) != hipSuccess) return MC_ENOMEM;
+        return mc_extract_keys_dev(c, R[r].dw.p, R[r].doff.p, b - a, nb, (uint32_t)W, reinterpret_cast<int64_t *>(R[r].send.p), R[r].send_p.p, windows,
+                                   R[r].owner_off.data());
+    });
+    if (rc) {
+        for (mc_ctx *c : g->ctx) if (!c->err.empty()) return gfail(g, rc, c->err);
+        return gfail(g, rc, "mc_group_add_reads_packed: extraction failed");
+    }
+    // ---- the exchange: owner d receives its piece of every rank's output, all pairs at once
+    const size_t unit = sk ? 16 : 8;
+    rc = per_rank(W, [&](size_t d) -> int {
+        mc_ctx *c = g->ctx[d];
+        if (hipSetDevice(c->cfg.device) != hipSuccess) return MC_EHIP;
+        uint64_t total = 0;
+        for (size_t r = 0; r < W; r++) total += R[r].owner_off[d + 1] - R[r].owner_off[d];
+        R[d].n_recv = total;
+        if (total == 0) return MC_OK;
+        if (R[d].recv.alloc(total * (sk ? 2 : 1)) != hipSuccess || R[d].recv_p.alloc(total) != hipSuccess) return MC_ENOMEM;
+        uint64_t at = 0;
+        for (size_t r = 0; r < W; r++) {
+            const uint64_t o0 = R[r].owner_off[d], m = R[r].owner_off[d + 1] - o0;
+            if (peer_copy(reinterpret_cast<char *>(R[d].recv.p) + at * unit, c, reinterpret_cast<const char *>(R[r].send.p) + o0 * unit, g->ctx[r], m * unit, c->stream) != hipSuccess ||
+                peer_copy(R[d].recv_p.p + at, c, R[r].send_p.p + o0, g->ctx[r], m * 4, c->stream) != hipSuccess)
+                return MC_EHIP;
+            at += m;
+        }
+        return hipStreamSynchronize(c->stream) == hipSuccess ? MC_OK : MC_EHIP;
+    });
+    if (rc) return gfail(g, rc, "mc_group_add_reads_packed: the exchange between the devices failed (peer copy)");
+    // ---- every device counts what it owns
+    rc = per_rank(W, [&](size_t d) -> int {
+        if (R[d].n_recv == 0) return MC_OK;
+        return sk ? mc_add_superkmers_dev(g->ctx[d], R[d].recv.p, R[d].recv_p.p, R[d].n_recv)
+                  : mc_add_keys_dev(g->ctx[d], reinterpret_cast<const int64_t *>(R[d].recv.p), R[d].recv_p.p, R[d].n_recv);
+    });
+    if (rc) {
+        for (mc_ctx *c : g->ctx) if (!c->err.empty()) return gfail(g, rc, c->err);
+        return gfail(g, rc, "mc_group_add_reads_packed: counting failed");
+    }
+    return MC_OK;
+}
+
+int mc_group_add_reads_file(mc_group *g, const char *path, uint64_t *n_reads)
+{
+    if (!g) return MC_EINVAL;
+    if (n_reads) *n_reads = 0;
+    if (!path) return gfail(g, MC_EINVAL, "mc_group_add_reads_file: null path");
+    if (g->ctx.size() == 1) {
+        const int rc = mc_add_reads_file(g->ctx[0], path, n_reads);
+        return rc ? gfail(g, rc, mc_last_error(g->ctx[0])) : MC_OK;
+    }
+    try {  // batches of 2^20 reads per device
+        int rc = MC_OK;
+        const uint64_t n = mch::load_reads_file(path, g->ctx.size() << 20, [&](mch::PackedBatch &b) {
+            if (rc == MC_OK) rc = mc_group_add_reads_packed(g, b.words.data(), b.offsets.data(), b.n_reads());
+        });
+        if (rc != MC_OK) return rc;
+        if (n_reads) *n_reads = n;
+        return MC_OK;
+    } catch (const mch::Error &e) {
+        return gfail(g, MC_EINVAL, e.what());
+    } catch (const std::bad_alloc &) {
+        return gfail(g, MC_ENOMEM, "mc_group_add_reads_file: out of host memory");
+    }
+}
+
+int mc_group_finalize_counts(mc_group *g, uint64_t *n_distinct)
+{
+    if (!g) return MC_EINVAL;
+    uint64_t total = 0;
+    for (mc_ctx *c : g->ctx) {
+        uint64_t n = 0;
+        const int rc = mc_finalize_counts(c, &n);
+        if (rc) return gfail(g, rc, mc_last_error(c));
+        total += n;  // owners are disjoint
+    }
+    if (n_distinct) *n_distinct = total;
+    return MC_OK;
+}
+
+int mc_group_bfs_batch(mc_group *g, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov, int64_t max_kmers, int64_t max_radius,
+                       mc_bfs_result *out)
+{
+    if (!g) return MC_EINVAL;
+    std::lock_guard<std::mutex> lk(g->mu);
+    const size_t W = g->ctx.size();
+    if (W == 1) {
+        const int rc = mc_bfs_batch(g->ctx[0], jobs, n_jobs, min_cov, max_kmers, max_radius, out);
+        return rc ? gfail(g, rc, mc_last_error(g->ctx[0])) : MC_OK;
+    }
+    if (g->dirty || g->solid_cov != min_cov) {
+        // ---- gather: every shard's (key, count, pointer) with count >= min_cov, side by side on the first device
+        std::vector<uint64_t> n(W, 0);
+        for (size_t r = 0; r < W; r++) {
+            const int rc = mc_export_dev(g->ctx[r], min_cov, nullptr, nullptr, nullptr, 0, &n[r]);
+            if (rc) return gfail(g, rc, mc_last_error(g->ctx[r]));
+        }
+        uint64_t total = 0;
+        for (uint64_t x : n) total += x;
+        mc_ctx *c0 = g->ctx[0];
+        if (hipSetDevice(c0->cfg.device) != hipSuccess) return gfail(g, MC_EHIP, "hipSetDevice failed");
+        DevBuf<int64_t> all_k;
+        DevBuf<int16_t> all_c;
+        DevBuf<uint32_t> all_p;
+        if (all_k.alloc(total) != hipSuccess || all_c.alloc(total) != hipSuccess || all_p.alloc(total) != hipSuccess)
+            return gfail(g, MC_ENOMEM, "mc_group_bfs_batch: no room for the gathered shards");
+        uint64_t at = 0;
+        for (size_t r = 0; r < W; r++) {
+            mc_ctx *c = g->ctx[r];
+            if (n[r] == 0) continue;
+            if (hipSetDevice(c->cfg.device) != hipSuccess) return gfail(g, MC_EHIP, "hipSetDevice failed");
+            DevBuf<int64_t> k_r;
+            DevBuf<int16_t> c_r;
+            DevBuf<uint32_t> p_r;
+            if (k_r.alloc(n[r]) != hipSuccess || c_r.alloc(n[r]) != hipSuccess || p_r.alloc(n[r]) != hipSuccess)
+                return gfail(g, MC_ENOMEM, "mc_group_bfs_batch: no room for a shard's export");
+            uint64_t got = 0;
+            const int rc = mc_export_dev(c, min_cov, k_r.p, c_r.p, p_r.p, n[r], &got);
+            if (rc) return gfail(g, rc, mc_last_error(c));
+            if (peer_copy(all_k.p + at, c0, k_r.p, c, got * 8, c0->stream) != hipSuccess || peer_copy(all_c.p + at, c0, c_r.p, c, got * 2, c0->stream) != hipSuccess ||
+                peer_copy(all_p.p + at, c0, p_r.p, c, got * 4, c0->stream) != hipSuccess || hipStreamSynchronize(c0->stream) != hipSuccess)
+                return gfail(g, MC_EHIP, "mc_group_bfs_batch: gathering the shards failed (peer copy)");
+            at += got;
+        }
+        if (hipSetDevice(c0->cfg.device) != hipSuccess) return gfail(g, MC_EHIP, "hipSetDevice failed");
+        int rc = mc_clear(g->solid);
+        if (!rc) rc = mc_share_read_store(g->solid, c0);
+        uint64_t kept = 0;
+        if (!rc) rc = mc_solid_from_pairs_dev(g->solid, all_k.p, all_c.p, all_p.p, at, min_cov, &kept);
+        if (rc) return gfail(g, rc, mc_last_error(g->solid));
+        g->solid_cov = min_cov;
+        g->dirty = false;
+    }
+    const int rc = mc_bfs_batch(g->solid, jobs, n_jobs, min_cov, max_kmers, max_radius, out);
+    return rc ? gfail(g, rc, mc_last_error(g->solid)) : MC_OK;
+}
+
+}  // extern "C"

@@ -280,3 +280,68 @@ def test_cli_config5_four_environments_then_multi_join(cli, tmp_path):
             assert f.read() == text, name
     gfa = want_files["graph.gfa"]
     assert gfa.count("\nS\t") > 3 and "#00ff00" in gfa  # the gene's unitigs are marked, the samples' bubbles coloured
+
+
+@pytest.mark.parametrize("devices,k,extra", [("0,0", 31, ["--maxkmers", "4000", "--coverage", "3"]),
+                                            ("0,0,0", 25, ["--maxradius", "200", "--coverage", "2", "--bothdirs", "true"]),
+                                            ("0,0", 41, ["--maxkmers", "2500", "--coverage", "3", "--bothdirs", "true"])])
+def test_cli_several_devices_equal_one(cli, tmp_path, devices, k, extra):
+    """`--devices a,b,...`: reads dealt to the devices, super-k-mer records (keys for k < 23 and hash keys) exchanged by owner
+    with peer copies, every device counts what it owns, the solid shards are gathered on the first for the BFS -- the
+    native counterpart of distributed.py.  Output byte-identical with one device's and with the oracle's.
+    This box has one GPU, so the devices are shares of it (the same ordinal several times): everything but the xGMI hop
+    itself is exercised."""
+    genome, reads, _ = synth_case(2, 40000, 12000, 150, 60)
+    fa1, fa2 = str(tmp_path / "a.fasta"), str(tmp_path / "b.fq")
+    _write_fasta(fa1, reads[:7000 * 150], 150, n_every=60)
+    with open(fa2, "w") as f:
+        for i in range(7000, 12000):
+            f.write("@r%d\n%s\n+\n%s\n" % (i, po.decode(reads[i * 150:(i + 1) * 150]), "I" * 150))
+    seq = str(tmp_path / "genes.fasta")
+    with open(seq, "w") as f:
+        f.write(">g1\n%s\n>g2\n%s\n" % (po.decode(genome[5000:5400]), po.decode(genome[52000:52300])))
+    hashed = k > 31
+    mode = po.KEY_POLY if hashed else po.KEY_PACKED
+    outs = {}
+    for name, dev in (("one", None), ("many", devices)):
+        out = str(tmp_path / ("out_" + name))
+        cmd = [cli, "-k", str(k), "-i", fa1, fa2, "--seq", seq, "-o", out, "-w", str(tmp_path / ("wd_" + name)), "--force"] + extra
+        if dev:
+            cmd += ["--devices", dev]
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs[name] = (out, p.stderr)
+    assert "Counting on %d devices" % len(devices.split(",")) in outs["many"][1]
+    size_line = [l for l in outs["one"][1].splitlines() if "Hashtable size" in l][0].split("Hashtable size")[1]
+    assert ("Hashtable size" + size_line) in outs["many"][1]  # owners are disjoint: the shards add up to the one table
+    kw = {}
+    it = iter(extra)
+    for a in it:
+        v = next(it)
+        kw[{"--maxkmers": "max_kmers", "--maxradius": "max_radius", "--coverage": "coverage", "--bothdirs": "bothdirs"}[a]] = (v == "true") if a == "--bothdirs" else int(v)
+    seqs, comments = ho.rich_fasta_read(seq)
+    want = str(tmp_path / "want")
+    _, res = _oracle_run([fa1, fa2], k, mode, seqs, comments, want, **kw)
+    _assert_same_tree(res, outs["many"][0], want)
+    _assert_same_tree(res, outs["one"][0], want)
+
+
+def test_cli_two_real_devices(cli, tmp_path):
+    """The same over two different GPUs (skipped on a one-GPU box)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    genome, reads, _ = synth_case(1, 40000, 9000, 150, 40)
+    fa = str(tmp_path / "reads.fasta")
+    _write_fasta(fa, reads, 150)
+    seq = str(tmp_path / "gene.fasta")
+    with open(seq, "w") as f:
+        f.write(">g\n%s\n" % po.decode(genome[9000:9400]))
+    trees = []
+    for dev in (None, "0,1"):
+        out = str(tmp_path / ("out" + (dev or "")))
+        cmd = [cli, "-k", "31", "-i", fa, "--seq", seq, "-o", out, "-w", str(tmp_path / ("wd" + (dev or ""))), "--force", "--maxkmers", "5000", "--coverage", "3"]
+        p = subprocess.run(cmd + (["--devices", dev] if dev else []), capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        trees.append({n: open(os.path.join(out, "g", n)).read() for n in ("graph.txt", "graph.gfa", "seqs.fasta")})
+    assert trees[0] == trees[1]
