@@ -1522,13 +1522,17 @@ int mc_create(const mc_config *cfg, mc_ctx **out)
     uint64_t want_slots = 1ull << 22;  // 4 M slots = 64 MB to start with
     if (cfg->capacity_hint) {
         // Load factor the hint is turned into.  Hash-prefix tables: 0.7 (regions are probed in LDS, a fuller table
-        // costs little).  Minimizer-bin tables fill less evenly (the k-mers of one locus share a bin) and the merge
-        // kernel's probe loops are what bounds it: measured on the 10 M-read workload, a table at load 0.22 merges
-        // 15 % faster than at 0.37; but every GB of table is swept once per BFS set-up, so large tables stay denser:
-        // 0.25 up to 64 M keys, + 0.1 per doubling, 0.45 from 256 M keys on.
+        // costs little).  Minimizer-bin tables fill less evenly (the k-mers of one locus share a bin) and both the merge
+        // kernel's probe loops and the walk's lookups pay for every extra probe, while a sparser table only costs its
+        // write-back: measured on the 10 M-read workload (364 M keys), count + BFS per step at load 0.60 / 0.51 / 0.43 /
+        // 0.36: 39.1 / 31.5 / 29.2 / 28.6 ms.  So 0.25 up to 64 M keys, + 0.05 per doubling, 0.36 at most -- but never
+        // more than 2^18 regions while the load stays under 0.6: beyond that a leaf of the counting pipeline covers two
+        // regions and the merge kernel sweeps each leaf twice (19 ms instead of 9).
         double load = 0.7;
-        if (c->mm_k) load = std::min(0.45, std::max(0.25, 0.25 + 0.1 * std::log2((double)cfg->capacity_hint / (double)(64u << 20))));
+        if (c->mm_k) load = std::min(0.36, std::max(0.25, 0.25 + 0.05 * std::log2((double)cfg->capacity_hint / (double)(64u << 20))));
         want_slots = std::max<uint64_t>(want_slots, (uint64_t)((double)cfg->capacity_hint / load));
+        const uint64_t one_leaf_each = 1ull << (18 + c->sb);
+        if (c->mm_k && want_slots > one_leaf_each && (double)cfg->capacity_hint <= 0.6 * (double)one_leaf_each) want_slots = one_leaf_each;
     }
     int rc = table_alloc(c, regions_for(c, want_slots));
     if (rc) {
