@@ -167,6 +167,12 @@ def main():
         elapsed = float(t.item())
     st = ctx.stats()
 
+    # which of BASELINE.json's configs the line is quoted on
+    full = (args.config == 1 and R == 10_000_000) or (args.config == 2 and R == 100_000_000)
+    if world > 1 and args.config == 1:
+        cfg_label = "configs[3]" if R * world == 1_000_000_000 else ("configs[1] on every GPU (weak scaling; configs[3] = --total-reads 1000000000)" if full else "configs[1] scaled, on every GPU")
+    else:
+        cfg_label = "configs[%d]%s" % (args.config, "" if full else " scaled")
     out = None
     if rank == 0:
         total_windows = windows * world
@@ -234,10 +240,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64",
             "data": "synthetic",
-            "config": {"workload": "configs[%d]%s: %dx%dbp reads per GPU, %dx%d bp random contigs, k=%d%s, coverage=%d, "
+            "config": {"workload": "%s: %dx%dbp reads per GPU, %dx%d bp random contigs, k=%d%s, coverage=%d, "
                                    "maxkmers=%d, bothdirs=%s, %s" % (
-                                       args.config if world == 1 or args.config != 1 else 3,
-                                       "" if (args.config == 1 and R == 10_000_000) or (args.config == 2 and R == 100_000_000) else " scaled",
+                                       cfg_label,
                                        R, L, args.contigs, args.contig_len, k, " (poly hash keys)" if mode == m.KEY_POLY else "", args.coverage, args.maxkmers, bothdirs,
                                        "E1 1%% substitutions" if args.err == 100 else "err=%d/10000" % args.err),
                        "reads_per_gpu": R, "read_len": L, "k": k, "err_per_10k": args.err,
