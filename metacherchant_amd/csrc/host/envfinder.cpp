@@ -987,6 +987,102 @@ bool load_reads_parallel(const std::string &path, bool fastq, size_t max_reads, 
 
 }  // namespace
 
+namespace {
+// itmo!/io/ReadersUtils.java:27-53 detectFileFormat on a lower-cased file name without its compression suffix
+void reads_format_of(const std::string &name, bool *binq, bool *fastq, bool *fasta)
+{
+    *binq = ends_with(name, ".binq");
+    *fastq = ends_with(name, ".fastq") || ends_with(name, ".fq");
+    *fasta = ends_with(name, ".fasta") || ends_with(name, ".fa") || ends_with(name, ".fn") || ends_with(name, ".fna");
+}
+}  // namespace
+
+PlainReadsFile::~PlainReadsFile()
+{
+    if (p && n) munmap(const_cast<char *>(p), n);
+    if (fd >= 0) close(fd);
+}
+
+bool map_plain_reads(const std::string &path, PlainReadsFile *out)
+{
+    const size_t slash = path.find_last_of('/');
+    const std::string name = lower(slash == std::string::npos ? path : path.substr(slash + 1));
+    bool binq, fastq, fasta;
+    reads_format_of(name, &binq, &fastq, &fasta);
+    if (binq || (!fastq && !fasta)) return false;  // (a .gz / .bz2 name matches neither)
+    out->fd = open(path.c_str(), O_RDONLY);
+    if (out->fd < 0) return false;
+    struct stat st;
+    if (fstat(out->fd, &st) != 0 || st.st_size <= 0) return false;
+    void *mp = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, out->fd, 0);
+    if (mp == MAP_FAILED) return false;
+    out->p = static_cast<const char *>(mp);
+    out->n = (size_t)st.st_size;
+    out->fastq = fastq;
+    if (fastq) {
+        MemLines src(out->p, out->p + out->n);
+        int offset = -1;
+        try {
+            if (!parse_fastq(src, [](const char *, size_t) {}, -1, true, &offset, 1) || offset < 0) return false;
+        } catch (const Error &) {
+            return false;  // the serial reader meets the same problem and reports it
+        }
+        out->offset = offset;
+    }
+    return true;
+}
+
+const char *plain_record_start(const PlainReadsFile &f, const char *q)
+{
+    const char *begin = f.p, *end = f.p + f.n;
+    auto line_end = [&](const char *s) { const char *nl = static_cast<const char *>(memchr(s, '\n', (size_t)(end - s))); return nl ? nl : end; };
+    auto next_line = [&](const char *s) { const char *e = line_end(s); return e < end ? e + 1 : end; };
+    auto len_of = [&](const char *s) { const char *e = line_end(s); size_t l = (size_t)(e - s); if (l && s[l - 1] == '\r') l--; return l; };
+    const char *l = begin;
+    if (q > begin) {
+        const char *nl = static_cast<const char *>(memchr(q - 1, '\n', (size_t)(end - (q - 1))));
+        l = nl ? nl + 1 : end;
+    }
+    for (; l < end; l = next_line(l)) {
+        if (!f.fastq) {
+            if (*l == '>' || *l == ';') return l;
+            continue;
+        }
+        // an '@' line whose third line starts with '+' and whose second and fourth lines are equally long (a quality
+        // line that starts with '@' fails the '+' test: the line two below it holds bases)
+        if (*l != '@') continue;
+        const char *l2 = next_line(l), *l3 = l2 < end ? next_line(l2) : end;
+        if (l3 >= end || *l3 != '+') continue;
+        const char *l4 = next_line(l3);
+        if (l4 < end && len_of(l2) == len_of(l4)) return l;
+    }
+    return end;
+}
+
+uint64_t parse_plain_range(const PlainReadsFile &f, const char *b, const char *e, size_t max_reads, const std::function<void(PackedBatch &)> &sink)
+{
+    uint64_t delivered = 0;
+    PackedBatch batch;
+    batch.clear();
+    auto emit = [&](const char *s, size_t n) {
+        batch.add_read(s, n);
+        delivered++;
+        if (batch.n_reads() >= max_reads) {
+            batch.finish();
+            sink(batch);
+            batch.clear();
+        }
+    };
+    MemLines src(b, e);
+    if (f.fastq) parse_fastq(src, emit, f.offset, false);
+    else parse_fasta(src, emit);
+    if (batch.n_reads() > 0) {
+        batch.finish();
+        sink(batch);
+    }
+    return delivered;
+}
+
 uint64_t load_reads_file(const std::string &path, size_t max_reads, const std::function<void(PackedBatch &)> &sink)
 {
     // itmo!/io/ReadersUtils.java:27-53 detectFileFormat: a .gz and then a .bz2 suffix come off, then the format

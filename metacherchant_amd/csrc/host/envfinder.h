@@ -106,6 +106,28 @@ struct PackedBatch {
 // Calls sink(batch) for every max_reads reads; returns the number of reads (pieces) delivered.
 uint64_t load_reads_file(const std::string &path, size_t max_reads, const std::function<void(PackedBatch &)> &sink);
 
+// What the device tokeniser (csrc/tokenizer.h) needs from the host: an uncompressed FASTA / FASTQ file mapped, its format,
+// the quality offset of its first 1000 records, record starts to cut it at, and this file's own parser for a byte range
+// the device declined (a byte that is no base, a record out of shape: the serial parser defines what happens then).
+struct PlainReadsFile {
+    const char *p = nullptr;
+    size_t n = 0;
+    bool fastq = false;
+    int offset = 0;  // FASTQ: 33 or 64
+    int fd = -1;
+    PlainReadsFile() = default;
+    PlainReadsFile(const PlainReadsFile &) = delete;
+    PlainReadsFile &operator=(const PlainReadsFile &) = delete;
+    ~PlainReadsFile();
+};
+// false: compressed, binq, unknown suffix, empty or unmappable, or a FASTQ whose first 1000 records are not plain
+// four-part records -- load_reads_file() is the reader for those
+bool map_plain_reads(const std::string &path, PlainReadsFile *out);
+// first record start at or after q (the end of the file when there is none)
+const char *plain_record_start(const PlainReadsFile &f, const char *q);
+// the serial parser over [b, e), which must begin at a record start; returns the reads delivered
+uint64_t parse_plain_range(const PlainReadsFile &f, const char *b, const char *e, size_t max_reads, const std::function<void(PackedBatch &)> &sink);
+
 // ---- 2-bit packed k-mers (k <= 63): base i of the string is bits 2(k-1-i)+1..2(k-1-i), codes A0 G1 C2 T3,
 // the layout of mc_bfs_result's hi/lo words (include/mcgpu.h)
 typedef unsigned __int128 kmer_t;

@@ -5,10 +5,12 @@
 // Reference lines each piece replaces are cited at the definitions (src/... and itmo!/... as in
 // include/mcgpu.h).  Nothing in this file links or calls oracle/.
 #include <hip/hip_runtime.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <array>
 #include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -24,11 +26,70 @@
 #include "kmer_device.h"
 #include "bfs_device.h"
 #include "count_pipeline.h"
+#include "tokenizer.h"
 #include "host/envfinder.h"
 
 using namespace mc;
 
 // ------------------------------------------------------------------------------------------ ctx
+
+// Device scratch of the tokeniser (csrc/tokenizer.h), kept between calls: a file is read in chunks of the same size,
+// and hipMalloc / hipFree of gigabyte buffers cost milliseconds each.  Best fit with at most 2x slack; at most 48 idle
+// blocks (the smallest goes first).
+struct DevPool {
+    std::vector<std::pair<void *, size_t>> idle;
+    hipError_t get(size_t bytes, void **out, size_t *got)
+    {
+        bytes = std::max<size_t>((bytes + 255) / 256 * 256, 256);
+        size_t best = idle.size();
+        for (size_t i = 0; i < idle.size(); i++)
+            if (idle[i].second >= bytes && idle[i].second <= 2 * bytes + (1u << 20) && (best == idle.size() || idle[i].second < idle[best].second)) best = i;
+        if (best < idle.size()) {
+            *out = idle[best].first;
+            *got = idle[best].second;
+            idle.erase(idle.begin() + (long)best);
+            return hipSuccess;
+        }
+        *got = bytes;
+        hipError_t e = hipMalloc(out, bytes);
+        if (e == hipErrorOutOfMemory && !idle.empty()) {  // give the idle blocks back and try once more
+            release();
+            e = hipMalloc(out, bytes);
+        }
+        return e;
+    }
+    void put(void *p, size_t bytes)
+    {
+        idle.emplace_back(p, bytes);
+        if (idle.size() > 48) {
+            size_t small = 0;
+            for (size_t i = 1; i < idle.size(); i++)
+                if (idle[i].second < idle[small].second) small = i;
+            (void)hipFree(idle[small].first);
+            idle.erase(idle.begin() + (long)small);
+        }
+    }
+    void release()
+    {
+        for (auto &b : idle) (void)hipFree(b.first);
+        idle.clear();
+    }
+};
+template <class T>
+struct PoolBuf {  // RAII: a block of a DevPool
+    T *p = nullptr;
+    size_t bytes = 0;
+    DevPool *pool = nullptr;
+    PoolBuf() = default;
+    PoolBuf(const PoolBuf &) = delete;
+    PoolBuf &operator=(const PoolBuf &) = delete;
+    ~PoolBuf() { if (p) pool->put(p, bytes); }
+    hipError_t alloc(DevPool *pl, size_t n)
+    {
+        pool = pl;
+        return pl->get(std::max<size_t>(n, 1) * sizeof(T), reinterpret_cast<void **>(&p), &bytes);
+    }
+};
 
 // device buffers of one BFS job, kept in the context between calls
 struct BfsJobBuffers {
@@ -112,8 +173,10 @@ struct mc_ctx {
     mc_stats st{};
     std::vector<std::unique_ptr<BfsJobBuffers>> bfs_pool;
 
-    char *pin[8] = {};                 // pinned staging buffers of h2d_fast, made on first use
-    hipStream_t pin_stream[4] = {};
+    char *pin[16] = {};                // pinned staging buffers of h2d_fast, made on first use
+    DevPool tok_pool;                  // scratch of the device tokeniser
+    std::mutex pin_mu;                 // the pinned buffers serve one copy at a time
+    hipStream_t pin_stream[8] = {};
     int mm_k = 0;        // != 0 (= k): regions are minimizer bins and reads are counted as super-k-mers (kmer_device.h)
     bool virgin = true;  // the table holds no key and its memory is not initialised yet
     int count_path = 0;  // 0 auto, 1 direct (atomics), 2 partitioned; MC_COUNT_PATH=direct|partition overrides
@@ -1562,6 +1625,7 @@ void mc_destroy(mc_ctx *c)
     for (auto &e : c->ev_piece) if (e) (void)hipEventDestroy(e);
     if (c->ev_p2) (void)hipEventDestroy(c->ev_p2);
     if (c->pipe_stream) { (void)hipStreamSynchronize(c->pipe_stream); (void)hipStreamDestroy(c->pipe_stream); }
+    c->tok_pool.release();
     for (char *p : c->pin) if (p) (void)hipHostFree(p);
     for (hipStream_t st : c->pin_stream) if (st) (void)hipStreamDestroy(st);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1630,24 +1694,27 @@ static int add_reads_dev_locked(mc_ctx *c, const uint64_t *d_words, const uint64
 // Host (pageable) memory to the device.  A plain hipMemcpy of pageable memory stages through one thread; a few
 // threads each staging 8 MB pieces through their own pinned buffers and stream reach the link rate
 // (scripts/microbench/hostreg.hip: 360 MB in 7-14 ms instead of 19 ms, or 176 ms for memory touched first here).
-static int h2d_fast(mc_ctx *c, void *dst, const void *src, size_t bytes)
+// fd >= 0: the bytes come from that file at file_off instead (pread straight into the pinned buffers: no page faults on
+// a mapping).  Touches no state of the context but the pinned buffers (under their own lock), so the file reader can
+// run it beside the kernels of the chunk before; returns a hipError_t-free verdict for the caller to report.
+static bool h2d_pinned(mc_ctx *c, void *dst, const void *src, size_t bytes, int fd, uint64_t file_off)
 {
     constexpr size_t CHUNK = 8u << 20;
-    constexpr int T = 4;
-    if (bytes < 4 * CHUNK) {
-        HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        return MC_OK;
-    }
+    static constexpr int TMAX = 8;
+    static const int T = [] { const char *e = getenv("MC_H2D_THREADS"); const int v = e && *e ? atoi(e) : 8; return std::min(std::max(v, 1), TMAX); }();
+    std::lock_guard<std::mutex> g(c->pin_mu);
+    if (hipSetDevice(c->cfg.device) != hipSuccess) return false;
     if (!c->pin[0]) {
-        for (int i = 0; i < 2 * T; i++) HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->pin[i]), CHUNK));
-        for (int i = 0; i < T; i++) HIPCHK(c, hipStreamCreateWithFlags(&c->pin_stream[i], hipStreamNonBlocking));
+        for (int i = 0; i < 2 * T; i++)
+            if (hipHostMalloc(reinterpret_cast<void **>(&c->pin[i]), CHUNK) != hipSuccess) return false;
+        for (int i = 0; i < T; i++)
+            if (hipStreamCreateWithFlags(&c->pin_stream[i], hipStreamNonBlocking) != hipSuccess) return false;
     }
     const size_t n_chunks = (bytes + CHUNK - 1) / CHUNK;
-    bool failed[T] = {false, false, false, false};
+    bool failed[TMAX] = {};
     const int device = c->cfg.device;
     std::vector<std::thread> th;
-    for (int t = 0; t < T; t++)
+    for (int t = 0; t < T && (size_t)t < n_chunks; t++)
         th.emplace_back([&, t] {
             if (hipSetDevice(device) != hipSuccess) { failed[t] = true; return; }
             hipEvent_t ev[2];
@@ -1658,7 +1725,15 @@ static int h2d_fast(mc_ctx *c, void *dst, const void *src, size_t bytes)
             for (size_t ch = (size_t)t; ch < n_chunks; ch += T) {
                 const size_t off = ch * CHUNK, len = std::min(CHUNK, bytes - off);
                 if (used[flip] && hipEventSynchronize(ev[flip]) != hipSuccess) failed[t] = true;
-                memcpy(c->pin[2 * t + flip], static_cast<const char *>(src) + off, len);
+                if (fd >= 0) {
+                    for (size_t got = 0; got < len;) {
+                        const ssize_t r = pread(fd, c->pin[2 * t + flip] + got, len - got, (off_t)(file_off + off + got));
+                        if (r <= 0) { failed[t] = true; break; }
+                        got += (size_t)r;
+                    }
+                } else {
+                    memcpy(c->pin[2 * t + flip], static_cast<const char *>(src) + off, len);
+                }
                 if (hipMemcpyAsync(static_cast<char *>(dst) + off, c->pin[2 * t + flip], len, hipMemcpyHostToDevice, c->pin_stream[t]) != hipSuccess ||
                     hipEventRecord(ev[flip], c->pin_stream[t]) != hipSuccess)
                     failed[t] = true;
@@ -1670,8 +1745,19 @@ static int h2d_fast(mc_ctx *c, void *dst, const void *src, size_t bytes)
             (void)hipEventDestroy(ev[1]);
         });
     for (auto &x : th) x.join();
-    for (bool f : failed)
-        if (f) return fail(c, MC_EHIP, "host-to-device copy failed");
+    for (int t = 0; t < TMAX; t++)
+        if (failed[t]) return false;
+    return true;
+}
+
+static int h2d_fast(mc_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (bytes < (32u << 20)) {
+        HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return MC_OK;
+    }
+    if (!h2d_pinned(c, dst, src, bytes, -1, 0)) return fail(c, MC_EHIP, "host-to-device copy failed");
     return MC_OK;
 }
 
@@ -1838,18 +1924,282 @@ int mc_add_pairs_dev(mc_ctx *c, const int64_t *d_keys, const int16_t *d_counts, 
     return MC_OK;
 }
 
+// ---- f1 on the device: csrc/tokenizer.h driven over one chunk of an uncompressed FASTA / FASTQ file
+
+// exclusive scan of n 32-bit counts into 64-bit offsets; *total on the host
+static int tok_scan(mc_ctx *c, const uint32_t *d_in, uint64_t n, unsigned long long *d_out, uint64_t *total)
+{
+    const uint64_t m = std::max<uint64_t>((n + tok::SCAN_TILE - 1) / tok::SCAN_TILE, 1);
+    PoolBuf<unsigned long long> sums;
+    HIPCHK(c, sums.alloc(&c->tok_pool, m + 1));
+    hipLaunchKernelGGL(tok::k_scan_sums, dim3((unsigned)m), dim3(tok::T_THREADS), 0, c->stream, d_in, n, sums.p);
+    hipLaunchKernelGGL(tok::k_scan_one, dim3(1), dim3(1024), 0, c->stream, sums.p, m, sums.p + m);
+    hipLaunchKernelGGL(tok::k_scan_apply, dim3((unsigned)m), dim3(tok::T_THREADS), 0, c->stream, d_in, n, sums.p, d_out);
+    HIPCHK(c, hipGetLastError());
+    unsigned long long t = 0;
+    HIPCHK(c, hipMemcpyAsync(&t, sums.p + m, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *total = t;
+    return MC_OK;
+}
+
+// Text bytes [b, e) of a mapped file (a whole number of records) -> packed reads in HBM -> counted.  *declined: the
+// device saw something the host parser has to deal with; nothing was added.  The context's lock is held.
+static int tokenize_chunk_locked(mc_ctx *c, const mch::PlainReadsFile &f, const char *b, const char *e, uint8_t *d_text, uint64_t *n_reads_out,
+                                 bool *declined)
+{
+    *declined = false;
+    *n_reads_out = 0;
+    const uint64_t n = (uint64_t)(e - b);
+    if (n == 0) return MC_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const bool dbg = getenv("MC_INGEST_DEBUG") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t1 = now();
+    struct { uint8_t *p; } text{d_text};  // (padded with zero bytes to whole tiles of the newline passes: tok_text_bytes)
+    {
+        const uint64_t n_padded = (n + tok::T_TILE - 1) / tok::T_TILE * tok::T_TILE;
+        if (n_padded > n) HIPCHK(c, hipMemsetAsync(text.p + n, 0, n_padded - n, c->stream));
+    }
+    int rc = MC_OK;
+    PoolBuf<uint32_t> flags;
+    HIPCHK(c, flags.alloc(&c->tok_pool, 1));
+    HIPCHK(c, hipMemsetAsync(flags.p, 0, 4, c->stream));
+    // pass 1: newline positions
+    const uint64_t n_tiles = (n + tok::T_TILE - 1) / tok::T_TILE;
+    if (n_tiles > 0x7FFFFFFFull) { *declined = true; return MC_OK; }
+    PoolBuf<uint32_t> tile_counts;
+    PoolBuf<unsigned long long> tile_off, nl;
+    HIPCHK(c, tile_counts.alloc(&c->tok_pool, n_tiles));
+    HIPCHK(c, tile_off.alloc(&c->tok_pool, n_tiles));
+    hipLaunchKernelGGL(tok::k_nl_count, dim3((unsigned)n_tiles), dim3(tok::T_THREADS), 0, c->stream, text.p, tile_counts.p);
+    uint64_t n_nl = 0;
+    rc = tok_scan(c, tile_counts.p, n_tiles, tile_off.p, &n_nl);
+    if (rc) return rc;
+    HIPCHK(c, nl.alloc(&c->tok_pool, n_nl));
+    hipLaunchKernelGGL(tok::k_nl_write, dim3((unsigned)n_tiles), dim3(tok::T_THREADS), 0, c->stream, text.p, tile_off.p, nl.p);
+    HIPCHK(c, hipGetLastError());
+    const uint64_t n_lines = n_nl + (e[-1] != '\n' ? 1 : 0);
+    if (n_lines >= 0xFFFFFFF0ull) { *declined = true; return MC_OK; }
+
+    auto read_flags = [&](uint32_t *out) -> int {
+        HIPCHK(c, hipMemcpyAsync(out, flags.p, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return MC_OK;
+    };
+    // where the packed words go: straight into the read store when the context keeps one
+    PoolBuf<uint64_t> own_words;
+    PoolBuf<uint64_t> offsets;
+    uint64_t *dst = nullptr;
+    int64_t in_store = -1;
+    auto reserve_words = [&](uint64_t total_bases) -> int {
+        const uint64_t n_words = (total_bases + 31) / 32 + 1;
+        if (c->rs_enabled) {
+            int r = rs_reserve(c, n_words);
+            if (r) return r;
+            in_store = (int64_t)(c->rs_bases / 32);
+            dst = c->rs_words + in_store;
+        } else {
+            HIPCHK(c, own_words.alloc(&c->tok_pool, n_words));
+            dst = own_words.p;
+        }
+        HIPCHK(c, hipMemsetAsync(dst, 0, n_words * 8, c->stream));
+        return MC_OK;
+    };
+    uint64_t n_reads = 0, total_bases = 0;
+    uint32_t fl = 0;
+    if (!f.fastq) {
+        PoolBuf<uint32_t> line_hdr, line_len, keep_len, rec_first, rec_keep;
+        PoolBuf<uint8_t> line_n, rec_n;
+        PoolBuf<unsigned long long> hdr_before, rec_len, out_off, rec_out;
+        HIPCHK(c, line_hdr.alloc(&c->tok_pool, n_lines));
+        HIPCHK(c, line_len.alloc(&c->tok_pool, n_lines));
+        HIPCHK(c, line_n.alloc(&c->tok_pool, n_lines));
+        HIPCHK(c, hdr_before.alloc(&c->tok_pool, n_lines));
+        hipLaunchKernelGGL(tok::k_fa_lines, dim3(grid_for(n_lines, 4, 1 << 14)), dim3(tok::T_THREADS), 0, c->stream, text.p, n, nl.p, n_nl, n_lines, line_hdr.p,
+                           line_len.p, line_n.p, flags.p);
+        uint64_t n_hdr = 0;
+        rc = tok_scan(c, line_hdr.p, n_lines, hdr_before.p, &n_hdr);
+        if (rc) return rc;
+        rc = read_flags(&fl);
+        if (rc) return rc;
+        if (fl) { *declined = true; return MC_OK; }
+        const uint64_t n_rec = n_hdr + 1;  // (record 0: the lines in front of the first header)
+        HIPCHK(c, rec_n.alloc(&c->tok_pool, n_rec));
+        HIPCHK(c, rec_len.alloc(&c->tok_pool, n_rec));
+        HIPCHK(c, rec_first.alloc(&c->tok_pool, n_rec));
+        HIPCHK(c, rec_keep.alloc(&c->tok_pool, n_rec));
+        HIPCHK(c, rec_out.alloc(&c->tok_pool, n_rec));
+        HIPCHK(c, keep_len.alloc(&c->tok_pool, n_lines));
+        HIPCHK(c, out_off.alloc(&c->tok_pool, n_lines));
+        HIPCHK(c, hipMemsetAsync(rec_n.p, 0, n_rec, c->stream));
+        HIPCHK(c, hipMemsetAsync(rec_len.p, 0, n_rec * 8, c->stream));
+        HIPCHK(c, hipMemsetAsync(rec_first.p, 0xFF, n_rec * 4, c->stream));
+        const int g = grid_for(n_lines, 256, 1 << 16);
+        hipLaunchKernelGGL(tok::k_fa_records, dim3(g), dim3(256), 0, c->stream, hdr_before.p, line_hdr.p, line_len.p, line_n.p, n_lines, rec_n.p, rec_len.p,
+                           rec_first.p);
+        hipLaunchKernelGGL(tok::k_fa_keep, dim3(g), dim3(256), 0, c->stream, hdr_before.p, line_hdr.p, line_len.p, n_lines, rec_n.p, keep_len.p);
+        hipLaunchKernelGGL(tok::k_fa_rec_keep, dim3(grid_for(n_rec, 256, 1 << 16)), dim3(256), 0, c->stream, rec_n.p, rec_len.p, n_rec, rec_keep.p);
+        rc = tok_scan(c, keep_len.p, n_lines, out_off.p, &total_bases);
+        if (rc) return rc;
+        rc = tok_scan(c, rec_keep.p, n_rec, rec_out.p, &n_reads);
+        if (rc) return rc;
+        if (n_reads) {
+            HIPCHK(c, offsets.alloc(&c->tok_pool, n_reads + 1));
+            rc = reserve_words(total_bases);
+            if (rc) return rc;
+            hipLaunchKernelGGL(tok::k_fa_offsets, dim3(grid_for(n_rec, 256, 1 << 16)), dim3(256), 0, c->stream, rec_keep.p, rec_out.p, rec_first.p, out_off.p,
+                               n_rec, n_reads, total_bases, offsets.p);
+            hipLaunchKernelGGL(tok::k_fa_pack, dim3(grid_for(n_lines, 4, 1 << 14)), dim3(tok::T_THREADS), 0, c->stream, text.p, n, nl.p, n_nl,
+                               n_lines, keep_len.p, out_off.p, dst, flags.p);
+            HIPCHK(c, hipGetLastError());
+        }
+    } else {
+        if (n_lines % 4) { *declined = true; return MC_OK; }
+        const uint64_t n_rec = n_lines / 4;
+        PoolBuf<uint32_t> rec_pieces, rec_bases;
+        PoolBuf<unsigned long long> piece_at, base_at;
+        HIPCHK(c, rec_pieces.alloc(&c->tok_pool, n_rec));
+        HIPCHK(c, rec_bases.alloc(&c->tok_pool, n_rec));
+        HIPCHK(c, piece_at.alloc(&c->tok_pool, n_rec));
+        HIPCHK(c, base_at.alloc(&c->tok_pool, n_rec));
+        const int g = grid_for(n_rec, 4, 1 << 14);  // a wave per record
+        hipLaunchKernelGGL(tok::k_fq_records, dim3(g), dim3(tok::T_THREADS), 0, c->stream, text.p, n, nl.p, n_nl, n_rec, f.offset, rec_pieces.p, rec_bases.p,
+                           flags.p);
+        rc = tok_scan(c, rec_pieces.p, n_rec, piece_at.p, &n_reads);
+        if (rc) return rc;
+        rc = tok_scan(c, rec_bases.p, n_rec, base_at.p, &total_bases);
+        if (rc) return rc;
+        rc = read_flags(&fl);
+        if (rc) return rc;
+        if (fl) { *declined = true; return MC_OK; }
+        if (n_reads) {
+            HIPCHK(c, offsets.alloc(&c->tok_pool, n_reads + 1));
+            rc = reserve_words(total_bases);
+            if (rc) return rc;
+            hipLaunchKernelGGL(tok::k_fq_emit, dim3(g), dim3(tok::T_THREADS), 0, c->stream, text.p, n, nl.p, n_nl, n_rec, f.offset, piece_at.p, base_at.p,
+                               rec_bases.p, n_reads, total_bases, offsets.p, dst);
+            HIPCHK(c, hipGetLastError());
+        }
+    }
+    rc = read_flags(&fl);
+    if (rc) return rc;
+    if (fl) { *declined = true; return MC_OK; }  // (cannot happen after the line pass; the read store was not advanced)
+    const double t2 = now();
+    if (n_reads) {
+        rc = add_reads_dev_locked(c, dst, offsets.p, n_reads, total_bases, in_store);
+        if (rc) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    if (dbg)
+        fprintf(stderr, "[ingest] device tokeniser: %.1f MB text, %llu lines, %llu reads, %llu bases: tokenise %.3f s, count %.3f s\n", n / 1e6,
+                (unsigned long long)n_lines, (unsigned long long)n_reads, (unsigned long long)total_bases, t2 - t1, now() - t2);
+    *n_reads_out = n_reads;
+    return MC_OK;
+}
+
 int mc_add_reads_file(mc_ctx *c, const char *path, uint64_t *n_reads)
 {
     if (!c) return MC_EINVAL;
     if (n_reads) *n_reads = 0;
     if (!path) return fail(c, MC_EINVAL, "mc_add_reads_file: null path");
-    // batches of 2^20 reads: parsed and packed on the host (csrc/host/envfinder.cpp: the reference's readers and
-    // their N / quality policy), counted on the device; the context's lock is taken per batch
     try {
         int rc = MC_OK;
-        const uint64_t n = mch::load_reads_file(path, 1u << 20, [&](mch::PackedBatch &b) {
+        auto sink = [&](mch::PackedBatch &b) {
             if (rc == MC_OK) rc = mc_add_reads_packed(c, b.words.data(), b.offsets.data(), b.n_reads());
-        });
+        };
+        // Uncompressed FASTA / FASTQ: the bytes go to the device in chunks cut at record starts and are tokenised there
+        // (csrc/tokenizer.h); a chunk the device declines goes through the host parser, as does any other kind of file
+        // (MC_TOKENIZER=host: every file).  Host batches hold 2^20 reads; the context's lock is taken per batch / chunk.
+        const char *mode = getenv("MC_TOKENIZER");
+        mch::PlainReadsFile f;
+        if (!(mode && !strcmp(mode, "host")) && mch::map_plain_reads(path, &f)) {
+            // chunks of 256 MB: the bytes of chunk i + 1 cross the link (a helper thread, pinned staging buffers) while
+            // the kernels tokenise and count chunk i
+            const char *e_chunk = getenv("MC_TOKENIZER_CHUNK_BYTES");
+            const uint64_t chunk = std::min<uint64_t>(std::max<uint64_t>(e_chunk && *e_chunk ? strtoull(e_chunk, nullptr, 10) : (1ull << 28), 64), 3ull << 29);
+            const bool dbg = getenv("MC_INGEST_DEBUG") != nullptr;
+            auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+            const double t_begin = now();
+            std::vector<std::pair<const char *, const char *>> cuts;
+            for (const char *b = f.p, *end = f.p + f.n; b < end;) {
+                const char *e = (uint64_t)(end - b) <= chunk + chunk / 4 ? end : mch::plain_record_start(f, b + chunk);
+                cuts.emplace_back(b, e);
+                b = e;
+            }
+            struct Upload {
+                PoolBuf<uint8_t> text;
+                std::thread th;
+                bool ok = true;
+            };
+            if (c->rs_enabled) {  // the read store grows once, not chunk by chunk (FASTA: a base a byte at most; FASTQ: half that)
+                std::lock_guard<std::mutex> g(c->mu);
+                HIPCHK(c, hipSetDevice(c->cfg.device));
+                int r = rs_reserve(c, (f.fastq ? f.n / 2 : f.n) / 32 + 2 * cuts.size() + 2);
+                if (r) return r;
+            }
+            std::unique_ptr<Upload> cur, nxt;
+            auto start_upload = [&](size_t i, std::unique_ptr<Upload> &u) -> int {
+                u.reset(new Upload);
+                const uint64_t n = (uint64_t)(cuts[i].second - cuts[i].first);
+                {
+                    std::lock_guard<std::mutex> g(c->mu);
+                    HIPCHK(c, hipSetDevice(c->cfg.device));
+                    HIPCHK(c, u->text.alloc(&c->tok_pool, (n + tok::T_TILE - 1) / tok::T_TILE * tok::T_TILE));
+                }
+                Upload *up = u.get();
+                const char *b = cuts[i].first;
+                up->th = std::thread([c, up, b, n, &f] { up->ok = h2d_pinned(c, up->text.p, b, n, f.fd, (uint64_t)(b - f.p)); });
+                return MC_OK;
+            };
+            auto finish = [&](std::unique_ptr<Upload> &u) {  // (the pool is the context's: blocks go back under its lock)
+                if (!u) return;
+                if (u->th.joinable()) u->th.join();
+                std::lock_guard<std::mutex> g(c->mu);
+                u.reset();
+            };
+            uint64_t total = 0;
+            rc = cuts.empty() ? MC_OK : start_upload(0, cur);
+            for (size_t i = 0; i < cuts.size() && rc == MC_OK; i++) {
+                cur->th.join();
+                if (!cur->ok) {
+                    std::lock_guard<std::mutex> g(c->mu);
+                    rc = fail(c, MC_EHIP, "mc_add_reads_file: host-to-device copy failed");
+                    break;
+                }
+                if (i + 1 < cuts.size()) {
+                    rc = start_upload(i + 1, nxt);
+                    if (rc != MC_OK) break;
+                }
+                uint64_t got = 0;
+                bool declined = false;
+                {
+                    std::lock_guard<std::mutex> g(c->mu);
+                    rc = tokenize_chunk_locked(c, f, cuts[i].first, cuts[i].second, cur->text.p, &got, &declined);
+                }
+                if (rc != MC_OK) break;
+                if (declined) {
+                    try {
+                        got = mch::parse_plain_range(f, cuts[i].first, cuts[i].second, 1u << 20, sink);
+                    } catch (...) {
+                        finish(cur);
+                        finish(nxt);
+                        throw;
+                    }
+                    if (rc != MC_OK) break;
+                }
+                total += got;
+                finish(cur);
+                cur = std::move(nxt);
+            }
+            finish(cur);
+            finish(nxt);
+            if (rc != MC_OK) return rc;
+            if (dbg) fprintf(stderr, "[ingest] device tokeniser: %zu chunk(s), %.1f MB in %.3f s\n", cuts.size(), f.n / 1e6, now() - t_begin);
+            if (n_reads) *n_reads = total;
+            return MC_OK;
+        }
+        const uint64_t n = mch::load_reads_file(path, 1u << 20, sink);
         if (rc != MC_OK) return rc;
         if (n_reads) *n_reads = n;
         return MC_OK;

@@ -1,5 +1,5 @@
-"""Wall-clock of mc_add_reads_file (parse + pack on the host, count on the GPU) for a synthetic FASTA / FASTQ,
-serial reader vs the parallel one.  Usage: python scripts/ingest_bench.py [n_reads]"""
+"""Wall-clock of mc_add_reads_file for a synthetic FASTA / FASTQ: the host parser on one core and on all of them, and
+the device tokeniser (csrc/tokenizer.h); counting on the GPU in all three.  Usage: python scripts/ingest_bench.py [n_reads]"""
 import os
 import subprocess
 import sys
@@ -34,11 +34,12 @@ t0 = time.time(); n = ctx.add_reads_file(sys.argv[1]); d = ctx.finalize(); t1 = 
 print("%%s: %%d reads, %%d distinct k-mers, %%.3f s = %%.1f Mbases/s" %% (sys.argv[1].rsplit(".", 1)[1], n, d, t1 - t0, n * %d / (t1 - t0) / 1e6))
 ''' % (ROOT, L)
 for path in (fa, fq):
-    for threads in ("1", ""):
+    for label, extra in (("host, 1 thread", {"MC_TOKENIZER": "host", "MC_INGEST_THREADS": "1"}), ("host, all cores", {"MC_TOKENIZER": "host"}),
+                         ("device tokeniser", {"MC_TOKENIZER": "device", "MC_INGEST_DEBUG": "1"})):
         env = dict(os.environ)
-        if threads:
-            env["MC_INGEST_THREADS"] = threads
-        else:
-            env.pop("MC_INGEST_THREADS", None)
+        env.pop("MC_INGEST_THREADS", None)
+        env.update(extra)
         out = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, env=env)
-        print("threads=%s" % (threads or "all"), out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-500:])
+        print("%-17s" % label, out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-500:])
+        if "MC_INGEST_DEBUG" in extra:
+            print("\n".join(l for l in out.stderr.splitlines() if "device tokeniser" in l))

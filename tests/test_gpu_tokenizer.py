@@ -1,0 +1,206 @@
+"""f1 on the device (csrc/tokenizer.h): uncompressed FASTA / FASTQ text tokenised in HBM must give the reads the
+oracle's readers give (oracle/host_oracle.py read_fasta_reads / read_fastq_reads, which restate itmo!/io/readers/
+FastaReader.java:54-104, FastqReader.java:53-112 and FastaReaderFromXQSourceTrunc.java:61-95) -- same number of reads,
+same table, bit for bit -- and must hand anything unusual to the host parser, which then behaves as before."""
+import numpy as np
+import pytest
+
+from oracle import host_oracle as ho
+from oracle import pyoracle as po
+from tests.helpers import oracle_table
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mc():
+    import metacherchant_amd as m
+    m.native.load()
+    return m
+
+
+def _table_of(reads, k):
+    codes = np.concatenate([po.encode(r) for r in reads]) if reads else np.zeros(0, dtype=np.uint8)
+    off = np.zeros(len(reads) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(r) for r in reads])
+    return oracle_table(codes, off, k, po.KEY_PACKED)[0]
+
+
+def _check(mc, path, want_reads, k, monkeypatch, expect_device=True, chunk=None):
+    t = _table_of([r.upper() for r in want_reads], k)
+    for mode in ("device", "host"):
+        monkeypatch.setenv("MC_TOKENIZER", mode)
+        monkeypatch.setenv("MC_INGEST_DEBUG", "1")
+        if chunk:
+            monkeypatch.setenv("MC_TOKENIZER_CHUNK_BYTES", str(chunk))
+        ctx = mc.Context(k, mc.KEY_PACKED, 0, 0)
+        assert ctx.add_reads_file(str(path)) == len(want_reads), mode
+        n = ctx.finalize()
+        assert n == t.size(), mode
+        gk, gc = ctx.export(0)
+        ok, oc = t.dump()
+        assert np.array_equal(gk, ok) and np.array_equal(gc, oc), mode
+        ctx.close()
+
+
+def _rand_seq(rng, n):
+    return "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+
+
+def _fasta_text(rng, n_rec, crlf=False, lower=False, with_n=True, width=70):
+    eol = "\r\n" if crlf else "\n"
+    out = []
+    for i in range(n_rec):
+        L = int(rng.integers(0, 400))
+        s = _rand_seq(rng, L)
+        if lower and i % 3 == 0:
+            s = s.lower()
+        if with_n and i % 7 == 3 and L:
+            p = int(rng.integers(0, L))
+            s = s[:p] + ("N" if i % 2 else "n") + s[p + 1:]
+        out.append((">" if i % 11 else ";") + "rec%d some text" % i + eol)
+        if i % 5 == 0:  # one line
+            out.append(s + eol)
+        else:
+            for j in range(0, max(L, 1), width):
+                out.append(s[j:j + width] + eol)
+        if i % 13 == 0:
+            out.append(eol)  # an empty line inside / after a record
+    return "".join(out)
+
+
+@pytest.mark.parametrize("crlf,lower", [(False, False), (True, True)])
+def test_fasta_device_tokeniser(mc, tmp_path, monkeypatch, crlf, lower):
+    rng = np.random.default_rng(5 + crlf)
+    text = "ACGTACGTTTGACCA\n" * 3 + _fasta_text(rng, 3000, crlf, lower)  # bases in front of the first header: a record
+    text = text.rstrip("\r\n")  # no newline at the end of the file
+    p = tmp_path / "reads.fasta"
+    p.write_text(text, newline="")
+    want = ho.read_fasta_reads(str(p))
+    assert 2000 < len(want) < 3001
+    _check(mc, p, want, 21, monkeypatch)
+    _check(mc, p, want, 21, monkeypatch, chunk=20000)  # ~40 chunks cut at header lines
+
+
+def test_fasta_one_long_record_and_empty_cases(mc, tmp_path, monkeypatch):
+    rng = np.random.default_rng(9)
+    s = _rand_seq(rng, 700001)  # more bases than a packing workgroup holds in LDS, on one line and on many
+    p = tmp_path / "contigs.fa"
+    p.write_text(">one\n" + s + "\n>two\n" + "\n".join(s[i:i + 60] for i in range(0, len(s), 60)) + "\n>three\n\n>four\nACGT\n")
+    want = ho.read_fasta_reads(str(p))
+    assert [len(r) for r in want] == [700001, 700001, 4]
+    _check(mc, p, want, 31, monkeypatch)
+    q = tmp_path / "only_headers.fna"
+    q.write_text(">a\n>b\n\n>c\n")
+    _check(mc, q, [], 31, monkeypatch)
+    r = tmp_path / "all_n.fn"
+    r.write_text(">a\nACGTNACGT\n>b\nnnnn\n")
+    _check(mc, r, [], 5, monkeypatch)
+
+
+def _fastq_text(rng, n_rec, offset, crlf=False):
+    eol = "\r\n" if crlf else "\n"
+    out = []
+    for i in range(n_rec):
+        L = int(rng.integers(0, 260))
+        s = list(_rand_seq(rng, L))
+        q = [chr(offset + int(x)) for x in rng.integers(2, 41, L)]
+        for _ in range(int(rng.integers(0, 4))):
+            if not L:
+                break
+            j = int(rng.integers(0, L))
+            kind = int(rng.integers(0, 4))
+            if kind == 0:
+                s[j] = "N"
+            elif kind == 1:
+                s[j] = "."
+                q[j] = chr(offset)
+            elif kind == 2:
+                q[j] = chr(offset)  # phred 0
+            else:
+                s[j] = "n"
+        if i % 17 == 0 and L > 3:
+            q[0] = chr(offset)
+            q[L - 1] = chr(offset)  # pieces that start late and end early
+        if i % 19 == 0 and L:
+            s = [c.lower() for c in s]
+        out.append("@read%d/1%s%s%s+%s%s%s" % (i, eol, "".join(s), eol, "read%d/1" % i if i % 2 else "", eol, "".join(q) + eol))
+    return "".join(out)
+
+
+@pytest.mark.parametrize("offset,crlf", [(33, False), (64, False), (33, True)])
+def test_fastq_device_tokeniser(mc, tmp_path, monkeypatch, offset, crlf):
+    rng = np.random.default_rng(40 + offset + crlf)
+    p = tmp_path / ("reads.fq" if offset == 33 else "reads.fastq")
+    p.write_text(_fastq_text(rng, 4000, offset, crlf), newline="")
+    want = ho.read_fastq_reads(str(p))
+    assert len(want) > 4000  # quality splits make more pieces than records
+    _check(mc, p, want, 17, monkeypatch)
+    _check(mc, p, want, 17, monkeypatch, chunk=50000)
+
+
+def test_fastq_phred_64_wraps(mc, tmp_path, monkeypatch):
+    """offset 33 with quality chars up to '~' (phred 93): phred 64 lives in 6 bits and reads as 0 (DnaQBuilder.java:32-35)."""
+    seq = "ACGTTGCAAGGCTTACGATC"
+    qual = "".join(chr(33 + v) for v in [40, 64, 40, 40, 93, 65, 0, 30, 30, 63, 64, 64, 20, 20, 20, 20, 20, 20, 20, 1])
+    p = tmp_path / "q.fq"
+    p.write_text("@a\n%s\n+\n%s\n" % (seq, qual) * 50)
+    want = ho.read_fastq_reads(str(p))
+    assert len(want) == 50 * 4
+    _check(mc, p, want, 3, monkeypatch)
+
+
+def test_device_tokeniser_declines_to_the_host_parser(mc, tmp_path, monkeypatch):
+    """Blank lines between FASTQ records, '+' records first, IUPAC codes, a quality char below the offset: not for the
+    device.  The host parser reads (or rejects) those exactly as before."""
+    rng = np.random.default_rng(77)
+    recs = _fastq_text(rng, 300, 33).split("@read")
+    p = tmp_path / "blank.fq"
+    p.write_text("@read".join(recs[:100]) + "\n\n@read" + "@read".join(recs[100:]))
+    want = ho.read_fastq_reads(str(p))
+    _check(mc, p, want, 15, monkeypatch)
+    # an IUPAC code: both readers refuse the file with the same message
+    bad = tmp_path / "iupac.fasta"
+    bad.write_text(">a\nACGTRACGT\n")
+    msgs = []
+    for mode in ("device", "host"):
+        monkeypatch.setenv("MC_TOKENIZER", mode)
+        ctx = mc.Context(5, mc.KEY_PACKED, 0, 0)
+        with pytest.raises(mc.native.McError) as ei:
+            ctx.add_reads_file(str(bad))
+        msgs.append(str(ei.value))
+        ctx.close()
+    assert msgs[0] == msgs[1]
+    # a quality char below the sniffed offset, late in the file (past the 1000 records the offset comes from)
+    late = tmp_path / "late.fq"
+    late.write_text("@a\nACGTACGT\n+\nhhhhhhhh\n" * 1200 + "@b\nACGTACGT\n+\nhhhh5hhh\n")
+    msgs = []
+    for mode in ("device", "host"):
+        monkeypatch.setenv("MC_TOKENIZER", mode)
+        ctx = mc.Context(5, mc.KEY_PACKED, 0, 0)
+        with pytest.raises(mc.native.McError, match="Invalid quality code char") as ei:
+            ctx.add_reads_file(str(late))
+        msgs.append(str(ei.value))
+        ctx.close()
+    assert msgs[0] == msgs[1]
+
+
+def test_device_tokeniser_feeds_the_read_store(mc, tmp_path, monkeypatch):
+    """Reads tokenised on the device land in the read store: a BFS that walks by read pointers gives the oracle's answer."""
+    from tests.helpers import assert_bfs_equal, seed_windows, synth_case
+    genome, reads, off = synth_case(2, 30000, 12000, 150, 50)
+    n = len(off) - 1
+    p = tmp_path / "r.fasta"
+    p.write_text("".join(">r%d\n%s\n" % (i, po.decode(reads[int(off[i]):int(off[i + 1])])) for i in range(n)))
+    t, _ = oracle_table(reads, off, 31, po.KEY_PACKED)
+    seed = genome[10000:10500]
+    hi, lo = seed_windows(seed, 31)
+    want = po.bfs(t, 31, po.KEY_PACKED, [seed], 1, 5, 3000, -1)
+    monkeypatch.setenv("MC_TOKENIZER", "device")
+    ctx = mc.Context(31, mc.KEY_PACKED, 0, 0)
+    ctx.set_coverage_hint(5)
+    assert ctx.add_reads_file(str(p)) == n
+    assert ctx.finalize() == t.size()
+    assert_bfs_equal(ctx.bfs(hi, lo, 1, 5, 3000, -1), want)
+    assert_bfs_equal(ctx.bfs(hi, lo, -1, 3, 3000, 400), po.bfs(t, 31, po.KEY_PACKED, [seed], -1, 3, 3000, 400))
+    ctx.close()
