@@ -118,7 +118,10 @@ int mc_add_reads_packed_dev(mc_ctx *ctx, const uint64_t *d_words, const uint64_t
  * itmo!/io/ReadersUtils.java:27-53,104-121): format by extension (.fasta .fa .fn .fna / .fastq .fq, optionally
  * .gz or .bz2; .binq), FASTA records with N dropped whole, FASTQ and BINQ reads split where phred < 1 (quality
  * offset sniffed on the first 1000 records); every read (piece) is counted as by mc_add_reads_packed.  *n_reads (may be NULL) = reads
- * added ("N reads added").  Errors carry the reference's messages ("Can't detect file format for file ..."). */
+ * added ("N reads added").  Errors carry the reference's messages ("Can't detect file format for file ...").
+ * Uncompressed FASTA / FASTQ text is tokenised on the device (csrc/tokenizer.h: the bytes cross the link in 256 MB
+ * chunks, each tokenised and counted while the next one is copied); what the device declines, and every compressed
+ * or .binq file, is parsed by the host (environment: MC_TOKENIZER=host parses every file on the host). */
 int mc_add_reads_file(mc_ctx *ctx, const char *path, uint64_t *n_reads);
 
 /* End of loadReads (src/io/IOUtils.java:217-248): waits for all queued counting work;
