@@ -30,6 +30,8 @@ constexpr int PT_THREADS = 1024;                    // workgroup of the scatter 
 constexpr int PT_ITEMS = 8;
 constexpr int PT_TILE = PT_THREADS * PT_ITEMS;      // 8192 windows / keys per tile
 constexpr int PT_MAX_BUCKETS = 512;                 // fan-out of one scatter level
+constexpr int PT_MAX_LEAVES2 = 1024;                // ... of the second level of the super-k-mer pipeline (k_sk2_scatter: an LDS cursor per leaf)
+constexpr int SK_LEAVES_LG = 19;                    // so up to 512 x 1024 leaves of one region each (8.6 G slots of 16 bytes = 34 GB of table)
 constexpr int P3_THREADS = 512;
 constexpr uint32_t REGION_SLOTS = 4096;             // == 1 << mc_ctx::sb
 constexpr uint32_t CURSOR1_STRIDE = 32;             // owner cursors of the multi-GPU split sit on separate 128-byte lines
@@ -489,7 +491,7 @@ __device__ __forceinline__ void sk_spill_push(const SkSpill &sp, const uint4 &re
 // append one record to this workgroup's piece of bucket d (fill levels in LDS: wcur = before this
 // tile, cnt = within it); runs of a bucket are short here, so the store is not staged through LDS
 struct SkCursors {
-    uint32_t cnt[PT_MAX_BUCKETS], wcur[PT_MAX_BUCKETS];
+    uint32_t cnt[PT_MAX_LEAVES2], wcur[PT_MAX_LEAVES2];
 };
 __device__ __forceinline__ void sk_emit(SkCursors &C, uint32_t d, const uint4 &rec, uint32_t bin, uint64_t cap, uint64_t base,
                                         uint64_t bucket_stride, uint4 *out_recs, uint32_t *out_bins, const SkSpill &sp)
@@ -528,6 +530,7 @@ constexpr int P1W_THREADS = 512;
 constexpr int P1W_WAVES = P1W_THREADS / 64;
 constexpr uint32_t P1W_TILE = 62 * PT_ITEMS;   // base positions per wave tile
 constexpr int P1W_SEGMENTS = 1024;             // workgroups of the launch = segments of every level-1 bucket
+static_assert(PT_MAX_LEAVES2 <= PT_THREADS, "one thread per leaf cursor");
 static_assert(P1W_SEGMENTS <= PT_THREADS && P1W_SEGMENTS >= PT_SEGMENTS, "k_sk2_scatter scans one segment count per thread");
 
 struct Sk1wLds {
@@ -801,7 +804,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk1_records(const uint4 *__restr
 {
     __shared__ SkCursors C;
     const uint32_t tid = threadIdx.x, n_buckets = np1;
-    if (tid < PT_MAX_BUCKETS) { C.wcur[tid] = 0; C.cnt[tid] = 0; }
+    if (tid < PT_MAX_LEAVES2) { C.wcur[tid] = 0; C.cnt[tid] = 0; }
     __syncthreads();
     const uint64_t n_tiles = (n + PT_TILE - 1) / PT_TILE;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -844,7 +847,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk2_scatter(const uint4 *__restr
     constexpr uint32_t TILE2 = PT_THREADS * 4;
     for (uint32_t bucket = blockIdx.x; bucket < n_buckets1; bucket += gridDim.x) {
         __syncthreads();
-        if (tid < PT_MAX_BUCKETS) { L.C.wcur[tid] = 0; L.C.cnt[tid] = 0; }
+        if (tid < PT_MAX_LEAVES2) { L.C.wcur[tid] = 0; L.C.cnt[tid] = 0; }
         {   // exclusive prefix of the bucket's segment fill levels (nseg_in <= PT_THREADS: one per thread)
             const uint32_t c = tid < nseg_in ? seg_counts1[(uint64_t)bucket * nseg_in + tid] : 0u;
             uint32_t x = c;

@@ -438,7 +438,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_solid_emit(const Slot *__restric
 {
     __shared__ SkCursors C;
     const uint32_t tid = threadIdx.x, n_buckets = np1;
-    if (tid < PT_MAX_BUCKETS) { C.wcur[tid] = 0; C.cnt[tid] = 0; }
+    if (tid < PT_MAX_LEAVES2) { C.wcur[tid] = 0; C.cnt[tid] = 0; }
     __syncthreads();
     const uint64_t n_tiles = (n_slots + PT_TILE - 1) / PT_TILE;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -474,7 +474,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_solid_emit_pairs(const int64_t *
 {
     __shared__ SkCursors C;
     const uint32_t tid = threadIdx.x, n_buckets = np1;
-    if (tid < PT_MAX_BUCKETS) { C.wcur[tid] = 0; C.cnt[tid] = 0; }
+    if (tid < PT_MAX_LEAVES2) { C.wcur[tid] = 0; C.cnt[tid] = 0; }
     __syncthreads();
     // Rows of 8 entries (64 bytes of keys: one memory sector) are dealt to the workgroups (= segments) round-robin.  An
     // export comes in table order, which for hash-prefix tables is the order of the very hash that picks the bucket
@@ -513,7 +513,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_solid_emit_list(const uint4 *__r
 {
     __shared__ SkCursors C;
     const uint32_t tid = threadIdx.x, n_buckets = np1;
-    if (tid < PT_MAX_BUCKETS) { C.wcur[tid] = 0; C.cnt[tid] = 0; }
+    if (tid < PT_MAX_LEAVES2) { C.wcur[tid] = 0; C.cnt[tid] = 0; }
     __syncthreads();
     for (uint32_t sg = blockIdx.x; sg < nseg; sg += gridDim.x) {
         const uint32_t n = list_counts[sg];
@@ -772,7 +772,7 @@ static uint64_t regions_for(const mc_ctx *c, uint64_t slots)
     while (p2 < want) p2 <<= 1;
     if (!c->mm_k || want <= 512) return p2;
     uint64_t step = 512;
-    while (((want + step - 1) / step) * step > (step << 9)) step <<= 1;  // keep <= 2^18 leaves of `step`-aligned size
+    while (((want + step - 1) / step) * step > (step << (SK_LEAVES_LG - 9))) step <<= 1;  // keep <= 2^19 leaves of `step`-aligned size
     return ((want + step - 1) / step) * step;
 }
 
@@ -976,7 +976,13 @@ static int ensure_buf(mc_ctx *c, T **p, uint64_t *cap, uint64_t need)
     if (*p) (void)hipFree(*p);
     *p = nullptr;
     *cap = 0;
-    HIPCHK(c, hipMalloc(reinterpret_cast<void **>(p), std::max<uint64_t>(need, 1) * sizeof(T)));
+    const hipError_t e = hipMalloc(reinterpret_cast<void **>(p), std::max<uint64_t>(need, 1) * sizeof(T));
+    if (e != hipSuccess) {
+        size_t fr = 0, tot = 0;
+        (void)hipMemGetInfo(&fr, &tot);
+        return fail(c, e == hipErrorOutOfMemory ? MC_ENOMEM : MC_EHIP, "scratch of %.2f GB: %s (%.2f of %.2f GB free on the device)",
+                    std::max<uint64_t>(need, 1) * sizeof(T) / 1e9, hipGetErrorString(e), fr / 1e9, tot / 1e9);
+    }
     *cap = need;
     return MC_OK;
 }
@@ -1018,16 +1024,17 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
             }
         }
     }
-    // leaves: the regions themselves up to 2^18 of them, else 2^g regions per leaf; level-1 buckets: up to 512, each
-    // of m2 <= 512 leaves (regions_for made the numbers divide)
+    // leaves: the regions themselves up to 2^19 of them (2^18 when keys travel, not records), else 2^g regions per leaf;
+    // level-1 buckets: up to 512, each of m2 <= 1024 (512) leaves (regions_for made the numbers divide)
     uint64_t n_leaves = c->n_regions;
     uint32_t g = 0;
-    while (n_leaves > (1ull << 18)) { n_leaves >>= 1; g++; }
+    const uint32_t max_b2 = n_records ? PT_MAX_LEAVES2 : PT_MAX_BUCKETS;  // (super-k-mer records: k_sk2_scatter; keys: k_p2_scatter)
+    while (n_leaves > (uint64_t)PT_MAX_BUCKETS * max_b2) { n_leaves >>= 1; g++; }
     if ((n_leaves << g) != c->n_regions) return fail(c, MC_EINVAL, "internal: %llu table regions do not split into leaves", (unsigned long long)c->n_regions);
     if (n_leaves < 4) return fail(c, MC_EINVAL, "internal: partitioned counting needs at least 4 table regions");
     uint64_t np1 = std::min<uint64_t>(n_leaves, PT_MAX_BUCKETS);
     while (n_leaves % np1) np1--;  // (a power of two, or 512 dividing a multiple of 512)
-    if (n_leaves / np1 > PT_MAX_BUCKETS) return fail(c, MC_EINVAL, "internal: %llu leaves do not fit two scatter levels", (unsigned long long)n_leaves);
+    if (n_leaves / np1 > max_b2) return fail(c, MC_EINVAL, "internal: %llu leaves do not fit two scatter levels", (unsigned long long)n_leaves);
     pl->b1 = (uint32_t)np1;               // level-1 buckets
     pl->b2 = (uint32_t)(n_leaves / np1);  // leaves per bucket; 1: the level-1 buckets already are the leaves, no P2
     pl->g = g;
@@ -1462,6 +1469,18 @@ static int rs_append(mc_ctx *c, const uint64_t *d_words, uint64_t first_off, uin
     return MC_OK;
 }
 
+// Bases one run of the partitioned pipeline takes.  Positions are 64-bit throughout; what is 32-bit is the index of a
+// record inside the scatter levels' arrays (pipe_prepare checks it): super-k-mer records are ~0.18 per window, so 2^34
+// bases (114 M reads of 150 bp) stay far below 2^32 records, while one 8-byte key per window (k > 31, hash keys) reaches
+// 2^32 x 0.8 at 3.4 G windows and costs 29 bytes of scratch per window -- those runs stay at 2^31 bases.
+// Every run reads and rewrites the whole table, so fewer, larger runs are what a large read set wants.
+static uint64_t max_run_bases(const mc_ctx *c)
+{
+    static const uint64_t env = [] { const char *e = getenv("MC_MAX_RUN_BASES"); return e && *e ? strtoull(e, nullptr, 10) : 0ull; }();
+    if (env) return std::max<uint64_t>(env, 1u << 20);
+    return c->mm_k ? (1ull << 34) : (1ull << 31) - (1ull << 24);
+}
+
 // counting with read offsets known on the host
 static int add_reads_impl(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_off, const uint64_t *h_off,
                           uint64_t n_reads)
@@ -1478,12 +1497,11 @@ static int add_reads_impl(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_
     const uint64_t total = windows_of(0, n_reads);
     const bool partition = c->count_path == 2 || (c->count_path == 0 && total >= (1ull << 22));
     if (partition) {
-        // batches of at most ~2^31 windows (32-bit bucket cursors)
-        const uint64_t max_bases = (1ull << 31) - (1ull << 24);
+        const uint64_t max_bases = max_run_bases(c);
         uint64_t r = 0;
         while (r < n_reads) {
             uint64_t r1 = (uint64_t)(std::upper_bound(h_off + r, h_off + n_reads + 1, h_off[r] + max_bases) - h_off) - 1;
-            if (r1 <= r) return fail(c, MC_EINVAL, "a single read of more than 2^31 bases is not supported");
+            if (r1 <= r) return fail(c, MC_EINVAL, "a single read of more than %llu bases is not supported", (unsigned long long)max_bases);
             if (r1 > n_reads) r1 = n_reads;
             const uint64_t wb = windows_of(r, r1);
             if (wb) {
@@ -1589,12 +1607,12 @@ int mc_create(const mc_config *cfg, mc_ctx **out)
         // kernel's probe loops and the walk's lookups pay for every extra probe, while a sparser table only costs its
         // write-back: measured on the 10 M-read workload (364 M keys), count + BFS per step at load 0.60 / 0.51 / 0.43 /
         // 0.36: 39.1 / 31.5 / 29.2 / 28.6 ms.  So 0.25 up to 64 M keys, + 0.05 per doubling, 0.36 at most -- but never
-        // more than 2^18 regions while the load stays under 0.6: beyond that a leaf of the counting pipeline covers two
-        // regions and the merge kernel sweeps each leaf twice (19 ms instead of 9).
+        // more than 2^19 regions while the load stays under 0.6: beyond that a leaf of the counting pipeline covers two
+        // regions and the merge kernel sweeps each leaf twice.
         double load = 0.7;
         if (c->mm_k) load = std::min(0.36, std::max(0.25, 0.25 + 0.05 * std::log2((double)cfg->capacity_hint / (double)(64u << 20))));
         want_slots = std::max<uint64_t>(want_slots, (uint64_t)((double)cfg->capacity_hint / load));
-        const uint64_t one_leaf_each = 1ull << (18 + c->sb);
+        const uint64_t one_leaf_each = 1ull << (SK_LEAVES_LG + c->sb);
         if (c->mm_k && want_slots > one_leaf_each && (double)cfg->capacity_hint <= 0.6 * (double)one_leaf_each) want_slots = one_leaf_each;
     }
     int rc = table_alloc(c, regions_for(c, want_slots));
@@ -1829,7 +1847,7 @@ static int add_reads_dev_locked(mc_ctx *c, const uint64_t *d_words, const uint64
         c->ptr_tries = 1;
     }
     const bool partition = c->count_path == 2 || (c->count_path == 0 && total >= (1ull << 22));
-    if (partition && last_off - first_off < (1ull << 31) - (1ull << 24)) {  // one batch: no need for the offsets on the host
+    if (partition && last_off - first_off < max_run_bases(c)) {  // one batch: no need for the offsets on the host
         if (total) {
             int rc = add_reads_partitioned(c, d_words, d_off, 0, n_reads, first_off, last_off, total);
             if (rc) return rc;
