@@ -91,9 +91,9 @@ def main():
     n_bases = R * L
     windows = R * (L - k + 1)
     genome_bases = args.contigs * args.contig_len
-    # expected distinct keys: the genome's k-mers + ~0.7 k novel k-mers per substitution error (fewer than k near read
-    # ends and where two errors share a window; measured 0.67 k at k = 31, 1 % errors)
-    est_distinct = int(min(world * windows, genome_bases + world * n_bases * (args.err / 10000.0) * k * 0.7))
+    # expected distinct keys: the genome's k-mers + a new key for every window with a substitution in it (measured at
+    # k = 31, 1 %: 363 M against 372 M; at k = 63: 4.58 G against 4.63 G -- a few windows repeat an error of another read)
+    est_distinct = int(min(world * windows, genome_bases + world * windows * (1.0 - (1.0 - args.err / 10000.0) ** k)))
     hint_local = args.capacity_hint or est_distinct // world + (1 << 20)
 
     ctx = m.Context(k, mode, local_rank, hint_local, m.native.FLAG_SOLID_LIST if world > 1 else 0)
