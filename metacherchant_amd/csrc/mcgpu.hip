@@ -26,6 +26,7 @@
 #include "kmer_device.h"
 #include "bfs_device.h"
 #include "count_pipeline.h"
+#include "count_long.h"
 #include "tokenizer.h"
 #include "host/envfinder.h"
 
@@ -181,6 +182,10 @@ struct mc_ctx {
     bool virgin = true;  // the table holds no key and its memory is not initialised yet
     int count_path = 0;  // 0 auto, 1 direct (atomics), 2 partitioned; MC_COUNT_PATH=direct|partition overrides
     bool sk_form = false;  // reads of this context can travel as super-k-mer records (set once; mm_k may be given up later)
+    // polynomial-hash keys, k = 32 .. 63 (count_long.h): skl_ok -- this context may count reads as 32-byte super-k-mer records;
+    // skl_state -- it does so now: mm_k == k and the table's regions are minimizer bins of the k-mers' BASES, so no kernel may
+    // address it by key (leave_long() rebuilds it by key hash before the first operation that has to)
+    bool skl_ok = false, skl_state = false;
     // scratch of the partitioned counting pipeline, kept between calls
     struct Pipe {
         uint64_t *a_keys = nullptr, *b_keys = nullptr, *spill_keys = nullptr;
@@ -900,10 +905,22 @@ static int drain_parked(mc_ctx *c)
     }
 }
 
+// count_long.h: back to regions by key hash, with everything counted so far moved over (a no-op for other contexts)
+static int leave_long(mc_ctx *c)
+{
+    if (!c->skl_state) return MC_OK;
+    c->skl_state = false;
+    return to_hash_regions(c);
+}
+
 // Make room for `incoming` more key occurrences: returns how many of them may be inserted by the
 // next launch without the load factor passing 0.85 even if every one is a new key.
 static int table_reserve(mc_ctx *c, uint64_t incoming, uint64_t *allowed)
 {
+    {
+        int lrc = leave_long(c);  // (every caller is about to address the table by key)
+        if (lrc) return lrc;
+    }
     int mrc = materialize(c);
     if (!mrc) mrc = drain_parked(c);  // (what the previous launch could not place)
     if (mrc) return mrc;
@@ -1362,13 +1379,186 @@ static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint6
     return MC_OK;
 }
 
+// One batch of reads [r0, r1) as 32-byte super-k-mer records (count_long.h): polynomial-hash keys, k = 32 .. 63, into a
+// table that holds nothing yet or was filled this way.  Returns 2 when this table cannot be split into the pipeline's
+// leaves (the caller takes the per-window pipeline).
+static int add_reads_partitioned_long(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_off, uint64_t r0, uint64_t r1, uint64_t base0,
+                                      uint64_t end_abs, uint64_t wb)
+{
+    mc_ctx::Pipe &P = c->pipe;
+    const uint64_t nr = r1 - r0;
+    const int k = c->cfg.k;
+    // leaves: the regions themselves up to 512 x 1024 of them, else 2^g regions per leaf
+    uint64_t n_leaves = c->n_regions;
+    uint32_t g = 0;
+    while (n_leaves > (uint64_t)PT_MAX_BUCKETS * PT_MAX_LEAVES2) { n_leaves >>= 1; g++; }
+    if ((n_leaves << g) != c->n_regions || n_leaves < 4 || g > 5) return 2;
+    uint64_t np1 = std::min<uint64_t>(n_leaves, PT_MAX_BUCKETS);
+    while (n_leaves % np1) np1--;
+    const uint64_t b2 = n_leaves / np1;
+    if (b2 > PT_MAX_LEAVES2) return 2;
+    {
+        unsigned long long used;
+        uint32_t fatal;
+        int rc = read_counters(c, &used, &fatal);
+        if (rc) return rc;
+        if (fatal) return fail(c, MC_EOVERFLOW, "a k-mer table region filled up (hash skew)");
+        c->n_used_host = used;
+    }
+    if (!c->skl_state) {  // (the table is empty: its regions are minimizer bins from here on)
+        c->mm_k = k;
+        c->skl_state = true;
+    }
+    c->solid_list_fresh = false;
+    const uint32_t nseg1 = SKL_SEGMENTS;
+    const uint64_t n_tiles_abs = (end_abs + SKL_TILE - 1) / SKL_TILE;
+    // records: a run of windows sharing a minimizer averages (w + 1) / 2 = 25 windows at k = 63 and is cut every 16, at
+    // read ends, at sequencing errors and at tile borders: ~0.1 per window measured; 0.16 + ... leaves room
+    const uint64_t units = (uint64_t)((double)wb * 0.16) + 2 * nr + 2 * (n_tiles_abs - base0 / SKL_TILE) + 1024;
+    const uint64_t cap1 = (uint64_t)((double)units / (double)np1 / (double)nseg1 * 1.25) + 64;
+    const double mean_leaf = (double)units / (double)n_leaves;
+    const uint64_t cap2 = (uint64_t)(mean_leaf * 1.15 + 32.0 * std::sqrt(mean_leaf) + 64.0);
+    const uint64_t spill_cap = std::max<uint64_t>(units / 16, 1u << 16);
+    if (np1 * nseg1 * cap1 >= 0xFFFFFFFFull || b2 * cap2 >= 0xFFFFFFFFull) return fail(c, MC_EINVAL, "internal: partitioned batch too large for 32-bit bucket indices");
+    int rc;
+#define ENSURE(ptr, capvar, need) do { rc = ensure_buf(c, &(ptr), &(capvar), (need)); if (rc) return rc; } while (0)
+    ENSURE(P.a_recs, P.a_recs_cap, 2 * np1 * nseg1 * cap1);  // (uint4 units: a record is two)
+    if (b2 > 1) ENSURE(P.b_recs, P.b_recs_cap, 2 * n_leaves * cap2);
+    ENSURE(P.spill_recs, P.spill_recs_cap, 2 * spill_cap);
+    ENSURE(P.seg_counts1, P.segs1_cap, np1 * nseg1);
+    ENSURE(P.cursors2, P.cursors2_cap, n_leaves);
+    { uint64_t cap = P.leaves_cap, dummy = P.leaves_cap; ENSURE(P.leaf_state, cap, n_leaves); ENSURE(P.leaf_new, dummy, n_leaves); P.leaves_cap = cap; }
+    ENSURE(P.tile_first, P.tiles1_cap, n_tiles_abs);
+#undef ENSURE
+    if (!P.flags) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.flags), 4 * sizeof(uint32_t)));
+    if (!P.spill_count) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.spill_count), sizeof(unsigned long long)));
+    HIPCHK(c, hipMemsetAsync(P.seg_counts1, 0, np1 * nseg1 * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(P.cursors2, 0, n_leaves * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(P.leaf_state, 0, n_leaves * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(P.leaf_new, 0, n_leaves * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(P.flags, 0, 4 * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(P.spill_count, 0, sizeof(unsigned long long), c->stream));
+    SkLRec *a = reinterpret_cast<SkLRec *>(P.a_recs), *b = reinterpret_cast<SkLRec *>(P.b_recs), *spill = reinterpret_cast<SkLRec *>(P.spill_recs);
+    const SkLSpill sp{spill, P.spill_count, spill_cap, P.flags};
+    const uint64_t *offs = d_off + r0;
+    const uint64_t p5k = pow5(k), p5km1 = pow5(k - 1);
+    const uint32_t thr = (uint32_t)(c->solid_tracked ? c->cov_hint : 0);
+    double ms1 = 0, ms2 = 0, ms3 = 0, ms4 = 0;
+    rc = timed(c, &ms1, [&] {
+        hipLaunchKernelGGL(k_tile_first_read, dim3((unsigned)((n_tiles_abs + 255) / 256)), dim3(256), 0, c->stream, offs, nr, n_tiles_abs, P.tile_first,
+                           SKL_TILE);
+        hipLaunchKernelGGL(k_skl_extract, dim3(nseg1), dim3(SKL_THREADS), 0, c->stream, d_words, offs, nr, base0, end_abs, n_tiles_abs, P.tile_first, k,
+                           (uint32_t)np1, P.seg_counts1, cap1, a, sp, c->cur_ptr_base);
+    });
+    if (rc) return rc;
+    if (b2 > 1) {
+        rc = timed(c, &ms2, [&] {
+            hipLaunchKernelGGL(k_skl2_scatter, dim3((unsigned)np1), dim3(PT_THREADS), 0, c->stream, a, cap1, P.seg_counts1, (uint32_t)np1, (uint32_t)np1,
+                               (uint32_t)b2, nseg1, P.cursors2, cap2, b, sp);
+        });
+        if (rc) return rc;
+    }
+    {
+        uint32_t lost = 0;
+        HIPCHK(c, hipMemcpy(&lost, P.flags, sizeof lost, hipMemcpyDeviceToHost));
+        if (lost) return fail(c, MC_EOVERFLOW, "internal: the record streams of the counting pipeline overflowed their spill list");
+    }
+    const SkLRec *lk = b2 > 1 ? b : a;
+    const uint32_t *lc = b2 > 1 ? P.cursors2 : P.seg_counts1;
+    const uint64_t lcap = b2 > 1 ? cap2 : cap1;
+    const uint32_t lseg = b2 > 1 ? 1u : nseg1;
+    const int virgin = c->virgin ? 1 : 0;
+    rc = timed(c, &ms3, [&] {
+        hipLaunchKernelGGL(k_p3l_merge, dim3((unsigned)std::min<uint64_t>(n_leaves, 256 * 2 * 4)), dim3(P3_THREADS), 0, c->stream, lk, lc, lcap, lseg,
+                           (uint32_t)n_leaves, g, c->view(), virgin, P.leaf_state, P.leaf_new, P.flags + 1, thr, c->d_ctr + 6, k, p5k, p5km1);
+    });
+    if (rc) return rc;
+    c->virgin = false;
+    hipLaunchKernelGGL(k_sum_leaf_new, dim3(64), dim3(256), 0, c->stream, P.leaf_new, (uint32_t)n_leaves, c->d_ctr);
+    HIPCHK(c, hipGetLastError());
+    uint32_t flags[2];
+    unsigned long long n_spill = 0;
+    HIPCHK(c, hipMemcpy(flags, P.flags, sizeof flags, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&n_spill, P.spill_count, sizeof n_spill, hipMemcpyDeviceToHost));
+    if (flags[1] || n_spill) {
+        // A region overflowed (its leaf was left alone), or records did not fit their buckets: the table goes back to
+        // regions by key hash -- it cannot be enlarged in place, the bins of its keys are not known any more -- and the
+        // records left over are counted window by window.
+        rc = leave_long(c);
+        if (rc) return rc;
+        if (flags[1]) {
+            std::vector<uint32_t> st(n_leaves), cnt(n_leaves * (uint64_t)lseg);
+            HIPCHK(c, hipMemcpy(st.data(), P.leaf_state, n_leaves * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(cnt.data(), lc, cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            uint32_t lo_leaf = 0;
+            while (lo_leaf < n_leaves) {
+                uint64_t allowed, need = 0;
+                uint32_t hi_leaf = lo_leaf;
+                rc = table_reserve(c, 1ull << 26, &allowed);
+                if (rc) return rc;
+                while (hi_leaf < n_leaves) {
+                    uint64_t w = 0;
+                    if (!st[hi_leaf])
+                        for (uint32_t sg = 0; sg < lseg; sg++) w += std::min<uint64_t>(cnt[(uint64_t)hi_leaf * lseg + sg], lcap) * SK_MAX_WINDOWS;
+                    if (hi_leaf > lo_leaf && need + w > allowed) break;
+                    need += w;
+                    hi_leaf++;
+                }
+                if (need > allowed) {
+                    rc = table_reserve(c, need, &allowed);
+                    if (rc) return rc;
+                    if (need > allowed) return fail(c, MC_EOVERFLOW, "internal: a leaf of %llu k-mer occurrences does not fit one launch", (unsigned long long)need);
+                }
+                if (need)
+                    hipLaunchKernelGGL(k_skl_add_unmerged, dim3(std::min<uint32_t>(hi_leaf - lo_leaf, 4096u)), dim3(256), 0, c->stream, lk, lc, lcap, lseg,
+                                       lo_leaf, hi_leaf, P.leaf_state, k, p5k, p5km1, c->view(), thr, c->d_ctr + 6);
+                HIPCHK(c, hipGetLastError());
+                lo_leaf = hi_leaf;
+            }
+        }
+        uint64_t i = 0;
+        while (i < n_spill) {
+            uint64_t allowed;
+            rc = table_reserve(c, (n_spill - i) * SK_MAX_WINDOWS, &allowed);
+            if (rc) return rc;
+            const uint64_t m = std::min<uint64_t>(std::max<uint64_t>(allowed / SK_MAX_WINDOWS, 1), n_spill - i);
+            hipLaunchKernelGGL(k_skl_add_records, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, spill + i, m, k, p5k, p5km1, c->view(), thr, c->d_ctr + 6);
+            HIPCHK(c, hipGetLastError());
+            i += m;
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    c->st.p1_ms += ms1;
+    c->st.p2_ms += ms2;
+    c->st.p3_ms += ms3;
+    c->st.spill_keys += n_spill;
+    c->st.count_ms += ms1 + ms2 + ms3 + ms4;
+    c->st.count_total_ms += ms1 + ms2 + ms3 + ms4;
+    c->st.count_launches++;
+    c->st.windows += wb;
+    return MC_OK;
+}
+
+// the pipeline a batch of reads takes: 32-byte records while the context may and the table allows, else the usual one
+static int add_reads_partitioned_any(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_off, uint64_t r0, uint64_t r1, uint64_t base0,
+                                     uint64_t end_abs, uint64_t wb)
+{
+    if (c->skl_ok && (c->skl_state || c->virgin)) {
+        const int rc = add_reads_partitioned_long(c, d_words, d_off, r0, r1, base0, end_abs, wb);
+        if (rc != 2) return rc;
+    }
+    return add_reads_partitioned(c, d_words, d_off, r0, r1, base0, end_abs, wb);
+}
+
 // A flat stream of keys (+ optional hints) through the partitioned pipeline: the keys a rank owns
 // after the multi-GPU exchange.
 static int add_keys_partitioned(mc_ctx *c, const uint64_t *d_keys, const uint32_t *d_hints, uint64_t n)
 {
     mc_ctx::Pipe &P = c->pipe;
     PipePlan pl;
-    int rc = pipe_prepare(c, n, &pl);
+    int rc = leave_long(c);
+    if (rc) return rc;
+    rc = pipe_prepare(c, n, &pl);
     if (rc) return rc;
     double ms1 = 0;
     rc = timed(c, &ms1, [&] {
@@ -1478,6 +1668,7 @@ static uint64_t max_run_bases(const mc_ctx *c)
 {
     static const uint64_t env = [] { const char *e = getenv("MC_MAX_RUN_BASES"); return e && *e ? strtoull(e, nullptr, 10) : 0ull; }();
     if (env) return std::max<uint64_t>(env, 1u << 20);
+    if (c->skl_ok && (c->skl_state || c->virgin)) return 1ull << 33;  // (32-byte records, ~0.1 per window: 12 bytes of scratch per window)
     return c->mm_k ? (1ull << 34) : (1ull << 31) - (1ull << 24);
 }
 
@@ -1505,7 +1696,7 @@ static int add_reads_impl(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_
             if (r1 > n_reads) r1 = n_reads;
             const uint64_t wb = windows_of(r, r1);
             if (wb) {
-                int rc = add_reads_partitioned(c, d_words, d_off, r, r1, h_off[r], h_off[r1], wb);
+                int rc = add_reads_partitioned_any(c, d_words, d_off, r, r1, h_off[r], h_off[r1], wb);
                 if (rc) return rc;
             }
             r = r1;
@@ -1600,6 +1791,10 @@ int mc_create(const mc_config *cfg, mc_ctx **out)
     if (cfg->key_mode == MC_KEY_PACKED && cfg->k >= SK_MIN_K) c->mm_k = cfg->k;
     if (const char *e = getenv("MC_SUPERKMERS")) if (!strcmp(e, "0")) c->mm_k = 0;
     c->sk_form = c->mm_k != 0;
+    // (an experiment, off unless MC_SK_LONG=1: measured on 10 M reads at k = 63 -- P1 24 + P2 2 + P3 32 ms against 35 ms for the
+    // per-window pipeline, and the bins of a table at load 0.43 overflow, which sends it back to hash regions: DESIGN.md section 7)
+    c->skl_ok = false;
+    if (const char *e = getenv("MC_SK_LONG")) c->skl_ok = !strcmp(e, "1") && cfg->key_mode == MC_KEY_POLY && cfg->k >= 32 && cfg->k <= 63;
     uint64_t want_slots = 1ull << 22;  // 4 M slots = 64 MB to start with
     if (cfg->capacity_hint) {
         // Load factor the hint is turned into.  Hash-prefix tables: 0.7 (regions are probed in LDS, a fuller table
@@ -1849,7 +2044,7 @@ static int add_reads_dev_locked(mc_ctx *c, const uint64_t *d_words, const uint64
     const bool partition = c->count_path == 2 || (c->count_path == 0 && total >= (1ull << 22));
     if (partition && last_off - first_off < max_run_bases(c)) {  // one batch: no need for the offsets on the host
         if (total) {
-            int rc = add_reads_partitioned(c, d_words, d_off, 0, n_reads, first_off, last_off, total);
+            int rc = add_reads_partitioned_any(c, d_words, d_off, 0, n_reads, first_off, last_off, total);
             if (rc) return rc;
         }
         c->finalized = false;
@@ -2260,6 +2455,10 @@ int mc_get_dev(mc_ctx *c, const int64_t *d_keys, uint64_t n, int16_t *d_out)
     if ((!d_keys || !d_out) && n) return fail(c, MC_EINVAL, "mc_get_dev: null pointer");
     if (n == 0) return MC_OK;
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    {
+        int lrc = leave_long(c);
+        if (lrc) return lrc;
+    }
     hipLaunchKernelGGL(k_get, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, d_keys, n, d_out, c->view());
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2819,7 +3018,8 @@ int solid_build(mc_ctx *c, uint64_t n, int min_cov, double *ms, const PairSource
 // Builds (or reuses) the solid table for this threshold.
 int ensure_solid(mc_ctx *c, int min_cov, double *ms)
 {
-    if (c->bfs_direct && !c->solid_external) {  // the walk looks its k-mers up in the counting table: nothing to build
+    if (c->bfs_direct && !c->solid_external && !c->skl_state) {  // the walk looks its k-mers up in the counting table: nothing to build
+        // (not while the table is organised by the minimizers of the bases, count_long.h: the walk then gets a copy of the solid k-mers)
         c->solid_is_table = true;
         c->solid_cov = min_cov;
         return MC_OK;

@@ -51,6 +51,8 @@ if os.environ.get("PROBE_STEPS"):
         print("step", s, "cleared", free(), flush=True)
         ctx.add_reads_packed_dev(d_words, d_off, B, B * L)
         nd = ctx.finalize()
-        print("step", s, "counted %.3f s" % (time.time() - t1), free(), flush=True)
+        st = ctx.stats()
+        print("step", s, "counted %.3f s" % (time.time() - t1), free(), "p1 %.1f p2 %.1f p3 %.1f spill %d grows %d launches %d" % (st.p1_ms, st.p2_ms, st.p3_ms, st.spill_keys, st.grows, st.count_launches), flush=True)
+        ctx.reset_stats()
         res = ctx.bfs_batch([(hi, lo, -1), (hi, lo, 1), (hi, lo, 0)], 3, 100000, -1)
         print("step", s, "bfs done %.3f s" % (time.time() - t1), [len(r["hi"]) if r else 0 for r in res], free(), flush=True)
