@@ -389,8 +389,11 @@ __global__ void __launch_bounds__(PT_THREADS) k_p2_scatter(const uint64_t *__res
                                                            const uint32_t *__restrict__ in_hints, uint64_t seg_cap1,
                                                            const uint32_t *__restrict__ seg_counts1, uint32_t n_buckets1,
                                                            uint32_t np1, uint32_t m2, uint32_t *leaf_counts, uint64_t cap2,
-                                                           uint64_t *out_keys, uint32_t *out_hints, SpillView sp, int mm_k)
+                                                           uint64_t *out_keys, uint32_t *out_hints, SpillView sp, int mm_k,
+                                                           uint32_t piece = 0, uint32_t n_pieces = 1)
 {
+    // piece / n_pieces: a large batch travels in n_pieces pieces that reuse the level-1 buffers one after the other;
+    // every leaf then has n_pieces segments of capacity cap2 and this launch fills segment `piece` (as k_sk2_scatter)
     __shared__ ScatterLds L;
     const uint32_t tid = threadIdx.x;
     const uint32_t n_buckets = m2;  // leaves per level-1 bucket
@@ -435,11 +438,11 @@ __global__ void __launch_bounds__(PT_THREADS) k_p2_scatter(const uint64_t *__res
                     dig[j] = mulhi32(bin32_of(key[j], mm_k), np1 * m2) - bucket * m2;
                 }
             }
-            scatter_tile(L, key, hint, dig, valid, n_buckets, nullptr, cap2, cap2, out_keys, out_hints,
-                         (uint64_t)bucket * n_buckets * cap2, sp);
+            scatter_tile(L, key, hint, dig, valid, n_buckets, nullptr, cap2, (uint64_t)n_pieces * cap2, out_keys, out_hints,
+                         ((uint64_t)bucket * n_buckets * n_pieces + piece) * cap2, sp);
         }
         __syncthreads();
-        if (tid < n_buckets) leaf_counts[(uint64_t)bucket * n_buckets + tid] = min(L.wcur[tid], (uint32_t)cap2);
+        if (tid < n_buckets) leaf_counts[((uint64_t)bucket * n_buckets + tid) * n_pieces + piece] = min(L.wcur[tid], (uint32_t)cap2);
     }
 }
 

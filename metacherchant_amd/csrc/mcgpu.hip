@@ -1078,7 +1078,7 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
         ENSURE(P.spill_recs, P.spill_recs_cap, pl->spill_cap);
     } else {
         { uint64_t cap = P.a_cap; ENSURE(P.a_keys, cap, np1 * nseg1 * pl->cap1); P.a_cap = cap; }
-        { uint64_t cap = P.b_cap; ENSURE(P.b_keys, cap, n_leaves * pl->cap2); P.b_cap = cap; }
+        { uint64_t cap = P.b_cap; ENSURE(P.b_keys, cap, n_leaves * pl->cap2 * pieces); P.b_cap = cap; }
         { uint64_t cap = P.spill_cap; ENSURE(P.spill_keys, cap, pl->spill_cap); dummy = P.spill_cap; ENSURE(P.spill_hints, dummy, pl->spill_cap); P.spill_cap = cap; }
     }
     ENSURE(P.a_hints, P.a_hints_cap, np1 * nseg1 * pl->cap1 * pieces);
@@ -1304,7 +1304,10 @@ static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint6
     // the overlap hides, and the merge pays for the shorter segments.
     uint32_t pieces = 1;
     if (const char *e = getenv("MC_PIPE_PIECES")) pieces = (uint32_t)std::min<unsigned long>(8, std::max<unsigned long>(1, strtoul(e, nullptr, 10)));
-    if (!n_records) pieces = 1;
+    // One key per window (hash keys, short k): a large batch goes through the two scatter levels in pieces of ~2^29 windows
+    // that REUSE the level-1 buffers, one after the other on the same stream, so that a run of twice the windows fits
+    // the same scratch and the whole table is rewritten half as often (max_run_bases).
+    if (!n_records) pieces = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, (wb + (1ull << 28)) >> 29));
     int rc = pipe_prepare(c, wb, &pl, n_records, n_records ? (uint32_t)P1W_SEGMENTS : (uint32_t)PT_SEGMENTS, pieces);
     if (rc) return rc;
     pieces = pl.pieces;
@@ -1315,7 +1318,23 @@ static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint6
     rc = ensure_buf(c, &P.tile_first, &P.tiles1_cap, n_tiles_abs);
     if (rc) return rc;
     double ms1 = 0;
-    if (pieces > 1) {
+    if (pieces > 1 && !pl.sk) {
+        const uint64_t t_first = base0 / tile_size, per = (n_tiles_abs - t_first + pieces - 1) / pieces;
+        rc = timed(c, &ms1, [&] {
+            hipLaunchKernelGGL(k_tile_first_read, dim3((unsigned)((n_tiles_abs + 255) / 256)), dim3(256), 0, c->stream, offs, nr, n_tiles_abs, P.tile_first,
+                               tile_size);
+            for (uint32_t pc = 0; pc < pieces; pc++) {
+                const uint64_t lo_t = t_first + pc * per, hi_t = std::min<uint64_t>(n_tiles_abs, lo_t + per);
+                if (lo_t >= hi_t) continue;
+                launch_p1_reads(c, d_words, offs, nr, pc == 0 ? base0 : lo_t * tile_size, end_abs, hi_t, P.tile_first, pl.b1, P.seg_counts1, pl.cap1,
+                                P.a_keys, P.a_hints, pl.sp, 0, nullptr);
+                hipLaunchKernelGGL(k_p2_scatter, dim3((unsigned)pl.np1), dim3(PT_THREADS), 0, c->stream, P.a_keys, P.a_hints, pl.cap1, P.seg_counts1,
+                                   (uint32_t)pl.np1, pl.b1, pl.b2, P.cursors2, pl.cap2, P.b_keys, P.b_hints, pl.sp, c->mm_k, pc, pieces);
+            }
+        });
+        if (rc) return rc;
+        rc = pipe_finish(c, pl, ms1, true, 0);
+    } else if (pieces > 1) {
         const uint64_t t_first = base0 / tile_size, per = (n_tiles_abs - t_first + pieces - 1) / pieces;
         const uint64_t a_stride = pl.np1 * pl.nseg1 * pl.cap1, c_stride = pl.np1 * pl.nseg1;
         HIPCHK(c, hipEventRecord(c->ev0, c->stream));
@@ -1661,15 +1680,21 @@ static int rs_append(mc_ctx *c, const uint64_t *d_words, uint64_t first_off, uin
 
 // Bases one run of the partitioned pipeline takes.  Positions are 64-bit throughout; what is 32-bit is the index of a
 // record inside the scatter levels' arrays (pipe_prepare checks it): super-k-mer records are ~0.18 per window, so 2^34
-// bases (114 M reads of 150 bp) stay far below 2^32 records, while one 8-byte key per window (k > 31, hash keys) reaches
-// 2^32 x 0.8 at 3.4 G windows and costs 29 bytes of scratch per window -- those runs stay at 2^31 bases.
+// bases (114 M reads of 150 bp) stay far below 2^32 records, while one 8-byte key per window (k > 31, hash keys) costs
+// scratch by the window -- those runs take what half the free memory holds, 2^31 to 2^33 bases.
 // Every run reads and rewrites the whole table, so fewer, larger runs are what a large read set wants.
 static uint64_t max_run_bases(const mc_ctx *c)
 {
     static const uint64_t env = [] { const char *e = getenv("MC_MAX_RUN_BASES"); return e && *e ? strtoull(e, nullptr, 10) : 0ull; }();
     if (env) return std::max<uint64_t>(env, 1u << 20);
     if (c->skl_ok && (c->skl_state || c->virgin)) return 1ull << 33;  // (32-byte records, ~0.1 per window: 12 bytes of scratch per window)
-    return c->mm_k ? (1ull << 34) : (1ull << 31) - (1ull << 24);
+    if (c->mm_k) return 1ull << 34;
+    // a key and a read pointer per window, in pieces (add_reads_partitioned): ~16 bytes of scratch per window.  Half of
+    // what the device has free may go there (the table is allocated already), between 2^31 and 2^33 bases.
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = 0;
+    fr += (c->pipe.a_cap + c->pipe.b_cap) * 12;  // (the scratch of the run before is ours to reuse)
+    return std::min<uint64_t>(1ull << 33, std::max<uint64_t>((1ull << 31) - (1ull << 24), fr / 2 / 16));
 }
 
 // counting with read offsets known on the host
@@ -2051,7 +2076,50 @@ static int add_reads_dev_locked(mc_ctx *c, const uint64_t *d_words, const uint64
         c->solid_cov = -1; c->solid_external = false;
         return MC_OK;
     }
-    // otherwise the launch planner needs the offsets on the host (8 bytes per read, once per call)
+    if (partition) {
+        // several runs: cut at read boundaries found by bisection on the device's offsets (a few 8-byte copies), each
+        // run's windows summed on the device -- the offsets of 100 M reads never travel to the host
+        auto off_at = [&](uint64_t i, uint64_t *v) -> int {
+            HIPCHK(c, hipMemcpyAsync(v, d_off + i, 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            return MC_OK;
+        };
+        uint64_t r = 0, off_r = first_off;
+        while (r < n_reads) {
+            const uint64_t max_bases = max_run_bases(c), target = off_r + max_bases;
+            uint64_t r1 = n_reads, off_r1 = last_off;
+            if (last_off > target) {
+                uint64_t lo = r, hi = n_reads;  // offsets[lo] <= target < offsets[hi]
+                while (hi - lo > 1) {
+                    const uint64_t mid = lo + (hi - lo) / 2;
+                    uint64_t v;
+                    int rc = off_at(mid, &v);
+                    if (rc) return rc;
+                    if (v <= target) lo = mid; else hi = mid;
+                }
+                r1 = lo;
+                int rc = off_at(r1, &off_r1);
+                if (rc) return rc;
+            }
+            if (r1 <= r) return fail(c, MC_EINVAL, "a single read of more than %llu bases is not supported", (unsigned long long)max_bases);
+            HIPCHK(c, hipMemsetAsync(sum, 0, 2 * sizeof(unsigned long long), c->stream));
+            hipLaunchKernelGGL(k_reads_summary, dim3(grid_for(r1 - r, 256)), dim3(256), 0, c->stream, d_off + r, r1 - r, (uint64_t)c->cfg.k, sum);
+            HIPCHK(c, hipGetLastError());
+            unsigned long long wb = 0;
+            HIPCHK(c, hipMemcpyAsync(&wb, sum, sizeof wb, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (wb) {
+                int rc = add_reads_partitioned_any(c, d_words, d_off, r, r1, off_r, off_r1, wb);
+                if (rc) return rc;
+            }
+            r = r1;
+            off_r = off_r1;
+        }
+        c->finalized = false;
+        c->solid_cov = -1; c->solid_external = false;
+        return MC_OK;
+    }
+    // the launch planner of the direct kernel needs the offsets on the host (8 bytes per read, once per call)
     std::vector<uint64_t> h_off(n_reads + 1);
     HIPCHK(c, hipMemcpyAsync(h_off.data(), d_off, (n_reads + 1) * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
