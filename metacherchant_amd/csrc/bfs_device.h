@@ -609,7 +609,7 @@ __device__ __forceinline__ void scout_eval(const SolidView &t, uint64_t *sw, uin
         __builtin_amdgcn_wave_barrier();
         uint32_t hmin = SK_NONE;
         for (uint32_t i = 0; i < w; i++) hmin = min(hmin, mh[lane + i]);
-        s0 = ((((uint64_t)sk_bin(hmin) * t.n_regions) >> 32) << 12) | sk_home(key);
+        s0 = ((((uint64_t)sk_bin(hmin) * t.n_regions) >> 32) << MC_REGION_LG) | sk_home(key);
     } else {
         s0 = solid_slot_of(t, key);
     }

@@ -33,7 +33,7 @@ constexpr int PT_MAX_BUCKETS = 512;                 // fan-out of one scatter le
 constexpr int PT_MAX_LEAVES2 = 1024;                // ... of the second level of the super-k-mer pipeline (k_sk2_scatter: an LDS cursor per leaf)
 constexpr int SK_LEAVES_LG = 19;                    // so up to 512 x 1024 leaves of one region each (8.6 G slots of 16 bytes = 34 GB of table)
 constexpr int P3_THREADS = 512;
-constexpr uint32_t REGION_SLOTS = 4096;             // == 1 << mc_ctx::sb
+constexpr uint32_t REGION_SLOTS = 1u << MC_REGION_LG;  // == 1 << mc_ctx::sb (4096: a 64 KB image in LDS)
 constexpr uint32_t CURSOR1_STRIDE = 32;             // owner cursors of the multi-GPU split sit on separate 128-byte lines
 constexpr int PT_SEGMENTS = 256;                    // workgroups of P1 (one per CU) = segments of every level-1 bucket
 
@@ -1024,8 +1024,11 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                                                          uint32_t nseg, uint32_t n_leaves, uint32_t g, TableView t, int virgin,
                                                          uint32_t *leaf_state, uint32_t *leaf_new, uint32_t *any_failed,
                                                          uint32_t solid_thr, unsigned long long *n_solid, int k, P3Emit emit,
-                                                         uint32_t ptr_tries)
+                                                         uint32_t ptr_tries, const uint32_t *lost = nullptr)
 {
+    // lost: the scatter levels' "records lost" flag -- the host enqueues this kernel behind them without looking; with
+    // the flag set nothing may be merged (the batch is counted another way)
+    if (lost && *lost) return;
     __shared__ MergeLds L;
     const uint32_t tid = threadIdx.x;
     const bool emitting = emit.recs != nullptr && solid_thr != 0;
@@ -1208,7 +1211,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                         const uint64_t key = kk[u];
                         if (key == EMPTY_KEY) continue;
                         const uint64_t gslot = slot_of(t, key);
-                        if (g && (gslot >> 12) != region) continue;
+                        if (g && (gslot >> MC_REGION_LG) != region) continue;
                         const bool done = lds_region_add(L, key, hh[u], (uint32_t)gslot & (REGION_SLOTS - 1), my_new,
                                                          ptr_pick(key, solid_thr >= 2 ? 1u : 0u, solid_thr), ptr_pick_late(key, solid_thr >= 2 ? 1u : 0u));
                         if (!done) atomicExch(&L.overflow, 1u);

@@ -318,11 +318,14 @@ struct TableView {
 
 // home slot inside a minimizer-bin region: 12 well-mixed bits of the key, cheaper than fmix64 (the
 // merge kernel of the counting pipeline computes it once per k-mer occurrence)
+#ifndef MC_REGION_LG
+#define MC_REGION_LG 12   // log2 of the slots of a table region = of the merge kernel's LDS image (tuning builds override it)
+#endif
 __host__ __device__ __forceinline__ uint32_t sk_home(uint64_t key)
 {
     uint32_t x = (uint32_t)key * 0x9E3779B1u + (uint32_t)(key >> 32) * 0x85EBCA6Bu;
     x ^= x >> 15; x *= 0xC2B2AE35u;
-    return x >> 20;
+    return x >> (32 - MC_REGION_LG);
 }
 
 // 32 bits whose TOP bits number the region of a key (and, in the counting pipeline, its buckets)
@@ -335,7 +338,7 @@ __host__ __device__ __forceinline__ uint64_t slot_of(const TableView &t, uint64_
 {
     if (t.mm_k == 0) return fmix64(key) >> t.shift;
     const uint64_t region = ((uint64_t)sk_bin(sk_hmin_of_kmer(key, t.mm_k)) * t.n_regions) >> 32;
-    return (region << 12) | sk_home(key);  // (regions are 4096 slots: count_pipeline.h REGION_SLOTS)
+    return (region << MC_REGION_LG) | sk_home(key);  // (count_pipeline.h REGION_SLOTS)
 }
 
 // addAndBound(key, inc) with the saturation deferred to read time (count is 32-bit here; a
@@ -430,7 +433,7 @@ __device__ __forceinline__ uint64_t solid_slot_of(const SolidView &t, uint64_t k
 {
     if (t.mm_k == 0) return fmix64(key) >> t.shift;
     const uint64_t region = ((uint64_t)sk_bin(sk_hmin_of_kmer(key, t.mm_k)) * t.n_regions) >> 32;
-    return (region << 12) | sk_home(key);
+    return (region << MC_REGION_LG) | sk_home(key);
 }
 
 // count (saturated) or -1; *aux (may be null) = the slot's read pointer

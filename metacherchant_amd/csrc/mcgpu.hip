@@ -128,6 +128,7 @@ struct mc_ctx {
     // the second scatter level of one piece of a batch runs here, next to the first level of the next piece (add_reads_partitioned)
     hipStream_t pipe_stream = nullptr;
     hipEvent_t ev_piece[8] = {}, ev_p2 = nullptr;
+    hipEvent_t ev_t[4] = {};  // P1 start, P1 end, P2 end, P3 end of a pipeline run enqueued without a host round trip in between
     // The read store: the packed bases of every read this context was given since the last mc_clear, batch after
     // batch (each starting on a word boundary).  Table slots point into it (kmer_device.h ptr_encode) and the BFS
     // reads its look-ahead from it.  rs_from: a BFS-only context (mc_solid_from_pairs_dev) borrows the store of the
@@ -147,7 +148,7 @@ struct mc_ctx {
     // table
     Slot *slots = nullptr;
     uint64_t n_regions = 0;    // regions of 2^sb slots: a power of two, or (minimizer-bin tables of >= 512 regions) any multiple of 512
-    uint32_t rb = 0, sb = 12;  // rb = log2(n_regions) when that is a power of two (else its floor)
+    uint32_t rb = 0, sb = MC_REGION_LG;  // rb = log2(n_regions) when that is a power of two (else its floor)
     unsigned long long *d_ctr = nullptr;  // [0] n_used, [1] empty_cnt, [2] scratch counter, [3] solid n_used, [4..5] read summary, [6] keys with count >= cov_hint
     uint32_t *d_fatal = nullptr;
     uint64_t n_used_host = 0;
@@ -377,7 +378,7 @@ __global__ void __launch_bounds__(512) k_build_solid_regions(const Slot *__restr
     __shared__ uint32_t overflow;
     const uint32_t tid = threadIdx.x;
     const uint32_t q = solid_lg - SOLID_SB;  // log2(#solid regions)
-    const uint32_t rb = main_lg - 12;        // log2(#counting regions)
+    const uint32_t rb = main_lg - MC_REGION_LG;  // log2(#counting regions)
     const uint64_t n_regions = 1ull << q;
     for (uint64_t Q = blockIdx.x; Q < n_regions; Q += gridDim.x) {
         for (uint32_t i = tid; i < SOLID_REGION; i += 512) {
@@ -387,8 +388,8 @@ __global__ void __launch_bounds__(512) k_build_solid_regions(const Slot *__restr
         __syncthreads();
         // counting-table slots to scan
         uint64_t first, count;
-        if (q <= rb) { first = (Q << (rb - q)) << 12; count = 1ull << (rb - q + 12); }
-        else { first = (Q >> (q - rb)) << 12; count = 4096; }
+        if (q <= rb) { first = (Q << (rb - q)) << MC_REGION_LG; count = 1ull << (rb - q + MC_REGION_LG); }
+        else { first = (Q >> (q - rb)) << MC_REGION_LG; count = 1u << MC_REGION_LG; }
         for (uint64_t i0 = tid; i0 < count; i0 += 4 * 512) {
             uint4 raws[4];
 #pragma unroll
@@ -1103,30 +1104,15 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
 // P2, P3 (with the retry after growing the table), spill drain and bookkeeping; ms1 = time of the
 // level-1 scatter that filled the a_* buckets.  Returns 1 (nothing merged yet) when the streams
 // overflowed even their spill list: the caller then counts the batch with the direct kernel.
-static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false, double ms2_exposed = 0)
+static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false, double ms2_exposed = 0, bool p1_pending = false)
 {   // p2_done: the caller ran P2 itself, piece by piece next to P1 (ms2_exposed = what of it outlasted P1)
+    // p1_pending: the caller recorded ev_t[0], enqueued P1 and did not wait: P2 and P3 follow on the stream at once and
+    // the host hears of all three together (a host round trip between two kernels leaves the device idle for tens of us)
     mc_ctx::Pipe &P = c->pipe;
     const uint64_t np1 = pl.np1, n_leaves = pl.n_leaves;
     const int k = c->cfg.k;
     int rc;
     double ms2 = ms2_exposed, ms3 = 0;
-    if (pl.b2 > 1 && !p2_done) {
-        rc = timed(c, &ms2, [&] {
-            if (pl.sk)
-                hipLaunchKernelGGL(k_sk2_scatter, dim3((unsigned)np1), dim3(PT_THREADS), 0, c->stream, P.a_recs, P.a_hints, pl.cap1,
-                                   P.seg_counts1, (uint32_t)np1, pl.b1, pl.b2, P.cursors2, pl.cap2, P.b_recs, P.b_hints, pl.sks, pl.nseg1);
-            else
-                hipLaunchKernelGGL(k_p2_scatter, dim3((unsigned)np1), dim3(PT_THREADS), 0, c->stream, P.a_keys, P.a_hints, pl.cap1,
-                                   P.seg_counts1, (uint32_t)np1, pl.b1, pl.b2, P.cursors2, pl.cap2, P.b_keys, P.b_hints, pl.sp, c->mm_k);
-        });
-        if (rc) return rc;
-    }
-    {   // the capacities are estimates (and a few heavy keys can fill a bucket's spill list alone): check before
-        // anything is merged, so that the caller can still count the batch another way
-        uint32_t lost = 0;
-        HIPCHK(c, hipMemcpy(&lost, P.flags, sizeof lost, hipMemcpyDeviceToHost));
-        if (lost) return 1;
-    }
     // P3 reads the leaves: P2's output (one segment each), or P1's buckets directly when there is no second level
     const void *lk = pl.sk ? (pl.b2 > 1 ? (const void *)P.b_recs : (const void *)P.a_recs)
                            : (pl.b2 > 1 ? (const void *)P.b_keys : (const void *)P.a_keys);
@@ -1146,21 +1132,52 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
         emit.counts = P.emit_counts;
         emit.seg_cap = std::min<uint64_t>(P.a_recs_cap / (uint64_t)p3_grid, 0xFFFFFFF0ull);
     }
-    // P3, retried with a larger table when a region overflows
-    for (int attempt = 0;; attempt++) {
+    auto launch_p3 = [&] {
         const int virgin = c->virgin ? 1 : 0;
-        rc = timed(c, &ms3, [&] {
-            const int grid = p3_grid;
 #define P3_ARGS lk, lh, lc, lcap, lseg, (uint32_t)n_leaves, pl.g, c->view(), virgin, P.leaf_state, P.leaf_new, P.flags + 1, \
-                (uint32_t)(c->solid_tracked ? c->cov_hint : 0), c->d_ctr + 6, k, emit, c->ptr_tries
-            if (pl.sk) hipLaunchKernelGGL(k_p3_merge<true>, dim3(grid), dim3(P3_THREADS), 0, c->stream, P3_ARGS);
-            else hipLaunchKernelGGL(k_p3_merge<false>, dim3(grid), dim3(P3_THREADS), 0, c->stream, P3_ARGS);
+                (uint32_t)(c->solid_tracked ? c->cov_hint : 0), c->d_ctr + 6, k, emit, c->ptr_tries, P.flags
+        if (pl.sk) hipLaunchKernelGGL(k_p3_merge<true>, dim3(p3_grid), dim3(P3_THREADS), 0, c->stream, P3_ARGS);
+        else hipLaunchKernelGGL(k_p3_merge<false>, dim3(p3_grid), dim3(P3_THREADS), 0, c->stream, P3_ARGS);
 #undef P3_ARGS
-        });
-        if (rc) return rc;
+    };
+    uint32_t flags[3] = {0, 0, 0};
+    unsigned long long n_spill = 0;
+    {   // P2 and the first P3 back to back.  The capacities of the streams are estimates (and a few heavy keys can fill
+        // a bucket's spill list alone): P3 looks at the "records lost" flag itself and merges nothing when it is set, so
+        // that the caller can still count the batch another way.
+        HIPCHK(c, hipEventRecord(c->ev_t[1], c->stream));
+        if (pl.b2 > 1 && !p2_done) {
+            if (pl.sk)
+                hipLaunchKernelGGL(k_sk2_scatter, dim3((unsigned)np1), dim3(PT_THREADS), 0, c->stream, P.a_recs, P.a_hints, pl.cap1,
+                                   P.seg_counts1, (uint32_t)np1, pl.b1, pl.b2, P.cursors2, pl.cap2, P.b_recs, P.b_hints, pl.sks, pl.nseg1);
+            else
+                hipLaunchKernelGGL(k_p2_scatter, dim3((unsigned)np1), dim3(PT_THREADS), 0, c->stream, P.a_keys, P.a_hints, pl.cap1,
+                                   P.seg_counts1, (uint32_t)np1, pl.b1, pl.b2, P.cursors2, pl.cap2, P.b_keys, P.b_hints, pl.sp, c->mm_k);
+            HIPCHK(c, hipGetLastError());
+        }
+        HIPCHK(c, hipEventRecord(c->ev_t[2], c->stream));
+        launch_p3();
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipEventRecord(c->ev_t[3], c->stream));
+        HIPCHK(c, hipMemcpyAsync(flags, P.flags, sizeof flags, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&n_spill, P.spill_count, sizeof n_spill, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        float f = 0;
+        if (p1_pending) { HIPCHK(c, hipEventElapsedTime(&f, c->ev_t[0], c->ev_t[1])); ms1 = f; }
+        if (pl.b2 > 1 && !p2_done) { HIPCHK(c, hipEventElapsedTime(&f, c->ev_t[1], c->ev_t[2])); ms2 += f; }
+        if (flags[0]) return 1;  // (nothing was merged)
+        HIPCHK(c, hipEventElapsedTime(&f, c->ev_t[2], c->ev_t[3]));
+        ms3 += f;
         c->virgin = false;
-        uint32_t flags[3];
-        HIPCHK(c, hipMemcpy(flags, P.flags, sizeof flags, hipMemcpyDeviceToHost));
+    }
+    // P3 again, with a larger table, while a region overflows
+    for (int attempt = 0;; attempt++) {
+        if (attempt > 0) {
+            rc = timed(c, &ms3, [&] { launch_p3(); });
+            if (rc) return rc;
+            c->virgin = false;
+            HIPCHK(c, hipMemcpy(flags, P.flags, sizeof flags, hipMemcpyDeviceToHost));
+        }
         if (flags[0]) return fail(c, MC_EOVERFLOW, "internal: spill list of the partitioned counting pipeline overflowed");
         if (flags[2]) emit.recs = nullptr;  // a segment of the solid list overflowed: the BFS set-up sweeps the table instead
         if (!flags[1]) break;
@@ -1212,9 +1229,7 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
     }
     hipLaunchKernelGGL(k_sum_leaf_new, dim3(64), dim3(256), 0, c->stream, P.leaf_new, (uint32_t)n_leaves, c->d_ctr);
     HIPCHK(c, hipGetLastError());
-    // what did not fit its bucket goes through the direct kernel
-    unsigned long long n_spill = 0;
-    HIPCHK(c, hipMemcpy(&n_spill, P.spill_count, sizeof n_spill, hipMemcpyDeviceToHost));
+    // what did not fit its bucket goes through the direct kernel (n_spill: read with the flags above)
     double ms4 = 0;
     if (n_spill) {
         const uint32_t thr = (uint32_t)(c->solid_tracked ? c->cov_hint : 0);
@@ -1365,18 +1380,17 @@ static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint6
         ms1 = f1;
         rc = pipe_finish(c, pl, ms1, true, f2 > 0 ? f2 : 0);
     } else {
-        rc = timed(c, &ms1, [&] {
-            hipLaunchKernelGGL(k_tile_first_read, dim3((unsigned)((n_tiles_abs + 255) / 256)), dim3(256), 0, c->stream, offs, nr,
-                               n_tiles_abs, P.tile_first, tile_size);
-            if (pl.sk)
-                hipLaunchKernelGGL(k_sk1w_extract<false>, dim3(P1W_SEGMENTS), dim3(P1W_THREADS), 0, c->stream, d_words, offs, nr, base0, end_abs,
-                                   n_tiles_abs, P.tile_first, c->cfg.k, pl.b1, P.seg_counts1, pl.cap1, P.a_recs, P.a_hints, pl.sks, c->cur_ptr_base);
-            else
-                launch_p1_reads(c, d_words, offs, nr, base0, end_abs, n_tiles_abs, P.tile_first, pl.b1, P.seg_counts1, pl.cap1, P.a_keys,
-                                P.a_hints, pl.sp, 0, nullptr);
-        });
-        if (rc) return rc;
-        rc = pipe_finish(c, pl, ms1);
+        HIPCHK(c, hipEventRecord(c->ev_t[0], c->stream));  // (no wait here: pipe_finish enqueues P2 and P3 right behind)
+        hipLaunchKernelGGL(k_tile_first_read, dim3((unsigned)((n_tiles_abs + 255) / 256)), dim3(256), 0, c->stream, offs, nr,
+                           n_tiles_abs, P.tile_first, tile_size);
+        if (pl.sk)
+            hipLaunchKernelGGL(k_sk1w_extract<false>, dim3(P1W_SEGMENTS), dim3(P1W_THREADS), 0, c->stream, d_words, offs, nr, base0, end_abs,
+                               n_tiles_abs, P.tile_first, c->cfg.k, pl.b1, P.seg_counts1, pl.cap1, P.a_recs, P.a_hints, pl.sks, c->cur_ptr_base);
+        else
+            launch_p1_reads(c, d_words, offs, nr, base0, end_abs, n_tiles_abs, P.tile_first, pl.b1, P.seg_counts1, pl.cap1, P.a_keys,
+                            P.a_hints, pl.sp, 0, nullptr);
+        HIPCHK(c, hipGetLastError());
+        rc = pipe_finish(c, pl, ms1, false, 0, true);
     }
     if (rc != 1) return rc;
     // (super-k-mer streams overflowed: unusually short runs) count this batch with the direct kernel instead
@@ -1802,6 +1816,7 @@ int mc_create(const mc_config *cfg, mc_ctx **out)
     CREATE_CHK(hipStreamCreateWithFlags(&c->pipe_stream, hipStreamNonBlocking));
     for (auto &e : c->ev_piece) CREATE_CHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     CREATE_CHK(hipEventCreate(&c->ev_p2));
+    for (auto &e : c->ev_t) CREATE_CHK(hipEventCreate(&e));
     CREATE_CHK(hipMalloc(reinterpret_cast<void **>(&c->d_ctr), 8 * sizeof(unsigned long long)));
     CREATE_CHK(hipMalloc(reinterpret_cast<void **>(&c->d_fatal), sizeof(uint32_t)));
     CREATE_CHK(hipMalloc(reinterpret_cast<void **>(&c->d_ovf), mc_ctx::OVF_CAP * sizeof(uint4)));
@@ -1862,6 +1877,7 @@ void mc_destroy(mc_ctx *c)
     if (c->rs_words) (void)hipFree(c->rs_words);
     for (auto &e : c->ev_piece) if (e) (void)hipEventDestroy(e);
     if (c->ev_p2) (void)hipEventDestroy(c->ev_p2);
+    for (auto &e : c->ev_t) if (e) (void)hipEventDestroy(e);
     if (c->pipe_stream) { (void)hipStreamSynchronize(c->pipe_stream); (void)hipStreamDestroy(c->pipe_stream); }
     c->tok_pool.release();
     for (char *p : c->pin) if (p) (void)hipHostFree(p);
