@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
+    ap.add_argument("--reads", type=int, default=None, help="reads per GPU (default: 10 M; --config 2: 100 M)")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--contigs", type=int, default=10)
@@ -82,7 +82,8 @@ def main():
         if args.k == 31: args.k = 63
         if args.contigs == 10: args.contigs = 100
         if args.coverage == 5: args.coverage = 3
-        if args.reads == 10_000_000: args.reads = 100_000_000
+        if args.reads is None: args.reads = 100_000_000
+    if args.reads is None: args.reads = 10_000_000
     if args.total_reads:
         args.reads = args.total_reads // world
     bothdirs = args.config == 2
