@@ -906,6 +906,130 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk2_scatter(const uint4 *__restr
     }
 }
 
+// SK-P2 with the tile's records put in leaf order in LDS before they go out: a tile of 1024 x ITEMS records holds only
+// a handful per leaf, and written one by one as they come (k_sk2_scatter) every 16-byte record and 4-byte pointer
+// dirties a memory line of its own at a time of its own -- 7.0 GB reached HBM for 2.7 GB of records.  Here the records
+// of one leaf leave together, from consecutive lanes to consecutive addresses, and the next tile continues where this
+// one stopped.  Counting pipeline only (records + read pointers; digits from the record's bin word).
+#ifndef MC_SK2_ITEMS
+#define MC_SK2_ITEMS 4   // records per thread and tile: 4096-record tiles, 104 KB of LDS, one workgroup per CU (2: 2.6 ms, 4: 2.3, 5: 2.3, 6: 2.5; unstaged 2.9-3.0)
+#endif
+template <int ITEMS>
+struct Sk2sLds {
+    uint4 rec[PT_THREADS * ITEMS];
+    uint32_t ptr[PT_THREADS * ITEMS];
+    uint16_t leaf[PT_THREADS * ITEMS];
+    uint32_t cnt[PT_MAX_LEAVES2], wcur[PT_MAX_LEAVES2], off[PT_MAX_LEAVES2];
+    uint32_t seg_prefix[P1W_SEGMENTS + 1];
+    uint32_t wave_tot[PT_THREADS / 64];
+    uint32_t tile_seg;
+};
+template <int ITEMS>
+__global__ void __launch_bounds__(PT_THREADS) k_sk2_scatter_staged(const uint4 *__restrict__ in_recs, const uint32_t *__restrict__ in_ptrs,
+                                                                   uint64_t seg_cap1, const uint32_t *__restrict__ seg_counts1,
+                                                                   uint32_t n_buckets1, uint32_t np1, uint32_t m2, uint32_t *leaf_counts,
+                                                                   uint64_t cap2, uint4 *out_recs, uint32_t *out_ptrs, SkSpill sp, uint32_t nseg_in)
+{
+    __shared__ Sk2sLds<ITEMS> L;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    constexpr uint32_t TILE = PT_THREADS * ITEMS;
+    auto block_excl = [&](uint32_t c, uint32_t *total) -> uint32_t {  // exclusive scan of one value per thread
+        uint32_t x = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o);
+            if ((int)lane >= o) x += y;
+        }
+        __syncthreads();  // (wave_tot may still be read from the scan before)
+        if (lane == 63u) L.wave_tot[wv] = x;
+        __syncthreads();
+        uint32_t before = 0, tot = 0;
+        for (uint32_t i = 0; i < PT_THREADS / 64; i++) {
+            const uint32_t t = L.wave_tot[i];
+            if (i < wv) before += t;
+            tot += t;
+        }
+        *total = tot;
+        return before + x - c;
+    };
+    for (uint32_t bucket = blockIdx.x; bucket < n_buckets1; bucket += gridDim.x) {
+        __syncthreads();
+        if (tid < PT_MAX_LEAVES2) { L.wcur[tid] = 0; L.cnt[tid] = 0; }
+        uint32_t total;
+        {
+            const uint32_t c = tid < nseg_in ? seg_counts1[(uint64_t)bucket * nseg_in + tid] : 0u;
+            const uint32_t ex = block_excl(c, &total);
+            if (tid < nseg_in) L.seg_prefix[tid] = ex;
+            if (tid == 0) L.seg_prefix[nseg_in] = total;
+        }
+        __syncthreads();
+        for (uint32_t first = 0; first < total; first += TILE) {
+            if (tid == 0) {  // segment of the tile's first record: largest sg with seg_prefix[sg] <= first
+                uint32_t lo_s = 0, hi_s = nseg_in;
+                while (hi_s - lo_s > 1) {
+                    const uint32_t mid = (lo_s + hi_s) >> 1;
+                    if (L.seg_prefix[mid] <= first) lo_s = mid; else hi_s = mid;
+                }
+                L.tile_seg = lo_s;
+            }
+            __syncthreads();
+            uint4 rec[ITEMS];
+            uint32_t ptr[ITEMS], d[ITEMS], rank[ITEMS];
+            bool have[ITEMS];
+            uint32_t sg = L.tile_seg;
+#pragma unroll
+            for (int j = 0; j < ITEMS; j++) {
+                const uint32_t e = first + (uint32_t)j * PT_THREADS + tid;
+                have[j] = e < total;
+                if (have[j]) {
+                    while (e >= L.seg_prefix[sg + 1]) sg++;
+                    const uint64_t at = ((uint64_t)bucket * nseg_in + sg) * seg_cap1 + (e - L.seg_prefix[sg]);
+                    rec[j] = in_recs[at];
+                    ptr[j] = in_ptrs[at];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < ITEMS; j++)
+                if (have[j]) {
+                    d[j] = mulhi32(rec[j].x, np1 * m2) - bucket * m2;
+                    rank[j] = atomicAdd(&L.cnt[d[j]], 1u);
+                }
+            __syncthreads();
+            {   // where each leaf's run starts in the staging area
+                uint32_t tot;
+                const uint32_t ex = block_excl(tid < m2 ? L.cnt[tid] : 0u, &tot);
+                if (tid < m2) L.off[tid] = ex;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < ITEMS; j++)
+                if (have[j]) {
+                    const uint32_t at = L.off[d[j]] + rank[j];
+                    L.rec[at] = rec[j];
+                    L.ptr[at] = ptr[j];
+                    L.leaf[at] = (uint16_t)d[j];
+                }
+            __syncthreads();
+            const uint32_t n_tile = min(TILE, total - first);
+            for (uint32_t i = tid; i < n_tile; i += PT_THREADS) {
+                const uint32_t dd = L.leaf[i];
+                const uint64_t dst = (uint64_t)L.wcur[dd] + (i - L.off[dd]);
+                if (dst < cap2) {
+                    const uint64_t at = ((uint64_t)bucket * m2 + dd) * cap2 + dst;
+                    out_recs[at] = L.rec[i];
+                    out_ptrs[at] = L.ptr[i];
+                } else {
+                    sk_spill_push(sp, L.rec[i]);
+                }
+            }
+            __syncthreads();
+            if (tid < m2) { L.wcur[tid] += L.cnt[tid]; L.cnt[tid] = 0; }
+        }
+        __syncthreads();
+        if (tid < m2) leaf_counts[(uint64_t)bucket * m2 + tid] = min(L.wcur[tid], (uint32_t)cap2);
+    }
+}
+
 // drains the record spill list through the direct path (solid_thr / n_solid as in k_p3_merge)
 __global__ void k_sk_add_records(const uint4 *__restrict__ recs, const uint32_t *__restrict__ ptrs, uint64_t n, int k, TableView t,
                                  uint32_t solid_thr, unsigned long long *n_solid)

@@ -1147,7 +1147,11 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
         // that the caller can still count the batch another way.
         HIPCHK(c, hipEventRecord(c->ev_t[1], c->stream));
         if (pl.b2 > 1 && !p2_done) {
-            if (pl.sk)
+            static const bool staged = [] { const char *e = getenv("MC_SK2_STAGED"); return !(e && !strcmp(e, "0")); }();
+            if (pl.sk && staged && pl.pieces == 1)
+                hipLaunchKernelGGL(k_sk2_scatter_staged<MC_SK2_ITEMS>, dim3((unsigned)np1), dim3(PT_THREADS), 0, c->stream, P.a_recs, P.a_hints, pl.cap1,
+                                   P.seg_counts1, (uint32_t)np1, pl.b1, pl.b2, P.cursors2, pl.cap2, P.b_recs, P.b_hints, pl.sks, pl.nseg1);
+            else if (pl.sk)
                 hipLaunchKernelGGL(k_sk2_scatter, dim3((unsigned)np1), dim3(PT_THREADS), 0, c->stream, P.a_recs, P.a_hints, pl.cap1,
                                    P.seg_counts1, (uint32_t)np1, pl.b1, pl.b2, P.cursors2, pl.cap2, P.b_recs, P.b_hints, pl.sks, pl.nseg1);
             else
