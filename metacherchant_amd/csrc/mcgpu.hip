@@ -178,6 +178,8 @@ struct mc_ctx {
     char *pin[16] = {};                // pinned staging buffers of h2d_fast, made on first use
     DevPool tok_pool;                  // scratch of the device tokeniser
     bool rs_copy_pending = false;      // a batch is on its way into the read store on pipe_stream (rs_append)
+    void *d_bfs_states = nullptr;      // BfsState[d_bfs_states_cap] of mc_bfs_batch
+    uint32_t d_bfs_states_cap = 0;
     std::mutex pin_mu;                 // the pinned buffers serve one copy at a time
     hipStream_t pin_stream[8] = {};
     int mm_k = 0;        // != 0 (= k): regions are minimizer bins and reads are counted as super-k-mers (kmer_device.h)
@@ -1894,6 +1896,7 @@ void mc_destroy(mc_ctx *c)
     for (auto &e : c->ev_t) if (e) (void)hipEventDestroy(e);
     if (c->pipe_stream) { (void)hipStreamSynchronize(c->pipe_stream); (void)hipStreamDestroy(c->pipe_stream); }
     c->tok_pool.release();
+    if (c->d_bfs_states) (void)hipFree(c->d_bfs_states);
     for (char *p : c->pin) if (p) (void)hipHostFree(p);
     for (hipStream_t st : c->pin_stream) if (st) (void)hipStreamDestroy(st);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -3346,8 +3349,15 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
         S.n_seeds = ns;
         S.dir = jobs[j].dir;
     }
-    DevBuf<BfsState> d_states;
-    HIPCHK(c, d_states.alloc(n_jobs));
+    struct { BfsState *p; } d_states{nullptr};  // (kept in the context: an allocation and a release per call cost more than the launch)
+    if (c->d_bfs_states_cap < n_jobs) {
+        if (c->d_bfs_states) (void)hipFree(c->d_bfs_states);
+        c->d_bfs_states = nullptr;
+        c->d_bfs_states_cap = 0;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_bfs_states), std::max<uint32_t>(n_jobs, 8) * sizeof(BfsState)));
+        c->d_bfs_states_cap = std::max<uint32_t>(n_jobs, 8);
+    }
+    d_states.p = static_cast<BfsState *>(c->d_bfs_states);
     std::vector<BfsState> h_states(n_jobs);
     std::vector<BfsCtl> ctl(n_jobs);
     const unsigned long long max_rounds = 1ull << 17;  // bounds one launch; unfinished jobs are relaunched

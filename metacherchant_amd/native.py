@@ -35,6 +35,21 @@ class _BfsJob(C.Structure):
                 ("dir", C.c_int32)]
 
 
+class _ResultOwner:
+    """Keeps one mc_bfs_result alive for the numpy views of its arrays; frees it with the last of them."""
+
+    def __init__(self, lib, res):
+        self._lib = lib
+        self._res = _BfsResult()
+        C.memmove(C.byref(self._res), C.byref(res), C.sizeof(_BfsResult))
+
+    def __del__(self):
+        try:
+            self._lib.mc_bfs_result_free(C.byref(self._res))
+        except Exception:  # (interpreter shutdown)
+            pass
+
+
 class Stats(C.Structure):
     _fields_ = [("windows", C.c_uint64), ("count_launches", C.c_uint64), ("count_ms", C.c_double),
                 ("count_total_ms", C.c_double), ("table_slots", C.c_uint64), ("table_bytes", C.c_uint64),
@@ -259,13 +274,18 @@ class Context:
                 out.append(None)
                 continue
 
-            def arr(ptr, dt):
-                return np.ctypeslib.as_array(ptr, shape=(m,)).astype(dt, copy=True)
+            # the arrays are views of the library's (page-locked) result memory, which goes back to the library when the
+            # last of them is collected: no second copy of 10^5 vertices per pass
+            owner = _ResultOwner(self._L, r)
 
-            out.append(dict(hi=arr(r.hi, np.uint64), lo=arr(r.lo, np.uint64), dist=arr(r.dist, np.int32),
-                            cov=arr(r.cov, np.int16), last=arr(r.last, np.uint8), levels=int(r.levels),
+            def arr(ptr, ctype, dt):
+                buf = (ctype * m).from_address(C.addressof(ptr.contents))
+                buf._owner = owner  # (the numpy array keeps `buf` alive as its base)
+                return np.frombuffer(buf, dtype=dt)
+
+            out.append(dict(hi=arr(r.hi, C.c_uint64, np.uint64), lo=arr(r.lo, C.c_uint64, np.uint64), dist=arr(r.dist, C.c_int32, np.int32),
+                            cov=arr(r.cov, C.c_int16, np.int16), last=arr(r.last, C.c_uint8, np.uint8), levels=int(r.levels),
                             lookups=int(r.lookups), rounds=int(r.rounds), device_ms=float(r.device_ms)))
-            self._L.mc_bfs_result_free(C.byref(r))
         return out
 
     def bfs(self, seed_hi, seed_lo, direction, min_cov, max_kmers=-1, max_radius=-1):
