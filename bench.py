@@ -35,11 +35,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=None, help="reads per GPU (default: 10 M; --config 2: 100 M)")
     ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--k", type=int, default=31)
-    ap.add_argument("--contigs", type=int, default=10)
+    ap.add_argument("--k", type=int, default=None, help="default 31; --config 2: 63")
+    ap.add_argument("--contigs", type=int, default=None, help="default 10; --config 2: 100")
     ap.add_argument("--contig-len", type=int, default=5_000_000)
     ap.add_argument("--err", type=int, default=100, help="substitution errors per 10000 bases (E1=100, E0=0)")
-    ap.add_argument("--coverage", type=int, default=5)
+    ap.add_argument("--coverage", type=int, default=None, help="default 5; --config 2: 3")
     ap.add_argument("--maxkmers", type=int, default=100000)
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -79,10 +79,13 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     if args.config == 2:  # BASELINE.json configs[2]
-        if args.k == 31: args.k = 63
-        if args.contigs == 10: args.contigs = 100
-        if args.coverage == 5: args.coverage = 3
+        if args.k is None: args.k = 63
+        if args.contigs is None: args.contigs = 100
+        if args.coverage is None: args.coverage = 3
         if args.reads is None: args.reads = 100_000_000
+    if args.k is None: args.k = 31
+    if args.contigs is None: args.contigs = 10
+    if args.coverage is None: args.coverage = 5
     if args.reads is None: args.reads = 10_000_000
     if args.total_reads:
         args.reads = args.total_reads // world
