@@ -53,6 +53,7 @@ struct ScatterLds {
     uint32_t starts[(PT_TILE + 256) / 32 + 2];  // P1: bit per base position = "a read starts here"
     uint32_t wave_tot[PT_THREADS / 64];
     uint32_t n_valid, tile_seg;
+    uint16_t polyF[256], polyR[256];             // P1, polynomial keys: kmer_device.h poly_hashes_tabled
     unsigned long long dbg[4];
 };
 
@@ -234,6 +235,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_p1_extract_scatter(
     const uint32_t tid = threadIdx.x;
     const uint32_t n_buckets = np1;  // (owner ranks, or level-1 buckets)
     if (tid < PT_MAX_BUCKETS) L.wcur[tid] = 0;  // (counting pipeline: gridDim.x == PT_SEGMENTS, segment = blockIdx.x)
+    if (MODE == KEY_POLY && tid < 256) poly_tables_fill(L.polyF, L.polyR, tid);  // (published by the first tile's barriers)
 #ifdef MC_P1_TIMING
     if (tid < 4) L.dbg[tid] = 0;
     unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tl = 0;
@@ -279,11 +281,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_p1_extract_scatter(
             // of 64-bit integers (and 5^k + sum (3 - b_i) 5^i for the other strand), so sliding the window by one
             // base is a handful of operations instead of 2k multiply-adds, with the same value bit for bit
             uint64_t hf = 1, hr = 1;
-            if (MODE == KEY_POLY)
-                for (int i = 0; i < k; i++) {
-                    hf = hf * 5 + base_at(v, k, i);
-                    hr = hr * 5 + (3u ^ base_at(v, k, k - 1 - i));
-                }
+            if (MODE == KEY_POLY) poly_hashes_tabled(v, k, L.polyF, L.polyR, &hf, &hr);
 #pragma unroll
             for (int j = 0; j < PT_ITEMS; j++) {
                 const uint64_t p = p0 + (uint64_t)j;

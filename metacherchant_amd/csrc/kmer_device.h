@@ -81,6 +81,47 @@ __host__ __device__ inline int64_t key_poly(const Kmer &v, int k, bool *flipped 
     return a < b ? a : b;  // Math.min on signed longs
 }
 
+// key_poly's two hashes four bases at a time: h <- h * 5^4 + T[byte] with T[b0 b1 b2 b3] = 125 b0 + 25 b1 + 5 b2 + b3, so a
+// k-mer costs k / 4 table look-ups per strand instead of k multiply-adds each with its own base extraction (the counting
+// pipeline's P1 does this once per thread and tile, then rolls: at k = 63 the start-up was most of the kernel).
+// polyF[byte] serves the forward strand (bytes from the top), polyR[byte] the other one (bytes from the bottom,
+// complemented, last base first); same values as key_poly bit for bit (ring arithmetic mod 2^64).
+__host__ __device__ inline void poly_tables_fill(uint16_t *polyF, uint16_t *polyR, uint32_t i)
+{   // entry i < 256 of both tables
+    const uint32_t b0 = (i >> 6) & 3, b1 = (i >> 4) & 3, b2 = (i >> 2) & 3, b3 = i & 3;
+    polyF[i] = (uint16_t)(125 * b0 + 25 * b1 + 5 * b2 + b3);
+    polyR[i] = (uint16_t)(125 * (3u ^ b3) + 25 * (3u ^ b2) + 5 * (3u ^ b1) + (3u ^ b0));
+}
+__host__ __device__ inline void poly_hashes_tabled(const Kmer &v, int k, const uint16_t *polyF, const uint16_t *polyR, uint64_t *hf_out,
+                                                   uint64_t *hr_out)
+{
+    // forward: the k bases top-aligned in 128 bits, eaten from the top
+    uint64_t t_hi, t_lo;
+    if (k <= 32) { t_hi = v.lo << (64 - 2 * k); t_lo = 0; }
+    else { t_hi = (v.hi << (128 - 2 * k)) | (v.lo >> (2 * k - 64)); t_lo = v.lo << (128 - 2 * k); }
+    uint64_t b_hi = k <= 32 ? 0 : v.hi, b_lo = v.lo;  // reverse: eaten from the bottom
+    uint64_t hf = 1, hr = 1;
+    const int n4 = k >> 2;
+    for (int i = 0; i < n4; i++) {
+        hf = hf * 625 + polyF[t_hi >> 56];
+        t_hi = (t_hi << 8) | (t_lo >> 56);
+        t_lo <<= 8;
+        hr = hr * 625 + polyR[b_lo & 0xFF];
+        b_lo = (b_lo >> 8) | (b_hi << 56);
+        b_hi >>= 8;
+    }
+    for (int i = n4 * 4; i < k; i++) {
+        hf = hf * 5 + (t_hi >> 62);
+        t_hi = (t_hi << 2) | (t_lo >> 62);
+        t_lo <<= 2;
+        hr = hr * 5 + (3u ^ (uint32_t)(b_lo & 3));
+        b_lo = (b_lo >> 2) | (b_hi << 62);
+        b_hi >>= 2;
+    }
+    *hf_out = hf;
+    *hr_out = hr;
+}
+
 // src/utils/FNV1AHash.java:8-9,33-42
 __host__ __device__ inline int64_t key_fnv1a(const Kmer &v, int k, bool *flipped = nullptr)
 {
