@@ -1087,6 +1087,10 @@ __global__ void k_sk_add_unmerged(const uint4 *__restrict__ leaf_recs, const uin
 // of the graph would all lead into the same read, which is no help once the walk has used that read up (ptr_pick).
 // ptr_tries > 1 (records of other ranks carry no pointer): the next occurrences try too while the slot has none.
 constexpr uint32_t P3_COUNT_CAP = 1u << 30;
+// A region counts as full when an insertion has looked at this many slots (at the loads the host aims for probe chains
+// stay below a few dozen); a region that really is full would otherwise cost 4096 probes per occurrence -- with no
+// capacity hint that made a first, too small table 40 times slower than the run itself.
+constexpr uint32_t P3_MAX_PROBES = REGION_SLOTS < 1024 ? REGION_SLOTS : 1024;
 #ifndef MC_PTR_LATE
 #define MC_PTR_LATE 0   // 1: a later occurrence (one of sixteen) replaces the early pointer (kmer_device.h ptr_pick_late): more different reads
                         // near a scout's tip, but + 0.6 ms in this kernel for 0.1 ms of walk on configs[1]
@@ -1119,7 +1123,7 @@ __device__ __forceinline__ bool lds_region_add(MergeLds &L, uint64_t key, uint32
                                                uint32_t pick2)
 {
     uint32_t s = home;
-    for (uint32_t probe = 0; probe < REGION_SLOTS; probe++) {
+    for (uint32_t probe = 0; probe < P3_MAX_PROBES; probe++) {
         uint64_t cur = L.key[s];
         if (cur == EMPTY_KEY) {
             cur = atomicCAS(reinterpret_cast<unsigned long long *>(&L.key[s]), (unsigned long long)EMPTY_KEY,
@@ -1244,6 +1248,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                     uint4 nxt = sgm == 0 ? pre : (r_lo + lane < r_hi ? recs[r_lo + lane] : make_uint4(0, 0, 0, 0));
                     uint32_t nxt_ptr = sgm == 0 ? pre_bin : (r_lo + lane < r_hi ? ptrs[r_lo + lane] : 0u);
                     for (uint32_t b0 = r_lo; b0 < r_hi; b0 += 64) {  // wave-uniform
+                        if (L.overflow) break;  // (the leaf will not be committed: no point in merging the rest of it)
                         const uint32_t r = b0 + lane;
                         const uint4 rec = nxt;
                         const uint32_t rptr = nxt_ptr;
@@ -1287,7 +1292,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                             const uint64_t key = rc < fw ? rc : fw;
                             uint32_t s = sk_home(key);
                             bool done = false;
-                            for (uint32_t probe = 0; probe < REGION_SLOTS; probe++) {
+                            for (uint32_t probe = 0; probe < P3_MAX_PROBES; probe++) {
                                 uint64_t cur = L.key[s];
                                 if (cur == EMPTY_KEY) {
                                     cur = atomicCAS(reinterpret_cast<unsigned long long *>(&L.key[s]), (unsigned long long)EMPTY_KEY,
@@ -1320,6 +1325,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                 const uint64_t *keys = static_cast<const uint64_t *>(leaf_keys) + ((uint64_t)leaf * nseg + sgm) * seg_cap;
                 const uint32_t *hints = leaf_hints + ((uint64_t)leaf * nseg + sgm) * seg_cap;
                 for (uint32_t i0 = tid; i0 < n; i0 += 4 * P3_THREADS) {
+                    if (L.overflow) break;  // (the leaf will not be committed)
                     uint64_t kk[4];
                     uint32_t hh[4];
 #pragma unroll

@@ -1014,6 +1014,7 @@ struct PipePlan {
     uint32_t nseg1 = PT_SEGMENTS;  // segments of every level-1 bucket = workgroups of the level-1 kernel
     uint32_t pieces = 1;           // the reads go through P1 / P2 in this many pieces (cap1, cap2: per piece); P3 sees `pieces` segments per leaf
     bool sk = false;  // the streams hold super-k-mer records; capacities are in records
+    bool guessed = false;  // no capacity hint vouches for the table's size: pipe_finish merges a sample of the leaves first
     SpillView sp{};
     SkSpill sks{};
 };
@@ -1037,6 +1038,7 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
         if (fatal) return fail(c, MC_EOVERFLOW, "a k-mer table region filled up (hash skew)");
         c->n_used_host = used;
         const bool hint_holds = c->cfg.capacity_hint && used < c->cfg.capacity_hint;
+        pl->guessed = !hint_holds;
         if (!hint_holds && c->n_slots() < wb / 4) {
             const uint64_t want = regions_for(c, (uint64_t)(((double)used + (double)wb / 8.0) / 0.5));
             if (want > c->n_regions) {
@@ -1107,7 +1109,8 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
 // P2, P3 (with the retry after growing the table), spill drain and bookkeeping; ms1 = time of the
 // level-1 scatter that filled the a_* buckets.  Returns 1 (nothing merged yet) when the streams
 // overflowed even their spill list: the caller then counts the batch with the direct kernel.
-static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false, double ms2_exposed = 0, bool p1_pending = false)
+static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false, double ms2_exposed = 0, bool p1_pending = false,
+                       bool may_rerun = false)
 {   // p2_done: the caller ran P2 itself, piece by piece next to P1 (ms2_exposed = what of it outlasted P1)
     // p1_pending: the caller recorded ev_t[0], enqueued P1 and did not wait: P2 and P3 follow on the stream at once and
     // the host hears of all three together (a host round trip between two kernels leaves the device idle for tens of us)
@@ -1145,21 +1148,87 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
     };
     uint32_t flags[3] = {0, 0, 0};
     unsigned long long n_spill = 0;
+    const bool virgin0 = c->virgin;
+    auto launch_p2 = [&] {
+        static const bool staged = [] { const char *e = getenv("MC_SK2_STAGED"); return !(e && !strcmp(e, "0")); }();
+        if (pl.sk && staged && pl.pieces == 1)
+            hipLaunchKernelGGL(k_sk2_scatter_staged<MC_SK2_ITEMS>, dim3((unsigned)np1), dim3(PT_THREADS), 0, c->stream, P.a_recs, P.a_hints, pl.cap1,
+                               P.seg_counts1, (uint32_t)np1, pl.b1, pl.b2, P.cursors2, pl.cap2, P.b_recs, P.b_hints, pl.sks, pl.nseg1);
+        else if (pl.sk)
+            hipLaunchKernelGGL(k_sk2_scatter, dim3((unsigned)np1), dim3(PT_THREADS), 0, c->stream, P.a_recs, P.a_hints, pl.cap1,
+                               P.seg_counts1, (uint32_t)np1, pl.b1, pl.b2, P.cursors2, pl.cap2, P.b_recs, P.b_hints, pl.sks, pl.nseg1);
+        else
+            hipLaunchKernelGGL(k_p2_scatter, dim3((unsigned)np1), dim3(PT_THREADS), 0, c->stream, P.a_keys, P.a_hints, pl.cap1,
+                               P.seg_counts1, (uint32_t)np1, pl.b1, pl.b2, P.cursors2, pl.cap2, P.b_keys, P.b_hints, pl.sp, c->mm_k);
+    };
+    // how many distinct keys the batch holds, judged by the leaves merged so far (a table that held nothing before)
+    auto resize_for_batch = [&](uint64_t sample_leaves) -> int {
+        std::vector<uint32_t> st(sample_leaves), nw(sample_leaves);
+        HIPCHK(c, hipMemcpy(st.data(), P.leaf_state, sample_leaves * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(nw.data(), P.leaf_new, sample_leaves * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        uint64_t merged = 0, added = 0;
+        for (uint64_t i = 0; i < sample_leaves; i++)
+            if (st[i]) { merged++; added += nw[i]; }
+        // (the leaves that overflowed hold more than the average: at least a full leaf each)
+        const uint64_t per_full = (uint64_t)REGION_SLOTS << pl.g;
+        const double est = ((double)added + (double)(sample_leaves - merged) * (double)per_full * 1.5) * ((double)n_leaves / (double)sample_leaves) * 1.1 + 1024.0;
+        const double load = c->mm_k ? 0.36 : 0.6;
+        if (merged == sample_leaves && est <= (c->mm_k ? 0.5 : 0.7) * (double)c->n_slots()) return MC_OK;  // it fits: carry on
+        uint64_t want = regions_for(c, (uint64_t)(est / load));
+        if (want <= c->n_regions) want = regions_for(c, c->n_slots() * 2);
+        static const bool dbg = getenv("MC_INGEST_DEBUG") != nullptr;
+        if (dbg) fprintf(stderr, "[count] table too small: %llu of %llu sampled leaves merged, %llu keys in them: %.0f M keys expected; new table %.1f GB\n",
+                         (unsigned long long)merged, (unsigned long long)sample_leaves, (unsigned long long)added, est / 1e6, (double)(want << c->sb) * 16 / 1e9);
+        (void)hipFree(c->slots);
+        c->slots = nullptr;
+        int r = table_alloc(c, want);
+        if (r) return r;
+        c->st.grows++;
+        HIPCHK(c, hipMemsetAsync(c->d_ctr + 6, 0, sizeof(unsigned long long), c->stream));  // keys at the coverage threshold: none yet
+        return 3;
+    };
+    if (may_rerun && virgin0 && pl.guessed && n_leaves >= 8192 && pl.b2 > 1 && !p2_done) {
+        // Nothing vouches for the table's size (no capacity hint): merge 1024 leaves first -- the bin word is a mixed hash,
+        // any range of leaves is a fair sample -- and see what they hold.  Costs a host round trip; a whole merge into a
+        // table that turns out too small costs seven times the run.
+        const uint64_t K = 1024;
+        HIPCHK(c, hipEventRecord(c->ev_t[1], c->stream));
+        launch_p2();
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipEventRecord(c->ev_t[2], c->stream));
+        {
+            const int virgin = 1;
+#define P3_ARGS lk, lh, lc, lcap, lseg, (uint32_t)K, pl.g, c->view(), virgin, P.leaf_state, P.leaf_new, P.flags + 1, \
+                (uint32_t)(c->solid_tracked ? c->cov_hint : 0), c->d_ctr + 6, k, emit, c->ptr_tries, P.flags
+            if (pl.sk) hipLaunchKernelGGL(k_p3_merge<true>, dim3((unsigned)K), dim3(P3_THREADS), 0, c->stream, P3_ARGS);
+            else hipLaunchKernelGGL(k_p3_merge<false>, dim3((unsigned)K), dim3(P3_THREADS), 0, c->stream, P3_ARGS);
+#undef P3_ARGS
+        }
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(flags, P.flags, sizeof flags, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        float f = 0;
+        if (p1_pending) { HIPCHK(c, hipEventElapsedTime(&f, c->ev_t[0], c->ev_t[1])); ms1 = f; p1_pending = false; }
+        HIPCHK(c, hipEventElapsedTime(&f, c->ev_t[1], c->ev_t[2]));
+        ms2 += f;
+        p2_done = true;
+        if (flags[0]) return 1;  // (records lost: nothing was merged)
+        rc = resize_for_batch(K);
+        if (rc == 3) {
+            c->st.p1_ms += ms1;
+            c->st.p2_ms += ms2;
+            c->st.count_ms += ms1 + ms2;
+            c->st.count_total_ms += ms1 + ms2;
+        }
+        if (rc) return rc;
+        HIPCHK(c, hipMemsetAsync(P.flags + 1, 0, sizeof(uint32_t), c->stream));
+    }
     {   // P2 and the first P3 back to back.  The capacities of the streams are estimates (and a few heavy keys can fill
         // a bucket's spill list alone): P3 looks at the "records lost" flag itself and merges nothing when it is set, so
         // that the caller can still count the batch another way.
         HIPCHK(c, hipEventRecord(c->ev_t[1], c->stream));
         if (pl.b2 > 1 && !p2_done) {
-            static const bool staged = [] { const char *e = getenv("MC_SK2_STAGED"); return !(e && !strcmp(e, "0")); }();
-            if (pl.sk && staged && pl.pieces == 1)
-                hipLaunchKernelGGL(k_sk2_scatter_staged<MC_SK2_ITEMS>, dim3((unsigned)np1), dim3(PT_THREADS), 0, c->stream, P.a_recs, P.a_hints, pl.cap1,
-                                   P.seg_counts1, (uint32_t)np1, pl.b1, pl.b2, P.cursors2, pl.cap2, P.b_recs, P.b_hints, pl.sks, pl.nseg1);
-            else if (pl.sk)
-                hipLaunchKernelGGL(k_sk2_scatter, dim3((unsigned)np1), dim3(PT_THREADS), 0, c->stream, P.a_recs, P.a_hints, pl.cap1,
-                                   P.seg_counts1, (uint32_t)np1, pl.b1, pl.b2, P.cursors2, pl.cap2, P.b_recs, P.b_hints, pl.sks, pl.nseg1);
-            else
-                hipLaunchKernelGGL(k_p2_scatter, dim3((unsigned)np1), dim3(PT_THREADS), 0, c->stream, P.a_keys, P.a_hints, pl.cap1,
-                                   P.seg_counts1, (uint32_t)np1, pl.b1, pl.b2, P.cursors2, pl.cap2, P.b_keys, P.b_hints, pl.sp, c->mm_k);
+            launch_p2();
             HIPCHK(c, hipGetLastError());
         }
         HIPCHK(c, hipEventRecord(c->ev_t[2], c->stream));
@@ -1176,6 +1245,20 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
         HIPCHK(c, hipEventElapsedTime(&f, c->ev_t[2], c->ev_t[3]));
         ms3 += f;
         c->virgin = false;
+    }
+    if (flags[1] && virgin0 && !flags[0] && may_rerun) {  // (may_rerun: the caller can run the batch again -- returns 3)
+        // The table held nothing before this run and is too small for it (no capacity hint, or a poor one).  Rebuilding it
+        // by rehashing and merging the leaves that are left in two sweeps each costs 40 times the run (785 against 19 ms
+        // on configs[1]); what the merged leaves added says how many distinct keys the batch holds, so: a fresh table of
+        // the right size, and the caller runs the batch again.
+        rc = resize_for_batch(n_leaves);
+        if (rc != 3) return rc ? rc : fail(c, MC_EOVERFLOW, "internal: a leaf overflowed in a table that should hold the batch");
+        c->st.p1_ms += ms1;
+        c->st.p2_ms += ms2;
+        c->st.p3_ms += ms3;
+        c->st.count_ms += ms1 + ms2 + ms3;
+        c->st.count_total_ms += ms1 + ms2 + ms3;
+        return 3;
     }
     // P3 again, with a larger table, while a region overflows
     for (int attempt = 0;; attempt++) {
@@ -1312,8 +1395,25 @@ static uint64_t sk_records_bound(const mc_ctx *c, uint64_t wb, uint64_t nr)
 
 // One batch of reads [r0, r1) through the partitioned pipeline (count_pipeline.h).  wb = its windows,
 // base0 / end_abs = read_offsets[r0] / read_offsets[r1].
+static int add_reads_partitioned_once(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_off, uint64_t r0, uint64_t r1,
+                                      uint64_t base0, uint64_t end_abs, uint64_t wb);
 static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_off, uint64_t r0, uint64_t r1,
                                  uint64_t base0, uint64_t end_abs, uint64_t wb)
+{
+    // 3 from the pipeline: the (empty) table was too small and has been replaced by one of the right size -- once more
+    unsigned long long empty0 = 0;  // occurrences of the key that looks like a free slot (hash keys): counted apart, by P1
+    HIPCHK(c, hipMemcpyAsync(&empty0, c->d_ctr + 1, sizeof empty0, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int run = 0;; run++) {
+        const int rc = add_reads_partitioned_once(c, d_words, d_off, r0, r1, base0, end_abs, wb);
+        if (rc != 3) return rc;
+        if (run >= 8) return fail(c, MC_EOVERFLOW, "k-mer table regions keep overflowing; pass a capacity_hint (distinct k-mers)");  // (a rerun multiplies the table by 4.5 at least)
+        HIPCHK(c, hipMemcpyAsync(c->d_ctr + 1, &empty0, sizeof empty0, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+}
+static int add_reads_partitioned_once(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_off, uint64_t r0, uint64_t r1,
+                                      uint64_t base0, uint64_t end_abs, uint64_t wb)
 {
     mc_ctx::Pipe &P = c->pipe;
     PipePlan pl;
@@ -1356,7 +1456,7 @@ static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint6
             }
         });
         if (rc) return rc;
-        rc = pipe_finish(c, pl, ms1, true, 0);
+        rc = pipe_finish(c, pl, ms1, true, 0, false, true);
     } else if (pieces > 1) {
         const uint64_t t_first = base0 / tile_size, per = (n_tiles_abs - t_first + pieces - 1) / pieces;
         const uint64_t a_stride = pl.np1 * pl.nseg1 * pl.cap1, c_stride = pl.np1 * pl.nseg1;
@@ -1386,7 +1486,7 @@ static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint6
         HIPCHK(c, hipEventElapsedTime(&f1, c->ev0, c->ev1));
         HIPCHK(c, hipEventElapsedTime(&f2, c->ev1, c->ev_p2));  // what the last piece's second level adds behind the first levels
         ms1 = f1;
-        rc = pipe_finish(c, pl, ms1, true, f2 > 0 ? f2 : 0);
+        rc = pipe_finish(c, pl, ms1, true, f2 > 0 ? f2 : 0, false, true);
     } else {
         HIPCHK(c, hipEventRecord(c->ev_t[0], c->stream));  // (no wait here: pipe_finish enqueues P2 and P3 right behind)
         hipLaunchKernelGGL(k_tile_first_read, dim3((unsigned)((n_tiles_abs + 255) / 256)), dim3(256), 0, c->stream, offs, nr,
@@ -1398,7 +1498,7 @@ static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint6
             launch_p1_reads(c, d_words, offs, nr, base0, end_abs, n_tiles_abs, P.tile_first, pl.b1, P.seg_counts1, pl.cap1, P.a_keys,
                             P.a_hints, pl.sp, 0, nullptr);
         HIPCHK(c, hipGetLastError());
-        rc = pipe_finish(c, pl, ms1, false, 0, true);
+        rc = pipe_finish(c, pl, ms1, false, 0, true, true);
     }
     if (rc != 1) return rc;
     // (super-k-mer streams overflowed: unusually short runs) count this batch with the direct kernel instead
