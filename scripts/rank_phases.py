@@ -54,6 +54,7 @@ for rep in range(3):
     _, ms_exp = t(lambda: ctx.export_dev(cov, keys, cnts, n, hints))
     solid.clear()
     _, ms_solid = t(lambda: solid.solid_from_pairs_dev(keys, cnts, n, cov, hints))
+    solid.share_read_store(ctx)  # (the pointers in `hints` lead into the counting context's read store: distributed.py gather_solid)
     res, ms_bfs = t(lambda: solid.bfs_batch(jobs, cov, 100000, -1))
     tot = ms_ext + ms_add + ms_fin + ms_cnt + ms_exp + ms_solid + ms_bfs
     st = ctx.stats()
