@@ -379,6 +379,8 @@ int run(const Options &o)
     if (o.maxkmers < 0 && o.maxradius < 0)  // EnvironmentFinderMain.java:171-175
         throw Error("At least one of --maxkmers and --maxradius parameters should be set");
     if (o.coverage < 0) throw Error("--coverage must not be negative (absent k-mers read as -1 and would pass)");
+    if (o.k > 63)  // (the reference hashes k-mer STRINGS of any length for k > 31; the walk here keeps oriented k-mers in 128 bits)
+        throw Error("k = " + std::to_string(o.k) + " is not supported: this build handles k <= 31 (packed keys) and 32 <= k <= 63 (hash keys)");
 
     const std::string wd = o.work_dir;
     if (!open_work_dir(o, "k=" + std::to_string(o.k) + "\nseq=" + o.seq + "\noutput=" + o.output + "\ncoverage=" +
