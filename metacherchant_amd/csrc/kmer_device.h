@@ -238,7 +238,10 @@ __host__ __device__ __forceinline__ uint32_t ptr_pick(uint64_t key, uint32_t ptr
 {   // which occurrence (counted from 0) leaves its pointer: ptr_from + r, r < min(4, thr - ptr_from) so that every key that reaches the threshold has one
     const uint32_t room = solid_thr > ptr_from ? solid_thr - ptr_from : 1u;
     const uint32_t r = (uint32_t)(key ^ (key >> 9) ^ (key >> 23)) & 3u;
-    return ptr_from + (room >= 4 ? r : r % room);
+    // r % room for room = 1, 2, 3 without a division (the compiler makes one of float operations, and the merge kernel
+    // comes here for the first occurrences of every key)
+    const uint32_t m = room >= 4 ? r : (room == 3 ? (r == 3 ? 0u : r) : (room == 2 ? (r & 1u) : 0u));
+    return ptr_from + m;
 }
 
 // ... and a later occurrence, one of sixteen, replaces it when the key has that many: the early arrivals of all the
