@@ -31,8 +31,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=None, help="reads per GPU (default: 10 M; --config 2: 100 M)")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--k", type=int, default=None, help="default 31; --config 2: 63")
