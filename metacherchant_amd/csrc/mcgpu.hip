@@ -1181,7 +1181,7 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
                          (unsigned long long)merged, (unsigned long long)sample_leaves, (unsigned long long)added, est / 1e6, (double)(want << c->sb) * 16 / 1e9);
         (void)hipFree(c->slots);
         c->slots = nullptr;
-        int r = table_alloc(c, want);
+        int r = table_alloc(c, want);  // (fresh device memory comes zeroed by the driver at ~30 GB/s: 0.7 s for 22 GB, once)
         if (r) return r;
         c->st.grows++;
         HIPCHK(c, hipMemsetAsync(c->d_ctr + 6, 0, sizeof(unsigned long long), c->stream));  // keys at the coverage threshold: none yet
@@ -2370,8 +2370,28 @@ static int tok_scan(mc_ctx *c, const uint32_t *d_in, uint64_t n, unsigned long l
 
 // Text bytes [b, e) of a mapped file (a whole number of records) -> packed reads in HBM -> counted.  *declined: the
 // device saw something the host parser has to deal with; nothing was added.  The context's lock is held.
+// The chunks of one file, tokenised into the read store back to back and counted together when the file ends: one run
+// of the counting pipeline (which reads and rewrites the whole table) instead of one per 256 MB of text.
+struct TokPending {
+    PoolBuf<uint64_t> off;     // read offsets of all chunks so far (+ the end), relative to the first chunk's first base
+    uint64_t off_cap = 0;
+    uint64_t reads = 0, bases = 0;
+    int64_t base_word = -1;    // where the first chunk starts in the read store
+};
+static int tok_flush_locked(mc_ctx *c, TokPending &P)
+{
+    if (P.reads == 0) { P.base_word = -1; P.bases = 0; return MC_OK; }
+    if ((uint64_t)P.base_word != c->rs_bases / 32)  // (the chunks sit behind the store's end until they are counted)
+        return fail(c, MC_ESTATE, "mc_add_reads_file: the context took other reads while a file was being read");
+    int rc = add_reads_dev_locked(c, c->rs_words + P.base_word, P.off.p, P.reads, P.bases, P.base_word);
+    if (!rc) HIPCHK(c, hipStreamSynchronize(c->stream));
+    P.reads = P.bases = 0;
+    P.base_word = -1;
+    return rc;
+}
+
 static int tokenize_chunk_locked(mc_ctx *c, const mch::PlainReadsFile &f, const char *b, const char *e, uint8_t *d_text, uint64_t *n_reads_out,
-                                 bool *declined)
+                                 bool *declined, TokPending *pend = nullptr)
 {
     *declined = false;
     *n_reads_out = 0;
@@ -2417,8 +2437,38 @@ static int tokenize_chunk_locked(mc_ctx *c, const mch::PlainReadsFile &f, const 
     PoolBuf<uint64_t> offsets;
     uint64_t *dst = nullptr;
     int64_t in_store = -1;
-    auto reserve_words = [&](uint64_t total_bases) -> int {
+    uint64_t dst_base = 0;  // this chunk's first base in `dst` (deferred counting: behind the chunks before it)
+    uint64_t *off_out = nullptr;
+    const bool defer = pend != nullptr && c->rs_enabled;
+    auto reserve_words = [&](uint64_t total_bases, uint64_t n_reads_chunk) -> int {
         const uint64_t n_words = (total_bases + 31) / 32 + 1;
+        if (defer) {
+            if (pend->base_word < 0) { pend->base_word = (int64_t)(c->rs_bases / 32); pend->bases = 0; pend->reads = 0; }
+            if ((uint64_t)pend->base_word != c->rs_bases / 32)
+                return fail(c, MC_ESTATE, "mc_add_reads_file: the context took other reads while a file was being read");
+            dst_base = pend->bases;
+            // (the caller reserved the store for the whole file: no reallocation may move the chunks packed so far)
+            if ((uint64_t)pend->base_word + (dst_base + total_bases + 31) / 32 + 2 > c->rs_cap_words)
+                return fail(c, MC_EINVAL, "internal: the read store was not reserved for the whole file");
+            dst = c->rs_words + pend->base_word;
+            in_store = pend->base_word;
+            const uint64_t first_new = (dst_base + 31) / 32;  // words before it hold bases of earlier chunks
+            HIPCHK(c, hipMemsetAsync(dst + first_new, 0, ((dst_base + total_bases + 31) / 32 + 1 - first_new) * 8, c->stream));
+            const uint64_t need = pend->reads + n_reads_chunk + 1;
+            if (need > pend->off_cap) {
+                PoolBuf<uint64_t> bigger;
+                const uint64_t cap = std::max<uint64_t>(need * 2, 1u << 20);
+                HIPCHK(c, bigger.alloc(&c->tok_pool, cap));
+                if (pend->reads) HIPCHK(c, hipMemcpyAsync(bigger.p, pend->off.p, (pend->reads + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                std::swap(pend->off.p, bigger.p);
+                std::swap(pend->off.bytes, bigger.bytes);
+                std::swap(pend->off.pool, bigger.pool);
+                pend->off_cap = cap;
+            }
+            off_out = pend->off.p + pend->reads;
+            return MC_OK;
+        }
         if (c->rs_enabled) {
             int r = rs_reserve(c, n_words);
             if (r) return r;
@@ -2470,13 +2520,13 @@ static int tokenize_chunk_locked(mc_ctx *c, const mch::PlainReadsFile &f, const 
         rc = tok_scan(c, rec_keep.p, n_rec, rec_out.p, &n_reads);
         if (rc) return rc;
         if (n_reads) {
-            HIPCHK(c, offsets.alloc(&c->tok_pool, n_reads + 1));
-            rc = reserve_words(total_bases);
+            rc = reserve_words(total_bases, n_reads);
             if (rc) return rc;
+            if (!off_out) { HIPCHK(c, offsets.alloc(&c->tok_pool, n_reads + 1)); off_out = offsets.p; }
             hipLaunchKernelGGL(tok::k_fa_offsets, dim3(grid_for(n_rec, 256, 1 << 16)), dim3(256), 0, c->stream, rec_keep.p, rec_out.p, rec_first.p, out_off.p,
-                               n_rec, n_reads, total_bases, offsets.p);
+                               n_rec, n_reads, total_bases, off_out, dst_base);
             hipLaunchKernelGGL(tok::k_fa_pack, dim3(grid_for(n_lines, 4, 1 << 14)), dim3(tok::T_THREADS), 0, c->stream, text.p, n, nl.p, n_nl,
-                               n_lines, keep_len.p, out_off.p, dst, flags.p);
+                               n_lines, keep_len.p, out_off.p, dst, flags.p, dst_base);
             HIPCHK(c, hipGetLastError());
         }
     } else {
@@ -2499,11 +2549,11 @@ static int tokenize_chunk_locked(mc_ctx *c, const mch::PlainReadsFile &f, const 
         if (rc) return rc;
         if (fl) { *declined = true; return MC_OK; }
         if (n_reads) {
-            HIPCHK(c, offsets.alloc(&c->tok_pool, n_reads + 1));
-            rc = reserve_words(total_bases);
+            rc = reserve_words(total_bases, n_reads);
             if (rc) return rc;
+            if (!off_out) { HIPCHK(c, offsets.alloc(&c->tok_pool, n_reads + 1)); off_out = offsets.p; }
             hipLaunchKernelGGL(tok::k_fq_emit, dim3(g), dim3(tok::T_THREADS), 0, c->stream, text.p, n, nl.p, n_nl, n_rec, f.offset, piece_at.p, base_at.p,
-                               rec_bases.p, n_reads, total_bases, offsets.p, dst);
+                               rec_bases.p, n_reads, total_bases, off_out, dst, dst_base);
             HIPCHK(c, hipGetLastError());
         }
     }
@@ -2511,8 +2561,12 @@ static int tokenize_chunk_locked(mc_ctx *c, const mch::PlainReadsFile &f, const 
     if (rc) return rc;
     if (fl) { *declined = true; return MC_OK; }  // (cannot happen after the line pass; the read store was not advanced)
     const double t2 = now();
-    if (n_reads) {
-        rc = add_reads_dev_locked(c, dst, offsets.p, n_reads, total_bases, in_store);
+    if (n_reads && defer) {  // counted with the rest of the file (tok_flush_locked)
+        pend->reads += n_reads;
+        pend->bases += total_bases;
+        HIPCHK(c, hipStreamSynchronize(c->stream));  // (the text buffer goes back to its pool)
+    } else if (n_reads) {
+        rc = add_reads_dev_locked(c, dst, off_out, n_reads, total_bases, in_store);
         if (rc) return rc;
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
@@ -2583,6 +2637,11 @@ int mc_add_reads_file(mc_ctx *c, const char *path, uint64_t *n_reads)
                 std::lock_guard<std::mutex> g(c->mu);
                 u.reset();
             };
+            std::unique_ptr<TokPending> pend(new TokPending);  // (its pool block goes back under the context's lock)
+            auto drop_pend = [&] {
+                std::lock_guard<std::mutex> g(c->mu);
+                pend.reset();
+            };
             uint64_t total = 0;
             rc = cuts.empty() ? MC_OK : start_upload(0, cur);
             for (size_t i = 0; i < cuts.size() && rc == MC_OK; i++) {
@@ -2600,7 +2659,8 @@ int mc_add_reads_file(mc_ctx *c, const char *path, uint64_t *n_reads)
                 bool declined = false;
                 {
                     std::lock_guard<std::mutex> g(c->mu);
-                    rc = tokenize_chunk_locked(c, f, cuts[i].first, cuts[i].second, cur->text.p, &got, &declined);
+                    rc = tokenize_chunk_locked(c, f, cuts[i].first, cuts[i].second, cur->text.p, &got, &declined, pend.get());
+                    if (rc == MC_OK && declined) rc = tok_flush_locked(c, *pend);  // (the host's batches are appended behind what is counted)
                 }
                 if (rc != MC_OK) break;
                 if (declined) {
@@ -2609,16 +2669,51 @@ int mc_add_reads_file(mc_ctx *c, const char *path, uint64_t *n_reads)
                     } catch (...) {
                         finish(cur);
                         finish(nxt);
+                        drop_pend();
                         throw;
                     }
                     if (rc != MC_OK) break;
                 }
                 total += got;
+                if (i == 0 && cuts.size() > 1) {
+                    // No capacity hint that still holds: the first chunk says how many distinct k-mers a byte of this file
+                    // brings, the file's size says how many chunks follow -- the table goes to its final size now, with one
+                    // chunk's keys to move, instead of being rebuilt every other chunk (10 M reads with 1 % errors in six
+                    // chunks: 110 ms of counting against ~45).  An over-estimate (the later chunks repeat k-mers of the first)
+                    // costs memory, bounded by a third of what the device has free.
+                    std::lock_guard<std::mutex> g(c->mu);
+                    unsigned long long used = 0;
+                    uint32_t fatal = 0;
+                    rc = read_counters(c, &used, &fatal);
+                    if (rc != MC_OK) break;
+                    const bool hint_holds = c->cfg.capacity_hint && used < c->cfg.capacity_hint;
+                    if (!hint_holds && used && !c->skl_state) {
+                        const double scale = (double)f.n / (double)(cuts[0].second - cuts[0].first);
+                        const double load = c->mm_k ? 0.36 : 0.6;
+                        size_t fr = 0, tot = 0;
+                        if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = 0;
+                        uint64_t want_slots = (uint64_t)((double)used * scale / load);
+                        want_slots = std::min<uint64_t>(want_slots, fr / 3 / sizeof(Slot));
+                        const uint64_t want = regions_for(c, want_slots);
+                        if (want > c->n_regions && want_slots > c->n_slots()) {
+                            if (dbg) fprintf(stderr, "[ingest] %llu distinct k-mers after %.0f MB of %.0f MB: table to %.1f GB\n", used,
+                                             (cuts[0].second - cuts[0].first) / 1e6, f.n / 1e6, (double)(want << c->sb) * sizeof(Slot) / 1e9);
+                            rc = table_grow(c, want);
+                            if (rc != MC_OK) break;
+                            c->solid_list_fresh = false;
+                        }
+                    }
+                }
                 finish(cur);
                 cur = std::move(nxt);
             }
             finish(cur);
             finish(nxt);
+            if (rc == MC_OK) {
+                std::lock_guard<std::mutex> g(c->mu);
+                rc = tok_flush_locked(c, *pend);
+            }
+            drop_pend();
             if (rc != MC_OK) return rc;
             if (dbg) fprintf(stderr, "[ingest] device tokeniser: %zu chunk(s), %.1f MB in %.3f s\n", cuts.size(), f.n / 1e6, now() - t_begin);
             if (n_reads) *n_reads = total;

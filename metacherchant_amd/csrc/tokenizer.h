@@ -298,18 +298,19 @@ __global__ void k_fa_rec_keep(const uint8_t *__restrict__ rec_n, const unsigned 
 }
 
 __global__ void k_fa_offsets(const uint32_t *__restrict__ rec_keep, const unsigned long long *__restrict__ rec_out, const uint32_t *__restrict__ rec_first,
-                             const unsigned long long *__restrict__ out_off, uint64_t n_rec, uint64_t n_reads, uint64_t total_bases, uint64_t *offsets)
-{
+                             const unsigned long long *__restrict__ out_off, uint64_t n_rec, uint64_t n_reads, uint64_t total_bases, uint64_t *offsets,
+                             uint64_t dst_base)
+{   // dst_base: where this chunk's first base goes in the output (the chunks of a file are packed back to back)
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rec; r += stride)
-        if (rec_keep[r]) offsets[rec_out[r]] = out_off[rec_first[r]];
-    if (blockIdx.x == 0 && threadIdx.x == 0) offsets[n_reads] = total_bases;
+        if (rec_keep[r]) offsets[rec_out[r]] = dst_base + out_off[rec_first[r]];
+    if (blockIdx.x == 0 && threadIdx.x == 0) offsets[n_reads] = dst_base + total_bases;
 }
 
 // pass 4: a wave per line packs it
 __global__ void __launch_bounds__(T_THREADS) k_fa_pack(const uint8_t *__restrict__ t, uint64_t n, const unsigned long long *__restrict__ nl, uint64_t n_nl,
                                                       uint64_t n_lines, const uint32_t *__restrict__ keep_len, const unsigned long long *__restrict__ out_off,
-                                                      uint64_t *words, uint32_t *flags)
+                                                      uint64_t *words, uint32_t *flags, uint64_t dst_base)
 {
     __shared__ uint64_t lds[T_THREADS / 64][WP_WORDS];
     const int lane = threadIdx.x & 63;
@@ -323,7 +324,7 @@ __global__ void __launch_bounds__(T_THREADS) k_fa_pack(const uint8_t *__restrict
         uint8_t c0;
         wave_line_spans(t, n, nl, n_nl, j, 1, &s, &e, &c0);
         s = shfl64(s, 0);
-        wp.open(out_off[j]);
+        wp.open(dst_base + out_off[j]);
         for (uint32_t q = 0; q < len; q += 64) {
             const bool in = q + lane < len;
             const int c = in ? base_code(t[s + q + lane]) : -1;
@@ -399,7 +400,7 @@ __global__ void __launch_bounds__(T_THREADS) k_fq_records(const uint8_t *__restr
 __global__ void __launch_bounds__(T_THREADS) k_fq_emit(const uint8_t *__restrict__ t, uint64_t n, const unsigned long long *__restrict__ nl, uint64_t n_nl,
                                                       uint64_t n_rec, int offset, const unsigned long long *__restrict__ piece_at,
                                                       const unsigned long long *__restrict__ base_at, const uint32_t *__restrict__ rec_bases, uint64_t n_reads,
-                                                      uint64_t total_bases, uint64_t *offsets, uint64_t *words)
+                                                      uint64_t total_bases, uint64_t *offsets, uint64_t *words, uint64_t dst_base)
 {
     __shared__ uint64_t lds[T_THREADS / 64][WP_WORDS];
     const int lane = threadIdx.x & 63;
@@ -410,7 +411,7 @@ __global__ void __launch_bounds__(T_THREADS) k_fq_emit(const uint8_t *__restrict
         if (rec_bases[r] == 0) continue;
         const FqRecord R = fq_record(t, n, nl, n_nl, r);
         uint64_t p = piece_at[r], carry = 0;
-        wp.open(base_at[r]);
+        wp.open(dst_base + base_at[r]);
         for (uint64_t q = 0; q < R.len; q += 64) {
             const bool in = q + lane < R.len;
             const uint8_t c = in ? t[R.s1 + q + lane] : 0;
@@ -424,7 +425,7 @@ __global__ void __launch_bounds__(T_THREADS) k_fq_emit(const uint8_t *__restrict
         }
         wp.flush();
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) offsets[n_reads] = total_bases;
+    if (blockIdx.x == 0 && threadIdx.x == 0) offsets[n_reads] = dst_base + total_bases;
 }
 
 }  // namespace tok
