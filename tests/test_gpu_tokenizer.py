@@ -159,6 +159,7 @@ def test_device_tokeniser_declines_to_the_host_parser(mc, tmp_path, monkeypatch)
     p.write_text("@read".join(recs[:100]) + "\n\n@read" + "@read".join(recs[100:]))
     want = ho.read_fastq_reads(str(p))
     _check(mc, p, want, 15, monkeypatch)
+    _check(mc, p, want, 15, monkeypatch, chunk=20000)  # one chunk of several declined: counted chunks, host batches, counted chunks
     # an IUPAC code: both readers refuse the file with the same message
     bad = tmp_path / "iupac.fasta"
     bad.write_text(">a\nACGTRACGT\n")
