@@ -1401,15 +1401,20 @@ static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint6
                                  uint64_t base0, uint64_t end_abs, uint64_t wb)
 {
     // 3 from the pipeline: the (empty) table was too small and has been replaced by one of the right size -- once more
-    unsigned long long empty0 = 0;  // occurrences of the key that looks like a free slot (hash keys): counted apart, by P1
-    HIPCHK(c, hipMemcpyAsync(&empty0, c->d_ctr + 1, sizeof empty0, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    unsigned long long empty0 = 0;  // occurrences of the key that looks like a free slot (hash keys only): counted apart, by P1
+    const bool hashed = c->cfg.key_mode != MC_KEY_PACKED;
+    if (hashed) {
+        HIPCHK(c, hipMemcpyAsync(&empty0, c->d_ctr + 1, sizeof empty0, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     for (int run = 0;; run++) {
         const int rc = add_reads_partitioned_once(c, d_words, d_off, r0, r1, base0, end_abs, wb);
         if (rc != 3) return rc;
         if (run >= 8) return fail(c, MC_EOVERFLOW, "k-mer table regions keep overflowing; pass a capacity_hint (distinct k-mers)");  // (a rerun multiplies the table by 4.5 at least)
-        HIPCHK(c, hipMemcpyAsync(c->d_ctr + 1, &empty0, sizeof empty0, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (hashed) {
+            HIPCHK(c, hipMemcpyAsync(c->d_ctr + 1, &empty0, sizeof empty0, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
     }
 }
 static int add_reads_partitioned_once(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_off, uint64_t r0, uint64_t r1,
