@@ -1157,6 +1157,12 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
     if (lost && *lost) return;
     __shared__ MergeLds L;
     const uint32_t tid = threadIdx.x;
+#ifdef MC_P3_TIMING
+    unsigned long long tph[4] = {0, 0, 0, 0}, tl = __builtin_amdgcn_s_memrealtime(), n_lv = 0;
+#define P3_STAMP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); tph[i] += n_ - tl; tl = n_; } while (0)
+#else
+#define P3_STAMP(i) do {} while (0)
+#endif
     const bool emitting = emit.recs != nullptr && solid_thr != 0;
     if (tid == 0) L.emit_cur = emitting ? emit.counts[blockIdx.x] : 0u;  // (published by the first barrier below)
     // solid_thr != 0: keep *n_solid = number of keys with count >= solid_thr up to date (the coverage
@@ -1227,6 +1233,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                 }
                 if (tid == 0) { L.n_new = 0; L.overflow = 0; }
                 __syncthreads();
+                P3_STAMP(0);
                 uint32_t my_new = 0;
                 for (uint32_t sgm = 0; sgm < nseg; sgm++) {
                 const uint32_t n = (SK && sgm == 0) ? n0_cur : min(seg_counts[(uint64_t)leaf * nseg + sgm], (uint32_t)seg_cap);
@@ -1351,8 +1358,10 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                     fetch_first(nl, n0_nxt);
                     first_fetched = true;
                 }
+                P3_STAMP(1);
                 if (my_new) atomicAdd(&L.n_new, my_new);
                 __syncthreads();
+                P3_STAMP(2);
                 const bool ovf = L.overflow != 0;
                 if (ovf) leaf_ok = false;
                 if (commit && !ovf) {
@@ -1399,7 +1408,14 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
         if (tid == 0) {
             if (leaf_ok) { leaf_state[leaf] = 1; leaf_new[leaf] = new_total; } else atomicExch(any_failed, 1u);
         }
+        P3_STAMP(3);
+#ifdef MC_P3_TIMING
+        n_lv++;
+#endif
     }
+#ifdef MC_P3_TIMING
+    if (blockIdx.x == 7 && (tid == 0 || tid == 448)) printf("[p3 block 7 thread %u] %llu leaves, us per leaf: init %.2f merge(own) %.2f wait-for-others %.2f writeback+rest %.2f\n", tid, n_lv, tph[0] * 0.01 / n_lv, tph[1] * 0.01 / n_lv, tph[2] * 0.01 / n_lv, tph[3] * 0.01 / n_lv);
+#endif
     if (solid_thr) wave_add_ull(n_solid, (unsigned long long)solid_delta);  // (two's complement: deltas may be negative)
     if (emitting) {
         __syncthreads();
