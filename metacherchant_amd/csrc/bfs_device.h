@@ -549,8 +549,15 @@ struct HopEval {
 // sw, mh: this wave's LDS scratch (SCOUT_WORDS words of the read store; SCOUT_MH minimizer hashes)
 template <int MODE>
 __device__ __forceinline__ void scout_eval(const SolidView &t, uint64_t *sw, uint32_t *mh, const Kmer &X, int k, int min_cov, uint32_t cptr,
-                                           uint32_t delta, uint32_t want, HopEval &R, unsigned long long &lookups)
+                                           uint32_t delta, uint32_t want, HopEval &R, unsigned long long &lookups, unsigned long long *tsc = nullptr)
 {
+#ifdef MC_SCOUT_TIMING
+    unsigned long long ts_ = __builtin_amdgcn_s_memrealtime();
+#define SC_STAMP(i) do { if (tsc) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); tsc[i] += n_ - ts_; ts_ = n_; } } while (0)
+#else
+#define SC_STAMP(i) do {} while (0)
+    (void)tsc;
+#endif
     const uint32_t lane = threadIdx.x & 63;
     R.m = 0; R.why = 1; R.fwd = true; R.Q = -1; R.e_hi = R.e_lo = 0; R.K = Kmer{0, 0}; R.aux = 0; R.other = false;
     uint32_t span;
@@ -563,6 +570,7 @@ __device__ __forceinline__ void scout_eval(const SolidView &t, uint64_t *sw, uin
     if (lane < SCOUT_WORDS) sw[lane] = t.reads[min(wlo + lane, last_word)];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    SC_STAMP(0);
     const uint64_t base = wlo * 32;
     const Kmer Xr = kmer_rc<MODE>(X, k);
     // where is the tip?  `delta` bases after the pointer's k-mer in a read that runs our way, before it otherwise
@@ -613,10 +621,12 @@ __device__ __forceinline__ void scout_eval(const SolidView &t, uint64_t *sw, uin
     } else {
         s0 = solid_slot_of(t, key);
     }
+    SC_STAMP(1);
     if (ok) {
         cov = solid_get4(t, key, &aux, s0);
         lookups++;
     }
+    SC_STAMP(2);
     const unsigned long long solid_m = __ballot(ok && cov >= min_cov);
     const uint32_t m = solid_m == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~solid_m);
     if (m == 0) return;
@@ -641,6 +651,7 @@ __device__ __forceinline__ void scout_eval(const SolidView &t, uint64_t *sw, uin
         other = !(at <= here && here < at + sp);
     }
     R.m = m; R.why = 0; R.e_hi = e_hi; R.e_lo = e_lo; R.K = K; R.aux = aux; R.other = other;
+    SC_STAMP(3);
 }
 
 __device__ __forceinline__ void st_u64(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -794,6 +805,8 @@ __device__ void scout_companion(const BfsState &S, const SolidView &t, TeamLds &
     constexpr uint32_t W = BFS_THREADS / 64;
     uint32_t last_seq = 0, idle = 0;
     unsigned long long lookups = 0, hops = 0, n_nf = 0, n_m0 = 0, iters = 0;
+    unsigned long long tsc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)tsc;
     for (;;) {
         if (tid == 0) { L.seq = ld_u32(&box->req_seq); L.quit = ld_u32(&box->quit); }
         __syncthreads();
@@ -843,9 +856,12 @@ __device__ void scout_companion(const BfsState &S, const SolidView &t, TeamLds &
             R.m = 0;
             const bool busy = member && !L.stuck[g] && L.levels[g] < budget;
             if (busy && u < L.nc[g]) {
-                scout_eval<MODE>(t, L.sw[wv], L.mh[wv], L.X[g], k, min_cov, L.cptr[g][u], L.cdelta[g][u], min(64u, budget - L.levels[g]), R, lookups);
+                scout_eval<MODE>(t, L.sw[wv], L.mh[wv], L.X[g], k, min_cov, L.cptr[g][u], L.cdelta[g][u], min(64u, budget - L.levels[g]), R, lookups, tsc);
                 if (R.why == 1) n_nf += lane == 0; else { hops += lane == 0; if (R.m == 0) n_m0 += lane == 0; }
             }
+#ifdef MC_SCOUT_TIMING
+            unsigned long long tq_ = __builtin_amdgcn_s_memrealtime();
+#endif
             if (lane == 0) L.reach[wv] = R.m;
             // The length the previous hop added is published now: its path words (write-through stores) were issued before
             // this hop's two round trips and every wave waits here for the stores it has outstanding, so they have arrived
@@ -894,6 +910,9 @@ __device__ void scout_companion(const BfsState &S, const SolidView &t, TeamLds &
             if (tid == 0 && probe != seq) L.stop = 1;
             if (tid == 0) iters++;
             __syncthreads();
+#ifdef MC_SCOUT_TIMING
+            { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); tsc[4] += n_ - tq_; tsc[5]++; }
+#endif
             bool any = false;
             for (uint32_t a = 0; a < F; a++) any = any || (!L.stuck[a] && L.levels[a] < budget);
             if (!any || L.stop) break;
@@ -905,6 +924,9 @@ __device__ void scout_companion(const BfsState &S, const SolidView &t, TeamLds &
         if (tid < F) atomicAdd(&box->levels, (unsigned long long)L.levels[tid]);
         __syncthreads();
     }
+#ifdef MC_SCOUT_TIMING
+    if (tid == 0 && tsc[5]) printf("[scout companion] %llu iterations, us each: fetch words %.2f, find tip + hash %.2f, look up %.2f, rest of eval %.2f, barriers + winner %.2f\n", tsc[5], tsc[0] * 0.01 / tsc[5], tsc[1] * 0.01 / tsc[5], tsc[2] * 0.01 / tsc[5], tsc[3] * 0.01 / tsc[5], tsc[4] * 0.01 / tsc[5]);
+#endif
     if (lane == 0) {
         atomicAdd(&box->hops, hops);
         atomicAdd(&box->nf, n_nf);
