@@ -785,6 +785,21 @@ static uint64_t regions_for(const mc_ctx *c, uint64_t slots)
     return ((want + step - 1) / step) * step;
 }
 
+// Slots for `keys` distinct k-mers at load `load` in a minimizer-bin table: never more than the pipeline has leaves for
+// (2^19, one region each) while the load stays under 0.6, and beyond that 2^g regions per leaf for the smallest g that
+// keeps it there -- every doubling of g doubles the merge kernel's sweeps over a leaf's records.
+static uint64_t mm_slots_for(const mc_ctx *c, double keys, double load)
+{
+    uint64_t want = (uint64_t)(keys / load);
+    const uint64_t one_leaf_each = 1ull << (SK_LEAVES_LG + c->sb);
+    if (c->mm_k && want > one_leaf_each) {
+        uint64_t cap_slots = one_leaf_each;
+        while (keys > 0.6 * (double)cap_slots) cap_slots <<= 1;
+        want = std::min(want, cap_slots);
+    }
+    return want;
+}
+
 static int table_alloc(mc_ctx *c, uint64_t n_regions)
 {
     if (n_regions < 1) n_regions = 1;
@@ -1174,7 +1189,7 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
         const double est = ((double)added + (double)(sample_leaves - merged) * (double)per_full * 1.5) * ((double)n_leaves / (double)sample_leaves) * 1.1 + 1024.0;
         const double load = c->mm_k ? 0.36 : 0.6;
         if (merged == sample_leaves && est <= (c->mm_k ? 0.5 : 0.7) * (double)c->n_slots()) return MC_OK;  // it fits: carry on
-        uint64_t want = regions_for(c, (uint64_t)(est / load));
+        uint64_t want = regions_for(c, c->mm_k ? mm_slots_for(c, est, load) : (uint64_t)(est / load));
         if (want <= c->n_regions) want = regions_for(c, c->n_slots() * 2);
         static const bool dbg = getenv("MC_INGEST_DEBUG") != nullptr;
         if (dbg) fprintf(stderr, "[count] table too small: %llu of %llu sampled leaves merged, %llu keys in them: %.0f M keys expected; new table %.1f GB\n",
@@ -1969,8 +1984,7 @@ int mc_create(const mc_config *cfg, mc_ctx **out)
         double load = 0.7;
         if (c->mm_k) load = std::min(0.36, std::max(0.25, 0.25 + 0.05 * std::log2((double)cfg->capacity_hint / (double)(64u << 20))));
         want_slots = std::max<uint64_t>(want_slots, (uint64_t)((double)cfg->capacity_hint / load));
-        const uint64_t one_leaf_each = 1ull << (SK_LEAVES_LG + c->sb);
-        if (c->mm_k && want_slots > one_leaf_each && (double)cfg->capacity_hint <= 0.6 * (double)one_leaf_each) want_slots = one_leaf_each;
+        if (c->mm_k) want_slots = std::max<uint64_t>(1ull << 22, mm_slots_for(c, (double)cfg->capacity_hint, load));
     }
     int rc = table_alloc(c, regions_for(c, want_slots));
     if (rc) {
