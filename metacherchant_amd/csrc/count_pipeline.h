@@ -31,7 +31,8 @@ constexpr int PT_ITEMS = 8;
 constexpr int PT_TILE = PT_THREADS * PT_ITEMS;      // 8192 windows / keys per tile
 constexpr int PT_MAX_BUCKETS = 512;                 // fan-out of one scatter level
 constexpr int PT_MAX_LEAVES2 = 1024;                // ... of the second level of the super-k-mer pipeline (k_sk2_scatter: an LDS cursor per leaf)
-constexpr int SK_LEAVES_LG = 19;                    // so up to 512 x 1024 leaves of one region each (8.6 G slots of 16 bytes = 34 GB of table)
+constexpr int PT_MAX_BUCKETS1_SK = 1024;             // level-1 buckets of the super-k-mer pipeline when 512 x 1024 leaves are not enough
+constexpr int SK_LEAVES_LG = 20;                    // so up to 1024 x 1024 leaves of one region each (4.3 G slots of 16 bytes = 69 GB of table)
 constexpr int P3_THREADS = 512;
 constexpr uint32_t REGION_SLOTS = 1u << MC_REGION_LG;  // == 1 << mc_ctx::sb (4096: a 64 KB image in LDS)
 constexpr uint32_t CURSOR1_STRIDE = 32;             // owner cursors of the multi-GPU split sit on separate 128-byte lines
@@ -535,7 +536,7 @@ static_assert(PT_MAX_LEAVES2 <= PT_THREADS, "one thread per leaf cursor");
 static_assert(P1W_SEGMENTS <= PT_THREADS && P1W_SEGMENTS >= PT_SEGMENTS, "k_sk2_scatter scans one segment count per thread");
 
 struct Sk1wLds {
-    uint32_t wcur[PT_MAX_BUCKETS];     // this workgroup's fill level of every bucket
+    uint32_t wcur[PT_MAX_BUCKETS1_SK];  // this workgroup's fill level of every bucket
     uint32_t starts[P1W_WAVES][24];    // per wave: bit b <-> "a read starts at position lo - 64 + b" (704 bits used)
     uint32_t brk[P1W_WAVES][20];       // per wave, as bytes: byte 2 + lane = that lane's 8 break bits; bytes 0,1 = 0; bytes 66.. = 0xFF
 };
@@ -562,7 +563,7 @@ __global__ void __launch_bounds__(P1W_THREADS, MC_P1W_MIN_WAVES) k_sk1w_extract(
 {
     __shared__ Sk1wLds L;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    for (uint32_t i = tid; i < PT_MAX_BUCKETS; i += P1W_THREADS) L.wcur[i] = 0;
+    for (uint32_t i = tid; i < PT_MAX_BUCKETS1_SK; i += P1W_THREADS) L.wcur[i] = 0;
     uint32_t *starts = L.starts[wv];
     uint32_t *brkw = L.brk[wv];
     uint8_t *brkb = reinterpret_cast<uint8_t *>(brkw);

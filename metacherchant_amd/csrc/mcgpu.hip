@@ -780,8 +780,10 @@ static uint64_t regions_for(const mc_ctx *c, uint64_t slots)
     uint64_t p2 = 1;
     while (p2 < want) p2 <<= 1;
     if (!c->mm_k || want <= 512) return p2;
-    uint64_t step = 512;
-    while (((want + step - 1) / step) * step > (step << (SK_LEAVES_LG - 9))) step <<= 1;  // keep <= 2^19 leaves of `step`-aligned size
+    // up to 2^19 regions: 512 level-1 buckets of up to 1024 leaves, regions in steps of 512; up to 2^20: 1024 buckets, steps of
+    // 1024; beyond: a leaf covers 2^g regions and the steps double with it
+    uint64_t step = ((want + 511) / 512) * 512 <= (512ull << 10) ? 512 : 1024;
+    while (((want + step - 1) / step) * step > (step << 10)) step <<= 1;
     return ((want + step - 1) / step) * step;
 }
 
@@ -1067,10 +1069,11 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
     uint64_t n_leaves = c->n_regions;
     uint32_t g = 0;
     const uint32_t max_b2 = n_records ? PT_MAX_LEAVES2 : PT_MAX_BUCKETS;  // (super-k-mer records: k_sk2_scatter; keys: k_p2_scatter)
-    while (n_leaves > (uint64_t)PT_MAX_BUCKETS * max_b2) { n_leaves >>= 1; g++; }
+    const uint32_t max_b1_big = n_records ? PT_MAX_BUCKETS1_SK : PT_MAX_BUCKETS;  // (1024 level-1 buckets only when 512 do not do)
+    while (n_leaves > (uint64_t)max_b1_big * max_b2) { n_leaves >>= 1; g++; }
     if ((n_leaves << g) != c->n_regions) return fail(c, MC_EINVAL, "internal: %llu table regions do not split into leaves", (unsigned long long)c->n_regions);
     if (n_leaves < 4) return fail(c, MC_EINVAL, "internal: partitioned counting needs at least 4 table regions");
-    uint64_t np1 = std::min<uint64_t>(n_leaves, PT_MAX_BUCKETS);
+    uint64_t np1 = std::min<uint64_t>(n_leaves, n_leaves > (uint64_t)PT_MAX_BUCKETS * max_b2 ? max_b1_big : (uint32_t)PT_MAX_BUCKETS);
     while (n_leaves % np1) np1--;  // (a power of two, or 512 dividing a multiple of 512)
     if (n_leaves / np1 > max_b2) return fail(c, MC_EINVAL, "internal: %llu leaves do not fit two scatter levels", (unsigned long long)n_leaves);
     pl->b1 = (uint32_t)np1;               // level-1 buckets
