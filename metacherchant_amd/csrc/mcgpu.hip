@@ -773,7 +773,7 @@ static int grid_for(uint64_t work_items, int block, int max_blocks = 256 * 8)
 
 // Number of regions for a table of at least `slots` slots.  Hash-prefix regions need a power of two; minimizer bins
 // are numbered by multiplication (count_pipeline.h mulhi32), so those tables come in steps of 512 regions (2 M slots,
-// 32 MB) -- times 2^g beyond 2^18 regions, where a leaf of the counting pipeline covers 2^g regions.
+// 32 MB), of 1024 beyond 2^19 regions -- times 2^g beyond 2^20, where a leaf of the counting pipeline covers 2^g regions.
 static uint64_t regions_for(const mc_ctx *c, uint64_t slots)
 {
     uint64_t want = std::max<uint64_t>((slots + (1ull << c->sb) - 1) >> c->sb, 1);
@@ -788,7 +788,7 @@ static uint64_t regions_for(const mc_ctx *c, uint64_t slots)
 }
 
 // Slots for `keys` distinct k-mers at load `load` in a minimizer-bin table: never more than the pipeline has leaves for
-// (2^19, one region each) while the load stays under 0.6, and beyond that 2^g regions per leaf for the smallest g that
+// (2^20, one region each) while the load stays under 0.6, and beyond that 2^g regions per leaf for the smallest g that
 // keeps it there -- every doubling of g doubles the merge kernel's sweeps over a leaf's records.
 static uint64_t mm_slots_for(const mc_ctx *c, double keys, double load)
 {
@@ -1064,7 +1064,7 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
             }
         }
     }
-    // leaves: the regions themselves up to 2^19 of them (2^18 when keys travel, not records), else 2^g regions per leaf;
+    // leaves: the regions themselves up to 2^20 of them (2^18 when keys travel, not records), else 2^g regions per leaf;
     // level-1 buckets: up to 512, each of m2 <= 1024 (512) leaves (regions_for made the numbers divide)
     uint64_t n_leaves = c->n_regions;
     uint32_t g = 0;
@@ -1982,7 +1982,7 @@ int mc_create(const mc_config *cfg, mc_ctx **out)
         // kernel's probe loops and the walk's lookups pay for every extra probe, while a sparser table only costs its
         // write-back: measured on the 10 M-read workload (364 M keys), count + BFS per step at load 0.60 / 0.51 / 0.43 /
         // 0.36: 39.1 / 31.5 / 29.2 / 28.6 ms.  So 0.25 up to 64 M keys, + 0.05 per doubling, 0.36 at most -- but never
-        // more than 2^19 regions while the load stays under 0.6: beyond that a leaf of the counting pipeline covers two
+        // more than 2^20 regions while the load stays under 0.6: beyond that a leaf of the counting pipeline covers two
         // regions and the merge kernel sweeps each leaf twice.
         double load = 0.7;
         if (c->mm_k) load = std::min(0.36, std::max(0.25, 0.25 + 0.05 * std::log2((double)cfg->capacity_hint / (double)(64u << 20))));
