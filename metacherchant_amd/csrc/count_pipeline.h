@@ -1424,6 +1424,369 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
     }
 }
 
+// =============================================================================================
+// P3 for super-k-mer records, one region per leaf, one segment per leaf (the headline case): k_p3_dedup.
+//
+// The records of a leaf come from the ~25 reads that cover each of its ~20 genome loci, and a read that covers a
+// locus's run of windows whole and without a sequencing error yields the SAME record as every other such read of its
+// strand: on configs[1] (30-fold depth, 1 % errors) 54 % of a leaf's records are copies of another one and they hold
+// 51 % of its windows (error-free reads: 82 %).  So the records are first merged in LDS -- a 1024-slot record table
+// per workgroup, claimed by a 16-bit fingerprint with one LDS CAS, verified word for word after a barrier (a record
+// whose fingerprint meets another record's, or that finds no slot in 8 probes, simply stays on its own: exact either
+// way) -- and only the DISTINCT records are expanded into windows, each window adding the record's number of copies.
+//
+// The region image is 12 bytes a slot instead of 16: key, and one word holding count (17 bits: a leaf adds < 2^16 to
+// a count that came in clamped to 32767, see DD_MAX_CAP) and, above it, WHICH window of which record slot supplies the
+// key's read pointer (0 = none; the pointer itself is worked out when the region goes back to HBM).  That word is
+// written by exactly one window -- the one whose addition carries the count across ptr_pick(key) + 1, which only one
+// addition does -- so a plain LDS atomic OR is enough; with ptr_tries > 1 (records of other ranks carry no pointer)
+// the next crossings try too, with a CAS.  Table layout, probing and results are those of k_p3_merge.
+constexpr uint32_t DD_SLOTS = 1024;      // record table of a leaf (a leaf holds ~250 distinct records on configs[1])
+constexpr uint32_t DD_PROBES = 8;
+constexpr uint32_t DD_CNT_BITS = 17, DD_CNT_MASK = (1u << DD_CNT_BITS) - 1;
+constexpr uint32_t DD_MAX_CAP = 2048;    // records per leaf: 32767 + 2048 * 16 windows < 2^17, and copies < 2^15
+constexpr uint32_t DD_NONE = 0xFFFFFFFFu, DD_OWNER = 0x80000000u;
+
+struct DedupLds {
+    uint64_t key[REGION_SLOTS];
+    uint32_t ca[REGION_SLOTS];          // count | (1 + (record slot << 4 | window)) << DD_CNT_BITS
+    uint4 drec[DD_SLOTS];               // {y, z, w of the record, fingerprint << 16 | 0x8000 | copies}; .w == 0: free
+    uint32_t dptr[DD_SLOTS];            // read pointer of the first window of one of the copies
+    uint8_t dq[P3_THREADS / 64][64 * SK_MAX_WINDOWS];  // per wave: window -> lane holding its record
+    uint32_t n_new, overflow, emit_cur;
+};
+
+// Linear probing for `key` in an array of REGION_SLOTS 64-bit keys at LDS byte address `base`, from slot `home` on: the
+// slot that holds the key when the loop ends, claimed with one LDS compare-and-swap per step when it was free (there is
+// no load first: a CAS that finds another key is that load).  The compiler's loop spends ~20 scalar instructions a step
+// on the bookkeeping of its exit conditions, and the slowest of 64 lanes decides the number of steps -- the scalar unit
+// was the busiest part of the CU in the merge kernel; this one spends 6.  *n_new_wave += keys the WAVE inserted;
+// *pending: lanes that found no slot in 1024 steps (their region is full).
+__device__ __forceinline__ uint32_t lds_probe_claim(uint32_t base, uint32_t home, uint64_t key, uint32_t *n_new_wave, unsigned long long *pending)
+{
+    uint32_t off = home * 8u, addr, cnt, t, it;
+    unsigned long long old, sv, hit, pend;
+    const unsigned long long empty = EMPTY_KEY;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b32 %[cnt], 0\n\t"
+        "s_movk_i32 %[it], 0x400\n"
+        "1:\n\t"
+        "v_add_u32 %[addr], %[base], %[off]\n\t"
+        "ds_cmpst_rtn_b64 %[old], %[addr], %[empty], %[key]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_eq_u64 vcc, %[old], %[empty]\n\t"
+        "v_cmp_eq_u64 %[hit], %[old], %[key]\n\t"
+        "s_bcnt1_i32_b64 %[t], vcc\n\t"
+        "s_add_u32 %[cnt], %[cnt], %[t]\n\t"
+        "s_or_b64 vcc, vcc, %[hit]\n\t"
+        "s_andn2_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execz 2f\n\t"
+        "v_add_u32 %[off], 8, %[off]\n\t"
+        "v_and_b32 %[off], %[wrap], %[off]\n\t"
+        "s_sub_u32 %[it], %[it], 1\n\t"
+        "s_cmp_lg_u32 %[it], 0\n\t"
+        "s_cbranch_scc1 1b\n"
+        "2:\n\t"
+        "s_mov_b64 %[pend], exec\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        : [off] "+v"(off), [old] "=&v"(old), [addr] "=&v"(addr), [sv] "=&s"(sv), [hit] "=&s"(hit), [cnt] "=&s"(cnt), [t] "=&s"(t),
+          [it] "=&s"(it), [pend] "=&s"(pend)
+        : [base] "s"(base), [empty] "v"(empty), [key] "v"(key), [wrap] "s"((uint32_t)(REGION_SLOTS * 8u - 8u))
+        : "vcc", "scc", "memory");
+    *n_new_wave += cnt;
+    *pending = pend;
+    return off >> 3;
+}
+
+__device__ __forceinline__ uint32_t dd_hash(uint32_t y, uint32_t z, uint32_t w)
+{
+    uint32_t h = (y ^ (z * 0x9E3779B1u));
+    h = (h ^ (h >> 15)) * 0x85EBCA6Bu;
+    h ^= w * 0xC2B2AE35u;
+    h = (h ^ (h >> 13)) * 0x27D4EB2Fu;
+    return h ^ (h >> 16);
+}
+
+template <bool VIRGIN>
+__global__ void __launch_bounds__(P3_THREADS) k_p3_dedup(const uint4 *__restrict__ leaf_recs, const uint32_t *__restrict__ leaf_ptrs,
+                                                         const uint32_t *__restrict__ leaf_counts, uint64_t seg_cap, uint32_t n_leaves,
+                                                         TableView t, uint32_t *leaf_state, uint32_t *leaf_new, uint32_t *any_failed,
+                                                         uint32_t solid_thr, unsigned long long *n_solid, int k, P3Emit emit,
+                                                         uint32_t ptr_tries, const uint32_t *lost)
+{
+    if (lost && *lost) return;
+    __shared__ DedupLds L;
+    const uint32_t tid = threadIdx.x, wv = tid >> 6, lane = tid & 63u;
+    const bool emitting = emit.recs != nullptr && solid_thr != 0;
+    if (tid == 0) L.emit_cur = emitting ? emit.counts[blockIdx.x] : 0u;
+    for (uint32_t i = tid; i < DD_SLOTS; i += P3_THREADS) L.drec[i].w = 0;
+    long long solid_delta = 0;
+    const uint32_t ptr_from = solid_thr >= 2 ? 1u : 0u;
+    const uint32_t kshift = 64u - 2u * (uint32_t)k;
+    uint8_t *dq = L.dq[wv];
+
+    const uint32_t key_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint64_t *)L.key;
+    uint32_t pick_tbl = 0;  // ptr_pick's choice for the four values of its two key bits
+    for (uint32_t r = 0; r < 4; r++) pick_tbl |= (ptr_pick((uint64_t)r, ptr_from, solid_thr) - ptr_from) << (2 * r);
+
+    // one batch of up to 64 records (one per lane: y, z, w; copies == 0: none) into the region image
+    uint32_t new_wave = 0;  // keys this WAVE inserted (the same number in every lane)
+    auto expand = [&](uint32_t y, uint32_t z, uint32_t w, uint32_t copies, bool hasptr, uint32_t slot) {
+        const uint32_t nw = copies ? (w >> 28) + 1u : 0u;
+        uint32_t incl = nw;
+#pragma unroll
+        for (uint32_t o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        const uint32_t excl = incl - nw, total = __shfl(incl, 63);
+        for (uint32_t i = 0; i < nw; i++) dq[excl + i] = (uint8_t)lane;
+        // the record's 46 bases top-aligned in three words; what a window needs besides them
+        const uint32_t d0 = __builtin_amdgcn_alignbit(w, z, 28), d1 = __builtin_amdgcn_alignbit(z, y, 28), d2 = y << 4;
+        const uint32_t meta = copies | (hasptr ? 0x8000u : 0u) | (slot << 16);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t base = 0; base < total; base += 64) {
+            const uint32_t widx = base + lane;
+            // (every lane takes part in the shuffles: a lane that is masked off hands out zeros)
+            const uint32_t src = widx < total ? dq[widx] : lane;
+            const uint32_t r0 = __shfl(d0, src), r1 = __shfl(d1, src), r2 = __shfl(d2, src), re = __shfl(excl, src), rm = __shfl(meta, src);
+            if (widx < total) {
+                const uint32_t j = widx - re, sh = 2u * j;  // (j <= 15)
+                const uint64_t top = ((uint64_t)r0 << 32) | r1;
+                const uint64_t fw = ((top << sh) | (uint64_t)((r2 >> 1) >> (31u - sh))) >> kshift, rc = rc_packed(fw, k);
+                const uint64_t key = rc < fw ? rc : fw;
+                unsigned long long pending;
+                const uint32_t s = lds_probe_claim(key_base, sk_home(key), key, &new_wave, &pending);
+                if (!((pending >> lane) & 1ull)) {
+                    const uint32_t cp = rm & 0x7FFFu;
+                    const uint32_t before = atomicAdd(&L.ca[s], cp) & DD_CNT_MASK;
+                    // the count an occurrence leaves its pointer at: kmer_device.h ptr_pick(key, ptr_from, solid_thr) + 1, from a table
+                    const uint32_t first = ptr_from + 1u + ((pick_tbl >> (2u * ((uint32_t)(key ^ (key >> 9) ^ (key >> 23)) & 3u))) & 3u);
+                    if ((rm & 0x8000u) && before < first + ptr_tries - 1u && before + cp >= first) {  // (one addition per key)
+                        const uint32_t occ = ((((rm >> 16) << 4) | j) + 1u) << DD_CNT_BITS;
+                        if (ptr_tries == 1) {
+                            atomicOr(&L.ca[s], occ);
+                        } else {
+                            for (int a = 0; a < 4; a++) {
+                                const uint32_t cur = L.ca[s];
+                                if ((cur >> DD_CNT_BITS) != 0 || atomicCAS(&L.ca[s], cur, cur | occ) == cur) break;
+                            }
+                        }
+                    }
+                } else {
+                    atomicExch(&L.overflow, 1u);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // (the queue is rewritten by the next batch)
+    };
+
+#ifdef MC_P3_TIMING
+    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memrealtime(), n_lv = 0;
+#define P3D_STAMP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); tph[i] += n_ - tl; tl = n_; } while (0)
+#else
+#define P3D_STAMP(i) do {} while (0)
+#endif
+    uint32_t st_nxt = 1u, n_nxt = 0;
+    uint4 pre_rec[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+    uint32_t pre_ptr[2] = {0, 0};
+    auto fetch = [&](uint32_t lf, uint32_t n) {  // this thread's first two records of leaf lf
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const uint32_t r = tid + (uint32_t)q * P3_THREADS;
+            if (r < n) {
+                pre_rec[q] = leaf_recs[(uint64_t)lf * seg_cap + r];
+                pre_ptr[q] = leaf_ptrs[(uint64_t)lf * seg_cap + r];
+            }
+        }
+    };
+    if (blockIdx.x < n_leaves) {
+        st_nxt = leaf_state[blockIdx.x];
+        n_nxt = min(leaf_counts[blockIdx.x], (uint32_t)seg_cap);
+        fetch(blockIdx.x, n_nxt);
+    }
+    __syncthreads();
+    for (uint32_t leaf = blockIdx.x; leaf < n_leaves; leaf += gridDim.x) {
+        const uint32_t st_cur = st_nxt, n0 = n_nxt;
+        const uint4 cur_rec[2] = {pre_rec[0], pre_rec[1]};
+        const uint32_t cur_ptr[2] = {pre_ptr[0], pre_ptr[1]};
+        const uint32_t nl = leaf + gridDim.x;
+        if (nl < n_leaves) {
+            st_nxt = leaf_state[nl];
+            n_nxt = min(leaf_counts[nl], (uint32_t)seg_cap);
+        }
+        if (st_cur) {  // uniform
+            if (nl < n_leaves) fetch(nl, n_nxt);
+            continue;
+        }
+        P3D_STAMP(7);
+        Slot *gs = t.slots + (uint64_t)leaf * REGION_SLOTS;
+        const uint4 *recs = leaf_recs + (uint64_t)leaf * seg_cap;
+        const uint32_t *ptrs = leaf_ptrs + (uint64_t)leaf * seg_cap;
+        int solid_before = 0;
+        for (uint32_t i = tid; i < REGION_SLOTS; i += P3_THREADS) {
+            if (VIRGIN) {
+                L.key[i] = EMPTY_KEY; L.ca[i] = 0;
+            } else {
+                const uint4 raw = *reinterpret_cast<const uint4 *>(gs + i);
+                L.key[i] = ((uint64_t)raw.y << 32) | raw.x;
+                L.ca[i] = min(raw.z, 32767u);  // (anything above reads the same: kmer_device.h table_get)
+                solid_before += solid_thr && raw.z >= solid_thr;  // (empty slots hold count 0)
+            }
+        }
+        if (tid == 0) { L.n_new = 0; L.overflow = 0; }
+        new_wave = 0;
+        // ---- the records into the record table, 1024 at a time (nearly always all of them)
+        for (uint32_t base = 0; base < n0; base += 2 * P3_THREADS) {  // uniform
+            uint4 rec[2];
+            uint32_t rptr[2], sl[2], hh[2];
+            bool have[2];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const uint32_t r = base + (uint32_t)q * P3_THREADS + tid;
+                have[q] = r < n0;
+                sl[q] = DD_NONE;
+                hh[q] = 0;
+                if (base == 0) { rec[q] = cur_rec[q]; rptr[q] = cur_ptr[q]; }
+                else if (have[q]) { rec[q] = recs[r]; rptr[q] = ptrs[r]; }
+                else { rec[q] = make_uint4(0, 0, 0, 0); rptr[q] = 0; }
+                if (have[q]) {
+                    const uint32_t h = dd_hash(rec[q].y, rec[q].z, rec[q].w), tag = (h & 0xFFFF0000u) | 0x8000u;
+                    hh[q] = h;
+                    uint32_t slot = h & (DD_SLOTS - 1);
+                    for (uint32_t p = 0; p < DD_PROBES; p++) {
+                        const uint32_t old = atomicCAS(&L.drec[slot].w, 0u, tag);
+                        if (old == 0) {  // claimed: this copy's words are what the others are compared with
+                            L.drec[slot].x = rec[q].y; L.drec[slot].y = rec[q].z; L.drec[slot].z = rec[q].w;
+                            L.dptr[slot] = rptr[q];
+                            sl[q] = slot | DD_OWNER;
+                            break;
+                        }
+                        if ((old & 0xFFFF8000u) == tag) { sl[q] = slot; break; }
+                        slot = (slot + 1) & (DD_SLOTS - 1);
+                    }
+                }
+            }
+            P3D_STAMP(0);
+            __syncthreads();
+            P3D_STAMP(1);
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                if (sl[q] != DD_NONE) {
+                    const uint32_t slot = sl[q] & ~DD_OWNER;
+                    if (sl[q] & DD_OWNER) {
+                        atomicAdd(&L.drec[slot].w, 1u);
+                    } else {
+                        const uint4 e = L.drec[slot];
+                        if (e.x == rec[q].y && e.y == rec[q].z && e.z == rec[q].w) {
+                            const uint32_t c = atomicAdd(&L.drec[slot].w, 1u) & 0x7FFFu;
+                            // one of the first copies leaves its pointer, not always the first (kmer_device.h ptr_pick: why)
+                            if (rptr[q] && (c == 1u + ((hh[q] >> 10) & 3u) || L.dptr[slot] == 0)) L.dptr[slot] = rptr[q];
+                        } else {
+                            sl[q] = DD_NONE;  // another record with this fingerprint
+                        }
+                    }
+                }
+                // records without a slot go through the window path as they are, one copy each, no pointer
+                const bool alone = have[q] && sl[q] == DD_NONE;
+                if (__ballot(alone)) expand(rec[q].y, rec[q].z, rec[q].w, alone ? 1u : 0u, false, 0u);
+            }
+        }
+        P3D_STAMP(2);
+        __syncthreads();
+        P3D_STAMP(3);
+        // ---- the distinct records into the region image
+        {   // a wave takes 128 slots of the record table; the ones in use (a quarter) are lined up first, so that a batch
+            // of 64 lanes holds 64 records
+            static_assert(DD_SLOTS == 2 * P3_THREADS, "two record slots per thread");
+            const uint32_t sa = wv * 128u + lane, sb = sa + 64u;
+            const bool ua = (L.drec[sa].w & 0x7FFFu) != 0, ub = (L.drec[sb].w & 0x7FFFu) != 0;
+            const unsigned long long ma = __ballot(ua), mb = __ballot(ub), lt = (1ull << lane) - 1ull;
+            const uint32_t na = (uint32_t)__popcll(ma), n_used = na + (uint32_t)__popcll(mb);
+            uint16_t *list = reinterpret_cast<uint16_t *>(dq);
+            if (ua) list[__popcll(ma & lt)] = (uint16_t)sa;
+            if (ub) list[na + (uint32_t)__popcll(mb & lt)] = (uint16_t)sb;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t s0 = lane < n_used ? list[lane] : DD_NONE, s1 = 64u + lane < n_used ? list[64u + lane] : DD_NONE;
+            __builtin_amdgcn_wave_barrier();  // (the list sits where the batches put their queue)
+#pragma unroll 1
+            for (uint32_t b = 0; b * 64u < n_used; b++) {  // uniform
+                const uint32_t slot = b ? s1 : s0;
+                uint4 e = make_uint4(0, 0, 0, 0);
+                bool hp = false;
+                if (slot != DD_NONE) { e = L.drec[slot]; hp = L.dptr[slot] != 0; }
+                expand(e.x, e.y, e.z, e.w & 0x7FFFu, hp, slot & (DD_SLOTS - 1));
+            }
+        }
+        if (nl < n_leaves) fetch(nl, n_nxt);  // the next leaf's first records: its count has long arrived
+        if (lane == 0 && new_wave) atomicAdd(&L.n_new, new_wave);
+        P3D_STAMP(4);
+        __syncthreads();
+        P3D_STAMP(5);
+        const bool ovf = L.overflow != 0;
+        if (!ovf) {
+            for (uint32_t i = tid; i < REGION_SLOTS; i += P3_THREADS) {
+                uint4 v;
+                const uint64_t kk = L.key[i];
+                const uint32_t c = L.ca[i];
+                uint32_t o = c >> DD_CNT_BITS;
+                v.x = (uint32_t)kk; v.y = (uint32_t)(kk >> 32);
+                v.z = c & DD_CNT_MASK;
+                if (o) { o -= 1u; v.w = ptr_advance(L.dptr[o >> 4], o & 15u); }
+                else if (VIRGIN) v.w = 0;
+                else v.w = reinterpret_cast<const uint32_t *>(gs + i)[3];  // the pointer the slot had
+                *reinterpret_cast<uint4 *>(gs + i) = v;
+                const bool solid = solid_thr && v.z >= solid_thr;
+                solid_delta += solid;
+                if (emitting) {  // (uniform; the loop's trip count is the same for every lane)
+                    const unsigned long long m = __ballot(solid);
+                    if (m) {
+                        uint32_t ebase = 0;
+                        const int leader = __ffsll((long long)m) - 1;
+                        if ((int)lane == leader) ebase = atomicAdd(&L.emit_cur, (uint32_t)__popcll(m));
+                        ebase = __shfl(ebase, leader);
+                        if (solid) {
+                            const uint32_t pos = ebase + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+                            if (pos < emit.seg_cap) {
+                                v.z = min(v.z, 32767u);
+                                emit.recs[(uint64_t)blockIdx.x * emit.seg_cap + pos] = v;
+                            } else {
+                                atomicExch(emit.lost, 1u);
+                            }
+                        }
+                    }
+                }
+            }
+            solid_delta -= solid_before;
+        } else if (VIRGIN) {  // nothing was there: leave a valid empty region behind
+            for (uint32_t i = tid; i < REGION_SLOTS; i += P3_THREADS) {
+                uint4 v; v.x = 0xFFFFFFFFu; v.y = 0xFFFFFFFFu; v.z = 0; v.w = 0;
+                *reinterpret_cast<uint4 *>(gs + i) = v;
+            }
+        }
+        for (uint32_t i = tid; i < DD_SLOTS; i += P3_THREADS) L.drec[i].w = 0;
+        if (tid == 0) {
+            if (!ovf) { leaf_state[leaf] = 1; leaf_new[leaf] = L.n_new; } else atomicExch(any_failed, 1u);
+        }
+        P3D_STAMP(6);
+        __syncthreads();
+#ifdef MC_P3_TIMING
+        n_lv++;
+#endif
+    }
+#ifdef MC_P3_TIMING
+    if (blockIdx.x == 7 && (tid == 0 || tid == 448)) printf("[p3d block 7 thread %u] %llu leaves, us per leaf: init+A1 %.2f wait %.2f A2 %.2f wait %.2f B %.2f wait %.2f writeback %.2f wait+next %.2f\n", tid, n_lv, tph[0] * 0.01 / n_lv, tph[1] * 0.01 / n_lv, tph[2] * 0.01 / n_lv, tph[3] * 0.01 / n_lv, tph[4] * 0.01 / n_lv, tph[5] * 0.01 / n_lv, tph[6] * 0.01 / n_lv, tph[7] * 0.01 / n_lv);
+#endif
+    if (solid_thr) wave_add_ull(n_solid, (unsigned long long)solid_delta);  // (two's complement: deltas may be negative)
+    if (emitting) {
+        __syncthreads();
+        if (tid == 0) emit.counts[blockIdx.x] = (uint64_t)L.emit_cur < emit.seg_cap ? L.emit_cur : (uint32_t)emit.seg_cap;
+    }
+}
+
 // n_used += sum(leaf_new): one atomic per workgroup instead of one per region on a single hot address
 __global__ void k_sum_leaf_new(const uint32_t *__restrict__ leaf_new, uint32_t n, unsigned long long *n_used)
 {

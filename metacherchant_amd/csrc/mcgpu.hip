@@ -1156,14 +1156,26 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
         emit.counts = P.emit_counts;
         emit.seg_cap = std::min<uint64_t>(P.a_recs_cap / (uint64_t)p3_grid, 0xFFFFFFF0ull);
     }
-    auto launch_p3 = [&] {
-        const int virgin = c->virgin ? 1 : 0;
-#define P3_ARGS lk, lh, lc, lcap, lseg, (uint32_t)n_leaves, pl.g, c->view(), virgin, P.leaf_state, P.leaf_new, P.flags + 1, \
+    // super-k-mer records, one region and one segment per leaf: the merge kernel that merges identical records first
+    // (count_pipeline.h k_p3_dedup; MC_P3_DEDUP=0: the general kernel)
+    static const bool dedup_on = [] { const char *e = getenv("MC_P3_DEDUP"); return !(e && !strcmp(e, "0")); }();
+    auto launch_p3_n = [&](uint32_t leaves, int grid, int virgin) {
+#define P3_ARGS lk, lh, lc, lcap, lseg, leaves, pl.g, c->view(), virgin, P.leaf_state, P.leaf_new, P.flags + 1, \
                 (uint32_t)(c->solid_tracked ? c->cov_hint : 0), c->d_ctr + 6, k, emit, c->ptr_tries, P.flags
-        if (pl.sk) hipLaunchKernelGGL(k_p3_merge<true>, dim3(p3_grid), dim3(P3_THREADS), 0, c->stream, P3_ARGS);
-        else hipLaunchKernelGGL(k_p3_merge<false>, dim3(p3_grid), dim3(P3_THREADS), 0, c->stream, P3_ARGS);
+#define P3D_ARGS static_cast<const uint4 *>(lk), lh, lc, lcap, leaves, c->view(), P.leaf_state, P.leaf_new, P.flags + 1, \
+                 (uint32_t)(c->solid_tracked ? c->cov_hint : 0), c->d_ctr + 6, k, emit, c->ptr_tries, P.flags
+        if (pl.sk && pl.g == 0 && lseg == 1 && lcap <= DD_MAX_CAP && dedup_on) {
+            if (virgin) hipLaunchKernelGGL(k_p3_dedup<true>, dim3(grid), dim3(P3_THREADS), 0, c->stream, P3D_ARGS);
+            else hipLaunchKernelGGL(k_p3_dedup<false>, dim3(grid), dim3(P3_THREADS), 0, c->stream, P3D_ARGS);
+        } else if (pl.sk) {
+            hipLaunchKernelGGL(k_p3_merge<true>, dim3(grid), dim3(P3_THREADS), 0, c->stream, P3_ARGS);
+        } else {
+            hipLaunchKernelGGL(k_p3_merge<false>, dim3(grid), dim3(P3_THREADS), 0, c->stream, P3_ARGS);
+        }
 #undef P3_ARGS
+#undef P3D_ARGS
     };
+    auto launch_p3 = [&] { launch_p3_n((uint32_t)n_leaves, p3_grid, c->virgin ? 1 : 0); };
     uint32_t flags[3] = {0, 0, 0};
     unsigned long long n_spill = 0;
     const bool virgin0 = c->virgin;
@@ -1214,14 +1226,7 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
         launch_p2();
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(c->ev_t[2], c->stream));
-        {
-            const int virgin = 1;
-#define P3_ARGS lk, lh, lc, lcap, lseg, (uint32_t)K, pl.g, c->view(), virgin, P.leaf_state, P.leaf_new, P.flags + 1, \
-                (uint32_t)(c->solid_tracked ? c->cov_hint : 0), c->d_ctr + 6, k, emit, c->ptr_tries, P.flags
-            if (pl.sk) hipLaunchKernelGGL(k_p3_merge<true>, dim3((unsigned)K), dim3(P3_THREADS), 0, c->stream, P3_ARGS);
-            else hipLaunchKernelGGL(k_p3_merge<false>, dim3((unsigned)K), dim3(P3_THREADS), 0, c->stream, P3_ARGS);
-#undef P3_ARGS
-        }
+        launch_p3_n((uint32_t)K, (int)K, 1);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(flags, P.flags, sizeof flags, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
