@@ -39,6 +39,9 @@ constexpr uint32_t SCOUT_BUDGET0 = 1024;              // levels of the first sco
 #define MC_TEAM_MAX 2   // waves that follow different candidate reads of one walker's hop (measured on configs[1], BFS phase: 1 wave 14.0 ms,
                         // 2 waves 11.2, 4 waves 11.8, 8 waves 14.3: the longer hops of a larger team cost more in lookups issued by one CU than they save)
 #endif
+#ifndef MC_SCOUT_WARM
+#define MC_SCOUT_WARM 0   // a hop's lanes touch the read-store lines their pointers name (the next hop starts at one of them)
+#endif
 #ifndef MC_SCOUT_PROBES
 #define MC_SCOUT_PROBES 4   // slots a scout's lookup requests at once
 #endif
@@ -627,9 +630,26 @@ __device__ __forceinline__ void scout_eval(const SolidView &t, uint64_t *sw, uin
         lookups++;
     }
     SC_STAMP(2);
+    // One of these pointers is where the next hop starts, and its first act is to fetch the read store's words around
+    // it: every lane asks for the lines around ITS pointer now, so that they are on their way into the caches while this
+    // hop is evaluated (the values are not used: `warm` only keeps the loads alive until the hop's end).
+    uint64_t warm = 0;
+#if MC_SCOUT_WARM
+    if (aux) {
+        uint32_t sp_;
+        const uint64_t plo = ptr_decode(aux, &sp_);
+        if (plo < t.reads_bases) {
+            const uint64_t w0 = (plo > 128 ? plo - 128 : 0) >> 5;
+            warm = t.reads[min(w0, last_word)] ^ t.reads[min(w0 + 8, last_word)] ^ t.reads[min(w0 + 15, last_word)];
+        }
+    }
+#endif
     const unsigned long long solid_m = __ballot(ok && cov >= min_cov);
     const uint32_t m = solid_m == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~solid_m);
-    if (m == 0) return;
+    if (m == 0) {
+        asm volatile("" ::"v"(warm));
+        return;
+    }
     // the m new bases, first on top: what follows the occurrence (precedes it, complemented)
     uint64_t e_hi, e_lo;
     if (fwd) {
@@ -651,6 +671,7 @@ __device__ __forceinline__ void scout_eval(const SolidView &t, uint64_t *sw, uin
         other = !(at <= here && here < at + sp);
     }
     R.m = m; R.why = 0; R.e_hi = e_hi; R.e_lo = e_lo; R.K = K; R.aux = aux; R.other = other;
+    asm volatile("" ::"v"(warm));
     SC_STAMP(3);
 }
 

@@ -528,6 +528,9 @@ __device__ __forceinline__ void sk_emit(SkCursors &C, uint32_t d, const uint4 &r
 #ifndef MC_P1W_PREFETCH_WORDS
 #define MC_P1W_PREFETCH_WORDS 1
 #endif
+#ifndef MC_P1W_COMPACT
+#define MC_P1W_COMPACT 1   // records are built one per lane from a queue of their starts (0: every lane loops over its own starts)
+#endif
 constexpr int P1W_THREADS = 512;
 constexpr int P1W_WAVES = P1W_THREADS / 64;
 constexpr uint32_t P1W_TILE = 62 * PT_ITEMS;   // base positions per wave tile
@@ -535,10 +538,15 @@ constexpr int P1W_SEGMENTS = 1024;             // workgroups of the launch = seg
 static_assert(PT_MAX_LEAVES2 <= PT_THREADS, "one thread per leaf cursor");
 static_assert(P1W_SEGMENTS <= PT_THREADS && P1W_SEGMENTS >= PT_SEGMENTS, "k_sk2_scatter scans one segment count per thread");
 
-struct Sk1wLds {
+struct alignas(16) Sk1wLds {
     uint32_t wcur[PT_MAX_BUCKETS1_SK];  // this workgroup's fill level of every bucket
     uint32_t starts[P1W_WAVES][24];    // per wave: bit b <-> "a read starts at position lo - 64 + b" (704 bits used)
     uint32_t brk[P1W_WAVES][20];       // per wave, as bytes: byte 2 + lane = that lane's 8 break bits; bytes 0,1 = 0; bytes 66.. = 0xFF
+#if MC_P1W_COMPACT
+    uint64_t wst[P1W_WAVES][24];       // per wave: the tile's words (word 0 holds base lo - 7)
+    uint32_t hst[P1W_WAVES][64 * PT_ITEMS];  // per wave: minimizer hash of every window of the tile
+    uint16_t squeue[P1W_WAVES][64 * PT_ITEMS];  // per wave: the windows that start a record, in order
+#endif
 };
 
 __device__ __forceinline__ uint32_t wave_from_next(uint32_t x)
@@ -567,6 +575,12 @@ __global__ void __launch_bounds__(P1W_THREADS, MC_P1W_MIN_WAVES) k_sk1w_extract(
     uint32_t *starts = L.starts[wv];
     uint32_t *brkw = L.brk[wv];
     uint8_t *brkb = reinterpret_cast<uint8_t *>(brkw);
+#if MC_P1W_COMPACT
+    uint64_t *wst = L.wst[wv];
+    uint32_t *hst = L.hst[wv];
+    uint16_t *squeue = L.squeue[wv];
+    if (lane < 24) wst[lane] = 0;
+#endif
     if (lane < 20) brkw[lane] = lane == 0 ? 0u : 0xFFFFFFFFu;  // (bytes 2 .. 65 are rewritten by every tile)
     __syncthreads();
     const int w = k - SK_M + 1;                       // SK_M-mers per window (9 .. 17)
@@ -713,6 +727,62 @@ __global__ void __launch_bounds__(P1W_THREADS, MC_P1W_MIN_WAVES) k_sk1w_extract(
         }
 
         // ---- records: a run is cut every SK_MAX_WINDOWS windows, counted from its first window
+#if MC_P1W_COMPACT
+        // A lane holds 0-4 record starts among its 8 positions, and a loop over them runs as long as the busiest lane's
+        // (about 4 rounds of ~70 instructions for 0.9 records per lane).  Instead the tile's ~55 starts are lined up --
+        // a lane writes the window numbers of its starts into the wave's queue at its prefix count -- and lane i builds
+        // the i-th record of the tile from what the wave put in LDS for that: the tile's words, the minimizer hash of
+        // every window, the break bitmap.
+        {
+            const uint32_t cnt = (uint32_t)__builtin_popcount(start_bits);
+            uint32_t incl = cnt;
+#pragma unroll
+            for (uint32_t o = 1; o < 64; o <<= 1) {
+                const uint32_t v = __shfl_up(incl, o);
+                if (lane >= o) incl += v;
+            }
+            const uint32_t total = __shfl(incl, 63);
+            uint32_t at = incl - cnt;
+            for (uint32_t todo = start_bits; todo; todo &= todo - 1) squeue[at++] = (uint16_t)(lane * PT_ITEMS + (uint32_t)__builtin_ctz(todo));
+            const uint32_t r7 = (uint32_t)(((int64_t)lo - 7) & 31);             // (lo - 7) = 32 * wbase + r7
+            const uint32_t idx0 = (r7 + lane * PT_ITEMS) >> 5;                  // my W0 is word wbase + idx0
+            wst[idx0] = W0; wst[idx0 + 1] = W1; wst[idx0 + 2] = W2;              // (lanes that hold the same word write the same value)
+            *reinterpret_cast<uint4 *>(&hst[lane * PT_ITEMS]) = make_uint4(hmin[0], hmin[1], hmin[2], hmin[3]);
+            *reinterpret_cast<uint4 *>(&hst[lane * PT_ITEMS + 4]) = make_uint4(hmin[4], hmin[5], hmin[6], hmin[7]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t i = lane; i < total; i += 64) {
+                const uint32_t wi = squeue[i];                                   // window number in the tile
+                const uint32_t b0 = 17u + wi;                                    // break bits of the 15 windows behind it
+                const uint32_t ahead = __builtin_amdgcn_alignbit(brkw[(b0 >> 5) + 1], brkw[b0 >> 5], b0 & 31u) & 0x7FFFu;
+                const uint32_t n = ahead ? (uint32_t)__builtin_ctz(ahead) + 1u : SK_MAX_WINDOWS;
+                const uint32_t len = n + (uint32_t)k - 1;  // bases of the run (<= 46)
+                // X0:X1 = the 64 bases from the run's first base on; the record keeps the first `len`
+                const uint32_t q = wi + 7u + r7, wq = q >> 5, sh = 2u * (q & 31u);
+                const uint64_t A = wst[wq], B = wst[wq + 1], C = wst[wq + 2];
+                const uint64_t X0 = (A << sh) | ((B >> 1) >> (63u - sh)), X1 = (B << sh) | ((C >> 1) >> (63u - sh));
+                uint64_t hi = X0 >> 4;                                                  // bases 0 .. 29
+                uint32_t tail = (uint32_t)(((X0 & 0xFull) << 28) | (X1 >> 36));         // bases 30 .. 45
+                if (len <= 30) { hi &= ~0ull << (60 - 2 * len); tail = 0; }
+                else tail &= len >= 46 ? ~0u : ~0u << (2 * (46 - len));
+                hi |= (uint64_t)(n - 1) << 60;
+                const uint32_t hsel = hst[wi];
+                const uint32_t bin = sk_bin(hsel);
+                const uint32_t d = OWNERS ? sk_owner(hsel, np1) : mulhi32(bin, np1);
+                uint4 rec;
+                rec.x = bin; rec.y = tail; rec.z = (uint32_t)hi; rec.w = (uint32_t)(hi >> 32);
+                const uint64_t dst = atomicAdd(&L.wcur[d], 1u);
+                if (dst < cap) {
+                    const uint64_t o = seg_base + (uint64_t)d * bucket_stride + dst;
+                    out_recs[o] = rec;
+                    out_ptrs[o] = ptr_base == ~0ull ? 0u : ptr_encode(ptr_base + lo + wi);
+                } else {
+                    sk_spill_push(sp, rec);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();  // (the next tile rewrites the staging area)
+        }
+#else
         for (uint32_t todo = start_bits; todo; todo &= todo - 1) {
             const uint32_t j = (uint32_t)__builtin_ctz(todo);
             const uint32_t ahead = (uint32_t)(bw >> (17 + j)) & 0x7FFFu;  // breaks among the next 15 windows
@@ -742,6 +812,7 @@ __global__ void __launch_bounds__(P1W_THREADS, MC_P1W_MIN_WAVES) k_sk1w_extract(
                 sk_spill_push(sp, rec);
             }
         }
+#endif
     }
     __syncthreads();
     for (uint32_t d = tid; d < np1; d += P1W_THREADS)  // how much of its segment of every bucket this workgroup filled
@@ -1437,22 +1508,26 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
 //
 // The region image is 12 bytes a slot instead of 16: key, and one word holding count (17 bits: a leaf adds < 2^16 to
 // a count that came in clamped to 32767, see DD_MAX_CAP) and, above it, WHICH window of which record slot supplies the
-// key's read pointer (0 = none; the pointer itself is worked out when the region goes back to HBM).  That word is
-// written by exactly one window -- the one whose addition carries the count across ptr_pick(key) + 1, which only one
-// addition does -- so a plain LDS atomic OR is enough; with ptr_tries > 1 (records of other ranks carry no pointer)
-// the next crossings try too, with a CAS.  Table layout, probing and results are those of k_p3_merge.
+// key's read pointer (0 = none).  That field is written by exactly one window -- the one whose addition carries the
+// count across ptr_pick(key) + 1, which only one addition does -- so a plain LDS atomic OR is enough; with ptr_tries
+// > 1 (records of other ranks carry no pointer) the next crossings try too, with a CAS.  The pointer itself is worked
+// out when the region goes back to HBM: a record slot keeps the pointers of its first three copies, and bits of the
+// key choose among them (with one pointer per record all k-mers of a stretch led into the same read, and a scout that
+// had used that read up found no other: + 1 ms of walk).  Table layout, probing and results are those of k_p3_merge.
 constexpr uint32_t DD_SLOTS = 1024;      // record table of a leaf (a leaf holds ~250 distinct records on configs[1])
 constexpr uint32_t DD_PROBES = 8;
 constexpr uint32_t DD_CNT_BITS = 17, DD_CNT_MASK = (1u << DD_CNT_BITS) - 1;
 constexpr uint32_t DD_MAX_CAP = 2048;    // records per leaf: 32767 + 2048 * 16 windows < 2^17, and copies < 2^15
 constexpr uint32_t DD_NONE = 0xFFFFFFFFu, DD_OWNER = 0x80000000u;
+constexpr uint32_t DD_DQ = 496;          // windows a wave queues at a time (64 records have up to 1024; a batch usually ~300)
 
 struct DedupLds {
     uint64_t key[REGION_SLOTS];
     uint32_t ca[REGION_SLOTS];          // count | (1 + (record slot << 4 | window)) << DD_CNT_BITS
     uint4 drec[DD_SLOTS];               // {y, z, w of the record, fingerprint << 16 | 0x8000 | copies}; .w == 0: free
-    uint32_t dptr[DD_SLOTS];            // read pointer of the first window of one of the copies
-    uint8_t dq[P3_THREADS / 64][64 * SK_MAX_WINDOWS];  // per wave: window -> lane holding its record
+    uint32_t dptr[3][DD_SLOTS];         // read pointers (of the first window) of the slot's first three copies that carry one;
+                                        // a window takes one of them, chosen by bits of its key
+    uint8_t dq[P3_THREADS / 64][DD_DQ];  // per wave: window -> lane holding its record, DD_DQ windows at a time
     uint32_t n_new, overflow, emit_cur;
 };
 
@@ -1541,18 +1616,20 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_dedup(const uint4 *__restrict
             if (lane >= o) incl += v;
         }
         const uint32_t excl = incl - nw, total = __shfl(incl, 63);
-        for (uint32_t i = 0; i < nw; i++) dq[excl + i] = (uint8_t)lane;
         // the record's 46 bases top-aligned in three words; what a window needs besides them
         const uint32_t d0 = __builtin_amdgcn_alignbit(w, z, 28), d1 = __builtin_amdgcn_alignbit(z, y, 28), d2 = y << 4;
         const uint32_t meta = copies | (hasptr ? 0x8000u : 0u) | (slot << 16);
+        for (uint32_t w0 = 0; w0 < total; w0 += DD_DQ) {  // uniform; nearly always one round
+        const uint32_t wend = min(total, w0 + DD_DQ);
+        for (uint32_t i = max(excl, w0); i < min(excl + nw, wend); i++) dq[i - w0] = (uint8_t)lane;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        for (uint32_t base = 0; base < total; base += 64) {
+        for (uint32_t base = w0; base < wend; base += 64) {
             const uint32_t widx = base + lane;
             // (every lane takes part in the shuffles: a lane that is masked off hands out zeros)
-            const uint32_t src = widx < total ? dq[widx] : lane;
+            const uint32_t src = widx < wend ? dq[widx - w0] : lane;
             const uint32_t r0 = __shfl(d0, src), r1 = __shfl(d1, src), r2 = __shfl(d2, src), re = __shfl(excl, src), rm = __shfl(meta, src);
-            if (widx < total) {
+            if (widx < wend) {
                 const uint32_t j = widx - re, sh = 2u * j;  // (j <= 15)
                 const uint64_t top = ((uint64_t)r0 << 32) | r1;
                 const uint64_t fw = ((top << sh) | (uint64_t)((r2 >> 1) >> (31u - sh))) >> kshift, rc = rc_packed(fw, k);
@@ -1580,7 +1657,8 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_dedup(const uint4 *__restrict
                 }
             }
         }
-        __builtin_amdgcn_wave_barrier();  // (the queue is rewritten by the next batch)
+        __builtin_amdgcn_wave_barrier();  // (the queue is rewritten by the next round or batch)
+        }
     };
 
 #ifdef MC_P3_TIMING
@@ -1660,7 +1738,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_dedup(const uint4 *__restrict
                         const uint32_t old = atomicCAS(&L.drec[slot].w, 0u, tag);
                         if (old == 0) {  // claimed: this copy's words are what the others are compared with
                             L.drec[slot].x = rec[q].y; L.drec[slot].y = rec[q].z; L.drec[slot].z = rec[q].w;
-                            L.dptr[slot] = rptr[q];
+                            L.dptr[0][slot] = 0; L.dptr[1][slot] = 0; L.dptr[2][slot] = 0;
                             sl[q] = slot | DD_OWNER;
                             break;
                         }
@@ -1676,17 +1754,25 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_dedup(const uint4 *__restrict
             for (int q = 0; q < 2; q++) {
                 if (sl[q] != DD_NONE) {
                     const uint32_t slot = sl[q] & ~DD_OWNER;
-                    if (sl[q] & DD_OWNER) {
-                        atomicAdd(&L.drec[slot].w, 1u);
-                    } else {
+                    bool same = true;
+                    if (!(sl[q] & DD_OWNER)) {
                         const uint4 e = L.drec[slot];
-                        if (e.x == rec[q].y && e.y == rec[q].z && e.z == rec[q].w) {
-                            const uint32_t c = atomicAdd(&L.drec[slot].w, 1u) & 0x7FFFu;
-                            // one of the first copies leaves its pointer, not always the first (kmer_device.h ptr_pick: why)
-                            if (rptr[q] && (c == 1u + ((hh[q] >> 10) & 3u) || L.dptr[slot] == 0)) L.dptr[slot] = rptr[q];
-                        } else {
-                            sl[q] = DD_NONE;  // another record with this fingerprint
+                        same = e.x == rec[q].y && e.y == rec[q].z && e.z == rec[q].w;
+                    }
+                    if (same) {
+                        // the first three copies that carry a read pointer are remembered (the occurrences of neighbouring
+                        // k-mers arrive in the same order: kmer_device.h ptr_pick says why one pointer per record is too few)
+                        const uint32_t c = atomicAdd(&L.drec[slot].w, 1u) & 0x7FFFu;
+                        if (rptr[q]) {
+                            if (c < 3u) {
+                                L.dptr[c][slot] = rptr[q];
+                            } else if (ptr_tries > 1) {  // (copies of other ranks carry none: a later one fills a field that stayed empty)
+                                for (uint32_t f = 0; f < 3u; f++)
+                                    if (L.dptr[f][slot] == 0) { L.dptr[f][slot] = rptr[q]; break; }
+                            }
                         }
+                    } else {
+                        sl[q] = DD_NONE;  // another record with this fingerprint
                     }
                 }
                 // records without a slot go through the window path as they are, one copy each, no pointer
@@ -1717,7 +1803,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_dedup(const uint4 *__restrict
                 const uint32_t slot = b ? s1 : s0;
                 uint4 e = make_uint4(0, 0, 0, 0);
                 bool hp = false;
-                if (slot != DD_NONE) { e = L.drec[slot]; hp = L.dptr[slot] != 0; }
+                if (slot != DD_NONE) { e = L.drec[slot]; hp = (L.dptr[0][slot] | L.dptr[1][slot] | L.dptr[2][slot]) != 0; }
                 expand(e.x, e.y, e.z, e.w & 0x7FFFu, hp, slot & (DD_SLOTS - 1));
             }
         }
@@ -1735,7 +1821,13 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_dedup(const uint4 *__restrict
                 uint32_t o = c >> DD_CNT_BITS;
                 v.x = (uint32_t)kk; v.y = (uint32_t)(kk >> 32);
                 v.z = c & DD_CNT_MASK;
-                if (o) { o -= 1u; v.w = ptr_advance(L.dptr[o >> 4], o & 15u); }
+                if (o) {  // the pointer of one of the record's copies, by bits of the key (one of three where ptr_pick has four)
+                    o -= 1u;
+                    uint32_t f = ((uint32_t)(kk ^ (kk >> 9) ^ (kk >> 23)) & 3u) % 3u, p0 = L.dptr[f][o >> 4];
+                    if (p0 == 0) { f = f == 2u ? 0u : f + 1u; p0 = L.dptr[f][o >> 4]; }
+                    if (p0 == 0) { f = f == 2u ? 0u : f + 1u; p0 = L.dptr[f][o >> 4]; }
+                    v.w = ptr_advance(p0, o & 15u);
+                }
                 else if (VIRGIN) v.w = 0;
                 else v.w = reinterpret_cast<const uint32_t *>(gs + i)[3];  // the pointer the slot had
                 *reinterpret_cast<uint4 *>(gs + i) = v;

@@ -94,6 +94,18 @@ for it in range(iters):
             kw["trim"] = True; extra += ["--trim"]
         if rng.integers(0, 3) == 0:
             kw["merge"] = True; extra += ["--merge"]
+        hic_comments = None
+        if rng.integers(0, 3) == 0:  # --hicseq: more seeds with --merge, only the directory names without it (EnvironmentFinderMain.java:149)
+            hicf = os.path.join(tmp, "hic.fasta")
+            n_hic = n_seq + int(rng.integers(0, 6))
+            with open(hicf, "w") as f:
+                for hi_ in range(n_hic):
+                    a = int(rng.integers(0, contigs * clen - 200))
+                    f.write(">hic%d of %d\n%s\n" % (hi_, it, po.decode(genome[a:a + int(rng.integers(k, 150))])))
+            hic_seqs, hic_comments = ho.rich_fasta_read(hicf)
+            extra += ["--hicseq", hicf]
+            if kw.get("merge"):
+                kw["hic_seqs"] = hic_seqs
         cl = int(rng.choice([1, 10, 50])); kw["chunk_length"] = cl; extra += ["--chunklength", str(cl)]
         if hashed:
             extra += ["--hash", hname] + ([] if k > 31 else ["--forcehash"])
@@ -119,6 +131,8 @@ for it in range(iters):
             raise SystemExit("it %d: the CLI did not finish; its log ends:\n%s" % (it, err[-1500:]))
         assert p.returncode == 0, (it, cmd, p.stderr[-2000:])
         seqs, comments = ho.rich_fasta_read(seq)
+        if hic_comments is not None:
+            comments = hic_comments
         t, res = oracle_run(files, k, mode, seqs, comments, want, **kw)
         assert "Hashtable size: %d kmers" % t.size() in p.stderr, (it, t.size(), p.stderr[-500:])
         _assert_same_tree(res, out, want)

@@ -1,4 +1,6 @@
 """Shared input builders for the parity tests (seeded, small enough for the CPU oracle)."""
+import os
+
 import numpy as np
 
 from oracle import pyoracle as po
@@ -65,3 +67,23 @@ def assert_bfs_equal(got, want):
             raise AssertionError("%s: %d vs %d entries, first differences at %s: got %s want %s (dist %s, n=%d)" % (
                 f, len(g), len(w), idx, g[idx], w[idx], np.asarray(want["dist"])[idx], len(w)))
     assert got["levels"] == want["levels"]
+
+
+def hic_case_reads(ref_example_dir, n_loci=40):
+    """Reads for the --hicseq tests (the reference's own test, tests/EnvironmentFinderMainTest.java:23-45, counts WGS reads
+    that are not shipped): the example's plasmid (first 30 kb) tiled without errors at 7.5-fold coverage, which holds the
+    --seq gene; and, since the shipped Hi-C sequences share no 31-mer with the plasmid, `n_loci` of them each inside a
+    locus of its own (80 random bases on either side), tiled at up to 10-fold coverage that thins out towards the locus
+    ends, so that a walk from a Hi-C seed runs into the flanks and stops where the coverage falls under the threshold."""
+    import numpy as np
+    from oracle import host_oracle as ho
+    from oracle import pyoracle as po
+    plasmid = ho.read_fasta_reads(os.path.join(ref_example_dir, "salmonella_pls.fasta"))[0][:30000]
+    reads = [plasmid[s:s + 150] for s in range(0, len(plasmid) - 150 + 1, 20)]
+    hic, _ = ho.rich_fasta_read(os.path.join(ref_example_dir, "selected_reads.fasta"))
+    rng = np.random.default_rng(2024)
+    for i in range(n_loci):
+        h = hic[i * (len(hic) // n_loci)]
+        locus = po.decode(rng.integers(0, 4, 80).astype(np.uint8)) + h + po.decode(rng.integers(0, 4, 80).astype(np.uint8))
+        reads += [locus[s:s + 100] for s in range(0, len(locus) - 100 + 1, 10)]
+    return reads

@@ -141,6 +141,73 @@ def test_cli_hash_key_modes(cli, tmp_path, k, hash_name, mode):
     _assert_same_tree(res, out, want)
 
 
+def _write_reads_fasta(path, reads):
+    with open(path, "w") as f:
+        for i, r in enumerate(reads):
+            f.write(">r%d\n%s\n" % (i, r))
+
+
+def test_cli_merge_with_hicseq(cli, golden_dir, tmp_path):
+    """The reference's integration test, tests/EnvironmentFinderMainTest.java:23-45: --merge true --hicseq selected_reads.fasta
+    --maxradius ... --bothdirs False --chunklength 10 (its WGS reads are not shipped: tests/helpers.py hic_case_reads).  The
+    1047 Hi-C sequences seed the walk after the --seq sequence (src/algo/OneSequenceCalculator.java:181-191)."""
+    from tests.helpers import hic_case_reads
+    g = os.path.join(golden_dir, "ref_example")
+    r1 = str(tmp_path / "wgs.fasta")
+    _write_reads_fasta(r1, hic_case_reads(g))
+    seq, hicf = os.path.join(g, "seq.fasta"), os.path.join(g, "selected_reads.fasta")
+    out, want = str(tmp_path / "out"), str(tmp_path / "want")
+    cmd = [cli, "--k", "31", "--coverage", "5", "--reads", r1, "--seq", seq, "--output", out, "--work-dir", str(tmp_path / "wd"),
+           "--maxradius", "100000", "--bothdirs", "False", "--chunklength", "10", "--merge", "true", "--hicseq", hicf, "--force"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr
+    assert "hicSequences = 1047" in p.stderr
+    assert "Finding single environment for 1 sequences" in p.stderr
+    seqs, comments = ho.rich_fasta_read(seq)
+    hic, _ = ho.rich_fasta_read(hicf)
+    _, res = _oracle_run([r1], 31, po.KEY_PACKED, seqs, comments, want, coverage=5, max_radius=100000, bothdirs=False,
+                         chunk_length=10, merge=True, hic_seqs=hic)
+    _assert_same_tree(res, out, want)
+    files = res[os.path.join(want, "merged") + "/"]
+    assert os.path.exists(os.path.join(out, "merged", "graph.gfa"))
+    # the plasmid piece the --seq gene sits in, plus what the Hi-C seeds reach in their loci; only the gene's nodes are green
+    _, alone = _oracle_run([r1], 31, po.KEY_PACKED, seqs, comments, str(tmp_path / "alone"), coverage=5, max_radius=100000,
+                           bothdirs=False, chunk_length=10, merge=True)
+    alone = alone[os.path.join(str(tmp_path / "alone"), "merged") + "/"]
+    assert len(files["graph.txt"].splitlines()) > len(alone["graph.txt"].splitlines()) + 2000
+    assert files["graph.gfa"].count("CL:Z:GREEN") == alone["graph.gfa"].count("CL:Z:GREEN") > 0
+
+
+def test_cli_hicseq_without_merge_names_directories_from_the_hic_file(cli, tmp_path):
+    """Without --merge the Hi-C sequences seed nothing, but their FASTA comments REPLACE those of --seq as output directory
+    names (src/tools/EnvironmentFinderMain.java:149 overwrites `comments`; :245-248 uses them); with fewer Hi-C records
+    than sequences the reference throws on the missing comment, here a clear error."""
+    genome, reads, _ = synth_case(1, 30000, 5000, 150, 50)
+    r1 = str(tmp_path / "reads.fasta")
+    _write_fasta(r1, reads, 150)
+    seq, hicf = str(tmp_path / "genes.fasta"), str(tmp_path / "hic.fasta")
+    with open(seq, "w") as f:
+        f.write(">geneA\n%s\n>geneB\n%s\n" % (po.decode(genome[3000:3200]), po.decode(genome[20000:20150])))
+    with open(hicf, "w") as f:
+        f.write(">first hic\n%s\n>second\n%s\n>third\n%s\n" % (po.decode(genome[9000:9100]), po.decode(genome[12000:12100]), po.decode(genome[15000:15100])))
+    out, want = str(tmp_path / "out"), str(tmp_path / "want")
+    cmd = [cli, "-k", "25", "-i", r1, "--seq", seq, "--hicseq", hicf, "-o", out, "-w", str(tmp_path / "wd"), "--force", "--maxkmers", "800",
+           "--coverage", "3"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr
+    seqs, _ = ho.rich_fasta_read(seq)
+    _, hic_comments = ho.rich_fasta_read(hicf)
+    assert hic_comments[:2] == ["first hic", "second"]
+    _, res = _oracle_run([r1], 25, po.KEY_PACKED, seqs, hic_comments, want, coverage=3, max_kmers=800)  # (no hic_seqs: not merged)
+    assert set(os.listdir(out)) == {"first hic", "second"}
+    _assert_same_tree(res, out, want)
+    # fewer Hi-C records than sequences
+    with open(hicf, "w") as f:
+        f.write(">only\n%s\n" % po.decode(genome[9000:9100]))
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 1 and "has no FASTA comment" in p.stderr
+
+
 def test_cli_error_paths(cli, tmp_path):
     """tests/EnvironmentFinderMainTest.java:47-94 pins the two messages."""
     r1 = str(tmp_path / "reads.fasta")

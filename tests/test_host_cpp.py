@@ -67,6 +67,46 @@ def test_fixture_example_all_files(hosttest, golden_dir, tmp_path):
     assert len(want["graph.txt"].splitlines()) == 93572
 
 
+from tests.helpers import hic_case_reads  # noqa: E402
+
+
+def test_merge_with_hic_seeds(hosttest, golden_dir, tmp_path):
+    """The reference's only integration-tested combination (tests/EnvironmentFinderMainTest.java:23-45): --merge true with
+    --hicseq.  The Hi-C sequences are BFS seeds AFTER the --seq sequences (src/algo/OneSequenceCalculator.java:181-191)
+    and never gene nodes (:421-432 looks at the --seq sequences only).  Reads: the example's plasmid tiled without errors."""
+    g = os.path.join(golden_dir, "ref_example")
+    reads = hic_case_reads(g)
+    codes = np.concatenate([po.encode(r) for r in reads])
+    off = np.zeros(len(reads) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(r) for r in reads])
+    k = 31
+    t = po.Table()
+    t.count_reads(codes, off, k, po.KEY_PACKED)
+    seqs, comments = ho.rich_fasta_read(os.path.join(g, "seq.fasta"))
+    hic, hic_comments = ho.rich_fasta_read(os.path.join(g, "selected_reads.fasta"))
+    assert len(hic) == 1047 and set(hic_comments) == {"1"}
+    want_dir = str(tmp_path / "want")
+    res = ho.environment_finder(t, k, po.KEY_PACKED, seqs, comments, want_dir, coverage=5, max_radius=40, bothdirs=False,
+                                chunk_length=10, merge=True, hic_seqs=hic)
+    want = res[os.path.join(want_dir, "merged") + "/"]
+    assert want is not None
+    # the same passes through the C++ host: seeds = --seq then Hi-C sequences, genes = --seq only
+    seeds = [po.encode(s) for s in seqs + hic]
+    passes = [(d, po.bfs(t, k, po.KEY_PACKED, seeds, d, 5, -1, 40)) for d in (-1, 1)]
+    dump, out = str(tmp_path / "dump.txt"), str(tmp_path / "out")
+    _dump(dump, k, 10, False, seqs, passes)
+    subprocess.check_call([hosttest, "env", dump, out])
+    for name, text in want.items():
+        with open(os.path.join(out, name)) as f:
+            assert f.read() == text, name
+    # the Hi-C seeds did reach vertices the --seq seed alone does not, and none of theirs is a gene node
+    alone = ho.environment_finder(t, k, po.KEY_PACKED, seqs, comments, str(tmp_path / "alone"), coverage=5, max_radius=40,
+                                  bothdirs=False, chunk_length=10, merge=True)
+    n_alone = len(alone[os.path.join(str(tmp_path / "alone"), "merged") + "/"]["graph.txt"].splitlines())
+    assert len(want["graph.txt"].splitlines()) > n_alone + 2000
+    assert want["graph.gfa"].count("CL:Z:GREEN") == alone[os.path.join(str(tmp_path / "alone"), "merged") + "/"]["graph.gfa"].count("CL:Z:GREEN") > 0
+
+
 @pytest.mark.parametrize("trim", [False, True])
 @pytest.mark.parametrize("bothdirs", [False, True])
 def test_branching_graph_trim_and_bothdirs(hosttest, tmp_path, trim, bothdirs):
