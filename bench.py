@@ -248,7 +248,7 @@ def main():
                                    "maxkmers=%d, bothdirs=%s, %s" % (
                                        cfg_label,
                                        R, L, args.contigs, args.contig_len, k, " (poly hash keys)" if mode == m.KEY_POLY else "", args.coverage, args.maxkmers, bothdirs,
-                                       "E1 1%% substitutions" if args.err == 100 else "err=%d/10000" % args.err),
+                                       "E1 1% substitutions" if args.err == 100 else "err=%d/10000" % args.err),
                        "reads_per_gpu": R, "read_len": L, "k": k, "err_per_10k": args.err,
                        "parallelism": "reads sharded x%d, all-to-all of super-k-mer records (keys for k < 23 / hash keys) by owner" % world if world > 1 else "1 GPU"},
             "distinct_kmers": distinct, "bfs": {"ms_per_step": round(info["bfs_ms"], 3), "reached": info["reached"],

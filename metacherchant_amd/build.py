@@ -15,8 +15,9 @@ LIB = os.path.join(LIBDIR, "libmcgpu.so")
 CLI = os.path.join(LIBDIR, "metacherchant")
 
 HIP_SOURCES = ["mcgpu.hip", os.path.join("host", "envfinder.cpp")]  # (the read-file entry point uses the host reader)
-HIP_DEPS = ["kmer_device.h", "bfs_device.h", "count_pipeline.h", os.path.join("host", "envfinder.h"),
-            os.path.join(ROOT, "include", "mcgpu.h")]
+# every header under csrc/ (mcgpu.hip includes them all; a stale library would travel to the GPU box unnoticed)
+HIP_DEPS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("host", "envfinder.h"),
+                                                                      os.path.join(ROOT, "include", "mcgpu.h")]
 
 
 def _hipcc():

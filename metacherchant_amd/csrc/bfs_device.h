@@ -456,16 +456,8 @@ __device__ __forceinline__ int solid_get2(const SolidView &t, uint64_t key, uint
     const uint64_t k1 = ((uint64_t)a1.y << 32) | a1.x;
     if (k1 == key) { *aux = a1.w; return a1.z > 32767u ? 32767 : (int)a1.z; }
     if (k1 == EMPTY_KEY) return -1;
-    uint64_t s = s0;  // both probes hit other keys: walk the region
-    const uint64_t base = s & ~(uint64_t)t.rmask;
-    for (uint32_t probe = 0; probe <= t.rmask; probe++) {
-        const uint4 raw = *reinterpret_cast<const uint4 *>(t.slots + s);
-        const uint64_t cur = ((uint64_t)raw.y << 32) | raw.x;
-        if (cur == key) { *aux = raw.w; return raw.z > 32767u ? 32767 : (int)raw.z; }
-        if (cur == EMPTY_KEY) return -1;
-        s = base | ((s + 1) & t.rmask);
-    }
-    return -1;
+    // both probes hit other keys: the rest of the sequence, four slots at a time
+    return solid_probe_from(t, key, (s0 & ~(uint64_t)t.rmask) | ((s0 + 2) & t.rmask), 2, aux);
 }
 
 // 32 bases from base q of a packed word array on, first base on top (reads one word past the last one it needs)
@@ -525,15 +517,7 @@ __device__ __forceinline__ int solid_get4(const SolidView &t, uint64_t key, uint
         if (cur == key) { *aux = a[i].w; return a[i].z > 32767u ? 32767 : (int)a[i].z; }
         if (cur == EMPTY_KEY) return -1;
     }
-    uint64_t s = base | ((s0 + NP) & t.rmask);
-    for (uint32_t probe = NP; probe <= t.rmask; probe++) {
-        const uint4 raw = *reinterpret_cast<const uint4 *>(t.slots + s);
-        const uint64_t cur = ((uint64_t)raw.y << 32) | raw.x;
-        if (cur == key) { *aux = raw.w; return raw.z > 32767u ? 32767 : (int)raw.z; }
-        if (cur == EMPTY_KEY) return -1;
-        s = base | ((s + 1) & t.rmask);
-    }
-    return -1;
+    return solid_probe_from(t, key, base | ((s0 + NP) & t.rmask), NP, aux);
 }
 
 // ---- one hop of a scout -------------------------------------------------------------------------------------------

@@ -1695,8 +1695,8 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_dedup(const uint4 *__restrict
             st_nxt = leaf_state[nl];
             n_nxt = min(leaf_counts[nl], (uint32_t)seg_cap);
         }
-        if (st_cur) {  // uniform
-            if (nl < n_leaves) fetch(nl, n_nxt);
+        if (st_cur || n0 > DD_MAX_CAP) {  // uniform; a leaf of more records than the packed counters are safe for is left
+            if (nl < n_leaves) fetch(nl, n_nxt);  // to k_p3_merge, which the host enqueues behind this kernel
             continue;
         }
         P3D_STAMP(7);

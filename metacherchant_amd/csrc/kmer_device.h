@@ -480,6 +480,31 @@ __device__ __forceinline__ uint64_t solid_slot_of(const SolidView &t, uint64_t k
     return (region << MC_REGION_LG) | sk_home(key);
 }
 
+// The probe sequence of `key` from slot s on, four slots to a memory round trip: a lookup in the walk is one link of a
+// dependent chain, and the lanes of a wave look different keys up -- the longest sequence among them decides, one round
+// trip per step (a table a little fuller than planned made the walk twice as long when this went slot by slot).
+// count (saturated) or -1; *aux (may be null) = the slot's read pointer; n_done = slots the caller has looked at already.
+__device__ __forceinline__ int solid_probe_from(const SolidView &t, uint64_t key, uint64_t s, uint32_t n_done, uint32_t *aux)
+{
+    const uint64_t base = s & ~(uint64_t)t.rmask;
+    for (uint32_t probe = n_done; probe <= t.rmask; probe += 4) {
+        uint4 a[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) a[i] = *reinterpret_cast<const uint4 *>(t.slots + (base | ((s + i) & t.rmask)));
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint64_t cur = ((uint64_t)a[i].y << 32) | a[i].x;
+            if (cur == key) {
+                if (aux) *aux = a[i].w;
+                return a[i].z > 32767u ? 32767 : (int)a[i].z;
+            }
+            if (cur == EMPTY_KEY) return -1;
+        }
+        s = base | ((s + 4) & t.rmask);
+    }
+    return -1;
+}
+
 // count (saturated) or -1; *aux (may be null) = the slot's read pointer
 __device__ __forceinline__ int solid_get(const SolidView &t, uint64_t key, uint32_t *aux = nullptr)
 {
@@ -488,19 +513,7 @@ __device__ __forceinline__ int solid_get(const SolidView &t, uint64_t key, uint3
         const unsigned long long c = *t.empty_cnt;
         return c == 0 ? -1 : (c > 32767ull ? 32767 : (int)c);
     }
-    uint64_t s = solid_slot_of(t, key);
-    const uint64_t base = s & ~(uint64_t)t.rmask;
-    for (uint32_t probe = 0; probe <= t.rmask; probe++) {
-        const uint4 raw = *reinterpret_cast<const uint4 *>(t.slots + s);
-        const uint64_t cur = ((uint64_t)raw.y << 32) | raw.x;
-        if (cur == key) {
-            if (aux) *aux = raw.w;
-            return raw.z > 32767u ? 32767 : (int)raw.z;
-        }
-        if (cur == EMPTY_KEY) return -1;
-        s = base | ((s + 1) & t.rmask);
-    }
-    return -1;
+    return solid_probe_from(t, key, solid_slot_of(t, key), 0, aux);
 }
 
 // sum over the wave, one atomic per wave.  Every lane of the wave must call it (convergent).

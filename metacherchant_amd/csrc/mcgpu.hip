@@ -1164,9 +1164,12 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
                 (uint32_t)(c->solid_tracked ? c->cov_hint : 0), c->d_ctr + 6, k, emit, c->ptr_tries, P.flags
 #define P3D_ARGS static_cast<const uint4 *>(lk), lh, lc, lcap, leaves, c->view(), P.leaf_state, P.leaf_new, P.flags + 1, \
                  (uint32_t)(c->solid_tracked ? c->cov_hint : 0), c->d_ctr + 6, k, emit, c->ptr_tries, P.flags
-        if (pl.sk && pl.g == 0 && lseg == 1 && lcap <= DD_MAX_CAP && dedup_on) {
+        if (pl.sk && pl.g == 0 && lseg == 1 && dedup_on) {
             if (virgin) hipLaunchKernelGGL(k_p3_dedup<true>, dim3(grid), dim3(P3_THREADS), 0, c->stream, P3D_ARGS);
             else hipLaunchKernelGGL(k_p3_dedup<false>, dim3(grid), dim3(P3_THREADS), 0, c->stream, P3D_ARGS);
+            // (it leaves the leaves of more than DD_MAX_CAP records alone: where the capacity allows such leaves, the general
+            // kernel follows at once and takes what is left -- it skips the merged ones, ~20 us when that is all of them)
+            if (lcap > DD_MAX_CAP) hipLaunchKernelGGL(k_p3_merge<true>, dim3(grid), dim3(P3_THREADS), 0, c->stream, P3_ARGS);
         } else if (pl.sk) {
             hipLaunchKernelGGL(k_p3_merge<true>, dim3(grid), dim3(P3_THREADS), 0, c->stream, P3_ARGS);
         } else {
@@ -1991,6 +1994,7 @@ int mc_create(const mc_config *cfg, mc_ctx **out)
         // regions and the merge kernel sweeps each leaf twice.
         double load = 0.7;
         if (c->mm_k) load = std::min(0.36, std::max(0.25, 0.25 + 0.05 * std::log2((double)cfg->capacity_hint / (double)(64u << 20))));
+        if (const char *e = getenv("MC_TABLE_LOAD")) { const double v = atof(e); if (v > 0.05 && v < 0.95) load = v; }  // (tuning runs)
         want_slots = std::max<uint64_t>(want_slots, (uint64_t)((double)cfg->capacity_hint / load));
         if (c->mm_k) want_slots = std::max<uint64_t>(1ull << 22, mm_slots_for(c, (double)cfg->capacity_hint, load));
     }
@@ -2926,6 +2930,9 @@ int mc_extract_superkmers_dev(mc_ctx *c, const uint64_t *d_words, const uint64_t
         int rrc = rs_append(c, d_words, first_off, last_off);
         if (rrc) return rrc;
     }
+    // The pieces go into pipe.a_recs, where the merge kernel may have left the list of solid k-mers (P3Emit): from here on
+    // that list is gone, whether or not this rank then adds any record of its own (as pipe_prepare says for every run).
+    c->solid_list_fresh = false;
     // windows <= bases: capacity of the (owner, segment) pieces from the same bound the caller sized its buffer with
     const uint64_t bound = sk_records_bound(c, n_bases - first_off, n_reads);
     const uint32_t nseg = P1W_SEGMENTS;
