@@ -1521,7 +1521,7 @@ constexpr uint32_t DD_MAX_CAP = 2048;    // records per leaf: 32767 + 2048 * 16 
 constexpr uint32_t DD_NONE = 0xFFFFFFFFu, DD_OWNER = 0x80000000u;
 constexpr uint32_t DD_DQ = 496;          // windows a wave queues at a time (64 records have up to 1024; a batch usually ~300)
 
-struct DedupLds {
+struct alignas(16) DedupLds {
     uint64_t key[REGION_SLOTS];
     uint32_t ca[REGION_SLOTS];          // count | (1 + (record slot << 4 | window)) << DD_CNT_BITS
     uint4 drec[DD_SLOTS];               // {y, z, w of the record, fingerprint << 16 | 0x8000 | copies}; .w == 0: free
@@ -1704,10 +1704,11 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_dedup(const uint4 *__restrict
         const uint4 *recs = leaf_recs + (uint64_t)leaf * seg_cap;
         const uint32_t *ptrs = leaf_ptrs + (uint64_t)leaf * seg_cap;
         int solid_before = 0;
-        for (uint32_t i = tid; i < REGION_SLOTS; i += P3_THREADS) {
-            if (VIRGIN) {
-                L.key[i] = EMPTY_KEY; L.ca[i] = 0;
-            } else {
+        if (VIRGIN) {  // 16 bytes a store
+            for (uint32_t i = tid; i < REGION_SLOTS / 2; i += P3_THREADS) reinterpret_cast<uint4 *>(L.key)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+            for (uint32_t i = tid; i < REGION_SLOTS / 4; i += P3_THREADS) reinterpret_cast<uint4 *>(L.ca)[i] = make_uint4(0, 0, 0, 0);
+        } else {
+            for (uint32_t i = tid; i < REGION_SLOTS; i += P3_THREADS) {
                 const uint4 raw = *reinterpret_cast<const uint4 *>(gs + i);
                 L.key[i] = ((uint64_t)raw.y << 32) | raw.x;
                 L.ca[i] = min(raw.z, 32767u);  // (anything above reads the same: kmer_device.h table_get)
@@ -1814,39 +1815,61 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_dedup(const uint4 *__restrict
         P3D_STAMP(5);
         const bool ovf = L.overflow != 0;
         if (!ovf) {
-            for (uint32_t i = tid; i < REGION_SLOTS; i += P3_THREADS) {
-                uint4 v;
-                const uint64_t kk = L.key[i];
-                const uint32_t c = L.ca[i];
-                uint32_t o = c >> DD_CNT_BITS;
-                v.x = (uint32_t)kk; v.y = (uint32_t)(kk >> 32);
-                v.z = c & DD_CNT_MASK;
-                if (o) {  // the pointer of one of the record's copies, by bits of the key (one of three where ptr_pick has four)
-                    o -= 1u;
-                    uint32_t f = ((uint32_t)(kk ^ (kk >> 9) ^ (kk >> 23)) & 3u) % 3u, p0 = L.dptr[f][o >> 4];
-                    if (p0 == 0) { f = f == 2u ? 0u : f + 1u; p0 = L.dptr[f][o >> 4]; }
-                    if (p0 == 0) { f = f == 2u ? 0u : f + 1u; p0 = L.dptr[f][o >> 4]; }
-                    v.w = ptr_advance(p0, o & 15u);
+            // four slots of a thread at a time, their LDS words requested together (a loop that waits for each slot's words
+            // before it stores the slot took 2.5 us of a leaf's 13)
+            for (uint32_t i0 = tid; i0 < REGION_SLOTS; i0 += 4 * P3_THREADS) {
+                uint64_t kk[4];
+                uint32_t cc[4], d3[4][3];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t i = i0 + (uint32_t)u * P3_THREADS;
+                    kk[u] = L.key[i];
+                    cc[u] = L.ca[i];
                 }
-                else if (VIRGIN) v.w = 0;
-                else v.w = reinterpret_cast<const uint32_t *>(gs + i)[3];  // the pointer the slot had
-                *reinterpret_cast<uint4 *>(gs + i) = v;
-                const bool solid = solid_thr && v.z >= solid_thr;
-                solid_delta += solid;
-                if (emitting) {  // (uniform; the loop's trip count is the same for every lane)
-                    const unsigned long long m = __ballot(solid);
-                    if (m) {
-                        uint32_t ebase = 0;
-                        const int leader = __ffsll((long long)m) - 1;
-                        if ((int)lane == leader) ebase = atomicAdd(&L.emit_cur, (uint32_t)__popcll(m));
-                        ebase = __shfl(ebase, leader);
-                        if (solid) {
-                            const uint32_t pos = ebase + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-                            if (pos < emit.seg_cap) {
-                                v.z = min(v.z, 32767u);
-                                emit.recs[(uint64_t)blockIdx.x * emit.seg_cap + pos] = v;
-                            } else {
-                                atomicExch(emit.lost, 1u);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t o = cc[u] >> DD_CNT_BITS;
+                    d3[u][0] = d3[u][1] = d3[u][2] = 0;
+                    if (o) {
+                        const uint32_t sl = (o - 1u) >> 4;
+                        d3[u][0] = L.dptr[0][sl]; d3[u][1] = L.dptr[1][sl]; d3[u][2] = L.dptr[2][sl];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t i = i0 + (uint32_t)u * P3_THREADS;
+                    const uint32_t o = cc[u] >> DD_CNT_BITS;
+                    uint4 v;
+                    v.x = (uint32_t)kk[u]; v.y = (uint32_t)(kk[u] >> 32);
+                    v.z = cc[u] & DD_CNT_MASK;
+                    if (o) {  // the pointer of one of the record's copies, by bits of the key (one of three where ptr_pick has four)
+                        const uint32_t r = (uint32_t)(kk[u] ^ (kk[u] >> 9) ^ (kk[u] >> 23)) & 3u;
+                        const uint32_t a0 = r == 1u ? d3[u][1] : (r == 2u ? d3[u][2] : d3[u][0]);   // field r mod 3 ...
+                        const uint32_t a1 = r == 1u ? d3[u][2] : (r == 2u ? d3[u][0] : d3[u][1]);   // ... the next ...
+                        const uint32_t a2 = r == 1u ? d3[u][0] : (r == 2u ? d3[u][1] : d3[u][2]);   // ... and the one after
+                        const uint32_t p0 = a0 ? a0 : (a1 ? a1 : a2);
+                        v.w = ptr_advance(p0, (o - 1u) & 15u);
+                    }
+                    else if (VIRGIN) v.w = 0;
+                    else v.w = reinterpret_cast<const uint32_t *>(gs + i)[3];  // the pointer the slot had
+                    *reinterpret_cast<uint4 *>(gs + i) = v;
+                    const bool solid = solid_thr && v.z >= solid_thr;
+                    solid_delta += solid;
+                    if (emitting) {  // (uniform; the loop's trip count is the same for every lane)
+                        const unsigned long long m = __ballot(solid);
+                        if (m) {
+                            uint32_t ebase = 0;
+                            const int leader = __ffsll((long long)m) - 1;
+                            if ((int)lane == leader) ebase = atomicAdd(&L.emit_cur, (uint32_t)__popcll(m));
+                            ebase = __shfl(ebase, leader);
+                            if (solid) {
+                                const uint32_t pos = ebase + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+                                if (pos < emit.seg_cap) {
+                                    v.z = min(v.z, 32767u);
+                                    emit.recs[(uint64_t)blockIdx.x * emit.seg_cap + pos] = v;
+                                } else {
+                                    atomicExch(emit.lost, 1u);
+                                }
                             }
                         }
                     }
