@@ -531,13 +531,29 @@ struct HopEval {
     Kmer K;               // (lane) the vertex lane + 1 levels past the tip, walk strand
     uint32_t aux;         // (lane) its read pointer
     bool other;           // (lane) ... which leads into another read than this one
+    // n_cand > 0 was asked for: the next hop's candidates -- the pointers nearest to the tip that lead into other reads, one
+    // per read -- and the read store's words around them, requested as soon as they are known (lanes 16 i .. 16 i + 15: the
+    // words of candidate i, see scout_word_of)
+    uint32_t nc, cptr[MC_TEAM_MAX], cdelta[MC_TEAM_MAX];  // (uniform)
+    uint64_t word;                                         // (lane)
 };
+
+// word i < SCOUT_WORDS of the piece of the read store a hop looks at for pointer `cptr` (what scout_eval stages in sw[i])
+__device__ __forceinline__ uint64_t scout_word_of(const SolidView &t, uint32_t cptr, uint32_t i)
+{
+    uint32_t span;
+    const uint64_t lo = ptr_decode(cptr, &span);
+    if (lo >= t.reads_bases) return 0;
+    const uint64_t wlo = (lo > 128 ? lo - 128 : 0) >> 5, last_word = (t.reads_bases + 31) / 32;
+    return t.reads[min(wlo + i, last_word)];
+}
 
 // sw, mh: this wave's LDS scratch (SCOUT_WORDS words of the read store; SCOUT_MH minimizer hashes)
 template <int MODE>
 __device__ __forceinline__ void scout_eval(const SolidView &t, uint64_t *sw, uint32_t *mh, const Kmer &X, int k, int min_cov, uint32_t cptr,
-                                           uint32_t delta, uint32_t want, HopEval &R, unsigned long long &lookups, unsigned long long *tsc = nullptr)
-{
+                                           uint32_t delta, uint32_t want, HopEval &R, unsigned long long &lookups, unsigned long long *tsc = nullptr,
+                                           bool staged = false, uint32_t n_cand = 0)
+{   // staged: sw already holds the SCOUT_WORDS words around the pointer (scout_words_of: the companion requests them a hop ahead)
 #ifdef MC_SCOUT_TIMING
     unsigned long long ts_ = __builtin_amdgcn_s_memrealtime();
 #define SC_STAMP(i) do { if (tsc) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); tsc[i] += n_ - ts_; ts_ = n_; } } while (0)
@@ -547,22 +563,36 @@ __device__ __forceinline__ void scout_eval(const SolidView &t, uint64_t *sw, uin
 #endif
     const uint32_t lane = threadIdx.x & 63;
     R.m = 0; R.why = 1; R.fwd = true; R.Q = -1; R.e_hi = R.e_lo = 0; R.K = Kmer{0, 0}; R.aux = 0; R.other = false;
+    R.nc = 0; R.word = 0;
+#pragma unroll
+    for (int i = 0; i < MC_TEAM_MAX; i++) { R.cptr[i] = 0; R.cdelta[i] = 0; }
     uint32_t span;
     const uint64_t lo = ptr_decode(cptr, &span);
     if (lo >= t.reads_bases) return;  // (a pointer from elsewhere)
     const uint64_t last_word = (t.reads_bases + 31) / 32;  // the pad word
     // the piece of the read store around the occurrence
     const uint64_t wlo = (lo > 128 ? lo - 128 : 0) >> 5;
-    __builtin_amdgcn_wave_barrier();
-    if (lane < SCOUT_WORDS) sw[lane] = t.reads[min(wlo + lane, last_word)];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    if (!staged) {
+        __builtin_amdgcn_wave_barrier();
+        if (lane < SCOUT_WORDS) sw[lane] = t.reads[min(wlo + lane, last_word)];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
     SC_STAMP(0);
     const uint64_t base = wlo * 32;
     const Kmer Xr = kmer_rc<MODE>(X, k);
     // where is the tip?  `delta` bases after the pointer's k-mer in a read that runs our way, before it otherwise
     long long Q = -1;
     bool fwd = true;
+    if (span == 1) {  // an exact pointer (the first 2^31 bases of the store): two places to look at, no search
+        const uint64_t qf = lo + delta;
+        const bool of = qf + (uint64_t)k <= t.reads_bases, orv = lo >= delta && lo - delta + (uint64_t)k <= t.reads_bases;
+        const bool mf = of && kmer_eq(kmer_at<MODE>(sw, qf - base, k), X);
+        const bool mr = !mf && orv && kmer_eq(kmer_at<MODE>(sw, lo - delta - base, k), Xr);
+        if (mf) Q = (long long)qf;
+        else if (mr) { Q = (long long)(lo - delta); fwd = false; }
+        fwd = __builtin_amdgcn_readfirstlane((int)fwd) != 0;  // (every lane computed the same)
+    } else
     for (uint32_t o0 = 0; o0 < span && Q < 0; o0 += 64) {
         const uint32_t o = o0 + lane;
         const uint64_t qf = lo + delta + o, qr = lo + o - delta;
@@ -596,14 +626,27 @@ __device__ __forceinline__ void scout_eval(const SolidView &t, uint64_t *sw, uin
         // all but one base, so every SK_M-mer is hashed once -- a lane hashes the last one of its own vertex, the first
         // lanes also the ones inside the tip -- and a lane takes the minimum over its w of them (w = k - SK_M + 1).
         const uint32_t w = (uint32_t)k - SK_M + 1;
-        auto mm_hash = [](uint32_t f) { const uint32_t r = sk_rc_mmer(f); return sk_order(f < r ? f : r); };
+        auto mm_hash = [](uint32_t f) {  // sk_order of the canonical SK_M-mer (sk_rc_mmer on 32 bits: this is one lone wave's time)
+            uint32_t r = __builtin_bitreverse32(f);
+            r = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
+            r = (~r) >> (32 - 2 * SK_M);
+            return sk_order(f < r ? f : r);
+        };
         __builtin_amdgcn_wave_barrier();
         if (lane + 1 < w) mh[lane] = mm_hash((uint32_t)(X.lo >> (2 * (w - 2 - lane))) & SK_MMASK);  // the tip's SK_M-mers from base lane + 1 on
         mh[w - 1 + lane] = ok ? mm_hash((uint32_t)K.lo & SK_MMASK) : SK_NONE;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         uint32_t hmin = SK_NONE;
-        for (uint32_t i = 0; i < w; i++) hmin = min(hmin, mh[lane + i]);
+        if (w == 17) {  // k = 31: the reads requested together
+            uint32_t hv[17];
+#pragma unroll
+            for (int i = 0; i < 17; i++) hv[i] = mh[lane + i];
+#pragma unroll
+            for (int i = 0; i < 17; i++) hmin = min(hmin, hv[i]);
+        } else {
+            for (uint32_t i = 0; i < w; i++) hmin = min(hmin, mh[lane + i]);
+        }
         s0 = ((((uint64_t)sk_bin(hmin) * t.n_regions) >> 32) << MC_REGION_LG) | sk_home(key);
     } else {
         s0 = solid_slot_of(t, key);
@@ -634,6 +677,35 @@ __device__ __forceinline__ void scout_eval(const SolidView &t, uint64_t *sw, uin
         asm volatile("" ::"v"(warm));
         return;
     }
+    bool other = aux != 0 && lane < m;
+    if (other) {  // does the pointer lead back into this very read?
+        uint32_t sp;
+        const uint64_t at = ptr_decode(aux, &sp);
+        const uint64_t here = fwd ? (uint64_t)Q + 1 + lane : (uint64_t)Q - 1 - lane;  // where this read holds lane's k-mer
+        other = !(at <= here && here < at + sp);
+    }
+    if (n_cand) {
+        uint32_t sp;
+        const uint64_t apos = aux ? ptr_decode(aux, &sp) : 0;
+        unsigned long long cm = __ballot(lane < m && lane + 48 >= m && other);
+#pragma unroll
+        for (int i = 0; i < MC_TEAM_MAX; i++) {
+            if (!cm || (uint32_t)i >= n_cand) break;
+            const uint32_t j = 63u - (uint32_t)__builtin_clzll(cm);
+            R.cptr[i] = (uint32_t)__builtin_amdgcn_readlane((int)aux, (int)j);
+            R.cdelta[i] = m - 1 - j;
+            R.nc = (uint32_t)i + 1;
+            const uint64_t cpos = readlane64(apos, j);
+            // lanes whose pointer sits in the same read at the matching distance add nothing
+            const uint64_t d = (uint64_t)j - lane;  // (lanes above j are out of the mask already)
+            cm &= ~__ballot(lane <= j && (apos + d == cpos || apos == cpos + d));
+        }
+        const uint32_t ci = lane / SCOUT_WORDS;
+        uint32_t cp = 0;
+#pragma unroll
+        for (int i = 0; i < MC_TEAM_MAX; i++) cp = ci == (uint32_t)i ? R.cptr[i] : cp;
+        if (ci < R.nc) R.word = scout_word_of(t, cp, lane % SCOUT_WORDS);
+    }
     // the m new bases, first on top: what follows the occurrence (precedes it, complemented)
     uint64_t e_hi, e_lo;
     if (fwd) {
@@ -647,13 +719,6 @@ __device__ __forceinline__ void scout_eval(const SolidView &t, uint64_t *sw, uin
     e_lo = uni64(e_lo);
     if (m < 32) e_hi &= ~0ull << (64 - 2 * m);
     if (m <= 32) e_lo = 0; else if (m < 64) e_lo &= ~0ull << (128 - 2 * m);
-    bool other = aux != 0 && lane < m;
-    if (other) {  // does the pointer lead back into this very read?
-        uint32_t sp;
-        const uint64_t at = ptr_decode(aux, &sp);
-        const uint64_t here = fwd ? (uint64_t)Q + 1 + lane : (uint64_t)Q - 1 - lane;  // where this read holds lane's k-mer
-        other = !(at <= here && here < at + sp);
-    }
     R.m = m; R.why = 0; R.e_hi = e_hi; R.e_lo = e_lo; R.K = K; R.aux = aux; R.other = other;
     asm volatile("" ::"v"(warm));
     SC_STAMP(3);
@@ -790,6 +855,7 @@ __device__ __forceinline__ uint32_t ld_u32(const uint32_t *p) { return __hip_ato
 __device__ __forceinline__ void st_u32(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t box_resp(uint32_t seq, bool finished, uint32_t levels) { return ((seq & 0x7FFFu) << 17) | (finished ? 1u << 16 : 0u) | levels; }
 
+static_assert(MC_TEAM_MAX * SCOUT_WORDS <= 64, "a wave requests the words of all its candidates at once, SCOUT_WORDS lanes each");
 struct TeamLds {
     Kmer X[SCOUT_MAX_F];  // tips, walk strand
     PathTail T[SCOUT_MAX_F];
@@ -797,6 +863,8 @@ struct TeamLds {
     uint32_t cptr[SCOUT_MAX_F][8], cdelta[SCOUT_MAX_F][8];
     uint32_t reach[BFS_THREADS / 64];
     uint64_t sw[BFS_THREADS / 64][SCOUT_WORDS];
+    uint64_t swn[SCOUT_MAX_F][MC_TEAM_MAX][SCOUT_WORDS];  // the words around the candidates of the NEXT hop, requested by the wave that found them
+    uint32_t staged[SCOUT_MAX_F];                         // ... are there (0 on a request's first hop)
     uint32_t mh[BFS_THREADS / 64][SCOUT_MH];
     uint32_t seq, quit, F, budget, stop;
     uint32_t published[SCOUT_MAX_F];  // levels whose path words are known to have arrived
@@ -855,18 +923,27 @@ __device__ void scout_companion(const BfsState &S, const SolidView &t, TeamLds &
         __syncthreads();
         // ---- hops, all teams in step
         HopEval R;
+        if (tid < SCOUT_MAX_F) L.staged[tid] = 0;
+        __syncthreads();
         for (;;) {
             uint32_t probe = seq;
             if (tid == 0) probe = ld_u32(&box->req_seq) | (ld_u32(&box->quit) << 31);  // (used at the end of the hop)
             R.m = 0;
             const bool busy = member && !L.stuck[g] && L.levels[g] < budget;
             if (busy && u < L.nc[g]) {
-                scout_eval<MODE>(t, L.sw[wv], L.mh[wv], L.X[g], k, min_cov, L.cptr[g][u], L.cdelta[g][u], min(64u, budget - L.levels[g]), R, lookups, tsc);
+                const bool staged = L.staged[g] != 0;
+                scout_eval<MODE>(t, staged ? L.swn[g][u] : L.sw[wv], L.mh[wv], L.X[g], k, min_cov, L.cptr[g][u], L.cdelta[g][u], min(64u, budget - L.levels[g]), R,
+                                 lookups, tsc, staged, Tm);
                 if (R.why == 1) n_nf += lane == 0; else { hops += lane == 0; if (R.m == 0) n_m0 += lane == 0; }
             }
 #ifdef MC_SCOUT_TIMING
             unsigned long long tq_ = __builtin_amdgcn_s_memrealtime();
 #endif
+            // What this wave hands to the next hop if its read got furthest: the candidates it found (R.cptr) and the read
+            // store's words around them, which it asked for inside scout_eval: they travel while the team finds its winner (a
+            // hop's first act used to be to ask for them and wait: 0.5 us of its 4).
+            const uint32_t my_nc = R.m ? R.nc : 0;
+            const uint64_t my_word = R.word;
             if (lane == 0) L.reach[wv] = R.m;
             // The length the previous hop added is published now: its path words (write-through stores) were issued before
             // this hop's two round trips and every wave waits here for the stores it has outstanding, so they have arrived
@@ -894,22 +971,13 @@ __device__ void scout_companion(const BfsState &S, const SolidView &t, TeamLds &
                     X.lo = readlane64(R.K.lo, m - 1);
                     X.hi = readlane64(R.K.hi, m - 1);
                     const uint32_t levels = L.levels[g] + m;
-                    // candidates: the pointers nearest to the tip that lead into other reads, one per read
-                    uint32_t sp;
-                    const uint64_t apos = R.aux ? ptr_decode(R.aux, &sp) : 0;
-                    unsigned long long cm = __ballot(lane < m && lane + 48 >= m && R.other);
-                    uint32_t nc = 0;
-                    while (cm && nc < Tm) {
-                        const uint32_t j = 63u - (uint32_t)__builtin_clzll(cm);
-                        const uint32_t cp = (uint32_t)__builtin_amdgcn_readlane((int)R.aux, (int)j);
-                        const uint64_t cpos = readlane64(apos, j);
-                        if (lane == 0) { L.cptr[g][nc] = cp; L.cdelta[g][nc] = m - 1 - j; }
-                        nc++;
-                        // lanes whose pointer sits in the same read at the matching distance add nothing
-                        const uint64_t d = (uint64_t)j - lane;  // (lanes above j are out of the mask already)
-                        cm &= ~__ballot(lane <= j && (apos + d == cpos || apos == cpos + d));
+                    if (lane / SCOUT_WORDS < my_nc) L.swn[g][lane / SCOUT_WORDS][lane % SCOUT_WORDS] = my_word;
+                    if (lane == 0) {
+#pragma unroll
+                        for (int i = 0; i < MC_TEAM_MAX; i++) { L.cptr[g][i] = R.cptr[i]; L.cdelta[g][i] = R.cdelta[i]; }
+                        L.T[g] = T; L.X[g] = X; L.levels[g] = levels; L.nc[g] = my_nc; L.staged[g] = 1;
+                        if (my_nc == 0) { L.stuck[g] = 1; atomicAdd(&box->e_nc0, 1ull); }
                     }
-                    if (lane == 0) { L.T[g] = T; L.X[g] = X; L.levels[g] = levels; L.nc[g] = nc; if (nc == 0) { L.stuck[g] = 1; atomicAdd(&box->e_nc0, 1ull); } }
                 }
             }
             if (tid == 0 && probe != seq) L.stop = 1;
