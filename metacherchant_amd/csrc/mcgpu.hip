@@ -1074,6 +1074,7 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
     if ((n_leaves << g) != c->n_regions) return fail(c, MC_EINVAL, "internal: %llu table regions do not split into leaves", (unsigned long long)c->n_regions);
     if (n_leaves < 4) return fail(c, MC_EINVAL, "internal: partitioned counting needs at least 4 table regions");
     uint64_t np1 = std::min<uint64_t>(n_leaves, n_leaves > (uint64_t)PT_MAX_BUCKETS * max_b2 ? max_b1_big : (uint32_t)PT_MAX_BUCKETS);
+    if (n_records) if (const char *e = getenv("MC_SK_B1")) np1 = std::min<uint64_t>(n_leaves, std::min<uint64_t>(strtoull(e, nullptr, 10), max_b1_big));  // (tuning runs)
     while (n_leaves % np1) np1--;  // (a power of two, or 512 dividing a multiple of 512)
     if (n_leaves / np1 > max_b2) return fail(c, MC_EINVAL, "internal: %llu leaves do not fit two scatter levels", (unsigned long long)n_leaves);
     pl->b1 = (uint32_t)np1;               // level-1 buckets
@@ -3604,14 +3605,17 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
         for (uint32_t j = 0; j < n_jobs; j++) HIPCHK(c, hipMemsetAsync(B[j]->S.box, 0, sizeof(ScoutBox), c->stream));
         int rc = timed(c, &total_ms, [&] { launch_bfs(c, c->stream, d_states.p, n_jobs, min_cov, max_kmers, max_radius, max_rounds, companions); });
         if (rc) return rc;
+        // (the jobs' control blocks and mailboxes come back in one go: a blocking copy each cost 4 x 20 us on two jobs)
+        std::vector<ScoutBox> hbs(companions ? n_jobs : 0);
+        for (uint32_t j = 0; j < n_jobs && companions; j++) HIPCHK(c, hipMemcpyAsync(&hbs[j], B[j]->S.box, sizeof(ScoutBox), hipMemcpyDeviceToHost, c->stream));
+        for (uint32_t j = 0; j < n_jobs; j++) HIPCHK(c, hipMemcpyAsync(&ctl[j], B[j]->S.ctl, sizeof(BfsCtl), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
         for (uint32_t j = 0; j < n_jobs && companions; j++) {
-            ScoutBox hb;
-            HIPCHK(c, hipMemcpy(&hb, B[j]->S.box, sizeof hb, hipMemcpyDeviceToHost));
+            const ScoutBox &hb = hbs[j];
             box_iters[j] += hb.iters; box_e[j][0] += hb.e_stuck; box_e[j][1] += hb.e_nc0; box_e[j][2] += hb.e_budget; box_e[j][3] += hb.e_stop; box_hops[j] += hb.hops; box_levels[j] += hb.levels; box_calls[j] += hb.calls; box_nf[j] += hb.nf; box_m0[j] += hb.m0;
         }
         bool all_done = true;
         for (uint32_t j = 0; j < n_jobs; j++) {
-            HIPCHK(c, hipMemcpy(&ctl[j], B[j]->S.ctl, sizeof(BfsCtl), hipMemcpyDeviceToHost));
             if (ctl[j].status == BFS_DONE) continue;
             all_done = false;
             if (ctl[j].status != BFS_NEED_GROW) continue;
@@ -3641,6 +3645,7 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
     }
 
     int ret = MC_OK;
+    std::vector<uint32_t *> fl_all;  // the jobs' flag words on the host (freed below)
     for (uint32_t j = 0; j < n_jobs; j++) {
         const BfsState &S = B[j]->S;
         const uint64_t n = ctl[j].n;
@@ -3678,7 +3683,6 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
             uint32_t *p;
             ~Scratch() { res_free(p); }
         } fl{static_cast<uint32_t *>(res_alloc(n * 4))};
-        const uint32_t *flags = fl.p;
         if (!o->hi || !o->lo || !o->dist || !o->cov || !o->last || !fl.p) {
             ret = fail(c, MC_ENOMEM, "mc_bfs: out of host memory");
             break;
@@ -3688,14 +3692,25 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
         HIPCHK(c, hipMemcpyAsync(o->dist, S.dist, n * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(o->cov, S.cov, n * 2, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(fl.p, S.flags, n * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        uint64_t levels = 0;
-        for (uint64_t i = 0; i < n; i++) {
-            o->last[i] = (uint8_t)(flags[i] & 1u);
-            if ((uint64_t)o->dist[i] > levels) levels = (uint64_t)o->dist[i];
-        }
-        o->levels = levels;
+        fl_all.push_back(fl.p);
+        fl.p = nullptr;
     }
+    if (ret == MC_OK) {  // one wait for all jobs' copies, then the little the host derives from them
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        size_t fi = 0;
+        for (uint32_t j = 0; j < n_jobs; j++) {
+            mc_bfs_result *o = &out[j];
+            if (o->n == 0) continue;
+            const uint32_t *flags = fl_all[fi++];
+            uint64_t levels = 0;
+            for (uint64_t i = 0; i < o->n; i++) {
+                o->last[i] = (uint8_t)(flags[i] & 1u);
+                if ((uint64_t)o->dist[i] > levels) levels = (uint64_t)o->dist[i];
+            }
+            o->levels = levels;
+        }
+    }
+    for (uint32_t *q : fl_all) res_free(q);
     if (ret != MC_OK)
         for (uint32_t j = 0; j < n_jobs; j++) mc_bfs_result_free(&out[j]);
     return ret;
