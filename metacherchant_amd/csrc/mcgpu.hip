@@ -178,8 +178,10 @@ struct mc_ctx {
     char *pin[16] = {};                // pinned staging buffers of h2d_fast, made on first use
     DevPool tok_pool;                  // scratch of the device tokeniser
     bool rs_copy_pending = false;      // a batch is on its way into the read store on pipe_stream (rs_append)
-    void *d_bfs_states = nullptr;      // BfsState[d_bfs_states_cap] of mc_bfs_batch
-    uint32_t d_bfs_states_cap = 0;
+    // mc_bfs_batch: job states + seeds go up in one copy (pinned h_bfs_stage -> d_bfs_stage), results come back packed
+    // (d_bfs_pack: a header block and the jobs' arrays back to back; h_bfs_hdr: the headers, pinned)
+    char *h_bfs_stage = nullptr, *d_bfs_stage = nullptr, *d_bfs_pack = nullptr, *h_bfs_hdr = nullptr;
+    uint64_t bfs_stage_cap = 0, bfs_pack_cap = 0, bfs_hdr_cap = 0;
     std::mutex pin_mu;                 // the pinned buffers serve one copy at a time
     hipStream_t pin_stream[8] = {};
     int mm_k = 0;        // != 0 (= k): regions are minimizer bins and reads are counted as super-k-mers (kmer_device.h)
@@ -2029,7 +2031,10 @@ void mc_destroy(mc_ctx *c)
     for (auto &e : c->ev_t) if (e) (void)hipEventDestroy(e);
     if (c->pipe_stream) { (void)hipStreamSynchronize(c->pipe_stream); (void)hipStreamDestroy(c->pipe_stream); }
     c->tok_pool.release();
-    if (c->d_bfs_states) (void)hipFree(c->d_bfs_states);
+    if (c->h_bfs_stage) (void)hipHostFree(c->h_bfs_stage);
+    if (c->d_bfs_stage) (void)hipFree(c->d_bfs_stage);
+    if (c->d_bfs_pack) (void)hipFree(c->d_bfs_pack);
+    if (c->h_bfs_hdr) (void)hipHostFree(c->h_bfs_hdr);
     for (char *p : c->pin) if (p) (void)hipHostFree(p);
     for (hipStream_t st : c->pin_stream) if (st) (void)hipStreamDestroy(st);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -3308,7 +3313,7 @@ void res_free(void *p)
 void mc_bfs_result_free(mc_bfs_result *r)
 {
     if (!r) return;
-    res_free(r->hi); res_free(r->lo); res_free(r->dist); res_free(r->cov); res_free(r->last);
+    res_free(r->hi);  // (one block holds all five arrays: mc_bfs_batch)
     memset(r, 0, sizeof *r);
 }
 
@@ -3460,6 +3465,73 @@ int ensure_solid(mc_ctx *c, int min_cov, double *ms)
     return solid_build(c, n, min_cov, ms, nullptr, from_list);
 }
 
+// What mc_bfs_batch used to do with 4 fills per job before the launch and 5 + 2 copies per job behind it (each a
+// launch of its own, 10-25 us apart: 0.7 ms of a 9 ms walk on two jobs) is one kernel either side.
+// k_bfs_reset: blockIdx.y = job.  full: index emptied, flags and control block cleared (a fresh run); always: the mailbox.
+__global__ void __launch_bounds__(256) k_bfs_reset(const BfsState *__restrict__ states, int full)
+{
+    const BfsState S = states[blockIdx.y];
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x, stride = (uint64_t)gridDim.x * 256;
+    if (full) {
+        uint4 *vis = reinterpret_cast<uint4 *>(S.vis);  // (bmask + 1 buckets of 16 bytes)
+        for (uint64_t i = t; i <= S.bmask; i += stride) vis[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+        for (uint64_t i = t; i < S.dcap; i += stride) S.flags[i] = 0;
+        uint32_t *ctl = reinterpret_cast<uint32_t *>(S.ctl);
+        for (uint64_t i = t; i < sizeof(BfsCtl) / 4; i += stride) ctl[i] = 0;
+    }
+    if (S.box) {
+        uint32_t *box = reinterpret_cast<uint32_t *>(S.box);
+        for (uint64_t i = t; i < sizeof(ScoutBox) / 4; i += stride) box[i] = 0;
+    }
+}
+
+// the header of a job's packed results
+struct BfsPackHdr {
+    BfsCtl ctl;
+    ScoutBox box;
+    unsigned long long offset;  // of the job's arrays in the data block: hi[n] lo[n] dist[n] cov[n] last[n], each padded to 8 bytes
+    unsigned long long levels;  // max distance
+};
+__host__ __device__ inline uint64_t bfs_pack_bytes(uint64_t n) { return 16 * n + ((4 * n + 7) & ~7ull) + ((2 * n + 7) & ~7ull) + ((n + 7) & ~7ull); }
+
+// k_bfs_pack: blockIdx.y = job.  Control block and mailbox into the job's header, its arrays (the first ctl.n entries)
+// into the data block behind the arrays of the jobs before it; `last` from bit 0 of the flags; the largest distance.
+__global__ void __launch_bounds__(256) k_bfs_pack(const BfsState *__restrict__ states, uint32_t n_jobs, BfsPackHdr *hdr, char *data, uint64_t data_cap)
+{
+    const uint32_t j = blockIdx.y;
+    const BfsState S = states[j];
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x, stride = (uint64_t)gridDim.x * 256;
+    unsigned long long off = 0;
+    for (uint32_t i = 0; i < j; i++) off += bfs_pack_bytes(ctl_ld(&states[i].ctl->n));
+    const uint64_t n = ctl_ld(&S.ctl->n);
+    if (blockIdx.x == 0) {
+        uint32_t *h = reinterpret_cast<uint32_t *>(&hdr[j]);
+        const uint32_t *ctl = reinterpret_cast<const uint32_t *>(S.ctl), *box = reinterpret_cast<const uint32_t *>(S.box);
+        for (uint32_t i = threadIdx.x; i < sizeof(BfsCtl) / 4; i += 256) h[i] = __hip_atomic_load(&ctl[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint32_t i = threadIdx.x; i < sizeof(ScoutBox) / 4; i += 256)
+            h[sizeof(BfsCtl) / 4 + i] = box ? __hip_atomic_load(&box[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        if (threadIdx.x == 0) hdr[j].offset = off;
+    }
+    if (off + bfs_pack_bytes(n) > data_cap) return;  // (the host sizes the block from the jobs' capacities: cannot happen)
+    uint64_t *hi = reinterpret_cast<uint64_t *>(data + off), *lo = hi + n;
+    int32_t *dist = reinterpret_cast<int32_t *>(lo + n);
+    int16_t *cov = reinterpret_cast<int16_t *>(reinterpret_cast<char *>(dist) + ((4 * n + 7) & ~7ull));
+    uint8_t *last = reinterpret_cast<uint8_t *>(reinterpret_cast<char *>(cov) + ((2 * n + 7) & ~7ull));
+    unsigned long long mx = 0;
+    for (uint64_t i = t; i < n; i += stride) {
+        hi[i] = S.hi[i];
+        lo[i] = S.lo[i];
+        const int32_t d = S.dist[i];
+        dist[i] = d;
+        cov[i] = S.cov[i];
+        last[i] = (uint8_t)(S.flags[i] & 1u);
+        mx = max(mx, (unsigned long long)(uint32_t)d);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned long long)__shfl_down(mx, o));
+    if ((threadIdx.x & 63) == 0 && mx) atomicMax(&hdr[j].levels, mx);
+}
+
 void launch_bfs(mc_ctx *c, hipStream_t stream, const BfsState *d_states, uint32_t n_jobs, int min_cov, int64_t max_kmers,
                 int64_t max_radius, unsigned long long max_rounds, int companions)
 {
@@ -3546,72 +3618,103 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
 
     while (c->bfs_pool.size() < n_jobs) c->bfs_pool.emplace_back(new BfsJobBuffers);
     auto &B = c->bfs_pool;
+    // ---- one upload: the job states, then every job's seeds (lo, hi)
+    uint64_t stage_bytes = ((uint64_t)n_jobs * sizeof(BfsState) + 63) & ~63ull, pack_bytes = 0;
+    std::vector<uint64_t> seed_at(n_jobs);
+    for (uint32_t j = 0; j < n_jobs; j++) {
+        seed_at[j] = stage_bytes;
+        stage_bytes += 2 * std::max<uint64_t>(jobs[j].n_seeds, 1) * 8;
+    }
+    if (c->bfs_stage_cap < stage_bytes) {
+        if (c->h_bfs_stage) (void)hipHostFree(c->h_bfs_stage);
+        if (c->d_bfs_stage) (void)hipFree(c->d_bfs_stage);
+        c->h_bfs_stage = c->d_bfs_stage = nullptr;
+        c->bfs_stage_cap = 0;
+        const uint64_t cap = std::max<uint64_t>(stage_bytes * 2, 1u << 16);
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_bfs_stage), cap, hipHostMallocDefault));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_bfs_stage), cap));
+        c->bfs_stage_cap = cap;
+    }
     for (uint32_t j = 0; j < n_jobs; j++) {
         BfsJobBuffers &J = *B[j];
         BfsState &S = J.S;
         const uint64_t ns = jobs[j].n_seeds;
-        if (J.seed_cap < std::max<uint64_t>(ns, 1)) {
-            (void)hipFree(J.d_seed_lo); (void)hipFree(J.d_seed_hi);
-            J.d_seed_lo = J.d_seed_hi = nullptr;
-            J.seed_cap = 0;
-            HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&J.d_seed_lo), std::max<uint64_t>(ns, 1) * 8));
-            HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&J.d_seed_hi), std::max<uint64_t>(ns, 1) * 8));
-            J.seed_cap = std::max<uint64_t>(ns, 1);
-        }
-        if (ns) HIPCHK(c, hipMemcpyAsync(J.d_seed_lo, jobs[j].seed_lo, ns * 8, hipMemcpyHostToDevice, c->stream));
-        if (ns && jobs[j].seed_hi)
-            HIPCHK(c, hipMemcpyAsync(J.d_seed_hi, jobs[j].seed_hi, ns * 8, hipMemcpyHostToDevice, c->stream));
+        uint64_t *h_lo = reinterpret_cast<uint64_t *>(c->h_bfs_stage + seed_at[j]), *h_hi = h_lo + std::max<uint64_t>(ns, 1);
+        if (ns) memcpy(h_lo, jobs[j].seed_lo, ns * 8);
+        if (ns && jobs[j].seed_hi) memcpy(h_hi, jobs[j].seed_hi, ns * 8);
         const uint64_t dcap = max_kmers >= 0 ? std::max<uint64_t>((uint64_t)max_kmers, ns) + 2 * BFS_THREADS
                                              : std::max<uint64_t>(1ull << 20, ns + 2 * BFS_THREADS);
         if (S.dcap < dcap || S.dcap > 4 * dcap || !S.hi) {
             J.free_arrays();
             int rc = bfs_alloc(c, S, dcap);
             if (rc) return rc;
-        } else {  // reuse: only the index and the flags need clearing
-            HIPCHK(c, hipMemsetAsync(S.vis, 0xFF, (S.bmask + 1) * 16, c->stream));
-            HIPCHK(c, hipMemsetAsync(S.flags, 0, S.dcap * 4, c->stream));
-        }
+        }  // (reused arrays: k_bfs_reset empties the index and clears the flags)
         if (!S.ctl) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&S.ctl), sizeof(BfsCtl)));
         if (!S.path) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&S.path), (size_t)SCOUT_MAX_F * PATH_WORDS * 8));
         if (!S.box) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&S.box), sizeof(ScoutBox)));
-        HIPCHK(c, hipMemsetAsync(S.ctl, 0, sizeof(BfsCtl), c->stream));
-        S.seed_hi = jobs[j].seed_hi ? J.d_seed_hi : nullptr;
-        S.seed_lo = J.d_seed_lo;
+        uint64_t *d_lo = reinterpret_cast<uint64_t *>(c->d_bfs_stage + seed_at[j]);
+        S.seed_hi = jobs[j].seed_hi ? d_lo + std::max<uint64_t>(ns, 1) : nullptr;
+        S.seed_lo = d_lo;
         S.n_seeds = ns;
         S.dir = jobs[j].dir;
     }
-    struct { BfsState *p; } d_states{nullptr};  // (kept in the context: an allocation and a release per call cost more than the launch)
-    if (c->d_bfs_states_cap < n_jobs) {
-        if (c->d_bfs_states) (void)hipFree(c->d_bfs_states);
-        c->d_bfs_states = nullptr;
-        c->d_bfs_states_cap = 0;
-        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_bfs_states), std::max<uint32_t>(n_jobs, 8) * sizeof(BfsState)));
-        c->d_bfs_states_cap = std::max<uint32_t>(n_jobs, 8);
-    }
-    d_states.p = static_cast<BfsState *>(c->d_bfs_states);
-    std::vector<BfsState> h_states(n_jobs);
+    BfsState *const d_states = reinterpret_cast<BfsState *>(c->d_bfs_stage);
+    BfsState *const h_states = reinterpret_cast<BfsState *>(c->h_bfs_stage);
     std::vector<BfsCtl> ctl(n_jobs);
     const unsigned long long max_rounds = 1ull << 17;  // bounds one launch; unfinished jobs are relaunched
     std::vector<std::array<unsigned long long, 4>> box_e(n_jobs, std::array<unsigned long long, 4>{0, 0, 0, 0});
     std::vector<unsigned long long> box_iters(n_jobs, 0), box_hops(n_jobs, 0), box_levels(n_jobs, 0), box_calls(n_jobs, 0), box_nf(n_jobs, 0), box_m0(n_jobs, 0);
-    for (;;) {
+    const uint64_t hdr_bytes = (uint64_t)n_jobs * sizeof(BfsPackHdr);
+    BfsPackHdr *h_hdr = nullptr;
+    for (int launch = 0;; launch++) {
         for (uint32_t j = 0; j < n_jobs; j++) h_states[j] = B[j]->S;
-        HIPCHK(c, hipMemcpyAsync(d_states.p, h_states.data(), n_jobs * sizeof(BfsState), hipMemcpyHostToDevice,
-                                 c->stream));
+        // (first launch: states and seeds; later ones, after a job's arrays grew: the states)
+        HIPCHK(c, hipMemcpyAsync(c->d_bfs_stage, c->h_bfs_stage, launch == 0 ? stage_bytes : (uint64_t)n_jobs * sizeof(BfsState), hipMemcpyHostToDevice, c->stream));
         // Few jobs: each gets a second workgroup that scouts ahead while the first verifies (bfs_device.h ScoutBox).  The
         // pair must be on the chip together to gain anything (it is correct either way), so not for large batches.
         static const bool no_comp = getenv("MC_BFS_COMPANION") && !strcmp(getenv("MC_BFS_COMPANION"), "0");
         const int companions = !no_comp && n_jobs <= 64 && c->solid_view().reads != nullptr ? 1 : 0;
-        for (uint32_t j = 0; j < n_jobs; j++) HIPCHK(c, hipMemsetAsync(B[j]->S.box, 0, sizeof(ScoutBox), c->stream));
-        int rc = timed(c, &total_ms, [&] { launch_bfs(c, c->stream, d_states.p, n_jobs, min_cov, max_kmers, max_radius, max_rounds, companions); });
-        if (rc) return rc;
-        // (the jobs' control blocks and mailboxes come back in one go: a blocking copy each cost 4 x 20 us on two jobs)
-        std::vector<ScoutBox> hbs(companions ? n_jobs : 0);
-        for (uint32_t j = 0; j < n_jobs && companions; j++) HIPCHK(c, hipMemcpyAsync(&hbs[j], B[j]->S.box, sizeof(ScoutBox), hipMemcpyDeviceToHost, c->stream));
-        for (uint32_t j = 0; j < n_jobs; j++) HIPCHK(c, hipMemcpyAsync(&ctl[j], B[j]->S.ctl, sizeof(BfsCtl), hipMemcpyDeviceToHost, c->stream));
+        hipLaunchKernelGGL(k_bfs_reset, dim3(n_jobs <= 8 ? 64 : 8, n_jobs), dim3(256), 0, c->stream, d_states, launch == 0 ? 1 : 0);
+        HIPCHK(c, hipGetLastError());
+        pack_bytes = 0;
+        for (uint32_t j = 0; j < n_jobs; j++) pack_bytes += bfs_pack_bytes(B[j]->S.dcap);
+        if (c->bfs_pack_cap < hdr_bytes + pack_bytes) {
+            if (c->d_bfs_pack) (void)hipFree(c->d_bfs_pack);
+            c->d_bfs_pack = nullptr;
+            c->bfs_pack_cap = 0;
+            HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_bfs_pack), hdr_bytes + pack_bytes));
+            c->bfs_pack_cap = hdr_bytes + pack_bytes;
+        }
+        if (c->bfs_hdr_cap < hdr_bytes) {
+            if (c->h_bfs_hdr) (void)hipHostFree(c->h_bfs_hdr);
+            c->h_bfs_hdr = nullptr;
+            c->bfs_hdr_cap = 0;
+            HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_bfs_hdr), hdr_bytes * 2, hipHostMallocDefault));
+            c->bfs_hdr_cap = hdr_bytes * 2;
+        }
+        // (the walk, the packing of its results and the copy of their headers are enqueued together: one wait)
+        HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+        launch_bfs(c, c->stream, d_states, n_jobs, min_cov, max_kmers, max_radius, max_rounds, companions);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+        int rc;
+        // ---- the results packed on the device: headers (control block, mailbox, offset, levels), then the jobs' arrays
+        h_hdr = reinterpret_cast<BfsPackHdr *>(c->h_bfs_hdr);
+        HIPCHK(c, hipMemsetAsync(c->d_bfs_pack, 0, hdr_bytes, c->stream));
+        hipLaunchKernelGGL(k_bfs_pack, dim3(n_jobs <= 8 ? 64 : 8, n_jobs), dim3(256), 0, c->stream, d_states, n_jobs,
+                           reinterpret_cast<BfsPackHdr *>(c->d_bfs_pack), c->d_bfs_pack + hdr_bytes, pack_bytes);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(h_hdr, c->d_bfs_pack, hdr_bytes, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        for (uint32_t j = 0; j < n_jobs && companions; j++) {
-            const ScoutBox &hb = hbs[j];
+        {
+            float ms = 0;
+            HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+            total_ms += ms;
+        }
+        for (uint32_t j = 0; j < n_jobs; j++) {
+            ctl[j] = h_hdr[j].ctl;
+            if (!companions) continue;
+            const ScoutBox &hb = h_hdr[j].box;
             box_iters[j] += hb.iters; box_e[j][0] += hb.e_stuck; box_e[j][1] += hb.e_nc0; box_e[j][2] += hb.e_budget; box_e[j][3] += hb.e_stop; box_hops[j] += hb.hops; box_levels[j] += hb.levels; box_calls[j] += hb.calls; box_nf[j] += hb.nf; box_m0[j] += hb.m0;
         }
         bool all_done = true;
@@ -3645,9 +3748,7 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
     }
 
     int ret = MC_OK;
-    std::vector<uint32_t *> fl_all;  // the jobs' flag words on the host (freed below)
     for (uint32_t j = 0; j < n_jobs; j++) {
-        const BfsState &S = B[j]->S;
         const uint64_t n = ctl[j].n;
         mc_bfs_result *o = &out[j];
         o->lookups = ctl[j].lookups;
@@ -3673,44 +3774,26 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
         }
 #endif
         if (n == 0) continue;  // the reference's "fail": no seed k-mer passes (out[j].n == 0)
-        o->n = n;
-        o->hi = static_cast<uint64_t *>(res_alloc(n * 8));
-        o->lo = static_cast<uint64_t *>(res_alloc(n * 8));
-        o->dist = static_cast<int32_t *>(res_alloc(n * 4));
-        o->cov = static_cast<int16_t *>(res_alloc(n * 2));
-        o->last = static_cast<uint8_t *>(res_alloc(n));
-        struct Scratch {
-            uint32_t *p;
-            ~Scratch() { res_free(p); }
-        } fl{static_cast<uint32_t *>(res_alloc(n * 4))};
-        if (!o->hi || !o->lo || !o->dist || !o->cov || !o->last || !fl.p) {
+        // one block per job (mc_bfs_result_free releases it through `hi`), laid out as k_bfs_pack wrote it
+        char *blk = static_cast<char *>(res_alloc(bfs_pack_bytes(n)));
+        if (!blk) {
             ret = fail(c, MC_ENOMEM, "mc_bfs: out of host memory");
             break;
         }
-        HIPCHK(c, hipMemcpyAsync(o->hi, S.hi, n * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(o->lo, S.lo, n * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(o->dist, S.dist, n * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(o->cov, S.cov, n * 2, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(fl.p, S.flags, n * 4, hipMemcpyDeviceToHost, c->stream));
-        fl_all.push_back(fl.p);
-        fl.p = nullptr;
-    }
-    if (ret == MC_OK) {  // one wait for all jobs' copies, then the little the host derives from them
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        size_t fi = 0;
-        for (uint32_t j = 0; j < n_jobs; j++) {
-            mc_bfs_result *o = &out[j];
-            if (o->n == 0) continue;
-            const uint32_t *flags = fl_all[fi++];
-            uint64_t levels = 0;
-            for (uint64_t i = 0; i < o->n; i++) {
-                o->last[i] = (uint8_t)(flags[i] & 1u);
-                if ((uint64_t)o->dist[i] > levels) levels = (uint64_t)o->dist[i];
-            }
-            o->levels = levels;
+        o->n = n;
+        o->hi = reinterpret_cast<uint64_t *>(blk);
+        o->lo = o->hi + n;
+        o->dist = reinterpret_cast<int32_t *>(o->lo + n);
+        o->cov = reinterpret_cast<int16_t *>(reinterpret_cast<char *>(o->dist) + ((4 * n + 7) & ~7ull));
+        o->last = reinterpret_cast<uint8_t *>(reinterpret_cast<char *>(o->cov) + ((2 * n + 7) & ~7ull));
+        o->levels = h_hdr[j].levels;
+        const hipError_t e = hipMemcpyAsync(blk, c->d_bfs_pack + hdr_bytes + h_hdr[j].offset, bfs_pack_bytes(n), hipMemcpyDeviceToHost, c->stream);
+        if (e != hipSuccess) {
+            ret = fail(c, MC_EHIP, "mc_bfs: %s", hipGetErrorString(e));
+            break;
         }
     }
-    for (uint32_t *q : fl_all) res_free(q);
+    if (hipStreamSynchronize(c->stream) != hipSuccess && ret == MC_OK) ret = fail(c, MC_EHIP, "mc_bfs: copying the results failed");
     if (ret != MC_OK)
         for (uint32_t j = 0; j < n_jobs; j++) mc_bfs_result_free(&out[j]);
     return ret;
