@@ -191,6 +191,23 @@ __global__ void k_tile_first_read(const uint64_t *__restrict__ offsets, uint64_t
     first_read[t] = (uint32_t)a;
 }
 
+// The same table from the reads' side, for short reads (a few per tile): read r names itself for the tiles whose `back`
+// lies inside it -- two coalesced loads and usually one store or none per read instead of a 23-step dependent search per
+// tile (84 -> ~20 us for 10 M reads of 150 bases).  Tiles in front of the first read get 0, as the search gives them.
+__global__ void k_tile_first_read_by_reads(const uint64_t *__restrict__ offsets, uint64_t n_reads, uint64_t n_tiles,
+                                           uint32_t *__restrict__ first_read, uint32_t tile_size)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint64_t a = offsets[r], b = offsets[r + 1];
+    if (b <= a && r != 0) return;  // (an empty read owns no position)
+    // back(t) = max(t * tile_size - 64, 0) in [a, b)  <=>  t in [ceil((a + 64) / T), ceil((b + 64) / T)), and t = 0 where a == 0
+    uint64_t t_lo = (a + 64 + tile_size - 1) / tile_size, t_hi = std::min<uint64_t>((b + 64 + tile_size - 1) / tile_size, n_tiles);
+    if (r == 0) t_lo = 0;  // (tile 0, and whatever lies in front of the first read)
+    else if (a == 0) t_lo = 0;
+    for (uint64_t t = t_lo; t < t_hi; t++) first_read[t] = (uint32_t)r;
+}
+
 __device__ __forceinline__ uint64_t starts_window(const uint32_t *bits, uint32_t pos)
 {  // 64 bits of the bitmap starting at bit `pos`
     const uint32_t w = pos >> 5, s = pos & 31;

@@ -149,7 +149,9 @@ struct mc_ctx {
     Slot *slots = nullptr;
     uint64_t n_regions = 0;    // regions of 2^sb slots: a power of two, or (minimizer-bin tables of >= 512 regions) any multiple of 512
     uint32_t rb = 0, sb = MC_REGION_LG;  // rb = log2(n_regions) when that is a power of two (else its floor)
-    unsigned long long *d_ctr = nullptr;  // [0] n_used, [1] empty_cnt, [2] scratch counter, [3] solid n_used, [4..5] read summary, [6] keys with count >= cov_hint
+    unsigned long long *d_ctr = nullptr;  // [0] n_used, [1] empty_cnt, [2] scratch counter, [3] solid n_used, [4..5] read summary, [6] keys with count >= cov_hint,
+                                          // [7] parked additions, [8] the `fatal` flag (d_fatal points here), [10..13] read summary of a device batch
+    unsigned long long *h_scratch = nullptr;  // 32 pinned words: where the small device-to-host copies land (a copy into pageable memory is staged)
     uint32_t *d_fatal = nullptr;
     uint64_t n_used_host = 0;
     bool finalized = false;
@@ -210,7 +212,7 @@ struct mc_ctx {
             (void)hipFree(a_recs); (void)hipFree(b_recs); (void)hipFree(spill_recs); (void)hipFree(solid_cursors); (void)hipFree(emit_counts);
             (void)hipFree(a_hints); (void)hipFree(b_hints); (void)hipFree(spill_hints); (void)hipFree(tile_first);
             (void)hipFree(cursors1); (void)hipFree(seg_counts1); (void)hipFree(cursors2); (void)hipFree(leaf_state); (void)hipFree(leaf_new); (void)hipFree(flags);
-            (void)hipFree(spill_count);
+            // (spill_count lives behind flags, in the same allocation)
             *this = Pipe{};
         }
     } pipe;
@@ -607,17 +609,24 @@ __global__ void __launch_bounds__(512) k_solid_from_leaves(const uint4 *__restri
 
 // windows = sum over reads of max(0, len - k + 1); also checks that the offsets never decrease
 __global__ void k_reads_summary(const uint64_t *__restrict__ offsets, uint64_t n_reads, uint64_t k,
-                                unsigned long long *out /* [0] windows, [1] violations */)
+                                unsigned long long *out /* [0] windows, [1] violations; ends != 0: [2] first offset, [3] last offset */, int ends = 0)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     unsigned long long w = 0, bad = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_reads; i += stride) {
+    // two reads a thread and step (three offsets, the middle one shared): half the loads of a read a thread
+    for (uint64_t i = 2 * ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x); i < n_reads; i += 2 * stride) {
         const uint64_t a = offsets[i], b = offsets[i + 1];
         if (b < a) bad++;
         else if (b - a >= k) w += b - a - k + 1;
+        if (i + 1 < n_reads) {
+            const uint64_t c2 = offsets[i + 2];
+            if (c2 < b) bad++;
+            else if (c2 - b >= k) w += c2 - b - k + 1;
+        }
     }
     wave_add_ull(out, w);
     wave_add_ull(out + 1, bad);
+    if (ends && blockIdx.x == 0 && threadIdx.x == 0) { out[2] = offsets[0]; out[3] = offsets[n_reads]; }
 }
 
 // K4: BigLong2ShortHashMap.get for a batch of keys
@@ -831,11 +840,11 @@ static int materialize(mc_ctx *c)
 
 static int read_counters(mc_ctx *c, unsigned long long *n_used, uint32_t *fatal)
 {
-    unsigned long long h[3];
-    HIPCHK(c, hipMemcpyAsync(h, c->d_ctr, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(fatal, c->d_fatal, sizeof *fatal, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long *h = c->h_scratch;
+    HIPCHK(c, hipMemcpyAsync(h, c->d_ctr, 9 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     *n_used = h[0];
+    *fatal = (uint32_t)h[8];
     return MC_OK;
 }
 
@@ -1038,6 +1047,26 @@ struct PipePlan {
     SkSpill sks{};
 };
 
+// first_read[t] for every tile (count_pipeline.h): by the reads where they are short, by a search per tile otherwise
+static void launch_tile_first(mc_ctx *c, const uint64_t *offs, uint64_t nr, uint64_t n_tiles, uint32_t *out, uint32_t tile_size)
+{
+    if (nr && n_tiles <= 8 * nr)  // (a read spans a few tiles at most on average: its thread's loop is short)
+        hipLaunchKernelGGL(k_tile_first_read_by_reads, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, c->stream, offs, nr, n_tiles, out, tile_size);
+    else
+        hipLaunchKernelGGL(k_tile_first_read, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, c->stream, offs, nr, n_tiles, out, tile_size);
+}
+
+// the control words of a pipeline run, cleared in one launch (flags: 4 words + the 64-bit spill counter behind them)
+__global__ void __launch_bounds__(256) k_pipe_reset(uint32_t *seg_counts1, uint64_t n1, uint32_t *cursors2, uint64_t n2, uint32_t *leaf_state,
+                                                    uint32_t *leaf_new, uint64_t n_leaves, uint32_t *flags)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x, stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = t; i < n1; i += stride) seg_counts1[i] = 0;
+    for (uint64_t i = t; i < n2; i += stride) cursors2[i] = 0;
+    for (uint64_t i = t; i < n_leaves; i += stride) { leaf_state[i] = 0; leaf_new[i] = 0; }
+    if (t < 6) flags[t] = 0;
+}
+
 // Table capacity check, scratch buffers and cursors for one run of the partitioned pipeline over
 // `wb` key occurrences.  n_records != 0: they travel as (an estimated) n_records super-k-mer records.
 static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records = 0, uint32_t nseg1 = PT_SEGMENTS, uint32_t pieces = 1)
@@ -1114,14 +1143,14 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
     ENSURE(P.cursors2, P.cursors2_cap, n_leaves * pieces);
     { uint64_t cap = P.leaves_cap; ENSURE(P.leaf_state, cap, n_leaves); dummy = P.leaves_cap; ENSURE(P.leaf_new, dummy, n_leaves); P.leaves_cap = cap; }
 #undef ENSURE
-    if (!P.flags) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.flags), 4 * sizeof(uint32_t)));
-    if (!P.spill_count) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.spill_count), sizeof(unsigned long long)));
-    HIPCHK(c, hipMemsetAsync(P.seg_counts1, 0, np1 * nseg1 * pieces * sizeof(uint32_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(P.cursors2, 0, n_leaves * pieces * sizeof(uint32_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(P.leaf_state, 0, n_leaves * sizeof(uint32_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(P.leaf_new, 0, n_leaves * sizeof(uint32_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(P.flags, 0, 4 * sizeof(uint32_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(P.spill_count, 0, sizeof(unsigned long long), c->stream));
+    if (!P.flags) {  // four flags and, behind them, the spill counter: cleared by one fill, read by one copy
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.flags), 4 * sizeof(uint32_t) + sizeof(unsigned long long)));
+        P.spill_count = reinterpret_cast<unsigned long long *>(P.flags + 4);
+    }
+    // (one launch clears all five: a fill each, 10 us apart, was 60 us in front of every run)
+    hipLaunchKernelGGL(k_pipe_reset, dim3(256), dim3(256), 0, c->stream, P.seg_counts1, np1 * nseg1 * pieces, P.cursors2, n_leaves * pieces, P.leaf_state,
+                       P.leaf_new, n_leaves, P.flags);
+    HIPCHK(c, hipGetLastError());
     pl->sp = SpillView{P.spill_keys, P.spill_hints, P.spill_count, pl->spill_cap, P.flags};
     pl->sks = SkSpill{P.spill_recs, P.spill_count, pl->spill_cap, P.flags};
     return MC_OK;
@@ -1264,9 +1293,10 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
         launch_p3();
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(c->ev_t[3], c->stream));
-        HIPCHK(c, hipMemcpyAsync(flags, P.flags, sizeof flags, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(&n_spill, P.spill_count, sizeof n_spill, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_scratch + 16, P.flags, 4 * sizeof(uint32_t) + sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        memcpy(flags, c->h_scratch + 16, sizeof flags);
+        n_spill = c->h_scratch[18];
         float f = 0;
         if (p1_pending) { HIPCHK(c, hipEventElapsedTime(&f, c->ev_t[0], c->ev_t[1])); ms1 = f; }
         if (pl.b2 > 1 && !p2_done) { HIPCHK(c, hipEventElapsedTime(&f, c->ev_t[1], c->ev_t[2])); ms2 += f; }
@@ -1478,8 +1508,7 @@ static int add_reads_partitioned_once(mc_ctx *c, const uint64_t *d_words, const 
     if (pieces > 1 && !pl.sk) {
         const uint64_t t_first = base0 / tile_size, per = (n_tiles_abs - t_first + pieces - 1) / pieces;
         rc = timed(c, &ms1, [&] {
-            hipLaunchKernelGGL(k_tile_first_read, dim3((unsigned)((n_tiles_abs + 255) / 256)), dim3(256), 0, c->stream, offs, nr, n_tiles_abs, P.tile_first,
-                               tile_size);
+            launch_tile_first(c, offs, nr, n_tiles_abs, P.tile_first, tile_size);
             for (uint32_t pc = 0; pc < pieces; pc++) {
                 const uint64_t lo_t = t_first + pc * per, hi_t = std::min<uint64_t>(n_tiles_abs, lo_t + per);
                 if (lo_t >= hi_t) continue;
@@ -1495,8 +1524,7 @@ static int add_reads_partitioned_once(mc_ctx *c, const uint64_t *d_words, const 
         const uint64_t t_first = base0 / tile_size, per = (n_tiles_abs - t_first + pieces - 1) / pieces;
         const uint64_t a_stride = pl.np1 * pl.nseg1 * pl.cap1, c_stride = pl.np1 * pl.nseg1;
         HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-        hipLaunchKernelGGL(k_tile_first_read, dim3((unsigned)((n_tiles_abs + 255) / 256)), dim3(256), 0, c->stream, offs, nr,
-                           n_tiles_abs, P.tile_first, tile_size);
+        launch_tile_first(c, offs, nr, n_tiles_abs, P.tile_first, tile_size);
         for (uint32_t pc = 0; pc < pieces; pc++) {
             const uint64_t lo_t = t_first + pc * per, hi_t = std::min<uint64_t>(n_tiles_abs, lo_t + per);
             if (lo_t < hi_t)
@@ -1523,8 +1551,7 @@ static int add_reads_partitioned_once(mc_ctx *c, const uint64_t *d_words, const 
         rc = pipe_finish(c, pl, ms1, true, f2 > 0 ? f2 : 0, false, true);
     } else {
         HIPCHK(c, hipEventRecord(c->ev_t[0], c->stream));  // (no wait here: pipe_finish enqueues P2 and P3 right behind)
-        hipLaunchKernelGGL(k_tile_first_read, dim3((unsigned)((n_tiles_abs + 255) / 256)), dim3(256), 0, c->stream, offs, nr,
-                           n_tiles_abs, P.tile_first, tile_size);
+        launch_tile_first(c, offs, nr, n_tiles_abs, P.tile_first, tile_size);
         if (pl.sk)
             hipLaunchKernelGGL(k_sk1w_extract<false>, dim3(P1W_SEGMENTS), dim3(P1W_THREADS), 0, c->stream, d_words, offs, nr, base0, end_abs,
                                n_tiles_abs, P.tile_first, c->cfg.k, pl.b1, P.seg_counts1, pl.cap1, P.a_recs, P.a_hints, pl.sks, c->cur_ptr_base);
@@ -1605,14 +1632,15 @@ static int add_reads_partitioned_long(mc_ctx *c, const uint64_t *d_words, const 
     { uint64_t cap = P.leaves_cap, dummy = P.leaves_cap; ENSURE(P.leaf_state, cap, n_leaves); ENSURE(P.leaf_new, dummy, n_leaves); P.leaves_cap = cap; }
     ENSURE(P.tile_first, P.tiles1_cap, n_tiles_abs);
 #undef ENSURE
-    if (!P.flags) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.flags), 4 * sizeof(uint32_t)));
-    if (!P.spill_count) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.spill_count), sizeof(unsigned long long)));
+    if (!P.flags) {  // four flags and, behind them, the spill counter: cleared by one fill, read by one copy
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.flags), 4 * sizeof(uint32_t) + sizeof(unsigned long long)));
+        P.spill_count = reinterpret_cast<unsigned long long *>(P.flags + 4);
+    }
     HIPCHK(c, hipMemsetAsync(P.seg_counts1, 0, np1 * nseg1 * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(P.cursors2, 0, n_leaves * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(P.leaf_state, 0, n_leaves * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(P.leaf_new, 0, n_leaves * sizeof(uint32_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(P.flags, 0, 4 * sizeof(uint32_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(P.spill_count, 0, sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(P.flags, 0, 4 * sizeof(uint32_t) + sizeof(unsigned long long), c->stream));
     SkLRec *a = reinterpret_cast<SkLRec *>(P.a_recs), *b = reinterpret_cast<SkLRec *>(P.b_recs), *spill = reinterpret_cast<SkLRec *>(P.spill_recs);
     const SkLSpill sp{spill, P.spill_count, spill_cap, P.flags};
     const uint64_t *offs = d_off + r0;
@@ -1620,8 +1648,7 @@ static int add_reads_partitioned_long(mc_ctx *c, const uint64_t *d_words, const 
     const uint32_t thr = (uint32_t)(c->solid_tracked ? c->cov_hint : 0);
     double ms1 = 0, ms2 = 0, ms3 = 0, ms4 = 0;
     rc = timed(c, &ms1, [&] {
-        hipLaunchKernelGGL(k_tile_first_read, dim3((unsigned)((n_tiles_abs + 255) / 256)), dim3(256), 0, c->stream, offs, nr, n_tiles_abs, P.tile_first,
-                           SKL_TILE);
+        launch_tile_first(c, offs, nr, n_tiles_abs, P.tile_first, SKL_TILE);
         hipLaunchKernelGGL(k_skl_extract, dim3(nseg1), dim3(SKL_THREADS), 0, c->stream, d_words, offs, nr, base0, end_abs, n_tiles_abs, P.tile_first, k,
                            (uint32_t)np1, P.seg_counts1, cap1, a, sp, c->cur_ptr_base);
     });
@@ -1968,11 +1995,12 @@ int mc_create(const mc_config *cfg, mc_ctx **out)
     for (auto &e : c->ev_piece) CREATE_CHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     CREATE_CHK(hipEventCreate(&c->ev_p2));
     for (auto &e : c->ev_t) CREATE_CHK(hipEventCreate(&e));
-    CREATE_CHK(hipMalloc(reinterpret_cast<void **>(&c->d_ctr), 8 * sizeof(unsigned long long)));
-    CREATE_CHK(hipMalloc(reinterpret_cast<void **>(&c->d_fatal), sizeof(uint32_t)));
+    CREATE_CHK(hipMalloc(reinterpret_cast<void **>(&c->d_ctr), 16 * sizeof(unsigned long long)));
+    CREATE_CHK(hipHostMalloc(reinterpret_cast<void **>(&c->h_scratch), 32 * sizeof(unsigned long long), hipHostMallocDefault));
+    c->d_fatal = reinterpret_cast<uint32_t *>(c->d_ctr + 8);  // (one copy brings the counters and the flag)
     CREATE_CHK(hipMalloc(reinterpret_cast<void **>(&c->d_ovf), mc_ctx::OVF_CAP * sizeof(uint4)));
-    CREATE_CHK(hipMemsetAsync(c->d_ctr, 0, 8 * sizeof(unsigned long long), c->stream));
-    CREATE_CHK(hipMemsetAsync(c->d_fatal, 0, sizeof(uint32_t), c->stream));
+    CREATE_CHK(hipMemsetAsync(c->d_ctr, 0, 16 * sizeof(unsigned long long), c->stream));
+
 #undef CREATE_CHK
     if (const char *e = getenv("MC_COUNT_PATH")) c->count_path = !strcmp(e, "direct") ? 1 : !strcmp(e, "partition") ? 2 : 0;
     if (const char *e = getenv("MC_BFS_DIRECT")) c->bfs_direct = strcmp(e, "0") != 0;
@@ -2021,7 +2049,7 @@ void mc_destroy(mc_ctx *c)
     c->pipe.release();
     c->bfs_pool.clear();
     if (c->d_ctr) (void)hipFree(c->d_ctr);
-    if (c->d_fatal) (void)hipFree(c->d_fatal);
+    if (c->h_scratch) (void)hipHostFree(c->h_scratch);
     if (c->d_ovf) (void)hipFree(c->d_ovf);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -2048,9 +2076,7 @@ int mc_clear(mc_ctx *c)
     HIPCHK(c, hipSetDevice(c->cfg.device));
     c->virgin = true;
     c->rs_bases = 0;  // (slots that pointed into the read store go with the table)
-    HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, 4 * sizeof(unsigned long long), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_ctr + 6, 0, 2 * sizeof(unsigned long long), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_fatal, 0, sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, 9 * sizeof(unsigned long long), c->stream));  // (counters and the fatal flag: one fill)
     c->n_used_host = 0;
     c->finalized = false;
     c->solid_cov = -1; c->solid_external = false;
@@ -2227,16 +2253,15 @@ static int add_reads_dev_counted(mc_ctx *c, const uint64_t *d_words, const uint6
 {
     // summary on the device: total windows, monotone offsets, first and last offset
     unsigned long long *sum = c->d_ctr + 4;
-    HIPCHK(c, hipMemsetAsync(sum, 0, 2 * sizeof(unsigned long long), c->stream));
-    hipLaunchKernelGGL(k_reads_summary, dim3(grid_for(n_reads, 256)), dim3(256), 0, c->stream, d_off, n_reads,
-                       (uint64_t)c->cfg.k, sum);
+    unsigned long long *sum4 = c->d_ctr + 10;  // windows, violations, first offset, last offset: one copy
+    HIPCHK(c, hipMemsetAsync(sum4, 0, 2 * sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(k_reads_summary, dim3(grid_for((n_reads + 1) / 2, 256)), dim3(256), 0, c->stream, d_off, n_reads,
+                       (uint64_t)c->cfg.k, sum4, 1);
     HIPCHK(c, hipGetLastError());
-    unsigned long long hs[2];
-    uint64_t first_off = 0, last_off = 0;
-    HIPCHK(c, hipMemcpyAsync(hs, sum, sizeof hs, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&first_off, d_off, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&last_off, d_off + n_reads, 8, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long *hs = c->h_scratch + 20;
+    HIPCHK(c, hipMemcpyAsync(hs, sum4, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    const uint64_t first_off = hs[2], last_off = hs[3];
     if (hs[1]) return fail(c, MC_EINVAL, "mc_add_reads_packed_dev: read_offsets not monotone");
     if (last_off != n_bases)
         return fail(c, MC_EINVAL, "mc_add_reads_packed_dev: read_offsets[n_reads]=%llu but n_bases=%llu",
@@ -2779,11 +2804,10 @@ int mc_finalize_counts(mc_ctx *c, uint64_t *n_distinct)
         if (!rc) rc = drain_parked(c);
         if (rc) return rc;
     }
-    unsigned long long h[3];
-    uint32_t fatal;
-    HIPCHK(c, hipMemcpyAsync(h, c->d_ctr, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&fatal, c->d_fatal, sizeof fatal, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long *h = c->h_scratch;
+    HIPCHK(c, hipMemcpyAsync(h, c->d_ctr, 9 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    const uint32_t fatal = (uint32_t)h[8];
     if (fatal) return fail(c, MC_EOVERFLOW, "a k-mer table region filled up (hash skew)");
     c->n_used_host = h[0];
     c->finalized = true;
@@ -2957,16 +2981,16 @@ int mc_extract_superkmers_dev(mc_ctx *c, const uint64_t *d_words, const uint64_t
     if (!rc) rc = ensure_buf(c, &P.a_hints, &P.a_hints_cap, (uint64_t)n_owners * nseg * seg_cap);
     if (!rc) rc = ensure_buf(c, &P.seg_counts1, &P.segs1_cap, (uint64_t)n_owners * nseg);
     if (rc) return rc;
-    if (!P.flags) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.flags), 4 * sizeof(uint32_t)));
-    if (!P.spill_count) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.spill_count), sizeof(unsigned long long)));
-    HIPCHK(c, hipMemsetAsync(P.flags, 0, 4 * sizeof(uint32_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(P.spill_count, 0, sizeof(unsigned long long), c->stream));
+    if (!P.flags) {  // four flags and, behind them, the spill counter: cleared by one fill, read by one copy
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.flags), 4 * sizeof(uint32_t) + sizeof(unsigned long long)));
+        P.spill_count = reinterpret_cast<unsigned long long *>(P.flags + 4);
+    }
+    HIPCHK(c, hipMemsetAsync(P.flags, 0, 4 * sizeof(uint32_t) + sizeof(unsigned long long), c->stream));
     DevBuf<unsigned long long> d_piece, d_owner;
     HIPCHK(c, d_piece.alloc((uint64_t)n_owners * nseg));
     HIPCHK(c, d_owner.alloc(n_owners + 1));
     const SkSpill none{nullptr, P.spill_count, 0, P.flags};  // no spill list: an overflow is reported
-    hipLaunchKernelGGL(k_tile_first_read, dim3((unsigned)((n_tiles_abs + 255) / 256)), dim3(256), 0, c->stream, d_off, n_reads,
-                       n_tiles_abs, P.tile_first, P1W_TILE);
+    launch_tile_first(c, d_off, n_reads, n_tiles_abs, P.tile_first, P1W_TILE);
     hipLaunchKernelGGL(k_sk1w_extract<true>, dim3(nseg), dim3(P1W_THREADS), 0, c->stream, d_words, d_off, n_reads, first_off,
                        last_off, n_tiles_abs, P.tile_first, c->cfg.k, n_owners, P.seg_counts1, seg_cap, P.a_recs, P.a_hints, none, c->cur_ptr_base);
     hipLaunchKernelGGL(k_sk_pack_offsets, dim3(1), dim3(1024), 0, c->stream, P.seg_counts1, n_owners, d_piece.p, d_owner.p, nseg);
@@ -3383,10 +3407,11 @@ int solid_build(mc_ctx *c, uint64_t n, int min_cov, double *ms, const PairSource
         if (!rc && sb2) rc = ensure_buf(c, l2_bins, l2_bins_cap, need2);
         if (!rc && sb2) rc = ensure_buf(c, &P.solid_cursors, &P.solid_cursors_cap, 1ull << q);
         if (rc) return rc;
-        if (!P.flags) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.flags), 4 * sizeof(uint32_t)));
-        if (!P.spill_count) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.spill_count), sizeof(unsigned long long)));
-        HIPCHK(c, hipMemsetAsync(P.flags, 0, 4 * sizeof(uint32_t), c->stream));
-        HIPCHK(c, hipMemsetAsync(P.spill_count, 0, sizeof(unsigned long long), c->stream));
+        if (!P.flags) {  // four flags and, behind them, the spill counter: cleared by one fill, read by one copy
+            HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.flags), 4 * sizeof(uint32_t) + sizeof(unsigned long long)));
+            P.spill_count = reinterpret_cast<unsigned long long *>(P.flags + 4);
+        }
+        HIPCHK(c, hipMemsetAsync(P.flags, 0, 4 * sizeof(uint32_t) + sizeof(unsigned long long), c->stream));
     }
     const bool list = partitioned && from_list && !pairs;
     uint4 *const r1 = list ? P.b_recs : P.a_recs, *const r2 = list ? P.a_recs : P.b_recs;
