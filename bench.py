@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--maxkmers", type=int, default=100000)
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--skip-no-hint", action="store_true", help="do not time the counting without a capacity hint (3 extra counting runs)")
     ap.add_argument("--capacity-hint", type=int, default=0, help="distinct k-mers per GPU expected (0: estimate from the error rate)")
     ap.add_argument("--config", type=int, default=1, choices=[1, 2],
                     help="BASELINE.json configs[N]: 1 = the headline (10 M reads, k=31, coverage 5, bothdirs False); 2 = k=63 poly-hash "
@@ -126,9 +127,11 @@ def main():
     info = {}
 
     def step():
+        t_c = time.perf_counter()
         ctx.clear()
         sc.add_reads_dev(d_words, d_off, R, n_bases, windows)
-        info["distinct"] = sc.finalize()
+        info["distinct"] = sc.finalize()  # (waits for the counting to end)
+        info["count_wall_s"] = info.get("count_wall_s", 0.0) + (time.perf_counter() - t_c)
         bctx = ctx
         if world > 1:
             if solid is not None:
@@ -160,6 +163,7 @@ def main():
         step()
     sync()
     ctx.reset_stats()
+    info["count_wall_s"] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -171,7 +175,27 @@ def main():
         elapsed = float(t.item())
     st = ctx.stats()
 
-    # which of BASELINE.json's configs the line is quoted on
+    # The same counting WITHOUT a capacity hint -- how the CLI and the reference's self-growing BigLong2ShortHashMap start:
+    # a fresh context per step (64 MB table), which sizes its table from the first level-1 bucket of the batch.
+    no_hint = None
+    if world == 1 and not args.skip_no_hint and args.config == 1:
+        walls = []
+        for i in range(4):  # (the first one brings the table's memory into the process: not timed)
+            c2 = m.Context(k, mode, local_rank, 0)
+            c2.set_coverage_hint(args.coverage)
+            torch.cuda.synchronize(dev)
+            t_c = time.perf_counter()
+            c2.add_reads_packed_dev(d_words, d_off, R, n_bases)
+            d2 = c2.finalize()
+            dt = time.perf_counter() - t_c
+            st2 = c2.stats()
+            c2.close()
+            if d2 != info["distinct"]:
+                raise SystemExit("no-hint context counted %d distinct k-mers, the hinted one %d" % (d2, info["distinct"]))
+            if i:
+                walls.append(dt)
+        no_hint = {"count_wall_ms": 1e3 * sum(walls) / len(walls), "table_grows": int(st2.grows), "table_bytes": int(st2.table_bytes)}
+
     full = (args.config == 1 and R == 10_000_000) or (args.config == 2 and R == 100_000_000)
     if world > 1 and args.config == 1:
         cfg_label = "configs[3]" if R * world == 1_000_000_000 else ("configs[1] on every GPU (weak scaling; configs[3] = --total-reads 1000000000)" if full else "configs[1] scaled, on every GPU")
@@ -257,6 +281,13 @@ def main():
             "spilled_records_per_step": int(st.spill_keys) // args.steps, "solid_sweeps_per_step": int(st.solid_sweeps) / args.steps, "solid_list_builds_per_step": int(st.solid_list_builds) / args.steps,
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        out["count_wall_ms"] = round(1e3 * info["count_wall_s"] / args.steps, 3)  # clear + count + finalize as the host sees them (kernels: roofline.count_ms_per_step)
+        if no_hint is not None:
+            # the headline's context knows the number of distinct k-mers beforehand (capacity hint); these do not
+            out["count_ms_no_hint"] = round(no_hint["count_wall_ms"], 3)
+            out["value_no_hint"] = total_windows / ((ms_per_step - out["count_wall_ms"] + no_hint["count_wall_ms"]) * 1e-3)
+            out["no_hint"] = {"table_grows_per_step": no_hint["table_grows"], "table_bytes": no_hint["table_bytes"],
+                              "how": "fresh context (64 MB table) per step; table sized from the first level-1 bucket of the batch; table memory recycled inside the process"}
         if world > 1:
             out["solid_kmers"] = info.get("solid")
             out["alltoall_bytes_sent_rank0_per_step"] = sc.bytes_sent // (args.steps + args.warmup)

@@ -29,7 +29,8 @@ namespace mc {
 constexpr int PT_THREADS = 1024;                    // workgroup of the scatter kernels
 constexpr int PT_ITEMS = 8;
 constexpr int PT_TILE = PT_THREADS * PT_ITEMS;      // 8192 windows / keys per tile
-constexpr int PT_MAX_BUCKETS = 512;                 // fan-out of one scatter level
+constexpr int PT_MAX_BUCKETS = 512;                 // fan-out of one scatter level (what a run takes unless the table needs more leaves)
+constexpr int PT_MAX_BUCKETS_KEYS = 1024;           // ... at most, in the per-window pipeline (k_p1_extract_scatter / k_p2_scatter: a thread per bucket): 2^20 leaves
 constexpr int PT_MAX_LEAVES2 = 1024;                // ... of the second level of the super-k-mer pipeline (k_sk2_scatter: an LDS cursor per leaf)
 constexpr int PT_MAX_BUCKETS1_SK = 1024;             // level-1 buckets of the super-k-mer pipeline when 512 x 1024 leaves are not enough
 constexpr int SK_LEAVES_LG = 20;                    // so up to 1024 x 1024 leaves of one region each (4.3 G slots of 16 bytes = 69 GB of table)
@@ -48,8 +49,8 @@ struct ScatterLds {
     uint64_t key[PT_TILE];
     uint32_t hint[PT_TILE];
     uint32_t rel[PT_TILE];                       // where the staged record goes, relative to out_base (~0 = spill)
-    uint32_t cnt[PT_MAX_BUCKETS], off[PT_MAX_BUCKETS], gbase[PT_MAX_BUCKETS];
-    uint32_t wcur[PT_MAX_BUCKETS];               // this workgroup's own fill level of every bucket
+    uint32_t cnt[PT_MAX_BUCKETS_KEYS], off[PT_MAX_BUCKETS_KEYS], gbase[PT_MAX_BUCKETS_KEYS];
+    uint32_t wcur[PT_MAX_BUCKETS_KEYS];          // this workgroup's own fill level of every bucket
     uint32_t seg_prefix[PT_SEGMENTS + 1];        // P2: where each input segment starts in the bucket's stream
     uint32_t starts[(PT_TILE + 256) / 32 + 2];  // P1: bit per base position = "a read starts here"
     uint32_t wave_tot[PT_THREADS / 64];
@@ -105,7 +106,7 @@ __device__ __forceinline__ void scatter_tile(ScatterLds &L, const uint64_t (&key
 #ifdef MC_P1_TIMING
     ts_[1] = __builtin_amdgcn_s_memrealtime();
 #endif
-    // exclusive scan of cnt[0..n_buckets) (n_buckets <= 512 <= blockDim)
+    // exclusive scan of cnt[0..n_buckets) (n_buckets <= PT_MAX_BUCKETS_KEYS <= blockDim)
     {
         const uint32_t lane = tid & 63, wv = tid >> 6;
         const uint32_t c = tid < n_buckets ? L.cnt[tid] : 0u;
@@ -252,7 +253,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_p1_extract_scatter(
     __shared__ ScatterLds L;
     const uint32_t tid = threadIdx.x;
     const uint32_t n_buckets = np1;  // (owner ranks, or level-1 buckets)
-    if (tid < PT_MAX_BUCKETS) L.wcur[tid] = 0;  // (counting pipeline: gridDim.x == PT_SEGMENTS, segment = blockIdx.x)
+    if (tid < PT_MAX_BUCKETS_KEYS) L.wcur[tid] = 0;  // (counting pipeline: gridDim.x == PT_SEGMENTS, segment = blockIdx.x)
     if (MODE == KEY_POLY && tid < 256) poly_tables_fill(L.polyF, L.polyR, tid);  // (published by the first tile's barriers)
 #ifdef MC_P1_TIMING
     if (tid < 4) L.dbg[tid] = 0;
@@ -369,7 +370,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_p1_keys_scatter(const uint64_t *
     const uint32_t tid = threadIdx.x;
     const uint32_t n_buckets = np1;
     const uint64_t n_tiles = (n + PT_TILE - 1) / PT_TILE;
-    if (tid < PT_MAX_BUCKETS) L.wcur[tid] = 0;
+    if (tid < PT_MAX_BUCKETS_KEYS) L.wcur[tid] = 0;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         if (tid < n_buckets) L.cnt[tid] = 0;
         __syncthreads();
@@ -415,7 +416,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_p2_scatter(const uint64_t *__res
     const uint32_t n_buckets = m2;  // leaves per level-1 bucket
     for (uint32_t bucket = blockIdx.x; bucket < n_buckets1; bucket += gridDim.x) {
         __syncthreads();
-        if (tid < PT_MAX_BUCKETS) L.wcur[tid] = 0;
+        if (tid < PT_MAX_BUCKETS_KEYS) L.wcur[tid] = 0;
         if (tid == 0) {  // (257 additions: not worth a parallel scan)
             uint32_t acc = 0;
             for (int sgm = 0; sgm < PT_SEGMENTS; sgm++) {
@@ -552,7 +553,7 @@ constexpr int P1W_THREADS = 512;
 constexpr int P1W_WAVES = P1W_THREADS / 64;
 constexpr uint32_t P1W_TILE = 62 * PT_ITEMS;   // base positions per wave tile
 constexpr int P1W_SEGMENTS = 1024;             // workgroups of the launch = segments of every level-1 bucket
-static_assert(PT_MAX_LEAVES2 <= PT_THREADS, "one thread per leaf cursor");
+static_assert(PT_MAX_LEAVES2 <= PT_THREADS && PT_MAX_BUCKETS_KEYS <= PT_THREADS, "one thread per leaf cursor");
 static_assert(P1W_SEGMENTS <= PT_THREADS && P1W_SEGMENTS >= PT_SEGMENTS, "k_sk2_scatter scans one segment count per thread");
 
 struct alignas(16) Sk1wLds {
@@ -876,6 +877,35 @@ __global__ void __launch_bounds__(256) k_sk_pack(const uint4 *__restrict__ recs,
             out_bins[dst + i] = bins[src + i];
         }
     }
+}
+
+// Distinct canonical k-mers among the records of level-1 bucket 0 (segments 0 .. gridDim.x - 1 of capacity seg_cap), counted
+// into a scratch set of 64-bit keys (all ones = free; mask + 1 slots, linear probing): the sample that sizes the table of a
+// context without a capacity hint (mcgpu.hip pipe_resize_by_sample).  An estimate is all that is asked: a key that finds
+// its probe sequence longer than 64 slots is counted as new.
+__global__ void __launch_bounds__(256) k_sk_sample_distinct(const uint4 *__restrict__ recs, const uint32_t *__restrict__ seg_counts, uint64_t seg_cap, int k,
+                                                            uint64_t *set, uint64_t mask, unsigned long long *n_distinct)
+{
+    const uint32_t n = min(seg_counts[blockIdx.x], (uint32_t)seg_cap);
+    const uint4 *seg = recs + (uint64_t)blockIdx.x * seg_cap;
+    unsigned long long n_new = 0;
+    for (uint32_t r = threadIdx.x; r < n; r += 256) {
+        const uint4 rec = seg[r];
+        const uint64_t lo = ((uint64_t)rec.y << 32) | rec.x, hi = ((uint64_t)rec.w << 32) | rec.z;
+        for (uint32_t j = 0; j < sk_windows(hi); j++) {
+            const uint64_t key = sk_window_key(lo, hi, j, k);
+            uint64_t s = fmix64(key) & mask;
+            bool placed = false;
+            for (int probe = 0; probe < 64 && !placed; probe++) {
+                const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&set[s]), ~0ull, (unsigned long long)key);
+                if (old == ~0ull) { n_new++; placed = true; }
+                else if (old == key) placed = true;
+                else s = (s + 1) & mask;
+            }
+            if (!placed) n_new++;
+        }
+    }
+    wave_add_ull(n_distinct, n_new);
 }
 
 // windows of a stream of records
@@ -1207,26 +1237,63 @@ struct P3Emit {
 };
 
 
+// Linear probing for `key` in an array of REGION_SLOTS 64-bit keys at LDS byte address `base`, from slot `home` on: the
+// slot that holds the key when the loop ends, claimed with one LDS compare-and-swap per step when it was free (there is
+// no load first: a CAS that finds another key is that load).  The compiler's loop spends ~20 scalar instructions a step
+// on the bookkeeping of its exit conditions, and the slowest of 64 lanes decides the number of steps -- the scalar unit
+// was the busiest part of the CU in the merge kernel; this one spends 6.  *n_new_wave += keys the WAVE inserted;
+// *pending: lanes that found no slot in 1024 steps (their region is full).
+__device__ __forceinline__ uint32_t lds_probe_claim(uint32_t base, uint32_t home, uint64_t key, uint32_t *n_new_wave, unsigned long long *pending)
+{
+    uint32_t off = home * 8u, addr, cnt, t, it;
+    unsigned long long old, sv, hit, pend;
+    const unsigned long long empty = EMPTY_KEY;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b32 %[cnt], 0\n\t"
+        "s_movk_i32 %[it], 0x400\n"
+        "1:\n\t"
+        "v_add_u32 %[addr], %[base], %[off]\n\t"
+        "ds_cmpst_rtn_b64 %[old], %[addr], %[empty], %[key]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_eq_u64 vcc, %[old], %[empty]\n\t"
+        "v_cmp_eq_u64 %[hit], %[old], %[key]\n\t"
+        "s_bcnt1_i32_b64 %[t], vcc\n\t"
+        "s_add_u32 %[cnt], %[cnt], %[t]\n\t"
+        "s_or_b64 vcc, vcc, %[hit]\n\t"
+        "s_andn2_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execz 2f\n\t"
+        "v_add_u32 %[off], 8, %[off]\n\t"
+        "v_and_b32 %[off], %[wrap], %[off]\n\t"
+        "s_sub_u32 %[it], %[it], 1\n\t"
+        "s_cmp_lg_u32 %[it], 0\n\t"
+        "s_cbranch_scc1 1b\n"
+        "2:\n\t"
+        "s_mov_b64 %[pend], exec\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        : [off] "+v"(off), [old] "=&v"(old), [addr] "=&v"(addr), [sv] "=&s"(sv), [hit] "=&s"(hit), [cnt] "=&s"(cnt), [t] "=&s"(t),
+          [it] "=&s"(it), [pend] "=&s"(pend)
+        : [base] "s"(base), [empty] "v"(empty), [key] "v"(key), [wrap] "s"((uint32_t)(REGION_SLOTS * 8u - 8u))
+        : "vcc", "scc", "memory");
+    *n_new_wave += cnt;
+    *pending = pend;
+    return off >> 3;
+}
+
 // one occurrence of `key` into the region held in LDS; false when the region is full
 __device__ __forceinline__ bool lds_region_add(MergeLds &L, uint64_t key, uint32_t hint, uint32_t home, uint32_t &my_new, uint32_t pick,
                                                uint32_t pick2)
 {
-    uint32_t s = home;
-    for (uint32_t probe = 0; probe < P3_MAX_PROBES; probe++) {
-        uint64_t cur = L.key[s];
-        if (cur == EMPTY_KEY) {
-            cur = atomicCAS(reinterpret_cast<unsigned long long *>(&L.key[s]), (unsigned long long)EMPTY_KEY,
-                            (unsigned long long)key);
-            if (cur == EMPTY_KEY) { my_new++; cur = key; }
-        }
-        if (cur == key) {
-            const uint32_t seen = atomicAdd(&L.cnt[s], 1u);
-            if (hint && (seen == pick || seen == pick2 || L.aux[s] == 0)) L.aux[s] = hint;  // (racy on purpose: any occurrence's pointer will do)
-            return true;
-        }
-        s = (s + 1) & (REGION_SLOTS - 1);
-    }
-    return false;
+    const uint32_t key_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint64_t *)L.key;
+    uint32_t new_wave = 0;
+    unsigned long long pending;
+    const uint32_t s = lds_probe_claim(key_base, home, key, &new_wave, &pending);
+    // (the probe loop counts the keys the WAVE inserted: the first of the lanes that came here books them)
+    if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)__ballot(true)) - 1u) my_new += new_wave;
+    if ((pending >> (threadIdx.x & 63u)) & 1ull) return false;
+    const uint32_t seen = atomicAdd(&L.cnt[s], 1u);
+    if (hint && (seen == pick || seen == pick2 || L.aux[s] == 0)) L.aux[s] = hint;  // (racy on purpose: any occurrence's pointer will do)
+    return true;
 }
 
 // A leaf's records sit in `nseg` segments of capacity seg_cap: 1 after P2, PT_SEGMENTS when the table
@@ -1547,49 +1614,6 @@ struct alignas(16) DedupLds {
     uint8_t dq[P3_THREADS / 64][DD_DQ];  // per wave: window -> lane holding its record, DD_DQ windows at a time
     uint32_t n_new, overflow, emit_cur;
 };
-
-// Linear probing for `key` in an array of REGION_SLOTS 64-bit keys at LDS byte address `base`, from slot `home` on: the
-// slot that holds the key when the loop ends, claimed with one LDS compare-and-swap per step when it was free (there is
-// no load first: a CAS that finds another key is that load).  The compiler's loop spends ~20 scalar instructions a step
-// on the bookkeeping of its exit conditions, and the slowest of 64 lanes decides the number of steps -- the scalar unit
-// was the busiest part of the CU in the merge kernel; this one spends 6.  *n_new_wave += keys the WAVE inserted;
-// *pending: lanes that found no slot in 1024 steps (their region is full).
-__device__ __forceinline__ uint32_t lds_probe_claim(uint32_t base, uint32_t home, uint64_t key, uint32_t *n_new_wave, unsigned long long *pending)
-{
-    uint32_t off = home * 8u, addr, cnt, t, it;
-    unsigned long long old, sv, hit, pend;
-    const unsigned long long empty = EMPTY_KEY;
-    asm volatile(
-        "s_mov_b64 %[sv], exec\n\t"
-        "s_mov_b32 %[cnt], 0\n\t"
-        "s_movk_i32 %[it], 0x400\n"
-        "1:\n\t"
-        "v_add_u32 %[addr], %[base], %[off]\n\t"
-        "ds_cmpst_rtn_b64 %[old], %[addr], %[empty], %[key]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_cmp_eq_u64 vcc, %[old], %[empty]\n\t"
-        "v_cmp_eq_u64 %[hit], %[old], %[key]\n\t"
-        "s_bcnt1_i32_b64 %[t], vcc\n\t"
-        "s_add_u32 %[cnt], %[cnt], %[t]\n\t"
-        "s_or_b64 vcc, vcc, %[hit]\n\t"
-        "s_andn2_b64 exec, exec, vcc\n\t"
-        "s_cbranch_execz 2f\n\t"
-        "v_add_u32 %[off], 8, %[off]\n\t"
-        "v_and_b32 %[off], %[wrap], %[off]\n\t"
-        "s_sub_u32 %[it], %[it], 1\n\t"
-        "s_cmp_lg_u32 %[it], 0\n\t"
-        "s_cbranch_scc1 1b\n"
-        "2:\n\t"
-        "s_mov_b64 %[pend], exec\n\t"
-        "s_mov_b64 exec, %[sv]\n\t"
-        : [off] "+v"(off), [old] "=&v"(old), [addr] "=&v"(addr), [sv] "=&s"(sv), [hit] "=&s"(hit), [cnt] "=&s"(cnt), [t] "=&s"(t),
-          [it] "=&s"(it), [pend] "=&s"(pend)
-        : [base] "s"(base), [empty] "v"(empty), [key] "v"(key), [wrap] "s"((uint32_t)(REGION_SLOTS * 8u - 8u))
-        : "vcc", "scc", "memory");
-    *n_new_wave += cnt;
-    *pending = pend;
-    return off >> 3;
-}
 
 __device__ __forceinline__ uint32_t dd_hash(uint32_t y, uint32_t z, uint32_t w)
 {

@@ -20,6 +20,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <map>
 #include <vector>
 
 #include "../../include/mcgpu.h"
@@ -92,6 +93,43 @@ struct PoolBuf {  // RAII: a block of a DevPool
     }
 };
 
+// Table memory, kept across tables: fresh device memory comes zero-filled by the driver at ~30 GB/s (0.7 s for the 22 GB
+// table of configs[1]), which a context without a capacity hint paid every time its table went to its real size.  A
+// table that is given up goes here instead of back to the driver (the two largest idle blocks per device are kept) and the
+// next table of about its size takes it; any allocation that fails for lack of memory empties the pool and tries again.
+struct TablePool {
+    std::mutex mu;
+    std::map<int, DevPool> per_device;
+    bool on = [] { const char *e = getenv("MC_TABLE_POOL"); return !(e && !strcmp(e, "0")); }();
+    hipError_t get(int dev, size_t bytes, void **out, size_t *got)
+    {
+        if (!on) { *got = bytes; return hipMalloc(out, bytes); }
+        std::lock_guard<std::mutex> g(mu);
+        return per_device[dev].get(bytes, out, got);
+    }
+    void put(int dev, void *p, size_t bytes)
+    {
+        if (!p) return;
+        if (!on) { (void)hipFree(p); return; }
+        std::lock_guard<std::mutex> g(mu);
+        DevPool &P = per_device[dev];
+        P.put(p, bytes);
+        while (P.idle.size() > 2) {
+            size_t small = 0;
+            for (size_t i = 1; i < P.idle.size(); i++)
+                if (P.idle[i].second < P.idle[small].second) small = i;
+            (void)hipFree(P.idle[small].first);
+            P.idle.erase(P.idle.begin() + (long)small);
+        }
+    }
+    void release(int dev)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        per_device[dev].release();
+    }
+};
+static TablePool g_table_pool;
+
 // device buffers of one BFS job, kept in the context between calls
 struct BfsJobBuffers {
     BfsState S{};
@@ -147,6 +185,7 @@ struct mc_ctx {
 
     // table
     Slot *slots = nullptr;
+    size_t slots_bytes = 0;    // size of the block `slots` sits in (it may come from g_table_pool, a little larger than asked for)
     uint64_t n_regions = 0;    // regions of 2^sb slots: a power of two, or (minimizer-bin tables of >= 512 regions) any multiple of 512
     uint32_t rb = 0, sb = MC_REGION_LG;  // rb = log2(n_regions) when that is a power of two (else its floor)
     unsigned long long *d_ctr = nullptr;  // [0] n_used, [1] empty_cnt, [2] scratch counter, [3] solid n_used, [4..5] read summary, [6] keys with count >= cov_hint,
@@ -820,7 +859,13 @@ static int table_alloc(mc_ctx *c, uint64_t n_regions)
     c->n_regions = n_regions;
     c->rb = 0;
     while ((2ull << c->rb) <= n_regions) c->rb++;
-    HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->slots), c->n_slots() * sizeof(Slot)));
+    {
+        void *blk = nullptr;
+        size_t got = 0;
+        HIPCHK(c, g_table_pool.get(c->cfg.device, c->n_slots() * sizeof(Slot), &blk, &got));
+        c->slots = static_cast<Slot *>(blk);
+        c->slots_bytes = got;
+    }
     c->virgin = true;  // filled lazily: the partitioned pipeline writes every region itself
     c->st.table_slots = c->n_slots();
     c->st.table_bytes = c->n_slots() * sizeof(Slot);
@@ -848,27 +893,49 @@ static int read_counters(mc_ctx *c, unsigned long long *n_used, uint32_t *fatal)
     return MC_OK;
 }
 
+// the table's block goes back to the pool
+static void table_release(mc_ctx *c, Slot *slots, size_t bytes) { g_table_pool.put(c->cfg.device, slots, bytes); }
+
+// What table_grow / to_hash_regions put aside while they move the keys: the old table comes back, with its counters, if
+// anything fails before the move is complete (and goes to the pool when it is).
+struct TableSwap {
+    mc_ctx *c;
+    Slot *old;
+    size_t old_bytes;
+    uint64_t old_regions;
+    uint32_t old_rb;
+    bool old_virgin;
+    int old_mm;
+    unsigned long long old_used = 0;
+    bool done = false;
+    explicit TableSwap(mc_ctx *ctx) : c(ctx), old(ctx->slots), old_bytes(ctx->slots_bytes), old_regions(ctx->n_regions), old_rb(ctx->rb), old_virgin(ctx->virgin), old_mm(ctx->mm_k) {}
+    ~TableSwap()
+    {
+        if (done) { table_release(c, old, old_bytes); return; }
+        if (c->slots && c->slots != old) table_release(c, c->slots, c->slots_bytes);  // the half-filled new table
+        c->slots = old; c->slots_bytes = old_bytes; c->n_regions = old_regions; c->rb = old_rb; c->virgin = old_virgin; c->mm_k = old_mm;
+        (void)hipMemcpy(c->d_ctr, &old_used, sizeof old_used, hipMemcpyHostToDevice);  // (n_used as it was)
+    }
+};
+
 static int table_grow(mc_ctx *c, uint64_t new_regions)
 {
-    Slot *old = c->slots;
-    const uint64_t old_n = c->n_slots(), old_regions = c->n_regions;
-    const bool old_virgin = c->virgin;
-    const uint32_t old_rb = c->rb;
+    TableSwap sw(c);
+    HIPCHK(c, hipMemcpyAsync(&sw.old_used, c->d_ctr, sizeof sw.old_used, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const uint64_t old_n = c->n_slots();
     c->slots = nullptr;
     int rc = table_alloc(c, new_regions);
-    if (rc) { c->slots = old; c->n_regions = old_regions; c->rb = old_rb; c->virgin = old_virgin; return rc; }
-    if (old_virgin) {  // nothing to move
-        HIPCHK(c, hipFree(old));
-        c->st.grows++;
-        return MC_OK;
-    }
-    rc = materialize(c);
     if (rc) return rc;
-    HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, sizeof(unsigned long long), c->stream));  // n_used is recounted
-    hipLaunchKernelGGL(k_rehash, dim3(grid_for(old_n, 256)), dim3(256), 0, c->stream, old, old_n, c->view());
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipFree(old));
+    if (!sw.old_virgin) {  // (else: nothing to move)
+        rc = materialize(c);
+        if (rc) return rc;
+        HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, sizeof(unsigned long long), c->stream));  // n_used is recounted
+        hipLaunchKernelGGL(k_rehash, dim3(grid_for(old_n, 256)), dim3(256), 0, c->stream, sw.old, old_n, c->view());
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    sw.done = true;
     c->st.grows++;
     return MC_OK;
 }
@@ -880,33 +947,28 @@ static int table_grow(mc_ctx *c, uint64_t new_regions)
 static int to_hash_regions(mc_ctx *c)
 {
     if (!c->mm_k) return MC_OK;
-    unsigned long long used = 0;
-    HIPCHK(c, hipMemcpyAsync(&used, c->d_ctr, sizeof used, hipMemcpyDeviceToHost, c->stream));
+    TableSwap sw(c);
+    HIPCHK(c, hipMemcpyAsync(&sw.old_used, c->d_ctr, sizeof sw.old_used, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    Slot *old = c->slots;
-    const uint64_t old_n = c->n_slots(), old_regions = c->n_regions;
-    const bool old_virgin = c->virgin;
-    const uint32_t old_rb = c->rb;
-    const int old_mm = c->mm_k;
+    const unsigned long long used = sw.old_used;
+    const uint64_t old_n = c->n_slots();
     c->mm_k = 0;
     c->slots = nullptr;
     int rc = table_alloc(c, regions_for(c, std::max<uint64_t>(old_n, 2 * used)));
-    if (rc) { c->slots = old; c->n_regions = old_regions; c->rb = old_rb; c->virgin = old_virgin; c->mm_k = old_mm; return rc; }
+    if (rc) return rc;
+    if (!sw.old_virgin) {
+        rc = materialize(c);
+        if (rc) return rc;
+        HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, sizeof(unsigned long long), c->stream));  // n_used is recounted
+        hipLaunchKernelGGL(k_rehash, dim3(grid_for(old_n, 256)), dim3(256), 0, c->stream, sw.old, old_n, c->view());
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    sw.done = true;
     c->solid_tracked = false;
     c->solid_list_fresh = false;
     c->solid_cov = -1;
     c->st.grows++;
-    if (old_virgin) {
-        HIPCHK(c, hipFree(old));
-        return MC_OK;
-    }
-    rc = materialize(c);
-    if (rc) return rc;
-    HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, sizeof(unsigned long long), c->stream));  // n_used is recounted
-    hipLaunchKernelGGL(k_rehash, dim3(grid_for(old_n, 256)), dim3(256), 0, c->stream, old, old_n, c->view());
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipFree(old));
     return MC_OK;
 }
 
@@ -1025,7 +1087,12 @@ static int ensure_buf(mc_ctx *c, T **p, uint64_t *cap, uint64_t need)
     if (*p) (void)hipFree(*p);
     *p = nullptr;
     *cap = 0;
-    const hipError_t e = hipMalloc(reinterpret_cast<void **>(p), std::max<uint64_t>(need, 1) * sizeof(T));
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(p), std::max<uint64_t>(need, 1) * sizeof(T));
+    if (e == hipErrorOutOfMemory) {  // (idle table blocks are given back first)
+        (void)hipGetLastError();
+        g_table_pool.release(c->cfg.device);
+        e = hipMalloc(reinterpret_cast<void **>(p), std::max<uint64_t>(need, 1) * sizeof(T));
+    }
     if (e != hipSuccess) {
         size_t fr = 0, tot = 0;
         (void)hipMemGetInfo(&fr, &tot);
@@ -1064,13 +1131,16 @@ __global__ void __launch_bounds__(256) k_pipe_reset(uint32_t *seg_counts1, uint6
     for (uint64_t i = t; i < n1; i += stride) seg_counts1[i] = 0;
     for (uint64_t i = t; i < n2; i += stride) cursors2[i] = 0;
     for (uint64_t i = t; i < n_leaves; i += stride) { leaf_state[i] = 0; leaf_new[i] = 0; }
-    if (t < 6) flags[t] = 0;
+    if (flags && t < 6) flags[t] = 0;
 }
 
 // Table capacity check, scratch buffers and cursors for one run of the partitioned pipeline over
 // `wb` key occurrences.  n_records != 0: they travel as (an estimated) n_records super-k-mer records.
-static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records = 0, uint32_t nseg1 = PT_SEGMENTS, uint32_t pieces = 1)
-{
+static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records = 0, uint32_t nseg1 = PT_SEGMENTS, uint32_t pieces = 1,
+                        bool level2_only = false)
+{   // level2_only: the level-1 scatter has run and the table has since been replaced by one of another size (pipe_resize_by_sample):
+    // the plan of the second level and of the merge is made again for it; level 1 (buckets, segments, their fill levels, the
+    // spill list) stays as it is -- the caller has checked that the new table splits into the same level-1 buckets
     pl->nseg1 = nseg1;
     pl->pieces = pieces;
     mc_ctx::Pipe &P = c->pipe;
@@ -1078,7 +1148,7 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
     // Make sure the table can take the batch: with a capacity hint that still holds the table was sized for
     // it; without one assume every eighth occurrence is a new key at most.  Either way the merge kernel
     // reports regions that would overflow and the table is grown then.
-    {
+    if (!level2_only) {
         unsigned long long used;
         uint32_t fatal;
         int rc = read_counters(c, &used, &fatal);
@@ -1099,8 +1169,10 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
     // level-1 buckets: up to 512, each of m2 <= 1024 (512) leaves (regions_for made the numbers divide)
     uint64_t n_leaves = c->n_regions;
     uint32_t g = 0;
-    const uint32_t max_b2 = n_records ? PT_MAX_LEAVES2 : PT_MAX_BUCKETS;  // (super-k-mer records: k_sk2_scatter; keys: k_p2_scatter)
-    const uint32_t max_b1_big = n_records ? PT_MAX_BUCKETS1_SK : PT_MAX_BUCKETS;  // (1024 level-1 buckets only when 512 do not do)
+    // (2^20 leaves at most in either form: a leaf that covers 2^g regions is swept 2^(g+1) times by the merge kernel -- with 2^18
+    // leaves the 137 GB table of configs[2] had g = 3, and two thirds of that run were those sweeps)
+    const uint32_t max_b2 = n_records ? PT_MAX_LEAVES2 : PT_MAX_BUCKETS_KEYS;  // (super-k-mer records: k_sk2_scatter; keys: k_p2_scatter)
+    const uint32_t max_b1_big = n_records ? PT_MAX_BUCKETS1_SK : PT_MAX_BUCKETS_KEYS;  // (1024 level-1 buckets only when 512 do not do)
     while (n_leaves > (uint64_t)max_b1_big * max_b2) { n_leaves >>= 1; g++; }
     if ((n_leaves << g) != c->n_regions) return fail(c, MC_EINVAL, "internal: %llu table regions do not split into leaves", (unsigned long long)c->n_regions);
     if (n_leaves < 4) return fail(c, MC_EINVAL, "internal: partitioned counting needs at least 4 table regions");
@@ -1129,17 +1201,17 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
     uint64_t dummy;
 #define ENSURE(ptr, capvar, need) do { rc = ensure_buf(c, &(ptr), &(capvar), (need)); if (rc) return rc; } while (0)
     if (pl->sk) {
-        ENSURE(P.a_recs, P.a_recs_cap, np1 * nseg1 * pl->cap1 * pieces);
+        if (!level2_only) ENSURE(P.a_recs, P.a_recs_cap, np1 * nseg1 * pl->cap1 * pieces);
         if (pl->b2 > 1) ENSURE(P.b_recs, P.b_recs_cap, n_leaves * pl->cap2 * pieces);
-        ENSURE(P.spill_recs, P.spill_recs_cap, pl->spill_cap);
+        if (!level2_only) ENSURE(P.spill_recs, P.spill_recs_cap, pl->spill_cap);
     } else {
         { uint64_t cap = P.a_cap; ENSURE(P.a_keys, cap, np1 * nseg1 * pl->cap1); P.a_cap = cap; }
         { uint64_t cap = P.b_cap; ENSURE(P.b_keys, cap, n_leaves * pl->cap2 * pieces); P.b_cap = cap; }
         { uint64_t cap = P.spill_cap; ENSURE(P.spill_keys, cap, pl->spill_cap); dummy = P.spill_cap; ENSURE(P.spill_hints, dummy, pl->spill_cap); P.spill_cap = cap; }
     }
-    ENSURE(P.a_hints, P.a_hints_cap, np1 * nseg1 * pl->cap1 * pieces);
+    if (!level2_only) ENSURE(P.a_hints, P.a_hints_cap, np1 * nseg1 * pl->cap1 * pieces);
     ENSURE(P.b_hints, P.b_hints_cap, n_leaves * pl->cap2 * pieces);
-    ENSURE(P.seg_counts1, P.segs1_cap, np1 * nseg1 * pieces);
+    if (!level2_only) ENSURE(P.seg_counts1, P.segs1_cap, np1 * nseg1 * pieces);
     ENSURE(P.cursors2, P.cursors2_cap, n_leaves * pieces);
     { uint64_t cap = P.leaves_cap; ENSURE(P.leaf_state, cap, n_leaves); dummy = P.leaves_cap; ENSURE(P.leaf_new, dummy, n_leaves); P.leaves_cap = cap; }
 #undef ENSURE
@@ -1148,11 +1220,63 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
         P.spill_count = reinterpret_cast<unsigned long long *>(P.flags + 4);
     }
     // (one launch clears all five: a fill each, 10 us apart, was 60 us in front of every run)
-    hipLaunchKernelGGL(k_pipe_reset, dim3(256), dim3(256), 0, c->stream, P.seg_counts1, np1 * nseg1 * pieces, P.cursors2, n_leaves * pieces, P.leaf_state,
-                       P.leaf_new, n_leaves, P.flags);
+    hipLaunchKernelGGL(k_pipe_reset, dim3(256), dim3(256), 0, c->stream, P.seg_counts1, level2_only ? 0 : np1 * nseg1 * pieces, P.cursors2, n_leaves * pieces,
+                       P.leaf_state, P.leaf_new, n_leaves, level2_only ? nullptr : P.flags);
     HIPCHK(c, hipGetLastError());
     pl->sp = SpillView{P.spill_keys, P.spill_hints, P.spill_count, pl->spill_cap, P.flags};
     pl->sks = SkSpill{P.spill_recs, P.spill_count, pl->spill_cap, P.flags};
+    return MC_OK;
+}
+
+// Nothing vouches for the table's size (no capacity hint) and it holds nothing yet: the level-1 scatter has just run, and
+// its first bucket is a fair sample of the batch -- 1 / np1 of the minimizer bins, whatever the table's size.  Its
+// distinct k-mers are counted into a scratch set, the table is replaced by one of the size they call for, and the second
+// level and the merge are planned for that table: the batch is scattered once (before, the merge of 1024 leaves told the
+// size, and then everything ran again: 31 ms of counting on configs[1] against 19 with a hint).
+static int pipe_resize_by_sample(mc_ctx *c, PipePlan &pl, uint64_t n_records)
+{
+    mc_ctx::Pipe &P = c->pipe;
+    if (!(pl.sk && pl.guessed && c->virgin && pl.b2 > 1 && pl.pieces == 1 && c->mm_k)) return MC_OK;
+    static const bool off = getenv("MC_NO_SAMPLE_RESIZE") != nullptr;
+    if (off) return MC_OK;
+    constexpr uint64_t SET_SLOTS = 1ull << 23;  // 64 MB of P.b_recs, which the second level has not touched yet
+    if (P.b_recs_cap * sizeof(uint4) < SET_SLOTS * 8) return MC_OK;
+    uint64_t *set = reinterpret_cast<uint64_t *>(P.b_recs);
+    HIPCHK(c, hipMemsetAsync(set, 0xFF, SET_SLOTS * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_ctr + 2, 0, sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(k_sk_sample_distinct, dim3(pl.nseg1), dim3(256), 0, c->stream, P.a_recs, P.seg_counts1, pl.cap1, c->cfg.k, set, SET_SLOTS - 1,
+                       c->d_ctr + 2);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_scratch + 24, c->d_ctr + 2, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_scratch + 25, P.flags, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    uint32_t fl[4];
+    memcpy(fl, c->h_scratch + 25, sizeof fl);
+    if (fl[0]) return MC_OK;  // (records were lost: pipe_finish sees the flag too and the batch is counted another way)
+    const double est = (double)c->h_scratch[24] * (double)pl.np1 * 1.1 + 1024.0;
+    if (est > 0.45 * (double)SET_SLOTS * (double)pl.np1) return MC_OK;  // (the scratch set was too full to count in: the old way)
+    const uint64_t want = regions_for(c, mm_slots_for(c, est, 0.36));
+    static const bool dbg = getenv("MC_INGEST_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[count] first bucket: %llu distinct k-mers, %.0f M expected in all; table of %llu regions, %llu wanted\n",
+                     (unsigned long long)c->h_scratch[24], est / 1e6, (unsigned long long)c->n_regions, (unsigned long long)want);
+    if (want != c->n_regions) {
+        // the new table must split into the level-1 buckets the records are in
+        if (want % pl.np1 || want / pl.np1 > PT_MAX_LEAVES2 || want / pl.np1 < 2) return MC_OK;
+        table_release(c, c->slots, c->slots_bytes);
+        c->slots = nullptr;
+        int rc = table_alloc(c, want);
+        if (rc) return rc;
+        c->st.grows++;
+        HIPCHK(c, hipMemsetAsync(c->d_ctr + 6, 0, sizeof(unsigned long long), c->stream));  // keys at the coverage threshold: none yet
+        PipePlan p2 = pl;
+        rc = pipe_prepare(c, pl.wb, &p2, n_records, pl.nseg1, 1, true);
+        if (rc) return rc;
+        if (p2.np1 != pl.np1 || p2.cap1 != pl.cap1 || p2.g != 0) return fail(c, MC_EINVAL, "internal: the resized table does not keep the level-1 buckets");
+        pl = p2;
+    } else {
+        // (the scratch set sat in the second level's buffer: nothing of it is read before it is written)
+    }
+    pl.guessed = false;  // the table was sized by what the batch holds
     return MC_OK;
 }
 
@@ -1244,7 +1368,7 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
         static const bool dbg = getenv("MC_INGEST_DEBUG") != nullptr;
         if (dbg) fprintf(stderr, "[count] table too small: %llu of %llu sampled leaves merged, %llu keys in them: %.0f M keys expected; new table %.1f GB\n",
                          (unsigned long long)merged, (unsigned long long)sample_leaves, (unsigned long long)added, est / 1e6, (double)(want << c->sb) * 16 / 1e9);
-        (void)hipFree(c->slots);
+        table_release(c, c->slots, c->slots_bytes);
         c->slots = nullptr;
         int r = table_alloc(c, want);  // (fresh device memory comes zeroed by the driver at ~30 GB/s: 0.7 s for 22 GB, once)
         if (r) return r;
@@ -1559,6 +1683,8 @@ static int add_reads_partitioned_once(mc_ctx *c, const uint64_t *d_words, const 
             launch_p1_reads(c, d_words, offs, nr, base0, end_abs, n_tiles_abs, P.tile_first, pl.b1, P.seg_counts1, pl.cap1, P.a_keys,
                             P.a_hints, pl.sp, 0, nullptr);
         HIPCHK(c, hipGetLastError());
+        rc = pipe_resize_by_sample(c, pl, n_records);
+        if (rc) return rc;
         rc = pipe_finish(c, pl, ms1, false, 0, true, true);
     }
     if (rc != 1) return rc;
@@ -1875,18 +2001,20 @@ static int rs_append(mc_ctx *c, const uint64_t *d_words, uint64_t first_off, uin
 // bases (114 M reads of 150 bp) stay far below 2^32 records, while one 8-byte key per window (k > 31, hash keys) costs
 // scratch by the window -- those runs take what half the free memory holds, 2^31 to 2^33 bases.
 // Every run reads and rewrites the whole table, so fewer, larger runs are what a large read set wants.
-static uint64_t max_run_bases(const mc_ctx *c)
-{
+static uint64_t max_run_bases(const mc_ctx *c, double windows_per_base = 1.0)
+{   // windows_per_base: of the read set at hand (88 / 150 for 150-base reads at k = 63): the scratch is per window
     static const uint64_t env = [] { const char *e = getenv("MC_MAX_RUN_BASES"); return e && *e ? strtoull(e, nullptr, 10) : 0ull; }();
     if (env) return std::max<uint64_t>(env, 1u << 20);
     if (c->skl_ok && (c->skl_state || c->virgin)) return 1ull << 33;  // (32-byte records, ~0.1 per window: 12 bytes of scratch per window)
     if (c->mm_k) return 1ull << 34;
-    // a key and a read pointer per window, in pieces (add_reads_partitioned): ~16 bytes of scratch per window.  Half of
-    // what the device has free may go there (the table is allocated already), between 2^31 and 2^33 bases.
+    // a key and a read pointer per window, in pieces (add_reads_partitioned): ~16.5 bytes of scratch per window.  Two
+    // thirds of what the device has free may go there (the table is allocated already), between 2^31 and 2^33 bases: every
+    // run reads and rewrites the whole table, so few, large runs (configs[2]: 2 instead of 4).
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = 0;
     fr += (c->pipe.a_cap + c->pipe.b_cap) * 12;  // (the scratch of the run before is ours to reuse)
-    return std::min<uint64_t>(1ull << 33, std::max<uint64_t>((1ull << 31) - (1ull << 24), fr / 2 / 16));
+    const double per_base = 16.5 * std::min(1.0, std::max(0.05, windows_per_base));
+    return std::min<uint64_t>(1ull << 33, std::max<uint64_t>((1ull << 31) - (1ull << 24), (uint64_t)((double)fr * 0.66 / per_base)));
 }
 
 // counting with read offsets known on the host
@@ -2044,7 +2172,7 @@ void mc_destroy(mc_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-    if (c->slots) (void)hipFree(c->slots);
+    if (c->slots) table_release(c, c->slots, c->slots_bytes);
     if (c->solid) (void)hipFree(c->solid);
     c->pipe.release();
     c->bfs_pool.clear();
@@ -2273,7 +2401,8 @@ static int add_reads_dev_counted(mc_ctx *c, const uint64_t *d_words, const uint6
         c->ptr_tries = 1;
     }
     const bool partition = c->count_path == 2 || (c->count_path == 0 && total >= (1ull << 22));
-    if (partition && last_off - first_off < max_run_bases(c)) {  // one batch: no need for the offsets on the host
+    const double wpb = last_off > first_off ? (double)total / (double)(last_off - first_off) : 1.0;  // windows per base
+    if (partition && last_off - first_off < max_run_bases(c, wpb)) {  // one batch: no need for the offsets on the host
         if (total) {
             int rc = add_reads_partitioned_any(c, d_words, d_off, 0, n_reads, first_off, last_off, total);
             if (rc) return rc;
@@ -2292,7 +2421,7 @@ static int add_reads_dev_counted(mc_ctx *c, const uint64_t *d_words, const uint6
         };
         uint64_t r = 0, off_r = first_off;
         while (r < n_reads) {
-            const uint64_t max_bases = max_run_bases(c), target = off_r + max_bases;
+            const uint64_t max_bases = max_run_bases(c, wpb), target = off_r + max_bases;
             uint64_t r1 = n_reads, off_r1 = last_off;
             if (last_off > target) {
                 uint64_t lo = r, hi = n_reads;  // offsets[lo] <= target < offsets[hi]

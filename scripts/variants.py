@@ -35,7 +35,7 @@ def do_run(args):
         if only and name not in only.split(","):
             continue
         env = dict(os.environ, MC_LIB=lib)
-        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"] + args, env=env,
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--skip-no-hint"] + args, env=env,
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
         line = [l for l in p.stdout.splitlines() if l.startswith("{")]
         if p.returncode or not line:
