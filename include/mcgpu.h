@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define MC_ABI_VERSION 8
+#define MC_ABI_VERSION 9
 
 /* error codes */
 #define MC_OK 0
@@ -64,6 +64,10 @@ enum { MC_KEY_PACKED = 0, MC_KEY_POLY = 1, MC_KEY_FNV1A = 2 };
 /* mc_config.flags.  MC_FLAG_SOLID_LIST: the k-mers at or above the coverage hint will be exported (a shard of a
  * multi-GPU run, mc_export_dev): the counting pass then lists them as it goes, which saves the export a table sweep. */
 #define MC_FLAG_SOLID_LIST 1
+/* MC_FLAG_GROUP_RCCL (mc_group_create only): the buckets travel between the devices through RCCL -- one communicator per
+ * device inside the process (ncclCommInitAll), the exchange as grouped ncclSend / ncclRecv over xGMI -- instead of
+ * peer-to-peer copies; the environment variable MC_GROUP_TRANSPORT=rccl|peer says the same.  librccl is loaded on demand. */
+#define MC_FLAG_GROUP_RCCL 4
 
 typedef struct mc_ctx mc_ctx;
 
@@ -285,6 +289,8 @@ typedef struct {
 } mc_stats;
 int mc_get_stats(mc_ctx *ctx, mc_stats *out);
 int mc_reset_stats(mc_ctx *ctx);
+/* ... of a group: counts and bytes summed over its devices, times the largest of any device (they work side by side) */
+int mc_group_get_stats(mc_group *g, mc_stats *out);
 
 /* ---- synthetic workload of SURVEY.md section 8(d) (spec: DESIGN.md "Synthetic workload"),
  * generated straight into HBM so that benchmarks start with the reads resident.

@@ -510,7 +510,8 @@ int run(const Options &o)
     info("Finished processing all sequences!");
 
     mc_stats stt{};
-    if (E.c) mc_get_stats(E.c, &stt);  // (several devices: per-device statistics are not summed up here)
+    if (E.c) mc_get_stats(E.c, &stt);
+    else if (E.g) mc_group_get_stats(E.g, &stt);  // (summed over the devices; times: the slowest device's)
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     char buf[512];
     snprintf(buf, sizeof buf,

@@ -23,6 +23,9 @@
 #include <map>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 #include "../../include/mcgpu.h"
 #include "kmer_device.h"
 #include "bfs_device.h"
@@ -324,7 +327,11 @@ template <typename T>
 struct DevBuf {  // RAII device buffer for temporaries
     T *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(n, 1) * sizeof(T)); }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    void reset() { if (p) (void)hipFree(p); p = nullptr; }
+    hipError_t alloc(size_t n) { reset(); return hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(n, 1) * sizeof(T)); }
 };
 
 // ------------------------------------------------------------------------------------------ kernels: table
@@ -3978,6 +3985,34 @@ int mc_bfs(mc_ctx *c, const uint64_t *seed_hi, const uint64_t *seed_lo, uint64_t
 // first device's reads: the others keep none).  What the reference does instead: P threads over one shared map
 // (src/io/IOUtils.java:283-315, src/io/ReadsDispatcher.java:34-53).
 
+// RCCL, loaded when a group asks for it (MC_GROUP_TRANSPORT=rccl / MC_FLAG_GROUP_RCCL): the library is large and a process
+// that counts on one GPU, or moves its buckets with peer copies, never needs it.  Types and constants from <rccl/rccl.h>.
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool load(std::string *why)
+    {
+        if (lib) return true;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) { *why = std::string("librccl.so.1 cannot be loaded: ") + dlerror(); return false; }
+#define RCCL_SYM(field, sym) field = reinterpret_cast<decltype(field)>(dlsym(lib, sym)); if (!field) { *why = std::string("librccl has no ") + sym; return false; }
+        RCCL_SYM(CommInitAll, "ncclCommInitAll") RCCL_SYM(CommDestroy, "ncclCommDestroy") RCCL_SYM(GroupStart, "ncclGroupStart")
+        RCCL_SYM(GroupEnd, "ncclGroupEnd") RCCL_SYM(Send, "ncclSend") RCCL_SYM(Recv, "ncclRecv") RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef RCCL_SYM
+        return true;
+    }
+};
+static RcclApi g_rccl;
+
 struct mc_group {
     std::vector<mc_ctx *> ctx;  // one per device, in the order given
     mc_ctx *solid = nullptr;    // BFS-only context on the first device (n > 1)
@@ -3986,6 +4021,11 @@ struct mc_group {
     mc_config cfg{};
     std::string err;
     std::mutex mu;
+    // how the buckets travel between the devices: peer-to-peer copies (every pair at once), or RCCL -- one communicator per
+    // device in this process (ncclCommInitAll), the exchange as grouped ncclSend / ncclRecv, which is what an all-to-all is
+    bool use_rccl = false;
+    std::vector<ncclComm_t> comm;
+    bool peer_all = true;       // every pair of distinct devices has peer access (else HIP stages those copies through the host)
 };
 
 namespace {
@@ -4002,8 +4042,11 @@ int per_rank(size_t n, F &&f)
 {
     std::vector<int> rc(n, 0);
     std::vector<std::thread> th;
-    for (size_t r = 1; r < n; r++) th.emplace_back([&, r] { rc[r] = f(r); });
-    rc[0] = f(0);
+    auto guarded = [&](size_t r) {  // (an exception must not leave a thread: std::terminate)
+        try { rc[r] = f(r); } catch (const std::bad_alloc &) { rc[r] = MC_ENOMEM; } catch (...) { rc[r] = MC_EINVAL; }
+    };
+    for (size_t r = 1; r < n; r++) th.emplace_back([&, r] { guarded(r); });
+    guarded(0);
     for (auto &t : th) t.join();
     for (int x : rc) if (x) return x;
     return MC_OK;
@@ -4026,6 +4069,7 @@ const char *mc_group_last_error(const mc_group *g) { return g ? g->err.c_str() :
 void mc_group_destroy(mc_group *g)
 {
     if (!g) return;
+    for (ncclComm_t cm : g->comm) if (cm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(cm);
     if (g->solid) mc_destroy(g->solid);
     for (mc_ctx *c : g->ctx) mc_destroy(c);
     delete g;
@@ -4049,12 +4093,42 @@ int mc_group_create(const mc_config *cfg, const int32_t *devices, uint32_t n_dev
         g->ctx.push_back(x);
         if (r > 0) (void)mc_set_read_pointers(x, 0);  // (the BFS device cannot see this one's reads)
     }
-    // peer access between every pair of different devices (already enabled: fine)
+    // peer access between every pair of different devices (already enabled: fine).  A pair without it still works -- HIP
+    // stages such copies through the host -- but at a fraction of the xGMI rate: say so once.
     for (uint32_t a = 0; a < n_devices; a++)
         for (uint32_t b = 0; b < n_devices; b++) {
             if (devices[a] == devices[b]) continue;
-            if (hipSetDevice(devices[a]) == hipSuccess) { (void)hipDeviceEnablePeerAccess(devices[b], 0); (void)hipGetLastError(); }
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devices[a], devices[b]) != hipSuccess) can = 0;
+            bool ok = false;
+            if (can && hipSetDevice(devices[a]) == hipSuccess) {
+                const hipError_t e = hipDeviceEnablePeerAccess(devices[b], 0);
+                ok = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+            }
+            (void)hipGetLastError();
+            if (!ok && g->peer_all) {
+                g->peer_all = false;
+                fprintf(stderr, "WARN: no peer access from GPU %d to GPU %d: the exchange between them is staged through the host\n", devices[a], devices[b]);
+            }
         }
+    {   // transport of the exchange
+        const char *e = getenv("MC_GROUP_TRANSPORT");
+        g->use_rccl = (cfg->flags & MC_FLAG_GROUP_RCCL) != 0 || (e && !strcmp(e, "rccl"));
+        if (e && !strcmp(e, "peer")) g->use_rccl = false;
+        if (g->use_rccl && n_devices > 1) {
+            for (uint32_t a = 0; a < n_devices; a++)
+                for (uint32_t b = a + 1; b < n_devices; b++)
+                    if (devices[a] == devices[b]) { mc_group_destroy(g); return fail(nullptr, MC_EINVAL, "mc_group_create: RCCL wants every rank on a GPU of its own (GPU %d is named twice); use the peer-copy transport for shares of one GPU", devices[a]); }
+            std::string why;
+            if (!g_rccl.load(&why)) { mc_group_destroy(g); return fail(nullptr, MC_EINVAL, "mc_group_create: %s", why.c_str()); }
+            g->comm.assign(n_devices, nullptr);
+            std::vector<int> devs(devices, devices + n_devices);
+            const ncclResult_t r = g_rccl.CommInitAll(g->comm.data(), (int)n_devices, devs.data());
+            if (r != ncclSuccess) { mc_group_destroy(g); return fail(nullptr, MC_EHIP, "mc_group_create: ncclCommInitAll: %s", g_rccl.GetErrorString(r)); }
+        } else {
+            g->use_rccl = false;
+        }
+    }
     if (n_devices > 1) {
         mc_config c = *cfg;
         c.device = devices[0];
@@ -4091,6 +4165,7 @@ int mc_group_add_reads_packed(mc_group *g, const uint64_t *words, const uint64_t
     }
     const int k = g->cfg.k;
     const bool sk = g->ctx[0]->sk_form;
+    bool sk_batch = sk;  // this batch travels as super-k-mer records (false: as keys)
     struct Rank {
         DevBuf<uint64_t> dw, doff, send, recv;   // reads; what goes out (records: 2 words each, or keys) and what came in
         DevBuf<uint32_t> send_p, recv_p;         // the read pointers that travel with them
@@ -4114,8 +4189,8 @@ int mc_group_add_reads_packed(mc_group *g, const uint64_t *words, const uint64_t
         }
         for (auto &x : rel) x -= w0 * 32;
         if (R[r].dw.alloc(w1 - w0) != hipSuccess || R[r].doff.alloc(b - a + 1) != hipSuccess) return MC_ENOMEM;
-        if (hipMemcpy(R[r].dw.p, words + w0, (w1 - w0) * 8, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(R[r].doff.p, rel.data(), (b - a + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) return MC_EHIP;
+        // (through the context's pinned staging buffers: a pageable copy runs at a third of the link's rate)
+        if (h2d_fast(c, R[r].dw.p, words + w0, (w1 - w0) * 8) != MC_OK || h2d_fast(c, R[r].doff.p, rel.data(), (b - a + 1) * 8) != MC_OK) return MC_EHIP;
         if (windows == 0) return MC_OK;
         if (sk) {
             const uint64_t cap = mc_superkmer_capacity(c, windows, b - a);
@@ -4126,12 +4201,72 @@ int mc_group_add_reads_packed(mc_group *g, const uint64_t *words, const uint64_t
         return mc_extract_keys_dev(c, R[r].dw.p, R[r].doff.p, b - a, nb, (uint32_t)W, reinterpret_cast<int64_t *>(R[r].send.p), R[r].send_p.p, windows,
                                    R[r].owner_off.data());
     });
+    if (rc == MC_EOVERFLOW && sk) {
+        // an owner's piece overflowed (reads of low complexity share one minimizer, hence one owner): this batch travels as
+        // keys instead, on every rank alike -- one record per window, bucketed by the key's own hash, which cannot be skewed
+        sk_batch = false;
+        for (mc_ctx *c : g->ctx) c->err.clear();
+        rc = per_rank(W, [&](size_t r) -> int {
+            mc_ctx *c = g->ctx[r];
+            const uint64_t a = n_reads * r / W, b = n_reads * (r + 1) / W;
+            R[r].owner_off.assign(W + 1, 0);
+            if (a == b) return MC_OK;
+            if (hipSetDevice(c->cfg.device) != hipSuccess) return MC_EHIP;
+            uint64_t windows = 0;
+            for (uint64_t i = a; i < b; i++) {
+                const uint64_t len = off[i + 1] - off[i];
+                if (len >= (uint64_t)k) windows += len - (uint64_t)k + 1;
+            }
+            if (windows == 0) return MC_OK;
+            const uint64_t nb = off[b] - off[a] / 32 * 32;
+            R[r].send.reset();
+            R[r].send_p.reset();
+            if (R[r].send.alloc(windows) != hipSuccess || R[r].send_p.alloc(windows) != hipSuccess) return MC_ENOMEM;
+            return mc_extract_keys_dev(c, R[r].dw.p, R[r].doff.p, b - a, nb, (uint32_t)W, reinterpret_cast<int64_t *>(R[r].send.p), R[r].send_p.p, windows,
+                                       R[r].owner_off.data());
+        });
+    }
     if (rc) {
         for (mc_ctx *c : g->ctx) if (!c->err.empty()) return gfail(g, rc, c->err);
         return gfail(g, rc, "mc_group_add_reads_packed: extraction failed");
     }
     // ---- the exchange: owner d receives its piece of every rank's output, all pairs at once
-    const size_t unit = sk ? 16 : 8;
+    const size_t unit = sk_batch ? 16 : 8;
+    if (g->use_rccl) {
+        // RCCL: every device's receive buffer first, then ONE group of sends and receives over all pairs (what an all-to-all
+        // with per-pair counts is), each communicator's calls on its own context's stream
+        rc = per_rank(W, [&](size_t d) -> int {
+            mc_ctx *c = g->ctx[d];
+            if (hipSetDevice(c->cfg.device) != hipSuccess) return MC_EHIP;
+            uint64_t total = 0;
+            for (size_t r = 0; r < W; r++) total += R[r].owner_off[d + 1] - R[r].owner_off[d];
+            R[d].n_recv = total;
+            if (total == 0) return MC_OK;
+            return R[d].recv.alloc(total * (sk_batch ? 2 : 1)) == hipSuccess && R[d].recv_p.alloc(total) == hipSuccess ? MC_OK : MC_ENOMEM;
+        });
+        if (rc) return gfail(g, rc, "mc_group_add_reads_packed: no room for the received buckets");
+        ncclResult_t nr = g_rccl.GroupStart();
+        std::vector<uint64_t> at(W, 0);
+        for (size_t r = 0; r < W && nr == ncclSuccess; r++)       // source
+            for (size_t d = 0; d < W && nr == ncclSuccess; d++) {  // owner
+                const uint64_t o0 = R[r].owner_off[d], m = R[r].owner_off[d + 1] - o0;
+                if (m == 0) continue;
+                nr = g_rccl.Send(reinterpret_cast<const char *>(R[r].send.p) + o0 * unit, m * unit, ncclUint8, (int)d, g->comm[r], g->ctx[r]->stream);
+                if (nr == ncclSuccess) nr = g_rccl.Recv(reinterpret_cast<char *>(R[d].recv.p) + at[d] * unit, m * unit, ncclUint8, (int)r, g->comm[d], g->ctx[d]->stream);
+                if (nr == ncclSuccess) nr = g_rccl.Send(R[r].send_p.p + o0, m * 4, ncclUint8, (int)d, g->comm[r], g->ctx[r]->stream);
+                if (nr == ncclSuccess) nr = g_rccl.Recv(R[d].recv_p.p + at[d], m * 4, ncclUint8, (int)r, g->comm[d], g->ctx[d]->stream);
+                at[d] += m;
+            }
+        const ncclResult_t ne = g_rccl.GroupEnd();
+        if (nr == ncclSuccess) nr = ne;
+        if (nr != ncclSuccess) return gfail(g, MC_EHIP, std::string("mc_group_add_reads_packed: RCCL exchange: ") + g_rccl.GetErrorString(nr));
+        rc = per_rank(W, [&](size_t d) -> int {
+            mc_ctx *c = g->ctx[d];
+            if (hipSetDevice(c->cfg.device) != hipSuccess) return MC_EHIP;
+            return hipStreamSynchronize(c->stream) == hipSuccess ? MC_OK : MC_EHIP;
+        });
+        if (rc) return gfail(g, rc, "mc_group_add_reads_packed: the RCCL exchange failed");
+    } else
     rc = per_rank(W, [&](size_t d) -> int {
         mc_ctx *c = g->ctx[d];
         if (hipSetDevice(c->cfg.device) != hipSuccess) return MC_EHIP;
@@ -4139,7 +4274,7 @@ int mc_group_add_reads_packed(mc_group *g, const uint64_t *words, const uint64_t
         for (size_t r = 0; r < W; r++) total += R[r].owner_off[d + 1] - R[r].owner_off[d];
         R[d].n_recv = total;
         if (total == 0) return MC_OK;
-        if (R[d].recv.alloc(total * (sk ? 2 : 1)) != hipSuccess || R[d].recv_p.alloc(total) != hipSuccess) return MC_ENOMEM;
+        if (R[d].recv.alloc(total * (sk_batch ? 2 : 1)) != hipSuccess || R[d].recv_p.alloc(total) != hipSuccess) return MC_ENOMEM;
         uint64_t at = 0;
         for (size_t r = 0; r < W; r++) {
             const uint64_t o0 = R[r].owner_off[d], m = R[r].owner_off[d + 1] - o0;
@@ -4150,11 +4285,11 @@ int mc_group_add_reads_packed(mc_group *g, const uint64_t *words, const uint64_t
         }
         return hipStreamSynchronize(c->stream) == hipSuccess ? MC_OK : MC_EHIP;
     });
-    if (rc) return gfail(g, rc, "mc_group_add_reads_packed: the exchange between the devices failed (peer copy)");
+    if (rc) return gfail(g, rc, "mc_group_add_reads_packed: the exchange between the devices failed");
     // ---- every device counts what it owns
     rc = per_rank(W, [&](size_t d) -> int {
         if (R[d].n_recv == 0) return MC_OK;
-        return sk ? mc_add_superkmers_dev(g->ctx[d], R[d].recv.p, R[d].recv_p.p, R[d].n_recv)
+        return sk_batch ? mc_add_superkmers_dev(g->ctx[d], R[d].recv.p, R[d].recv_p.p, R[d].n_recv)
                   : mc_add_keys_dev(g->ctx[d], reinterpret_cast<const int64_t *>(R[d].recv.p), R[d].recv_p.p, R[d].n_recv);
     });
     if (rc) {
@@ -4173,9 +4308,13 @@ int mc_group_add_reads_file(mc_group *g, const char *path, uint64_t *n_reads)
         const int rc = mc_add_reads_file(g->ctx[0], path, n_reads);
         return rc ? gfail(g, rc, mc_last_error(g->ctx[0])) : MC_OK;
     }
-    try {  // batches of 2^20 reads per device
+    try {
+        // Batches of 2^24 reads per device (2.5 G bases of 150-base reads: 0.6 GB of host memory per device): every batch is
+        // one exchange and one counting run on every device, and a counting run rewrites the device's whole table -- with
+        // 2^20 reads a batch, as before, a billion reads meant 119 rewrites of a 100 GB-class table per device.
+        static const uint64_t per_dev = [] { const char *e = getenv("MC_GROUP_BATCH_READS"); return e && *e ? std::max<uint64_t>(strtoull(e, nullptr, 10), 1024) : 1ull << 24; }();
         int rc = MC_OK;
-        const uint64_t n = mch::load_reads_file(path, g->ctx.size() << 20, [&](mch::PackedBatch &b) {
+        const uint64_t n = mch::load_reads_file(path, g->ctx.size() * per_dev, [&](mch::PackedBatch &b) {
             if (rc == MC_OK) rc = mc_group_add_reads_packed(g, b.words.data(), b.offsets.data(), b.n_reads());
         });
         if (rc != MC_OK) return rc;
@@ -4202,6 +4341,24 @@ int mc_group_finalize_counts(mc_group *g, uint64_t *n_distinct)
     return MC_OK;
 }
 
+int mc_group_get_stats(mc_group *g, mc_stats *out)
+{
+    if (!g || !out) return MC_EINVAL;
+    mc_stats t{};
+    for (mc_ctx *c : g->ctx) {
+        mc_stats s{};
+        const int rc = mc_get_stats(c, &s);
+        if (rc) return gfail(g, rc, mc_last_error(c));
+        t.windows += s.windows; t.count_launches += s.count_launches; t.table_slots += s.table_slots; t.table_bytes += s.table_bytes;
+        t.grows += s.grows; t.spill_keys += s.spill_keys; t.solid_kmers += s.solid_kmers; t.solid_sweeps += s.solid_sweeps;
+        t.solid_list_builds += s.solid_list_builds;
+        t.count_ms = std::max(t.count_ms, s.count_ms); t.count_total_ms = std::max(t.count_total_ms, s.count_total_ms);
+        t.p1_ms = std::max(t.p1_ms, s.p1_ms); t.p2_ms = std::max(t.p2_ms, s.p2_ms); t.p3_ms = std::max(t.p3_ms, s.p3_ms);
+    }
+    *out = t;
+    return MC_OK;
+}
+
 int mc_group_bfs_batch(mc_group *g, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov, int64_t max_kmers, int64_t max_radius,
                        mc_bfs_result *out)
 {
@@ -4213,14 +4370,26 @@ int mc_group_bfs_batch(mc_group *g, const mc_bfs_job *jobs, uint32_t n_jobs, int
         return rc ? gfail(g, rc, mc_last_error(g->ctx[0])) : MC_OK;
     }
     if (g->dirty || g->solid_cov != min_cov) {
-        // ---- gather: every shard's (key, count, pointer) with count >= min_cov, side by side on the first device
+        // ---- gather: every shard's (key, count, pointer) with count >= min_cov, side by side on the first device.  The
+        // shards are exported on all devices at once; the copies are then issued on the first device's stream with that
+        // device current, and waited for once.
         std::vector<uint64_t> n(W, 0);
-        for (size_t r = 0; r < W; r++) {
-            const int rc = mc_export_dev(g->ctx[r], min_cov, nullptr, nullptr, nullptr, 0, &n[r]);
-            if (rc) return gfail(g, rc, mc_last_error(g->ctx[r]));
+        struct Shard { DevBuf<int64_t> k; DevBuf<int16_t> c; DevBuf<uint32_t> p; uint64_t got = 0; };
+        std::vector<Shard> sh(W);
+        int grc = per_rank(W, [&](size_t r) -> int {
+            mc_ctx *c = g->ctx[r];
+            if (hipSetDevice(c->cfg.device) != hipSuccess) return MC_EHIP;
+            int rc = mc_export_dev(c, min_cov, nullptr, nullptr, nullptr, 0, &n[r]);
+            if (rc || n[r] == 0) return rc;
+            if (sh[r].k.alloc(n[r]) != hipSuccess || sh[r].c.alloc(n[r]) != hipSuccess || sh[r].p.alloc(n[r]) != hipSuccess) return MC_ENOMEM;
+            return mc_export_dev(c, min_cov, sh[r].k.p, sh[r].c.p, sh[r].p.p, n[r], &sh[r].got);
+        });
+        if (grc) {
+            for (mc_ctx *c : g->ctx) if (!c->err.empty()) return gfail(g, grc, c->err);
+            return gfail(g, grc, "mc_group_bfs_batch: exporting the shards failed");
         }
         uint64_t total = 0;
-        for (uint64_t x : n) total += x;
+        for (size_t r = 0; r < W; r++) total += sh[r].got;
         mc_ctx *c0 = g->ctx[0];
         if (hipSetDevice(c0->cfg.device) != hipSuccess) return gfail(g, MC_EHIP, "hipSetDevice failed");
         DevBuf<int64_t> all_k;
@@ -4230,22 +4399,14 @@ int mc_group_bfs_batch(mc_group *g, const mc_bfs_job *jobs, uint32_t n_jobs, int
             return gfail(g, MC_ENOMEM, "mc_group_bfs_batch: no room for the gathered shards");
         uint64_t at = 0;
         for (size_t r = 0; r < W; r++) {
-            mc_ctx *c = g->ctx[r];
-            if (n[r] == 0) continue;
-            if (hipSetDevice(c->cfg.device) != hipSuccess) return gfail(g, MC_EHIP, "hipSetDevice failed");
-            DevBuf<int64_t> k_r;
-            DevBuf<int16_t> c_r;
-            DevBuf<uint32_t> p_r;
-            if (k_r.alloc(n[r]) != hipSuccess || c_r.alloc(n[r]) != hipSuccess || p_r.alloc(n[r]) != hipSuccess)
-                return gfail(g, MC_ENOMEM, "mc_group_bfs_batch: no room for a shard's export");
-            uint64_t got = 0;
-            const int rc = mc_export_dev(c, min_cov, k_r.p, c_r.p, p_r.p, n[r], &got);
-            if (rc) return gfail(g, rc, mc_last_error(c));
-            if (peer_copy(all_k.p + at, c0, k_r.p, c, got * 8, c0->stream) != hipSuccess || peer_copy(all_c.p + at, c0, c_r.p, c, got * 2, c0->stream) != hipSuccess ||
-                peer_copy(all_p.p + at, c0, p_r.p, c, got * 4, c0->stream) != hipSuccess || hipStreamSynchronize(c0->stream) != hipSuccess)
+            const uint64_t got = sh[r].got;
+            if (got == 0) continue;
+            if (peer_copy(all_k.p + at, c0, sh[r].k.p, g->ctx[r], got * 8, c0->stream) != hipSuccess || peer_copy(all_c.p + at, c0, sh[r].c.p, g->ctx[r], got * 2, c0->stream) != hipSuccess ||
+                peer_copy(all_p.p + at, c0, sh[r].p.p, g->ctx[r], got * 4, c0->stream) != hipSuccess)
                 return gfail(g, MC_EHIP, "mc_group_bfs_batch: gathering the shards failed (peer copy)");
             at += got;
         }
+        if (hipStreamSynchronize(c0->stream) != hipSuccess) return gfail(g, MC_EHIP, "mc_group_bfs_batch: gathering the shards failed (peer copy)");
         if (hipSetDevice(c0->cfg.device) != hipSuccess) return gfail(g, MC_EHIP, "hipSetDevice failed");
         int rc = mc_clear(g->solid);
         if (!rc) rc = mc_share_read_store(g->solid, c0);

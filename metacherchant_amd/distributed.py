@@ -35,8 +35,11 @@ class ShardedCounter:
         self.bfs_rank = bfs_rank
         if self.world > 1 and bfs_rank is not None and self.rank != bfs_rank and hasattr(ctx, "set_read_pointers"):
             ctx.set_read_pointers(False)
-        # see _exchange_superkmers (MC_EXCHANGE_MIN_READS: read sets from this size on go in two pieces)
-        self.parts, self.parts_min_reads = 2, int(os.environ.get("MC_EXCHANGE_MIN_READS", 1 << 20))
+        # A rank's reads are exchanged and counted in chunks of at most this many reads (MC_EXCHANGE_CHUNK_READS): what bounds
+        # the memory of one exchange -- records to send, records received, the counting pipeline's scratch -- whatever the
+        # size of the rank's share (configs[3]: 125 M reads a rank; DESIGN.md section 6 has the budget).  Every chunk is one
+        # counting run, and a run rewrites the rank's whole table: as few chunks as fit.
+        self.chunk_reads = int(os.environ.get("MC_EXCHANGE_CHUNK_READS", 32 << 20))
 
     def add_reads_dev(self, d_words, d_offsets, n_reads, n_bases, max_windows):
         """Counts this rank's reads into the sharded table: extract -> all-to-all -> count owned keys.
@@ -45,22 +48,50 @@ class ShardedCounter:
         if W == 1:
             ctx.add_reads_packed_dev(d_words, d_offsets, n_reads, n_bases)
             return
-        cap = ctx.superkmer_capacity(max_windows, n_reads) if hasattr(ctx, "superkmer_capacity") else 0
-        if cap:  # packed keys, k >= 23: the reads travel as super-k-mer records, a seventh of the bytes
-            self._exchange_superkmers(d_words, d_offsets, n_reads, n_bases, cap)
-            return
-        send = torch.empty(max(int(max_windows), 1), dtype=torch.int64, device=self.device)
-        send_h = torch.empty(max(int(max_windows), 1), dtype=torch.int32, device=self.device)  # speculation hints
-        off = ctx.extract_keys_dev(d_words, d_offsets, n_reads, n_bases, W, send, send.numel(), send_h)
-        send_counts = [int(off[o + 1] - off[o]) for o in range(W)]
+        # Every rank must issue the same collectives: the number of chunks is the largest any rank needs (one all-reduce, the
+        # only host round trip besides one per chunk for the record counts), and a rank that has run out of reads still
+        # takes part in the remaining exchanges with zero counts.
+        nc = torch.tensor([max(1, -(-int(n_reads) // self.chunk_reads))], dtype=torch.int64, device=self.device)
+        dist.all_reduce(nc, op=dist.ReduceOp.MAX, group=self.group)
+        n_chunks = int(nc.item())
+        bounds = [n_reads * c // n_chunks for c in range(n_chunks + 1)]
+        if n_chunks > 1:  # the chunk boundaries' base offsets in one copy
+            idx = torch.tensor(bounds[1:-1], dtype=torch.int64, device=self.device)
+            base_at = [0] + [int(x) for x in d_offsets[idx].cpu().tolist()] + [int(n_bases)]
+        else:
+            base_at = [0, int(n_bases)]
+        sk = hasattr(ctx, "superkmer_capacity") and ctx.superkmer_capacity(max(int(max_windows), 1), max(int(n_reads), 1)) != 0
+        for c in range(n_chunks):
+            a, b = bounds[c], bounds[c + 1]
+            nb = base_at[c + 1] - base_at[c]
+            # (offsets are absolute in the rank's buffer: a chunk is the reads [a, b) with the bases up to base_at[c + 1])
+            if sk:
+                self._exchange_superkmers(d_words, d_offsets[a:], b - a, base_at[c + 1], nb)
+            else:
+                self._exchange_keys(d_words, d_offsets[a:], b - a, base_at[c + 1], min(int(max_windows), nb))
+
+    def _counts(self, send_counts):
+        """The one host round trip of an exchange: what every rank will send me."""
+        W = self.world
         sc = torch.tensor(send_counts, dtype=torch.int64, device=self.device)
         rc = torch.empty(W, dtype=torch.int64, device=self.device)
         dist.all_to_all_single(rc, sc, group=self.group)
-        recv_counts = [int(x) for x in rc.cpu().tolist()]
-        n_recv = sum(recv_counts)
+        return [int(x) for x in rc.cpu().tolist()]
+
+    def _exchange_keys(self, d_words, d_offsets, n_reads, n_bases_end, max_windows):
+        ctx, W = self.ctx, self.world
+        cap = max(int(max_windows), 1)
+        send = torch.empty(cap, dtype=torch.int64, device=self.device)
+        send_h = torch.empty(cap, dtype=torch.int32, device=self.device)  # the read pointers
+        if n_reads:
+            off = ctx.extract_keys_dev(d_words, d_offsets, n_reads, n_bases_end, W, send, send.numel(), send_h)
+        else:
+            off = np.zeros(W + 1, dtype=np.uint64)
+        send_counts = [int(off[o + 1] - off[o]) for o in range(W)]
+        recv_counts = self._counts(send_counts)
+        n_recv, n_send = sum(recv_counts), int(off[W])
         recv = torch.empty(max(n_recv, 1), dtype=torch.int64, device=self.device)
         recv_h = torch.empty(max(n_recv, 1), dtype=torch.int32, device=self.device)
-        n_send = int(off[W])
         dist.all_to_all_single(recv[:n_recv], send[:n_send], output_split_sizes=recv_counts,
                                input_split_sizes=send_counts, group=self.group)
         dist.all_to_all_single(recv_h[:n_recv], send_h[:n_send], output_split_sizes=recv_counts,
@@ -71,65 +102,34 @@ class ShardedCounter:
         del send, send_h
         ctx.add_keys_dev(recv, n_recv, recv_h)
 
-    def _exchange_superkmers(self, d_words, d_offsets, n_reads, n_bases, cap):
-        """The reads go in `parts` consecutive pieces: the all-to-all of piece p (asynchronous: RCCL has its own
-        stream) runs while piece p + 1 is being extracted.  All pieces land in ONE receive buffer and are counted by
-        one call: every counting pass rewrites the whole table, so one pass per piece would cost more than the
-        overlap gains."""
+    def _exchange_superkmers(self, d_words, d_offsets, n_reads, n_bases_end, n_bases):
+        """One chunk as super-k-mer records (packed keys, k >= 23: a seventh of the bytes of one key per window): extract,
+        one exchange of the counts, the records and their read pointers in two all-to-alls, one counting run."""
         ctx, W = self.ctx, self.world
-        # every rank must issue the same collectives: the number of pieces is decided by the smallest share, and a rank
-        # without reads in a piece still takes part in its exchange (with zero counts)
-        nmin = torch.tensor([int(n_reads)], dtype=torch.int64, device=self.device)
-        dist.all_reduce(nmin, op=dist.ReduceOp.MIN, group=self.group)
-        parts = self.parts if int(nmin.item()) >= self.parts_min_reads else 1
-        bounds = [n_reads * p // parts for p in range(parts + 1)]
-        base_at = [0] + [int(d_offsets[b].item()) for b in bounds[1:-1]] + [int(n_bases)]
-        recv = recv_b = None
-        filled = 0
-        inflight = []   # (work, work, send buffers kept alive)
-        leftovers = []  # a piece that did not fit the shared buffer: counted by a call of its own
-        for p in range(parts):
-            a, b = bounds[p], bounds[p + 1]
-            cap_p = max(cap if parts == 1 else ctx.superkmer_capacity(base_at[p + 1] - base_at[p], b - a), 1)
-            send = torch.empty((cap_p, 2), dtype=torch.int64, device=self.device)   # 16-byte records
-            send_b = torch.empty(cap_p, dtype=torch.int32, device=self.device)      # the read pointers of their first windows
-            if b > a:
-                off = ctx.extract_superkmers_dev(d_words, d_offsets[a:], b - a, base_at[p + 1], W, send, send_b, cap_p)
-            else:
-                off = np.zeros(W + 1, dtype=np.uint64)
-            send_counts = [int(off[o + 1] - off[o]) for o in range(W)]
-            sc = torch.tensor(send_counts, dtype=torch.int64, device=self.device)
-            rc = torch.empty(W, dtype=torch.int64, device=self.device)
-            dist.all_to_all_single(rc, sc, group=self.group)
-            recv_counts = [int(x) for x in rc.cpu().tolist()]
-            n_recv, n_send = sum(recv_counts), int(off[W])
-            if recv is None:  # room for all pieces, sized from the first (the pieces are equal shares of the reads)
-                room = max(int(n_recv * (parts - p) * 1.1) + 1024, 1) if parts > 1 else max(n_recv, 1)
-                recv = torch.empty((room, 2), dtype=torch.int64, device=self.device)
-                recv_b = torch.empty(room, dtype=torch.int32, device=self.device)
-            if filled + n_recv <= recv.shape[0]:
-                dst, dst_b = recv[filled:filled + n_recv], recv_b[filled:filled + n_recv]
-                filled += n_recv
-            else:
-                dst = torch.empty((max(n_recv, 1), 2), dtype=torch.int64, device=self.device)[:n_recv]
-                dst_b = torch.empty(max(n_recv, 1), dtype=torch.int32, device=self.device)[:n_recv]
-                leftovers.append((dst, dst_b, n_recv))
-            w1 = dist.all_to_all_single(dst, send[:n_send], output_split_sizes=recv_counts, input_split_sizes=send_counts,
-                                        group=self.group, async_op=True)
-            w2 = dist.all_to_all_single(dst_b, send_b[:n_send], output_split_sizes=recv_counts, input_split_sizes=send_counts,
-                                        group=self.group, async_op=True)
-            inflight.append((w1, w2, send, send_b))
-            self.bytes_sent += 20 * (n_send - send_counts[self.rank])
-        for w1, w2, _, _ in inflight:
-            w1.wait()
-            w2.wait()
+        cap = max(ctx.superkmer_capacity(max(int(n_bases), 1), max(int(n_reads), 1)), 1)
+        send = torch.empty((cap, 2), dtype=torch.int64, device=self.device)   # 16-byte records
+        send_b = torch.empty(cap, dtype=torch.int32, device=self.device)      # the read pointers of their first windows
+        if n_reads:
+            off = ctx.extract_superkmers_dev(d_words, d_offsets, n_reads, n_bases_end, W, send, send_b, cap)
+        else:
+            off = np.zeros(W + 1, dtype=np.uint64)
+        send_counts = [int(off[o + 1] - off[o]) for o in range(W)]
+        recv_counts = self._counts(send_counts)
+        n_recv, n_send = sum(recv_counts), int(off[W])
+        recv = torch.empty((max(n_recv, 1), 2), dtype=torch.int64, device=self.device)
+        recv_b = torch.empty(max(n_recv, 1), dtype=torch.int32, device=self.device)
+        w1 = dist.all_to_all_single(recv[:n_recv], send[:n_send], output_split_sizes=recv_counts, input_split_sizes=send_counts,
+                                    group=self.group, async_op=True)
+        w2 = dist.all_to_all_single(recv_b[:n_recv], send_b[:n_send], output_split_sizes=recv_counts, input_split_sizes=send_counts,
+                                    group=self.group, async_op=True)
+        w1.wait()
+        w2.wait()
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
-        del inflight
-        if recv is not None:
-            ctx.add_superkmers_dev(recv, recv_b, filled)
-        for dst, dst_b, n in leftovers:
-            ctx.add_superkmers_dev(dst, dst_b, n)
+        self.bytes_sent += 20 * (n_send - send_counts[self.rank])
+        del send, send_b
+        # (a rank that received nothing still calls: the context must know its pipeline buffers were reused, mcgpu.hip)
+        ctx.add_superkmers_dev(recv, recv_b, n_recv)
 
     def finalize(self):
         """Local distinct keys; the sum over ranks is the table size (owners are disjoint)."""
@@ -148,9 +148,9 @@ class ShardedCounter:
             return None  # the caller BFSes on ctx itself
         n_local = ctx.export_count(min_cov)  # no sweep when the context tracked this threshold (set_coverage_hint)
         nt = torch.tensor([n_local], dtype=torch.int64, device=self.device)
-        sizes = [torch.empty(1, dtype=torch.int64, device=self.device) for _ in range(W)]
-        dist.all_gather(sizes, nt, group=self.group)
-        sizes = [int(s.item()) for s in sizes]
+        sizes_t = torch.empty(W, dtype=torch.int64, device=self.device)
+        dist.all_gather_into_tensor(sizes_t, nt, group=self.group)
+        sizes = [int(x) for x in sizes_t.cpu().tolist()]  # (one copy, not one per rank)
         mx = max(max(sizes), 1)
         keys = torch.zeros(mx, dtype=torch.int64, device=self.device)
         cnts = torch.full((mx,), -1, dtype=torch.int16, device=self.device)  # -1 marks the padding behind a short shard

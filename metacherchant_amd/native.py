@@ -64,7 +64,7 @@ EXPORTS = [
     "mc_add_reads_packed_dev", "mc_add_reads_file", "mc_finalize_counts", "mc_get", "mc_get_dev", "mc_kmer_keys", "mc_bfs", "mc_bfs_batch",
     "mc_bfs_result_free", "mc_export", "mc_export_dev", "mc_add_pairs_dev", "mc_solid_from_pairs_dev", "mc_save_kmers", "mc_load_kmers", "mc_key_owner", "mc_extract_keys_dev",
     "mc_group_create", "mc_group_destroy", "mc_group_last_error", "mc_group_set_coverage_hint", "mc_group_add_reads_packed", "mc_group_add_reads_file",
-    "mc_group_finalize_counts", "mc_group_bfs_batch", "mc_add_keys_dev", "mc_superkmer_capacity", "mc_extract_superkmers_dev", "mc_add_superkmers_dev", "mc_get_stats", "mc_reset_stats", "mc_synth_reads_dev", "mc_synth_genome",
+    "mc_group_finalize_counts", "mc_group_bfs_batch", "mc_group_get_stats", "mc_add_keys_dev", "mc_superkmer_capacity", "mc_extract_superkmers_dev", "mc_add_superkmers_dev", "mc_get_stats", "mc_reset_stats", "mc_synth_reads_dev", "mc_synth_genome",
 ]
 
 _LIB = None
