@@ -232,7 +232,7 @@ def main():
             # its kernels were built from, and the number is only reported while the counting kernels are unchanged since
             # (git diff of csrc/count_pipeline.h and csrc/kmer_device.h against that commit is empty), else null.
             traffic, traffic_source = None, None
-            pmc = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic_e1.csv")
+            pmc = os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic_e1.csv")
             if pipeline and world == 1 and args.err == 100 and R == 10_000_000 and k == 31 and os.path.exists(pmc):
                 import csv
                 import subprocess
@@ -249,10 +249,10 @@ def main():
                     gb = 0.0
                     for row in rows:
                         # (k_sk2_scatter is also used by the BFS-table build of a sharded run; on one GPU only by the pipeline)
-                        if row["kernel"].startswith(("mc::k_sk1w_extract", "mc::k_p3_merge", "mc::k_sk2_scatter", "void mc::k_sk1w_extract", "void mc::k_p3_merge")):
+                        if row["kernel"].startswith(("mc::k_sk1w_extract", "mc::k_p3_merge", "mc::k_p3_dedup", "mc::k_sk2_scatter", "void mc::k_sk1w_extract", "void mc::k_p3_merge", "void mc::k_p3_dedup")):
                             gb += float(row["fetch_GB_corrected_x2"]) + float(row["write_GB"])
                     traffic = round(gb * 1e9)
-                    traffic_source = "profiles/r02_pmc_hbm_traffic_e1.csv (commit %s)" % commit
+                    traffic_source = "profiles/r03_pmc_hbm_traffic_e1.csv (commit %s)" % commit
             roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                         "kernel": dominant, "launch": "counting pipeline p1+p2+p3" if pipeline else "k_count_reads",

@@ -7,6 +7,9 @@
 # Generates the synthetic workload of DESIGN.md section 3.4 (10 x 5 Mb contigs scaled down to n_reads at 30x), writes it
 # as FASTA, runs `java -jar $MC_REFERENCE_JAR --tool environment-finder` and the native `metacherchant` on the same
 # files with the same flags, and diffs graph.txt, graph.gfa, seqs.fasta and tsvs/* of every output directory.
+# A third leg, when MC_PATCHED_JAR names a jar built from the reference with integration/patches/* applied and
+# integration/java/gpu/McGpu.java + integration/jni/mcgpu_jni.c built (integration/README.md): the same command with
+# MC_GPU_DEVICE=0, i.e. the original Java host over the C ABI, diffed against the other two.
 # Exit status 0 = every file identical.  The Java log's timestamps around "Loading file" ... "Hashtable size" ...
 # "Finished processing all sequences!" are printed as the reference's phase times on this box's cores.
 set -euo pipefail
@@ -50,5 +53,13 @@ while IFS= read -r f; do
     rel="${f#$W/java_out/}"
     if cmp -s "$f" "$W/hip_out/$rel"; then echo "identical  $rel"; else echo "DIFFERENT  $rel"; rc=1; fi
 done < <(find "$W/java_out" -type f \( -name graph.txt -o -name graph.gfa -o -name seqs.fasta -o -name '*.tsv' \) | sort)
+if [ -f "${MC_PATCHED_JAR:-}" ]; then   # the Java host over the C ABI (integration/: McGpu.java, mcgpu_jni.c, patches)
+    MC_GPU_DEVICE=0 java -Djava.library.path="$ROOT/metacherchant_amd/lib" -jar "$MC_PATCHED_JAR" --tool environment-finder -k "$K" \
+         --reads "$W/reads.fasta" --seq "$W/seed.fasta" --output "$W/jni_out" --work-dir "$W/jni_wd" -p "$CORES" --force "${EXTRA[@]}" > "$W/jni.stdout" 2> "$W/jni.log"
+    while IFS= read -r f; do
+        rel="${f#$W/java_out/}"
+        if cmp -s "$f" "$W/jni_out/$rel"; then echo "identical (JNI host)  $rel"; else echo "DIFFERENT (JNI host)  $rel"; rc=1; fi
+    done < <(find "$W/java_out" -type f \( -name graph.txt -o -name graph.gfa -o -name seqs.fasta -o -name '*.tsv' \) | sort)
+fi
 [ $rc -eq 0 ] && echo "all output files byte-identical with the reference" || echo "MISMATCH: see above"
 exit $rc
