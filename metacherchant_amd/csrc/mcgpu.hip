@@ -30,7 +30,9 @@
 #include "kmer_device.h"
 #include "bfs_device.h"
 #include "count_pipeline.h"
-#include "count_long.h"
+#ifdef MC_SK_LONG_BUILD
+#include "count_long.h"   // an experiment (32-byte super-k-mer records for hash keys): only in libraries built with -DMC_SK_LONG_BUILD
+#endif
 #include "tokenizer.h"
 #include "host/envfinder.h"
 
@@ -1714,6 +1716,7 @@ static int add_reads_partitioned_once(mc_ctx *c, const uint64_t *d_words, const 
     return MC_OK;
 }
 
+#ifdef MC_SK_LONG_BUILD
 // One batch of reads [r0, r1) as 32-byte super-k-mer records (count_long.h): polynomial-hash keys, k = 32 .. 63, into a
 // table that holds nothing yet or was filled this way.  Returns 2 when this table cannot be split into the pipeline's
 // leaves (the caller takes the per-window pipeline).
@@ -1875,13 +1878,17 @@ static int add_reads_partitioned_long(mc_ctx *c, const uint64_t *d_words, const 
 }
 
 // the pipeline a batch of reads takes: 32-byte records while the context may and the table allows, else the usual one
+#endif  // MC_SK_LONG_BUILD
+
 static int add_reads_partitioned_any(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_off, uint64_t r0, uint64_t r1, uint64_t base0,
                                      uint64_t end_abs, uint64_t wb)
 {
+#ifdef MC_SK_LONG_BUILD
     if (c->skl_ok && (c->skl_state || c->virgin)) {
         const int rc = add_reads_partitioned_long(c, d_words, d_off, r0, r1, base0, end_abs, wb);
         if (rc != 2) return rc;
     }
+#endif
     return add_reads_partitioned(c, d_words, d_off, r0, r1, base0, end_abs, wb);
 }
 
@@ -2148,7 +2155,9 @@ int mc_create(const mc_config *cfg, mc_ctx **out)
     // (an experiment, off unless MC_SK_LONG=1: measured on 10 M reads at k = 63 -- P1 24 + P2 2 + P3 32 ms against 35 ms for the
     // per-window pipeline, and the bins of a table at load 0.43 overflow, which sends it back to hash regions: DESIGN.md section 7)
     c->skl_ok = false;
+#ifdef MC_SK_LONG_BUILD
     if (const char *e = getenv("MC_SK_LONG")) c->skl_ok = !strcmp(e, "1") && cfg->key_mode == MC_KEY_POLY && cfg->k >= 32 && cfg->k <= 63;
+#endif
     uint64_t want_slots = 1ull << 22;  // 4 M slots = 64 MB to start with
     if (cfg->capacity_hint) {
         // Load factor the hint is turned into.  Hash-prefix tables: 0.7 (regions are probed in LDS, a fuller table
@@ -3659,6 +3668,7 @@ __host__ __device__ inline uint64_t bfs_pack_bytes(uint64_t n) { return 16 * n +
 // into the data block behind the arrays of the jobs before it; `last` from bit 0 of the flags; the largest distance.
 __global__ void __launch_bounds__(256) k_bfs_pack(const BfsState *__restrict__ states, uint32_t n_jobs, BfsPackHdr *hdr, char *data, uint64_t data_cap)
 {
+    (void)n_jobs;
     const uint32_t j = blockIdx.y;
     const BfsState S = states[j];
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x, stride = (uint64_t)gridDim.x * 256;

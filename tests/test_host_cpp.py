@@ -436,3 +436,19 @@ def test_treeified_bins_same_order_in_all_three_maps(hosttest, tmp_path):
     out = subprocess.check_output([hosttest, "hashmap", str(path)]).decode().splitlines()
     assert out[0].split()[3] == "1" and out[12].split()[3] == "1"
     assert [(l.split()[1], int(l.split()[2])) for l in out[1:12]] == list(m.items())
+
+
+def test_cli_refuses_k_above_63_with_a_clear_message(tmp_path):
+    """The reference takes any k > 31 (it hashes k-mer strings, src/io/LargeKIOUtils.java:41-54); this build keeps oriented
+    k-mers in 128 bits and says so instead of miscounting.  The check comes before any device is touched: CPU test."""
+    from metacherchant_amd import build
+    build.build_all()
+    if not os.path.exists(build.CLI):
+        pytest.skip("the CLI needs libmcgpu.so (hipcc)")
+    seq = tmp_path / "s.fasta"
+    seq.write_text(">s\n" + "ACGT" * 40 + "\n")
+    for k in (64, 127):
+        p = subprocess.run([build.CLI, "-k", str(k), "-i", str(seq), "--seq", str(seq), "-o", str(tmp_path / "o"), "-w", str(tmp_path / "wd"),
+                            "--maxkmers", "10", "--force"], capture_output=True, text=True, timeout=120)
+        assert p.returncode == 1
+        assert "k = %d is not supported: this build handles k <= 31 (packed keys) and 32 <= k <= 63 (hash keys)" % k in p.stderr
