@@ -32,8 +32,8 @@ constexpr int PT_TILE = PT_THREADS * PT_ITEMS;      // 8192 windows / keys per t
 constexpr int PT_MAX_BUCKETS = 512;                 // fan-out of one scatter level (what a run takes unless the table needs more leaves)
 constexpr int PT_MAX_BUCKETS_KEYS = 1024;           // ... at most, in the per-window pipeline (k_p1_extract_scatter / k_p2_scatter: a thread per bucket): 2^20 leaves
 constexpr int PT_MAX_LEAVES2 = 1024;                // ... of the second level of the super-k-mer pipeline (k_sk2_scatter: an LDS cursor per leaf)
-constexpr int PT_MAX_BUCKETS1_SK = 1024;             // level-1 buckets of the super-k-mer pipeline when 512 x 1024 leaves are not enough
-constexpr int SK_LEAVES_LG = 20;                    // so up to 1024 x 1024 leaves of one region each (4.3 G slots of 16 bytes = 69 GB of table)
+constexpr int PT_MAX_BUCKETS1_SK = 2048;             // level-1 buckets of the super-k-mer pipeline at most (512 unless the table needs more leaves, then 1024, then 2048)
+constexpr int SK_LEAVES_LG = 21;                    // so up to 2048 x 1024 leaves of one region each (8.6 G slots of 16 bytes = 137 GB of table)
 constexpr int P3_THREADS = 512;
 constexpr uint32_t REGION_SLOTS = 1u << MC_REGION_LG;  // == 1 << mc_ctx::sb (4096: a 64 KB image in LDS)
 constexpr uint32_t CURSOR1_STRIDE = 32;             // owner cursors of the multi-GPU split sit on separate 128-byte lines
@@ -922,9 +922,9 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk1_records(const uint4 *__restr
                                                             uint64_t n, uint32_t np1, uint32_t *seg_counts, uint64_t cap,
                                                             uint4 *out_recs, uint32_t *out_bins, SkSpill sp)
 {
-    __shared__ SkCursors C;
+    __shared__ uint32_t wcur[PT_MAX_BUCKETS1_SK];  // this workgroup's fill level of every bucket
     const uint32_t tid = threadIdx.x, n_buckets = np1;
-    if (tid < PT_MAX_LEAVES2) { C.wcur[tid] = 0; C.cnt[tid] = 0; }
+    for (uint32_t i = tid; i < PT_MAX_BUCKETS1_SK; i += PT_THREADS) wcur[i] = 0;
     __syncthreads();
     const uint64_t n_tiles = (n + PT_TILE - 1) / PT_TILE;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -933,14 +933,20 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk1_records(const uint4 *__restr
             const uint64_t i = tile * PT_TILE + tid + (uint64_t)j * PT_THREADS;
             if (i < n) {
                 const uint4 rec = in_recs[i];  // (its bin word rides in rec.x; in_bins / out_bins carry the read pointers)
-                sk_emit(C, mulhi32(rec.x, np1), rec, in_bins[i], cap, (uint64_t)blockIdx.x * cap, (uint64_t)PT_SEGMENTS * cap, out_recs, out_bins, sp);
+                const uint32_t d = mulhi32(rec.x, np1);
+                const uint64_t dst = atomicAdd(&wcur[d], 1u);
+                if (dst < cap) {
+                    const uint64_t at = (uint64_t)blockIdx.x * cap + (uint64_t)d * ((uint64_t)PT_SEGMENTS * cap) + dst;
+                    out_recs[at] = rec;
+                    out_bins[at] = in_bins[i];
+                } else {
+                    sk_spill_push(sp, rec);
+                }
             }
         }
-        __syncthreads();
-        if (tid < n_buckets) { C.wcur[tid] += C.cnt[tid]; C.cnt[tid] = 0; }
-        __syncthreads();
     }
-    if (tid < n_buckets) seg_counts[(uint64_t)tid * PT_SEGMENTS + blockIdx.x] = min(C.wcur[tid], (uint32_t)cap);
+    __syncthreads();
+    for (uint32_t d = tid; d < n_buckets; d += PT_THREADS) seg_counts[(uint64_t)d * PT_SEGMENTS + blockIdx.x] = (uint32_t)min((uint64_t)wcur[d], cap);
 }
 
 // SK-P2: one workgroup per level-1 bucket; its segments are read as one stream and
@@ -1209,7 +1215,7 @@ constexpr uint32_t P3_COUNT_CAP = 1u << 30;
 // A region counts as full when an insertion has looked at this many slots (at the loads the host aims for probe chains
 // stay below a few dozen); a region that really is full would otherwise cost 4096 probes per occurrence -- with no
 // capacity hint that made a first, too small table 40 times slower than the run itself.
-constexpr uint32_t P3_MAX_PROBES = REGION_SLOTS < 1024 ? REGION_SLOTS : 1024;
+constexpr uint32_t P3_MAX_PROBES = REGION_SLOTS < TABLE_MAX_PROBES ? REGION_SLOTS : TABLE_MAX_PROBES;  // (the table's probing rule, kmer_device.h)
 #ifndef MC_PTR_LATE
 #define MC_PTR_LATE 0   // 1: a later occurrence (one of sixteen) replaces the early pointer (kmer_device.h ptr_pick_late): more different reads
                         // near a scout's tip, but + 0.6 ms in this kernel for 0.1 ms of walk on configs[1]
@@ -1237,12 +1243,25 @@ struct P3Emit {
 };
 
 
+// An occurrence that found no room within its stretch of the region held in LDS (the table's probing rule, kmer_device.h):
+// it goes on to the region behind -- by the direct kernel, after this launch, from the list TableView::ovf (mcgpu.hip
+// pipe_finish).  false: the list is full; the leaf is then not committed and merged again later, as before.
+__device__ __forceinline__ bool ovf_push(const TableView &t, uint64_t key, uint32_t inc, uint32_t hint, uint32_t leaf)
+{
+    if (!t.ovf || !t.ovf_leaf) return false;
+    const unsigned long long i = atomicAdd(t.ovf_n, 1ull);
+    if (i >= t.ovf_cap) return false;
+    t.ovf[i] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), inc, hint);
+    t.ovf_leaf[i] = leaf;  // (a leaf that fails after this -- the list ran full -- is merged again: its entries are then skipped)
+    return true;
+}
+
 // Linear probing for `key` in an array of REGION_SLOTS 64-bit keys at LDS byte address `base`, from slot `home` on: the
 // slot that holds the key when the loop ends, claimed with one LDS compare-and-swap per step when it was free (there is
 // no load first: a CAS that finds another key is that load).  The compiler's loop spends ~20 scalar instructions a step
 // on the bookkeeping of its exit conditions, and the slowest of 64 lanes decides the number of steps -- the scalar unit
 // was the busiest part of the CU in the merge kernel; this one spends 6.  *n_new_wave += keys the WAVE inserted;
-// *pending: lanes that found no slot in 1024 steps (their region is full).
+// *pending: lanes that found no slot in P3_MAX_PROBES steps (their key goes on to the next region: TableView::ovf).
 __device__ __forceinline__ uint32_t lds_probe_claim(uint32_t base, uint32_t home, uint64_t key, uint32_t *n_new_wave, unsigned long long *pending)
 {
     uint32_t off = home * 8u, addr, cnt, t, it;
@@ -1251,7 +1270,7 @@ __device__ __forceinline__ uint32_t lds_probe_claim(uint32_t base, uint32_t home
     asm volatile(
         "s_mov_b64 %[sv], exec\n\t"
         "s_mov_b32 %[cnt], 0\n\t"
-        "s_movk_i32 %[it], 0x400\n"
+        "s_mov_b32 %[it], %[maxp]\n"
         "1:\n\t"
         "v_add_u32 %[addr], %[base], %[off]\n\t"
         "ds_cmpst_rtn_b64 %[old], %[addr], %[empty], %[key]\n\t"
@@ -1273,7 +1292,7 @@ __device__ __forceinline__ uint32_t lds_probe_claim(uint32_t base, uint32_t home
         "s_mov_b64 exec, %[sv]\n\t"
         : [off] "+v"(off), [old] "=&v"(old), [addr] "=&v"(addr), [sv] "=&s"(sv), [hit] "=&s"(hit), [cnt] "=&s"(cnt), [t] "=&s"(t),
           [it] "=&s"(it), [pend] "=&s"(pend)
-        : [base] "s"(base), [empty] "v"(empty), [key] "v"(key), [wrap] "s"((uint32_t)(REGION_SLOTS * 8u - 8u))
+        : [base] "s"(base), [empty] "v"(empty), [key] "v"(key), [wrap] "s"((uint32_t)(REGION_SLOTS * 8u - 8u)), [maxp] "s"((uint32_t)P3_MAX_PROBES)
         : "vcc", "scc", "memory");
     *n_new_wave += cnt;
     *pending = pend;
@@ -1478,8 +1497,8 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                                         if (p0 && (seen == first || seen == late || L.aux[s] == 0)) L.aux[s] = ptr_advance(p0, j);
                                     }
                                 }
-                            } else {
-                                atomicExch(&L.overflow, 1u);
+                            } else if (commit) {  // (a sweep that only checks, g > 0, leaves it to the one that commits)
+                                if (!ovf_push(t, key, 1u, ptr_advance(sq[src_c], j), leaf)) atomicExch(&L.overflow, 1u);
                             }
                         }
                         __builtin_amdgcn_wave_barrier();  // (the queue is rewritten by the next batch)
@@ -1505,7 +1524,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                         if (g && (gslot >> MC_REGION_LG) != region) continue;
                         const bool done = lds_region_add(L, key, hh[u], (uint32_t)gslot & (REGION_SLOTS - 1), my_new,
                                                          ptr_pick(key, solid_thr >= 2 ? 1u : 0u, solid_thr), ptr_pick_late(key, solid_thr >= 2 ? 1u : 0u));
-                        if (!done) atomicExch(&L.overflow, 1u);
+                        if (!done && commit && !ovf_push(t, key, 1u, hh[u], leaf)) atomicExch(&L.overflow, 1u);
                     }
                 }
                 }
@@ -1648,6 +1667,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_dedup(const uint4 *__restrict
 
     // one batch of up to 64 records (one per lane: y, z, w; copies == 0: none) into the region image
     uint32_t new_wave = 0;  // keys this WAVE inserted (the same number in every lane)
+    uint32_t cur_leaf = 0;  // the leaf being merged
     auto expand = [&](uint32_t y, uint32_t z, uint32_t w, uint32_t copies, bool hasptr, uint32_t slot) {
         const uint32_t nw = copies ? (w >> 28) + 1u : 0u;
         uint32_t incl = nw;
@@ -1693,7 +1713,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_dedup(const uint4 *__restrict
                             }
                         }
                     }
-                } else {
+                } else if (!ovf_push(t, key, rm & 0x7FFFu, 0u, cur_leaf)) {
                     atomicExch(&L.overflow, 1u);
                 }
             }
@@ -1758,6 +1778,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_dedup(const uint4 *__restrict
         }
         if (tid == 0) { L.n_new = 0; L.overflow = 0; }
         new_wave = 0;
+        cur_leaf = leaf;
         // ---- the records into the record table, 1024 at a time (nearly always all of them)
         for (uint32_t base = 0; base < n0; base += 2 * P3_THREADS) {  // uniform
             uint4 rec[2];

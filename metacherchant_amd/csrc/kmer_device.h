@@ -204,30 +204,50 @@ __host__ __device__ __forceinline__ Kmer neighbour(const Kmer &v, int k, int dir
 // mcgpu.hip) and a slot remembers WHERE one occurrence of its key sits in it.  The BFS uses that only to GUESS the
 // next vertices of a linear stretch -- the bases that follow the occurrence in its read are the path a walker will
 // most likely take -- and looks every guess up, so a missing, stale or wrong pointer can cost time but never change a
-// result.  32 bits: 0 = none; v = aux - 1 < 2^31: the occurrence starts at base v of the store, exactly; otherwise
-// somewhere in the PTR_COARSE + PTR_SLACK bases from 2^31 + ((v - 2^31) << 6) on (the reader matches the k-mer against
-// every offset of that range).  Exact for the first 2.1 G bases (14 M reads of 150), 6-bit granules up to 139 G.
+// result.  32 bits: 0 = none; v = aux - 1 < 2^31: the occurrence starts at base v of the store, exactly (14 M reads of
+// 150 bases).  Beyond that the value names a GRANULE of the store and the reader matches the k-mer against every offset of
+// it (+ PTR_SLACK, see ptr_advance), in tiers, so that a store a few times the exact range still gets fine pointers:
+//   v in [2^31,            2^31 + 2^30)            granules of   4 bases   positions 2.1 G ..   6.4 G
+//   v in [2^31 + 2^30,     2^31 + 2^30 + 2^29)     granules of  16 bases             6.4 G ..  15.0 G
+//   v in [2^31 + 3 * 2^29, 2^32 - 2)               granules of  64 bases            15.0 G ..  49 G   (beyond: no pointer)
+// (one tier of 64-base granules from 2^31 on, as it was, made the walk over 50 M reads twice as long as over 10 M.)
 constexpr uint64_t PTR_EXACT_END = 1ull << 31;
-constexpr uint32_t PTR_COARSE_LG = 6, PTR_COARSE = 1u << PTR_COARSE_LG, PTR_SLACK = 16;
+constexpr uint32_t PTR_SLACK = 16;
+constexpr uint32_t PTR_T1_LG = 2, PTR_T2_LG = 4, PTR_T3_LG = 6;  // (a hop looks at 512 bases around a pointer: 64 + PTR_SLACK candidate offsets is what fits)
+constexpr uint64_t PTR_T1_N = 1ull << 30, PTR_T2_N = 1ull << 29, PTR_T3_N = (1ull << 29) - 2;
+constexpr uint64_t PTR_T1_POS = PTR_EXACT_END, PTR_T2_POS = PTR_T1_POS + (PTR_T1_N << PTR_T1_LG), PTR_T3_POS = PTR_T2_POS + (PTR_T2_N << PTR_T2_LG);
 __host__ __device__ __forceinline__ uint32_t ptr_encode(uint64_t pos)
 {
     if (pos < PTR_EXACT_END) return (uint32_t)pos + 1u;
-    const uint64_t v = PTR_EXACT_END + ((pos - PTR_EXACT_END) >> PTR_COARSE_LG);
-    return v < 0xFFFFFFFEull ? (uint32_t)v + 1u : 0u;
+    uint64_t v;
+    if (pos < PTR_T2_POS) v = PTR_EXACT_END + ((pos - PTR_T1_POS) >> PTR_T1_LG);
+    else if (pos < PTR_T3_POS) v = PTR_EXACT_END + PTR_T1_N + ((pos - PTR_T2_POS) >> PTR_T2_LG);
+    else {
+        const uint64_t g = (pos - PTR_T3_POS) >> PTR_T3_LG;
+        if (g >= PTR_T3_N) return 0u;
+        v = PTR_EXACT_END + PTR_T1_N + PTR_T2_N + g;
+    }
+    return (uint32_t)v + 1u;
 }
 // first base of the range the occurrence starts in; *span = number of candidate offsets
 __host__ __device__ __forceinline__ uint64_t ptr_decode(uint32_t aux, uint32_t *span)
 {
     const uint64_t v = (uint64_t)aux - 1;
     if (v < PTR_EXACT_END) { *span = 1; return v; }
-    *span = PTR_COARSE + PTR_SLACK;
-    return PTR_EXACT_END + ((v - PTR_EXACT_END) << PTR_COARSE_LG);
+    const uint64_t w = v - PTR_EXACT_END;
+    if (w < PTR_T1_N) { *span = (1u << PTR_T1_LG) + PTR_SLACK; return PTR_T1_POS + (w << PTR_T1_LG); }
+    if (w < PTR_T1_N + PTR_T2_N) { *span = (1u << PTR_T2_LG) + PTR_SLACK; return PTR_T2_POS + ((w - PTR_T1_N) << PTR_T2_LG); }
+    *span = (1u << PTR_T3_LG) + PTR_SLACK;
+    return PTR_T3_POS + ((w - PTR_T1_N - PTR_T2_N) << PTR_T3_LG);
 }
-// pointer of the window j bases after the window a pointer names (windows of one super-k-mer record)
+// pointer of the window j <= 15 bases after the window a pointer names (windows of one super-k-mer record)
 __host__ __device__ __forceinline__ uint32_t ptr_advance(uint32_t aux, uint32_t j)
 {
     if (aux == 0) return 0;
-    return ((uint64_t)aux - 1 < PTR_EXACT_END - 64) ? aux + j : aux;  // (coarse granules: the reader's range has PTR_SLACK to spare)
+    const uint64_t v = (uint64_t)aux - 1;
+    if (v + 16 < PTR_EXACT_END) return aux + j;
+    if (v < PTR_EXACT_END) return ptr_encode(v + j);  // (the last exact positions: window j may lie in the first granule)
+    return aux;  // (a granule: the reader's range has PTR_SLACK to spare)
 }
 
 // Which occurrence of a key (counted from 0 in the order the counting kernels meet them) leaves its pointer:
@@ -358,6 +378,10 @@ struct TableView {
     uint4 *ovf;
     unsigned long long *ovf_n;
     uint64_t ovf_cap;
+    // The merge kernels of the counting pipeline use the same list for occurrences that go on to the next region
+    // (count_pipeline.h ovf_push): ovf_leaf[i] = the leaf entry i came from, so that the entries of a leaf that was not
+    // committed after all are dropped when the list is drained (0xFFFFFFFF: an entry of table_add's own, always kept).
+    uint32_t *ovf_leaf;
 };
 
 // home slot inside a minimizer-bin region: 12 well-mixed bits of the key, cheaper than fmix64 (the
@@ -385,6 +409,21 @@ __host__ __device__ __forceinline__ uint64_t slot_of(const TableView &t, uint64_
     return (region << MC_REGION_LG) | sk_home(key);  // (count_pipeline.h REGION_SLOTS)
 }
 
+// Probing rule of the table, the same for every kernel that inserts or looks up: a key sits within TABLE_MAX_PROBES slots of
+// its home slot (linear probing that wraps inside the region), or -- when those slots held no free one at the time it came
+// -- within as many slots of the same offset in the region behind, and so on through TABLE_CHAIN regions.  A lookup stops at
+// the first free slot; it moves on to the next region only after TABLE_MAX_PROBES occupied ones.  Minimizer-bin regions
+// fill unevenly (a 300-fold covered genome puts 7 loci' worth of error k-mers into one region in fifty), and a table
+// that cannot be doubled any more -- 137 GB on a 288 GB device -- used to have no way out.
+constexpr uint32_t TABLE_MAX_PROBES = 128;
+constexpr uint32_t TABLE_CHAIN = 4;
+// first slot of the region behind the one that starts at `base` (regions of rmask + 1 slots, n_regions of them)
+__host__ __device__ __forceinline__ uint64_t next_region_base(uint64_t base, uint32_t rmask, uint64_t n_regions)
+{
+    const uint64_t nb = base + (uint64_t)rmask + 1;
+    return nb >= n_regions * ((uint64_t)rmask + 1) ? 0 : nb;
+}
+
 // addAndBound(key, inc) with the saturation deferred to read time (count is 32-bit here; a
 // counter that already reached 2^31 is left alone, launches add < 2^30 each, so it never wraps
 // and min(32767, count) equals the reference's saturating short, itmo!/utils/NumUtils.java:21-26).
@@ -401,8 +440,12 @@ __device__ __forceinline__ uint32_t table_add(const TableView &t, uint64_t key, 
         return 0;
     }
     uint64_t s = slot_of(t, key);
-    const uint64_t base = s & ~(uint64_t)t.rmask;
-    for (uint32_t probe = 0; probe <= t.rmask; probe++) {
+    uint64_t base = s & ~(uint64_t)t.rmask;
+    // (TABLE_MAX_PROBES slots from the home slot, then the same stretch of the region behind, ...: see there)
+    const uint64_t home = s & t.rmask;
+    const uint32_t max_probes = t.rmask + 1 < TABLE_MAX_PROBES ? t.rmask + 1 : TABLE_MAX_PROBES;
+    for (uint32_t hop = 0; hop < TABLE_CHAIN; hop++, base = next_region_base(base, t.rmask, t.n_regions), s = base | home)
+    for (uint32_t probe = 0; probe < max_probes; probe++) {
         Slot *p = t.slots + s;
         const uint4 raw = *reinterpret_cast<const uint4 *>(p);
         uint64_t cur = ((uint64_t)raw.y << 32) | raw.x;
@@ -440,6 +483,7 @@ __device__ __forceinline__ uint32_t table_add(const TableView &t, uint64_t key, 
         const unsigned long long i = atomicAdd(t.ovf_n, 1ull);
         if (i < t.ovf_cap) {
             t.ovf[i] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), inc, hint);
+            if (t.ovf_leaf) t.ovf_leaf[i] = 0xFFFFFFFFu;
             return 0;
         }
     }
@@ -486,21 +530,30 @@ __device__ __forceinline__ uint64_t solid_slot_of(const SolidView &t, uint64_t k
 // count (saturated) or -1; *aux (may be null) = the slot's read pointer; n_done = slots the caller has looked at already.
 __device__ __forceinline__ int solid_probe_from(const SolidView &t, uint64_t key, uint64_t s, uint32_t n_done, uint32_t *aux)
 {
-    const uint64_t base = s & ~(uint64_t)t.rmask;
-    for (uint32_t probe = n_done; probe <= t.rmask; probe += 4) {
-        uint4 a[4];
+    uint64_t base = s & ~(uint64_t)t.rmask;
+    const uint64_t n_regions = t.n_regions ? (uint64_t)t.n_regions : ((1ull << (64 - t.shift)) / ((uint64_t)t.rmask + 1));
+    const uint64_t home = (s - n_done) & t.rmask;
+    const uint32_t max_probes = t.rmask + 1 < TABLE_MAX_PROBES ? t.rmask + 1 : TABLE_MAX_PROBES;
+    for (uint32_t hop = 0; hop < TABLE_CHAIN; hop++) {
+        for (uint32_t probe = hop ? 0 : n_done; probe < max_probes; probe += 4) {
+            uint4 a[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) a[i] = *reinterpret_cast<const uint4 *>(t.slots + (base | ((s + i) & t.rmask)));
+            for (int i = 0; i < 4; i++) a[i] = *reinterpret_cast<const uint4 *>(t.slots + (base | ((s + i) & t.rmask)));
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint64_t cur = ((uint64_t)a[i].y << 32) | a[i].x;
-            if (cur == key) {
-                if (aux) *aux = a[i].w;
-                return a[i].z > 32767u ? 32767 : (int)a[i].z;
+            for (int i = 0; i < 4; i++) {
+                if (probe + (uint32_t)i >= max_probes) break;  // (a free slot BEHIND the stretch says nothing: the key may have moved on)
+                const uint64_t cur = ((uint64_t)a[i].y << 32) | a[i].x;
+                if (cur == key) {
+                    if (aux) *aux = a[i].w;
+                    return a[i].z > 32767u ? 32767 : (int)a[i].z;
+                }
+                if (cur == EMPTY_KEY) return -1;
             }
-            if (cur == EMPTY_KEY) return -1;
+            s = base | ((s + 4) & t.rmask);
         }
-        s = base | ((s + 4) & t.rmask);
+        // no free slot in the whole stretch: the key may have been handed on to the next region (table_add)
+        base = next_region_base(base, t.rmask, n_regions);
+        s = base | home;
     }
     return -1;
 }
@@ -532,8 +585,11 @@ __device__ __forceinline__ int table_get(const TableView &t, uint64_t key)
         return c == 0 ? -1 : (c > 32767ull ? 32767 : (int)c);
     }
     uint64_t s = slot_of(t, key);
-    const uint64_t base = s & ~(uint64_t)t.rmask;
-    for (uint32_t probe = 0; probe <= t.rmask; probe++) {
+    uint64_t base = s & ~(uint64_t)t.rmask;
+    const uint64_t home = s & t.rmask;
+    const uint32_t max_probes = t.rmask + 1 < TABLE_MAX_PROBES ? t.rmask + 1 : TABLE_MAX_PROBES;
+    for (uint32_t hop = 0; hop < TABLE_CHAIN; hop++, base = next_region_base(base, t.rmask, t.n_regions), s = base | home)
+    for (uint32_t probe = 0; probe < max_probes; probe++) {
         const uint4 raw = *reinterpret_cast<const uint4 *>(t.slots + s);
         const uint64_t cur = ((uint64_t)raw.y << 32) | raw.x;
         if (cur == key) return raw.z > 32767u ? 32767 : (int)raw.z;

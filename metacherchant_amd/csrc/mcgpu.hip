@@ -298,10 +298,12 @@ struct mc_ctx {
         t.ovf = d_ovf;
         t.ovf_n = d_ctr + 7;
         t.ovf_cap = d_ovf ? OVF_CAP : 0;
+        t.ovf_leaf = d_ovf_leaf;
         return t;
     }
     static constexpr uint64_t OVF_CAP = 1ull << 22;
     uint4 *d_ovf = nullptr;  // TableView::ovf
+    uint32_t *d_ovf_leaf = nullptr;  // TableView::ovf_leaf
 };
 
 static thread_local std::string g_create_err;
@@ -394,11 +396,18 @@ __global__ void k_add_pairs(const int64_t *__restrict__ keys, const int16_t *__r
 }
 
 // the parked additions of TableView::ovf, once the table has been enlarged
-__global__ void k_add_parked(const uint4 *__restrict__ list, uint64_t n, TableView t)
+// entry_leaf / leaf_state (may be null): an entry the merge kernels left (count_pipeline.h ovf_push) is skipped when its
+// leaf was not committed -- that leaf is merged again and leaves its entries again
+__global__ void k_add_parked(const uint4 *__restrict__ list, uint64_t n, TableView t, const uint32_t *__restrict__ entry_leaf = nullptr,
+                             const uint32_t *__restrict__ leaf_state = nullptr)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     unsigned long long n_new = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (entry_leaf && leaf_state) {
+            const uint32_t lf = entry_leaf[i];
+            if (lf != 0xFFFFFFFFu && leaf_state[lf] == 0) continue;
+        }
         const uint4 e = list[i];
         n_new += table_add(t, ((uint64_t)e.y << 32) | e.x, e.z, e.w);
     }
@@ -1185,7 +1194,10 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
     while (n_leaves > (uint64_t)max_b1_big * max_b2) { n_leaves >>= 1; g++; }
     if ((n_leaves << g) != c->n_regions) return fail(c, MC_EINVAL, "internal: %llu table regions do not split into leaves", (unsigned long long)c->n_regions);
     if (n_leaves < 4) return fail(c, MC_EINVAL, "internal: partitioned counting needs at least 4 table regions");
-    uint64_t np1 = std::min<uint64_t>(n_leaves, n_leaves > (uint64_t)PT_MAX_BUCKETS * max_b2 ? max_b1_big : (uint32_t)PT_MAX_BUCKETS);
+    // (512 level-1 buckets while 512 x max_b2 leaves do, then 1024, then -- super-k-mer records only -- 2048)
+    uint64_t np1 = PT_MAX_BUCKETS;
+    while (np1 < max_b1_big && n_leaves > np1 * max_b2) np1 *= 2;
+    np1 = std::min<uint64_t>(n_leaves, np1);
     if (n_records) if (const char *e = getenv("MC_SK_B1")) np1 = std::min<uint64_t>(n_leaves, std::min<uint64_t>(strtoull(e, nullptr, 10), max_b1_big));  // (tuning runs)
     while (n_leaves % np1) np1--;  // (a power of two, or 512 dividing a multiple of 512)
     if (n_leaves / np1 > max_b2) return fail(c, MC_EINVAL, "internal: %llu leaves do not fit two scatter levels", (unsigned long long)n_leaves);
@@ -1234,6 +1246,24 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
     HIPCHK(c, hipGetLastError());
     pl->sp = SpillView{P.spill_keys, P.spill_hints, P.spill_count, pl->spill_cap, P.flags};
     pl->sks = SkSpill{P.spill_recs, P.spill_count, pl->spill_cap, P.flags};
+    return MC_OK;
+}
+
+// The occurrences the merge kernels handed on (count_pipeline.h ovf_push: no room within their stretch of the region) go
+// into the table through the direct kernel, which follows the table's region chain; entries of leaves that were not
+// committed are dropped (those leaves are merged again).  Only after a launch that has been over EVERY leaf: the regions
+// behind must hold valid slots.  *n_parked (may be null): how many there were.
+static int pipe_drain_handed_on(mc_ctx *c, uint64_t n_listed)
+{
+    mc_ctx::Pipe &P = c->pipe;
+    const uint64_t n = std::min<uint64_t>(n_listed, mc_ctx::OVF_CAP);
+    if (n == 0) return MC_OK;
+    hipLaunchKernelGGL(k_add_parked, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->d_ovf, n, c->view(), c->d_ovf_leaf, P.leaf_state);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemsetAsync(c->d_ctr + 7, 0, sizeof(unsigned long long), c->stream));
+    c->solid_tracked = false;  // (these additions were not watched for crossing the coverage threshold)
+    c->solid_list_fresh = false;
+    c->st.spill_keys += n;
     return MC_OK;
 }
 
@@ -1345,7 +1375,7 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
     };
     auto launch_p3 = [&] { launch_p3_n((uint32_t)n_leaves, p3_grid, c->virgin ? 1 : 0); };
     uint32_t flags[3] = {0, 0, 0};
-    unsigned long long n_spill = 0;
+    unsigned long long n_spill = 0, n_handed_on = 0;
     const bool virgin0 = c->virgin;
     auto launch_p2 = [&] {
         static const bool staged = [] { const char *e = getenv("MC_SK2_STAGED"); return !(e && !strcmp(e, "0")); }();
@@ -1367,6 +1397,12 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
         uint64_t merged = 0, added = 0;
         for (uint64_t i = 0; i < sample_leaves; i++)
             if (st[i]) { merged++; added += nw[i]; }
+        {   // occurrences the merged leaves handed on to the next region (ovf_push) are keys too, nearly all of them new
+            unsigned long long ho = 0;
+            HIPCHK(c, hipMemcpy(&ho, c->d_ctr + 7, sizeof ho, hipMemcpyDeviceToHost));
+            added += std::min<uint64_t>(ho, mc_ctx::OVF_CAP);
+            if (ho > mc_ctx::OVF_CAP) added += (uint64_t)((double)(ho - mc_ctx::OVF_CAP));
+        }
         // (the leaves that overflowed hold more than the average: at least a full leaf each)
         const uint64_t per_full = (uint64_t)REGION_SLOTS << pl.g;
         const double est = ((double)added + (double)(sample_leaves - merged) * (double)per_full * 1.5) * ((double)n_leaves / (double)sample_leaves) * 1.1 + 1024.0;
@@ -1382,7 +1418,7 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
         int r = table_alloc(c, want);  // (fresh device memory comes zeroed by the driver at ~30 GB/s: 0.7 s for 22 GB, once)
         if (r) return r;
         c->st.grows++;
-        HIPCHK(c, hipMemsetAsync(c->d_ctr + 6, 0, sizeof(unsigned long long), c->stream));  // keys at the coverage threshold: none yet
+        HIPCHK(c, hipMemsetAsync(c->d_ctr + 6, 0, 2 * sizeof(unsigned long long), c->stream));  // keys at the coverage threshold: none yet; nothing handed on
         return 3;
     };
     if (may_rerun && virgin0 && pl.guessed && n_leaves >= 8192 && pl.b2 > 1 && !p2_done) {
@@ -1427,9 +1463,11 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(c->ev_t[3], c->stream));
         HIPCHK(c, hipMemcpyAsync(c->h_scratch + 16, P.flags, 4 * sizeof(uint32_t) + sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_scratch + 19, c->d_ctr + 7, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         memcpy(flags, c->h_scratch + 16, sizeof flags);
         n_spill = c->h_scratch[18];
+        n_handed_on = c->h_scratch[19];
         float f = 0;
         if (p1_pending) { HIPCHK(c, hipEventElapsedTime(&f, c->ev_t[0], c->ev_t[1])); ms1 = f; }
         if (pl.b2 > 1 && !p2_done) { HIPCHK(c, hipEventElapsedTime(&f, c->ev_t[1], c->ev_t[2])); ms2 += f; }
@@ -1459,8 +1497,13 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
             if (rc) return rc;
             c->virgin = false;
             HIPCHK(c, hipMemcpy(flags, P.flags, sizeof flags, hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(&n_handed_on, c->d_ctr + 7, sizeof n_handed_on, hipMemcpyDeviceToHost));
         }
         if (flags[0]) return fail(c, MC_EOVERFLOW, "internal: spill list of the partitioned counting pipeline overflowed");
+        // (every leaf has been merged or, where the hand-on list ran full, left as a valid region: the list can go in)
+        rc = pipe_drain_handed_on(c, n_handed_on);
+        if (rc) return rc;
+        n_handed_on = 0;
         if (flags[2]) emit.recs = nullptr;  // a segment of the solid list overflowed: the BFS set-up sweeps the table instead
         if (!flags[1]) break;
         if (attempt >= 6 || pl.g >= 5) {
@@ -2141,6 +2184,7 @@ int mc_create(const mc_config *cfg, mc_ctx **out)
     CREATE_CHK(hipHostMalloc(reinterpret_cast<void **>(&c->h_scratch), 32 * sizeof(unsigned long long), hipHostMallocDefault));
     c->d_fatal = reinterpret_cast<uint32_t *>(c->d_ctr + 8);  // (one copy brings the counters and the flag)
     CREATE_CHK(hipMalloc(reinterpret_cast<void **>(&c->d_ovf), mc_ctx::OVF_CAP * sizeof(uint4)));
+    CREATE_CHK(hipMalloc(reinterpret_cast<void **>(&c->d_ovf_leaf), mc_ctx::OVF_CAP * sizeof(uint32_t)));
     CREATE_CHK(hipMemsetAsync(c->d_ctr, 0, 16 * sizeof(unsigned long long), c->stream));
 
 #undef CREATE_CHK
@@ -2195,6 +2239,7 @@ void mc_destroy(mc_ctx *c)
     if (c->d_ctr) (void)hipFree(c->d_ctr);
     if (c->h_scratch) (void)hipHostFree(c->h_scratch);
     if (c->d_ovf) (void)hipFree(c->d_ovf);
+    if (c->d_ovf_leaf) (void)hipFree(c->d_ovf_leaf);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->rs_words) (void)hipFree(c->rs_words);
