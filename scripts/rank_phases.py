@@ -85,6 +85,15 @@ for rep in range(1 if args.shard else 3):
                 first, first + n, ms_ext, nr, cap * 20 / 1e9, ms, used()), flush=True)
         del send, send_b, recv, recv_b
     nd, ms_fin = t(lambda: ctx.finalize())
+    if args.shard:
+        # (the BFS table of configs[3] is a matter of its own -- 5 G solid k-mers of 8 shards on one device: DESIGN.md section 6 --
+        # and this rank's eighth of them does not fit next to its counting table and the pipeline's scratch: counting phase only)
+        st = ctx.stats()
+        n, ms_cnt = t(lambda: ctx.export_count(cov))
+        print("owners %d, %d reads: extract %.1f ms (%d records, %.1f GB sent / received) | count %.1f ms | finalize %.1f (%d distinct, %d solid) | "
+              "table %.1f GB, grows %d, handed on / spilled %d | peak device memory %.1f GB" % (
+                  W, R, ms_ext, n_rec, n_rec * 20 / 1e9, ms_add, ms_fin, nd, n, st.table_bytes / 1e9, st.grows, st.spill_keys, peak), flush=True)
+        break
     n, ms_cnt = t(lambda: ctx.export_count(cov))
     keys = torch.zeros(n, dtype=torch.int64, device=dev)
     cnts = torch.full((n,), -1, dtype=torch.int16, device=dev)
