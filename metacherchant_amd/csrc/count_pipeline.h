@@ -549,7 +549,10 @@ __device__ __forceinline__ void sk_emit(SkCursors &C, uint32_t d, const uint4 &r
 #ifndef MC_P1W_COMPACT
 #define MC_P1W_COMPACT 1   // records are built one per lane from a queue of their starts (0: every lane loops over its own starts)
 #endif
-constexpr int P1W_THREADS = 512;
+#ifndef MC_P1W_THREADS
+#define MC_P1W_THREADS 512
+#endif
+constexpr int P1W_THREADS = MC_P1W_THREADS;
 constexpr int P1W_WAVES = P1W_THREADS / 64;
 constexpr uint32_t P1W_TILE = 62 * PT_ITEMS;   // base positions per wave tile
 constexpr int P1W_SEGMENTS = 1024;             // workgroups of the launch = segments of every level-1 bucket
