@@ -135,6 +135,49 @@ struct TablePool {
 };
 static TablePool g_table_pool;
 
+// The large scratch buffers of the counting pipeline (record and key streams: gigabytes per context), kept across contexts
+// the same way: memory handed back with hipFree is reclaimed by the driver lazily and in bulk -- every third fresh context
+// of a process that counted configs[1] stalled 1.5 - 4 s in its first launch while that happened.  Blocks of 64 MB or more
+// go to this pool (DevPool's limits: best fit with at most 2x slack, 48 idle blocks); an allocation that fails for lack of
+// memory empties both pools and tries again.
+struct ScratchPool {
+    static constexpr size_t MIN_BYTES = 64ull << 20;
+    std::mutex mu;
+    std::map<int, DevPool> per_device;
+    bool on = [] { const char *e = getenv("MC_SCRATCH_POOL"); return !(e && !strcmp(e, "0")); }();
+    hipError_t get(int dev, size_t bytes, void **out, size_t *got)
+    {
+        if (!on || bytes < MIN_BYTES) { *got = bytes; return hipMalloc(out, std::max<size_t>(bytes, 1)); }
+        std::lock_guard<std::mutex> g(mu);
+        return per_device[dev].get(bytes, out, got);
+    }
+    void put(int dev, void *p, size_t bytes)
+    {
+        if (!p) return;
+        if (!on || bytes < MIN_BYTES) { (void)hipFree(p); return; }
+        std::lock_guard<std::mutex> g(mu);
+        DevPool &P = per_device[dev];
+        P.put(p, bytes);
+        for (;;) {  // at most max_idle bytes stay idle (MC_SCRATCH_POOL_GB, default 64): the largest blocks go first
+            size_t total = 0, big = 0;
+            for (size_t i = 0; i < P.idle.size(); i++) {
+                total += P.idle[i].second;
+                if (P.idle[i].second > P.idle[big].second) big = i;
+            }
+            if (total <= max_idle || P.idle.empty()) break;
+            (void)hipFree(P.idle[big].first);
+            P.idle.erase(P.idle.begin() + (long)big);
+        }
+    }
+    void release(int dev)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        per_device[dev].release();
+    }
+    size_t max_idle = [] { const char *e = getenv("MC_SCRATCH_POOL_GB"); return (size_t)((e ? atof(e) : 64.0) * 1e9); }();
+};
+static ScratchPool g_scratch_pool;
+
 // device buffers of one BFS job, kept in the context between calls
 struct BfsJobBuffers {
     BfsState S{};
@@ -250,11 +293,12 @@ struct mc_ctx {
         uint32_t *cursors1 = nullptr, *seg_counts1 = nullptr, *cursors2 = nullptr, *leaf_state = nullptr, *leaf_new = nullptr, *flags = nullptr;  // cursors1: owner cursors (multi-GPU split); cursors2: leaf fill levels; flags: [0] spill lost, [1] any leaf failed, [2] a segment of the solid list overflowed
         unsigned long long *spill_count = nullptr;
         uint64_t a_cap = 0, b_cap = 0, spill_cap = 0, tiles1_cap = 0, leaves_cap = 0, segs1_cap = 0, a_hints_cap = 0, b_hints_cap = 0, cursors2_cap = 0;
-        void release()
-        {
-            (void)hipFree(a_keys); (void)hipFree(b_keys); (void)hipFree(spill_keys);
-            (void)hipFree(a_recs); (void)hipFree(b_recs); (void)hipFree(spill_recs); (void)hipFree(solid_cursors); (void)hipFree(emit_counts);
-            (void)hipFree(a_hints); (void)hipFree(b_hints); (void)hipFree(spill_hints); (void)hipFree(tile_first);
+        void release(int dev)
+        {   // (the large streams go to g_scratch_pool: ensure_buf took them from there)
+            g_scratch_pool.put(dev, a_keys, a_cap * 8); g_scratch_pool.put(dev, b_keys, b_cap * 8); (void)hipFree(spill_keys);
+            g_scratch_pool.put(dev, a_recs, a_recs_cap * sizeof(uint4)); g_scratch_pool.put(dev, b_recs, b_recs_cap * sizeof(uint4));
+            (void)hipFree(spill_recs); (void)hipFree(solid_cursors); (void)hipFree(emit_counts);
+            g_scratch_pool.put(dev, a_hints, a_hints_cap * 4); g_scratch_pool.put(dev, b_hints, b_hints_cap * 4); (void)hipFree(spill_hints); (void)hipFree(tile_first);
             (void)hipFree(cursors1); (void)hipFree(seg_counts1); (void)hipFree(cursors2); (void)hipFree(leaf_state); (void)hipFree(leaf_new); (void)hipFree(flags);
             // (spill_count lives behind flags, in the same allocation)
             *this = Pipe{};
@@ -880,7 +924,13 @@ static int table_alloc(mc_ctx *c, uint64_t n_regions)
     {
         void *blk = nullptr;
         size_t got = 0;
-        HIPCHK(c, g_table_pool.get(c->cfg.device, c->n_slots() * sizeof(Slot), &blk, &got));
+        hipError_t e = g_table_pool.get(c->cfg.device, c->n_slots() * sizeof(Slot), &blk, &got);
+        if (e == hipErrorOutOfMemory) {  // (idle scratch blocks are given back first)
+            (void)hipGetLastError();
+            g_scratch_pool.release(c->cfg.device);
+            e = g_table_pool.get(c->cfg.device, c->n_slots() * sizeof(Slot), &blk, &got);
+        }
+        HIPCHK(c, e);
         c->slots = static_cast<Slot *>(blk);
         c->slots_bytes = got;
     }
@@ -1098,26 +1148,43 @@ static void launch_count(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_o
     }
 }
 
-template <typename T>
-static int ensure_buf(mc_ctx *c, T **p, uint64_t *cap, uint64_t need)
+// hipMalloc that gives the pools' idle blocks back to the driver before it reports "out of memory"
+static hipError_t dev_malloc(mc_ctx *c, void **p, size_t bytes)
 {
-    if (*cap >= need && *p) return MC_OK;
-    if (*p) (void)hipFree(*p);
-    *p = nullptr;
-    *cap = 0;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(p), std::max<uint64_t>(need, 1) * sizeof(T));
-    if (e == hipErrorOutOfMemory) {  // (idle table blocks are given back first)
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory) {
         (void)hipGetLastError();
         g_table_pool.release(c->cfg.device);
-        e = hipMalloc(reinterpret_cast<void **>(p), std::max<uint64_t>(need, 1) * sizeof(T));
+        g_scratch_pool.release(c->cfg.device);
+        e = hipMalloc(p, bytes);
+    }
+    return e;
+}
+
+template <typename T>
+static int ensure_buf(mc_ctx *c, T **p, uint64_t *cap, uint64_t need)
+{   // (blocks of 64 MB and more come from and go to g_scratch_pool: *cap may come out above `need`)
+    if (*cap >= need && *p) return MC_OK;
+    if (*p) g_scratch_pool.put(c->cfg.device, *p, *cap * sizeof(T));
+    *p = nullptr;
+    *cap = 0;
+    const size_t bytes = std::max<uint64_t>(need, 1) * sizeof(T);
+    size_t got = 0;
+    hipError_t e = g_scratch_pool.get(c->cfg.device, bytes, reinterpret_cast<void **>(p), &got);
+    if (e == hipErrorOutOfMemory) {  // (idle blocks are given back first)
+        (void)hipGetLastError();
+        g_table_pool.release(c->cfg.device);
+        g_scratch_pool.release(c->cfg.device);
+        e = g_scratch_pool.get(c->cfg.device, bytes, reinterpret_cast<void **>(p), &got);
     }
     if (e != hipSuccess) {
         size_t fr = 0, tot = 0;
         (void)hipMemGetInfo(&fr, &tot);
+        *p = nullptr;
         return fail(c, e == hipErrorOutOfMemory ? MC_ENOMEM : MC_EHIP, "scratch of %.2f GB: %s (%.2f of %.2f GB free on the device)",
-                    std::max<uint64_t>(need, 1) * sizeof(T) / 1e9, hipGetErrorString(e), fr / 1e9, tot / 1e9);
+                    bytes / 1e9, hipGetErrorString(e), fr / 1e9, tot / 1e9);
     }
-    *cap = need;
+    *cap = std::max<uint64_t>(need, got / sizeof(T));
     return MC_OK;
 }
 
@@ -2018,7 +2085,7 @@ static int rs_reserve(mc_ctx *c, uint64_t more_words)
     if (need <= c->rs_cap_words) return MC_OK;
     uint64_t cap = std::max<uint64_t>(c->rs_cap_words * 2, std::max<uint64_t>(need, 1ull << 20));
     uint64_t *nw = nullptr;
-    HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&nw), cap * 8));
+    HIPCHK(c, dev_malloc(c, reinterpret_cast<void **>(&nw), cap * 8));
     if (used) HIPCHK(c, hipMemcpyAsync(nw, c->rs_words, used * 8, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->rs_words) (void)hipFree(c->rs_words);
@@ -2234,7 +2301,7 @@ void mc_destroy(mc_ctx *c)
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     if (c->slots) table_release(c, c->slots, c->slots_bytes);
     if (c->solid) (void)hipFree(c->solid);
-    c->pipe.release();
+    c->pipe.release(c->cfg.device);
     c->bfs_pool.clear();
     if (c->d_ctr) (void)hipFree(c->d_ctr);
     if (c->h_scratch) (void)hipHostFree(c->h_scratch);
@@ -3565,7 +3632,7 @@ int solid_build(mc_ctx *c, uint64_t n, int min_cov, double *ms, const PairSource
     if (lg < SOLID_SB + 1) lg = SOLID_SB + 1;
     if (!c->solid || lg != c->solid_lg) {
         if (c->solid) { (void)hipFree(c->solid); c->solid = nullptr; }
-        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->solid), sizeof(Slot) << lg));
+        HIPCHK(c, dev_malloc(c, reinterpret_cast<void **>(&c->solid), sizeof(Slot) << lg));
         c->solid_lg = lg;
     }
     // counting table organised by minimizer bins, or entries from outside: the solid entries are partitioned by
