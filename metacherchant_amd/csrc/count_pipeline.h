@@ -22,6 +22,7 @@
 // Results are identical to the direct kernel: same slot placement rule (home slot from the hash,
 // linear probing inside the region), saturation as in kmer_device.h.
 #pragma once
+#include <utility>
 #include "kmer_device.h"
 
 namespace mc {
@@ -584,12 +585,20 @@ __device__ __forceinline__ uint64_t p1w_bits(uint64_t W0, uint64_t W1, uint64_t 
     return (a << sh) | ((b >> 1) >> (63 - sh));
 }
 
-template <bool OWNERS>
+// COMPACT: a record leaves as ONE 16-byte unit whose first word holds, instead of the bin word, what the second level needs of
+// it -- the leaf inside the level-1 bucket (10 bits, `m2` leaves per bucket) -- and the position of its first window RELATIVE to
+// the first base of the workgroup's tiles (22 bits): a workgroup then takes `chunk_tiles` CONSECUTIVE tiles (chunk_tiles x
+// P1W_TILE <= 2^22), and the reader (k_sk2_scatter_compact) knows the segment = workgroup of every record.  out_ptrs is not
+// written.  The 16-byte and 4-byte stores of the two-array form reach HBM as two partly filled sectors per record (the lines
+// of 512 buckets x 1024 segments do not live in the L2 until they are full): 9.2 GB written for 2.7 GB on configs[1].
+constexpr uint32_t SKC_REL_BITS = 22;
+template <bool OWNERS, bool COMPACT = false>
 __global__ void __launch_bounds__(P1W_THREADS, MC_P1W_MIN_WAVES) k_sk1w_extract(
     const uint64_t *__restrict__ words, const uint64_t *__restrict__ offsets, uint64_t n_reads, uint64_t base_lo,
     uint64_t n_bases, uint64_t n_tiles, const uint32_t *__restrict__ first_read, int k, uint32_t np1, uint32_t *seg_counts,
-    uint64_t cap, uint4 *out_recs, uint32_t *out_ptrs, SkSpill sp, uint64_t ptr_base)
+    uint64_t cap, uint4 *out_recs, uint32_t *out_ptrs, SkSpill sp, uint64_t ptr_base, uint32_t chunk_tiles = 0, uint32_t m2 = 0)
 {
+    static_assert(!(OWNERS && COMPACT), "the compact form is for the single-GPU pipeline");
     __shared__ Sk1wLds L;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     for (uint32_t i = tid; i < PT_MAX_BUCKETS1_SK; i += P1W_THREADS) L.wcur[i] = 0;
@@ -626,9 +635,13 @@ __global__ void __launch_bounds__(P1W_THREADS, MC_P1W_MIN_WAVES) k_sk1w_extract(
         const uint64_t r = (uint64_t)pf_first + lane;
         pf_off = r < n_reads ? offsets[r] : ~0ull;
     };
-    const uint64_t tile0 = base_lo / P1W_TILE + wave_id;
+    // tiles of this wave: every n_waves-th of the launch, or (COMPACT) every P1W_WAVES-th of the workgroup's own stretch
+    const uint64_t chunk_lo = base_lo / P1W_TILE + (uint64_t)blockIdx.x * chunk_tiles;
+    const uint64_t tile_end = COMPACT ? min(n_tiles, chunk_lo + chunk_tiles) : n_tiles;
+    const uint64_t tile0 = COMPACT ? chunk_lo + wv : base_lo / P1W_TILE + wave_id;
+    const uint64_t tile_step = COMPACT ? (uint64_t)P1W_WAVES : n_waves;
     prefetch(tile0);
-    for (uint64_t tile = tile0; tile < n_tiles; tile += n_waves) {
+    for (uint64_t tile = tile0; tile < tile_end; tile += tile_step) {
         const uint64_t lo = tile * (uint64_t)P1W_TILE;
         const int64_t bm_lo = (int64_t)lo - 64;
         const uint64_t bm_hi = lo + 640;
@@ -636,7 +649,7 @@ __global__ void __launch_bounds__(P1W_THREADS, MC_P1W_MIN_WAVES) k_sk1w_extract(
         const uint64_t W0 = pfW0, W1 = pfW1, W2 = pfW2;
         uint64_t s = pf_off;
         const uint32_t my_first = pf_first;
-        prefetch(tile + n_waves);
+        prefetch(tile + tile_step);
         const uint64_t p0 = lo + (uint64_t)lane * PT_ITEMS;
         const uint32_t off0 = (uint32_t)((int64_t)p0 - 32 * (((int64_t)p0 - 7) >> 5));  // base p0 inside W0:W1:W2 (8, 16, 24 or 32)
 
@@ -795,8 +808,14 @@ __global__ void __launch_bounds__(P1W_THREADS, MC_P1W_MIN_WAVES) k_sk1w_extract(
                 const uint64_t dst = atomicAdd(&L.wcur[d], 1u);
                 if (dst < cap) {
                     const uint64_t o = seg_base + (uint64_t)d * bucket_stride + dst;
-                    out_recs[o] = rec;
-                    out_ptrs[o] = ptr_base == ~0ull ? 0u : ptr_encode(ptr_base + lo + wi);
+                    if (COMPACT) {
+                        const uint32_t rel = (uint32_t)(tile - chunk_lo) * P1W_TILE + wi;
+                        rec.x = rel | ((mulhi32(bin, np1 * m2) - d * m2) << SKC_REL_BITS);
+                        out_recs[o] = rec;
+                    } else {
+                        out_recs[o] = rec;
+                        out_ptrs[o] = ptr_base == ~0ull ? 0u : ptr_encode(ptr_base + lo + wi);
+                    }
                 } else {
                     sk_spill_push(sp, rec);
                 }
@@ -827,8 +846,14 @@ __global__ void __launch_bounds__(P1W_THREADS, MC_P1W_MIN_WAVES) k_sk1w_extract(
             const uint64_t dst = atomicAdd(&L.wcur[d], 1u);
             if (dst < cap) {
                 const uint64_t at = seg_base + (uint64_t)d * bucket_stride + dst;
-                out_recs[at] = rec;
-                out_ptrs[at] = ptr_base == ~0ull ? 0u : ptr_encode(ptr_base + p0 + j);
+                if (COMPACT) {
+                    const uint32_t rel = (uint32_t)(tile - chunk_lo) * P1W_TILE + lane * PT_ITEMS + j;
+                    rec.x = rel | ((mulhi32(bin, np1 * m2) - d * m2) << SKC_REL_BITS);
+                    out_recs[at] = rec;
+                } else {
+                    out_recs[at] = rec;
+                    out_ptrs[at] = ptr_base == ~0ull ? 0u : ptr_encode(ptr_base + p0 + j);
+                }
             } else {
                 sk_spill_push(sp, rec);
             }
@@ -888,7 +913,7 @@ __global__ void __launch_bounds__(256) k_sk_pack(const uint4 *__restrict__ recs,
 // its probe sequence longer than 64 slots is counted as new.
 __global__ void __launch_bounds__(256) k_sk_sample_distinct(const uint4 *__restrict__ recs, const uint32_t *__restrict__ seg_counts, uint64_t seg_cap, int k,
                                                             uint64_t *set, uint64_t mask, unsigned long long *n_distinct)
-{
+{   // (the records' first word -- bin word or the compact form's -- is not looked at)
     const uint32_t n = min(seg_counts[blockIdx.x], (uint32_t)seg_cap);
     const uint4 *seg = recs + (uint64_t)blockIdx.x * seg_cap;
     unsigned long long n_new = 0;
@@ -1032,6 +1057,13 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk2_scatter(const uint4 *__restr
     }
 }
 
+// 16 bytes as a native vector: copies of a HIP uint4 whose fields are then touched one by one go through a 12-byte memcpy into
+// a private slot that ends up in LDS (48 KB of the staged scatter kernels' LDS were that); these stay in registers
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4u ld_v4u(const uint4 *p) { return *reinterpret_cast<const v4u *>(p); }
+__device__ __forceinline__ void st_v4u(uint4 *p, v4u v) { *reinterpret_cast<v4u *>(p) = v; }
+__device__ __forceinline__ uint4 as_uint4(v4u v) { return make_uint4(v.x, v.y, v.z, v.w); }
+
 // SK-P2 with the tile's records put in leaf order in LDS before they go out: a tile of 1024 x ITEMS records holds only
 // a handful per leaf, and written one by one as they come (k_sk2_scatter) every 16-byte record and 4-byte pointer
 // dirties a memory line of its own at a time of its own -- 7.0 GB reached HBM for 2.7 GB of records.  Here the records
@@ -1099,7 +1131,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk2_scatter_staged(const uint4 *
                 L.tile_seg = lo_s;
             }
             __syncthreads();
-            uint4 rec[ITEMS];
+            v4u rec[ITEMS];
             uint32_t ptr[ITEMS], d[ITEMS], rank[ITEMS];
             bool have[ITEMS];
             uint32_t sg = L.tile_seg;
@@ -1110,7 +1142,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk2_scatter_staged(const uint4 *
                 if (have[j]) {
                     while (e >= L.seg_prefix[sg + 1]) sg++;
                     const uint64_t at = ((uint64_t)bucket * nseg_in + sg) * seg_cap1 + (e - L.seg_prefix[sg]);
-                    rec[j] = in_recs[at];
+                    rec[j] = ld_v4u(&in_recs[at]);
                     ptr[j] = in_ptrs[at];
                 }
             }
@@ -1131,7 +1163,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk2_scatter_staged(const uint4 *
             for (int j = 0; j < ITEMS; j++)
                 if (have[j]) {
                     const uint32_t at = L.off[d[j]] + rank[j];
-                    L.rec[at] = rec[j];
+                    st_v4u(&L.rec[at], rec[j]);
                     L.ptr[at] = ptr[j];
                     L.leaf[at] = (uint16_t)d[j];
                 }
@@ -1142,11 +1174,139 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk2_scatter_staged(const uint4 *
                 const uint64_t dst = (uint64_t)L.wcur[dd] + (i - L.off[dd]);
                 if (dst < cap2) {
                     const uint64_t at = ((uint64_t)bucket * m2 + dd) * cap2 + dst;
-                    out_recs[at] = L.rec[i];
+                    st_v4u(&out_recs[at], ld_v4u(&L.rec[i]));
                     out_ptrs[at] = L.ptr[i];
                 } else {
                     sk_spill_push(sp, L.rec[i]);
                 }
+            }
+            __syncthreads();
+            if (tid < m2) { L.wcur[tid] += L.cnt[tid]; L.cnt[tid] = 0; }
+        }
+        __syncthreads();
+        if (tid < m2) leaf_counts[(uint64_t)bucket * m2 + tid] = min(L.wcur[tid], (uint32_t)cap2);
+    }
+}
+
+// SK-P2 for k_sk1w_extract's COMPACT records (first word = position relative to the segment's first base | leaf in the bucket
+// << 22): the same staging as k_sk2_scatter_staged, and what leaves is again ONE 16-byte unit per record -- first word = the
+// read pointer of the record's first window, which only now, with the segment known, becomes absolute.  No pointer array on
+// either side: 16 bytes in and 16 out per record against 20 and 20, and the staging area (72 KB) leaves room for two
+// workgroups on a CU.  pos0 = position of segment 0's first base, seg_bases = bases per segment (chunk_tiles x P1W_TILE).
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): per-thread arrays indexed only by these stay in registers (a
+// `#pragma unroll` loop with a data-dependent inner loop left them in scratch / LDS: 48 KB of the staged kernel's LDS were that)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+#ifndef MC_SK2C_ITEMS
+#define MC_SK2C_ITEMS 3   // records per thread and tile of k_sk2_scatter_compact: 3 = 72 KB of LDS and 64 registers, two workgroups on a CU (configs[1]: 1.61 ms; 4: 1.88, 5: 1.81)
+#endif
+template <int ITEMS>
+struct Sk2cLds {
+    uint4 rec[PT_THREADS * ITEMS];
+    uint16_t leaf[PT_THREADS * ITEMS];
+    uint32_t cnt[PT_MAX_LEAVES2], wcur[PT_MAX_LEAVES2], off[PT_MAX_LEAVES2];
+    uint32_t seg_prefix[P1W_SEGMENTS + 1];
+    uint32_t wave_tot[PT_THREADS / 64];
+    uint32_t tile_seg;
+};
+template <int ITEMS>
+__global__ void __launch_bounds__(PT_THREADS, ITEMS <= 3 ? 8 : 4) k_sk2_scatter_compact(const uint4 *__restrict__ in_recs, uint64_t seg_cap1,
+                                                                       const uint32_t *__restrict__ seg_counts1, uint32_t n_buckets1, uint32_t m2,
+                                                                       uint32_t *leaf_counts, uint64_t cap2, uint4 *out_recs, SkSpill sp,
+                                                                       uint32_t nseg_in, uint64_t ptr_base, uint64_t pos0, uint64_t seg_bases)
+{
+    __shared__ Sk2cLds<ITEMS> L;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    constexpr uint32_t TILE = PT_THREADS * ITEMS;
+    auto block_excl = [&](uint32_t c, uint32_t *total) -> uint32_t {  // exclusive scan of one value per thread
+        uint32_t x = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o);
+            if ((int)lane >= o) x += y;
+        }
+        __syncthreads();  // (wave_tot may still be read from the scan before)
+        if (lane == 63u) L.wave_tot[wv] = x;
+        __syncthreads();
+        uint32_t before = 0, tot = 0;
+        for (uint32_t i = 0; i < PT_THREADS / 64; i++) {
+            const uint32_t t = L.wave_tot[i];
+            if (i < wv) before += t;
+            tot += t;
+        }
+        *total = tot;
+        return before + x - c;
+    };
+    for (uint32_t bucket = blockIdx.x; bucket < n_buckets1; bucket += gridDim.x) {
+        __syncthreads();
+        if (tid < PT_MAX_LEAVES2) { L.wcur[tid] = 0; L.cnt[tid] = 0; }
+        uint32_t total;
+        {
+            const uint32_t c = tid < nseg_in ? seg_counts1[(uint64_t)bucket * nseg_in + tid] : 0u;
+            const uint32_t ex = block_excl(c, &total);
+            if (tid < nseg_in) L.seg_prefix[tid] = ex;
+            if (tid == 0) L.seg_prefix[nseg_in] = total;
+        }
+        __syncthreads();
+        for (uint32_t first = 0; first < total; first += TILE) {
+            if (tid == 0) {  // segment of the tile's first record: largest sg with seg_prefix[sg] <= first
+                uint32_t lo_s = 0, hi_s = nseg_in;
+                while (hi_s - lo_s > 1) {
+                    const uint32_t mid = (lo_s + hi_s) >> 1;
+                    if (L.seg_prefix[mid] <= first) lo_s = mid; else hi_s = mid;
+                }
+                L.tile_seg = lo_s;
+            }
+            __syncthreads();
+            v4u rec[ITEMS];
+            uint32_t d[ITEMS], rank[ITEMS], seg_of[ITEMS];
+            bool have[ITEMS];
+            uint32_t sg = L.tile_seg;
+            static_for<ITEMS>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                const uint32_t e = first + (uint32_t)j * PT_THREADS + tid;
+                have[j] = e < total;
+                if (have[j]) {
+                    while (e >= L.seg_prefix[sg + 1]) sg++;
+                    rec[j] = ld_v4u(&in_recs[((uint64_t)bucket * nseg_in + sg) * seg_cap1 + (e - L.seg_prefix[sg])]);
+                    seg_of[j] = sg;
+                }
+            });
+            static_for<ITEMS>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                if (have[j]) {
+                    d[j] = rec[j].x >> SKC_REL_BITS;
+                    rank[j] = atomicAdd(&L.cnt[d[j]], 1u);
+                    const uint64_t pos = pos0 + (uint64_t)seg_of[j] * seg_bases + (rec[j].x & ((1u << SKC_REL_BITS) - 1u));
+                    rec[j].x = ptr_base == ~0ull ? 0u : ptr_encode(ptr_base + pos);
+                }
+            });
+            __syncthreads();
+            {   // where each leaf's run starts in the staging area
+                uint32_t tot;
+                const uint32_t ex = block_excl(tid < m2 ? L.cnt[tid] : 0u, &tot);
+                if (tid < m2) L.off[tid] = ex;
+            }
+            __syncthreads();
+            static_for<ITEMS>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                if (have[j]) {
+                    const uint32_t at = L.off[d[j]] + rank[j];
+                    st_v4u(&L.rec[at], rec[j]);
+                    L.leaf[at] = (uint16_t)d[j];
+                }
+            });
+            __syncthreads();
+            const uint32_t n_tile = min(TILE, total - first);
+            for (uint32_t i = tid; i < n_tile; i += PT_THREADS) {
+                const uint32_t dd = L.leaf[i];
+                const uint64_t dst = (uint64_t)L.wcur[dd] + (i - L.off[dd]);
+                const v4u r = ld_v4u(&L.rec[i]);
+                if (dst < cap2) st_v4u(&out_recs[((uint64_t)bucket * m2 + dd) * cap2 + dst], r);
+                else sk_spill_push(sp, as_uint4(r));  // (the spill list's records go in without pointers and their first word is not looked at)
             }
             __syncthreads();
             if (tid < m2) { L.wcur[tid] += L.cnt[tid]; L.cnt[tid] = 0; }
@@ -1193,7 +1353,7 @@ __global__ void k_sk_add_unmerged(const uint4 *__restrict__ leaf_recs, const uin
             const uint32_t *ptrs = leaf_ptrs + ((uint64_t)leaf * nseg + sgm) * seg_cap;
             for (uint64_t r = threadIdx.x; r < n; r += blockDim.x) {
                 const uint4 rec = recs[r];
-                const uint32_t p0 = ptrs[r];
+                const uint32_t p0 = leaf_ptrs ? ptrs[r] : rec.x;  // (no array: the record's first word, k_sk2_scatter_compact)
                 const uint64_t lo = ((uint64_t)rec.y << 32) | rec.x, hi = ((uint64_t)rec.w << 32) | rec.z;
                 for (uint32_t j = 0; j < sk_windows(hi); j++) n_new += table_add(t, sk_window_key(lo, hi, j, k), 1u, ptr_advance(p0, j));
             }
@@ -1360,7 +1520,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
             const uint32_t per = (n0 + N_WAVES - 1) / N_WAVES, r = wv * per + lane, end = (wv + 1) * per < n0 ? (wv + 1) * per : n0;
             if (r < end) {
                 pre_nxt = static_cast<const uint4 *>(leaf_keys)[(uint64_t)lf * nseg * seg_cap + r];
-                pre_bin_nxt = leaf_hints[(uint64_t)lf * nseg * seg_cap + r];  // (the record's read pointer)
+                pre_bin_nxt = leaf_hints ? leaf_hints[(uint64_t)lf * nseg * seg_cap + r] : pre_nxt.x;  // (the record's read pointer; no array: the record's first word, k_sk2_scatter_compact)
             }
         }
     };
@@ -1423,7 +1583,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                     // by ds_bpermute, and is cut out of the record directly (no rolling state).  The next batch's
                     // records are in flight meanwhile.
                     const uint4 *recs = static_cast<const uint4 *>(leaf_keys) + ((uint64_t)leaf * nseg + sgm) * seg_cap;
-                    const uint32_t *ptrs = leaf_hints + ((uint64_t)leaf * nseg + sgm) * seg_cap;
+                    const uint32_t *ptrs = leaf_hints ? leaf_hints + ((uint64_t)leaf * nseg + sgm) * seg_cap : nullptr;
                     const uint32_t ptr_from = solid_thr >= 2 ? 1u : 0u, ptr_last = ptr_from + (MC_PTR_LATE ? 19 : 3) + ptr_tries - 1;
                     uint8_t *dq = L.dq[wv];
                     uint32_t *sq = L.sq[wv];
@@ -1431,7 +1591,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                     // waits for the slowest wave
                     const uint32_t per = (n + N_WAVES - 1) / N_WAVES, r_lo = wv * per, r_hi = r_lo + per < n ? r_lo + per : n;
                     uint4 nxt = sgm == 0 ? pre : (r_lo + lane < r_hi ? recs[r_lo + lane] : make_uint4(0, 0, 0, 0));
-                    uint32_t nxt_ptr = sgm == 0 ? pre_bin : (r_lo + lane < r_hi ? ptrs[r_lo + lane] : 0u);
+                    uint32_t nxt_ptr = sgm == 0 ? pre_bin : (r_lo + lane < r_hi ? (ptrs ? ptrs[r_lo + lane] : nxt.x) : 0u);
                     for (uint32_t b0 = r_lo; b0 < r_hi; b0 += 64) {  // wave-uniform
                         if (L.overflow) break;  // (the leaf will not be committed: no point in merging the rest of it)
                         const uint32_t r = b0 + lane;
@@ -1439,9 +1599,12 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
                         const uint32_t rptr = nxt_ptr;
                         if (r + 64 < r_hi) {
                             nxt = recs[r + 64];
-                            nxt_ptr = ptrs[r + 64];
+                            nxt_ptr = ptrs ? ptrs[r + 64] : nxt.x;
                         }
-                        const bool mine = r < r_hi && !(g && mulhi32(rec.x, t.n_regions) != region);
+                        // (g != 0 with compact records -- the table grew under a run that had planned one region per leaf: the
+                        // bin word is worked out again from the record's first window)
+                        const bool mine = r < r_hi && !(g && mulhi32(ptrs ? rec.x : bin32_of(sk_window_key(((uint64_t)rec.y << 32) | rec.x, ((uint64_t)rec.w << 32) | rec.z, 0, k), k),
+                                                                     t.n_regions) != region);
                         const uint32_t nw = mine ? sk_windows(((uint64_t)rec.w << 32) | rec.z) : 0u;
                         uint32_t incl = nw;  // inclusive scan of the window counts
 #pragma unroll
@@ -1740,7 +1903,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_dedup(const uint4 *__restrict
             const uint32_t r = tid + (uint32_t)q * P3_THREADS;
             if (r < n) {
                 pre_rec[q] = leaf_recs[(uint64_t)lf * seg_cap + r];
-                pre_ptr[q] = leaf_ptrs[(uint64_t)lf * seg_cap + r];
+                pre_ptr[q] = leaf_ptrs ? leaf_ptrs[(uint64_t)lf * seg_cap + r] : pre_rec[q].x;  // (no array: the record's first word, k_sk2_scatter_compact)
             }
         }
     };
@@ -1794,7 +1957,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_dedup(const uint4 *__restrict
                 sl[q] = DD_NONE;
                 hh[q] = 0;
                 if (base == 0) { rec[q] = cur_rec[q]; rptr[q] = cur_ptr[q]; }
-                else if (have[q]) { rec[q] = recs[r]; rptr[q] = ptrs[r]; }
+                else if (have[q]) { rec[q] = recs[r]; rptr[q] = leaf_ptrs ? ptrs[r] : rec[q].x; }
                 else { rec[q] = make_uint4(0, 0, 0, 0); rptr[q] = 0; }
                 if (have[q]) {
                     const uint32_t h = dd_hash(rec[q].y, rec[q].z, rec[q].w), tag = (h & 0xFFFF0000u) | 0x8000u;

@@ -1194,6 +1194,11 @@ struct PipePlan {
     uint32_t nseg1 = PT_SEGMENTS;  // segments of every level-1 bucket = workgroups of the level-1 kernel
     uint32_t pieces = 1;           // the reads go through P1 / P2 in this many pieces (cap1, cap2: per piece); P3 sees `pieces` segments per leaf
     bool sk = false;  // the streams hold super-k-mer records; capacities are in records
+    // compact: the streams hold 16-byte units and no pointer arrays (count_pipeline.h k_sk1w_extract<false, true>, k_sk2_scatter_compact):
+    // every level-1 segment = workgroup took chunk_tiles consecutive tiles, the first of them at base position pos0
+    bool compact = false;
+    uint32_t chunk_tiles = 0;
+    uint64_t pos0 = 0;
     bool guessed = false;  // no capacity hint vouches for the table's size: pipe_finish merges a sample of the leaves first
     SpillView sp{};
     SkSpill sks{};
@@ -1222,8 +1227,10 @@ __global__ void __launch_bounds__(256) k_pipe_reset(uint32_t *seg_counts1, uint6
 // Table capacity check, scratch buffers and cursors for one run of the partitioned pipeline over
 // `wb` key occurrences.  n_records != 0: they travel as (an estimated) n_records super-k-mer records.
 static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records = 0, uint32_t nseg1 = PT_SEGMENTS, uint32_t pieces = 1,
-                        bool level2_only = false)
-{   // level2_only: the level-1 scatter has run and the table has since been replaced by one of another size (pipe_resize_by_sample):
+                        bool level2_only = false, uint64_t compact_tiles = 0)
+{   // compact_tiles != 0: the caller's level-1 kernel is k_sk1w_extract over this many tiles in one piece and can write the compact
+    // form: taken up when the rest of the run allows it (a second level through the staged kernel, one region per leaf, segments
+    // short enough for 22-bit positions)   // level2_only: the level-1 scatter has run and the table has since been replaced by one of another size (pipe_resize_by_sample):
     // the plan of the second level and of the merge is made again for it; level 1 (buckets, segments, their fill levels, the
     // spill list) stays as it is -- the caller has checked that the new table splits into the same level-1 buckets
     pl->nseg1 = nseg1;
@@ -1276,6 +1283,17 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
     pl->n_leaves = n_leaves;
     pl->sk = n_records != 0;
     if (pl->b2 <= 1) pl->pieces = pieces = 1;  // (no second level to overlap with)
+    if (!level2_only) {
+        const char *ce = getenv("MC_SK_COMPACT");  // (read on every run: the tests switch it)
+        const bool compact_on = !(ce && !strcmp(ce, "0"));
+        static const bool staged = [] { const char *e = getenv("MC_SK2_STAGED"); return !(e && !strcmp(e, "0")); }();
+        const uint64_t chunk = (compact_tiles + nseg1 - 1) / std::max<uint32_t>(nseg1, 1);
+        // (not where pipe_resize_by_sample may replace the table between the two levels: the leaf numbers inside the records
+        // are those of the table the first level saw)
+        pl->compact = compact_tiles && compact_on && staged && pl->sk && pl->b2 > 1 && pl->b2 <= (1u << (32 - SKC_REL_BITS)) && g == 0 && pieces == 1 &&
+                      chunk * P1W_TILE <= (1ull << SKC_REL_BITS) && !(pl->guessed && c->virgin);
+        pl->chunk_tiles = pl->compact ? (uint32_t)chunk : 0;
+    }
     const uint64_t units = (pl->sk ? n_records : wb) / pieces + (pieces > 1 ? 1024 : 0);  // records in the streams (of one piece)
     pl->cap1 = (uint64_t)((double)units / (double)pl->np1 / (double)nseg1 * 1.25) + (pl->sk ? 64 : 256);  // per segment
     const double mean_leaf = (double)units / (double)pl->n_leaves;
@@ -1297,8 +1315,10 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
         { uint64_t cap = P.b_cap; ENSURE(P.b_keys, cap, n_leaves * pl->cap2 * pieces); P.b_cap = cap; }
         { uint64_t cap = P.spill_cap; ENSURE(P.spill_keys, cap, pl->spill_cap); dummy = P.spill_cap; ENSURE(P.spill_hints, dummy, pl->spill_cap); P.spill_cap = cap; }
     }
-    if (!level2_only) ENSURE(P.a_hints, P.a_hints_cap, np1 * nseg1 * pl->cap1 * pieces);
-    ENSURE(P.b_hints, P.b_hints_cap, n_leaves * pl->cap2 * pieces);
+    if (!pl->compact) {  // (the compact form keeps the read pointers inside the records)
+        if (!level2_only) ENSURE(P.a_hints, P.a_hints_cap, np1 * nseg1 * pl->cap1 * pieces);
+        ENSURE(P.b_hints, P.b_hints_cap, n_leaves * pl->cap2 * pieces);
+    }
     if (!level2_only) ENSURE(P.seg_counts1, P.segs1_cap, np1 * nseg1 * pieces);
     ENSURE(P.cursors2, P.cursors2_cap, n_leaves * pieces);
     { uint64_t cap = P.leaves_cap; ENSURE(P.leaf_state, cap, n_leaves); dummy = P.leaves_cap; ENSURE(P.leaf_new, dummy, n_leaves); P.leaves_cap = cap; }
@@ -1402,7 +1422,7 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
     // P3 reads the leaves: P2's output (one segment each), or P1's buckets directly when there is no second level
     const void *lk = pl.sk ? (pl.b2 > 1 ? (const void *)P.b_recs : (const void *)P.a_recs)
                            : (pl.b2 > 1 ? (const void *)P.b_keys : (const void *)P.a_keys);
-    const uint32_t *lh = pl.b2 > 1 ? P.b_hints : P.a_hints;
+    const uint32_t *lh = pl.compact ? nullptr : (pl.b2 > 1 ? P.b_hints : P.a_hints);  // (compact: the pointers sit in the records)
     const uint32_t *lc = pl.b2 > 1 ? P.cursors2 : P.seg_counts1;
     const uint64_t lcap = pl.b2 > 1 ? pl.cap2 : pl.cap1;
     const uint32_t lseg = pl.b2 > 1 ? pl.pieces : pl.nseg1;
@@ -1446,7 +1466,11 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
     const bool virgin0 = c->virgin;
     auto launch_p2 = [&] {
         static const bool staged = [] { const char *e = getenv("MC_SK2_STAGED"); return !(e && !strcmp(e, "0")); }();
-        if (pl.sk && staged && pl.pieces == 1)
+        if (pl.sk && pl.compact)
+            hipLaunchKernelGGL(k_sk2_scatter_compact<MC_SK2C_ITEMS>, dim3((unsigned)np1), dim3(PT_THREADS), 0, c->stream, P.a_recs, pl.cap1,
+                               P.seg_counts1, (uint32_t)np1, pl.b2, P.cursors2, pl.cap2, P.b_recs, pl.sks, pl.nseg1, c->cur_ptr_base, pl.pos0,
+                               (uint64_t)pl.chunk_tiles * P1W_TILE);
+        else if (pl.sk && staged && pl.pieces == 1)
             hipLaunchKernelGGL(k_sk2_scatter_staged<MC_SK2_ITEMS>, dim3((unsigned)np1), dim3(PT_THREADS), 0, c->stream, P.a_recs, P.a_hints, pl.cap1,
                                P.seg_counts1, (uint32_t)np1, pl.b1, pl.b2, P.cursors2, pl.cap2, P.b_recs, P.b_hints, pl.sks, pl.nseg1);
         else if (pl.sk)
@@ -1738,7 +1762,8 @@ static int add_reads_partitioned_once(mc_ctx *c, const uint64_t *d_words, const 
     // the same scratch and the whole table is rewritten half as often (max_run_bases).
     // (only where the memory is needed: at 0.9 G windows two pieces cost 55 ms against 35 ms in one)
     if (!n_records) pieces = wb < (3ull << 29) ? 1u : (uint32_t)std::min<uint64_t>(8, (wb + (1ull << 30) - 1) >> 30);
-    int rc = pipe_prepare(c, wb, &pl, n_records, n_records ? (uint32_t)P1W_SEGMENTS : (uint32_t)PT_SEGMENTS, pieces);
+    int rc = pipe_prepare(c, wb, &pl, n_records, n_records ? (uint32_t)P1W_SEGMENTS : (uint32_t)PT_SEGMENTS, pieces, false,
+                          n_records != 0 && pieces == 1 ? (end_abs + P1W_TILE - 1) / P1W_TILE - base0 / P1W_TILE : 0);
     if (rc) return rc;
     pieces = pl.pieces;
     const uint64_t *offs = d_off + r0;
@@ -1795,7 +1820,16 @@ static int add_reads_partitioned_once(mc_ctx *c, const uint64_t *d_words, const 
     } else {
         HIPCHK(c, hipEventRecord(c->ev_t[0], c->stream));  // (no wait here: pipe_finish enqueues P2 and P3 right behind)
         launch_tile_first(c, offs, nr, n_tiles_abs, P.tile_first, tile_size);
-        if (pl.sk)
+        if (pl.sk && pl.compact) {
+            pl.pos0 = base0 / P1W_TILE * P1W_TILE;
+            if (getenv("MC_INGEST_DEBUG"))
+                fprintf(stderr, "[count] compact records: %u buckets x %u leaves, %u tiles a segment from base %llu\n", pl.b1, pl.b2, pl.chunk_tiles,
+                        (unsigned long long)pl.pos0);
+            hipLaunchKernelGGL((k_sk1w_extract<false, true>), dim3(P1W_SEGMENTS), dim3(P1W_THREADS), 0, c->stream, d_words, offs, nr, base0, end_abs,
+                               n_tiles_abs, P.tile_first, c->cfg.k, pl.b1, P.seg_counts1, pl.cap1, P.a_recs, nullptr, pl.sks, c->cur_ptr_base,
+                               pl.chunk_tiles, pl.b2);
+        }
+        else if (pl.sk)
             hipLaunchKernelGGL(k_sk1w_extract<false>, dim3(P1W_SEGMENTS), dim3(P1W_THREADS), 0, c->stream, d_words, offs, nr, base0, end_abs,
                                n_tiles_abs, P.tile_first, c->cfg.k, pl.b1, P.seg_counts1, pl.cap1, P.a_recs, P.a_hints, pl.sks, c->cur_ptr_base);
         else
@@ -3652,7 +3686,7 @@ int solid_build(mc_ctx *c, uint64_t n, int min_cov, double *ms, const PairSource
         // The solid list sits in a_recs: the level-1 buckets then go to b_recs and the leaves, once the list has been
         // read, to a_recs -- which must not be reallocated for it (and a one-level build would have to read and
         // write a_recs at once): otherwise the table is swept as usual.
-        if (from_list && (!sb2 || need2 > P.a_recs_cap || need2 > P.a_hints_cap)) from_list = false;
+        if (from_list && (!sb2 || need2 > P.a_recs_cap)) from_list = false;  // (a_hints holds nothing of the list: it may grow, or come to be here -- compact runs do without it)
         uint4 **l1_recs = from_list ? &P.b_recs : &P.a_recs, **l2_recs = from_list ? &P.a_recs : &P.b_recs;
         uint32_t **l1_bins = from_list ? &P.b_hints : &P.a_hints, **l2_bins = from_list ? &P.a_hints : &P.b_hints;
         uint64_t *l1_recs_cap = from_list ? &P.b_recs_cap : &P.a_recs_cap, *l2_recs_cap = from_list ? &P.a_recs_cap : &P.b_recs_cap;

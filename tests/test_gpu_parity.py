@@ -259,6 +259,39 @@ def test_coverage_hint_tracks_solid_count_over_batches(mc, monkeypatch):
     ctx.close()
 
 
+def test_compact_records_of_the_counting_pipeline(mc, monkeypatch, capfd):
+    """Reads into a table whose size is vouched for (capacity hint) travel through the two scatter levels as 16-byte units
+    that carry the leaf number and, in place of a pointer array, the RELATIVE position of their first window
+    (count_pipeline.h k_sk1w_extract<false, true>, k_sk2_scatter_compact).  Same (key, count) pairs as the oracle and as the
+    two-array form, over two batches (the second one starts in the middle of a tile of the read store), and the read
+    pointers made the trip: the walk needs few round trips."""
+    monkeypatch.delenv("MC_COUNT_PATH", raising=False)
+    monkeypatch.setenv("MC_INGEST_DEBUG", "1")
+    genome, reads, off = synth_case(2, 200000, 80000, 150, 50)
+    t, _ = oracle_table(reads, off, 31, po.KEY_PACKED)
+    ok, oc = t.dump()
+    seed = genome[10000:10500]
+    hi, lo = seed_windows(seed, 31)
+    want = po.bfs(t, 31, po.KEY_PACKED, [seed], 1, 5, 3000, -1)
+    cut = 40001
+    for compact in ("1", "0"):
+        monkeypatch.setenv("MC_SK_COMPACT", compact)
+        capfd.readouterr()
+        ctx = mc.Context(31, mc.KEY_PACKED, 0, 3_000_000)  # ~3000 regions: two scatter levels
+        ctx.set_coverage_hint(5)
+        ctx.add_reads_packed(po.pack(reads[:off[cut]]), off[:cut + 1])
+        ctx.add_reads_packed(po.pack(reads[off[cut]:]), off[cut:] - off[cut])
+        assert ctx.finalize() == t.size()
+        err = capfd.readouterr().err
+        assert (err.count("[count] compact records") == 2) == (compact == "1"), err
+        gk, gc = ctx.export(1)
+        assert np.array_equal(gk, ok) and np.array_equal(gc, oc)
+        got = ctx.bfs(hi, lo, 1, 5, 3000, -1)
+        assert_bfs_equal(got, want)
+        assert got["rounds"] * 4 < got["levels"]
+        ctx.close()
+
+
 def test_solid_list_from_the_merge_kernel(mc, monkeypatch):
     """With the threshold known while counting, the merge kernel lists the keys at or above it as it writes each
     region back (tables of more than 512 regions), and the BFS set-up builds its table from that list instead of
