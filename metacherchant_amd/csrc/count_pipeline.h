@@ -551,7 +551,7 @@ __device__ __forceinline__ void sk_emit(SkCursors &C, uint32_t d, const uint4 &r
 #define MC_P1W_COMPACT 1   // records are built one per lane from a queue of their starts (0: every lane loops over its own starts)
 #endif
 #ifndef MC_P1W_THREADS
-#define MC_P1W_THREADS 512
+#define MC_P1W_THREADS 1024   // (16 waves: one workgroup a CU, 256 x 512 bucket lines open at a time -- 4.3 ms and 5.1 GB written on configs[1] against 4.5 ms and 5.8 GB with 512)
 #endif
 constexpr int P1W_THREADS = MC_P1W_THREADS;
 constexpr int P1W_WAVES = P1W_THREADS / 64;
