@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define MC_ABI_VERSION 9
+#define MC_ABI_VERSION 10
 
 /* error codes */
 #define MC_OK 0
@@ -289,6 +289,12 @@ typedef struct {
 } mc_stats;
 int mc_get_stats(mc_ctx *ctx, mc_stats *out);
 int mc_reset_stats(mc_ctx *ctx);
+/* Gives the counting pipeline's scratch (the record / key streams of the last run: about 1.3 bytes per base counted) and
+ * the idle blocks of the process-wide pools back to the driver; the table, the read store and the list of solid k-mers
+ * stay.  For callers that need the device's memory between counting and what follows (the next counting call allocates
+ * its scratch again).  No counterpart in the reference: the JVM's collector does this for BigLong2ShortHashMap's
+ * transient arrays (itmo!/structures/map/BigLong2ShortHashMap.java:46-70). */
+int mc_trim(mc_ctx *ctx);
 /* ... of a group: counts and bytes summed over its devices, times the largest of any device (they work side by side) */
 int mc_group_get_stats(mc_group *g, mc_stats *out);
 

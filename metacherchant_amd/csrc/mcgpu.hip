@@ -266,6 +266,9 @@ struct mc_ctx {
 
     char *pin[16] = {};                // pinned staging buffers of h2d_fast, made on first use
     DevPool tok_pool;                  // scratch of the device tokeniser
+    uint4 *d_ovf_tmp = nullptr;        // pipe_drain_handed_on: the list moved aside while it is drained
+    uint32_t *d_ovf_leaf_tmp = nullptr;
+    uint64_t ovf_tmp_cap = 0, ovf_leaf_tmp_cap = 0;
     bool rs_copy_pending = false;      // a batch is on its way into the read store on pipe_stream (rs_append)
     // mc_bfs_batch: job states + seeds go up in one copy (pinned h_bfs_stage -> d_bfs_stage), results come back packed
     // (d_bfs_pack: a header block and the jobs' arrays back to back; h_bfs_hdr: the headers, pinned)
@@ -1345,13 +1348,37 @@ static int pipe_drain_handed_on(mc_ctx *c, uint64_t n_listed)
     mc_ctx::Pipe &P = c->pipe;
     const uint64_t n = std::min<uint64_t>(n_listed, mc_ctx::OVF_CAP);
     if (n == 0) return MC_OK;
-    hipLaunchKernelGGL(k_add_parked, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->d_ovf, n, c->view(), c->d_ovf_leaf, P.leaf_state);
-    HIPCHK(c, hipGetLastError());
+    // The direct kernel parks what IT cannot place (no room in the whole chain: a table far too small) in the same list:
+    // the entries are moved aside first and the list starts again from 0 -- read and appended to in one launch, the
+    // additions parked by the drain itself were wiped with the list's counter (15 000 of 21 M keys lost in a soak case with a
+    // capacity hint a quarter of what the reads held).
+    int rc = ensure_buf(c, &c->d_ovf_tmp, &c->ovf_tmp_cap, (uint64_t)mc_ctx::OVF_CAP);
+    if (!rc) rc = ensure_buf(c, &c->d_ovf_leaf_tmp, &c->ovf_leaf_tmp_cap, (uint64_t)mc_ctx::OVF_CAP);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_ovf_tmp, c->d_ovf, n * sizeof(uint4), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_ovf_leaf_tmp, c->d_ovf_leaf, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_ctr + 7, 0, sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(k_add_parked, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->d_ovf_tmp, n, c->view(), c->d_ovf_leaf_tmp, P.leaf_state);
+    HIPCHK(c, hipGetLastError());
     c->solid_tracked = false;  // (these additions were not watched for crossing the coverage threshold)
     c->solid_list_fresh = false;
     c->st.spill_keys += n;
-    return MC_OK;
+    // what the drain parked: into a table of twice the regions, until nothing is left (pipe_finish sees the new size)
+    for (int attempt = 0;; attempt++) {
+        unsigned long long m = 0;
+        HIPCHK(c, hipMemcpyAsync(c->h_scratch + 26, c->d_ctr + 7, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        m = c->h_scratch[26];
+        if (m == 0) return MC_OK;
+        if (m > mc_ctx::OVF_CAP || attempt >= 6)
+            return fail(c, MC_EOVERFLOW, "k-mer table regions keep overflowing (%llu additions parked); pass a capacity_hint (distinct k-mers)", m);
+        HIPCHK(c, hipMemcpyAsync(c->d_ovf_tmp, c->d_ovf, m * sizeof(uint4), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_ctr + 7, 0, sizeof(unsigned long long), c->stream));
+        rc = table_grow(c, c->n_regions * 2);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_add_parked, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, c->d_ovf_tmp, (uint64_t)m, c->view());
+        HIPCHK(c, hipGetLastError());
+    }
 }
 
 // Nothing vouches for the table's size (no capacity hint) and it holds nothing yet: the level-1 scatter has just run, and
@@ -1595,6 +1622,10 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
         rc = pipe_drain_handed_on(c, n_handed_on);
         if (rc) return rc;
         n_handed_on = 0;
+        if ((n_leaves << pl.g) < c->n_regions) {  // (the drain doubled the table: a leaf covers more regions now; n_used was recounted)
+            while ((n_leaves << pl.g) < c->n_regions) pl.g++;
+            HIPCHK(c, hipMemsetAsync(P.leaf_new, 0, n_leaves * sizeof(uint32_t), c->stream));
+        }
         if (flags[2]) emit.recs = nullptr;  // a segment of the solid list overflowed: the BFS set-up sweeps the table instead
         if (!flags[1]) break;
         if (attempt >= 6 || pl.g >= 5) {
@@ -2341,6 +2372,8 @@ void mc_destroy(mc_ctx *c)
     if (c->h_scratch) (void)hipHostFree(c->h_scratch);
     if (c->d_ovf) (void)hipFree(c->d_ovf);
     if (c->d_ovf_leaf) (void)hipFree(c->d_ovf_leaf);
+    g_scratch_pool.put(c->cfg.device, c->d_ovf_tmp, c->ovf_tmp_cap * sizeof(uint4));
+    if (c->d_ovf_leaf_tmp) (void)hipFree(c->d_ovf_leaf_tmp);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->rs_words) (void)hipFree(c->rs_words);
@@ -3528,6 +3561,30 @@ int mc_reset_stats(mc_ctx *c)
     c->st = mc_stats{};
     c->st.table_slots = slots;
     c->st.table_bytes = bytes;
+    return MC_OK;
+}
+
+int mc_trim(mc_ctx *c)
+{
+    if (!c) return MC_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    mc_ctx::Pipe &P = c->pipe;
+    const int dev = c->cfg.device;
+    // (the list of solid k-mers sits in a_recs, its fill levels in emit_counts: they stay while the list is valid)
+    uint4 *keep_recs = nullptr;
+    uint64_t keep_cap = 0;
+    uint32_t *keep_counts = nullptr;
+    if (c->solid_list_fresh) {
+        keep_recs = P.a_recs; keep_cap = P.a_recs_cap; keep_counts = P.emit_counts;
+        P.a_recs = nullptr; P.a_recs_cap = 0; P.emit_counts = nullptr;
+    }
+    P.release(dev);
+    P.a_recs = keep_recs; P.a_recs_cap = keep_cap; P.emit_counts = keep_counts;
+    g_scratch_pool.put(dev, c->d_ovf_tmp, c->ovf_tmp_cap * sizeof(uint4));
+    c->d_ovf_tmp = nullptr; c->ovf_tmp_cap = 0;
+    g_scratch_pool.release(dev);
+    g_table_pool.release(dev);
     return MC_OK;
 }
 

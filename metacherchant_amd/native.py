@@ -64,7 +64,7 @@ EXPORTS = [
     "mc_add_reads_packed_dev", "mc_add_reads_file", "mc_finalize_counts", "mc_get", "mc_get_dev", "mc_kmer_keys", "mc_bfs", "mc_bfs_batch",
     "mc_bfs_result_free", "mc_export", "mc_export_dev", "mc_add_pairs_dev", "mc_solid_from_pairs_dev", "mc_save_kmers", "mc_load_kmers", "mc_key_owner", "mc_extract_keys_dev",
     "mc_group_create", "mc_group_destroy", "mc_group_last_error", "mc_group_set_coverage_hint", "mc_group_add_reads_packed", "mc_group_add_reads_file",
-    "mc_group_finalize_counts", "mc_group_bfs_batch", "mc_group_get_stats", "mc_add_keys_dev", "mc_superkmer_capacity", "mc_extract_superkmers_dev", "mc_add_superkmers_dev", "mc_get_stats", "mc_reset_stats", "mc_synth_reads_dev", "mc_synth_genome",
+    "mc_group_finalize_counts", "mc_group_bfs_batch", "mc_group_get_stats", "mc_add_keys_dev", "mc_superkmer_capacity", "mc_extract_superkmers_dev", "mc_add_superkmers_dev", "mc_get_stats", "mc_reset_stats", "mc_trim", "mc_synth_reads_dev", "mc_synth_genome",
 ]
 
 _LIB = None
@@ -131,6 +131,7 @@ def load():
     L.mc_add_superkmers_dev.argtypes = [vp, vp, vp, u64]
     L.mc_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.mc_reset_stats.argtypes = [vp]
+    L.mc_trim.argtypes = [vp]
     L.mc_synth_reads_dev.argtypes = [vp, u64, u64, u64, u64, u64, u64, C.c_uint32, C.c_uint32, vp, vp]
     L.mc_synth_genome.argtypes = [u64, u64, u64, C.POINTER(C.c_uint8)]
     _LIB = L
@@ -363,6 +364,10 @@ class Context:
 
     def reset_stats(self):
         self._chk(self._L.mc_reset_stats(self._h))
+
+    def trim(self):
+        """mc_trim: the counting pipeline's scratch and the pools' idle blocks go back to the driver."""
+        self._chk(self._L.mc_trim(self._h))
 
     def synth_reads_dev(self, genome_seed, n_contigs, contig_len, read_seed, first_read, n_reads, read_len,
                         err_per_10k, d_words, d_offsets):

@@ -15,6 +15,7 @@ from oracle import pyoracle as po
 from tests.helpers import GENOME_SEED, assert_bfs_equal, seed_windows
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+only = int(os.environ["SOAK_ONLY"]) if "SOAK_ONLY" in os.environ else None  # replay one iteration of a run (the others only draw their numbers)
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t0 = time.time()
 for it in range(iters):
@@ -29,6 +30,12 @@ for it in range(iters):
     hint = bool(rng.integers(0, 2))
     cap = int(rng.choice([0, 0, 2_000_000, 6_000_000]))
     rseed = int(rng.integers(1, 1 << 30))
+    if only is not None and it != only:
+        if bool(rng.integers(0, 4) == 0):
+            rng.integers(0, L + 1, n_reads)
+        rng.integers(0, 2)
+        rng.integers(0, max(1, clen - 600))
+        continue
     print("it %d: k=%d err=%d L=%d reads=%d genome=%dx%d cov=%d hint=%d cap=%d rseed=%d" % (it, k, err, L, n_reads, contigs, clen, cov, hint, cap, rseed), flush=True)
     genome = po.synth_genome(GENOME_SEED + it, contigs * clen)
     reads = po.synth_reads(genome, contigs, clen, rseed, 0, n_reads, L, err)

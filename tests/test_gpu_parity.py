@@ -292,6 +292,29 @@ def test_compact_records_of_the_counting_pipeline(mc, monkeypatch, capfd):
         ctx.close()
 
 
+def test_capacity_hint_a_quarter_of_what_the_reads_hold(mc, monkeypatch):
+    """A capacity hint vouches for the table's size, so the pipeline merges into it without sampling -- and finds most regions
+    full: leaves hand occurrences on to the next regions, the direct kernel that drains that list parks what finds no room in
+    the whole chain, the table doubles (several times) under the run.  Every (key, count) pair must still be there (the drain
+    once read and appended to the same list in one launch and wiped what it had parked itself: scripts/soak.py found 15 000
+    of 21 M keys missing)."""
+    monkeypatch.delenv("MC_COUNT_PATH", raising=False)
+    genome, reads, off = synth_case(3, 150000, 100000, 250, 200)
+    t, _ = oracle_table(reads, off, 29, po.KEY_PACKED)
+    ok, oc = t.dump()
+    assert t.size() > 8_000_000
+    ctx = mc.Context(29, mc.KEY_PACKED, 0, 2_400_000)
+    half = 50000
+    ctx.add_reads_packed(po.pack(reads[:off[half]]), off[:half + 1])
+    ctx.add_reads_packed(po.pack(reads[off[half]:]), off[half:] - off[half])
+    assert ctx.finalize() == t.size()
+    gk, gc = ctx.export(0)
+    assert np.array_equal(gk, ok) and np.array_equal(gc, oc)
+    st = ctx.stats()
+    assert st.spill_keys > 0 and st.grows > 0
+    ctx.close()
+
+
 def test_solid_list_from_the_merge_kernel(mc, monkeypatch):
     """With the threshold known while counting, the merge kernel lists the keys at or above it as it writes each
     region back (tables of more than 512 regions), and the BFS set-up builds its table from that list instead of
