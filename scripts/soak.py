@@ -16,6 +16,7 @@ from tests.helpers import GENOME_SEED, assert_bfs_equal, seed_windows
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 only = int(os.environ["SOAK_ONLY"]) if "SOAK_ONLY" in os.environ else None  # replay one iteration of a run (the others only draw their numbers)
+first = int(os.environ.get("SOAK_FROM", 0))                                     # ... or all from this one on
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t0 = time.time()
 for it in range(iters):
@@ -30,7 +31,7 @@ for it in range(iters):
     hint = bool(rng.integers(0, 2))
     cap = int(rng.choice([0, 0, 2_000_000, 6_000_000]))
     rseed = int(rng.integers(1, 1 << 30))
-    if only is not None and it != only:
+    if (only is not None and it != only) or it < first:
         if bool(rng.integers(0, 4) == 0):
             rng.integers(0, L + 1, n_reads)
         rng.integers(0, 2)
@@ -69,6 +70,14 @@ for it in range(iters):
     for d in (1, -1, 0):
         got = ctx.bfs(hi, lo, d, cov, 20000, -1)
         want = po.bfs(t, k, omode, [seed], d, cov, 20000, -1)
+        if len(got["hi"]) != len(want["hi"]):  # what the replayed iteration got too much / too little
+            n = min(len(got["hi"]), len(want["hi"]))
+            for name, r in (("device", got), ("oracle", want)):
+                for j in range(n, len(r["hi"])):
+                    key = int(r["lo"][j])
+                    print("dir %d: %s only: entry %d lo=%x dist=%d cov=%d last=%d | oracle table count of that k-mer (as a packed key, both strands): %s | device table: %s" % (
+                        d, name, j, key, r["dist"][j], r["cov"][j], r["last"][j], t.get(np.array([key], dtype=np.uint64)) if hasattr(t, "get") else "?",
+                        ctx.get(np.array([key], dtype=np.uint64))), flush=True)
         assert_bfs_equal(got, want)
     st = ctx.stats()
     ctx.close()
