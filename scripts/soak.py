@@ -70,7 +70,7 @@ for it in range(iters):
     for d in (1, -1, 0):
         got = ctx.bfs(hi, lo, d, cov, 20000, -1)
         want = po.bfs(t, k, omode, [seed], d, cov, 20000, -1)
-        if len(got["hi"]) != len(want["hi"]):  # what the replayed iteration got too much / too little
+        if got is not None and want is not None and len(got["hi"]) != len(want["hi"]):  # what the replayed iteration got too much / too little
             n = min(len(got["hi"]), len(want["hi"]))
             for name, r in (("device", got), ("oracle", want)):
                 for j in range(n, len(r["hi"])):
