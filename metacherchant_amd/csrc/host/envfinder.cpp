@@ -225,6 +225,129 @@ void JavaTreeOrder::put(std::vector<uint32_t> &chain, uint32_t id)
     }
 }
 
+uint32_t JavaTreeOrder::balance_deletion(uint32_t root, uint32_t x)
+{   // HashMap.TreeNode.balanceDeletion (JDK 8)
+    auto red = [&](uint32_t n) { return n != NIL && t_[n].red; };
+    for (;;) {
+        if (x == NIL || x == root) return root;
+        uint32_t xp = t_[x].parent;
+        if (xp == NIL) { t_[x].red = false; return x; }
+        if (t_[x].red) { t_[x].red = false; return root; }
+        uint32_t xpl = t_[xp].left;
+        if (xpl == x) {
+            uint32_t xpr = t_[xp].right;
+            if (red(xpr)) {
+                t_[xpr].red = false; t_[xp].red = true;
+                root = rotate_left(root, xp);
+                xp = t_[x].parent;
+                xpr = xp == NIL ? NIL : t_[xp].right;
+            }
+            if (xpr == NIL) { x = xp; continue; }
+            uint32_t sl = t_[xpr].left, sr = t_[xpr].right;
+            if (!red(sr) && !red(sl)) { t_[xpr].red = true; x = xp; continue; }
+            if (!red(sr)) {
+                if (sl != NIL) t_[sl].red = false;
+                t_[xpr].red = true;
+                root = rotate_right(root, xpr);
+                xp = t_[x].parent;
+                xpr = xp == NIL ? NIL : t_[xp].right;
+            }
+            if (xpr != NIL) {
+                t_[xpr].red = xp == NIL ? false : t_[xp].red;
+                sr = t_[xpr].right;
+                if (sr != NIL) t_[sr].red = false;
+            }
+            if (xp != NIL) { t_[xp].red = false; root = rotate_left(root, xp); }
+            x = root;
+        } else {  // symmetric
+            if (red(xpl)) {
+                t_[xpl].red = false; t_[xp].red = true;
+                root = rotate_right(root, xp);
+                xp = t_[x].parent;
+                xpl = xp == NIL ? NIL : t_[xp].left;
+            }
+            if (xpl == NIL) { x = xp; continue; }
+            uint32_t sl = t_[xpl].left, sr = t_[xpl].right;
+            if (!red(sl) && !red(sr)) { t_[xpl].red = true; x = xp; continue; }
+            if (!red(sl)) {
+                if (sr != NIL) t_[sr].red = false;
+                t_[xpl].red = true;
+                root = rotate_left(root, xpl);
+                xp = t_[x].parent;
+                xpl = xp == NIL ? NIL : t_[xp].left;
+            }
+            if (xpl != NIL) {
+                t_[xpl].red = xp == NIL ? false : t_[xp].red;
+                sl = t_[xpl].left;
+                if (sl != NIL) t_[sl].red = false;
+            }
+            if (xp != NIL) { t_[xp].red = false; root = rotate_right(root, xp); }
+            x = root;
+        }
+    }
+}
+
+bool JavaTreeOrder::remove(std::vector<uint32_t> &chain, uint32_t p, bool movable)
+{   // HashMap.TreeNode.removeTreeNode (JDK 8)
+    uint32_t root = chain[0];  // ("first" as it was before the node left the chain)
+    chain.erase(std::find(chain.begin(), chain.end(), p));
+    if (chain.empty()) { t_.erase(p); return true; }
+    while (t_[root].parent != NIL) root = t_[root].parent;
+    {
+        const uint32_t rl = t_[root].left;
+        if (t_[root].right == NIL || rl == NIL || t_[rl].left == NIL) { t_.erase(p); return true; }  // too small: untreeify
+    }
+    const uint32_t pl = t_[p].left, pr = t_[p].right;
+    uint32_t replacement;
+    if (pl != NIL && pr != NIL) {
+        uint32_t s = pr;
+        while (t_[s].left != NIL) s = t_[s].left;  // the successor
+        std::swap(t_[s].red, t_[p].red);
+        const uint32_t sr = t_[s].right, pp = t_[p].parent;
+        if (s == pr) {  // p was s's direct parent
+            t_[p].parent = s;
+            t_[s].right = p;
+        } else {
+            const uint32_t sp = t_[s].parent;
+            t_[p].parent = sp;
+            if (sp != NIL) { if (s == t_[sp].left) t_[sp].left = p; else t_[sp].right = p; }
+            t_[s].right = pr;
+            if (pr != NIL) t_[pr].parent = s;
+        }
+        t_[p].left = NIL;
+        t_[p].right = sr;
+        if (sr != NIL) t_[sr].parent = p;
+        t_[s].left = pl;
+        if (pl != NIL) t_[pl].parent = s;
+        t_[s].parent = pp;
+        if (pp == NIL) root = s;
+        else if (p == t_[pp].left) t_[pp].left = s;
+        else t_[pp].right = s;
+        replacement = sr != NIL ? sr : p;
+    } else if (pl != NIL) replacement = pl;
+    else if (pr != NIL) replacement = pr;
+    else replacement = p;
+    if (replacement != p) {
+        const uint32_t pp = t_[replacement].parent = t_[p].parent;
+        if (pp == NIL) root = replacement;
+        else if (p == t_[pp].left) t_[pp].left = replacement;
+        else t_[pp].right = replacement;
+        t_[p].left = t_[p].right = t_[p].parent = NIL;
+    }
+    const uint32_t r = t_[p].red ? root : balance_deletion(root, replacement);
+    if (replacement == p) {  // detach
+        const uint32_t pp = t_[p].parent;
+        t_[p].parent = NIL;
+        if (pp != NIL) {
+            if (p == t_[pp].left) t_[pp].left = NIL;
+            else if (p == t_[pp].right) t_[pp].right = NIL;
+        }
+    }
+    t_.erase(p);
+    if (movable) root_to_front(chain, r);
+    return false;
+}
+
 // ------------------------------------------------------------------------------------------ JavaHashMap
 
 static uint32_t java_string_hash(const std::string &s)
@@ -310,18 +433,16 @@ bool JavaHashMap::find(const std::string &key, int *value) const
     return true;
 }
 
-void JavaHashMap::remove(const std::string &key)
-{
+void JavaHashMap::remove(const std::string &key, bool movable)
+{   // (movable: HashMap.remove(key) passes true, an iterator's remove -- retainAll -- false)
     auto it = index_.find(key);
     if (it == index_.end()) return;
     const size_t b = entries_[it->second].hash & (cap_ - 1);
     auto &bin = bins_[b];
-    bin.erase(std::find(bin.begin(), bin.end(), it->second));
-    if (is_tree_[b]) {  // removeTreeNode is not replayed: the order inside this bin is no longer the JVM's for sure
-        order_unknown_ = true;
-        tree_.forget(bin);
-        tree_.forget({it->second});
-        if (bin.size() > 6) tree_.treeify(bin); else is_tree_[b] = 0;
+    if (is_tree_[b]) {  // TreeNode.removeTreeNode
+        if (tree_.remove(bin, it->second, movable)) { tree_.forget(bin); is_tree_[b] = 0; }
+    } else {
+        bin.erase(std::find(bin.begin(), bin.end(), it->second));
     }
     index_.erase(it);
     size_--;
@@ -1276,19 +1397,17 @@ void JavaKmerMap::resize()
     }
 }
 
-void JavaKmerMap::remove(kmer_t key)
-{
+void JavaKmerMap::remove(kmer_t key, bool movable)
+{   // (movable: HashMap.remove(key) passes true, an iterator's remove -- runTrimPaths' retainAll -- false)
     const size_t b = hash_of(key) & (cap_ - 1);
     auto tb = tree_bins_.find(b);
-    if (tb != tree_bins_.end()) {  // removeTreeNode is not replayed: the order inside this bin is no longer the JVM's for sure
+    if (tb != tree_bins_.end()) {  // TreeNode.removeTreeNode
         std::vector<uint32_t> &chain = tb->second;
         for (size_t i = 0; i < chain.size(); i++)
             if (entries_[chain[i]].key == key) {
-                order_unknown_ = true;
-                tree_.forget(chain);
-                chain.erase(chain.begin() + (long)i);
-                if (chain.size() > 6) { tree_.treeify(chain); relink(b, chain); }
-                else { relink(b, chain); tree_bins_.erase(tb); }
+                const bool plain = tree_.remove(chain, chain[i], movable);
+                relink(b, chain);
+                if (plain) { tree_.forget(chain); tree_bins_.erase(tb); }
                 size_--;
                 return;
             }

@@ -38,6 +38,10 @@ public:
     explicit JavaTreeOrder(std::function<int(uint32_t, uint32_t)> dir) : dir_(std::move(dir)) {}
     void treeify(std::vector<uint32_t> &chain);
     void put(std::vector<uint32_t> &chain, uint32_t id);
+    // removeTreeNode + balanceDeletion: the chain only loses `id` (with `movable` -- HashMap.remove; an iterator's remove, which
+    // is what retainAll uses, passes false -- the root then moves to the front).  Returns true when the bin untreeifies (the tree
+    // was too small BEFORE the removal) or is empty: the caller forgets the tree and keeps the chain as a plain list.
+    bool remove(std::vector<uint32_t> &chain, uint32_t id, bool movable);
     void forget(const std::vector<uint32_t> &chain) { for (uint32_t id : chain) t_.erase(id); }
 
 private:
@@ -46,6 +50,7 @@ private:
     uint32_t rotate_left(uint32_t root, uint32_t p);
     uint32_t rotate_right(uint32_t root, uint32_t p);
     uint32_t balance_insertion(uint32_t root, uint32_t x);
+    uint32_t balance_deletion(uint32_t root, uint32_t x);
     static void root_to_front(std::vector<uint32_t> &chain, uint32_t root);
     std::function<int(uint32_t, uint32_t)> dir_;
     std::unordered_map<uint32_t, Node> t_;
@@ -59,10 +64,10 @@ public:
     bool contains(const std::string &key) const { return index_.count(key) != 0; }
     int get(const std::string &key) const;         // throws if absent
     bool find(const std::string &key, int *value) const;
-    void remove(const std::string &key);
+    void remove(const std::string &key, bool movable = false);
     size_t size() const { return size_; }
-    // The order of a treeified bin is replayed node for node (JavaTreeOrder) except for a REMOVAL from such a bin
-    // (removeTreeNode: only runTrimPaths' retainAll removes): then the JDK's order is no longer guaranteed.
+    // The order of a treeified bin is replayed node for node (JavaTreeOrder), removals included (removeTreeNode): nothing sets
+    // the flag any more; it stays for callers that ask.
     bool treeified() const { return order_unknown_; }
     size_t bins_treeified() const { return n_treeified_; }  // bins that were treeified at some point (tests)
     template <typename F>
@@ -145,7 +150,7 @@ public:
     int put(kmer_t key, int value);   // entry index; an existing key keeps its place and gets the value
     int find_entry(kmer_t key) const;  // -1 when absent
     int value_at(int e) const { return entries_[(size_t)e].value; }
-    void remove(kmer_t key);
+    void remove(kmer_t key, bool movable = false);
     size_t size() const { return size_; }
     size_t n_entries() const { return entries_.size(); }  // removed ones included: bound of the entry indices
     bool treeified() const { return order_unknown_; }  // (see JavaHashMap::treeified)

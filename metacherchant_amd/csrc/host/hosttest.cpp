@@ -40,17 +40,17 @@ int main(int argc, char **argv)
             fputs(java_format_6_2f(strtof(argv[2], nullptr)).c_str(), stdout);
             return 0;
         }
-        if (argc == 3 && std::string(argv[1]) == "hashmap") {  // put every k-mer string of the file ("-kmer": remove it), print both maps' orders
+        if (argc == 3 && std::string(argv[1]) == "hashmap") {  // put every k-mer string of the file ("-kmer": remove it as an iterator does, "~kmer": as HashMap.remove does), print both maps' orders
             std::ifstream f(argv[2]);
             if (!f) throw Error("cannot open key file");
             std::vector<std::string> ops;
             for (std::string line; std::getline(f, line);) if (!line.empty()) ops.push_back(line);
-            const int k = (int)(ops.empty() ? 1 : ops[0].size() - (ops[0][0] == '-'));
+            const int k = (int)(ops.empty() ? 1 : ops[0].size() - (ops[0][0] == '-' || ops[0][0] == '~'));
             JavaHashMap hm;
             JavaKmerMap km(k);
             int v = 0;
             for (const std::string &op : ops) {
-                if (op[0] == '-') { hm.remove(op.substr(1)); km.remove(pack_kmer128(op.substr(1))); }
+                if (op[0] == '-' || op[0] == '~') { hm.remove(op.substr(1), op[0] == '~'); km.remove(pack_kmer128(op.substr(1)), op[0] == '~'); }
                 else { hm.put(op, v); km.put(pack_kmer128(op), v); v++; }
             }
             printf("S %zu %zu %d\n", hm.size(), hm.bins_treeified(), hm.treeified() ? 1 : 0);

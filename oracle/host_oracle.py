@@ -146,6 +146,84 @@ def _balance_insertion(root, x):
                         root = _rotate_left(root, xpp)
 
 
+def _balance_deletion(root, x):
+    """HashMap.TreeNode.balanceDeletion (JDK 8)."""
+    while True:
+        if x is None or x is root:
+            return root
+        xp = x.parent
+        if xp is None:
+            x.red = False
+            return x
+        if x.red:
+            x.red = False
+            return root
+        xpl = xp.left
+        if xpl is x:
+            xpr = xp.right
+            if xpr is not None and xpr.red:
+                xpr.red = False
+                xp.red = True
+                root = _rotate_left(root, xp)
+                xp = x.parent
+                xpr = None if xp is None else xp.right
+            if xpr is None:
+                x = xp
+            else:
+                sl, sr = xpr.left, xpr.right
+                if (sr is None or not sr.red) and (sl is None or not sl.red):
+                    xpr.red = True
+                    x = xp
+                else:
+                    if sr is None or not sr.red:
+                        if sl is not None:
+                            sl.red = False
+                        xpr.red = True
+                        root = _rotate_right(root, xpr)
+                        xp = x.parent
+                        xpr = None if xp is None else xp.right
+                    if xpr is not None:
+                        xpr.red = False if xp is None else xp.red
+                        sr = xpr.right
+                        if sr is not None:
+                            sr.red = False
+                    if xp is not None:
+                        xp.red = False
+                        root = _rotate_left(root, xp)
+                    x = root
+        else:  # symmetric
+            if xpl is not None and xpl.red:
+                xpl.red = False
+                xp.red = True
+                root = _rotate_right(root, xp)
+                xp = x.parent
+                xpl = None if xp is None else xp.left
+            if xpl is None:
+                x = xp
+            else:
+                sl, sr = xpl.left, xpl.right
+                if (sl is None or not sl.red) and (sr is None or not sr.red):
+                    xpl.red = True
+                    x = xp
+                else:
+                    if sl is None or not sl.red:
+                        if sr is not None:
+                            sr.red = False
+                        xpl.red = True
+                        root = _rotate_left(root, xpl)
+                        xp = x.parent
+                        xpl = None if xp is None else xp.left
+                    if xpl is not None:
+                        xpl.red = False if xp is None else xp.red
+                        sl = xpl.left
+                        if sl is not None:
+                            sl.red = False
+                    if xp is not None:
+                        xp.red = False
+                        root = _rotate_right(root, xp)
+                    x = root
+
+
 class _TreeBin:
     """One treeified bin: `first` heads the next-chain (always the tree's root: moveRootToFront)."""
 
@@ -240,6 +318,94 @@ class _TreeBin:
                 self._move_root_to_front(_balance_insertion(root, x))
                 return
 
+    def remove(self, e, movable):
+        """removeTreeNode (JDK 8) of the node that holds entry e.  Returns the bin's entries as a plain list when the bin
+        untreeifies (too small: judged on the tree as it was BEFORE the removal) or is empty, else None.  The next-chain only
+        loses the node; with movable (HashMap.remove; an iterator's remove -- retainAll -- passes false) the root moves to the
+        front afterwards."""
+        p = self.first
+        while p.e is not e:
+            p = p.next
+        first = root = self.first
+        succ, pred = p.next, p.prev
+        if pred is None:
+            self.first = first = succ
+        else:
+            pred.next = succ
+        if succ is not None:
+            succ.prev = pred
+        if first is None:
+            return []
+        while root.parent is not None:
+            root = root.parent
+        rl = root.left
+        if root.right is None or rl is None or rl.left is None:
+            return list(self.entries())  # untreeify: plain nodes in chain order
+        pl, pr = p.left, p.right
+        if pl is not None and pr is not None:
+            s = pr
+            while s.left is not None:  # the successor
+                s = s.left
+            s.red, p.red = p.red, s.red
+            sr = s.right
+            pp = p.parent
+            if s is pr:  # p was s's direct parent
+                p.parent = s
+                s.right = p
+            else:
+                sp = s.parent
+                p.parent = sp
+                if sp is not None:
+                    if s is sp.left:
+                        sp.left = p
+                    else:
+                        sp.right = p
+                s.right = pr
+                if pr is not None:
+                    pr.parent = s
+            p.left = None
+            p.right = sr
+            if sr is not None:
+                sr.parent = p
+            s.left = pl
+            if pl is not None:
+                pl.parent = s
+            s.parent = pp
+            if pp is None:
+                root = s
+            elif p is pp.left:
+                pp.left = s
+            else:
+                pp.right = s
+            replacement = sr if sr is not None else p
+        elif pl is not None:
+            replacement = pl
+        elif pr is not None:
+            replacement = pr
+        else:
+            replacement = p
+        if replacement is not p:
+            pp = replacement.parent = p.parent
+            if pp is None:
+                root = replacement
+            elif p is pp.left:
+                pp.left = replacement
+            else:
+                pp.right = replacement
+            p.left = p.right = p.parent = None
+        r = root if p.red else _balance_deletion(root, replacement)
+        if replacement is p:  # detach
+            pp = p.parent
+            p.parent = None
+            if pp is not None:
+                if p is pp.left:
+                    pp.left = None
+                elif p is pp.right:
+                    pp.right = None
+        if movable:
+            self._move_root_to_front(r)
+        return None
+
     def entries(self):
         x = self.first
         while x is not None:
@@ -260,9 +426,10 @@ class JavaHashMap:
     table is resized instead): its iteration order is the TreeNodes' next-chain --
     treeify() moves the tree's root to the front, putTreeVal() links a new node right
     behind its tree parent, split() keeps the chain order, untreeifies halves of <= 6
-    nodes and re-treeifies the others when the bin really split.  Only a REMOVAL from a
-    treeified bin (runTrimPaths' retainAll) is not replayed node for node: it sets
-    `order_unknown`, the one case left in which the order may differ from the JVM's.
+    nodes and re-treeifies the others when the bin really split; a removal (runTrimPaths'
+    retainAll, through the key set's iterator) is removeTreeNode + balanceDeletion: the chain
+    only loses the node, the bin untreeifies when the tree was too small.  `order_unknown`
+    is never set any more (kept for callers that ask).
     """
 
     def __init__(self):
@@ -362,16 +529,18 @@ class JavaHashMap:
     def __len__(self):
         return self.size
 
-    def remove(self, key):
+    def remove(self, key, movable=False):
+        """HashMap.removeNode.  movable: HashMap.remove(key) passes true; the removals this pipeline makes come from an
+        iterator (runTrimPaths: keySet().retainAll -> Iterator.remove -> removeNode(..., movable = false))."""
         e = self.index.pop(key, None)
         if e is not None:
             e[3] = False
             i = e[2] & (self.cap - 1)
             b = self.bins[i]
-            if isinstance(b, _TreeBin):  # (removeTreeNode is not replayed: order of this bin no longer guaranteed)
-                self.order_unknown = True
-                rest = [x for x in b.entries() if x is not e]
-                self.bins[i] = _TreeBin(rest) if len(rest) > 6 else rest
+            if isinstance(b, _TreeBin):  # TreeNode.removeTreeNode
+                plain = b.remove(e, movable)
+                if plain is not None:
+                    self.bins[i] = plain
             else:
                 b.remove(e)
             self.size -= 1

@@ -419,23 +419,81 @@ def test_treeified_bins_same_order_in_all_three_maps(hosttest, tmp_path):
         got_k = [(l.split()[1], int(l.split()[2])) for l in out[2 + n:2 + 2 * n]]
         assert got_s == want and got_k == want
 
-    # a removal from a treeified bin is the one thing not replayed: all three say so, and still agree on the order
-    keys = []
-    while len(keys) < 12:
-        s = rand_kmer(25)
-        if _spread(s) & 63 == 9:
-            keys.append(s)
-    ops = keys + ["-" + keys[4]]
-    m = ho.JavaHashMap()
-    for i, s in enumerate(keys):
-        m.put(s, i)
-    m.remove(keys[4])
-    assert m.order_unknown
-    path = tmp_path / "ops.txt"
-    path.write_text("\n".join(ops) + "\n")
-    out = subprocess.check_output([hosttest, "hashmap", str(path)]).decode().splitlines()
-    assert out[0].split()[3] == "1" and out[12].split()[3] == "1"
-    assert [(l.split()[1], int(l.split()[2])) for l in out[1:12]] == list(m.items())
+    # removals from treeified bins (removeTreeNode + balanceDeletion): runTrimPaths' retainAll goes through the key set's
+    # iterator (movable = false: the chain only loses the node), HashMap.remove moves the root to the front afterwards; a bin
+    # whose tree was too small before the removal goes back to a plain list.  Puts after removals land where the REBALANCED
+    # tree says, so a wrong tree shows in the order.  The three maps agree after every mix; the Python tree keeps the
+    # red-black invariants throughout.
+    def check_rb(bin_):
+        root = bin_.first
+        while root.parent is not None:
+            root = root.parent
+        assert not root.red
+
+        def walk(n):
+            if n is None:
+                return 1
+            if n.red:
+                assert not (n.left is not None and n.left.red) and not (n.right is not None and n.right.red)
+            for c in (n.left, n.right):
+                assert c is None or c.parent is n
+            hl, hr = walk(n.left), walk(n.right)
+            assert hl == hr
+            return hl + (0 if n.red else 1)
+
+        walk(root)
+        assert sum(1 for _ in bin_.entries()) == count(root)
+
+    def count(n):
+        return 0 if n is None else 1 + count(n.left) + count(n.right)
+
+    for trial in range(12):
+        pool = []
+        while len(pool) < 60:  # two buckets of 30 keys each at any capacity up to 1024
+            s = rand_kmer(25)
+            if _spread(s) & 1023 in (9, 600):
+                pool.append(s)
+        ops, live = [], []
+        m = ho.JavaHashMap()
+        val = 0
+        n_tree_removals = 0
+        for step in range(400):
+            r = rng.random()
+            if live and (r < 0.35 or len(live) == len(pool)):
+                s = live.pop(int(rng.integers(0, len(live))))
+                movable = bool(rng.integers(0, 2))
+                was_tree = isinstance(m.bins[_spread(s) & (m.cap - 1)], ho._TreeBin)
+                ops.append(("~" if movable else "-") + s)
+                m.remove(s, movable)
+                n_tree_removals += was_tree
+            elif r < 0.9 or not live:
+                cand = [s for s in pool if s not in live]
+                if not cand:
+                    continue
+                s = cand[int(rng.integers(0, len(cand)))]
+                live.append(s)
+                ops.append(s)
+                m.put(s, val)
+                val += 1
+            else:  # a filler key now and then: resizes split and rebuild the bins
+                s = rand_kmer(25)
+                if s in m:
+                    continue
+                ops.append(s)
+                m.put(s, val)
+                val += 1
+            for bn in m.bins:
+                if isinstance(bn, ho._TreeBin):
+                    check_rb(bn)
+        assert n_tree_removals > 20 and not m.order_unknown
+        path = tmp_path / ("ops%d.txt" % trial)
+        path.write_text("\n".join(ops) + "\n")
+        out = subprocess.check_output([hosttest, "hashmap", str(path)]).decode().splitlines()
+        want = list(m.items())
+        n = len(want)
+        assert out[0].split()[1] == str(n) and out[0].split()[3] == "0" and out[1 + n].split()[3] == "0"
+        assert [(l.split()[1], int(l.split()[2])) for l in out[1:1 + n]] == want
+        assert [(l.split()[1], int(l.split()[2])) for l in out[2 + n:2 + 2 * n]] == want
 
 
 def test_cli_refuses_k_above_63_with_a_clear_message(tmp_path):
