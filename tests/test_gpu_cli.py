@@ -349,10 +349,14 @@ def test_cli_config5_four_environments_then_multi_join(cli, tmp_path):
     assert gfa.count("\nS\t") > 3 and "#00ff00" in gfa  # the gene's unitigs are marked, the samples' bubbles coloured
 
 
-@pytest.mark.parametrize("devices,k,extra", [("0,0", 31, ["--maxkmers", "4000", "--coverage", "3"]),
-                                            ("0,0,0", 25, ["--maxradius", "200", "--coverage", "2", "--bothdirs", "true"]),
-                                            ("0,0", 41, ["--maxkmers", "2500", "--coverage", "3", "--bothdirs", "true"])])
-def test_cli_several_devices_equal_one(cli, tmp_path, devices, k, extra):
+@pytest.mark.parametrize("devices,k,extra,env", [("0,0", 31, ["--maxkmers", "4000", "--coverage", "3"], {}),
+                                                ("0,0,0", 25, ["--maxradius", "200", "--coverage", "2", "--bothdirs", "true"], {}),
+                                                ("0,0", 41, ["--maxkmers", "2500", "--coverage", "3", "--bothdirs", "true"], {}),
+                                                # exchanges of 3 x 833 reads: the FASTQ's last one holds TWO reads, so a share extracts
+                                                # (into the buffer its list of solid k-mers sat in) and then owns nothing of the batch:
+                                                # the list must not be taken for valid
+                                                ("0,0,0", 31, ["--maxkmers", "4000", "--coverage", "3"], {"MC_GROUP_BATCH_READS": "833"})])
+def test_cli_several_devices_equal_one(cli, tmp_path, devices, k, extra, env):
     """`--devices a,b,...`: reads dealt to the devices, super-k-mer records (keys for k < 23 and hash keys) exchanged by owner
     with peer copies, every device counts what it owns, the solid shards are gathered on the first for the BFS -- the
     native counterpart of distributed.py.  Output byte-identical with one device's and with the oracle's.
@@ -375,7 +379,7 @@ def test_cli_several_devices_equal_one(cli, tmp_path, devices, k, extra):
         cmd = [cli, "-k", str(k), "-i", fa1, fa2, "--seq", seq, "-o", out, "-w", str(tmp_path / ("wd_" + name)), "--force"] + extra
         if dev:
             cmd += ["--devices", dev]
-        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
         assert p.returncode == 0, p.stderr[-2000:]
         outs[name] = (out, p.stderr)
     assert "Counting on %d devices" % len(devices.split(",")) in outs["many"][1]
@@ -393,8 +397,24 @@ def test_cli_several_devices_equal_one(cli, tmp_path, devices, k, extra):
     _assert_same_tree(res, outs["one"][0], want)
 
 
+def test_cli_rccl_transport_wants_a_gpu_per_rank(cli, tmp_path):
+    """The RCCL transport of the native driver (ncclCommInitAll, grouped ncclSend / ncclRecv) cannot run on shares of one GPU
+    -- a communicator takes every device once -- and says so instead of hanging in the rendezvous; test_cli_two_real_devices
+    runs it where there are two GPUs."""
+    genome, reads, _ = synth_case(1, 5000, 300, 100, 0)
+    fa, seq = str(tmp_path / "r.fasta"), str(tmp_path / "s.fasta")
+    _write_fasta(fa, reads, 100)
+    with open(seq, "w") as f:
+        f.write(">g\n%s\n" % po.decode(genome[1000:1200]))
+    p = subprocess.run([cli, "-k", "31", "-i", fa, "--seq", seq, "-o", str(tmp_path / "o"), "-w", str(tmp_path / "w"), "--maxkmers", "1000",
+                        "--devices", "0,0"], capture_output=True, text=True, timeout=300, env=dict(os.environ, MC_GROUP_TRANSPORT="rccl"))
+    assert p.returncode != 0 and "RCCL wants every rank on a GPU of its own" in (p.stderr + p.stdout)
+
+
 def test_cli_two_real_devices(cli, tmp_path):
-    """The same over two different GPUs (skipped on a one-GPU box)."""
+    """The same over two different GPUs, with both transports of the native driver (peer copies, RCCL), and bench.py's
+    two-rank path over RCCL (`nccl`) -- skipped on a one-GPU box."""
+    import sys
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs")
@@ -405,10 +425,25 @@ def test_cli_two_real_devices(cli, tmp_path):
     with open(seq, "w") as f:
         f.write(">g\n%s\n" % po.decode(genome[9000:9400]))
     trees = []
-    for dev in (None, "0,1"):
-        out = str(tmp_path / ("out" + (dev or "")))
-        cmd = [cli, "-k", "31", "-i", fa, "--seq", seq, "-o", out, "-w", str(tmp_path / ("wd" + (dev or ""))), "--force", "--maxkmers", "5000", "--coverage", "3"]
-        p = subprocess.run(cmd + (["--devices", dev] if dev else []), capture_output=True, text=True, timeout=600)
+    for dev, transport in ((None, None), ("0,1", "peer"), ("0,1", "rccl")):
+        out = str(tmp_path / ("out" + (transport or "")))
+        cmd = [cli, "-k", "31", "-i", fa, "--seq", seq, "-o", out, "-w", str(tmp_path / ("wd" + (transport or ""))), "--force", "--maxkmers", "5000", "--coverage", "3"]
+        p = subprocess.run(cmd + (["--devices", dev] if dev else []), capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, **({"MC_GROUP_TRANSPORT": transport} if transport else {})))
         assert p.returncode == 0, p.stderr[-2000:]
         trees.append({n: open(os.path.join(out, "g", n)).read() for n in ("graph.txt", "graph.gfa", "seqs.fasta")})
-    assert trees[0] == trees[1]
+    assert trees[0] == trees[1] == trees[2]
+    # bench.py --gpus 2: one process per GPU, the exchange as all-to-alls over RCCL; its step checks the walk against the
+    # one-GPU result itself (distinct k-mers and vertices reached are printed: compare with a one-rank run of twice the reads)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29571", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "1000000",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert two.returncode == 0, two.stderr[-2000:]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--reads", "2000000", "--no-cpu-baseline",
+                          "--skip-no-hint"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert one.returncode == 0, one.stderr[-2000:]
+    import json
+    j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert j2["n_gpus"] == 2 and j2["distinct_kmers"] == j1["distinct_kmers"] and j2["bfs"]["reached"] == j1["bfs"]["reached"]
