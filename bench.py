@@ -142,7 +142,9 @@ def main():
             bfs_ms, reached, levels, lookups = 0.0, 0, 0, 0
             # buildEnvironment with bothdirs=False: runBfs(-1), runBfs(+1) -- independent passes, one launch
             jobs = [(seed_hi, seed_lo, 0)] if bothdirs else [(seed_hi, seed_lo, -1), (seed_hi, seed_lo, 1)]
+            t_b = time.perf_counter()
             res = bctx.bfs_batch(jobs, args.coverage, args.maxkmers, -1)
+            info["bfs_wall_s"] = info.get("bfs_wall_s", 0.0) + (time.perf_counter() - t_b)
             for r in res:
                 if r is None:
                     raise SystemExit("BFS found no seed k-mer: synthetic workload broken")
@@ -164,6 +166,7 @@ def main():
     sync()
     ctx.reset_stats()
     info["count_wall_s"] = 0.0
+    info["bfs_wall_s"] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -282,6 +285,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         out["count_wall_ms"] = round(1e3 * info["count_wall_s"] / args.steps, 3)  # clear + count + finalize as the host sees them (kernels: roofline.count_ms_per_step)
+        out["bfs_wall_ms"] = round(1e3 * info.get("bfs_wall_s", 0.0) / args.steps, 3)  # mc_bfs_batch as the host sees it: upload, walk, packed results back, arrays for the caller (kernel: bfs.ms_per_step)
         if no_hint is not None:
             # the headline's context knows the number of distinct k-mers beforehand (capacity hint); these do not
             out["count_ms_no_hint"] = round(no_hint["count_wall_ms"], 3)

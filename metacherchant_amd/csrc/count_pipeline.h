@@ -1854,6 +1854,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_dedup(const uint4 *__restrict
         for (uint32_t base = w0; base < wend; base += 64) {
             const uint32_t widx = base + lane;
             // (every lane takes part in the shuffles: a lane that is masked off hands out zeros)
+            // (asking for the NEXT batch's words before this batch's probe loop was measured: 7.45 against 7.35 ms)
             const uint32_t src = widx < wend ? dq[widx - w0] : lane;
             const uint32_t r0 = __shfl(d0, src), r1 = __shfl(d1, src), r2 = __shfl(d2, src), re = __shfl(excl, src), rm = __shfl(meta, src);
             if (widx < wend) {

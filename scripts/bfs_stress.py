@@ -19,16 +19,28 @@ reads = po.synth_reads(genome, contigs, clen, 274713999, 0, n_reads, L, err)
 off = np.arange(n_reads + 1, dtype=np.uint64) * L
 t = po.Table()
 t.count_reads(reads, off, k, po.KEY_PACKED)
-ctx = mc.Context(k, mc.KEY_PACKED, 0, 6_000_000)
-ctx.set_coverage_hint(cov)
-h = n_reads // 2
-ctx.add_reads_packed(po.pack(reads[:off[h]]), off[:h + 1])
-ctx.add_reads_packed(po.pack(reads[off[h]:]), off[h:] - off[h])
-assert ctx.finalize() == t.size()
+FRESH = int(os.environ.get("STRESS_FRESH", 0))  # a new context every FRESH repeats (0: one context for all)
+packed0, packed1 = po.pack(reads[:off[n_reads // 2]]), po.pack(reads[off[n_reads // 2]:])
+
+
+def make_ctx():
+    c = mc.Context(k, mc.KEY_PACKED, 0, 6_000_000)
+    c.set_coverage_hint(cov)
+    h = n_reads // 2
+    c.add_reads_packed(packed0, off[:h + 1])
+    c.add_reads_packed(packed1, off[h:] - off[h])
+    assert c.finalize() == t.size()
+    return c
+
+
+ctx = make_ctx()
 rng = np.random.default_rng(5)
 bad = 0
 t0 = time.time()
 for rep in range(reps):
+    if FRESH and rep and rep % FRESH == 0:
+        ctx.close()
+        ctx = make_ctx()
     if rep % 50 == 0:
         s0 = int(rng.integers(0, clen - 600))
         seed = genome[s0:s0 + 400]
