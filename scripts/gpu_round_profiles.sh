@@ -10,7 +10,7 @@ timeout -k 10 300 python bench.py --no-cpu-baseline --config 2 --reads 10000000 
 timeout -k 10 600 python bench.py --no-cpu-baseline --config 2 --steps 2 --warmup 1 > gpurun_out/p/r03_bench_config2_full.json 2>/dev/null
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p/prof_e1 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --skip-no-hint > gpurun_out/p/prof_e1.log 2>&1
 for f in $(find gpurun_out/p/prof_e1 -name '*kernel_stats*.csv'); do cp $f gpurun_out/p/r03_e1_kernel_stats.csv; done
-MC_COMMIT=1dceba3 bash scripts/gpu_pmc.sh --skip-no-hint > gpurun_out/p/pmc.log 2>&1; cp gpurun_out/pmc_summary.csv gpurun_out/p/r03_pmc_hbm_traffic_e1.csv
+MC_COMMIT=fee1fda bash scripts/gpu_pmc.sh --skip-no-hint > gpurun_out/p/pmc.log 2>&1; cp gpurun_out/pmc_summary.csv gpurun_out/p/r03_pmc_hbm_traffic_e1.csv
 bash scripts/gpu_pmc_sq.sh r3f --skip-no-hint > gpurun_out/p/sq.log 2>&1; cp gpurun_out/sq_r3f_summary.csv gpurun_out/p/r03_sq_counters_e1.csv
 bash scripts/gpu_timeline.sh --skip-no-hint > /dev/null 2>&1; cp gpurun_out/timeline.txt gpurun_out/p/r03_timeline_e1.txt
 timeout -k 10 300 python scripts/rank_phases.py 8 > gpurun_out/p/r03_rank_phases_8owners.txt 2>&1
