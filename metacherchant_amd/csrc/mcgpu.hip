@@ -1366,9 +1366,9 @@ static int pipe_drain_handed_on(mc_ctx *c, uint64_t n_listed)
     // what the drain parked: into a table of twice the regions, until nothing is left (pipe_finish sees the new size)
     for (int attempt = 0;; attempt++) {
         unsigned long long m = 0;
-        HIPCHK(c, hipMemcpyAsync(c->h_scratch + 26, c->d_ctr + 7, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_scratch + 29, c->d_ctr + 7, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        m = c->h_scratch[26];
+        m = c->h_scratch[29];
         if (m == 0) return MC_OK;
         if (m > mc_ctx::OVF_CAP || attempt >= 6)
             return fail(c, MC_EOVERFLOW, "k-mer table regions keep overflowing (%llu additions parked); pass a capacity_hint (distinct k-mers)", m);

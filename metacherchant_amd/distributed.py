@@ -8,8 +8,8 @@ exchange the buckets with ONE all-to-all (all 7 xGMI links of a GPU busy at once
 and each rank counts only the keys it owns.  Counting is then identical to the 1-GPU path.  For
 the BFS the thresholded shards (count >= coverage: everything the BFS can ever ask for, since
 absent and below-threshold are indistinguishable to `occs >= minOccurences`,
-src/algo/OneSequenceCalculator.java:203-204) are all-gathered and merged into one "solid" table
-on the rank(s) that run the BFS; a distributed per-level BFS is rejected because the frontier is
+src/algo/OneSequenceCalculator.java:203-204) are sent to the rank that runs the BFS (or all-gathered when every rank does)
+and merged into one "solid" table there; a distributed per-level BFS is rejected because the frontier is
 typically one vertex wide.
 
 `backend` objects only need the Context methods used below, so the CPU (gloo) tests drive this
@@ -141,8 +141,8 @@ class ShardedCounter:
         return int(t.item())
 
     def gather_solid(self, solid_ctx, min_cov, dst=0):
-        """All-gather the (key, count >= min_cov, hint) entries of every shard and build solid_ctx's BFS table from
-        them on rank `dst` (pass dst=None to build it on every rank).  Returns the number of solid k-mers."""
+        """Brings the (key, count >= min_cov, hint) entries of every shard to rank `dst` (direct sends) and builds solid_ctx's
+        BFS table from them there; dst=None: an all-gather, and every rank builds it.  Returns the number of solid k-mers."""
         ctx, W = self.ctx, self.world
         if W == 1:
             return None  # the caller BFSes on ctx itself
@@ -151,6 +151,36 @@ class ShardedCounter:
         sizes_t = torch.empty(W, dtype=torch.int64, device=self.device)
         dist.all_gather_into_tensor(sizes_t, nt, group=self.group)
         sizes = [int(x) for x in sizes_t.cpu().tolist()]  # (one copy, not one per rank)
+        if dst is not None:
+            # Only `dst` builds a table: every rank SENDS its shard straight to it (all-to-alls in which the other ranks receive
+            # nothing: seven point-to-point transfers into dst over seven xGMI links at once, exact sizes) -- an all-gather
+            # would put all W shards, padded to the largest, on every rank (8 x 0.7 GB each way at configs[1] x 8, through
+            # whatever rings the library forms).
+            keys = torch.empty(max(n_local, 1), dtype=torch.int64, device=self.device)
+            cnts = torch.empty(max(n_local, 1), dtype=torch.int16, device=self.device)
+            hints = torch.empty(max(n_local, 1), dtype=torch.int32, device=self.device)
+            got = ctx.export_dev(min_cov, keys, cnts, max(n_local, 1), hints)
+            assert got == n_local
+            total = sum(sizes) if self.rank == dst else 0
+            all_k = torch.empty(max(total, 1), dtype=torch.int64, device=self.device)
+            all_c = torch.empty(max(total, 1), dtype=torch.int16, device=self.device)
+            all_h = torch.empty(max(total, 1), dtype=torch.int32, device=self.device)
+            send = [n_local if o == dst else 0 for o in range(W)]
+            recv = sizes if self.rank == dst else [0] * W
+            dist.all_to_all_single(all_k[:total], keys[:n_local], output_split_sizes=recv, input_split_sizes=send, group=self.group)
+            # counts travel as bytes: neither RCCL nor gloo has a 16-bit integer type
+            dist.all_to_all_single(all_c.view(torch.uint8)[:2 * total], cnts.view(torch.uint8)[:2 * n_local],
+                                   output_split_sizes=[2 * x for x in recv], input_split_sizes=[2 * x for x in send], group=self.group)
+            dist.all_to_all_single(all_h[:total], hints[:n_local], output_split_sizes=recv, input_split_sizes=send, group=self.group)
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
+            self.bytes_sent += 14 * (n_local if self.rank != dst else 0)
+            if self.rank == dst:
+                if hasattr(solid_ctx, "share_read_store"):
+                    solid_ctx.share_read_store(ctx)  # the pointers refer to this rank's reads
+                kept = solid_ctx.solid_from_pairs_dev(all_k, all_c, total, min_cov, all_h)
+                assert kept == sum(sizes), (kept, sizes)
+            return sum(sizes)
         mx = max(max(sizes), 1)
         keys = torch.zeros(mx, dtype=torch.int64, device=self.device)
         cnts = torch.full((mx,), -1, dtype=torch.int16, device=self.device)  # -1 marks the padding behind a short shard
