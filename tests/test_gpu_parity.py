@@ -315,6 +315,37 @@ def test_capacity_hint_a_quarter_of_what_the_reads_hold(mc, monkeypatch):
     ctx.close()
 
 
+def test_trim_gives_the_scratch_back_and_the_context_carries_on(mc, monkeypatch):
+    """mc_trim: the pipeline's scratch and the pools' idle blocks go back to the driver; the table, the read store and a valid
+    list of solid k-mers stay, so walks before and after are the same, and the next batch allocates its scratch again."""
+    import torch
+    monkeypatch.delenv("MC_COUNT_PATH", raising=False)
+    monkeypatch.setenv("MC_BFS_DIRECT", "0")  # (the walk's table is built from the merge kernel's list: it must survive the trim)
+    genome, reads, off = synth_case(2, 200000, 80000, 150, 50)
+    t, _ = oracle_table(reads, off, 31, po.KEY_PACKED)
+    half = 40000
+    t1, _ = oracle_table(reads[:off[half]], off[:half + 1], 31, po.KEY_PACKED)
+    seed = genome[10000:10500]
+    hi, lo = seed_windows(seed, 31)
+    ctx = mc.Context(31, mc.KEY_PACKED, 0, 3_000_000)
+    ctx.set_coverage_hint(5)
+    ctx.add_reads_packed(po.pack(reads[:off[half]]), off[:half + 1])
+    ctx.finalize()
+    free0 = torch.cuda.mem_get_info()[0]
+    ctx.trim()
+    assert torch.cuda.mem_get_info()[0] > free0  # something came back
+    assert_bfs_equal(ctx.bfs(hi, lo, 1, 5, 3000, -1), po.bfs(t1, 31, po.KEY_PACKED, [seed], 1, 5, 3000, -1))
+    assert ctx.stats().solid_list_builds == 1  # the list survived
+    ctx.add_reads_packed(po.pack(reads[off[half]:]), off[half:] - off[half])
+    assert ctx.finalize() == t.size()
+    ctx.trim()
+    gk, gc = ctx.export(1)
+    ok, oc = t.dump()
+    assert np.array_equal(gk, ok) and np.array_equal(gc, oc)
+    assert_bfs_equal(ctx.bfs(hi, lo, -1, 5, 3000, -1), po.bfs(t, 31, po.KEY_PACKED, [seed], -1, 5, 3000, -1))
+    ctx.close()
+
+
 def test_solid_list_from_the_merge_kernel(mc, monkeypatch):
     """With the threshold known while counting, the merge kernel lists the keys at or above it as it writes each
     region back (tables of more than 512 regions), and the BFS set-up builds its table from that list instead of
