@@ -266,6 +266,7 @@ struct mc_ctx {
 
     char *pin[16] = {};                // pinned staging buffers of h2d_fast, made on first use
     DevPool tok_pool;                  // scratch of the device tokeniser
+    int64_t extract_in_store = -1;     // mc_group: the reads the next mc_extract_*_dev call is given sit in the read store already, from this word on (consumed by that call)
     uint4 *d_ovf_tmp = nullptr;        // pipe_drain_handed_on: the list moved aside while it is drained
     uint32_t *d_ovf_leaf_tmp = nullptr;
     uint64_t ovf_tmp_cap = 0, ovf_leaf_tmp_cap = 0;
@@ -3214,7 +3215,9 @@ int mc_extract_keys_dev(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_of
         return fail(c, MC_EINVAL, "mc_extract_keys_dev: read_offsets[n_reads]=%llu but n_bases=%llu",
                     (unsigned long long)last_off, (unsigned long long)n_bases);
     if (d_keys) {  // (the pass that writes the keys: their read pointers refer to this context's read store)
-        int rrc = rs_append(c, d_words, first_off, last_off);
+        const int64_t in_store = c->extract_in_store;  // (mc_group: tokenised on this device, in the store already)
+        c->extract_in_store = -1;
+        int rrc = rs_append(c, d_words, first_off, last_off, in_store);
         if (rrc) return rrc;
     } else {
         c->cur_ptr_base = ~0ull;
@@ -3281,7 +3284,9 @@ int mc_extract_superkmers_dev(mc_ctx *c, const uint64_t *d_words, const uint64_t
         return fail(c, MC_EINVAL, "mc_extract_superkmers_dev: read_offsets[n_reads]=%llu but n_bases=%llu",
                     (unsigned long long)last_off, (unsigned long long)n_bases);
     {
-        int rrc = rs_append(c, d_words, first_off, last_off);
+        const int64_t in_store = c->extract_in_store;  // (mc_group: tokenised on this device, in the store already)
+        c->extract_in_store = -1;
+        int rrc = rs_append(c, d_words, first_off, last_off, in_store);
         if (rrc) return rrc;
     }
     // The pieces go into pipe.a_recs, where the merge kernel may have left the list of solid k-mers (P3Emit): from here on
@@ -4364,80 +4369,49 @@ int mc_group_set_coverage_hint(mc_group *g, int min_cov)
     return MC_OK;
 }
 
-int mc_group_add_reads_packed(mc_group *g, const uint64_t *words, const uint64_t *off, uint64_t n_reads)
+namespace {
+// what one device brings to an exchange: its share of the reads (device pointers) and, filled on the way, what it sends and receives
+struct GroupRank {
+    DevBuf<uint64_t> dw, doff, send, recv;   // reads uploaded here (host batches); what goes out (records: 2 words each, or keys) and what came in
+    DevBuf<uint32_t> send_p, recv_p;         // the read pointers that travel with them
+    std::vector<uint64_t> owner_off;         // owner o's piece of `send` = [owner_off[o], owner_off[o + 1])
+    uint64_t n_recv = 0;
+    const uint64_t *d_words = nullptr, *d_off = nullptr;  // the share: d_off[0 .. n_reads] index bases of d_words
+    uint64_t n_reads = 0, n_bases = 0, windows = 0;       // n_bases = d_off[n_reads]; windows: k-mer occurrences, or an upper bound
+    int64_t in_store = -1;                                // >= 0: the share sits in this device's read store from that word on
+};
+
+// every device: its share -> records (keys) bucketed by owner; the exchange; every device counts what it owns
+int group_exchange_count(mc_group *g, std::vector<GroupRank> &R)
 {
-    if (!g) return MC_EINVAL;
-    std::lock_guard<std::mutex> lk(g->mu);
-    if ((!words || !off) && n_reads) return gfail(g, MC_EINVAL, "mc_group_add_reads_packed: null pointer");
-    if (n_reads == 0) return MC_OK;
-    g->dirty = true;
     const size_t W = g->ctx.size();
-    if (W == 1) {
-        const int rc = mc_add_reads_packed(g->ctx[0], words, off, n_reads);
-        return rc ? gfail(g, rc, mc_last_error(g->ctx[0])) : MC_OK;
-    }
-    const int k = g->cfg.k;
     const bool sk = g->ctx[0]->sk_form;
     bool sk_batch = sk;  // this batch travels as super-k-mer records (false: as keys)
-    struct Rank {
-        DevBuf<uint64_t> dw, doff, send, recv;   // reads; what goes out (records: 2 words each, or keys) and what came in
-        DevBuf<uint32_t> send_p, recv_p;         // the read pointers that travel with them
-        std::vector<uint64_t> owner_off;         // owner o's piece of `send` = [owner_off[o], owner_off[o + 1])
-        uint64_t n_recv = 0;
-    };
-    std::vector<Rank> R(W);
-    // ---- every device: its share of the reads -> records (keys) bucketed by owner
-    int rc = per_rank(W, [&](size_t r) -> int {
+    auto extract = [&](size_t r, bool as_records) -> int {
         mc_ctx *c = g->ctx[r];
-        const uint64_t a = n_reads * r / W, b = n_reads * (r + 1) / W;
-        R[r].owner_off.assign(W + 1, 0);
-        if (a == b) return MC_OK;
+        GroupRank &X = R[r];
+        X.owner_off.assign(W + 1, 0);
+        if (X.n_reads == 0 || X.windows == 0) return MC_OK;
         if (hipSetDevice(c->cfg.device) != hipSuccess) return MC_EHIP;
-        const uint64_t w0 = off[a] / 32, w1 = (off[b] + 31) / 32 + 1, nb = off[b] - w0 * 32;
-        std::vector<uint64_t> rel(off + a, off + b + 1);
-        uint64_t windows = 0;
-        for (uint64_t i = 0; i < b - a; i++) {
-            const uint64_t len = rel[i + 1] - rel[i];
-            if (len >= (uint64_t)k) windows += len - (uint64_t)k + 1;
+        X.send.reset();
+        X.send_p.reset();
+        c->extract_in_store = X.in_store;
+        if (as_records) {
+            const uint64_t cap = mc_superkmer_capacity(c, X.windows, X.n_reads);
+            if (X.send.alloc(cap * 2) != hipSuccess || X.send_p.alloc(cap) != hipSuccess) return MC_ENOMEM;
+            return mc_extract_superkmers_dev(c, X.d_words, X.d_off, X.n_reads, X.n_bases, (uint32_t)W, X.send.p, X.send_p.p, cap, X.owner_off.data());
         }
-        for (auto &x : rel) x -= w0 * 32;
-        if (R[r].dw.alloc(w1 - w0) != hipSuccess || R[r].doff.alloc(b - a + 1) != hipSuccess) return MC_ENOMEM;
-        // (through the context's pinned staging buffers: a pageable copy runs at a third of the link's rate)
-        if (h2d_fast(c, R[r].dw.p, words + w0, (w1 - w0) * 8) != MC_OK || h2d_fast(c, R[r].doff.p, rel.data(), (b - a + 1) * 8) != MC_OK) return MC_EHIP;
-        if (windows == 0) return MC_OK;
-        if (sk) {
-            const uint64_t cap = mc_superkmer_capacity(c, windows, b - a);
-            if (R[r].send.alloc(cap * 2) != hipSuccess || R[r].send_p.alloc(cap) != hipSuccess) return MC_ENOMEM;
-            return mc_extract_superkmers_dev(c, R[r].dw.p, R[r].doff.p, b - a, nb, (uint32_t)W, R[r].send.p, R[r].send_p.p, cap, R[r].owner_off.data());
-        }
-        if (R[r].send.alloc(windows) != hipSuccess || R[r].send_p.alloc(windows) != hipSuccess) return MC_ENOMEM;
-        return mc_extract_keys_dev(c, R[r].dw.p, R[r].doff.p, b - a, nb, (uint32_t)W, reinterpret_cast<int64_t *>(R[r].send.p), R[r].send_p.p, windows,
-                                   R[r].owner_off.data());
-    });
+        if (X.send.alloc(X.windows) != hipSuccess || X.send_p.alloc(X.windows) != hipSuccess) return MC_ENOMEM;
+        return mc_extract_keys_dev(c, X.d_words, X.d_off, X.n_reads, X.n_bases, (uint32_t)W, reinterpret_cast<int64_t *>(X.send.p), X.send_p.p, X.windows,
+                                   X.owner_off.data());
+    };
+    int rc = per_rank(W, [&](size_t r) -> int { return extract(r, sk); });
     if (rc == MC_EOVERFLOW && sk) {
         // an owner's piece overflowed (reads of low complexity share one minimizer, hence one owner): this batch travels as
         // keys instead, on every rank alike -- one record per window, bucketed by the key's own hash, which cannot be skewed
         sk_batch = false;
         for (mc_ctx *c : g->ctx) c->err.clear();
-        rc = per_rank(W, [&](size_t r) -> int {
-            mc_ctx *c = g->ctx[r];
-            const uint64_t a = n_reads * r / W, b = n_reads * (r + 1) / W;
-            R[r].owner_off.assign(W + 1, 0);
-            if (a == b) return MC_OK;
-            if (hipSetDevice(c->cfg.device) != hipSuccess) return MC_EHIP;
-            uint64_t windows = 0;
-            for (uint64_t i = a; i < b; i++) {
-                const uint64_t len = off[i + 1] - off[i];
-                if (len >= (uint64_t)k) windows += len - (uint64_t)k + 1;
-            }
-            if (windows == 0) return MC_OK;
-            const uint64_t nb = off[b] - off[a] / 32 * 32;
-            R[r].send.reset();
-            R[r].send_p.reset();
-            if (R[r].send.alloc(windows) != hipSuccess || R[r].send_p.alloc(windows) != hipSuccess) return MC_ENOMEM;
-            return mc_extract_keys_dev(c, R[r].dw.p, R[r].doff.p, b - a, nb, (uint32_t)W, reinterpret_cast<int64_t *>(R[r].send.p), R[r].send_p.p, windows,
-                                       R[r].owner_off.data());
-        });
+        rc = per_rank(W, [&](size_t r) -> int { return extract(r, false); });
     }
     if (rc) {
         for (mc_ctx *c : g->ctx) if (!c->err.empty()) return gfail(g, rc, c->err);
@@ -4511,6 +4485,56 @@ int mc_group_add_reads_packed(mc_group *g, const uint64_t *words, const uint64_t
     }
     return MC_OK;
 }
+}  // namespace
+
+namespace {
+// a batch of packed reads in host memory: shares up to the devices, exchange, count (the caller holds the group's lock)
+int group_add_host_batch(mc_group *g, const uint64_t *words, const uint64_t *off, uint64_t n_reads)
+{
+    const size_t W = g->ctx.size();
+    const int k = g->cfg.k;
+    std::vector<GroupRank> R(W);
+    int rc = per_rank(W, [&](size_t r) -> int {
+        mc_ctx *c = g->ctx[r];
+        const uint64_t a = n_reads * r / W, b = n_reads * (r + 1) / W;
+        if (a == b) return MC_OK;
+        if (hipSetDevice(c->cfg.device) != hipSuccess) return MC_EHIP;
+        const uint64_t w0 = off[a] / 32, w1 = (off[b] + 31) / 32 + 1, nb = off[b] - w0 * 32;
+        std::vector<uint64_t> rel(off + a, off + b + 1);
+        uint64_t windows = 0;
+        for (uint64_t i = 0; i < b - a; i++) {
+            const uint64_t len = rel[i + 1] - rel[i];
+            if (len >= (uint64_t)k) windows += len - (uint64_t)k + 1;
+        }
+        for (auto &x : rel) x -= w0 * 32;
+        if (R[r].dw.alloc(w1 - w0) != hipSuccess || R[r].doff.alloc(b - a + 1) != hipSuccess) return MC_ENOMEM;
+        // (through the context's pinned staging buffers: a pageable copy runs at a third of the link's rate)
+        if (h2d_fast(c, R[r].dw.p, words + w0, (w1 - w0) * 8) != MC_OK || h2d_fast(c, R[r].doff.p, rel.data(), (b - a + 1) * 8) != MC_OK) return MC_EHIP;
+        R[r].d_words = R[r].dw.p; R[r].d_off = R[r].doff.p;
+        R[r].n_reads = b - a; R[r].n_bases = nb; R[r].windows = windows;
+        return MC_OK;
+    });
+    if (rc) {
+        for (mc_ctx *c : g->ctx) if (!c->err.empty()) return gfail(g, rc, c->err);
+        return gfail(g, rc, "mc_group_add_reads_packed: the reads did not reach the devices");
+    }
+    return group_exchange_count(g, R);
+}
+}  // namespace
+
+int mc_group_add_reads_packed(mc_group *g, const uint64_t *words, const uint64_t *off, uint64_t n_reads)
+{
+    if (!g) return MC_EINVAL;
+    std::lock_guard<std::mutex> lk(g->mu);
+    if ((!words || !off) && n_reads) return gfail(g, MC_EINVAL, "mc_group_add_reads_packed: null pointer");
+    if (n_reads == 0) return MC_OK;
+    g->dirty = true;
+    if (g->ctx.size() == 1) {
+        const int rc = mc_add_reads_packed(g->ctx[0], words, off, n_reads);
+        return rc ? gfail(g, rc, mc_last_error(g->ctx[0])) : MC_OK;
+    }
+    return group_add_host_batch(g, words, off, n_reads);
+}
 
 int mc_group_add_reads_file(mc_group *g, const char *path, uint64_t *n_reads)
 {
@@ -4527,6 +4551,164 @@ int mc_group_add_reads_file(mc_group *g, const char *path, uint64_t *n_reads)
         // 2^20 reads a batch, as before, a billion reads meant 119 rewrites of a 100 GB-class table per device.
         static const uint64_t per_dev = [] { const char *e = getenv("MC_GROUP_BATCH_READS"); return e && *e ? std::max<uint64_t>(strtoull(e, nullptr, 10), 1024) : 1ull << 24; }();
         int rc = MC_OK;
+        // Uncompressed FASTA / FASTQ: tokenised on the FIRST device (csrc/tokenizer.h, chunk i + 1 crossing PCIe while chunk i
+        // is tokenised), into its read store -- the one the walk reads --; when W x per_dev reads have gathered, or the file
+        // ends, the other devices fetch their shares of the packed reads from it (device to device) and the batch is exchanged
+        // and counted.  A chunk the device declines goes through the host reader like any other file.
+        const char *mode = getenv("MC_TOKENIZER");
+        mch::PlainReadsFile f;
+        if (!(mode && !strcmp(mode, "host")) && g->ctx[0]->rs_enabled && mch::map_plain_reads(path, &f)) {
+            std::lock_guard<std::mutex> lk(g->mu);
+            g->dirty = true;
+            mc_ctx *c0 = g->ctx[0];
+            const size_t W = g->ctx.size();
+            const char *e_chunk = getenv("MC_TOKENIZER_CHUNK_BYTES");
+            const uint64_t chunk = std::min<uint64_t>(std::max<uint64_t>(e_chunk && *e_chunk ? strtoull(e_chunk, nullptr, 10) : (1ull << 28), 64), 3ull << 29);
+            std::vector<std::pair<const char *, const char *>> cuts;
+            for (const char *b = f.p, *end = f.p + f.n; b < end;) {
+                const char *e = (uint64_t)(end - b) <= chunk + chunk / 4 ? end : mch::plain_record_start(f, b + chunk);
+                cuts.emplace_back(b, e);
+                b = e;
+            }
+            {
+                std::lock_guard<std::mutex> g0(c0->mu);
+                HIPCHK(c0, hipSetDevice(c0->cfg.device));
+                const int r = rs_reserve(c0, (f.fastq ? f.n / 2 : f.n) / 32 + 2 * cuts.size() + 2);
+                if (r) return gfail(g, r, c0->err);
+            }
+            std::unique_ptr<TokPending> pend(new TokPending);
+            auto drop_pend = [&] { std::lock_guard<std::mutex> g0(c0->mu); pend.reset(); };
+            uint64_t total = 0, n_flushes = 0;
+            // the reads gathered in `pend` so far: shares to the devices, exchange, count; the store then ends behind them
+            auto flush = [&]() -> int {
+                if (pend->reads == 0) { pend->base_word = -1; pend->bases = 0; return MC_OK; }
+                n_flushes++;
+                const uint64_t n = pend->reads, base_word = (uint64_t)pend->base_word;
+                std::vector<uint64_t> cut_off(W + 1, 0);  // base offset (relative to the batch) of every share's first read
+                {
+                    std::lock_guard<std::mutex> g0(c0->mu);
+                    if (hipSetDevice(c0->cfg.device) != hipSuccess) return gfail(g, MC_EHIP, "mc_group_add_reads_file: hipSetDevice");
+                    for (size_t r = 0; r <= W; r++)
+                        if (hipMemcpyAsync(&cut_off[r], pend->off.p + n * r / W, 8, hipMemcpyDeviceToHost, c0->stream) != hipSuccess) return gfail(g, MC_EHIP, "mc_group_add_reads_file: copy failed");
+                    if (hipStreamSynchronize(c0->stream) != hipSuccess) return gfail(g, MC_EHIP, "mc_group_add_reads_file: copy failed");
+                }
+                std::vector<GroupRank> R(W);
+                int frc = per_rank(W, [&](size_t r) -> int {
+                    mc_ctx *c = g->ctx[r];
+                    const uint64_t a = n * r / W, b = n * (r + 1) / W;
+                    if (a == b) return MC_OK;
+                    GroupRank &X = R[r];
+                    X.n_reads = b - a;
+                    X.n_bases = cut_off[r + 1];
+                    X.windows = cut_off[r + 1] - cut_off[r];  // (an upper bound: a window per base)
+                    if (r == 0) {  // in place: the share is where the walk will read it
+                        X.d_words = c0->rs_words + base_word;
+                        X.d_off = pend->off.p;
+                        X.in_store = (int64_t)base_word;
+                        return MC_OK;
+                    }
+                    // the words [w0, w1] of the share and its offsets come over; d_words is handed on as if it held the batch from
+                    // its first word (the offsets stay relative to the batch: nothing below w0 is looked at)
+                    if (hipSetDevice(c->cfg.device) != hipSuccess) return MC_EHIP;
+                    // (with 512 words before the share's first: the extract kernels load whole tiles, up to 8191 bases ahead of it)
+                    const uint64_t w0 = std::max<uint64_t>(cut_off[r] / 32, 512) - 512, w1 = (cut_off[r + 1] + 31) / 32 + 1;
+                    if (X.dw.alloc(w1 - w0) != hipSuccess || X.doff.alloc(b - a + 1) != hipSuccess) return MC_ENOMEM;
+                    if (peer_copy(X.dw.p, c, c0->rs_words + base_word + w0, c0, (w1 - w0) * 8, c->stream) != hipSuccess ||
+                        peer_copy(X.doff.p, c, pend->off.p + a, c0, (b - a + 1) * 8, c->stream) != hipSuccess ||
+                        hipStreamSynchronize(c->stream) != hipSuccess)
+                        return MC_EHIP;
+                    X.d_words = X.dw.p - w0;
+                    X.d_off = X.doff.p;
+                    return MC_OK;
+                });
+                if (frc) return gfail(g, frc, "mc_group_add_reads_file: the shares did not reach the devices");
+                frc = group_exchange_count(g, R);
+                {   // the batch's reads stay in the first device's store, whoever counted them
+                    std::lock_guard<std::mutex> g0(c0->mu);
+                    c0->rs_bases = std::max<uint64_t>(c0->rs_bases, (base_word + (pend->bases + 31) / 32) * 32);
+                }
+                pend->reads = pend->bases = 0;
+                pend->base_word = -1;
+                return frc;
+            };
+            struct Upload {
+                PoolBuf<uint8_t> text;
+                std::thread th;
+                bool ok = true;
+            };
+            std::unique_ptr<Upload> cur, nxt;
+            auto start_upload = [&](size_t i, std::unique_ptr<Upload> &u) -> int {
+                u.reset(new Upload);
+                const uint64_t n = (uint64_t)(cuts[i].second - cuts[i].first);
+                {
+                    std::lock_guard<std::mutex> g0(c0->mu);
+                    HIPCHK(c0, hipSetDevice(c0->cfg.device));
+                    HIPCHK(c0, u->text.alloc(&c0->tok_pool, (n + tok::T_TILE - 1) / tok::T_TILE * tok::T_TILE));
+                }
+                Upload *up = u.get();
+                const char *b = cuts[i].first;
+                up->th = std::thread([c0, up, b, n, &f] { up->ok = h2d_pinned(c0, up->text.p, b, n, f.fd, (uint64_t)(b - f.p)); });
+                return MC_OK;
+            };
+            auto finish = [&](std::unique_ptr<Upload> &u) {
+                if (!u) return;
+                if (u->th.joinable()) u->th.join();
+                std::lock_guard<std::mutex> g0(c0->mu);
+                u.reset();
+            };
+            rc = cuts.empty() ? MC_OK : start_upload(0, cur);
+            if (rc) rc = gfail(g, rc, c0->err);
+            for (size_t i = 0; i < cuts.size() && rc == MC_OK; i++) {
+                cur->th.join();
+                if (!cur->ok) { rc = gfail(g, MC_EHIP, "mc_group_add_reads_file: host-to-device copy failed"); break; }
+                if (i + 1 < cuts.size()) {
+                    rc = start_upload(i + 1, nxt);
+                    if (rc) { rc = gfail(g, rc, c0->err); break; }
+                }
+                uint64_t got = 0;
+                bool declined = false;
+                {
+                    std::lock_guard<std::mutex> g0(c0->mu);
+                    rc = tokenize_chunk_locked(c0, f, cuts[i].first, cuts[i].second, cur->text.p, &got, &declined, pend.get());
+                    if (rc) rc = gfail(g, rc, c0->err);
+                }
+                if (rc != MC_OK) break;
+                if (declined) {  // (what was gathered goes first: the host's batches are appended behind it)
+                    rc = flush();
+                    if (rc != MC_OK) break;
+                    int hrc = MC_OK;
+                    try {
+                        got = mch::parse_plain_range(f, cuts[i].first, cuts[i].second, W * per_dev, [&](mch::PackedBatch &b) {
+                            if (hrc == MC_OK && b.n_reads()) hrc = group_add_host_batch(g, b.words.data(), b.offsets.data(), b.n_reads());
+                        });
+                    } catch (...) {
+                        finish(cur);
+                        finish(nxt);
+                        drop_pend();
+                        throw;
+                    }
+                    rc = hrc;
+                    if (rc != MC_OK) break;
+                }
+                total += got;
+                if (pend->reads >= W * per_dev) {
+                    rc = flush();
+                    if (rc != MC_OK) break;
+                }
+                finish(cur);
+                cur = std::move(nxt);
+            }
+            finish(cur);
+            finish(nxt);
+            if (rc == MC_OK) rc = flush();
+            drop_pend();
+            if (rc != MC_OK) return rc;
+            if (getenv("MC_INGEST_DEBUG"))
+                fprintf(stderr, "[ingest] group: %zu chunk(s) tokenised on device %d, %llu reads in %llu exchange(s) over %zu devices\n", cuts.size(), c0->cfg.device,
+                        (unsigned long long)total, (unsigned long long)n_flushes, W);
+            if (n_reads) *n_reads = total;
+            return MC_OK;
+        }
         const uint64_t n = mch::load_reads_file(path, g->ctx.size() * per_dev, [&](mch::PackedBatch &b) {
             if (rc == MC_OK) rc = mc_group_add_reads_packed(g, b.words.data(), b.offsets.data(), b.n_reads());
         });

@@ -355,7 +355,11 @@ def test_cli_config5_four_environments_then_multi_join(cli, tmp_path):
                                                 # exchanges of 3 x 833 reads: the FASTQ's last one holds TWO reads, so a share extracts
                                                 # (into the buffer its list of solid k-mers sat in) and then owns nothing of the batch:
                                                 # the list must not be taken for valid
-                                                ("0,0,0", 31, ["--maxkmers", "4000", "--coverage", "3"], {"MC_GROUP_BATCH_READS": "833"})])
+                                                ("0,0,0", 31, ["--maxkmers", "4000", "--coverage", "3"], {"MC_GROUP_BATCH_READS": "833", "MC_TOKENIZER": "host"}),
+                                                # the files tokenised on the first device in chunks of ~1000 reads, the other devices
+                                                # fetching their shares from its read store: several exchanges a file
+                                                ("0,0,0", 31, ["--maxkmers", "4000", "--coverage", "3"],
+                                                 {"MC_GROUP_BATCH_READS": "1024", "MC_TOKENIZER_CHUNK_BYTES": "160000", "MC_INGEST_DEBUG": "1"})])
 def test_cli_several_devices_equal_one(cli, tmp_path, devices, k, extra, env):
     """`--devices a,b,...`: reads dealt to the devices, super-k-mer records (keys for k < 23 and hash keys) exchanged by owner
     with peer copies, every device counts what it owns, the solid shards are gathered on the first for the BFS -- the
@@ -383,6 +387,9 @@ def test_cli_several_devices_equal_one(cli, tmp_path, devices, k, extra, env):
         assert p.returncode == 0, p.stderr[-2000:]
         outs[name] = (out, p.stderr)
     assert "Counting on %d devices" % len(devices.split(",")) in outs["many"][1]
+    if "MC_INGEST_DEBUG" in env:  # (the device path ran, in several exchanges)
+        lines = [l for l in outs["many"][1].splitlines() if "[ingest] group:" in l]
+        assert len(lines) == 2 and all(int(l.split(" reads in ")[1].split()[0]) >= 2 for l in lines), outs["many"][1][-2000:]
     size_line = [l for l in outs["one"][1].splitlines() if "Hashtable size" in l][0].split("Hashtable size")[1]
     assert ("Hashtable size" + size_line) in outs["many"][1]  # owners are disjoint: the shards add up to the one table
     kw = {}
