@@ -109,6 +109,11 @@ for it in range(iters):
         cl = int(rng.choice([1, 10, 50])); kw["chunk_length"] = cl; extra += ["--chunklength", str(cl)]
         if hashed:
             extra += ["--hash", hname] + ([] if k > 31 else ["--forcehash"])
+        env_extra = {}
+        if os.environ.get("SOAK_DEVICES") and rng.integers(0, 2) == 0:  # the native multi-device driver on shares of this GPU: same files out
+            extra += ["--devices", ",".join(["0"] * int(rng.integers(2, 4)))]
+            if rng.integers(0, 2) == 0:  # several exchanges a file; small tokeniser chunks
+                env_extra = {"MC_GROUP_BATCH_READS": str(int(rng.choice([1024, 3000]))), "MC_TOKENIZER_CHUNK_BYTES": str(int(rng.choice([40000, 300000])))}
         out, want = os.path.join(tmp, "out"), os.path.join(tmp, "want")
         cmd = [build.CLI, "-k", str(k), "--reads"] + files + ["--seq", seq, "-o", out, "-w", os.path.join(tmp, "wd"), "--force"] + extra
         print("it %d: %s" % (it, " ".join(cmd[1:])), flush=True)
@@ -125,7 +130,7 @@ for it in range(iters):
         if it < int(os.environ.get("SOAK_FROM", "0")):
             continue
         try:
-            p = subprocess.run(cmd, capture_output=True, text=True, timeout=int(os.environ.get("SOAK_CLI_TIMEOUT", "120")))
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=int(os.environ.get("SOAK_CLI_TIMEOUT", "120")), env=dict(os.environ, **env_extra))
         except subprocess.TimeoutExpired as e:
             err = e.stderr.decode() if isinstance(e.stderr, bytes) else (e.stderr or "")
             raise SystemExit("it %d: the CLI did not finish; its log ends:\n%s" % (it, err[-1500:]))
