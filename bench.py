@@ -226,8 +226,12 @@ def main():
             # scatters the records (or keys) received from the other ranks instead of extracting them from reads
             sk = mode == m.KEY_PACKED and k >= 23 and os.environ.get("MC_SUPERKMERS") != "0"
             p1 = ("k_sk1w_extract" if world == 1 else "k_sk1_records") if sk else ("k_p1_extract_scatter" if world == 1 else "k_p1_keys_scatter")
+            # (the merge kernel of super-k-mer records on one GPU with one region per leaf is k_p3_dedup; the level-2 kernel of a
+            # hinted one-GPU run k_sk2_scatter_compact: the names rocprofv3 prints)
+            dedup = sk and os.environ.get("MC_P3_DEDUP") != "0" and st.table_slots <= (1 << 21) * 4096
+            p3 = "k_p3_dedup" if dedup else "k_p3_merge"
             parts = {p1: st.p1_ms / launches, "k_sk2_scatter" if sk else "k_p2_scatter": st.p2_ms / launches,
-                     "k_p3_merge": st.p3_ms / launches}
+                     p3: st.p3_ms / launches}
             pipeline = st.p3_ms > 0
             dominant = max(parts, key=parts.get) if pipeline else "k_count_reads"
             # HBM bytes per pipeline run from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH_SIZE doubled
