@@ -2150,11 +2150,22 @@ static int rs_reserve(mc_ctx *c, uint64_t more_words)
     const uint64_t used = c->rs_bases / 32, need = used + more_words + 2;
     if (need <= c->rs_cap_words) return MC_OK;
     uint64_t cap = std::max<uint64_t>(c->rs_cap_words * 2, std::max<uint64_t>(need, 1ull << 20));
+    // (from the process-wide pool of large blocks, like the pipeline's scratch: a context's read store handed back with
+    // hipFree is reclaimed lazily, and a later context's first launch waits for it)
     uint64_t *nw = nullptr;
-    HIPCHK(c, dev_malloc(c, reinterpret_cast<void **>(&nw), cap * 8));
+    size_t got = 0;
+    hipError_t e = g_scratch_pool.get(c->cfg.device, cap * 8, reinterpret_cast<void **>(&nw), &got);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        g_table_pool.release(c->cfg.device);
+        g_scratch_pool.release(c->cfg.device);
+        e = g_scratch_pool.get(c->cfg.device, cap * 8, reinterpret_cast<void **>(&nw), &got);
+    }
+    HIPCHK(c, e);
+    cap = std::max<uint64_t>(cap, got / 8);
     if (used) HIPCHK(c, hipMemcpyAsync(nw, c->rs_words, used * 8, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->rs_words) (void)hipFree(c->rs_words);
+    g_scratch_pool.put(c->cfg.device, c->rs_words, c->rs_cap_words * 8);
     c->rs_words = nw;
     c->rs_cap_words = cap;
     return MC_OK;
@@ -2377,7 +2388,7 @@ void mc_destroy(mc_ctx *c)
     if (c->d_ovf_leaf_tmp) (void)hipFree(c->d_ovf_leaf_tmp);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
-    if (c->rs_words) (void)hipFree(c->rs_words);
+    g_scratch_pool.put(c->cfg.device, c->rs_words, c->rs_cap_words * 8);
     for (auto &e : c->ev_piece) if (e) (void)hipEventDestroy(e);
     if (c->ev_p2) (void)hipEventDestroy(c->ev_p2);
     for (auto &e : c->ev_t) if (e) (void)hipEventDestroy(e);
