@@ -53,6 +53,9 @@ extern "C" {
 #define MC_EOVERFLOW (-5) /* an internal capacity was exceeded and could not be grown */
 #define MC_ENOSEED (-6)   /* no seed k-mer reaches min_cov: the reference's "fail"
                              (src/algo/OneSequenceCalculator.java:193-196) */
+#define MC_ECHECK (-7)    /* debugging only: MC_BFS_SELFCHECK=1 was set and a finished walk broke an invariant of
+                             runBfs (no duplicate vertices, coverages as in the table, queue order, every vertex
+                             has a parent); the message lists what */
 
 /* Key modes, chosen exactly as src/tools/EnvironmentFinderMain.java:128-136,157-169:
  * k <= 31 and !forcehash -> PACKED (key = min(fw, rc) of the 2-bit packed k-mer as signed long,

@@ -53,6 +53,44 @@ constexpr uint32_t LH_EMPTY = 0xFFFFFFFFu;
 
 enum { BFS_RUNNING = 0, BFS_DONE = 1, BFS_NEED_GROW = 2 };
 
+// ---- debugging aids of the walk (tuning builds only; the product library is built without them) ------------------------
+// -DMC_BFS_FUZZ: every workgroup barrier of the walk is followed by a pause that differs from wave to wave and from time
+// to time, so that the waves of a workgroup run the stretch behind it far out of step.  What is only ordered by "the other
+// waves cannot be that late" breaks within a few walks instead of once in 10^7 (tests/test_gpu_bfs_race.py).
+#ifdef MC_BFS_FUZZ
+__device__ __forceinline__ void bfs_fuzz(uint32_t point)
+{
+    uint32_t x = (uint32_t)__builtin_readcyclecounter() ^ (point * 0x9E3779B1u) ^ ((threadIdx.x >> 6) * 0x85EBCA6Bu) ^ (blockIdx.x * 0xC2B2AE35u);
+    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
+    x = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
+    if ((x & 3u) == 0) {
+        const uint32_t n = (x & 0x40u) ? (x >> 8) & 63u : (x >> 8) & 7u;  // mostly a few hundred cycles, now and then a few thousand
+        for (uint32_t i = 0; i < n; i++) __builtin_amdgcn_s_sleep(1);
+    }
+}
+#define BFS_FUZZ(p) bfs_fuzz(p)
+#else
+#define BFS_FUZZ(p) do {} while (0)
+#endif
+#define BFS_SYNC() do { __syncthreads(); BFS_FUZZ(__LINE__); } while (0)
+
+// -DMC_BFS_TRACE: a ring of 8-word records per job, one per narrow round (tid 0) and one per run of the companion; the host
+// dumps it when the self-check of a walk (k_bfs_check) finds something, or always with MC_BFS_TRACE_DUMP=<file>.
+constexpr uint32_t BFS_TRACE_RECORDS = 1u << 16;
+#ifdef MC_BFS_TRACE
+#define BFS_TRACE(S, w0, w1, w2, w3, w4, w5, w6, w7)                                                              \
+    do {                                                                                                          \
+        if ((S).trace) {                                                                                          \
+            const unsigned long long ti_ = atomicAdd(&(S).ctl->trace_n, 1ull) & (BFS_TRACE_RECORDS - 1);          \
+            uint4 *tp_ = reinterpret_cast<uint4 *>((S).trace + 8 * ti_);                                          \
+            tp_[0] = make_uint4((uint32_t)(w0), (uint32_t)(w1), (uint32_t)(w2), (uint32_t)(w3));                  \
+            tp_[1] = make_uint4((uint32_t)(w4), (uint32_t)(w5), (uint32_t)(w6), (uint32_t)(w7));                  \
+        }                                                                                                         \
+    } while (0)
+#else
+#define BFS_TRACE(S, w0, w1, w2, w3, w4, w5, w6, w7) do {} while (0)
+#endif
+
 struct BfsCtl {
     unsigned long long n;       // |distanceToKmer|
     unsigned long long lb, le;  // current frontier = entries [lb, le)
@@ -60,6 +98,7 @@ struct BfsCtl {
     unsigned long long lookups;
     unsigned long long rounds_narrow, rounds_slow, chunks_wide, scout_hops, scout_levels, scout_calls, scout_nf, scout_m0, slow_mismatch, slow_starved, slow_forced;
     unsigned long long tacc[8];  // MC_BFS_TIMING builds: 10 ns ticks per phase of a narrow round
+    unsigned long long trace_n;  // MC_BFS_TRACE builds: records written to BfsState::trace so far
     long long level;            // distance of the frontier
     int status;
     int seeds_done;
@@ -77,6 +116,7 @@ struct BfsState {
     BfsCtl *ctl;
     uint64_t *path;     // SCOUT_MAX_F * PATH_WORDS words: the predicted paths of the walkers (scout_run)
     ScoutBox *box;      // mailbox between this job's workgroup and its scouting companion (nullptr: none)
+    uint32_t *trace;    // MC_BFS_TRACE builds: BFS_TRACE_RECORDS records of 8 words (nullptr: none)
     const uint64_t *seed_hi, *seed_lo;
     uint64_t n_seeds;
     int dir;
@@ -209,7 +249,7 @@ __device__ __forceinline__ uint32_t block_scan_flag(bool flag, uint32_t *lds_wav
     const unsigned long long m = __ballot(flag);
     const uint32_t in_wave = (uint32_t)__popcll(m & ((1ull << lane) - 1));
     if (lane == 0) lds_wave_tot[wv] = (uint32_t)__popcll(m);
-    __syncthreads();
+    BFS_SYNC();
     uint32_t before = 0, tot = 0;
     const uint32_t n_waves = blockDim.x >> 6;
     for (uint32_t i = 0; i < n_waves; i++) {
@@ -217,7 +257,7 @@ __device__ __forceinline__ uint32_t block_scan_flag(bool flag, uint32_t *lds_wav
         if (i < wv) before += c;
         tot += c;
     }
-    __syncthreads();
+    BFS_SYNC();
     *total = tot;
     return before + in_wave;
 }
@@ -299,10 +339,10 @@ __device__ void bfs_chunk_wide(const BfsState &S, const SolidView &t, WideLds &L
             contender = true;
         }
     }
-    __syncthreads();
+    BFS_SYNC();
     uint32_t slot = 0;
     if (contender) slot = lds_set_min(L.set, WH_SIZE - 1, L.kmer, cand, tid);
-    __syncthreads();
+    BFS_SYNC();
     const bool winner = contender && L.set[slot] == tid;
     if (contender && !winner && !is_seed) mark_last = true;  // an earlier rank inserts it first
     uint32_t total;
@@ -331,7 +371,7 @@ __device__ void bfs_chunk_wide(const BfsState &S, const SolidView &t, WideLds &L
         if (wi != LH_EMPTY) atomicOr(&S.flags[wi], 2u);
     }
     if (tid == 0) ctl_st(&ctl->n, n_before + n_acc);
-    __syncthreads();
+    BFS_SYNC();
 }
 
 // number of tree nodes under ONE root down to depth d: nb + nb^2 + ... + nb^d
@@ -882,9 +922,9 @@ __device__ void scout_companion(const BfsState &S, const SolidView &t, TeamLds &
     (void)tsc;
     for (;;) {
         if (tid == 0) { L.seq = ld_u32(&box->req_seq); L.quit = ld_u32(&box->quit); }
-        __syncthreads();
+        BFS_SYNC();
         const uint32_t seq = L.seq, quit = L.quit;
-        __syncthreads();
+        BFS_SYNC();
         if (quit) break;
         if (seq == last_seq) {
             if (++idle > BOX_IDLE_POLLS) break;
@@ -908,7 +948,7 @@ __device__ void scout_companion(const BfsState &S, const SolidView &t, TeamLds &
             L.cdelta[tid][0] = 0;
             L.nc[tid] = p0 ? 1 : 0;
         }
-        __syncthreads();
+        BFS_SYNC();
         const uint32_t F = min(L.F, (uint32_t)SCOUT_MAX_F), budget = min(L.budget, PATH_CAP);
         if (F == 0) continue;
         uint32_t Tm = min(W, (uint32_t)MC_TEAM_MAX);  // team size: the largest power of two with F * Tm <= W
@@ -920,11 +960,11 @@ __device__ void scout_companion(const BfsState &S, const SolidView &t, TeamLds &
             const PathTail T0 = path_open(P, L.X[g], k, lane == 0);
             if (lane == 0) { L.T[g] = T0; P[T0.wi] = T0.tailw; P[T0.wi + 1] = 0; }
         }
-        __syncthreads();
+        BFS_SYNC();
         // ---- hops, all teams in step
         HopEval R;
         if (tid < SCOUT_MAX_F) L.staged[tid] = 0;
-        __syncthreads();
+        BFS_SYNC();
         for (;;) {
             uint32_t probe = seq;
             if (tid == 0) probe = ld_u32(&box->req_seq) | (ld_u32(&box->quit) << 31);  // (used at the end of the hop)
@@ -950,7 +990,7 @@ __device__ void scout_companion(const BfsState &S, const SolidView &t, TeamLds &
             // -- a release fence at agent scope right behind the stores would cost a cache write-back on every hop.
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             const uint32_t lv_done = tid < F ? L.levels[tid] : 0;  // (read before the barrier: this hop's winner changes it behind it)
-            __syncthreads();
+            BFS_SYNC();
             if (tid < F && lv_done != L.published[tid]) {
                 st_u32(&box->resp[tid], box_resp(seq, false, lv_done));
                 L.published[tid] = lv_done;
@@ -982,7 +1022,7 @@ __device__ void scout_companion(const BfsState &S, const SolidView &t, TeamLds &
             }
             if (tid == 0 && probe != seq) L.stop = 1;
             if (tid == 0) iters++;
-            __syncthreads();
+            BFS_SYNC();
 #ifdef MC_SCOUT_TIMING
             { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); tsc[4] += n_ - tq_; tsc[5]++; }
 #endif
@@ -991,11 +1031,12 @@ __device__ void scout_companion(const BfsState &S, const SolidView &t, TeamLds &
             if (!any || L.stop) break;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __syncthreads();
+        BFS_SYNC();
         if (!L.stop && tid < F) st_u32(&box->resp[tid], box_resp(seq, true, L.levels[tid]));
         if (tid == 0) { atomicAdd(&box->calls, 1ull); if (L.stop) atomicAdd(&box->e_stop, 1ull); else if (L.levels[0] >= budget) atomicAdd(&box->e_budget, 1ull); }
+        if (tid == 0) BFS_TRACE(S, 8u << 24 | (seq & 0xFFFFFF), F | Tm << 8 | L.stop << 16, L.levels[0], F > 1 ? L.levels[1] : 0u, budget, L.stuck[0] | (F > 1 ? L.stuck[1] : 0u) << 8, (uint32_t)iters, 0u);
         if (tid < F) atomicAdd(&box->levels, (unsigned long long)L.levels[tid]);
-        __syncthreads();
+        BFS_SYNC();
     }
 #ifdef MC_SCOUT_TIMING
     if (tid == 0 && tsc[5]) printf("[scout companion] %llu iterations, us each: fetch words %.2f, find tip + hash %.2f, look up %.2f, rest of eval %.2f, barriers + winner %.2f\n", tsc[5], tsc[0] * 0.01 / tsc[5], tsc[1] * 0.01 / tsc[5], tsc[2] * 0.01 / tsc[5], tsc[3] * 0.01 / tsc[5], tsc[4] * 0.01 / tsc[5]);
@@ -1068,7 +1109,7 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
             L.root_bad = 0;
         }
     }
-    __syncthreads();
+    BFS_SYNC();
 
     // the path words the next round reads, for every walker (requested while the previous round still appends)
     auto load_pseg = [&](uint32_t F) {
@@ -1126,6 +1167,15 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
                 // wait until every walker has something ahead of it (or is known to have nothing)
                 bool used_up = true;
                 for (uint32_t a = 0; a < F; a++) used_up = used_up && L.pdone[a] != 0;
+#ifndef MC_BFS_OLD_RACE
+                // `avail` and `used_up` decide which barriers a wave meets, and the threads that poll the mailbox below store
+                // to the very words they were read from (plen, pdone): no wave may get that far while another still reads.
+                // (Round 3 had no barrier here.  A wave that shares its SIMD with another kernel's waves can be microseconds
+                // late: it then saw a path where the others saw none, left this branch and ran one barrier out of step with
+                // its workgroup from there on -- the vertices of the last round entered the index too late for the look-ups
+                // that needed them, and the walk appended vertices it already had: gpurun_out/soak_r3.log:80.)
+                BFS_SYNC();
+#endif
                 uint32_t seq = seq0;
                 if (!open0 || used_up) {
                     seq = seq0 + 1;
@@ -1142,9 +1192,20 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
                         box->right[tid] = L.wright[tid];
                     }
                     if (tid == 0) { box->F = F; box->budget = (uint32_t)min((long long)PATH_CAP, lv_left); }
+#ifdef MC_BFS_OLD_RACE
+                    // (round 3 as shipped: the reset in front of the barrier.  `avail` and `used_up` above come from these very
+                    // words, and they decide whether a wave takes this branch and its barriers: a wave late enough to read the
+                    // new plen beside the old ppos gets avail = 2^32 - ppos, leaves the branch and is one barrier out of step with
+                    // the rest of the workgroup from then on -- tests/test_gpu_bfs_race.py builds this on purpose.)
                     if (tid < SCOUT_MAX_F) { L.plen[tid] = 0; L.ppos[tid] = 0; L.pdone[tid] = 0; }
+#endif
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    __syncthreads();
+                    BFS_SYNC();
+#ifndef MC_BFS_OLD_RACE
+                    // behind the barrier: every wave has taken its decisions from the old values (the polling below starts
+                    // with these threads' own stores, then a barrier)
+                    if (tid < SCOUT_MAX_F) { L.plen[tid] = 0; L.ppos[tid] = 0; L.pdone[tid] = 0; }
+#endif
                     if (tid == 0) { st_u32(&box->req_seq, seq); L.req_seq = seq; L.req_open = 1; }
                 }
                 bool ready = false;
@@ -1153,10 +1214,10 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
                         const uint32_t r = ld_u32(&box->resp[tid]);
                         if ((r >> 17) == (seq & 0x7FFFu)) { L.plen[tid] = r & 0xFFFFu; L.pdone[tid] = (r >> 16) & 1u; }
                     }
-                    __syncthreads();
+                    BFS_SYNC();
                     ready = true;
                     for (uint32_t a = 0; a < F; a++) ready = ready && (L.plen[a] > L.ppos[a] || L.pdone[a]);
-                    __syncthreads();
+                    BFS_SYNC();
                     if (!ready) __builtin_amdgcn_s_sleep(4);
                 }
                 if (ready) {
@@ -1164,25 +1225,28 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
                     avail = 0xFFFFFFFFu;
                     for (uint32_t a = 0; a < F; a++) avail = min(avail, L.plen[a] - L.ppos[a]);
                     load_pseg(F);
-                    __syncthreads();
+                    BFS_SYNC();
                     if (tid == 0) {
                         if (avail == 0) { L.scout_skip = L.scout_wait; L.scout_wait = min(L.scout_wait * 2, 64u); L.req_open = 0; } else L.scout_wait = 1;
                     }
                 } else {  // no answer: the companion is not there; this workgroup scouts for itself from now on
                     if (tid == 0) { L.comp = 0; L.req_open = 0; }
                     if (tid < SCOUT_MAX_F) { L.plen[tid] = 0; L.ppos[tid] = 0; L.pdone[tid] = 0; }
-                    __syncthreads();
+                    BFS_SYNC();
                     inline_scout = true;
                 }
             }
             if (inline_scout) {
                 const uint32_t budget = (uint32_t)min((long long)min(budget0, PATH_CAP), lv_left);
+#ifndef MC_BFS_OLD_RACE
+                BFS_SYNC();  // scout_run ends with stores to plen / ppos, which every wave read for `avail` above
+#endif
                 if (wv < F) scout_run<MODE>(S, t, L, wv, k, min_cov, budget, lookups);
-                __syncthreads();
+                BFS_SYNC();
                 avail = 0xFFFFFFFFu;
                 for (uint32_t a = 0; a < F; a++) avail = min(avail, L.plen[a]);
                 load_pseg(F);
-                __syncthreads();
+                BFS_SYNC();
                 if (tid == 0) {
                     if (avail >= budget && budget0 < PATH_CAP) L.scout_budget = budget0 * 2;
                     // a walker nobody can predict (no pointer, a dead end ahead): plain levels for a while, longer every time
@@ -1269,7 +1333,7 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
         }
         L.set[tid] = LH_EMPTY;
         L.set[tid + BFS_THREADS] = LH_EMPTY;
-        __syncthreads();
+        BFS_SYNC();
         MC_STAMP(2);
         // is a solid node already in distanceToKmer when the sequential BFS meets it?  = in the index,
         // or one of the expected vertices that come earlier in level-major order.  The expected
@@ -1280,7 +1344,7 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
         if (npred) myslot = lds_set_min(L.set, RH_SIZE - 1, L.pk, nk, pos);
         bool ind = false;
         if (solid) ind = vis_find(S, nk);
-        __syncthreads();
+        BFS_SYNC();
         if (solid && !ind && H > 1) {
             if (npred) {
                 ind = L.set[myslot] != pos;  // the same k-mer is expected earlier on some walker's path
@@ -1301,24 +1365,26 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
             if (!ok && H > 1) atomicMin(&L.bad_lvl, ni);
             if (root_bad) L.root_bad = 1;
         }
-        __syncthreads();
+        BFS_SYNC();
         MC_STAMP(3);
         uint32_t J = 0;
         if (H > 1) J = min(H, L.bad_lvl - 1);
         if (L.root_bad) {
             // the path does not start at the walker: none of this round's nodes means anything (the one-level replay below
             // takes level 1 to be the walkers' own neighbours).  The paths are dropped and the next round is a plain one.
-            __syncthreads();
+            BFS_SYNC();
             if (tid < SCOUT_MAX_F) { L.plen[tid] = 0; L.ppos[tid] = 0; L.pdone[tid] = 0; }
             if (tid == 0) {
                 L.root_bad = 0;
                 L.force_slow = 1;
                 L.req_open = 0;
+                L.pend = 0;  // (indexed above, in front of this round's first barrier)
                 L.rounds_left--;
                 if (dec_skip) L.scout_skip = skip0 - 1;
                 atomicAdd(&ctl->slow_mismatch, 1ull);
+                BFS_TRACE(S, 3u << 24 | (uint32_t)(rounds & 0xFFFFFF), n, F | H << 8, level, pend, seq0 | open0 << 31, resp_now, L.plen[0] | L.ppos[0] << 16);
             }
-            __syncthreads();
+            BFS_SYNC();
             continue;
         }
 
@@ -1343,7 +1409,7 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
                     atomicOr(&S.flags[pidx], 1u);
                 }
             }
-            __syncthreads();
+            BFS_SYNC();
             if (tid < F) {
                 L.root[tid] = L.pk[(J - 1) * F + tid];
                 L.ppos[tid] += J;
@@ -1361,6 +1427,8 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
                 L.rounds_left--;
                 if (J < H) L.force_slow = 1;  // the level behind them is something else: replayed exactly by the next round
                 if (dec_skip) L.scout_skip = skip0 - 1;
+                BFS_TRACE(S, 1u << 24 | (uint32_t)(rounds & 0xFFFFFF), n, F | H << 8 | J << 16 | fslow0 << 24 | comp0 << 25, level, pend | min(L.bad_lvl, 0xFFFFu) << 16,
+                          seq0 | open0 << 31, resp_now, L.plen[0] | L.ppos[0] << 16);
             }
             if (comp0 && open0 && tid < F && L.req_seq == seq0 && (resp_now >> 17) == (seq0 & 0x7FFFu)) {  // how far the companion has got meanwhile (same request)
                 if ((resp_now & 0xFFFFu) >= L.plen[tid]) {  // (the wait above may have seen a later answer already)
@@ -1368,14 +1436,14 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
                     L.pdone[tid] = (resp_now >> 16) & 1u;
                 }
             }
-            __syncthreads();
+            BFS_SYNC();
             load_pseg(F);
             MC_STAMP(4);
         } else {
             // ---- exact one-level replay of level 1 (ids [0, FN) are the plain neighbour sets of the walkers)
             slow_rounds++;
             if (tid < FN && H > 1) L.vis[tid] = (solid && vis_find(S, nk)) ? 1 : 0;  // index only, no expectations
-            __syncthreads();
+            BFS_SYNC();
             if (tid < 64) {
                 uint32_t last_base = 0;
                 const uint32_t n_new = replay_slow(S, L, 1, min_cov, max_kmers, max_radius, lg, flim, &last_base);
@@ -1409,19 +1477,21 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
                     L.force_slow = 0;
                     L.req_open = 0;  // (the companion's run, if any, is for walkers that no longer exist)
                     if (dec_skip) L.scout_skip = skip0 - 1;
+                    BFS_TRACE(S, 2u << 24 | (uint32_t)(rounds & 0xFFFFFF), n, F | H << 8 | n_new << 16 | fslow0 << 24 | comp0 << 25, level, pend | Fn << 16,
+                              seq0 | open0 << 31, resp_now, L.n);
                 }
             }
             MC_STAMP(4);
         }
-        __syncthreads();
+        BFS_SYNC();
         MC_STAMP(5);
     }
-    __syncthreads();
+    BFS_SYNC();
     {   // vertices of the last fast round still waiting for the index
         const uint32_t pend = L.pend;
         if (tid < pend) vis_insert(S, L.pub_k[tid], L.pub_idx[tid]);
     }
-    __syncthreads();
+    BFS_SYNC();
     if (tid == 0) {
         L.pend = 0;
         ctl_st(&ctl->n, L.n);
@@ -1441,7 +1511,7 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
         for (int i = 0; i < 8; i++) ctl->tacc[i] += tacc[i];
 #endif
     }
-    __syncthreads();
+    BFS_SYNC();
 }
 
 union BfsLds {
@@ -1475,8 +1545,15 @@ __global__ void __launch_bounds__(BFS_THREADS) k_bfs(const BfsState *__restrict_
 
     // seeds: every window with reads.get(key) >= minOccurences, in order (:159-192)
     if (!ctl_ld(&ctl->seeds_done)) {
+        // (the chunk counter is read ONCE: behind the loop thread 0 resets it, and a wave that came late to a second read
+        // would see 0 and start over, alone, one barrier out of step with the others -- MC_BFS_OLD_RACE keeps round 3's loop
+        // for tests/test_gpu_bfs_race.py)
+#ifdef MC_BFS_OLD_RACE
         for (;;) {
             const unsigned long long c0 = ctl_ld(&ctl->c0);
+#else
+        for (unsigned long long c0 = ctl_ld(&ctl->c0);; c0 += BFS_THREADS) {
+#endif
             if (c0 >= S.n_seeds) break;
             if (ctl_ld(&ctl->n) + BFS_THREADS > S.dcap) {
                 if (tid == 0) ctl_st(&ctl->status, BFS_NEED_GROW);
@@ -1489,10 +1566,10 @@ __global__ void __launch_bounds__(BFS_THREADS) k_bfs(const BfsState *__restrict_
             const bool have = r < S.n_seeds;
             Kmer cand{0, 0};
             if (have) { cand.hi = S.seed_hi ? S.seed_hi[r] : 0; cand.lo = S.seed_lo[r]; }
-            __syncthreads();
+            BFS_SYNC();
             bfs_chunk_wide<MODE>(S, t, lds.w, k, min_cov, -1, true, have, cand, UINT64_MAX, 0, lookups);
             if (tid == 0) ctl_st(&ctl->c0, c0 + BFS_THREADS);
-            __syncthreads();
+            BFS_SYNC();
         }
         if (tid == 0) {
             ctl_st(&ctl->seeds_done, 1);
@@ -1501,7 +1578,7 @@ __global__ void __launch_bounds__(BFS_THREADS) k_bfs(const BfsState *__restrict_
             ctl_st(&ctl->c0, 0);
             ctl_st(&ctl->level, 0);
         }
-        __syncthreads();
+        BFS_SYNC();
     }
 
     for (;;) {
@@ -1513,10 +1590,10 @@ __global__ void __launch_bounds__(BFS_THREADS) k_bfs(const BfsState *__restrict_
         if (ctl_ld(&ctl->status) != BFS_RUNNING) break;
         if (rounds_left == 0) break;
         if (ctl_ld(&ctl->c0) == 0 && le - lb <= flim) {
-            __syncthreads();
+            BFS_SYNC();
             bfs_narrow<MODE>(S, t, lds.n, k, min_cov, max_kmers, max_radius, rounds_left, lookups, companions != 0);
             rounds_left = lds.n.rounds_left;
-            __syncthreads();
+            BFS_SYNC();
             if (ctl_ld(&ctl->status) != BFS_RUNNING) break;  // done, or distanceToKmer must grow
             if (ctl_ld(&ctl->le) - ctl_ld(&ctl->lb) <= flim && ctl_ld(&ctl->le) != ctl_ld(&ctl->lb)) break;  // round budget used up: relaunch
             continue;
@@ -1524,8 +1601,12 @@ __global__ void __launch_bounds__(BFS_THREADS) k_bfs(const BfsState *__restrict_
         const long long level = ctl_ld(&ctl->level);
         const bool radius_ok = max_radius < 0 || level + 1 <= max_radius;  // newDistance > threshold -> false
         const unsigned long long ncand = (le - lb) * (unsigned long long)nb;
+#ifdef MC_BFS_OLD_RACE
         for (;;) {
             const unsigned long long c0 = ctl_ld(&ctl->c0);
+#else
+        for (unsigned long long c0 = ctl_ld(&ctl->c0);; c0 += BFS_THREADS) {  // (read once: see the seeds' loop)
+#endif
             if (c0 >= ncand) break;
             if (ctl_ld(&ctl->n) + BFS_THREADS > S.dcap) {
                 if (tid == 0) ctl_st(&ctl->status, BFS_NEED_GROW);
@@ -1543,11 +1624,11 @@ __global__ void __launch_bounds__(BFS_THREADS) k_bfs(const BfsState *__restrict_
                 const Kmer pv{S.hi[parent], S.lo[parent]};
                 cand = neighbour(pv, k, dir, (int)(rank % nb));
             }
-            __syncthreads();
+            BFS_SYNC();
             bfs_chunk_wide<MODE>(S, t, lds.w, k, min_cov, max_kmers, radius_ok, have, cand, parent,
                                  (int32_t)(level + 1), lookups);
             if (tid == 0) ctl_st(&ctl->c0, c0 + BFS_THREADS);
-            __syncthreads();
+            BFS_SYNC();
         }
         if (tid == 0) {
             ctl_st(&ctl->lb, le);
@@ -1555,7 +1636,7 @@ __global__ void __launch_bounds__(BFS_THREADS) k_bfs(const BfsState *__restrict_
             ctl_st(&ctl->c0, 0);
             ctl_st(&ctl->level, level + 1);
         }
-        __syncthreads();
+        BFS_SYNC();
     }
 out:
     atomicAdd(&ctl->lookups, lookups);
@@ -1570,6 +1651,107 @@ __global__ void k_vis_rebuild(BfsState S, uint64_t n)
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const Kmer v{S.hi[i], S.lo[i]};
         vis_insert(S, v, (uint32_t)i);
+    }
+}
+
+
+// ---- a device-side check of a finished walk (debug: MC_BFS_SELFCHECK=1 makes mc_bfs_batch run it behind every job) ------
+// What a result of OneSequenceCalculator.runBfs (src/algo/OneSequenceCalculator.java:154-214) must satisfy whatever the
+// order of events on the device was:
+//   dup      no two entries hold the same oriented k-mer (distanceToKmer is a map);
+//   cov      every entry's coverage is what the table holds for its key, and >= minOccurences;
+//   order    distances never decrease along the insertion order (a queue BFS), seeds first;
+//   orphan   an entry with dist > 0 is a `dir`-neighbour of an entry with dist - 1 that comes before it;
+//   open     (only when neither --maxkmers nor --maxradius cut the walk) every solid neighbour of an entry is an entry.
+// The first violations are written down with the entries they concern.
+struct BfsCheck {
+    unsigned long long dup, cov, order, orphan, open;
+    uint32_t n_first;
+    uint32_t first[16][4];  // kind (1 dup, 2 cov, 3 order, 4 orphan, 5 open), entry, the other entry / the table's value, distance
+};
+constexpr uint32_t CHK_EMPTY = 0xFFFFFFFFu;
+
+__device__ __forceinline__ void bfs_check_note(BfsCheck *out, uint32_t kind, uint32_t a, uint32_t b, uint32_t c)
+{
+    const uint32_t i = atomicAdd(&out->n_first, 1u);
+    if (i < 16) { out->first[i][0] = kind; out->first[i][1] = a; out->first[i][2] = b; out->first[i][3] = c; }
+}
+
+// entry holding k-mer v, or CHK_EMPTY
+__device__ __forceinline__ uint32_t bfs_check_find(const BfsState &S, const uint32_t *set, uint32_t mask, const Kmer &v)
+{
+    uint32_t s = (uint32_t)vis_hash(v) & mask;
+    for (uint32_t probe = 0; probe <= mask; probe++) {
+        const uint32_t e = set[s];
+        if (e == CHK_EMPTY) return CHK_EMPTY;
+        if (S.lo[e] == v.lo && S.hi[e] == v.hi) return e;
+        s = (s + 1) & mask;
+    }
+    return CHK_EMPTY;
+}
+
+// pass 1: an index of the result built from nothing but the result (set: mask + 1 words, all CHK_EMPTY)
+__global__ void __launch_bounds__(256) k_bfs_check_index(BfsState S, uint64_t n, uint32_t *set, uint32_t mask, BfsCheck *out)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const Kmer v{S.hi[i], S.lo[i]};
+        uint32_t s = (uint32_t)vis_hash(v) & mask;
+        for (uint32_t probe = 0; probe <= mask; probe++) {
+            uint32_t e = set[s];
+            if (e == CHK_EMPTY) e = atomicCAS(&set[s], CHK_EMPTY, (uint32_t)i);
+            if (e == CHK_EMPTY) break;
+            if (S.lo[e] == v.lo && S.hi[e] == v.hi) {
+                atomicAdd(&out->dup, 1ull);
+                bfs_check_note(out, 1, (uint32_t)max((uint64_t)e, i), (uint32_t)min((uint64_t)e, i), (uint32_t)S.dist[i]);
+                break;
+            }
+            s = (s + 1) & mask;
+        }
+    }
+}
+
+// pass 2
+template <int MODE>
+__global__ void __launch_bounds__(256) k_bfs_check(BfsState S, uint64_t n, SolidView t, int k, int min_cov, long long max_kmers,
+                                                   long long max_radius, const uint32_t *set, uint32_t mask, BfsCheck *out)
+{
+    const int dir = S.dir, nb = dir == 0 ? 8 : 4;
+    const bool uncut = (max_kmers < 0 || (long long)n < max_kmers);  // the cap never refused an addition
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const Kmer v{S.hi[i], S.lo[i]};
+        const int32_t d = S.dist[i];
+        const int have = solid_get(t, (uint64_t)key_of<MODE>(v, k));
+        if (have != (int)S.cov[i] || have < min_cov) {
+            atomicAdd(&out->cov, 1ull);
+            bfs_check_note(out, 2, (uint32_t)i, (uint32_t)have, (uint32_t)d);
+        }
+        if (i && S.dist[i - 1] > d) {
+            atomicAdd(&out->order, 1ull);
+            bfs_check_note(out, 3, (uint32_t)i, (uint32_t)S.dist[i - 1], (uint32_t)d);
+        }
+        if (d > 0) {  // some parent: v is the c-th dir-neighbour of p  <=>  p is one of v's neighbours the other way
+            bool found = false;
+            for (int c = 0; c < nb && !found; c++) {
+                const Kmer p = neighbour(v, k, dir == 0 ? 0 : -dir, c);
+                const uint32_t e = bfs_check_find(S, set, mask, p);
+                found = e != CHK_EMPTY && e < i && S.dist[e] == d - 1;
+            }
+            if (!found) {
+                atomicAdd(&out->orphan, 1ull);
+                bfs_check_note(out, 4, (uint32_t)i, 0, (uint32_t)d);
+            }
+        }
+        if (uncut && (max_radius < 0 || d + 1 <= max_radius)) {
+            for (int c = 0; c < nb; c++) {
+                const Kmer q = neighbour(v, k, dir, c);
+                if (solid_get(t, (uint64_t)key_of<MODE>(q, k)) >= min_cov && bfs_check_find(S, set, mask, q) == CHK_EMPTY) {
+                    atomicAdd(&out->open, 1ull);
+                    bfs_check_note(out, 5, (uint32_t)i, (uint32_t)c, (uint32_t)d);
+                }
+            }
+        }
     }
 }
 

@@ -198,6 +198,7 @@ struct BfsJobBuffers {
         (void)hipFree(S.ctl);
         (void)hipFree(S.path);
         (void)hipFree(S.box);
+        (void)hipFree(S.trace);
         (void)hipFree(d_seed_hi);
         (void)hipFree(d_seed_lo);
     }
@@ -3922,6 +3923,89 @@ __global__ void __launch_bounds__(256) k_bfs_pack(const BfsState *__restrict__ s
     if ((threadIdx.x & 63) == 0 && mx) atomicMax(&hdr[j].levels, mx);
 }
 
+// MC_BFS_SELFCHECK: the finished walks of a batch against the invariants of k_bfs_check; *report names what was found
+int bfs_selfcheck(mc_ctx *c, uint32_t n_jobs, const std::vector<BfsCtl> &ctl, int min_cov, int64_t max_kmers, int64_t max_radius,
+                  std::string *report)
+{
+    const SolidView t = c->solid_view();
+    BfsCheck *d_out = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&d_out), sizeof(BfsCheck)));
+    for (uint32_t j = 0; j < n_jobs; j++) {
+        const BfsState &S = c->bfs_pool[j]->S;
+        const uint64_t n = ctl[j].n;
+        if (n == 0) continue;
+        uint64_t cap = 1024;
+        while (cap < 4 * n) cap <<= 1;
+        uint32_t *d_set = nullptr;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&d_set), cap * 4));
+        HIPCHK(c, hipMemsetAsync(d_set, 0xFF, cap * 4, c->stream));
+        HIPCHK(c, hipMemsetAsync(d_out, 0, sizeof(BfsCheck), c->stream));
+        const unsigned grid = (unsigned)std::min<uint64_t>(grid_for(n, 256), 4096);
+        hipLaunchKernelGGL(k_bfs_check_index, dim3(grid), dim3(256), 0, c->stream, S, n, d_set, (uint32_t)(cap - 1), d_out);
+        switch (c->cfg.key_mode) {
+        case MC_KEY_PACKED:
+            hipLaunchKernelGGL(k_bfs_check<KEY_PACKED>, dim3(grid), dim3(256), 0, c->stream, S, n, t, c->cfg.k, min_cov, (long long)max_kmers,
+                               (long long)max_radius, d_set, (uint32_t)(cap - 1), d_out);
+            break;
+        case MC_KEY_POLY:
+            hipLaunchKernelGGL(k_bfs_check<KEY_POLY>, dim3(grid), dim3(256), 0, c->stream, S, n, t, c->cfg.k, min_cov, (long long)max_kmers,
+                               (long long)max_radius, d_set, (uint32_t)(cap - 1), d_out);
+            break;
+        default:
+            hipLaunchKernelGGL(k_bfs_check<KEY_FNV1A>, dim3(grid), dim3(256), 0, c->stream, S, n, t, c->cfg.k, min_cov, (long long)max_kmers,
+                               (long long)max_radius, d_set, (uint32_t)(cap - 1), d_out);
+        }
+        HIPCHK(c, hipGetLastError());
+        BfsCheck h;
+        HIPCHK(c, hipMemcpyAsync(&h, d_out, sizeof h, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(d_set);
+        if (h.dup | h.cov | h.order | h.orphan | h.open) {
+            char buf[256];
+            snprintf(buf, sizeof buf, "job %u (dir %d, n %llu): %llu duplicate, %llu wrong coverage, %llu out of order, %llu without parent, %llu solid neighbours left out;",
+                     j, S.dir, (unsigned long long)n, h.dup, h.cov, h.order, h.orphan, h.open);
+            *report += buf;
+            static const char *kind[] = {"?", "dup", "cov", "order", "orphan", "open"};
+            for (uint32_t i = 0; i < std::min<uint32_t>(h.n_first, 16); i++) {
+                snprintf(buf, sizeof buf, " [%s entry %u other %u dist %u]", kind[std::min<uint32_t>(h.first[i][0], 5)], h.first[i][1], h.first[i][2], h.first[i][3]);
+                *report += buf;
+            }
+        }
+    }
+    (void)hipFree(d_out);
+    return MC_OK;
+}
+
+// the rounds' trace of every job (MC_BFS_TRACE builds; nothing otherwise), oldest record first, as text
+void bfs_trace_dump(mc_ctx *c, uint32_t n_jobs, const std::vector<BfsCtl> &ctl, const char *path, const std::string &why)
+{
+    FILE *f = fopen(path, "a");
+    if (!f) return;
+    if (!why.empty()) fprintf(f, "# %s\n", why.c_str());
+    for (uint32_t j = 0; j < n_jobs; j++) {
+        const BfsState &S = c->bfs_pool[j]->S;
+        fprintf(f, "# job %u dir %d n %llu level %lld status %d rounds_narrow %llu slow %llu trace records %llu\n", j, S.dir, ctl[j].n, ctl[j].level, ctl[j].status,
+                ctl[j].rounds_narrow, ctl[j].rounds_slow, ctl[j].trace_n);
+        if (!S.trace || !ctl[j].trace_n) continue;
+        std::vector<uint32_t> ring((size_t)BFS_TRACE_RECORDS * 8);
+        if (hipMemcpy(ring.data(), S.trace, ring.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) continue;
+        const unsigned long long tn = ctl[j].trace_n, first = tn > BFS_TRACE_RECORDS ? tn - BFS_TRACE_RECORDS : 0;
+        for (unsigned long long r = first; r < tn; r++) {
+            const uint32_t *w = &ring[(size_t)(r & (BFS_TRACE_RECORDS - 1)) * 8];
+            const uint32_t kind = w[0] >> 24;
+            if (kind == 8)
+                fprintf(f, "%llu companion seq %u F %u team %u stopped %u levels %u %u budget %u stuck %u %u iters %u\n", r, w[0] & 0xFFFFFF, w[1] & 0xFF, (w[1] >> 8) & 0xFF,
+                        (w[1] >> 16) & 1, w[2], w[3], w[4], w[5] & 0xFF, (w[5] >> 8) & 0xFF, w[6]);
+            else
+                fprintf(f, "%llu %s round %u n %u F %u H %u %s %u force_slow %u comp %u level %u pend %u %s %u seq %u open %u resp %08x %s %u %u\n", r,
+                        kind == 1 ? "fast" : kind == 2 ? "slow" : "root_bad", w[0] & 0xFFFFFF, w[1], w[2] & 0xFF, (w[2] >> 8) & 0xFF, kind == 2 ? "n_new" : "J", (w[2] >> 16) & 0xFF,
+                        (w[2] >> 24) & 1, (w[2] >> 25) & 1, w[3], w[4] & 0xFFFF, kind == 2 ? "F_next" : "bad_lvl", w[4] >> 16, w[5] & 0x7FFFFFFF, w[5] >> 31, w[6],
+                        kind == 2 ? "n_after" : "plen0/ppos0", kind == 2 ? w[7] : w[7] & 0xFFFF, kind == 2 ? 0u : w[7] >> 16);
+        }
+    }
+    fclose(f);
+}
+
 void launch_bfs(mc_ctx *c, hipStream_t stream, const BfsState *d_states, uint32_t n_jobs, int min_cov, int64_t max_kmers,
                 int64_t max_radius, unsigned long long max_rounds, int companions)
 {
@@ -4042,6 +4126,9 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
         if (!S.ctl) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&S.ctl), sizeof(BfsCtl)));
         if (!S.path) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&S.path), (size_t)SCOUT_MAX_F * PATH_WORDS * 8));
         if (!S.box) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&S.box), sizeof(ScoutBox)));
+#ifdef MC_BFS_TRACE
+        if (!S.trace) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&S.trace), (size_t)BFS_TRACE_RECORDS * 32));
+#endif
         uint64_t *d_lo = reinterpret_cast<uint64_t *>(c->d_bfs_stage + seed_at[j]);
         S.seed_hi = jobs[j].seed_hi ? d_lo + std::max<uint64_t>(ns, 1) : nullptr;
         S.seed_lo = d_lo;
@@ -4138,6 +4225,17 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
     }
 
     int ret = MC_OK;
+    {   // debug: every walk checked on the device (bfs_device.h k_bfs_check); the rounds' trace of a tuning build written out
+        const char *sc = getenv("MC_BFS_SELFCHECK");
+        const char *dump = getenv("MC_BFS_TRACE_DUMP");
+        std::string report;
+        if (sc && *sc && *sc != '0') {
+            int rc = bfs_selfcheck(c, n_jobs, ctl, min_cov, max_kmers, max_radius, &report);
+            if (rc) return rc;
+        }
+        if (!report.empty() || (dump && *dump)) bfs_trace_dump(c, n_jobs, ctl, report.empty() ? dump : (dump && *dump ? dump : "/dev/stderr"), report);
+        if (!report.empty()) return fail(c, MC_ECHECK, "mc_bfs: self-check failed: %s", report.c_str());
+    }
     for (uint32_t j = 0; j < n_jobs; j++) {
         const uint64_t n = ctl[j].n;
         mc_bfs_result *o = &out[j];
