@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define MC_ABI_VERSION 10
+#define MC_ABI_VERSION 11
 
 /* error codes */
 #define MC_OK 0

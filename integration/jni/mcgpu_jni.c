@@ -54,11 +54,13 @@ JNIEXPORT void JNICALL Java_gpu_McGpu_setCoverageHint(JNIEnv *env, jobject self,
 JNIEXPORT void JNICALL Java_gpu_McGpu_addReadsPacked(JNIEnv *env, jobject self, jlongArray words, jlongArray offsets, jint n_reads)
 {
     mc_ctx *ctx = ctx_of(env, self);
-    jlong *w = (*env)->GetPrimitiveArrayCritical(env, words, 0);
-    jlong *o = (*env)->GetPrimitiveArrayCritical(env, offsets, 0);
+    /* (not Get/ReleasePrimitiveArrayCritical: the call uploads, launches kernels and waits for the stream -- seconds for a
+     * large batch -- and a critical region must not block: it holds up the collector for every loader thread) */
+    jlong *w = (*env)->GetLongArrayElements(env, words, 0);
+    jlong *o = (*env)->GetLongArrayElements(env, offsets, 0);
     int rc = (w && o) ? mc_add_reads_packed(ctx, (const uint64_t *)w, (const uint64_t *)o, (uint64_t)n_reads) : MC_ENOMEM;
-    if (o) (*env)->ReleasePrimitiveArrayCritical(env, offsets, o, JNI_ABORT);
-    if (w) (*env)->ReleasePrimitiveArrayCritical(env, words, w, JNI_ABORT);
+    if (o) (*env)->ReleaseLongArrayElements(env, offsets, o, JNI_ABORT);
+    if (w) (*env)->ReleaseLongArrayElements(env, words, w, JNI_ABORT);
     if (rc != MC_OK) throw_failed(env, mc_last_error(ctx));
 }
 
@@ -152,13 +154,18 @@ JNIEXPORT jobjectArray JNICALL Java_gpu_McGpu_bfsBatch(JNIEnv *env, jobject self
         if (jobs && jobs[j].seed_lo) (*env)->ReleaseLongArrayElements(env, al[j], (jlong *)jobs[j].seed_lo, JNI_ABORT);
     }
     if (d) (*env)->ReleaseIntArrayElements(env, dir, d, JNI_ABORT);
-    if (rc == MC_OK)
+    if (rc == MC_OK) {
+        int pending = 0;  /* a Java exception is pending: no further JNI calls that may throw, but every result block is freed */
         for (jsize j = 0; j < nj; j++) {
-            jobject o = make_result(env, rcls, &res[j]);
-            if ((*env)->ExceptionCheck(env)) break;
-            (*env)->SetObjectArrayElement(env, out, j, o);
+            if (!pending) {
+                jobject o = make_result(env, rcls, &res[j]);
+                pending = (*env)->ExceptionCheck(env);
+                if (!pending) (*env)->SetObjectArrayElement(env, out, j, o);
+            }
             mc_bfs_result_free(&res[j]);
         }
+        if (pending) out = NULL;
+    }
     free(jobs); free(res); free(ah); free(al);
     if (rc != MC_OK) { throw_failed(env, mc_last_error(ctx)); return NULL; }
     return out;

@@ -75,8 +75,26 @@ def build_host(force=False, verbose=False):
     return CLI
 
 
+# tuning builds the GPU tests load with MC_LIB (tests/test_gpu_bfs_race.py): the walk with a pause behind every barrier,
+# as it is now and as round 3 shipped it
+VARIANTS = {
+    "fuzz": ("MC_BFS_FUZZ", "MC_BFS_TRACE"),
+    "fuzz_old": ("MC_BFS_FUZZ", "MC_BFS_TRACE", "MC_BFS_OLD_RACE"),
+}
+
+
+def build_variants(force=False, verbose=False):
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(len(VARIANTS)) as ex:
+        return list(ex.map(lambda kv: build_lib(force, verbose, variant=kv[0], defines=kv[1]), sorted(VARIANTS.items())))
+
+
 def build_all(force=False, verbose=False):
-    build_lib(force, verbose)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(2) as ex:  # (hipcc runs a minute per library: the three of them side by side)
+        v = ex.submit(build_variants, force, verbose)
+        build_lib(force, verbose)
+        v.result()
     build_host(force, verbose)
 
 

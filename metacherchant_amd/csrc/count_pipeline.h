@@ -322,7 +322,9 @@ __global__ void __launch_bounds__(PT_THREADS) k_p1_extract_scatter(
                     hint[j] = ptr_base == ~0ull ? 0u : ptr_encode(ptr_base + p);  // the occurrence's place in the read store
                     if (OWNERS) {
                         valid[j] = true;
-                        dig[j] = owner_of(key[j], n_buckets);
+                        // (mm_k != 0 here: the owner of the key's MINIMIZER, as the super-k-mer records of the same group are
+                        // dealt -- a batch that falls back to keys must not send a k-mer to another owner than the records did)
+                        dig[j] = mm_k ? sk_owner(sk_hmin_of_kmer(key[j], mm_k), n_buckets) : owner_of(key[j], n_buckets);
                     } else if (key[j] == EMPTY_KEY) {
                         atomicAdd(empty_cnt, 1ull);
                     } else {

@@ -24,15 +24,20 @@
 #include <vector>
 
 #include <dlfcn.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// librccl is loaded at run time (RcclApi below); without its headers the library still builds, from the few declarations
+// of <rccl/rccl.h> the transport uses
+typedef struct ncclComm *ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1 } ncclDataType_t;
+#endif
 
 #include "../../include/mcgpu.h"
 #include "kmer_device.h"
 #include "bfs_device.h"
 #include "count_pipeline.h"
-#ifdef MC_SK_LONG_BUILD
-#include "count_long.h"   // an experiment (32-byte super-k-mer records for hash keys): only in libraries built with -DMC_SK_LONG_BUILD
-#endif
 #include "tokenizer.h"
 #include "host/envfinder.h"
 
@@ -268,6 +273,7 @@ struct mc_ctx {
     char *pin[16] = {};                // pinned staging buffers of h2d_fast, made on first use
     DevPool tok_pool;                  // scratch of the device tokeniser
     int64_t extract_in_store = -1;     // mc_group: the reads the next mc_extract_*_dev call is given sit in the read store already, from this word on (consumed by that call)
+    bool extract_by_minimizer = false; // mc_group: the next mc_extract_keys_dev call deals the keys to the owners of their minimizers (sk_owner), as the group's records are dealt (consumed by that call)
     uint4 *d_ovf_tmp = nullptr;        // pipe_drain_handed_on: the list moved aside while it is drained
     uint32_t *d_ovf_leaf_tmp = nullptr;
     uint64_t ovf_tmp_cap = 0, ovf_leaf_tmp_cap = 0;
@@ -282,10 +288,6 @@ struct mc_ctx {
     bool virgin = true;  // the table holds no key and its memory is not initialised yet
     int count_path = 0;  // 0 auto, 1 direct (atomics), 2 partitioned; MC_COUNT_PATH=direct|partition overrides
     bool sk_form = false;  // reads of this context can travel as super-k-mer records (set once; mm_k may be given up later)
-    // polynomial-hash keys, k = 32 .. 63 (count_long.h): skl_ok -- this context may count reads as 32-byte super-k-mer records;
-    // skl_state -- it does so now: mm_k == k and the table's regions are minimizer bins of the k-mers' BASES, so no kernel may
-    // address it by key (leave_long() rebuilds it by key hash before the first operation that has to)
-    bool skl_ok = false, skl_state = false;
     // scratch of the partitioned counting pipeline, kept between calls
     struct Pipe {
         uint64_t *a_keys = nullptr, *b_keys = nullptr, *spill_keys = nullptr;
@@ -477,75 +479,15 @@ __global__ void k_rehash(const Slot *__restrict__ old_slots, uint64_t n_old, Tab
     wave_add_ull(t.n_used, n_new);
 }
 
-// K6, region-wise: one workgroup assembles one region of the solid table (SOLID_REGION slots, 32 KB)
-// in LDS from the counting-table region(s) that hash to it and writes it out with plain coalesced
-// stores: no fill pass, no atomics.  Both tables index by the top bits of the same hash, so the
-// counting regions of a solid region are consecutive (or it is a slice of one counting region).
-// (Counting table organised by minimizer bins: see k_solid_emit / k_solid_from_leaves instead.)
+// The solid table's regions (SOLID_REGION slots, 32 KB)
 constexpr uint32_t SOLID_SB = 11, SOLID_REGION = 1u << SOLID_SB;
+// (Round 3 also had k_build_solid_regions: a workgroup per solid region, fed from the counting regions whose hash prefix it
+// shares.  It took every key to sit in its home counting region -- no longer so since additions that find their stretch full
+// move on to the next region, kmer_device.h TABLE_CHAIN -- and lost the others: every solid table is now built
+// by the sweep below, which asks no such thing.)
 
-__global__ void __launch_bounds__(512) k_build_solid_regions(const Slot *__restrict__ slots, uint32_t main_lg,
-                                                             int min_cov, SolidView solid, uint32_t solid_lg)
-{
-    __shared__ Slot R[SOLID_REGION];
-    __shared__ uint32_t overflow;
-    const uint32_t tid = threadIdx.x;
-    const uint32_t q = solid_lg - SOLID_SB;  // log2(#solid regions)
-    const uint32_t rb = main_lg - MC_REGION_LG;  // log2(#counting regions)
-    const uint64_t n_regions = 1ull << q;
-    for (uint64_t Q = blockIdx.x; Q < n_regions; Q += gridDim.x) {
-        for (uint32_t i = tid; i < SOLID_REGION; i += 512) {
-            R[i].key = EMPTY_KEY; R[i].count = 0; R[i].aux = 0;
-        }
-        if (tid == 0) overflow = 0;
-        __syncthreads();
-        // counting-table slots to scan
-        uint64_t first, count;
-        if (q <= rb) { first = (Q << (rb - q)) << MC_REGION_LG; count = 1ull << (rb - q + MC_REGION_LG); }
-        else { first = (Q >> (q - rb)) << MC_REGION_LG; count = 1u << MC_REGION_LG; }
-        for (uint64_t i0 = tid; i0 < count; i0 += 4 * 512) {
-            uint4 raws[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {  // four independent loads in flight per thread
-                const uint64_t i = i0 + (uint64_t)u * 512;
-                raws[u] = i < count ? *reinterpret_cast<const uint4 *>(slots + first + i) : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint4 raw = raws[u];
-                const uint64_t key = ((uint64_t)raw.y << 32) | raw.x;
-                if (key == EMPTY_KEY) continue;
-                const int c = raw.z > 32767u ? 32767 : (int)raw.z;
-                if (c < min_cov) continue;
-                const uint64_t ss = fmix64(key) >> (64 - solid_lg);
-                if ((ss >> SOLID_SB) != Q) continue;  // (q > rb: the counting region feeds several solid regions)
-                uint32_t s = (uint32_t)ss & (SOLID_REGION - 1);
-                bool done = false;
-                for (uint32_t probe = 0; probe < SOLID_REGION; probe++) {
-                    if (atomicCAS(reinterpret_cast<unsigned long long *>(&R[s].key), (unsigned long long)EMPTY_KEY,
-                                  (unsigned long long)key) == EMPTY_KEY) {
-                        R[s].count = (uint32_t)c;
-                        R[s].aux = raw.w;
-                        done = true;
-                        break;
-                    }
-                    s = (s + 1) & (SOLID_REGION - 1);
-                }
-                if (!done) atomicExch(&overflow, 1u);
-            }
-        }
-        __syncthreads();
-        if (overflow && tid == 0) atomicExch(solid.fatal, 1u);
-        uint4 *dst = reinterpret_cast<uint4 *>(solid.slots + Q * SOLID_REGION);
-        const uint4 *src = reinterpret_cast<const uint4 *>(R);
-        for (uint32_t i = tid; i < SOLID_REGION; i += 512) dst[i] = src[i];
-        __syncthreads();
-    }
-}
-
-
-// K6 when the counting table is organised by minimizer bins (mc_ctx::mm_k): the solid table still
-// indexes by the key's own hash, so its regions draw from all over the counting table.  The solid
+// K6: the solid table indexes by the key's own hash, so its regions draw from all over a counting table organised by
+// minimizer bins (mc_ctx::mm_k) -- and from next door in one organised by hash prefixes, where a key may have been handed on.  The solid
 // entries (a few % of the occurrences) therefore take the same route as the counting records:
 // k_solid_emit sweeps the counting table and appends every entry with count >= min_cov to the level-1
 // bucket of its solid slot (256 workgroups, each its own segment of every bucket), k_sk2_scatter
@@ -691,7 +633,7 @@ __global__ void __launch_bounds__(512) k_solid_from_leaves(const uint4 *__restri
                 const uint64_t key = ((uint64_t)raw.y << 32) | raw.x;
                 uint32_t s = (uint32_t)(fmix64(key) >> (64 - solid_lg)) & (SOLID_REGION - 1);
                 bool done = false;
-                for (uint32_t probe = 0; probe < SOLID_REGION; probe++) {
+                for (uint32_t probe = 0; probe < (SOLID_REGION < TABLE_MAX_PROBES ? SOLID_REGION : TABLE_MAX_PROBES); probe++) {  // (where a lookup gives the region up: kmer_device.h solid_probe_from)
                     if (atomicCAS(reinterpret_cast<unsigned long long *>(&R[s].key), (unsigned long long)EMPTY_KEY,
                                   (unsigned long long)key) == EMPTY_KEY) {
                         R[s].count = raw.z;
@@ -980,6 +922,7 @@ struct TableSwap {
     bool old_virgin;
     int old_mm;
     unsigned long long old_used = 0;
+    bool have_used = false;  // old_used has been read (only then is it written back when the swap is abandoned)
     bool done = false;
     explicit TableSwap(mc_ctx *ctx) : c(ctx), old(ctx->slots), old_bytes(ctx->slots_bytes), old_regions(ctx->n_regions), old_rb(ctx->rb), old_virgin(ctx->virgin), old_mm(ctx->mm_k) {}
     ~TableSwap()
@@ -987,7 +930,7 @@ struct TableSwap {
         if (done) { table_release(c, old, old_bytes); return; }
         if (c->slots && c->slots != old) table_release(c, c->slots, c->slots_bytes);  // the half-filled new table
         c->slots = old; c->slots_bytes = old_bytes; c->n_regions = old_regions; c->rb = old_rb; c->virgin = old_virgin; c->mm_k = old_mm;
-        (void)hipMemcpy(c->d_ctr, &old_used, sizeof old_used, hipMemcpyHostToDevice);  // (n_used as it was)
+        if (have_used) (void)hipMemcpy(c->d_ctr, &old_used, sizeof old_used, hipMemcpyHostToDevice);  // (n_used as it was)
     }
 };
 
@@ -996,6 +939,7 @@ static int table_grow(mc_ctx *c, uint64_t new_regions)
     TableSwap sw(c);
     HIPCHK(c, hipMemcpyAsync(&sw.old_used, c->d_ctr, sizeof sw.old_used, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    sw.have_used = true;
     const uint64_t old_n = c->n_slots();
     c->slots = nullptr;
     int rc = table_alloc(c, new_regions);
@@ -1023,6 +967,7 @@ static int to_hash_regions(mc_ctx *c)
     TableSwap sw(c);
     HIPCHK(c, hipMemcpyAsync(&sw.old_used, c->d_ctr, sizeof sw.old_used, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    sw.have_used = true;
     const unsigned long long used = sw.old_used;
     const uint64_t old_n = c->n_slots();
     c->mm_k = 0;
@@ -1072,22 +1017,10 @@ static int drain_parked(mc_ctx *c)
     }
 }
 
-// count_long.h: back to regions by key hash, with everything counted so far moved over (a no-op for other contexts)
-static int leave_long(mc_ctx *c)
-{
-    if (!c->skl_state) return MC_OK;
-    c->skl_state = false;
-    return to_hash_regions(c);
-}
-
 // Make room for `incoming` more key occurrences: returns how many of them may be inserted by the
 // next launch without the load factor passing 0.85 even if every one is a new key.
 static int table_reserve(mc_ctx *c, uint64_t incoming, uint64_t *allowed)
 {
-    {
-        int lrc = leave_long(c);  // (every caller is about to address the table by key)
-        if (lrc) return lrc;
-    }
     int mrc = materialize(c);
     if (!mrc) mrc = drain_parked(c);  // (what the previous launch could not place)
     if (mrc) return mrc;
@@ -1170,7 +1103,11 @@ template <typename T>
 static int ensure_buf(mc_ctx *c, T **p, uint64_t *cap, uint64_t need)
 {   // (blocks of 64 MB and more come from and go to g_scratch_pool: *cap may come out above `need`)
     if (*cap >= need && *p) return MC_OK;
-    if (*p) g_scratch_pool.put(c->cfg.device, *p, *cap * sizeof(T));
+    if (*p) {  // (a block that goes back to the pool may be handed out at once: what is queued on it must be done)
+        (void)hipStreamSynchronize(c->stream);
+        if (c->pipe_stream) (void)hipStreamSynchronize(c->pipe_stream);
+        g_scratch_pool.put(c->cfg.device, *p, *cap * sizeof(T));
+    }
     *p = nullptr;
     *cap = 0;
     const size_t bytes = std::max<uint64_t>(need, 1) * sizeof(T);
@@ -1725,7 +1662,9 @@ static void launch_p1_reads(mc_ctx *c, const uint64_t *d_words, const uint64_t *
     const int grid = owners_mode == 0 ? PT_SEGMENTS
                                       : (int)std::min<uint64_t>(std::max<uint64_t>(n_tiles_abs - base0 / PT_TILE, 1), 256);
     const int k = c->cfg.k;
-#define P1_ARGS d_words, offs, nr, base0, end_abs, n_tiles_abs, tile_first, k, b1, cursors, cap, out_keys, out_hints, c->d_ctr + 1, sp, bases, c->mm_k, c->cur_ptr_base
+    // (owner modes: the kernel's mm_k chooses the owner rule -- 0: mc_key_owner, the key's own hash; k: the owner of the key's minimizer)
+    const int p1_mm_k = owners_mode == 0 ? c->mm_k : (c->extract_by_minimizer ? k : 0);
+#define P1_ARGS d_words, offs, nr, base0, end_abs, n_tiles_abs, tile_first, k, b1, cursors, cap, out_keys, out_hints, c->d_ctr + 1, sp, bases, p1_mm_k, c->cur_ptr_base
 #define P1_LAUNCH(MODE)                                                                                                  \
     do {                                                                                                                 \
         if (owners_mode == 0)                                                                                            \
@@ -1893,179 +1832,10 @@ static int add_reads_partitioned_once(mc_ctx *c, const uint64_t *d_words, const 
     return MC_OK;
 }
 
-#ifdef MC_SK_LONG_BUILD
-// One batch of reads [r0, r1) as 32-byte super-k-mer records (count_long.h): polynomial-hash keys, k = 32 .. 63, into a
-// table that holds nothing yet or was filled this way.  Returns 2 when this table cannot be split into the pipeline's
-// leaves (the caller takes the per-window pipeline).
-static int add_reads_partitioned_long(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_off, uint64_t r0, uint64_t r1, uint64_t base0,
-                                      uint64_t end_abs, uint64_t wb)
-{
-    mc_ctx::Pipe &P = c->pipe;
-    const uint64_t nr = r1 - r0;
-    const int k = c->cfg.k;
-    // leaves: the regions themselves up to 512 x 1024 of them, else 2^g regions per leaf
-    uint64_t n_leaves = c->n_regions;
-    uint32_t g = 0;
-    while (n_leaves > (uint64_t)PT_MAX_BUCKETS * PT_MAX_LEAVES2) { n_leaves >>= 1; g++; }
-    if ((n_leaves << g) != c->n_regions || n_leaves < 4 || g > 5) return 2;
-    uint64_t np1 = std::min<uint64_t>(n_leaves, PT_MAX_BUCKETS);
-    while (n_leaves % np1) np1--;
-    const uint64_t b2 = n_leaves / np1;
-    if (b2 > PT_MAX_LEAVES2) return 2;
-    {
-        unsigned long long used;
-        uint32_t fatal;
-        int rc = read_counters(c, &used, &fatal);
-        if (rc) return rc;
-        if (fatal) return fail(c, MC_EOVERFLOW, "a k-mer table region filled up (hash skew)");
-        c->n_used_host = used;
-    }
-    if (!c->skl_state) {  // (the table is empty: its regions are minimizer bins from here on)
-        c->mm_k = k;
-        c->skl_state = true;
-    }
-    c->solid_list_fresh = false;
-    const uint32_t nseg1 = SKL_SEGMENTS;
-    const uint64_t n_tiles_abs = (end_abs + SKL_TILE - 1) / SKL_TILE;
-    // records: a run of windows sharing a minimizer averages (w + 1) / 2 = 25 windows at k = 63 and is cut every 16, at
-    // read ends, at sequencing errors and at tile borders: ~0.1 per window measured; 0.16 + ... leaves room
-    const uint64_t units = (uint64_t)((double)wb * 0.16) + 2 * nr + 2 * (n_tiles_abs - base0 / SKL_TILE) + 1024;
-    const uint64_t cap1 = (uint64_t)((double)units / (double)np1 / (double)nseg1 * 1.25) + 64;
-    const double mean_leaf = (double)units / (double)n_leaves;
-    const uint64_t cap2 = (uint64_t)(mean_leaf * 1.15 + 32.0 * std::sqrt(mean_leaf) + 64.0);
-    const uint64_t spill_cap = std::max<uint64_t>(units / 16, 1u << 16);
-    if (np1 * nseg1 * cap1 >= 0xFFFFFFFFull || b2 * cap2 >= 0xFFFFFFFFull) return fail(c, MC_EINVAL, "internal: partitioned batch too large for 32-bit bucket indices");
-    int rc;
-#define ENSURE(ptr, capvar, need) do { rc = ensure_buf(c, &(ptr), &(capvar), (need)); if (rc) return rc; } while (0)
-    ENSURE(P.a_recs, P.a_recs_cap, 2 * np1 * nseg1 * cap1);  // (uint4 units: a record is two)
-    if (b2 > 1) ENSURE(P.b_recs, P.b_recs_cap, 2 * n_leaves * cap2);
-    ENSURE(P.spill_recs, P.spill_recs_cap, 2 * spill_cap);
-    ENSURE(P.seg_counts1, P.segs1_cap, np1 * nseg1);
-    ENSURE(P.cursors2, P.cursors2_cap, n_leaves);
-    { uint64_t cap = P.leaves_cap, dummy = P.leaves_cap; ENSURE(P.leaf_state, cap, n_leaves); ENSURE(P.leaf_new, dummy, n_leaves); P.leaves_cap = cap; }
-    ENSURE(P.tile_first, P.tiles1_cap, n_tiles_abs);
-#undef ENSURE
-    if (!P.flags) {  // four flags and, behind them, the spill counter: cleared by one fill, read by one copy
-        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.flags), 4 * sizeof(uint32_t) + sizeof(unsigned long long)));
-        P.spill_count = reinterpret_cast<unsigned long long *>(P.flags + 4);
-    }
-    HIPCHK(c, hipMemsetAsync(P.seg_counts1, 0, np1 * nseg1 * sizeof(uint32_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(P.cursors2, 0, n_leaves * sizeof(uint32_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(P.leaf_state, 0, n_leaves * sizeof(uint32_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(P.leaf_new, 0, n_leaves * sizeof(uint32_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(P.flags, 0, 4 * sizeof(uint32_t) + sizeof(unsigned long long), c->stream));
-    SkLRec *a = reinterpret_cast<SkLRec *>(P.a_recs), *b = reinterpret_cast<SkLRec *>(P.b_recs), *spill = reinterpret_cast<SkLRec *>(P.spill_recs);
-    const SkLSpill sp{spill, P.spill_count, spill_cap, P.flags};
-    const uint64_t *offs = d_off + r0;
-    const uint64_t p5k = pow5(k), p5km1 = pow5(k - 1);
-    const uint32_t thr = (uint32_t)(c->solid_tracked ? c->cov_hint : 0);
-    double ms1 = 0, ms2 = 0, ms3 = 0, ms4 = 0;
-    rc = timed(c, &ms1, [&] {
-        launch_tile_first(c, offs, nr, n_tiles_abs, P.tile_first, SKL_TILE);
-        hipLaunchKernelGGL(k_skl_extract, dim3(nseg1), dim3(SKL_THREADS), 0, c->stream, d_words, offs, nr, base0, end_abs, n_tiles_abs, P.tile_first, k,
-                           (uint32_t)np1, P.seg_counts1, cap1, a, sp, c->cur_ptr_base);
-    });
-    if (rc) return rc;
-    if (b2 > 1) {
-        rc = timed(c, &ms2, [&] {
-            hipLaunchKernelGGL(k_skl2_scatter, dim3((unsigned)np1), dim3(PT_THREADS), 0, c->stream, a, cap1, P.seg_counts1, (uint32_t)np1, (uint32_t)np1,
-                               (uint32_t)b2, nseg1, P.cursors2, cap2, b, sp);
-        });
-        if (rc) return rc;
-    }
-    {
-        uint32_t lost = 0;
-        HIPCHK(c, hipMemcpy(&lost, P.flags, sizeof lost, hipMemcpyDeviceToHost));
-        if (lost) return fail(c, MC_EOVERFLOW, "internal: the record streams of the counting pipeline overflowed their spill list");
-    }
-    const SkLRec *lk = b2 > 1 ? b : a;
-    const uint32_t *lc = b2 > 1 ? P.cursors2 : P.seg_counts1;
-    const uint64_t lcap = b2 > 1 ? cap2 : cap1;
-    const uint32_t lseg = b2 > 1 ? 1u : nseg1;
-    const int virgin = c->virgin ? 1 : 0;
-    rc = timed(c, &ms3, [&] {
-        hipLaunchKernelGGL(k_p3l_merge, dim3((unsigned)std::min<uint64_t>(n_leaves, 256 * 2 * 4)), dim3(P3_THREADS), 0, c->stream, lk, lc, lcap, lseg,
-                           (uint32_t)n_leaves, g, c->view(), virgin, P.leaf_state, P.leaf_new, P.flags + 1, thr, c->d_ctr + 6, k, p5k, p5km1);
-    });
-    if (rc) return rc;
-    c->virgin = false;
-    hipLaunchKernelGGL(k_sum_leaf_new, dim3(64), dim3(256), 0, c->stream, P.leaf_new, (uint32_t)n_leaves, c->d_ctr);
-    HIPCHK(c, hipGetLastError());
-    uint32_t flags[2];
-    unsigned long long n_spill = 0;
-    HIPCHK(c, hipMemcpy(flags, P.flags, sizeof flags, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(&n_spill, P.spill_count, sizeof n_spill, hipMemcpyDeviceToHost));
-    if (flags[1] || n_spill) {
-        // A region overflowed (its leaf was left alone), or records did not fit their buckets: the table goes back to
-        // regions by key hash -- it cannot be enlarged in place, the bins of its keys are not known any more -- and the
-        // records left over are counted window by window.
-        rc = leave_long(c);
-        if (rc) return rc;
-        if (flags[1]) {
-            std::vector<uint32_t> st(n_leaves), cnt(n_leaves * (uint64_t)lseg);
-            HIPCHK(c, hipMemcpy(st.data(), P.leaf_state, n_leaves * sizeof(uint32_t), hipMemcpyDeviceToHost));
-            HIPCHK(c, hipMemcpy(cnt.data(), lc, cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-            uint32_t lo_leaf = 0;
-            while (lo_leaf < n_leaves) {
-                uint64_t allowed, need = 0;
-                uint32_t hi_leaf = lo_leaf;
-                rc = table_reserve(c, 1ull << 26, &allowed);
-                if (rc) return rc;
-                while (hi_leaf < n_leaves) {
-                    uint64_t w = 0;
-                    if (!st[hi_leaf])
-                        for (uint32_t sg = 0; sg < lseg; sg++) w += std::min<uint64_t>(cnt[(uint64_t)hi_leaf * lseg + sg], lcap) * SK_MAX_WINDOWS;
-                    if (hi_leaf > lo_leaf && need + w > allowed) break;
-                    need += w;
-                    hi_leaf++;
-                }
-                if (need > allowed) {
-                    rc = table_reserve(c, need, &allowed);
-                    if (rc) return rc;
-                    if (need > allowed) return fail(c, MC_EOVERFLOW, "internal: a leaf of %llu k-mer occurrences does not fit one launch", (unsigned long long)need);
-                }
-                if (need)
-                    hipLaunchKernelGGL(k_skl_add_unmerged, dim3(std::min<uint32_t>(hi_leaf - lo_leaf, 4096u)), dim3(256), 0, c->stream, lk, lc, lcap, lseg,
-                                       lo_leaf, hi_leaf, P.leaf_state, k, p5k, p5km1, c->view(), thr, c->d_ctr + 6);
-                HIPCHK(c, hipGetLastError());
-                lo_leaf = hi_leaf;
-            }
-        }
-        uint64_t i = 0;
-        while (i < n_spill) {
-            uint64_t allowed;
-            rc = table_reserve(c, (n_spill - i) * SK_MAX_WINDOWS, &allowed);
-            if (rc) return rc;
-            const uint64_t m = std::min<uint64_t>(std::max<uint64_t>(allowed / SK_MAX_WINDOWS, 1), n_spill - i);
-            hipLaunchKernelGGL(k_skl_add_records, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, spill + i, m, k, p5k, p5km1, c->view(), thr, c->d_ctr + 6);
-            HIPCHK(c, hipGetLastError());
-            i += m;
-        }
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-    }
-    c->st.p1_ms += ms1;
-    c->st.p2_ms += ms2;
-    c->st.p3_ms += ms3;
-    c->st.spill_keys += n_spill;
-    c->st.count_ms += ms1 + ms2 + ms3 + ms4;
-    c->st.count_total_ms += ms1 + ms2 + ms3 + ms4;
-    c->st.count_launches++;
-    c->st.windows += wb;
-    return MC_OK;
-}
-
-// the pipeline a batch of reads takes: 32-byte records while the context may and the table allows, else the usual one
-#endif  // MC_SK_LONG_BUILD
 
 static int add_reads_partitioned_any(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_off, uint64_t r0, uint64_t r1, uint64_t base0,
                                      uint64_t end_abs, uint64_t wb)
 {
-#ifdef MC_SK_LONG_BUILD
-    if (c->skl_ok && (c->skl_state || c->virgin)) {
-        const int rc = add_reads_partitioned_long(c, d_words, d_off, r0, r1, base0, end_abs, wb);
-        if (rc != 2) return rc;
-    }
-#endif
     return add_reads_partitioned(c, d_words, d_off, r0, r1, base0, end_abs, wb);
 }
 
@@ -2075,9 +1845,7 @@ static int add_keys_partitioned(mc_ctx *c, const uint64_t *d_keys, const uint32_
 {
     mc_ctx::Pipe &P = c->pipe;
     PipePlan pl;
-    int rc = leave_long(c);
-    if (rc) return rc;
-    rc = pipe_prepare(c, n, &pl);
+    int rc = pipe_prepare(c, n, &pl);
     if (rc) return rc;
     double ms1 = 0;
     rc = timed(c, &ms1, [&] {
@@ -2207,7 +1975,6 @@ static uint64_t max_run_bases(const mc_ctx *c, double windows_per_base = 1.0)
 {   // windows_per_base: of the read set at hand (88 / 150 for 150-base reads at k = 63): the scratch is per window
     static const uint64_t env = [] { const char *e = getenv("MC_MAX_RUN_BASES"); return e && *e ? strtoull(e, nullptr, 10) : 0ull; }();
     if (env) return std::max<uint64_t>(env, 1u << 20);
-    if (c->skl_ok && (c->skl_state || c->virgin)) return 1ull << 33;  // (32-byte records, ~0.1 per window: 12 bytes of scratch per window)
     if (c->mm_k) return 1ull << 34;
     // a key and a read pointer per window, in pieces (add_reads_partitioned): ~16.5 bytes of scratch per window.  Two
     // thirds of what the device has free may go there (the table is allocated already), between 2^31 and 2^33 bases: every
@@ -2343,10 +2110,6 @@ int mc_create(const mc_config *cfg, mc_ctx **out)
     c->sk_form = c->mm_k != 0;
     // (an experiment, off unless MC_SK_LONG=1: measured on 10 M reads at k = 63 -- P1 24 + P2 2 + P3 32 ms against 35 ms for the
     // per-window pipeline, and the bins of a table at load 0.43 overflow, which sends it back to hash regions: DESIGN.md section 7)
-    c->skl_ok = false;
-#ifdef MC_SK_LONG_BUILD
-    if (const char *e = getenv("MC_SK_LONG")) c->skl_ok = !strcmp(e, "1") && cfg->key_mode == MC_KEY_POLY && cfg->k >= 32 && cfg->k <= 63;
-#endif
     uint64_t want_slots = 1ull << 22;  // 4 M slots = 64 MB to start with
     if (cfg->capacity_hint) {
         // Load factor the hint is turned into.  Hash-prefix tables: 0.7 (regions are probed in LDS, a fuller table
@@ -2376,7 +2139,12 @@ void mc_destroy(mc_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
-    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    // Blocks go back to process-wide pools below and may be handed to another context at once (hipFree used to wait for the
+    // device; a pool does not): everything this context still has queued must be done first -- on the caller's stream too
+    // (mc_set_stream) and on the side stream of the pipeline.
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->own_stream && c->own_stream != c->stream) (void)hipStreamSynchronize(c->own_stream);
+    if (c->pipe_stream) (void)hipStreamSynchronize(c->pipe_stream);
     if (c->slots) table_release(c, c->slots, c->slots_bytes);
     if (c->solid) (void)hipFree(c->solid);
     c->pipe.release(c->cfg.device);
@@ -3086,7 +2854,7 @@ int mc_add_reads_file(mc_ctx *c, const char *path, uint64_t *n_reads)
                     rc = read_counters(c, &used, &fatal);
                     if (rc != MC_OK) break;
                     const bool hint_holds = c->cfg.capacity_hint && used < c->cfg.capacity_hint;
-                    if (!hint_holds && used && !c->skl_state) {
+                    if (!hint_holds && used) {
                         const double scale = (double)f.n / (double)(cuts[0].second - cuts[0].first);
                         const double load = c->mm_k ? 0.36 : 0.6;
                         size_t fr = 0, tot = 0;
@@ -3160,10 +2928,6 @@ int mc_get_dev(mc_ctx *c, const int64_t *d_keys, uint64_t n, int16_t *d_out)
     if ((!d_keys || !d_out) && n) return fail(c, MC_EINVAL, "mc_get_dev: null pointer");
     if (n == 0) return MC_OK;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    {
-        int lrc = leave_long(c);
-        if (lrc) return lrc;
-    }
     hipLaunchKernelGGL(k_get, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, d_keys, n, d_out, c->view());
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -3213,6 +2977,9 @@ int mc_extract_keys_dev(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_of
 {
     if (!c) return MC_EINVAL;
     std::lock_guard<std::mutex> g(c->mu);
+    struct ResetRule { mc_ctx *c; ~ResetRule() { c->extract_by_minimizer = false; } } reset_rule{c};  // (the group's choice holds for this call only)
+    if (c->extract_by_minimizer && !(c->cfg.key_mode == MC_KEY_PACKED && c->cfg.k >= SK_MIN_K))
+        return fail(c, MC_ESTATE, "internal: keys can only be dealt by minimizer where records are (packed keys, k >= %d)", SK_MIN_K);
     if (!owner_offsets || n_owners == 0 || n_owners > PT_MAX_BUCKETS)
         return fail(c, MC_EINVAL, "mc_extract_keys_dev: bad n_owners / owner_offsets");
     HIPCHK(c, hipSetDevice(c->cfg.device));
@@ -3588,6 +3355,8 @@ int mc_trim(mc_ctx *c)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     mc_ctx::Pipe &P = c->pipe;
     const int dev = c->cfg.device;
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // (the blocks may be reused by another context at once: see mc_destroy)
+    if (c->pipe_stream) HIPCHK(c, hipStreamSynchronize(c->pipe_stream));
     // (the list of solid k-mers sits in a_recs, its fill levels in emit_counts: they stay while the list is valid)
     uint4 *keep_recs = nullptr;
     uint64_t keep_cap = 0;
@@ -3745,7 +3514,7 @@ int solid_build(mc_ctx *c, uint64_t n, int min_cov, double *ms, const PairSource
     }
     // counting table organised by minimizer bins, or entries from outside: the solid entries are partitioned by
     // their own hash first
-    const bool partitioned = c->mm_k || pairs;
+    const bool partitioned = true;
     mc_ctx::Pipe &P = c->pipe;
     const uint32_t q = lg - SOLID_SB, sb1 = std::min<uint32_t>(q, 9), sb2 = q - sb1;
     uint64_t scap1 = 0, scap2 = 0;
@@ -3802,9 +3571,6 @@ int solid_build(mc_ctx *c, uint64_t n, int min_cov, double *ms, const PairSource
             hipLaunchKernelGGL(k_solid_from_leaves, dim3((unsigned)std::min<uint64_t>(1ull << q, 256 * 2 * 8)), dim3(512), 0, c->stream,
                                sb2 ? r2 : r1, sb2 ? leaf_counts : P.seg_counts1, sb2 ? scap2 : scap1,
                                sb2 ? 1u : (uint32_t)PT_SEGMENTS, c->solid_view(), lg);
-        } else {
-            hipLaunchKernelGGL(k_build_solid_regions, dim3((unsigned)std::min<uint64_t>(1ull << (lg - SOLID_SB), 256 * 2 * 8)), dim3(512), 0,
-                               c->stream, c->slots, c->rb + c->sb, min_cov, c->solid_view(), lg);  // (hash-prefix regions: a power of two)
         }
     });
     if (rc) return rc;
@@ -3823,8 +3589,7 @@ int solid_build(mc_ctx *c, uint64_t n, int min_cov, double *ms, const PairSource
 // Builds (or reuses) the solid table for this threshold.
 int ensure_solid(mc_ctx *c, int min_cov, double *ms)
 {
-    if (c->bfs_direct && !c->solid_external && !c->skl_state) {  // the walk looks its k-mers up in the counting table: nothing to build
-        // (not while the table is organised by the minimizers of the bases, count_long.h: the walk then gets a copy of the solid k-mers)
+    if (c->bfs_direct && !c->solid_external) {  // the walk looks its k-mers up in the counting table: nothing to build
         c->solid_is_table = true;
         c->solid_cov = min_cov;
         return MC_OK;
@@ -4511,15 +4276,21 @@ int group_exchange_count(mc_group *g, std::vector<GroupRank> &R)
             return mc_extract_superkmers_dev(c, X.d_words, X.d_off, X.n_reads, X.n_bases, (uint32_t)W, X.send.p, X.send_p.p, cap, X.owner_off.data());
         }
         if (X.send.alloc(X.windows) != hipSuccess || X.send_p.alloc(X.windows) != hipSuccess) return MC_ENOMEM;
+        // A group that deals super-k-mer records deals by minimizer (sk_owner), and the owner of a k-mer must not depend on the
+        // form a batch travels in: one batch as keys dealt by the key's own hash would split a k-mer's count over two shards
+        // -- each under the threshold, perhaps, and the k-mer gone from the graph.
+        c->extract_by_minimizer = sk;
         return mc_extract_keys_dev(c, X.d_words, X.d_off, X.n_reads, X.n_bases, (uint32_t)W, reinterpret_cast<int64_t *>(X.send.p), X.send_p.p, X.windows,
                                    X.owner_off.data());
     };
     int rc = per_rank(W, [&](size_t r) -> int { return extract(r, sk); });
     if (rc == MC_EOVERFLOW && sk) {
         // an owner's piece overflowed (reads of low complexity share one minimizer, hence one owner): this batch travels as
-        // keys instead, on every rank alike -- one record per window, bucketed by the key's own hash, which cannot be skewed
+        // keys instead, on every rank alike -- one record per window, counted per owner first and then packed (no piece to
+        // overflow), and dealt to the SAME owners: those of the keys' minimizers
         sk_batch = false;
         for (mc_ctx *c : g->ctx) c->err.clear();
+        if (getenv("MC_INGEST_DEBUG")) fprintf(stderr, "[ingest] group: an owner's piece of the record form overflowed; this batch travels as keys, dealt by minimizer\n");
         rc = per_rank(W, [&](size_t r) -> int { return extract(r, false); });
     }
     if (rc) {

@@ -30,6 +30,7 @@ class ShardedCounter:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.bytes_sent = 0
+        self.n_chunks = 0
         # Read pointers (include/mcgpu.h mc_set_read_pointers): the BFS rank walks with look-ahead read from ITS OWN
         # reads, so only its records carry pointers; the other ranks keep no read store and send zeros.
         self.bfs_rank = bfs_rank
@@ -54,6 +55,7 @@ class ShardedCounter:
         nc = torch.tensor([max(1, -(-int(n_reads) // self.chunk_reads))], dtype=torch.int64, device=self.device)
         dist.all_reduce(nc, op=dist.ReduceOp.MAX, group=self.group)
         n_chunks = int(nc.item())
+        self.n_chunks = n_chunks  # (of the last call: the tests look at it)
         bounds = [n_reads * c // n_chunks for c in range(n_chunks + 1)]
         if n_chunks > 1:  # the chunk boundaries' base offsets in one copy
             idx = torch.tensor(bounds[1:-1], dtype=torch.int64, device=self.device)

@@ -4,6 +4,7 @@ import os
 import sys
 import time
 
+os.environ.setdefault("MC_BFS_SELFCHECK", "1")  # every walk also checked on the device (bfs_device.h k_bfs_check)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np

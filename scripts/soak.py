@@ -6,6 +6,7 @@ import sys
 import time
 
 os.environ["MC_COUNT_PATH"] = "partition"
+os.environ.setdefault("MC_BFS_SELFCHECK", "1")  # every walk also checked on the device (bfs_device.h k_bfs_check)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
@@ -18,6 +19,8 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 only = int(os.environ["SOAK_ONLY"]) if "SOAK_ONLY" in os.environ else None  # replay one iteration of a run (the others only draw their numbers)
 first = int(os.environ.get("SOAK_FROM", 0))                                     # ... or all from this one on
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+SEEDS = int(os.environ.get("SOAK_SEEDS", 6))  # seed sequences per table, three walks each
+walks = 0
 t0 = time.time()
 for it in range(iters):
     k = int(rng.choice([21, 23, 24, 25, 27, 28, 29, 30, 31, 31, 31, 41]))
@@ -65,11 +68,18 @@ for it in range(iters):
     ok, oc = t.dump()
     assert np.array_equal(gk, ok) and np.array_equal(gc, oc), it
     a = int(rng.integers(0, max(1, clen - 600)))
-    seed = genome[a:a + 400]
-    hi, lo = seed_windows(seed, k)
-    for d in (1, -1, 0):
-        got = ctx.bfs(hi, lo, d, cov, 20000, -1)
-        want = po.bfs(t, k, omode, [seed], d, cov, 20000, -1)
+    srng = np.random.default_rng(rseed)  # (a generator of its own: the iterations' draws stay what they were)
+    for si, d in [(si, d) for si in range(SEEDS) for d in (1, -1, 0)]:
+        if d == 1:
+            if si:
+                a = int(srng.integers(0, max(1, contigs * clen - 600)))
+            seed = genome[a:a + 400]
+            hi, lo = seed_windows(seed, k)
+        # --maxkmers: 20000 as ever for the first seed, then around the size of a contig (the cap bites a few vertices from the end), small, or out of reach
+        maxk = 20000 if si == 0 else int(srng.choice([20000, clen - k + 1 + int(srng.integers(-40, 41)), int(srng.integers(400, 3000)), 1 << 20]))
+        got = ctx.bfs(hi, lo, d, cov, maxk, -1)
+        want = po.bfs(t, k, omode, [seed], d, cov, maxk, -1)
+        walks += 1
         if got is not None and want is not None and len(got["hi"]) != len(want["hi"]):  # what the replayed iteration got too much / too little
             n = min(len(got["hi"]), len(want["hi"]))
             for name, r in (("device", got), ("oracle", want)):
@@ -83,4 +93,4 @@ for it in range(iters):
     ctx.close()
     print("it %d ok%s: k=%d err=%d L=%d reads=%d genome=%dx%d cov=%d hint=%d cap=%d batches=%d distinct=%d list=%d sweeps=%d spills=%d (%.0f s)" % (
         it, " (ragged)" if ragged else "", k, err, L, n_reads, contigs, clen, cov, hint, cap, 2 if two else 1, nd, st.solid_list_builds, st.solid_sweeps, st.spill_keys, time.time() - t0), flush=True)
-print("soak ok: %d iterations" % iters)
+print("soak ok: %d iterations, %d walks" % (iters, walks))

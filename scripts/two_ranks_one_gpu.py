@@ -41,6 +41,12 @@ def _worker(rank, world, port, k, q):
         err, cov, hint = int(rng.choice([0, 50, 100, 300])), int(rng.integers(2, 6)), bool(rng.integers(0, 2))
     genome, reads, off = synth_case(contigs, clen, n_reads, L, err)
     lo, hi = split_reads(n_reads, world, rank)
+    if not VARIANT or VARIANT % 2:
+        # the exchange in several chunks (configs[3] needs four a rank), the shares unequal: rank 1 has fewer reads than
+        # chunks, so some of its chunks are empty while rank 0 still sends -- and rank 0's chunks start at absolute offsets
+        share0 = n_reads - 3
+        lo, hi = (0, share0) if rank == 0 else (share0, n_reads)
+        os.environ["MC_EXCHANGE_CHUNK_READS"] = str(-(-share0 // 5))
     mine = reads[lo * L:hi * L]
     words = torch.from_numpy(po.pack(mine).view(np.int64)).to(dev)
     offs = torch.from_numpy((np.arange(hi - lo + 1, dtype=np.uint64) * L).view(np.int64)).to(dev)
@@ -49,8 +55,9 @@ def _worker(rank, world, port, k, q):
     if hint:
         ctx.set_coverage_hint(cov)
     sc = ShardedCounter(ctx, dev)
-    sc.parts_min_reads = 0  # two pieces even for this small read set: the pipelined exchange is what runs at scale
     sc.add_reads_dev(words, offs, hi - lo, (hi - lo) * L, (hi - lo) * (L - k + 1))
+    if not VARIANT or VARIANT % 2:
+        assert sc.n_chunks == 5, sc.n_chunks
     total = sc.finalize()
     solid = m.Context(k, mode, 0, 0) if rank == 0 else None
     n_solid = sc.gather_solid(solid, cov, dst=0)
@@ -71,7 +78,7 @@ def _worker(rank, world, port, k, q):
                 continue
             assert np.array_equal(got["lo"], want["lo"]) and np.array_equal(got["dist"], want["dist"])
             assert np.array_equal(got["cov"], want["cov"]) and np.array_equal(got["hi"], want["hi"])
-        q.put(("ok", total, n_solid, sc.bytes_sent, ctx.superkmer_capacity(1000, 10) > 0))
+        q.put(("ok", total, n_solid, sc.bytes_sent, sc.n_chunks, ctx.superkmer_capacity(1000, 10) > 0))
     dist.barrier()
     dist.destroy_process_group()
 

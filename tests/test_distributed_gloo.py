@@ -101,21 +101,25 @@ class OracleBackedContext:
         return n
 
 
-def _worker(rank, world, port, k, mode, reads, L, n_reads, min_cov, q, records=False, pieces=1):
+def _worker(rank, world, port, k, mode, reads, L, n_reads, min_cov, q, records=False, chunk_reads=0, share0=None):
+    # chunk_reads: MC_EXCHANGE_CHUNK_READS (0: the default, one chunk here); share0: reads of rank 0 (None: equal shares)
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        if chunk_reads:
+            os.environ["MC_EXCHANGE_CHUNK_READS"] = str(chunk_reads)
         from metacherchant_amd.distributed import ShardedCounter, split_reads
         from oracle import pyoracle as po
         lo, hi = split_reads(n_reads, world, rank)
+        if share0 is not None:  # unequal shares of a world of two: the small one runs out of reads while the other still has chunks
+            lo, hi = (0, share0) if rank == 0 else (share0, n_reads)
         mine = reads[lo * L:hi * L]
         words = torch.from_numpy(po.pack(mine).view(np.int64))
         off = torch.from_numpy((np.arange(hi - lo + 1, dtype=np.uint64) * L).view(np.int64))
         ctx = OracleBackedContext(k, mode, records)
         sc = ShardedCounter(ctx, torch.device("cpu"))
-        sc.parts, sc.parts_min_reads = pieces, 0  # pieces > 1: the exchange of a piece overlaps the extraction of the next
         sc.add_reads_dev(words, off, hi - lo, (hi - lo) * L, (hi - lo) * (L - k + 1))
         total = sc.finalize()
         solid = OracleBackedContext(k, mode)
@@ -125,7 +129,7 @@ def _worker(rank, world, port, k, mode, reads, L, n_reads, min_cov, q, records=F
         assert all(native.key_owner(int(x), world) == rank for x in own_keys[:500])
         if rank == 0:
             sk, scnt = solid.t.dump()
-            q.put((total, n_solid, sk, scnt, sc.bytes_sent))
+            q.put((total, n_solid, sk, scnt, sc.bytes_sent, sc.n_chunks))
     finally:
         dist.destroy_process_group()
 
@@ -138,8 +142,11 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("k,mode,records,pieces", [(31, 0, False, 1), (35, 1, False, 1), (31, 0, True, 1), (31, 0, True, 2), (27, 0, True, 3)])
-def test_sharded_count_equals_single_table(k, mode, records, pieces):
+# (k, key mode, record form, MC_EXCHANGE_CHUNK_READS, reads of rank 0 of 300): the last three run the exchange in several chunks,
+# with shares so unequal that rank 1 (6, 2 and 0 reads) has chunks without a read while rank 0 still sends
+@pytest.mark.parametrize("k,mode,records,chunk_reads,share0", [(31, 0, False, 0, None), (35, 1, False, 0, None), (31, 0, True, 0, None),
+                                                                (31, 0, True, 64, 294), (27, 0, True, 50, 298), (33, 1, False, 64, 300)])
+def test_sharded_count_equals_single_table(k, mode, records, chunk_reads, share0):
     from metacherchant_amd import build
     build.build_lib()  # key_owner comes from the C ABI (host function, no GPU needed)
     from oracle import pyoracle as po
@@ -151,10 +158,10 @@ def test_sharded_count_equals_single_table(k, mode, records, pieces):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, k, mode, reads, L, n_reads, min_cov, q, records, pieces)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, k, mode, reads, L, n_reads, min_cov, q, records, chunk_reads, share0)) for r in range(2)]
     for p in procs:
         p.start()
-    total, n_solid, sk, scnt, sent = q.get(timeout=120)
+    total, n_solid, sk, scnt, sent, n_chunks = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -164,6 +171,7 @@ def test_sharded_count_equals_single_table(k, mode, records, pieces):
     assert n_solid == int(m.sum())
     assert np.array_equal(sk, ok[m]) and np.array_equal(scnt, oc[m])
     assert sent > 0
+    assert n_chunks == (1 if not chunk_reads else -(-share0 // chunk_reads)) and (not chunk_reads or n_chunks >= 3)
 
 
 def test_split_reads_covers_everything():

@@ -404,6 +404,49 @@ def test_cli_several_devices_equal_one(cli, tmp_path, devices, k, extra, env):
     _assert_same_tree(res, outs["one"][0], want)
 
 
+def test_cli_devices_batch_that_falls_back_to_keys_keeps_its_owners(cli, tmp_path):
+    """a batch whose records overflow an owner's piece (low-complexity reads: one minimizer, one owner) travels as
+    keys instead.  Keys used to be dealt by their own hash, records by their minimizer: a k-mer counted as records in one
+    batch and as keys in the next had its count split over two shards, each perhaps under --coverage.  Here the middle one
+    of three exchanges is two thirds poly-A / (AC)n reads and takes the key form on eight shares of the GPU, the genome's
+    reads are spread over all three, and the output must be the one device's and the oracle's, byte for byte."""
+    genome, reads, _ = synth_case(2, 40000, 60000, 150, 60)
+    L = 150
+    low = np.zeros(L, dtype=np.uint8), np.tile(np.array([0, 2], dtype=np.uint8), L // 2)  # AAAA..., ACAC...
+    # 20 000 genome reads, 14 000 low-complexity ones in runs of 1 000 (a workgroup of the extraction then holds nothing else,
+    # and all its records go to one owner), 40 000 genome reads: exchanges of 8 x 4 200 reads -- the first two meet the runs
+    # and fall back to keys, the third (6 800 genome reads) travels as records
+    parts = [reads[:20000 * L]] + [np.tile(low[(i // 1000) & 1], 1) for i in range(14000)] + [reads[20000 * L:]]
+    allr = np.concatenate(parts)
+    n = len(allr) // L
+    assert n == 74000
+    fa = str(tmp_path / "reads.fasta")
+    _write_fasta(fa, allr, L)
+    seq = str(tmp_path / "genes.fasta")
+    with open(seq, "w") as f:
+        f.write(">g1\n%s\n" % po.decode(genome[5000:5400]))
+    outs = {}
+    for name, dev in (("one", None), ("many", "0,0,0,0,0,0,0,0")):
+        out = str(tmp_path / ("out_" + name))
+        cmd = [cli, "-k", "31", "-i", fa, "--seq", seq, "-o", out, "-w", str(tmp_path / ("wd_" + name)), "--force", "--maxkmers", "6000", "--coverage", "40"]
+        if dev:
+            cmd += ["--devices", dev]
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, MC_GROUP_BATCH_READS="4200", MC_TOKENIZER="host", MC_INGEST_DEBUG="1"))
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs[name] = (out, p.stderr)
+    assert "this batch travels as keys" in outs["many"][1], outs["many"][1][-3000:]
+    assert outs["many"][1].count("this batch travels as keys") == 2  # (not every batch: the k-mers of the genome are counted in both forms)
+    size_line = [l for l in outs["one"][1].splitlines() if "Hashtable size" in l][0].split("Hashtable size")[1]
+    assert ("Hashtable size" + size_line) in outs["many"][1]
+    seqs, comments = ho.rich_fasta_read(seq)
+    want = str(tmp_path / "want")
+    # --coverage 40 of ~110-fold: a k-mer whose count were split over two shards would fall under it
+    _, res = _oracle_run([fa], 31, po.KEY_PACKED, seqs, comments, want, max_kmers=6000, coverage=40)
+    _assert_same_tree(res, outs["many"][0], want)
+    _assert_same_tree(res, outs["one"][0], want)
+
+
 def test_cli_rccl_transport_wants_a_gpu_per_rank(cli, tmp_path):
     """The RCCL transport of the native driver (ncclCommInitAll, grouped ncclSend / ncclRecv) cannot run on shares of one GPU
     -- a communicator takes every device once -- and says so instead of hanging in the rendezvous; test_cli_two_real_devices

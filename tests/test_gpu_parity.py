@@ -315,6 +315,31 @@ def test_capacity_hint_a_quarter_of_what_the_reads_hold(mc, monkeypatch):
     ctx.close()
 
 
+@pytest.mark.parametrize("k,mode", [(21, "packed"), (41, "poly")])
+def test_solid_copy_of_a_crowded_hash_prefix_table_holds_the_keys_that_moved_on(mc, monkeypatch, k, mode):
+    """tables whose regions are hash prefixes (k < 23, hash keys) hand an addition that finds its stretch full on to
+    the next region (kmer_device.h TABLE_CHAIN).  The builder of the walk's own copy of the solid k-mers (MC_BFS_DIRECT=0) scanned
+    only the counting regions a solid region's keys are AT HOME in and lost the ones that had moved on: the walk then took a
+    solid k-mer for absent.  A capacity hint far too small crowds the table; walks in all directions against the oracle."""
+    monkeypatch.delenv("MC_COUNT_PATH", raising=False)
+    monkeypatch.setenv("MC_BFS_DIRECT", "0")
+    omode, gmode = (po.KEY_PACKED, mc.KEY_PACKED) if mode == "packed" else (po.KEY_POLY, mc.KEY_POLY)
+    genome, reads, off = synth_case(3, 150000, 100000, 250, 200)
+    t, _ = oracle_table(reads, off, k, omode)
+    ctx = mc.Context(k, gmode, 0, t.size() // 4)
+    half = 50000
+    ctx.add_reads_packed(po.pack(reads[:off[half]]), off[:half + 1])
+    ctx.add_reads_packed(po.pack(reads[off[half]:]), off[half:] - off[half])
+    assert ctx.finalize() == t.size()
+    assert ctx.stats().spill_keys > 0  # (occurrences were handed on / parked)
+    for a in (20000, 170000, 400000):
+        seed = genome[a:a + 300]
+        hi, lo = seed_windows(seed, k)
+        for d in (1, -1, 0):
+            assert_bfs_equal(ctx.bfs(hi, lo, d, 3, 8000, -1), po.bfs(t, k, omode, [seed], d, 3, 8000, -1))
+    ctx.close()
+
+
 def test_trim_gives_the_scratch_back_and_the_context_carries_on(mc, monkeypatch):
     """mc_trim: the pipeline's scratch and the pools' idle blocks go back to the driver; the table, the read store and a valid
     list of solid k-mers stay, so walks before and after are the same, and the next batch allocates its scratch again."""
@@ -698,39 +723,3 @@ def test_hints_survive_exchange_and_speed_up_the_walk(mc):
     assert_bfs_equal(res["with"], res["without"])
     assert rounds["with"] * 4 < rounds["without"]
     ex.close()
-
-
-@pytest.mark.parametrize("k", [63, 33, 48])
-def test_long_superkmer_records_give_the_same_table_and_walk(mc, k, monkeypatch):
-    """MC_SK_LONG=1 (csrc/count_long.h, an experiment that is off by default): polynomial-hash keys for k = 32 .. 63 counted
-    from 32-byte super-k-mer records into a table organised by the minimizers of the k-mers' bases -- the oracle's table,
-    the oracle's walk (which makes the table go back to regions by key hash for get()), then a second batch on top."""
-    monkeypatch.setenv("MC_SK_LONG", "1")
-    monkeypatch.setenv("MC_COUNT_PATH", "partition")
-    genome, reads, off = synth_case(2, 30000, 8000, 150, 100)
-    t, n = oracle_table(reads, off, k, po.KEY_POLY)
-    ctx = mc.Context(k, mc.KEY_POLY, 0, 0)
-    ctx.set_coverage_hint(3)
-    half = 5000
-    ctx.add_reads_packed(po.pack(reads[:off[half]]), off[:half + 1])
-    ctx.add_reads_packed(po.pack(reads[off[half]:]), off[half:] - off[half])
-    assert ctx.stats().windows == n
-    nd = ctx.finalize()
-    seed = genome[10000:10400]
-    hi, lo = seed_windows(seed, k)
-    for d in (0, 1):  # (the walk reads a copy of the solid k-mers while the table is in minimizer bins)
-        assert_bfs_equal(ctx.bfs(hi, lo, d, 3, 3000, -1), po.bfs(t, k, po.KEY_POLY, [seed], d, 3, 3000, -1))
-    _assert_tables_equal(ctx, nd, t)
-    gk, _ = ctx.export(0)
-    q = np.concatenate([gk[:500], np.array([12345, -7], dtype=np.int64)])
-    assert np.array_equal(ctx.get(q), t.get_many(q))  # by key: the table is rebuilt by key hash first
-    assert_bfs_equal(ctx.bfs(hi, lo, -1, 3, 3000, -1), po.bfs(t, k, po.KEY_POLY, [seed], -1, 3, 3000, -1))
-    # a ragged batch (empty reads, reads shorter than k) through the same records
-    ctx.clear()
-    rng = np.random.default_rng(k)
-    _, codes, roff = ragged_case(rng, 3000, max_len=300, genome_len=20000)
-    t2, n2 = oracle_table(codes, roff, k, po.KEY_POLY)
-    ctx.add_reads_packed(po.pack(codes), roff)
-    assert ctx.stats().windows == n + n2
-    _assert_tables_equal(ctx, ctx.finalize(), t2)
-    ctx.close()

@@ -20,13 +20,14 @@ def test_two_ranks_on_one_gpu(k, records):
     line = [l for l in p.stdout.splitlines() if l.startswith("two ranks on one GPU")][-1]
     assert "'ok'" in line
     assert line.rstrip(")").endswith("True" if records else "False")  # which form of the exchange ran
+    assert ", 5, " in line  # ... in five chunks, rank 1 with three reads in all (scripts/two_ranks_one_gpu.py)
 
 
 def test_bench_multi_rank_path_on_one_gpu():
     """bench.py --gpus 2 as the driver launches it (torch.distributed.run), both ranks on the one GPU over gloo:
     the sharded step runs and rank 0 prints one JSON line with the whole-job numbers."""
     import json
-    env = dict(os.environ, MC_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MC_EXCHANGE_MIN_READS="0")  # two pieces, as at full size
+    env = dict(os.environ, MC_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MC_EXCHANGE_CHUNK_READS="40000")  # four chunks a rank, as configs[3] needs
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29617", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--reads", "300000", "--contigs", "2", "--contig-len", "1000000", "--no-cpu-baseline"]
