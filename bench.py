@@ -103,8 +103,11 @@ def main():
 
     ctx = m.Context(k, mode, local_rank, hint_local, m.native.FLAG_SOLID_LIST if world > 1 else 0)
     ctx.set_coverage_hint(args.coverage)  # --coverage is known before the reads are loaded (the CLI does the same)
+    # several ranks: rank 0 walks over every rank's table in place (mc_shard_attach); MC_BENCH_WALK=gather keeps round 3's way --
+    # the k-mers at or above --coverage gathered into a BFS-only context on rank 0
+    walk_in_place = os.environ.get("MC_BENCH_WALK", "shards") != "gather"
     solid = None
-    if world > 1 and rank == 0:
+    if world > 1 and rank == 0 and not walk_in_place:
         solid = m.Context(k, mode, local_rank, 1 << 20)  # BFS-only (mc_solid_from_pairs_dev): its counting table stays empty
 
     # ---- synthetic reads straight into HBM (not timed)
@@ -133,7 +136,9 @@ def main():
         info["distinct"] = sc.finalize()  # (waits for the counting to end)
         info["count_wall_s"] = info.get("count_wall_s", 0.0) + (time.perf_counter() - t_c)
         bctx = ctx
-        if world > 1:
+        if world > 1 and walk_in_place:
+            sc.attach_shards(dst=0)
+        elif world > 1:
             if solid is not None:
                 solid.clear()
             info["solid"] = sc.gather_solid(solid, args.coverage, dst=0)
@@ -153,6 +158,8 @@ def main():
                 lookups += r["lookups"]
             bfs_ms = res[0]["device_ms"]
             info.update(bfs_ms=bfs_ms, reached=reached, levels=levels, lookups=lookups)
+        if world > 1 and walk_in_place:
+            sc.walk_done(dst=0)  # (the other ranks' tables were being read: nobody clears before rank 0 has let go)
 
     def sync():
         if world > 1:
@@ -298,6 +305,7 @@ def main():
                               "how": "fresh context (64 MB table) per step; table sized from the first level-1 bucket of the batch; table memory recycled inside the process"}
         if world > 1:
             out["solid_kmers"] = info.get("solid")
+            out["walk"] = "rank 0 reads every rank's counting table in place (mc_shard_attach)" if walk_in_place else "solid k-mers gathered into a BFS-only context on rank 0"
             out["alltoall_bytes_sent_rank0_per_step"] = sc.bytes_sent // (args.steps + args.warmup)
     if world > 1:
         dist.barrier()

@@ -243,12 +243,34 @@ int mc_extract_superkmers_dev(mc_ctx *ctx, const uint64_t *d_words, const uint64
                               uint64_t records_cap, uint64_t *owner_offsets);
 int mc_add_superkmers_dev(mc_ctx *ctx, const uint64_t *d_records, const uint32_t *d_bins, uint64_t n);
 
+/* ---- the walk over several ranks' tables where they are.  After the exchange every rank's counting table holds the k-mers it
+ * owns; instead of gathering the ones at or above --coverage into a second table on the rank that walks (mc_export_dev ->
+ * mc_solid_from_pairs_dev: at configs[3]'s size that copy does not fit beside the rank's own table), the walking context
+ * is given every rank's table and looks a k-mer up in its owner's, through peer access (contexts of one process) or an
+ * IPC mapping (one process per GPU).  What the reference does: P threads read the one shared map,
+ * src/algo/OneSequenceCalculator.java:203-204.
+ *   mc_shard_export  after mc_finalize_counts: an opaque, fixed-size description of this context's table (geometry, an IPC
+ *                    handle of its memory) to be sent to the walking rank by any means (an all-gather of 128 bytes).  The
+ *                    table must stay as it is -- no counting, no mc_clear, no mc_destroy -- until the walker has detached.
+ *   mc_shard_attach  on the walking context (which has counted its own share and keeps the read store the walk reads its
+ *                    look-ahead from): shards[i] = rank i's handle, shards[self] its own.  by_minimizer != 0: the exchange
+ *                    dealt super-k-mer records (mc_extract_superkmers_dev), so a k-mer is owned by the owner of its
+ *                    minimizer; 0: it dealt keys (mc_key_owner).  From here on mc_bfs / mc_bfs_batch on this context walk the
+ *                    union of the tables, any --coverage; results equal a single context's.  mc_get / mc_export still see
+ *                    this context's own shard only.
+ *   mc_shard_detach  gives the mappings up (mc_clear and mc_destroy do so too). */
+typedef struct { unsigned char bytes[128]; } mc_shard_handle;
+int mc_shard_export(mc_ctx *ctx, mc_shard_handle *out);
+int mc_shard_attach(mc_ctx *ctx, const mc_shard_handle *shards, uint32_t n_shards, uint32_t self, int by_minimizer);
+int mc_shard_detach(mc_ctx *ctx);
+
 /* ---- several GPUs of one node as ONE table, for a host that is one process (the native `metacherchant --devices 0,1,...`).
  * A context per device and one host thread per device; reads are dealt to the devices in equal contiguous shares, every
  * device buckets its share by owner (mc_extract_superkmers_dev / mc_extract_keys_dev), the buckets travel as peer-to-peer
  * copies over xGMI -- every (source, destination) pair at once -- and every device counts what it owns
- * (mc_add_superkmers_dev / mc_add_keys_dev); for the BFS the k-mers at or above the threshold are gathered on the first
- * device (mc_export_dev -> mc_solid_from_pairs_dev) and the walk runs there.  Results equal a single context's.
+ * (mc_add_superkmers_dev / mc_add_keys_dev); the walk runs on the first device and reads every device's table in place
+ * (mc_shard_attach; without peer access between all devices, or with MC_GROUP_WALK=gather, the k-mers at or above the
+ * threshold are gathered on the first device instead: mc_export_dev -> mc_solid_from_pairs_dev).  Results equal a single context's.
  * `cfg->device` is ignored; capacity_hint is the whole job's.  A device may be named more than once (shares of one GPU).
  * Replaces the same Java as the single-context calls: the P threads over one shared map of src/io/IOUtils.java:283-315 and
  * the work list of src/io/ReadsDispatcher.java:34-53.  ctx may be NULL in mc_group_last_error after a failed create. */

@@ -36,14 +36,30 @@ constexpr uint32_t SCOUT_WORDS = 16;                  // read-store words a hop 
 constexpr uint32_t SCOUT_MH = 64 + SK_M + 2;          // minimizer hashes a hop looks at (64 new vertices + the tip's own)
 constexpr uint32_t SCOUT_BUDGET0 = 1024;              // levels of the first scout run; doubled after every run the rounds used up
 #ifndef MC_TEAM_MAX
-#define MC_TEAM_MAX 2   // waves that follow different candidate reads of one walker's hop (measured on configs[1], BFS phase: 1 wave 14.0 ms,
-                        // 2 waves 11.2, 4 waves 11.8, 8 waves 14.3: the longer hops of a larger team cost more in lookups issued by one CU than they save)
+#define MC_TEAM_MAX 2   // waves of one walker's hop: MC_CAND_MAX candidate reads, each looked at by MC_TEAM_MAX / MC_CAND_MAX waves -- wave s of a
+                        // candidate takes the levels 64 s + 1 .. 64 s + 64 past the tip.  Two waves per candidate (-DMC_TEAM_MAX=4: a hop of up
+                        // to 128 levels of ONE read) were built and measured in round 4: the hops are cut by the reads' errors and ends, not
+                        // by the 64 lanes (mean error-free run at 1 %: 100 bases), and four busy waves make a hop 6.2 us instead of 4.6:
+                        // 9.8 ms against 9.4 on configs[1].  Left as an option.
 #endif
+#ifndef MC_CAND_MAX
+#define MC_CAND_MAX 2   // candidate reads a hop follows (measured in round 2 on configs[1], one 64-level wave per candidate: 1 candidate 14.0 ms,
+                        // 2: 11.2, 4: 11.8, 8: 14.3)
+#endif
+#ifndef MC_SEG_MIN
+#define MC_SEG_MIN 8    // a hop's second stretch of 64 levels counts only when it holds at least this many (the next hop's candidates are
+                        // the read pointers of its last vertices: too few of them and the hop after finds no read to follow)
+#endif
+constexpr uint32_t SCOUT_BACK = 192;                  // bases in front of a pointer's position a hop's words reach back to (a read that runs against the
+                                                      // walk is followed up to 128 + 47 bases backwards)
 #ifndef MC_SCOUT_WARM
 #define MC_SCOUT_WARM 0   // a hop's lanes touch the read-store lines their pointers name (the next hop starts at one of them)
 #endif
 #ifndef MC_SCOUT_PROBES
 #define MC_SCOUT_PROBES 4   // slots a scout's lookup requests at once
+#endif
+#ifndef MC_SCOUT_OPTIMISTIC
+#define MC_SCOUT_OPTIMISTIC 0   // 1: a scout's lookup that finds neither its key nor a free slot among those takes the vertex for solid
 #endif
 constexpr int NARROW_CAND = 64;           // candidates per replayed level = lanes of one wave
 constexpr int RH_SIZE = 1024;             // round-local LDS set (narrow, slow replay)
@@ -557,7 +573,15 @@ __device__ __forceinline__ int solid_get4(const SolidView &t, uint64_t key, uint
         if (cur == key) { *aux = a[i].w; return a[i].z > 32767u ? 32767 : (int)a[i].z; }
         if (cur == EMPTY_KEY) return -1;
     }
+#if MC_SCOUT_OPTIMISTIC
+    // None of the NP slots held the key and none was free: the key sits further along (1 % of the solid k-mers at the table's
+    // load) or is not there.  A scout only guesses: it takes the vertex for solid (without a pointer) and saves the second
+    // round trip that the slowest of its 64 lanes would make the whole hop wait for (every other hop has such a lane); the
+    // walk's rounds look every vertex up properly.
+    return 32767;
+#else
     return solid_probe_from(t, key, base | ((s0 + NP) & t.rmask), NP, aux);
+#endif
 }
 
 // ---- one hop of a scout -------------------------------------------------------------------------------------------
@@ -574,7 +598,7 @@ struct HopEval {
     // n_cand > 0 was asked for: the next hop's candidates -- the pointers nearest to the tip that lead into other reads, one
     // per read -- and the read store's words around them, requested as soon as they are known (lanes 16 i .. 16 i + 15: the
     // words of candidate i, see scout_word_of)
-    uint32_t nc, cptr[MC_TEAM_MAX], cdelta[MC_TEAM_MAX];  // (uniform)
+    uint32_t nc, cptr[MC_CAND_MAX], cdelta[MC_CAND_MAX];  // (uniform)
     uint64_t word;                                         // (lane)
 };
 
@@ -584,7 +608,7 @@ __device__ __forceinline__ uint64_t scout_word_of(const SolidView &t, uint32_t c
     uint32_t span;
     const uint64_t lo = ptr_decode(cptr, &span);
     if (lo >= t.reads_bases) return 0;
-    const uint64_t wlo = (lo > 128 ? lo - 128 : 0) >> 5, last_word = (t.reads_bases + 31) / 32;
+    const uint64_t wlo = (lo > SCOUT_BACK ? lo - SCOUT_BACK : 0) >> 5, last_word = (t.reads_bases + 31) / 32;
     return t.reads[min(wlo + i, last_word)];
 }
 
@@ -592,8 +616,9 @@ __device__ __forceinline__ uint64_t scout_word_of(const SolidView &t, uint32_t c
 template <int MODE>
 __device__ __forceinline__ void scout_eval(const SolidView &t, uint64_t *sw, uint32_t *mh, const Kmer &X, int k, int min_cov, uint32_t cptr,
                                            uint32_t delta, uint32_t want, HopEval &R, unsigned long long &lookups, unsigned long long *tsc = nullptr,
-                                           bool staged = false, uint32_t n_cand = 0)
+                                           bool staged = false, uint32_t n_cand = 0, uint32_t lane_base = 0)
 {   // staged: sw already holds the SCOUT_WORDS words around the pointer (scout_words_of: the companion requests them a hop ahead)
+    // lane_base: this wave looks at the vertices lane_base + 1 .. lane_base + 64 levels past the tip (the second wave of a candidate: 64)
 #ifdef MC_SCOUT_TIMING
     unsigned long long ts_ = __builtin_amdgcn_s_memrealtime();
 #define SC_STAMP(i) do { if (tsc) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); tsc[i] += n_ - ts_; ts_ = n_; } } while (0)
@@ -605,13 +630,13 @@ __device__ __forceinline__ void scout_eval(const SolidView &t, uint64_t *sw, uin
     R.m = 0; R.why = 1; R.fwd = true; R.Q = -1; R.e_hi = R.e_lo = 0; R.K = Kmer{0, 0}; R.aux = 0; R.other = false;
     R.nc = 0; R.word = 0;
 #pragma unroll
-    for (int i = 0; i < MC_TEAM_MAX; i++) { R.cptr[i] = 0; R.cdelta[i] = 0; }
+    for (int i = 0; i < MC_CAND_MAX; i++) { R.cptr[i] = 0; R.cdelta[i] = 0; }
     uint32_t span;
     const uint64_t lo = ptr_decode(cptr, &span);
     if (lo >= t.reads_bases) return;  // (a pointer from elsewhere)
     const uint64_t last_word = (t.reads_bases + 31) / 32;  // the pad word
     // the piece of the read store around the occurrence
-    const uint64_t wlo = (lo > 128 ? lo - 128 : 0) >> 5;
+    const uint64_t wlo = (lo > SCOUT_BACK ? lo - SCOUT_BACK : 0) >> 5;
     if (!staged) {
         __builtin_amdgcn_wave_barrier();
         if (lane < SCOUT_WORDS) sw[lane] = t.reads[min(wlo + lane, last_word)];
@@ -646,22 +671,32 @@ __device__ __forceinline__ void scout_eval(const SolidView &t, uint64_t *sw, uin
     if (Q < 0) return;
     Q = (long long)uni64((uint64_t)Q);  // (wave-uniform: what follows from it can run on the scalar unit)
     R.Q = Q; R.fwd = fwd; R.why = 2;
-    // lane i: the vertex i + 1 levels past the tip
+    // lane i: the vertex lane_base + i + 1 levels past the tip
+    const uint32_t lv = lane_base + lane;
     Kmer K{0, 0};
     bool ok = lane < want;
     if (fwd) {
-        const uint64_t pi = (uint64_t)Q + 1 + lane;
-        ok = ok && pi + (uint64_t)k <= t.reads_bases;
+        const uint64_t pi = (uint64_t)Q + 1 + lv;
+        ok = ok && pi + (uint64_t)k <= t.reads_bases && pi + (uint64_t)k <= (base + 32ull * (SCOUT_WORDS - 1));  // (inside the words at hand)
         if (ok) K = kmer_at<MODE>(sw, pi - base, k);
     } else {
-        ok = ok && (uint64_t)Q >= (uint64_t)lane + 1;
-        if (ok) K = kmer_rc<MODE>(kmer_at<MODE>(sw, (uint64_t)Q - 1 - lane - base, k), k);
+        ok = ok && (uint64_t)Q >= (uint64_t)lv + 1 + base;
+        if (ok) K = kmer_rc<MODE>(kmer_at<MODE>(sw, (uint64_t)Q - 1 - lv - base, k), k);
+    }
+    // the vertex in front of this wave's first one (the tip itself for the first wave of a candidate): its SK_M-mers are the
+    // ones the first lanes' windows reach back into
+    Kmer Xs = X;
+    if (lane_base) {
+        const bool okx = fwd ? (uint64_t)Q + lane_base + (uint64_t)k <= t.reads_bases : (uint64_t)Q >= (uint64_t)lane_base + base;
+        if (!okx) return;  // (uniform: the read ends before this wave's stretch begins)
+        Xs = fwd ? kmer_at<MODE>(sw, (uint64_t)Q + lane_base - base, k) : kmer_rc<MODE>(kmer_at<MODE>(sw, (uint64_t)Q - lane_base - base, k), k);
     }
     uint32_t aux = 0;
     int cov = -1;
     const uint64_t key = ok ? (uint64_t)key_of<MODE>(K, k) : 0;
     uint64_t s0;
-    if (MODE == KEY_PACKED && t.mm_k) {
+    SolidView h = t;  // the table this lane's vertex lives in (several GPUs: its owner's)
+    if (MODE == KEY_PACKED && (t.n_shards > 1 ? t.owner_mm_k : t.mm_k)) {
         // The counting table's regions are minimizer bins (kmer_device.h).  The vertices of consecutive lanes overlap in
         // all but one base, so every SK_M-mer is hashed once -- a lane hashes the last one of its own vertex, the first
         // lanes also the ones inside the tip -- and a lane takes the minimum over its w of them (w = k - SK_M + 1).
@@ -673,7 +708,7 @@ __device__ __forceinline__ void scout_eval(const SolidView &t, uint64_t *sw, uin
             return sk_order(f < r ? f : r);
         };
         __builtin_amdgcn_wave_barrier();
-        if (lane + 1 < w) mh[lane] = mm_hash((uint32_t)(X.lo >> (2 * (w - 2 - lane))) & SK_MMASK);  // the tip's SK_M-mers from base lane + 1 on
+        if (lane + 1 < w) mh[lane] = mm_hash((uint32_t)(Xs.lo >> (2 * (w - 2 - lane))) & SK_MMASK);  // the SK_M-mers of the vertex in front, from base lane + 1 on
         mh[w - 1 + lane] = ok ? mm_hash((uint32_t)K.lo & SK_MMASK) : SK_NONE;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -687,13 +722,13 @@ __device__ __forceinline__ void scout_eval(const SolidView &t, uint64_t *sw, uin
         } else {
             for (uint32_t i = 0; i < w; i++) hmin = min(hmin, mh[lane + i]);
         }
-        s0 = ((((uint64_t)sk_bin(hmin) * t.n_regions) >> 32) << MC_REGION_LG) | sk_home(key);
+        s0 = solid_locate(t, key, h, &hmin);
     } else {
-        s0 = solid_slot_of(t, key);
+        s0 = solid_locate(t, key, h);
     }
     SC_STAMP(1);
     if (ok) {
-        cov = solid_get4(t, key, &aux, s0);
+        cov = solid_get4(h, key, &aux, s0);
         lookups++;
     }
     SC_STAMP(2);
@@ -721,7 +756,7 @@ __device__ __forceinline__ void scout_eval(const SolidView &t, uint64_t *sw, uin
     if (other) {  // does the pointer lead back into this very read?
         uint32_t sp;
         const uint64_t at = ptr_decode(aux, &sp);
-        const uint64_t here = fwd ? (uint64_t)Q + 1 + lane : (uint64_t)Q - 1 - lane;  // where this read holds lane's k-mer
+        const uint64_t here = fwd ? (uint64_t)Q + 1 + lv : (uint64_t)Q - 1 - lv;  // where this read holds lane's k-mer
         other = !(at <= here && here < at + sp);
     }
     if (n_cand) {
@@ -729,7 +764,7 @@ __device__ __forceinline__ void scout_eval(const SolidView &t, uint64_t *sw, uin
         const uint64_t apos = aux ? ptr_decode(aux, &sp) : 0;
         unsigned long long cm = __ballot(lane < m && lane + 48 >= m && other);
 #pragma unroll
-        for (int i = 0; i < MC_TEAM_MAX; i++) {
+        for (int i = 0; i < MC_CAND_MAX; i++) {
             if (!cm || (uint32_t)i >= n_cand) break;
             const uint32_t j = 63u - (uint32_t)__builtin_clzll(cm);
             R.cptr[i] = (uint32_t)__builtin_amdgcn_readlane((int)aux, (int)j);
@@ -743,17 +778,17 @@ __device__ __forceinline__ void scout_eval(const SolidView &t, uint64_t *sw, uin
         const uint32_t ci = lane / SCOUT_WORDS;
         uint32_t cp = 0;
 #pragma unroll
-        for (int i = 0; i < MC_TEAM_MAX; i++) cp = ci == (uint32_t)i ? R.cptr[i] : cp;
+        for (int i = 0; i < MC_CAND_MAX; i++) cp = ci == (uint32_t)i ? R.cptr[i] : cp;
         if (ci < R.nc) R.word = scout_word_of(t, cp, lane % SCOUT_WORDS);
     }
     // the m new bases, first on top: what follows the occurrence (precedes it, complemented)
     uint64_t e_hi, e_lo;
     if (fwd) {
-        e_hi = bases32(sw, (uint32_t)((uint64_t)Q + (uint64_t)k - base));
-        e_lo = m > 32 ? bases32(sw, (uint32_t)((uint64_t)Q + (uint64_t)k + 32 - base)) : 0;
+        e_hi = bases32(sw, (uint32_t)((uint64_t)Q + lane_base + (uint64_t)k - base));
+        e_lo = m > 32 ? bases32(sw, (uint32_t)((uint64_t)Q + lane_base + (uint64_t)k + 32 - base)) : 0;
     } else {
-        e_hi = bases32_before_rc(sw, (uint32_t)((uint64_t)Q - base));
-        e_lo = m > 32 ? bases32_before_rc(sw, (uint32_t)((uint64_t)Q - 32 - base)) : 0;
+        e_hi = bases32_before_rc(sw, (uint32_t)((uint64_t)Q - lane_base - base));
+        e_lo = m > 32 ? bases32_before_rc(sw, (uint32_t)((uint64_t)Q - lane_base - 32 - base)) : 0;
     }
     e_hi = uni64(e_hi);
     e_lo = uni64(e_lo);
@@ -895,15 +930,17 @@ __device__ __forceinline__ uint32_t ld_u32(const uint32_t *p) { return __hip_ato
 __device__ __forceinline__ void st_u32(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t box_resp(uint32_t seq, bool finished, uint32_t levels) { return ((seq & 0x7FFFu) << 17) | (finished ? 1u << 16 : 0u) | levels; }
 
-static_assert(MC_TEAM_MAX * SCOUT_WORDS <= 64, "a wave requests the words of all its candidates at once, SCOUT_WORDS lanes each");
+static_assert(MC_CAND_MAX * SCOUT_WORDS <= 64, "a wave requests the words of all its candidates at once, SCOUT_WORDS lanes each");
+static_assert(MC_TEAM_MAX % MC_CAND_MAX == 0 && MC_TEAM_MAX / MC_CAND_MAX <= 2, "one or two waves per candidate");
 struct TeamLds {
     Kmer X[SCOUT_MAX_F];  // tips, walk strand
     PathTail T[SCOUT_MAX_F];
     uint32_t levels[SCOUT_MAX_F], nc[SCOUT_MAX_F], stuck[SCOUT_MAX_F], right[SCOUT_MAX_F];
     uint32_t cptr[SCOUT_MAX_F][8], cdelta[SCOUT_MAX_F][8];
     uint32_t reach[BFS_THREADS / 64];
+    uint64_t ext[BFS_THREADS / 64][2];                    // the bases a candidate's second wave would add (e_hi, e_lo): its first wave appends them
     uint64_t sw[BFS_THREADS / 64][SCOUT_WORDS];
-    uint64_t swn[SCOUT_MAX_F][MC_TEAM_MAX][SCOUT_WORDS];  // the words around the candidates of the NEXT hop, requested by the wave that found them
+    uint64_t swn[SCOUT_MAX_F][MC_CAND_MAX][SCOUT_WORDS];  // the words around the candidates of the NEXT hop, requested by the wave that found them
     uint32_t staged[SCOUT_MAX_F];                         // ... are there (0 on a request's first hop)
     uint32_t mh[BFS_THREADS / 64][SCOUT_MH];
     uint32_t seq, quit, F, budget, stop;
@@ -953,7 +990,9 @@ __device__ void scout_companion(const BfsState &S, const SolidView &t, TeamLds &
         if (F == 0) continue;
         uint32_t Tm = min(W, (uint32_t)MC_TEAM_MAX);  // team size: the largest power of two with F * Tm <= W
         while (Tm > 1 && F * Tm > W) Tm >>= 1;
-        const uint32_t g = wv / Tm, u = wv - g * Tm;
+        // a team = n_cd candidate reads x n_sg waves each: wave s of a candidate looks at the levels 64 s + 1 .. 64 s + 64 past the tip
+        const uint32_t n_sg = Tm > (uint32_t)MC_CAND_MAX ? Tm / (uint32_t)MC_CAND_MAX : 1u, n_cd = Tm / n_sg;
+        const uint32_t g = wv / Tm, u = wv - g * Tm, cd = u / n_sg, sg = u - cd * n_sg;
         const bool member = g < F;
         uint64_t *P = S.path + (uint64_t)g * PATH_WORDS;
         if (member && u == 0) {
@@ -968,26 +1007,27 @@ __device__ void scout_companion(const BfsState &S, const SolidView &t, TeamLds &
         for (;;) {
             uint32_t probe = seq;
             if (tid == 0) probe = ld_u32(&box->req_seq) | (ld_u32(&box->quit) << 31);  // (used at the end of the hop)
-            R.m = 0;
+            R.m = 0; R.e_hi = 0; R.e_lo = 0;
             const bool busy = member && !L.stuck[g] && L.levels[g] < budget;
-            if (busy && u < L.nc[g]) {
+            if (busy && cd < L.nc[g] && budget - L.levels[g] > 64u * sg) {
                 const bool staged = L.staged[g] != 0;
-                scout_eval<MODE>(t, staged ? L.swn[g][u] : L.sw[wv], L.mh[wv], L.X[g], k, min_cov, L.cptr[g][u], L.cdelta[g][u], min(64u, budget - L.levels[g]), R,
-                                 lookups, tsc, staged, Tm);
-                if (R.why == 1) n_nf += lane == 0; else { hops += lane == 0; if (R.m == 0) n_m0 += lane == 0; }
+                scout_eval<MODE>(t, staged ? L.swn[g][cd] : L.sw[wv], L.mh[wv], L.X[g], k, min_cov, L.cptr[g][cd], L.cdelta[g][cd],
+                                 min(64u, budget - L.levels[g] - 64u * sg), R, lookups, tsc, staged, n_cd, 64u * sg);
+                if (sg == 0) { if (R.why == 1) n_nf += lane == 0; else { hops += lane == 0; if (R.m == 0) n_m0 += lane == 0; } }
             }
 #ifdef MC_SCOUT_TIMING
             unsigned long long tq_ = __builtin_amdgcn_s_memrealtime();
 #endif
-            // What this wave hands to the next hop if its read got furthest: the candidates it found (R.cptr) and the read
-            // store's words around them, which it asked for inside scout_eval: they travel while the team finds its winner (a
-            // hop's first act used to be to ask for them and wait: 0.5 us of its 4).
+            // What this wave hands to the next hop if the stretch it looked at ends the hop: the candidates it found (R.cptr) and
+            // the read store's words around them, which it asked for inside scout_eval: they travel while the team finds its
+            // winner (a hop's first act used to be to ask for them and wait: 0.5 us of its 4).
             const uint32_t my_nc = R.m ? R.nc : 0;
             const uint64_t my_word = R.word;
-            if (lane == 0) L.reach[wv] = R.m;
+            if (lane == 0) { L.reach[wv] = R.m; L.ext[wv][0] = R.e_hi; L.ext[wv][1] = R.e_lo; }
             // The length the previous hop added is published now: its path words (write-through stores) were issued before
-            // this hop's two round trips and every wave waits here for the stores it has outstanding, so they have arrived
-            // -- a release fence at agent scope right behind the stores would cost a cache write-back on every hop.
+            // this hop's two round trips, and a wave's loads come back behind its earlier stores, so they have arrived -- a release
+            // fence at agent scope right behind the stores would cost a cache write-back on every hop.  (The length only steers:
+            // the walk's rounds check every level they take from a path against the table.)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             const uint32_t lv_done = tid < F ? L.levels[tid] : 0;  // (read before the barrier: this hop's winner changes it behind it)
             BFS_SYNC();
@@ -996,27 +1036,35 @@ __device__ void scout_companion(const BfsState &S, const SolidView &t, TeamLds &
                 L.published[tid] = lv_done;
             }
             if (busy) {
-                uint32_t best = 0, best_u = 0;
-                for (uint32_t i = 0; i < Tm; i++) {
-                    const uint32_t r = L.reach[g * Tm + i];
-                    if (r > best) { best = r; best_u = i; }
+                // how far each candidate got: its first wave's stretch and, when that one is whole, its second wave's -- unless that
+                // holds too few vertices to name the next hop's candidates from (MC_SEG_MIN): the hop after covers them again
+                uint32_t best = 0, best_c = 0, best_r0 = 0, best_r1 = 0;
+                for (uint32_t i = 0; i < n_cd; i++) {
+                    const uint32_t r0 = L.reach[g * Tm + i * n_sg], r1x = n_sg > 1 ? L.reach[g * Tm + i * n_sg + 1] : 0u;
+                    const uint32_t r1 = (r0 == 64u && r1x >= (uint32_t)MC_SEG_MIN) ? r1x : 0u;
+                    if (r0 + r1 > best) { best = r0 + r1; best_c = i; best_r0 = r0; best_r1 = r1; }
                 }
                 if (best == 0) {
                     if (u == 0 && lane == 0) { L.stuck[g] = 1; atomicAdd(&box->e_stuck, 1ull); }
-                } else if (u == best_u) {  // this wave's read got furthest: it extends the path and names the next candidates
-                    const uint32_t m = R.m;
-                    PathTail T = L.T[g];
-                    path_append(P, T, R.e_hi, R.e_lo, m, lane == 0);
-                    Kmer X;
-                    X.lo = readlane64(R.K.lo, m - 1);
-                    X.hi = readlane64(R.K.hi, m - 1);
-                    const uint32_t levels = L.levels[g] + m;
-                    if (lane / SCOUT_WORDS < my_nc) L.swn[g][lane / SCOUT_WORDS][lane % SCOUT_WORDS] = my_word;
-                    if (lane == 0) {
+                } else if (cd == best_c) {
+                    if (sg == 0) {  // the candidate's first wave extends the path, by its own stretch and then by the second wave's
+                        PathTail T = L.T[g];
+                        path_append(P, T, R.e_hi, R.e_lo, best_r0, lane == 0);
+                        if (best_r1) path_append(P, T, L.ext[wv + 1][0], L.ext[wv + 1][1], best_r1, lane == 0);
+                        if (lane == 0) { L.T[g] = T; L.levels[g] = L.levels[g] + best; }
+                    }
+                    if (sg == (best_r1 ? 1u : 0u)) {  // the wave whose stretch ends the hop: the new tip, the next hop's candidates and their words
+                        const uint32_t m = best_r1 ? best_r1 : best_r0;
+                        Kmer X;
+                        X.lo = readlane64(R.K.lo, m - 1);
+                        X.hi = readlane64(R.K.hi, m - 1);
+                        if (lane / SCOUT_WORDS < my_nc) L.swn[g][lane / SCOUT_WORDS][lane % SCOUT_WORDS] = my_word;
+                        if (lane == 0) {
 #pragma unroll
-                        for (int i = 0; i < MC_TEAM_MAX; i++) { L.cptr[g][i] = R.cptr[i]; L.cdelta[g][i] = R.cdelta[i]; }
-                        L.T[g] = T; L.X[g] = X; L.levels[g] = levels; L.nc[g] = my_nc; L.staged[g] = 1;
-                        if (my_nc == 0) { L.stuck[g] = 1; atomicAdd(&box->e_nc0, 1ull); }
+                            for (int i = 0; i < MC_CAND_MAX; i++) { L.cptr[g][i] = R.cptr[i]; L.cdelta[g][i] = R.cdelta[i]; }
+                            L.X[g] = X; L.nc[g] = my_nc; L.staged[g] = 1;
+                            if (my_nc == 0) { L.stuck[g] = 1; atomicAdd(&box->e_nc0, 1ull); }
+                        }
                     }
                 }
             }
@@ -1267,6 +1315,7 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
         int cov = -1;
         uint32_t naux = 0;
         uint64_t key = 0, s0 = 0;
+        SolidView h = t;  // the table the node's k-mer lives in (several GPUs: its owner's)
         uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
         bool root_bad = false;
         if (tid < H * FN) {
@@ -1313,10 +1362,10 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
                 nk = neighbour(v, k, dir, (int)c);
                 key = (uint64_t)key_of<MODE>(nk, k, &nflip);
             }
-            s0 = solid_slot_of(t, key);
-            const uint64_t s1 = (s0 & ~(uint64_t)t.rmask) | ((s0 + 1) & t.rmask);
-            a0 = *reinterpret_cast<const uint4 *>(t.slots + s0);
-            a1 = *reinterpret_cast<const uint4 *>(t.slots + s1);
+            s0 = solid_locate(t, key, h);
+            const uint64_t s1 = (s0 & ~(uint64_t)h.rmask) | ((s0 + 1) & h.rmask);
+            a0 = *reinterpret_cast<const uint4 *>(h.slots + s0);
+            a1 = *reinterpret_cast<const uint4 *>(h.slots + s1);
             lookups++;
             have = true;
         }
@@ -1325,7 +1374,7 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
         if (BFS_THREADS - 1 - tid < pend) vis_insert(S, L.pub_k[BFS_THREADS - 1 - tid], L.pub_idx[BFS_THREADS - 1 - tid]);
         MC_STAMP(1);
         if (have) {
-            cov = solid_get2(t, key, s0, a0, a1, &naux);
+            cov = solid_get2(h, key, s0, a0, a1, &naux);
             L.cov[tid] = (int16_t)cov;
             L.kmer[tid] = nk;
             L.naux[tid] = naux;

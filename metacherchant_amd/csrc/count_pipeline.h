@@ -237,10 +237,7 @@ __device__ __forceinline__ uint64_t bits128(uint64_t lo, uint64_t hi, uint32_t f
 // itmo!/dna/kmers/ShortKmer.java:68-71): one new base per step instead of a fresh extraction.
 // bucket of a key: mulhi32(its bin word, np1) (counting pipeline), or its owner rank (multi-GPU split;
 // low hash bits, disjoint from the bits that place it in the table)
-__device__ __forceinline__ uint32_t owner_of(uint64_t key, uint32_t n_owners)
-{
-    return (uint32_t)((fmix64(key) & 0xFFFFFFFFull) % n_owners);
-}
+// (owner_of: kmer_device.h)
 
 // OWNERS: the np1 buckets are owner ranks instead of ranges of the bin word, EMPTY_KEY is an
 // ordinary key, and the output is packed at `bases` (from a COUNT_ONLY run of the same kernel).

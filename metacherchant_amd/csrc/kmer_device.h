@@ -503,11 +503,21 @@ __device__ __forceinline__ uint32_t crosses(uint32_t before, uint32_t inc, uint3
 // <= 1/4 so that its (mostly negative) lookups end at the first probe.  Same 16-byte slots as the counting table
 // {key, count (already saturated), read pointer}, regions of SOLID_REGION slots, always indexed by the key's own
 // hash (a BFS lookup must not pay for a minimizer).  The view also carries the read store the pointers refer to.
+// One rank's counting table as the walk on another device sees it (several GPUs: the walk reads the owners' tables where
+// they are -- peer access inside one process, hipIpc between processes -- instead of a gathered copy: mcgpu.hip mc_group,
+// mc_shard_attach).  32 bytes; an array of them sits in the walker's device memory.
+struct ShardRef {
+    Slot *slots;
+    uint32_t shift, rmask, n_regions;
+    int mm_k;
+    unsigned long long empty;  // the shard's count of the key that equals EMPTY_KEY (hash modes), as it was when the shard was attached
+};
+
 struct SolidView {
     Slot *slots;
     uint32_t shift;  // 64 - log2(#slots)
     uint32_t rmask;  // region size - 1 (probing wraps inside a region, as in the counting table)
-    unsigned long long *empty_cnt;
+    const unsigned long long *empty_cnt;
     uint32_t *fatal;
     const uint64_t *reads;  // packed bases of the read store (nullptr: none), one readable pad word behind them
     uint64_t reads_bases;
@@ -515,13 +525,51 @@ struct SolidView {
     // are those of the TableView -- minimizer bins when mm_k != 0 -- and counts are clamped when read, as by table_get.
     int mm_k;
     uint32_t n_regions;
+    // n_shards > 1: the table is the union of n_shards ranks' tables; a key lives in its owner's -- the owner of its
+    // minimizer (owner_mm_k = k: the exchange dealt super-k-mer records, sk_owner) or of its own hash (0: owner_of) --
+    // and every lookup goes there (solid_locate); the fields above then describe the walker's own shard.
+    const ShardRef *shards;
+    uint32_t n_shards;
+    int owner_mm_k;
 };
+
+// owner rank of a key dealt by its own hash (the multi-GPU split of key streams: low hash bits, disjoint from the bits that
+// place the key in its owner's table); pure function, same on every rank -- mc_key_owner
+__host__ __device__ __forceinline__ uint32_t owner_of(uint64_t key, uint32_t n_owners)
+{
+    return (uint32_t)((fmix64(key) & 0xFFFFFFFFull) % n_owners);
+}
 
 __device__ __forceinline__ uint64_t solid_slot_of(const SolidView &t, uint64_t key)
 {
     if (t.mm_k == 0) return fmix64(key) >> t.shift;
     const uint64_t region = ((uint64_t)sk_bin(sk_hmin_of_kmer(key, t.mm_k)) * t.n_regions) >> 32;
     return (region << MC_REGION_LG) | sk_home(key);
+}
+
+// h = the view of shard o of t (the read store stays the walker's)
+__device__ __forceinline__ void shard_into(SolidView &h, const SolidView &t, uint32_t o)
+{
+    const ShardRef &r = t.shards[o];
+    h.slots = r.slots; h.shift = r.shift; h.rmask = r.rmask; h.n_regions = r.n_regions; h.mm_k = r.mm_k;
+    h.empty_cnt = &r.empty;
+}
+// Where `key` lives: h = the view of the table that holds it (t itself on one GPU), the result its home slot there.
+// hmin (may be null): the key's minimizer hash when the caller has it already (sk_hmin_of_kmer is 17 hashes at k = 31).
+__device__ __forceinline__ uint64_t solid_locate(const SolidView &t, uint64_t key, SolidView &h, const uint32_t *hmin = nullptr)
+{
+    h = t;
+    if (t.n_shards <= 1) {
+        if (t.mm_k == 0) return fmix64(key) >> t.shift;
+        const uint32_t hm = hmin ? *hmin : sk_hmin_of_kmer(key, t.mm_k);
+        return ((((uint64_t)sk_bin(hm) * t.n_regions) >> 32) << MC_REGION_LG) | sk_home(key);
+    }
+    uint32_t hm = 0;
+    if (t.owner_mm_k) hm = hmin ? *hmin : sk_hmin_of_kmer(key, t.owner_mm_k);
+    shard_into(h, t, t.owner_mm_k ? sk_owner(hm, t.n_shards) : owner_of(key, t.n_shards));
+    if (h.mm_k == 0) return fmix64(key) >> h.shift;
+    if (!t.owner_mm_k) hm = sk_hmin_of_kmer(key, h.mm_k);
+    return ((((uint64_t)sk_bin(hm) * h.n_regions) >> 32) << MC_REGION_LG) | sk_home(key);
 }
 
 // The probe sequence of `key` from slot s on, four slots to a memory round trip: a lookup in the walk is one link of a
@@ -563,8 +611,13 @@ __device__ __forceinline__ int solid_get(const SolidView &t, uint64_t key, uint3
 {
     if (aux) *aux = 0;
     if (key == EMPTY_KEY) {
-        const unsigned long long c = *t.empty_cnt;
+        const unsigned long long c = t.n_shards > 1 ? t.shards[owner_of(key, t.n_shards)].empty : *t.empty_cnt;  // (hash modes only: dealt by the key's hash)
         return c == 0 ? -1 : (c > 32767ull ? 32767 : (int)c);
+    }
+    if (t.n_shards > 1) {  // (the owner's table)
+        SolidView h;
+        const uint64_t s0 = solid_locate(t, key, h);
+        return solid_probe_from(h, key, s0, 0, aux);
     }
     return solid_probe_from(t, key, solid_slot_of(t, key), 0, aux);
 }

@@ -273,6 +273,13 @@ struct mc_ctx {
     char *pin[16] = {};                // pinned staging buffers of h2d_fast, made on first use
     DevPool tok_pool;                  // scratch of the device tokeniser
     int64_t extract_in_store = -1;     // mc_group: the reads the next mc_extract_*_dev call is given sit in the read store already, from this word on (consumed by that call)
+    // Several GPUs: the walk of this context reads the counting tables of all ranks where they are (mc_shard_attach; mc_group
+    // with peer access).  h_shards[i] describes rank i's table (this context's own among them), d_shards is the same array in
+    // device memory, ipc_opened the mappings of other processes' tables this context holds.
+    std::vector<ShardRef> h_shards;
+    ShardRef *d_shards = nullptr;
+    int shard_owner_mm_k = 0;
+    std::vector<void *> ipc_opened;
     bool extract_by_minimizer = false; // mc_group: the next mc_extract_keys_dev call deals the keys to the owners of their minimizers (sk_owner), as the group's records are dealt (consumed by that call)
     uint4 *d_ovf_tmp = nullptr;        // pipe_drain_handed_on: the list moved aside while it is drained
     uint32_t *d_ovf_leaf_tmp = nullptr;
@@ -333,6 +340,9 @@ struct mc_ctx {
         const mc_ctx *rs = rs_from ? rs_from : this;
         t.reads = rs->rs_bases ? rs->rs_words : nullptr;
         t.reads_bases = rs->rs_bases;
+        t.shards = d_shards;
+        t.n_shards = d_shards ? (uint32_t)h_shards.size() : 0u;
+        t.owner_mm_k = shard_owner_mm_k;
         return t;
     }
     TableView view() const
@@ -501,12 +511,19 @@ __global__ void __launch_bounds__(PT_THREADS) k_solid_emit(const Slot *__restric
     const uint32_t tid = threadIdx.x, n_buckets = np1;
     if (tid < PT_MAX_LEAVES2) { C.wcur[tid] = 0; C.cnt[tid] = 0; }
     __syncthreads();
-    const uint64_t n_tiles = (n_slots + PT_TILE - 1) / PT_TILE;
-    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // Rows of 4 slots (64 bytes: one memory sector) are dealt to the workgroups (= segments) round-robin, as k_solid_emit_pairs
+    // deals its rows: a table whose regions are hash prefixes is in the order of the very hash that picks the bucket here, and
+    // whole tiles of it would put a bucket's entries into a few segments only (the segment capacities count on every segment
+    // getting its share of every bucket).
+    constexpr uint32_t WAVES = PT_THREADS / 64, ROW = 4, ROWS_PER_WAVE = 64 / ROW;
+    const uint64_t n_rows = (n_slots + ROW - 1) / ROW;
+    const uint32_t wave = tid >> 6, lane = tid & 63;
+    for (uint64_t t0 = 0; t0 * WAVES * ROWS_PER_WAVE * gridDim.x < n_rows; t0 += PT_ITEMS) {
         uint4 raws[PT_ITEMS];
 #pragma unroll
         for (int j = 0; j < PT_ITEMS; j++) {
-            const uint64_t i = tile * PT_TILE + tid + (uint64_t)j * PT_THREADS;
+            const uint64_t local = ((t0 + (uint64_t)j) * WAVES + wave) * ROWS_PER_WAVE + lane / ROW;  // this workgroup's row number
+            const uint64_t i = (local * gridDim.x + blockIdx.x) * ROW + lane % ROW;
             raws[j] = i < n_slots ? *reinterpret_cast<const uint4 *>(slots + i) : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0);
         }
 #pragma unroll
@@ -2145,6 +2162,8 @@ void mc_destroy(mc_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->own_stream && c->own_stream != c->stream) (void)hipStreamSynchronize(c->own_stream);
     if (c->pipe_stream) (void)hipStreamSynchronize(c->pipe_stream);
+    for (void *p : c->ipc_opened) (void)hipIpcCloseMemHandle(p);
+    if (c->d_shards) (void)hipFree(c->d_shards);
     if (c->slots) table_release(c, c->slots, c->slots_bytes);
     if (c->solid) (void)hipFree(c->solid);
     c->pipe.release(c->cfg.device);
@@ -2179,6 +2198,12 @@ int mc_clear(mc_ctx *c)
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->cfg.device));
     c->virgin = true;
+    if (c->d_shards) {  // (the tables an attachment describes are about to change)
+        for (void *p : c->ipc_opened) (void)hipIpcCloseMemHandle(p);
+        c->ipc_opened.clear();
+        (void)hipFree(c->d_shards);
+        c->d_shards = nullptr; c->h_shards.clear(); c->shard_owner_mm_k = 0;
+    }
     c->rs_bases = 0;  // (slots that pointed into the read store go with the table)
     HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, 9 * sizeof(unsigned long long), c->stream));  // (counters and the fatal flag: one fill)
     c->n_used_host = 0;
@@ -3523,7 +3548,7 @@ int solid_build(mc_ctx *c, uint64_t n, int min_cov, double *ms, const PairSource
         const double m1 = (double)n / (double)(1ull << sb1) / (double)PT_SEGMENTS;
         const double m2 = (double)n / (double)(1ull << q);
         scap1 = (uint64_t)(m1 * 1.25 + 10.0 * std::sqrt(m1) + 64.0);
-        if (pairs) scap1 += 64;  // rows of 64 entries are dealt to the segments: one of them may bring a whole row more
+        scap1 += 64;  // rows of entries are dealt to the segments: one of them may bring a whole row more
         scap2 = (uint64_t)(m2 * 1.15 + 10.0 * std::sqrt(m2) + 64.0);
         const uint64_t need1 = (uint64_t)(1ull << sb1) * PT_SEGMENTS * scap1, need2 = sb2 ? (uint64_t)(1ull << q) * scap2 : 0;
         // The solid list sits in a_recs: the level-1 buckets then go to b_recs and the leaves, once the list has been
@@ -3589,7 +3614,7 @@ int solid_build(mc_ctx *c, uint64_t n, int min_cov, double *ms, const PairSource
 // Builds (or reuses) the solid table for this threshold.
 int ensure_solid(mc_ctx *c, int min_cov, double *ms)
 {
-    if (c->bfs_direct && !c->solid_external) {  // the walk looks its k-mers up in the counting table: nothing to build
+    if (c->d_shards || (c->bfs_direct && !c->solid_external)) {  // the walk looks its k-mers up in the counting table(s): nothing to build
         c->solid_is_table = true;
         c->solid_cov = min_cov;
         return MC_OK;
@@ -4061,6 +4086,141 @@ int mc_bfs(mc_ctx *c, const uint64_t *seed_hi, const uint64_t *seed_lo, uint64_t
     int rc = mc_bfs_batch(c, &job, 1, min_cov, max_kmers, max_radius, out);
     if (rc) return rc;
     if (out->n == 0) return fail(c, MC_ENOSEED, "Could not find any k-mers of the target gene in the input");
+    return MC_OK;
+}
+
+}  // extern "C"
+
+
+// ---- the walk over several ranks' tables where they are (include/mcgpu.h mc_shard_*) -------------------------------------
+namespace {
+struct ShardWire {  // what a mc_shard_handle holds
+    hipIpcMemHandle_t ipc;  // of the table's block (all zero: none could be made; the handle then only serves its own process)
+    uint64_t addr, bytes;   // the table in the exporting process
+    uint32_t shift, rmask, n_regions;
+    int32_t mm_k;
+    uint64_t empty;         // count of the key that equals EMPTY_KEY (hash modes)
+    int32_t pid, device, k, key_mode;
+    uint32_t magic, has_ipc;
+};
+static_assert(sizeof(ShardWire) <= sizeof(mc_shard_handle), "mc_shard_handle is too small");
+constexpr uint32_t SHARD_MAGIC = 0x4D435348u;  // "MCSH"
+
+// this context's counting table, ready to be read by another walker: initialised, nothing parked, counters read
+int shard_describe(mc_ctx *c, ShardWire *w, bool want_ipc)
+{
+    memset(w, 0, sizeof *w);
+    if (!c->finalized) return fail(c, MC_ESTATE, "mc_shard_export: call mc_finalize_counts first");
+    if (c->solid_external) return fail(c, MC_ESTATE, "mc_shard_export: a BFS-only context has no counting table to share");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    int rc = materialize(c);  // (a rank that owns nothing of the batch still offers a valid, empty table)
+    if (rc) return rc;
+    unsigned long long *h = c->h_scratch;
+    HIPCHK(c, hipMemcpyAsync(h, c->d_ctr, 9 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const TableView t = c->view();
+    w->addr = (uint64_t)(uintptr_t)c->slots;
+    w->bytes = c->n_slots() * sizeof(Slot);
+    w->shift = t.shift; w->rmask = t.rmask; w->n_regions = t.n_regions; w->mm_k = t.mm_k;
+    w->empty = h[1];
+    w->pid = (int32_t)getpid(); w->device = c->cfg.device; w->k = c->cfg.k; w->key_mode = c->cfg.key_mode;
+    w->magic = SHARD_MAGIC;
+    if (want_ipc) {
+        const hipError_t e = hipIpcGetMemHandle(&w->ipc, c->slots);
+        w->has_ipc = e == hipSuccess;
+        if (e != hipSuccess) (void)hipGetLastError();  // (the handle still serves this process)
+    }
+    return MC_OK;
+}
+
+void shard_detach_locked(mc_ctx *c)
+{
+    (void)hipSetDevice(c->cfg.device);
+    for (void *p : c->ipc_opened) (void)hipIpcCloseMemHandle(p);
+    c->ipc_opened.clear();
+    if (c->d_shards) (void)hipFree(c->d_shards);
+    c->d_shards = nullptr;
+    c->h_shards.clear();
+    c->shard_owner_mm_k = 0;
+}
+
+int shard_attach_locked(mc_ctx *c, const ShardWire *w, uint32_t n, uint32_t self, int by_minimizer)
+{
+    shard_detach_locked(c);
+    if (!c->finalized) return fail(c, MC_ESTATE, "mc_shard_attach: call mc_finalize_counts first");
+    if (n == 0 || n > 512 || self >= n) return fail(c, MC_EINVAL, "mc_shard_attach: bad number of shards / own index");
+    if (by_minimizer && !(c->cfg.key_mode == MC_KEY_PACKED && c->cfg.k >= SK_MIN_K))
+        return fail(c, MC_EINVAL, "mc_shard_attach: keys are dealt by minimizer only where reads travel as super-k-mer records (packed keys, k >= %d)", SK_MIN_K);
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    std::vector<ShardRef> refs(n);
+    for (uint32_t i = 0; i < n; i++) {
+        const ShardWire &x = w[i];
+        if (x.magic != SHARD_MAGIC) return fail(c, MC_EINVAL, "mc_shard_attach: shard %u is not a handle of mc_shard_export", i);
+        if (x.k != c->cfg.k || x.key_mode != c->cfg.key_mode) return fail(c, MC_EINVAL, "mc_shard_attach: shard %u was counted with k = %d, key mode %d", i, x.k, x.key_mode);
+        Slot *slots = nullptr;
+        if (i == self) {
+            if (x.addr != (uint64_t)(uintptr_t)c->slots || x.pid != (int32_t)getpid())
+                return fail(c, MC_EINVAL, "mc_shard_attach: shard %u is not this context's table as it is now (export again after counting)", i);
+            slots = c->slots;
+        } else if (x.pid == (int32_t)getpid()) {  // another context of this process: its pointer, through peer access when it is another device's
+            slots = reinterpret_cast<Slot *>((uintptr_t)x.addr);
+            if (x.device != c->cfg.device) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, c->cfg.device, x.device) != hipSuccess || !can)
+                    return fail(c, MC_EHIP, "mc_shard_attach: GPU %d cannot read GPU %d's memory (no peer access)", c->cfg.device, x.device);
+                const hipError_t e = hipDeviceEnablePeerAccess(x.device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(c, MC_EHIP, "mc_shard_attach: hipDeviceEnablePeerAccess: %s", hipGetErrorString(e));
+                (void)hipGetLastError();
+            }
+        } else {
+            if (!x.has_ipc) { shard_detach_locked(c); return fail(c, MC_EHIP, "mc_shard_attach: shard %u comes from another process without an IPC handle", i); }
+            void *p = nullptr;
+            const hipError_t e = hipIpcOpenMemHandle(&p, x.ipc, hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) { shard_detach_locked(c); return fail(c, MC_EHIP, "mc_shard_attach: hipIpcOpenMemHandle (shard %u): %s", i, hipGetErrorString(e)); }
+            c->ipc_opened.push_back(p);
+            slots = static_cast<Slot *>(p);
+        }
+        refs[i].slots = slots; refs[i].shift = x.shift; refs[i].rmask = x.rmask; refs[i].n_regions = x.n_regions; refs[i].mm_k = x.mm_k;
+        refs[i].empty = x.empty;
+    }
+    if (hipMalloc(reinterpret_cast<void **>(&c->d_shards), n * sizeof(ShardRef)) != hipSuccess) { shard_detach_locked(c); return fail(c, MC_ENOMEM, "mc_shard_attach: out of device memory"); }
+    if (hipMemcpy(c->d_shards, refs.data(), n * sizeof(ShardRef), hipMemcpyHostToDevice) != hipSuccess) { shard_detach_locked(c); return fail(c, MC_EHIP, "mc_shard_attach: upload failed"); }
+    c->h_shards = refs;
+    c->shard_owner_mm_k = by_minimizer ? c->cfg.k : 0;
+    return MC_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int mc_shard_export(mc_ctx *c, mc_shard_handle *out)
+{
+    if (!c) return MC_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!out) return fail(c, MC_EINVAL, "mc_shard_export: out is null");
+    ShardWire w;
+    const int rc = shard_describe(c, &w, true);
+    if (rc) return rc;
+    memset(out, 0, sizeof *out);
+    memcpy(out, &w, sizeof w);
+    return MC_OK;
+}
+
+int mc_shard_attach(mc_ctx *c, const mc_shard_handle *shards, uint32_t n_shards, uint32_t self, int by_minimizer)
+{
+    if (!c) return MC_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!shards) return fail(c, MC_EINVAL, "mc_shard_attach: shards is null");
+    std::vector<ShardWire> w(n_shards);
+    for (uint32_t i = 0; i < n_shards; i++) memcpy(&w[i], &shards[i], sizeof(ShardWire));
+    return shard_attach_locked(c, w.data(), n_shards, self, by_minimizer);
+}
+
+int mc_shard_detach(mc_ctx *c)
+{
+    if (!c) return MC_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    shard_detach_locked(c);
     return MC_OK;
 }
 
@@ -4643,6 +4803,33 @@ int mc_group_bfs_batch(mc_group *g, const mc_bfs_job *jobs, uint32_t n_jobs, int
     if (W == 1) {
         const int rc = mc_bfs_batch(g->ctx[0], jobs, n_jobs, min_cov, max_kmers, max_radius, out);
         return rc ? gfail(g, rc, mc_last_error(g->ctx[0])) : MC_OK;
+    }
+    // ---- the walk reads every device's counting table where it is (round 4): the first context gets the other tables' addresses
+    // (peer access; the same device for shares of one GPU) and looks a k-mer up in its owner's table.  No export, no copy of
+    // the solid k-mers, no second table -- and what made configs[3] impossible: 5 G gathered solid k-mers do not fit beside
+    // rank 0's counting table.  MC_GROUP_WALK=gather keeps round 3's way (and a group without peer
+    // access between all its devices has no other).
+    static const bool want_gather = getenv("MC_GROUP_WALK") && !strcmp(getenv("MC_GROUP_WALK"), "gather");
+    if (!want_gather && g->peer_all) {
+        mc_ctx *c0 = g->ctx[0];
+        if (g->dirty || !c0->d_shards) {
+            std::vector<ShardWire> w(W);
+            int grc = per_rank(W, [&](size_t r) -> int {
+                std::lock_guard<std::mutex> cl(g->ctx[r]->mu);
+                return shard_describe(g->ctx[r], &w[r], false);
+            });
+            if (grc) {
+                for (mc_ctx *c : g->ctx) if (!c->err.empty()) return gfail(g, grc, c->err);
+                return gfail(g, grc, "mc_group_bfs_batch: a device's table could not be shared");
+            }
+            std::lock_guard<std::mutex> cl(c0->mu);
+            grc = shard_attach_locked(c0, w.data(), (uint32_t)W, 0, c0->sk_form ? 1 : 0);
+            if (grc) return gfail(g, grc, c0->err);
+            g->dirty = false;
+            g->solid_cov = -1;
+        }
+        const int rc = mc_bfs_batch(c0, jobs, n_jobs, min_cov, max_kmers, max_radius, out);
+        return rc ? gfail(g, rc, mc_last_error(c0)) : MC_OK;
     }
     if (g->dirty || g->solid_cov != min_cov) {
         // ---- gather: every shard's (key, count, pointer) with count >= min_cov, side by side on the first device.  The

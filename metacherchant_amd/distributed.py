@@ -31,6 +31,7 @@ class ShardedCounter:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.bytes_sent = 0
         self.n_chunks = 0
+        self.by_minimizer = False
         # Read pointers (include/mcgpu.h mc_set_read_pointers): the BFS rank walks with look-ahead read from ITS OWN
         # reads, so only its records carry pointers; the other ranks keep no read store and send zeros.
         self.bfs_rank = bfs_rank
@@ -63,6 +64,7 @@ class ShardedCounter:
         else:
             base_at = [0, int(n_bases)]
         sk = hasattr(ctx, "superkmer_capacity") and ctx.superkmer_capacity(max(int(max_windows), 1), max(int(n_reads), 1)) != 0
+        self.by_minimizer = sk  # (records are dealt to the owners of their minimizers, keys to the owners of their own hashes)
         for c in range(n_chunks):
             a, b = bounds[c], bounds[c + 1]
             nb = base_at[c + 1] - base_at[c]
@@ -141,6 +143,31 @@ class ShardedCounter:
         t = torch.tensor([n], dtype=torch.int64, device=self.device)
         dist.all_reduce(t, group=self.group)
         return int(t.item())
+
+    def attach_shards(self, dst=0):
+        """The walk in place (include/mcgpu.h mc_shard_*): every rank describes its counting table in 128 bytes (geometry + an
+        IPC handle of its memory), one all-gather brings the descriptions to everybody, and rank `dst` maps the other ranks'
+        tables: its bfs / bfs_batch then look every k-mer up in its owner's table over xGMI.  Nothing is exported, copied or
+        rebuilt (gather_solid: 0.4 + ~14 + 3.2 ms at 8 x configs[1], and a copy that does not fit at configs[3]'s size).  The
+        other ranks must leave their tables alone until walk_done()."""
+        ctx, W = self.ctx, self.world
+        if W == 1:
+            return
+        mine = torch.frombuffer(bytearray(ctx.shard_export()), dtype=torch.uint8).to(self.device)
+        allh = torch.empty(W * mine.numel(), dtype=torch.uint8, device=self.device)
+        dist.all_gather_into_tensor(allh, mine, group=self.group)
+        if self.rank == dst:
+            raw = allh.cpu().numpy().tobytes()
+            n = mine.numel()
+            ctx.shard_attach([raw[i * n:(i + 1) * n] for i in range(W)], self.rank, self.by_minimizer)
+
+    def walk_done(self, dst=0):
+        """behind the walk: rank `dst` gives the mappings up, and nobody touches its table before that"""
+        if self.world == 1:
+            return
+        if self.rank == dst:
+            self.ctx.shard_detach()
+        dist.barrier(group=self.group)
 
     def gather_solid(self, solid_ctx, min_cov, dst=0):
         """Brings the (key, count >= min_cov, hint) entries of every shard to rank `dst` (direct sends) and builds solid_ctx's

@@ -65,6 +65,7 @@ EXPORTS = [
     "mc_bfs_result_free", "mc_export", "mc_export_dev", "mc_add_pairs_dev", "mc_solid_from_pairs_dev", "mc_save_kmers", "mc_load_kmers", "mc_key_owner", "mc_extract_keys_dev",
     "mc_group_create", "mc_group_destroy", "mc_group_last_error", "mc_group_set_coverage_hint", "mc_group_add_reads_packed", "mc_group_add_reads_file",
     "mc_group_finalize_counts", "mc_group_bfs_batch", "mc_group_get_stats", "mc_add_keys_dev", "mc_superkmer_capacity", "mc_extract_superkmers_dev", "mc_add_superkmers_dev", "mc_get_stats", "mc_reset_stats", "mc_trim", "mc_synth_reads_dev", "mc_synth_genome",
+    "mc_shard_export", "mc_shard_attach", "mc_shard_detach",
 ]
 
 _LIB = None
@@ -134,6 +135,9 @@ def load():
     L.mc_trim.argtypes = [vp]
     L.mc_synth_reads_dev.argtypes = [vp, u64, u64, u64, u64, u64, u64, C.c_uint32, C.c_uint32, vp, vp]
     L.mc_synth_genome.argtypes = [u64, u64, u64, C.POINTER(C.c_uint8)]
+    L.mc_shard_export.argtypes = [vp, C.c_char_p]
+    L.mc_shard_attach.argtypes = [vp, C.c_char_p, C.c_uint32, C.c_uint32, i32]
+    L.mc_shard_detach.argtypes = [vp]
     _LIB = L
     return L
 
@@ -355,6 +359,24 @@ class Context:
 
     def add_superkmers_dev(self, d_recs, d_bins, n):
         self._chk(self._L.mc_add_superkmers_dev(self._h, _dptr(d_recs), _dptr(d_bins), n))
+
+    # ---- the walk over several ranks' tables in place (include/mcgpu.h mc_shard_*)
+    SHARD_HANDLE_BYTES = 128
+
+    def shard_export(self):
+        """this context's table as 128 opaque bytes for the walking rank (after finalize; keep the table as it is meanwhile)"""
+        buf = C.create_string_buffer(self.SHARD_HANDLE_BYTES)
+        self._chk(self._L.mc_shard_export(self._h, buf))
+        return buf.raw
+
+    def shard_attach(self, handles, self_index, by_minimizer):
+        """handles[i] = rank i's shard_export() (this context's own at self_index): bfs / bfs_batch then walk all the tables"""
+        blob = b"".join(handles)
+        assert len(blob) == self.SHARD_HANDLE_BYTES * len(handles)
+        self._chk(self._L.mc_shard_attach(self._h, blob, len(handles), self_index, 1 if by_minimizer else 0))
+
+    def shard_detach(self):
+        self._chk(self._L.mc_shard_detach(self._h))
 
     # ---- measurement / synthetic data
     def stats(self):

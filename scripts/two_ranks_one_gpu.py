@@ -59,8 +59,16 @@ def _worker(rank, world, port, k, q):
     if not VARIANT or VARIANT % 2:
         assert sc.n_chunks == 5, sc.n_chunks
     total = sc.finalize()
-    solid = m.Context(k, mode, 0, 0) if rank == 0 else None
-    n_solid = sc.gather_solid(solid, cov, dst=0)
+    in_place = os.environ.get("TWO_RANKS_WALK", "shards") != "gather"
+    if in_place:  # rank 0 maps rank 1's table (an IPC handle through the all-gather) and walks over both
+        sc.attach_shards(dst=0)
+        solid, n_solid = ctx, ctx.export_count(cov)
+        nt = torch.tensor([n_solid], dtype=torch.int64, device=dev)
+        dist.all_reduce(nt)
+        n_solid = int(nt.item())
+    else:
+        solid = m.Context(k, mode, 0, 0) if rank == 0 else None
+        n_solid = sc.gather_solid(solid, cov, dst=0)
     if rank == 0:
         t = po.Table()
         t.count_reads(reads, off, k, mode)
@@ -79,6 +87,8 @@ def _worker(rank, world, port, k, q):
             assert np.array_equal(got["lo"], want["lo"]) and np.array_equal(got["dist"], want["dist"])
             assert np.array_equal(got["cov"], want["cov"]) and np.array_equal(got["hi"], want["hi"])
         q.put(("ok", total, n_solid, sc.bytes_sent, sc.n_chunks, ctx.superkmer_capacity(1000, 10) > 0))
+    if in_place:
+        sc.walk_done(dst=0)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -352,6 +352,10 @@ def test_cli_config5_four_environments_then_multi_join(cli, tmp_path):
 @pytest.mark.parametrize("devices,k,extra,env", [("0,0", 31, ["--maxkmers", "4000", "--coverage", "3"], {}),
                                                 ("0,0,0", 25, ["--maxradius", "200", "--coverage", "2", "--bothdirs", "true"], {}),
                                                 ("0,0", 41, ["--maxkmers", "2500", "--coverage", "3", "--bothdirs", "true"], {}),
+                                                # round 3's way of walking (the solid k-mers gathered into a second table on the first device);
+                                                # by default the first device reads the others' tables in place
+                                                ("0,0,0", 31, ["--maxkmers", "4000", "--coverage", "3"], {"MC_GROUP_WALK": "gather"}),
+                                                ("0,0", 41, ["--maxkmers", "2500", "--coverage", "3"], {"MC_GROUP_WALK": "gather"}),
                                                 # exchanges of 3 x 833 reads: the FASTQ's last one holds TWO reads, so a share extracts
                                                 # (into the buffer its list of solid k-mers sat in) and then owns nothing of the batch:
                                                 # the list must not be taken for valid

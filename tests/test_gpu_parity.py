@@ -723,3 +723,59 @@ def test_hints_survive_exchange_and_speed_up_the_walk(mc):
     assert_bfs_equal(res["with"], res["without"])
     assert rounds["with"] * 4 < rounds["without"]
     ex.close()
+
+
+@pytest.mark.parametrize("k,mode,n_owners", [(31, "packed", 3), (27, "packed", 2), (41, "poly", 3), (21, "packed", 2)])
+def test_walk_over_the_owners_tables_in_place(mc, k, mode, n_owners):
+    """Several GPUs, the walk without a gather (include/mcgpu.h mc_shard_export / mc_shard_attach): the reads' super-k-mer
+    records (keys for hash keys and k < 23) are dealt to `n_owners` contexts -- shares of the one GPU here --, every owner
+    counts its own, and the first one, handed the others' tables, walks over all of them: each lookup goes to the table of
+    the k-mer's owner (the owner of its minimizer for records, of its own hash for keys).  Walks in all directions equal the
+    oracle's over ONE table; detached, the first context sees its own shard only."""
+    import torch
+    dev = torch.device("cuda:0")
+    omode, gmode = (po.KEY_PACKED, mc.KEY_PACKED) if mode == "packed" else (po.KEY_POLY, mc.KEY_POLY)
+    genome, reads, off = synth_case(2, 60000, 30000, 150, 60)
+    t, n = oracle_table(reads, off, k, omode)
+    d_words = torch.from_numpy(po.pack(reads).view(np.int64)).to(dev)
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    own = [mc.Context(k, gmode, 0, 0) for _ in range(n_owners)]
+    n_reads, n_bases = len(off) - 1, int(off[-1])
+    cap = own[0].superkmer_capacity(n, n_reads)
+    records = cap != 0
+    assert records == (mode == "packed" and k >= 23)
+    if records:  # own[0] is the rank whose reads these are: it extracts (its read store is the one the pointers lead into) and counts its share
+        d_recs = torch.zeros((cap, 2), dtype=torch.int64, device=dev)
+        d_ptrs = torch.zeros(cap, dtype=torch.int32, device=dev)
+        ooff = own[0].extract_superkmers_dev(d_words, d_off, n_reads, n_bases, n_owners, d_recs, d_ptrs, cap)
+        for o in range(n_owners):
+            a, b = int(ooff[o]), int(ooff[o + 1])
+            assert b > a
+            own[o].add_superkmers_dev(d_recs[a:b].contiguous(), d_ptrs[a:b].contiguous(), b - a)
+    else:
+        d_keys = torch.zeros(n, dtype=torch.int64, device=dev)
+        d_hints = torch.zeros(n, dtype=torch.int32, device=dev)
+        ooff = own[0].extract_keys_dev(d_words, d_off, n_reads, n_bases, n_owners, d_keys, n, d_hints)
+        for o in range(n_owners):
+            a, b = int(ooff[o]), int(ooff[o + 1])
+            own[o].add_keys_dev(d_keys[a:b].contiguous(), b - a, d_hints[a:b].contiguous())
+    assert sum(c.finalize() for c in own) == t.size()  # owners are disjoint
+    handles = [c.shard_export() for c in own]
+    own[0].shard_attach(handles, 0, records)
+    seeds = [genome[5000:5400], genome[61000:61300]]
+    for seed in seeds:
+        hi, lo = seed_windows(seed, k)
+        for d in (1, -1, 0):
+            assert_bfs_equal(own[0].bfs(hi, lo, d, 3, 6000, -1), po.bfs(t, k, omode, [seed], d, 3, 6000, -1))
+    # a second threshold on the same attachment (nothing is rebuilt: the walk reads the counts themselves)
+    hi, lo = seed_windows(seeds[0], k)
+    assert_bfs_equal(own[0].bfs(hi, lo, 0, 6, 3000, 200), po.bfs(t, k, omode, [seeds[0]], 0, 6, 3000, 200))
+    own[0].shard_detach()
+    alone = own[0].bfs(hi, lo, 0, 3, 6000, -1)
+    want = po.bfs(t, k, omode, [seeds[0]], 0, 3, 6000, -1)
+    assert alone is None or len(alone["lo"]) < len(want["lo"])  # (a third or half of the k-mers: the walk falls apart)
+    with pytest.raises(mc.McError):
+        own[1].shard_attach(handles, 0, records)  # handle 0 is not context 1's own table
+    for c in own:
+        c.close()
+

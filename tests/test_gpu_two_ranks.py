@@ -12,10 +12,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("k,records", [(31, True), (25, True), (41, False), (21, False)])
-def test_two_ranks_on_one_gpu(k, records):
+# walk: "shards" -- rank 0 maps rank 1's counting table (hipIpc handle, mc_shard_attach) and walks over both in place;
+# "gather" -- round 3's way: the k-mers at or above --coverage gathered into a BFS-only context on rank 0
+@pytest.mark.parametrize("k,records,walk", [(31, True, "shards"), (25, True, "shards"), (41, False, "shards"), (21, False, "shards"),
+                                           (31, True, "gather"), (41, False, "gather")])
+def test_two_ranks_on_one_gpu(k, records, walk):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "two_ranks_one_gpu.py"), str(k)], capture_output=True,
-                       text=True, timeout=900, cwd=ROOT)
+                       text=True, timeout=900, cwd=ROOT, env=dict(os.environ, TWO_RANKS_WALK=walk, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("two ranks on one GPU")][-1]
     assert "'ok'" in line
