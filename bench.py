@@ -138,6 +138,10 @@ def main():
         bctx = ctx
         if world > 1 and walk_in_place:
             sc.attach_shards(dst=0)
+            if "solid" not in info:  # (reported once: every shard's number of k-mers at or above --coverage, from the counter the merge kernel keeps)
+                nt = torch.tensor([ctx.export_count(args.coverage)], dtype=torch.int64, device=dev)
+                dist.all_reduce(nt)
+                info["solid"] = int(nt.item())
         elif world > 1:
             if solid is not None:
                 solid.clear()

@@ -4472,6 +4472,8 @@ int group_exchange_count(mc_group *g, std::vector<GroupRank> &R)
             return R[d].recv.alloc(total * (sk_batch ? 2 : 1)) == hipSuccess && R[d].recv_p.alloc(total) == hipSuccess ? MC_OK : MC_ENOMEM;
         });
         if (rc) return gfail(g, rc, "mc_group_add_reads_packed: no room for the received buckets");
+        struct Zero { size_t d; uint64_t at, m; };
+        std::vector<Zero> ptr_zero;
         ncclResult_t nr = g_rccl.GroupStart();
         std::vector<uint64_t> at(W, 0);
         for (size_t r = 0; r < W && nr == ncclSuccess; r++)       // source
@@ -4480,12 +4482,22 @@ int group_exchange_count(mc_group *g, std::vector<GroupRank> &R)
                 if (m == 0) continue;
                 nr = g_rccl.Send(reinterpret_cast<const char *>(R[r].send.p) + o0 * unit, m * unit, ncclUint8, (int)d, g->comm[r], g->ctx[r]->stream);
                 if (nr == ncclSuccess) nr = g_rccl.Recv(reinterpret_cast<char *>(R[d].recv.p) + at[d] * unit, m * unit, ncclUint8, (int)r, g->comm[d], g->ctx[d]->stream);
-                if (nr == ncclSuccess) nr = g_rccl.Send(R[r].send_p.p + o0, m * 4, ncclUint8, (int)d, g->comm[r], g->ctx[r]->stream);
-                if (nr == ncclSuccess) nr = g_rccl.Recv(R[d].recv_p.p + at[d], m * 4, ncclUint8, (int)r, g->comm[d], g->ctx[d]->stream);
+                // (read pointers lead into the FIRST device's read store, the one the walk reads: the other devices keep none, and the
+                // zeros they used to send -- a fifth of their bytes -- are filled in where they arrive)
+                if (r == 0) {
+                    if (nr == ncclSuccess) nr = g_rccl.Send(R[r].send_p.p + o0, m * 4, ncclUint8, (int)d, g->comm[r], g->ctx[r]->stream);
+                    if (nr == ncclSuccess) nr = g_rccl.Recv(R[d].recv_p.p + at[d], m * 4, ncclUint8, (int)r, g->comm[d], g->ctx[d]->stream);
+                } else {
+                    ptr_zero.push_back({d, at[d], m});
+                }
                 at[d] += m;
             }
         const ncclResult_t ne = g_rccl.GroupEnd();
         if (nr == ncclSuccess) nr = ne;
+        for (const Zero &z : ptr_zero) {
+            if (hipSetDevice(g->ctx[z.d]->cfg.device) != hipSuccess || hipMemsetAsync(R[z.d].recv_p.p + z.at, 0, z.m * 4, g->ctx[z.d]->stream) != hipSuccess)
+                return gfail(g, MC_EHIP, "mc_group_add_reads_packed: clearing the pointers of pointer-less records failed");
+        }
         if (nr != ncclSuccess) return gfail(g, MC_EHIP, std::string("mc_group_add_reads_packed: RCCL exchange: ") + g_rccl.GetErrorString(nr));
         rc = per_rank(W, [&](size_t d) -> int {
             mc_ctx *c = g->ctx[d];
@@ -4505,8 +4517,10 @@ int group_exchange_count(mc_group *g, std::vector<GroupRank> &R)
         uint64_t at = 0;
         for (size_t r = 0; r < W; r++) {
             const uint64_t o0 = R[r].owner_off[d], m = R[r].owner_off[d + 1] - o0;
+            // (pointers: from the first device only -- they lead into its read store; the others' would be zeros)
             if (peer_copy(reinterpret_cast<char *>(R[d].recv.p) + at * unit, c, reinterpret_cast<const char *>(R[r].send.p) + o0 * unit, g->ctx[r], m * unit, c->stream) != hipSuccess ||
-                peer_copy(R[d].recv_p.p + at, c, R[r].send_p.p + o0, g->ctx[r], m * 4, c->stream) != hipSuccess)
+                (r == 0 ? peer_copy(R[d].recv_p.p + at, c, R[r].send_p.p + o0, g->ctx[r], m * 4, c->stream)
+                        : (m ? hipMemsetAsync(R[d].recv_p.p + at, 0, m * 4, c->stream) : hipSuccess)) != hipSuccess)
                 return MC_EHIP;
             at += m;
         }

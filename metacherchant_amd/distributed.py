@@ -37,15 +37,30 @@ class ShardedCounter:
         self.bfs_rank = bfs_rank
         if self.world > 1 and bfs_rank is not None and self.rank != bfs_rank and hasattr(ctx, "set_read_pointers"):
             ctx.set_read_pointers(False)
-        # A rank's reads are exchanged and counted in chunks of at most this many reads (MC_EXCHANGE_CHUNK_READS): what bounds
-        # the memory of one exchange -- records to send, records received, the counting pipeline's scratch -- whatever the
-        # size of the rank's share (configs[3]: 125 M reads a rank; DESIGN.md section 6 has the budget).  Every chunk is one
-        # counting run, and a run rewrites the rank's whole table: as few chunks as fit.
+        # A rank's reads are exchanged in chunks of at most this many reads (MC_EXCHANGE_CHUNK_READS): what bounds the memory of
+        # one extraction whatever the size of the rank's share (configs[3]: 125 M reads a rank; DESIGN.md section 6 has the
+        # budget); see add_reads_dev for what happens to the chunks.
         self.chunk_reads = int(os.environ.get("MC_EXCHANGE_CHUNK_READS", 32 << 20))
+        self.min_chunks = int(os.environ.get("MC_EXCHANGE_MIN_CHUNKS", 4))          # so that transfers and extraction overlap ...
+        self.min_chunk_share = int(os.environ.get("MC_EXCHANGE_MIN_SHARE", 1 << 20))  # ... for shares of at least this many reads
+        self.count_every = int(os.environ.get("MC_EXCHANGE_COUNT_EVERY", 0))          # chunks per counting run (0: one run for all ...
+        # ... that fit: what is kept of the chunks received so far is counted as soon as it passes this many bytes.  One rank of
+        # configs[3] receives 11 GB a chunk beside a 137 GB table: kept until the end (44 GB) the one run's scratch leaves no
+        # room -- 287 of 288 GB in use, the allocations stall, 1 108 ms against 787 for a run per chunk (profiles/r04_rank_shard_*)
+        self.keep_bytes = int(float(os.environ.get("MC_EXCHANGE_KEEP_GB", 12)) * 1e9)
+        self.n_count_runs = 0
 
     def add_reads_dev(self, d_words, d_offsets, n_reads, n_bases, max_windows):
         """Counts this rank's reads into the sharded table: extract -> all-to-all -> count owned keys.
-        max_windows bounds the number of k-mer occurrences of the local reads (n_bases is always enough)."""
+        max_windows bounds the number of k-mer occurrences of the local reads (n_bases is always enough).
+
+        The reads go through the exchange in chunks (at least MC_EXCHANGE_MIN_CHUNKS = 4 for a share of a million reads or
+        more, and never more than MC_EXCHANGE_CHUNK_READS reads each): the all-to-alls of chunk c are issued asynchronously
+        and travel while chunk c + 1 is extracted, what arrives is kept, and the rank counts everything it received in ONE
+        run of the pipeline at the end -- a run rewrites the rank's whole table, so one is what a rank wants (round 3: a run
+        per chunk, and nothing overlapped) -- as long as what is kept stays under MC_EXCHANGE_KEEP_GB (12): beyond that, and
+        after every MC_EXCHANGE_COUNT_EVERY chunks when that is set, a counting run takes what has arrived (configs[3]: a run per
+        chunk)."""
         ctx, W = self.ctx, self.world
         if W == 1:
             ctx.add_reads_packed_dev(d_words, d_offsets, n_reads, n_bases)
@@ -53,7 +68,10 @@ class ShardedCounter:
         # Every rank must issue the same collectives: the number of chunks is the largest any rank needs (one all-reduce, the
         # only host round trip besides one per chunk for the record counts), and a rank that has run out of reads still
         # takes part in the remaining exchanges with zero counts.
-        nc = torch.tensor([max(1, -(-int(n_reads) // self.chunk_reads))], dtype=torch.int64, device=self.device)
+        want = max(1, -(-int(n_reads) // self.chunk_reads))
+        if n_reads >= self.min_chunk_share:
+            want = max(want, self.min_chunks)
+        nc = torch.tensor([want], dtype=torch.int64, device=self.device)
         dist.all_reduce(nc, op=dist.ReduceOp.MAX, group=self.group)
         n_chunks = int(nc.item())
         self.n_chunks = n_chunks  # (of the last call: the tests look at it)
@@ -65,14 +83,45 @@ class ShardedCounter:
             base_at = [0, int(n_bases)]
         sk = hasattr(ctx, "superkmer_capacity") and ctx.superkmer_capacity(max(int(max_windows), 1), max(int(n_reads), 1)) != 0
         self.by_minimizer = sk  # (records are dealt to the owners of their minimizers, keys to the owners of their own hashes)
+        # Read pointers travel only FROM the rank that walks (they lead into its read store; the others keep none and used to
+        # send an array of zeros: a fifth of the bytes of seven ranks out of eight)
+        with_ptrs = self.bfs_rank is None or self.rank == self.bfs_rank
+        ptr_sources = list(range(W)) if self.bfs_rank is None else [self.bfs_rank]
+        pending = []  # (handles, send buffers kept alive, received payload, received pointers, n)
+        self.n_count_runs = 0
+
+        def count_pending():
+            if not pending:
+                return
+            for hs, _keep, _r, _p, _n in pending:
+                for h in hs:
+                    h.wait()
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
+            n_all = sum(x[4] for x in pending)
+            if len(pending) == 1:
+                recv, recv_p = pending[0][2], pending[0][3]
+            else:
+                recv = torch.cat([x[2][:x[4]] for x in pending]) if n_all else pending[0][2]
+                recv_p = torch.cat([x[3][:x[4]] for x in pending]) if n_all else pending[0][3]
+            pending.clear()
+            # (a rank that received nothing still calls: the context must know its pipeline buffers were reused, mcgpu.hip)
+            if sk:
+                ctx.add_superkmers_dev(recv, recv_p, n_all)
+            else:
+                ctx.add_keys_dev(recv, n_all, recv_p)
+            self.n_count_runs += 1
+
         for c in range(n_chunks):
             a, b = bounds[c], bounds[c + 1]
             nb = base_at[c + 1] - base_at[c]
             # (offsets are absolute in the rank's buffer: a chunk is the reads [a, b) with the bases up to base_at[c + 1])
-            if sk:
-                self._exchange_superkmers(d_words, d_offsets[a:], b - a, base_at[c + 1], nb)
-            else:
-                self._exchange_keys(d_words, d_offsets[a:], b - a, base_at[c + 1], min(int(max_windows), nb))
+            pending.append(self._exchange_chunk(sk, d_words, d_offsets[a:], b - a, base_at[c + 1], nb if sk else min(int(max_windows), nb),
+                                                with_ptrs, ptr_sources))
+            kept = sum(x[2].numel() * 8 + x[3].numel() * 4 for x in pending)
+            if (self.count_every and len(pending) >= self.count_every) or kept >= self.keep_bytes:
+                count_pending()
+        count_pending()
 
     def _counts(self, send_counts):
         """The one host round trip of an exchange: what every rank will send me."""
@@ -82,58 +131,50 @@ class ShardedCounter:
         dist.all_to_all_single(rc, sc, group=self.group)
         return [int(x) for x in rc.cpu().tolist()]
 
-    def _exchange_keys(self, d_words, d_offsets, n_reads, n_bases_end, max_windows):
+    def _exchange_chunk(self, sk, d_words, d_offsets, n_reads, n_bases_end, room, with_ptrs, ptr_sources):
+        """One chunk: extract (super-k-mer records of 16 bytes for packed keys, k >= 23 -- a seventh of the bytes of one key
+        per window --, else keys), one exchange of the counts, then the payload and the read pointers as asynchronous
+        all-to-alls.  Returns (handles, send buffers, received payload, received pointers, n received): the caller waits."""
         ctx, W = self.ctx, self.world
-        cap = max(int(max_windows), 1)
-        send = torch.empty(cap, dtype=torch.int64, device=self.device)
-        send_h = torch.empty(cap, dtype=torch.int32, device=self.device)  # the read pointers
+        if sk:
+            cap = max(ctx.superkmer_capacity(max(int(room), 1), max(int(n_reads), 1)), 1)
+            send = torch.empty((cap, 2), dtype=torch.int64, device=self.device)   # 16-byte records
+        else:
+            cap = max(int(room), 1)
+            send = torch.empty(cap, dtype=torch.int64, device=self.device)
+        send_p = torch.empty(cap, dtype=torch.int32, device=self.device)          # the read pointers (of the records' first windows)
         if n_reads:
-            off = ctx.extract_keys_dev(d_words, d_offsets, n_reads, n_bases_end, W, send, send.numel(), send_h)
+            if sk:
+                off = ctx.extract_superkmers_dev(d_words, d_offsets, n_reads, n_bases_end, W, send, send_p, cap)
+            else:
+                off = ctx.extract_keys_dev(d_words, d_offsets, n_reads, n_bases_end, W, send, cap, send_p)
         else:
             off = np.zeros(W + 1, dtype=np.uint64)
         send_counts = [int(off[o + 1] - off[o]) for o in range(W)]
         recv_counts = self._counts(send_counts)
         n_recv, n_send = sum(recv_counts), int(off[W])
-        recv = torch.empty(max(n_recv, 1), dtype=torch.int64, device=self.device)
-        recv_h = torch.empty(max(n_recv, 1), dtype=torch.int32, device=self.device)
-        dist.all_to_all_single(recv[:n_recv], send[:n_send], output_split_sizes=recv_counts,
-                               input_split_sizes=send_counts, group=self.group)
-        dist.all_to_all_single(recv_h[:n_recv], send_h[:n_send], output_split_sizes=recv_counts,
-                               input_split_sizes=send_counts, group=self.group)
-        if self.device.type == "cuda":
-            torch.cuda.synchronize(self.device)
-        self.bytes_sent += 12 * (n_send - send_counts[self.rank])
-        del send, send_h
-        ctx.add_keys_dev(recv, n_recv, recv_h)
-
-    def _exchange_superkmers(self, d_words, d_offsets, n_reads, n_bases_end, n_bases):
-        """One chunk as super-k-mer records (packed keys, k >= 23: a seventh of the bytes of one key per window): extract,
-        one exchange of the counts, the records and their read pointers in two all-to-alls, one counting run."""
-        ctx, W = self.ctx, self.world
-        cap = max(ctx.superkmer_capacity(max(int(n_bases), 1), max(int(n_reads), 1)), 1)
-        send = torch.empty((cap, 2), dtype=torch.int64, device=self.device)   # 16-byte records
-        send_b = torch.empty(cap, dtype=torch.int32, device=self.device)      # the read pointers of their first windows
-        if n_reads:
-            off = ctx.extract_superkmers_dev(d_words, d_offsets, n_reads, n_bases_end, W, send, send_b, cap)
+        recv = torch.empty((max(n_recv, 1), 2) if sk else max(n_recv, 1), dtype=torch.int64, device=self.device)
+        # pointers: only the ranks in ptr_sources send theirs; what comes from the others is zero (no pointer)
+        all_send = len(ptr_sources) == W
+        recv_p = (torch.empty if all_send else torch.zeros)(max(n_recv, 1), dtype=torch.int32, device=self.device)
+        hs = [dist.all_to_all_single(recv[:n_recv], send[:n_send], output_split_sizes=recv_counts, input_split_sizes=send_counts,
+                                     group=self.group, async_op=True)]
+        if all_send:
+            hs.append(dist.all_to_all_single(recv_p[:n_recv], send_p[:n_send], output_split_sizes=recv_counts, input_split_sizes=send_counts,
+                                             group=self.group, async_op=True))
+            ptr_bytes = 4 * (n_send - send_counts[self.rank])
         else:
-            off = np.zeros(W + 1, dtype=np.uint64)
-        send_counts = [int(off[o + 1] - off[o]) for o in range(W)]
-        recv_counts = self._counts(send_counts)
-        n_recv, n_send = sum(recv_counts), int(off[W])
-        recv = torch.empty((max(n_recv, 1), 2), dtype=torch.int64, device=self.device)
-        recv_b = torch.empty(max(n_recv, 1), dtype=torch.int32, device=self.device)
-        w1 = dist.all_to_all_single(recv[:n_recv], send[:n_send], output_split_sizes=recv_counts, input_split_sizes=send_counts,
-                                    group=self.group, async_op=True)
-        w2 = dist.all_to_all_single(recv_b[:n_recv], send_b[:n_send], output_split_sizes=recv_counts, input_split_sizes=send_counts,
-                                    group=self.group, async_op=True)
-        w1.wait()
-        w2.wait()
-        if self.device.type == "cuda":
-            torch.cuda.synchronize(self.device)
-        self.bytes_sent += 20 * (n_send - send_counts[self.rank])
-        del send, send_b
-        # (a rank that received nothing still calls: the context must know its pipeline buffers were reused, mcgpu.hip)
-        ctx.add_superkmers_dev(recv, recv_b, n_recv)
+            # the pointer stream as an all-to-all in which only ptr_sources have anything to send: the receiver's slice for source
+            # r starts where r's records start
+            p_send = send_counts if with_ptrs else [0] * W
+            p_recv = [recv_counts[r] if r in ptr_sources else 0 for r in range(W)]
+            src = ptr_sources[0]
+            at = sum(recv_counts[:src])
+            hs.append(dist.all_to_all_single(recv_p[at:at + recv_counts[src]], send_p[:n_send if with_ptrs else 0], output_split_sizes=p_recv,
+                                             input_split_sizes=p_send, group=self.group, async_op=True))
+            ptr_bytes = 4 * (n_send - send_counts[self.rank]) if with_ptrs else 0
+        self.bytes_sent += (16 if sk else 8) * (n_send - send_counts[self.rank]) + ptr_bytes
+        return hs, (send, send_p), recv, recv_p, n_recv
 
     def finalize(self):
         """Local distinct keys; the sum over ranks is the table size (owners are disjoint)."""

@@ -18,11 +18,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 class OracleBackedContext:
     """Implements the Context methods distributed.py uses, on CPU tensors, with oracle/ functions."""
 
-    def __init__(self, k, mode, records=False):
+    def __init__(self, k, mode, records=False, rank=0):
         from oracle import pyoracle as po
         self.po, self.k, self.mode = po, k, mode
         self.t = po.Table()
         self.records = records  # stand in for a context that splits reads into super-k-mer records
+        self.rank = rank        # stamped into what this context extracts, so that the receiver can tell the sources apart
 
     # the record form of the split, degenerate here: one window per record, the key in the record's first word
     def superkmer_capacity(self, n_windows, n_reads):
@@ -33,12 +34,16 @@ class OracleBackedContext:
         keys = torch.zeros(cap, dtype=torch.int64)
         out = self.extract_keys_dev(d_words, d_off, n_reads, n_bases, n_owners, keys, cap)
         d_recs[:, 0] = keys
-        d_recs[:, 1] = 7
+        d_recs[:, 1] = 7 + 16 * self.rank
         d_bins[:] = 5
         return out
 
     def add_superkmers_dev(self, d_recs, d_bins, n):
-        assert bool((d_recs[:n, 1] == 7).all()) and bool((d_bins[:n] == 5).all())
+        # the second words say which rank a record came from; read pointers travel only from the rank that walks (rank 0):
+        # its records bring theirs (5), everybody else's arrive with none
+        src = (d_recs[:n, 1] - 7) // 16
+        assert bool(((d_recs[:n, 1] - 7) % 16 == 0).all())
+        assert bool((d_bins[:n][src == 0] == 5).all()) and bool((d_bins[:n][src != 0] == 0).all())
         self.add_keys_dev(d_recs[:n, 0].contiguous(), n)
 
     def add_reads_packed_dev(self, d_words, d_off, n_reads, n_bases):
@@ -101,7 +106,7 @@ class OracleBackedContext:
         return n
 
 
-def _worker(rank, world, port, k, mode, reads, L, n_reads, min_cov, q, records=False, chunk_reads=0, share0=None):
+def _worker(rank, world, port, k, mode, reads, L, n_reads, min_cov, q, records=False, chunk_reads=0, share0=None, count_every=0):
     # chunk_reads: MC_EXCHANGE_CHUNK_READS (0: the default, one chunk here); share0: reads of rank 0 (None: equal shares)
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -110,6 +115,8 @@ def _worker(rank, world, port, k, mode, reads, L, n_reads, min_cov, q, records=F
     try:
         if chunk_reads:
             os.environ["MC_EXCHANGE_CHUNK_READS"] = str(chunk_reads)
+        if count_every:
+            os.environ["MC_EXCHANGE_COUNT_EVERY"] = str(count_every)  # (what bounds the memory of the kept chunks at configs[3]'s size)
         from metacherchant_amd.distributed import ShardedCounter, split_reads
         from oracle import pyoracle as po
         lo, hi = split_reads(n_reads, world, rank)
@@ -118,7 +125,7 @@ def _worker(rank, world, port, k, mode, reads, L, n_reads, min_cov, q, records=F
         mine = reads[lo * L:hi * L]
         words = torch.from_numpy(po.pack(mine).view(np.int64))
         off = torch.from_numpy((np.arange(hi - lo + 1, dtype=np.uint64) * L).view(np.int64))
-        ctx = OracleBackedContext(k, mode, records)
+        ctx = OracleBackedContext(k, mode, records, rank)
         sc = ShardedCounter(ctx, torch.device("cpu"))
         sc.add_reads_dev(words, off, hi - lo, (hi - lo) * L, (hi - lo) * (L - k + 1))
         total = sc.finalize()
@@ -129,7 +136,7 @@ def _worker(rank, world, port, k, mode, reads, L, n_reads, min_cov, q, records=F
         assert all(native.key_owner(int(x), world) == rank for x in own_keys[:500])
         if rank == 0:
             sk, scnt = solid.t.dump()
-            q.put((total, n_solid, sk, scnt, sc.bytes_sent, sc.n_chunks))
+            q.put((total, n_solid, sk, scnt, sc.bytes_sent, sc.n_chunks, sc.n_count_runs))
     finally:
         dist.destroy_process_group()
 
@@ -144,9 +151,10 @@ def _free_port():
 
 # (k, key mode, record form, MC_EXCHANGE_CHUNK_READS, reads of rank 0 of 300): the last three run the exchange in several chunks,
 # with shares so unequal that rank 1 (6, 2 and 0 reads) has chunks without a read while rank 0 still sends
-@pytest.mark.parametrize("k,mode,records,chunk_reads,share0", [(31, 0, False, 0, None), (35, 1, False, 0, None), (31, 0, True, 0, None),
-                                                                (31, 0, True, 64, 294), (27, 0, True, 50, 298), (33, 1, False, 64, 300)])
-def test_sharded_count_equals_single_table(k, mode, records, chunk_reads, share0):
+@pytest.mark.parametrize("k,mode,records,chunk_reads,share0,count_every", [(31, 0, False, 0, None, 0), (35, 1, False, 0, None, 0), (31, 0, True, 0, None, 0),
+                                                                            (31, 0, True, 64, 294, 0), (27, 0, True, 50, 298, 0), (33, 1, False, 64, 300, 0),
+                                                                            (31, 0, True, 64, 294, 2)])
+def test_sharded_count_equals_single_table(k, mode, records, chunk_reads, share0, count_every):
     from metacherchant_amd import build
     build.build_lib()  # key_owner comes from the C ABI (host function, no GPU needed)
     from oracle import pyoracle as po
@@ -158,10 +166,10 @@ def test_sharded_count_equals_single_table(k, mode, records, chunk_reads, share0
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, k, mode, reads, L, n_reads, min_cov, q, records, chunk_reads, share0)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, k, mode, reads, L, n_reads, min_cov, q, records, chunk_reads, share0, count_every)) for r in range(2)]
     for p in procs:
         p.start()
-    total, n_solid, sk, scnt, sent, n_chunks = q.get(timeout=120)
+    total, n_solid, sk, scnt, sent, n_chunks, runs = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -172,6 +180,8 @@ def test_sharded_count_equals_single_table(k, mode, records, chunk_reads, share0
     assert np.array_equal(sk, ok[m]) and np.array_equal(scnt, oc[m])
     assert sent > 0
     assert n_chunks == (1 if not chunk_reads else -(-share0 // chunk_reads)) and (not chunk_reads or n_chunks >= 3)
+    # however many chunks travelled: ONE counting run (a run rewrites the rank's whole table), unless the memory bound asks for more
+    assert runs == (1 if not count_every else -(-n_chunks // count_every))
 
 
 def test_split_reads_covers_everything():
