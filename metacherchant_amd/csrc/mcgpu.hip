@@ -220,6 +220,7 @@ struct mc_ctx {
     // the second scatter level of one piece of a batch runs here, next to the first level of the next piece (add_reads_partitioned)
     hipStream_t pipe_stream = nullptr;
     hipEvent_t ev_piece[8] = {}, ev_p2 = nullptr;
+    hipEvent_t ev_seq[16] = {};  // behind every kernel of a per-window run in pieces (add_reads_partitioned_once)
     hipEvent_t ev_t[4] = {};  // P1 start, P1 end, P2 end, P3 end of a pipeline run enqueued without a host round trip in between
     // The read store: the packed bases of every read this context was given since the last mc_clear, batch after
     // batch (each starting on a word boundary).  Table slots point into it (kmer_device.h ptr_encode) and the BFS
@@ -1764,19 +1765,34 @@ static int add_reads_partitioned_once(mc_ctx *c, const uint64_t *d_words, const 
     double ms1 = 0;
     if (pieces > 1 && !pl.sk) {
         const uint64_t t_first = base0 / tile_size, per = (n_tiles_abs - t_first + pieces - 1) / pieces;
-        rc = timed(c, &ms1, [&] {
-            launch_tile_first(c, offs, nr, n_tiles_abs, P.tile_first, tile_size);
-            for (uint32_t pc = 0; pc < pieces; pc++) {
-                const uint64_t lo_t = t_first + pc * per, hi_t = std::min<uint64_t>(n_tiles_abs, lo_t + per);
-                if (lo_t >= hi_t) continue;
+        // (the two levels alternate on one stream; an event behind every kernel books each level's time where it belongs --
+        // round 3 booked both under the first level and reported k_p2_scatter: 0.0 for configs[2] at full size)
+        for (uint32_t i = 0; i < 2 * pieces; i++)
+            if (!c->ev_seq[i]) HIPCHK(c, hipEventCreate(&c->ev_seq[i]));
+        HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+        launch_tile_first(c, offs, nr, n_tiles_abs, P.tile_first, tile_size);
+        for (uint32_t pc = 0; pc < pieces; pc++) {
+            const uint64_t lo_t = t_first + pc * per, hi_t = std::min<uint64_t>(n_tiles_abs, lo_t + per);
+            if (lo_t < hi_t)
                 launch_p1_reads(c, d_words, offs, nr, pc == 0 ? base0 : lo_t * tile_size, end_abs, hi_t, P.tile_first, pl.b1, P.seg_counts1, pl.cap1,
                                 P.a_keys, P.a_hints, pl.sp, 0, nullptr);
+            HIPCHK(c, hipEventRecord(c->ev_seq[2 * pc], c->stream));
+            if (lo_t < hi_t)
                 hipLaunchKernelGGL(k_p2_scatter, dim3((unsigned)pl.np1), dim3(PT_THREADS), 0, c->stream, P.a_keys, P.a_hints, pl.cap1, P.seg_counts1,
                                    (uint32_t)pl.np1, pl.b1, pl.b2, P.cursors2, pl.cap2, P.b_keys, P.b_hints, pl.sp, c->mm_k, pc, pieces);
-            }
-        });
-        if (rc) return rc;
-        rc = pipe_finish(c, pl, ms1, true, 0, false, true);
+            HIPCHK(c, hipEventRecord(c->ev_seq[2 * pc + 1], c->stream));
+        }
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipEventSynchronize(c->ev_seq[2 * pieces - 1]));
+        double ms2 = 0;
+        for (uint32_t pc = 0; pc < pieces; pc++) {
+            float f1 = 0, f2 = 0;
+            HIPCHK(c, hipEventElapsedTime(&f1, pc ? c->ev_seq[2 * pc - 1] : c->ev0, c->ev_seq[2 * pc]));
+            HIPCHK(c, hipEventElapsedTime(&f2, c->ev_seq[2 * pc], c->ev_seq[2 * pc + 1]));
+            ms1 += f1;
+            ms2 += f2;
+        }
+        rc = pipe_finish(c, pl, ms1, true, ms2, false, true);
     } else if (pieces > 1) {
         const uint64_t t_first = base0 / tile_size, per = (n_tiles_abs - t_first + pieces - 1) / pieces;
         const uint64_t a_stride = pl.np1 * pl.nseg1 * pl.cap1, c_stride = pl.np1 * pl.nseg1;
@@ -2178,6 +2194,7 @@ void mc_destroy(mc_ctx *c)
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     g_scratch_pool.put(c->cfg.device, c->rs_words, c->rs_cap_words * 8);
     for (auto &e : c->ev_piece) if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->ev_seq) if (e) (void)hipEventDestroy(e);
     if (c->ev_p2) (void)hipEventDestroy(c->ev_p2);
     for (auto &e : c->ev_t) if (e) (void)hipEventDestroy(e);
     if (c->pipe_stream) { (void)hipStreamSynchronize(c->pipe_stream); (void)hipStreamDestroy(c->pipe_stream); }

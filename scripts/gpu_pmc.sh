@@ -1,9 +1,11 @@
 #!/bin/bash
-# HBM traffic of the bench kernels from PMC counters (separate passes, kernel-trace only), MI355X_MICROARCH.md "HBM"
+# HBM traffic of the bench kernels from PMC counters (separate passes, kernel-trace only), MI355X_MICROARCH.md "HBM".
+# Two steps without warm-up: dispatch 1 of every kernel is the COLD step (a table never touched before), dispatch 2 the
+# WARM one (mc_clear, the same table memory again -- the step the bench times)
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d gpurun_out/pmc_$ctr -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > gpurun_out/pmc_$ctr.log 2>&1
+  timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d gpurun_out/pmc_$ctr -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline "$@" > gpurun_out/pmc_$ctr.log 2>&1
   echo "$ctr rc=$?"
 done
 python3 - <<'PY'

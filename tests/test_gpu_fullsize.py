@@ -76,5 +76,15 @@ def test_config1_full_size_table_checksums_and_bfs():
     res = ctx.bfs_batch([(hi, lo, -1), (hi, lo, 1)], cov, 100000, -1)
     for d, r in zip((-1, 1), res):
         assert_bfs_equal(r, po.bfs(t, k, po.KEY_PACKED, [seed], d, cov, 100000, -1))
+    # --maxkmers that BITES at full size: the right-hand pass is cut at 50 000 vertices in the middle of its walk (the cut
+    # order is TerminationMode.java:31-47's: the cap is tested at every single insertion), and 17 000 cuts the left-hand one
+    # 789 vertices before it would have ended by itself; --maxradius cutting both at once
+    for cap_k, cap_r in ((50000, -1), (17000, -1), (100000, 12345)):
+        res = ctx.bfs_batch([(hi, lo, -1), (hi, lo, 1)], cov, cap_k, cap_r)
+        for d, r in zip((-1, 1), res):
+            want = po.bfs(t, k, po.KEY_PACKED, [seed], d, cov, cap_k, cap_r)
+            assert_bfs_equal(r, want)
+            if cap_r < 0 and d == 1:
+                assert len(want["lo"]) == cap_k  # (it did bite)
     assert ctx.stats().solid_sweeps == 0
     ctx.close()
