@@ -321,7 +321,9 @@ struct NarrowLds {
 // ---- wide path: one chunk of <= BFS_THREADS candidates in rank order.  parent == UINT64_MAX marks a
 // seed window (src/algo/OneSequenceCalculator.java:159-192: queued when reads.get(key) >= minOccurences).
 template <int MODE>
-__device__ void bfs_chunk_wide(const BfsState &S, const SolidView &t, WideLds &L, int k, int min_cov,
+// (forceinline, like the walk's other parts: called out of line -- it has two call sites -- it takes S and t by reference, which puts
+// both into scratch memory for the WHOLE kernel: every t.slots / t.reads then costs a scratch load)
+__device__ __forceinline__ void bfs_chunk_wide(const BfsState &S, const SolidView &t, WideLds &L, int k, int min_cov,
                                long long max_kmers, bool radius_ok, bool have, const Kmer &cand, uint64_t parent,
                                int32_t new_dist, unsigned long long &lookups)
 {
@@ -411,7 +413,7 @@ __device__ __forceinline__ uint32_t tree_size(int nb, int d)
 
 // Exact level-by-level replay of one speculated round (wave 0).  Returns the number of accepted
 // vertices; updates n/lb/le/level/cur/F in L.
-__device__ inline uint32_t replay_slow(const BfsState &S, NarrowLds &L, int d, int min_cov, long long max_kmers,
+__device__ __forceinline__ uint32_t replay_slow(const BfsState &S, NarrowLds &L, int d, int min_cov, long long max_kmers,
                                        long long max_radius, uint32_t lg, uint32_t flim, uint32_t *last_base)
 {
     const uint32_t lane = threadIdx.x & 63;
@@ -501,11 +503,11 @@ __device__ inline uint32_t replay_slow(const BfsState &S, NarrowLds &L, int d, i
 }
 
 // lookup with the first two probe slots already loaded; *aux = the read pointer stored with the key (0 when absent)
-__device__ __forceinline__ int solid_get2(const SolidView &t, uint64_t key, uint64_t s0, const uint4 &a0, const uint4 &a1,
+__device__ __forceinline__ int solid_get2(const SolidView &tv, const TableRef &t, uint64_t key, uint64_t s0, const uint4 &a0, const uint4 &a1,
                                           uint32_t *aux)
-{
+{   // t: the table the key lives in (kmer_device.h solid_locate), s0 its home slot there; tv: the walk's view (the out-of-band key)
     *aux = 0;
-    if (key == EMPTY_KEY) return solid_get(t, key);
+    if (key == EMPTY_KEY) return solid_get(tv, key);
     const uint64_t k0 = ((uint64_t)a0.y << 32) | a0.x;
     if (k0 == key) { *aux = a0.w; return a0.z > 32767u ? 32767 : (int)a0.z; }
     if (k0 == EMPTY_KEY) return -1;
@@ -558,10 +560,10 @@ __device__ __forceinline__ Kmer kmer_rc(const Kmer &v, int k)
 
 // lookup with the first four probe slots requested at once: the lanes of a wave look different keys up, and the
 // slowest one decides -- at load 1/4 one in ~8 lookups needs a second probe, nearly none a fifth
-__device__ __forceinline__ int solid_get4(const SolidView &t, uint64_t key, uint32_t *aux, uint64_t s0)
-{   // s0 = solid_slot_of(t, key)
+__device__ __forceinline__ int solid_get4(const SolidView &tv, const TableRef &t, uint64_t key, uint32_t *aux, uint64_t s0)
+{   // t, s0: where the key lives (solid_locate); tv: the walk's view
     *aux = 0;
-    if (key == EMPTY_KEY) return solid_get(t, key);
+    if (key == EMPTY_KEY) return solid_get(tv, key);
     const uint64_t base = s0 & ~(uint64_t)t.rmask;
     constexpr int NP = MC_SCOUT_PROBES;
     uint4 a[NP];
@@ -613,7 +615,7 @@ __device__ __forceinline__ uint64_t scout_word_of(const SolidView &t, uint32_t c
 }
 
 // sw, mh: this wave's LDS scratch (SCOUT_WORDS words of the read store; SCOUT_MH minimizer hashes)
-template <int MODE>
+template <int MODE, bool SH = false>
 __device__ __forceinline__ void scout_eval(const SolidView &t, uint64_t *sw, uint32_t *mh, const Kmer &X, int k, int min_cov, uint32_t cptr,
                                            uint32_t delta, uint32_t want, HopEval &R, unsigned long long &lookups, unsigned long long *tsc = nullptr,
                                            bool staged = false, uint32_t n_cand = 0, uint32_t lane_base = 0)
@@ -695,8 +697,9 @@ __device__ __forceinline__ void scout_eval(const SolidView &t, uint64_t *sw, uin
     int cov = -1;
     const uint64_t key = ok ? (uint64_t)key_of<MODE>(K, k) : 0;
     uint64_t s0;
-    SolidView h = t;  // the table this lane's vertex lives in (several GPUs: its owner's)
-    if (MODE == KEY_PACKED && (t.n_shards > 1 ? t.owner_mm_k : t.mm_k)) {
+    // h: the table this lane's vertex lives in -- SH (several GPUs): its owner's; else the walker's own (uniform values)
+    TableRef h;
+    if (MODE == KEY_PACKED && (SH ? t.owner_mm_k : t.mm_k)) {
         // The counting table's regions are minimizer bins (kmer_device.h).  The vertices of consecutive lanes overlap in
         // all but one base, so every SK_M-mer is hashed once -- a lane hashes the last one of its own vertex, the first
         // lanes also the ones inside the tip -- and a lane takes the minimum over its w of them (w = k - SK_M + 1).
@@ -722,13 +725,15 @@ __device__ __forceinline__ void scout_eval(const SolidView &t, uint64_t *sw, uin
         } else {
             for (uint32_t i = 0; i < w; i++) hmin = min(hmin, mh[lane + i]);
         }
-        s0 = solid_locate(t, key, h, &hmin);
+        if (SH) s0 = solid_locate(t, key, h, true, hmin);
+        else { h = own_table(t); s0 = ((((uint64_t)sk_bin(hmin) * t.n_regions) >> 32) << MC_REGION_LG) | sk_home(key); }
     } else {
-        s0 = solid_locate(t, key, h);
+        if (SH) s0 = solid_locate(t, key, h);
+        else { h = own_table(t); s0 = solid_slot_of(t, key); }
     }
     SC_STAMP(1);
     if (ok) {
-        cov = solid_get4(h, key, &aux, s0);
+        cov = solid_get4(t, h, key, &aux, s0);
         lookups++;
     }
     SC_STAMP(2);
@@ -851,8 +856,8 @@ __device__ __forceinline__ void path_append(uint64_t *P, PathTail &T, uint64_t e
 // reverse complement, so that the walk always appends), 32 bases per word into S.path: first the k bases of the
 // walker's vertex, then one base per predicted level.  Only `solid` is checked here; whether each level is what the
 // sequential BFS would find is the rounds' business.
-template <int MODE>
-__device__ void scout_run(const BfsState &S, const SolidView &t, NarrowLds &L, uint32_t a, int k, int min_cov, uint32_t budget,
+template <int MODE, bool SH = false>
+__device__ __forceinline__ void scout_run(const BfsState &S, const SolidView &t, NarrowLds &L, uint32_t a, int k, int min_cov, uint32_t budget,
                           unsigned long long &lookups)
 {
     const uint32_t lane = threadIdx.x & 63;
@@ -874,7 +879,7 @@ __device__ void scout_run(const BfsState &S, const SolidView &t, NarrowLds &L, u
     while (levels < budget && nc) {
         bool progressed = false;
         for (uint32_t ci = 0; ci < nc && !progressed; ci++) {
-            scout_eval<MODE>(t, L.sw[a], L.mh[a], X, k, min_cov, cptr[ci], cdelta[ci], min(64u, budget - levels), R, lookups);
+            scout_eval<MODE, SH>(t, L.sw[a], L.mh[a], X, k, min_cov, cptr[ci], cdelta[ci], min(64u, budget - levels), R, lookups);
             if (R.why == 1) { n_nf++; continue; }
             hops++;
             if (R.m == 0) { n_m0++; continue; }
@@ -947,8 +952,8 @@ struct TeamLds {
     uint32_t published[SCOUT_MAX_F];  // levels whose path words are known to have arrived
 };
 
-template <int MODE>
-__device__ void scout_companion(const BfsState &S, const SolidView &t, TeamLds &L, int k, int min_cov)
+template <int MODE, bool SH = false>
+__device__ __forceinline__ void scout_companion(const BfsState &S, const SolidView &t, TeamLds &L, int k, int min_cov)
 {
     ScoutBox *box = S.box;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1011,7 +1016,7 @@ __device__ void scout_companion(const BfsState &S, const SolidView &t, TeamLds &
             const bool busy = member && !L.stuck[g] && L.levels[g] < budget;
             if (busy && cd < L.nc[g] && budget - L.levels[g] > 64u * sg) {
                 const bool staged = L.staged[g] != 0;
-                scout_eval<MODE>(t, staged ? L.swn[g][cd] : L.sw[wv], L.mh[wv], L.X[g], k, min_cov, L.cptr[g][cd], L.cdelta[g][cd],
+                scout_eval<MODE, SH>(t, staged ? L.swn[g][cd] : L.sw[wv], L.mh[wv], L.X[g], k, min_cov, L.cptr[g][cd], L.cdelta[g][cd],
                                  min(64u, budget - L.levels[g] - 64u * sg), R, lookups, tsc, staged, n_cd, 64u * sg);
                 if (sg == 0) { if (R.why == 1) n_nf += lane == 0; else { hops += lane == 0; if (R.m == 0) n_m0 += lane == 0; } }
             }
@@ -1110,8 +1115,8 @@ __device__ void scout_companion(const BfsState &S, const SolidView &t, TeamLds &
 // sequential discovery order.  The first level that holds anything else (a branch, a dead end, a cycle,
 // the cap, the radius) is left to the exact one-level replay with the LDS set (replay_slow, wave 0).
 // Predictions only steer the guess; every guess is checked against the table and the visited index.
-template <int MODE>
-__device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, int k, int min_cov,
+template <int MODE, bool SH = false>
+__device__ __forceinline__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, int k, int min_cov,
                            long long max_kmers, long long max_radius, unsigned long long rounds_budget,
                            unsigned long long &lookups, bool companion)
 {
@@ -1289,7 +1294,7 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
 #ifndef MC_BFS_OLD_RACE
                 BFS_SYNC();  // scout_run ends with stores to plen / ppos, which every wave read for `avail` above
 #endif
-                if (wv < F) scout_run<MODE>(S, t, L, wv, k, min_cov, budget, lookups);
+                if (wv < F) scout_run<MODE, SH>(S, t, L, wv, k, min_cov, budget, lookups);
                 BFS_SYNC();
                 avail = 0xFFFFFFFFu;
                 for (uint32_t a = 0; a < F; a++) avail = min(avail, L.plen[a]);
@@ -1315,7 +1320,7 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
         int cov = -1;
         uint32_t naux = 0;
         uint64_t key = 0, s0 = 0;
-        SolidView h = t;  // the table the node's k-mer lives in (several GPUs: its owner's)
+        TableRef h = own_table(t);  // the table the node's k-mer lives in (SH, several GPUs: its owner's)
         uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
         bool root_bad = false;
         if (tid < H * FN) {
@@ -1362,7 +1367,7 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
                 nk = neighbour(v, k, dir, (int)c);
                 key = (uint64_t)key_of<MODE>(nk, k, &nflip);
             }
-            s0 = solid_locate(t, key, h);
+            s0 = SH ? solid_locate(t, key, h) : solid_slot_of(t, key);
             const uint64_t s1 = (s0 & ~(uint64_t)h.rmask) | ((s0 + 1) & h.rmask);
             a0 = *reinterpret_cast<const uint4 *>(h.slots + s0);
             a1 = *reinterpret_cast<const uint4 *>(h.slots + s1);
@@ -1374,7 +1379,7 @@ __device__ void bfs_narrow(const BfsState &S, const SolidView &t, NarrowLds &L, 
         if (BFS_THREADS - 1 - tid < pend) vis_insert(S, L.pub_k[BFS_THREADS - 1 - tid], L.pub_idx[BFS_THREADS - 1 - tid]);
         MC_STAMP(1);
         if (have) {
-            cov = solid_get2(h, key, s0, a0, a1, &naux);
+            cov = solid_get2(t, h, key, s0, a0, a1, &naux);
             L.cov[tid] = (int16_t)cov;
             L.kmer[tid] = nk;
             L.naux[tid] = naux;
@@ -1569,7 +1574,7 @@ union BfsLds {
     TeamLds t;
 };
 
-template <int MODE>
+template <int MODE, bool SH = false>
 __global__ void __launch_bounds__(BFS_THREADS) k_bfs(const BfsState *__restrict__ states, SolidView t, int k,
                                                      int min_cov, long long max_kmers, long long max_radius,
                                                      unsigned long long max_rounds, int companions)
@@ -1580,7 +1585,7 @@ __global__ void __launch_bounds__(BFS_THREADS) k_bfs(const BfsState *__restrict_
     BfsCtl *ctl = S.ctl;
     const uint32_t tid = threadIdx.x;
     if (companions && (blockIdx.x & 1u)) {
-        if (S.box && t.reads) scout_companion<MODE>(S, t, lds.t, k, min_cov);
+        if (S.box && t.reads) scout_companion<MODE, SH>(S, t, lds.t, k, min_cov);
         return;
     }
     if (ctl_ld(&ctl->status) != BFS_RUNNING) {  // finished (or waiting for the host) in an earlier launch
@@ -1640,7 +1645,7 @@ __global__ void __launch_bounds__(BFS_THREADS) k_bfs(const BfsState *__restrict_
         if (rounds_left == 0) break;
         if (ctl_ld(&ctl->c0) == 0 && le - lb <= flim) {
             BFS_SYNC();
-            bfs_narrow<MODE>(S, t, lds.n, k, min_cov, max_kmers, max_radius, rounds_left, lookups, companions != 0);
+            bfs_narrow<MODE, SH>(S, t, lds.n, k, min_cov, max_kmers, max_radius, rounds_left, lookups, companions != 0);
             rounds_left = lds.n.rounds_left;
             BFS_SYNC();
             if (ctl_ld(&ctl->status) != BFS_RUNNING) break;  // done, or distanceToKmer must grow

@@ -547,26 +547,34 @@ __device__ __forceinline__ uint64_t solid_slot_of(const SolidView &t, uint64_t k
     return (region << MC_REGION_LG) | sk_home(key);
 }
 
-// h = the view of shard o of t (the read store stays the walker's)
-__device__ __forceinline__ void shard_into(SolidView &h, const SolidView &t, uint32_t o)
+// What a lookup needs of the table it goes to -- the walker's own or, with several GPUs, the key's owner's.  Built field by
+// field: a whole-struct copy of the kernel argument `t` made the compiler keep `t` in scratch memory, and every t.slots /
+// t.reads of the walk became a scratch load (k_bfs went from 9.4 to 10.7 ms on configs[1] before this was noticed).
+struct TableRef {
+    Slot *slots;
+    uint32_t shift, rmask, n_regions;
+    int mm_k;
+    const unsigned long long *empty_cnt;
+};
+__device__ __forceinline__ TableRef own_table(const SolidView &t) { return TableRef{t.slots, t.shift, t.rmask, t.n_regions, t.mm_k, t.empty_cnt}; }
+__device__ __forceinline__ TableRef shard_table(const SolidView &t, uint32_t o)
 {
     const ShardRef &r = t.shards[o];
-    h.slots = r.slots; h.shift = r.shift; h.rmask = r.rmask; h.n_regions = r.n_regions; h.mm_k = r.mm_k;
-    h.empty_cnt = &r.empty;
+    return TableRef{r.slots, r.shift, r.rmask, r.n_regions, r.mm_k, &r.empty};
 }
-// Where `key` lives: h = the view of the table that holds it (t itself on one GPU), the result its home slot there.
-// hmin (may be null): the key's minimizer hash when the caller has it already (sk_hmin_of_kmer is 17 hashes at k = 31).
-__device__ __forceinline__ uint64_t solid_locate(const SolidView &t, uint64_t key, SolidView &h, const uint32_t *hmin = nullptr)
+// Where `key` lives: h = the table that holds it (t's own on one GPU), the result its home slot there.
+// have_hmin / hmin: the key's minimizer hash when the caller has it already (sk_hmin_of_kmer is 17 hashes at k = 31).
+__device__ __forceinline__ uint64_t solid_locate(const SolidView &t, uint64_t key, TableRef &h, bool have_hmin = false, uint32_t hmin = 0)
 {
-    h = t;
     if (t.n_shards <= 1) {
+        h = own_table(t);
         if (t.mm_k == 0) return fmix64(key) >> t.shift;
-        const uint32_t hm = hmin ? *hmin : sk_hmin_of_kmer(key, t.mm_k);
+        const uint32_t hm = have_hmin ? hmin : sk_hmin_of_kmer(key, t.mm_k);
         return ((((uint64_t)sk_bin(hm) * t.n_regions) >> 32) << MC_REGION_LG) | sk_home(key);
     }
     uint32_t hm = 0;
-    if (t.owner_mm_k) hm = hmin ? *hmin : sk_hmin_of_kmer(key, t.owner_mm_k);
-    shard_into(h, t, t.owner_mm_k ? sk_owner(hm, t.n_shards) : owner_of(key, t.n_shards));
+    if (t.owner_mm_k) hm = have_hmin ? hmin : sk_hmin_of_kmer(key, t.owner_mm_k);
+    h = shard_table(t, t.owner_mm_k ? sk_owner(hm, t.n_shards) : owner_of(key, t.n_shards));
     if (h.mm_k == 0) return fmix64(key) >> h.shift;
     if (!t.owner_mm_k) hm = sk_hmin_of_kmer(key, h.mm_k);
     return ((((uint64_t)sk_bin(hm) * h.n_regions) >> 32) << MC_REGION_LG) | sk_home(key);
@@ -576,7 +584,7 @@ __device__ __forceinline__ uint64_t solid_locate(const SolidView &t, uint64_t ke
 // dependent chain, and the lanes of a wave look different keys up -- the longest sequence among them decides, one round
 // trip per step (a table a little fuller than planned made the walk twice as long when this went slot by slot).
 // count (saturated) or -1; *aux (may be null) = the slot's read pointer; n_done = slots the caller has looked at already.
-__device__ __forceinline__ int solid_probe_from(const SolidView &t, uint64_t key, uint64_t s, uint32_t n_done, uint32_t *aux)
+__device__ __forceinline__ int solid_probe_from(const TableRef &t, uint64_t key, uint64_t s, uint32_t n_done, uint32_t *aux)
 {
     uint64_t base = s & ~(uint64_t)t.rmask;
     const uint64_t n_regions = t.n_regions ? (uint64_t)t.n_regions : ((1ull << (64 - t.shift)) / ((uint64_t)t.rmask + 1));
@@ -614,12 +622,9 @@ __device__ __forceinline__ int solid_get(const SolidView &t, uint64_t key, uint3
         const unsigned long long c = t.n_shards > 1 ? t.shards[owner_of(key, t.n_shards)].empty : *t.empty_cnt;  // (hash modes only: dealt by the key's hash)
         return c == 0 ? -1 : (c > 32767ull ? 32767 : (int)c);
     }
-    if (t.n_shards > 1) {  // (the owner's table)
-        SolidView h;
-        const uint64_t s0 = solid_locate(t, key, h);
-        return solid_probe_from(h, key, s0, 0, aux);
-    }
-    return solid_probe_from(t, key, solid_slot_of(t, key), 0, aux);
+    TableRef h;  // (several GPUs: the owner's table)
+    const uint64_t s0 = solid_locate(t, key, h);
+    return solid_probe_from(h, key, s0, 0, aux);
 }
 
 // sum over the wave, one atomic per wave.  Every lane of the wave must call it (convergent).

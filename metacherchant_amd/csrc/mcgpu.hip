@@ -3818,19 +3818,22 @@ void launch_bfs(mc_ctx *c, hipStream_t stream, const BfsState *d_states, uint32_
 {
     const SolidView t = c->solid_view();
     if (companions) n_jobs *= 2;
+    // (SH: the walk over several ranks' tables, every look-up through its key's owner; the one-table kernel carries none of that)
+#define BFS_LAUNCH(MODE)                                                                                                          \
+    do {                                                                                                                          \
+        if (t.n_shards > 1)                                                                                                       \
+            hipLaunchKernelGGL((k_bfs<MODE, true>), dim3(n_jobs), dim3(BFS_THREADS), 0, stream, d_states, t, c->cfg.k, min_cov,    \
+                               (long long)max_kmers, (long long)max_radius, max_rounds, companions);                              \
+        else                                                                                                                      \
+            hipLaunchKernelGGL((k_bfs<MODE, false>), dim3(n_jobs), dim3(BFS_THREADS), 0, stream, d_states, t, c->cfg.k, min_cov,   \
+                               (long long)max_kmers, (long long)max_radius, max_rounds, companions);                              \
+    } while (0)
     switch (c->cfg.key_mode) {
-    case MC_KEY_PACKED:
-        hipLaunchKernelGGL(k_bfs<KEY_PACKED>, dim3(n_jobs), dim3(BFS_THREADS), 0, stream, d_states, t, c->cfg.k,
-                           min_cov, (long long)max_kmers, (long long)max_radius, max_rounds, companions);
-        break;
-    case MC_KEY_POLY:
-        hipLaunchKernelGGL(k_bfs<KEY_POLY>, dim3(n_jobs), dim3(BFS_THREADS), 0, stream, d_states, t, c->cfg.k,
-                           min_cov, (long long)max_kmers, (long long)max_radius, max_rounds, companions);
-        break;
-    default:
-        hipLaunchKernelGGL(k_bfs<KEY_FNV1A>, dim3(n_jobs), dim3(BFS_THREADS), 0, stream, d_states, t, c->cfg.k,
-                           min_cov, (long long)max_kmers, (long long)max_radius, max_rounds, companions);
+    case MC_KEY_PACKED: BFS_LAUNCH(KEY_PACKED); break;
+    case MC_KEY_POLY: BFS_LAUNCH(KEY_POLY); break;
+    default: BFS_LAUNCH(KEY_FNV1A);
     }
+#undef BFS_LAUNCH
 }
 
 }  // namespace

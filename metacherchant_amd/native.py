@@ -135,9 +135,10 @@ def load():
     L.mc_trim.argtypes = [vp]
     L.mc_synth_reads_dev.argtypes = [vp, u64, u64, u64, u64, u64, u64, C.c_uint32, C.c_uint32, vp, vp]
     L.mc_synth_genome.argtypes = [u64, u64, u64, C.POINTER(C.c_uint8)]
-    L.mc_shard_export.argtypes = [vp, C.c_char_p]
-    L.mc_shard_attach.argtypes = [vp, C.c_char_p, C.c_uint32, C.c_uint32, i32]
-    L.mc_shard_detach.argtypes = [vp]
+    if hasattr(L, "mc_shard_export"):  # (a tuning build of an older revision, MC_LIB: scripts/gpu_variants.sh)
+        L.mc_shard_export.argtypes = [vp, C.c_char_p]
+        L.mc_shard_attach.argtypes = [vp, C.c_char_p, C.c_uint32, C.c_uint32, i32]
+        L.mc_shard_detach.argtypes = [vp]
     _LIB = L
     return L
 

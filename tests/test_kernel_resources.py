@@ -1,0 +1,41 @@
+"""The hot kernels' compiled resources, read from the code object inside libmcgpu.so (no GPU needed).  A kernel of the walk that
+touches scratch memory is a regression: in round 4 one out-of-line call (a function taking the walk's state by reference) put the
+kernel arguments into scratch for the whole of k_bfs, every t.slots / t.reads became a scratch load, and the walk went from 9.4
+to 10.7 ms before anyone looked at `private_segment_fixed_size`."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def _kernel_notes(tmp_path):
+    from metacherchant_amd import build
+    lib = build.build_lib()
+    tools = [os.path.join(LLVM, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")]
+    if not all(os.path.exists(t) for t in tools):
+        pytest.skip("ROCm's llvm tools are not here")
+    fat, co = str(tmp_path / "fatbin"), str(tmp_path / "k.co")
+    subprocess.check_call([tools[0], "--dump-section", ".hip_fatbin=" + fat, lib, str(tmp_path / "stripped.so")])
+    subprocess.check_call([tools[1], "--unbundle", "--type=o", "--input=" + fat, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+    text = subprocess.check_output([tools[2], "--notes", co], text=True)
+    kernels = {}
+    for block in text.split("- .agpr_count")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block).group(1)
+        kernels[name] = {k: int(v) for k, v in re.findall(r"\.(private_segment_fixed_size|vgpr_count|group_segment_fixed_size|vgpr_spill_count):\s+(\d+)", block)}
+    return kernels
+
+
+def test_the_walk_and_the_merge_kernel_use_no_scratch_memory(tmp_path):
+    kernels = _kernel_notes(tmp_path)
+    walk = {n: r for n, r in kernels.items() if "k_bfsILi" in n}
+    assert len(walk) == 6  # three key modes x (one table, several ranks' tables)
+    for name, r in list(walk.items()) + [(n, r) for n, r in kernels.items() if "k_p3_dedup" in n or "k_sk1w_extract" in n]:
+        assert r["private_segment_fixed_size"] == 0 and r["vgpr_spill_count"] == 0, (name, r)
+    # the merge kernel's two workgroups a CU: 2 x 81.8 KB of the CU's 160 KB of LDS, and at most 128 registers for 4 waves a SIMD
+    for name, r in kernels.items():
+        if "k_p3_dedup" in name:
+            assert 2 * r["group_segment_fixed_size"] <= 160 * 1024 and r["vgpr_count"] <= 128, (name, r)
