@@ -614,7 +614,6 @@ __global__ void __launch_bounds__(P1W_THREADS, MC_P1W_MIN_WAVES) k_sk1w_extract(
     __syncthreads();
     const int w = k - SK_M + 1;                       // SK_M-mers per window (9 .. 17)
     const uint64_t last_word = (n_bases + 31) / 32;   // the pad word
-    const uint32_t kmask1 = (1u << (k - 1)) - 1u;     // k - 1 <= 30 positions after a window's first base
     const uint64_t seg_base = (uint64_t)blockIdx.x * cap, bucket_stride = (uint64_t)gridDim.x * cap;
     const uint64_t wave_id = (uint64_t)blockIdx.x * P1W_WAVES + wv, n_waves = (uint64_t)gridDim.x * P1W_WAVES;
 
@@ -718,12 +717,19 @@ __global__ void __launch_bounds__(P1W_THREADS, MC_P1W_MIN_WAVES) k_sk1w_extract(
         // ---- which of my positions start a window, and where runs of equal minimizers break
         uint32_t valid_bits = 0;
         if (lane < 62 && p0 + (uint64_t)k <= n_bases) {
+            // the window [p, p+k) lies inside one read iff no read starts at p+1 .. p+k-1: bit j of S = OR of the read-start bits
+            // of p0 + j + 1 .. p0 + j + k - 1, for all eight windows at once (doubling shifts; round 3 tested the eight apart,
+            // each behind 64-bit range checks: 90 instructions for what takes 30)
+            uint64_t S = ((((uint64_t)ws[1]) << 32) | ws[0]) >> 9;  // bit b <-> a read starts at p0 + 1 + b
+            uint32_t width = 1;
+            for (; 2 * width <= (uint32_t)k - 1; width *= 2) S |= S >> width;  // (uniform: k - 1 is 22 .. 30, four rounds)
+            S |= S >> ((uint32_t)k - 1 - width);
             const uint64_t jmax = n_bases - (uint64_t)k - p0;  // last j with p0 + j + k <= n_bases
-#pragma unroll
-            for (int j = 0; j < PT_ITEMS; j++)  // the window [p, p+k) lies inside one read iff no read starts at p+1 .. p+k-1
-                if ((uint64_t)j <= jmax && p0 + (uint64_t)j >= base_lo && (__builtin_amdgcn_alignbit(ws[1], ws[0], 9 + j) & kmask1) == 0)
-                    valid_bits |= 1u << j;
+            const uint32_t jm = jmax < 7 ? (uint32_t)jmax : 7u;
+            const uint32_t j0 = p0 >= base_lo ? 0u : (base_lo - p0 < 8 ? (uint32_t)(base_lo - p0) : 8u);  // first j with p0 + j >= base_lo
+            valid_bits = ~(uint32_t)S & ((2u << jm) - 1u) & ~((1u << j0) - 1u) & 0xFFu;
         }
+        uint32_t brk_bits = 0;  // bit j: my window j breaks the run of equal minimizers (or is no window)
         {
             const uint32_t last = (valid_bits >> (PT_ITEMS - 1)) & 1u ? hmin[PT_ITEMS - 1] : SK_NONE;
             uint32_t prev = __shfl_up(last, 1);
@@ -736,27 +742,30 @@ __global__ void __launch_bounds__(P1W_THREADS, MC_P1W_MIN_WAVES) k_sk1w_extract(
                 prev = v ? hmin[j] : SK_NONE;
             }
             brkb[2 + lane] = (uint8_t)bits;  // window i of the tile <-> bit 16 + i of the wave's break bitmap
+            brk_bits = bits;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        uint64_t bw;  // bit b <-> window lane*8 - 16 + b
-        {
-            const uint32_t wd = lane >> 2, sh = 8 * (lane & 3);
-            const uint32_t d0 = brkw[wd], d1 = brkw[wd + 1], d2 = brkw[wd + 2];
-            bw = ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32) | __builtin_amdgcn_alignbit(d1, d0, sh);
-        }
+        // A window starts a record when it breaks the run of equal minimizers or sits a multiple of SK_MAX_WINDOWS behind the
+        // run's first window.  Where did the run start?  The last lane below mine that holds a break is a ballot and a count of
+        // leading zeros away, its break bits one cross-lane read; from there the run start is carried along my 8 windows.
+        // (Round 3 looked the start up in the wave's bitmap only for windows of runs of 16 and more -- a branch with a loop over
+        // LDS words in it, for each of the 8 windows apart.  One window in seven is that deep in its run, so every one of the
+        // eight branches ran in nearly every tile with a handful of lanes in it: 330 of the kernel's 556 vector instructions
+        // per tile.)
         uint32_t start_bits = 0;
+        {
+            const unsigned long long holders = __ballot(brk_bits != 0);  // (lane 0 is one: a tile always starts a run)
+            const unsigned long long below = holders & ((1ull << lane) - 1ull);
+            const uint32_t P = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
+            const uint32_t bp = (uint32_t)__shfl((int)brk_bits, (int)P);
+            uint32_t cur = P * PT_ITEMS + (31u - (uint32_t)__builtin_clz(bp | 1u));  // tile window of the last break before my first one (lane 0: unused)
 #pragma unroll
-        for (int j = 0; j < PT_ITEMS; j++) {
-            if (!((valid_bits >> j) & 1u)) continue;
-            if ((bw >> (16 + j)) & 1ull) { start_bits |= 1u << j; continue; }           // first window of its run
-            if ((bw >> (1 + j)) & 0x7FFFull) continue;                                   // the run started < 16 windows ago
-            const uint32_t i = 16 + lane * PT_ITEMS + j;                                 // a run of 16 or more: find its start
-            uint32_t wd = i >> 5;
-            uint32_t x = brkw[wd] & ((2u << (i & 31)) - 1u);
-            while (x == 0) x = brkw[--wd];  // (window 0 of the tile always breaks)
-            const uint32_t run_start = wd * 32 + 31 - (uint32_t)__builtin_clz(x);
-            if ((i - run_start) % SK_MAX_WINDOWS == 0) start_bits |= 1u << j;
+            for (int j = 0; j < PT_ITEMS; j++) {
+                const uint32_t pos = lane * PT_ITEMS + (uint32_t)j;
+                cur = (brk_bits >> j) & 1u ? pos : cur;
+                if (((valid_bits >> j) & 1u) && ((pos - cur) % SK_MAX_WINDOWS) == 0) start_bits |= 1u << j;
+            }
         }
 
         // ---- records: a run is cut every SK_MAX_WINDOWS windows, counted from its first window
@@ -822,6 +831,12 @@ __global__ void __launch_bounds__(P1W_THREADS, MC_P1W_MIN_WAVES) k_sk1w_extract(
             __builtin_amdgcn_wave_barrier();  // (the next tile rewrites the staging area)
         }
 #else
+        uint64_t bw;  // bit b <-> window lane*8 - 16 + b
+        {
+            const uint32_t wd = lane >> 2, sh = 8 * (lane & 3);
+            const uint32_t d0 = brkw[wd], d1 = brkw[wd + 1], d2 = brkw[wd + 2];
+            bw = ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32) | __builtin_amdgcn_alignbit(d1, d0, sh);
+        }
         for (uint32_t todo = start_bits; todo; todo &= todo - 1) {
             const uint32_t j = (uint32_t)__builtin_ctz(todo);
             const uint32_t ahead = (uint32_t)(bw >> (17 + j)) & 0x7FFFu;  // breaks among the next 15 windows

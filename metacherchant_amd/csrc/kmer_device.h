@@ -329,11 +329,14 @@ constexpr uint32_t SK_MMASK = (1u << (2 * SK_M)) - 1;
 constexpr uint32_t SK_NONE = 0xFFFFFFFFu;  // "no window here" in arrays of minimizer hashes
 
 __host__ __device__ __forceinline__ uint32_t sk_order(uint32_t canon_mmer)
-{  // a bijection of 32-bit words: random-looking total order of the SK_M-mers (ties impossible below 2^30)
+{  // a bijection of 32-bit words: random-looking total order of the SK_M-mers (ties impossible below 2^30).  It never gives
+   // SK_NONE for an SK_M-mer: the one word it maps there is 0xCCFF8DF3, and canonical 15-mers are below 2^30 (round 3 tested
+   // every hash against it: two of the thirteen instructions a base position costs the extraction kernel)
     uint32_t x = canon_mmer * 0x9E3779B1u;
     x ^= x >> 15;
-    return x == SK_NONE ? SK_NONE - 1 : x;
+    return x;
 }
+static_assert(SK_M == 15, "sk_order's image of the SK_M-mers must not hold SK_NONE: check again for another SK_M");
 __host__ __device__ __forceinline__ uint32_t sk_bin(uint32_t hmin)
 {  // the minimum of many hashes is small: mix again before taking top bits as a bin number
     uint32_t x = hmin;
