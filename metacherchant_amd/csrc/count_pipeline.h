@@ -298,11 +298,38 @@ __global__ void __launch_bounds__(PT_THREADS) k_p1_extract_scatter(
             // of 64-bit integers (and 5^k + sum (3 - b_i) 5^i for the other strand), so sliding the window by one
             // base is a handful of operations instead of 2k multiply-adds, with the same value bit for bit
             uint64_t hf = 1, hr = 1;
-            if (MODE == KEY_POLY) poly_hashes_tabled(v, k, L.polyF, L.polyR, &hf, &hr);
+            // Polynomial keys, a thread whose eight windows all lie inside the data (all but the last tile's): the forward
+            // hashes roll left to right, the reverse-strand ones RIGHT TO LEFT -- that way both rolls are "times 5, plus the
+            // base that comes in, minus (4 + the base that goes out) x 5^k", a few shifts, adds and selects.  (Round 3 rolled
+            // both left to right: the reverse hash then loses its LOWEST term and must be divided by 5 -- a 64-bit
+            // multiplication by 5^-1 -- and both strands multiplied a base by 5^k or 5^(k-1): three 64-bit multiplications a
+            // window at a quarter of the vector unit's rate, ~300 cycles, more than everything else a window costs here.)
+            const bool poly_fast = MODE == KEY_POLY && p0 + (uint64_t)(PT_ITEMS - 1) + (uint64_t)k <= n_bases;
+            uint64_t hr8[PT_ITEMS];
+            uint32_t ob8 = 0, ib8 = 0;  // the windows' first bases / the bases behind them, 2 bits each, window 0 on top of 16 bits
+            if (poly_fast) {
+                // p0 is a multiple of 8: the eight bases from p0 (and from p0 + k) sit in at most two words
+                const uint64_t qo = p0, qi = p0 + (uint64_t)k, last_w = (n_bases + 31) / 32;
+                const uint64_t wo = words[qo >> 5];
+                ob8 = (uint32_t)(wo >> (48 - 2 * (qo & 31))) & 0xFFFFu;  // (qo & 31 <= 24)
+                const uint64_t wi0 = words[qi >> 5], wi1 = words[min((qi >> 5) + 1, last_w)];
+                const uint32_t sh = 2 * (uint32_t)(qi & 31);
+                ib8 = (uint32_t)((sh ? ((wi0 << sh) | (wi1 >> (64 - sh))) : wi0) >> 48);
+                hf = poly_hash_f_tabled(v, k, L.polyF);
+                hr8[PT_ITEMS - 1] = poly_hash_r_tabled(extract_kmer(words, p0 + PT_ITEMS - 1, k), k, L.polyR);
+#pragma unroll
+                for (int j = PT_ITEMS - 2; j >= 0; j--) {
+                    const uint32_t bf = (ob8 >> (14 - 2 * j)) & 3u, inb = (ib8 >> (14 - 2 * j)) & 3u;
+                    hr8[j] = hr8[j + 1] * 5 + (3u - bf) - poly_4x_times(3u - inb, pow5_k);
+                }
+            } else if (MODE == KEY_POLY) {
+                poly_hashes_tabled(v, k, L.polyF, L.polyR, &hf, &hr);
+            }
 #pragma unroll
             for (int j = 0; j < PT_ITEMS; j++) {
                 const uint64_t p = p0 + (uint64_t)j;
                 if (p + (uint64_t)k > n_bases) break;
+                if (poly_fast) hr = hr8[j];
                 const uint32_t b = 8 + (uint32_t)j;
                 // the window [p, p+k) lies inside one read iff no read starts at p+1 .. p+k-1
                 if (p >= base_lo && bits128(w_lo, w_hi, b + 1, (uint32_t)(k - 1)) == 0) {
@@ -330,6 +357,10 @@ __global__ void __launch_bounds__(PT_THREADS) k_p1_extract_scatter(
                     }
                 }
                 // roll to p + 1: the window takes the first base after it, loses its first base
+                if (poly_fast) {
+                    if (j + 1 < PT_ITEMS) hf = hf * 5 + ((ib8 >> (14 - 2 * j)) & 3u) - poly_4x_times((ob8 >> (14 - 2 * j)) & 3u, pow5_k);
+                    continue;
+                }
                 const uint32_t in = base_or0(words, p + (uint64_t)k, n_bases), out = base_at(v, k, 0);
                 if (MODE == KEY_PACKED) {
                     v.lo = ((v.lo << 2) | in) & kmask;

@@ -122,6 +122,49 @@ __host__ __device__ inline void poly_hashes_tabled(const Kmer &v, int k, const u
     *hr_out = hr;
 }
 
+// one strand each (the extraction kernel starts its forward hashes at a thread's first window and its reverse ones at its last)
+__host__ __device__ inline uint64_t poly_hash_f_tabled(const Kmer &v, int k, const uint16_t *polyF)
+{
+    uint64_t t_hi, t_lo;
+    if (k <= 32) { t_hi = v.lo << (64 - 2 * k); t_lo = 0; }
+    else { t_hi = (v.hi << (128 - 2 * k)) | (v.lo >> (2 * k - 64)); t_lo = v.lo << (128 - 2 * k); }
+    uint64_t hf = 1;
+    const int n4 = k >> 2;
+    for (int i = 0; i < n4; i++) {
+        hf = hf * 625 + polyF[t_hi >> 56];
+        t_hi = (t_hi << 8) | (t_lo >> 56);
+        t_lo <<= 8;
+    }
+    for (int i = n4 * 4; i < k; i++) {
+        hf = hf * 5 + (t_hi >> 62);
+        t_hi = (t_hi << 2) | (t_lo >> 62);
+        t_lo <<= 2;
+    }
+    return hf;
+}
+__host__ __device__ inline uint64_t poly_hash_r_tabled(const Kmer &v, int k, const uint16_t *polyR)
+{
+    uint64_t b_hi = k <= 32 ? 0 : v.hi, b_lo = v.lo;
+    uint64_t hr = 1;
+    const int n4 = k >> 2;
+    for (int i = 0; i < n4; i++) {
+        hr = hr * 625 + polyR[b_lo & 0xFF];
+        b_lo = (b_lo >> 8) | (b_hi << 56);
+        b_hi >>= 8;
+    }
+    for (int i = n4 * 4; i < k; i++) {
+        hr = hr * 5 + (3u ^ (uint32_t)(b_lo & 3));
+        b_lo = (b_lo >> 2) | (b_hi << 62);
+        b_hi >>= 2;
+    }
+    return hr;
+}
+// (4 + x) * p for x = 0 .. 3 without a multiplication (p = 5^k: what a rolling step of either strand's hash takes away)
+__host__ __device__ __forceinline__ uint64_t poly_4x_times(uint32_t x, uint64_t p)
+{
+    return 4 * p + ((x & 1u) ? p : 0ull) + ((x & 2u) ? 2 * p : 0ull);
+}
+
 // src/utils/FNV1AHash.java:8-9,33-42
 __host__ __device__ inline int64_t key_fnv1a(const Kmer &v, int k, bool *flipped = nullptr)
 {
