@@ -136,17 +136,22 @@ def main():
         info["distinct"] = sc.finalize()  # (waits for the counting to end)
         info["count_wall_s"] = info.get("count_wall_s", 0.0) + (time.perf_counter() - t_c)
         bctx = ctx
-        if world > 1 and walk_in_place:
-            sc.attach_shards(dst=0)
+        in_place = world > 1 and walk_in_place and sc.attach_shards(dst=0)
+        if world > 1 and walk_in_place and not in_place and "walk_fallback" not in info:
+            info["walk_fallback"] = sc.attach_error  # (rank 0 could not map the other ranks' tables: the gather of round 3 instead)
+            if rank == 0:
+                info["solid_ctx"] = m.Context(k, mode, local_rank, 1 << 20)
+        if in_place:
             if "solid" not in info:  # (reported once: every shard's number of k-mers at or above --coverage, from the counter the merge kernel keeps)
                 nt = torch.tensor([ctx.export_count(args.coverage)], dtype=torch.int64, device=dev)
                 dist.all_reduce(nt)
                 info["solid"] = int(nt.item())
         elif world > 1:
-            if solid is not None:
-                solid.clear()
-            info["solid"] = sc.gather_solid(solid, args.coverage, dst=0)
-            bctx = solid
+            sctx = solid if solid is not None else info.get("solid_ctx")
+            if sctx is not None:
+                sctx.clear()
+            info["solid"] = sc.gather_solid(sctx, args.coverage, dst=0)
+            bctx = sctx
         if rank == 0:
             bfs_ms, reached, levels, lookups = 0.0, 0, 0, 0
             # buildEnvironment with bothdirs=False: runBfs(-1), runBfs(+1) -- independent passes, one launch
@@ -162,7 +167,7 @@ def main():
                 lookups += r["lookups"]
             bfs_ms = res[0]["device_ms"]
             info.update(bfs_ms=bfs_ms, reached=reached, levels=levels, lookups=lookups)
-        if world > 1 and walk_in_place:
+        if in_place:
             sc.walk_done(dst=0)  # (the other ranks' tables were being read: nobody clears before rank 0 has let go)
 
     def sync():
@@ -311,7 +316,8 @@ def main():
                               "how": "fresh context (64 MB table) per step; table sized from the first level-1 bucket of the batch; table memory recycled inside the process"}
         if world > 1:
             out["solid_kmers"] = info.get("solid")
-            out["walk"] = "rank 0 reads every rank's counting table in place (mc_shard_attach)" if walk_in_place else "solid k-mers gathered into a BFS-only context on rank 0"
+            out["walk"] = ("rank 0 reads every rank's counting table in place (mc_shard_attach)" if walk_in_place and "walk_fallback" not in info
+                           else "solid k-mers gathered into a BFS-only context on rank 0" + (" (the tables could not be mapped: %s)" % info["walk_fallback"] if "walk_fallback" in info else ""))
             out["alltoall_bytes_sent_rank0_per_step"] = sc.bytes_sent // (args.steps + args.warmup)
     if world > 1:
         dist.barrier()

@@ -503,9 +503,10 @@ __device__ __forceinline__ uint32_t replay_slow(const BfsState &S, NarrowLds &L,
 }
 
 // lookup with the first two probe slots already loaded; *aux = the read pointer stored with the key (0 when absent)
-__device__ __forceinline__ int solid_get2(const SolidView &tv, const TableRef &t, uint64_t key, uint64_t s0, const uint4 &a0, const uint4 &a1,
+__device__ __forceinline__ int solid_get2(const SolidView &tv, const TableRef &t, uint64_t key, uint64_t s0, uint4 a0, uint4 a1,
                                           uint32_t *aux)
 {   // t: the table the key lives in (kmer_device.h solid_locate), s0 its home slot there; tv: the walk's view (the out-of-band key)
+    slots_wanted(a0, a1);  // (every word of both slots is used from here on: the loads stay whole, see there)
     *aux = 0;
     if (key == EMPTY_KEY) return solid_get(tv, key);
     const uint64_t k0 = ((uint64_t)a0.y << 32) | a0.x;
@@ -569,6 +570,8 @@ __device__ __forceinline__ int solid_get4(const SolidView &tv, const TableRef &t
     uint4 a[NP];
 #pragma unroll
     for (int i = 0; i < NP; i++) a[i] = *reinterpret_cast<const uint4 *>(t.slots + (base | ((s0 + i) & t.rmask)));
+    if (NP == 4) slots_wanted(a[0], a[1], a[NP > 2 ? 2 : 0], a[NP > 3 ? 3 : 0]);  // (kmer_device.h: one round trip, as written)
+    else if (NP == 2) slots_wanted(a[0], a[1]);
 #pragma unroll
     for (int i = 0; i < NP; i++) {
         const uint64_t cur = ((uint64_t)a[i].y << 32) | a[i].x;

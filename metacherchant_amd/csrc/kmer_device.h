@@ -630,6 +630,24 @@ __device__ __forceinline__ uint64_t solid_locate(const SolidView &t, uint64_t ke
 // dependent chain, and the lanes of a wave look different keys up -- the longest sequence among them decides, one round
 // trip per step (a table a little fuller than planned made the walk twice as long when this went slot by slot).
 // count (saturated) or -1; *aux (may be null) = the slot's read pointer; n_done = slots the caller has looked at already.
+// Probe slots that were requested together are wanted together, whole.  Left to itself the compiler (read in the code object of
+// k_bfs, round 4) fetches a slot's key alone and its count and read pointer in a SECOND, dependent load for the lanes whose key
+// matched, and sinks each further slot's load below the test that ends the loop at the slot before it: a lookup that the source
+// shows as one round trip made two to five.  An empty asm that names every word pins the loads where they are written.
+__device__ __forceinline__ void slots_wanted([[maybe_unused]] uint4 &a, [[maybe_unused]] uint4 &b)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MC_NO_SLOTS_WANTED)
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
+#endif
+}
+__device__ __forceinline__ void slots_wanted([[maybe_unused]] uint4 &a, [[maybe_unused]] uint4 &b, [[maybe_unused]] uint4 &c, [[maybe_unused]] uint4 &d)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MC_NO_SLOTS_WANTED)
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w),
+                      "+v"(c.x), "+v"(c.y), "+v"(c.z), "+v"(c.w), "+v"(d.x), "+v"(d.y), "+v"(d.z), "+v"(d.w));
+#endif
+}
+
 __device__ __forceinline__ int solid_probe_from(const TableRef &t, uint64_t key, uint64_t s, uint32_t n_done, uint32_t *aux)
 {
     uint64_t base = s & ~(uint64_t)t.rmask;
@@ -641,6 +659,7 @@ __device__ __forceinline__ int solid_probe_from(const TableRef &t, uint64_t key,
             uint4 a[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) a[i] = *reinterpret_cast<const uint4 *>(t.slots + (base | ((s + i) & t.rmask)));
+            slots_wanted(a[0], a[1], a[2], a[3]);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 if (probe + (uint32_t)i >= max_probes) break;  // (a free slot BEHIND the stretch says nothing: the key may have moved on)

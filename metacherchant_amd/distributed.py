@@ -30,6 +30,8 @@ class ShardedCounter:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.bytes_sent = 0
+        self.attach_ok = None    # attach_shards: could the walking rank map the other ranks' tables (None: not tried yet)
+        self.attach_error = ""
         self.n_chunks = 0
         self.by_minimizer = False
         # Read pointers (include/mcgpu.h mc_set_read_pointers): the BFS rank walks with look-ahead read from ITS OWN
@@ -190,21 +192,35 @@ class ShardedCounter:
         IPC handle of its memory), one all-gather brings the descriptions to everybody, and rank `dst` maps the other ranks'
         tables: its bfs / bfs_batch then look every k-mer up in its owner's table over xGMI.  Nothing is exported, copied or
         rebuilt (gather_solid: 0.4 + ~14 + 3.2 ms at 8 x configs[1], and a copy that does not fit at configs[3]'s size).  The
-        other ranks must leave their tables alone until walk_done()."""
+        other ranks must leave their tables alone until walk_done().  Returns False -- on every rank alike -- when `dst` cannot map
+        them (attach_error says why): the caller then gathers the solid k-mers (gather_solid)."""
         ctx, W = self.ctx, self.world
         if W == 1:
-            return
+            return True
+        if self.attach_ok is False:
+            return False
         mine = torch.frombuffer(bytearray(ctx.shard_export()), dtype=torch.uint8).to(self.device)
         allh = torch.empty(W * mine.numel(), dtype=torch.uint8, device=self.device)
         dist.all_gather_into_tensor(allh, mine, group=self.group)
+        ok = 1
         if self.rank == dst:
             raw = allh.cpu().numpy().tobytes()
             n = mine.numel()
-            ctx.shard_attach([raw[i * n:(i + 1) * n] for i in range(W)], self.rank, self.by_minimizer)
+            try:
+                ctx.shard_attach([raw[i * n:(i + 1) * n] for i in range(W)], self.rank, self.by_minimizer)
+            except Exception as e:  # (no peer mapping between these devices / processes: the caller gathers the solid k-mers instead)
+                if self.attach_ok:  # it worked before: this is not the machine's answer but a fault
+                    raise
+                ok, self.attach_error = 0, str(e)
+        if self.attach_ok is None:  # the first walk: every rank learns whether `dst` could map the tables (later walks take that as read)
+            flag = torch.tensor([ok], dtype=torch.int64, device=self.device)
+            dist.broadcast(flag, src=dst, group=self.group)
+            self.attach_ok = bool(int(flag.item()))
+        return self.attach_ok
 
     def walk_done(self, dst=0):
         """behind the walk: rank `dst` gives the mappings up, and nobody touches its table before that"""
-        if self.world == 1:
+        if self.world == 1 or not self.attach_ok:
             return
         if self.rank == dst:
             self.ctx.shard_detach()

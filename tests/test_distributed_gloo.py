@@ -141,6 +141,41 @@ def _worker(rank, world, port, k, mode, reads, L, n_reads, min_cov, q, records=F
         dist.destroy_process_group()
 
 
+def _attach_worker(rank, world, port, fails, q):
+    # ShardedCounter.attach_shards on two ranks: rank 0 maps (or cannot map) rank 1's table, and BOTH ranks learn which
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from metacherchant_amd.distributed import ShardedCounter
+
+        class Ctx(OracleBackedContext):
+            attached = None
+
+            def shard_export(self):
+                return bytes([self.rank]) * 128
+
+            def shard_attach(self, handles, own, by_minimizer):
+                if fails:
+                    raise RuntimeError("GPU 0 cannot read GPU 1's memory (no peer access)")
+                self.attached = [h[0] for h in handles]
+
+            def shard_detach(self):
+                self.attached = None
+
+        ctx = Ctx(31, 0, True, rank)
+        sc = ShardedCounter(ctx, torch.device("cpu"))
+        got = []
+        for _ in range(2):  # (the second walk takes the first one's answer as read: no further broadcast)
+            ok = sc.attach_shards(dst=0)
+            got.append((ok, ctx.attached))
+            sc.walk_done(dst=0)
+        q.put((rank, got, sc.attach_error))
+    finally:
+        dist.destroy_process_group()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -192,3 +227,22 @@ def test_split_reads_covers_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+@pytest.mark.parametrize("fails", [False, True])
+def test_attach_shards_tells_every_rank_whether_the_tables_could_be_mapped(fails):
+    # (a rank 0 that cannot map the other tables must not leave the others waiting at walk_done: bench.py then gathers instead)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_attach_worker, args=(r, 2, port, fails, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict((r, (got, err)) for r, got, err in (q.get(timeout=120) for _ in range(2)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        assert [ok for ok, _ in res[r][0]] == [not fails, not fails]
+    assert res[0][0][0][1] == (None if fails else [0, 1])  # rank 0 held both tables during the walk
+    assert ("no peer access" in res[0][1]) == fails
