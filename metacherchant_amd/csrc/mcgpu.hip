@@ -690,8 +690,18 @@ __global__ void k_reads_summary(const uint64_t *__restrict__ offsets, uint64_t n
             else if (c2 - b >= k) w += c2 - b - k + 1;
         }
     }
-    wave_add_ull(out, w);
-    wave_add_ull(out + 1, bad);
+    // one pair of atomics a WORKGROUP, at most 512 of them: atomics on one address take their turns at ~7 ns each, and a pair per
+    // wave of 2048 workgroups (16 000 of them) was 120 us for 10 M reads -- four times what reading the offsets takes
+    __shared__ unsigned long long part[2][4];
+    for (int o = 32; o > 0; o >>= 1) { w += __shfl_down(w, o); bad += __shfl_down(bad, o); }
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = w; part[1][threadIdx.x >> 6] = bad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long tw = 0, tb = 0;
+        for (unsigned i = 0; i < (blockDim.x + 63) / 64 && i < 4; i++) { tw += part[0][i]; tb += part[1][i]; }
+        if (tw) atomicAdd(out, tw);
+        if (tb) atomicAdd(out + 1, tb);
+    }
     if (ends && blockIdx.x == 0 && threadIdx.x == 0) { out[2] = offsets[0]; out[3] = offsets[n_reads]; }
 }
 
@@ -2401,7 +2411,7 @@ static int add_reads_dev_counted(mc_ctx *c, const uint64_t *d_words, const uint6
     unsigned long long *sum = c->d_ctr + 4;
     unsigned long long *sum4 = c->d_ctr + 10;  // windows, violations, first offset, last offset: one copy
     HIPCHK(c, hipMemsetAsync(sum4, 0, 2 * sizeof(unsigned long long), c->stream));
-    hipLaunchKernelGGL(k_reads_summary, dim3(grid_for((n_reads + 1) / 2, 256)), dim3(256), 0, c->stream, d_off, n_reads,
+    hipLaunchKernelGGL(k_reads_summary, dim3(grid_for((n_reads + 1) / 2, 256, 512)), dim3(256), 0, c->stream, d_off, n_reads,
                        (uint64_t)c->cfg.k, sum4, 1);
     HIPCHK(c, hipGetLastError());
     unsigned long long *hs = c->h_scratch + 20;
@@ -2456,7 +2466,7 @@ static int add_reads_dev_counted(mc_ctx *c, const uint64_t *d_words, const uint6
             }
             if (r1 <= r) return fail(c, MC_EINVAL, "a single read of more than %llu bases is not supported", (unsigned long long)max_bases);
             HIPCHK(c, hipMemsetAsync(sum, 0, 2 * sizeof(unsigned long long), c->stream));
-            hipLaunchKernelGGL(k_reads_summary, dim3(grid_for(r1 - r, 256)), dim3(256), 0, c->stream, d_off + r, r1 - r, (uint64_t)c->cfg.k, sum);
+            hipLaunchKernelGGL(k_reads_summary, dim3(grid_for(r1 - r, 256, 512)), dim3(256), 0, c->stream, d_off + r, r1 - r, (uint64_t)c->cfg.k, sum);
             HIPCHK(c, hipGetLastError());
             unsigned long long wb = 0;
             HIPCHK(c, hipMemcpyAsync(&wb, sum, sizeof wb, hipMemcpyDeviceToHost, c->stream));
