@@ -61,6 +61,20 @@ constexpr uint32_t SCOUT_BACK = 192;                  // bases in front of a poi
 #ifndef MC_SCOUT_OPTIMISTIC
 #define MC_SCOUT_OPTIMISTIC 0   // 1: a scout's lookup that finds neither its key nor a free slot among those takes the vertex for solid
 #endif
+#ifndef MC_CONS_PAIRS
+#define MC_CONS_PAIRS 0   // scout_cons: 1 = the longest agreement of any PAIR of candidate reads is the hop; 0 = a vote a level among all of them
+#endif
+#ifndef MC_SCOUT_CONSENSUS
+#define MC_SCOUT_CONSENSUS 1   // the companion's hops take the path from the CONSENSUS of up to CONS_N reads and look only the last CONS_TAIL
+                               // vertices up (scout_cons); 0: round 2's hop -- every level of the better of two reads looked up (scout_eval)
+#endif
+constexpr uint32_t CONS_N = 8;       // candidate reads of a consensus hop
+constexpr uint32_t CONS_WORDS = 8;   // read-store words staged per candidate: 256 bases from word (pos - CONS_BACK) / 32 on
+constexpr uint32_t CONS_BACK = 96;   // ... enough for the 64 levels past a tip that sits within CONS_TAIL bases of pos, either way the read runs
+constexpr uint32_t CONS_TAIL = 24;   // levels at the end of a consensus whose vertices are looked up: the tip must be solid, and their read
+                                     // pointers are the next hop's candidates (so a candidate's pointer is < CONS_TAIL levels behind its tip)
+static_assert(CONS_N * CONS_WORDS == 64, "a lane per staged word");
+static_assert(CONS_TAIL + 64 + 31 <= CONS_WORDS * 32 - CONS_BACK - 31 && CONS_TAIL + 64 <= CONS_BACK, "the staged words hold 64 levels either way");
 constexpr int NARROW_CAND = 64;           // candidates per replayed level = lanes of one wave
 constexpr int RH_SIZE = 1024;             // round-local LDS set (narrow, slow replay)
 constexpr int WH_SIZE = 2 * BFS_THREADS;  // chunk-local LDS set (wide)
@@ -953,7 +967,348 @@ struct TeamLds {
     uint32_t mh[BFS_THREADS / 64][SCOUT_MH];
     uint32_t seq, quit, F, budget, stop;
     uint32_t published[SCOUT_MAX_F];  // levels whose path words are known to have arrived
+    // consensus hops (scout_cons): one wave per walker, everything below is that wave's own
+    uint64_t cw[SCOUT_MAX_F][CONS_N * CONS_WORDS];  // the read-store words around the candidates' pointers
+    uint64_t cs[SCOUT_MAX_F][4];                    // the tip's k bases and the levels' bases behind them, 32 bases a word
+    uint64_t cstr[SCOUT_MAX_F][CONS_N][2];          // the 64 bases each candidate holds for the levels past the tip, first on top
+    uint32_t cnp[SCOUT_MAX_F][CONS_N], cnd[SCOUT_MAX_F][CONS_N];  // the next hop's candidates being picked: pointer, levels behind the tip
 };
+
+
+// ---- a consensus hop (round 4) ----------------------------------------------------------------------------------------
+// What bounds a hop of scout_eval is the ERRORS of the one read it follows: at 1 % a read's next 64 k-mers are all right
+// with probability 0.99^64 = 1/2, and the better of two reads gets 48 levels far (scripts/hop_model.py, 47.9 measured) -- for
+// 128 table look-ups and two lone waves' ~600 instructions each.  But a guess needs no look-up: where two reads that hold the
+// tip AGREE on the next base, that base is right (both wrong alike: 10^-4 a level), and which reads hold the tip the store's
+// words tell.  So a hop here takes up to CONS_N candidate reads (the pointers of the last vertices, as before), lines them up at
+// the tip (lane i: candidate i -- its 64 next bases as two words), and lane l votes on level l + 1: the path goes on while at
+// least two reads that are still "alive" agree and no other base has as many votes.  Only the hop's LAST CONS_TAIL vertices are
+// looked up: the new tip must be solid (the path is cut back to the last solid vertex: this is where a consensus that has run
+// out of reads goes wrong), and their read pointers name the next hop's candidates.  With a single usable read (the first hop
+// of a request, thin coverage) every level is looked up, as scout_eval does.
+// One wave per walker, nothing shared with other waves: no workgroup barrier inside a request's hops.
+struct ConsHop {
+    uint32_t m;           // (uniform) levels added; 0: the hop failed
+    int why;              // (uniform) 0 ok, 1 no candidate holds the tip, 2 nothing agreed on / solid behind it
+    uint64_t e_hi, e_lo;  // (uniform) the m new bases, first on top
+    Kmer X;               // (uniform) the new tip, walk strand
+    uint32_t nc;          // (uniform) candidates found for the next hop (lanes < nc hold them)
+    uint32_t used;        // (uniform) reads that held the tip
+};
+
+__device__ __forceinline__ uint64_t cons_first_word(uint64_t pos) { return (pos > CONS_BACK ? pos - CONS_BACK : 0) >> 5; }
+__device__ __forceinline__ uint64_t cons_word_of(const SolidView &t, uint32_t cptr, uint32_t i)
+{   // word i < CONS_WORDS of the piece of the read store a consensus hop stages for the (exact) pointer cptr
+    if (cptr == 0) return 0;
+    const uint64_t pos = (uint64_t)cptr - 1;
+    if (pos >= t.reads_bases) return 0;
+    return t.reads[min(cons_first_word(pos) + i, (t.reads_bases + 31) / 32)];
+}
+
+// the largest and the second largest of four byte counters, and which is the largest (ties: the lower index)
+__device__ __forceinline__ uint32_t cons_top(uint32_t cnt, uint32_t &top, uint32_t &second)
+{
+    const uint32_t c0 = cnt & 255u, c1 = (cnt >> 8) & 255u, c2 = (cnt >> 16) & 255u, c3 = cnt >> 24;
+    const uint32_t m01 = max(c0, c1), n01 = min(c0, c1), m23 = max(c2, c3), n23 = min(c2, c3);
+    const bool hi = m23 > m01;
+    top = hi ? m23 : m01;
+    second = max(hi ? m01 : m23, hi ? n23 : n01);
+    return hi ? (c3 > c2 ? 3u : 2u) : (c1 > c0 ? 1u : 0u);
+}
+
+// lane l holds the base of level l + 1 (`on`: it counts): the 64 bases as two words, first on top -- OR over the rows of 16 lanes
+// (row_shr 1, 2, 4, 8; a row makes half a word)
+__device__ __forceinline__ void cons_pack(uint32_t base, bool on, uint32_t lane, uint64_t &hi, uint64_t &lo)
+{
+    int v = on ? (int)(base << (30u - 2u * (lane & 15u))) : 0;
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
+    hi = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(v, 15) << 32) | (uint32_t)__builtin_amdgcn_readlane(v, 31);
+    lo = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(v, 47) << 32) | (uint32_t)__builtin_amdgcn_readlane(v, 63);
+}
+
+// c_ptr / c_del: lane i < nc holds candidate i (an exact read pointer, and how many levels behind the tip its k-mer sits); on
+// return the next hop's candidates, and `word` = this lane's word of their pieces of the read store (requested, not waited for:
+// the caller stores it into L.cw[g][lane] once it has done its own work).  staged: L.cw[g] holds the words of THESE candidates.
+template <int MODE, bool SH = false>
+__device__ __forceinline__ void scout_cons(const SolidView &t, TeamLds &L, uint32_t g, const Kmer &X, int k, int min_cov, uint32_t &c_ptr,
+                                           uint32_t &c_del, uint32_t nc, uint32_t want, bool staged, ConsHop &R, uint64_t &word,
+                                           unsigned long long &lookups, unsigned long long *tsc = nullptr)
+{
+    static_assert(MODE == KEY_PACKED, "the tip and its levels in 64-bit words");
+#ifdef MC_SCOUT_TIMING
+    unsigned long long ts_ = __builtin_amdgcn_s_memrealtime();
+#else
+    (void)tsc;
+#endif
+    const uint32_t lane = threadIdx.x & 63;
+    uint64_t *cw = L.cw[g];
+    R.m = 0; R.why = 1; R.e_hi = R.e_lo = 0; R.X = X; R.nc = 0; R.used = 0;
+    word = 0;
+    if (!staged) {
+        const uint32_t cp = (uint32_t)__shfl((int)c_ptr, (int)(lane >> 3));
+        __builtin_amdgcn_wave_barrier();
+        cw[lane] = (lane >> 3) < nc ? cons_word_of(t, cp, lane & 7u) : 0ull;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- where does each candidate hold the tip, and which way does it run?  (lane i: candidate i.  32-bit places: every
+    // pointer is exact, so the store has fewer than 2^31 bases)
+    const uint32_t sk2 = 2u * (uint32_t)k, rb = (uint32_t)t.reads_bases;
+    const Kmer Xr = kmer_rc<MODE>(X, k);
+    uint32_t Qv = ~0u, wbv = 0;  // place of the tip in the store | 1 << 31: the read runs the walk's way (~0: not there); first staged base
+    if (lane < nc && c_ptr) {
+        const uint32_t pos = c_ptr - 1u;
+        if (pos + (uint32_t)k <= rb) {
+            const uint32_t wb = (pos > CONS_BACK ? pos - CONS_BACK : 0u) & ~31u;
+            const uint64_t *sw = cw + CONS_WORDS * lane;
+            wbv = wb;
+            const uint32_t qf = pos + c_del;
+            if (qf + (uint32_t)k <= rb && kmer_eq(kmer_at<MODE>(sw, qf - wb, k), X)) Qv = qf | 0x80000000u;
+            else if (pos >= c_del + wb && kmer_eq(kmer_at<MODE>(sw, pos - c_del - wb, k), Xr)) Qv = pos - c_del;
+        }
+    }
+    // two candidates that hold the tip at the same place are one read: its vote counts once (the candidates sit in the first
+    // lanes of a row of sixteen: row_shr brings the earlier ones' places over, zeros from beyond the row's start)
+    {
+        static_assert(CONS_N == 8, "seven earlier candidates to compare with");
+#define MC_CONS_EARLIER(o) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)Qv, 0x110 + (o), 0xF, 0xF, true) == Qv)
+        // (| not ||: every lane takes part in every one of them)
+        const bool dup = MC_CONS_EARLIER(1) | MC_CONS_EARLIER(2) | MC_CONS_EARLIER(3) | MC_CONS_EARLIER(4) | MC_CONS_EARLIER(5) |
+                         MC_CONS_EARLIER(6) | MC_CONS_EARLIER(7);
+#undef MC_CONS_EARLIER
+        if (dup && Qv != 0u) Qv = ~0u;  // (0: what row_shr brings from beyond the row's start)
+    }
+    const uint32_t U = (uint32_t)__ballot(lane < CONS_N && Qv != ~0u);
+    const uint32_t nU = (uint32_t)__popc(U);
+    R.used = nU;
+    if (nU == 0) return;
+    R.why = 2;
+    const bool single = nU == 1;
+#ifdef MC_SCOUT_TIMING
+    if (tsc) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); tsc[0] += n_ - ts_; ts_ = n_; }
+#endif
+    // ---- lane i < CONS_N: the 64 bases candidate i holds for the levels 1 .. 64, first on top, and how many of them lie in
+    // its staged words.  The walk's next bases FOLLOW the tip in a read that runs its way and PRECEDE it, complemented, in
+    // one that does not.
+    uint32_t len = 0;
+    uint64_t s_hi = 0, s_lo = 0;
+    {
+        if (lane < CONS_N && Qv != ~0u) {
+            const uint32_t Q = Qv & 0x7FFFFFFFu;
+            const uint64_t *sw = cw + CONS_WORDS * lane;
+            if (Qv >> 31) {
+                const uint32_t off0 = Q + (uint32_t)k - wbv, lim = min(CONS_WORDS * 32u, rb - wbv);
+                if (off0 < lim) { len = min(64u, lim - off0); s_hi = bases32(sw, off0); s_lo = bases32(sw, off0 + 32u); }
+            } else {
+                const uint32_t a = Q - wbv;  // staged bases in front of the tip (fewer than 64 only at the very start of the store)
+                if (a >= 64u) { len = 64u; s_hi = rc64_pairs(bases32(sw, a - 32u)); s_lo = rc64_pairs(bases32(sw, a - 64u)); }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < CONS_N) { L.cstr[g][lane][0] = s_hi; L.cstr[g][lane][1] = s_lo; L.cnd[g][lane] = len; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    uint32_t m0;
+    uint64_t e_hi, e_lo;
+#if MC_CONS_PAIRS
+    // ---- lane (i, j): how far do candidates i < j AGREE?  The longest agreement of any pair is the hop.  (Measured against
+    // the vote below: 0.78 us instead of 1.10, but 48 levels a hop instead of 54 -- a lone error of the best pair ends it.)
+    {
+        const uint32_t pi = lane >> 3, pj = lane & 7u;
+        const uint64_t a_hi = L.cstr[g][pi][0], a_lo = L.cstr[g][pi][1], b_hi = L.cstr[g][pj][0], b_lo = L.cstr[g][pj][1];
+        const uint32_t la = L.cnd[g][pi], lb = L.cnd[g][pj];
+        const uint64_t x_hi = a_hi ^ b_hi, x_lo = a_lo ^ b_lo;
+        uint32_t agree = x_hi ? (uint32_t)__builtin_clzll(x_hi) >> 1 : (x_lo ? 32u + ((uint32_t)__builtin_clzll(x_lo) >> 1) : 64u);
+        agree = min(min(agree, want), min(la, lb));
+        if (single ? pi != pj : pi >= pj) agree = 0;
+        int v = (int)agree;
+        v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true));
+        v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true));
+        v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true));
+        v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true));
+        m0 = (uint32_t)max(max(__builtin_amdgcn_readlane(v, 15), __builtin_amdgcn_readlane(v, 31)),
+                           max(__builtin_amdgcn_readlane(v, 47), __builtin_amdgcn_readlane(v, 63)));
+        if (m0 == 0) return;
+        const uint32_t wl = (uint32_t)__builtin_ctzll(__ballot(agree == m0));
+        e_hi = readlane64(a_hi, wl);
+        e_lo = readlane64(a_lo, wl);
+        if (m0 < 32u) { e_hi &= ~0ull << (64u - 2u * m0); e_lo = 0; }
+        else if (m0 == 32u) e_lo = 0;
+        else if (m0 < 64u) e_lo &= ~0ull << (128u - 2u * m0);
+    }
+#else
+    // ---- lane l votes on level l + 1: the candidates' bases there (4 bits each, 8: none) and a first count, four byte counters
+    uint32_t bb = 0, cnt = 0;
+    {
+        const uint64_t *col = &L.cstr[g][0][lane >> 5];
+        const uint32_t sh = 62u - 2u * (lane & 31u);
+        uint64_t wv_[CONS_N];
+#pragma unroll
+        for (uint32_t i = 0; i < CONS_N; i++) wv_[i] = col[2u * i];  // (requested together)
+#pragma unroll
+        for (uint32_t i = 0; i < CONS_N; i++) {
+            const uint32_t len_i = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)i);
+            const bool valid = lane < len_i;
+            const uint32_t b = (uint32_t)(wv_[i] >> sh) & 3u;
+            cnt += (valid ? 1u : 0u) << (8u * b);
+            bb |= (valid ? b : 8u) << (4u * i);
+        }
+    }
+    uint32_t top, second;
+    uint32_t base = cons_top(cnt, top, second);
+    bool ok = top >= 1;
+    if (!single) {
+        // ---- up to which level is each read alive?  A read stops being alive at its first disagreement with the first count's
+        // winners that has a second one within the two levels behind it: a sequencing error is one lone disagreement, the end
+        // of a read (the store holds the next read's bases behind it) a run of them.  Lane i < CONS_N compares candidate i's 64
+        // bases with the winners all at once: a flag a level in the even bits (two bits a level, first level on top, so
+        // "behind" is to the right), levels it holds no base for flagged too
+        uint64_t p_hi, p_lo;
+        cons_pack(base, true, lane, p_hi, p_lo);
+        uint32_t end = 0;
+        if (lane < CONS_N) {
+            constexpr uint64_t EV = 0x5555555555555555ull;
+            const uint64_t x_hi = s_hi ^ p_hi, x_lo = s_lo ^ p_lo;
+            uint64_t d_hi = (x_hi | (x_hi >> 1)) & EV, d_lo = (x_lo | (x_lo >> 1)) & EV;
+            if (len < 32u) { d_hi |= EV >> (2u * len); d_lo = EV; }
+            else if (len < 64u) d_lo |= EV >> (2u * (len - 32u));
+            const uint64_t f_hi = d_hi & ((d_hi << 2) | (d_lo >> 62) | (d_hi << 4) | (d_lo >> 60)), f_lo = d_lo & ((d_lo << 2) | (d_lo << 4));
+            end = f_hi ? (uint32_t)__builtin_clzll(f_hi) >> 1 : (f_lo ? 32u + ((uint32_t)__builtin_clzll(f_lo) >> 1) : 64u);
+            end = min(end, len);
+        }
+        // ---- the count among the reads that are alive: the path goes on while two of them agree and no other base has as many votes
+        uint32_t cnt2 = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < CONS_N; i++) {
+            const uint32_t end_i = (uint32_t)__builtin_amdgcn_readlane((int)end, (int)i);
+            cnt2 += (lane < end_i ? 1u : 0u) << (8u * ((bb >> (4u * i)) & 3u));
+        }
+        base = cons_top(cnt2, top, second);
+        ok = top >= 2 && top > second;
+    }
+    {
+        const unsigned long long okm = __ballot(ok && lane < want);
+        m0 = okm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~okm);
+        if (m0 == 0) return;
+        cons_pack(base, lane < m0, lane, e_hi, e_lo);
+    }
+#endif
+    // the tip's k bases and the levels behind them, 32 bases a word: vertex j levels past the tip = bases [j, j + k) of it
+    uint64_t *cs = L.cs[g];
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        cs[0] = (X.lo << (64u - sk2)) | (e_hi >> sk2);
+        cs[1] = (e_hi << (64u - sk2)) | (e_lo >> sk2);
+        cs[2] = e_lo << (64u - sk2);
+        cs[3] = 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#ifdef MC_SCOUT_TIMING
+    if (tsc) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); tsc[1] += n_ - ts_; ts_ = n_; }
+#endif
+    // ---- the vertices that are looked up: lane l <-> level lo + l
+    const uint32_t lo = single || m0 <= CONS_TAIL ? 1u : m0 - CONS_TAIL + 1u, n_lk = m0 - lo + 1u;
+    const bool lk = lane < n_lk;
+    const uint32_t j = lo + lane;
+    const Kmer K{0, lk ? bases32(cs, j) >> (64u - sk2) : 0ull};
+    const uint64_t key = lk ? (uint64_t)key_of<MODE>(K, k) : 0;
+    uint64_t s0;
+    TableRef h;
+    if (SH ? t.owner_mm_k : t.mm_k) {
+        // the minimizer bins of the vertices (scout_eval says how): the SK_M-mers at bases lo .. m0 + w - 1, one or two a lane
+        const uint32_t w = (uint32_t)k - SK_M + 1, n_mm = n_lk + w - 1;
+        uint32_t *mh = L.mh[g];
+        auto mm_hash = [](uint32_t f) {
+            uint32_t r = __builtin_bitreverse32(f);
+            r = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
+            r = (~r) >> (32 - 2 * SK_M);
+            return sk_order(f < r ? f : r);
+        };
+        __builtin_amdgcn_wave_barrier();
+        if (lane < n_mm) mh[lane] = mm_hash((uint32_t)(bases32(cs, lo + lane) >> (64 - 2 * SK_M)));
+        if (64u + lane < n_mm) mh[64u + lane] = mm_hash((uint32_t)(bases32(cs, lo + 64u + lane) >> (64 - 2 * SK_M)));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t hmin = SK_NONE;
+        if (lk) {
+            if (w == 17) {
+                uint32_t hv[17];
+#pragma unroll
+                for (int i = 0; i < 17; i++) hv[i] = mh[lane + i];
+#pragma unroll
+                for (int i = 0; i < 17; i++) hmin = min(hmin, hv[i]);
+            } else {
+                for (uint32_t i = 0; i < w; i++) hmin = min(hmin, mh[lane + i]);
+            }
+        }
+        if (SH) s0 = solid_locate(t, key, h, true, hmin);
+        else { h = own_table(t); s0 = ((((uint64_t)sk_bin(hmin) * t.n_regions) >> 32) << MC_REGION_LG) | sk_home(key); }
+    } else {
+        if (SH) s0 = solid_locate(t, key, h);
+        else { h = own_table(t); s0 = solid_slot_of(t, key); }
+    }
+#ifdef MC_SCOUT_TIMING
+    if (tsc) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); tsc[2] += n_ - ts_; ts_ = n_; }
+#endif
+    // (appending the levels in front of the looked-up ones to the path while the slots travel was measured: the wait for the slots
+    // then waits for those write-through stores too, 0.8 -> 1.45 us)
+    uint32_t aux = 0;
+    int cov = -1;
+    if (lk) {
+        cov = solid_get4(t, h, key, &aux, s0);
+        lookups++;
+    }
+#ifdef MC_SCOUT_TIMING
+    if (tsc) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); tsc[3] += n_ - ts_; ts_ = n_; }
+#endif
+    const unsigned long long sm = __ballot(lk && cov >= min_cov);
+    const uint32_t ps = sm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~sm);  // the looked-up vertices that are solid, from the first on
+    const uint32_t m = lo - 1u + ps;  // (ps == 0 behind a consensus: its unchecked part stays, and the hop names no candidates)
+    if (m == 0) return;
+
+    // ---- the next hop's candidates: the pointers of the solid vertices nearest to the new tip, one a read where that is cheap to
+    // tell (the same read holds neighbouring vertices at neighbouring places; what is left is dropped when the tip is looked for)
+    bool el = lane < ps && aux != 0 && aux - 1u + (uint32_t)k <= rb && m - j < CONS_TAIL;
+    {   // (through the staged words' LDS, which nobody reads any more: three neighbours' values in six reads that travel together)
+        uint32_t *scr = reinterpret_cast<uint32_t *>(cw);
+        const uint32_t fw = el ? aux - j : 0xFFFFFF00u + 2u * lane, rv = el ? aux + j : 0xFFFFFF01u + 2u * lane;  // (pointers are below 2^31)
+        __builtin_amdgcn_wave_barrier();
+        scr[2u * lane] = fw;
+        scr[2u * lane + 1u] = rv;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        bool same = false;
+#pragma unroll
+        for (uint32_t o = 1; o <= 3; o++) {
+            const uint32_t n = min(lane + o, 63u);
+            same = same || (n != lane && (scr[2u * n] == fw || scr[2u * n + 1u] == rv));
+        }
+        el = el && !same;
+    }
+    const unsigned long long cm = __ballot(el);
+    const uint32_t n_sel = min((uint32_t)__popcll(cm), CONS_N);
+    const uint32_t rank = lane == 63u ? 0u : (uint32_t)__popcll(cm >> (lane + 1u));  // eligible lanes nearer to the tip
+    __builtin_amdgcn_wave_barrier();
+    if (el && rank < CONS_N) { L.cnp[g][rank] = aux; L.cnd[g][rank] = m - j; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    c_ptr = lane < n_sel ? L.cnp[g][lane] : 0u;
+    c_del = lane < n_sel ? L.cnd[g][lane] : 0u;
+    if ((lane >> 3) < n_sel) word = cons_word_of(t, L.cnp[g][lane >> 3], lane & 7u);
+    if (m < 32) { e_hi &= ~0ull << (64u - 2u * m); e_lo = 0; }
+    else if (m == 32) e_lo = 0;
+    else if (m < 64) e_lo &= ~0ull << (128u - 2u * m);
+    R.m = m; R.why = 0; R.e_hi = e_hi; R.e_lo = e_lo; R.nc = n_sel;
+    R.X = Kmer{0, bases32(cs, m) >> (64u - sk2)};
+#ifdef MC_SCOUT_TIMING
+    if (tsc) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); tsc[4] += n_ - ts_; ts_ = n_; }
+#endif
+}
 
 template <int MODE, bool SH = false>
 __device__ __forceinline__ void scout_companion(const BfsState &S, const SolidView &t, TeamLds &L, int k, int min_cov)
@@ -996,6 +1351,65 @@ __device__ __forceinline__ void scout_companion(const BfsState &S, const SolidVi
         BFS_SYNC();
         const uint32_t F = min(L.F, (uint32_t)SCOUT_MAX_F), budget = min(L.budget, PATH_CAP);
         if (F == 0) continue;
+        bool cons_done = false;
+        if constexpr (MC_SCOUT_CONSENSUS != 0 && MODE == KEY_PACKED) {
+            if (t.reads_bases < PTR_EXACT_END) {  // (every read pointer names its place exactly: scout_cons looks for the tip nowhere else)
+                // ---- consensus hops: wave g is walker g's scout, on its own until the request is done with
+                cons_done = true;
+                if (wv < F) {
+                    uint64_t *P = S.path + (uint64_t)wv * PATH_WORDS;
+                    Kmer X = L.X[wv];
+                    PathTail T = path_open(P, X, k, lane == 0);
+                    if (lane == 0) { P[T.wi] = T.tailw; P[T.wi + 1] = 0; }
+                    uint32_t levels = 0, published = 0, nc = L.nc[wv];
+                    uint32_t c_ptr = lane == 0 ? L.cptr[wv][0] : 0u, c_del = 0;
+                    bool staged = false, stopped = false;
+                    while (nc && levels < budget) {
+                        uint32_t probe = seq;
+                        if (lane == 0) probe = ld_u32(&box->req_seq) | (ld_u32(&box->quit) << 31);  // (used at the end of the hop)
+                        ConsHop R;
+                        uint64_t word;
+                        scout_cons<MODE, SH>(t, L, wv, X, k, min_cov, c_ptr, c_del, nc, min(64u, budget - levels), staged, R, word, lookups, tsc);
+                        if (tid == 0) iters++;
+#ifdef MC_SCOUT_TIMING
+                        unsigned long long tq_ = __builtin_amdgcn_s_memrealtime();
+#endif
+                        // the length the PREVIOUS hop added is published now: its path words were stored before this hop's round
+                        // trips, and a wave's loads come back behind its earlier stores (see the other loop below)
+                        if (lane == 0 && levels != published) st_u32(&box->resp[wv], box_resp(seq, false, levels));
+                        published = levels;
+                        if (R.why == 1) n_nf += lane == 0; else { hops += lane == 0; if (R.m == 0) n_m0 += lane == 0; }
+                        if (R.m == 0) {
+                            if (lane == 0) atomicAdd(&box->e_stuck, 1ull);
+                            break;
+                        }
+                        path_append(P, T, R.e_hi, R.e_lo, R.m, lane == 0);
+                        levels += R.m;
+                        X = R.X;
+                        nc = R.nc;
+                        if (nc == 0) {
+                            if (lane == 0) atomicAdd(&box->e_nc0, 1ull);
+                        } else {  // the words around the next hop's candidates: asked for inside the hop, they have travelled meanwhile
+                            __builtin_amdgcn_wave_barrier();
+                            L.cw[wv][lane] = word;
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            staged = true;
+                        }
+#ifdef MC_SCOUT_TIMING
+                        if (wv == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); tsc[5] += n_ - tq_; tsc[6]++; }
+#endif
+                        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)probe) != seq) { stopped = true; break; }
+                    }
+                    if (lane == 0) {
+                        L.levels[wv] = levels;
+                        L.stuck[wv] = levels < budget;
+                        if (stopped) L.stop = 1;
+                    }
+                }
+            }
+        }
+        if (!cons_done) {
         uint32_t Tm = min(W, (uint32_t)MC_TEAM_MAX);  // team size: the largest power of two with F * Tm <= W
         while (Tm > 1 && F * Tm > W) Tm >>= 1;
         // a team = n_cd candidate reads x n_sg waves each: wave s of a candidate looks at the levels 64 s + 1 .. 64 s + 64 past the tip
@@ -1086,16 +1500,18 @@ __device__ __forceinline__ void scout_companion(const BfsState &S, const SolidVi
             for (uint32_t a = 0; a < F; a++) any = any || (!L.stuck[a] && L.levels[a] < budget);
             if (!any || L.stop) break;
         }
+        }  // (!cons_done)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         BFS_SYNC();
         if (!L.stop && tid < F) st_u32(&box->resp[tid], box_resp(seq, true, L.levels[tid]));
         if (tid == 0) { atomicAdd(&box->calls, 1ull); if (L.stop) atomicAdd(&box->e_stop, 1ull); else if (L.levels[0] >= budget) atomicAdd(&box->e_budget, 1ull); }
-        if (tid == 0) BFS_TRACE(S, 8u << 24 | (seq & 0xFFFFFF), F | Tm << 8 | L.stop << 16, L.levels[0], F > 1 ? L.levels[1] : 0u, budget, L.stuck[0] | (F > 1 ? L.stuck[1] : 0u) << 8, (uint32_t)iters, 0u);
+        if (tid == 0) BFS_TRACE(S, 8u << 24 | (seq & 0xFFFFFF), F | (cons_done ? 1u : 0u) << 8 | L.stop << 16, L.levels[0], F > 1 ? L.levels[1] : 0u, budget, L.stuck[0] | (F > 1 ? L.stuck[1] : 0u) << 8, (uint32_t)iters, 0u);
         if (tid < F) atomicAdd(&box->levels, (unsigned long long)L.levels[tid]);
         BFS_SYNC();
     }
 #ifdef MC_SCOUT_TIMING
-    if (tid == 0 && tsc[5]) printf("[scout companion] %llu iterations, us each: fetch words %.2f, find tip + hash %.2f, look up %.2f, rest of eval %.2f, barriers + winner %.2f\n", tsc[5], tsc[0] * 0.01 / tsc[5], tsc[1] * 0.01 / tsc[5], tsc[2] * 0.01 / tsc[5], tsc[3] * 0.01 / tsc[5], tsc[4] * 0.01 / tsc[5]);
+    if (tid == 0 && tsc[6]) printf("[scout companion, consensus hops] %llu hops, us each: words + tip %.2f, consensus %.2f, vertices + minimizers %.2f, look up %.2f, candidates %.2f, append + store words %.2f\n", tsc[6], tsc[0] * 0.01 / tsc[6], tsc[1] * 0.01 / tsc[6], tsc[2] * 0.01 / tsc[6], tsc[3] * 0.01 / tsc[6], tsc[4] * 0.01 / tsc[6], tsc[5] * 0.01 / tsc[6]);
+    else if (tid == 0 && tsc[5]) printf("[scout companion] %llu iterations, us each: fetch words %.2f, find tip + hash %.2f, look up %.2f, rest of eval %.2f, barriers + winner %.2f\n", tsc[5], tsc[0] * 0.01 / tsc[5], tsc[1] * 0.01 / tsc[5], tsc[2] * 0.01 / tsc[5], tsc[3] * 0.01 / tsc[5], tsc[4] * 0.01 / tsc[5]);
 #endif
     if (lane == 0) {
         atomicAdd(&box->hops, hops);
