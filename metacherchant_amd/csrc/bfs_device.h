@@ -58,8 +58,14 @@ constexpr uint32_t SCOUT_BACK = 192;                  // bases in front of a poi
 #ifndef MC_SCOUT_PROBES
 #define MC_SCOUT_PROBES 4   // slots a scout's lookup requests at once
 #endif
+#ifndef MC_ROUND_PROBES
+#define MC_ROUND_PROBES 2   // slots a round's look-up requests at once (4 was measured in round 4: the 512 look-ups' wait 3.2 -> 3.5 us a round, the walk 7.7 -> 8.05 ms)
+#endif
 #ifndef MC_SCOUT_OPTIMISTIC
 #define MC_SCOUT_OPTIMISTIC 0   // 1: a scout's lookup that finds neither its key nor a free slot among those takes the vertex for solid
+#endif
+#ifndef MC_CONS_NEIGHBOURS
+#define MC_CONS_NEIGHBOURS 7   // scout_cons: a vertex's pointer is dropped when one of this many vertices nearer to the tip points into the same read
 #endif
 #ifndef MC_CONS_PAIRS
 #define MC_CONS_PAIRS 0   // scout_cons: 1 = the longest agreement of any PAIR of candidate reads is the hop; 0 = a vote a level among all of them
@@ -531,6 +537,23 @@ __device__ __forceinline__ int solid_get2(const SolidView &tv, const TableRef &t
     if (k1 == EMPTY_KEY) return -1;
     // both probes hit other keys: the rest of the sequence, four slots at a time
     return solid_probe_from(t, key, (s0 & ~(uint64_t)t.rmask) | ((s0 + 2) & t.rmask), 2, aux);
+}
+
+// ... with four probe slots already loaded (MC_ROUND_PROBES == 4: measured, not the default)
+__device__ __forceinline__ int solid_get4l(const SolidView &tv, const TableRef &t, uint64_t key, uint64_t s0, uint4 a0, uint4 a1, uint4 a2, uint4 a3,
+                                           uint32_t *aux)
+{
+    slots_wanted(a0, a1, a2, a3);
+    *aux = 0;
+    if (key == EMPTY_KEY) return solid_get(tv, key);
+    const uint4 av[4] = {a0, a1, a2, a3};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint64_t cur = ((uint64_t)av[i].y << 32) | av[i].x;
+        if (cur == key) { *aux = av[i].w; return av[i].z > 32767u ? 32767 : (int)av[i].z; }
+        if (cur == EMPTY_KEY) return -1;
+    }
+    return solid_probe_from(t, key, (s0 & ~(uint64_t)t.rmask) | ((s0 + 4) & t.rmask), 4, aux);
 }
 
 // 32 bases from base q of a packed word array on, first base on top (reads one word past the last one it needs)
@@ -1274,7 +1297,7 @@ __device__ __forceinline__ void scout_cons(const SolidView &t, TeamLds &L, uint3
     // ---- the next hop's candidates: the pointers of the solid vertices nearest to the new tip, one a read where that is cheap to
     // tell (the same read holds neighbouring vertices at neighbouring places; what is left is dropped when the tip is looked for)
     bool el = lane < ps && aux != 0 && aux - 1u + (uint32_t)k <= rb && m - j < CONS_TAIL;
-    {   // (through the staged words' LDS, which nobody reads any more: three neighbours' values in six reads that travel together)
+    {   // (through the staged words' LDS, which nobody reads any more: the neighbours' values in reads that travel together)
         uint32_t *scr = reinterpret_cast<uint32_t *>(cw);
         const uint32_t fw = el ? aux - j : 0xFFFFFF00u + 2u * lane, rv = el ? aux + j : 0xFFFFFF01u + 2u * lane;  // (pointers are below 2^31)
         __builtin_amdgcn_wave_barrier();
@@ -1284,9 +1307,10 @@ __device__ __forceinline__ void scout_cons(const SolidView &t, TeamLds &L, uint3
         __builtin_amdgcn_wave_barrier();
         bool same = false;
 #pragma unroll
-        for (uint32_t o = 1; o <= 3; o++) {
+        for (uint32_t o = 1; o <= MC_CONS_NEIGHBOURS; o++) {
             const uint32_t n = min(lane + o, 63u);
-            same = same || (n != lane && (scr[2u * n] == fw || scr[2u * n + 1u] == rv));
+            const uint2 other = *reinterpret_cast<const uint2 *>(scr + 2u * n);
+            same = same | (n != lane && (other.x == fw || other.y == rv));
         }
         el = el && !same;
     }
@@ -1397,7 +1421,7 @@ __device__ __forceinline__ void scout_companion(const BfsState &S, const SolidVi
                             staged = true;
                         }
 #ifdef MC_SCOUT_TIMING
-                        if (wv == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); tsc[5] += n_ - tq_; tsc[6]++; }
+                        if (wv == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); tsc[5] += n_ - tq_; tsc[6]++; tsc[7] += ((unsigned long long)R.used << 32) + R.nc; }
 #endif
                         if ((uint32_t)__builtin_amdgcn_readfirstlane((int)probe) != seq) { stopped = true; break; }
                     }
@@ -1510,7 +1534,7 @@ __device__ __forceinline__ void scout_companion(const BfsState &S, const SolidVi
         BFS_SYNC();
     }
 #ifdef MC_SCOUT_TIMING
-    if (tid == 0 && tsc[6]) printf("[scout companion, consensus hops] %llu hops, us each: words + tip %.2f, consensus %.2f, vertices + minimizers %.2f, look up %.2f, candidates %.2f, append + store words %.2f\n", tsc[6], tsc[0] * 0.01 / tsc[6], tsc[1] * 0.01 / tsc[6], tsc[2] * 0.01 / tsc[6], tsc[3] * 0.01 / tsc[6], tsc[4] * 0.01 / tsc[6], tsc[5] * 0.01 / tsc[6]);
+    if (tid == 0 && tsc[6]) printf("[scout companion, consensus hops] %llu hops, us each: words + tip %.2f, consensus %.2f, vertices + minimizers %.2f, look up %.2f, candidates %.2f, append + store words %.2f; reads that held the tip %.2f a hop, candidates named %.2f\n", tsc[6], tsc[0] * 0.01 / tsc[6], tsc[1] * 0.01 / tsc[6], tsc[2] * 0.01 / tsc[6], tsc[3] * 0.01 / tsc[6], tsc[4] * 0.01 / tsc[6], tsc[5] * 0.01 / tsc[6], (double)(tsc[7] >> 32) / tsc[6], (double)(tsc[7] & 0xFFFFFFFFull) / tsc[6]);
     else if (tid == 0 && tsc[5]) printf("[scout companion] %llu iterations, us each: fetch words %.2f, find tip + hash %.2f, look up %.2f, rest of eval %.2f, barriers + winner %.2f\n", tsc[5], tsc[0] * 0.01 / tsc[5], tsc[1] * 0.01 / tsc[5], tsc[2] * 0.01 / tsc[5], tsc[3] * 0.01 / tsc[5], tsc[4] * 0.01 / tsc[5]);
 #endif
     if (lane == 0) {
@@ -1740,7 +1764,7 @@ __device__ __forceinline__ void bfs_narrow(const BfsState &S, const SolidView &t
         uint32_t naux = 0;
         uint64_t key = 0, s0 = 0;
         TableRef h = own_table(t);  // the table the node's k-mer lives in (SH, several GPUs: its owner's)
-        uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+        uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0, a2 = a0, a3 = a0;
         bool root_bad = false;
         if (tid < H * FN) {
             const uint32_t tl = tid;
@@ -1790,6 +1814,10 @@ __device__ __forceinline__ void bfs_narrow(const BfsState &S, const SolidView &t
             const uint64_t s1 = (s0 & ~(uint64_t)h.rmask) | ((s0 + 1) & h.rmask);
             a0 = *reinterpret_cast<const uint4 *>(h.slots + s0);
             a1 = *reinterpret_cast<const uint4 *>(h.slots + s1);
+#if MC_ROUND_PROBES == 4
+            a2 = *reinterpret_cast<const uint4 *>(h.slots + ((s0 & ~(uint64_t)h.rmask) | ((s0 + 2) & h.rmask)));
+            a3 = *reinterpret_cast<const uint4 *>(h.slots + ((s0 & ~(uint64_t)h.rmask) | ((s0 + 3) & h.rmask)));
+#endif
             lookups++;
             have = true;
         }
@@ -1798,7 +1826,11 @@ __device__ __forceinline__ void bfs_narrow(const BfsState &S, const SolidView &t
         if (BFS_THREADS - 1 - tid < pend) vis_insert(S, L.pub_k[BFS_THREADS - 1 - tid], L.pub_idx[BFS_THREADS - 1 - tid]);
         MC_STAMP(1);
         if (have) {
+#if MC_ROUND_PROBES == 4
+            cov = solid_get4l(t, h, key, s0, a0, a1, a2, a3, &naux);
+#else
             cov = solid_get2(t, h, key, s0, a0, a1, &naux);
+#endif
             L.cov[tid] = (int16_t)cov;
             L.kmer[tid] = nk;
             L.naux[tid] = naux;

@@ -1460,6 +1460,12 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
     const bool virgin0 = c->virgin;
     auto launch_p2 = [&] {
         static const bool staged = [] { const char *e = getenv("MC_SK2_STAGED"); return !(e && !strcmp(e, "0")); }();
+        static bool told = getenv("MC_INGEST_DEBUG") == nullptr;
+        if (!told) {  // (where the streams lie: the second level's time differs between processes that differ in nothing else)
+            told = true;
+            fprintf(stderr, "[count] level-1 stream %p (%llu records a segment), level-2 stream %p (%llu a leaf), table %p\n", (void *)P.a_recs,
+                    (unsigned long long)pl.cap1, (void *)P.b_recs, (unsigned long long)pl.cap2, (void *)c->slots);
+        }
         if (pl.sk && pl.compact)
             hipLaunchKernelGGL(k_sk2_scatter_compact<MC_SK2C_ITEMS>, dim3((unsigned)np1), dim3(PT_THREADS), 0, c->stream, P.a_recs, pl.cap1,
                                P.seg_counts1, (uint32_t)np1, pl.b2, P.cursors2, pl.cap2, P.b_recs, pl.sks, pl.nseg1, c->cur_ptr_base, pl.pos0,
