@@ -58,6 +58,9 @@ constexpr uint32_t SCOUT_BACK = 192;                  // bases in front of a poi
 #ifndef MC_SCOUT_PROBES
 #define MC_SCOUT_PROBES 4   // slots a scout's lookup requests at once
 #endif
+#ifndef MC_ROUND_TAIL
+#define MC_ROUND_TAIL 4   // slots a round's look-up requests at once when its first two did not decide it (8: measured in round 4, no difference)
+#endif
 #ifndef MC_ROUND_PROBES
 #define MC_ROUND_PROBES 2   // slots a round's look-up requests at once (4 was measured in round 4: the 512 look-ups' wait 3.2 -> 3.5 us a round, the walk 7.7 -> 8.05 ms)
 #endif
@@ -536,7 +539,7 @@ __device__ __forceinline__ int solid_get2(const SolidView &tv, const TableRef &t
     if (k1 == key) { *aux = a1.w; return a1.z > 32767u ? 32767 : (int)a1.z; }
     if (k1 == EMPTY_KEY) return -1;
     // both probes hit other keys: the rest of the sequence, four slots at a time
-    return solid_probe_from(t, key, (s0 & ~(uint64_t)t.rmask) | ((s0 + 2) & t.rmask), 2, aux);
+    return solid_probe_from<MC_ROUND_TAIL>(t, key, (s0 & ~(uint64_t)t.rmask) | ((s0 + 2) & t.rmask), 2, aux);
 }
 
 // ... with four probe slots already loaded (MC_ROUND_PROBES == 4: measured, not the default)

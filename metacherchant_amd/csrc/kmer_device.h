@@ -648,20 +648,22 @@ __device__ __forceinline__ void slots_wanted([[maybe_unused]] uint4 &a, [[maybe_
 #endif
 }
 
+template <int CHUNK = 4>
 __device__ __forceinline__ int solid_probe_from(const TableRef &t, uint64_t key, uint64_t s, uint32_t n_done, uint32_t *aux)
-{
+{   // CHUNK: slots requested together (4, or 8 where many lanes wait for the slowest of them: a walk's round)
     uint64_t base = s & ~(uint64_t)t.rmask;
     const uint64_t n_regions = t.n_regions ? (uint64_t)t.n_regions : ((1ull << (64 - t.shift)) / ((uint64_t)t.rmask + 1));
     const uint64_t home = (s - n_done) & t.rmask;
     const uint32_t max_probes = t.rmask + 1 < TABLE_MAX_PROBES ? t.rmask + 1 : TABLE_MAX_PROBES;
     for (uint32_t hop = 0; hop < TABLE_CHAIN; hop++) {
-        for (uint32_t probe = hop ? 0 : n_done; probe < max_probes; probe += 4) {
-            uint4 a[4];
+        for (uint32_t probe = hop ? 0 : n_done; probe < max_probes; probe += CHUNK) {
+            uint4 a[CHUNK];
 #pragma unroll
-            for (int i = 0; i < 4; i++) a[i] = *reinterpret_cast<const uint4 *>(t.slots + (base | ((s + i) & t.rmask)));
+            for (int i = 0; i < CHUNK; i++) a[i] = *reinterpret_cast<const uint4 *>(t.slots + (base | ((s + i) & t.rmask)));
             slots_wanted(a[0], a[1], a[2], a[3]);
+            if (CHUNK == 8) slots_wanted(a[CHUNK - 4], a[CHUNK - 3], a[CHUNK - 2], a[CHUNK - 1]);
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < CHUNK; i++) {
                 if (probe + (uint32_t)i >= max_probes) break;  // (a free slot BEHIND the stretch says nothing: the key may have moved on)
                 const uint64_t cur = ((uint64_t)a[i].y << 32) | a[i].x;
                 if (cur == key) {
@@ -670,7 +672,7 @@ __device__ __forceinline__ int solid_probe_from(const TableRef &t, uint64_t key,
                 }
                 if (cur == EMPTY_KEY) return -1;
             }
-            s = base | ((s + 4) & t.rmask);
+            s = base | ((s + CHUNK) & t.rmask);
         }
         // no free slot in the whole stretch: the key may have been handed on to the next region (table_add)
         base = next_region_base(base, t.rmask, n_regions);
