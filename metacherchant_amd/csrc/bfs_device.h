@@ -58,6 +58,9 @@ constexpr uint32_t SCOUT_BACK = 192;                  // bases in front of a poi
 #ifndef MC_SCOUT_PROBES
 #define MC_SCOUT_PROBES 4   // slots a scout's lookup requests at once
 #endif
+#ifndef MC_QUAD_MINIMIZER
+#define MC_QUAD_MINIMIZER 1   // a round's four nodes of a level share the hashing of their vertex's SK_M-mers (0: every thread all 17)
+#endif
 #ifndef MC_ROUND_TAIL
 #define MC_ROUND_TAIL 4   // slots a round's look-up requests at once when its first two did not decide it (8: measured in round 4, no difference)
 #endif
@@ -1294,6 +1297,9 @@ __device__ __forceinline__ void scout_cons(const SolidView &t, TeamLds &L, uint3
 #endif
     const unsigned long long sm = __ballot(lk && cov >= min_cov);
     const uint32_t ps = sm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~sm);  // the looked-up vertices that are solid, from the first on
+    // (a retry CONS_TAIL levels earlier when the first of them is not solid, and a hop that follows the first usable read alone
+    // when no two agree on the very next base, were built and measured: 4 requests a walk instead of 9, but the loop around the
+    // look-ups made every hop 0.3 us longer -- 8.1 ms against 7.8)
     const uint32_t m = lo - 1u + ps;  // (ps == 0 behind a consensus: its unchecked part stays, and the hop names no candidates)
     if (m == 0) return;
 
@@ -1641,6 +1647,7 @@ __device__ __forceinline__ void bfs_narrow(const BfsState &S, const SolidView &t
         const bool capped0 = max_kmers >= 0 && (long long)n >= max_kmers;
         const long long room = max_radius < 0 ? (long long)PATH_CAP : max_radius - level;  // levels that may still add
         const uint32_t FN = F << lg;  // nodes per level
+        const bool quad_mm = MC_QUAD_MINIMIZER != 0 && F == 1 && dir != 0 && (SH ? t.owner_mm_k : t.mm_k) != 0;  // (see where the nodes' slots are worked out)
         // x / F for x <= 512 and F <= 16 is (x * ceil(2^16 / F)) >> 16: integer divisions cost a lone wave ~30 instructions
         // each.  F rarely changes.
         if (F != div_f) { div_f = F; div_m = (65536u + F - 1) / F; }
@@ -1813,7 +1820,35 @@ __device__ __forceinline__ void bfs_narrow(const BfsState &S, const SolidView &t
                 nk = neighbour(v, k, dir, (int)c);
                 key = (uint64_t)key_of<MODE>(nk, k, &nflip);
             }
-            s0 = SH ? solid_locate(t, key, h) : solid_slot_of(t, key);
+            if (MODE == KEY_PACKED && quad_mm) {
+                // The counting table's region is the bin of the k-mer's MINIMIZER (kmer_device.h), the smallest of the hashes of its
+                // k - SK_M + 1 SK_M-mers -- 17 hashes a node when every thread works its own out (sk_hmin_of_kmer), two thirds of
+                // what a round's threads compute before their look-ups go out.  One walker, one direction: the four nodes of a level
+                // are the four lanes of a quad, neighbours of the SAME vertex v, and share all of v's SK_M-mers but one: each lane hashes
+                // a quarter of those, the quad takes the smallest (two DPP steps), and a lane adds the one SK_M-mer that holds its own base.
+                const uint32_t w1 = (uint32_t)k - SK_M;  // SK_M-mers of v that the neighbour keeps: v's all but its first (right) / last (left)
+                auto mm_hash = [](uint32_t f) {
+                    uint32_t r = __builtin_bitreverse32(f);
+                    r = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
+                    r = (~r) >> (32 - 2 * SK_M);
+                    return sk_order(f < r ? f : r);
+                };
+                const bool lft = dir < 0;
+                uint32_t hm = SK_NONE;
+                for (uint32_t p = c + (lft ? 0u : 1u); p < w1 + (lft ? 0u : 1u); p += 4)  // (SK_M-mer p of v: its bases p .. p + SK_M - 1)
+                    hm = min(hm, mm_hash((uint32_t)(v.lo >> (2u * ((uint32_t)k - SK_M - p))) & SK_MMASK));
+                hm = min(hm, (uint32_t)__builtin_amdgcn_update_dpp((int)SK_NONE, (int)hm, 0xB1, 0xF, 0xF, false));  // quad_perm [1, 0, 3, 2]
+                hm = min(hm, (uint32_t)__builtin_amdgcn_update_dpp((int)SK_NONE, (int)hm, 0x4E, 0xF, 0xF, false));  // quad_perm [2, 3, 0, 1]
+                hm = min(hm, mm_hash((uint32_t)(lft ? nk.lo >> (2u * ((uint32_t)k - SK_M)) : nk.lo) & SK_MMASK));
+                if (SH) s0 = solid_locate(t, key, h, true, hm);
+                else s0 = ((((uint64_t)sk_bin(hm) * t.n_regions) >> 32) << MC_REGION_LG) | sk_home(key);
+#ifdef MC_BFS_CHECK_SLOTS
+                { TableRef h2 = own_table(t); const uint64_t want = SH ? solid_locate(t, key, h2) : solid_slot_of(t, key);
+                  if (want != s0) printf("[bfs] quad minimizer: slot %llu, solid_slot_of says %llu (key %llx, level %u, c %u, dir %d)\n", (unsigned long long)s0, (unsigned long long)want, (unsigned long long)key, lvl, c, dir); }
+#endif
+            } else {
+                s0 = SH ? solid_locate(t, key, h) : solid_slot_of(t, key);
+            }
             const uint64_t s1 = (s0 & ~(uint64_t)h.rmask) | ((s0 + 1) & h.rmask);
             a0 = *reinterpret_cast<const uint4 *>(h.slots + s0);
             a1 = *reinterpret_cast<const uint4 *>(h.slots + s1);
@@ -2025,23 +2060,30 @@ __device__ __forceinline__ void bfs_narrow(const BfsState &S, const SolidView &t
 union BfsLds {
     WideLds w;
     NarrowLds n;
-    TeamLds t;
 };
+
+// The scouts of a batch's jobs, one workgroup each, as a kernel of their own beside k_bfs (on another stream): its registers are
+// allotted for the hops alone.  (Rounds 2-4 ran them as the odd workgroups of k_bfs: one kernel, so one register allotment for the
+// walk and the scouts together -- 177 vector registers and ~290 scalar values parked in vector lanes, every use of one an
+// instruction of a lone wave.)  Correct whether or not the two grids are on the chip together: scout_companion says why.
+template <int MODE, bool SH = false>
+__global__ void __launch_bounds__(BFS_THREADS) k_bfs_scout(const BfsState *__restrict__ states, SolidView t, int k, int min_cov)
+{
+    __shared__ TeamLds lds;
+    const BfsState S = states[blockIdx.x];
+    if (S.box && t.reads) scout_companion<MODE, SH>(S, t, lds, k, min_cov);
+}
 
 template <int MODE, bool SH = false>
 __global__ void __launch_bounds__(BFS_THREADS) k_bfs(const BfsState *__restrict__ states, SolidView t, int k,
                                                      int min_cov, long long max_kmers, long long max_radius,
                                                      unsigned long long max_rounds, int companions)
 {
-    // companions: two workgroups per job -- 2j walks (this function), 2j + 1 scouts for it (scout_companion)
+    // companions: k_bfs_scout runs beside this grid, a workgroup per job that scouts for this one (scout_companion)
     __shared__ BfsLds lds;
-    const BfsState S = states[companions ? blockIdx.x >> 1 : blockIdx.x];
+    const BfsState S = states[blockIdx.x];
     BfsCtl *ctl = S.ctl;
     const uint32_t tid = threadIdx.x;
-    if (companions && (blockIdx.x & 1u)) {
-        if (S.box && t.reads) scout_companion<MODE, SH>(S, t, lds.t, k, min_cov);
-        return;
-    }
     if (ctl_ld(&ctl->status) != BFS_RUNNING) {  // finished (or waiting for the host) in an earlier launch
         if (companions && S.box && tid == 0) st_u32(&S.box->quit, 1u);
         return;

@@ -3833,16 +3833,26 @@ void launch_bfs(mc_ctx *c, hipStream_t stream, const BfsState *d_states, uint32_
                 int64_t max_radius, unsigned long long max_rounds, int companions)
 {
     const SolidView t = c->solid_view();
-    if (companions) n_jobs *= 2;
+    // companions: the scouts' kernel beside the walk's, on the side stream -- behind what the main stream has enqueued so far (the
+    // mailboxes' reset), and the main stream takes nothing up behind the walk before the scouts have left (they leave when the walk
+    // sets `quit`, which it does on every way out)
+    hipStream_t side = companions && c->pipe_stream ? c->pipe_stream : nullptr;
+    if (companions && !side) companions = 0;
+    if (side) {
+        if (hipEventRecord(c->ev_piece[0], stream) != hipSuccess || hipStreamWaitEvent(side, c->ev_piece[0], 0) != hipSuccess) { side = nullptr; companions = 0; }
+    }
     // (SH: the walk over several ranks' tables, every look-up through its key's owner; the one-table kernel carries none of that)
 #define BFS_LAUNCH(MODE)                                                                                                          \
     do {                                                                                                                          \
-        if (t.n_shards > 1)                                                                                                       \
+        if (t.n_shards > 1) {                                                                                                     \
+            if (side) hipLaunchKernelGGL((k_bfs_scout<MODE, true>), dim3(n_jobs), dim3(BFS_THREADS), 0, side, d_states, t, c->cfg.k, min_cov); \
             hipLaunchKernelGGL((k_bfs<MODE, true>), dim3(n_jobs), dim3(BFS_THREADS), 0, stream, d_states, t, c->cfg.k, min_cov,    \
                                (long long)max_kmers, (long long)max_radius, max_rounds, companions);                              \
-        else                                                                                                                      \
+        } else {                                                                                                                  \
+            if (side) hipLaunchKernelGGL((k_bfs_scout<MODE, false>), dim3(n_jobs), dim3(BFS_THREADS), 0, side, d_states, t, c->cfg.k, min_cov); \
             hipLaunchKernelGGL((k_bfs<MODE, false>), dim3(n_jobs), dim3(BFS_THREADS), 0, stream, d_states, t, c->cfg.k, min_cov,   \
                                (long long)max_kmers, (long long)max_radius, max_rounds, companions);                              \
+        }                                                                                                                         \
     } while (0)
     switch (c->cfg.key_mode) {
     case MC_KEY_PACKED: BFS_LAUNCH(KEY_PACKED); break;
@@ -3850,6 +3860,10 @@ void launch_bfs(mc_ctx *c, hipStream_t stream, const BfsState *d_states, uint32_
     default: BFS_LAUNCH(KEY_FNV1A);
     }
 #undef BFS_LAUNCH
+    if (side) {
+        (void)hipEventRecord(c->ev_piece[1], side);
+        (void)hipStreamWaitEvent(stream, c->ev_piece[1], 0);
+    }
 }
 
 }  // namespace

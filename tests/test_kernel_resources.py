@@ -31,8 +31,8 @@ def _kernel_notes(tmp_path):
 
 def test_the_walk_and_the_merge_kernel_use_no_scratch_memory(tmp_path):
     kernels = _kernel_notes(tmp_path)
-    walk = {n: r for n, r in kernels.items() if "k_bfsILi" in n}
-    assert len(walk) == 6  # three key modes x (one table, several ranks' tables)
+    walk = {n: r for n, r in kernels.items() if "k_bfsILi" in n or "k_bfs_scoutILi" in n}
+    assert len(walk) == 12  # the walk and its scouts' kernel: three key modes x (one table, several ranks' tables) each
     for name, r in list(walk.items()) + [(n, r) for n, r in kernels.items() if "k_p3_dedup" in n or "k_sk1w_extract" in n]:
         assert r["private_segment_fixed_size"] == 0 and r["vgpr_spill_count"] == 0, (name, r)
     # the merge kernel's two workgroups a CU: 2 x 81.8 KB of the CU's 160 KB of LDS, and at most 128 registers for 4 waves a SIMD
