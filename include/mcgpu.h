@@ -258,6 +258,9 @@ int mc_add_superkmers_dev(mc_ctx *ctx, const uint64_t *d_records, const uint32_t
  *                    minimizer; 0: it dealt keys (mc_key_owner).  From here on mc_bfs / mc_bfs_batch on this context walk the
  *                    union of the tables, any --coverage; results equal a single context's.  mc_get / mc_export still see
  *                    this context's own shard only.
+ *                    An attachment names every table's block and geometry AS THEY WERE: any call that changes this context's
+ *                    counts afterwards (mc_add_*, which may also move the table) drops it, and mc_bfs then fails with
+ *                    MC_ESTATE until the tables are exported and attached again (or mc_shard_detach says one table is meant).
  *   mc_shard_detach  gives the mappings up (mc_clear and mc_destroy do so too). */
 typedef struct { unsigned char bytes[128]; } mc_shard_handle;
 int mc_shard_export(mc_ctx *ctx, mc_shard_handle *out);

@@ -2176,6 +2176,579 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_dedup(const uint4 *__restrict
     }
 }
 
+// =============================================================================================
+// k_p3_dedup2 (round 5): the same merge -- identical records first, then the distinct ones' windows into the region image --
+// with the expansion rebuilt around what round 4's counters and the kernel's ISA showed: a window cost a byte-table read,
+// FIVE cross-lane reads (ds_bpermute: 24 ticks of the SIMD's LDS port each), 21 vector instructions for its two strands
+// and a probe loop of its own; the prefix over a wave's records was six dependent ds_bpermutes; and the eight waves'
+// shares of a leaf differed by a quarter.  Here
+//   * the unit of work is a PAIR of windows of one record: its lane reads the record itself from the record table (one
+//     ds_read_b128 -- lanes of one record read the same address: a broadcast), cuts the 32 bases the pair spans out once,
+//     reverse-complements them once, and both windows' strands are shifts and masks of those two words;
+//   * the two keys go through ONE probe loop (lds_probe_claim2: both compare-and-swaps of a step in flight together), the
+//     two count additions likewise;
+//   * the units of ALL distinct records of the leaf are lined up in one list (a DPP prefix per wave, one LDS atomic per wave
+//     for its place) and every wave takes an eighth of the list;
+//   * which occurrence leaves its pointer is decided by two bits of the home-slot hash the window needs anyway.
+// Results are those of k_p3_dedup (every parity test runs through this kernel; MC_P3_V2=0 launches the old one).
+#ifndef MC_D2_THREADS
+#define MC_D2_THREADS 512
+#endif
+#ifndef MC_D2_UL_CAP
+#define MC_D2_UL_CAP 1976
+#endif
+constexpr int D2_THREADS = MC_D2_THREADS;           // threads of the workgroup that merges a leaf
+#ifndef MC_D2_SLOTS
+#define MC_D2_SLOTS 1024
+#endif
+#ifndef MC_D2_WAVES_PER_EU
+#define MC_D2_WAVES_PER_EU (MC_D2_THREADS / 128)   // two workgroups on a CU: 4 waves a SIMD with 512 threads (128 registers), 8 with 1024 (64)
+#endif
+constexpr uint32_t D2_SLOTS = MC_D2_SLOTS;          // its record table (a leaf of configs[1] holds ~250 distinct records)
+constexpr int D2_NQ = D2_SLOTS / D2_THREADS;        // record table slots, and records of a round, per thread
+static_assert(D2_NQ * D2_THREADS == (int)D2_SLOTS && (D2_NQ == 1 || D2_NQ == 2), "one or two record slots per thread");
+constexpr uint32_t D2_UL_CAP = MC_D2_UL_CAP;        // units queued at a time (a leaf of configs[1] holds ~1300)
+constexpr uint32_t D2_CP_MASK = 0xFFFu;  // copies of a record: <= DD_MAX_CAP = 2048
+
+struct alignas(16) Dedup2Lds {
+    uint64_t key[REGION_SLOTS];         // at LDS address 0: the probe loop's addresses are offsets into it
+    uint32_t ca[REGION_SLOTS];          // count | (1 + (record slot << 4 | window)) << DD_CNT_BITS
+    uint4 drec[D2_SLOTS];               // {d0, d1, d2 | windows - 1, fingerprint << 16 | 0x8000 | copies}: the bases top-aligned in d0:d1:d2; .w == 0: free
+    uint32_t dptr[3][D2_SLOTS];
+    uint16_t ul[D2_UL_CAP];             // record slot << 3 | pair number
+    uint32_t n_new, overflow, emit_cur, n_units;
+};
+static_assert(sizeof(Dedup2Lds) * (1024 / D2_THREADS) <= 160 * 1024, "sixteen waves of the merge kernel on a CU");
+
+// kmer_device.h rc64_pairs word by word: the bits reversed, the two bits of every base swapped back (one v_bfi), complemented
+__device__ __forceinline__ uint32_t rc32_pairs_fast(uint32_t x)
+{
+    const uint32_t r = __builtin_bitreverse32(x);
+    return ~(((r << 1) & 0xAAAAAAAAu) | ((r >> 1) & ~0xAAAAAAAAu));
+}
+__device__ __forceinline__ uint64_t rc64_pairs_fast(uint64_t x)
+{
+    return ((uint64_t)rc32_pairs_fast((uint32_t)x) << 32) | rc32_pairs_fast((uint32_t)(x >> 32));
+}
+
+// inclusive prefix sum over the wave's lanes (row_shr 1, 2, 4, 8 inside a row of sixteen, then the rows' totals: row_bcast 15 / 31)
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+    return v;
+}
+
+// lds_probe_claim for two keys a lane: offA / offB = byte offsets of the home slots in the key array AT LDS ADDRESS 0, mA / mB =
+// the lanes that hold a first / a second key.  Both compare-and-swaps of a step travel together; a lane is done with a key
+// when it found it or claimed a free slot.  On return offX = the slot's byte offset, *pendX = lanes whose key found no room
+// in P3_MAX_PROBES steps; *n_new_wave += keys the wave inserted.
+__device__ __forceinline__ void lds_probe_claim2(uint32_t &offA, uint32_t &offB, uint64_t keyA, uint64_t keyB, unsigned long long mA,
+                                                 unsigned long long mB, uint32_t *n_new_wave, unsigned long long *pendA,
+                                                 unsigned long long *pendB)
+{
+    unsigned long long oldA, oldB, sv, hit;
+    uint32_t cnt, t, it;
+    const unsigned long long empty = EMPTY_KEY;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b32 %[cnt], 0\n\t"
+        "s_mov_b32 %[it], %[maxp]\n"
+        "1:\n\t"
+        "s_mov_b64 exec, %[mA]\n\t"
+        "ds_cmpst_rtn_b64 %[oldA], %[offA], %[empty], %[keyA]\n\t"
+        "s_mov_b64 exec, %[mB]\n\t"
+        "ds_cmpst_rtn_b64 %[oldB], %[offB], %[empty], %[keyB]\n\t"
+        "s_mov_b64 exec, %[mA]\n\t"
+        "s_waitcnt lgkmcnt(1)\n\t"
+        "v_cmp_eq_u64 vcc, %[oldA], %[empty]\n\t"
+        "v_cmp_eq_u64 %[hit], %[oldA], %[keyA]\n\t"
+        "s_bcnt1_i32_b64 %[t], vcc\n\t"
+        "s_add_u32 %[cnt], %[cnt], %[t]\n\t"
+        "s_or_b64 vcc, vcc, %[hit]\n\t"
+        "s_andn2_b64 %[mA], %[mA], vcc\n\t"
+        "s_mov_b64 exec, %[mA]\n\t"
+        "v_add_u32 %[offA], 8, %[offA]\n\t"
+        "v_and_b32 %[offA], %[wrap], %[offA]\n\t"
+        "s_mov_b64 exec, %[mB]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_eq_u64 vcc, %[oldB], %[empty]\n\t"
+        "v_cmp_eq_u64 %[hit], %[oldB], %[keyB]\n\t"
+        "s_bcnt1_i32_b64 %[t], vcc\n\t"
+        "s_add_u32 %[cnt], %[cnt], %[t]\n\t"
+        "s_or_b64 vcc, vcc, %[hit]\n\t"
+        "s_andn2_b64 %[mB], %[mB], vcc\n\t"
+        "s_mov_b64 exec, %[mB]\n\t"
+        "v_add_u32 %[offB], 8, %[offB]\n\t"
+        "v_and_b32 %[offB], %[wrap], %[offB]\n\t"
+        "s_or_b64 %[hit], %[mA], %[mB]\n\t"
+        "s_cbranch_scc0 2f\n\t"
+        "s_sub_u32 %[it], %[it], 1\n\t"
+        "s_cmp_lg_u32 %[it], 0\n\t"
+        "s_cbranch_scc1 1b\n"
+        "2:\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        : [offA] "+v"(offA), [offB] "+v"(offB), [mA] "+s"(mA), [mB] "+s"(mB), [oldA] "=&v"(oldA), [oldB] "=&v"(oldB), [sv] "=&s"(sv),
+          [hit] "=&s"(hit), [cnt] "=&s"(cnt), [t] "=&s"(t), [it] "=&s"(it)
+        : [empty] "v"(empty), [keyA] "v"(keyA), [keyB] "v"(keyB), [wrap] "s"((uint32_t)(REGION_SLOTS * 8u - 8u)), [maxp] "s"((uint32_t)P3_MAX_PROBES)
+        : "vcc", "scc", "memory");
+    *n_new_wave += cnt;
+    *pendA = mA;
+    *pendB = mB;
+}
+
+template <bool VIRGIN>
+__global__ void __launch_bounds__(D2_THREADS, MC_D2_WAVES_PER_EU) k_p3_dedup2(const uint4 *__restrict__ leaf_recs, const uint32_t *__restrict__ leaf_ptrs,
+                                                          const uint32_t *__restrict__ leaf_counts, uint64_t seg_cap, uint32_t n_leaves,
+                                                          TableView t, uint32_t *leaf_state, uint32_t *leaf_new, uint32_t *any_failed,
+                                                          uint32_t solid_thr, unsigned long long *n_solid, int k, P3Emit emit,
+                                                          uint32_t ptr_tries, const uint32_t *lost)
+{
+    if (lost && *lost) return;
+    __shared__ Dedup2Lds L;
+    const uint32_t tid = threadIdx.x, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = tid & 63u;
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint64_t *)L.key != 0u) {  // (uniform; never: the kernel's one LDS object)
+        if (tid == 0) atomicExch(any_failed, 1u);
+        return;
+    }
+    const bool emitting = emit.recs != nullptr && solid_thr != 0;
+    if (tid == 0) L.emit_cur = emitting ? emit.counts[blockIdx.x] : 0u;
+    auto clear_records = [&] {  // the record table's tags and pointer fields (trip counts known: no loop bookkeeping)
+#pragma unroll
+        for (int it = 0; it < D2_NQ; it++) L.drec[tid + (uint32_t)it * D2_THREADS].w = 0;
+        static_assert((3 * D2_SLOTS / 4) % D2_THREADS == 0 || (3 * D2_SLOTS / 4) < D2_THREADS || D2_THREADS == 512, "dptr in whole steps");
+#pragma unroll
+        for (int it = 0; it < (int)((3 * D2_SLOTS / 4 + D2_THREADS - 1) / D2_THREADS); it++) {
+            const uint32_t i = tid + (uint32_t)it * D2_THREADS;
+            if (i < 3 * D2_SLOTS / 4) reinterpret_cast<uint4 *>(L.dptr)[i] = make_uint4(0, 0, 0, 0);
+        }
+    };
+    clear_records();
+    long long solid_delta = 0;
+    const uint32_t ptr_from = solid_thr >= 2 ? 1u : 0u;
+    const uint32_t sh_a = 64u - 2u * (uint32_t)k, sh_b = 62u - 2u * (uint32_t)k;  // (k <= 31: a pair of windows spans k + 1 <= 32 bases)
+    const uint64_t kmask = ~0ull >> sh_a;
+    uint32_t pick_tbl = 0;  // ptr_pick's choice for the four values of its two bits
+    for (uint32_t r = 0; r < 4; r++) pick_tbl |= (ptr_pick((uint64_t)r, ptr_from, solid_thr) - ptr_from) << (2 * r);
+
+    uint32_t new_wave = 0;   // keys this WAVE inserted in the pair loop (the same number in every lane)
+    uint32_t new_mine = 0;   // ... and this lane, for records that got no place in the record table
+    uint32_t cur_leaf = 0;
+    // one occurrence set of `key` (inc copies) by the plain rule: records without a place in the record table (a fingerprint
+    // met another record's, or eight occupied places: one leaf in a thousand has such a record)
+    auto add_plain = [&](uint64_t key, uint32_t inc) {
+        uint32_t s = sk_home(key);
+#pragma unroll 1
+        for (uint32_t p = 0; p < P3_MAX_PROBES; p++) {
+            const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&L.key[s]), (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+            if (old == EMPTY_KEY || old == key) {
+                new_mine += old == EMPTY_KEY;
+                atomicAdd(&L.ca[s], inc);
+                return;
+            }
+            s = (s + 1u) & (REGION_SLOTS - 1u);
+        }
+        if (!ovf_push(t, key, inc, 0u, cur_leaf)) atomicExch(&L.overflow, 1u);
+    };
+
+#ifdef MC_P3_TIMING
+    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memrealtime(), n_lv = 0;
+#define P3E_STAMP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); tph[i] += n_ - tl; tl = n_; } while (0)
+#else
+#define P3E_STAMP(i) do {} while (0)
+#endif
+    uint32_t st_nxt = 1u, n_nxt = 0;
+    uint4 pre_rec[D2_NQ];
+    uint32_t pre_ptr[D2_NQ];
+#pragma unroll
+    for (int q = 0; q < D2_NQ; q++) { pre_rec[q] = make_uint4(0, 0, 0, 0); pre_ptr[q] = 0; }
+    auto fetch = [&](uint32_t lf, uint32_t n) {  // this thread's first records of leaf lf
+#pragma unroll
+        for (int q = 0; q < D2_NQ; q++) {
+            const uint32_t r = tid + (uint32_t)q * D2_THREADS;
+            if (r < n) {
+                pre_rec[q] = leaf_recs[(uint64_t)lf * seg_cap + r];
+                pre_ptr[q] = leaf_ptrs ? leaf_ptrs[(uint64_t)lf * seg_cap + r] : pre_rec[q].x;  // (no array: the record's first word, k_sk2_scatter_compact)
+            }
+        }
+    };
+    if (blockIdx.x < n_leaves) {
+        st_nxt = leaf_state[blockIdx.x];
+        n_nxt = min(leaf_counts[blockIdx.x], (uint32_t)seg_cap);
+        fetch(blockIdx.x, n_nxt);
+    }
+    __syncthreads();
+    for (uint32_t leaf = blockIdx.x; leaf < n_leaves; leaf += gridDim.x) {
+        const uint32_t st_cur = st_nxt, n0 = n_nxt;
+        uint4 cur_rec[D2_NQ];
+        uint32_t cur_ptr[D2_NQ];
+#pragma unroll
+        for (int q = 0; q < D2_NQ; q++) { cur_rec[q] = pre_rec[q]; cur_ptr[q] = pre_ptr[q]; }
+        const uint32_t nl = leaf + gridDim.x;
+        if (nl < n_leaves) {
+            st_nxt = leaf_state[nl];
+            n_nxt = min(leaf_counts[nl], (uint32_t)seg_cap);
+        }
+        if (st_cur || n0 > DD_MAX_CAP) {  // uniform; a leaf of more records than the packed counters are safe for is left
+            if (nl < n_leaves) fetch(nl, n_nxt);  // to k_p3_merge, which the host enqueues behind this kernel
+            continue;
+        }
+        P3E_STAMP(7);
+        Slot *gs = t.slots + (uint64_t)leaf * REGION_SLOTS;
+        const uint4 *recs = leaf_recs + (uint64_t)leaf * seg_cap;
+        const uint32_t *ptrs = leaf_ptrs + (uint64_t)leaf * seg_cap;
+        int solid_before = 0;
+        if (VIRGIN) {  // 16 bytes a store
+            static_assert((REGION_SLOTS / 4) % D2_THREADS == 0, "the image is cleared in whole steps");
+#pragma unroll
+            for (int it = 0; it < (int)(REGION_SLOTS / 2 / D2_THREADS); it++) reinterpret_cast<uint4 *>(L.key)[tid + (uint32_t)it * D2_THREADS] = make_uint4(~0u, ~0u, ~0u, ~0u);
+#pragma unroll
+            for (int it = 0; it < (int)(REGION_SLOTS / 4 / D2_THREADS); it++) reinterpret_cast<uint4 *>(L.ca)[tid + (uint32_t)it * D2_THREADS] = make_uint4(0, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int it = 0; it < (int)(REGION_SLOTS / D2_THREADS); it++) {
+                const uint32_t i = tid + (uint32_t)it * D2_THREADS;
+                const uint4 raw = *reinterpret_cast<const uint4 *>(gs + i);
+                L.key[i] = ((uint64_t)raw.y << 32) | raw.x;
+                L.ca[i] = min(raw.z, 32767u);  // (anything above reads the same: kmer_device.h table_get)
+                solid_before += solid_thr && raw.z >= solid_thr;  // (empty slots hold count 0)
+            }
+        }
+        if (tid == 0) { L.n_new = 0; L.overflow = 0; L.n_units = 0; }
+        new_wave = 0;
+        new_mine = 0;
+        cur_leaf = leaf;
+        // ---- A: the records into the record table, 1024 at a time (nearly always all of them)
+        for (uint32_t base = 0; base < n0; base += D2_SLOTS) {  // uniform
+            uint32_t e0[D2_NQ], e1[D2_NQ], e2[D2_NQ], rptr[D2_NQ], sl[D2_NQ];
+            bool have[D2_NQ];
+#pragma unroll
+            for (int q = 0; q < D2_NQ; q++) {
+                const uint32_t r = base + (uint32_t)q * D2_THREADS + tid;
+                have[q] = r < n0;
+                sl[q] = DD_NONE;
+                uint4 rec;
+                if (base == 0) { rec = cur_rec[q]; rptr[q] = cur_ptr[q]; }
+                else if (have[q]) { rec = recs[r]; rptr[q] = leaf_ptrs ? ptrs[r] : rec.x; }
+                else { rec = make_uint4(0, 0, 0, 0); rptr[q] = 0; }
+                // the record's 46 bases top-aligned in three words, windows - 1 in the four bits below them
+                e0[q] = __builtin_amdgcn_alignbit(rec.w, rec.z, 28);
+                e1[q] = __builtin_amdgcn_alignbit(rec.z, rec.y, 28);
+                e2[q] = (rec.y << 4) | (rec.w >> 28);
+                if (have[q]) {
+                    const uint32_t h = dd_hash(rec.y, rec.z, rec.w), tag = (h & 0xFFFF0000u) | 0x8000u;
+                    uint32_t slot = h & (D2_SLOTS - 1);
+                    for (uint32_t p = 0; p < DD_PROBES; p++) {
+                        const uint32_t old = atomicCAS(&L.drec[slot].w, 0u, tag);
+                        if (old == 0) {  // claimed: this copy's words are what the others are compared with
+                            L.drec[slot].x = e0[q]; L.drec[slot].y = e1[q]; L.drec[slot].z = e2[q];  // (its pointer fields were cleared with the table)
+                            sl[q] = slot | DD_OWNER;
+                            break;
+                        }
+                        if ((old & 0xFFFF8000u) == tag) { sl[q] = slot; break; }
+                        slot = (slot + 1) & (D2_SLOTS - 1);
+                    }
+                }
+            }
+            P3E_STAMP(0);
+            __syncthreads();
+            P3E_STAMP(1);
+#pragma unroll
+            for (int q = 0; q < D2_NQ; q++) {
+                if (sl[q] != DD_NONE) {
+                    const uint32_t slot = sl[q] & ~DD_OWNER;
+                    bool same = true;
+                    if (!(sl[q] & DD_OWNER)) {
+                        const uint4 e = L.drec[slot];
+                        same = e.x == e0[q] && e.y == e1[q] && e.z == e2[q];
+                    }
+                    if (same) {
+                        // the first three copies that carry a read pointer are remembered (the occurrences of neighbouring
+                        // k-mers arrive in the same order: kmer_device.h ptr_pick says why one pointer per record is too few)
+                        const uint32_t c = atomicAdd(&L.drec[slot].w, 1u) & D2_CP_MASK;
+                        if (rptr[q]) {
+                            if (c < 3u) {
+                                L.dptr[c][slot] = rptr[q];
+                            } else if (ptr_tries > 1) {  // (copies of other ranks carry none: a later one fills a field that stayed empty)
+                                for (uint32_t f = 0; f < 3u; f++)
+                                    if (L.dptr[f][slot] == 0) { L.dptr[f][slot] = rptr[q]; break; }
+                            }
+                        }
+                    } else {
+                        sl[q] = DD_NONE;  // another record with this fingerprint
+                    }
+                }
+                // a record without a place goes into the region image as it is: one copy of every window, no pointer
+                if (have[q] && sl[q] == DD_NONE) {
+                    const uint32_t nw = (e2[q] & 15u) + 1u;
+                    const uint64_t top = ((uint64_t)e0[q] << 32) | e1[q];
+                    for (uint32_t j = 0; j < nw; j++) {
+                        const uint32_t sh = 2u * j;
+                        const uint64_t fw = ((top << sh) | (uint64_t)((e2[q] >> 1) >> (31u - sh))) >> sh_a, rc = rc_packed(fw, k);
+                        add_plain(rc < fw ? rc : fw, 1u);
+                    }
+                }
+            }
+        }
+        // ---- the pairs of windows of all distinct records, lined up (a record table slot belongs to one thread; its tag and
+        // window count were written before the barrier above, and the copies are only read behind the next one)
+        uint32_t u_cnt[D2_NQ], u_at[D2_NQ];
+        {
+            uint32_t mine = 0;
+#pragma unroll
+            for (int q = 0; q < D2_NQ; q++) {
+                const uint32_t slot = tid + (uint32_t)q * D2_THREADS;
+                const uint2 zw = *reinterpret_cast<const uint2 *>(&L.drec[slot].z);
+                u_cnt[q] = zw.y ? ((zw.x & 15u) + 2u) >> 1 : 0u;
+                mine += u_cnt[q];
+            }
+            const uint32_t incl = wave_incl_sum(mine);
+            uint32_t wbase = 0;
+            if (lane == 63u && incl) wbase = atomicAdd(&L.n_units, incl);
+            wbase = (uint32_t)__builtin_amdgcn_readlane((int)wbase, 63);
+            u_at[0] = wbase + incl - mine;
+#pragma unroll
+            for (int q = 1; q < D2_NQ; q++) u_at[q] = u_at[q - 1] + u_cnt[q - 1];
+        }
+        auto line_up = [&](uint32_t r0) {  // the units r0 .. r0 + D2_UL_CAP - 1 into the list
+            // (uniform: a wave whose units all fall into the round -- nearly always -- stores without looking)
+            const uint32_t w_lo = (uint32_t)__builtin_amdgcn_readlane((int)u_at[0], 0);
+            const uint32_t w_hi = (uint32_t)__builtin_amdgcn_readlane((int)(u_at[D2_NQ - 1] + u_cnt[D2_NQ - 1]), 63);
+            const bool inside = w_lo >= r0 && w_hi <= r0 + D2_UL_CAP;
+#pragma unroll
+            for (int q = 0; q < D2_NQ; q++) {
+                uint32_t val = (tid + (uint32_t)q * D2_THREADS) << 3;
+                uint16_t *dst = &L.ul[u_at[q] - r0];
+                if (inside) {
+#pragma unroll 1
+                    for (uint32_t left = u_cnt[q]; left; left--) *dst++ = (uint16_t)val++;
+                } else {
+                    for (uint32_t u = 0; u < u_cnt[q]; u++) {
+                        const uint32_t at = u_at[q] + u - r0;
+                        if (at < D2_UL_CAP) L.ul[at] = (uint16_t)(val | u);
+                    }
+                }
+            }
+        };
+        line_up(0);
+        P3E_STAMP(2);
+        __syncthreads();
+        P3E_STAMP(3);
+        // ---- B: the pairs into the region image, an eighth of the list per wave
+        const uint32_t n_units = L.n_units;
+        const bool one_round = n_units <= D2_UL_CAP;
+        uint32_t *wl = reinterpret_cast<uint32_t *>(L.ul);
+        for (uint32_t r0 = 0; r0 < n_units; r0 += D2_UL_CAP) {  // uniform; nearly always one round
+            if (r0) {
+                __syncthreads();
+                line_up(r0);
+                __syncthreads();
+            }
+            const uint32_t nr = min(n_units - r0, D2_UL_CAP);
+            const uint32_t lo = (nr * wv) / (D2_THREADS / 64), hi = (nr * (wv + 1u)) / (D2_THREADS / 64);
+            const uint32_t wbeg = (lo + 1u) >> 1;
+            uint32_t wcur = wbeg;  // (uniform) the wave's notes: 32-bit words of its own part of the list, behind what it has read
+#ifdef MC_P3_NOB   // (timing experiments: the tables of such builds are not usable)
+            if (n_leaves) continue;
+#endif
+#pragma unroll 1
+            for (uint32_t b = lo; b < hi; b += 64) {  // uniform
+                const uint32_t idx = b + lane;
+                const bool va = idx < hi;
+                const uint32_t ue = va ? (uint32_t)L.ul[idx] : 0u;
+                const uint32_t slot = ue >> 3, u = ue & 7u;
+                const uint4 e = L.drec[slot];
+                const uint32_t nw = (e.z & 15u) + 1u, ja = 2u * u, cp = e.w & D2_CP_MASK;
+                const bool vb = va && ja + 1u < nw;
+                // the 32 bases from the pair's first one on, and their reverse complement
+                const uint32_t sh = 4u * u;  // <= 28
+                const uint64_t X = ((((uint64_t)e.x << 32) | e.y) << sh) | (uint64_t)((e.z >> 1) >> (31u - sh));
+                const uint64_t R = rc64_pairs_fast(X);
+                const uint64_t fa = X >> sh_a, fb = (X >> sh_b) & kmask, ra = R & kmask, rb = (R >> 2) & kmask;
+                const uint64_t keyA = ra < fa ? ra : fa, keyB = rb < fb ? rb : fb;
+                const uint32_t hxA = sk_home_mix(keyA), hxB = sk_home_mix(keyB);
+                uint32_t offA = (hxA >> (32 - MC_REGION_LG)) << 3, offB = (hxB >> (32 - MC_REGION_LG)) << 3;
+                unsigned long long pendA, pendB;
+                lds_probe_claim2(offA, offB, keyA, keyB, __ballot(va), __ballot(vb), &new_wave, &pendA, &pendB);
+                const bool okA = va && !((pendA >> lane) & 1ull), okB = vb && !((pendB >> lane) & 1ull);
+                // (a lane without a key adds nothing to a word of its own)
+                const uint32_t sA = okA ? offA >> 3 : lane, sB = okB ? offB >> 3 : lane;
+                const uint32_t befA = atomicAdd(&L.ca[sA], okA ? cp : 0u) & DD_CNT_MASK;
+                const uint32_t befB = atomicAdd(&L.ca[sB], okB ? cp : 0u) & DD_CNT_MASK;
+                // the count an occurrence leaves its pointer at (kmer_device.h ptr_pick: here by two bits of the home-slot hash)
+                const uint32_t firstA = ptr_from + 1u + ((pick_tbl >> ((hxA >> 17) & 6u)) & 3u);
+                const uint32_t firstB = ptr_from + 1u + ((pick_tbl >> ((hxB >> 17) & 6u)) & 3u);
+                const bool wantA = okA && befA < firstA + ptr_tries - 1u && befA + cp >= firstA;  // (one addition per key when ptr_tries == 1)
+                const bool wantB = okB && befB < firstB + ptr_tries - 1u && befB + cp >= firstB;
+                const unsigned long long wmA = __ballot(wantA), wmB = __ballot(wantB);
+                if (wmA | wmB) {  // uniform
+                    const uint32_t wnA = (uint32_t)__popcll(wmA), wnB = (uint32_t)__popcll(wmB);
+                    if (one_round) {
+                        // ... is noted in the part of the list this wave has used up: (slot of the region, slot of the record, window)
+                        const uint32_t wlim = min(b + 64u, hi) >> 1;
+                        const uint32_t iA = wcur + __builtin_amdgcn_mbcnt_hi((uint32_t)(wmA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wmA, 0u));
+                        const uint32_t iB = wcur + wnA + __builtin_amdgcn_mbcnt_hi((uint32_t)(wmB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wmB, 0u));
+                        if (wantA && iA < wlim) wl[iA] = sA << 14 | slot << 4 | ja;
+                        if (wantB && iB < wlim) wl[iB] = sB << 14 | slot << 4 | (ja + 1u);
+                        wcur = min(wcur + wnA + wnB, wlim);  // (what finds no room leaves no pointer: a hint less)
+                    } else {
+                        // a leaf of more units than the list holds: (record slot, window) beside the count, worked out when the region goes back
+                        const uint32_t occA = (((slot << 4) | ja) + 1u) << DD_CNT_BITS, occB = occA + (1u << DD_CNT_BITS);
+                        // (records of other ranks carry no pointer: theirs must not take the field)
+                        const bool hp = ptr_tries == 1 || (L.dptr[0][slot] | L.dptr[1][slot] | L.dptr[2][slot]) != 0;
+                        if (wantA && hp)
+                            for (int a = 0; a < 4; a++) {
+                                const uint32_t cur = L.ca[sA];
+                                if ((cur >> DD_CNT_BITS) != 0 || atomicCAS(&L.ca[sA], cur, cur | occA) == cur) break;
+                            }
+                        if (wantB && hp)
+                            for (int a = 0; a < 4; a++) {
+                                const uint32_t cur = L.ca[sB];
+                                if ((cur >> DD_CNT_BITS) != 0 || atomicCAS(&L.ca[sB], cur, cur | occB) == cur) break;
+                            }
+                    }
+                }
+                if (va && !okA && !ovf_push(t, keyA, cp, 0u, cur_leaf)) atomicExch(&L.overflow, 1u);
+                if (vb && !okB && !ovf_push(t, keyB, cp, 0u, cur_leaf)) atomicExch(&L.overflow, 1u);
+            }
+            // the wave's notes become pointers, a lane each: one of the record's (up to three) copies' pointers, moved on to the
+            // window; the region slot gets the note's place, and the write-back finds the pointer there
+#pragma unroll 1
+            for (uint32_t i0 = wbeg; i0 < wcur; i0 += 64) {  // uniform; one turn
+                const uint32_t i = i0 + lane;
+                if (i < wcur) {
+                    const uint32_t e = wl[i], rs = (e >> 4) & (D2_SLOTS - 1u), j = e & 15u, sg = e >> 14;
+                    const uint32_t r = sg & 3u, f = r == 3u ? 0u : r;
+                    uint32_t p0 = L.dptr[f][rs];
+                    if (p0 == 0) p0 = L.dptr[0][rs];
+                    if (ptr_tries > 1 && p0 == 0) p0 = L.dptr[1][rs] ? L.dptr[1][rs] : L.dptr[2][rs];  // (fields fill in the order of ALL copies there)
+                    const uint32_t pw = p0 - 1u < 0x7FFFFFEFu ? p0 + j : ptr_advance(p0, j);  // (exact pointers: kmer_device.h ptr_advance's first case)
+                    wl[i] = pw;
+                    if (pw) {
+                        const uint32_t occ = (i + 1u) << DD_CNT_BITS;
+                        if (ptr_tries == 1) {
+                            atomicOr(&L.ca[sg], occ);
+                        } else {  // (records of other ranks carry no pointer: the first occurrence that has one takes the field)
+                            for (int a = 0; a < 4; a++) {
+                                const uint32_t cur = L.ca[sg];
+                                if ((cur >> DD_CNT_BITS) != 0 || atomicCAS(&L.ca[sg], cur, cur | occ) == cur) break;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (nl < n_leaves) fetch(nl, n_nxt);  // the next leaf's first records: its count has long arrived
+        {
+            uint32_t mine = new_mine;  // (rare: the wave's lanes differ)
+            if (__ballot(mine != 0)) {
+                for (uint32_t o = 32; o; o >>= 1) mine += __shfl_xor(mine, o);
+                new_wave += mine;
+            }
+        }
+        if (lane == 0 && new_wave) atomicAdd(&L.n_new, new_wave);
+        P3E_STAMP(4);
+        __syncthreads();
+        P3E_STAMP(5);
+        const bool ovf = L.overflow != 0;
+        if (!ovf) {
+            // four slots of a thread at a time, their LDS words requested together
+            static_assert(REGION_SLOTS % (4 * D2_THREADS) == 0, "the region goes back in whole steps");
+#pragma unroll
+            for (int it = 0; it < (int)(REGION_SLOTS / (4 * D2_THREADS)); it++) {
+                const uint32_t i0 = tid + (uint32_t)it * 4u * D2_THREADS;
+                uint64_t kk[4];
+                uint32_t cc[4], pp[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t i = i0 + (uint32_t)u * D2_THREADS;
+                    kk[u] = L.key[i];
+                    cc[u] = L.ca[i];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t o = cc[u] >> DD_CNT_BITS;
+                    pp[u] = 0;
+                    if (o) {
+                        if (one_round) {
+                            pp[u] = wl[o - 1u];
+                        } else {  // the pointer of one of the record's copies, by bits of the key; the first copy's when that one has none
+                            const uint32_t sl = (o - 1u) >> 4, j = (o - 1u) & 15u;
+                            const uint32_t r = ((uint32_t)kk[u] >> 7) & 3u, f = r == 3u ? 0u : r;
+                            uint32_t p0 = L.dptr[f][sl];
+                            if (p0 == 0) p0 = L.dptr[0][sl];
+                            if (ptr_tries > 1 && p0 == 0) p0 = L.dptr[1][sl] ? L.dptr[1][sl] : L.dptr[2][sl];
+                            pp[u] = ptr_advance(p0, j);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t i = i0 + (uint32_t)u * D2_THREADS;
+                    uint4 v;
+                    v.x = (uint32_t)kk[u]; v.y = (uint32_t)(kk[u] >> 32);
+                    v.z = cc[u] & DD_CNT_MASK;
+                    v.w = pp[u];
+                    if (!VIRGIN && v.w == 0) v.w = reinterpret_cast<const uint32_t *>(gs + i)[3];  // the pointer the slot had
+#ifdef MC_P3_NOWB
+                    if (v.z == 0x12345u)
+#endif
+                    *reinterpret_cast<uint4 *>(gs + i) = v;
+                    const bool solid = solid_thr && v.z >= solid_thr;
+                    solid_delta += solid;
+                    if (emitting) {  // (uniform; the loop's trip count is the same for every lane)
+                        const unsigned long long m = __ballot(solid);
+                        if (m) {
+                            uint32_t ebase = 0;
+                            const int leader = __ffsll((long long)m) - 1;
+                            if ((int)lane == leader) ebase = atomicAdd(&L.emit_cur, (uint32_t)__popcll(m));
+                            ebase = __shfl(ebase, leader);
+                            if (solid) {
+                                const uint32_t pos = ebase + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+                                if (pos < emit.seg_cap) {
+                                    v.z = min(v.z, 32767u);
+                                    emit.recs[(uint64_t)blockIdx.x * emit.seg_cap + pos] = v;
+                                } else {
+                                    atomicExch(emit.lost, 1u);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            solid_delta -= solid_before;
+        } else if (VIRGIN) {  // nothing was there: leave a valid empty region behind
+#pragma unroll
+            for (int it = 0; it < (int)(REGION_SLOTS / D2_THREADS); it++) {
+                const uint32_t i = tid + (uint32_t)it * D2_THREADS;
+                uint4 v; v.x = 0xFFFFFFFFu; v.y = 0xFFFFFFFFu; v.z = 0; v.w = 0;
+                *reinterpret_cast<uint4 *>(gs + i) = v;
+            }
+        }
+        clear_records();
+        if (tid == 0) {
+            if (!ovf) { leaf_state[leaf] = 1; leaf_new[leaf] = L.n_new; } else atomicExch(any_failed, 1u);
+        }
+        P3E_STAMP(6);
+        __syncthreads();
+#ifdef MC_P3_TIMING
+        n_lv++;
+#endif
+    }
+#ifdef MC_P3_TIMING
+    if (blockIdx.x == 7 && (tid == 0 || tid == 448)) printf("[p3d2 block 7 thread %u] %llu leaves, us per leaf: init+A1 %.2f wait %.2f A2+line-up %.2f wait %.2f B %.2f wait %.2f writeback %.2f wait+next %.2f\n", tid, n_lv, tph[0] * 0.01 / n_lv, tph[1] * 0.01 / n_lv, tph[2] * 0.01 / n_lv, tph[3] * 0.01 / n_lv, tph[4] * 0.01 / n_lv, tph[5] * 0.01 / n_lv, tph[6] * 0.01 / n_lv, tph[7] * 0.01 / n_lv);
+#endif
+    if (solid_thr) wave_add_ull(n_solid, (unsigned long long)solid_delta);  // (two's complement: deltas may be negative)
+    if (emitting) {
+        __syncthreads();
+        if (tid == 0) emit.counts[blockIdx.x] = (uint64_t)L.emit_cur < emit.seg_cap ? L.emit_cur : (uint32_t)emit.seg_cap;
+    }
+}
+
 // n_used += sum(leaf_new): one atomic per workgroup instead of one per region on a single hot address
 __global__ void k_sum_leaf_new(const uint32_t *__restrict__ leaf_new, uint32_t n, unsigned long long *n_used)
 {

@@ -435,12 +435,13 @@ struct TableView {
 #ifndef MC_REGION_LG
 #define MC_REGION_LG 12   // log2 of the slots of a table region = of the merge kernel's LDS image (tuning builds override it)
 #endif
-__host__ __device__ __forceinline__ uint32_t sk_home(uint64_t key)
-{
+__host__ __device__ __forceinline__ uint32_t sk_home_mix(uint64_t key)
+{   // (the home slot is the top MC_REGION_LG bits; the merge kernel takes two more bits below them for its pointer rule)
     uint32_t x = (uint32_t)key * 0x9E3779B1u + (uint32_t)(key >> 32) * 0x85EBCA6Bu;
     x ^= x >> 15; x *= 0xC2B2AE35u;
-    return x >> (32 - MC_REGION_LG);
+    return x;
 }
+__host__ __device__ __forceinline__ uint32_t sk_home(uint64_t key) { return sk_home_mix(key) >> (32 - MC_REGION_LG); }
 
 // 32 bits whose TOP bits number the region of a key (and, in the counting pipeline, its buckets)
 __host__ __device__ __forceinline__ uint32_t bin32_of(uint64_t key, int mm_k)

@@ -279,6 +279,8 @@ struct mc_ctx {
     // device memory, ipc_opened the mappings of other processes' tables this context holds.
     std::vector<ShardRef> h_shards;
     ShardRef *d_shards = nullptr;
+    uint32_t shard_self = 0;
+    bool shards_dropped = false;  // an attachment was dropped because the table changed: the next walk must not quietly read this rank's table alone
     int shard_owner_mm_k = 0;
     std::vector<void *> ipc_opened;
     bool extract_by_minimizer = false; // mc_group: the next mc_extract_keys_dev call deals the keys to the owners of their minimizers (sk_owner), as the group's records are dealt (consumed by that call)
@@ -916,6 +918,16 @@ static int table_alloc(mc_ctx *c, uint64_t n_regions)
 }
 
 // the direct kernels, lookups and exports need real (EMPTY-initialised) slots
+namespace { void shard_detach_locked(mc_ctx *c); }
+// The table is about to hold other counts (or to move: growing and rehashing give the old block back to the pool): results
+// read before are void, and so is a walker's view of the ranks' tables (mc_shard_attach) -- it names this table's block
+// and geometry as they were.  ADVICE r4: the attachment used to survive, and the next walk read a freed block.
+static inline void counts_changed(mc_ctx *c)
+{
+    if (c->d_shards) { shard_detach_locked(c); c->shards_dropped = true; }
+    c->finalized = false;
+}
+
 static int materialize(mc_ctx *c)
 {
     if (!c->virgin) return MC_OK;
@@ -1422,12 +1434,12 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
     const uint32_t lseg = pl.b2 > 1 ? pl.pieces : pl.nseg1;
     // The solid list (P3Emit): super-k-mer form with the leaves in b_recs, so that a_recs is free to take it, and a
     // threshold to track.  Each P3 workgroup owns a segment.
-    const int p3_grid = (int)std::min<uint64_t>(n_leaves, 256 * 2 * 4);
+    const int p3_grid = (int)std::min<uint64_t>(n_leaves, 256 * 2 * 4 * (D2_THREADS < P3_THREADS ? P3_THREADS / D2_THREADS : 1));
     P3Emit emit{nullptr, nullptr, 0, P.flags + 2};
     static const bool no_list = getenv("MC_NO_SOLID_LIST") != nullptr;
     if (pl.sk && pl.b2 > 1 && c->mm_k && c->solid_tracked && c->cov_hint > 0 && !no_list && c->want_list) {
-        if (!P.emit_counts) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.emit_counts), 256 * 2 * 4 * sizeof(uint32_t)));
-        HIPCHK(c, hipMemsetAsync(P.emit_counts, 0, 256 * 2 * 4 * sizeof(uint32_t), c->stream));
+        if (!P.emit_counts) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.emit_counts), 256 * 2 * 4 * (D2_THREADS < P3_THREADS ? P3_THREADS / D2_THREADS : 1) * sizeof(uint32_t)));
+        HIPCHK(c, hipMemsetAsync(P.emit_counts, 0, 256 * 2 * 4 * (D2_THREADS < P3_THREADS ? P3_THREADS / D2_THREADS : 1) * sizeof(uint32_t), c->stream));
         emit.recs = P.a_recs;
         emit.counts = P.emit_counts;
         emit.seg_cap = std::min<uint64_t>(P.a_recs_cap / (uint64_t)p3_grid, 0xFFFFFFF0ull);
@@ -1441,7 +1453,11 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
 #define P3D_ARGS static_cast<const uint4 *>(lk), lh, lc, lcap, leaves, c->view(), P.leaf_state, P.leaf_new, P.flags + 1, \
                  (uint32_t)(c->solid_tracked ? c->cov_hint : 0), c->d_ctr + 6, k, emit, c->ptr_tries, P.flags
         if (pl.sk && pl.g == 0 && lseg == 1 && dedup_on) {
-            if (virgin) hipLaunchKernelGGL(k_p3_dedup<true>, dim3(grid), dim3(P3_THREADS), 0, c->stream, P3D_ARGS);
+            static const bool v2 = [] { const char *e = getenv("MC_P3_V2"); return !(e && !strcmp(e, "0")); }();
+            if (v2) {
+                if (virgin) hipLaunchKernelGGL(k_p3_dedup2<true>, dim3(grid), dim3(D2_THREADS), 0, c->stream, P3D_ARGS);
+                else hipLaunchKernelGGL(k_p3_dedup2<false>, dim3(grid), dim3(D2_THREADS), 0, c->stream, P3D_ARGS);
+            } else if (virgin) hipLaunchKernelGGL(k_p3_dedup<true>, dim3(grid), dim3(P3_THREADS), 0, c->stream, P3D_ARGS);
             else hipLaunchKernelGGL(k_p3_dedup<false>, dim3(grid), dim3(P3_THREADS), 0, c->stream, P3D_ARGS);
             // (it leaves the leaves of more than DD_MAX_CAP records alone: where the capacity allows such leaves, the general
             // kernel follows at once and takes what is left -- it skips the merged ones, ~20 us when that is all of them)
@@ -2064,7 +2080,7 @@ static int add_reads_impl(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_
             }
             r = r1;
         }
-        c->finalized = false;
+        counts_changed(c);
         c->solid_cov = -1; c->solid_external = false;
         return MC_OK;
     }
@@ -2090,7 +2106,7 @@ static int add_reads_impl(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_
         c->st.windows += win;
         r = r1;
     }
-    c->finalized = false;
+    counts_changed(c);
     c->solid_cov = -1; c->solid_external = false;
     return MC_OK;
 }
@@ -2241,6 +2257,7 @@ int mc_clear(mc_ctx *c)
     HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, 9 * sizeof(unsigned long long), c->stream));  // (counters and the fatal flag: one fill)
     c->n_used_host = 0;
     c->finalized = false;
+    c->shards_dropped = false;
     c->solid_cov = -1; c->solid_external = false;
     c->solid_tracked = true;
     c->solid_list_fresh = false;
@@ -2441,7 +2458,7 @@ static int add_reads_dev_counted(mc_ctx *c, const uint64_t *d_words, const uint6
             int rc = add_reads_partitioned_any(c, d_words, d_off, 0, n_reads, first_off, last_off, total);
             if (rc) return rc;
         }
-        c->finalized = false;
+        counts_changed(c);
         c->solid_cov = -1; c->solid_external = false;
         return MC_OK;
     }
@@ -2484,7 +2501,7 @@ static int add_reads_dev_counted(mc_ctx *c, const uint64_t *d_words, const uint6
             r = r1;
             off_r = off_r1;
         }
-        c->finalized = false;
+        counts_changed(c);
         c->solid_cov = -1; c->solid_external = false;
         return MC_OK;
     }
@@ -2545,7 +2562,7 @@ int mc_add_keys_dev(mc_ctx *c, const int64_t *d_keys, const uint32_t *d_hints, u
             i += m;
         }
     }
-    c->finalized = false;
+    counts_changed(c);
     c->solid_cov = -1; c->solid_external = false;
     return MC_OK;
 }
@@ -2569,7 +2586,7 @@ int mc_add_pairs_dev(mc_ctx *c, const int64_t *d_keys, const int16_t *d_counts, 
         HIPCHK(c, hipGetLastError());
         i += m;
     }
-    c->finalized = false;
+    counts_changed(c);
     c->solid_cov = -1; c->solid_external = false;
     return MC_OK;
 }
@@ -3197,7 +3214,7 @@ int mc_add_superkmers_dev(mc_ctx *c, const uint64_t *d_recs, const uint32_t *d_b
             HIPCHK(c, hipGetLastError());
             i += m;
         }
-        c->finalized = false;
+        counts_changed(c);
         c->solid_cov = -1; c->solid_external = false;
         return MC_OK;
     }
@@ -3207,7 +3224,7 @@ int mc_add_superkmers_dev(mc_ctx *c, const uint64_t *d_recs, const uint32_t *d_b
         int rc = add_records_partitioned(c, reinterpret_cast<const uint4 *>(d_recs) + i, d_bins + i, m);
         if (rc) return rc;
     }
-    c->finalized = false;
+    counts_changed(c);
     c->solid_cov = -1; c->solid_external = false;
     return MC_OK;
 }
@@ -3909,6 +3926,8 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
     if (!out || !jobs || n_jobs == 0) return fail(c, MC_EINVAL, "mc_bfs: null argument");
     memset(out, 0, sizeof(mc_bfs_result) * n_jobs);
     if (!c->finalized) return fail(c, MC_ESTATE, "mc_bfs: call mc_finalize_counts first");
+    if (c->shards_dropped)
+        return fail(c, MC_ESTATE, "mc_bfs: the table changed after mc_shard_attach, which dropped the attachment: export and attach the ranks' tables again (or mc_shard_detach to walk this table alone)");
     if (max_kmers < 0 && max_radius < 0)
         return fail(c, MC_EINVAL, "At least one of --maxkmers and --maxradius parameters should be set");
     if (min_cov < 0)
@@ -4150,9 +4169,23 @@ struct ShardWire {  // what a mc_shard_handle holds
     uint32_t shift, rmask, n_regions;
     int32_t mm_k;
     uint64_t empty;         // count of the key that equals EMPTY_KEY (hash modes)
-    int32_t pid, device, k, key_mode;
+    int32_t pid;
+    int16_t device;
+    uint8_t k, key_mode;
+    uint64_t token;         // drawn once per process: ranks in separate PID namespaces can share a pid, and a foreign address must never be taken for a local one
     uint32_t magic, has_ipc;
 };
+static_assert(sizeof(ShardWire) == 128, "the wire format of a shard handle");
+uint64_t process_token()
+{
+    static const uint64_t tok = [] {
+        uint64_t v = 0;
+        if (FILE *f = fopen("/dev/urandom", "rb")) { if (fread(&v, sizeof v, 1, f) != 1) v = 0; fclose(f); }
+        v ^= ((uint64_t)getpid() << 32) ^ (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count() ^ (uint64_t)(uintptr_t)&v;
+        return v ? v : 1;
+    }();
+    return tok;
+}
 static_assert(sizeof(ShardWire) <= sizeof(mc_shard_handle), "mc_shard_handle is too small");
 constexpr uint32_t SHARD_MAGIC = 0x4D435348u;  // "MCSH"
 
@@ -4173,7 +4206,8 @@ int shard_describe(mc_ctx *c, ShardWire *w, bool want_ipc)
     w->bytes = c->n_slots() * sizeof(Slot);
     w->shift = t.shift; w->rmask = t.rmask; w->n_regions = t.n_regions; w->mm_k = t.mm_k;
     w->empty = h[1];
-    w->pid = (int32_t)getpid(); w->device = c->cfg.device; w->k = c->cfg.k; w->key_mode = c->cfg.key_mode;
+    w->pid = (int32_t)getpid(); w->device = (int16_t)c->cfg.device; w->k = (uint8_t)c->cfg.k; w->key_mode = (uint8_t)c->cfg.key_mode;
+    w->token = process_token();
     w->magic = SHARD_MAGIC;
     if (want_ipc) {
         const hipError_t e = hipIpcGetMemHandle(&w->ipc, c->slots);
@@ -4197,6 +4231,7 @@ void shard_detach_locked(mc_ctx *c)
 int shard_attach_locked(mc_ctx *c, const ShardWire *w, uint32_t n, uint32_t self, int by_minimizer)
 {
     shard_detach_locked(c);
+    c->shards_dropped = false;
     if (!c->finalized) return fail(c, MC_ESTATE, "mc_shard_attach: call mc_finalize_counts first");
     if (n == 0 || n > 512 || self >= n) return fail(c, MC_EINVAL, "mc_shard_attach: bad number of shards / own index");
     if (by_minimizer && !(c->cfg.key_mode == MC_KEY_PACKED && c->cfg.k >= SK_MIN_K))
@@ -4209,10 +4244,10 @@ int shard_attach_locked(mc_ctx *c, const ShardWire *w, uint32_t n, uint32_t self
         if (x.k != c->cfg.k || x.key_mode != c->cfg.key_mode) return fail(c, MC_EINVAL, "mc_shard_attach: shard %u was counted with k = %d, key mode %d", i, x.k, x.key_mode);
         Slot *slots = nullptr;
         if (i == self) {
-            if (x.addr != (uint64_t)(uintptr_t)c->slots || x.pid != (int32_t)getpid())
+            if (x.addr != (uint64_t)(uintptr_t)c->slots || x.token != process_token())
                 return fail(c, MC_EINVAL, "mc_shard_attach: shard %u is not this context's table as it is now (export again after counting)", i);
             slots = c->slots;
-        } else if (x.pid == (int32_t)getpid()) {  // another context of this process: its pointer, through peer access when it is another device's
+        } else if (x.token == process_token()) {  // another context of this process: its pointer, through peer access when it is another device's
             slots = reinterpret_cast<Slot *>((uintptr_t)x.addr);
             if (x.device != c->cfg.device) {
                 int can = 0;
@@ -4236,6 +4271,7 @@ int shard_attach_locked(mc_ctx *c, const ShardWire *w, uint32_t n, uint32_t self
     if (hipMalloc(reinterpret_cast<void **>(&c->d_shards), n * sizeof(ShardRef)) != hipSuccess) { shard_detach_locked(c); return fail(c, MC_ENOMEM, "mc_shard_attach: out of device memory"); }
     if (hipMemcpy(c->d_shards, refs.data(), n * sizeof(ShardRef), hipMemcpyHostToDevice) != hipSuccess) { shard_detach_locked(c); return fail(c, MC_EHIP, "mc_shard_attach: upload failed"); }
     c->h_shards = refs;
+    c->shard_self = self;
     c->shard_owner_mm_k = by_minimizer ? c->cfg.k : 0;
     return MC_OK;
 }
@@ -4261,6 +4297,7 @@ int mc_shard_attach(mc_ctx *c, const mc_shard_handle *shards, uint32_t n_shards,
     if (!c) return MC_EINVAL;
     std::lock_guard<std::mutex> g(c->mu);
     if (!shards) return fail(c, MC_EINVAL, "mc_shard_attach: shards is null");
+    if (n_shards == 0 || n_shards > 512) return fail(c, MC_EINVAL, "mc_shard_attach: bad number of shards / own index");  // (before anything is sized by it)
     std::vector<ShardWire> w(n_shards);
     for (uint32_t i = 0; i < n_shards; i++) memcpy(&w[i], &shards[i], sizeof(ShardWire));
     return shard_attach_locked(c, w.data(), n_shards, self, by_minimizer);
@@ -4271,6 +4308,7 @@ int mc_shard_detach(mc_ctx *c)
     if (!c) return MC_EINVAL;
     std::lock_guard<std::mutex> g(c->mu);
     shard_detach_locked(c);
+    c->shards_dropped = false;
     return MC_OK;
 }
 

@@ -776,6 +776,18 @@ def test_walk_over_the_owners_tables_in_place(mc, k, mode, n_owners):
     assert alone is None or len(alone["lo"]) < len(want["lo"])  # (a third or half of the k-mers: the walk falls apart)
     with pytest.raises(mc.McError):
         own[1].shard_attach(handles, 0, records)  # handle 0 is not context 1's own table
+    # an attachment names the tables as they were.  More reads into the walking context (its table may grow, i.e.
+    # move) drop it, and the walk refuses to run on a view that is gone -- it used to read the freed block -- until the
+    # tables are attached again; the walk then sees the new counts too.
+    own[0].shard_attach(handles, 0, records)
+    er = np.ascontiguousarray(genome[5000:5400], dtype=np.uint8)
+    own[0].add_reads_packed(po.pack(er), np.array([0, len(er)], dtype=np.uint64))
+    own[0].finalize()
+    with pytest.raises(mc.McError, match="attach"):
+        own[0].bfs(hi, lo, 0, 3, 6000, -1)
+    handles = [c.shard_export() for c in own]
+    own[0].shard_attach(handles, 0, records)
+    assert own[0].bfs(hi, lo, 0, 3, 6000, -1) is not None
     for c in own:
         c.close()
 
