@@ -2244,21 +2244,21 @@ __device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v)
 }
 
 // lds_probe_claim for two keys a lane: offA / offB = byte offsets of the home slots in the key array AT LDS ADDRESS 0, mA / mB =
-// the lanes that hold a first / a second key.  Both compare-and-swaps of a step travel together; a lane is done with a key
-// when it found it or claimed a free slot.  On return offX = the slot's byte offset, *pendX = lanes whose key found no room
-// in P3_MAX_PROBES steps; *n_new_wave += keys the wave inserted.
+// the lanes that hold a first / a second key.  A lane is done with a key when it found it or claimed a free slot.  Two steps
+// with both compare-and-swaps in flight together settle 95 % of the keys; the slowest of a wave's 128 keys needs 4.6 steps
+// (measured on a model of configs[1]'s leaves), so what is left then -- a lane's first key, or its second one when the first
+// is settled -- goes through a loop of ONE key a lane (half the instructions a step), and the few lanes that still owe
+// their second key take it once more.  On return offX = the slot's byte offset, *pendX = lanes whose key found no room in
+// P3_MAX_PROBES steps.  (Keys inserted are counted when the region goes back: occupied slots after - before.)
 __device__ __forceinline__ void lds_probe_claim2(uint32_t &offA, uint32_t &offB, uint64_t keyA, uint64_t keyB, unsigned long long mA,
-                                                 unsigned long long mB, uint32_t *n_new_wave, unsigned long long *pendA,
-                                                 unsigned long long *pendB)
+                                                 unsigned long long mB, unsigned long long *pendA, unsigned long long *pendB)
 {
-    unsigned long long oldA, oldB, sv, hit;
-    uint32_t cnt, t, it;
+    unsigned long long oldA, oldB, keyX, sv, hit, mX2, pA, pB;
+    uint32_t offX, it;
     const unsigned long long empty = EMPTY_KEY;
     asm volatile(
         "s_mov_b64 %[sv], exec\n\t"
-        "s_mov_b32 %[cnt], 0\n\t"
-        "s_mov_b32 %[it], %[maxp]\n"
-        "1:\n\t"
+        ".rept 2\n\t"
         "s_mov_b64 exec, %[mA]\n\t"
         "ds_cmpst_rtn_b64 %[oldA], %[offA], %[empty], %[keyA]\n\t"
         "s_mov_b64 exec, %[mB]\n\t"
@@ -2267,8 +2267,6 @@ __device__ __forceinline__ void lds_probe_claim2(uint32_t &offA, uint32_t &offB,
         "s_waitcnt lgkmcnt(1)\n\t"
         "v_cmp_eq_u64 vcc, %[oldA], %[empty]\n\t"
         "v_cmp_eq_u64 %[hit], %[oldA], %[keyA]\n\t"
-        "s_bcnt1_i32_b64 %[t], vcc\n\t"
-        "s_add_u32 %[cnt], %[cnt], %[t]\n\t"
         "s_or_b64 vcc, vcc, %[hit]\n\t"
         "s_andn2_b64 %[mA], %[mA], vcc\n\t"
         "s_mov_b64 exec, %[mA]\n\t"
@@ -2278,27 +2276,105 @@ __device__ __forceinline__ void lds_probe_claim2(uint32_t &offA, uint32_t &offB,
         "s_waitcnt lgkmcnt(0)\n\t"
         "v_cmp_eq_u64 vcc, %[oldB], %[empty]\n\t"
         "v_cmp_eq_u64 %[hit], %[oldB], %[keyB]\n\t"
-        "s_bcnt1_i32_b64 %[t], vcc\n\t"
-        "s_add_u32 %[cnt], %[cnt], %[t]\n\t"
         "s_or_b64 vcc, vcc, %[hit]\n\t"
         "s_andn2_b64 %[mB], %[mB], vcc\n\t"
         "s_mov_b64 exec, %[mB]\n\t"
         "v_add_u32 %[offB], 8, %[offB]\n\t"
         "v_and_b32 %[offB], %[wrap], %[offB]\n\t"
-        "s_or_b64 %[hit], %[mA], %[mB]\n\t"
-        "s_cbranch_scc0 2f\n\t"
+        ".endr\n\t"
+        // what is left, one key a lane: the first key of the lanes in mA, the second of those in mB & ~mA
+        "s_andn2_b64 %[mX2], %[mB], %[mA]\n\t"
+        "s_mov_b64 exec, %[mA]\n\t"
+        "v_mov_b64 %[keyX], %[keyA]\n\t"
+        "v_mov_b32 %[offX], %[offA]\n\t"
+        "s_mov_b64 exec, %[mX2]\n\t"
+        "v_mov_b64 %[keyX], %[keyB]\n\t"
+        "v_mov_b32 %[offX], %[offB]\n\t"
+        "s_or_b64 exec, %[mA], %[mX2]\n\t"
+        "s_mov_b32 %[it], %[maxp]\n"
+        "1:\n\t"
+        "ds_cmpst_rtn_b64 %[oldA], %[offX], %[empty], %[keyX]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_eq_u64 vcc, %[oldA], %[empty]\n\t"
+        "v_cmp_eq_u64 %[hit], %[oldA], %[keyX]\n\t"
+        "s_or_b64 vcc, vcc, %[hit]\n\t"
+        "s_andn2_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execz 2f\n\t"
+        "v_add_u32 %[offX], 8, %[offX]\n\t"
+        "v_and_b32 %[offX], %[wrap], %[offX]\n\t"
         "s_sub_u32 %[it], %[it], 1\n\t"
         "s_cmp_lg_u32 %[it], 0\n\t"
         "s_cbranch_scc1 1b\n"
         "2:\n\t"
+        "s_and_b64 %[pA], exec, %[mA]\n\t"
+        "s_and_b64 %[pB], exec, %[mX2]\n\t"
+        "s_mov_b64 exec, %[mA]\n\t"
+        "v_mov_b32 %[offA], %[offX]\n\t"
+        "s_mov_b64 exec, %[mX2]\n\t"
+        "v_mov_b32 %[offB], %[offX]\n\t"
+        // the lanes whose two keys were both left: their second key (one step in five has such a lane)
+        "s_and_b64 exec, %[mA], %[mB]\n\t"
+        "s_cbranch_execz 4f\n\t"
+        "s_mov_b32 %[it], %[maxp]\n"
+        "3:\n\t"
+        "ds_cmpst_rtn_b64 %[oldB], %[offB], %[empty], %[keyB]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_eq_u64 vcc, %[oldB], %[empty]\n\t"
+        "v_cmp_eq_u64 %[hit], %[oldB], %[keyB]\n\t"
+        "s_or_b64 vcc, vcc, %[hit]\n\t"
+        "s_andn2_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execz 4f\n\t"
+        "v_add_u32 %[offB], 8, %[offB]\n\t"
+        "v_and_b32 %[offB], %[wrap], %[offB]\n\t"
+        "s_sub_u32 %[it], %[it], 1\n\t"
+        "s_cmp_lg_u32 %[it], 0\n\t"
+        "s_cbranch_scc1 3b\n"
+        "4:\n\t"
+        "s_or_b64 %[pB], %[pB], exec\n\t"
         "s_mov_b64 exec, %[sv]\n\t"
-        : [offA] "+v"(offA), [offB] "+v"(offB), [mA] "+s"(mA), [mB] "+s"(mB), [oldA] "=&v"(oldA), [oldB] "=&v"(oldB), [sv] "=&s"(sv),
-          [hit] "=&s"(hit), [cnt] "=&s"(cnt), [t] "=&s"(t), [it] "=&s"(it)
+        : [offA] "+v"(offA), [offB] "+v"(offB), [mA] "+s"(mA), [mB] "+s"(mB), [oldA] "=&v"(oldA), [oldB] "=&v"(oldB), [keyX] "=&v"(keyX),
+          [offX] "=&v"(offX), [sv] "=&s"(sv), [hit] "=&s"(hit), [mX2] "=&s"(mX2), [pA] "=&s"(pA), [pB] "=&s"(pB), [it] "=&s"(it)
         : [empty] "v"(empty), [keyA] "v"(keyA), [keyB] "v"(keyB), [wrap] "s"((uint32_t)(REGION_SLOTS * 8u - 8u)), [maxp] "s"((uint32_t)P3_MAX_PROBES)
         : "vcc", "scc", "memory");
-    *n_new_wave += cnt;
-    *pendA = mA;
-    *pendB = mB;
+    *pendA = pA;
+    *pendB = pB;
+}
+
+// A record claims a place in the record table by its tag (fingerprint << 16 | 0x8000): up to DD_PROBES compare-and-swaps on
+// the tag words from byte address `addr` on (record table of 16-byte entries, a power of two of them, aligned to its
+// size).  On return addr = the tag word of the place, *claimed = lanes that took a free one (they store their record
+// there), *none = lanes that met DD_PROBES other records.  (The compiler's loop spent 35 instructions a step on this.)
+__device__ __forceinline__ void lds_tag_claim(uint32_t &addr, uint32_t tag, unsigned long long *claimed, unsigned long long *none)
+{
+    unsigned long long sv, hit, cl, nn;
+    uint32_t old, it, nxt;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 %[cl], 0\n\t"
+        "s_mov_b32 %[it], %[maxp]\n"
+        "1:\n\t"
+        "ds_cmpst_rtn_b32 %[old], %[addr], %[zero], %[tag]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_eq_u32 vcc, 0, %[old]\n\t"
+        "v_and_b32 %[old], 0xffff8000, %[old]\n\t"
+        "s_or_b64 %[cl], %[cl], vcc\n\t"
+        "v_cmp_eq_u32 %[hit], %[old], %[tag]\n\t"
+        "s_or_b64 vcc, vcc, %[hit]\n\t"
+        "s_andn2_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execz 2f\n\t"
+        "v_add_u32 %[nxt], 16, %[addr]\n\t"
+        "v_bfi_b32 %[addr], %[wrap], %[nxt], %[addr]\n\t"
+        "s_sub_u32 %[it], %[it], 1\n\t"
+        "s_cmp_lg_u32 %[it], 0\n\t"
+        "s_cbranch_scc1 1b\n"
+        "2:\n\t"
+        "s_mov_b64 %[nn], exec\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        : [addr] "+v"(addr), [old] "=&v"(old), [nxt] "=&v"(nxt), [sv] "=&s"(sv), [hit] "=&s"(hit), [cl] "=&s"(cl), [nn] "=&s"(nn), [it] "=&s"(it)
+        : [zero] "v"(0u), [tag] "v"(tag), [wrap] "s"((uint32_t)(D2_SLOTS * 16u - 1u)), [maxp] "s"((uint32_t)DD_PROBES)
+        : "vcc", "scc", "memory");
+    *claimed = cl;
+    *none = nn;
 }
 
 template <bool VIRGIN>
@@ -2329,14 +2405,14 @@ __global__ void __launch_bounds__(D2_THREADS, MC_D2_WAVES_PER_EU) k_p3_dedup2(co
     };
     clear_records();
     long long solid_delta = 0;
+    static_assert(offsetof(Dedup2Lds, drec) % (D2_SLOTS * 16u) == 0, "lds_tag_claim wraps inside the aligned record table");
+    const uint32_t drec_w = (uint32_t)offsetof(Dedup2Lds, drec) + 12u;  // byte address of the first tag word (the struct sits at LDS address 0)
     const uint32_t ptr_from = solid_thr >= 2 ? 1u : 0u;
     const uint32_t sh_a = 64u - 2u * (uint32_t)k, sh_b = 62u - 2u * (uint32_t)k;  // (k <= 31: a pair of windows spans k + 1 <= 32 bases)
     const uint64_t kmask = ~0ull >> sh_a;
     uint32_t pick_tbl = 0;  // ptr_pick's choice for the four values of its two bits
     for (uint32_t r = 0; r < 4; r++) pick_tbl |= (ptr_pick((uint64_t)r, ptr_from, solid_thr) - ptr_from) << (2 * r);
 
-    uint32_t new_wave = 0;   // keys this WAVE inserted in the pair loop (the same number in every lane)
-    uint32_t new_mine = 0;   // ... and this lane, for records that got no place in the record table
     uint32_t cur_leaf = 0;
     // one occurrence set of `key` (inc copies) by the plain rule: records without a place in the record table (a fingerprint
     // met another record's, or eight occupied places: one leaf in a thousand has such a record)
@@ -2346,7 +2422,6 @@ __global__ void __launch_bounds__(D2_THREADS, MC_D2_WAVES_PER_EU) k_p3_dedup2(co
         for (uint32_t p = 0; p < P3_MAX_PROBES; p++) {
             const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&L.key[s]), (unsigned long long)EMPTY_KEY, (unsigned long long)key);
             if (old == EMPTY_KEY || old == key) {
-                new_mine += old == EMPTY_KEY;
                 atomicAdd(&L.ca[s], inc);
                 return;
             }
@@ -2402,6 +2477,7 @@ __global__ void __launch_bounds__(D2_THREADS, MC_D2_WAVES_PER_EU) k_p3_dedup2(co
         const uint4 *recs = leaf_recs + (uint64_t)leaf * seg_cap;
         const uint32_t *ptrs = leaf_ptrs + (uint64_t)leaf * seg_cap;
         int solid_before = 0;
+        uint32_t occupied = 0;  // (uniform) slots of the region that hold a key: after the merge, less before it = keys inserted
         if (VIRGIN) {  // 16 bytes a store
             static_assert((REGION_SLOTS / 4) % D2_THREADS == 0, "the image is cleared in whole steps");
 #pragma unroll
@@ -2409,18 +2485,17 @@ __global__ void __launch_bounds__(D2_THREADS, MC_D2_WAVES_PER_EU) k_p3_dedup2(co
 #pragma unroll
             for (int it = 0; it < (int)(REGION_SLOTS / 4 / D2_THREADS); it++) reinterpret_cast<uint4 *>(L.ca)[tid + (uint32_t)it * D2_THREADS] = make_uint4(0, 0, 0, 0);
         } else {
-#pragma unroll
-            for (int it = 0; it < (int)(REGION_SLOTS / D2_THREADS); it++) {
+#pragma unroll 2
+            for (int it = 0; it < (int)(REGION_SLOTS / D2_THREADS); it++) {  // (all eight loads in flight cost 32 registers)
                 const uint32_t i = tid + (uint32_t)it * D2_THREADS;
                 const uint4 raw = *reinterpret_cast<const uint4 *>(gs + i);
                 L.key[i] = ((uint64_t)raw.y << 32) | raw.x;
                 L.ca[i] = min(raw.z, 32767u);  // (anything above reads the same: kmer_device.h table_get)
                 solid_before += solid_thr && raw.z >= solid_thr;  // (empty slots hold count 0)
+                occupied -= (uint32_t)__popcll(__ballot(raw.z != 0));  // (a key in the table has been counted at least once)
             }
         }
         if (tid == 0) { L.n_new = 0; L.overflow = 0; L.n_units = 0; }
-        new_wave = 0;
-        new_mine = 0;
         cur_leaf = leaf;
         // ---- A: the records into the record table, 1024 at a time (nearly always all of them)
         for (uint32_t base = 0; base < n0; base += D2_SLOTS) {  // uniform
@@ -2441,16 +2516,15 @@ __global__ void __launch_bounds__(D2_THREADS, MC_D2_WAVES_PER_EU) k_p3_dedup2(co
                 e2[q] = (rec.y << 4) | (rec.w >> 28);
                 if (have[q]) {
                     const uint32_t h = dd_hash(rec.y, rec.z, rec.w), tag = (h & 0xFFFF0000u) | 0x8000u;
-                    uint32_t slot = h & (D2_SLOTS - 1);
-                    for (uint32_t p = 0; p < DD_PROBES; p++) {
-                        const uint32_t old = atomicCAS(&L.drec[slot].w, 0u, tag);
-                        if (old == 0) {  // claimed: this copy's words are what the others are compared with
-                            L.drec[slot].x = e0[q]; L.drec[slot].y = e1[q]; L.drec[slot].z = e2[q];  // (its pointer fields were cleared with the table)
-                            sl[q] = slot | DD_OWNER;
-                            break;
-                        }
-                        if ((old & 0xFFFF8000u) == tag) { sl[q] = slot; break; }
-                        slot = (slot + 1) & (D2_SLOTS - 1);
+                    uint32_t at = drec_w + ((h & (D2_SLOTS - 1)) << 4);
+                    unsigned long long claimed, none;
+                    lds_tag_claim(at, tag, &claimed, &none);
+                    const uint32_t slot = (at - drec_w) >> 4;
+                    if ((claimed >> lane) & 1ull) {  // this copy's words are what the others are compared with (its pointer fields were cleared with the table)
+                        L.drec[slot].x = e0[q]; L.drec[slot].y = e1[q]; L.drec[slot].z = e2[q];
+                        sl[q] = slot | DD_OWNER;
+                    } else if (!((none >> lane) & 1ull)) {
+                        sl[q] = slot;
                     }
                 }
             }
@@ -2573,7 +2647,7 @@ __global__ void __launch_bounds__(D2_THREADS, MC_D2_WAVES_PER_EU) k_p3_dedup2(co
                 const uint32_t hxA = sk_home_mix(keyA), hxB = sk_home_mix(keyB);
                 uint32_t offA = (hxA >> (32 - MC_REGION_LG)) << 3, offB = (hxB >> (32 - MC_REGION_LG)) << 3;
                 unsigned long long pendA, pendB;
-                lds_probe_claim2(offA, offB, keyA, keyB, __ballot(va), __ballot(vb), &new_wave, &pendA, &pendB);
+                lds_probe_claim2(offA, offB, keyA, keyB, __ballot(va), __ballot(vb), &pendA, &pendB);
                 const bool okA = va && !((pendA >> lane) & 1ull), okB = vb && !((pendB >> lane) & 1ull);
                 // (a lane without a key adds nothing to a word of its own)
                 const uint32_t sA = okA ? offA >> 3 : lane, sB = okB ? offB >> 3 : lane;
@@ -2643,83 +2717,80 @@ __global__ void __launch_bounds__(D2_THREADS, MC_D2_WAVES_PER_EU) k_p3_dedup2(co
             }
         }
         if (nl < n_leaves) fetch(nl, n_nxt);  // the next leaf's first records: its count has long arrived
-        {
-            uint32_t mine = new_mine;  // (rare: the wave's lanes differ)
-            if (__ballot(mine != 0)) {
-                for (uint32_t o = 32; o; o >>= 1) mine += __shfl_xor(mine, o);
-                new_wave += mine;
-            }
-        }
-        if (lane == 0 && new_wave) atomicAdd(&L.n_new, new_wave);
         P3E_STAMP(4);
         __syncthreads();
         P3E_STAMP(5);
         const bool ovf = L.overflow != 0;
         if (!ovf) {
-            // four slots of a thread at a time, their LDS words requested together
-            static_assert(REGION_SLOTS % (4 * D2_THREADS) == 0, "the region goes back in whole steps");
+            // four slots of a thread at a time, their LDS words requested together; FAST: the pointers are in the list
+            auto write_back = [&](auto fast) {
+                constexpr bool FAST = decltype(fast)::value;
 #pragma unroll
-            for (int it = 0; it < (int)(REGION_SLOTS / (4 * D2_THREADS)); it++) {
-                const uint32_t i0 = tid + (uint32_t)it * 4u * D2_THREADS;
-                uint64_t kk[4];
-                uint32_t cc[4], pp[4];
+                for (int it = 0; it < (int)(REGION_SLOTS / (4 * D2_THREADS)); it++) {
+                    const uint32_t i0 = tid + (uint32_t)it * 4u * D2_THREADS;
+                    uint64_t kk[4];
+                    uint32_t cc[4], pp[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t i = i0 + (uint32_t)u * D2_THREADS;
-                    kk[u] = L.key[i];
-                    cc[u] = L.ca[i];
-                }
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t i = i0 + (uint32_t)u * D2_THREADS;
+                        kk[u] = L.key[i];
+                        cc[u] = L.ca[i];
+                    }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t o = cc[u] >> DD_CNT_BITS;
-                    pp[u] = 0;
-                    if (o) {
-                        if (one_round) {
-                            pp[u] = wl[o - 1u];
-                        } else {  // the pointer of one of the record's copies, by bits of the key; the first copy's when that one has none
-                            const uint32_t sl = (o - 1u) >> 4, j = (o - 1u) & 15u;
-                            const uint32_t r = ((uint32_t)kk[u] >> 7) & 3u, f = r == 3u ? 0u : r;
-                            uint32_t p0 = L.dptr[f][sl];
-                            if (p0 == 0) p0 = L.dptr[0][sl];
-                            if (ptr_tries > 1 && p0 == 0) p0 = L.dptr[1][sl] ? L.dptr[1][sl] : L.dptr[2][sl];
-                            pp[u] = ptr_advance(p0, j);
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t o = cc[u] >> DD_CNT_BITS;
+                        pp[u] = 0;
+                        if (o) {
+                            if (FAST) {
+                                pp[u] = wl[o - 1u];
+                            } else {  // the pointer of one of the record's copies, by bits of the key; the first copy's when that one has none
+                                const uint32_t sl = (o - 1u) >> 4, j = (o - 1u) & 15u;
+                                const uint32_t r = ((uint32_t)kk[u] >> 7) & 3u, f = r == 3u ? 0u : r;
+                                uint32_t p0 = L.dptr[f][sl];
+                                if (p0 == 0) p0 = L.dptr[0][sl];
+                                if (ptr_tries > 1 && p0 == 0) p0 = L.dptr[1][sl] ? L.dptr[1][sl] : L.dptr[2][sl];
+                                pp[u] = ptr_advance(p0, j);
+                            }
                         }
                     }
-                }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t i = i0 + (uint32_t)u * D2_THREADS;
-                    uint4 v;
-                    v.x = (uint32_t)kk[u]; v.y = (uint32_t)(kk[u] >> 32);
-                    v.z = cc[u] & DD_CNT_MASK;
-                    v.w = pp[u];
-                    if (!VIRGIN && v.w == 0) v.w = reinterpret_cast<const uint32_t *>(gs + i)[3];  // the pointer the slot had
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t i = i0 + (uint32_t)u * D2_THREADS;
+                        uint4 v;
+                        v.x = (uint32_t)kk[u]; v.y = (uint32_t)(kk[u] >> 32);
+                        v.z = cc[u] & DD_CNT_MASK;
+                        v.w = pp[u];
+                        if (!VIRGIN && v.w == 0) v.w = reinterpret_cast<const uint32_t *>(gs + i)[3];  // the pointer the slot had
 #ifdef MC_P3_NOWB
-                    if (v.z == 0x12345u)
+                        if (v.z == 0x12345u)
 #endif
-                    *reinterpret_cast<uint4 *>(gs + i) = v;
-                    const bool solid = solid_thr && v.z >= solid_thr;
-                    solid_delta += solid;
-                    if (emitting) {  // (uniform; the loop's trip count is the same for every lane)
-                        const unsigned long long m = __ballot(solid);
-                        if (m) {
-                            uint32_t ebase = 0;
-                            const int leader = __ffsll((long long)m) - 1;
-                            if ((int)lane == leader) ebase = atomicAdd(&L.emit_cur, (uint32_t)__popcll(m));
-                            ebase = __shfl(ebase, leader);
-                            if (solid) {
-                                const uint32_t pos = ebase + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-                                if (pos < emit.seg_cap) {
-                                    v.z = min(v.z, 32767u);
-                                    emit.recs[(uint64_t)blockIdx.x * emit.seg_cap + pos] = v;
-                                } else {
-                                    atomicExch(emit.lost, 1u);
+                        *reinterpret_cast<uint4 *>(gs + i) = v;
+                        occupied += (uint32_t)__popcll(__ballot(v.z != 0));  // (a key in the image has been counted at least once)
+                        const bool solid = solid_thr && v.z >= solid_thr;
+                        solid_delta += solid;
+                        if (emitting) {  // (uniform; the loop's trip count is the same for every lane)
+                            const unsigned long long m = __ballot(solid);
+                            if (m) {
+                                uint32_t ebase = 0;
+                                const int leader = __ffsll((long long)m) - 1;
+                                if ((int)lane == leader) ebase = atomicAdd(&L.emit_cur, (uint32_t)__popcll(m));
+                                ebase = __shfl(ebase, leader);
+                                if (solid) {
+                                    const uint32_t pos = ebase + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+                                    if (pos < emit.seg_cap) {
+                                        v.z = min(v.z, 32767u);
+                                        emit.recs[(uint64_t)blockIdx.x * emit.seg_cap + pos] = v;
+                                    } else {
+                                        atomicExch(emit.lost, 1u);
+                                    }
                                 }
                             }
                         }
                     }
                 }
-            }
+            };
+            if (one_round) write_back(std::true_type{}); else write_back(std::false_type{});
+            if (lane == 0 && occupied) atomicAdd(&L.n_new, occupied);  // (two's complement: a wave may have loaded more keys than it writes back)
             solid_delta -= solid_before;
         } else if (VIRGIN) {  // nothing was there: leave a valid empty region behind
 #pragma unroll
@@ -2730,11 +2801,11 @@ __global__ void __launch_bounds__(D2_THREADS, MC_D2_WAVES_PER_EU) k_p3_dedup2(co
             }
         }
         clear_records();
-        if (tid == 0) {
-            if (!ovf) { leaf_state[leaf] = 1; leaf_new[leaf] = L.n_new; } else atomicExch(any_failed, 1u);
-        }
         P3E_STAMP(6);
         __syncthreads();
+        if (tid == 0) {  // (behind the barrier: the waves' key counts are in)
+            if (!ovf) { leaf_state[leaf] = 1; leaf_new[leaf] = L.n_new; } else atomicExch(any_failed, 1u);
+        }
 #ifdef MC_P3_TIMING
         n_lv++;
 #endif
