@@ -2377,6 +2377,42 @@ __device__ __forceinline__ void lds_tag_claim(uint32_t &addr, uint32_t tag, unsi
     *none = nn;
 }
 
+// the n <= 8 consecutive numbers val, val + 1, ... as 16-bit words from LDS byte address dst on: eight compare-and-store
+// steps under a shrinking exec mask (the compiler's loop of the same took seven instructions a trip)
+__device__ __forceinline__ void lds_line_up8(uint32_t dst, uint32_t val, uint32_t n)
+{
+    unsigned long long sv;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "v_cmpx_lt_u32 vcc, 0, %[n]\n\t"
+        "ds_write_b16 %[dst], %[val]\n\t"
+        "v_add_u32 %[val], 1, %[val]\n\t"
+        "v_cmpx_lt_u32 vcc, 1, %[n]\n\t"
+        "ds_write_b16 %[dst], %[val] offset:2\n\t"
+        "v_add_u32 %[val], 1, %[val]\n\t"
+        "v_cmpx_lt_u32 vcc, 2, %[n]\n\t"
+        "ds_write_b16 %[dst], %[val] offset:4\n\t"
+        "v_add_u32 %[val], 1, %[val]\n\t"
+        "v_cmpx_lt_u32 vcc, 3, %[n]\n\t"
+        "ds_write_b16 %[dst], %[val] offset:6\n\t"
+        "v_add_u32 %[val], 1, %[val]\n\t"
+        "v_cmpx_lt_u32 vcc, 4, %[n]\n\t"
+        "ds_write_b16 %[dst], %[val] offset:8\n\t"
+        "v_add_u32 %[val], 1, %[val]\n\t"
+        "v_cmpx_lt_u32 vcc, 5, %[n]\n\t"
+        "ds_write_b16 %[dst], %[val] offset:10\n\t"
+        "v_add_u32 %[val], 1, %[val]\n\t"
+        "v_cmpx_lt_u32 vcc, 6, %[n]\n\t"
+        "ds_write_b16 %[dst], %[val] offset:12\n\t"
+        "v_add_u32 %[val], 1, %[val]\n\t"
+        "v_cmpx_lt_u32 vcc, 7, %[n]\n\t"
+        "ds_write_b16 %[dst], %[val] offset:14\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        : [val] "+v"(val), [sv] "=&s"(sv)
+        : [dst] "v"(dst), [n] "v"(n)
+        : "vcc", "memory");
+}
+
 template <bool VIRGIN>
 __global__ void __launch_bounds__(D2_THREADS, MC_D2_WAVES_PER_EU) k_p3_dedup2(const uint4 *__restrict__ leaf_recs, const uint32_t *__restrict__ leaf_ptrs,
                                                           const uint32_t *__restrict__ leaf_counts, uint64_t seg_cap, uint32_t n_leaves,
@@ -2533,37 +2569,37 @@ __global__ void __launch_bounds__(D2_THREADS, MC_D2_WAVES_PER_EU) k_p3_dedup2(co
             P3E_STAMP(1);
 #pragma unroll
             for (int q = 0; q < D2_NQ; q++) {
-                if (sl[q] != DD_NONE) {
-                    const uint32_t slot = sl[q] & ~DD_OWNER;
-                    bool same = true;
-                    if (!(sl[q] & DD_OWNER)) {
-                        const uint4 e = L.drec[slot];
-                        same = e.x == e0[q] && e.y == e1[q] && e.z == e2[q];
-                    }
-                    if (same) {
-                        // the first three copies that carry a read pointer are remembered (the occurrences of neighbouring
-                        // k-mers arrive in the same order: kmer_device.h ptr_pick says why one pointer per record is too few)
-                        const uint32_t c = atomicAdd(&L.drec[slot].w, 1u) & D2_CP_MASK;
-                        if (rptr[q]) {
-                            if (c < 3u) {
-                                L.dptr[c][slot] = rptr[q];
-                            } else if (ptr_tries > 1) {  // (copies of other ranks carry none: a later one fills a field that stayed empty)
-                                for (uint32_t f = 0; f < 3u; f++)
-                                    if (L.dptr[f][slot] == 0) { L.dptr[f][slot] = rptr[q]; break; }
-                            }
+                // (one 16-byte read and no short cuts: the compiler made three dependent reads behind three branches of the comparison)
+                const bool has = sl[q] != DD_NONE;
+                const uint32_t slot = has ? sl[q] & (D2_SLOTS - 1u) : 0u;
+                const uint4 e = L.drec[slot];
+                const bool same = has & (((e.x ^ e0[q]) | (e.y ^ e1[q]) | (e.z ^ e2[q])) == 0u);  // (its own words for the copy that claimed the place)
+                if (same) {
+                    // the first three copies that carry a read pointer are remembered (the occurrences of neighbouring
+                    // k-mers arrive in the same order: kmer_device.h ptr_pick says why one pointer per record is too few)
+                    const uint32_t c = atomicAdd(&L.drec[slot].w, 1u) & D2_CP_MASK;
+                    if (rptr[q] != 0u) {
+                        if (c < 3u) {
+                            L.dptr[c][slot] = rptr[q];
+                        } else if (ptr_tries > 1) {  // (copies of other ranks carry none: a later one fills a field that stayed empty)
+                            for (uint32_t f = 0; f < 3u; f++)
+                                if (L.dptr[f][slot] == 0) { L.dptr[f][slot] = rptr[q]; break; }
                         }
-                    } else {
-                        sl[q] = DD_NONE;  // another record with this fingerprint
                     }
                 }
-                // a record without a place goes into the region image as it is: one copy of every window, no pointer
-                if (have[q] && sl[q] == DD_NONE) {
-                    const uint32_t nw = (e2[q] & 15u) + 1u;
-                    const uint64_t top = ((uint64_t)e0[q] << 32) | e1[q];
-                    for (uint32_t j = 0; j < nw; j++) {
-                        const uint32_t sh = 2u * j;
-                        const uint64_t fw = ((top << sh) | (uint64_t)((e2[q] >> 1) >> (31u - sh))) >> sh_a, rc = rc_packed(fw, k);
-                        add_plain(rc < fw ? rc : fw, 1u);
+                // a record without a place (another record with its fingerprint, or eight occupied places) goes into the region
+                // image as it is: one copy of every window, no pointer
+                const bool alone = have[q] & !same;
+                if (__ballot(alone)) {  // uniform; one leaf in a thousand
+                    if (alone) {
+                        const uint32_t nw = (e2[q] & 15u) + 1u;
+                        const uint64_t top = ((uint64_t)e0[q] << 32) | e1[q];
+#pragma unroll 1
+                        for (uint32_t j = 0; j < nw; j++) {
+                            const uint32_t sh = 2u * j;
+                            const uint64_t fw = ((top << sh) | (uint64_t)((e2[q] >> 1) >> (31u - sh))) >> sh_a, rc = rc_packed(fw, k);
+                            add_plain(rc < fw ? rc : fw, 1u);
+                        }
                     }
                 }
             }
@@ -2595,11 +2631,9 @@ __global__ void __launch_bounds__(D2_THREADS, MC_D2_WAVES_PER_EU) k_p3_dedup2(co
             const bool inside = w_lo >= r0 && w_hi <= r0 + D2_UL_CAP;
 #pragma unroll
             for (int q = 0; q < D2_NQ; q++) {
-                uint32_t val = (tid + (uint32_t)q * D2_THREADS) << 3;
-                uint16_t *dst = &L.ul[u_at[q] - r0];
+                const uint32_t val = (tid + (uint32_t)q * D2_THREADS) << 3;
                 if (inside) {
-#pragma unroll 1
-                    for (uint32_t left = u_cnt[q]; left; left--) *dst++ = (uint16_t)val++;
+                    lds_line_up8((uint32_t)offsetof(Dedup2Lds, ul) + 2u * (u_at[q] - r0), val, u_cnt[q]);  // (the struct sits at LDS address 0)
                 } else {
                     for (uint32_t u = 0; u < u_cnt[q]; u++) {
                         const uint32_t at = u_at[q] + u - r0;
