@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-no-hint", action="store_true", help="do not time the counting without a capacity hint (3 extra counting runs)")
+    ap.add_argument("--skip-config2", action="store_true", help="do not add the `config2` object (configs[2]'s k = 63 pipeline on the same reads, a few steps)")
+    ap.add_argument("--config2-steps", type=int, default=4)
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="time the CPU port on the WHOLE workload instead of --cpu-sample-reads (minutes; once a round, into profiles/)")
     ap.add_argument("--capacity-hint", type=int, default=0, help="distinct k-mers per GPU expected (0: estimate from the error rate)")
     ap.add_argument("--config", type=int, default=1, choices=[1, 2],
                     help="BASELINE.json configs[N]: 1 = the headline (10 M reads, k=31, coverage 5, bothdirs False); 2 = k=63 poly-hash "
@@ -131,9 +134,11 @@ def main():
 
     def step():
         t_c = time.perf_counter()
-        ctx.clear()
+        sc.clear()
         sc.add_reads_dev(d_words, d_off, R, n_bases, windows)
+        t_f = time.perf_counter()
         info["distinct"] = sc.finalize()  # (waits for the counting to end)
+        info["finalize_s"] = info.get("finalize_s", 0.0) + (time.perf_counter() - t_f)
         info["count_wall_s"] = info.get("count_wall_s", 0.0) + (time.perf_counter() - t_c)
         bctx = ctx
         in_place = world > 1 and walk_in_place and sc.attach_shards(dst=0)
@@ -181,8 +186,10 @@ def main():
         step()
     sync()
     ctx.reset_stats()
+    sc.reset_phases()
     info["count_wall_s"] = 0.0
     info["bfs_wall_s"] = 0.0
+    info["finalize_s"] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -193,6 +200,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = ctx.stats()
+    # what every rank spent where, per step (ms, host clocks): the record of a multi-GPU run must say how many ranks there
+    # were and what each of them did, so that a scaling number can be read without the source
+    ranks_seen, rank_phases = world, None
+    if world > 1:
+        ranks_seen = dist.get_world_size()
+        mine = torch.tensor([sc.phase_s["extract"], sc.phase_s["exchange_wait"], sc.phase_s["count"], info["finalize_s"],
+                             info.get("bfs_wall_s", 0.0), float(sc.bytes_sent), float(st.p1_ms + st.p2_ms + st.p3_ms), float(R)],
+                            dtype=torch.float64, device=dev)
+        allp = torch.empty(world * mine.numel(), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allp, mine)
+        allp = allp.view(world, -1).cpu().tolist()
+        rank_phases = [{"rank": r, "reads": int(p[7]), "extract_ms": round(1e3 * p[0] / args.steps, 3), "exchange_wait_ms": round(1e3 * p[1] / args.steps, 3),
+                        "count_enqueue_ms": round(1e3 * p[2] / args.steps, 3), "finalize_wait_ms": round(1e3 * p[3] / args.steps, 3),
+                        "count_kernels_ms": round(p[6] / args.steps, 3), "walk_ms": round(1e3 * p[4] / args.steps, 3),
+                        "exchange_GB_sent": round(p[5] / args.steps / 1e9, 4)} for r, p in enumerate(allp)]
 
     # The same counting WITHOUT a capacity hint -- how the CLI and the reference's self-growing BigLong2ShortHashMap start:
     # a fresh context per step (64 MB table), which sizes its table from the first level-1 bucket of the batch.
@@ -318,12 +340,83 @@ def main():
             out["solid_kmers"] = info.get("solid")
             out["walk"] = ("rank 0 reads every rank's counting table in place (mc_shard_attach)" if walk_in_place and "walk_fallback" not in info
                            else "solid k-mers gathered into a BFS-only context on rank 0" + (" (the tables could not be mapped: %s)" % info["walk_fallback"] if "walk_fallback" in info else ""))
-            out["alltoall_bytes_sent_rank0_per_step"] = sc.bytes_sent // (args.steps + args.warmup)
+            out["alltoall_bytes_sent_rank0_per_step"] = sc.bytes_sent // args.steps
+            # the run describes itself: the world size the process group reports (not the flag), which walk ran and why, what
+            # travelled and what each rank did
+            out["ranks_seen"] = ranks_seen
+            out["backend"] = dist.get_backend()
+            out["walk_mode"] = "in_place" if walk_in_place and "walk_fallback" not in info else "gather"
+            out["walk_fallback"] = info.get("walk_fallback")
+            out["exchange_GB_per_step"] = round(sum(p["exchange_GB_sent"] for p in rank_phases), 4)
+            out["exchange_chunks"] = sc.n_chunks
+            out["count_runs_per_step"] = sc.n_count_runs
+            out["rank_phases_ms_per_step"] = rank_phases
+    if world == 1 and args.config == 1 and not args.skip_config2 and rank == 0:
+        # configs[2]'s pipeline (k = 63: polynomial-hash keys, one 12-byte record per window, coverage 3, bothdirs True) on the
+        # SAME reads -- 10 M x 150 bp over 10 x 5 Mb is configs[2] scaled to a tenth at its own 30-fold depth --, a few steps:
+        # a driver-run k = 63 number with its own roofline fraction beside the headline.
+        ctx.close()
+        out["config2"] = config2_leg(args, m, torch, dev, local_rank, d_words, d_off, R, L, n_bases)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:
         print(json.dumps(out), flush=True)
+
+
+def config2_leg(args, m, torch, dev, local_rank, d_words, d_off, R, L, n_bases):
+    import numpy as np
+    k, cov = 63, 3
+    windows = R * (L - k + 1)
+    genome_bases = args.contigs * args.contig_len
+    est = int(min(windows, genome_bases + windows * (1.0 - (1.0 - args.err / 10000.0) ** k)))
+    ctx = m.Context(k, m.KEY_POLY, local_rank, est + (1 << 20))
+    ctx.set_coverage_hint(cov)
+    seed = m.native.synth_genome(GENOME_SEED, 100000, 1000)
+    sv = []
+    for i in range(len(seed) - k + 1):
+        v = 0
+        for c in seed[i:i + k]:
+            v = (v << 2) | int(c)
+        sv.append(v)
+    seed_hi = np.array([v >> 64 for v in sv], dtype=np.uint64)
+    seed_lo = np.array([v & 0xFFFFFFFFFFFFFFFF for v in sv], dtype=np.uint64)
+    res = {}
+
+    def step():
+        ctx.clear()
+        ctx.add_reads_packed_dev(d_words, d_off, R, n_bases)
+        res["distinct"] = ctx.finalize()
+        r = ctx.bfs_batch([(seed_hi, seed_lo, 0)], cov, args.maxkmers, -1)[0]
+        if r is None:
+            raise SystemExit("config2: BFS found no seed k-mer")
+        res["bfs_ms"], res["reached"] = r["device_ms"], len(r["lo"])
+
+    step()
+    torch.cuda.synchronize(dev)
+    ctx.reset_stats()
+    t0 = time.perf_counter()
+    for _ in range(args.config2_steps):
+        step()
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    st = ctx.stats()
+    launches = max(int(st.count_launches), 1)
+    A = L / (4.0 * (L - k + 1)) + 12.0 + 8.0 * res["distinct"] / float(windows)
+    avg_ms = st.count_ms / launches
+    ach = st.windows / launches * A / (avg_ms * 1e-3) / 1e9
+    out = {"workload": "configs[2] scaled to a tenth: %dx%dbp reads, %dx%d bp contigs (30-fold), k=63 polynomial-hash keys, coverage=3, bothdirs=True, "
+                       "maxkmers=%d, err=%d/10000" % (R, L, args.contigs, args.contig_len, args.maxkmers, args.err),
+           "value": windows * args.config2_steps / el, "unit": "k-mers/s", "steps": args.config2_steps, "ms_per_step": round(1e3 * el / args.config2_steps, 3),
+           "distinct_kmers": res["distinct"], "bfs": {"ms_per_step": round(res["bfs_ms"], 3), "reached": res["reached"]},
+           "table_bytes": int(st.table_bytes),
+           "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                        "bytes_per_kmer": round(A, 3), "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches / args.config2_steps,
+                        "kernel_ms": {"k_p1_extract_scatter": round(st.p1_ms / launches, 3), "k_p2_scatter": round(st.p2_ms / launches, 3),
+                                      "k_p3_merge": round(st.p3_ms / launches, 3)},
+                        "count_ms_per_step": round(st.count_total_ms / args.config2_steps, 3)}}
+    ctx.close()
+    return out
 
 
 def cpu_baseline(args, k, mode, L):
@@ -343,7 +436,7 @@ def cpu_baseline(args, k, mode, L):
     # thresholds -- and scales the genome with the reads: n reads over ONE contig of n * L / depth bases (the first n reads
     # of the full set would cover its genome n / reads times as thinly: hardly a k-mer would reach the coverage threshold
     # and the BFS leg would time nothing).
-    n = min(args.cpu_sample_reads, args.reads)
+    n = args.reads if args.cpu_baseline_full else min(args.cpu_sample_reads, args.reads)
     depth = args.reads * L / float(args.contigs * args.contig_len)
     glen = max(int(n * L / depth), 400000)
     genome = po.synth_genome(GENOME_SEED, glen)

@@ -75,6 +75,25 @@ def build_host(force=False, verbose=False):
     return CLI
 
 
+def build_host_sanitized(kind, force=False, verbose=False):
+    """mc_hosttest under a CPU sanitizer (kind: "asan" = address + undefined behaviour, "tsan" = threads): the host code --
+    readers on several threads, the replay of java.util.HashMap with its tree bins, compaction, writers -- run by
+    tests/test_host_sanitizers.py.  (No GPU sanitizer runs on this pool; the HIP side has the device self-check instead.)"""
+    hdir = os.path.join(CSRC, "host")
+    os.makedirs(LIBDIR, exist_ok=True)
+    out = os.path.join(LIBDIR, "mc_hosttest_" + kind)
+    srcs = [os.path.join(hdir, "hosttest.cpp"), os.path.join(hdir, "envfinder.cpp")]
+    hdrs = [os.path.join(hdir, "envfinder.h"), os.path.join(ROOT, "include", "mcgpu.h")]
+    san = {"asan": ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"], "tsan": ["-fsanitize=thread"]}[kind]
+    if force or _stale(out, srcs + hdrs):
+        cmd = ["g++", "-O1", "-g", "-fno-omit-frame-pointer", "-std=c++17", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include")] + san + [
+            "-o", out] + srcs + ["-lz", "-ldl", "-lpthread"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return out
+
+
 # tuning builds the GPU tests load with MC_LIB (tests/test_gpu_bfs_race.py): the walk with a pause behind every barrier,
 # as it is now and as round 3 shipped it
 VARIANTS = {

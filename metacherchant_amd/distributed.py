@@ -16,6 +16,7 @@ typically one vertex wide.
 file with a stand-in built on the oracle; the product always passes metacherchant_amd.Context.
 """
 import os
+import time
 
 import numpy as np
 import torch
@@ -51,6 +52,20 @@ class ShardedCounter:
         # room -- 287 of 288 GB in use, the allocations stall, 1 108 ms against 787 for a run per chunk (profiles/r04_rank_shard_*)
         self.keep_bytes = int(float(os.environ.get("MC_EXCHANGE_KEEP_GB", 12)) * 1e9)
         self.n_count_runs = 0
+        # where a rank's time goes, as its host sees it (seconds, summed over add_reads_dev calls until reset_phases): `extract`
+        # = mc_extract_*_dev (synchronous), `exchange_wait` = waiting for transfers that the next chunk's extraction did not
+        # cover, `count` = the counting runs up to their enqueueing (finalize waits for them: bench.py books that wait as well)
+        self.phase_s = {"extract": 0.0, "exchange_wait": 0.0, "count": 0.0}
+
+    def clear(self):
+        """empties the sharded table (every rank calls it): the context's mc_clear, and the table may then be fed in either form"""
+        self.ctx.clear()
+        self._fed = False
+
+    def reset_phases(self):
+        for key in self.phase_s:
+            self.phase_s[key] = 0.0
+        self.bytes_sent = 0
 
     def add_reads_dev(self, d_words, d_offsets, n_reads, n_bases, max_windows):
         """Counts this rank's reads into the sharded table: extract -> all-to-all -> count owned keys.
@@ -84,34 +99,61 @@ class ShardedCounter:
         else:
             base_at = [0, int(n_bases)]
         sk = hasattr(ctx, "superkmer_capacity") and ctx.superkmer_capacity(max(int(max_windows), 1), max(int(n_reads), 1)) != 0
-        self.by_minimizer = sk  # (records are dealt to the owners of their minimizers, keys to the owners of their own hashes)
+        # (records are dealt to the owners of their minimizers, keys to the owners of their own hashes: a table fed in both
+        # forms would hold a k-mer on two ranks, and attach_shards could name only one rule -- ADVICE r4)
+        if getattr(self, "_fed", False) and self.by_minimizer != sk:
+            raise RuntimeError("ShardedCounter: this table was fed %s before and would now be fed %s: clear it first" % (
+                "super-k-mer records" if self.by_minimizer else "keys", "super-k-mer records" if sk else "keys"))
+        self.by_minimizer = sk
+        self._fed = True
         # Read pointers travel only FROM the rank that walks (they lead into its read store; the others keep none and used to
         # send an array of zeros: a fifth of the bytes of seven ranks out of eight)
         with_ptrs = self.bfs_rank is None or self.rank == self.bfs_rank
         ptr_sources = list(range(W)) if self.bfs_rank is None else [self.bfs_rank]
-        pending = []  # (handles, send buffers kept alive, received payload, received pointers, n)
+        pending = []  # per chunk: [handles, send buffers (kept alive while the transfers run), received payload, received pointers, n]
         self.n_count_runs = 0
+        # What arrives is received straight into ONE buffer sized from the first chunk (x chunks left, + 12 %), so that the
+        # one counting run needs no second copy of everything (torch.cat doubled the peak); a chunk that does not
+        # fit any more gets tensors of its own and the run's input is concatenated after all.
+        pool = {"recv": None, "recv_p": None, "at": 0}
+
+        def settle(entry):
+            """waits for one chunk's transfers and lets go of its send buffers (capacity-sized: round 4 kept every chunk's until the end)"""
+            if entry[0]:
+                t_w = time.perf_counter()
+                for h in entry[0]:
+                    h.wait()
+                self.phase_s["exchange_wait"] += time.perf_counter() - t_w
+                entry[0] = []
+            entry[1] = None
 
         def count_pending():
             if not pending:
                 return
-            for hs, _keep, _r, _p, _n in pending:
-                for h in hs:
-                    h.wait()
+            for entry in pending:
+                settle(entry)
+            t_w = time.perf_counter()
             if self.device.type == "cuda":
                 torch.cuda.synchronize(self.device)
+            self.phase_s["exchange_wait"] += time.perf_counter() - t_w
             n_all = sum(x[4] for x in pending)
+            in_pool = pool["recv"] is not None and all(x[5] for x in pending)
             if len(pending) == 1:
                 recv, recv_p = pending[0][2], pending[0][3]
+            elif in_pool:  # the chunks lie back to back in the pool, from its start
+                recv, recv_p = pool["recv"], pool["recv_p"]
             else:
                 recv = torch.cat([x[2][:x[4]] for x in pending]) if n_all else pending[0][2]
                 recv_p = torch.cat([x[3][:x[4]] for x in pending]) if n_all else pending[0][3]
             pending.clear()
+            pool["at"] = 0
+            t_c = time.perf_counter()
             # (a rank that received nothing still calls: the context must know its pipeline buffers were reused, mcgpu.hip)
             if sk:
                 ctx.add_superkmers_dev(recv, recv_p, n_all)
             else:
                 ctx.add_keys_dev(recv, n_all, recv_p)
+            self.phase_s["count"] += time.perf_counter() - t_c
             self.n_count_runs += 1
 
         for c in range(n_chunks):
@@ -119,8 +161,11 @@ class ShardedCounter:
             nb = base_at[c + 1] - base_at[c]
             # (offsets are absolute in the rank's buffer: a chunk is the reads [a, b) with the bases up to base_at[c + 1])
             pending.append(self._exchange_chunk(sk, d_words, d_offsets[a:], b - a, base_at[c + 1], nb if sk else min(int(max_windows), nb),
-                                                with_ptrs, ptr_sources))
-            kept = sum(x[2].numel() * 8 + x[3].numel() * 4 for x in pending)
+                                                with_ptrs, ptr_sources, pool, n_chunks - c))
+            if len(pending) >= 2:
+                settle(pending[-2])  # (its transfers had this chunk's extraction to travel in)
+            # what is held: the received payloads, and the send buffers of the chunk whose transfers are still running
+            kept = sum(x[4] * ((16 if sk else 8) + 4) for x in pending) + sum(t.numel() * t.element_size() for x in pending if x[1] for t in x[1])
             if (self.count_every and len(pending) >= self.count_every) or kept >= self.keep_bytes:
                 count_pending()
         count_pending()
@@ -133,7 +178,7 @@ class ShardedCounter:
         dist.all_to_all_single(rc, sc, group=self.group)
         return [int(x) for x in rc.cpu().tolist()]
 
-    def _exchange_chunk(self, sk, d_words, d_offsets, n_reads, n_bases_end, room, with_ptrs, ptr_sources):
+    def _exchange_chunk(self, sk, d_words, d_offsets, n_reads, n_bases_end, room, with_ptrs, ptr_sources, pool, chunks_left):
         """One chunk: extract (super-k-mer records of 16 bytes for packed keys, k >= 23 -- a seventh of the bytes of one key
         per window --, else keys), one exchange of the counts, then the payload and the read pointers as asynchronous
         all-to-alls.  Returns (handles, send buffers, received payload, received pointers, n received): the caller waits."""
@@ -145,6 +190,7 @@ class ShardedCounter:
             cap = max(int(room), 1)
             send = torch.empty(cap, dtype=torch.int64, device=self.device)
         send_p = torch.empty(cap, dtype=torch.int32, device=self.device)          # the read pointers (of the records' first windows)
+        t_e = time.perf_counter()
         if n_reads:
             if sk:
                 off = ctx.extract_superkmers_dev(d_words, d_offsets, n_reads, n_bases_end, W, send, send_p, cap)
@@ -152,13 +198,27 @@ class ShardedCounter:
                 off = ctx.extract_keys_dev(d_words, d_offsets, n_reads, n_bases_end, W, send, cap, send_p)
         else:
             off = np.zeros(W + 1, dtype=np.uint64)
+        self.phase_s["extract"] += time.perf_counter() - t_e
         send_counts = [int(off[o + 1] - off[o]) for o in range(W)]
         recv_counts = self._counts(send_counts)
         n_recv, n_send = sum(recv_counts), int(off[W])
-        recv = torch.empty((max(n_recv, 1), 2) if sk else max(n_recv, 1), dtype=torch.int64, device=self.device)
         # pointers: only the ranks in ptr_sources send theirs; what comes from the others is zero (no pointer)
         all_send = len(ptr_sources) == W
-        recv_p = (torch.empty if all_send else torch.zeros)(max(n_recv, 1), dtype=torch.int32, device=self.device)
+        if pool["recv"] is None and chunks_left > 1:  # the first of several chunks sizes the buffer for all of them
+            room_all = max(int(n_recv * chunks_left * 1.12) + 1024, 1)
+            pool["recv"] = torch.empty((room_all, 2) if sk else room_all, dtype=torch.int64, device=self.device)
+            pool["recv_p"] = torch.zeros(room_all, dtype=torch.int32, device=self.device)
+            pool["at"] = 0
+        in_pool = pool["recv"] is not None and pool["at"] + n_recv <= pool["recv"].shape[0]
+        if in_pool:
+            at0 = pool["at"]
+            recv, recv_p = pool["recv"][at0:at0 + max(n_recv, 1)], pool["recv_p"][at0:at0 + max(n_recv, 1)]
+            if not all_send:
+                recv_p.zero_()  # (the pool is reused by the next counting run's chunks)
+            pool["at"] = at0 + n_recv
+        else:
+            recv = torch.empty((max(n_recv, 1), 2) if sk else max(n_recv, 1), dtype=torch.int64, device=self.device)
+            recv_p = (torch.empty if all_send else torch.zeros)(max(n_recv, 1), dtype=torch.int32, device=self.device)
         hs = [dist.all_to_all_single(recv[:n_recv], send[:n_send], output_split_sizes=recv_counts, input_split_sizes=send_counts,
                                      group=self.group, async_op=True)]
         if all_send:
@@ -176,7 +236,7 @@ class ShardedCounter:
                                              input_split_sizes=p_send, group=self.group, async_op=True))
             ptr_bytes = 4 * (n_send - send_counts[self.rank]) if with_ptrs else 0
         self.bytes_sent += (16 if sk else 8) * (n_send - send_counts[self.rank]) + ptr_bytes
-        return hs, (send, send_p), recv, recv_p, n_recv
+        return [hs, (send, send_p), recv, recv_p, n_recv, in_pool]
 
     def finalize(self):
         """Local distinct keys; the sum over ranks is the table size (owners are disjoint)."""

@@ -41,7 +41,10 @@ def lib():
         return _LIB
     path = os.path.join(_HERE, "libmcoracle.so")
     src = os.path.join(_HERE, "mc_oracle.c")
-    if not os.path.exists(path) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(path)):
+    alt = os.environ.get("MCO_LIB")  # (tests/test_host_sanitizers.py: the AddressSanitizer build, `make asan`, with libasan preloaded)
+    if alt:
+        path = alt
+    elif not os.path.exists(path) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(path)):
         build()
     L = C.CDLL(path)
     u8p, u64p, i64p, i16p = (C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_int64),

@@ -14,6 +14,8 @@ from oracle import pyoracle as po
 
 @pytest.fixture(scope="module")
 def hosttest():
+    if os.environ.get("MC_HOSTTEST"):  # (tests/test_host_sanitizers.py: the same tests on a sanitizer build)
+        return os.environ["MC_HOSTTEST"]
     from metacherchant_amd import build
     build.build_host()
     assert os.path.exists(build.HOSTTEST)
