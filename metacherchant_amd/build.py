@@ -94,23 +94,33 @@ def build_host_sanitized(kind, force=False, verbose=False):
     return out
 
 
-# tuning builds the GPU tests load with MC_LIB (tests/test_gpu_bfs_race.py): the walk with a pause behind every barrier,
-# as it is now and as round 3 shipped it
+# Tuning builds the GPU tests and scripts load with MC_LIB.  `fuzz` (the walk with a pause behind every barrier) is what the
+# gating test of tests/test_gpu_bfs_race.py runs: build_all makes it beside the product library.  The others are made when
+# somebody asks for them (build_variant): `fuzz_old` = round 3's racy walk fuzzed the same way (the opt-in half of that test,
+# MC_RUN_OLD_RACE=1), `trace_old` and `sctime` what scripts/gpu_bfs_hunt.sh and scripts/gpu_r4_bfs.sh load.
 VARIANTS = {
     "fuzz": ("MC_BFS_FUZZ", "MC_BFS_TRACE"),
     "fuzz_old": ("MC_BFS_FUZZ", "MC_BFS_TRACE", "MC_BFS_OLD_RACE"),
+    "trace_old": ("MC_BFS_TRACE", "MC_BFS_OLD_RACE"),
+    "sctime": ("MC_SCOUT_TIMING",),
 }
+DEFAULT_VARIANTS = ("fuzz",)
 
 
-def build_variants(force=False, verbose=False):
+def build_variant(name, force=False, verbose=False):
+    """lib/libmcgpu_<name>.so for a name of VARIANTS (a minute of hipcc when it is missing or stale)"""
+    return build_lib(force, verbose, variant=name, defines=VARIANTS[name])
+
+
+def build_variants(force=False, verbose=False, names=DEFAULT_VARIANTS):
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(len(VARIANTS)) as ex:
-        return list(ex.map(lambda kv: build_lib(force, verbose, variant=kv[0], defines=kv[1]), sorted(VARIANTS.items())))
+    with ThreadPoolExecutor(max(len(names), 1)) as ex:
+        return list(ex.map(lambda n: build_variant(n, force, verbose), names))
 
 
 def build_all(force=False, verbose=False):
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(2) as ex:  # (hipcc runs a minute per library: the three of them side by side)
+    with ThreadPoolExecutor(2) as ex:  # (hipcc runs a minute per library: the product and the fuzzed walk side by side)
         v = ex.submit(build_variants, force, verbose)
         build_lib(force, verbose)
         v.result()

@@ -1821,29 +1821,16 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
 // way) -- and only the DISTINCT records are expanded into windows, each window adding the record's number of copies.
 //
 // The region image is 12 bytes a slot instead of 16: key, and one word holding count (17 bits: a leaf adds < 2^16 to
-// a count that came in clamped to 32767, see DD_MAX_CAP) and, above it, WHICH window of which record slot supplies the
-// key's read pointer (0 = none).  That field is written by exactly one window -- the one whose addition carries the
-// count across ptr_pick(key) + 1, which only one addition does -- so a plain LDS atomic OR is enough; with ptr_tries
-// > 1 (records of other ranks carry no pointer) the next crossings try too, with a CAS.  The pointer itself is worked
-// out when the region goes back to HBM: a record slot keeps the pointers of its first three copies, and bits of the
-// key choose among them (with one pointer per record all k-mers of a stretch led into the same read, and a scout that
+// a count that came in clamped to 32767, see DD_MAX_CAP) and, above it, where the key's read pointer is found when the
+// region goes back to HBM (0 = none).  That field is written for exactly one window -- the one whose addition carries the
+// count across ptr_pick + 1, which only one addition does; with ptr_tries > 1 (records of other ranks carry no pointer)
+// the next crossings try too, with a CAS.  A record slot keeps the pointers of its first three copies, and bits of the
+// slot choose among them (with one pointer per record all k-mers of a stretch led into the same read, and a scout that
 // had used that read up found no other: + 1 ms of walk).  Table layout, probing and results are those of k_p3_merge.
-constexpr uint32_t DD_SLOTS = 1024;      // record table of a leaf (a leaf holds ~250 distinct records on configs[1])
 constexpr uint32_t DD_PROBES = 8;
 constexpr uint32_t DD_CNT_BITS = 17, DD_CNT_MASK = (1u << DD_CNT_BITS) - 1;
-constexpr uint32_t DD_MAX_CAP = 2048;    // records per leaf: 32767 + 2048 * 16 windows < 2^17, and copies < 2^15
+constexpr uint32_t DD_MAX_CAP = 2048;    // records per leaf: 32767 + 2048 * 16 windows < 2^17, and copies < 2^12
 constexpr uint32_t DD_NONE = 0xFFFFFFFFu, DD_OWNER = 0x80000000u;
-constexpr uint32_t DD_DQ = 496;          // windows a wave queues at a time (64 records have up to 1024; a batch usually ~300)
-
-struct alignas(16) DedupLds {
-    uint64_t key[REGION_SLOTS];
-    uint32_t ca[REGION_SLOTS];          // count | (1 + (record slot << 4 | window)) << DD_CNT_BITS
-    uint4 drec[DD_SLOTS];               // {y, z, w of the record, fingerprint << 16 | 0x8000 | copies}; .w == 0: free
-    uint32_t dptr[3][DD_SLOTS];         // read pointers (of the first window) of the slot's first three copies that carry one;
-                                        // a window takes one of them, chosen by bits of its key
-    uint8_t dq[P3_THREADS / 64][DD_DQ];  // per wave: window -> lane holding its record, DD_DQ windows at a time
-    uint32_t n_new, overflow, emit_cur;
-};
 
 __device__ __forceinline__ uint32_t dd_hash(uint32_t y, uint32_t z, uint32_t w)
 {
@@ -1854,334 +1841,12 @@ __device__ __forceinline__ uint32_t dd_hash(uint32_t y, uint32_t z, uint32_t w)
     return h ^ (h >> 16);
 }
 
-template <bool VIRGIN>
-__global__ void __launch_bounds__(P3_THREADS) k_p3_dedup(const uint4 *__restrict__ leaf_recs, const uint32_t *__restrict__ leaf_ptrs,
-                                                         const uint32_t *__restrict__ leaf_counts, uint64_t seg_cap, uint32_t n_leaves,
-                                                         TableView t, uint32_t *leaf_state, uint32_t *leaf_new, uint32_t *any_failed,
-                                                         uint32_t solid_thr, unsigned long long *n_solid, int k, P3Emit emit,
-                                                         uint32_t ptr_tries, const uint32_t *lost)
-{
-    if (lost && *lost) return;
-    __shared__ DedupLds L;
-    const uint32_t tid = threadIdx.x, wv = tid >> 6, lane = tid & 63u;
-    const bool emitting = emit.recs != nullptr && solid_thr != 0;
-    if (tid == 0) L.emit_cur = emitting ? emit.counts[blockIdx.x] : 0u;
-    for (uint32_t i = tid; i < DD_SLOTS; i += P3_THREADS) L.drec[i].w = 0;
-    long long solid_delta = 0;
-    const uint32_t ptr_from = solid_thr >= 2 ? 1u : 0u;
-    const uint32_t kshift = 64u - 2u * (uint32_t)k;
-    uint8_t *dq = L.dq[wv];
-
-    const uint32_t key_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint64_t *)L.key;
-    uint32_t pick_tbl = 0;  // ptr_pick's choice for the four values of its two key bits
-    for (uint32_t r = 0; r < 4; r++) pick_tbl |= (ptr_pick((uint64_t)r, ptr_from, solid_thr) - ptr_from) << (2 * r);
-
-    // one batch of up to 64 records (one per lane: y, z, w; copies == 0: none) into the region image
-    uint32_t new_wave = 0;  // keys this WAVE inserted (the same number in every lane)
-    uint32_t cur_leaf = 0;  // the leaf being merged
-    auto expand = [&](uint32_t y, uint32_t z, uint32_t w, uint32_t copies, bool hasptr, uint32_t slot) {
-        const uint32_t nw = copies ? (w >> 28) + 1u : 0u;
-        uint32_t incl = nw;
-#pragma unroll
-        for (uint32_t o = 1; o < 64; o <<= 1) {
-            const uint32_t v = __shfl_up(incl, o);
-            if (lane >= o) incl += v;
-        }
-        const uint32_t excl = incl - nw, total = __shfl(incl, 63);
-        // the record's 46 bases top-aligned in three words; what a window needs besides them
-        const uint32_t d0 = __builtin_amdgcn_alignbit(w, z, 28), d1 = __builtin_amdgcn_alignbit(z, y, 28), d2 = y << 4;
-        const uint32_t meta = copies | (hasptr ? 0x8000u : 0u) | (slot << 16);
-        for (uint32_t w0 = 0; w0 < total; w0 += DD_DQ) {  // uniform; nearly always one round
-        const uint32_t wend = min(total, w0 + DD_DQ);
-        for (uint32_t i = max(excl, w0); i < min(excl + nw, wend); i++) dq[i - w0] = (uint8_t)lane;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t base = w0; base < wend; base += 64) {
-            const uint32_t widx = base + lane;
-            // (every lane takes part in the shuffles: a lane that is masked off hands out zeros)
-            // (asking for the NEXT batch's words before this batch's probe loop was measured: 7.45 against 7.35 ms)
-            const uint32_t src = widx < wend ? dq[widx - w0] : lane;
-            const uint32_t r0 = __shfl(d0, src), r1 = __shfl(d1, src), r2 = __shfl(d2, src), re = __shfl(excl, src), rm = __shfl(meta, src);
-            if (widx < wend) {
-                const uint32_t j = widx - re, sh = 2u * j;  // (j <= 15)
-                const uint64_t top = ((uint64_t)r0 << 32) | r1;
-                const uint64_t fw = ((top << sh) | (uint64_t)((r2 >> 1) >> (31u - sh))) >> kshift, rc = rc_packed(fw, k);
-                const uint64_t key = rc < fw ? rc : fw;
-                unsigned long long pending;
-                const uint32_t s = lds_probe_claim(key_base, sk_home(key), key, &new_wave, &pending);
-                if (!((pending >> lane) & 1ull)) {
-                    const uint32_t cp = rm & 0x7FFFu;
-                    const uint32_t before = atomicAdd(&L.ca[s], cp) & DD_CNT_MASK;
-                    // the count an occurrence leaves its pointer at: kmer_device.h ptr_pick(key, ptr_from, solid_thr) + 1, from a table
-                    const uint32_t first = ptr_from + 1u + ((pick_tbl >> (2u * ((uint32_t)(key ^ (key >> 9) ^ (key >> 23)) & 3u))) & 3u);
-                    if ((rm & 0x8000u) && before < first + ptr_tries - 1u && before + cp >= first) {  // (one addition per key)
-                        const uint32_t occ = ((((rm >> 16) << 4) | j) + 1u) << DD_CNT_BITS;
-                        if (ptr_tries == 1) {
-                            atomicOr(&L.ca[s], occ);
-                        } else {
-                            for (int a = 0; a < 4; a++) {
-                                const uint32_t cur = L.ca[s];
-                                if ((cur >> DD_CNT_BITS) != 0 || atomicCAS(&L.ca[s], cur, cur | occ) == cur) break;
-                            }
-                        }
-                    }
-                } else if (!ovf_push(t, key, rm & 0x7FFFu, 0u, cur_leaf)) {
-                    atomicExch(&L.overflow, 1u);
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();  // (the queue is rewritten by the next round or batch)
-        }
-    };
-
-#ifdef MC_P3_TIMING
-    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memrealtime(), n_lv = 0;
-#define P3D_STAMP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); tph[i] += n_ - tl; tl = n_; } while (0)
-#else
-#define P3D_STAMP(i) do {} while (0)
-#endif
-    uint32_t st_nxt = 1u, n_nxt = 0;
-    uint4 pre_rec[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-    uint32_t pre_ptr[2] = {0, 0};
-    auto fetch = [&](uint32_t lf, uint32_t n) {  // this thread's first two records of leaf lf
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const uint32_t r = tid + (uint32_t)q * P3_THREADS;
-            if (r < n) {
-                pre_rec[q] = leaf_recs[(uint64_t)lf * seg_cap + r];
-                pre_ptr[q] = leaf_ptrs ? leaf_ptrs[(uint64_t)lf * seg_cap + r] : pre_rec[q].x;  // (no array: the record's first word, k_sk2_scatter_compact)
-            }
-        }
-    };
-    if (blockIdx.x < n_leaves) {
-        st_nxt = leaf_state[blockIdx.x];
-        n_nxt = min(leaf_counts[blockIdx.x], (uint32_t)seg_cap);
-        fetch(blockIdx.x, n_nxt);
-    }
-    __syncthreads();
-    for (uint32_t leaf = blockIdx.x; leaf < n_leaves; leaf += gridDim.x) {
-        const uint32_t st_cur = st_nxt, n0 = n_nxt;
-        const uint4 cur_rec[2] = {pre_rec[0], pre_rec[1]};
-        const uint32_t cur_ptr[2] = {pre_ptr[0], pre_ptr[1]};
-        const uint32_t nl = leaf + gridDim.x;
-        if (nl < n_leaves) {
-            st_nxt = leaf_state[nl];
-            n_nxt = min(leaf_counts[nl], (uint32_t)seg_cap);
-        }
-        if (st_cur || n0 > DD_MAX_CAP) {  // uniform; a leaf of more records than the packed counters are safe for is left
-            if (nl < n_leaves) fetch(nl, n_nxt);  // to k_p3_merge, which the host enqueues behind this kernel
-            continue;
-        }
-        P3D_STAMP(7);
-        Slot *gs = t.slots + (uint64_t)leaf * REGION_SLOTS;
-        const uint4 *recs = leaf_recs + (uint64_t)leaf * seg_cap;
-        const uint32_t *ptrs = leaf_ptrs + (uint64_t)leaf * seg_cap;
-        int solid_before = 0;
-        if (VIRGIN) {  // 16 bytes a store
-            for (uint32_t i = tid; i < REGION_SLOTS / 2; i += P3_THREADS) reinterpret_cast<uint4 *>(L.key)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
-            for (uint32_t i = tid; i < REGION_SLOTS / 4; i += P3_THREADS) reinterpret_cast<uint4 *>(L.ca)[i] = make_uint4(0, 0, 0, 0);
-        } else {
-            for (uint32_t i = tid; i < REGION_SLOTS; i += P3_THREADS) {
-                const uint4 raw = *reinterpret_cast<const uint4 *>(gs + i);
-                L.key[i] = ((uint64_t)raw.y << 32) | raw.x;
-                L.ca[i] = min(raw.z, 32767u);  // (anything above reads the same: kmer_device.h table_get)
-                solid_before += solid_thr && raw.z >= solid_thr;  // (empty slots hold count 0)
-            }
-        }
-        if (tid == 0) { L.n_new = 0; L.overflow = 0; }
-        new_wave = 0;
-        cur_leaf = leaf;
-        // ---- the records into the record table, 1024 at a time (nearly always all of them)
-        for (uint32_t base = 0; base < n0; base += 2 * P3_THREADS) {  // uniform
-            uint4 rec[2];
-            uint32_t rptr[2], sl[2], hh[2];
-            bool have[2];
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const uint32_t r = base + (uint32_t)q * P3_THREADS + tid;
-                have[q] = r < n0;
-                sl[q] = DD_NONE;
-                hh[q] = 0;
-                if (base == 0) { rec[q] = cur_rec[q]; rptr[q] = cur_ptr[q]; }
-                else if (have[q]) { rec[q] = recs[r]; rptr[q] = leaf_ptrs ? ptrs[r] : rec[q].x; }
-                else { rec[q] = make_uint4(0, 0, 0, 0); rptr[q] = 0; }
-                if (have[q]) {
-                    const uint32_t h = dd_hash(rec[q].y, rec[q].z, rec[q].w), tag = (h & 0xFFFF0000u) | 0x8000u;
-                    hh[q] = h;
-                    uint32_t slot = h & (DD_SLOTS - 1);
-                    for (uint32_t p = 0; p < DD_PROBES; p++) {
-                        const uint32_t old = atomicCAS(&L.drec[slot].w, 0u, tag);
-                        if (old == 0) {  // claimed: this copy's words are what the others are compared with
-                            L.drec[slot].x = rec[q].y; L.drec[slot].y = rec[q].z; L.drec[slot].z = rec[q].w;
-                            L.dptr[0][slot] = 0; L.dptr[1][slot] = 0; L.dptr[2][slot] = 0;
-                            sl[q] = slot | DD_OWNER;
-                            break;
-                        }
-                        if ((old & 0xFFFF8000u) == tag) { sl[q] = slot; break; }
-                        slot = (slot + 1) & (DD_SLOTS - 1);
-                    }
-                }
-            }
-            P3D_STAMP(0);
-            __syncthreads();
-            P3D_STAMP(1);
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                if (sl[q] != DD_NONE) {
-                    const uint32_t slot = sl[q] & ~DD_OWNER;
-                    bool same = true;
-                    if (!(sl[q] & DD_OWNER)) {
-                        const uint4 e = L.drec[slot];
-                        same = e.x == rec[q].y && e.y == rec[q].z && e.z == rec[q].w;
-                    }
-                    if (same) {
-                        // the first three copies that carry a read pointer are remembered (the occurrences of neighbouring
-                        // k-mers arrive in the same order: kmer_device.h ptr_pick says why one pointer per record is too few)
-                        const uint32_t c = atomicAdd(&L.drec[slot].w, 1u) & 0x7FFFu;
-                        if (rptr[q]) {
-                            if (c < 3u) {
-                                L.dptr[c][slot] = rptr[q];
-                            } else if (ptr_tries > 1) {  // (copies of other ranks carry none: a later one fills a field that stayed empty)
-                                for (uint32_t f = 0; f < 3u; f++)
-                                    if (L.dptr[f][slot] == 0) { L.dptr[f][slot] = rptr[q]; break; }
-                            }
-                        }
-                    } else {
-                        sl[q] = DD_NONE;  // another record with this fingerprint
-                    }
-                }
-                // records without a slot go through the window path as they are, one copy each, no pointer
-                const bool alone = have[q] && sl[q] == DD_NONE;
-                if (__ballot(alone)) expand(rec[q].y, rec[q].z, rec[q].w, alone ? 1u : 0u, false, 0u);
-            }
-        }
-        P3D_STAMP(2);
-        __syncthreads();
-        P3D_STAMP(3);
-        // ---- the distinct records into the region image
-        {   // a wave takes 128 slots of the record table; the ones in use (a quarter) are lined up first, so that a batch
-            // of 64 lanes holds 64 records
-            static_assert(DD_SLOTS == 2 * P3_THREADS, "two record slots per thread");
-            const uint32_t sa = wv * 128u + lane, sb = sa + 64u;
-            const bool ua = (L.drec[sa].w & 0x7FFFu) != 0, ub = (L.drec[sb].w & 0x7FFFu) != 0;
-            const unsigned long long ma = __ballot(ua), mb = __ballot(ub), lt = (1ull << lane) - 1ull;
-            const uint32_t na = (uint32_t)__popcll(ma), n_used = na + (uint32_t)__popcll(mb);
-            uint16_t *list = reinterpret_cast<uint16_t *>(dq);
-            if (ua) list[__popcll(ma & lt)] = (uint16_t)sa;
-            if (ub) list[na + (uint32_t)__popcll(mb & lt)] = (uint16_t)sb;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t s0 = lane < n_used ? list[lane] : DD_NONE, s1 = 64u + lane < n_used ? list[64u + lane] : DD_NONE;
-            __builtin_amdgcn_wave_barrier();  // (the list sits where the batches put their queue)
-#pragma unroll 1
-            for (uint32_t b = 0; b * 64u < n_used; b++) {  // uniform
-                const uint32_t slot = b ? s1 : s0;
-                uint4 e = make_uint4(0, 0, 0, 0);
-                bool hp = false;
-                if (slot != DD_NONE) { e = L.drec[slot]; hp = (L.dptr[0][slot] | L.dptr[1][slot] | L.dptr[2][slot]) != 0; }
-                expand(e.x, e.y, e.z, e.w & 0x7FFFu, hp, slot & (DD_SLOTS - 1));
-            }
-        }
-        if (nl < n_leaves) fetch(nl, n_nxt);  // the next leaf's first records: its count has long arrived
-        if (lane == 0 && new_wave) atomicAdd(&L.n_new, new_wave);
-        P3D_STAMP(4);
-        __syncthreads();
-        P3D_STAMP(5);
-        const bool ovf = L.overflow != 0;
-        if (!ovf) {
-            // four slots of a thread at a time, their LDS words requested together (a loop that waits for each slot's words
-            // before it stores the slot took 2.5 us of a leaf's 13)
-            for (uint32_t i0 = tid; i0 < REGION_SLOTS; i0 += 4 * P3_THREADS) {
-                uint64_t kk[4];
-                uint32_t cc[4], d3[4][3];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t i = i0 + (uint32_t)u * P3_THREADS;
-                    kk[u] = L.key[i];
-                    cc[u] = L.ca[i];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t o = cc[u] >> DD_CNT_BITS;
-                    d3[u][0] = d3[u][1] = d3[u][2] = 0;
-                    if (o) {
-                        const uint32_t sl = (o - 1u) >> 4;
-                        d3[u][0] = L.dptr[0][sl]; d3[u][1] = L.dptr[1][sl]; d3[u][2] = L.dptr[2][sl];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t i = i0 + (uint32_t)u * P3_THREADS;
-                    const uint32_t o = cc[u] >> DD_CNT_BITS;
-                    uint4 v;
-                    v.x = (uint32_t)kk[u]; v.y = (uint32_t)(kk[u] >> 32);
-                    v.z = cc[u] & DD_CNT_MASK;
-                    if (o) {  // the pointer of one of the record's copies, by bits of the key (one of three where ptr_pick has four)
-                        const uint32_t r = (uint32_t)(kk[u] ^ (kk[u] >> 9) ^ (kk[u] >> 23)) & 3u;
-                        const uint32_t a0 = r == 1u ? d3[u][1] : (r == 2u ? d3[u][2] : d3[u][0]);   // field r mod 3 ...
-                        const uint32_t a1 = r == 1u ? d3[u][2] : (r == 2u ? d3[u][0] : d3[u][1]);   // ... the next ...
-                        const uint32_t a2 = r == 1u ? d3[u][0] : (r == 2u ? d3[u][1] : d3[u][2]);   // ... and the one after
-                        const uint32_t p0 = a0 ? a0 : (a1 ? a1 : a2);
-                        v.w = ptr_advance(p0, (o - 1u) & 15u);
-                    }
-                    else if (VIRGIN) v.w = 0;
-                    else v.w = reinterpret_cast<const uint32_t *>(gs + i)[3];  // the pointer the slot had
-                    *reinterpret_cast<uint4 *>(gs + i) = v;
-                    const bool solid = solid_thr && v.z >= solid_thr;
-                    solid_delta += solid;
-                    if (emitting) {  // (uniform; the loop's trip count is the same for every lane)
-                        const unsigned long long m = __ballot(solid);
-                        if (m) {
-                            uint32_t ebase = 0;
-                            const int leader = __ffsll((long long)m) - 1;
-                            if ((int)lane == leader) ebase = atomicAdd(&L.emit_cur, (uint32_t)__popcll(m));
-                            ebase = __shfl(ebase, leader);
-                            if (solid) {
-                                const uint32_t pos = ebase + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-                                if (pos < emit.seg_cap) {
-                                    v.z = min(v.z, 32767u);
-                                    emit.recs[(uint64_t)blockIdx.x * emit.seg_cap + pos] = v;
-                                } else {
-                                    atomicExch(emit.lost, 1u);
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-            solid_delta -= solid_before;
-        } else if (VIRGIN) {  // nothing was there: leave a valid empty region behind
-            for (uint32_t i = tid; i < REGION_SLOTS; i += P3_THREADS) {
-                uint4 v; v.x = 0xFFFFFFFFu; v.y = 0xFFFFFFFFu; v.z = 0; v.w = 0;
-                *reinterpret_cast<uint4 *>(gs + i) = v;
-            }
-        }
-        for (uint32_t i = tid; i < DD_SLOTS; i += P3_THREADS) L.drec[i].w = 0;
-        if (tid == 0) {
-            if (!ovf) { leaf_state[leaf] = 1; leaf_new[leaf] = L.n_new; } else atomicExch(any_failed, 1u);
-        }
-        P3D_STAMP(6);
-        __syncthreads();
-#ifdef MC_P3_TIMING
-        n_lv++;
-#endif
-    }
-#ifdef MC_P3_TIMING
-    if (blockIdx.x == 7 && (tid == 0 || tid == 448)) printf("[p3d block 7 thread %u] %llu leaves, us per leaf: init+A1 %.2f wait %.2f A2 %.2f wait %.2f B %.2f wait %.2f writeback %.2f wait+next %.2f\n", tid, n_lv, tph[0] * 0.01 / n_lv, tph[1] * 0.01 / n_lv, tph[2] * 0.01 / n_lv, tph[3] * 0.01 / n_lv, tph[4] * 0.01 / n_lv, tph[5] * 0.01 / n_lv, tph[6] * 0.01 / n_lv, tph[7] * 0.01 / n_lv);
-#endif
-    if (solid_thr) wave_add_ull(n_solid, (unsigned long long)solid_delta);  // (two's complement: deltas may be negative)
-    if (emitting) {
-        __syncthreads();
-        if (tid == 0) emit.counts[blockIdx.x] = (uint64_t)L.emit_cur < emit.seg_cap ? L.emit_cur : (uint32_t)emit.seg_cap;
-    }
-}
-
-// =============================================================================================
-// k_p3_dedup2 (round 5): the same merge -- identical records first, then the distinct ones' windows into the region image --
-// with the expansion rebuilt around what round 4's counters and the kernel's ISA showed: a window cost a byte-table read,
+// Round 5: the kernel rebuilt around what round 4's counters and its ISA showed (the round-4 kernel: a window cost a byte-table read,
 // FIVE cross-lane reads (ds_bpermute: 24 ticks of the SIMD's LDS port each), 21 vector instructions for its two strands
-// and a probe loop of its own; the prefix over a wave's records was six dependent ds_bpermutes; and the eight waves'
-// shares of a leaf differed by a quarter.  Here
+// and a probe loop of its own; the prefix over a wave's records was six dependent ds_bpermutes; the eight waves' shares of
+// a leaf differed by a quarter; and -- what decided -- the kernel's time follows the number of instructions its waves issue,
+// scalar ones included: 3.9 G of them at a quarter of an instruction a cycle and SIMD, 45 % scalar, most of those the
+// compiler's bookkeeping of divergent branches).  Here
 //   * the unit of work is a PAIR of windows of one record: its lane reads the record itself from the record table (one
 //     ds_read_b128 -- lanes of one record read the same address: a broadcast), cuts the 32 bases the pair spans out once,
 //     reverse-complements them once, and both windows' strands are shifts and masks of those two words;
@@ -2190,7 +1855,10 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_dedup(const uint4 *__restrict
 //   * the units of ALL distinct records of the leaf are lined up in one list (a DPP prefix per wave, one LDS atomic per wave
 //     for its place) and every wave takes an eighth of the list;
 //   * which occurrence leaves its pointer is decided by two bits of the home-slot hash the window needs anyway.
-// Results are those of k_p3_dedup (every parity test runs through this kernel; MC_P3_V2=0 launches the old one).
+//   * what the compiler turned into exec-mask bookkeeping is written without branches or by hand: the record table's claims
+//     (lds_tag_claim), the unit list (lds_line_up8), loops of known trip count unrolled, inserted keys counted when the region
+//     goes back (occupied slots after - before) instead of in every probe step.
+// 7.3 -> 5.9 ms on configs[1] (DESIGN.md section 3.1 has the steps and the instruction budget).
 #ifndef MC_D2_THREADS
 #define MC_D2_THREADS 512
 #endif
@@ -2210,7 +1878,7 @@ static_assert(D2_NQ * D2_THREADS == (int)D2_SLOTS && (D2_NQ == 1 || D2_NQ == 2),
 constexpr uint32_t D2_UL_CAP = MC_D2_UL_CAP;        // units queued at a time (a leaf of configs[1] holds ~1300)
 constexpr uint32_t D2_CP_MASK = 0xFFFu;  // copies of a record: <= DD_MAX_CAP = 2048
 
-struct alignas(16) Dedup2Lds {
+struct alignas(16) DedupLds {
     uint64_t key[REGION_SLOTS];         // at LDS address 0: the probe loop's addresses are offsets into it
     uint32_t ca[REGION_SLOTS];          // count | (1 + (record slot << 4 | window)) << DD_CNT_BITS
     uint4 drec[D2_SLOTS];               // {d0, d1, d2 | windows - 1, fingerprint << 16 | 0x8000 | copies}: the bases top-aligned in d0:d1:d2; .w == 0: free
@@ -2218,7 +1886,7 @@ struct alignas(16) Dedup2Lds {
     uint16_t ul[D2_UL_CAP];             // record slot << 3 | pair number
     uint32_t n_new, overflow, emit_cur, n_units;
 };
-static_assert(sizeof(Dedup2Lds) * (1024 / D2_THREADS) <= 160 * 1024, "sixteen waves of the merge kernel on a CU");
+static_assert(sizeof(DedupLds) * (1024 / D2_THREADS) <= 160 * 1024, "sixteen waves of the merge kernel on a CU");
 
 // kmer_device.h rc64_pairs word by word: the bits reversed, the two bits of every base swapped back (one v_bfi), complemented
 __device__ __forceinline__ uint32_t rc32_pairs_fast(uint32_t x)
@@ -2414,14 +2082,14 @@ __device__ __forceinline__ void lds_line_up8(uint32_t dst, uint32_t val, uint32_
 }
 
 template <bool VIRGIN>
-__global__ void __launch_bounds__(D2_THREADS, MC_D2_WAVES_PER_EU) k_p3_dedup2(const uint4 *__restrict__ leaf_recs, const uint32_t *__restrict__ leaf_ptrs,
+__global__ void __launch_bounds__(D2_THREADS, MC_D2_WAVES_PER_EU) k_p3_dedup(const uint4 *__restrict__ leaf_recs, const uint32_t *__restrict__ leaf_ptrs,
                                                           const uint32_t *__restrict__ leaf_counts, uint64_t seg_cap, uint32_t n_leaves,
                                                           TableView t, uint32_t *leaf_state, uint32_t *leaf_new, uint32_t *any_failed,
                                                           uint32_t solid_thr, unsigned long long *n_solid, int k, P3Emit emit,
                                                           uint32_t ptr_tries, const uint32_t *lost)
 {
     if (lost && *lost) return;
-    __shared__ Dedup2Lds L;
+    __shared__ DedupLds L;
     const uint32_t tid = threadIdx.x, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = tid & 63u;
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint64_t *)L.key != 0u) {  // (uniform; never: the kernel's one LDS object)
         if (tid == 0) atomicExch(any_failed, 1u);
@@ -2441,8 +2109,8 @@ __global__ void __launch_bounds__(D2_THREADS, MC_D2_WAVES_PER_EU) k_p3_dedup2(co
     };
     clear_records();
     long long solid_delta = 0;
-    static_assert(offsetof(Dedup2Lds, drec) % (D2_SLOTS * 16u) == 0, "lds_tag_claim wraps inside the aligned record table");
-    const uint32_t drec_w = (uint32_t)offsetof(Dedup2Lds, drec) + 12u;  // byte address of the first tag word (the struct sits at LDS address 0)
+    static_assert(offsetof(DedupLds, drec) % (D2_SLOTS * 16u) == 0, "lds_tag_claim wraps inside the aligned record table");
+    const uint32_t drec_w = (uint32_t)offsetof(DedupLds, drec) + 12u;  // byte address of the first tag word (the struct sits at LDS address 0)
     const uint32_t ptr_from = solid_thr >= 2 ? 1u : 0u;
     const uint32_t sh_a = 64u - 2u * (uint32_t)k, sh_b = 62u - 2u * (uint32_t)k;  // (k <= 31: a pair of windows spans k + 1 <= 32 bases)
     const uint64_t kmask = ~0ull >> sh_a;
@@ -2633,7 +2301,7 @@ __global__ void __launch_bounds__(D2_THREADS, MC_D2_WAVES_PER_EU) k_p3_dedup2(co
             for (int q = 0; q < D2_NQ; q++) {
                 const uint32_t val = (tid + (uint32_t)q * D2_THREADS) << 3;
                 if (inside) {
-                    lds_line_up8((uint32_t)offsetof(Dedup2Lds, ul) + 2u * (u_at[q] - r0), val, u_cnt[q]);  // (the struct sits at LDS address 0)
+                    lds_line_up8((uint32_t)offsetof(DedupLds, ul) + 2u * (u_at[q] - r0), val, u_cnt[q]);  // (the struct sits at LDS address 0)
                 } else {
                     for (uint32_t u = 0; u < u_cnt[q]; u++) {
                         const uint32_t at = u_at[q] + u - r0;
@@ -2845,7 +2513,7 @@ __global__ void __launch_bounds__(D2_THREADS, MC_D2_WAVES_PER_EU) k_p3_dedup2(co
 #endif
     }
 #ifdef MC_P3_TIMING
-    if (blockIdx.x == 7 && (tid == 0 || tid == 448)) printf("[p3d2 block 7 thread %u] %llu leaves, us per leaf: init+A1 %.2f wait %.2f A2+line-up %.2f wait %.2f B %.2f wait %.2f writeback %.2f wait+next %.2f\n", tid, n_lv, tph[0] * 0.01 / n_lv, tph[1] * 0.01 / n_lv, tph[2] * 0.01 / n_lv, tph[3] * 0.01 / n_lv, tph[4] * 0.01 / n_lv, tph[5] * 0.01 / n_lv, tph[6] * 0.01 / n_lv, tph[7] * 0.01 / n_lv);
+    if (blockIdx.x == 7 && (tid == 0 || tid == 448)) printf("[p3d block 7 thread %u] %llu leaves, us per leaf: init+A1 %.2f wait %.2f A2+line-up %.2f wait %.2f B %.2f wait %.2f writeback %.2f wait+next %.2f\n", tid, n_lv, tph[0] * 0.01 / n_lv, tph[1] * 0.01 / n_lv, tph[2] * 0.01 / n_lv, tph[3] * 0.01 / n_lv, tph[4] * 0.01 / n_lv, tph[5] * 0.01 / n_lv, tph[6] * 0.01 / n_lv, tph[7] * 0.01 / n_lv);
 #endif
     if (solid_thr) wave_add_ull(n_solid, (unsigned long long)solid_delta);  // (two's complement: deltas may be negative)
     if (emitting) {

@@ -1,10 +1,4 @@
 cd /root/repo
-for v in "" t2; do
-  echo "== lib=${v:-product}"
-  if [ -n "$v" ]; then export MC_LIB=metacherchant_amd/lib/libmcgpu_$v.so; else unset MC_LIB; fi
-  timeout -k 10 200 python scripts/count_only.py 100 2>&1 | grep -v amdgpu.ids | tail -3
-done
-unset MC_LIB
-python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | tail -3
-MC_LIB=metacherchant_amd/lib/libmcgpu_ul64.so python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | tail -3
-bash scripts/gpu_variants.sh old::MC_P3_V2=0 new::MC_P3_V2=1
+MC_LIB=metacherchant_amd/lib/libmcgpu_p1time.so timeout -k 10 300 python bench.py --config 2 --reads 10000000 --contigs 10 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/b_p1time.json 2> gpurun_out/b_p1time.err
+grep -h "p1 block" gpurun_out/b_p1time.err gpurun_out/b_p1time.json | tail -4
+tail -c 600 gpurun_out/b_p1time.json

@@ -7,6 +7,7 @@ set -o pipefail
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 L=metacherchant_amd/lib
+python -c "from metacherchant_amd import build as b; b.build_variants(names=('fuzz', 'fuzz_old', 'trace_old'))" || exit 1   # (only `fuzz` comes with build())
 W=${HUNT_WALKS:-20000}
 STEPS=${HUNT_STEPS:-product fuzz old fuzz_old}
 for s in $STEPS; do

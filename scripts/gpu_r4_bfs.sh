@@ -4,6 +4,7 @@
 set -o pipefail
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
+python -c "from metacherchant_amd import build as b; b.build_variants(names=('fuzz', 'sctime'))" || exit 1   # (only `fuzz` comes with build())
 timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_bfs_race.py -x -q -m gpu -k "bfs or walk or race or fixed or selfcheck or round3" > gpurun_out/r4_bfs_tests.log 2>&1; rc=$?; echo "bfs tests rc=$rc"; tail -3 gpurun_out/r4_bfs_tests.log
 [ $rc -eq 0 ] || exit $rc
 timeout -k 10 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --skip-no-hint > gpurun_out/r4_bench_bfs.json 2> gpurun_out/r4_bench_bfs.err; echo "bench rc=$?"; python - <<'PY'

@@ -10,7 +10,8 @@ different time behind every barrier.  So:
   vertices of --maxkmers, two and three jobs a launch) exactly like src/algo/OneSequenceCalculator.java:154-214 restated in
   oracle/mc_oracle.c.
 
-Both libraries are built by __graft_entry__.build() next to the product library."""
+The fuzzed build of the current kernel comes with __graft_entry__.build(); the old kernel's half is opt-in (MC_RUN_OLD_RACE=1:
+it needs a library of its own, is probabilistic by nature, and a kernel whose waves fall out of step can hold the GPU)."""
 import os
 import subprocess
 import sys
@@ -24,10 +25,7 @@ STRESS = os.path.join(ROOT, "scripts", "bfs_endgame_stress.py")
 
 def _variant(name):
     from metacherchant_amd import build as b
-    path = os.path.join(b.LIBDIR, "libmcgpu_%s.so" % name)
-    if not os.path.exists(path):
-        pytest.fail("%s is missing: __graft_entry__.build() makes it (metacherchant_amd/build.py build_variants)" % path)
-    return path
+    return b.build_variant(name)  # (`fuzz` comes with __graft_entry__.build(); anything else is compiled here, a minute of hipcc)
 
 
 def _stress(lib, *args):
@@ -36,8 +34,13 @@ def _stress(lib, *args):
     return subprocess.run([sys.executable, STRESS] + list(args), capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
 
 
+@pytest.mark.skipif(os.environ.get("MC_RUN_OLD_RACE") != "1", reason="opt-in (MC_RUN_OLD_RACE=1): a deliberately racy kernel must FAIL within 900 walks -- "
+                    "probabilistic, and waves out of step at barriers can hold a shared GPU for minutes (ADVICE r4); profiles/r04_bfs_hunts.txt has its runs")
 def test_round3_kernel_goes_wrong_when_its_waves_are_held_up():
-    p = _stress(_variant("fuzz_old"), "--walks", "900", "--jobs", "3", "--max-bad", "2")
+    try:
+        p = _stress(_variant("fuzz_old"), "--walks", "900", "--jobs", "3", "--max-bad", "2")
+    except subprocess.TimeoutExpired:
+        pytest.skip("the racy kernel hung until the time limit: that is one of the ways it goes wrong, but nothing to gate on")
     out = p.stdout + p.stderr
     assert p.returncode == 1, out[-3000:]
     assert "self-check failed" in out or "first differences" in out, out[-3000:]
