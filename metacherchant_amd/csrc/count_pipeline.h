@@ -590,6 +590,18 @@ constexpr int P1W_SEGMENTS = 1024;             // workgroups of the launch = seg
 static_assert(PT_MAX_LEAVES2 <= PT_THREADS && PT_MAX_BUCKETS_KEYS <= PT_THREADS, "one thread per leaf cursor");
 static_assert(P1W_SEGMENTS <= PT_THREADS && P1W_SEGMENTS >= PT_SEGMENTS, "k_sk2_scatter scans one segment count per thread");
 
+// inclusive prefix sum over the wave's lanes (row_shr 1, 2, 4, 8 inside a row of sixteen, then the rows' totals: row_bcast 15 / 31)
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+    return v;
+}
+
 struct alignas(16) Sk1wLds {
     uint32_t wcur[PT_MAX_BUCKETS1_SK];  // this workgroup's fill level of every bucket
     uint32_t starts[P1W_WAVES][24];    // per wave: bit b <-> "a read starts at position lo - 64 + b" (704 bits used)
@@ -808,13 +820,8 @@ __global__ void __launch_bounds__(P1W_THREADS, MC_P1W_MIN_WAVES) k_sk1w_extract(
         // every window, the break bitmap.
         {
             const uint32_t cnt = (uint32_t)__builtin_popcount(start_bits);
-            uint32_t incl = cnt;
-#pragma unroll
-            for (uint32_t o = 1; o < 64; o <<= 1) {
-                const uint32_t v = __shfl_up(incl, o);
-                if (lane >= o) incl += v;
-            }
-            const uint32_t total = __shfl(incl, 63);
+            const uint32_t incl = wave_incl_sum(cnt);  // (six DPP additions; as six cross-lane reads through the LDS port it was 24 instructions)
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             uint32_t at = incl - cnt;
             for (uint32_t todo = start_bits; todo; todo &= todo - 1) squeue[at++] = (uint16_t)(lane * PT_ITEMS + (uint32_t)__builtin_ctz(todo));
             const uint32_t r7 = (uint32_t)(((int64_t)lo - 7) & 31);             // (lo - 7) = 32 * wbase + r7
@@ -1899,18 +1906,6 @@ __device__ __forceinline__ uint64_t rc64_pairs_fast(uint64_t x)
     return ((uint64_t)rc32_pairs_fast((uint32_t)x) << 32) | rc32_pairs_fast((uint32_t)(x >> 32));
 }
 
-// inclusive prefix sum over the wave's lanes (row_shr 1, 2, 4, 8 inside a row of sixteen, then the rows' totals: row_bcast 15 / 31)
-__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v)
-{
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
-    return v;
-}
-
 // lds_probe_claim for two keys a lane: offA / offB = byte offsets of the home slots in the key array AT LDS ADDRESS 0, mA / mB =
 // the lanes that hold a first / a second key.  A lane is done with a key when it found it or claimed a free slot.  Two steps
 // with both compare-and-swaps in flight together settle 95 % of the keys; the slowest of a wave's 128 keys needs 4.6 steps
@@ -2349,8 +2344,11 @@ __global__ void __launch_bounds__(D2_THREADS, MC_D2_WAVES_PER_EU) k_p3_dedup(con
                 const uint32_t hxA = sk_home_mix(keyA), hxB = sk_home_mix(keyB);
                 uint32_t offA = (hxA >> (32 - MC_REGION_LG)) << 3, offB = (hxB >> (32 - MC_REGION_LG)) << 3;
                 unsigned long long pendA, pendB;
-                lds_probe_claim2(offA, offB, keyA, keyB, __ballot(va), __ballot(vb), &pendA, &pendB);
-                const bool okA = va && !((pendA >> lane) & 1ull), okB = vb && !((pendB >> lane) & 1ull);
+                // (lane masks straight from and to conditions: __ballot(int) and a shifted-mask test cost two and three vector
+                // instructions each where the hardware needs none)
+                const unsigned long long mvA = __builtin_amdgcn_ballot_w64(va), mvB = __builtin_amdgcn_ballot_w64(vb);
+                lds_probe_claim2(offA, offB, keyA, keyB, mvA, mvB, &pendA, &pendB);
+                const bool okA = __builtin_amdgcn_inverse_ballot_w64(mvA & ~pendA), okB = __builtin_amdgcn_inverse_ballot_w64(mvB & ~pendB);
                 // (a lane without a key adds nothing to a word of its own)
                 const uint32_t sA = okA ? offA >> 3 : lane, sB = okB ? offB >> 3 : lane;
                 const uint32_t befA = atomicAdd(&L.ca[sA], okA ? cp : 0u) & DD_CNT_MASK;
@@ -2360,7 +2358,7 @@ __global__ void __launch_bounds__(D2_THREADS, MC_D2_WAVES_PER_EU) k_p3_dedup(con
                 const uint32_t firstB = ptr_from + 1u + ((pick_tbl >> ((hxB >> 17) & 6u)) & 3u);
                 const bool wantA = okA && befA < firstA + ptr_tries - 1u && befA + cp >= firstA;  // (one addition per key when ptr_tries == 1)
                 const bool wantB = okB && befB < firstB + ptr_tries - 1u && befB + cp >= firstB;
-                const unsigned long long wmA = __ballot(wantA), wmB = __ballot(wantB);
+                const unsigned long long wmA = __builtin_amdgcn_ballot_w64(wantA), wmB = __builtin_amdgcn_ballot_w64(wantB);
                 if (wmA | wmB) {  // uniform
                     const uint32_t wnA = (uint32_t)__popcll(wmA), wnB = (uint32_t)__popcll(wmB);
                     if (one_round) {
@@ -2388,8 +2386,10 @@ __global__ void __launch_bounds__(D2_THREADS, MC_D2_WAVES_PER_EU) k_p3_dedup(con
                             }
                     }
                 }
-                if (va && !okA && !ovf_push(t, keyA, cp, 0u, cur_leaf)) atomicExch(&L.overflow, 1u);
-                if (vb && !okB && !ovf_push(t, keyB, cp, 0u, cur_leaf)) atomicExch(&L.overflow, 1u);
+                if (pendA | pendB) {  // uniform; a region that is full (the table's chain takes the occurrence: TableView::ovf)
+                    if (__builtin_amdgcn_inverse_ballot_w64(pendA) && !ovf_push(t, keyA, cp, 0u, cur_leaf)) atomicExch(&L.overflow, 1u);
+                    if (__builtin_amdgcn_inverse_ballot_w64(pendB) && !ovf_push(t, keyB, cp, 0u, cur_leaf)) atomicExch(&L.overflow, 1u);
+                }
             }
             // the wave's notes become pointers, a lane each: one of the record's (up to three) copies' pointers, moved on to the
             // window; the region slot gets the note's place, and the write-back finds the pointer there
