@@ -277,7 +277,7 @@ def main():
             # its kernels were built from, and the number is only reported while the counting kernels are unchanged since
             # (git diff of csrc/count_pipeline.h and csrc/kmer_device.h against that commit is empty), else null.
             traffic, traffic_source = None, None
-            pmc = os.path.join(ROOT, "profiles", "r04_pmc_hbm_traffic_e1.csv")
+            pmc = os.path.join(ROOT, "profiles", "r05_pmc_hbm_traffic_e1.csv")
             if pipeline and world == 1 and args.err == 100 and R == 10_000_000 and k == 31 and os.path.exists(pmc):
                 import csv
                 import subprocess
@@ -296,10 +296,11 @@ def main():
                         if row.get("dispatch", "1") != "2":
                             continue  # (dispatch 1: the cold step, 2: the warm one -- mc_clear, the same table again: what the bench times)
                         # (k_sk2_scatter is also used by the BFS-table build of a sharded run; on one GPU only by the pipeline)
-                        if row["kernel"].startswith(("mc::k_sk1w_extract", "mc::k_p3_merge", "mc::k_p3_dedup", "mc::k_sk2_scatter", "void mc::k_sk1w_extract", "void mc::k_p3_merge", "void mc::k_p3_dedup")):
+                        # (the three kernels of the headline's pipeline; the file may also hold the config2 leg's per-window kernels)
+                        if row["kernel"].startswith(("mc::k_sk1w_extract", "mc::k_p3_dedup", "mc::k_sk2_scatter", "void mc::k_sk1w_extract", "void mc::k_p3_dedup", "void mc::k_sk2_scatter")):
                             gb += float(row["fetch_GB_corrected_x2"]) + float(row["write_GB"])
                     traffic = round(gb * 1e9)
-                    traffic_source = "profiles/r04_pmc_hbm_traffic_e1.csv (commit %s; the warm step's dispatches)" % commit
+                    traffic_source = "profiles/r05_pmc_hbm_traffic_e1.csv (commit %s; the warm step's dispatches)" % commit
             roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                         "kernel": dominant, "launch": "counting pipeline p1+p2+p3" if pipeline else "k_count_reads",
