@@ -1836,7 +1836,8 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_merge(const void *__restrict_
 // had used that read up found no other: + 1 ms of walk).  Table layout, probing and results are those of k_p3_merge.
 constexpr uint32_t DD_PROBES = 8;
 constexpr uint32_t DD_CNT_BITS = 17, DD_CNT_MASK = (1u << DD_CNT_BITS) - 1;
-constexpr uint32_t DD_MAX_CAP = 2048;    // records per leaf: 32767 + 2048 * 16 windows < 2^17, and copies < 2^12
+constexpr uint32_t DD_MAX_CAP = 4096;    // records per leaf: 32767 + 4096 * 16 windows < 2^17, and copies < 2^13 (round 4: 2048 -- the leaves of
+                                         // error-free reads, whose table is small, hold ~2650 and all went to the general kernel)
 constexpr uint32_t DD_NONE = 0xFFFFFFFFu, DD_OWNER = 0x80000000u;
 
 __device__ __forceinline__ uint32_t dd_hash(uint32_t y, uint32_t z, uint32_t w)
@@ -1883,15 +1884,17 @@ constexpr uint32_t D2_SLOTS = MC_D2_SLOTS;          // its record table (a leaf 
 constexpr int D2_NQ = D2_SLOTS / D2_THREADS;        // record table slots, and records of a round, per thread
 static_assert(D2_NQ * D2_THREADS == (int)D2_SLOTS && (D2_NQ == 1 || D2_NQ == 2), "one or two record slots per thread");
 constexpr uint32_t D2_UL_CAP = MC_D2_UL_CAP;        // units queued at a time (a leaf of configs[1] holds ~1300)
-constexpr uint32_t D2_CP_MASK = 0xFFFu;  // copies of a record: <= DD_MAX_CAP = 2048
+constexpr uint32_t D2_CP_MASK = 0x1FFFu;  // copies of a record: <= DD_MAX_CAP = 4096 (the tag word keeps 15 bits for them)
+static_assert(32767u + DD_MAX_CAP * SK_MAX_WINDOWS < (1u << DD_CNT_BITS) && DD_MAX_CAP <= D2_CP_MASK, "a leaf's additions fit the packed counters");
 
 struct alignas(16) DedupLds {
     uint64_t key[REGION_SLOTS];         // at LDS address 0: the probe loop's addresses are offsets into it
     uint32_t ca[REGION_SLOTS];          // count | (1 + (record slot << 4 | window)) << DD_CNT_BITS
     uint4 drec[D2_SLOTS];               // {d0, d1, d2 | windows - 1, fingerprint << 16 | 0x8000 | copies}: the bases top-aligned in d0:d1:d2; .w == 0: free
     uint32_t dptr[3][D2_SLOTS];
-    uint16_t ul[D2_UL_CAP];             // record slot << 3 | pair number
+    uint16_t ul[D2_UL_CAP];             // record slot << 3 | pair number; behind what a wave has read of it, and from its end down: pointers (32 bits)
     uint32_t n_new, overflow, emit_cur, n_units;
+    uint32_t want_used, pad_[3];        // pointers noted from the list's end down (the waves' own parts ran out)
 };
 static_assert(sizeof(DedupLds) * (1024 / D2_THREADS) <= 160 * 1024, "sixteen waves of the merge kernel on a CU");
 
@@ -2076,13 +2079,16 @@ __device__ __forceinline__ void lds_line_up8(uint32_t dst, uint32_t val, uint32_
         : "vcc", "memory");
 }
 
-template <bool VIRGIN>
+// ONE_GPU: the run of one GPU on its own reads -- every record carries its pointer (ptr_tries == 1) and no list of solid k-mers
+// is kept for a gather (P3Emit): the branches of the other case leave the loops (uniform ones cost scalar instructions too)
+template <bool VIRGIN, bool ONE_GPU>
 __global__ void __launch_bounds__(D2_THREADS, MC_D2_WAVES_PER_EU) k_p3_dedup(const uint4 *__restrict__ leaf_recs, const uint32_t *__restrict__ leaf_ptrs,
                                                           const uint32_t *__restrict__ leaf_counts, uint64_t seg_cap, uint32_t n_leaves,
                                                           TableView t, uint32_t *leaf_state, uint32_t *leaf_new, uint32_t *any_failed,
                                                           uint32_t solid_thr, unsigned long long *n_solid, int k, P3Emit emit,
-                                                          uint32_t ptr_tries, const uint32_t *lost)
+                                                          uint32_t ptr_tries_arg, const uint32_t *lost)
 {
+    const uint32_t ptr_tries = ONE_GPU ? 1u : ptr_tries_arg;
     if (lost && *lost) return;
     __shared__ DedupLds L;
     const uint32_t tid = threadIdx.x, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = tid & 63u;
@@ -2090,7 +2096,7 @@ __global__ void __launch_bounds__(D2_THREADS, MC_D2_WAVES_PER_EU) k_p3_dedup(con
         if (tid == 0) atomicExch(any_failed, 1u);
         return;
     }
-    const bool emitting = emit.recs != nullptr && solid_thr != 0;
+    const bool emitting = !ONE_GPU && emit.recs != nullptr && solid_thr != 0;
     if (tid == 0) L.emit_cur = emitting ? emit.counts[blockIdx.x] : 0u;
     auto clear_records = [&] {  // the record table's tags and pointer fields (trip counts known: no loop bookkeeping)
 #pragma unroll
@@ -2194,7 +2200,7 @@ __global__ void __launch_bounds__(D2_THREADS, MC_D2_WAVES_PER_EU) k_p3_dedup(con
                 occupied -= (uint32_t)__popcll(__ballot(raw.z != 0));  // (a key in the table has been counted at least once)
             }
         }
-        if (tid == 0) { L.n_new = 0; L.overflow = 0; L.n_units = 0; }
+        if (tid == 0) { L.n_new = 0; L.overflow = 0; L.n_units = 0; L.want_used = 0; }
         cur_leaf = leaf;
         // ---- A: the records into the record table, 1024 at a time (nearly always all of them)
         for (uint32_t base = 0; base < n0; base += D2_SLOTS) {  // uniform
@@ -2313,6 +2319,30 @@ __global__ void __launch_bounds__(D2_THREADS, MC_D2_WAVES_PER_EU) k_p3_dedup(con
         const uint32_t n_units = L.n_units;
         const bool one_round = n_units <= D2_UL_CAP;
         uint32_t *wl = reinterpret_cast<uint32_t *>(L.ul);
+        const uint32_t tail_lo = (n_units + 1u) >> 1;  // the list's 32-bit words behind the units
+        // the pointer of window j of the record in slot rs: one of the record's (up to three) copies' pointers, chosen by bits of the
+        // region slot sg, moved on to the window
+        auto window_ptr = [&](uint32_t rs, uint32_t j, uint32_t sg) {
+            const uint32_t r = sg & 3u, f = r == 3u ? 0u : r;
+            uint32_t p0 = L.dptr[f][rs];
+            if (p0 == 0) p0 = L.dptr[0][rs];
+            if (ptr_tries > 1 && p0 == 0) p0 = L.dptr[1][rs] ? L.dptr[1][rs] : L.dptr[2][rs];  // (fields fill in the order of ALL copies there)
+            return p0 - 1u < 0x7FFFFFEFu ? p0 + j : ptr_advance(p0, j);  // (exact pointers: kmer_device.h ptr_advance's first case)
+        };
+        auto note_ptr = [&](uint32_t sg, uint32_t at, uint32_t pw) {  // region slot sg finds its pointer in word `at` of the list
+            wl[at] = pw;
+            if (pw) {
+                const uint32_t occ = (at + 1u) << DD_CNT_BITS;
+                if (ptr_tries == 1) {
+                    atomicOr(&L.ca[sg], occ);
+                } else {  // (records of other ranks carry no pointer: the first occurrence that has one takes the field)
+                    for (int a = 0; a < 4; a++) {
+                        const uint32_t cur = L.ca[sg];
+                        if ((cur >> DD_CNT_BITS) != 0 || atomicCAS(&L.ca[sg], cur, cur | occ) == cur) break;
+                    }
+                }
+            }
+        };
         for (uint32_t r0 = 0; r0 < n_units; r0 += D2_UL_CAP) {  // uniform; nearly always one round
             if (r0) {
                 __syncthreads();
@@ -2368,7 +2398,24 @@ __global__ void __launch_bounds__(D2_THREADS, MC_D2_WAVES_PER_EU) k_p3_dedup(con
                         const uint32_t iB = wcur + wnA + __builtin_amdgcn_mbcnt_hi((uint32_t)(wmB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wmB, 0u));
                         if (wantA && iA < wlim) wl[iA] = sA << 14 | slot << 4 | ja;
                         if (wantB && iB < wlim) wl[iB] = sB << 14 | slot << 4 | (ja + 1u);
-                        wcur = min(wcur + wnA + wnB, wlim);  // (what finds no room leaves no pointer: a hint less)
+                        if (wcur + wnA + wnB > wlim) {  // uniform
+                            // More crossings than the wave has read units: error-free reads -- few distinct records, every window
+                            // of them a k-mer that reaches the threshold at once.  Those pointers are worked out here and noted
+                            // from the END of the list down, where no unit lies (an LDS counter hands the words out).
+                            const bool oA = wantA && iA >= wlim, oB = wantB && iB >= wlim;
+                            const unsigned long long omA = __builtin_amdgcn_ballot_w64(oA), omB = __builtin_amdgcn_ballot_w64(oB);
+                            const uint32_t onA = (uint32_t)__popcll(omA), on = onA + (uint32_t)__popcll(omB);
+                            uint32_t ob = 0;
+                            if (lane == 0) ob = atomicAdd(&L.want_used, on);
+                            ob = (uint32_t)__builtin_amdgcn_readfirstlane((int)ob);
+                            const uint32_t top = D2_UL_CAP / 2u - 1u;
+                            const uint32_t kA = ob + __builtin_amdgcn_mbcnt_hi((uint32_t)(omA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)omA, 0u));
+                            const uint32_t kB = ob + onA + __builtin_amdgcn_mbcnt_hi((uint32_t)(omB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)omB, 0u));
+                            // (what finds no room there either leaves no pointer: a hint less)
+                            if (oA && kA <= top && top - kA >= tail_lo) note_ptr(sA, top - kA, window_ptr(slot, ja, sA));
+                            if (oB && kB <= top && top - kB >= tail_lo) note_ptr(sB, top - kB, window_ptr(slot, ja + 1u, sB));
+                        }
+                        wcur = min(wcur + wnA + wnB, wlim);
                     } else {
                         // a leaf of more units than the list holds: (record slot, window) beside the count, worked out when the region goes back
                         const uint32_t occA = (((slot << 4) | ja) + 1u) << DD_CNT_BITS, occB = occA + (1u << DD_CNT_BITS);
@@ -2398,23 +2445,7 @@ __global__ void __launch_bounds__(D2_THREADS, MC_D2_WAVES_PER_EU) k_p3_dedup(con
                 const uint32_t i = i0 + lane;
                 if (i < wcur) {
                     const uint32_t e = wl[i], rs = (e >> 4) & (D2_SLOTS - 1u), j = e & 15u, sg = e >> 14;
-                    const uint32_t r = sg & 3u, f = r == 3u ? 0u : r;
-                    uint32_t p0 = L.dptr[f][rs];
-                    if (p0 == 0) p0 = L.dptr[0][rs];
-                    if (ptr_tries > 1 && p0 == 0) p0 = L.dptr[1][rs] ? L.dptr[1][rs] : L.dptr[2][rs];  // (fields fill in the order of ALL copies there)
-                    const uint32_t pw = p0 - 1u < 0x7FFFFFEFu ? p0 + j : ptr_advance(p0, j);  // (exact pointers: kmer_device.h ptr_advance's first case)
-                    wl[i] = pw;
-                    if (pw) {
-                        const uint32_t occ = (i + 1u) << DD_CNT_BITS;
-                        if (ptr_tries == 1) {
-                            atomicOr(&L.ca[sg], occ);
-                        } else {  // (records of other ranks carry no pointer: the first occurrence that has one takes the field)
-                            for (int a = 0; a < 4; a++) {
-                                const uint32_t cur = L.ca[sg];
-                                if ((cur >> DD_CNT_BITS) != 0 || atomicCAS(&L.ca[sg], cur, cur | occ) == cur) break;
-                            }
-                        }
-                    }
+                    note_ptr(sg, i, window_ptr(rs, j, sg));
                 }
             }
         }

@@ -1453,8 +1453,11 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
 #define P3D_ARGS static_cast<const uint4 *>(lk), lh, lc, lcap, leaves, c->view(), P.leaf_state, P.leaf_new, P.flags + 1, \
                  (uint32_t)(c->solid_tracked ? c->cov_hint : 0), c->d_ctr + 6, k, emit, c->ptr_tries, P.flags
         if (pl.sk && pl.g == 0 && lseg == 1 && dedup_on) {
-            if (virgin) hipLaunchKernelGGL(k_p3_dedup<true>, dim3(grid), dim3(D2_THREADS), 0, c->stream, P3D_ARGS);
-            else hipLaunchKernelGGL(k_p3_dedup<false>, dim3(grid), dim3(D2_THREADS), 0, c->stream, P3D_ARGS);
+            const bool one_gpu = c->ptr_tries == 1 && (emit.recs == nullptr || !(c->solid_tracked && c->cov_hint > 0));
+            if (virgin && one_gpu) hipLaunchKernelGGL((k_p3_dedup<true, true>), dim3(grid), dim3(D2_THREADS), 0, c->stream, P3D_ARGS);
+            else if (virgin) hipLaunchKernelGGL((k_p3_dedup<true, false>), dim3(grid), dim3(D2_THREADS), 0, c->stream, P3D_ARGS);
+            else if (one_gpu) hipLaunchKernelGGL((k_p3_dedup<false, true>), dim3(grid), dim3(D2_THREADS), 0, c->stream, P3D_ARGS);
+            else hipLaunchKernelGGL((k_p3_dedup<false, false>), dim3(grid), dim3(D2_THREADS), 0, c->stream, P3D_ARGS);
             // (it leaves the leaves of more than DD_MAX_CAP records alone: where the capacity allows such leaves, the general
             // kernel follows at once and takes what is left -- it skips the merged ones, ~20 us when that is all of them)
             if (lcap > DD_MAX_CAP) hipLaunchKernelGGL(k_p3_merge<true>, dim3(grid), dim3(P3_THREADS), 0, c->stream, P3_ARGS);

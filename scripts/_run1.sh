@@ -1,3 +1,4 @@
 cd /root/repo
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -x -q 2>&1 | tail -2
-bash scripts/gpu_variants.sh a b c
+python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | tail -2
+VAR_ARGS="--skip-config2 --err 0" bash scripts/gpu_variants.sh e0a e0b
+VAR_ARGS=--skip-config2 bash scripts/gpu_variants.sh e1a
