@@ -282,7 +282,10 @@ struct mc_ctx {
     uint32_t shard_self = 0;
     bool shards_dropped = false;  // an attachment was dropped because the table changed: the next walk must not quietly read this rank's table alone
     int shard_owner_mm_k = 0;
-    std::vector<void *> ipc_opened;
+    // A walker attaches the same tables step after step (bench.py: every step; the CLI: every batch of seeds): a mapping stays
+    // open while its handle keeps coming (in_use: part of the current attachment) and is closed when it has not for a while.
+    struct IpcMap { hipIpcMemHandle_t h; void *p; bool in_use; };
+    std::vector<IpcMap> ipc_opened;
     bool extract_by_minimizer = false; // mc_group: the next mc_extract_keys_dev call deals the keys to the owners of their minimizers (sk_owner), as the group's records are dealt (consumed by that call)
     uint4 *d_ovf_tmp = nullptr;        // pipe_drain_handed_on: the list moved aside while it is drained
     uint32_t *d_ovf_leaf_tmp = nullptr;
@@ -2209,7 +2212,7 @@ void mc_destroy(mc_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->own_stream && c->own_stream != c->stream) (void)hipStreamSynchronize(c->own_stream);
     if (c->pipe_stream) (void)hipStreamSynchronize(c->pipe_stream);
-    for (void *p : c->ipc_opened) (void)hipIpcCloseMemHandle(p);
+    for (auto &m : c->ipc_opened) (void)hipIpcCloseMemHandle(m.p);
     if (c->d_shards) (void)hipFree(c->d_shards);
     if (c->slots) table_release(c, c->slots, c->slots_bytes);
     if (c->solid) (void)hipFree(c->solid);
@@ -2246,9 +2249,8 @@ int mc_clear(mc_ctx *c)
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->cfg.device));
     c->virgin = true;
-    if (c->d_shards) {  // (the tables an attachment describes are about to change)
-        for (void *p : c->ipc_opened) (void)hipIpcCloseMemHandle(p);
-        c->ipc_opened.clear();
+    if (c->d_shards) {  // (the tables an attachment describes are about to change; their mappings stay for the next attachment)
+        for (auto &m : c->ipc_opened) m.in_use = false;
         (void)hipFree(c->d_shards);
         c->d_shards = nullptr; c->h_shards.clear(); c->shard_owner_mm_k = 0;
     }
@@ -4219,8 +4221,7 @@ int shard_describe(mc_ctx *c, ShardWire *w, bool want_ipc)
 void shard_detach_locked(mc_ctx *c)
 {
     (void)hipSetDevice(c->cfg.device);
-    for (void *p : c->ipc_opened) (void)hipIpcCloseMemHandle(p);
-    c->ipc_opened.clear();
+    for (auto &m : c->ipc_opened) m.in_use = false;  // (closed when the next attachments do not ask for them: shard_attach_locked)
     if (c->d_shards) (void)hipFree(c->d_shards);
     c->d_shards = nullptr;
     c->h_shards.clear();
@@ -4259,9 +4260,13 @@ int shard_attach_locked(mc_ctx *c, const ShardWire *w, uint32_t n, uint32_t self
         } else {
             if (!x.has_ipc) { shard_detach_locked(c); return fail(c, MC_EHIP, "mc_shard_attach: shard %u comes from another process without an IPC handle", i); }
             void *p = nullptr;
-            const hipError_t e = hipIpcOpenMemHandle(&p, x.ipc, hipIpcMemLazyEnablePeerAccess);
-            if (e != hipSuccess) { shard_detach_locked(c); return fail(c, MC_EHIP, "mc_shard_attach: hipIpcOpenMemHandle (shard %u): %s", i, hipGetErrorString(e)); }
-            c->ipc_opened.push_back(p);
+            for (auto &m : c->ipc_opened)  // (the same table as last time: its mapping is still there)
+                if (!m.in_use && memcmp(&m.h, &x.ipc, sizeof x.ipc) == 0) { p = m.p; m.in_use = true; break; }
+            if (!p) {
+                const hipError_t e = hipIpcOpenMemHandle(&p, x.ipc, hipIpcMemLazyEnablePeerAccess);
+                if (e != hipSuccess) { shard_detach_locked(c); return fail(c, MC_EHIP, "mc_shard_attach: hipIpcOpenMemHandle (shard %u): %s", i, hipGetErrorString(e)); }
+                c->ipc_opened.push_back(mc_ctx::IpcMap{x.ipc, p, true});
+            }
             slots = static_cast<Slot *>(p);
         }
         refs[i].slots = slots; refs[i].shift = x.shift; refs[i].rmask = x.rmask; refs[i].n_regions = x.n_regions; refs[i].mm_k = x.mm_k;
@@ -4269,6 +4274,12 @@ int shard_attach_locked(mc_ctx *c, const ShardWire *w, uint32_t n, uint32_t self
     }
     if (hipMalloc(reinterpret_cast<void **>(&c->d_shards), n * sizeof(ShardRef)) != hipSuccess) { shard_detach_locked(c); return fail(c, MC_ENOMEM, "mc_shard_attach: out of device memory"); }
     if (hipMemcpy(c->d_shards, refs.data(), n * sizeof(ShardRef), hipMemcpyHostToDevice) != hipSuccess) { shard_detach_locked(c); return fail(c, MC_EHIP, "mc_shard_attach: upload failed"); }
+    // mappings nobody asked for this time go once there are more of them than tables (a peer's table that grew has a new handle)
+    if (c->ipc_opened.size() > 2 * (size_t)n) {
+        std::vector<mc_ctx::IpcMap> keep;
+        for (auto &m : c->ipc_opened) { if (m.in_use) keep.push_back(m); else (void)hipIpcCloseMemHandle(m.p); }
+        c->ipc_opened.swap(keep);
+    }
     c->h_shards = refs;
     c->shard_self = self;
     c->shard_owner_mm_k = by_minimizer ? c->cfg.k : 0;
