@@ -2000,8 +2000,12 @@ __device__ __forceinline__ void lds_probe_claim2(uint32_t &offA, uint32_t &offB,
         "s_mov_b64 exec, %[sv]\n\t"
         : [offA] "+v"(offA), [offB] "+v"(offB), [mA] "+s"(mA), [mB] "+s"(mB), [oldA] "=&v"(oldA), [oldB] "=&v"(oldB), [keyX] "=&v"(keyX),
           [offX] "=&v"(offX), [sv] "=&s"(sv), [hit] "=&s"(hit), [mX2] "=&s"(mX2), [pA] "=&s"(pA), [pB] "=&s"(pB), [it] "=&s"(it)
-        : [empty] "v"(empty), [keyA] "v"(keyA), [keyB] "v"(keyB), [wrap] "s"((uint32_t)(REGION_SLOTS * 8u - 8u)), [maxp] "s"((uint32_t)P3_MAX_PROBES)
+        // (the two steps above count: a key may sit P3_MAX_PROBES slots from its home at most -- where a look-up stops, kmer_device.h.
+        // Round 5's first build let the loops run P3_MAX_PROBES steps MORE: in a region crowded enough, a key two slots beyond what
+        // table_get examines; the randomised soak found the walk that missed it)
+        : [empty] "v"(empty), [keyA] "v"(keyA), [keyB] "v"(keyB), [wrap] "s"((uint32_t)(REGION_SLOTS * 8u - 8u)), [maxp] "s"((uint32_t)(P3_MAX_PROBES - 2u))
         : "vcc", "scc", "memory");
+    static_assert(P3_MAX_PROBES > 2, "two probe steps outside the loops");
     *pendA = pA;
     *pendB = pB;
 }

@@ -312,6 +312,35 @@ def test_capacity_hint_a_quarter_of_what_the_reads_hold(mc, monkeypatch):
     assert np.array_equal(gk, ok) and np.array_equal(gc, oc)
     st = ctx.stats()
     assert st.spill_keys > 0 and st.grows > 0
+    # ... and every key must be FOUND where the probing rule looks (mc_get probes; the export above sweeps): round 5's merge
+    # kernel once placed keys two slots beyond the TABLE_MAX_PROBES a look-up examines
+    assert np.array_equal(ctx.get(ok), oc)
+    ctx.close()
+
+
+def test_every_key_of_a_crowded_table_is_where_lookups_look(mc, monkeypatch):
+    """scripts/soak.py, seed 51, iteration 0 (round 5): k = 27, 5 % errors, 250-base reads at 600-fold depth, a capacity hint a
+    third of what the reads hold, coverage 2.  The regions are crowded enough for probe sequences of 128 slots; the merge kernel's
+    pair loop ran its two unrolled steps OUTSIDE the count of TABLE_MAX_PROBES, so a key could land at slots 129-130 from its home:
+    the export (a sweep) showed it, a look-up did not, and a walk of a million vertices missed one.  Look-ups of every key, and
+    the walk that went wrong, against the oracle."""
+    monkeypatch.setenv("MC_COUNT_PATH", "partition")
+    k, cov = 27, 2
+    genome = po.synth_genome(GENOME_SEED, 2 * 20000)
+    reads = po.synth_reads(genome, 2, 20000, 844180353, 0, 97570, 250, 500)
+    off = np.arange(97570 + 1, dtype=np.uint64) * 250
+    t, _ = oracle_table(reads, off, k, po.KEY_PACKED)
+    ok, oc = t.dump()
+    ctx = mc.Context(k, mc.KEY_PACKED, 0, 6_000_000)
+    ctx.add_reads_packed(po.pack(reads), off)
+    assert ctx.finalize() == t.size()
+    gk, gc = ctx.export(0)
+    assert np.array_equal(gk, ok) and np.array_equal(gc, oc)
+    assert np.array_equal(ctx.get(ok), oc)
+    seed = genome[1000:1400]
+    hi, lo = seed_windows(seed, k)
+    for d in (1, 0):
+        assert_bfs_equal(ctx.bfs(hi, lo, d, cov, 300000, -1), po.bfs(t, k, po.KEY_PACKED, [seed], d, cov, 300000, -1))
     ctx.close()
 
 
