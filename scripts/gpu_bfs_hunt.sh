@@ -7,9 +7,11 @@ set -o pipefail
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 L=metacherchant_amd/lib
-python -c "from metacherchant_amd import build as b; b.build_variants(names=('fuzz', 'fuzz_old', 'trace_old'))" || exit 1   # (only `fuzz` comes with build())
 W=${HUNT_WALKS:-20000}
 STEPS=${HUNT_STEPS:-product fuzz old fuzz_old}
+# the libraries the chosen steps load (only `fuzz` comes with build(); a minute of hipcc each for the others)
+NEED="'fuzz',"; case " $STEPS " in *" old "*) NEED="$NEED 'trace_old',";; esac; case " $STEPS " in *" fuzz_old "*) NEED="$NEED 'fuzz_old',";; esac
+python -c "from metacherchant_amd import build as b; b.build_variants(names=($NEED))" || exit 1
 for s in $STEPS; do
   case $s in
     product) timeout -k 10 900 python scripts/bfs_endgame_stress.py --walks $W --jobs 3 --contend 1 --dirs 0,0,1,-1 > gpurun_out/hunt_product_contend.log 2>&1; echo "product+contend rc=$?"; tail -1 gpurun_out/hunt_product_contend.log;;
