@@ -52,6 +52,8 @@ class ShardedCounter:
         # room -- 287 of 288 GB in use, the allocations stall, 1 108 ms against 787 for a run per chunk (profiles/r04_rank_shard_*)
         self.keep_bytes = int(float(os.environ.get("MC_EXCHANGE_KEEP_GB", 12)) * 1e9)
         self.n_count_runs = 0
+        self.pool_slack = float(os.environ.get("MC_EXCHANGE_POOL_SLACK", 1.12))  # the one receive buffer: the first chunk's records x chunks x this
+        self.n_pool_misses = 0  # chunks that did not fit it any more (they get tensors of their own; the tests look at it)
         # where a rank's time goes, as its host sees it (seconds, summed over add_reads_dev calls until reset_phases): `extract`
         # = mc_extract_*_dev (synchronous), `exchange_wait` = waiting for transfers that the next chunk's extraction did not
         # cover, `count` = the counting runs up to their enqueueing (finalize waits for them: bench.py books that wait as well)
@@ -205,7 +207,7 @@ class ShardedCounter:
         # pointers: only the ranks in ptr_sources send theirs; what comes from the others is zero (no pointer)
         all_send = len(ptr_sources) == W
         if pool["recv"] is None and chunks_left > 1:  # the first of several chunks sizes the buffer for all of them
-            room_all = max(int(n_recv * chunks_left * 1.12) + 1024, 1)
+            room_all = max(int(n_recv * chunks_left * self.pool_slack) + 1024, 1)
             pool["recv"] = torch.empty((room_all, 2) if sk else room_all, dtype=torch.int64, device=self.device)
             pool["recv_p"] = torch.zeros(room_all, dtype=torch.int32, device=self.device)
             pool["at"] = 0
@@ -217,6 +219,7 @@ class ShardedCounter:
                 recv_p.zero_()  # (the pool is reused by the next counting run's chunks)
             pool["at"] = at0 + n_recv
         else:
+            self.n_pool_misses += pool["recv"] is not None
             recv = torch.empty((max(n_recv, 1), 2) if sk else max(n_recv, 1), dtype=torch.int64, device=self.device)
             recv_p = (torch.empty if all_send else torch.zeros)(max(n_recv, 1), dtype=torch.int32, device=self.device)
         hs = [dist.all_to_all_single(recv[:n_recv], send[:n_send], output_split_sizes=recv_counts, input_split_sizes=send_counts,

@@ -106,7 +106,7 @@ class OracleBackedContext:
         return n
 
 
-def _worker(rank, world, port, k, mode, reads, L, n_reads, min_cov, q, records=False, chunk_reads=0, share0=None, count_every=0):
+def _worker(rank, world, port, k, mode, reads, L, n_reads, min_cov, q, records=False, chunk_reads=0, share0=None, count_every=0, pool_slack=None):
     # chunk_reads: MC_EXCHANGE_CHUNK_READS (0: the default, one chunk here); share0: reads of rank 0 (None: equal shares)
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -117,6 +117,8 @@ def _worker(rank, world, port, k, mode, reads, L, n_reads, min_cov, q, records=F
             os.environ["MC_EXCHANGE_CHUNK_READS"] = str(chunk_reads)
         if count_every:
             os.environ["MC_EXCHANGE_COUNT_EVERY"] = str(count_every)  # (what bounds the memory of the kept chunks at configs[3]'s size)
+        if pool_slack is not None:
+            os.environ["MC_EXCHANGE_POOL_SLACK"] = str(pool_slack)  # (the one receive buffer too small: later chunks get tensors of their own)
         from metacherchant_amd.distributed import ShardedCounter, split_reads
         from oracle import pyoracle as po
         lo, hi = split_reads(n_reads, world, rank)
@@ -136,7 +138,7 @@ def _worker(rank, world, port, k, mode, reads, L, n_reads, min_cov, q, records=F
         assert all(native.key_owner(int(x), world) == rank for x in own_keys[:500])
         if rank == 0:
             sk, scnt = solid.t.dump()
-            q.put((total, n_solid, sk, scnt, sc.bytes_sent, sc.n_chunks, sc.n_count_runs))
+            q.put((total, n_solid, sk, scnt, sc.bytes_sent, sc.n_chunks, sc.n_count_runs, sc.n_pool_misses))
     finally:
         dist.destroy_process_group()
 
@@ -186,10 +188,13 @@ def _free_port():
 
 # (k, key mode, record form, MC_EXCHANGE_CHUNK_READS, reads of rank 0 of 300): the last three run the exchange in several chunks,
 # with shares so unequal that rank 1 (6, 2 and 0 reads) has chunks without a read while rank 0 still sends
-@pytest.mark.parametrize("k,mode,records,chunk_reads,share0,count_every", [(31, 0, False, 0, None, 0), (35, 1, False, 0, None, 0), (31, 0, True, 0, None, 0),
-                                                                            (31, 0, True, 64, 294, 0), (27, 0, True, 50, 298, 0), (33, 1, False, 64, 300, 0),
-                                                                            (31, 0, True, 64, 294, 2)])
-def test_sharded_count_equals_single_table(k, mode, records, chunk_reads, share0, count_every):
+# ... and the last two with a receive buffer half of what arrives (the chunks that do not fit get tensors of their own, and the
+# counting run's input is put together after all)
+@pytest.mark.parametrize("k,mode,records,chunk_reads,share0,count_every,pool_slack", [
+    (31, 0, False, 0, None, 0, None), (35, 1, False, 0, None, 0, None), (31, 0, True, 0, None, 0, None),
+    (31, 0, True, 64, 294, 0, None), (27, 0, True, 50, 298, 0, None), (33, 1, False, 64, 300, 0, None), (31, 0, True, 64, 294, 2, None),
+    (31, 0, True, 64, 294, 0, 0.5), (33, 1, False, 64, 300, 0, 0.5)])
+def test_sharded_count_equals_single_table(k, mode, records, chunk_reads, share0, count_every, pool_slack):
     from metacherchant_amd import build
     build.build_lib()  # key_owner comes from the C ABI (host function, no GPU needed)
     from oracle import pyoracle as po
@@ -201,10 +206,10 @@ def test_sharded_count_equals_single_table(k, mode, records, chunk_reads, share0
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, k, mode, reads, L, n_reads, min_cov, q, records, chunk_reads, share0, count_every)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, k, mode, reads, L, n_reads, min_cov, q, records, chunk_reads, share0, count_every, pool_slack)) for r in range(2)]
     for p in procs:
         p.start()
-    total, n_solid, sk, scnt, sent, n_chunks, runs = q.get(timeout=120)
+    total, n_solid, sk, scnt, sent, n_chunks, runs, pool_misses = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -217,6 +222,7 @@ def test_sharded_count_equals_single_table(k, mode, records, chunk_reads, share0
     assert n_chunks == (1 if not chunk_reads else -(-share0 // chunk_reads)) and (not chunk_reads or n_chunks >= 3)
     # however many chunks travelled: ONE counting run (a run rewrites the rank's whole table), unless the memory bound asks for more
     assert runs == (1 if not count_every else -(-n_chunks // count_every))
+    assert (pool_misses > 0) == (pool_slack is not None)  # (every chunk of a run lands in the one buffer unless it was made too small)
 
 
 def test_split_reads_covers_everything():
