@@ -357,7 +357,10 @@ def main():
         # SAME reads -- 10 M x 150 bp over 10 x 5 Mb is configs[2] scaled to a tenth at its own 30-fold depth --, a few steps:
         # a driver-run k = 63 number with its own roofline fraction beside the headline.
         ctx.close()
-        out["config2"] = config2_leg(args, m, torch, dev, local_rank, d_words, d_off, R, L, n_bases)
+        try:
+            out["config2"] = config2_leg(args, m, torch, dev, local_rank, d_words, d_off, R, L, n_bases)
+        except Exception as e:  # (the headline line must not depend on the extra leg)
+            out["config2"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
