@@ -393,7 +393,7 @@ def config2_leg(args, m, torch, dev, local_rank, d_words, d_off, R, L, n_bases):
         res["distinct"] = ctx.finalize()
         r = ctx.bfs_batch([(seed_hi, seed_lo, 0)], cov, args.maxkmers, -1)[0]
         if r is None:
-            raise SystemExit("config2: BFS found no seed k-mer")
+            raise RuntimeError("config2: BFS found no seed k-mer")
         res["bfs_ms"], res["reached"] = r["device_ms"], len(r["lo"])
 
     step()
