@@ -42,3 +42,33 @@ def test_bench_multi_rank_path_on_one_gpu():
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["bfs"]["reached"] > 1000 and out["solid_kmers"] > 100000
     assert out["roofline"]["kernel_ms"]["k_sk1_records"] > 0  # the super-k-mer form of the exchange ran
+    # the record says what ran: how many ranks the process group had, which walk, what travelled, what every rank did
+    assert out["ranks_seen"] == 2 and out["backend"] == "gloo" and out["walk_mode"] == "in_place" and out["walk_fallback"] is None
+    assert out["exchange_chunks"] >= 4 and out["count_runs_per_step"] == 1 and out["exchange_GB_per_step"] > 0
+    ph = out["rank_phases_ms_per_step"]
+    assert [p["rank"] for p in ph] == [0, 1] and all(p["reads"] == 300000 and p["extract_ms"] > 0 and p["count_kernels_ms"] > 0 for p in ph)
+    assert ph[0]["walk_ms"] > 0 and ph[1]["walk_ms"] == 0
+
+
+def test_bench_default_line_has_what_the_contract_names():
+    """python bench.py on one GPU (a small workload): ONE JSON line with the metric, `roofline`, `cpu_baseline` and the `config2`
+    object (configs[2]'s k = 63 pipeline on the same reads)."""
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--reads", "400000", "--contigs", "2",
+           "--contig-len", "1000000", "--cpu-sample-reads", "20000", "--config2-steps", "2"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["dtype"] == "int64" and out["vs_baseline"] is None and "workload" in out["config"]
+    r = out["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert set(r["kernel_ms"]) == {"k_sk1w_extract", "k_sk2_scatter", "k_p3_dedup"} and all(v > 0 for v in r["kernel_ms"].values())
+    c = out["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    c2 = out["config2"]
+    assert "error" not in c2 and c2["value"] > 0 and c2["roofline"]["frac"] > 0 and c2["distinct_kmers"] > c2["bfs"]["reached"] > 0
+    assert set(c2["roofline"]["kernel_ms"]) == {"k_p1_extract_scatter", "k_p2_scatter", "k_p3_merge"}
