@@ -2084,8 +2084,9 @@ __device__ __forceinline__ void lds_line_up8(uint32_t dst, uint32_t val, uint32_
 }
 
 // ONE_GPU: the run of one GPU on its own reads -- every record carries its pointer (ptr_tries == 1) and no list of solid k-mers
-// is kept for a gather (P3Emit): the branches of the other case leave the loops (uniform ones cost scalar instructions too)
-template <bool VIRGIN, bool ONE_GPU>
+// is kept for a gather (P3Emit): the branches of the other case leave the loops (uniform ones cost scalar instructions too).
+// K31: k == 31 -- the windows' shifts and masks are constants (a pair of windows is exactly the 32 bases of the two words)
+template <bool VIRGIN, bool ONE_GPU, bool K31 = false>
 __global__ void __launch_bounds__(D2_THREADS, MC_D2_WAVES_PER_EU) k_p3_dedup(const uint4 *__restrict__ leaf_recs, const uint32_t *__restrict__ leaf_ptrs,
                                                           const uint32_t *__restrict__ leaf_counts, uint64_t seg_cap, uint32_t n_leaves,
                                                           TableView t, uint32_t *leaf_state, uint32_t *leaf_new, uint32_t *any_failed,
@@ -2117,7 +2118,7 @@ __global__ void __launch_bounds__(D2_THREADS, MC_D2_WAVES_PER_EU) k_p3_dedup(con
     static_assert(offsetof(DedupLds, drec) % (D2_SLOTS * 16u) == 0, "lds_tag_claim wraps inside the aligned record table");
     const uint32_t drec_w = (uint32_t)offsetof(DedupLds, drec) + 12u;  // byte address of the first tag word (the struct sits at LDS address 0)
     const uint32_t ptr_from = solid_thr >= 2 ? 1u : 0u;
-    const uint32_t sh_a = 64u - 2u * (uint32_t)k, sh_b = 62u - 2u * (uint32_t)k;  // (k <= 31: a pair of windows spans k + 1 <= 32 bases)
+    const uint32_t sh_a = K31 ? 2u : 64u - 2u * (uint32_t)k, sh_b = K31 ? 0u : 62u - 2u * (uint32_t)k;  // (k <= 31: a pair of windows spans k + 1 <= 32 bases)
     const uint64_t kmask = ~0ull >> sh_a;
     uint32_t pick_tbl = 0;  // ptr_pick's choice for the four values of its two bits
     for (uint32_t r = 0; r < 4; r++) pick_tbl |= (ptr_pick((uint64_t)r, ptr_from, solid_thr) - ptr_from) << (2 * r);

@@ -1283,7 +1283,10 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
     pl->cap1 = (uint64_t)((double)units / (double)pl->np1 / (double)nseg1 * 1.25) + (pl->sk ? 64 : 256);  // per segment
     const double mean_leaf = (double)units / (double)pl->n_leaves;
     // (records of one locus come in clumps -- one per read covering it -- so leaves vary more than Poisson)
-    pl->cap2 = (uint64_t)(mean_leaf * 1.15 + (pl->sk ? 32.0 : 8.0) * std::sqrt(mean_leaf) + 64.0);  // (a spilled record also costs the solid list, P3Emit)
+    double sig2 = pl->sk ? 32.0 : 8.0;
+    if (const char *e = getenv("MC_CAP2_SIGMAS")) { const double v = atof(e); if (v >= 1.0 && v <= 64.0) sig2 = v; }  // (tuning runs: how far apart the leaves' streams lie)
+    pl->cap2 = (uint64_t)(mean_leaf * 1.15 + sig2 * std::sqrt(mean_leaf) + 64.0);  // (a spilled record also costs the solid list, P3Emit)
+    if (const char *e = getenv("MC_CAP2")) { const long v = atol(e); if (v >= 64) pl->cap2 = (uint64_t)v; }  // (tuning runs)
     pl->spill_cap = pl->sk ? std::max<uint64_t>(units * pieces / 16, 1u << 16) : std::max<uint64_t>(wb / 64, 1u << 20);
     if (pl->np1 * nseg1 * pl->cap1 >= 0xFFFFFFFFull || (uint64_t)pl->b2 * pl->cap2 * pieces >= 0xFFFFFFFFull)
         return fail(c, MC_EINVAL, "internal: partitioned batch too large for 32-bit bucket indices");
@@ -1457,7 +1460,8 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
                  (uint32_t)(c->solid_tracked ? c->cov_hint : 0), c->d_ctr + 6, k, emit, c->ptr_tries, P.flags
         if (pl.sk && pl.g == 0 && lseg == 1 && dedup_on) {
             const bool one_gpu = c->ptr_tries == 1 && (emit.recs == nullptr || !(c->solid_tracked && c->cov_hint > 0));
-            if (virgin && one_gpu) hipLaunchKernelGGL((k_p3_dedup<true, true>), dim3(grid), dim3(D2_THREADS), 0, c->stream, P3D_ARGS);
+            if (virgin && one_gpu && k == 31) hipLaunchKernelGGL((k_p3_dedup<true, true, true>), dim3(grid), dim3(D2_THREADS), 0, c->stream, P3D_ARGS);
+            else if (virgin && one_gpu) hipLaunchKernelGGL((k_p3_dedup<true, true>), dim3(grid), dim3(D2_THREADS), 0, c->stream, P3D_ARGS);
             else if (virgin) hipLaunchKernelGGL((k_p3_dedup<true, false>), dim3(grid), dim3(D2_THREADS), 0, c->stream, P3D_ARGS);
             else if (one_gpu) hipLaunchKernelGGL((k_p3_dedup<false, true>), dim3(grid), dim3(D2_THREADS), 0, c->stream, P3D_ARGS);
             else hipLaunchKernelGGL((k_p3_dedup<false, false>), dim3(grid), dim3(D2_THREADS), 0, c->stream, P3D_ARGS);
