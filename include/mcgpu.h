@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define MC_ABI_VERSION 11
+#define MC_ABI_VERSION 12
 
 /* error codes */
 #define MC_OK 0
@@ -314,6 +314,7 @@ typedef struct {
     uint64_t solid_kmers;    /* k-mers with count >= min_cov found by the last BFS set-up */
     uint64_t solid_sweeps;   /* table sweeps BFS set-ups needed to count them (0 with mc_set_coverage_hint) */
     uint64_t solid_list_builds; /* BFS set-ups and exports that took their entries from the list the merge kernel left, without sweeping the table */
+    uint64_t long_runs;      /* pipeline runs that took long records (polynomial keys, k > 32, a capacity hint: csrc/count_long.h) */
 } mc_stats;
 int mc_get_stats(mc_ctx *ctx, mc_stats *out);
 int mc_reset_stats(mc_ctx *ctx);

@@ -361,7 +361,7 @@ __device__ __forceinline__ void bfs_chunk_wide(const BfsState &S, const SolidVie
     L.set[tid + BFS_THREADS] = LH_EMPTY;
     int cov = -1;
     if (have) {
-        cov = solid_get(t, (uint64_t)key_of<MODE>(cand, k));
+        cov = solid_get_kmer<MODE>(t, cand, k, (uint64_t)key_of<MODE>(cand, k));
         lookups++;
     }
     const bool solid = have && cov >= min_cov;
@@ -775,6 +775,7 @@ __device__ __forceinline__ void scout_eval(const SolidView &t, uint64_t *sw, uin
         else { h = own_table(t); s0 = ((((uint64_t)sk_bin(hmin) * t.n_regions) >> 32) << MC_REGION_LG) | sk_home(key); }
     } else {
         if (SH) s0 = solid_locate(t, key, h);
+        else if (MODE != KEY_PACKED && t.mm_k != 0) s0 = solid_locate_kmer<MODE>(t, K, k, key, h);  // (hash keys in minimizer bins: kmer_device.h)
         else { h = own_table(t); s0 = solid_slot_of(t, key); }
     }
     SC_STAMP(1);
@@ -915,7 +916,7 @@ __device__ __forceinline__ void scout_run(const BfsState &S, const SolidView &t,
     {
         uint32_t p0 = L.wptr[a];
         if (p0 == 0) {  // the walker's k-mer has not been looked up with its pointer yet
-            (void)solid_get(t, (uint64_t)key_of<MODE>(L.root[a], k), &p0);
+            (void)solid_get_kmer<MODE>(t, L.root[a], k, (uint64_t)key_of<MODE>(L.root[a], k), &p0);
             lookups++;
         }
         if (p0) { cptr[0] = p0; nc = 1; }
@@ -1688,7 +1689,7 @@ __device__ __forceinline__ void bfs_narrow(const BfsState &S, const SolidView &t
                     if (tid < F) {
                         uint32_t p0 = L.wptr[tid];
                         if (p0 == 0) {  // the walker's k-mer has not been looked up with its pointer yet
-                            (void)solid_get(t, (uint64_t)key_of<MODE>(L.root[tid], k), &p0);
+                            (void)solid_get_kmer<MODE>(t, L.root[tid], k, (uint64_t)key_of<MODE>(L.root[tid], k), &p0);
                             lookups++;
                             L.wptr[tid] = p0;
                         }
@@ -1847,7 +1848,8 @@ __device__ __forceinline__ void bfs_narrow(const BfsState &S, const SolidView &t
                   if (want != s0) printf("[bfs] quad minimizer: slot %llu, solid_slot_of says %llu (key %llx, level %u, c %u, dir %d)\n", (unsigned long long)s0, (unsigned long long)want, (unsigned long long)key, lvl, c, dir); }
 #endif
             } else {
-                s0 = SH ? solid_locate(t, key, h) : solid_slot_of(t, key);
+                if (MODE != KEY_PACKED && !SH && t.mm_k != 0) s0 = solid_locate_kmer<MODE>(t, nk, k, key, h);  // (hash keys in minimizer bins)
+                else s0 = SH ? solid_locate(t, key, h) : solid_slot_of(t, key);
             }
             const uint64_t s1 = (s0 & ~(uint64_t)h.rmask) | ((s0 + 1) & h.rmask);
             a0 = *reinterpret_cast<const uint4 *>(h.slots + s0);
@@ -2272,7 +2274,7 @@ __global__ void __launch_bounds__(256) k_bfs_check(BfsState S, uint64_t n, Solid
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const Kmer v{S.hi[i], S.lo[i]};
         const int32_t d = S.dist[i];
-        const int have = solid_get(t, (uint64_t)key_of<MODE>(v, k));
+        const int have = solid_get_kmer<MODE>(t, v, k, (uint64_t)key_of<MODE>(v, k));
         if (have != (int)S.cov[i] || have < min_cov) {
             atomicAdd(&out->cov, 1ull);
             bfs_check_note(out, 2, (uint32_t)i, (uint32_t)have, (uint32_t)d);
@@ -2296,7 +2298,7 @@ __global__ void __launch_bounds__(256) k_bfs_check(BfsState S, uint64_t n, Solid
         if (uncut && (max_radius < 0 || d + 1 <= max_radius)) {
             for (int c = 0; c < nb; c++) {
                 const Kmer q = neighbour(v, k, dir, c);
-                if (solid_get(t, (uint64_t)key_of<MODE>(q, k)) >= min_cov && bfs_check_find(S, set, mask, q) == CHK_EMPTY) {
+                if (solid_get_kmer<MODE>(t, q, k, (uint64_t)key_of<MODE>(q, k)) >= min_cov && bfs_check_find(S, set, mask, q) == CHK_EMPTY) {
                     atomicAdd(&out->open, 1ull);
                     bfs_check_note(out, 5, (uint32_t)i, (uint32_t)c, (uint32_t)d);
                 }

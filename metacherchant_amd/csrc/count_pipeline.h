@@ -1255,22 +1255,24 @@ __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make
 #ifndef MC_SK2C_ITEMS
 #define MC_SK2C_ITEMS 3   // records per thread and tile of k_sk2_scatter_compact: 3 = 72 KB of LDS and 64 registers, two workgroups on a CU (configs[1]: 1.61 ms; 4: 1.88, 5: 1.81)
 #endif
-template <int ITEMS>
+template <int ITEMS, int RW = 1>
 struct Sk2cLds {
-    uint4 rec[PT_THREADS * ITEMS];
+    uint4 rec[PT_THREADS * ITEMS * RW];
     uint16_t leaf[PT_THREADS * ITEMS];
     uint32_t cnt[PT_MAX_LEAVES2], wcur[PT_MAX_LEAVES2], off[PT_MAX_LEAVES2];
     uint32_t seg_prefix[P1W_SEGMENTS + 1];
     uint32_t wave_tot[PT_THREADS / 64];
     uint32_t tile_seg;
 };
-template <int ITEMS>
-__global__ void __launch_bounds__(PT_THREADS, ITEMS <= 3 ? 8 : 4) k_sk2_scatter_compact(const uint4 *__restrict__ in_recs, uint64_t seg_cap1,
+// RW = 16-byte words per record: 1, or 2 for the long records of count_long.h (same first word; a spilled long record goes to
+// the list two words a record)
+template <int ITEMS, int RW = 1>
+__global__ void __launch_bounds__(PT_THREADS, ITEMS * RW <= 3 ? 8 : 4) k_sk2_scatter_compact(const uint4 *__restrict__ in_recs, uint64_t seg_cap1,
                                                                        const uint32_t *__restrict__ seg_counts1, uint32_t n_buckets1, uint32_t m2,
                                                                        uint32_t *leaf_counts, uint64_t cap2, uint4 *out_recs, SkSpill sp,
                                                                        uint32_t nseg_in, uint64_t ptr_base, uint64_t pos0, uint64_t seg_bases)
 {
-    __shared__ Sk2cLds<ITEMS> L;
+    __shared__ Sk2cLds<ITEMS, RW> L;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     constexpr uint32_t TILE = PT_THREADS * ITEMS;
     auto block_excl = [&](uint32_t c, uint32_t *total) -> uint32_t {  // exclusive scan of one value per thread
@@ -1313,7 +1315,7 @@ __global__ void __launch_bounds__(PT_THREADS, ITEMS <= 3 ? 8 : 4) k_sk2_scatter_
                 L.tile_seg = lo_s;
             }
             __syncthreads();
-            v4u rec[ITEMS];
+            v4u rec[ITEMS], rec2[ITEMS];
             uint32_t d[ITEMS], rank[ITEMS], seg_of[ITEMS];
             bool have[ITEMS];
             uint32_t sg = L.tile_seg;
@@ -1323,16 +1325,20 @@ __global__ void __launch_bounds__(PT_THREADS, ITEMS <= 3 ? 8 : 4) k_sk2_scatter_
                 have[j] = e < total;
                 if (have[j]) {
                     while (e >= L.seg_prefix[sg + 1]) sg++;
-                    rec[j] = ld_v4u(&in_recs[((uint64_t)bucket * nseg_in + sg) * seg_cap1 + (e - L.seg_prefix[sg])]);
+                    const uint64_t at = ((uint64_t)bucket * nseg_in + sg) * seg_cap1 + (e - L.seg_prefix[sg]);
+                    rec[j] = ld_v4u(&in_recs[at * RW]);
+                    if (RW == 2) rec2[j] = ld_v4u(&in_recs[at * RW + 1]);
                     seg_of[j] = sg;
                 }
             });
             static_for<ITEMS>([&](auto J) {
                 constexpr int j = decltype(J)::value;
                 if (have[j]) {
-                    d[j] = rec[j].x >> SKC_REL_BITS;
+                    // (long records: the leaf sits in the second word above the window count, the position has the first to itself)
+                    d[j] = RW == 2 ? rec[j].y >> 8 : rec[j].x >> SKC_REL_BITS;
+                    if (RW == 2) rec[j].y &= 0xFFu;
                     rank[j] = atomicAdd(&L.cnt[d[j]], 1u);
-                    const uint64_t pos = pos0 + (uint64_t)seg_of[j] * seg_bases + (rec[j].x & ((1u << SKC_REL_BITS) - 1u));
+                    const uint64_t pos = pos0 + (uint64_t)seg_of[j] * seg_bases + (RW == 2 ? rec[j].x : rec[j].x & ((1u << SKC_REL_BITS) - 1u));
                     rec[j].x = ptr_base == ~0ull ? 0u : ptr_encode(ptr_base + pos);
                 }
             });
@@ -1347,7 +1353,8 @@ __global__ void __launch_bounds__(PT_THREADS, ITEMS <= 3 ? 8 : 4) k_sk2_scatter_
                 constexpr int j = decltype(J)::value;
                 if (have[j]) {
                     const uint32_t at = L.off[d[j]] + rank[j];
-                    st_v4u(&L.rec[at], rec[j]);
+                    st_v4u(&L.rec[at * RW], rec[j]);
+                    if (RW == 2) st_v4u(&L.rec[at * RW + 1], rec2[j]);
                     L.leaf[at] = (uint16_t)d[j];
                 }
             });
@@ -1356,9 +1363,21 @@ __global__ void __launch_bounds__(PT_THREADS, ITEMS <= 3 ? 8 : 4) k_sk2_scatter_
             for (uint32_t i = tid; i < n_tile; i += PT_THREADS) {
                 const uint32_t dd = L.leaf[i];
                 const uint64_t dst = (uint64_t)L.wcur[dd] + (i - L.off[dd]);
-                const v4u r = ld_v4u(&L.rec[i]);
-                if (dst < cap2) st_v4u(&out_recs[((uint64_t)bucket * m2 + dd) * cap2 + dst], r);
-                else sk_spill_push(sp, as_uint4(r));  // (the spill list's records go in without pointers and their first word is not looked at)
+                const v4u r = ld_v4u(&L.rec[i * RW]);
+                if (RW == 1) {
+                    if (dst < cap2) st_v4u(&out_recs[((uint64_t)bucket * m2 + dd) * cap2 + dst], r);
+                    else sk_spill_push(sp, as_uint4(r));  // (the spill list's records go in without pointers and their first word is not looked at)
+                } else {
+                    const v4u r2 = ld_v4u(&L.rec[i * RW + 1]);
+                    if (dst < cap2) {
+                        const uint64_t o = (((uint64_t)bucket * m2 + dd) * cap2 + dst) * RW;
+                        st_v4u(&out_recs[o], r);
+                        st_v4u(&out_recs[o + 1], r2);
+                    } else {
+                        const unsigned long long si = atomicAdd(sp.count, 1ull);
+                        if (si < sp.cap) { sp.recs[2 * si] = as_uint4(r); sp.recs[2 * si + 1] = as_uint4(r2); } else atomicExch(sp.lost, 1u);
+                    }
+                }
             }
             __syncthreads();
             if (tid < m2) { L.wcur[tid] += L.cnt[tid]; L.cnt[tid] = 0; }

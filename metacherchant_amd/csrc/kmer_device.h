@@ -410,6 +410,23 @@ __host__ __device__ inline uint32_t sk_hmin_of_kmer(uint64_t fw, int k)
     return best;
 }
 
+// ... of a k-mer of up to 64 bases (hi:lo, right-aligned).  Hash keys say nothing about their bases: where such keys live in
+// minimizer bins (k > 32 with polynomial keys, count_pipeline.h "long records") every look-up brings the k-mer itself.
+__host__ __device__ inline uint32_t sk_hmin_of_kmer2(const Kmer &v, int k)
+{
+    uint32_t f = 0, r = 0, best = SK_NONE;
+    for (int i = 0; i < k; i++) {
+        const uint32_t b = base_at(v, k, i);
+        f = ((f << 2) | b) & SK_MMASK;
+        r = (r >> 2) | ((3u - b) << (2 * (SK_M - 1)));
+        if (i >= SK_M - 1) {
+            const uint32_t h = sk_order(f < r ? f : r);
+            best = h < best ? h : best;
+        }
+    }
+    return best;
+}
+
 struct TableView {
     Slot *slots;
     uint32_t shift;   // 64 - (rb + sb)
@@ -477,8 +494,9 @@ __host__ __device__ __forceinline__ uint64_t next_region_base(uint64_t base, uin
 // Returns 1 when the key was new: callers add these up and publish them with wave_add_ull once per
 // wave (one hot counter address hammered by every insert costs more than the inserts themselves).
 // *before (optional): the key's count before this addition (0 for a new key).
-__device__ __forceinline__ uint32_t table_add(const TableView &t, uint64_t key, uint32_t inc, uint32_t hint = 0,
-                                              uint32_t *before = nullptr, uint32_t pick = 0, uint32_t pick2 = 0)
+// table_add_at: the same from home slot `s` on (callers that know the key's region otherwise: hash keys in minimizer bins)
+__device__ __forceinline__ uint32_t table_add_at(const TableView &t, uint64_t s, uint64_t key, uint32_t inc, uint32_t hint = 0,
+                                                 uint32_t *before = nullptr, uint32_t pick = 0, uint32_t pick2 = 0)
 {   // pick != 0: the occurrences that find `pick` / `pick2` before them replace the inserter's read pointer with their own (ptr_pick)
     if (before) *before = 0;
     if (key == EMPTY_KEY) {
@@ -486,7 +504,6 @@ __device__ __forceinline__ uint32_t table_add(const TableView &t, uint64_t key, 
         if (before) *before = old > 0x80000000ull ? 0x80000000u : (uint32_t)old;
         return 0;
     }
-    uint64_t s = slot_of(t, key);
     uint64_t base = s & ~(uint64_t)t.rmask;
     // (TABLE_MAX_PROBES slots from the home slot, then the same stretch of the region behind, ...: see there)
     const uint64_t home = s & t.rmask;
@@ -536,6 +553,12 @@ __device__ __forceinline__ uint32_t table_add(const TableView &t, uint64_t key, 
     }
     atomicExch(t.fatal, 1u);
     return 0;
+}
+
+__device__ __forceinline__ uint32_t table_add(const TableView &t, uint64_t key, uint32_t inc, uint32_t hint = 0,
+                                              uint32_t *before = nullptr, uint32_t pick = 0, uint32_t pick2 = 0)
+{
+    return table_add_at(t, key == EMPTY_KEY ? 0 : slot_of(t, key), key, inc, hint, before, pick, pick2);
 }
 
 // does an addition of `inc` to a count that was `before` carry it over the threshold? (both clamp at 32767 when read)
@@ -692,6 +715,24 @@ __device__ __forceinline__ int solid_get(const SolidView &t, uint64_t key, uint3
     }
     TableRef h;  // (several GPUs: the owner's table)
     const uint64_t s0 = solid_locate(t, key, h);
+    return solid_probe_from(h, key, s0, 0, aux);
+}
+
+// The same for the k-mer `v` whose key is `key`, in any key mode: a hash key says nothing about its bases, so where such keys
+// live in minimizer bins (t.mm_k != 0 with MODE != KEY_PACKED: the long-record counting pipeline) the bin comes from v itself.
+template <int MODE>
+__device__ __forceinline__ uint64_t solid_locate_kmer(const SolidView &t, const Kmer &v, int k, uint64_t key, TableRef &h)
+{
+    if (MODE != KEY_PACKED && t.n_shards <= 1 && t.mm_k != 0) return solid_locate(t, key, h, true, sk_hmin_of_kmer2(v, k));
+    return solid_locate(t, key, h);
+}
+template <int MODE>
+__device__ __forceinline__ int solid_get_kmer(const SolidView &t, const Kmer &v, int k, uint64_t key, uint32_t *aux = nullptr)
+{
+    if (MODE == KEY_PACKED || t.n_shards > 1 || t.mm_k == 0 || key == EMPTY_KEY) return solid_get(t, key, aux);
+    if (aux) *aux = 0;
+    TableRef h;
+    const uint64_t s0 = solid_locate(t, key, h, true, sk_hmin_of_kmer2(v, k));
     return solid_probe_from(h, key, s0, 0, aux);
 }
 

@@ -38,6 +38,7 @@ typedef enum { ncclInt8 = 0, ncclUint8 = 1 } ncclDataType_t;
 #include "kmer_device.h"
 #include "bfs_device.h"
 #include "count_pipeline.h"
+#include "count_long.h"
 #include "tokenizer.h"
 #include "host/envfinder.h"
 
@@ -465,18 +466,23 @@ __global__ void k_add_pairs(const int64_t *__restrict__ keys, const int16_t *__r
 // the parked additions of TableView::ovf, once the table has been enlarged
 // entry_leaf / leaf_state (may be null): an entry the merge kernels left (count_pipeline.h ovf_push) is skipped when its
 // leaf was not committed -- that leaf is merged again and leaves its entries again
+// region_of_leaf: hash keys in minimizer bins (count_long.h) -- the key does not say where it lives, the leaf it was handed on from
+// does (one region a leaf; every entry of such a list comes from a leaf)
 __global__ void k_add_parked(const uint4 *__restrict__ list, uint64_t n, TableView t, const uint32_t *__restrict__ entry_leaf = nullptr,
-                             const uint32_t *__restrict__ leaf_state = nullptr)
+                             const uint32_t *__restrict__ leaf_state = nullptr, int region_of_leaf = 0)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     unsigned long long n_new = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint32_t lf = 0xFFFFFFFFu;
         if (entry_leaf && leaf_state) {
-            const uint32_t lf = entry_leaf[i];
+            lf = entry_leaf[i];
             if (lf != 0xFFFFFFFFu && leaf_state[lf] == 0) continue;
         }
         const uint4 e = list[i];
-        n_new += table_add(t, ((uint64_t)e.y << 32) | e.x, e.z, e.w);
+        const uint64_t key = ((uint64_t)e.y << 32) | e.x;
+        if (region_of_leaf && lf != 0xFFFFFFFFu) n_new += table_add_at(t, ((uint64_t)lf << MC_REGION_LG) | sk_home(key), key, e.z, e.w);
+        else n_new += table_add(t, key, e.z, e.w);
     }
     wave_add_ull(t.n_used, n_new);
 }
@@ -977,8 +983,21 @@ struct TableSwap {
     }
 };
 
+// Hash keys in minimizer bins (count_long.h: polynomial keys, k > 32, counted as long records): nothing that has only the key
+// can find it there, and such a table cannot be rebuilt with another number of bins either.  Everything that works by key --
+// mc_get, key streams, the direct kernel, growing -- first moves the table to hash-prefix regions, for good (by_key_ready).
+static inline bool hash_bins(const mc_ctx *c) { return c->mm_k != 0 && c->cfg.key_mode != MC_KEY_PACKED; }
+static int to_hash_regions(mc_ctx *c);
+static inline int by_key_ready(mc_ctx *c) { return hash_bins(c) ? to_hash_regions(c) : MC_OK; }
+
 static int table_grow(mc_ctx *c, uint64_t new_regions)
 {
+    if (hash_bins(c)) {
+        int rc = to_hash_regions(c);
+        if (rc) return rc;
+        new_regions = regions_for(c, new_regions << c->sb);  // (a power of two now)
+        if (new_regions <= c->n_regions) return MC_OK;
+    }
     TableSwap sw(c);
     HIPCHK(c, hipMemcpyAsync(&sw.old_used, c->d_ctr, sizeof sw.old_used, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1042,6 +1061,7 @@ static int drain_parked(mc_ctx *c)
         HIPCHK(c, hipMemcpyAsync(&n, c->d_ctr + 7, sizeof n, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (n == 0) return MC_OK;
+        if (int brc = by_key_ready(c)) return brc;  // (the parked additions are keys)
         if (n > mc_ctx::OVF_CAP || attempt >= 8)
             return fail(c, MC_EOVERFLOW, "k-mer table regions keep overflowing (%llu additions parked); pass a capacity_hint "
                         "(distinct k-mers), or set MC_SUPERKMERS=0 for read sets that cover a genome thousands of times", n);
@@ -1064,7 +1084,8 @@ static int drain_parked(mc_ctx *c)
 // next launch without the load factor passing 0.85 even if every one is a new key.
 static int table_reserve(mc_ctx *c, uint64_t incoming, uint64_t *allowed)
 {
-    int mrc = materialize(c);
+    int mrc = by_key_ready(c);  // (what follows goes in by key)
+    if (!mrc) mrc = materialize(c);
     if (!mrc) mrc = drain_parked(c);  // (what the previous launch could not place)
     if (mrc) return mrc;
     unsigned long long used;
@@ -1185,6 +1206,7 @@ struct PipePlan {
     uint32_t chunk_tiles = 0;
     uint64_t pos0 = 0;
     bool guessed = false;  // no capacity hint vouches for the table's size: pipe_finish merges a sample of the leaves first
+    bool lng = false;      // long records (count_long.h): two 16-byte words a record in every stream
     SpillView sp{};
     SkSpill sks{};
 };
@@ -1212,8 +1234,10 @@ __global__ void __launch_bounds__(256) k_pipe_reset(uint32_t *seg_counts1, uint6
 // Table capacity check, scratch buffers and cursors for one run of the partitioned pipeline over
 // `wb` key occurrences.  n_records != 0: they travel as (an estimated) n_records super-k-mer records.
 static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records = 0, uint32_t nseg1 = PT_SEGMENTS, uint32_t pieces = 1,
-                        bool level2_only = false, uint64_t compact_tiles = 0)
-{   // compact_tiles != 0: the caller's level-1 kernel is k_sk1w_extract over this many tiles in one piece and can write the compact
+                        bool level2_only = false, uint64_t compact_tiles = 0, bool lng = false)
+{
+    pl->lng = lng;
+    const uint64_t rw = lng ? 2 : 1;  // 16-byte words a record   // compact_tiles != 0: the caller's level-1 kernel is k_sk1w_extract over this many tiles in one piece and can write the compact
     // form: taken up when the rest of the run allows it (a second level through the staged kernel, one region per leaf, segments
     // short enough for 22-bit positions)   // level2_only: the level-1 scatter has run and the table has since been replaced by one of another size (pipe_resize_by_sample):
     // the plan of the second level and of the merge is made again for it; level 1 (buckets, segments, their fill levels, the
@@ -1277,6 +1301,8 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
         // are those of the table the first level saw)
         pl->compact = compact_tiles && compact_on && staged && pl->sk && pl->b2 > 1 && pl->b2 <= (1u << (32 - SKC_REL_BITS)) && g == 0 && pieces == 1 &&
                       chunk * P1W_TILE <= (1ull << SKC_REL_BITS) && !(pl->guessed && c->virgin);
+        // (long records keep the leaf in their second word: 32 bits of position)
+        if (lng) pl->compact = compact_tiles && pl->sk && pl->b2 > 1 && pl->b2 <= 1024 && g == 0 && pieces == 1 && chunk * P1L_TILE < (1ull << 32) && !pl->guessed;
         pl->chunk_tiles = pl->compact ? (uint32_t)chunk : 0;
     }
     const uint64_t units = (pl->sk ? n_records : wb) / pieces + (pieces > 1 ? 1024 : 0);  // records in the streams (of one piece)
@@ -1295,15 +1321,15 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
     uint64_t dummy;
 #define ENSURE(ptr, capvar, need) do { rc = ensure_buf(c, &(ptr), &(capvar), (need)); if (rc) return rc; } while (0)
     if (pl->sk) {
-        if (!level2_only) ENSURE(P.a_recs, P.a_recs_cap, np1 * nseg1 * pl->cap1 * pieces);
-        if (pl->b2 > 1) ENSURE(P.b_recs, P.b_recs_cap, n_leaves * pl->cap2 * pieces);
-        if (!level2_only) ENSURE(P.spill_recs, P.spill_recs_cap, pl->spill_cap);
+        if (!level2_only) ENSURE(P.a_recs, P.a_recs_cap, np1 * nseg1 * pl->cap1 * pieces * rw);
+        if (pl->b2 > 1) ENSURE(P.b_recs, P.b_recs_cap, n_leaves * pl->cap2 * pieces * rw);
+        if (!level2_only) ENSURE(P.spill_recs, P.spill_recs_cap, pl->spill_cap * rw);
     } else {
         { uint64_t cap = P.a_cap; ENSURE(P.a_keys, cap, np1 * nseg1 * pl->cap1); P.a_cap = cap; }
         { uint64_t cap = P.b_cap; ENSURE(P.b_keys, cap, n_leaves * pl->cap2 * pieces); P.b_cap = cap; }
         { uint64_t cap = P.spill_cap; ENSURE(P.spill_keys, cap, pl->spill_cap); dummy = P.spill_cap; ENSURE(P.spill_hints, dummy, pl->spill_cap); P.spill_cap = cap; }
     }
-    if (!pl->compact) {  // (the compact form keeps the read pointers inside the records)
+    if (!pl->compact && !lng) {  // (the compact form keeps the read pointers inside the records)
         if (!level2_only) ENSURE(P.a_hints, P.a_hints_cap, np1 * nseg1 * pl->cap1 * pieces);
         ENSURE(P.b_hints, P.b_hints_cap, n_leaves * pl->cap2 * pieces);
     }
@@ -1328,7 +1354,7 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
 // into the table through the direct kernel, which follows the table's region chain; entries of leaves that were not
 // committed are dropped (those leaves are merged again).  Only after a launch that has been over EVERY leaf: the regions
 // behind must hold valid slots.  *n_parked (may be null): how many there were.
-static int pipe_drain_handed_on(mc_ctx *c, uint64_t n_listed)
+static int pipe_drain_handed_on(mc_ctx *c, uint64_t n_listed, bool lng = false)
 {
     mc_ctx::Pipe &P = c->pipe;
     const uint64_t n = std::min<uint64_t>(n_listed, mc_ctx::OVF_CAP);
@@ -1343,7 +1369,8 @@ static int pipe_drain_handed_on(mc_ctx *c, uint64_t n_listed)
     HIPCHK(c, hipMemcpyAsync(c->d_ovf_tmp, c->d_ovf, n * sizeof(uint4), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_ovf_leaf_tmp, c->d_ovf_leaf, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_ctr + 7, 0, sizeof(unsigned long long), c->stream));
-    hipLaunchKernelGGL(k_add_parked, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->d_ovf_tmp, n, c->view(), c->d_ovf_leaf_tmp, P.leaf_state);
+    hipLaunchKernelGGL(k_add_parked, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->d_ovf_tmp, n, c->view(), c->d_ovf_leaf_tmp, P.leaf_state,
+                       lng && hash_bins(c) ? 1 : 0);
     HIPCHK(c, hipGetLastError());
     c->solid_tracked = false;  // (these additions were not watched for crossing the coverage threshold)
     c->solid_list_fresh = false;
@@ -1458,7 +1485,10 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
                 (uint32_t)(c->solid_tracked ? c->cov_hint : 0), c->d_ctr + 6, k, emit, c->ptr_tries, P.flags
 #define P3D_ARGS static_cast<const uint4 *>(lk), lh, lc, lcap, leaves, c->view(), P.leaf_state, P.leaf_new, P.flags + 1, \
                  (uint32_t)(c->solid_tracked ? c->cov_hint : 0), c->d_ctr + 6, k, emit, c->ptr_tries, P.flags
-        if (pl.sk && pl.g == 0 && lseg == 1 && dedup_on) {
+        if (pl.lng) {
+            hipLaunchKernelGGL(k_p3_long, dim3(grid), dim3(P3_THREADS), 0, c->stream, static_cast<const uint4 *>(lk), lc, lcap, leaves, c->view(), virgin,
+                               P.leaf_state, P.leaf_new, P.flags + 1, (uint32_t)(c->solid_tracked ? c->cov_hint : 0), c->d_ctr + 6, k, emit, P.flags);
+        } else if (pl.sk && pl.g == 0 && lseg == 1 && dedup_on) {
             const bool one_gpu = c->ptr_tries == 1 && (emit.recs == nullptr || !(c->solid_tracked && c->cov_hint > 0));
             if (virgin && one_gpu && k == 31) hipLaunchKernelGGL((k_p3_dedup<true, true, true>), dim3(grid), dim3(D2_THREADS), 0, c->stream, P3D_ARGS);
             else if (virgin && one_gpu) hipLaunchKernelGGL((k_p3_dedup<true, true>), dim3(grid), dim3(D2_THREADS), 0, c->stream, P3D_ARGS);
@@ -1488,7 +1518,11 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
             fprintf(stderr, "[count] level-1 stream %p (%llu records a segment), level-2 stream %p (%llu a leaf), table %p\n", (void *)P.a_recs,
                     (unsigned long long)pl.cap1, (void *)P.b_recs, (unsigned long long)pl.cap2, (void *)c->slots);
         }
-        if (pl.sk && pl.compact)
+        if (pl.lng)
+            hipLaunchKernelGGL((k_sk2_scatter_compact<2, 2>), dim3((unsigned)np1), dim3(PT_THREADS), 0, c->stream, P.a_recs, pl.cap1,
+                               P.seg_counts1, (uint32_t)np1, pl.b2, P.cursors2, pl.cap2, P.b_recs, pl.sks, pl.nseg1, c->cur_ptr_base, pl.pos0,
+                               (uint64_t)pl.chunk_tiles * P1L_TILE);
+        else if (pl.sk && pl.compact)
             hipLaunchKernelGGL(k_sk2_scatter_compact<MC_SK2C_ITEMS>, dim3((unsigned)np1), dim3(PT_THREADS), 0, c->stream, P.a_recs, pl.cap1,
                                P.seg_counts1, (uint32_t)np1, pl.b2, P.cursors2, pl.cap2, P.b_recs, pl.sks, pl.nseg1, c->cur_ptr_base, pl.pos0,
                                (uint64_t)pl.chunk_tiles * P1W_TILE);
@@ -1614,17 +1648,21 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
         }
         if (flags[0]) return fail(c, MC_EOVERFLOW, "internal: spill list of the partitioned counting pipeline overflowed");
         // (every leaf has been merged or, where the hand-on list ran full, left as a valid region: the list can go in)
-        rc = pipe_drain_handed_on(c, n_handed_on);
+        const bool bins_before = hash_bins(c);
+        rc = pipe_drain_handed_on(c, n_handed_on, pl.lng);
         if (rc) return rc;
         n_handed_on = 0;
-        if ((n_leaves << pl.g) < c->n_regions) {  // (the drain doubled the table: a leaf covers more regions now; n_used was recounted)
+        if (pl.lng && bins_before && !hash_bins(c))  // (the drain moved the table to hash-prefix regions: n_used was recounted, the merged leaves' keys included)
+            HIPCHK(c, hipMemsetAsync(P.leaf_new, 0, n_leaves * sizeof(uint32_t), c->stream));
+        if (!pl.lng && (n_leaves << pl.g) < c->n_regions) {  // (the drain doubled the table: a leaf covers more regions now; n_used was recounted)
             while ((n_leaves << pl.g) < c->n_regions) pl.g++;
             HIPCHK(c, hipMemsetAsync(P.leaf_new, 0, n_leaves * sizeof(uint32_t), c->stream));
         }
         if (flags[2]) emit.recs = nullptr;  // a segment of the solid list overflowed: the BFS set-up sweeps the table instead
         if (!flags[1]) break;
-        if (attempt >= 6 || pl.g >= 5) {
-            if (!(pl.sk && c->mm_k))
+        if (pl.lng || attempt >= 6 || pl.g >= 5) {
+            // (long records: a table of hash keys in minimizer bins cannot be rebuilt with more bins -- it gives them up at the first leaf that fails)
+            if (!(pl.sk && (c->mm_k || pl.lng)))
                 return fail(c, MC_EOVERFLOW, "k-mer table regions keep overflowing; pass a capacity_hint (distinct k-mers)");
             // minimizer bins that no number of regions can hold: regions by the key's hash from here on, and the leaves
             // that were not merged go through the direct kernel, as many at a time as the table has room for
@@ -1643,7 +1681,7 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
                 while (hi_leaf < n_leaves) {
                     uint64_t w = 0;
                     if (!st[hi_leaf])
-                        for (uint32_t sg = 0; sg < lseg; sg++) w += std::min<uint64_t>(cnt[(uint64_t)hi_leaf * lseg + sg], lcap) * SK_MAX_WINDOWS;
+                        for (uint32_t sg = 0; sg < lseg; sg++) w += std::min<uint64_t>(cnt[(uint64_t)hi_leaf * lseg + sg], lcap) * (pl.lng ? SKL_MAX_WINDOWS : SK_MAX_WINDOWS);
                     if (hi_leaf > lo_leaf && need + w > allowed) break;
                     need += w;
                     hi_leaf++;
@@ -1653,7 +1691,10 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
                     if (rc) return rc;
                     if (need > allowed) return fail(c, MC_EOVERFLOW, "internal: a leaf of %llu k-mer occurrences does not fit one launch", (unsigned long long)need);
                 }
-                if (need)
+                if (need && pl.lng)
+                    hipLaunchKernelGGL(k_skl_add_unmerged, dim3(std::min<uint32_t>(hi_leaf - lo_leaf, 4096u)), dim3(256), 0, c->stream,
+                                       static_cast<const uint4 *>(lk), lc, lcap, lo_leaf, hi_leaf, P.leaf_state, k, c->view());
+                else if (need)
                     hipLaunchKernelGGL(k_sk_add_unmerged, dim3(std::min<uint32_t>(hi_leaf - lo_leaf, 4096u)), dim3(256), 0, c->stream,
                                        static_cast<const uint4 *>(lk), lh, lc, lcap, lseg, lo_leaf, hi_leaf, P.leaf_state, k, c->view());
                 HIPCHK(c, hipGetLastError());
@@ -1676,13 +1717,27 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
     if (n_spill) {
         const uint32_t thr = (uint32_t)(c->solid_tracked ? c->cov_hint : 0);
         uint64_t i = 0;
+        if (pl.lng && hash_bins(c)) {
+            // (the table was sized by the hint that let this run take long records, and the direct path's usual preparations would
+            // move it out of its minimizer bins: the few records that found no room in the streams go in as they are, each to its bin)
+            rc = timed(c, &ms4, [&] {
+                hipLaunchKernelGGL(k_skl_add_records, dim3(grid_for(n_spill, 256)), dim3(256), 0, c->stream, P.spill_recs, (uint64_t)n_spill, k, c->view(), thr, c->d_ctr + 6);
+            });
+            if (rc) return rc;
+            i = n_spill;
+            unsigned long long parked = 0;  // what found no room in its bin's chain is a key without a leaf: only a by-key table takes it
+            HIPCHK(c, hipMemcpy(&parked, c->d_ctr + 7, sizeof parked, hipMemcpyDeviceToHost));
+            if (parked) { rc = drain_parked(c); if (rc) return rc; }
+        }
         while (i < n_spill) {
             uint64_t allowed;
-            rc = table_reserve(c, (n_spill - i) * (pl.sk ? SK_MAX_WINDOWS : 1), &allowed);
+            rc = table_reserve(c, (n_spill - i) * (pl.lng ? SKL_MAX_WINDOWS : pl.sk ? SK_MAX_WINDOWS : 1), &allowed);
             if (rc) return rc;
-            const uint64_t m = std::min<uint64_t>(pl.sk ? std::max<uint64_t>(allowed / SK_MAX_WINDOWS, 1) : allowed, n_spill - i);
+            const uint64_t m = std::min<uint64_t>(pl.lng ? std::max<uint64_t>(allowed / SKL_MAX_WINDOWS, 1) : pl.sk ? std::max<uint64_t>(allowed / SK_MAX_WINDOWS, 1) : allowed, n_spill - i);
             rc = timed(c, &ms4, [&] {
-                if (pl.sk)
+                if (pl.lng)
+                    hipLaunchKernelGGL(k_skl_add_records, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, P.spill_recs + 2 * i, m, k, c->view(), thr, c->d_ctr + 6);
+                else if (pl.sk)
                     hipLaunchKernelGGL(k_sk_add_records, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, P.spill_recs + i, (const uint32_t *)nullptr, m, k,
                                        c->view(), thr, c->d_ctr + 6);
                 else
@@ -1771,12 +1826,78 @@ static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint6
         }
     }
 }
+// the reads [r0, r1) through the direct kernel, as many at a time as the table has room for
+static int count_batch_direct(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_off, uint64_t r0, uint64_t r1, uint64_t base0, uint64_t end_abs,
+                              uint64_t wb)
+{
+    const uint64_t nr = r1 - r0;
+    uint64_t r = r0;
+    while (r < r1) {
+        uint64_t allowed;
+        int rc = table_reserve(c, wb, &allowed);
+        if (rc) return rc;
+        const uint64_t step = std::max<uint64_t>(1, std::min<uint64_t>(r1 - r, allowed / std::max<uint64_t>(1, (end_abs - base0) / nr + 1)));
+        double ms = 0;
+        rc = timed(c, &ms, [&] { launch_count(c, d_words, d_off, r, r + step); });
+        if (rc) return rc;
+        c->st.count_ms += ms;
+        c->st.count_total_ms += ms;
+        c->st.count_launches++;
+        r += step;
+    }
+    c->st.windows += wb;
+    return MC_OK;
+}
+
+// One run as long records (count_long.h).  4: the run does not qualify -- the caller moves the table to hash-prefix regions and
+// takes the per-window form; otherwise what pipe_finish returns.
+static int add_reads_long(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_off, uint64_t r0, uint64_t r1, uint64_t base0, uint64_t end_abs,
+                          uint64_t wb)
+{
+    mc_ctx::Pipe &P = c->pipe;
+    const uint64_t nr = r1 - r0;
+    if (c->cfg.key_mode != MC_KEY_POLY || c->cfg.k < SKL_MIN_K || c->cfg.k > SKL_MAX_K) return 4;
+    unsigned long long used;
+    uint32_t fatal;
+    int rc = read_counters(c, &used, &fatal);
+    if (rc) return rc;
+    if (fatal || !(c->cfg.capacity_hint && used < c->cfg.capacity_hint)) return 4;  // (only a table sized for what it will hold: it cannot grow)
+    PipePlan pl;
+    const uint64_t n_records = sk_records_bound(c, wb, nr);
+    const uint64_t n_tiles_abs = (end_abs + P1L_TILE - 1) / P1L_TILE;
+    rc = pipe_prepare(c, wb, &pl, n_records, (uint32_t)P1W_SEGMENTS, 1, false, n_tiles_abs - base0 / P1L_TILE, true);
+    if (rc) return rc;
+    if (!pl.compact || !hash_bins(c)) return 4;
+    const uint64_t *offs = d_off + r0;
+    rc = ensure_buf(c, &P.tile_first, &P.tiles1_cap, n_tiles_abs);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->ev_t[0], c->stream));  // (no wait here: pipe_finish enqueues the second level and the merge right behind)
+    launch_tile_first(c, offs, nr, n_tiles_abs, P.tile_first, P1L_TILE);
+    pl.pos0 = base0 / P1L_TILE * P1L_TILE;
+    if (getenv("MC_INGEST_DEBUG"))
+        fprintf(stderr, "[count] long records: %u buckets x %u leaves, %u tiles a segment from base %llu, %llu records expected\n", pl.b1, pl.b2, pl.chunk_tiles,
+                (unsigned long long)pl.pos0, (unsigned long long)n_records);
+    const SklSpill sp{P.spill_recs, P.spill_count, pl.spill_cap, P.flags};
+    hipLaunchKernelGGL(k_skl_extract, dim3(P1W_SEGMENTS), dim3(P1W_THREADS), 0, c->stream, d_words, offs, nr, base0, end_abs, n_tiles_abs, P.tile_first,
+                       c->cfg.k, pl.b1, P.seg_counts1, pl.cap1, P.a_recs, sp, pl.chunk_tiles, pl.b2);
+    HIPCHK(c, hipGetLastError());
+    c->st.long_runs++;
+    return pipe_finish(c, pl, 0, false, 0, true, false);
+}
+
 static int add_reads_partitioned_once(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_off, uint64_t r0, uint64_t r1,
                                       uint64_t base0, uint64_t end_abs, uint64_t wb)
 {
     mc_ctx::Pipe &P = c->pipe;
     PipePlan pl;
     const uint64_t nr = r1 - r0;
+    if (hash_bins(c)) {
+        int lrc = add_reads_long(c, d_words, d_off, r0, r1, base0, end_abs, wb);
+        if (lrc == 1) return count_batch_direct(c, d_words, d_off, r0, r1, base0, end_abs, wb);  // (the streams lost records: nothing was merged)
+        if (lrc != 4) return lrc;
+        lrc = to_hash_regions(c);
+        if (lrc) return lrc;
+    }
     const uint64_t n_records = c->mm_k ? sk_records_bound(c, wb, nr) : 0;
     // MC_PIPE_PIECES=n (an experiment, off by default): the reads go through the two scatter levels in n pieces, the
     // second level of piece p on a side stream next to the first level of piece p + 1; the merge kernel then finds n
@@ -1885,22 +2006,7 @@ static int add_reads_partitioned_once(mc_ctx *c, const uint64_t *d_words, const 
     }
     if (rc != 1) return rc;
     // (super-k-mer streams overflowed: unusually short runs) count this batch with the direct kernel instead
-    uint64_t r = r0;
-    while (r < r1) {
-        uint64_t allowed;
-        rc = table_reserve(c, wb, &allowed);
-        if (rc) return rc;
-        const uint64_t step = std::max<uint64_t>(1, std::min<uint64_t>(r1 - r, allowed / std::max<uint64_t>(1, (end_abs - base0) / nr + 1)));
-        double ms = 0;
-        rc = timed(c, &ms, [&] { launch_count(c, d_words, d_off, r, r + step); });
-        if (rc) return rc;
-        c->st.count_ms += ms;
-        c->st.count_total_ms += ms;
-        c->st.count_launches++;
-        r += step;
-    }
-    c->st.windows += wb;
-    return MC_OK;
+    return count_batch_direct(c, d_words, d_off, r0, r1, base0, end_abs, wb);
 }
 
 
@@ -1916,7 +2022,8 @@ static int add_keys_partitioned(mc_ctx *c, const uint64_t *d_keys, const uint32_
 {
     mc_ctx::Pipe &P = c->pipe;
     PipePlan pl;
-    int rc = pipe_prepare(c, n, &pl);
+    int rc = by_key_ready(c);
+    if (!rc) rc = pipe_prepare(c, n, &pl);
     if (rc) return rc;
     double ms1 = 0;
     rc = timed(c, &ms1, [&] {
@@ -2179,8 +2286,12 @@ int mc_create(const mc_config *cfg, mc_ctx **out)
     if (cfg->key_mode == MC_KEY_PACKED && cfg->k >= SK_MIN_K) c->mm_k = cfg->k;
     if (const char *e = getenv("MC_SUPERKMERS")) if (!strcmp(e, "0")) c->mm_k = 0;
     c->sk_form = c->mm_k != 0;
-    // (an experiment, off unless MC_SK_LONG=1: measured on 10 M reads at k = 63 -- P1 24 + P2 2 + P3 32 ms against 35 ms for the
-    // per-window pipeline, and the bins of a table at load 0.43 overflow, which sends it back to hash regions: DESIGN.md section 7)
+    // polynomial keys of 33 .. 63 bases in a table sized by a capacity hint: minimizer bins too, reads counted as long records
+    // (count_long.h; hash_bins() above says what such a table cannot do and what happens then).  MC_LONG_RECORDS=0: the per-window pipeline.
+    if (cfg->key_mode == MC_KEY_POLY && cfg->k >= SKL_MIN_K && cfg->k <= SKL_MAX_K && cfg->capacity_hint) {
+        const char *e = getenv("MC_LONG_RECORDS");
+        if (!(e && !strcmp(e, "0"))) c->mm_k = cfg->k;
+    }
     uint64_t want_slots = 1ull << 22;  // 4 M slots = 64 MB to start with
     if (cfg->capacity_hint) {
         // Load factor the hint is turned into.  Hash-prefix tables: 0.7 (regions are probed in LDS, a fuller table
@@ -3008,6 +3119,7 @@ int mc_get_dev(mc_ctx *c, const int64_t *d_keys, uint64_t n, int16_t *d_out)
     if ((!d_keys || !d_out) && n) return fail(c, MC_EINVAL, "mc_get_dev: null pointer");
     if (n == 0) return MC_OK;
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (int brc = by_key_ready(c)) return brc;  // (a look-up by key: the table leaves minimizer bins for it, include/mcgpu.h)
     hipLaunchKernelGGL(k_get, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, d_keys, n, d_out, c->view());
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -4201,7 +4313,8 @@ int shard_describe(mc_ctx *c, ShardWire *w, bool want_ipc)
     if (!c->finalized) return fail(c, MC_ESTATE, "mc_shard_export: call mc_finalize_counts first");
     if (c->solid_external) return fail(c, MC_ESTATE, "mc_shard_export: a BFS-only context has no counting table to share");
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    int rc = materialize(c);  // (a rank that owns nothing of the batch still offers a valid, empty table)
+    int rc = by_key_ready(c);  // (the walkers of other ranks come with keys)
+    if (!rc) rc = materialize(c);  // (a rank that owns nothing of the batch still offers a valid, empty table)
     if (rc) return rc;
     unsigned long long *h = c->h_scratch;
     HIPCHK(c, hipMemcpyAsync(h, c->d_ctr, 9 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
@@ -4903,6 +5016,7 @@ int mc_group_get_stats(mc_group *g, mc_stats *out)
         t.windows += s.windows; t.count_launches += s.count_launches; t.table_slots += s.table_slots; t.table_bytes += s.table_bytes;
         t.grows += s.grows; t.spill_keys += s.spill_keys; t.solid_kmers += s.solid_kmers; t.solid_sweeps += s.solid_sweeps;
         t.solid_list_builds += s.solid_list_builds;
+        t.long_runs += s.long_runs;
         t.count_ms = std::max(t.count_ms, s.count_ms); t.count_total_ms = std::max(t.count_total_ms, s.count_total_ms);
         t.p1_ms = std::max(t.p1_ms, s.p1_ms); t.p2_ms = std::max(t.p2_ms, s.p2_ms); t.p3_ms = std::max(t.p3_ms, s.p3_ms);
     }

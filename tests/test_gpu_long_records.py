@@ -1,0 +1,135 @@
+"""The long-record form of the counting pipeline (csrc/count_long.h): polynomial-hash keys of 33 .. 63 bases, a table sized by
+a capacity hint, regions = minimizer bins of the k-mers' BASES.  Same (key, count) pairs and the same walks as the CPU oracle
+(oracle/pyoracle.py follows src/utils/PolynomialHash.java:19-28, src/io/IOUtils.java:207-208 and
+src/algo/OneSequenceCalculator.java) -- and as the per-window form, which MC_LONG_RECORDS=0 keeps.  Needs a real MI355X."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from tests.helpers import assert_bfs_equal, oracle_table, ragged_case, seed_windows, synth_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mc():
+    import metacherchant_amd as m
+    m.native.load()
+    return m
+
+
+def _walks(ctx, t, k, genome, cov):
+    seed = genome[10000:10400]
+    hi, lo = seed_windows(seed, k)
+    for d, mk, mr in [(0, 100000, -1), (1, 3000, -1), (-1, -1, 200), (0, 777, -1)]:
+        assert_bfs_equal(ctx.bfs(hi, lo, d, cov, mk, mr), po.bfs(t, k, po.KEY_POLY, [seed], d, cov, mk, mr))
+
+
+@pytest.mark.parametrize("k", [63, 33, 40, 41, 47, 48, 55, 62])
+def test_long_records_count_and_walk(mc, monkeypatch, k):
+    """Two batches (the second one into a table that holds keys already, starting in the middle of a tile of the read store):
+    every (key, count) pair of the oracle, the walks of the oracle straight on the minimizer-bin table (look-ups by the k-mers'
+    bases), then a look-up BY KEY of everything -- which moves the table to hash-prefix regions -- and the walks again."""
+    monkeypatch.setenv("MC_COUNT_PATH", "partition")  # (a batch of under 2^22 windows takes the direct kernel otherwise: by key)
+    monkeypatch.delenv("MC_LONG_RECORDS", raising=False)
+    n_reads = 80000 if k > 50 else 50000
+    genome, reads, off = synth_case(2, 200000, n_reads, 150, 50)
+    t, _ = oracle_table(reads, off, k, po.KEY_POLY)
+    ok, oc = t.dump()
+    ctx = mc.Context(k, mc.KEY_POLY, 0, int(t.size() * 1.3))
+    ctx.set_coverage_hint(3)
+    cut = n_reads // 2 + 1
+    ctx.add_reads_packed(po.pack(reads[:off[cut]]), off[:cut + 1])
+    ctx.add_reads_packed(po.pack(reads[off[cut]:]), off[cut:] - off[cut])
+    assert ctx.finalize() == t.size()
+    st = ctx.stats()
+    assert st.long_runs == 2 and st.grows == 0, (st.long_runs, st.grows)
+    gk, gc = ctx.export(0)
+    assert np.array_equal(gk, ok) and np.array_equal(gc, oc)
+    _walks(ctx, t, k, genome, 3)
+    assert np.array_equal(ctx.get(ok), oc)       # by key: the table gives up its minimizer bins
+    assert ctx.stats().grows == 1
+    gk, gc = ctx.export(0)
+    assert np.array_equal(gk, ok) and np.array_equal(gc, oc)
+    _walks(ctx, t, k, genome, 3)
+    # ... and what comes now takes the per-window form, into the same table
+    ctx.add_reads_packed(po.pack(reads[:off[cut]]), off[:cut + 1])
+    ctx.finalize()
+    assert ctx.stats().long_runs == 2
+    t2 = po.Table()
+    t2.count_reads(reads, off, k, po.KEY_POLY)
+    t2.count_reads(reads[:off[cut]], off[:cut + 1], k, po.KEY_POLY)
+    ok2, oc2 = t2.dump()
+    gk, gc = ctx.export(0)
+    assert np.array_equal(gk, ok2) and np.array_equal(gc, oc2)
+    ctx.close()
+
+
+@pytest.mark.parametrize("k", [33, 63, 50])
+def test_long_records_of_ragged_reads(mc, monkeypatch, k):
+    """Empty reads, reads of k - 1, k and k + 1 bases, reads of every length up to 220: windows never span two reads (the
+    128-bit read-start mask of k_skl_extract), runs are cut at 32 windows, tiles end inside reads."""
+    monkeypatch.setenv("MC_COUNT_PATH", "partition")
+    monkeypatch.delenv("MC_LONG_RECORDS", raising=False)
+    rng = np.random.default_rng(100 + k)
+    genome, reads, off = ragged_case(rng, 6000, 220, 20000)
+    # a few reads of exactly k - 1, k, k + 1 bases, and a long error-free one (runs of more than 32 windows)
+    extra = [genome[5:5 + k - 1], genome[50:50 + k], genome[90:90 + k + 1], genome[1000:3000]]
+    lens = np.diff(off).tolist() + [len(e) for e in extra]
+    reads = np.concatenate([reads] + extra)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    t, _ = oracle_table(reads, off, k, po.KEY_POLY)
+    ok, oc = t.dump()
+    ctx = mc.Context(k, mc.KEY_POLY, 0, 100000)
+    ctx.add_reads_packed(po.pack(reads), off)
+    assert ctx.finalize() == t.size()
+    assert ctx.stats().long_runs == 1
+    gk, gc = ctx.export(0)
+    assert np.array_equal(gk, ok) and np.array_equal(gc, oc)
+    seed = genome[1200:1500]
+    hi, lo = seed_windows(seed, k)
+    for d in (0, 1, -1):
+        assert_bfs_equal(ctx.bfs(hi, lo, d, 2, 5000, -1), po.bfs(t, k, po.KEY_POLY, [seed], d, 2, 5000, -1))
+    ctx.close()
+
+
+def test_long_records_into_a_table_a_quarter_the_size(mc, monkeypatch):
+    """A capacity hint a quarter of what the reads hold: bins overflow, leaves hand occurrences on along the region chain or
+    fail -- and a table of hash keys in minimizer bins cannot be rebuilt with more bins: it moves to hash-prefix regions under
+    the run and the leaves that were left go in by key.  Nothing may be lost or counted twice."""
+    monkeypatch.delenv("MC_COUNT_PATH", raising=False)
+    monkeypatch.delenv("MC_LONG_RECORDS", raising=False)
+    k = 47
+    genome, reads, off = synth_case(2, 150000, 60000, 150, 150)
+    t, _ = oracle_table(reads, off, k, po.KEY_POLY)
+    ok, oc = t.dump()
+    ctx = mc.Context(k, mc.KEY_POLY, 0, t.size() // 4)
+    ctx.add_reads_packed(po.pack(reads), off)
+    assert ctx.finalize() == t.size()
+    gk, gc = ctx.export(0)
+    assert np.array_equal(gk, ok) and np.array_equal(gc, oc)
+    assert np.array_equal(ctx.get(ok), oc)
+    seed = genome[10000:10300]
+    hi, lo = seed_windows(seed, k)
+    assert_bfs_equal(ctx.bfs(hi, lo, 0, 3, 20000, -1), po.bfs(t, k, po.KEY_POLY, [seed], 0, 3, 20000, -1))
+    ctx.close()
+
+
+def test_long_records_switched_off(mc, monkeypatch):
+    """MC_LONG_RECORDS=0 (read at mc_create): the per-window pipeline, as before -- and no hint, no long records."""
+    monkeypatch.delenv("MC_COUNT_PATH", raising=False)
+    genome, reads, off = synth_case(1, 100000, 50000, 150, 50)
+    t, _ = oracle_table(reads, off, 63, po.KEY_POLY)
+    ok, oc = t.dump()
+    for env, hint in (("0", 3_000_000), (None, 0)):
+        if env is None:
+            monkeypatch.delenv("MC_LONG_RECORDS", raising=False)
+        else:
+            monkeypatch.setenv("MC_LONG_RECORDS", env)
+        ctx = mc.Context(63, mc.KEY_POLY, 0, hint)
+        ctx.add_reads_packed(po.pack(reads), off)
+        assert ctx.finalize() == t.size()
+        assert ctx.stats().long_runs == 0
+        gk, gc = ctx.export(0)
+        assert np.array_equal(gk, ok) and np.array_equal(gc, oc)
+        ctx.close()
