@@ -416,8 +416,10 @@ def config2_leg(args, m, torch, dev, local_rank, d_words, d_off, R, L, n_bases):
            "table_bytes": int(st.table_bytes),
            "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                         "bytes_per_kmer": round(A, 3), "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches / args.config2_steps,
-                        "kernel_ms": {"k_p1_extract_scatter": round(st.p1_ms / launches, 3), "k_p2_scatter": round(st.p2_ms / launches, 3),
-                                      "k_p3_merge": round(st.p3_ms / launches, 3)},
+                        "form": "long records (csrc/count_long.h)" if st.long_runs else "a key per window",
+                        "kernel_ms": dict(zip(("k_skl_extract", "k_sk2_scatter_compact<2,2>", "k_p3_long") if st.long_runs else
+                                              ("k_p1_extract_scatter", "k_p2_scatter", "k_p3_merge"),
+                                              (round(st.p1_ms / launches, 3), round(st.p2_ms / launches, 3), round(st.p3_ms / launches, 3)))),
                         "count_ms_per_step": round(st.count_total_ms / args.config2_steps, 3)}}
     ctx.close()
     return out

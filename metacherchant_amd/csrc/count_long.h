@@ -302,13 +302,48 @@ __global__ void __launch_bounds__(P1W_THREADS, MC_P1W_MIN_WAVES) k_skl_extract(
 // Merge: one workgroup per leaf = table region (count_pipeline.h k_p3_merge, whose layout, probing, pointer rule, hand-on list
 // and solid list these are).  A lane takes a record, starts both strands' hashes of its first window four bases at a time from
 // two 256-entry LDS tables (kmer_device.h poly_hashes_tabled) and rolls them along its windows.
+#ifndef MC_SKL_CHUNK
+#define MC_SKL_CHUNK 8   // windows a lane of the merge kernel takes of a record
+#endif
+constexpr uint32_t SKL_CHUNK = MC_SKL_CHUNK, SKL_CPR = SKL_MAX_WINDOWS / SKL_CHUNK;  // chunks (lanes) per record
+static_assert(SKL_CPR * SKL_CHUNK == SKL_MAX_WINDOWS && SKL_CHUNK * 2 * (SKL_CPR - 1) < 64, "a chunk starts less than a word into the record");
+constexpr uint32_t SKL_ROUND = 1024;                 // records whose chunks are lined up at a time
+constexpr uint32_t SKL_TASKS = SKL_ROUND * SKL_CPR;
 struct alignas(16) LongLds {
     uint64_t key[REGION_SLOTS];
     uint32_t cnt[REGION_SLOTS];
     uint32_t aux[REGION_SLOTS];
     uint16_t polyF[256], polyR[256];
+    uint16_t tasks[SKL_TASKS];          // record (of the 1024 at hand) << 2 | chunk
     uint32_t n_new, overflow, emit_cur, n_empty;
+    uint32_t n_tasks, pad_[3];
 };
+static_assert(2 * sizeof(LongLds) <= 160 * 1024, "two workgroups of the long merge kernel on a CU");
+
+// both strands' hashes of the k-mer at the top of X0:X1 (kmer_device.h poly_hashes_tabled, whose values these are): the bytes
+// of either strand sit at fixed places of X0:X1 and of the right-aligned k-mer, so the sixteen steps are unrolled with constant
+// shifts instead of moving two 128-bit words along (a third of what a chunk of 8 windows costs was this start-up)
+__device__ __forceinline__ void poly_start(uint64_t X0, uint64_t X1, uint64_t X2, int k, const uint16_t *polyF, const uint16_t *polyR, uint64_t *hf_out,
+                                           uint64_t *hr_out)
+{
+    const int n4 = k >> 2, rem = k & 3;
+    const Kmer v = skl_first_kmer(X0, X1, k);
+    uint64_t hf = 1, hr = 1;
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        if (i < n4) {  // (uniform)
+            const uint32_t fb = (uint32_t)((i < 8 ? X0 : X1) >> (56 - 8 * (i & 7))) & 0xFFu;
+            const uint32_t rb = (uint32_t)((i < 8 ? v.lo : v.hi) >> (8 * (i & 7))) & 0xFFu;
+            hf = hf * 625ull + polyF[fb];
+            hr = hr * 625ull + polyR[rb];
+        }
+    for (int e = 0; e < rem; e++) {
+        hf = hf * 5ull + skl_base(X0, X1, X2, (uint32_t)(4 * n4 + e));
+        hr = hr * 5ull + (3u ^ skl_base(X0, X1, X2, (uint32_t)(rem - 1 - e)));
+    }
+    *hf_out = hf;
+    *hr_out = hr;
+}
 
 __global__ void __launch_bounds__(P3_THREADS) k_p3_long(const uint4 *__restrict__ leaf_recs, const uint32_t *__restrict__ leaf_counts, uint64_t cap,
                                                         uint32_t n_leaves, TableView t, int virgin, uint32_t *leaf_state, uint32_t *leaf_new,
@@ -331,9 +366,10 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_long(const uint4 *__restrict_
         Slot *gs = t.slots + (uint64_t)leaf * REGION_SLOTS;
         const uint32_t n = min(leaf_counts[leaf], (uint32_t)cap);
         const uint4 *recs = leaf_recs + 2 * (uint64_t)leaf * cap;
-        // the first round's records are requested before the region image is set up
-        uint4 r0 = make_uint4(0, 0, 0, 0), r1 = make_uint4(0, 0, 0, 0);
-        if (tid < n) { r0 = recs[2 * tid]; r1 = recs[2 * tid + 1]; }
+        // window counts of the first 1024 records: requested before the region image is set up
+        uint32_t nw_pre[SKL_ROUND / P3_THREADS];
+#pragma unroll
+        for (uint32_t u = 0; u < SKL_ROUND / P3_THREADS; u++) nw_pre[u] = tid + u * P3_THREADS < n ? (recs[2 * (tid + u * P3_THREADS)].y & 0xFFu) + 1u : 0u;
         int solid_before = 0;
         for (uint32_t i = tid; i < REGION_SLOTS; i += P3_THREADS) {
             if (virgin) {
@@ -346,38 +382,87 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_long(const uint4 *__restrict_
                 solid_before += solid_thr && raw.z >= solid_thr;  // (empty slots hold count 0)
             }
         }
-        if (tid == 0) { L.n_new = 0; L.overflow = 0; L.n_empty = 0; }
+        if (tid == 0) { L.n_new = 0; L.overflow = 0; L.n_empty = 0; L.n_tasks = 0; }
         __syncthreads();
         uint32_t my_new = 0, my_empty = 0;
-        for (uint32_t r = tid; r - tid < n; r += P3_THREADS) {  // (uniform trip count: every wave that starts a round has a lane in it or leaves at once)
-            const bool mine = r < n;
-            if (r != tid && mine) { r0 = recs[2 * r]; r1 = recs[2 * r + 1]; }
-            if (!__ballot(mine)) break;
-            const uint32_t nw = mine ? (r0.y & 0xFFu) + 1u : 0u, p0 = r0.x;
-            const uint64_t X0 = ((uint64_t)r0.w << 32) | r0.z, X1 = ((uint64_t)r1.y << 32) | r1.x, X2 = ((uint64_t)r1.w << 32) | r1.z;
-            uint64_t hf = 0, hr = 0;
-            if (mine) poly_hashes_tabled(skl_first_kmer(X0, X1, k), k, L.polyF, L.polyR, &hf, &hr);
-            for (uint32_t j = 0; j < SKL_MAX_WINDOWS; j++) {
-                const bool act = j < nw;
-                if (!__ballot(act)) break;
-                if (act) {
-                    const uint64_t key = (int64_t)hf < (int64_t)hr ? hf : hr;  // (Math.min on signed longs)
-                    if (key == EMPTY_KEY) {
-                        my_empty++;
-                    } else {
-                        uint32_t new_wave = 0;
-                        unsigned long long pending;
-                        const uint32_t s = lds_probe_claim(key_base, sk_home(key), key, &new_wave, &pending);
-                        if ((tid & 63u) == (uint32_t)__ffsll((long long)__ballot(true)) - 1u) my_new += new_wave;
-                        if ((pending >> (tid & 63u)) & 1ull) {
-                            if (!ovf_push(t, key, 1u, ptr_advance_long(p0, j), leaf)) atomicExch(&L.overflow, 1u);
-                        } else {
-                            const uint32_t seen = atomicAdd(&L.cnt[s], 1u);
-                            if (p0 && seen >= ptr_from && seen <= ptr_from + 3u && seen == ptr_pick(key, ptr_from, solid_thr)) L.aux[s] = ptr_advance_long(p0, j);
-                        }
-                    }
-                    if (j + 1 < nw) poly_roll(hf, hr, skl_base(X0, X1, X2, j), skl_base(X0, X1, X2, j + (uint32_t)k), p_k, p_km1);
+        // A lane takes a CHUNK of SKL_CHUNK windows of a record.  With a lane a record three of the eight waves had work, for 32
+        // steps, and -- what cost most -- the ~30 reads that cover a locus give as many near-identical records, whose lanes came to
+        // the SAME key at the same step: every compare-and-swap and every count addition ten lanes deep on one LDS address (20 ms
+        // for configs[2]'s 10 M reads against 6 for the per-window merge).  The chunks that hold windows are lined up first (one
+        // LDS atomic a record for its place: chunks of a record next to each other, so the lanes of a wave mostly hold different keys).
+        for (uint32_t rbase = 0; rbase < n; rbase += SKL_ROUND) {
+#pragma unroll
+            for (uint32_t u = 0; u < SKL_ROUND / P3_THREADS; u++) {
+                const uint32_t rl = tid + u * P3_THREADS, r = rbase + rl;
+                const uint32_t nw = rbase == 0 ? nw_pre[u] : (r < n ? (recs[2 * r].y & 0xFFu) + 1u : 0u);
+                const uint32_t nch = (nw + SKL_CHUNK - 1) / SKL_CHUNK;
+                if (nch) {
+                    const uint32_t at = atomicAdd(&L.n_tasks, nch);
+                    for (uint32_t c = 0; c < nch; c++) L.tasks[at + c] = (uint16_t)((rl << 2) | c);
                 }
+            }
+            __syncthreads();
+            const uint32_t nt = L.n_tasks;
+            for (uint32_t T = tid; T - tid < nt; T += P3_THREADS) {  // (uniform trip count)
+                const bool mine = T < nt;
+                if (!__ballot(mine)) continue;
+                const uint32_t task = mine ? L.tasks[T] : 0u;
+                const uint32_t r = rbase + (task >> 2), j0 = (task & 3u) * SKL_CHUNK;
+                uint4 r0 = make_uint4(0, 0, 0, 0), r1 = make_uint4(0, 0, 0, 0);
+                if (mine) { r0 = recs[2 * r]; r1 = recs[2 * r + 1]; }
+                const uint32_t nw = mine ? (r0.y & 0xFFu) + 1u : 0u, p0 = r0.x;
+                const uint32_t cnt = j0 < nw ? min(SKL_CHUNK, nw - j0) : 0u;
+                uint64_t X0 = ((uint64_t)r0.w << 32) | r0.z, X1 = ((uint64_t)r1.y << 32) | r1.x, X2 = ((uint64_t)r1.w << 32) | r1.z;
+                if (j0) {  // the bases from the chunk's first window on (j0 = 8, 16, 24)
+                    const uint32_t sh = 2 * j0;
+                    X0 = (X0 << sh) | (X1 >> (64 - sh));
+                    X1 = (X1 << sh) | (X2 >> (64 - sh));
+                    X2 <<= sh;
+                }
+                uint64_t hf = 0, hr = 0;
+#ifdef MC_SKL_NOHASH   // (tuning builds: what the hashes cost / what the insertions cost)
+                hf = fmix64(X0 ^ (X1 * 0x9E3779B97F4A7C15ull) ^ j0); hr = ~0ull >> 1;
+#else
+                if (cnt) poly_start(X0, X1, X2, k, L.polyF, L.polyR, &hf, &hr);
+#endif
+#pragma unroll 1
+                for (uint32_t j = 0; j < SKL_CHUNK; j++) {
+                    const bool act = j < cnt;
+                    if (!__ballot(act)) break;
+                    if (act) {
+                        const uint64_t key = (int64_t)hf < (int64_t)hr ? hf : hr;  // (Math.min on signed longs)
+#ifdef MC_SKL_NOINSERT
+                        if ((key & 0xFFFFFFFFFull) == 12345ull) {
+#else
+                        if (key == EMPTY_KEY) {
+#endif
+                            my_empty++;
+                        } else {
+#ifndef MC_SKL_NOINSERT
+                            uint32_t new_wave = 0;
+                            unsigned long long pending;
+                            const uint32_t s = lds_probe_claim(key_base, sk_home(key), key, &new_wave, &pending);
+                            if ((tid & 63u) == (uint32_t)__ffsll((long long)__ballot(true)) - 1u) my_new += new_wave;
+                            if ((pending >> (tid & 63u)) & 1ull) {
+                                if (!ovf_push(t, key, 1u, ptr_advance_long(p0, j0 + j), leaf)) atomicExch(&L.overflow, 1u);
+                            } else {
+                                const uint32_t seen = atomicAdd(&L.cnt[s], 1u);
+                                if (p0 && seen >= ptr_from && seen <= ptr_from + 3u && seen == ptr_pick(key, ptr_from, solid_thr)) L.aux[s] = ptr_advance_long(p0, j0 + j);
+                            }
+#endif
+                        }
+#ifdef MC_SKL_NOHASH
+                        hf = hf * 0x9E3779B97F4A7C15ull + 1;
+#else
+                        if (j + 1 < cnt) poly_roll(hf, hr, skl_base(X0, X1, X2, j), skl_base(X0, X1, X2, j + (uint32_t)k), p_k, p_km1);
+#endif
+                    }
+                }
+            }
+            if (rbase + SKL_ROUND < n) {  // (uniform) the list is rewritten
+                __syncthreads();
+                if (tid == 0) L.n_tasks = 0;
+                __syncthreads();
             }
         }
         if (my_new) atomicAdd(&L.n_new, my_new);

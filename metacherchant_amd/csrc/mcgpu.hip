@@ -2306,6 +2306,15 @@ int mc_create(const mc_config *cfg, mc_ctx **out)
         if (const char *e = getenv("MC_TABLE_LOAD")) { const double v = atof(e); if (v > 0.05 && v < 0.95) load = v; }  // (tuning runs)
         want_slots = std::max<uint64_t>(want_slots, (uint64_t)((double)cfg->capacity_hint / load));
         if (c->mm_k) want_slots = std::max<uint64_t>(1ull << 22, mm_slots_for(c, (double)cfg->capacity_hint, load));
+        if (hash_bins(c) && (double)cfg->capacity_hint > 0.40 * (double)want_slots) {
+            // Long records need their bins roomy: at k = 63 a region holds the k-mers of four or five loci (each with the error
+            // variants of the ~30 reads that cover it), and 2^21 regions -- one a leaf, all the merge kernel takes -- at load 0.53
+            // (configs[2] at full size: 4.6 G keys, 137 GB) leave a few per cent of them overfull, more than the hand-on list
+            // holds; such a table cannot be rebuilt either.  Those contexts keep the per-window pipeline.
+            c->mm_k = 0;
+            want_slots = std::max<uint64_t>(1ull << 22, (uint64_t)((double)cfg->capacity_hint / 0.7));
+            if (const char *e = getenv("MC_TABLE_LOAD")) { const double v = atof(e); if (v > 0.05 && v < 0.95) want_slots = std::max<uint64_t>(1ull << 22, (uint64_t)((double)cfg->capacity_hint / v)); }
+        }
     }
     int rc = table_alloc(c, regions_for(c, want_slots));
     if (rc) {

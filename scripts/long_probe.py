@@ -1,0 +1,29 @@
+"""Tuning: configs[2] scaled to 10 M reads (k = 63 polynomial keys) counted a few times; prints the levels' times.
+MC_LIB selects a tuning build.  python scripts/long_probe.py [reads]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import metacherchant_amd as m
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+L, k = 150, 63
+m.native.load()
+dev = torch.device("cuda:0")
+n_bases = R * L
+words = torch.empty((n_bases + 31) // 32 + 1, dtype=torch.int64, device=dev)
+off = torch.empty(R + 1, dtype=torch.int64, device=dev)
+gen = m.Context(31, m.KEY_PACKED, 0, 1 << 20)
+from bench import GENOME_SEED, READ_SEED
+gen.synth_reads_dev(GENOME_SEED, 10, R // 2, READ_SEED, 0, R, L, 100, words, off)
+gen.close()
+windows = R * (L - k + 1)
+ctx = m.Context(k, m.KEY_POLY, 0, int(windows * 0.53) + (1 << 20))
+ctx.set_coverage_hint(3)
+for it in range(3):
+    ctx.clear()
+    ctx.reset_stats()
+    ctx.add_reads_packed_dev(words, off, R, n_bases)
+    nd = ctx.finalize()
+    st = ctx.stats()
+    print("lib %s: distinct %d long_runs %d p1 %.2f p2 %.2f p3 %.2f ms (count %.2f), spills %d grows %d" % (
+        os.path.basename(os.environ.get("MC_LIB", "product")), nd, st.long_runs, st.p1_ms, st.p2_ms, st.p3_ms, st.count_total_ms, st.spill_keys, st.grows), flush=True)
+ctx.close()

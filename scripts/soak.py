@@ -19,11 +19,13 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 only = int(os.environ["SOAK_ONLY"]) if "SOAK_ONLY" in os.environ else None  # replay one iteration of a run (the others only draw their numbers)
 first = int(os.environ.get("SOAK_FROM", 0))                                     # ... or all from this one on
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+# SOAK_KS=33,41,47,55,63: other k-mer lengths (above 31: polynomial keys -- with a capacity hint, the long-record pipeline)
+KS = [int(x) for x in os.environ.get("SOAK_KS", "").split(",") if x] or [21, 23, 24, 25, 27, 28, 29, 30, 31, 31, 31, 41]
 SEEDS = int(os.environ.get("SOAK_SEEDS", 6))  # seed sequences per table, three walks each
 walks = 0
 t0 = time.time()
 for it in range(iters):
-    k = int(rng.choice([21, 23, 24, 25, 27, 28, 29, 30, 31, 31, 31, 41]))
+    k = int(rng.choice(KS))
     mode, omode = (mc.KEY_PACKED, po.KEY_PACKED) if k <= 31 else (mc.KEY_POLY, po.KEY_POLY)
     err = int(rng.choice([0, 50, 100, 200, 500]))
     L = int(rng.choice([45, 70, 100, 150, 250]))
@@ -91,6 +93,7 @@ for it in range(iters):
         assert_bfs_equal(got, want)
     st = ctx.stats()
     ctx.close()
-    print("it %d ok%s: k=%d err=%d L=%d reads=%d genome=%dx%d cov=%d hint=%d cap=%d batches=%d distinct=%d list=%d sweeps=%d spills=%d (%.0f s)" % (
-        it, " (ragged)" if ragged else "", k, err, L, n_reads, contigs, clen, cov, hint, cap, 2 if two else 1, nd, st.solid_list_builds, st.solid_sweeps, st.spill_keys, time.time() - t0), flush=True)
+    print("it %d ok%s: k=%d err=%d L=%d reads=%d genome=%dx%d cov=%d hint=%d cap=%d batches=%d distinct=%d list=%d sweeps=%d spills=%d long=%d grows=%d (%.0f s)" % (
+        it, " (ragged)" if ragged else "", k, err, L, n_reads, contigs, clen, cov, hint, cap, 2 if two else 1, nd, st.solid_list_builds, st.solid_sweeps, st.spill_keys,
+        st.long_runs, st.grows, time.time() - t0), flush=True)
 print("soak ok: %d iterations, %d walks" % (iters, walks))
