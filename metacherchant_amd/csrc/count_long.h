@@ -307,14 +307,17 @@ __global__ void __launch_bounds__(P1W_THREADS, MC_P1W_MIN_WAVES) k_skl_extract(
 #endif
 constexpr uint32_t SKL_CHUNK = MC_SKL_CHUNK, SKL_CPR = SKL_MAX_WINDOWS / SKL_CHUNK;  // chunks (lanes) per record
 static_assert(SKL_CPR * SKL_CHUNK == SKL_MAX_WINDOWS && SKL_CHUNK * 2 * (SKL_CPR - 1) < 64, "a chunk starts less than a word into the record");
-constexpr uint32_t SKL_ROUND = 1024;                 // records whose chunks are lined up at a time
+constexpr uint32_t SKL_ROUND = P3_THREADS;           // records at hand at a time: one a thread (merged where equal, their chunks lined up)
+constexpr uint32_t SKL_DTAB = 1024;                  // slots of the table that finds equal records
 constexpr uint32_t SKL_TASKS = SKL_ROUND * SKL_CPR;
 struct alignas(16) LongLds {
     uint64_t key[REGION_SLOTS];
     uint32_t cnt[REGION_SLOTS];
     uint32_t aux[REGION_SLOTS];
     uint16_t polyF[256], polyR[256];
-    uint16_t tasks[SKL_TASKS];          // record (of the 1024 at hand) << 2 | chunk
+    uint16_t tasks[SKL_TASKS];          // record (of the 512 at hand) << 2 | chunk
+    uint32_t dtab[SKL_DTAB];            // 0: free; fingerprint << 16 | record + 1
+    uint16_t copies[SKL_ROUND];         // of a record that stands for its equals, itself included
     uint32_t n_new, overflow, emit_cur, n_empty;
     uint32_t n_tasks, pad_[3];
 };
@@ -345,12 +348,16 @@ __device__ __forceinline__ void poly_start(uint64_t X0, uint64_t X1, uint64_t X2
     *hr_out = hr;
 }
 
+// KT: the k-mer length when the kernel is built for one (63: configs[2]) -- shifts, trip counts and the powers of 5 are constants
+// then -- or 0: any length, from the argument.
+template <int KT>
 __global__ void __launch_bounds__(P3_THREADS) k_p3_long(const uint4 *__restrict__ leaf_recs, const uint32_t *__restrict__ leaf_counts, uint64_t cap,
                                                         uint32_t n_leaves, TableView t, int virgin, uint32_t *leaf_state, uint32_t *leaf_new,
-                                                        uint32_t *any_failed, uint32_t solid_thr, unsigned long long *n_solid, int k, P3Emit emit,
+                                                        uint32_t *any_failed, uint32_t solid_thr, unsigned long long *n_solid, int k_arg, P3Emit emit,
                                                         const uint32_t *lost)
 {
     if (lost && *lost) return;  // (the scatter levels lost records: the batch is counted another way)
+    const int k = KT ? KT : k_arg;
     __shared__ LongLds L;
     const uint32_t tid = threadIdx.x;
     const bool emitting = emit.recs != nullptr && solid_thr != 0;
@@ -366,39 +373,74 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_long(const uint4 *__restrict_
         Slot *gs = t.slots + (uint64_t)leaf * REGION_SLOTS;
         const uint32_t n = min(leaf_counts[leaf], (uint32_t)cap);
         const uint4 *recs = leaf_recs + 2 * (uint64_t)leaf * cap;
-        // window counts of the first 1024 records: requested before the region image is set up
-        uint32_t nw_pre[SKL_ROUND / P3_THREADS];
-#pragma unroll
-        for (uint32_t u = 0; u < SKL_ROUND / P3_THREADS; u++) nw_pre[u] = tid + u * P3_THREADS < n ? (recs[2 * (tid + u * P3_THREADS)].y & 0xFFu) + 1u : 0u;
+        // a thread's own record of the first 512: requested before the region image is set up
+        uint4 q0 = make_uint4(0, 0, 0, 0), q1 = make_uint4(0, 0, 0, 0);
+        if (tid < n) { q0 = recs[2 * tid]; q1 = recs[2 * tid + 1]; }
         int solid_before = 0;
+        uint32_t occ = 0;  // occupied slots when the region goes back - when it came: the keys this leaf added
         for (uint32_t i = tid; i < REGION_SLOTS; i += P3_THREADS) {
             if (virgin) {
                 L.key[i] = EMPTY_KEY; L.cnt[i] = 0; L.aux[i] = 0;
             } else {
                 const uint4 raw = *reinterpret_cast<const uint4 *>(gs + i);
+                occ -= (raw.x & raw.y) != 0xFFFFFFFFu;
                 L.key[i] = ((uint64_t)raw.y << 32) | raw.x;
                 L.cnt[i] = min(raw.z, P3_COUNT_CAP);
                 L.aux[i] = raw.w;
                 solid_before += solid_thr && raw.z >= solid_thr;  // (empty slots hold count 0)
             }
         }
+        for (uint32_t i = tid; i < SKL_DTAB; i += P3_THREADS) L.dtab[i] = 0;
+        L.copies[tid] = 1;
         if (tid == 0) { L.n_new = 0; L.overflow = 0; L.n_empty = 0; L.n_tasks = 0; }
         __syncthreads();
-        uint32_t my_new = 0, my_empty = 0;
+        uint32_t my_empty = 0;
         // A lane takes a CHUNK of SKL_CHUNK windows of a record.  With a lane a record three of the eight waves had work, for 32
         // steps, and -- what cost most -- the ~30 reads that cover a locus give as many near-identical records, whose lanes came to
         // the SAME key at the same step: every compare-and-swap and every count addition ten lanes deep on one LDS address (20 ms
         // for configs[2]'s 10 M reads against 6 for the per-window merge).  The chunks that hold windows are lined up first (one
         // LDS atomic a record for its place: chunks of a record next to each other, so the lanes of a wave mostly hold different keys).
         for (uint32_t rbase = 0; rbase < n; rbase += SKL_ROUND) {
+            // Equal records first: a read that covers a locus's run of windows whole and without an error yields the same record as
+            // every other such read -- 0.99^94 = 39 % of configs[2]'s records, a dozen of each -- and one of them stands for all,
+            // each of its windows adding their number.  A thread registers its record's fingerprint in a small table with one
+            // compare-and-swap; who finds the fingerprint there compares the records word for word (a record that finds neither
+            // its equal nor a free slot in four probes stays on its own: exact either way).
+            if (rbase) {
+                q0 = make_uint4(0, 0, 0, 0); q1 = q0;
+                if (rbase + tid < n) { q0 = recs[2 * (rbase + tid)]; q1 = recs[2 * (rbase + tid) + 1]; }
+            }
+            const bool have = rbase + tid < n;
+            const uint32_t nw_own = have ? (q0.y & 0xFFu) + 1u : 0u;
+            uint32_t cand = 0xFFFFFFFFu;  // the record mine may be a copy of
+            if (have) {
+                uint32_t h = q0.z * 0x9E3779B1u ^ q0.w;
+                h = (h ^ (h >> 15)) * 0x85EBCA6Bu ^ q1.x;
+                h = (h ^ (h >> 13)) * 0xC2B2AE35u ^ q1.y;
+                h = (h ^ (h >> 16)) * 0x27D4EB2Fu ^ q1.z;
+                h = (h ^ (h >> 15)) * 0x165667B1u ^ q1.w ^ nw_own;
+                h ^= h >> 16;
+                const uint32_t mine_e = (h & 0xFFFF0000u) | (tid + 1u);
+                uint32_t sl = h & (SKL_DTAB - 1u);
 #pragma unroll
-            for (uint32_t u = 0; u < SKL_ROUND / P3_THREADS; u++) {
-                const uint32_t rl = tid + u * P3_THREADS, r = rbase + rl;
-                const uint32_t nw = rbase == 0 ? nw_pre[u] : (r < n ? (recs[2 * r].y & 0xFFu) + 1u : 0u);
-                const uint32_t nch = (nw + SKL_CHUNK - 1) / SKL_CHUNK;
+                for (int pr = 0; pr < 4; pr++) {
+                    const uint32_t old = atomicCAS(&L.dtab[sl], 0u, mine_e);
+                    if (old == 0u) break;  // registered
+                    if ((old & 0xFFFF0000u) == (mine_e & 0xFFFF0000u)) { cand = (old & 0xFFFFu) - 1u; break; }
+                    sl = (sl + 1u) & (SKL_DTAB - 1u);
+                }
+            }
+            bool copy = false;
+            if (cand != 0xFFFFFFFFu) {
+                const uint4 o0 = recs[2 * (rbase + cand)], o1 = recs[2 * (rbase + cand) + 1];
+                copy = ((o0.y ^ q0.y) & 0xFFu) == 0 && o0.z == q0.z && o0.w == q0.w && o1.x == q1.x && o1.y == q1.y && o1.z == q1.z && o1.w == q1.w;
+            }
+            if (copy) atomicAdd(reinterpret_cast<uint32_t *>(&L.copies[cand & ~1u]), (cand & 1u) ? 0x10000u : 1u);  // (16-bit counters, two a word; < 512 copies)
+            {   // (the barrier behind the task list also stands between these additions and the tasks that read them)
+                const uint32_t nch = copy ? 0u : (nw_own + SKL_CHUNK - 1) / SKL_CHUNK;
                 if (nch) {
                     const uint32_t at = atomicAdd(&L.n_tasks, nch);
-                    for (uint32_t c = 0; c < nch; c++) L.tasks[at + c] = (uint16_t)((rl << 2) | c);
+                    for (uint32_t c = 0; c < nch; c++) L.tasks[at + c] = (uint16_t)((tid << 2) | c);
                 }
             }
             __syncthreads();
@@ -411,6 +453,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_long(const uint4 *__restrict_
                 uint4 r0 = make_uint4(0, 0, 0, 0), r1 = make_uint4(0, 0, 0, 0);
                 if (mine) { r0 = recs[2 * r]; r1 = recs[2 * r + 1]; }
                 const uint32_t nw = mine ? (r0.y & 0xFFu) + 1u : 0u, p0 = r0.x;
+                const uint32_t cp = mine ? L.copies[task >> 2] : 0u;
                 const uint32_t cnt = j0 < nw ? min(SKL_CHUNK, nw - j0) : 0u;
                 uint64_t X0 = ((uint64_t)r0.w << 32) | r0.z, X1 = ((uint64_t)r1.y << 32) | r1.x, X2 = ((uint64_t)r1.w << 32) | r1.z;
                 if (j0) {  // the bases from the chunk's first window on (j0 = 8, 16, 24)
@@ -419,53 +462,62 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_long(const uint4 *__restrict_
                     X1 = (X1 << sh) | (X2 >> (64 - sh));
                     X2 <<= sh;
                 }
+                // the bases that leave (from the chunk's first on) and the ones that enter (from base k on) at the top of a word each
+                uint64_t outs = X0, ins;
+                {
+                    const uint32_t sh = 2u * ((uint32_t)k - 32u);  // (k > 32: base k lies in X1, or is X2's first)
+                    ins = sh < 64u ? ((X1 << sh) | ((X2 >> 1) >> (63u - sh))) : X2;
+                }
                 uint64_t hf = 0, hr = 0;
-#ifdef MC_SKL_NOHASH   // (tuning builds: what the hashes cost / what the insertions cost)
-                hf = fmix64(X0 ^ (X1 * 0x9E3779B97F4A7C15ull) ^ j0); hr = ~0ull >> 1;
-#else
                 if (cnt) poly_start(X0, X1, X2, k, L.polyF, L.polyR, &hf, &hr);
-#endif
 #pragma unroll 1
                 for (uint32_t j = 0; j < SKL_CHUNK; j++) {
                     const bool act = j < cnt;
                     if (!__ballot(act)) break;
                     if (act) {
                         const uint64_t key = (int64_t)hf < (int64_t)hr ? hf : hr;  // (Math.min on signed longs)
-#ifdef MC_SKL_NOINSERT
-                        if ((key & 0xFFFFFFFFFull) == 12345ull) {
-#else
-                        if (key == EMPTY_KEY) {
-#endif
-                            my_empty++;
+                        const bool odd_key = key == EMPTY_KEY;  // (the key that looks like a free slot: counted apart)
+                        const uint32_t home = sk_home(key);
+                        // the home slot's compare-and-swap goes out, the hashes move on to the next window while it travels (nine
+                        // keys in ten settle there; the merge kernel's time was the sum of its waits and its arithmetic before)
+                        unsigned long long old0 = EMPTY_KEY;
+                        if (!odd_key) old0 = atomicCAS(reinterpret_cast<unsigned long long *>(&L.key[home]), (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+                        poly_roll(hf, hr, (uint32_t)(outs >> 62), (uint32_t)(ins >> 62), p_k, p_km1);  // (one step past the last window does no harm)
+                        outs <<= 2;
+                        ins <<= 2;
+                        if (odd_key) {
+                            my_empty += cp;
                         } else {
-#ifndef MC_SKL_NOINSERT
-                            uint32_t new_wave = 0;
-                            unsigned long long pending;
-                            const uint32_t s = lds_probe_claim(key_base, sk_home(key), key, &new_wave, &pending);
-                            if ((tid & 63u) == (uint32_t)__ffsll((long long)__ballot(true)) - 1u) my_new += new_wave;
-                            if ((pending >> (tid & 63u)) & 1ull) {
-                                if (!ovf_push(t, key, 1u, ptr_advance_long(p0, j0 + j), leaf)) atomicExch(&L.overflow, 1u);
-                            } else {
-                                const uint32_t seen = atomicAdd(&L.cnt[s], 1u);
-                                if (p0 && seen >= ptr_from && seen <= ptr_from + 3u && seen == ptr_pick(key, ptr_from, solid_thr)) L.aux[s] = ptr_advance_long(p0, j0 + j);
+                            uint32_t s = home;
+                            bool fits = true;
+                            if (old0 != EMPTY_KEY && old0 != key) {  // on from the slot behind, TABLE_MAX_PROBES slots in all (where look-ups look)
+                                uint32_t unused = 0;
+                                unsigned long long pending;
+                                s = lds_probe_claim(key_base, (home + 1u) & (REGION_SLOTS - 1u), key, &unused, &pending, P3_MAX_PROBES - 1u);
+                                fits = !((pending >> (tid & 63u)) & 1ull);
                             }
-#endif
+                            if (!fits) {
+                                if (!ovf_push(t, key, cp, ptr_advance_long(p0, j0 + j), leaf)) atomicExch(&L.overflow, 1u);
+                            } else {
+                                const uint32_t seen = atomicAdd(&L.cnt[s], cp);
+                                // (the occurrence that leaves its pointer, kmer_device.h ptr_pick, is one of these cp)
+                                if (p0 && seen <= ptr_from + 3u && seen + cp > ptr_from) {
+                                    const uint32_t pk = ptr_pick(key, ptr_from, solid_thr);
+                                    if (seen <= pk && pk < seen + cp) L.aux[s] = ptr_advance_long(p0, j0 + j);
+                                }
+                            }
                         }
-#ifdef MC_SKL_NOHASH
-                        hf = hf * 0x9E3779B97F4A7C15ull + 1;
-#else
-                        if (j + 1 < cnt) poly_roll(hf, hr, skl_base(X0, X1, X2, j), skl_base(X0, X1, X2, j + (uint32_t)k), p_k, p_km1);
-#endif
                     }
                 }
             }
-            if (rbase + SKL_ROUND < n) {  // (uniform) the list is rewritten
+            if (rbase + SKL_ROUND < n) {  // (uniform) the list and the table of records are rewritten
                 __syncthreads();
+                for (uint32_t i = tid; i < SKL_DTAB; i += P3_THREADS) L.dtab[i] = 0;
+                L.copies[tid] = 1;
                 if (tid == 0) L.n_tasks = 0;
                 __syncthreads();
             }
         }
-        if (my_new) atomicAdd(&L.n_new, my_new);
         if (my_empty) atomicAdd(&L.n_empty, my_empty);
         __syncthreads();
         const bool ovf = L.overflow != 0;
@@ -476,6 +528,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_long(const uint4 *__restrict_
                 v.x = (uint32_t)kk; v.y = (uint32_t)(kk >> 32);
                 v.z = min(L.cnt[i], P3_COUNT_CAP);
                 v.w = L.aux[i];
+                occ += kk != EMPTY_KEY;
                 *reinterpret_cast<uint4 *>(gs + i) = v;
                 const bool solid = solid_thr && v.z >= solid_thr;
                 solid_delta += solid;
@@ -499,6 +552,9 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_long(const uint4 *__restrict_
                 }
             }
             solid_delta -= solid_before;
+            const uint32_t wsum = wave_incl_sum(occ);  // (two's complement: a thread's own difference may be negative)
+            if ((tid & 63u) == 63u) atomicAdd(&L.n_new, wsum);
+            __syncthreads();
         } else if (virgin) {  // nothing was there: leave a valid empty region behind
             for (uint32_t i = tid; i < REGION_SLOTS; i += P3_THREADS) {
                 uint4 v; v.x = 0xFFFFFFFFu; v.y = 0xFFFFFFFFu; v.z = 0; v.w = 0;

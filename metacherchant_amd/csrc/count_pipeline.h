@@ -1496,8 +1496,9 @@ __device__ __forceinline__ bool ovf_push(const TableView &t, uint64_t key, uint3
 // on the bookkeeping of its exit conditions, and the slowest of 64 lanes decides the number of steps -- the scalar unit
 // was the busiest part of the CU in the merge kernel; this one spends 6.  *n_new_wave += keys the WAVE inserted;
 // *pending: lanes that found no slot in P3_MAX_PROBES steps (their key goes on to the next region: TableView::ovf).
-__device__ __forceinline__ uint32_t lds_probe_claim(uint32_t base, uint32_t home, uint64_t key, uint32_t *n_new_wave, unsigned long long *pending)
-{
+__device__ __forceinline__ uint32_t lds_probe_claim(uint32_t base, uint32_t home, uint64_t key, uint32_t *n_new_wave, unsigned long long *pending,
+                                                    uint32_t max_steps = P3_MAX_PROBES)
+{   // max_steps: the caller has looked at P3_MAX_PROBES - max_steps slots in front of `home` itself
     uint32_t off = home * 8u, addr, cnt, t, it;
     unsigned long long old, sv, hit, pend;
     const unsigned long long empty = EMPTY_KEY;
@@ -1526,7 +1527,7 @@ __device__ __forceinline__ uint32_t lds_probe_claim(uint32_t base, uint32_t home
         "s_mov_b64 exec, %[sv]\n\t"
         : [off] "+v"(off), [old] "=&v"(old), [addr] "=&v"(addr), [sv] "=&s"(sv), [hit] "=&s"(hit), [cnt] "=&s"(cnt), [t] "=&s"(t),
           [it] "=&s"(it), [pend] "=&s"(pend)
-        : [base] "s"(base), [empty] "v"(empty), [key] "v"(key), [wrap] "s"((uint32_t)(REGION_SLOTS * 8u - 8u)), [maxp] "s"((uint32_t)P3_MAX_PROBES)
+        : [base] "s"(base), [empty] "v"(empty), [key] "v"(key), [wrap] "s"((uint32_t)(REGION_SLOTS * 8u - 8u)), [maxp] "s"(max_steps)
         : "vcc", "scc", "memory");
     *n_new_wave += cnt;
     *pending = pend;

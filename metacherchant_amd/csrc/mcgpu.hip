@@ -1486,8 +1486,11 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
 #define P3D_ARGS static_cast<const uint4 *>(lk), lh, lc, lcap, leaves, c->view(), P.leaf_state, P.leaf_new, P.flags + 1, \
                  (uint32_t)(c->solid_tracked ? c->cov_hint : 0), c->d_ctr + 6, k, emit, c->ptr_tries, P.flags
         if (pl.lng) {
-            hipLaunchKernelGGL(k_p3_long, dim3(grid), dim3(P3_THREADS), 0, c->stream, static_cast<const uint4 *>(lk), lc, lcap, leaves, c->view(), virgin,
-                               P.leaf_state, P.leaf_new, P.flags + 1, (uint32_t)(c->solid_tracked ? c->cov_hint : 0), c->d_ctr + 6, k, emit, P.flags);
+#define P3L_ARGS static_cast<const uint4 *>(lk), lc, lcap, leaves, c->view(), virgin, P.leaf_state, P.leaf_new, P.flags + 1, \
+                 (uint32_t)(c->solid_tracked ? c->cov_hint : 0), c->d_ctr + 6, k, emit, P.flags
+            if (k == 63) hipLaunchKernelGGL(k_p3_long<63>, dim3(grid), dim3(P3_THREADS), 0, c->stream, P3L_ARGS);
+            else hipLaunchKernelGGL(k_p3_long<0>, dim3(grid), dim3(P3_THREADS), 0, c->stream, P3L_ARGS);
+#undef P3L_ARGS
         } else if (pl.sk && pl.g == 0 && lseg == 1 && dedup_on) {
             const bool one_gpu = c->ptr_tries == 1 && (emit.recs == nullptr || !(c->solid_tracked && c->cov_hint > 0));
             if (virgin && one_gpu && k == 31) hipLaunchKernelGGL((k_p3_dedup<true, true, true>), dim3(grid), dim3(D2_THREADS), 0, c->stream, P3D_ARGS);

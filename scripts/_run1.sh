@@ -1,12 +1,7 @@
 #!/bin/bash
-# scratch: long-record tests, then the default bench line
+# scratch: the whole GPU suite, then a soak of the long-record lengths
 set -o pipefail
-timeout -k 10 800 python -m pytest tests/test_gpu_long_records.py -x -q > gpurun_out/long1.log 2>&1; rc=$?; tail -3 gpurun_out/long1.log
+timeout -k 10 1500 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_all.log 2>&1; rc=$?; tail -4 gpurun_out/gpu_all.log
 [ $rc -eq 0 ] || exit $rc
-timeout -k 10 600 python bench.py --steps 3 --warmup 1 > gpurun_out/b_long1.json 2> gpurun_out/b_long1.err
-python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/b_long1.json').read().strip().splitlines()[-1])
-print(d['value']/1e9, d['ms_per_step'], d['roofline']['kernel_ms'])
-c=d['config2']; print(c['value']/1e9, c['ms_per_step'], c['bfs'], c['roofline']['kernel_ms'])
-PY
+SOAK_KS=33,41,47,55,63,36,60 SOAK_SEEDS=2 timeout -k 10 900 python scripts/soak.py 40 77 > gpurun_out/soak_long.log 2>&1; rc=$?; tail -3 gpurun_out/soak_long.log; grep -c "long=[1-9]" gpurun_out/soak_long.log
+exit $rc
