@@ -270,6 +270,8 @@ def main():
             p3 = "k_p3_dedup" if dedup else "k_p3_merge"
             parts = {p1: st.p1_ms / launches, "k_sk2_scatter" if sk else "k_p2_scatter": st.p2_ms / launches,
                      p3: st.p3_ms / launches}
+            if st.long_runs:  # polynomial keys, k > 32, as long records (csrc/count_long.h)
+                parts = {"k_skl_extract": st.p1_ms / launches, "k_sk2_scatter_compact<2,2>": st.p2_ms / launches, "k_p3_long": st.p3_ms / launches}
             pipeline = st.p3_ms > 0
             dominant = max(parts, key=parts.get) if pipeline else "k_count_reads"
             # HBM bytes per pipeline run from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH_SIZE doubled

@@ -16,6 +16,7 @@ timeout -k 10 600 python bench.py --no-cpu-baseline --config 2 --steps 2 --warmu
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p/prof_e1 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --skip-no-hint --config2-steps 2 > gpurun_out/p/prof_e1.log 2>&1
 for f in $(find gpurun_out/p/prof_e1 -name '*kernel_stats*.csv'); do cp $f gpurun_out/p/${R}_e1_kernel_stats.csv; done
 bash scripts/gpu_pmc.sh --skip-no-hint --skip-config2 > gpurun_out/p/pmc.log 2>&1; cp gpurun_out/pmc_summary.csv gpurun_out/p/${R}_pmc_hbm_traffic_e1.csv
+bash scripts/gpu_pmc.sh --skip-no-hint --config 2 --reads 10000000 --contigs 10 > gpurun_out/p/pmc_c2.log 2>&1; cp gpurun_out/pmc_summary.csv gpurun_out/p/${R}_pmc_hbm_traffic_config2_scaled.csv
 bash scripts/gpu_pmc_sq.sh ${R} --skip-no-hint --skip-config2 > gpurun_out/p/sq.log 2>&1; cp gpurun_out/sq_${R}_summary.csv gpurun_out/p/${R}_sq_counters_e1.csv
 bash scripts/gpu_timeline.sh --skip-no-hint --skip-config2 > /dev/null 2>&1; cp gpurun_out/timeline.txt gpurun_out/p/${R}_timeline_e1.txt
 timeout -k 10 300 python scripts/rank_phases.py 8 > gpurun_out/p/${R}_rank_phases_8owners.txt 2>&1
