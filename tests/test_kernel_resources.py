@@ -39,3 +39,15 @@ def test_the_walk_and_the_merge_kernel_use_no_scratch_memory(tmp_path):
     for name, r in kernels.items():
         if "k_p3_dedup" in name:
             assert 2 * r["group_segment_fixed_size"] <= 160 * 1024 and r["vgpr_count"] <= 128, (name, r)
+
+
+def test_the_long_record_kernels_fit_two_workgroups_a_cu(tmp_path):
+    """csrc/count_long.h: the first level and the merge kernel of long records use no scratch memory, and the merge kernel's
+    region image, chunk list and record table leave room for two workgroups a CU (160 KB of LDS, 128 registers a wave at 4 a SIMD)."""
+    kernels = _kernel_notes(tmp_path)
+    long_k = {n: r for n, r in kernels.items() if "k_p3_longILi" in n or "k_skl_extract" in n or "k_sk2_scatter_compactILi2ELi2E" in n}
+    assert sum("k_p3_longILi" in n for n in long_k) == 2 and len(long_k) == 4, sorted(long_k)  # built for k = 63, and for any k
+    for name, r in long_k.items():
+        assert r["private_segment_fixed_size"] == 0 and r["vgpr_spill_count"] == 0, (name, r)
+        if "k_p3_long" in name:
+            assert 2 * r["group_segment_fixed_size"] <= 160 * 1024 and r["vgpr_count"] <= 128, (name, r)
