@@ -9,7 +9,10 @@
 //
 //   r0.x  level 1 -> 2 (k_skl_extract): position of the first window relative to the workgroup's first base (the compact form
 //         of count_pipeline.h, with all 32 bits for the position); level 2 -> merge: the read pointer of the first window
-//   r0.y  windows - 1 | (level 1 -> 2 only) leaf in the level-1 bucket << 8
+//   r0.y  windows - 1 | (level 1 -> 2 only) the top 24 bits of the record's bin word << 8: the second level takes its leaf from
+//         them (the table may have been replaced by one of another size since the first level ran: mcgpu.hip pipe_resize_by_sample),
+//         and so that everybody agrees on a key's region, the REGION of a hash key in minimizer bins is worked out from those 24
+//         bits alone wherever it is worked out (skl_bin)
 //   r0.w:r0.z, r1.y:r1.x, r1.w:r1.z   the run's bases (windows + k - 1 <= 96), first base on top, unused tail zero
 //
 // About 20 windows a record at k = 63: the streams shrink ~8-fold.  Nothing by-key can find a key in such a table (mc_get, key
@@ -24,6 +27,9 @@ constexpr uint32_t P1L_LANES = 57;                      // lanes of a wave's til
 constexpr uint32_t P1L_TILE = P1L_LANES * PT_ITEMS;     // 456 base positions per wave tile
 constexpr int SKL_MIN_K = 33, SKL_MAX_K = 63;           // (two-word k-mers; mc_create takes hash keys up to k = 63)
 static_assert((SKL_MAX_K - SK_M) / 8 + 1 <= 64 - (int)P1L_LANES, "k_skl_extract: a window reaches at most that many lanes up");
+
+// the bin word of a hash key's minimizer: sk_bin with its low byte cleared (see the record's second word)
+__host__ __device__ __forceinline__ uint32_t skl_bin(uint32_t hmin) { return sk_bin(hmin) & 0xFFFFFF00u; }
 
 struct SklSpill {
     uint4 *recs;  // two per record
@@ -85,7 +91,7 @@ __device__ __forceinline__ uint32_t ptr_advance_long(uint32_t aux, uint32_t j)
 __global__ void __launch_bounds__(P1W_THREADS, MC_P1W_MIN_WAVES) k_skl_extract(
     const uint64_t *__restrict__ words, const uint64_t *__restrict__ offsets, uint64_t n_reads, uint64_t base_lo,
     uint64_t n_bases, uint64_t n_tiles, const uint32_t *__restrict__ first_read, int k, uint32_t np1, uint32_t *seg_counts,
-    uint64_t cap, uint4 *out_recs, SklSpill sp, uint32_t chunk_tiles, uint32_t m2)
+    uint64_t cap, uint4 *out_recs, SklSpill sp, uint32_t chunk_tiles)
 {
     __shared__ Sk1wLds L;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
@@ -273,12 +279,12 @@ __global__ void __launch_bounds__(P1W_THREADS, MC_P1W_MIN_WAVES) k_skl_extract(
                 else if (len == 64) X2 = 0;
                 else if (len < 96) X2 &= ~0ull << (2 * (96 - len));
                 const uint32_t hsel = hst[wi];
-                const uint32_t bin = sk_bin(hsel);
+                const uint32_t bin = skl_bin(hsel);
                 const uint32_t d = mulhi32(bin, np1);
                 const uint32_t rel = (uint32_t)(tile - chunk_lo) * P1L_TILE + wi;
                 uint4 r0, r1;
                 r0.x = rel;
-                r0.y = (n - 1) | ((mulhi32(bin, np1 * m2) - d * m2) << 8);
+                r0.y = (n - 1) | bin;
                 r0.z = (uint32_t)X0; r0.w = (uint32_t)(X0 >> 32);
                 r1.x = (uint32_t)X1; r1.y = (uint32_t)(X1 >> 32); r1.z = (uint32_t)X2; r1.w = (uint32_t)(X2 >> 32);
                 const uint64_t dst = atomicAdd(&L.wcur[d], 1u);
@@ -578,7 +584,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_long(const uint4 *__restrict_
 __device__ __forceinline__ uint64_t skl_region_base(const TableView &t, uint64_t X0, uint64_t X1, int k)
 {
     const uint32_t hm = sk_hmin_of_kmer2(skl_first_kmer(X0, X1, k), k);  // (every window of a record has the same minimizer)
-    return (((uint64_t)sk_bin(hm) * t.n_regions) >> 32) << MC_REGION_LG;
+    return (((uint64_t)skl_bin(hm) * t.n_regions) >> 32) << MC_REGION_LG;
 }
 
 // one record's windows through the direct path: the spill list of the scatter levels (n records at `recs`, pointerless), or the
@@ -613,6 +619,42 @@ __global__ void k_skl_add_records(const uint4 *__restrict__ recs, uint64_t n, in
         skl_add_record(t, recs[2 * i], recs[2 * i + 1], 0u, k, p_k, p_km1, solid_thr, n_new, n_cross);
     wave_add_ull(t.n_used, n_new);
     if (solid_thr) wave_add_ull(n_solid, n_cross);
+}
+
+// Distinct keys among the records of level-1 bucket 0 (count_pipeline.h k_sk_sample_distinct, for long records): the sample
+// that sizes the table of a context without a capacity hint.
+__global__ void __launch_bounds__(256) k_skl_sample_distinct(const uint4 *__restrict__ recs, const uint32_t *__restrict__ seg_counts, uint64_t seg_cap, int k,
+                                                             uint64_t *set, uint64_t mask, unsigned long long *n_distinct)
+{
+    const uint32_t n = min(seg_counts[blockIdx.x], (uint32_t)seg_cap);
+    const uint4 *seg = recs + 2 * (uint64_t)blockIdx.x * seg_cap;
+    const uint64_t p_k = pow5(k), p_km1 = pow5(k - 1);
+    unsigned long long n_new = 0;
+    for (uint32_t r = threadIdx.x; r < n; r += 256) {
+        const uint4 r0 = seg[2 * r], r1 = seg[2 * r + 1];
+        const uint32_t nw = (r0.y & 0xFFu) + 1u;
+        const uint64_t X0 = ((uint64_t)r0.w << 32) | r0.z, X1 = ((uint64_t)r1.y << 32) | r1.x, X2 = ((uint64_t)r1.w << 32) | r1.z;
+        const Kmer v = skl_first_kmer(X0, X1, k);
+        uint64_t hf = 1, hr = 1;
+        for (int i = 0; i < k; i++) {
+            hf = hf * 5 + base_at(v, k, i);
+            hr = hr * 5 + (3u ^ base_at(v, k, k - 1 - i));
+        }
+        for (uint32_t j = 0; j < nw; j++) {
+            const uint64_t key = (int64_t)hf < (int64_t)hr ? hf : hr;
+            uint64_t s = fmix64(key) & mask;
+            bool placed = key == ~0ull;
+            for (int probe = 0; probe < 64 && !placed; probe++) {
+                const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&set[s]), ~0ull, (unsigned long long)key);
+                if (old == ~0ull) { n_new++; placed = true; }
+                else if (old == key) placed = true;
+                else s = (s + 1) & mask;
+            }
+            if (!placed) n_new++;
+            if (j + 1 < nw) poly_roll(hf, hr, skl_base(X0, X1, X2, j), skl_base(X0, X1, X2, j + (uint32_t)k), p_k, p_km1);
+        }
+    }
+    wave_add_ull(n_distinct, n_new);
 }
 
 // the records of the leaves [leaf_lo, leaf_hi) that k_p3_long left unmerged (leaf_state == 0), after the table has given up

@@ -1334,8 +1334,9 @@ __global__ void __launch_bounds__(PT_THREADS, ITEMS * RW <= 3 ? 8 : 4) k_sk2_sca
             static_for<ITEMS>([&](auto J) {
                 constexpr int j = decltype(J)::value;
                 if (have[j]) {
-                    // (long records: the leaf sits in the second word above the window count, the position has the first to itself)
-                    d[j] = RW == 2 ? rec[j].y >> 8 : rec[j].x >> SKC_REL_BITS;
+                    // (long records: the bin word's top 24 bits sit in the second word above the window count -- the leaf is worked out here,
+                    // for the table as it is now --, the position has the first word to itself)
+                    d[j] = RW == 2 ? mulhi32(rec[j].y & 0xFFFFFF00u, n_buckets1 * m2) - bucket * m2 : rec[j].x >> SKC_REL_BITS;
                     if (RW == 2) rec[j].y &= 0xFFu;
                     rank[j] = atomicAdd(&L.cnt[d[j]], 1u);
                     const uint64_t pos = pos0 + (uint64_t)seg_of[j] * seg_bases + (RW == 2 ? rec[j].x : rec[j].x & ((1u << SKC_REL_BITS) - 1u));

@@ -723,7 +723,10 @@ __device__ __forceinline__ int solid_get(const SolidView &t, uint64_t key, uint3
 template <int MODE>
 __device__ __forceinline__ uint64_t solid_locate_kmer(const SolidView &t, const Kmer &v, int k, uint64_t key, TableRef &h)
 {
-    if (MODE != KEY_PACKED && t.n_shards <= 1 && t.mm_k != 0) return solid_locate(t, key, h, true, sk_hmin_of_kmer2(v, k));
+    if (MODE != KEY_PACKED && t.n_shards <= 1 && t.mm_k != 0) {
+        h = own_table(t);  // (the bin word of a hash key: its low byte cleared, count_long.h skl_bin)
+        return ((((uint64_t)(sk_bin(sk_hmin_of_kmer2(v, k)) & 0xFFFFFF00u) * t.n_regions) >> 32) << MC_REGION_LG) | sk_home(key);
+    }
     return solid_locate(t, key, h);
 }
 template <int MODE>
@@ -732,7 +735,7 @@ __device__ __forceinline__ int solid_get_kmer(const SolidView &t, const Kmer &v,
     if (MODE == KEY_PACKED || t.n_shards > 1 || t.mm_k == 0 || key == EMPTY_KEY) return solid_get(t, key, aux);
     if (aux) *aux = 0;
     TableRef h;
-    const uint64_t s0 = solid_locate(t, key, h, true, sk_hmin_of_kmer2(v, k));
+    const uint64_t s0 = solid_locate_kmer<MODE>(t, v, k, key, h);
     return solid_probe_from(h, key, s0, 0, aux);
 }
 

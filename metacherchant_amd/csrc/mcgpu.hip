@@ -1302,7 +1302,9 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
         pl->compact = compact_tiles && compact_on && staged && pl->sk && pl->b2 > 1 && pl->b2 <= (1u << (32 - SKC_REL_BITS)) && g == 0 && pieces == 1 &&
                       chunk * P1W_TILE <= (1ull << SKC_REL_BITS) && !(pl->guessed && c->virgin);
         // (long records keep the leaf in their second word: 32 bits of position)
-        if (lng) pl->compact = compact_tiles && pl->sk && pl->b2 > 1 && pl->b2 <= 1024 && g == 0 && pieces == 1 && chunk * P1L_TILE < (1ull << 32) && !pl->guessed;
+        // (... and the bin word, so the table may still be replaced between the levels: a virgin table without a hint qualifies)
+        if (lng) pl->compact = compact_tiles && pl->sk && pl->b2 > 1 && pl->b2 <= 1024 && g == 0 && pieces == 1 && chunk * P1L_TILE < (1ull << 32) &&
+                               !(pl->guessed && !c->virgin);
         pl->chunk_tiles = pl->compact ? (uint32_t)chunk : 0;
     }
     const uint64_t units = (pl->sk ? n_records : wb) / pieces + (pieces > 1 ? 1024 : 0);  // records in the streams (of one piece)
@@ -1322,7 +1324,8 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
 #define ENSURE(ptr, capvar, need) do { rc = ensure_buf(c, &(ptr), &(capvar), (need)); if (rc) return rc; } while (0)
     if (pl->sk) {
         if (!level2_only) ENSURE(P.a_recs, P.a_recs_cap, np1 * nseg1 * pl->cap1 * pieces * rw);
-        if (pl->b2 > 1) ENSURE(P.b_recs, P.b_recs_cap, n_leaves * pl->cap2 * pieces * rw);
+        // (long records into a table nothing vouches for: the second level's buffer first serves as the sample's scratch set, 64 MB)
+        if (pl->b2 > 1) ENSURE(P.b_recs, P.b_recs_cap, std::max<uint64_t>(n_leaves * pl->cap2 * pieces * rw, lng && pl->guessed ? (1ull << 22) : 0));
         if (!level2_only) ENSURE(P.spill_recs, P.spill_recs_cap, pl->spill_cap * rw);
     } else {
         { uint64_t cap = P.a_cap; ENSURE(P.a_keys, cap, np1 * nseg1 * pl->cap1); P.a_cap = cap; }
@@ -1409,8 +1412,12 @@ static int pipe_resize_by_sample(mc_ctx *c, PipePlan &pl, uint64_t n_records)
     uint64_t *set = reinterpret_cast<uint64_t *>(P.b_recs);
     HIPCHK(c, hipMemsetAsync(set, 0xFF, SET_SLOTS * 8, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_ctr + 2, 0, sizeof(unsigned long long), c->stream));
-    hipLaunchKernelGGL(k_sk_sample_distinct, dim3(pl.nseg1), dim3(256), 0, c->stream, P.a_recs, P.seg_counts1, pl.cap1, c->cfg.k, set, SET_SLOTS - 1,
-                       c->d_ctr + 2);
+    if (pl.lng)
+        hipLaunchKernelGGL(k_skl_sample_distinct, dim3(pl.nseg1), dim3(256), 0, c->stream, P.a_recs, P.seg_counts1, pl.cap1, c->cfg.k, set, SET_SLOTS - 1,
+                           c->d_ctr + 2);
+    else
+        hipLaunchKernelGGL(k_sk_sample_distinct, dim3(pl.nseg1), dim3(256), 0, c->stream, P.a_recs, P.seg_counts1, pl.cap1, c->cfg.k, set, SET_SLOTS - 1,
+                           c->d_ctr + 2);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_scratch + 24, c->d_ctr + 2, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_scratch + 25, P.flags, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -1421,6 +1428,8 @@ static int pipe_resize_by_sample(mc_ctx *c, PipePlan &pl, uint64_t n_records)
     const double est = (double)c->h_scratch[24] * (double)pl.np1 * 1.1 + 1024.0;
     if (est > 0.45 * (double)SET_SLOTS * (double)pl.np1) return MC_OK;  // (the scratch set was too full to count in: the old way)
     const uint64_t want = regions_for(c, mm_slots_for(c, est, 0.36));
+    if (pl.lng && est > 0.40 * (double)(want << c->sb)) return 4;  // (hash keys need their bins roomy, mc_create: the caller takes the per-window form)
+    if (pl.lng && want <= c->n_regions) { pl.guessed = false; return MC_OK; }  // (the table it was created with holds the batch)
     static const bool dbg = getenv("MC_INGEST_DEBUG") != nullptr;
     if (dbg) fprintf(stderr, "[count] first bucket: %llu distinct k-mers, %.0f M expected in all; table of %llu regions, %llu wanted\n",
                      (unsigned long long)c->h_scratch[24], est / 1e6, (unsigned long long)c->n_regions, (unsigned long long)want);
@@ -1434,7 +1443,7 @@ static int pipe_resize_by_sample(mc_ctx *c, PipePlan &pl, uint64_t n_records)
         c->st.grows++;
         HIPCHK(c, hipMemsetAsync(c->d_ctr + 6, 0, sizeof(unsigned long long), c->stream));  // keys at the coverage threshold: none yet
         PipePlan p2 = pl;
-        rc = pipe_prepare(c, pl.wb, &p2, n_records, pl.nseg1, 1, true);
+        rc = pipe_prepare(c, pl.wb, &p2, n_records, pl.nseg1, 1, true, 0, pl.lng);
         if (rc) return rc;
         if (p2.np1 != pl.np1 || p2.cap1 != pl.cap1 || p2.g != 0) return fail(c, MC_EINVAL, "internal: the resized table does not keep the level-1 buckets");
         pl = p2;
@@ -1864,7 +1873,8 @@ static int add_reads_long(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_
     uint32_t fatal;
     int rc = read_counters(c, &used, &fatal);
     if (rc) return rc;
-    if (fatal || !(c->cfg.capacity_hint && used < c->cfg.capacity_hint)) return 4;  // (only a table sized for what it will hold: it cannot grow)
+    // (only a table sized for what it will hold -- by a hint that still holds, or, holding nothing yet, by a sample of this batch: it cannot grow)
+    if (fatal || !((c->cfg.capacity_hint && used < c->cfg.capacity_hint) || c->virgin)) return 4;
     PipePlan pl;
     const uint64_t n_records = sk_records_bound(c, wb, nr);
     const uint64_t n_tiles_abs = (end_abs + P1L_TILE - 1) / P1L_TILE;
@@ -1882,8 +1892,11 @@ static int add_reads_long(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_
                 (unsigned long long)pl.pos0, (unsigned long long)n_records);
     const SklSpill sp{P.spill_recs, P.spill_count, pl.spill_cap, P.flags};
     hipLaunchKernelGGL(k_skl_extract, dim3(P1W_SEGMENTS), dim3(P1W_THREADS), 0, c->stream, d_words, offs, nr, base0, end_abs, n_tiles_abs, P.tile_first,
-                       c->cfg.k, pl.b1, P.seg_counts1, pl.cap1, P.a_recs, sp, pl.chunk_tiles, pl.b2);
+                       c->cfg.k, pl.b1, P.seg_counts1, pl.cap1, P.a_recs, sp, pl.chunk_tiles);
     HIPCHK(c, hipGetLastError());
+    rc = pipe_resize_by_sample(c, pl, n_records);  // (no hint: the table is sized by what the first bucket holds; 4: its bins would be too full)
+    if (rc) return rc;
+    if (pl.guessed) return 4;  // (no sample could be taken: nothing vouches for the table)
     c->st.long_runs++;
     return pipe_finish(c, pl, 0, false, 0, true, false);
 }
@@ -2291,7 +2304,7 @@ int mc_create(const mc_config *cfg, mc_ctx **out)
     c->sk_form = c->mm_k != 0;
     // polynomial keys of 33 .. 63 bases in a table sized by a capacity hint: minimizer bins too, reads counted as long records
     // (count_long.h; hash_bins() above says what such a table cannot do and what happens then).  MC_LONG_RECORDS=0: the per-window pipeline.
-    if (cfg->key_mode == MC_KEY_POLY && cfg->k >= SKL_MIN_K && cfg->k <= SKL_MAX_K && cfg->capacity_hint) {
+    if (cfg->key_mode == MC_KEY_POLY && cfg->k >= SKL_MIN_K && cfg->k <= SKL_MAX_K) {
         const char *e = getenv("MC_LONG_RECORDS");
         if (!(e && !strcmp(e, "0"))) c->mm_k = cfg->k;
     }

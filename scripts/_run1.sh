@@ -1,4 +1,5 @@
 #!/bin/bash
-# scratch: the round's profiles on the final build
-ROUND=r05 MC_COMMIT=$1 bash scripts/gpu_round_profiles.sh > gpurun_out/profiles_run.log 2>&1
-tail -30 gpurun_out/profiles_run.log
+set -o pipefail
+timeout -k 10 600 python -m pytest tests/test_gpu_long_records.py -x -q > gpurun_out/long1.log 2>&1; rc=$?; tail -15 gpurun_out/long1.log
+[ $rc -eq 0 ] || exit $rc
+timeout -k 10 300 python scripts/long_probe.py | grep "^lib"

@@ -16,9 +16,14 @@ from bench import GENOME_SEED, READ_SEED
 gen.synth_reads_dev(GENOME_SEED, 10, R // 2, READ_SEED, 0, R, L, 100, words, off)
 gen.close()
 windows = R * (L - k + 1)
-ctx = m.Context(k, m.KEY_POLY, 0, int(windows * 0.53) + (1 << 20))
+NO_HINT = os.environ.get("PROBE_NO_HINT") == "1"   # a fresh context without a capacity hint per iteration (the CLI's default)
+ctx = m.Context(k, m.KEY_POLY, 0, 0 if NO_HINT else int(windows * 0.53) + (1 << 20))
 ctx.set_coverage_hint(3)
 for it in range(3):
+    if NO_HINT and it:
+        ctx.close()
+        ctx = m.Context(k, m.KEY_POLY, 0, 0)
+        ctx.set_coverage_hint(3)
     ctx.clear()
     ctx.reset_stats()
     ctx.add_reads_packed_dev(words, off, R, n_bases)

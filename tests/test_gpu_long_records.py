@@ -116,16 +116,13 @@ def test_long_records_into_a_table_a_quarter_the_size(mc, monkeypatch):
 
 
 def test_long_records_switched_off(mc, monkeypatch):
-    """MC_LONG_RECORDS=0 (read at mc_create): the per-window pipeline, as before -- and no hint, no long records."""
+    """MC_LONG_RECORDS=0 (read at mc_create): the per-window pipeline, as before."""
     monkeypatch.delenv("MC_COUNT_PATH", raising=False)
+    monkeypatch.setenv("MC_LONG_RECORDS", "0")
     genome, reads, off = synth_case(1, 100000, 50000, 150, 50)
     t, _ = oracle_table(reads, off, 63, po.KEY_POLY)
     ok, oc = t.dump()
-    for env, hint in (("0", 3_000_000), (None, 0)):
-        if env is None:
-            monkeypatch.delenv("MC_LONG_RECORDS", raising=False)
-        else:
-            monkeypatch.setenv("MC_LONG_RECORDS", env)
+    for hint in (3_000_000, 0):
         ctx = mc.Context(63, mc.KEY_POLY, 0, hint)
         ctx.add_reads_packed(po.pack(reads), off)
         assert ctx.finalize() == t.size()
@@ -133,3 +130,36 @@ def test_long_records_switched_off(mc, monkeypatch):
         gk, gc = ctx.export(0)
         assert np.array_equal(gk, ok) and np.array_equal(gc, oc)
         ctx.close()
+
+
+@pytest.mark.parametrize("k", [63, 45])
+def test_long_records_without_a_capacity_hint(mc, monkeypatch, k):
+    """No hint (the CLI's default): the first batch into the empty table still travels as long records -- the records carry their
+    bin word, the distinct keys of the first level-1 bucket size the table between the two levels (pipe_resize_by_sample) -- and
+    the second batch, into a table that now holds keys and that nothing vouches for, moves it to hash-prefix regions and takes the
+    per-window form.  Pairs and walks as the oracle's after either."""
+    monkeypatch.delenv("MC_COUNT_PATH", raising=False)
+    monkeypatch.delenv("MC_LONG_RECORDS", raising=False)
+    n_reads = 120000
+    genome, reads, off = synth_case(2, 200000, n_reads, 150, 100)
+    cut = 70000
+    t1, _ = oracle_table(reads[:off[cut]], off[:cut + 1], k, po.KEY_POLY)
+    ctx = mc.Context(k, mc.KEY_POLY, 0, 0)
+    ctx.set_coverage_hint(2)
+    ctx.add_reads_packed(po.pack(reads[:off[cut]]), off[:cut + 1])
+    assert ctx.finalize() == t1.size()
+    st = ctx.stats()
+    assert st.long_runs == 1 and st.grows == 1, (st.long_runs, st.grows)  # (the 64 MB table it was created with was replaced once, empty)
+    ok, oc = t1.dump()
+    gk, gc = ctx.export(0)
+    assert np.array_equal(gk, ok) and np.array_equal(gc, oc)
+    _walks(ctx, t1, k, genome, 2)
+    t, _ = oracle_table(reads, off, k, po.KEY_POLY)
+    ctx.add_reads_packed(po.pack(reads[off[cut]:]), off[cut:] - off[cut])
+    assert ctx.finalize() == t.size()
+    assert ctx.stats().long_runs == 1
+    ok, oc = t.dump()
+    gk, gc = ctx.export(0)
+    assert np.array_equal(gk, ok) and np.array_equal(gc, oc)
+    _walks(ctx, t, k, genome, 2)
+    ctx.close()
