@@ -138,8 +138,9 @@ int mc_finalize_counts(mc_ctx *ctx, uint64_t *n_distinct);
 /* BigLong2ShortHashMap.get (itmo!/structures/map/BigLong2ShortHashMap.java:74-77 ->
  * Long2ShortHashMap.java:160-175): out[i] = count saturated at 32767
  * (itmo!/utils/NumUtils.java:21-26), or -1 when the key is absent.  Key 0 is legal.
- * A context with polynomial-hash keys of 33 .. 63 bases and a capacity_hint keeps its table in minimizer bins of the
- * k-mers' BASES while reads are counted (csrc/count_long.h), where a bare key cannot be found: the first look-up by key --
+ * A context with polynomial-hash keys of 33 .. 63 bases keeps its table in minimizer bins of the k-mers' BASES while reads
+ * are counted into a table whose size something vouches for -- a capacity_hint that still holds, or, for the first batch into
+ * an empty table, a sample of that batch -- (csrc/count_long.h), where a bare key cannot be found: the first look-up by key --
  * like the first key stream (mc_add_keys_dev, mc_add_pairs_dev), mc_shard_export or any batch that takes the direct kernel --
  * moves every key to hash-prefix regions first, once and for good (a rebuild of the table: mc_stats.grows counts it), and
  * reads counted after that take the per-window pipeline.  Results are the same either way. */

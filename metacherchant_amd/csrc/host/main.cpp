@@ -212,7 +212,7 @@ void usage()
     puts("                -t/--tool <name>, -p/--available-processors <n> and -m/--memory <arg> (accepted, unused),");
     puts("                --device <n> (GPU ordinal), --devices <a,b,...|a-b> (several GPUs as one table: reads dealt to them,");
     puts("                k-mers exchanged by owner over xGMI, BFS on the first), --capacity-hint <distinct k-mers>");
-    puts("                (sizes the table once; with -k 33..63 it also lets the reads be counted as super-k-mer records: twice as fast)");
+    puts("                (sizes the table once; with -k 33..63 every batch then travels as super-k-mer records, not only the first)");
 }
 
 #define MC_CHECK(ctx, call)                                                       \

@@ -992,6 +992,13 @@ static inline int by_key_ready(mc_ctx *c) { return hash_bins(c) ? to_hash_region
 
 static int table_grow(mc_ctx *c, uint64_t new_regions)
 {
+    if (hash_bins(c) && c->virgin) {  // nothing to move: another empty table, still in minimizer bins
+        table_release(c, c->slots, c->slots_bytes);
+        c->slots = nullptr;
+        int rc = table_alloc(c, new_regions);
+        if (!rc) c->st.grows++;
+        return rc;
+    }
     if (hash_bins(c)) {
         int rc = to_hash_regions(c);
         if (rc) return rc;

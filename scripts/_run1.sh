@@ -1,5 +1,4 @@
 #!/bin/bash
 set -o pipefail
-timeout -k 10 600 python -m pytest tests/test_gpu_long_records.py -x -q > gpurun_out/long1.log 2>&1; rc=$?; tail -15 gpurun_out/long1.log
-[ $rc -eq 0 ] || exit $rc
-timeout -k 10 300 python scripts/long_probe.py | grep "^lib"
+MC_INGEST_DEBUG=1 PROBE_NO_HINT=1 timeout -k 10 300 python scripts/long_probe.py 2>&1 | grep "^lib\|count\]" | head -12
+timeout -k 10 600 python -m pytest tests/test_gpu_long_records.py -x -q 2>&1 | tail -3

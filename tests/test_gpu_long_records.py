@@ -1,5 +1,5 @@
 """The long-record form of the counting pipeline (csrc/count_long.h): polynomial-hash keys of 33 .. 63 bases, a table sized by
-a capacity hint, regions = minimizer bins of the k-mers' BASES.  Same (key, count) pairs and the same walks as the CPU oracle
+a capacity hint (or an empty table, sized by a sample of the batch), regions = minimizer bins of the k-mers' BASES.  Same (key, count) pairs and the same walks as the CPU oracle
 (oracle/pyoracle.py follows src/utils/PolynomialHash.java:19-28, src/io/IOUtils.java:207-208 and
 src/algo/OneSequenceCalculator.java) -- and as the per-window form, which MC_LONG_RECORDS=0 keeps.  Needs a real MI355X."""
 import numpy as np
