@@ -1,4 +1,6 @@
 #!/bin/bash
-set -o pipefail
-MC_INGEST_DEBUG=1 PROBE_NO_HINT=1 timeout -k 10 300 python scripts/long_probe.py 2>&1 | grep "^lib\|count\]" | head -12
-timeout -k 10 600 python -m pytest tests/test_gpu_long_records.py -x -q 2>&1 | tail -3
+# scratch: the round's profiles on the final build, then the whole GPU suite
+ROUND=r05 MC_COMMIT=$1 bash scripts/gpu_round_profiles.sh > gpurun_out/profiles_run.log 2>&1
+ls gpurun_out/p | head -40
+timeout -k 10 1500 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_all.log 2>&1; rc=$?; tail -4 gpurun_out/gpu_all.log
+exit $rc
