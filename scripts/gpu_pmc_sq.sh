@@ -27,7 +27,7 @@ for f in sorted(glob.glob("gpurun_out/sq_%s_*/*/*counter_collection.csv" % tag))
         acc[name][r["Counter_Name"]] += float(r["Counter_Value"])
 with open("gpurun_out/sq_%s_summary.csv" % tag, "w") as out:
     for k, d in acc.items():
-        if not any(x in k for x in ("k_p3", "k_p1", "k_p2", "k_sk1", "k_sk2", "k_solid", "k_bfs")): continue
+        if not any(x in k for x in ("k_p3", "k_p1", "k_p2", "k_sk1", "k_sk2", "k_skl", "k_solid", "k_bfs")): continue
         line = k + "," + ",".join("%s=%.4g" % kv for kv in d.items())
         out.write(line + "\n"); print(line)
 PY
