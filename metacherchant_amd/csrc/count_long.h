@@ -476,43 +476,42 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_long(const uint4 *__restrict_
                 }
                 uint64_t hf = 0, hr = 0;
                 if (cnt) poly_start(X0, X1, X2, k, L.polyF, L.polyR, &hf, &hr);
+                // the pointer of the chunk's first window, once; window j of the chunk is j bases on where pointers name places, and
+                // within the slack of the granule where they name granules (kmer_device.h ptr_advance: the same rule)
+                const uint32_t pbase = ptr_advance_long(p0, j0);
+                const uint32_t pstep = pbase != 0 && (uint64_t)pbase - 1 + SKL_MAX_WINDOWS < PTR_EXACT_END ? 0xFFFFFFFFu : 0u;
 #pragma unroll 1
                 for (uint32_t j = 0; j < SKL_CHUNK; j++) {
                     const bool act = j < cnt;
                     if (!__ballot(act)) break;
-                    if (act) {
-                        const uint64_t key = (int64_t)hf < (int64_t)hr ? hf : hr;  // (Math.min on signed longs)
-                        const bool odd_key = key == EMPTY_KEY;  // (the key that looks like a free slot: counted apart)
-                        const uint32_t home = sk_home(key);
-                        // the home slot's compare-and-swap goes out, the hashes move on to the next window while it travels (nine
-                        // keys in ten settle there; the merge kernel's time was the sum of its waits and its arithmetic before)
-                        unsigned long long old0 = EMPTY_KEY;
-                        if (!odd_key) old0 = atomicCAS(reinterpret_cast<unsigned long long *>(&L.key[home]), (unsigned long long)EMPTY_KEY, (unsigned long long)key);
-                        poly_roll(hf, hr, (uint32_t)(outs >> 62), (uint32_t)(ins >> 62), p_k, p_km1);  // (one step past the last window does no harm)
-                        outs <<= 2;
-                        ins <<= 2;
-                        if (odd_key) {
-                            my_empty += cp;
-                        } else {
-                            uint32_t s = home;
-                            bool fits = true;
-                            if (old0 != EMPTY_KEY && old0 != key) {  // on from the slot behind, TABLE_MAX_PROBES slots in all (where look-ups look)
-                                uint32_t unused = 0;
-                                unsigned long long pending;
-                                s = lds_probe_claim(key_base, (home + 1u) & (REGION_SLOTS - 1u), key, &unused, &pending, P3_MAX_PROBES - 1u);
-                                fits = !((pending >> (tid & 63u)) & 1ull);
-                            }
-                            if (!fits) {
-                                if (!ovf_push(t, key, cp, ptr_advance_long(p0, j0 + j), leaf)) atomicExch(&L.overflow, 1u);
-                            } else {
-                                const uint32_t seen = atomicAdd(&L.cnt[s], cp);
-                                // (the occurrence that leaves its pointer, kmer_device.h ptr_pick, is one of these cp)
-                                if (p0 && seen <= ptr_from + 3u && seen + cp > ptr_from) {
-                                    const uint32_t pk = ptr_pick(key, ptr_from, solid_thr);
-                                    if (seen <= pk && pk < seen + cp) L.aux[s] = ptr_advance_long(p0, j0 + j);
-                                }
-                            }
-                        }
+                    const uint64_t key = (int64_t)hf < (int64_t)hr ? hf : hr;  // (Math.min on signed longs)
+                    const bool odd_key = key == EMPTY_KEY;  // (the key that looks like a free slot: counted apart)
+                    const bool ins_it = act && !odd_key;
+                    const uint32_t home = sk_home(key);
+                    // which of the key's occurrences leaves its pointer (kmer_device.h ptr_pick): worked out for every lane, so that what
+                    // follows the count's addition is one comparison and one masked store (as nested branches the rule was a quarter
+                    // of the loop's instructions, most of them the compiler's bookkeeping of who is in and who is out)
+                    const uint32_t pk = ptr_pick(key, ptr_from, solid_thr);
+                    unsigned long long old0 = EMPTY_KEY;
+                    if (ins_it) old0 = atomicCAS(reinterpret_cast<unsigned long long *>(&L.key[home]), (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+                    poly_roll(hf, hr, (uint32_t)(outs >> 62), (uint32_t)(ins >> 62), p_k, p_km1);  // (one step past the last window does no harm)
+                    outs <<= 2;
+                    ins <<= 2;
+                    my_empty += act && odd_key ? cp : 0u;
+                    uint32_t s = home;
+                    bool fits = ins_it;
+                    if (ins_it && old0 != EMPTY_KEY && old0 != key) {  // on from the slot behind, TABLE_MAX_PROBES slots in all (where look-ups look)
+                        uint32_t unused = 0;
+                        unsigned long long pending;
+                        s = lds_probe_claim(key_base, (home + 1u) & (REGION_SLOTS - 1u), key, &unused, &pending, P3_MAX_PROBES - 1u);
+                        fits = !((pending >> (tid & 63u)) & 1ull);
+                    }
+                    const uint32_t ptr = pbase + (j & pstep);
+                    if (fits) {
+                        const uint32_t seen = atomicAdd(&L.cnt[s], cp);
+                        if (pbase != 0 && seen <= pk && pk < seen + cp) L.aux[s] = ptr;  // (the occurrence that leaves its pointer is one of these cp)
+                    } else if (ins_it) {
+                        if (!ovf_push(t, key, cp, ptr, leaf)) atomicExch(&L.overflow, 1u);
                     }
                 }
             }
