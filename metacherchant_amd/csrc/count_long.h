@@ -31,6 +31,21 @@ static_assert((SKL_MAX_K - SK_M) / 8 + 1 <= 64 - (int)P1L_LANES, "k_skl_extract:
 // the bin word of a hash key's minimizer: sk_bin with its low byte cleared (see the record's second word)
 __host__ __device__ __forceinline__ uint32_t skl_bin(uint32_t hmin) { return sk_bin(hmin) & 0xFFFFFF00u; }
 
+// TWO SMALLEST (TableView::mm_k < 0, mcgpu.hip mc_create): the word that picks a key's bin is made of the two smallest sk_order
+// values among the window's canonical SK_M-mers (as a multiset: a value that occurs twice is both) instead of the smallest alone.
+// Runs of windows that share it are two thirds as long, and a region holds the k-mers of half again as many, smaller stretches of
+// the genome: scripts/bin_model.py -- at load 0.53 the fullest of 4 200 regions is 87 % full (116 % with the smallest alone, 1.6 % of
+// the regions above 90 %), which is what lets configs[2] at FULL size (4.6 G keys in the 2^21 regions the merge kernel takes) travel
+// as long records at all.  Either strand of a k-mer holds the same multiset, so the word is a function of the key.
+__host__ __device__ __forceinline__ uint32_t skl_word2(uint32_t lo, uint32_t hi) { return lo ^ (hi * 0x85EBCA6Bu); }
+// (lo, hi) <- the two smallest of (lo, hi) and (blo, bhi)
+__device__ __forceinline__ void skl_merge2(uint32_t &lo, uint32_t &hi, uint32_t blo, uint32_t bhi)
+{
+    const uint32_t t = max(lo, blo);
+    lo = min(lo, blo);
+    hi = min(t, min(hi, bhi));
+}
+
 struct SklSpill {
     uint4 *recs;  // two per record
     unsigned long long *count;
@@ -88,19 +103,28 @@ __device__ __forceinline__ uint32_t ptr_advance_long(uint32_t aux, uint32_t j)
 //     so 57 lanes of a tile own windows and the tile is 456 positions;
 //   * "no read starts inside the window" looks 63 positions ahead: the doubling shifts run on 128 bits;
 //   * a run is cut every 32 windows and its record holds up to 96 bases in three words.
+struct alignas(16) Sk1lLds {  // Sk1wLds (count_pipeline.h) + a second staging array for the second-smallest hashes
+    uint32_t wcur[PT_MAX_BUCKETS1_SK];
+    uint32_t starts[P1W_WAVES][24];
+    uint32_t brk[P1W_WAVES][20];
+    uint64_t wst[P1W_WAVES][24];
+    uint32_t hst[P1W_WAVES][64 * PT_ITEMS];
+    uint16_t squeue[P1W_WAVES][64 * PT_ITEMS];
+    uint32_t hst2[P1W_WAVES][64 * PT_ITEMS];
+};
 __global__ void __launch_bounds__(P1W_THREADS, MC_P1W_MIN_WAVES) k_skl_extract(
     const uint64_t *__restrict__ words, const uint64_t *__restrict__ offsets, uint64_t n_reads, uint64_t base_lo,
     uint64_t n_bases, uint64_t n_tiles, const uint32_t *__restrict__ first_read, int k, uint32_t np1, uint32_t *seg_counts,
-    uint64_t cap, uint4 *out_recs, SklSpill sp, uint32_t chunk_tiles)
-{
-    __shared__ Sk1wLds L;
+    uint64_t cap, uint4 *out_recs, SklSpill sp, uint32_t chunk_tiles, uint32_t two)
+{   // two: the bin word from the two smallest hashes of a window (skl_word2)
+    __shared__ Sk1lLds L;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     for (uint32_t i = tid; i < PT_MAX_BUCKETS1_SK; i += P1W_THREADS) L.wcur[i] = 0;
     uint32_t *starts = L.starts[wv];
     uint32_t *brkw = L.brk[wv];
     uint8_t *brkb = reinterpret_cast<uint8_t *>(brkw);
     uint64_t *wst = L.wst[wv];
-    uint32_t *hst = L.hst[wv];
+    uint32_t *hst = L.hst[wv], *hst2 = L.hst2[wv];
     uint16_t *squeue = L.squeue[wv];
     if (lane < 24) wst[lane] = 0;
     if (lane < 20) brkw[lane] = lane == 0 ? 0u : 0xFFFFFFFFu;  // (bytes 2 .. 65 are rewritten by every tile)
@@ -176,27 +200,59 @@ __global__ void __launch_bounds__(P1W_THREADS, MC_P1W_MIN_WAVES) k_skl_extract(
                 r = (r >> 2) | ((3u - nb) << (2 * (SK_M - 1)));
                 hh[i] = sk_order(f < r ? f : r);
             }
-            uint32_t pre[PT_ITEMS];
-            pre[0] = hh[0];
+            if (!two) {
+                uint32_t pre[PT_ITEMS];
+                pre[0] = hh[0];
 #pragma unroll
-            for (int i = 1; i < 8; i++) pre[i] = min(pre[i - 1], hh[i]);
-            suf[7] = hh[7];
+                for (int i = 1; i < 8; i++) pre[i] = min(pre[i - 1], hh[i]);
+                suf[7] = hh[7];
 #pragma unroll
-            for (int j = 6; j >= 0; j--) suf[j] = min(suf[j + 1], hh[j]);
-            *reinterpret_cast<uint4 *>(&hst[lane * PT_ITEMS]) = make_uint4(pre[0], pre[1], pre[2], pre[3]);
-            *reinterpret_cast<uint4 *>(&hst[lane * PT_ITEMS + 4]) = make_uint4(pre[4], pre[5], pre[6], pre[7]);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t m8 = pre[7];
-            uint32_t M = SK_NONE;  // the whole blocks strictly between mine and the one the windows end in
-            for (uint32_t d = 1; d < qd; d++) M = min(M, (uint32_t)__shfl_down((int)m8, d));
-            const uint32_t m8A = (uint32_t)__shfl_down((int)m8, qd);
-            const uint32_t at = (lane + qd) * PT_ITEMS + rd;
+                for (int j = 6; j >= 0; j--) suf[j] = min(suf[j + 1], hh[j]);
+                *reinterpret_cast<uint4 *>(&hst[lane * PT_ITEMS]) = make_uint4(pre[0], pre[1], pre[2], pre[3]);
+                *reinterpret_cast<uint4 *>(&hst[lane * PT_ITEMS + 4]) = make_uint4(pre[4], pre[5], pre[6], pre[7]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t m8 = pre[7];
+                uint32_t M = SK_NONE;  // the whole blocks strictly between mine and the one the windows end in
+                for (uint32_t d = 1; d < qd; d++) M = min(M, (uint32_t)__shfl_down((int)m8, d));
+                const uint32_t m8A = (uint32_t)__shfl_down((int)m8, qd);
+                const uint32_t at = (lane + qd) * PT_ITEMS + rd;
 #pragma unroll
-            for (int j = 0; j < PT_ITEMS; j++) {
-                uint32_t x = hst[min(at + (uint32_t)j, 64u * PT_ITEMS - 1u)];  // (the lanes that own no window read whatever is there)
-                if (rd + (uint32_t)j >= 8u) x = min(x, m8A);
-                hmin[j] = min(min(suf[j], M), x);
+                for (int j = 0; j < PT_ITEMS; j++) {
+                    uint32_t x = hst[min(at + (uint32_t)j, 64u * PT_ITEMS - 1u)];  // (the lanes that own no window read whatever is there)
+                    if (rd + (uint32_t)j >= 8u) x = min(x, m8A);
+                    hmin[j] = min(min(suf[j], M), x);
+                }
+            } else {
+                // the same with PAIRS: the two smallest of every prefix and suffix of my 8 hashes, of the whole blocks, of the end block
+                uint32_t plo[PT_ITEMS], phi[PT_ITEMS], suh[PT_ITEMS];
+                plo[0] = hh[0]; phi[0] = SK_NONE;
+#pragma unroll
+                for (int i = 1; i < 8; i++) { plo[i] = plo[i - 1]; phi[i] = phi[i - 1]; skl_merge2(plo[i], phi[i], hh[i], SK_NONE); }
+                suf[7] = hh[7]; suh[7] = SK_NONE;
+#pragma unroll
+                for (int j = 6; j >= 0; j--) { suf[j] = suf[j + 1]; suh[j] = suh[j + 1]; skl_merge2(suf[j], suh[j], hh[j], SK_NONE); }
+                *reinterpret_cast<uint4 *>(&hst[lane * PT_ITEMS]) = make_uint4(plo[0], plo[1], plo[2], plo[3]);
+                *reinterpret_cast<uint4 *>(&hst[lane * PT_ITEMS + 4]) = make_uint4(plo[4], plo[5], plo[6], plo[7]);
+                *reinterpret_cast<uint4 *>(&hst2[lane * PT_ITEMS]) = make_uint4(phi[0], phi[1], phi[2], phi[3]);
+                *reinterpret_cast<uint4 *>(&hst2[lane * PT_ITEMS + 4]) = make_uint4(phi[4], phi[5], phi[6], phi[7]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t tl = plo[7], th = phi[7];
+                uint32_t Ml = SK_NONE, Mh = SK_NONE;
+                for (uint32_t d = 1; d < qd; d++) skl_merge2(Ml, Mh, (uint32_t)__shfl_down((int)tl, d), (uint32_t)__shfl_down((int)th, d));
+                const uint32_t Al = (uint32_t)__shfl_down((int)tl, qd), Ah = (uint32_t)__shfl_down((int)th, qd);
+                const uint32_t at = (lane + qd) * PT_ITEMS + rd;
+#pragma unroll
+                for (int j = 0; j < PT_ITEMS; j++) {
+                    const uint32_t idx = min(at + (uint32_t)j, 64u * PT_ITEMS - 1u);
+                    uint32_t xl = hst[idx], xh = hst2[idx];
+                    if (rd + (uint32_t)j >= 8u) skl_merge2(xl, xh, Al, Ah);
+                    uint32_t rl = suf[j], rh = suh[j];
+                    skl_merge2(rl, rh, Ml, Mh);
+                    skl_merge2(rl, rh, xl, xh);
+                    hmin[j] = skl_word2(rl, rh);
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();  // (the staging area now takes the windows' minimizers)
@@ -582,7 +638,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_long(const uint4 *__restrict_
 // home slot of window keys of a record in the table `t`: the record's minimizer bin while the table has minimizer bins
 __device__ __forceinline__ uint64_t skl_region_base(const TableView &t, uint64_t X0, uint64_t X1, int k)
 {
-    const uint32_t hm = sk_hmin_of_kmer2(skl_first_kmer(X0, X1, k), k);  // (every window of a record has the same minimizer)
+    const uint32_t hm = sk_hmin_of_kmer2(skl_first_kmer(X0, X1, k), k, t.mm_k < 0);  // (every window of a record has the same bin word)
     return (((uint64_t)skl_bin(hm) * t.n_regions) >> 32) << MC_REGION_LG;
 }
 

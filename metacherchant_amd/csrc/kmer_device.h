@@ -412,19 +412,21 @@ __host__ __device__ inline uint32_t sk_hmin_of_kmer(uint64_t fw, int k)
 
 // ... of a k-mer of up to 64 bases (hi:lo, right-aligned).  Hash keys say nothing about their bases: where such keys live in
 // minimizer bins (k > 32 with polynomial keys, count_pipeline.h "long records") every look-up brings the k-mer itself.
-__host__ __device__ inline uint32_t sk_hmin_of_kmer2(const Kmer &v, int k)
-{
-    uint32_t f = 0, r = 0, best = SK_NONE;
+__host__ __device__ inline uint32_t sk_hmin_of_kmer2(const Kmer &v, int k, bool two = false)
+{   // two: the word made of the TWO smallest values, as a multiset (count_long.h skl_word2) -- tables with mm_k < 0
+    uint32_t f = 0, r = 0, best = SK_NONE, second = SK_NONE;
     for (int i = 0; i < k; i++) {
         const uint32_t b = base_at(v, k, i);
         f = ((f << 2) | b) & SK_MMASK;
         r = (r >> 2) | ((3u - b) << (2 * (SK_M - 1)));
         if (i >= SK_M - 1) {
             const uint32_t h = sk_order(f < r ? f : r);
+            const uint32_t t = h > best ? h : best;
             best = h < best ? h : best;
+            second = t < second ? t : second;
         }
     }
-    return best;
+    return two ? best ^ (second * 0x85EBCA6Bu) : best;
 }
 
 struct TableView {
@@ -725,7 +727,7 @@ __device__ __forceinline__ uint64_t solid_locate_kmer(const SolidView &t, const 
 {
     if (MODE != KEY_PACKED && t.n_shards <= 1 && t.mm_k != 0) {
         h = own_table(t);  // (the bin word of a hash key: its low byte cleared, count_long.h skl_bin)
-        return ((((uint64_t)(sk_bin(sk_hmin_of_kmer2(v, k)) & 0xFFFFFF00u) * t.n_regions) >> 32) << MC_REGION_LG) | sk_home(key);
+        return ((((uint64_t)(sk_bin(sk_hmin_of_kmer2(v, k, t.mm_k < 0)) & 0xFFFFFF00u) * t.n_regions) >> 32) << MC_REGION_LG) | sk_home(key);
     }
     return solid_locate(t, key, h);
 }

@@ -1315,10 +1315,12 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
         pl->chunk_tiles = pl->compact ? (uint32_t)chunk : 0;
     }
     const uint64_t units = (pl->sk ? n_records : wb) / pieces + (pieces > 1 ? 1024 : 0);  // records in the streams (of one piece)
-    pl->cap1 = (uint64_t)((double)units / (double)pl->np1 / (double)nseg1 * 1.25) + (pl->sk ? 64 : 256);  // per segment
+    // (long records into 2^20 leaves and more -- configs[2] at full size, where the table leaves the streams 130 GB --: tighter streams)
+    const bool tight = lng && n_leaves >= (1ull << 20);
+    pl->cap1 = (uint64_t)((double)units / (double)pl->np1 / (double)nseg1 * (tight ? 1.12 : 1.25)) + (pl->sk ? 64 : 256);  // per segment
     const double mean_leaf = (double)units / (double)pl->n_leaves;
     // (records of one locus come in clumps -- one per read covering it -- so leaves vary more than Poisson)
-    double sig2 = pl->sk ? 32.0 : 8.0;
+    double sig2 = pl->sk ? (tight ? 12.0 : 32.0) : 8.0;
     if (const char *e = getenv("MC_CAP2_SIGMAS")) { const double v = atof(e); if (v >= 1.0 && v <= 64.0) sig2 = v; }  // (tuning runs: how far apart the leaves' streams lie)
     pl->cap2 = (uint64_t)(mean_leaf * 1.15 + sig2 * std::sqrt(mean_leaf) + 64.0);  // (a spilled record also costs the solid list, P3Emit)
     if (const char *e = getenv("MC_CAP2")) { const long v = atol(e); if (v >= 64) pl->cap2 = (uint64_t)v; }  // (tuning runs)
@@ -1883,7 +1885,8 @@ static int add_reads_long(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_
     // (only a table sized for what it will hold -- by a hint that still holds, or, holding nothing yet, by a sample of this batch: it cannot grow)
     if (fatal || !((c->cfg.capacity_hint && used < c->cfg.capacity_hint) || c->virgin)) return 4;
     PipePlan pl;
-    const uint64_t n_records = sk_records_bound(c, wb, nr);
+    // (bin words of the two smallest hashes: runs two thirds as long -- 10.6 windows a record for 15.9 on configs[2]'s reads)
+    const uint64_t n_records = c->mm_k < 0 ? sk_records_bound(c, wb, nr) * 8 / 5 : sk_records_bound(c, wb, nr);
     const uint64_t n_tiles_abs = (end_abs + P1L_TILE - 1) / P1L_TILE;
     rc = pipe_prepare(c, wb, &pl, n_records, (uint32_t)P1W_SEGMENTS, 1, false, n_tiles_abs - base0 / P1L_TILE, true);
     if (rc) return rc;
@@ -1899,7 +1902,7 @@ static int add_reads_long(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_
                 (unsigned long long)pl.pos0, (unsigned long long)n_records);
     const SklSpill sp{P.spill_recs, P.spill_count, pl.spill_cap, P.flags};
     hipLaunchKernelGGL(k_skl_extract, dim3(P1W_SEGMENTS), dim3(P1W_THREADS), 0, c->stream, d_words, offs, nr, base0, end_abs, n_tiles_abs, P.tile_first,
-                       c->cfg.k, pl.b1, P.seg_counts1, pl.cap1, P.a_recs, sp, pl.chunk_tiles);
+                       c->cfg.k, pl.b1, P.seg_counts1, pl.cap1, P.a_recs, sp, pl.chunk_tiles, c->mm_k < 0 ? 1u : 0u);
     HIPCHK(c, hipGetLastError());
     rc = pipe_resize_by_sample(c, pl, n_records);  // (no hint: the table is sized by what the first bucket holds; 4: its bins would be too full)
     if (rc) return rc;
@@ -2329,11 +2332,17 @@ int mc_create(const mc_config *cfg, mc_ctx **out)
         if (const char *e = getenv("MC_TABLE_LOAD")) { const double v = atof(e); if (v > 0.05 && v < 0.95) load = v; }  // (tuning runs)
         want_slots = std::max<uint64_t>(want_slots, (uint64_t)((double)cfg->capacity_hint / load));
         if (c->mm_k) want_slots = std::max<uint64_t>(1ull << 22, mm_slots_for(c, (double)cfg->capacity_hint, load));
-        if (hash_bins(c) && (double)cfg->capacity_hint > 0.40 * (double)want_slots) {
-            // Long records need their bins roomy: at k = 63 a region holds the k-mers of four or five loci (each with the error
-            // variants of the ~30 reads that cover it), and 2^21 regions -- one a leaf, all the merge kernel takes -- at load 0.53
-            // (configs[2] at full size: 4.6 G keys, 137 GB) leave a few per cent of them overfull, more than the hand-on list
-            // holds; such a table cannot be rebuilt either.  Those contexts keep the per-window pipeline.
+        // Long records need their bins roomy: at k = 63 a region holds the k-mers of four or five loci (each with the error variants
+        // of the ~30 reads that cover it), and 2^21 regions -- one a leaf, all the merge kernel takes -- at load 0.53 (configs[2] at
+        // full size: 4.6 G keys, 137 GB) leave a few per cent of them overfull, more than the hand-on list holds; such a table cannot
+        // be rebuilt either.  A table that cannot be roomy takes its bin words from the TWO smallest hashes of a window (count_long.h
+        // skl_word2: mm_k < 0 -- half again as many, smaller loci a region: even enough up to load ~0.55, scripts/bin_model.py);
+        // beyond that, and with MC_LONG_BINS=1 (tuning runs; 2: two smallest for every table), the per-window pipeline.
+        const bool crowded = hash_bins(c) && (double)cfg->capacity_hint > 0.40 * (double)want_slots;
+        const char *be = getenv("MC_LONG_BINS");
+        const bool two = hash_bins(c) && (be ? !strcmp(be, "2") : crowded);
+        if (two && (double)cfg->capacity_hint <= 0.56 * (double)want_slots) c->mm_k = -cfg->k;
+        else if (crowded) {
             c->mm_k = 0;
             want_slots = std::max<uint64_t>(1ull << 22, (uint64_t)((double)cfg->capacity_hint / 0.7));
             if (const char *e = getenv("MC_TABLE_LOAD")) { const double v = atof(e); if (v > 0.05 && v < 0.95) want_slots = std::max<uint64_t>(1ull << 22, (uint64_t)((double)cfg->capacity_hint / v)); }

@@ -25,13 +25,24 @@ def _walks(ctx, t, k, genome, cov):
         assert_bfs_equal(ctx.bfs(hi, lo, d, cov, mk, mr), po.bfs(t, k, po.KEY_POLY, [seed], d, cov, mk, mr))
 
 
+def _bins(monkeypatch, bins):
+    """MC_LONG_BINS=2 (read at mc_create): the bin word of a window from its TWO smallest minimizer hashes (count_long.h skl_word2) --
+    what a context picks by itself when its table cannot be roomy (configs[2] at full size); the tests force it at any load."""
+    if bins is None:
+        monkeypatch.delenv("MC_LONG_BINS", raising=False)
+    else:
+        monkeypatch.setenv("MC_LONG_BINS", bins)
+
+
+@pytest.mark.parametrize("bins", [None, "2"])
 @pytest.mark.parametrize("k", [63, 33, 40, 41, 47, 48, 55, 62])
-def test_long_records_count_and_walk(mc, monkeypatch, k):
+def test_long_records_count_and_walk(mc, monkeypatch, k, bins):
     """Two batches (the second one into a table that holds keys already, starting in the middle of a tile of the read store):
     every (key, count) pair of the oracle, the walks of the oracle straight on the minimizer-bin table (look-ups by the k-mers'
     bases), then a look-up BY KEY of everything -- which moves the table to hash-prefix regions -- and the walks again."""
     monkeypatch.setenv("MC_COUNT_PATH", "partition")  # (a batch of under 2^22 windows takes the direct kernel otherwise: by key)
     monkeypatch.delenv("MC_LONG_RECORDS", raising=False)
+    _bins(monkeypatch, bins)
     n_reads = 80000 if k > 50 else 50000
     genome, reads, off = synth_case(2, 200000, n_reads, 150, 50)
     t, _ = oracle_table(reads, off, k, po.KEY_POLY)
@@ -65,12 +76,14 @@ def test_long_records_count_and_walk(mc, monkeypatch, k):
     ctx.close()
 
 
+@pytest.mark.parametrize("bins", [None, "2"])
 @pytest.mark.parametrize("k", [33, 63, 50])
-def test_long_records_of_ragged_reads(mc, monkeypatch, k):
+def test_long_records_of_ragged_reads(mc, monkeypatch, k, bins):
     """Empty reads, reads of k - 1, k and k + 1 bases, reads of every length up to 220: windows never span two reads (the
     128-bit read-start mask of k_skl_extract), runs are cut at 32 windows, tiles end inside reads."""
     monkeypatch.setenv("MC_COUNT_PATH", "partition")
     monkeypatch.delenv("MC_LONG_RECORDS", raising=False)
+    _bins(monkeypatch, bins)
     rng = np.random.default_rng(100 + k)
     genome, reads, off = ragged_case(rng, 6000, 220, 20000)
     # a few reads of exactly k - 1, k, k + 1 bases, and a long error-free one (runs of more than 32 windows)
