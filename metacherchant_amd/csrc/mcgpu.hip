@@ -724,6 +724,58 @@ __global__ void k_get(const int64_t *__restrict__ keys, uint64_t n, int16_t *__r
         out[i] = (int16_t)table_get(t, (uint64_t)keys[i]);
 }
 
+// ... for a table of hash keys in minimizer bins (count_long.h), where a bare key does not say which region it lives in: the
+// QUERIES go into a small set (qk: key, ~0 = free; qi: the first query that asked for it), the whole table is swept once and
+// every slot whose key is in the set answers, queries that repeat a key copy the answer.  A sweep per call -- 20 GB in 5 ms --
+// instead of a rebuild of the table that would end the long-record form for good (and cannot be afforded where the table is
+// half the device's memory).
+__global__ void k_getq_build(const int64_t *__restrict__ keys, uint64_t n, unsigned long long *qk, uint32_t *qi, uint64_t mask)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t key = (uint64_t)keys[i];
+        if (key == EMPTY_KEY) continue;
+        for (uint64_t s = fmix64(key) & mask;; s = (s + 1) & mask) {
+            const unsigned long long old = atomicCAS(&qk[s], ~0ull, (unsigned long long)key);
+            if (old == ~0ull) { qi[s] = (uint32_t)i; break; }
+            if (old == key) break;
+        }
+    }
+}
+__global__ void k_getq_sweep(const Slot *__restrict__ slots, uint64_t n_slots, const unsigned long long *__restrict__ qk, const uint32_t *__restrict__ qi,
+                             uint64_t mask, int16_t *__restrict__ out)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += stride) {
+        const uint4 raw = *reinterpret_cast<const uint4 *>(slots + i);
+        const uint64_t key = ((uint64_t)raw.y << 32) | raw.x;
+        if (key == EMPTY_KEY) continue;
+        for (uint64_t s = fmix64(key) & mask;; s = (s + 1) & mask) {
+            const unsigned long long q = qk[s];
+            if (q == ~0ull) break;
+            if (q == key) { out[qi[s]] = (int16_t)(raw.z > 32767u ? 32767u : raw.z); break; }
+        }
+    }
+}
+__global__ void k_getq_finish(const int64_t *__restrict__ keys, uint64_t n, const unsigned long long *__restrict__ qk, const uint32_t *__restrict__ qi,
+                              uint64_t mask, int16_t *__restrict__ out, const unsigned long long *__restrict__ empty_cnt)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t key = (uint64_t)keys[i];
+        if (key == EMPTY_KEY) {
+            const unsigned long long c = *empty_cnt;
+            out[i] = (int16_t)(c == 0 ? -1 : (c > 32767ull ? 32767 : (int)c));
+            continue;
+        }
+        for (uint64_t s = fmix64(key) & mask;; s = (s + 1) & mask)
+            if (qk[s] == key) {
+                if (qi[s] != (uint32_t)i) out[i] = out[qi[s]];  // (the first query for this key got the answer)
+                break;
+            }
+    }
+}
+
 // K6: (key, count) pairs with count >= min_cov; with keys == nullptr only counts them.
 constexpr int EXP_THREADS = 256, EXP_ITEMS = 8, EXP_TILE = EXP_THREADS * EXP_ITEMS;
 
@@ -3160,7 +3212,24 @@ int mc_get_dev(mc_ctx *c, const int64_t *d_keys, uint64_t n, int16_t *d_out)
     if ((!d_keys || !d_out) && n) return fail(c, MC_EINVAL, "mc_get_dev: null pointer");
     if (n == 0) return MC_OK;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    if (int brc = by_key_ready(c)) return brc;  // (a look-up by key: the table leaves minimizer bins for it, include/mcgpu.h)
+    if (hash_bins(c) && !c->virgin) {  // (hash keys in minimizer bins: one sweep of the table answers all the queries, k_getq_*)
+        if (n >= (1ull << 31)) return fail(c, MC_EINVAL, "mc_get: at most 2^31 - 1 keys a call on this table");
+        uint64_t qn = 1024;
+        while (qn < 2 * n) qn <<= 1;
+        DevBuf<unsigned long long> qk;
+        DevBuf<uint32_t> qi;
+        HIPCHK(c, qk.alloc(qn));
+        HIPCHK(c, qi.alloc(qn));
+        HIPCHK(c, hipMemsetAsync(qk.p, 0xFF, qn * sizeof(unsigned long long), c->stream));
+        HIPCHK(c, hipMemsetAsync(d_out, 0xFF, n * sizeof(int16_t), c->stream));  // (-1: absent)
+        hipLaunchKernelGGL(k_getq_build, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, d_keys, n, qk.p, qi.p, qn - 1);
+        hipLaunchKernelGGL(k_getq_sweep, dim3(grid_for(c->n_slots(), 256, 256 * 16)), dim3(256), 0, c->stream, c->slots, c->n_slots(), qk.p, qi.p, qn - 1, d_out);
+        hipLaunchKernelGGL(k_getq_finish, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, d_keys, n, qk.p, qi.p, qn - 1, d_out, c->d_ctr + 1);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return MC_OK;
+    }
+    if (int brc = by_key_ready(c)) return brc;
     hipLaunchKernelGGL(k_get, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, d_keys, n, d_out, c->view());
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -39,7 +39,8 @@ def _bins(monkeypatch, bins):
 def test_long_records_count_and_walk(mc, monkeypatch, k, bins):
     """Two batches (the second one into a table that holds keys already, starting in the middle of a tile of the read store):
     every (key, count) pair of the oracle, the walks of the oracle straight on the minimizer-bin table (look-ups by the k-mers'
-    bases), then a look-up BY KEY of everything -- which moves the table to hash-prefix regions -- and the walks again."""
+    bases), a look-up BY KEY of everything (one sweep of the table answers it: the table stays as it is), a third batch as long
+    records again, and then a key stream (mc_add_keys_dev) -- which moves the table to hash-prefix regions -- and the walks again."""
     monkeypatch.setenv("MC_COUNT_PATH", "partition")  # (a batch of under 2^22 windows takes the direct kernel otherwise: by key)
     monkeypatch.delenv("MC_LONG_RECORDS", raising=False)
     _bins(monkeypatch, bins)
@@ -58,21 +59,34 @@ def test_long_records_count_and_walk(mc, monkeypatch, k, bins):
     gk, gc = ctx.export(0)
     assert np.array_equal(gk, ok) and np.array_equal(gc, oc)
     _walks(ctx, t, k, genome, 3)
-    assert np.array_equal(ctx.get(ok), oc)       # by key: the table gives up its minimizer bins
-    assert ctx.stats().grows == 1
-    gk, gc = ctx.export(0)
-    assert np.array_equal(gk, ok) and np.array_equal(gc, oc)
-    _walks(ctx, t, k, genome, 3)
-    # ... and what comes now takes the per-window form, into the same table
+    assert np.array_equal(ctx.get(ok), oc)       # by key: answered by a sweep
+    absent = ok[:1000] ^ np.int64(0x5DEECE66D)   # keys that are (almost surely) not there, one of them asked for twice
+    got = ctx.get(np.concatenate([absent, ok[:5], ok[:5]]))
+    assert np.array_equal(got[1000:1005], oc[:5]) and np.array_equal(got[1005:], oc[:5])
+    assert np.all((got[:1000] == -1) | np.isin(absent, ok))
+    assert ctx.stats().grows == 0
+    # ... a third batch, long records again into the same table
     ctx.add_reads_packed(po.pack(reads[:off[cut]]), off[:cut + 1])
     ctx.finalize()
-    assert ctx.stats().long_runs == 2
+    assert ctx.stats().long_runs == 3
     t2 = po.Table()
     t2.count_reads(reads, off, k, po.KEY_POLY)
     t2.count_reads(reads[:off[cut]], off[:cut + 1], k, po.KEY_POLY)
     ok2, oc2 = t2.dump()
     gk, gc = ctx.export(0)
     assert np.array_equal(gk, ok2) and np.array_equal(gc, oc2)
+    _walks(ctx, t2, k, genome, 3)
+    # ... and a stream of bare keys: the table leaves its minimizer bins for it (one rebuild), everything stays findable
+    import torch
+    extra = torch.from_numpy(ok2[:100000].copy()).to("cuda:0")
+    ctx.add_keys_dev(extra, len(extra))
+    ctx.finalize()
+    assert ctx.stats().grows == 1
+    oc3 = oc2.copy()
+    oc3[:100000] = np.minimum(oc3[:100000].astype(np.int32) + 1, 32767).astype(np.int16)
+    gk, gc = ctx.export(0)
+    assert np.array_equal(gk, ok2) and np.array_equal(gc, oc3)
+    assert np.array_equal(ctx.get(ok2[:200000]), oc3[:200000])
     ctx.close()
 
 
