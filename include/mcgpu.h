@@ -140,10 +140,11 @@ int mc_finalize_counts(mc_ctx *ctx, uint64_t *n_distinct);
  * (itmo!/utils/NumUtils.java:21-26), or -1 when the key is absent.  Key 0 is legal.
  * A context with polynomial-hash keys of 33 .. 63 bases keeps its table in minimizer bins of the k-mers' BASES while reads
  * are counted into a table whose size something vouches for -- a capacity_hint that still holds, or, for the first batch into
- * an empty table, a sample of that batch -- (csrc/count_long.h), where a bare key cannot be found: the first look-up by key --
- * like the first key stream (mc_add_keys_dev, mc_add_pairs_dev), mc_shard_export or any batch that takes the direct kernel --
- * moves every key to hash-prefix regions first, once and for good (a rebuild of the table: mc_stats.grows counts it), and
- * reads counted after that take the per-window pipeline.  Results are the same either way. */
+ * an empty table, a sample of that batch -- (csrc/count_long.h), where a bare key does not say which region it lives in: mc_get
+ * then answers all n queries with ONE sweep of the table (cost: the table's size, not n), and the first key stream
+ * (mc_add_keys_dev, mc_add_pairs_dev, mc_load_kmers), mc_shard_export or batch that takes the direct kernel moves every key to
+ * hash-prefix regions first, once and for good (a rebuild of the table: mc_stats.grows counts it), after which reads take the
+ * per-window pipeline.  Results are the same either way. */
 int mc_get(mc_ctx *ctx, const int64_t *keys, uint64_t n, int16_t *out);
 int mc_get_dev(mc_ctx *ctx, const int64_t *d_keys, uint64_t n, int16_t *d_out);
 
