@@ -15,8 +15,9 @@
 //         bits alone wherever it is worked out (skl_bin)
 //   r0.w:r0.z, r1.y:r1.x, r1.w:r1.z   the run's bases (windows + k - 1 <= 96), first base on top, unused tail zero
 //
-// About 20 windows a record at k = 63: the streams shrink ~8-fold.  Nothing by-key can find a key in such a table (mc_get, key
-// streams of other ranks, the direct kernel): mcgpu.hip moves the table to hash-prefix regions before any of those (by_key_ready).
+// About 16 windows a record at k = 63 on reads with 1 % errors: the streams shrink ~8-fold.  A bare key does not say where it lives
+// in such a table: mc_get answers by one sweep of the table (mcgpu.hip k_getq_*), and before key streams of other ranks, the direct
+// kernel or a shard export mcgpu.hip moves the table to hash-prefix regions (by_key_ready).
 #pragma once
 #include "count_pipeline.h"
 
