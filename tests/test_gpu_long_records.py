@@ -190,3 +190,34 @@ def test_long_records_without_a_capacity_hint(mc, monkeypatch, k):
     assert np.array_equal(gk, ok) and np.array_equal(gc, oc)
     _walks(ctx, t, k, genome, 2)
     ctx.close()
+
+
+def test_long_records_without_a_read_store_and_through_a_kmers_file(mc, monkeypatch, tmp_path):
+    """No read store (mc_set_read_pointers(0): the records carry no pointers, the walk gets no look-ahead) -- same pairs, same
+    walks; and the table as a .kmers.bin file (a sweep) loaded into another context of the same kind (a key stream: that one
+    leaves its minimizer bins for it) -- same pairs, same walks again."""
+    monkeypatch.setenv("MC_COUNT_PATH", "partition")
+    monkeypatch.delenv("MC_LONG_RECORDS", raising=False)
+    monkeypatch.delenv("MC_LONG_BINS", raising=False)
+    k = 51
+    genome, reads, off = synth_case(2, 150000, 40000, 150, 50)
+    t, _ = oracle_table(reads, off, k, po.KEY_POLY)
+    ok, oc = t.dump()
+    ctx = mc.Context(k, mc.KEY_POLY, 0, int(t.size() * 1.2))
+    ctx.set_read_pointers(False)
+    ctx.add_reads_packed(po.pack(reads), off)
+    assert ctx.finalize() == t.size() and ctx.stats().long_runs == 1
+    gk, gc = ctx.export(0)
+    assert np.array_equal(gk, ok) and np.array_equal(gc, oc)
+    _walks(ctx, t, k, genome, 3)
+    path = str(tmp_path / "t.kmers.bin")
+    ctx.save_kmers(path)
+    other = mc.Context(k, mc.KEY_POLY, 0, int(t.size() * 1.2))
+    other.load_kmers(path)
+    assert other.finalize() == t.size()
+    gk, gc = other.export(0)
+    assert np.array_equal(gk, ok) and np.array_equal(gc, oc)
+    assert np.array_equal(other.get(ok[:50000]), oc[:50000])
+    _walks(other, t, k, genome, 3)
+    other.close()
+    ctx.close()
