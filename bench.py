@@ -191,10 +191,14 @@ def main():
     info["bfs_wall_s"] = 0.0
     info["finalize_s"] = 0.0
     t0 = time.perf_counter()
+    step_marks = []
     for _ in range(args.steps):
         step()
+        step_marks.append(time.perf_counter())  # (host clock when the step's last call returned: the walk's results are on the host then)
     sync()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("MC_BENCH_STEP_TIMES"):  # (debugging: where a slow step sits)
+        print("step ms: " + " ".join("%.2f" % (1e3 * (b_ - a_)) for a_, b_ in zip([t0] + step_marks[:-1], step_marks)), file=sys.stderr)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
