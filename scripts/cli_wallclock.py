@@ -1,9 +1,10 @@
 """Wall clock of the native CLI end to end (FASTA from the page cache -> graph.txt, seqs.fasta, graph.gfa, tsvs)
-on a synthetic 30x data set.  Usage: python scripts/cli_wallclock.py [n_reads]"""
+on a synthetic 30x data set.  Usage: [CLI_K=63] [NOHINT=1] [MC_LONG_RECORDS=0] python scripts/cli_wallclock.py [n_reads]"""
 import json, os, subprocess, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
+K = os.environ.get("CLI_K", "31")  # (above 31 the CLI hashes its k-mers: polynomial keys; NOHINT=1: without --capacity-hint)
 L = 150
 rng = np.random.default_rng(0)
 lut = np.frombuffer(b"AGCT", dtype=np.uint8)
@@ -20,7 +21,7 @@ cli = os.path.join(ROOT, "metacherchant_amd", "lib", "metacherchant")
 out, wd = os.path.join(tmp, "cli_out"), os.path.join(tmp, "cli_wd")
 for rep in range(2):
     t0 = time.time()
-    p = subprocess.run([cli, "--tool", "environment-finder", "-k", "31", "--coverage", "5", "--reads", fa, "--seq", seq, "--output", out,
+    p = subprocess.run([cli, "--tool", "environment-finder", "-k", K, "--coverage", "5", "--reads", fa, "--seq", seq, "--output", out,
                         "--work-dir", wd, "--maxkmers", "100000", "--force"] + ([] if os.environ.get("NOHINT") else ["--capacity-hint", str(len(genome) + (1 << 20))]),
                        capture_output=True, text=True)
     t1 = time.time()
