@@ -68,19 +68,6 @@ __host__ __device__ __forceinline__ int64_t key_packed(uint64_t fw, int k, bool 
     return a < b ? a : b;
 }
 
-// src/utils/PolynomialHash.java:19-28
-__host__ __device__ inline int64_t key_poly(const Kmer &v, int k, bool *flipped = nullptr)
-{
-    uint64_t fw = 1, rc = 1;
-    for (int i = 0; i < k; i++) {
-        fw = fw * 5 + base_at(v, k, i);
-        rc = rc * 5 + (3u ^ base_at(v, k, k - 1 - i));
-    }
-    const int64_t a = (int64_t)fw, b = (int64_t)rc;
-    if (flipped) *flipped = b < a;
-    return a < b ? a : b;  // Math.min on signed longs
-}
-
 // key_poly's two hashes four bases at a time: h <- h * 5^4 + T[byte] with T[b0 b1 b2 b3] = 125 b0 + 25 b1 + 5 b2 + b3, so a
 // k-mer costs k / 4 table look-ups per strand instead of k multiply-adds each with its own base extraction (the counting
 // pipeline's P1 does this once per thread and tile, then rolls: at k = 63 the start-up was most of the kernel).
@@ -159,6 +146,49 @@ __host__ __device__ inline uint64_t poly_hash_r_tabled(const Kmer &v, int k, con
     }
     return hr;
 }
+// src/utils/PolynomialHash.java:19-28
+__host__ __device__ inline int64_t key_poly_plain(const Kmer &v, int k, bool *flipped = nullptr)
+{
+    uint64_t fw = 1, rc = 1;
+    for (int i = 0; i < k; i++) {
+        fw = fw * 5 + base_at(v, k, i);
+        rc = rc * 5 + (3u ^ base_at(v, k, k - 1 - i));
+    }
+    const int64_t a = (int64_t)fw, b = (int64_t)rc;
+    if (flipped) *flipped = b < a;
+    return a < b ? a : b;  // Math.min on signed longs
+}
+
+// The two 256-entry tables of poly_hashes_tabled as constants of the code object: a key worked out from scratch on the device --
+// every node of a round of the walk at k > 31, every window of the direct kernel -- takes k / 4 look-ups a strand instead of k
+// multiply-adds with a base extraction each (~1 400 instructions a key at k = 63: most of what a round of the walk computed).
+struct PolyTabs {
+    uint16_t f[256], r[256];
+    constexpr PolyTabs() : f(), r()
+    {
+        for (uint32_t i = 0; i < 256; i++) {
+            const uint32_t b0 = (i >> 6) & 3, b1 = (i >> 4) & 3, b2 = (i >> 2) & 3, b3 = i & 3;
+            f[i] = (uint16_t)(125 * b0 + 25 * b1 + 5 * b2 + b3);
+            r[i] = (uint16_t)(125 * (3u ^ b3) + 25 * (3u ^ b2) + 5 * (3u ^ b1) + (3u ^ b0));
+        }
+    }
+};
+__device__ const PolyTabs g_poly_tabs = PolyTabs();
+
+// src/utils/PolynomialHash.java:19-28 (key_poly_plain above is the loop as written there; same values)
+__host__ __device__ inline int64_t key_poly(const Kmer &v, int k, bool *flipped = nullptr)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t fw, rc;
+    poly_hashes_tabled(v, k, g_poly_tabs.f, g_poly_tabs.r, &fw, &rc);
+    const int64_t a = (int64_t)fw, b = (int64_t)rc;
+    if (flipped) *flipped = b < a;
+    return a < b ? a : b;  // Math.min on signed longs
+#else
+    return key_poly_plain(v, k, flipped);
+#endif
+}
+
 // (4 + x) * p for x = 0 .. 3 without a multiplication (p = 5^k: what a rolling step of either strand's hash takes away)
 __host__ __device__ __forceinline__ uint64_t poly_4x_times(uint32_t x, uint64_t p)
 {
@@ -414,11 +444,16 @@ __host__ __device__ inline uint32_t sk_hmin_of_kmer(uint64_t fw, int k)
 // minimizer bins (k > 32 with polynomial keys, count_pipeline.h "long records") every look-up brings the k-mer itself.
 __host__ __device__ inline uint32_t sk_hmin_of_kmer2(const Kmer &v, int k, bool two = false)
 {   // two: the word made of the TWO smallest values, as a multiset (count_long.h skl_word2) -- tables with mm_k < 0
+    // (the bases are taken from the k-mer's END -- two bits off the bottom of hi:lo a step --: the set of SK_M-mers is the same from
+    // either side, and base_at's two variable 64-bit shifts a base were a third of what a look-up of the walk computed)
+    uint64_t lo = v.lo, hi = v.hi;
     uint32_t f = 0, r = 0, best = SK_NONE, second = SK_NONE;
     for (int i = 0; i < k; i++) {
-        const uint32_t b = base_at(v, k, i);
-        f = ((f << 2) | b) & SK_MMASK;
-        r = (r >> 2) | ((3u - b) << (2 * (SK_M - 1)));
+        const uint32_t b = (uint32_t)lo & 3u;
+        lo = (lo >> 2) | (hi << 62);
+        hi >>= 2;
+        f = (f >> 2) | (b << (2 * (SK_M - 1)));   // the SK_M-mer that STARTS at this base, first base on top
+        r = ((r << 2) | (3u - b)) & SK_MMASK;     // ... and its reverse complement
         if (i >= SK_M - 1) {
             const uint32_t h = sk_order(f < r ? f : r);
             const uint32_t t = h > best ? h : best;
