@@ -1,4 +1,4 @@
 #!/bin/bash
-# scratch: what one gpurun call of the moment runs
-ROUND=r05 MC_COMMIT=$1 bash scripts/gpu_round_profiles.sh > gpurun_out/profiles_run.log 2>&1
-ls gpurun_out/p | wc -l
+# scratch: what one gpurun call of the moment runs (edited freely between calls; the scripts that matter are gpu_round_*.sh)
+set -o pipefail
+timeout -k 10 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
