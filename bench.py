@@ -335,6 +335,9 @@ def main():
             "spilled_records_per_step": int(st.spill_keys) // args.steps, "solid_sweeps_per_step": int(st.solid_sweeps) / args.steps, "solid_list_builds_per_step": int(st.solid_list_builds) / args.steps,
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if st.long_runs:  # hash keys in minimizer bins: what mc_finalize_counts' join of the keys by key cost, and what it found
+            out["key_join"] = {"mode": "unchecked (MC_DUP_CHECK=0)" if st.dup_unchecked else "exact: keys joined by key at mc_finalize_counts, the walk's absent look-ups asked again by key (csrc/dup_check.h)",
+                               "ms_per_step": round(st.dup_ms / args.steps, 3), "joins_per_step": st.dup_checks / args.steps, "keys_in_several_regions": int(st.dup_keys)}
         out["count_wall_ms"] = round(1e3 * info["count_wall_s"] / args.steps, 3)  # clear + count + finalize as the host sees them (kernels: roofline.count_ms_per_step)
         out["bfs_wall_ms"] = round(1e3 * info.get("bfs_wall_s", 0.0) / args.steps, 3)  # mc_bfs_batch as the host sees it: upload, walk, packed results back, arrays for the caller (kernel: bfs.ms_per_step)
         if no_hint is not None:
@@ -402,6 +405,23 @@ def config2_leg(args, m, torch, dev, local_rank, d_words, d_off, R, L, n_bases):
             raise RuntimeError("config2: BFS found no seed k-mer")
         res["bfs_ms"], res["reached"] = r["device_ms"], len(r["lo"])
 
+    # Hash keys in minimizer bins (csrc/count_long.h): mc_finalize_counts joins the table's keys by key so that different k-mers
+    # with one 64-bit hash share a counter as in the reference (csrc/dup_check.h), and a walk's "absent" look-ups are asked again
+    # by key.  `value` is measured with both (the library's default: results do not depend on the table's internal form);
+    # `value_unchecked` with MC_DUP_CHECK=0 -- the same kernels without the join, for what the join costs.
+    unchecked = None
+    if os.environ.get("MC_DUP_CHECK") != "0":
+        os.environ["MC_DUP_CHECK"] = "0"
+        try:
+            step()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(args.config2_steps):
+                step()
+            torch.cuda.synchronize(dev)
+            unchecked = time.perf_counter() - t0
+        finally:
+            del os.environ["MC_DUP_CHECK"]
     step()
     torch.cuda.synchronize(dev)
     ctx.reset_stats()
@@ -427,6 +447,13 @@ def config2_leg(args, m, torch, dev, local_rank, d_words, d_off, R, L, n_bases):
                                               ("k_p1_extract_scatter", "k_p2_scatter", "k_p3_merge"),
                                               (round(st.p1_ms / launches, 3), round(st.p2_ms / launches, 3), round(st.p3_ms / launches, 3)))),
                         "count_ms_per_step": round(st.count_total_ms / args.config2_steps, 3)}}
+    if st.long_runs:
+        out["key_join"] = {"mode": "unchecked (MC_DUP_CHECK=0)" if st.dup_unchecked else "exact: keys joined by key at mc_finalize_counts, the walk's absent look-ups asked again by key (csrc/dup_check.h)",
+                           "ms_per_step": round(st.dup_ms / args.config2_steps, 3), "joins_per_step": st.dup_checks / args.config2_steps,
+                           "keys_in_several_regions": int(st.dup_keys)}
+        if unchecked is not None:
+            out["value_unchecked"] = windows * args.config2_steps / unchecked
+            out["ms_per_step_unchecked"] = round(1e3 * unchecked / args.config2_steps, 3)
     ctx.close()
     return out
 

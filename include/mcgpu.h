@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define MC_ABI_VERSION 12
+#define MC_ABI_VERSION 13
 
 /* error codes */
 #define MC_OK 0
@@ -61,7 +61,12 @@ extern "C" {
  * k <= 31 and !forcehash -> PACKED (key = min(fw, rc) of the 2-bit packed k-mer as signed long,
  * itmo!/dna/kmers/ShortKmer.java:54-56); otherwise a 64-bit strand-symmetric hash of the k-mer
  * (src/utils/PolynomialHash.java:19-28 default, src/utils/FNV1AHash.java:33-42 with --hash fnv1a);
- * colliding k-mers share a counter, as in the reference. */
+ * colliding k-mers share a counter, as in the reference (src/io/LargeKIOUtils.java:46-49 adds the HASH of every window to the
+ * map).  That holds for every internal form of the table: where hash keys are kept in minimizer bins of the k-mers' bases
+ * (mc_get below), mc_finalize_counts joins the table's keys by key (csrc/dup_check.h), gives a key that two different k-mers
+ * brought to two regions the SUM of its counters wherever it is read, and counts and exports it once (mc_stats.dup_keys,
+ * dup_ms).  Environment MC_DUP_CHECK=0 skips the join (measurements only: a colliding pair -- expected n^2 / 2^65 of them among n
+ * keys -- then keeps two counters, "Hashtable size" counts it twice, an export lists it twice; mc_stats.dup_unchecked says so). */
 enum { MC_KEY_PACKED = 0, MC_KEY_POLY = 1, MC_KEY_FNV1A = 2 };
 
 /* mc_config.flags.  MC_FLAG_SOLID_LIST: the k-mers at or above the coverage hint will be exported (a shard of a
@@ -144,7 +149,7 @@ int mc_finalize_counts(mc_ctx *ctx, uint64_t *n_distinct);
  * then answers all n queries with ONE sweep of the table (cost: the table's size, not n), and the first key stream
  * (mc_add_keys_dev, mc_add_pairs_dev, mc_load_kmers), mc_shard_export or batch that takes the direct kernel moves every key to
  * hash-prefix regions first, once and for good (a rebuild of the table: mc_stats.grows counts it), after which reads take the
- * per-window pipeline.  Results are the same either way. */
+ * per-window pipeline.  Results are the same either way: mc_finalize_counts has merged the counters of colliding k-mers (above). */
 int mc_get(mc_ctx *ctx, const int64_t *keys, uint64_t n, int16_t *out);
 int mc_get_dev(mc_ctx *ctx, const int64_t *d_keys, uint64_t n, int16_t *d_out);
 
@@ -322,6 +327,11 @@ typedef struct {
     uint64_t solid_sweeps;   /* table sweeps BFS set-ups needed to count them (0 with mc_set_coverage_hint) */
     uint64_t solid_list_builds; /* BFS set-ups and exports that took their entries from the list the merge kernel left, without sweeping the table */
     uint64_t long_runs;      /* pipeline runs that took long records (polynomial keys, k > 32, a capacity hint: csrc/count_long.h) */
+    uint64_t dup_keys;       /* hash keys in minimizer bins: keys that different k-mers brought to more than one region, as the last
+                                mc_finalize_counts found them (their counters are merged; 0 once the table has moved to hash-prefix regions) */
+    uint64_t dup_checks;     /* joins of the table's keys by key that found that out (csrc/dup_check.h), ... */
+    double dup_ms;           /* ... and their summed device time */
+    uint64_t dup_unchecked;  /* 1: MC_DUP_CHECK=0 skipped the join for the table as it is now */
 } mc_stats;
 int mc_get_stats(mc_ctx *ctx, mc_stats *out);
 int mc_reset_stats(mc_ctx *ctx);

@@ -20,6 +20,7 @@
 // kernel or a shard export mcgpu.hip moves the table to hash-prefix regions (by_key_ready).
 #pragma once
 #include "count_pipeline.h"
+#include "dup_check.h"
 
 namespace mc {
 
@@ -383,6 +384,7 @@ struct alignas(16) LongLds {
     uint16_t copies[SKL_ROUND];         // of a record that stands for its equals, itself included
     uint32_t n_new, overflow, emit_cur, n_empty;
     uint32_t n_tasks, pad_[3];
+    uint32_t dcur[DUP_B1];              // fill levels of this workgroup's segments of the key stream (dup_check.h level 1)
 };
 static_assert(2 * sizeof(LongLds) <= 160 * 1024, "two workgroups of the long merge kernel on a CU");
 
@@ -417,12 +419,14 @@ template <int KT>
 __global__ void __launch_bounds__(P3_THREADS) k_p3_long(const uint4 *__restrict__ leaf_recs, const uint32_t *__restrict__ leaf_counts, uint64_t cap,
                                                         uint32_t n_leaves, TableView t, int virgin, uint32_t *leaf_state, uint32_t *leaf_new,
                                                         uint32_t *any_failed, uint32_t solid_thr, unsigned long long *n_solid, int k_arg, P3Emit emit,
-                                                        const uint32_t *lost)
-{
+                                                        const uint32_t *lost, DupL1 d1)
+{   // d1: every key that goes back to HBM is also appended to the workgroup's segment of its key bucket (dup_check.h: the join by
+    // key that finds a key two different k-mers brought to two regions starts from these streams instead of a sweep of the table)
     if (lost && *lost) return;  // (the scatter levels lost records: the batch is counted another way)
     const int k = KT ? KT : k_arg;
     __shared__ LongLds L;
     const uint32_t tid = threadIdx.x;
+    if (d1.keys && tid < DUP_B1) L.dcur[tid] = d1.counts[tid * d1.nseg + blockIdx.x];  // (a launch goes on where the last one stopped; published by the barriers below)
     const bool emitting = emit.recs != nullptr && solid_thr != 0;
     if (tid < 256) poly_tables_fill(L.polyF, L.polyR, tid);
     if (tid == 0) L.emit_cur = emitting ? emit.counts[blockIdx.x] : 0u;  // (published by the first barrier below)
@@ -592,6 +596,11 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_long(const uint4 *__restrict_
                 v.w = L.aux[i];
                 occ += kk != EMPTY_KEY;
                 *reinterpret_cast<uint4 *>(gs + i) = v;
+                if (d1.keys && kk != EMPTY_KEY) {  // (slots are in home-slot order: the lanes of a bucket sit side by side)
+                    const uint32_t b = dup_b1(kk);
+                    const uint32_t pos = atomicAdd(&L.dcur[b], 1u);
+                    if (pos < d1.cap) d1.keys[((uint64_t)b * d1.nseg + blockIdx.x) * d1.cap + pos] = kk; else atomicExch(d1.lost, 1u);
+                }
                 const bool solid = solid_thr && v.z >= solid_thr;
                 solid_delta += solid;
                 if (emitting) {  // (uniform; the loop's trip count is the same for every lane)
@@ -630,6 +639,7 @@ __global__ void __launch_bounds__(P3_THREADS) k_p3_long(const uint4 *__restrict_
     }
     if (tid == 0 && empty_total) atomicAdd(t.empty_cnt, empty_total);
     if (solid_thr) wave_add_ull(n_solid, (unsigned long long)solid_delta);  // (two's complement: deltas may be negative)
+    if (d1.keys && tid < DUP_B1) d1.counts[tid * d1.nseg + blockIdx.x] = (uint32_t)min((uint64_t)L.dcur[tid], d1.cap);  // (the leaf loop ends in a barrier)
     if (emitting) {
         __syncthreads();
         if (tid == 0) emit.counts[blockIdx.x] = (uint64_t)L.emit_cur < emit.seg_cap ? L.emit_cur : (uint32_t)emit.seg_cap;
@@ -646,7 +656,7 @@ __device__ __forceinline__ uint64_t skl_region_base(const TableView &t, uint64_t
 // one record's windows through the direct path: the spill list of the scatter levels (n records at `recs`, pointerless), or the
 // leaves the merge kernel left unmerged (below)
 __device__ __forceinline__ void skl_add_record(const TableView &t, const uint4 &r0, const uint4 &r1, uint32_t p0, int k, uint64_t p_k, uint64_t p_km1,
-                                               uint32_t solid_thr, unsigned long long &n_new, unsigned long long &n_cross)
+                                               uint32_t solid_thr, unsigned long long &n_new, unsigned long long &n_cross, const DupL1 &d1)
 {
     const uint32_t nw = (r0.y & 0xFFu) + 1u;
     const uint64_t X0 = ((uint64_t)r0.w << 32) | r0.z, X1 = ((uint64_t)r1.y << 32) | r1.x, X2 = ((uint64_t)r1.w << 32) | r1.z;
@@ -660,19 +670,21 @@ __device__ __forceinline__ void skl_add_record(const TableView &t, const uint4 &
     for (uint32_t j = 0; j < nw; j++) {
         const uint64_t key = (int64_t)hf < (int64_t)hr ? hf : hr;
         uint32_t before;
-        n_new += table_add_at(t, key == EMPTY_KEY ? 0 : (t.mm_k ? (rbase | sk_home(key)) : slot_of(t, key)), key, 1u, ptr_advance_long(p0, j), &before);
+        const uint32_t fresh = table_add_at(t, key == EMPTY_KEY ? 0 : (t.mm_k ? (rbase | sk_home(key)) : slot_of(t, key)), key, 1u, ptr_advance_long(p0, j), &before);
+        n_new += fresh;
+        if (fresh) dup_l1_extra(d1, key);  // (a key the merge kernel's streams do not hold)
         n_cross += crosses(before, 1u, solid_thr);
         if (j + 1 < nw) poly_roll(hf, hr, skl_base(X0, X1, X2, j), skl_base(X0, X1, X2, j + (uint32_t)k), p_k, p_km1);
     }
 }
 
-__global__ void k_skl_add_records(const uint4 *__restrict__ recs, uint64_t n, int k, TableView t, uint32_t solid_thr, unsigned long long *n_solid)
+__global__ void k_skl_add_records(const uint4 *__restrict__ recs, uint64_t n, int k, TableView t, uint32_t solid_thr, unsigned long long *n_solid, DupL1 d1)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t p_k = pow5(k), p_km1 = pow5(k - 1);
     unsigned long long n_new = 0, n_cross = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        skl_add_record(t, recs[2 * i], recs[2 * i + 1], 0u, k, p_k, p_km1, solid_thr, n_new, n_cross);
+        skl_add_record(t, recs[2 * i], recs[2 * i + 1], 0u, k, p_k, p_km1, solid_thr, n_new, n_cross, d1);
     wave_add_ull(t.n_used, n_new);
     if (solid_thr) wave_add_ull(n_solid, n_cross);
 }
@@ -724,7 +736,7 @@ __global__ void k_skl_add_unmerged(const uint4 *__restrict__ leaf_recs, const ui
         if (leaf_state[leaf]) continue;
         const uint64_t n = min((uint64_t)leaf_counts[leaf], cap);
         const uint4 *recs = leaf_recs + 2 * (uint64_t)leaf * cap;
-        for (uint64_t r = threadIdx.x; r < n; r += blockDim.x) skl_add_record(t, recs[2 * r], recs[2 * r + 1], recs[2 * r].x, k, p_k, p_km1, 0u, n_new, n_cross);
+        for (uint64_t r = threadIdx.x; r < n; r += blockDim.x) skl_add_record(t, recs[2 * r], recs[2 * r + 1], recs[2 * r].x, k, p_k, p_km1, 0u, n_new, n_cross, DupL1{nullptr, nullptr, 0, 0, nullptr});
     }
     wave_add_ull(t.n_used, n_new);
 }

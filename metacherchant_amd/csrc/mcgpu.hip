@@ -326,6 +326,49 @@ struct mc_ctx {
         }
     } pipe;
 
+    // Hash keys in minimizer bins: the join of the table's keys by key (dup_check.h) and what it found.
+    struct Dup {
+        // level 1: the merge kernel's (or the sweep's) key streams
+        uint64_t *l1_keys = nullptr;
+        uint64_t l1_words = 0;
+        uint32_t *l1_counts = nullptr;
+        uint64_t l1_counts_cap = 0;
+        uint32_t l1_nseg = 0;
+        uint64_t l1_cap = 0;
+        bool l1_armed = false;       // the last long run's merge kernel collected into the streams (and nothing else has touched the table since)
+        double expected_keys = 0;    // what the sample of the batch said the table will hold (a context without a hint)
+        // levels 2 and 3
+        uint64_t *l2_own = nullptr;  // where the pipeline's idle streams are too small to serve
+        uint64_t l2_own_words = 0;
+        uint32_t *l2_counts = nullptr;
+        uint64_t l2_counts_cap = 0;
+        uint32_t *flags = nullptr;            // [0] a level-1 segment overflowed, [1] a level-2 stream did
+        unsigned long long *ctr = nullptr;    // [0] keys listed, [1] distinct keys in the set, [2] slots noted
+        unsigned long long *list = nullptr;   // the listed keys (LIST_CAP)
+        static constexpr uint64_t LIST_CAP = 1u << 16;
+        // what the fix-up left: the set of keys held by more than one slot, their slots with their own counts
+        DupSet set{nullptr, nullptr, nullptr, 0, nullptr};
+        uint64_t set_slots = 0;
+        DupTwin *tw = nullptr;
+        uint64_t tw_cap = 0, n_tw = 0, n_keys = 0;
+        bool merged = false;         // the noted slots hold their keys' sums now (else: their own counts)
+        long long solid_delta = 0;   // what merging added to d_ctr[6] (keys at the coverage hint)
+        bool checked = false;        // the table as it is has been joined
+        DupL2 l2{nullptr, nullptr, 0, nullptr, 0, 0, 0, nullptr};  // the table's keys by key, as the last join left them (valid while l2_valid)
+        bool l2_valid = false;
+        // the check of a walk's "absent" look-ups by key (dup_check.h PhantomQ): queries, their order by sub-bucket, the hits
+        unsigned long long *pq_mem = nullptr;
+        uint64_t pq_cap = 0;
+        uint32_t *pq_groups = nullptr;  // [G]: the first query of every sub-bucket's list
+        uint64_t pq_groups_cap = 0;
+    } dup;
+    DupL1 dup_l1_view() const
+    {
+        if (!dup.l1_armed) return DupL1{nullptr, nullptr, 0, 0, nullptr};
+        return DupL1{dup.l1_keys, dup.l1_counts, dup.l1_nseg, dup.l1_cap, dup.flags};
+    }
+    DupSet dup_filter() const { return dup.merged && dup.n_tw ? dup.set : DupSet{nullptr, nullptr, nullptr, 0, nullptr}; }
+
     uint64_t n_slots() const { return n_regions << sb; }
     SolidView solid_view() const
     {
@@ -469,8 +512,8 @@ __global__ void k_add_pairs(const int64_t *__restrict__ keys, const int16_t *__r
 // region_of_leaf: hash keys in minimizer bins (count_long.h) -- the key does not say where it lives, the leaf it was handed on from
 // does (one region a leaf; every entry of such a list comes from a leaf)
 __global__ void k_add_parked(const uint4 *__restrict__ list, uint64_t n, TableView t, const uint32_t *__restrict__ entry_leaf = nullptr,
-                             const uint32_t *__restrict__ leaf_state = nullptr, int region_of_leaf = 0)
-{
+                             const uint32_t *__restrict__ leaf_state = nullptr, int region_of_leaf = 0, DupL1 d1 = DupL1{nullptr, nullptr, 0, 0, nullptr})
+{   // d1: keys that are new to a table of hash keys in minimizer bins also go to the key streams of dup_check.h
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     unsigned long long n_new = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -481,8 +524,11 @@ __global__ void k_add_parked(const uint4 *__restrict__ list, uint64_t n, TableVi
         }
         const uint4 e = list[i];
         const uint64_t key = ((uint64_t)e.y << 32) | e.x;
-        if (region_of_leaf && lf != 0xFFFFFFFFu) n_new += table_add_at(t, ((uint64_t)lf << MC_REGION_LG) | sk_home(key), key, e.z, e.w);
-        else n_new += table_add(t, key, e.z, e.w);
+        if (region_of_leaf && lf != 0xFFFFFFFFu) {
+            const uint32_t fresh = table_add_at(t, ((uint64_t)lf << MC_REGION_LG) | sk_home(key), key, e.z, e.w);
+            n_new += fresh;
+            if (fresh) dup_l1_extra(d1, key);
+        } else n_new += table_add(t, key, e.z, e.w);
     }
     wave_add_ull(t.n_used, n_new);
 }
@@ -781,8 +827,11 @@ constexpr int EXP_THREADS = 256, EXP_ITEMS = 8, EXP_TILE = EXP_THREADS * EXP_ITE
 
 __global__ void __launch_bounds__(EXP_THREADS) k_export(const Slot *__restrict__ slots, uint64_t n_slots, int min_cov,
                                                         int64_t *__restrict__ keys, int16_t *__restrict__ counts,
-                                                        uint32_t *__restrict__ hints, uint64_t cap, unsigned long long *cursor)
+                                                        uint32_t *__restrict__ hints, uint64_t cap, unsigned long long *cursor,
+                                                        DupSet dq = DupSet{nullptr, nullptr, nullptr, 0, nullptr})
 {
+    // dq: hash keys in minimizer bins -- a key that two k-mers brought to two regions is counted / listed at its first slot only
+    // (dup_check.h; every slot of it holds the sum of its counters)
     // A tile of slots is compacted in LDS (one LDS cursor update per wave and row), takes ONE slice of the output
     // with a single global atomic and leaves in coalesced stores: a global atomic per wave and row would put
     // n_slots / 64 updates on one address, which alone costs ~10 ns each.
@@ -804,7 +853,7 @@ __global__ void __launch_bounds__(EXP_THREADS) k_export(const Slot *__restrict__
             for (int j = 0; j < EXP_ITEMS; j++) {
                 const uint64_t key = ((uint64_t)raws[j].y << 32) | raws[j].x;
                 const int c = raws[j].z > 32767u ? 32767 : (int)raws[j].z;
-                counted += key != EMPTY_KEY && c >= min_cov ? 1u : 0u;
+                counted += key != EMPTY_KEY && c >= min_cov && !dup_is_shadow(dq, key, tile * EXP_TILE + (uint64_t)j * EXP_THREADS + tid) ? 1u : 0u;
             }
             continue;
         }
@@ -814,7 +863,7 @@ __global__ void __launch_bounds__(EXP_THREADS) k_export(const Slot *__restrict__
         for (int j = 0; j < EXP_ITEMS; j++) {
             const uint64_t key = ((uint64_t)raws[j].y << 32) | raws[j].x;
             const int c = raws[j].z > 32767u ? 32767 : (int)raws[j].z;
-            const bool take = key != EMPTY_KEY && c >= min_cov;
+            const bool take = key != EMPTY_KEY && c >= min_cov && !dup_is_shadow(dq, key, tile * EXP_TILE + (uint64_t)j * EXP_THREADS + tid);
             const unsigned long long m = __ballot(take);
             if (!m) continue;
             uint32_t base = 0;
@@ -987,6 +1036,8 @@ static inline void counts_changed(mc_ctx *c)
 {
     if (c->d_shards) { shard_detach_locked(c); c->shards_dropped = true; }
     c->finalized = false;
+    c->dup.checked = false;
+    c->dup.l2_valid = false;
 }
 
 static int materialize(mc_ctx *c)
@@ -1039,6 +1090,33 @@ struct TableSwap {
 // can find it there, and such a table cannot be rebuilt with another number of bins either.  Everything that works by key --
 // mc_get, key streams, the direct kernel, growing -- first moves the table to hash-prefix regions, for good (by_key_ready).
 static inline bool hash_bins(const mc_ctx *c) { return c->mm_k != 0 && c->cfg.key_mode != MC_KEY_PACKED; }
+__global__ void k_ctr_add(unsigned long long *p, long long d) { if (threadIdx.x == 0 && blockIdx.x == 0) *p += (unsigned long long)d; }
+// The slots of keys that sit in several regions (dup_check.h) get their own counts back: before the table takes more reads (the
+// merge kernel adds to whichever slot a k-mer's bin holds) and before its keys move to hash-prefix regions (where equal keys meet
+// and their counts add up by themselves).
+static int dup_unmerge(mc_ctx *c)
+{
+    mc_ctx::Dup &D = c->dup;
+    if (!D.merged || !D.n_tw) { D.merged = false; return MC_OK; }
+    hipLaunchKernelGGL(k_dup_apply, dim3((unsigned)((D.n_tw + 255) / 256)), dim3(256), 0, c->stream, c->slots, D.tw, D.n_tw, D.set, 0);
+    HIPCHK(c, hipGetLastError());
+    if (D.solid_delta) {
+        hipLaunchKernelGGL(k_ctr_add, dim3(1), dim3(64), 0, c->stream, c->d_ctr + 6, -D.solid_delta);
+        HIPCHK(c, hipGetLastError());
+    }
+    D.merged = false;
+    D.solid_delta = 0;
+    D.checked = false;
+    return MC_OK;
+}
+// nothing is known about the table's keys any more (it is empty, or no longer in minimizer bins)
+static void dup_forget(mc_ctx *c)
+{
+    mc_ctx::Dup &D = c->dup;
+    D.merged = false; D.n_tw = 0; D.n_keys = 0; D.solid_delta = 0; D.checked = false; D.l1_armed = false; D.expected_keys = 0; D.l2_valid = false;
+    c->st.dup_keys = 0;
+    c->st.dup_unchecked = 0;
+}
 static int to_hash_regions(mc_ctx *c);
 static inline int by_key_ready(mc_ctx *c) { return hash_bins(c) ? to_hash_regions(c) : MC_OK; }
 
@@ -1085,6 +1163,7 @@ static int table_grow(mc_ctx *c, uint64_t new_regions)
 static int to_hash_regions(mc_ctx *c)
 {
     if (!c->mm_k) return MC_OK;
+    if (int urc = dup_unmerge(c)) return urc;  // (equal keys meet in the new table: their own counts add up there)
     TableSwap sw(c);
     HIPCHK(c, hipMemcpyAsync(&sw.old_used, c->d_ctr, sizeof sw.old_used, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1104,6 +1183,7 @@ static int to_hash_regions(mc_ctx *c)
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     sw.done = true;
+    dup_forget(c);
     c->solid_tracked = false;
     c->solid_list_fresh = false;
     c->solid_cov = -1;
@@ -1253,6 +1333,215 @@ static int ensure_buf(mc_ctx *c, T **p, uint64_t *cap, uint64_t need)
     return MC_OK;
 }
 
+// ------------------------------------------------------------------------------------------ equal keys in different regions (dup_check.h)
+
+static bool dup_check_on()
+{
+    const char *e = getenv("MC_DUP_CHECK");  // (read on every call: the tests switch it)
+    return !(e && !strcmp(e, "0"));
+}
+
+static int dup_small_bufs(mc_ctx *c)
+{
+    mc_ctx::Dup &D = c->dup;
+    if (!D.flags) {
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&D.flags), 4 * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&D.ctr), 4 * sizeof(unsigned long long)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&D.list), mc_ctx::Dup::LIST_CAP * sizeof(unsigned long long)));
+        HIPCHK(c, hipMemsetAsync(D.flags, 0, 4 * sizeof(uint32_t), c->stream));
+    }
+    return MC_OK;
+}
+
+// capacity of a stream that is expected to take `mean` keys (they come hashed: Poisson, and a little more for the regions' unevenness)
+static uint64_t dup_cap(double mean) { return (uint64_t)(mean * 1.12 + 7.0 * std::sqrt(mean) + 64.0); }
+
+// The level-1 streams for a launch of k_p3_long with `grid` workgroups into a table that will hold about `keys` keys.  Not
+// getting them is no error: the join then starts with a sweep of the table.
+static void dup_arm(mc_ctx *c, double keys, uint32_t grid)
+{
+    mc_ctx::Dup &D = c->dup;
+    D.l1_armed = false;
+    static const bool fused = [] { const char *e = getenv("MC_DUP_FUSED"); return !(e && !strcmp(e, "0")); }();
+    if (!fused || !dup_check_on() || keys < 1.0) return;
+    const std::string keep = c->err;
+    if (dup_small_bufs(c)) { c->err = keep; (void)hipGetLastError(); return; }
+    const uint32_t nseg = grid + 1;  // (the last one: keys that enter the table outside the merge kernel)
+    const uint64_t cap = dup_cap(keys / ((double)DUP_B1 * (double)grid));
+    if (ensure_buf(c, &D.l1_keys, &D.l1_words, (uint64_t)DUP_B1 * nseg * cap) || ensure_buf(c, &D.l1_counts, &D.l1_counts_cap, (uint64_t)DUP_B1 * nseg)) {
+        c->err = keep;
+        (void)hipGetLastError();
+        return;
+    }
+    if (hipMemsetAsync(D.l1_counts, 0, (uint64_t)DUP_B1 * nseg * sizeof(uint32_t), c->stream) != hipSuccess ||
+        hipMemsetAsync(D.flags, 0, sizeof(uint32_t), c->stream) != hipSuccess) { (void)hipGetLastError(); return; }
+    D.l1_nseg = nseg;
+    D.l1_cap = cap;
+    D.l1_armed = true;
+}
+
+// The listed keys' slots: one sweep of the table notes them, every one of them then holds the sum of its key's counters
+// (dup_check.h); past what the lists take, the table gives up its minimizer bins instead -- equal keys meet in hash-prefix regions.
+static int dup_fixup(mc_ctx *c, uint64_t n_listed)
+{
+    mc_ctx::Dup &D = c->dup;
+    if (n_listed > mc_ctx::Dup::LIST_CAP) return to_hash_regions(c);
+    uint64_t want = 1024;
+    while (want < 4 * n_listed) want <<= 1;
+    if (want > D.set_slots) {
+        if (D.set.qk) { (void)hipFree(D.set.qk); D.set.qk = nullptr; D.set_slots = 0; }
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&D.set.qk), want * 3 * sizeof(unsigned long long)));
+        D.set_slots = want;
+    }
+    D.set.tot = D.set.qk + D.set_slots;
+    D.set.prim = D.set.qk + 2 * D.set_slots;
+    D.set.mask = D.set_slots - 1;
+    D.set.n_keys = D.ctr + 1;
+    const uint64_t tw_want = 8 * n_listed + 64;
+    if (tw_want > D.tw_cap) {
+        if (D.tw) { (void)hipFree(D.tw); D.tw = nullptr; D.tw_cap = 0; }
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&D.tw), tw_want * sizeof(DupTwin)));
+        D.tw_cap = tw_want;
+    }
+    HIPCHK(c, hipMemsetAsync(D.set.qk, 0xFF, D.set_slots * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(D.set.tot, 0, D.set_slots * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(D.set.prim, 0xFF, D.set_slots * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(D.ctr + 1, 0, 2 * sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(k_dupq_build, dim3(grid_for(n_listed, 256)), dim3(256), 0, c->stream, D.list, n_listed, D.set);
+    hipLaunchKernelGGL(k_dupq_sweep, dim3(grid_for(c->n_slots(), 256, 256 * 16)), dim3(256), 0, c->stream, c->slots, c->n_slots(), D.set, D.tw, D.ctr + 2, D.tw_cap);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_scratch + 20, D.ctr, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const uint64_t n_keys = c->h_scratch[21], n_tw = c->h_scratch[22];
+    if (n_tw > D.tw_cap) return to_hash_regions(c);  // (a key in more slots than anybody planned for)
+    D.n_keys = n_keys;
+    D.n_tw = n_tw;
+    D.solid_delta = 0;
+    if (c->solid_tracked && c->cov_hint > 0 && n_tw) {  // d_ctr[6] counts KEYS at the threshold: once for a merged key, by its sum
+        std::vector<DupTwin> tw(n_tw);
+        std::vector<unsigned long long> tot(D.set_slots);
+        HIPCHK(c, hipMemcpy(tw.data(), D.tw, n_tw * sizeof(DupTwin), hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(tot.data(), D.set.tot, D.set_slots * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        std::map<uint32_t, int> own_solid;
+        for (const DupTwin &t : tw) own_solid[t.entry] += t.own >= (uint32_t)c->cov_hint ? 1 : 0;
+        for (const auto &e : own_solid) D.solid_delta += (tot[e.first] >= (unsigned long long)c->cov_hint ? 1 : 0) - e.second;
+    }
+    if (n_tw) {
+        hipLaunchKernelGGL(k_dup_apply, dim3((unsigned)((n_tw + 255) / 256)), dim3(256), 0, c->stream, c->slots, D.tw, n_tw, D.set, 1);
+        if (D.solid_delta) hipLaunchKernelGGL(k_ctr_add, dim3(1), dim3(64), 0, c->stream, c->d_ctr + 6, D.solid_delta);
+        HIPCHK(c, hipGetLastError());
+        c->solid_list_fresh = false;  // (the merge kernel listed these keys by their own counts, once a slot)
+    }
+    D.merged = true;
+    return MC_OK;
+}
+
+// mc_finalize_counts: a table of hash keys in minimizer bins is joined by key (dup_check.h) unless that has been done for the
+// table as it is.
+static int ensure_dups(mc_ctx *c)
+{
+    mc_ctx::Dup &D = c->dup;
+    mc_ctx::Pipe &P = c->pipe;
+    if (!hash_bins(c) || c->virgin) { dup_forget(c); return MC_OK; }
+    if (D.checked) return MC_OK;
+    if (!dup_check_on()) { D.checked = true; D.l1_armed = false; c->st.dup_unchecked = 1; return MC_OK; }
+    c->st.dup_unchecked = 0;
+    int rc = dup_unmerge(c);  // (only a table whose slots hold their own counts is joined: nothing has touched it since, but say so)
+    if (rc) return rc;
+    D.n_tw = 0; D.n_keys = 0;
+    rc = dup_small_bufs(c);
+    if (rc) return rc;
+    unsigned long long n_used = 0;
+    HIPCHK(c, hipMemcpyAsync(c->h_scratch + 20, c->d_ctr, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    if (D.l1_armed) HIPCHK(c, hipMemcpyAsync(c->h_scratch + 21, D.flags, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    n_used = c->h_scratch[20];
+    bool have_l1 = D.l1_armed && (uint32_t)c->h_scratch[21] == 0;
+    D.l1_armed = false;  // (whatever happens next: the streams serve one join)
+    if (n_used < 2) { D.checked = true; c->st.dup_keys = 0; return MC_OK; }
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    uint64_t n_listed = 0;
+    for (int attempt = 0;; attempt++) {
+        if (!have_l1) {  // level 1 by a sweep of the table: 1021 workgroups, each a segment of every bucket
+            const uint32_t grid = 1021, nseg = grid + 1;  // (a region is 16 rows of the sweep, and a row's slots lie in 16 of the 256 buckets: not a multiple of 16)
+            const uint64_t cap = dup_cap((double)n_used / ((double)DUP_B1 * grid));
+            rc = ensure_buf(c, &D.l1_keys, &D.l1_words, (uint64_t)DUP_B1 * nseg * cap);
+            if (!rc) rc = ensure_buf(c, &D.l1_counts, &D.l1_counts_cap, (uint64_t)DUP_B1 * nseg);
+            if (rc) return rc;
+            HIPCHK(c, hipMemsetAsync(D.l1_counts, 0, (uint64_t)DUP_B1 * nseg * sizeof(uint32_t), c->stream));
+            HIPCHK(c, hipMemsetAsync(D.flags, 0, sizeof(uint32_t), c->stream));
+            D.l1_nseg = nseg;
+            D.l1_cap = cap;
+            hipLaunchKernelGGL(k_dup_sweep, dim3(grid), dim3(256), 0, c->stream, c->slots, c->n_slots(), DupL1{D.l1_keys, D.l1_counts, nseg, cap, D.flags});
+            HIPCHK(c, hipGetLastError());
+        }
+        // level 2 into sub-buckets of ~1500 keys, every workgroup (bucket, slice of its segments) its own segment of each; the streams
+        // borrow the pipeline's idle ones where those are large enough
+        const uint32_t slices = std::max<uint32_t>(2u, (D.l1_nseg + DUP_MAX_SLICE_SEGS - 1) / DUP_MAX_SLICE_SEGS);
+        if (slices > DUP_MAX_SLICES) return fail(c, MC_EINVAL, "internal: %u key-stream segments a bucket", D.l1_nseg);
+        uint32_t f2_lg = 0;
+        while (f2_lg < DUP_MAX_F2_LG && (double)n_used / ((double)DUP_B1 * (double)(1u << f2_lg)) > 1800.0) f2_lg++;
+        const double per_sub = (double)n_used / ((double)DUP_B1 * (double)(1u << f2_lg));
+        const uint64_t cap2 = dup_cap(per_sub / slices);
+        const uint64_t per_bucket = ((uint64_t)slices << f2_lg) * cap2, need = per_bucket * DUP_B1;
+        DupL2 l2{nullptr, nullptr, DUP_B1, nullptr, f2_lg, slices, cap2, D.flags + 1};
+        {
+            const uint64_t a_words = P.a_recs ? P.a_recs_cap * 2 : 0, b_words = P.b_recs ? P.b_recs_cap * 2 : 0;
+            const uint64_t in_a = std::min<uint64_t>(a_words / per_bucket, DUP_B1);
+            if (in_a + std::min<uint64_t>(b_words / per_bucket, DUP_B1) >= DUP_B1 && in_a > 0) {
+                l2.out_a = reinterpret_cast<uint64_t *>(P.a_recs);
+                l2.out_b = reinterpret_cast<uint64_t *>(P.b_recs);
+                l2.split = (uint32_t)in_a;
+                c->solid_list_fresh = false;  // (the solid list sat in a_recs)
+            } else {
+                rc = ensure_buf(c, &D.l2_own, &D.l2_own_words, need);
+                if (rc) return rc;
+                l2.out_a = D.l2_own;
+                l2.out_b = D.l2_own;
+            }
+        }
+        const uint64_t n_cnt2 = ((uint64_t)DUP_B1 << f2_lg) * slices;
+        rc = ensure_buf(c, &D.l2_counts, &D.l2_counts_cap, n_cnt2);
+        if (rc) return rc;
+        l2.counts = D.l2_counts;
+        HIPCHK(c, hipMemsetAsync(D.flags + 1, 0, sizeof(uint32_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(D.ctr, 0, sizeof(unsigned long long), c->stream));
+        const DupL1 l1{D.l1_keys, D.l1_counts, D.l1_nseg, D.l1_cap, D.flags};
+        hipLaunchKernelGGL(k_dup_scatter, dim3(DUP_B1 * slices), dim3(DUP_THREADS), 0, c->stream, l1, l2);
+        const DupOut lst{D.list, D.ctr, mc_ctx::Dup::LIST_CAP};
+        // (an LDS set of 2^13 32-bit fingerprints, 32 KB: five workgroups a CU; sub-buckets beyond 4 900 keys -- a table of more than
+        // 1.3 G keys -- go through it in passes)
+        hipLaunchKernelGGL(k_dup_find<13>, dim3(std::min<uint32_t>(DUP_B1 << f2_lg, 256u * 40u)), dim3(DUP_FIND_THREADS), 0, c->stream, l2, lst);
+        HIPCHK(c, hipGetLastError());
+        D.l2 = l2;
+        HIPCHK(c, hipMemcpyAsync(c->h_scratch + 20, D.ctr, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_scratch + 21, D.flags, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        uint32_t fl[2];
+        memcpy(fl, c->h_scratch + 21, sizeof fl);
+        if (!fl[0] && !fl[1]) { n_listed = c->h_scratch[20]; break; }
+        // a stream overflowed (the merge kernel's were sized by a hint that fell short, or the keys are far from evenly spread): once
+        // more from a sweep, whose streams are sized by the number of keys the table holds
+        if (attempt >= 1 || !have_l1)
+            return fail(c, MC_EOVERFLOW, "internal: the key streams of the duplicate-key join overflowed (%llu keys)", n_used);
+        have_l1 = false;
+    }
+    if (n_listed) {
+        rc = dup_fixup(c, n_listed);
+        if (rc) return rc;
+    }
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->st.dup_ms += ms;
+    c->st.dup_checks++;
+    c->st.dup_keys = D.n_keys;
+    D.checked = true;
+    D.l2_valid = hash_bins(c);  // (the streams of level 2 hold the table's keys by key until the pipeline takes its buffers back)
+    return MC_OK;
+}
+
 struct PipePlan {
     uint32_t b1 = 0, b2 = 1, g = 0;  // b1 level-1 buckets of b2 leaves each (counts, not bits); a leaf covers 2^g regions
     uint64_t np1 = 0, n_leaves = 0, cap1 = 0, cap2 = 0, spill_cap = 0, wb = 0;
@@ -1305,6 +1594,7 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
     pl->pieces = pieces;
     mc_ctx::Pipe &P = c->pipe;
     c->solid_list_fresh = false;  // the pipeline buffers are about to be reused
+    c->dup.l2_valid = false;      // (... and with them what the key join left there)
     // Make sure the table can take the batch: with a capacity hint that still holds the table was sized for
     // it; without one assume every eighth occurrence is a new key at most.  Either way the merge kernel
     // reports regions that would overflow and the table is grown then.
@@ -1434,7 +1724,7 @@ static int pipe_drain_handed_on(mc_ctx *c, uint64_t n_listed, bool lng = false)
     HIPCHK(c, hipMemcpyAsync(c->d_ovf_leaf_tmp, c->d_ovf_leaf, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_ctr + 7, 0, sizeof(unsigned long long), c->stream));
     hipLaunchKernelGGL(k_add_parked, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->d_ovf_tmp, n, c->view(), c->d_ovf_leaf_tmp, P.leaf_state,
-                       lng && hash_bins(c) ? 1 : 0);
+                       lng && hash_bins(c) ? 1 : 0, lng && hash_bins(c) ? c->dup_l1_view() : DupL1{nullptr, nullptr, 0, 0, nullptr});
     HIPCHK(c, hipGetLastError());
     c->solid_tracked = false;  // (these additions were not watched for crossing the coverage threshold)
     c->solid_list_fresh = false;
@@ -1487,6 +1777,7 @@ static int pipe_resize_by_sample(mc_ctx *c, PipePlan &pl, uint64_t n_records)
     memcpy(fl, c->h_scratch + 25, sizeof fl);
     if (fl[0]) return MC_OK;  // (records were lost: pipe_finish sees the flag too and the batch is counted another way)
     const double est = (double)c->h_scratch[24] * (double)pl.np1 * 1.1 + 1024.0;
+    c->dup.expected_keys = est;  // (what the key streams of dup_check.h are sized by in a context without a hint)
     if (est > 0.45 * (double)SET_SLOTS * (double)pl.np1) return MC_OK;  // (the scratch set was too full to count in: the old way)
     const uint64_t want = regions_for(c, mm_slots_for(c, est, 0.36));
     if (pl.lng && est > 0.40 * (double)(want << c->sb)) return 4;  // (hash keys need their bins roomy, mc_create: the caller takes the per-window form)
@@ -1557,7 +1848,7 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
                  (uint32_t)(c->solid_tracked ? c->cov_hint : 0), c->d_ctr + 6, k, emit, c->ptr_tries, P.flags
         if (pl.lng) {
 #define P3L_ARGS static_cast<const uint4 *>(lk), lc, lcap, leaves, c->view(), virgin, P.leaf_state, P.leaf_new, P.flags + 1, \
-                 (uint32_t)(c->solid_tracked ? c->cov_hint : 0), c->d_ctr + 6, k, emit, P.flags
+                 (uint32_t)(c->solid_tracked ? c->cov_hint : 0), c->d_ctr + 6, k, emit, P.flags, c->dup_l1_view()
             if (k == 63) hipLaunchKernelGGL(k_p3_long<63>, dim3(grid), dim3(P3_THREADS), 0, c->stream, P3L_ARGS);
             else hipLaunchKernelGGL(k_p3_long<0>, dim3(grid), dim3(P3_THREADS), 0, c->stream, P3L_ARGS);
 #undef P3L_ARGS
@@ -1580,6 +1871,12 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
 #undef P3D_ARGS
     };
     auto launch_p3 = [&] { launch_p3_n((uint32_t)n_leaves, p3_grid, c->virgin ? 1 : 0); };
+    // hash keys in minimizer bins: the merge kernel also leaves every key it writes back in the key streams of dup_check.h, sized
+    // by what is known about the number of keys the table will hold
+    if (pl.lng && hash_bins(c) && pl.g == 0)
+        dup_arm(c, c->cfg.capacity_hint ? (double)c->cfg.capacity_hint : c->dup.expected_keys, (uint32_t)p3_grid);
+    else
+        c->dup.l1_armed = false;
     uint32_t flags[3] = {0, 0, 0};
     unsigned long long n_spill = 0, n_handed_on = 0;
     const bool virgin0 = c->virgin;
@@ -1794,7 +2091,8 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
             // (the table was sized by the hint that let this run take long records, and the direct path's usual preparations would
             // move it out of its minimizer bins: the few records that found no room in the streams go in as they are, each to its bin)
             rc = timed(c, &ms4, [&] {
-                hipLaunchKernelGGL(k_skl_add_records, dim3(grid_for(n_spill, 256)), dim3(256), 0, c->stream, P.spill_recs, (uint64_t)n_spill, k, c->view(), thr, c->d_ctr + 6);
+                hipLaunchKernelGGL(k_skl_add_records, dim3(grid_for(n_spill, 256)), dim3(256), 0, c->stream, P.spill_recs, (uint64_t)n_spill, k, c->view(), thr, c->d_ctr + 6,
+                                   c->dup_l1_view());
             });
             if (rc) return rc;
             i = n_spill;
@@ -1809,7 +2107,8 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
             const uint64_t m = std::min<uint64_t>(pl.lng ? std::max<uint64_t>(allowed / SKL_MAX_WINDOWS, 1) : pl.sk ? std::max<uint64_t>(allowed / SK_MAX_WINDOWS, 1) : allowed, n_spill - i);
             rc = timed(c, &ms4, [&] {
                 if (pl.lng)
-                    hipLaunchKernelGGL(k_skl_add_records, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, P.spill_recs + 2 * i, m, k, c->view(), thr, c->d_ctr + 6);
+                    hipLaunchKernelGGL(k_skl_add_records, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, P.spill_recs + 2 * i, m, k, c->view(), thr, c->d_ctr + 6,
+                                       DupL1{nullptr, nullptr, 0, 0, nullptr});  // (by key: the table is in hash-prefix regions by now)
                 else if (pl.sk)
                     hipLaunchKernelGGL(k_sk_add_records, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, P.spill_recs + i, (const uint32_t *)nullptr, m, k,
                                        c->view(), thr, c->d_ctr + 6);
@@ -1932,7 +2231,8 @@ static int add_reads_long(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_
     if (c->cfg.key_mode != MC_KEY_POLY || c->cfg.k < SKL_MIN_K || c->cfg.k > SKL_MAX_K) return 4;
     unsigned long long used;
     uint32_t fatal;
-    int rc = read_counters(c, &used, &fatal);
+    int rc = dup_unmerge(c);  // (slots that hold their keys' sums get their own counts back: the merge kernel adds to whichever slot a bin holds)
+    if (!rc) rc = read_counters(c, &used, &fatal);
     if (rc) return rc;
     // (only a table sized for what it will hold -- by a hint that still holds, or, holding nothing yet, by a sample of this batch: it cannot grow)
     if (fatal || !((c->cfg.capacity_hint && used < c->cfg.capacity_hint) || c->virgin)) return 4;
@@ -2425,6 +2725,20 @@ void mc_destroy(mc_ctx *c)
     if (c->slots) table_release(c, c->slots, c->slots_bytes);
     if (c->solid) (void)hipFree(c->solid);
     c->pipe.release(c->cfg.device);
+    {
+        mc_ctx::Dup &D = c->dup;
+        g_scratch_pool.put(c->cfg.device, D.l1_keys, D.l1_words * 8);
+        g_scratch_pool.put(c->cfg.device, D.l1_counts, D.l1_counts_cap * 4);
+        g_scratch_pool.put(c->cfg.device, D.l2_own, D.l2_own_words * 8);
+        g_scratch_pool.put(c->cfg.device, D.l2_counts, D.l2_counts_cap * 4);
+        if (D.flags) (void)hipFree(D.flags);
+        if (D.ctr) (void)hipFree(D.ctr);
+        if (D.list) (void)hipFree(D.list);
+        if (D.set.qk) (void)hipFree(D.set.qk);
+        if (D.tw) (void)hipFree(D.tw);
+        if (D.pq_mem) (void)hipFree(D.pq_mem);
+        if (D.pq_groups) (void)hipFree(D.pq_groups);
+    }
     c->bfs_pool.clear();
     if (c->d_ctr) (void)hipFree(c->d_ctr);
     if (c->h_scratch) (void)hipHostFree(c->h_scratch);
@@ -2470,6 +2784,7 @@ int mc_clear(mc_ctx *c)
     c->solid_cov = -1; c->solid_external = false;
     c->solid_tracked = true;
     c->solid_list_fresh = false;
+    dup_forget(c);
     return MC_OK;
 }
 
@@ -3191,6 +3506,9 @@ int mc_finalize_counts(mc_ctx *c, uint64_t *n_distinct)
     {
         int rc = materialize(c);
         if (!rc) rc = drain_parked(c);
+        // hash keys in minimizer bins: a key that different k-mers brought to different regions gets the sum of its counters
+        // wherever it is read, and counts once (dup_check.h; src/io/LargeKIOUtils.java:46-49 has one counter a hash)
+        if (!rc) rc = ensure_dups(c);
         if (rc) return rc;
     }
     unsigned long long *h = c->h_scratch;
@@ -3200,7 +3518,8 @@ int mc_finalize_counts(mc_ctx *c, uint64_t *n_distinct)
     if (fatal) return fail(c, MC_EOVERFLOW, "a k-mer table region filled up (hash skew)");
     c->n_used_host = h[0];
     c->finalized = true;
-    if (n_distinct) *n_distinct = h[0] + (h[1] ? 1 : 0);
+    const uint64_t shadows = c->dup.merged ? c->dup.n_tw - c->dup.n_keys : 0;  // (slots beyond a key's first)
+    if (n_distinct) *n_distinct = h[0] - shadows + (h[1] ? 1 : 0);
     return MC_OK;
 }
 
@@ -3478,7 +3797,7 @@ int mc_export_dev(mc_ctx *c, int min_cov, int64_t *d_keys, int16_t *d_counts, ui
     } else {
         HIPCHK(c, hipMemsetAsync(cursor, 0, sizeof(unsigned long long), c->stream));
         hipLaunchKernelGGL(k_export, dim3(grid_for(c->n_slots(), 256)), dim3(256), 0, c->stream, c->slots, c->n_slots(),
-                           min_cov, d_keys, d_counts, d_hints, cap, cursor);
+                           min_cov, d_keys, d_counts, d_hints, cap, cursor, c->dup_filter());
         HIPCHK(c, hipGetLastError());
     }
     unsigned long long n = 0, empty_cnt = 0;
@@ -3635,6 +3954,7 @@ int mc_get_stats(mc_ctx *c, mc_stats *out)
 {
     if (!c || !out) return MC_EINVAL;
     std::lock_guard<std::mutex> g(c->mu);
+    c->st.dup_keys = c->dup.merged ? c->dup.n_keys : 0;
     *out = c->st;
     return MC_OK;
 }
@@ -3671,6 +3991,14 @@ int mc_trim(mc_ctx *c)
     P.a_recs = keep_recs; P.a_recs_cap = keep_cap; P.emit_counts = keep_counts;
     g_scratch_pool.put(dev, c->d_ovf_tmp, c->ovf_tmp_cap * sizeof(uint4));
     c->d_ovf_tmp = nullptr; c->ovf_tmp_cap = 0;
+    {   // the key streams of the duplicate-key join (dup_check.h): the next join starts with a sweep of the table
+        mc_ctx::Dup &D = c->dup;
+        g_scratch_pool.put(dev, D.l1_keys, D.l1_words * 8); D.l1_keys = nullptr; D.l1_words = 0;
+        g_scratch_pool.put(dev, D.l1_counts, D.l1_counts_cap * 4); D.l1_counts = nullptr; D.l1_counts_cap = 0;
+        g_scratch_pool.put(dev, D.l2_own, D.l2_own_words * 8); D.l2_own = nullptr; D.l2_own_words = 0;
+        D.l1_armed = false;
+        D.l2_valid = false;
+    }
     g_scratch_pool.release(dev);
     g_table_pool.release(dev);
     return MC_OK;
@@ -3898,6 +4226,8 @@ int ensure_solid(mc_ctx *c, int min_cov, double *ms)
     }
     c->solid_is_table = false;
     if (c->solid_cov == min_cov && c->solid) return MC_OK;
+    if (c->dup.merged && c->dup.n_tw)  // (a copy is built by key: the keys that sit in several regions meet in hash-prefix regions first)
+        if (int brc = by_key_ready(c)) return brc;
     if (c->solid_external)
         return fail(c, MC_ESTATE, "this context's solid table came from mc_solid_from_pairs_dev at coverage %d; it serves that threshold only",
                     c->solid_external_cov);
@@ -4110,6 +4440,76 @@ void launch_bfs(mc_ctx *c, hipStream_t stream, const BfsState *d_states, uint32_
     }
 }
 
+
+// After a walk over a table of hash keys in minimizer bins: every look-up of it that came back "absent" is asked again by key
+// (dup_check.h, "Look-ups of k-mers that were never counted").  *redo: a key turned up that a string nobody counted had asked for;
+// it has been given a slot in that string's bin, the table has been joined again, and the walks must be repeated.
+int phantom_verify(mc_ctx *c, uint32_t n_jobs, std::vector<std::unique_ptr<BfsJobBuffers>> &B, const std::vector<BfsCtl> &ctl, bool *redo)
+{
+    *redo = false;
+    mc_ctx::Dup &D = c->dup;
+    if (!hash_bins(c) || !c->solid_is_table || c->d_shards || !dup_check_on() || !D.checked || !D.l2_valid) return MC_OK;
+    uint64_t cap = 64;
+    for (uint32_t j = 0; j < n_jobs; j++) cap += ctl[j].n * (B[j]->S.dir == 0 ? 8 : 4) + B[j]->S.n_seeds;
+    if (cap >= (1ull << 32)) return fail(c, MC_EOVERFLOW, "mc_bfs: %llu look-ups to check by key", (unsigned long long)cap);
+    const uint64_t hit_cap = 4096;
+    const uint64_t words = 3 * cap + (cap + 1) / 2 + hit_cap / 2 + 8;  // key, hi, lo; order (32-bit); hits (32-bit); two counters
+    if (D.pq_cap < words) {
+        if (D.pq_mem) (void)hipFree(D.pq_mem);
+        D.pq_mem = nullptr; D.pq_cap = 0;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&D.pq_mem), words * 2 * 8));
+        D.pq_cap = words * 2;
+    }
+    const uint32_t G = DUP_B1 << D.l2.f2_lg;
+    if (D.pq_groups_cap < G) {
+        if (D.pq_groups) (void)hipFree(D.pq_groups);
+        D.pq_groups = nullptr; D.pq_groups_cap = 0;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&D.pq_groups), (uint64_t)G * sizeof(uint32_t)));
+        D.pq_groups_cap = G;
+    }
+    unsigned long long *ctr = D.pq_mem;  // [0] queries, [1] hits
+    PhantomQ q{D.pq_mem + 8, D.pq_mem + 8 + cap, D.pq_mem + 8 + 2 * cap, ctr, cap};
+    uint32_t *next = reinterpret_cast<uint32_t *>(D.pq_mem + 8 + 3 * cap);
+    uint32_t *hits = next + 2 * ((cap + 1) / 2);
+    uint32_t *head = D.pq_groups;
+    HIPCHK(c, hipMemsetAsync(ctr, 0, 2 * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(head, 0xFF, G * sizeof(uint32_t), c->stream));
+    const SolidView t = c->solid_view();
+    const int k = c->cfg.k;
+    for (uint32_t j = 0; j < n_jobs; j++) {
+        const BfsState &S = B[j]->S;
+        const int nb = S.dir == 0 ? 8 : 4;
+#define PQ_LAUNCH(MODE)                                                                                                                               \
+        do {                                                                                                                                          \
+            if (ctl[j].n) hipLaunchKernelGGL(k_phantom_queries<MODE>, dim3(grid_for(ctl[j].n * nb, 256)), dim3(256), 0, c->stream, S.hi, S.lo, (uint64_t)ctl[j].n, nb, S.dir, k, t, q); \
+            if (S.n_seeds) hipLaunchKernelGGL(k_phantom_queries<MODE>, dim3(grid_for(S.n_seeds, 256)), dim3(256), 0, c->stream, S.seed_hi, S.seed_lo, (uint64_t)S.n_seeds, 0, S.dir, k, t, q); \
+        } while (0)
+        if (c->cfg.key_mode == MC_KEY_POLY) PQ_LAUNCH(KEY_POLY); else PQ_LAUNCH(KEY_FNV1A);
+#undef PQ_LAUNCH
+    }
+    hipLaunchKernelGGL(k_pq_link, dim3(256), dim3(256), 0, c->stream, q.key, ctr, cap, D.l2.f2_lg, head, next);
+    hipLaunchKernelGGL(k_pq_match, dim3(std::min<uint32_t>(G, 256u * 16u)), dim3(256), 0, c->stream, D.l2, head, next, q.key, hits, ctr + 1, hit_cap);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_scratch + 20, ctr, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const uint64_t n_hits = c->h_scratch[21];
+    if (n_hits == 0) return MC_OK;
+    // ---- a string nobody counted asked for a key the table holds: the key gets a slot in that string's bin and the join runs again
+    int rc = dup_unmerge(c);
+    if (rc) return rc;
+    const uint64_t nh = std::min<uint64_t>(n_hits, hit_cap);
+    hipLaunchKernelGGL(k_alias_insert, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, c->stream, hits, nh, q, c->view(), k);
+    HIPCHK(c, hipGetLastError());
+    rc = drain_parked(c);  // (no room in that bin's chain: the table gives up its bins, and every look-up is by key from then on)
+    if (rc) return rc;
+    D.checked = false; D.l1_armed = false; D.l2_valid = false;
+    c->solid_tracked = false;  // (slots the merge kernel did not count)
+    rc = ensure_dups(c);
+    if (rc) return rc;
+    *redo = true;
+    return MC_OK;
+}
+
 }  // namespace
 
 int mc_solid_from_pairs_dev(mc_ctx *c, const int64_t *d_keys, const int16_t *d_counts, const uint32_t *d_hints, uint64_t n,
@@ -4173,6 +4573,14 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
     c->pending_solid_ms = 0;
     {
         int rc = ensure_solid(c, min_cov, &total_ms);
+        // (hash keys in minimizer bins: the join of mc_finalize_counts, once more where something has taken its streams since --
+        // the walk's "absent" look-ups are checked against them, phantom_verify)
+        if (!rc && hash_bins(c) && c->solid_is_table && !c->d_shards && dup_check_on() && (!c->dup.checked || !c->dup.l2_valid)) {
+            c->dup.checked = false;
+            c->dup.l1_armed = false;
+            rc = ensure_dups(c);
+            if (!rc) rc = ensure_solid(c, min_cov, &total_ms);
+        }
         if (rc) return rc;
     }
 
@@ -4229,6 +4637,7 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
     std::vector<unsigned long long> box_iters(n_jobs, 0), box_hops(n_jobs, 0), box_levels(n_jobs, 0), box_calls(n_jobs, 0), box_nf(n_jobs, 0), box_m0(n_jobs, 0);
     const uint64_t hdr_bytes = (uint64_t)n_jobs * sizeof(BfsPackHdr);
     BfsPackHdr *h_hdr = nullptr;
+    for (int pass = 0;; pass++) {  // (a pass more where the check of the walk's look-ups by key gave the table a slot: phantom_verify)
     for (int launch = 0;; launch++) {
         for (uint32_t j = 0; j < n_jobs; j++) h_states[j] = B[j]->S;
         // (first launch: states and seeds; later ones, after a job's arrays grew: the states)
@@ -4308,6 +4717,11 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
             S = N;
         }
         if (all_done) break;
+    }
+    bool redo = false;
+    if (int vrc = phantom_verify(c, n_jobs, B, ctl, &redo)) return vrc;
+    if (!redo) break;
+    if (pass >= 8) return fail(c, MC_EOVERFLOW, "mc_bfs: the walk keeps finding keys that strings nobody counted ask for");
     }
 
     int ret = MC_OK;
@@ -5127,6 +5541,7 @@ int mc_group_get_stats(mc_group *g, mc_stats *out)
         t.grows += s.grows; t.spill_keys += s.spill_keys; t.solid_kmers += s.solid_kmers; t.solid_sweeps += s.solid_sweeps;
         t.solid_list_builds += s.solid_list_builds;
         t.long_runs += s.long_runs;
+        t.dup_keys += s.dup_keys; t.dup_checks += s.dup_checks; t.dup_ms = std::max(t.dup_ms, s.dup_ms); t.dup_unchecked |= s.dup_unchecked;
         t.count_ms = std::max(t.count_ms, s.count_ms); t.count_total_ms = std::max(t.count_total_ms, s.count_total_ms);
         t.p1_ms = std::max(t.p1_ms, s.p1_ms); t.p2_ms = std::max(t.p2_ms, s.p2_ms); t.p3_ms = std::max(t.p3_ms, s.p3_ms);
     }

@@ -27,8 +27,26 @@ for it in range(3):
     ctx.clear()
     ctx.reset_stats()
     ctx.add_reads_packed_dev(words, off, R, n_bases)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     nd = ctx.finalize()
+    t_fin = (time.perf_counter() - t0) * 1e3
     st = ctx.stats()
-    print("lib %s: distinct %d long_runs %d p1 %.2f p2 %.2f p3 %.2f ms (count %.2f), spills %d grows %d" % (
-        os.path.basename(os.environ.get("MC_LIB", "product")), nd, st.long_runs, st.p1_ms, st.p2_ms, st.p3_ms, st.count_total_ms, st.spill_keys, st.grows), flush=True)
+    # the walk of configs[2] (direction 0 from the seed gene, coverage 3): host time of the call, its set-up included
+    import numpy as np
+    seed = m.native.synth_genome(GENOME_SEED, 100000, 1000)
+    sv = []
+    for i in range(len(seed) - k + 1):
+        v = 0
+        for c in seed[i:i + k]:
+            v = (v << 2) | int(c)
+        sv.append(v)
+    hi = np.array([v >> 64 for v in sv], dtype=np.uint64)
+    lo = np.array([v & 0xFFFFFFFFFFFFFFFF for v in sv], dtype=np.uint64)
+    t0 = time.perf_counter()
+    res = ctx.bfs(hi, lo, 0, 3, 100000, -1)
+    t_bfs = (time.perf_counter() - t0) * 1e3
+    print("lib %s: distinct %d long_runs %d p1 %.2f p2 %.2f p3 %.2f ms (count %.2f), spills %d grows %d; finalize %.2f ms (key join %.2f ms, %d checks, %d keys in several regions, unchecked %d); walk %.2f ms host / %.2f device, %d vertices" % (
+        os.path.basename(os.environ.get("MC_LIB", "product")), nd, st.long_runs, st.p1_ms, st.p2_ms, st.p3_ms, st.count_total_ms, st.spill_keys, st.grows,
+        t_fin, st.dup_ms, st.dup_checks, st.dup_keys, st.dup_unchecked, t_bfs, res["device_ms"], len(res["hi"])), flush=True)
 ctx.close()
