@@ -2178,6 +2178,8 @@ static uint64_t sk_records_bound(const mc_ctx *c, uint64_t wb, uint64_t nr)
 // base0 / end_abs = read_offsets[r0] / read_offsets[r1].
 static int add_reads_partitioned_once(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_off, uint64_t r0, uint64_t r1,
                                       uint64_t base0, uint64_t end_abs, uint64_t wb);
+static uint64_t max_run_bases(const mc_ctx *c, double windows_per_base);
+constexpr int RC_RESPLIT = 5;  // (internal) the run must be cut again: the table has left its minimizer bins under it and takes one record a window now
 static int add_reads_partitioned(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_off, uint64_t r0, uint64_t r1,
                                  uint64_t base0, uint64_t end_abs, uint64_t wb)
 {
@@ -2275,6 +2277,9 @@ static int add_reads_partitioned_once(mc_ctx *c, const uint64_t *d_words, const 
         if (lrc != 4) return lrc;
         lrc = to_hash_regions(c);
         if (lrc) return lrc;
+        // The run was cut for long records (2^34 bases); one record a window takes far less (39 M reads of 150 bases
+        // at k = 63 pass the 32-bit bucket indices).  The caller cuts what is left again, for the table as it is now.
+        if (end_abs - base0 > max_run_bases(c, (double)wb / (double)std::max<uint64_t>(end_abs - base0, 1))) return RC_RESPLIT;
     }
     const uint64_t n_records = c->mm_k ? sk_records_bound(c, wb, nr) : 0;
     // MC_PIPE_PIECES=n (an experiment, off by default): the reads go through the two scatter levels in n pieces, the
@@ -2527,11 +2532,13 @@ static int rs_append(mc_ctx *c, const uint64_t *d_words, uint64_t first_off, uin
 // bases (114 M reads of 150 bp) stay far below 2^32 records, while one 8-byte key per window (k > 31, hash keys) costs
 // scratch by the window -- those runs take what half the free memory holds, 2^31 to 2^33 bases.
 // Every run reads and rewrites the whole table, so fewer, larger runs are what a large read set wants.
-static uint64_t max_run_bases(const mc_ctx *c, double windows_per_base = 1.0)
+static uint64_t max_run_bases(const mc_ctx *c, double windows_per_base)
 {   // windows_per_base: of the read set at hand (88 / 150 for 150-base reads at k = 63): the scratch is per window
     static const uint64_t env = [] { const char *e = getenv("MC_MAX_RUN_BASES"); return e && *e ? strtoull(e, nullptr, 10) : 0ull; }();
     if (env) return std::max<uint64_t>(env, 1u << 20);
     if (c->mm_k) return 1ull << 34;
+    // (tests: the per-window form's limit alone, so that a run cut for long records is too large for it)
+    if (const char *e = getenv("MC_MAX_RUN_BASES_PER_WINDOW")) if (*e) return std::max<uint64_t>(strtoull(e, nullptr, 10), 1u << 20);
     // a key and a read pointer per window, in pieces (add_reads_partitioned): ~16.5 bytes of scratch per window.  Two
     // thirds of what the device has free may go there (the table is allocated already), between 2^31 and 2^33 bases: every
     // run reads and rewrites the whole table, so few, large runs (configs[2]: 2 instead of 4).
@@ -2558,7 +2565,7 @@ static int add_reads_impl(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_
     const uint64_t total = windows_of(0, n_reads);
     const bool partition = c->count_path == 2 || (c->count_path == 0 && total >= (1ull << 22));
     if (partition) {
-        const uint64_t max_bases = max_run_bases(c);
+        uint64_t max_bases = max_run_bases(c, 1.0);
         uint64_t r = 0;
         while (r < n_reads) {
             uint64_t r1 = (uint64_t)(std::upper_bound(h_off + r, h_off + n_reads + 1, h_off[r] + max_bases) - h_off) - 1;
@@ -2567,6 +2574,7 @@ static int add_reads_impl(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_
             const uint64_t wb = windows_of(r, r1);
             if (wb) {
                 int rc = add_reads_partitioned_any(c, d_words, d_off, r, r1, h_off[r], h_off[r1], wb);
+                if (rc == RC_RESPLIT) { max_bases = max_run_bases(c, 1.0); continue; }  // (nothing of [r, r1) was counted)
                 if (rc) return rc;
             }
             r = r1;
@@ -2978,13 +2986,13 @@ static int add_reads_dev_counted(mc_ctx *c, const uint64_t *d_words, const uint6
     const bool partition = c->count_path == 2 || (c->count_path == 0 && total >= (1ull << 22));
     const double wpb = last_off > first_off ? (double)total / (double)(last_off - first_off) : 1.0;  // windows per base
     if (partition && last_off - first_off < max_run_bases(c, wpb)) {  // one batch: no need for the offsets on the host
-        if (total) {
-            int rc = add_reads_partitioned_any(c, d_words, d_off, 0, n_reads, first_off, last_off, total);
+        int rc = total ? add_reads_partitioned_any(c, d_words, d_off, 0, n_reads, first_off, last_off, total) : MC_OK;
+        if (rc != RC_RESPLIT) {  // (RC_RESPLIT: the long form declined and the batch is too large for one record a window: in runs, below)
             if (rc) return rc;
+            counts_changed(c);
+            c->solid_cov = -1; c->solid_external = false;
+            return MC_OK;
         }
-        counts_changed(c);
-        c->solid_cov = -1; c->solid_external = false;
-        return MC_OK;
     }
     if (partition) {
         // several runs: cut at read boundaries found by bisection on the device's offsets (a few 8-byte copies), each
@@ -3020,6 +3028,7 @@ static int add_reads_dev_counted(mc_ctx *c, const uint64_t *d_words, const uint6
             HIPCHK(c, hipStreamSynchronize(c->stream));
             if (wb) {
                 int rc = add_reads_partitioned_any(c, d_words, d_off, r, r1, off_r, off_r1, wb);
+                if (rc == RC_RESPLIT) continue;  // (nothing of [r, r1) was counted; the next cut is made for the table as it is now)
                 if (rc) return rc;
             }
             r = r1;

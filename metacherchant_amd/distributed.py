@@ -52,6 +52,7 @@ class ShardedCounter:
         # room -- 287 of 288 GB in use, the allocations stall, 1 108 ms against 787 for a run per chunk (profiles/r04_rank_shard_*)
         self.keep_bytes = int(float(os.environ.get("MC_EXCHANGE_KEEP_GB", 12)) * 1e9)
         self.n_count_runs = 0
+        self.pool_rows = 0  # rows of the one receive buffer of the last add_reads_dev call that made one (tests)
         self.pool_slack = float(os.environ.get("MC_EXCHANGE_POOL_SLACK", 1.12))  # the one receive buffer: the first chunk's records x chunks x this
         self.n_pool_misses = 0  # chunks that did not fit it any more (they get tensors of their own; the tests look at it)
         # where a rank's time goes, as its host sees it (seconds, summed over add_reads_dev calls until reset_phases): `extract`
@@ -206,8 +207,16 @@ class ShardedCounter:
         n_recv, n_send = sum(recv_counts), int(off[W])
         # pointers: only the ranks in ptr_sources send theirs; what comes from the others is zero (no pointer)
         all_send = len(ptr_sources) == W
-        if pool["recv"] is None and chunks_left > 1:  # the first of several chunks sizes the buffer for all of them
-            room_all = max(int(n_recv * chunks_left * self.pool_slack) + 1024, 1)
+        if pool["recv"] is None and chunks_left > 1:  # the first of several chunks sizes the buffer for all that are held together
+            # ... which is not all of them where a counting run comes every few chunks (MC_EXCHANGE_COUNT_EVERY) or as soon as
+            # MC_EXCHANGE_KEEP_GB are held (configs[3]: 11 GB a chunk beside a 137 GB table -- a pool for all four chunks pinned 49 GB
+            # through the whole call and brought back the stalls the limit was made for): at most what the limit lets
+            # gather, plus the chunk that crosses it
+            held = chunks_left if not self.count_every else min(chunks_left, self.count_every)
+            row_bytes = (16 if sk else 8) + 4
+            room_all = min(n_recv * held * self.pool_slack, self.keep_bytes / row_bytes + n_recv * self.pool_slack)
+            room_all = max(int(room_all) + 1024, 1)
+            self.pool_rows = room_all
             pool["recv"] = torch.empty((room_all, 2) if sk else room_all, dtype=torch.int64, device=self.device)
             pool["recv_p"] = torch.zeros(room_all, dtype=torch.int32, device=self.device)
             pool["at"] = 0

@@ -106,7 +106,7 @@ class OracleBackedContext:
         return n
 
 
-def _worker(rank, world, port, k, mode, reads, L, n_reads, min_cov, q, records=False, chunk_reads=0, share0=None, count_every=0, pool_slack=None):
+def _worker(rank, world, port, k, mode, reads, L, n_reads, min_cov, q, records=False, chunk_reads=0, share0=None, count_every=0, pool_slack=None, keep_gb=None):
     # chunk_reads: MC_EXCHANGE_CHUNK_READS (0: the default, one chunk here); share0: reads of rank 0 (None: equal shares)
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -117,6 +117,8 @@ def _worker(rank, world, port, k, mode, reads, L, n_reads, min_cov, q, records=F
             os.environ["MC_EXCHANGE_CHUNK_READS"] = str(chunk_reads)
         if count_every:
             os.environ["MC_EXCHANGE_COUNT_EVERY"] = str(count_every)  # (what bounds the memory of the kept chunks at configs[3]'s size)
+        if keep_gb is not None:
+            os.environ["MC_EXCHANGE_KEEP_GB"] = repr(keep_gb)  # (a counting run as soon as this much is held)
         if pool_slack is not None:
             os.environ["MC_EXCHANGE_POOL_SLACK"] = str(pool_slack)  # (the one receive buffer too small: later chunks get tensors of their own)
         from metacherchant_amd.distributed import ShardedCounter, split_reads
@@ -138,7 +140,7 @@ def _worker(rank, world, port, k, mode, reads, L, n_reads, min_cov, q, records=F
         assert all(native.key_owner(int(x), world) == rank for x in own_keys[:500])
         if rank == 0:
             sk, scnt = solid.t.dump()
-            q.put((total, n_solid, sk, scnt, sc.bytes_sent, sc.n_chunks, sc.n_count_runs, sc.n_pool_misses))
+            q.put((total, n_solid, sk, scnt, sc.bytes_sent, sc.n_chunks, sc.n_count_runs, sc.n_pool_misses, sc.pool_rows))
     finally:
         dist.destroy_process_group()
 
@@ -209,7 +211,7 @@ def test_sharded_count_equals_single_table(k, mode, records, chunk_reads, share0
     procs = [ctx.Process(target=_worker, args=(r, 2, port, k, mode, reads, L, n_reads, min_cov, q, records, chunk_reads, share0, count_every, pool_slack)) for r in range(2)]
     for p in procs:
         p.start()
-    total, n_solid, sk, scnt, sent, n_chunks, runs, pool_misses = q.get(timeout=120)
+    total, n_solid, sk, scnt, sent, n_chunks, runs, pool_misses, _ = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -223,6 +225,36 @@ def test_sharded_count_equals_single_table(k, mode, records, chunk_reads, share0
     # however many chunks travelled: ONE counting run (a run rewrites the rank's whole table), unless the memory bound asks for more
     assert runs == (1 if not count_every else -(-n_chunks // count_every))
     assert (pool_misses > 0) == (pool_slack is not None)  # (every chunk of a run lands in the one buffer unless it was made too small)
+
+
+def test_receive_pool_holds_what_may_gather_between_counting_runs():
+    """the one receive buffer was sized for ALL remaining chunks whatever MC_EXCHANGE_COUNT_EVERY / MC_EXCHANGE_KEEP_GB
+    allow to gather (configs[3]: 49 GB pinned through the call beside a 137 GB table).  Five chunks: with a counting run every two
+    chunks, or as soon as ~1.5 chunks' bytes are held, the buffer is well under half of the unlimited one -- same table either way."""
+    from metacherchant_amd import build
+    build.build_lib()
+    from oracle import pyoracle as po
+    from tests.helpers import synth_case
+    L, n_reads, min_cov, k = 100, 300, 2, 31
+    _, reads, off = synth_case(1, 3000, n_reads, L, 100)
+    t = po.Table()
+    t.count_reads(reads, off, k, 0)
+    rows = {}
+    for name, count_every, keep_gb in (("all", 0, None), ("every2", 2, None), ("keep", 0, 1.5e-5)):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, k, 0, reads, L, n_reads, min_cov, q, True, 64, 294, count_every, None, keep_gb)) for r in range(2)]
+        for p in procs:
+            p.start()
+        total, n_solid, sk, scnt, sent, n_chunks, runs, pool_misses, pool_rows = q.get(timeout=120)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert total == t.size() and n_chunks == 5
+        rows[name] = (pool_rows, runs)
+    assert rows["all"][1] == 1 and rows["every2"][1] == 3 and rows["keep"][1] >= 2, rows
+    assert rows["every2"][0] < 0.55 * rows["all"][0] and rows["keep"][0] < 0.7 * rows["all"][0], rows
 
 
 def test_split_reads_covers_everything():

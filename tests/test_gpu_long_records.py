@@ -221,3 +221,41 @@ def test_long_records_without_a_read_store_and_through_a_kmers_file(mc, monkeypa
     _walks(other, t, k, genome, 3)
     other.close()
     ctx.close()
+
+
+def test_a_run_cut_for_long_records_is_cut_again_when_the_long_form_declines(mc, monkeypatch):
+    """a k = 33 .. 63 context cuts its batches for long records (2^34 bases a run).  When the long form declines at run
+    time -- here: a second batch into a table no hint vouches for -- the table moves to hash-prefix regions and the batch takes one
+    record a window, for which the run may be far too large (32-bit bucket indices, scratch).  The caller must cut it again.
+    MC_MAX_RUN_BASES_PER_WINDOW plays the small limit: the second batch goes through in several runs, same counts as the oracle."""
+    monkeypatch.setenv("MC_COUNT_PATH", "partition")
+    monkeypatch.delenv("MC_LONG_RECORDS", raising=False)
+    monkeypatch.setenv("MC_MAX_RUN_BASES_PER_WINDOW", str(1 << 21))
+    k = 47
+    genome, reads, off = synth_case(2, 200000, 60000, 150, 50)
+    t, _ = oracle_table(reads, off, k, po.KEY_POLY)
+    ctx = mc.Context(k, mc.KEY_POLY, 0, 0)
+    cut = 20000
+    ctx.add_reads_packed(po.pack(reads[:off[cut]]), off[:cut + 1])          # long records, table sized by the sample
+    assert ctx.stats().long_runs == 1
+    launches = ctx.stats().count_launches
+    ctx.add_reads_packed(po.pack(reads[off[cut]:]), off[cut:] - off[cut])   # 6 M bases: declined, then three runs of <= 2 M bases
+    st = ctx.stats()
+    assert st.long_runs == 1 and st.count_launches - launches >= 3, (st.long_runs, st.count_launches - launches)
+    assert ctx.finalize() == t.size()
+    gk, gc = ctx.export(0)
+    ok, oc = t.dump()
+    assert np.array_equal(gk, ok) and np.array_equal(gc, oc)
+    # ... and the same from device memory (mc_add_reads_packed_dev cuts by bisection on the device's offsets)
+    import torch
+    ctx2 = mc.Context(k, mc.KEY_POLY, 0, 0)
+    ctx2.add_reads_packed(po.pack(reads[:off[cut]]), off[:cut + 1])
+    w = torch.from_numpy(po.pack(reads[off[cut]:]).view(np.int64)).to("cuda:0")
+    o = torch.from_numpy((off[cut:] - off[cut]).astype(np.int64)).to("cuda:0")
+    ctx2.add_reads_packed_dev(w, o, len(off) - 1 - cut, int(off[-1] - off[cut]))
+    assert ctx2.stats().count_launches >= 4
+    assert ctx2.finalize() == t.size()
+    gk, gc = ctx2.export(0)
+    assert np.array_equal(gk, ok) and np.array_equal(gc, oc)
+    ctx.close()
+    ctx2.close()
