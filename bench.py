@@ -442,6 +442,9 @@ def config2_leg(args, m, torch, dev, local_rank, d_words, d_off, R, L, n_bases):
            "table_bytes": int(st.table_bytes),
            "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                         "bytes_per_kmer": round(A, 3), "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches / args.config2_steps,
+                        #  `achieved` prices every window at SURVEY 8(d)'s algorithmic bytes -- the reference's own per-window
+                        # traffic --, whatever travels: a long-record run moves 32 bytes per ~16 windows between the levels, not 12 a window
+                        "bytes_model": "algorithmic, per window (SURVEY.md 8d); what the kernels really move: profiles/r06_pmc_hbm_traffic_config2_scaled.csv",
                         "form": "long records (csrc/count_long.h)" if st.long_runs else "a key per window",
                         "kernel_ms": dict(zip(("k_skl_extract", "k_sk2_scatter_compact<2,2>", "k_p3_long") if st.long_runs else
                                               ("k_p1_extract_scatter", "k_p2_scatter", "k_p3_merge"),
@@ -456,6 +459,23 @@ def config2_leg(args, m, torch, dev, local_rank, d_words, d_off, R, L, n_bases):
             out["ms_per_step_unchecked"] = round(1e3 * unchecked / args.config2_steps, 3)
     ctx.close()
     return out
+
+
+def _cpu_full_note():
+    """the 1 M-read sample flatters the port (its table fits the last-level caches); the whole-workload figure that
+    --cpu-baseline-full measured once a round is quoted beside it (the newest profiles/r*_bench_e1_cpu_full.json)."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_e1_cpu_full.json"))):
+        try:
+            cb = json.load(open(f)).get("cpu_baseline") or {}
+            if cb.get("value"):
+                best = (os.path.basename(f), cb["value"], cb.get("cores"))
+        except Exception:
+            pass
+    if not best:
+        return ""
+    return "; on the WHOLE workload (%s: the table no longer fits the caches) the same port reaches %.1f M k-mers/s on %s threads" % (best[0], best[1] / 1e6, best[2])
 
 
 def cpu_baseline(args, k, mode, L):
@@ -502,7 +522,7 @@ def cpu_baseline(args, k, mode, L):
     return {"value": w / (sec + bfs_sec), "unit": "k-mers/s", "cores": cores, "kind": "port",
             "sample": "count + BFS on %d reads of the same kind over one %d-base contig (the workload's %.0f-fold depth; %d k-mer "
                       "occurrences, %d distinct): counting %.2f s on %d threads (%.1f M k-mers/s), BFS %.3f s on one thread "
-                      "(%d vertices)" % (n, glen, depth, w, nd, sec, cores, w / sec / 1e6, bfs_sec, reached)}
+                      "(%d vertices)%s" % (n, glen, depth, w, nd, sec, cores, w / sec / 1e6, bfs_sec, reached, _cpu_full_note())}
 
 
 def java_baseline(args, k, L, n, genome, reads, cores, jar):

@@ -332,6 +332,12 @@ typedef struct {
     uint64_t dup_checks;     /* joins of the table's keys by key that found that out (csrc/dup_check.h), ... */
     double dup_ms;           /* ... and their summed device time */
     uint64_t dup_unchecked;  /* 1: MC_DUP_CHECK=0 skipped the join for the table as it is now */
+    uint64_t left_bins;      /* hash keys of 33 .. 63 bases: 0 while the table is in minimizer bins (reads travel as long records), else why
+                                it moved to hash-prefix regions for good (reads take one record a window from then on, ~3 x the counting
+                                time): 1 something came or asked by key (mc_add_keys_dev, mc_add_pairs_dev, mc_load_kmers, mc_shard_export,
+                                a copy of the solid k-mers), 2 a batch of under 2^22 windows took the direct kernel, 3 nothing vouched for
+                                the table's size when a batch came (no capacity_hint that still holds, and the table not empty), 4 bins
+                                overflowed or the table had to grow, 5 more keys in several regions than the join's lists take */
 } mc_stats;
 int mc_get_stats(mc_ctx *ctx, mc_stats *out);
 int mc_reset_stats(mc_ctx *ctx);

@@ -16,7 +16,7 @@ CLI = os.path.join(LIBDIR, "metacherchant")
 
 HIP_SOURCES = ["mcgpu.hip", os.path.join("host", "envfinder.cpp")]  # (the read-file entry point uses the host reader)
 # every header under csrc/ (mcgpu.hip includes them all; a stale library would travel to the GPU box unnoticed)
-HIP_DEPS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("host", "envfinder.h"),
+HIP_DEPS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("host", "envfinder.h"), os.path.join("test", "bfs_old_race.h"),
                                                                       os.path.join(ROOT, "include", "mcgpu.h")]
 
 

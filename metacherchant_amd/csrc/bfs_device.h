@@ -115,6 +115,17 @@ __device__ __forceinline__ void bfs_fuzz(uint32_t point)
 #define BFS_FUZZ(p) do {} while (0)
 #endif
 #define BFS_SYNC() do { __syncthreads(); BFS_FUZZ(__LINE__); } while (0)
+// Four places of the walk where round 3 let a wave decide about barriers from words another wave was about to overwrite
+// (DESIGN.md section 3.3).  The product has the fixed forms below; round 3's forms live in csrc/test/bfs_old_race.h, which only a
+// build with -DMC_BFS_OLD_RACE (tests/test_gpu_bfs_race.py: the fuzzed old kernel must fail) pulls in.
+#ifdef MC_BFS_OLD_RACE
+#include "test/bfs_old_race.h"
+#else
+#define BFS_DECIDED_SYNC() BFS_SYNC()
+#define BFS_PATH_RESET_EARLY(L, tid) do {} while (0)
+#define BFS_PATH_RESET(L, tid) do { if ((tid) < SCOUT_MAX_F) { (L).plen[tid] = 0; (L).ppos[tid] = 0; (L).pdone[tid] = 0; } } while (0)
+#define BFS_CHUNK_LOOP(c0) for (unsigned long long c0 = ctl_ld(&ctl->c0);; c0 += BFS_THREADS)
+#endif
 
 // -DMC_BFS_TRACE: a ring of 8-word records per job, one per narrow round (tid 0) and one per run of the companion; the host
 // dumps it when the self-check of a walk (k_bfs_check) finds something, or always with MC_BFS_TRACE_DUMP=<file>.
@@ -1674,15 +1685,13 @@ __device__ __forceinline__ void bfs_narrow(const BfsState &S, const SolidView &t
                 // wait until every walker has something ahead of it (or is known to have nothing)
                 bool used_up = true;
                 for (uint32_t a = 0; a < F; a++) used_up = used_up && L.pdone[a] != 0;
-#ifndef MC_BFS_OLD_RACE
                 // `avail` and `used_up` decide which barriers a wave meets, and the threads that poll the mailbox below store
                 // to the very words they were read from (plen, pdone): no wave may get that far while another still reads.
                 // (Round 3 had no barrier here.  A wave that shares its SIMD with another kernel's waves can be microseconds
                 // late: it then saw a path where the others saw none, left this branch and ran one barrier out of step with
                 // its workgroup from there on -- the vertices of the last round entered the index too late for the look-ups
                 // that needed them, and the walk appended vertices it already had: gpurun_out/soak_r3.log:80.)
-                BFS_SYNC();
-#endif
+                BFS_DECIDED_SYNC();
                 uint32_t seq = seq0;
                 if (!open0 || used_up) {
                     seq = seq0 + 1;
@@ -1699,20 +1708,12 @@ __device__ __forceinline__ void bfs_narrow(const BfsState &S, const SolidView &t
                         box->right[tid] = L.wright[tid];
                     }
                     if (tid == 0) { box->F = F; box->budget = (uint32_t)min((long long)PATH_CAP, lv_left); }
-#ifdef MC_BFS_OLD_RACE
-                    // (round 3 as shipped: the reset in front of the barrier.  `avail` and `used_up` above come from these very
-                    // words, and they decide whether a wave takes this branch and its barriers: a wave late enough to read the
-                    // new plen beside the old ppos gets avail = 2^32 - ppos, leaves the branch and is one barrier out of step with
-                    // the rest of the workgroup from then on -- tests/test_gpu_bfs_race.py builds this on purpose.)
-                    if (tid < SCOUT_MAX_F) { L.plen[tid] = 0; L.ppos[tid] = 0; L.pdone[tid] = 0; }
-#endif
+                    BFS_PATH_RESET_EARLY(L, tid);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                     BFS_SYNC();
-#ifndef MC_BFS_OLD_RACE
                     // behind the barrier: every wave has taken its decisions from the old values (the polling below starts
                     // with these threads' own stores, then a barrier)
-                    if (tid < SCOUT_MAX_F) { L.plen[tid] = 0; L.ppos[tid] = 0; L.pdone[tid] = 0; }
-#endif
+                    BFS_PATH_RESET(L, tid);
                     if (tid == 0) { st_u32(&box->req_seq, seq); L.req_seq = seq; L.req_open = 1; }
                 }
                 bool ready = false;
@@ -1745,9 +1746,7 @@ __device__ __forceinline__ void bfs_narrow(const BfsState &S, const SolidView &t
             }
             if (inline_scout) {
                 const uint32_t budget = (uint32_t)min((long long)min(budget0, PATH_CAP), lv_left);
-#ifndef MC_BFS_OLD_RACE
-                BFS_SYNC();  // scout_run ends with stores to plen / ppos, which every wave read for `avail` above
-#endif
+                BFS_DECIDED_SYNC();  // scout_run ends with stores to plen / ppos, which every wave read for `avail` above
                 if (wv < F) scout_run<MODE, SH>(S, t, L, wv, k, min_cov, budget, lookups);
                 BFS_SYNC();
                 avail = 0xFFFFFFFFu;
@@ -2098,14 +2097,8 @@ __global__ void __launch_bounds__(BFS_THREADS) k_bfs(const BfsState *__restrict_
     // seeds: every window with reads.get(key) >= minOccurences, in order (:159-192)
     if (!ctl_ld(&ctl->seeds_done)) {
         // (the chunk counter is read ONCE: behind the loop thread 0 resets it, and a wave that came late to a second read
-        // would see 0 and start over, alone, one barrier out of step with the others -- MC_BFS_OLD_RACE keeps round 3's loop
-        // for tests/test_gpu_bfs_race.py)
-#ifdef MC_BFS_OLD_RACE
-        for (;;) {
-            const unsigned long long c0 = ctl_ld(&ctl->c0);
-#else
-        for (unsigned long long c0 = ctl_ld(&ctl->c0);; c0 += BFS_THREADS) {
-#endif
+        // would see 0 and start over, alone, one barrier out of step with the others)
+        BFS_CHUNK_LOOP(c0) {
             if (c0 >= S.n_seeds) break;
             if (ctl_ld(&ctl->n) + BFS_THREADS > S.dcap) {
                 if (tid == 0) ctl_st(&ctl->status, BFS_NEED_GROW);
@@ -2153,12 +2146,7 @@ __global__ void __launch_bounds__(BFS_THREADS) k_bfs(const BfsState *__restrict_
         const long long level = ctl_ld(&ctl->level);
         const bool radius_ok = max_radius < 0 || level + 1 <= max_radius;  // newDistance > threshold -> false
         const unsigned long long ncand = (le - lb) * (unsigned long long)nb;
-#ifdef MC_BFS_OLD_RACE
-        for (;;) {
-            const unsigned long long c0 = ctl_ld(&ctl->c0);
-#else
-        for (unsigned long long c0 = ctl_ld(&ctl->c0);; c0 += BFS_THREADS) {  // (read once: see the seeds' loop)
-#endif
+        BFS_CHUNK_LOOP(c0) {  // (read once: see the seeds' loop)
             if (c0 >= ncand) break;
             if (ctl_ld(&ctl->n) + BFS_THREADS > S.dcap) {
                 if (tid == 0) ctl_st(&ctl->status, BFS_NEED_GROW);

@@ -1316,31 +1316,33 @@ __global__ void __launch_bounds__(PT_THREADS, ITEMS * RW <= 3 ? 8 : 4) k_sk2_sca
             }
             __syncthreads();
             v4u rec[ITEMS], rec2[ITEMS];
-            uint32_t d[ITEMS], rank[ITEMS], seg_of[ITEMS];
-            bool have[ITEMS];
+            // (dr: leaf << 16 | rank in the leaf's run of this tile, or NONE for a thread without a record -- one register an item where
+            // leaf, rank, segment and a flag were four: at 64 registers a thread the kernel kept 16 of them in scratch memory)
+            constexpr uint32_t NONE = 0xFFFFFFFFu;
+            uint32_t dr[ITEMS];
             uint32_t sg = L.tile_seg;
             static_for<ITEMS>([&](auto J) {
                 constexpr int j = decltype(J)::value;
                 const uint32_t e = first + (uint32_t)j * PT_THREADS + tid;
-                have[j] = e < total;
-                if (have[j]) {
+                dr[j] = NONE;
+                if (e < total) {
                     while (e >= L.seg_prefix[sg + 1]) sg++;
                     const uint64_t at = ((uint64_t)bucket * nseg_in + sg) * seg_cap1 + (e - L.seg_prefix[sg]);
                     rec[j] = ld_v4u(&in_recs[at * RW]);
                     if (RW == 2) rec2[j] = ld_v4u(&in_recs[at * RW + 1]);
-                    seg_of[j] = sg;
+                    dr[j] = sg;  // (the segment, until the record has arrived)
                 }
             });
             static_for<ITEMS>([&](auto J) {
                 constexpr int j = decltype(J)::value;
-                if (have[j]) {
+                if (dr[j] != NONE) {
                     // (long records: the bin word's top 24 bits sit in the second word above the window count -- the leaf is worked out here,
                     // for the table as it is now --, the position has the first word to itself)
-                    d[j] = RW == 2 ? mulhi32(rec[j].y & 0xFFFFFF00u, n_buckets1 * m2) - bucket * m2 : rec[j].x >> SKC_REL_BITS;
+                    const uint32_t dj = RW == 2 ? mulhi32(rec[j].y & 0xFFFFFF00u, n_buckets1 * m2) - bucket * m2 : rec[j].x >> SKC_REL_BITS;
                     if (RW == 2) rec[j].y &= 0xFFu;
-                    rank[j] = atomicAdd(&L.cnt[d[j]], 1u);
-                    const uint64_t pos = pos0 + (uint64_t)seg_of[j] * seg_bases + (RW == 2 ? rec[j].x : rec[j].x & ((1u << SKC_REL_BITS) - 1u));
+                    const uint64_t pos = pos0 + (uint64_t)dr[j] * seg_bases + (RW == 2 ? rec[j].x : rec[j].x & ((1u << SKC_REL_BITS) - 1u));
                     rec[j].x = ptr_base == ~0ull ? 0u : ptr_encode(ptr_base + pos);
+                    dr[j] = (dj << 16) | atomicAdd(&L.cnt[dj], 1u);  // (a tile holds TILE <= 5 * 1024 records: the rank fits 16 bits)
                 }
             });
             __syncthreads();
@@ -1352,11 +1354,12 @@ __global__ void __launch_bounds__(PT_THREADS, ITEMS * RW <= 3 ? 8 : 4) k_sk2_sca
             __syncthreads();
             static_for<ITEMS>([&](auto J) {
                 constexpr int j = decltype(J)::value;
-                if (have[j]) {
-                    const uint32_t at = L.off[d[j]] + rank[j];
+                if (dr[j] != NONE) {
+                    const uint32_t dj = dr[j] >> 16;
+                    const uint32_t at = L.off[dj] + (dr[j] & 0xFFFFu);
                     st_v4u(&L.rec[at * RW], rec[j]);
                     if (RW == 2) st_v4u(&L.rec[at * RW + 1], rec2[j]);
-                    L.leaf[at] = (uint16_t)d[j];
+                    L.leaf[at] = (uint16_t)dj;
                 }
             });
             __syncthreads();

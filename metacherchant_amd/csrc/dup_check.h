@@ -182,7 +182,7 @@ struct DupOut {
     unsigned long long *n;      // how many were listed (may pass cap: the list is then incomplete and the caller says so)
     uint64_t cap;
 };
-constexpr int DUP_FIND_THREADS = 256, DUP_FIND_ITEMS = 8;
+constexpr int DUP_FIND_ITEMS = 8;
 constexpr uint32_t DUP_MAX_CAND = 32;
 // a second 32-bit word of the key for the set's entries (never 0: that is a free slot)
 __host__ __device__ __forceinline__ uint32_t dup_fp(uint64_t key)
@@ -192,7 +192,9 @@ __host__ __device__ __forceinline__ uint32_t dup_fp(uint64_t key)
     x ^= x >> 16;
     return x | 1u;
 }
-template <int SET_LG>
+// <13, 256>: 32 KB of LDS, five workgroups a CU, sub-buckets up to 4 900 keys in one pass; <15, 1024>: 128 KB, one workgroup a CU, up to
+// 19 600 (a table of more than 1.2 G keys: configs[2] at full size has 17 500 a sub-bucket)
+template <int SET_LG, int DUP_FIND_THREADS>
 __global__ void __launch_bounds__(DUP_FIND_THREADS) k_dup_find(DupL2 in, DupOut out)
 {
     // The set holds 32-bit fingerprints: what bounds this kernel is the rate of LDS compare-and-swaps, and a 64-bit one costs twice a
@@ -440,6 +442,41 @@ __global__ void __launch_bounds__(256) k_pq_match(DupL2 in, const uint32_t *__re
                             if (at < hit_cap) hits[at] = qi[j];
                         }
                 }
+            }
+        }
+    }
+}
+// ... the same check where the join's streams are gone (mc_trim, a pipeline run since): the queries as a set in global memory, one
+// sweep of the table, every slot whose key is in the set names the query that brought it (the first of several with one key).
+__global__ void k_pq_set_build(const unsigned long long *__restrict__ keys, const unsigned long long *__restrict__ n_ptr, uint64_t cap, unsigned long long *qk, uint32_t *qidx,
+                               uint64_t mask)
+{
+    const uint64_t n = min((uint64_t)*n_ptr, cap);
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t key = keys[i];
+        for (uint64_t s = fmix64(key) & mask;; s = (s + 1) & mask) {
+            const unsigned long long old = atomicCAS(&qk[s], ~0ull, (unsigned long long)key);
+            if (old == ~0ull) { qidx[s] = (uint32_t)i; break; }
+            if (old == key) break;
+        }
+    }
+}
+__global__ void k_pq_sweep(const Slot *__restrict__ slots, uint64_t n_slots, const unsigned long long *__restrict__ qk, const uint32_t *__restrict__ qidx, uint64_t mask,
+                           uint32_t *hits, unsigned long long *n_hits, uint64_t hit_cap)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += stride) {
+        const uint4 raw = *reinterpret_cast<const uint4 *>(slots + i);
+        const uint64_t key = ((uint64_t)raw.y << 32) | raw.x;
+        if (key == EMPTY_KEY) continue;
+        for (uint64_t s = fmix64(key) & mask;; s = (s + 1) & mask) {
+            const unsigned long long v = qk[s];
+            if (v == ~0ull) break;
+            if (v == key) {
+                const unsigned long long at = atomicAdd(n_hits, 1ull);
+                if (at < hit_cap) hits[at] = qidx[s];
+                break;
             }
         }
     }

@@ -285,7 +285,7 @@ struct mc_ctx {
     int shard_owner_mm_k = 0;
     // A walker attaches the same tables step after step (bench.py: every step; the CLI: every batch of seeds): a mapping stays
     // open while its handle keeps coming (in_use: part of the current attachment) and is closed when it has not for a while.
-    struct IpcMap { hipIpcMemHandle_t h; void *p; bool in_use; };
+    struct IpcMap { hipIpcMemHandle_t h; void *p; bool in_use; uint64_t addr, bytes; };  // (addr, bytes: the block in its owner's process -- a handle alone may be handed out again for another block)
     std::vector<IpcMap> ipc_opened;
     bool extract_by_minimizer = false; // mc_group: the next mc_extract_keys_dev call deals the keys to the owners of their minimizers (sk_owner), as the group's records are dealt (consumed by that call)
     uint4 *d_ovf_tmp = nullptr;        // pipe_drain_handed_on: the list moved aside while it is drained
@@ -1117,8 +1117,11 @@ static void dup_forget(mc_ctx *c)
     c->st.dup_keys = 0;
     c->st.dup_unchecked = 0;
 }
-static int to_hash_regions(mc_ctx *c);
-static inline int by_key_ready(mc_ctx *c) { return hash_bins(c) ? to_hash_regions(c) : MC_OK; }
+// why: what mc_stats.left_bins reports (include/mcgpu.h): 1 something came or asked by key (a key stream, mc_load_kmers, mc_shard_export, a
+// copy of the solid k-mers), 2 a small batch took the direct kernel, 3 the long form declined a batch (nothing vouched for the table's
+// size), 4 bins overflowed or the table had to grow, 5 more keys sat in several regions than the join's lists take
+static int to_hash_regions(mc_ctx *c, int why = 1);
+static inline int by_key_ready(mc_ctx *c, int why = 1) { return hash_bins(c) ? to_hash_regions(c, why) : MC_OK; }
 
 static int table_grow(mc_ctx *c, uint64_t new_regions)
 {
@@ -1130,7 +1133,7 @@ static int table_grow(mc_ctx *c, uint64_t new_regions)
         return rc;
     }
     if (hash_bins(c)) {
-        int rc = to_hash_regions(c);
+        int rc = to_hash_regions(c, 4);
         if (rc) return rc;
         new_regions = regions_for(c, new_regions << c->sb);  // (a power of two now)
         if (new_regions <= c->n_regions) return MC_OK;
@@ -1160,9 +1163,10 @@ static int table_grow(mc_ctx *c, uint64_t new_regions)
 // variants of one locus share its minimizer and outnumber a region's 4096 slots -- no number of regions helps.  The
 // context then gives up minimizer bins for good: regions by the key's own hash, as for hash keys and short k-mers
 // (reads take the per-window pipeline from here on), with everything counted so far moved over.
-static int to_hash_regions(mc_ctx *c)
+static int to_hash_regions(mc_ctx *c, int why)
 {
     if (!c->mm_k) return MC_OK;
+    if (hash_bins(c)) c->st.left_bins = (uint64_t)why;  // (the long-record form ends here for good, and only mc_stats.grows used to show it)
     if (int urc = dup_unmerge(c)) return urc;  // (equal keys meet in the new table: their own counts add up there)
     TableSwap sw(c);
     HIPCHK(c, hipMemcpyAsync(&sw.old_used, c->d_ctr, sizeof sw.old_used, hipMemcpyDeviceToHost, c->stream));
@@ -1209,7 +1213,7 @@ static int drain_parked(mc_ctx *c)
         HIPCHK(c, hipMemcpyAsync(tmp.p, c->d_ovf, n * sizeof(uint4), hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_ctr + 7, 0, sizeof(unsigned long long), c->stream));
         // (minimizer bins: if two doublings did not make room, the crowd shares one bin)
-        int rc = (c->mm_k && attempt >= 2) ? to_hash_regions(c) : table_grow(c, c->n_regions * 2);
+        int rc = (c->mm_k && attempt >= 2) ? to_hash_regions(c, 4) : table_grow(c, c->n_regions * 2);
         if (rc) return rc;
         c->solid_tracked = false;  // (these additions were not watched for crossing the coverage threshold)
         c->solid_list_fresh = false;
@@ -1223,7 +1227,7 @@ static int drain_parked(mc_ctx *c)
 // next launch without the load factor passing 0.85 even if every one is a new key.
 static int table_reserve(mc_ctx *c, uint64_t incoming, uint64_t *allowed)
 {
-    int mrc = by_key_ready(c);  // (what follows goes in by key)
+    int mrc = by_key_ready(c, 2);  // (what follows goes in by key: the direct kernel)
     if (!mrc) mrc = materialize(c);
     if (!mrc) mrc = drain_parked(c);  // (what the previous launch could not place)
     if (mrc) return mrc;
@@ -1353,6 +1357,47 @@ static int dup_small_bufs(mc_ctx *c)
     return MC_OK;
 }
 
+// Before the join takes tens of GB beside a table that fills half the device: blocks that sit idle in the process-wide pools go back
+// to the driver when less than `need` + 6 GB is free (an allocation that only just fits leaves a later kernel launch nothing for its
+// own bookkeeping: configs[2] at full size after other contexts of the process had left their blocks in the pools).
+static void dup_make_room(mc_ctx *c, uint64_t need_bytes)
+{
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return; }
+    if ((uint64_t)fr >= need_bytes + (6ull << 30)) return;
+    (void)hipStreamSynchronize(c->stream);
+    g_scratch_pool.release(c->cfg.device);
+    g_table_pool.release(c->cfg.device);
+}
+
+// The key streams of the join go back to the scratch pool (mc_trim, or a result buffer that does not fit beside them: 84 GB at
+// configs[2]'s full size): the next long run's merge kernel gets new ones, a walk's check by key sweeps the table instead.
+static void dup_release_streams(mc_ctx *c)
+{
+    mc_ctx::Dup &D = c->dup;
+    const int dev = c->cfg.device;
+    (void)hipStreamSynchronize(c->stream);
+    g_scratch_pool.put(dev, D.l1_keys, D.l1_words * 8); D.l1_keys = nullptr; D.l1_words = 0;
+    g_scratch_pool.put(dev, D.l1_counts, D.l1_counts_cap * 4); D.l1_counts = nullptr; D.l1_counts_cap = 0;
+    g_scratch_pool.put(dev, D.l2_own, D.l2_own_words * 8); D.l2_own = nullptr; D.l2_own_words = 0;
+    D.l1_armed = false;
+    if (D.l2.out_a && D.l2.out_a != reinterpret_cast<uint64_t *>(c->pipe.a_recs)) D.l2_valid = false;  // (streams borrowed from the pipeline stay)
+}
+// a result buffer for the caller: when the device is full, the join's streams and the pools' idle blocks make room
+template <typename T>
+static hipError_t alloc_result(mc_ctx *c, DevBuf<T> &b, size_t n)
+{
+    hipError_t e = b.alloc(n);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        dup_release_streams(c);
+        g_scratch_pool.release(c->cfg.device);
+        g_table_pool.release(c->cfg.device);
+        e = b.alloc(n);
+    }
+    return e;
+}
+
 // capacity of a stream that is expected to take `mean` keys (they come hashed: Poisson, and a little more for the regions' unevenness)
 static uint64_t dup_cap(double mean) { return (uint64_t)(mean * 1.12 + 7.0 * std::sqrt(mean) + 64.0); }
 
@@ -1368,6 +1413,7 @@ static void dup_arm(mc_ctx *c, double keys, uint32_t grid)
     if (dup_small_bufs(c)) { c->err = keep; (void)hipGetLastError(); return; }
     const uint32_t nseg = grid + 1;  // (the last one: keys that enter the table outside the merge kernel)
     const uint64_t cap = dup_cap(keys / ((double)DUP_B1 * (double)grid));
+    if (D.l1_words < (uint64_t)DUP_B1 * nseg * cap) dup_make_room(c, (uint64_t)DUP_B1 * nseg * cap * 8);
     if (ensure_buf(c, &D.l1_keys, &D.l1_words, (uint64_t)DUP_B1 * nseg * cap) || ensure_buf(c, &D.l1_counts, &D.l1_counts_cap, (uint64_t)DUP_B1 * nseg)) {
         c->err = keep;
         (void)hipGetLastError();
@@ -1385,7 +1431,7 @@ static void dup_arm(mc_ctx *c, double keys, uint32_t grid)
 static int dup_fixup(mc_ctx *c, uint64_t n_listed)
 {
     mc_ctx::Dup &D = c->dup;
-    if (n_listed > mc_ctx::Dup::LIST_CAP) return to_hash_regions(c);
+    if (n_listed > mc_ctx::Dup::LIST_CAP) return to_hash_regions(c, 5);
     uint64_t want = 1024;
     while (want < 4 * n_listed) want <<= 1;
     if (want > D.set_slots) {
@@ -1413,7 +1459,7 @@ static int dup_fixup(mc_ctx *c, uint64_t n_listed)
     HIPCHK(c, hipMemcpyAsync(c->h_scratch + 20, D.ctr, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const uint64_t n_keys = c->h_scratch[21], n_tw = c->h_scratch[22];
-    if (n_tw > D.tw_cap) return to_hash_regions(c);  // (a key in more slots than anybody planned for)
+    if (n_tw > D.tw_cap) return to_hash_regions(c, 5);  // (a key in more slots than anybody planned for)
     D.n_keys = n_keys;
     D.n_tw = n_tw;
     D.solid_delta = 0;
@@ -1465,6 +1511,7 @@ static int ensure_dups(mc_ctx *c)
         if (!have_l1) {  // level 1 by a sweep of the table: 1021 workgroups, each a segment of every bucket
             const uint32_t grid = 1021, nseg = grid + 1;  // (a region is 16 rows of the sweep, and a row's slots lie in 16 of the 256 buckets: not a multiple of 16)
             const uint64_t cap = dup_cap((double)n_used / ((double)DUP_B1 * grid));
+            if (D.l1_words < (uint64_t)DUP_B1 * nseg * cap) dup_make_room(c, (uint64_t)DUP_B1 * nseg * cap * 8);
             rc = ensure_buf(c, &D.l1_keys, &D.l1_words, (uint64_t)DUP_B1 * nseg * cap);
             if (!rc) rc = ensure_buf(c, &D.l1_counts, &D.l1_counts_cap, (uint64_t)DUP_B1 * nseg);
             if (rc) return rc;
@@ -1494,6 +1541,7 @@ static int ensure_dups(mc_ctx *c)
                 l2.split = (uint32_t)in_a;
                 c->solid_list_fresh = false;  // (the solid list sat in a_recs)
             } else {
+                if (D.l2_own_words < need) dup_make_room(c, need * 8);
                 rc = ensure_buf(c, &D.l2_own, &D.l2_own_words, need);
                 if (rc) return rc;
                 l2.out_a = D.l2_own;
@@ -1509,9 +1557,10 @@ static int ensure_dups(mc_ctx *c)
         const DupL1 l1{D.l1_keys, D.l1_counts, D.l1_nseg, D.l1_cap, D.flags};
         hipLaunchKernelGGL(k_dup_scatter, dim3(DUP_B1 * slices), dim3(DUP_THREADS), 0, c->stream, l1, l2);
         const DupOut lst{D.list, D.ctr, mc_ctx::Dup::LIST_CAP};
-        // (an LDS set of 2^13 32-bit fingerprints, 32 KB: five workgroups a CU; sub-buckets beyond 4 900 keys -- a table of more than
-        // 1.3 G keys -- go through it in passes)
-        hipLaunchKernelGGL(k_dup_find<13>, dim3(std::min<uint32_t>(DUP_B1 << f2_lg, 256u * 40u)), dim3(DUP_FIND_THREADS), 0, c->stream, l2, lst);
+        // (an LDS set of 2^13 32-bit fingerprints, 32 KB, five workgroups a CU -- or, for sub-buckets beyond 4 500 keys, i.e. a table of
+        // more than 1.2 G keys, of 2^15 in a workgroup of 1024 threads; beyond 19 600 keys a sub-bucket goes through the set in passes)
+        if (per_sub <= 4500.0) hipLaunchKernelGGL((k_dup_find<13, 256>), dim3(std::min<uint32_t>(DUP_B1 << f2_lg, 256u * 40u)), dim3(256), 0, c->stream, l2, lst);
+        else hipLaunchKernelGGL((k_dup_find<15, 1024>), dim3(std::min<uint32_t>(DUP_B1 << f2_lg, 256u * 8u)), dim3(1024), 0, c->stream, l2, lst);
         HIPCHK(c, hipGetLastError());
         D.l2 = l2;
         HIPCHK(c, hipMemcpyAsync(c->h_scratch + 20, D.ctr, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
@@ -1849,7 +1898,11 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
         if (pl.lng) {
 #define P3L_ARGS static_cast<const uint4 *>(lk), lc, lcap, leaves, c->view(), virgin, P.leaf_state, P.leaf_new, P.flags + 1, \
                  (uint32_t)(c->solid_tracked ? c->cov_hint : 0), c->d_ctr + 6, k, emit, P.flags, c->dup_l1_view()
+            // (built for the k-mer lengths people run -- constant shifts, trip counts and powers of 5 --, and for any other from the argument)
             if (k == 63) hipLaunchKernelGGL(k_p3_long<63>, dim3(grid), dim3(P3_THREADS), 0, c->stream, P3L_ARGS);
+            else if (k == 55) hipLaunchKernelGGL(k_p3_long<55>, dim3(grid), dim3(P3_THREADS), 0, c->stream, P3L_ARGS);
+            else if (k == 47) hipLaunchKernelGGL(k_p3_long<47>, dim3(grid), dim3(P3_THREADS), 0, c->stream, P3L_ARGS);
+            else if (k == 41) hipLaunchKernelGGL(k_p3_long<41>, dim3(grid), dim3(P3_THREADS), 0, c->stream, P3L_ARGS);
             else hipLaunchKernelGGL(k_p3_long<0>, dim3(grid), dim3(P3_THREADS), 0, c->stream, P3L_ARGS);
 #undef P3L_ARGS
         } else if (pl.sk && pl.g == 0 && lseg == 1 && dedup_on) {
@@ -2036,7 +2089,7 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
                 return fail(c, MC_EOVERFLOW, "k-mer table regions keep overflowing; pass a capacity_hint (distinct k-mers)");
             // minimizer bins that no number of regions can hold: regions by the key's hash from here on, and the leaves
             // that were not merged go through the direct kernel, as many at a time as the table has room for
-            rc = to_hash_regions(c);
+            rc = to_hash_regions(c, 4);
             if (rc) return rc;
             HIPCHK(c, hipMemsetAsync(P.leaf_new, 0, n_leaves * sizeof(uint32_t), c->stream));  // (n_used was recounted)
             std::vector<uint32_t> st(n_leaves), cnt(n_leaves * (uint64_t)lseg);
@@ -2275,7 +2328,7 @@ static int add_reads_partitioned_once(mc_ctx *c, const uint64_t *d_words, const 
         int lrc = add_reads_long(c, d_words, d_off, r0, r1, base0, end_abs, wb);
         if (lrc == 1) return count_batch_direct(c, d_words, d_off, r0, r1, base0, end_abs, wb);  // (the streams lost records: nothing was merged)
         if (lrc != 4) return lrc;
-        lrc = to_hash_regions(c);
+        lrc = to_hash_regions(c, 3);
         if (lrc) return lrc;
         // The run was cut for long records (2^34 bases); one record a window takes far less (39 M reads of 150 bases
         // at k = 63 pass the 32-bit bucket indices).  The caller cuts what is left again, for the table as it is now.
@@ -3575,8 +3628,8 @@ int mc_get(mc_ctx *c, const int64_t *keys, uint64_t n, int16_t *out)
         std::lock_guard<std::mutex> g(c->mu);
         if (!c->finalized) return fail(c, MC_ESTATE, "mc_get: call mc_finalize_counts first");
         HIPCHK(c, hipSetDevice(c->cfg.device));
-        HIPCHK(c, dk.alloc(n));
-        HIPCHK(c, dout.alloc(n));
+        HIPCHK(c, alloc_result(c, dk, n));
+        HIPCHK(c, alloc_result(c, dout, n));
         HIPCHK(c, hipMemcpyAsync(dk.p, keys, n * 8, hipMemcpyHostToDevice, c->stream));
     }
     int rc = mc_get_dev(c, dk.p, n, dout.p);
@@ -3839,8 +3892,8 @@ int mc_export(mc_ctx *c, int min_cov, int64_t *keys, int16_t *counts, uint64_t c
     {
         std::lock_guard<std::mutex> g(c->mu);
         HIPCHK(c, hipSetDevice(c->cfg.device));
-        HIPCHK(c, dk.alloc(cap));
-        HIPCHK(c, dc.alloc(cap));
+        HIPCHK(c, alloc_result(c, dk, cap));
+        HIPCHK(c, alloc_result(c, dc, cap));
     }
     int rc = mc_export_dev(c, min_cov, dk.p, dc.p, nullptr, cap, n_out);
     if (rc) return rc;
@@ -3972,10 +4025,12 @@ int mc_reset_stats(mc_ctx *c)
 {
     if (!c) return MC_EINVAL;
     std::lock_guard<std::mutex> g(c->mu);
-    const uint64_t slots = c->st.table_slots, bytes = c->st.table_bytes;
+    const uint64_t slots = c->st.table_slots, bytes = c->st.table_bytes, left = c->st.left_bins, unchecked = c->st.dup_unchecked;
     c->st = mc_stats{};
     c->st.table_slots = slots;
     c->st.table_bytes = bytes;
+    c->st.left_bins = left;  // (states of the table, not counters)
+    c->st.dup_unchecked = unchecked;
     return MC_OK;
 }
 
@@ -4000,14 +4055,7 @@ int mc_trim(mc_ctx *c)
     P.a_recs = keep_recs; P.a_recs_cap = keep_cap; P.emit_counts = keep_counts;
     g_scratch_pool.put(dev, c->d_ovf_tmp, c->ovf_tmp_cap * sizeof(uint4));
     c->d_ovf_tmp = nullptr; c->ovf_tmp_cap = 0;
-    {   // the key streams of the duplicate-key join (dup_check.h): the next join starts with a sweep of the table
-        mc_ctx::Dup &D = c->dup;
-        g_scratch_pool.put(dev, D.l1_keys, D.l1_words * 8); D.l1_keys = nullptr; D.l1_words = 0;
-        g_scratch_pool.put(dev, D.l1_counts, D.l1_counts_cap * 4); D.l1_counts = nullptr; D.l1_counts_cap = 0;
-        g_scratch_pool.put(dev, D.l2_own, D.l2_own_words * 8); D.l2_own = nullptr; D.l2_own_words = 0;
-        D.l1_armed = false;
-        D.l2_valid = false;
-    }
+    dup_release_streams(c);
     g_scratch_pool.release(dev);
     g_table_pool.release(dev);
     return MC_OK;
@@ -4457,7 +4505,8 @@ int phantom_verify(mc_ctx *c, uint32_t n_jobs, std::vector<std::unique_ptr<BfsJo
 {
     *redo = false;
     mc_ctx::Dup &D = c->dup;
-    if (!hash_bins(c) || !c->solid_is_table || c->d_shards || !dup_check_on() || !D.checked || !D.l2_valid) return MC_OK;
+    if (!hash_bins(c) || !c->solid_is_table || c->d_shards || !dup_check_on() || !D.checked) return MC_OK;
+    const bool by_streams = D.l2_valid;  // (else: the join's streams are gone -- mc_trim, a pipeline run since --: one sweep of the table instead)
     uint64_t cap = 64;
     for (uint32_t j = 0; j < n_jobs; j++) cap += ctl[j].n * (B[j]->S.dir == 0 ? 8 : 4) + B[j]->S.n_seeds;
     if (cap >= (1ull << 32)) return fail(c, MC_EOVERFLOW, "mc_bfs: %llu look-ups to check by key", (unsigned long long)cap);
@@ -4469,7 +4518,10 @@ int phantom_verify(mc_ctx *c, uint32_t n_jobs, std::vector<std::unique_ptr<BfsJo
         HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&D.pq_mem), words * 2 * 8));
         D.pq_cap = words * 2;
     }
-    const uint32_t G = DUP_B1 << D.l2.f2_lg;
+    uint64_t set_slots = 1024;  // (the sweep form: the queries as a set, 12 bytes an entry in the same block)
+    while (set_slots < 2 * cap) set_slots <<= 1;
+    const uint32_t G = by_streams ? DUP_B1 << D.l2.f2_lg : (uint32_t)std::min<uint64_t>(3 * set_slots, 0xFFFFFFF0ull);
+    if (!by_streams && 3 * set_slots > 0xFFFFFFF0ull) return fail(c, MC_EOVERFLOW, "mc_bfs: %llu look-ups to check by key", (unsigned long long)cap);
     if (D.pq_groups_cap < G) {
         if (D.pq_groups) (void)hipFree(D.pq_groups);
         D.pq_groups = nullptr; D.pq_groups_cap = 0;
@@ -4482,7 +4534,7 @@ int phantom_verify(mc_ctx *c, uint32_t n_jobs, std::vector<std::unique_ptr<BfsJo
     uint32_t *hits = next + 2 * ((cap + 1) / 2);
     uint32_t *head = D.pq_groups;
     HIPCHK(c, hipMemsetAsync(ctr, 0, 2 * sizeof(unsigned long long), c->stream));
-    HIPCHK(c, hipMemsetAsync(head, 0xFF, G * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(head, 0xFF, (by_streams ? (uint64_t)G : 2 * set_slots) * sizeof(uint32_t), c->stream));  // (list heads, or the set's keys: ~0 = free)
     const SolidView t = c->solid_view();
     const int k = c->cfg.k;
     for (uint32_t j = 0; j < n_jobs; j++) {
@@ -4496,8 +4548,15 @@ int phantom_verify(mc_ctx *c, uint32_t n_jobs, std::vector<std::unique_ptr<BfsJo
         if (c->cfg.key_mode == MC_KEY_POLY) PQ_LAUNCH(KEY_POLY); else PQ_LAUNCH(KEY_FNV1A);
 #undef PQ_LAUNCH
     }
-    hipLaunchKernelGGL(k_pq_link, dim3(256), dim3(256), 0, c->stream, q.key, ctr, cap, D.l2.f2_lg, head, next);
-    hipLaunchKernelGGL(k_pq_match, dim3(std::min<uint32_t>(G, 256u * 16u)), dim3(256), 0, c->stream, D.l2, head, next, q.key, hits, ctr + 1, hit_cap);
+    if (by_streams) {
+        hipLaunchKernelGGL(k_pq_link, dim3(256), dim3(256), 0, c->stream, q.key, ctr, cap, D.l2.f2_lg, head, next);
+        hipLaunchKernelGGL(k_pq_match, dim3(std::min<uint32_t>(G, 256u * 16u)), dim3(256), 0, c->stream, D.l2, head, next, q.key, hits, ctr + 1, hit_cap);
+    } else {
+        unsigned long long *qk = reinterpret_cast<unsigned long long *>(D.pq_groups);
+        uint32_t *qidx = D.pq_groups + 2 * set_slots;
+        hipLaunchKernelGGL(k_pq_set_build, dim3(256), dim3(256), 0, c->stream, q.key, ctr, cap, qk, qidx, set_slots - 1);
+        hipLaunchKernelGGL(k_pq_sweep, dim3(grid_for(c->n_slots(), 256, 256 * 16)), dim3(256), 0, c->stream, c->slots, c->n_slots(), qk, qidx, set_slots - 1, hits, ctr + 1, hit_cap);
+    }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_scratch + 20, ctr, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -4582,10 +4641,8 @@ int mc_bfs_batch(mc_ctx *c, const mc_bfs_job *jobs, uint32_t n_jobs, int min_cov
     c->pending_solid_ms = 0;
     {
         int rc = ensure_solid(c, min_cov, &total_ms);
-        // (hash keys in minimizer bins: the join of mc_finalize_counts, once more where something has taken its streams since --
-        // the walk's "absent" look-ups are checked against them, phantom_verify)
-        if (!rc && hash_bins(c) && c->solid_is_table && !c->d_shards && dup_check_on() && (!c->dup.checked || !c->dup.l2_valid)) {
-            c->dup.checked = false;
+        // (hash keys in minimizer bins: the join of mc_finalize_counts, should anything have skipped it)
+        if (!rc && hash_bins(c) && c->solid_is_table && !c->d_shards && dup_check_on() && !c->dup.checked) {
             c->dup.l1_armed = false;
             rc = ensure_dups(c);
             if (!rc) rc = ensure_solid(c, min_cov, &total_ms);
@@ -4911,11 +4968,11 @@ int shard_attach_locked(mc_ctx *c, const ShardWire *w, uint32_t n, uint32_t self
             if (!x.has_ipc) { shard_detach_locked(c); return fail(c, MC_EHIP, "mc_shard_attach: shard %u comes from another process without an IPC handle", i); }
             void *p = nullptr;
             for (auto &m : c->ipc_opened)  // (the same table as last time: its mapping is still there)
-                if (!m.in_use && memcmp(&m.h, &x.ipc, sizeof x.ipc) == 0) { p = m.p; m.in_use = true; break; }
+                if (!m.in_use && memcmp(&m.h, &x.ipc, sizeof x.ipc) == 0 && m.addr == x.addr && m.bytes == x.bytes) { p = m.p; m.in_use = true; break; }
             if (!p) {
                 const hipError_t e = hipIpcOpenMemHandle(&p, x.ipc, hipIpcMemLazyEnablePeerAccess);
                 if (e != hipSuccess) { shard_detach_locked(c); return fail(c, MC_EHIP, "mc_shard_attach: hipIpcOpenMemHandle (shard %u): %s", i, hipGetErrorString(e)); }
-                c->ipc_opened.push_back(mc_ctx::IpcMap{x.ipc, p, true});
+                c->ipc_opened.push_back(mc_ctx::IpcMap{x.ipc, p, true, x.addr, x.bytes});
             }
             slots = static_cast<Slot *>(p);
         }
@@ -4924,8 +4981,9 @@ int shard_attach_locked(mc_ctx *c, const ShardWire *w, uint32_t n, uint32_t self
     }
     if (hipMalloc(reinterpret_cast<void **>(&c->d_shards), n * sizeof(ShardRef)) != hipSuccess) { shard_detach_locked(c); return fail(c, MC_ENOMEM, "mc_shard_attach: out of device memory"); }
     if (hipMemcpy(c->d_shards, refs.data(), n * sizeof(ShardRef), hipMemcpyHostToDevice) != hipSuccess) { shard_detach_locked(c); return fail(c, MC_EHIP, "mc_shard_attach: upload failed"); }
-    // mappings nobody asked for this time go once there are more of them than tables (a peer's table that grew has a new handle)
-    if (c->ipc_opened.size() > 2 * (size_t)n) {
+    // Mappings nobody asked for this time are closed at once (kept until twice as many had gathered, a peer's table
+    // that had been replaced -- grown, or given back to the driver -- stayed pinned through its mapping, up to 137 GB each).
+    {
         std::vector<mc_ctx::IpcMap> keep;
         for (auto &m : c->ipc_opened) { if (m.in_use) keep.push_back(m); else (void)hipIpcCloseMemHandle(m.p); }
         c->ipc_opened.swap(keep);
@@ -5551,6 +5609,7 @@ int mc_group_get_stats(mc_group *g, mc_stats *out)
         t.solid_list_builds += s.solid_list_builds;
         t.long_runs += s.long_runs;
         t.dup_keys += s.dup_keys; t.dup_checks += s.dup_checks; t.dup_ms = std::max(t.dup_ms, s.dup_ms); t.dup_unchecked |= s.dup_unchecked;
+        t.left_bins = std::max(t.left_bins, s.left_bins);
         t.count_ms = std::max(t.count_ms, s.count_ms); t.count_total_ms = std::max(t.count_total_ms, s.count_total_ms);
         t.p1_ms = std::max(t.p1_ms, s.p1_ms); t.p2_ms = std::max(t.p2_ms, s.p2_ms); t.p3_ms = std::max(t.p3_ms, s.p3_ms);
     }

@@ -56,7 +56,7 @@ class Stats(C.Structure):
                 ("grows", C.c_uint64), ("p1_ms", C.c_double), ("p2_ms", C.c_double), ("p3_ms", C.c_double),
                 ("spill_keys", C.c_uint64), ("solid_kmers", C.c_uint64), ("solid_sweeps", C.c_uint64),
                 ("solid_list_builds", C.c_uint64), ("long_runs", C.c_uint64), ("dup_keys", C.c_uint64),
-                ("dup_checks", C.c_uint64), ("dup_ms", C.c_double), ("dup_unchecked", C.c_uint64)]
+                ("dup_checks", C.c_uint64), ("dup_ms", C.c_double), ("dup_unchecked", C.c_uint64), ("left_bins", C.c_uint64)]
 
 
 # every symbol include/mcgpu.h declares; tests check that the library exports all of them

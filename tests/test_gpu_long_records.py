@@ -242,6 +242,7 @@ def test_a_run_cut_for_long_records_is_cut_again_when_the_long_form_declines(mc,
     ctx.add_reads_packed(po.pack(reads[off[cut]:]), off[cut:] - off[cut])   # 6 M bases: declined, then three runs of <= 2 M bases
     st = ctx.stats()
     assert st.long_runs == 1 and st.count_launches - launches >= 3, (st.long_runs, st.count_launches - launches)
+    assert st.left_bins == 3  # (mc_stats says why the table left its minimizer bins: nothing vouched for its size)
     assert ctx.finalize() == t.size()
     gk, gc = ctx.export(0)
     ok, oc = t.dump()

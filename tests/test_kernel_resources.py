@@ -41,12 +41,27 @@ def test_the_walk_and_the_merge_kernel_use_no_scratch_memory(tmp_path):
             assert 2 * r["group_segment_fixed_size"] <= 160 * 1024 and r["vgpr_count"] <= 128, (name, r)
 
 
+def test_the_key_join_kernels_use_no_scratch_and_fit_their_workgroups(tmp_path):
+    """csrc/dup_check.h: level 2 keeps two workgroups of 1024 threads on a CU (80 KB of LDS, 64 registers), level 3 five of 256."""
+    kernels = _kernel_notes(tmp_path)
+    dup = {n: r for n, r in kernels.items() if "k_dup_" in n or "k_pq_" in n or "k_phantom_queries" in n or "k_dupq_" in n}
+    assert len(dup) >= 9, sorted(dup)
+    for name, r in dup.items():
+        assert r["private_segment_fixed_size"] == 0 and r["vgpr_spill_count"] == 0, (name, r)
+        if "k_dup_scatter" in name:
+            assert 2 * r["group_segment_fixed_size"] <= 160 * 1024 and r["vgpr_count"] <= 64, (name, r)
+        if "k_dup_findILi13E" in name:
+            assert 4 * r["group_segment_fixed_size"] <= 160 * 1024 and r["vgpr_count"] <= 128, (name, r)
+        if "k_dup_findILi15E" in name:  # (one workgroup of 1024 threads a CU: 4 waves a SIMD)
+            assert r["group_segment_fixed_size"] <= 160 * 1024 and r["vgpr_count"] <= 128, (name, r)
+
+
 def test_the_long_record_kernels_fit_two_workgroups_a_cu(tmp_path):
     """csrc/count_long.h: the first level and the merge kernel of long records use no scratch memory, and the merge kernel's
     region image, chunk list and record table leave room for two workgroups a CU (160 KB of LDS, 128 registers a wave at 4 a SIMD)."""
     kernels = _kernel_notes(tmp_path)
     long_k = {n: r for n, r in kernels.items() if "k_p3_longILi" in n or "k_skl_extract" in n or "k_sk2_scatter_compactILi2ELi2E" in n}
-    assert sum("k_p3_longILi" in n for n in long_k) == 2 and len(long_k) == 4, sorted(long_k)  # built for k = 63, and for any k
+    assert sum("k_p3_longILi" in n for n in long_k) == 5 and len(long_k) == 7, sorted(long_k)  # built for k = 63, 55, 47, 41, and for any k
     for name, r in long_k.items():
         assert r["private_segment_fixed_size"] == 0 and r["vgpr_spill_count"] == 0, (name, r)
         if "k_p3_long" in name:
