@@ -33,7 +33,7 @@ constexpr uint32_t PATH_CAP = 1u << 15;               // levels one scout run ma
 constexpr uint32_t PATH_WORDS = (PATH_CAP + 64 + 96) / 32 + 4;  // the walker's own k bases + the levels, 32 bases per word
 constexpr uint32_t PSEG_WORDS = 12;                   // path words a round needs: (31 + MAX_NODES / 4 + 63 + 1) bases and one to spare
 constexpr uint32_t SCOUT_WORDS = 16;                  // read-store words a hop looks at
-constexpr uint32_t SCOUT_MH = 64 + SK_M + 2;          // minimizer hashes a hop looks at (64 new vertices + the tip's own)
+constexpr uint32_t SCOUT_MH = 64 + (63 - SK_M) + 4;   // minimizer hashes a hop looks at: 64 new vertices' last SK_M-mers + the ones inside the vertex in front (k - SK_M of them, k <= 63)
 constexpr uint32_t SCOUT_BUDGET0 = 1024;              // levels of the first scout run; doubled after every run the rounds used up
 #ifndef MC_TEAM_MAX
 #define MC_TEAM_MAX 2   // waves of one walker's hop: MC_CAND_MAX candidate reads, each looked at by MC_TEAM_MAX / MC_CAND_MAX waves -- wave s of a
@@ -784,9 +784,43 @@ __device__ __forceinline__ void scout_eval(const SolidView &t, uint64_t *sw, uin
         }
         if (SH) s0 = solid_locate(t, key, h, true, hmin);
         else { h = own_table(t); s0 = ((((uint64_t)sk_bin(hmin) * t.n_regions) >> 32) << MC_REGION_LG) | sk_home(key); }
+    } else if (MODE != KEY_PACKED && !SH && t.mm_k != 0) {
+        // Hash keys in minimizer bins (count_long.h): the bin comes from the vertex's BASES, 19 .. 49 SK_M-mers each.  The same as above for
+        // k-mers of two words: every SK_M-mer of the hop hashed once (a lane worked all 49 of its vertex out, solid_locate_kmer: most of
+        // a hop's time at k = 63), a lane takes the smallest -- or the two smallest, as a multiset: mm_k < 0 -- of its w.
+        const uint32_t w = (uint32_t)k - SK_M + 1, wq = w - 1;
+        auto mm_hash = [](uint32_t f) {
+            uint32_t r = __builtin_bitreverse32(f);
+            r = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
+            r = (~r) >> (32 - 2 * SK_M);
+            return sk_order(f < r ? f : r);
+        };
+        auto mer_at = [&](const Kmer &x, uint32_t p) -> uint32_t {  // SK_M-mer p of a k-mer: its bases p .. p + SK_M - 1
+            const uint32_t o = 2u * (wq - p);
+            const uint64_t ww = o >= 64 ? (x.hi >> (o - 64)) : (o == 0 ? x.lo : ((x.lo >> o) | (x.hi << (64 - o))));
+            return (uint32_t)ww & SK_MMASK;
+        };
+        __builtin_amdgcn_wave_barrier();
+        if (lane + 1 < w) mh[lane] = mm_hash(mer_at(Xs, lane + 1));  // the SK_M-mers of the vertex in front, from base lane + 1 on
+        mh[w - 1 + lane] = ok ? mm_hash((uint32_t)K.lo & SK_MMASK) : SK_NONE;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t m_lo = SK_NONE, m_hi = SK_NONE;
+        for (uint32_t i = 0; i < w; i++) {
+            const uint32_t x = mh[lane + i];
+            const uint32_t tm = max(m_lo, x);
+            m_lo = min(m_lo, x);
+            m_hi = min(m_hi, tm);
+        }
+        const uint32_t hm = t.mm_k < 0 ? m_lo ^ (m_hi * 0x85EBCA6Bu) : m_lo;  // (count_long.h skl_word2)
+        h = own_table(t);
+        s0 = ((((uint64_t)(sk_bin(hm) & 0xFFFFFF00u) * t.n_regions) >> 32) << MC_REGION_LG) | sk_home(key);  // (skl_bin)
+#ifdef MC_BFS_CHECK_SLOTS
+        if (ok) { TableRef h2; const uint64_t want = solid_locate_kmer<MODE>(t, K, k, key, h2);
+                  if (want != s0) printf("[bfs] scout minimizer (hash keys): slot %llu, solid_locate_kmer says %llu (lane %u)\n", (unsigned long long)s0, (unsigned long long)want, lane); }
+#endif
     } else {
         if (SH) s0 = solid_locate(t, key, h);
-        else if (MODE != KEY_PACKED && t.mm_k != 0) s0 = solid_locate_kmer<MODE>(t, K, k, key, h);  // (hash keys in minimizer bins: kmer_device.h)
         else { h = own_table(t); s0 = solid_slot_of(t, key); }
     }
     SC_STAMP(1);
@@ -1660,6 +1694,7 @@ __device__ __forceinline__ void bfs_narrow(const BfsState &S, const SolidView &t
         const long long room = max_radius < 0 ? (long long)PATH_CAP : max_radius - level;  // levels that may still add
         const uint32_t FN = F << lg;  // nodes per level
         const bool quad_mm = MC_QUAD_MINIMIZER != 0 && F == 1 && dir != 0 && (SH ? t.owner_mm_k : t.mm_k) != 0;  // (see where the nodes' slots are worked out)
+        const bool quad_hash = MC_QUAD_MINIMIZER != 0 && F == 1;  // hash keys in minimizer bins: the same for the bins of the k-mers' bases, in any direction
         // x / F for x <= 512 and F <= 16 is (x * ceil(2^16 / F)) >> 16: integer divisions cost a lone wave ~30 instructions
         // each.  F rarely changes.
         if (F != div_f) { div_f = F; div_m = (65536u + F - 1) / F; }
@@ -1845,6 +1880,56 @@ __device__ __forceinline__ void bfs_narrow(const BfsState &S, const SolidView &t
 #ifdef MC_BFS_CHECK_SLOTS
                 { TableRef h2 = own_table(t); const uint64_t want = SH ? solid_locate(t, key, h2) : solid_slot_of(t, key);
                   if (want != s0) printf("[bfs] quad minimizer: slot %llu, solid_slot_of says %llu (key %llx, level %u, c %u, dir %d)\n", (unsigned long long)s0, (unsigned long long)want, (unsigned long long)key, lvl, c, dir); }
+#endif
+            } else if (MODE != KEY_PACKED && !SH && t.mm_k != 0 && quad_hash) {
+                // Hash keys in minimizer bins (count_long.h): the region is the bin of the k-mer's BASES -- 49 SK_M-mer hashes a node at
+                // k = 63 when every thread works its own out (sk_hmin_of_kmer2), most of what a round computed (the CLI's walk at
+                // k = 63: 19 ms on such a table against 12 on a hash-prefix one).  One walker: the nb nodes of a level are nb lanes side
+                // by side, neighbours of the SAME vertex v, and share v's SK_M-mers but the one at either end: the lanes hash a share
+                // each, the group takes the smallest (the two smallest, as a multiset, where the table's bin word is made of two:
+                // mm_k < 0) over DPP, and a lane adds what only its side keeps and the SK_M-mer that holds its own base.
+                const bool two = t.mm_k < 0;
+                const uint32_t wq = (uint32_t)k - SK_M;  // SK_M-mer p of a k-mer: its bases p .. p + SK_M - 1, p = 0 .. wq
+                auto mer_at = [&](const Kmer &x, uint32_t p) -> uint32_t {
+                    const uint32_t o = 2u * (wq - p);
+                    const uint64_t w = o >= 64 ? (x.hi >> (o - 64)) : (o == 0 ? x.lo : ((x.lo >> o) | (x.hi << (64 - o))));
+                    return (uint32_t)w & SK_MMASK;
+                };
+                auto mm_hash = [](uint32_t f) {
+                    uint32_t r = __builtin_bitreverse32(f);
+                    r = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
+                    r = (~r) >> (32 - 2 * SK_M);
+                    return sk_order(f < r ? f : r);
+                };
+                uint32_t m_lo = SK_NONE, m_hi = SK_NONE;  // the two smallest so far
+                auto take = [&](uint32_t x) { const uint32_t tm = max(m_lo, x); m_lo = min(m_lo, x); m_hi = min(m_hi, tm); };
+                auto merge = [&](uint32_t o_lo, uint32_t o_hi) { const uint32_t tm = max(m_lo, o_lo); m_lo = min(m_lo, o_lo); m_hi = min(tm, min(m_hi, o_hi)); };
+                const bool lft = dir < 0 || (dir == 0 && !(c & 1));
+                if (dir != 0) {  // four lanes; the neighbours keep v's SK_M-mers 0 .. wq - 1 (left) or 1 .. wq (right)
+                    for (uint32_t p = c + (lft ? 0u : 1u); p < wq + (lft ? 0u : 1u); p += 4) take(mm_hash(mer_at(v, p)));
+                } else {         // eight lanes, left and right neighbours in turn: all keep 1 .. wq - 1
+                    for (uint32_t p = 1u + c; p < wq; p += 8) take(mm_hash(mer_at(v, p)));
+                }
+                {
+                    uint32_t o_lo = (uint32_t)__builtin_amdgcn_update_dpp((int)SK_NONE, (int)m_lo, 0xB1, 0xF, 0xF, false);  // quad_perm [1, 0, 3, 2]
+                    uint32_t o_hi = (uint32_t)__builtin_amdgcn_update_dpp((int)SK_NONE, (int)m_hi, 0xB1, 0xF, 0xF, false);
+                    merge(o_lo, o_hi);
+                    o_lo = (uint32_t)__builtin_amdgcn_update_dpp((int)SK_NONE, (int)m_lo, 0x4E, 0xF, 0xF, false);           // quad_perm [2, 3, 0, 1]
+                    o_hi = (uint32_t)__builtin_amdgcn_update_dpp((int)SK_NONE, (int)m_hi, 0x4E, 0xF, 0xF, false);
+                    merge(o_lo, o_hi);
+                    if (dir == 0) {
+                        o_lo = (uint32_t)__builtin_amdgcn_update_dpp((int)SK_NONE, (int)m_lo, 0x141, 0xF, 0xF, false);      // row_half_mirror: the other quad of my eight
+                        o_hi = (uint32_t)__builtin_amdgcn_update_dpp((int)SK_NONE, (int)m_hi, 0x141, 0xF, 0xF, false);
+                        merge(o_lo, o_hi);
+                        take(mm_hash(mer_at(v, lft ? 0u : wq)));  // what only my side keeps of v
+                    }
+                }
+                take(mm_hash(mer_at(nk, lft ? 0u : wq)));  // the SK_M-mer that holds my own base
+                const uint32_t hm = two ? m_lo ^ (m_hi * 0x85EBCA6Bu) : m_lo;  // (count_long.h skl_word2)
+                s0 = ((((uint64_t)(sk_bin(hm) & 0xFFFFFF00u) * t.n_regions) >> 32) << MC_REGION_LG) | sk_home(key);  // (skl_bin)
+#ifdef MC_BFS_CHECK_SLOTS
+                { TableRef h2 = own_table(t); const uint64_t want = solid_locate_kmer<MODE>(t, nk, k, key, h2);
+                  if (want != s0) printf("[bfs] group minimizer (hash keys): slot %llu, solid_locate_kmer says %llu (level %u, c %u, dir %d)\n", (unsigned long long)s0, (unsigned long long)want, lvl, c, dir); }
 #endif
             } else {
                 if (MODE != KEY_PACKED && !SH && t.mm_k != 0) s0 = solid_locate_kmer<MODE>(t, nk, k, key, h);  // (hash keys in minimizer bins)
