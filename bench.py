@@ -283,7 +283,9 @@ def main():
             # its kernels were built from, and the number is only reported while the counting kernels are unchanged since
             # (git diff of csrc/count_pipeline.h and csrc/kmer_device.h against that commit is empty), else null.
             traffic, traffic_source = None, None
-            pmc = os.path.join(ROOT, "profiles", "r05_pmc_hbm_traffic_e1.csv")
+            import glob
+            pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic_e1.csv")))  # (the newest round's)
+            pmc = pmcs[-1] if pmcs else os.path.join(ROOT, "profiles", "r05_pmc_hbm_traffic_e1.csv")
             if pipeline and world == 1 and args.err == 100 and R == 10_000_000 and k == 31 and os.path.exists(pmc):
                 import csv
                 import subprocess
@@ -306,7 +308,7 @@ def main():
                         if row["kernel"].startswith(("mc::k_sk1w_extract", "mc::k_p3_dedup", "mc::k_sk2_scatter", "void mc::k_sk1w_extract", "void mc::k_p3_dedup", "void mc::k_sk2_scatter")):
                             gb += float(row["fetch_GB_corrected_x2"]) + float(row["write_GB"])
                     traffic = round(gb * 1e9)
-                    traffic_source = "profiles/r05_pmc_hbm_traffic_e1.csv (commit %s; the warm step's dispatches)" % commit
+                    traffic_source = "profiles/%s (commit %s; the warm step's dispatches)" % (os.path.basename(pmc), commit)
             roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                         "kernel": dominant, "launch": "counting pipeline p1+p2+p3" if pipeline else "k_count_reads",

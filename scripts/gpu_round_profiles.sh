@@ -2,7 +2,7 @@
 # Everything under profiles/<round>_* in ONE gpurun call: bench lines (E1 with the CPU baseline, E0, 20 / 50 / 100 M reads,
 # configs[2] scaled and full), rocprofv3 kernel stats, PMC traffic (cold and warm step), SQ counters, the step's timeline.
 # usage: ROUND=r04 MC_COMMIT=<short hash the kernels were built from> bash scripts/gpu_round_profiles.sh
-R=${ROUND:-r05}
+R=${ROUND:-r06}
 set -x
 mkdir -p gpurun_out/p
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
