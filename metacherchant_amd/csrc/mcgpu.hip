@@ -3565,17 +3565,26 @@ int mc_finalize_counts(mc_ctx *c, uint64_t *n_distinct)
     if (!c) return MC_EINVAL;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    unsigned long long *h = c->h_scratch;
     {
         int rc = materialize(c);
-        if (!rc) rc = drain_parked(c);
+        if (rc) return rc;
+        // (one wait for all the counters: the parked additions' among them -- a wait of its own before, for a number that is 0
+        // in every run that fits its table)
+        HIPCHK(c, hipMemcpyAsync(h, c->d_ctr, 9 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const bool parked = h[7] != 0;
+        if (parked) rc = drain_parked(c);
         // hash keys in minimizer bins: a key that different k-mers brought to different regions gets the sum of its counters
         // wherever it is read, and counts once (dup_check.h; src/io/LargeKIOUtils.java:46-49 has one counter a hash)
+        const bool joins = hash_bins(c) && !c->virgin && !c->dup.checked;
         if (!rc) rc = ensure_dups(c);
         if (rc) return rc;
+        if (parked || joins) {  // (the counters may have moved)
+            HIPCHK(c, hipMemcpyAsync(h, c->d_ctr, 9 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
     }
-    unsigned long long *h = c->h_scratch;
-    HIPCHK(c, hipMemcpyAsync(h, c->d_ctr, 9 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     const uint32_t fatal = (uint32_t)h[8];
     if (fatal) return fail(c, MC_EOVERFLOW, "a k-mer table region filled up (hash skew)");
     c->n_used_host = h[0];

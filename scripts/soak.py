@@ -22,6 +22,13 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 # SOAK_KS=33,41,47,55,63: other k-mer lengths (above 31: polynomial keys -- with a capacity hint, the long-record pipeline)
 KS = [int(x) for x in os.environ.get("SOAK_KS", "").split(",") if x] or [21, 23, 24, 25, 27, 28, 29, 30, 31, 31, 31, 41]
 SEEDS = int(os.environ.get("SOAK_SEEDS", 6))  # seed sequences per table, three walks each
+# SOAK_COLLIDE=1: where k has constructed vectors (33, 41, 47, 55, 63), a pair of k-mers with one hash is written into the genome
+COLLIDE = os.environ.get("SOAK_COLLIDE") == "1"
+VECTORS = {}
+if COLLIDE:
+    import json
+    for _v in json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "poly_collisions.json")))["vectors"]:
+        VECTORS.setdefault(_v["k"], []).append(_v)
 walks = 0
 t0 = time.time()
 for it in range(iters):
@@ -44,6 +51,24 @@ for it in range(iters):
         continue
     print("it %d: k=%d err=%d L=%d reads=%d genome=%dx%d cov=%d hint=%d cap=%d rseed=%d" % (it, k, err, L, n_reads, contigs, clen, cov, hint, cap, rseed), flush=True)
     genome = po.synth_genome(GENOME_SEED + it, contigs * clen)
+    planted = None
+    if COLLIDE and k in VECTORS and clen >= 3000:
+        # two different k-mers with one PolynomialHash key (tests/golden/poly_collisions.json) written into the genome before the reads
+        # are drawn: x in contig 0 where the first seed's walk passes, y (or its reverse complement) somewhere else -- the reference
+        # counts both in one counter (csrc/dup_check.h), and the neighbours of x that nobody counted may have the hash of y's neighbours
+        crng = np.random.default_rng(rseed ^ 0xC0111DE)  # (a generator of its own: the iterations' draws stay what they were)
+        v = VECTORS[k][int(crng.integers(0, len(VECTORS[k])))]
+        x, y = po.encode(v["x"]), po.encode(v["y"])
+        if crng.integers(0, 2):
+            y = (3 - y[::-1]).astype(np.uint8)
+        px = int(crng.integers(300, clen - 600 - k))
+        py = int(crng.integers(100, contigs * clen - k - 100))
+        while abs(py - px) < 2 * k + 400 or (py % clen) + k > clen:
+            py = int(crng.integers(100, contigs * clen - k - 100))
+        genome = genome.copy()
+        genome[px:px + k] = x
+        genome[py:py + k] = y
+        planted = (px, py, v["key"])
     reads = po.synth_reads(genome, contigs, clen, rseed, 0, n_reads, L, err)
     off = np.arange(n_reads + 1, dtype=np.uint64) * L
     ragged = bool(rng.integers(0, 4) == 0)
@@ -70,6 +95,9 @@ for it in range(iters):
     ok, oc = t.dump()
     assert np.array_equal(gk, ok) and np.array_equal(gc, oc), it
     a = int(rng.integers(0, max(1, clen - 600)))
+    if planted:
+        a = max(0, planted[0] - 250)  # the first seed sequence ends in front of x
+        assert ctx.get(np.array([planted[2]], dtype=np.int64))[0] == t.get(planted[2]), it
     srng = np.random.default_rng(rseed)  # (a generator of its own: the iterations' draws stay what they were)
     for si, d in [(si, d) for si in range(SEEDS) for d in (1, -1, 0)]:
         if d == 1:
@@ -95,5 +123,5 @@ for it in range(iters):
     ctx.close()
     print("it %d ok%s: k=%d err=%d L=%d reads=%d genome=%dx%d cov=%d hint=%d cap=%d batches=%d distinct=%d list=%d sweeps=%d spills=%d long=%d grows=%d (%.0f s)" % (
         it, " (ragged)" if ragged else "", k, err, L, n_reads, contigs, clen, cov, hint, cap, 2 if two else 1, nd, st.solid_list_builds, st.solid_sweeps, st.spill_keys,
-        st.long_runs, st.grows, time.time() - t0), flush=True)
+        st.long_runs, st.grows, time.time() - t0) + (" planted x at %d, y at %d: %d keys in several regions" % (planted[0], planted[1], st.dup_keys) if planted else ""), flush=True)
 print("soak ok: %d iterations, %d walks" % (iters, walks))
