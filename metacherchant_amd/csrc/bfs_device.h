@@ -76,17 +76,22 @@ constexpr uint32_t SCOUT_BACK = 192;                  // bases in front of a poi
 #ifndef MC_CONS_PAIRS
 #define MC_CONS_PAIRS 0   // scout_cons: 1 = the longest agreement of any PAIR of candidate reads is the hop; 0 = a vote a level among all of them
 #endif
+#ifndef MC_CONS_LEVELS
+#define MC_CONS_LEVELS 128   // levels a consensus hop may add: 64 (one stretch, rounds 4-5) or 128 (a second stretch with the same reads, no look-ups in between)
+#endif
 #ifndef MC_SCOUT_CONSENSUS
 #define MC_SCOUT_CONSENSUS 1   // the companion's hops take the path from the CONSENSUS of up to CONS_N reads and look only the last CONS_TAIL
                                // vertices up (scout_cons); 0: round 2's hop -- every level of the better of two reads looked up (scout_eval)
 #endif
 constexpr uint32_t CONS_N = 8;       // candidate reads of a consensus hop
-constexpr uint32_t CONS_WORDS = 8;   // read-store words staged per candidate: 256 bases from word (pos - CONS_BACK) / 32 on
-constexpr uint32_t CONS_BACK = 96;   // ... enough for the 64 levels past a tip that sits within CONS_TAIL bases of pos, either way the read runs
+constexpr uint32_t CONS_WORDS = 12;  // read-store words staged per candidate: 384 bases from word (pos - CONS_BACK) / 32 on
+constexpr uint32_t CONS_BACK = 160;  // ... enough for TWO stretches of 64 levels past a tip that sits within CONS_TAIL bases of pos, either way the read runs
+                                     // (round 6: a hop that ran its 64 lanes out goes on for a second stretch with the same reads -- their words
+                                     // are there, and so are the reads: the second longest of the ~6 that hold the tip reaches ~85 levels past it)
 constexpr uint32_t CONS_TAIL = 24;   // levels at the end of a consensus whose vertices are looked up: the tip must be solid, and their read
                                      // pointers are the next hop's candidates (so a candidate's pointer is < CONS_TAIL levels behind its tip)
-static_assert(CONS_N * CONS_WORDS == 64, "a lane per staged word");
-static_assert(CONS_TAIL + 64 + 31 <= CONS_WORDS * 32 - CONS_BACK - 31 && CONS_TAIL + 64 <= CONS_BACK, "the staged words hold 64 levels either way");
+static_assert(CONS_N * CONS_WORDS == 96, "a lane per staged word, the first 32 lanes a second one");
+static_assert(CONS_TAIL + 128 + 31 <= CONS_WORDS * 32 - CONS_BACK - 31 && CONS_TAIL + 128 <= CONS_BACK, "the staged words hold 128 levels either way");
 constexpr int NARROW_CAND = 64;           // candidates per replayed level = lanes of one wave
 constexpr int RH_SIZE = 1024;             // round-local LDS set (narrow, slow replay)
 constexpr int WH_SIZE = 2 * BFS_THREADS;  // chunk-local LDS set (wide)
@@ -1044,7 +1049,7 @@ struct TeamLds {
     uint32_t published[SCOUT_MAX_F];  // levels whose path words are known to have arrived
     // consensus hops (scout_cons): one wave per walker, everything below is that wave's own
     uint64_t cw[SCOUT_MAX_F][CONS_N * CONS_WORDS];  // the read-store words around the candidates' pointers
-    uint64_t cs[SCOUT_MAX_F][4];                    // the tip's k bases and the levels' bases behind them, 32 bases a word
+    uint64_t cs[SCOUT_MAX_F][8];                    // the tip's k bases and the levels' bases behind them (two stretches of 64), 32 bases a word
     uint64_t cstr[SCOUT_MAX_F][CONS_N][2];          // the 64 bases each candidate holds for the levels past the tip, first on top
     uint32_t cnp[SCOUT_MAX_F][CONS_N], cnd[SCOUT_MAX_F][CONS_N];  // the next hop's candidates being picked: pointer, levels behind the tip
 };
@@ -1065,7 +1070,8 @@ struct TeamLds {
 struct ConsHop {
     uint32_t m;           // (uniform) levels added; 0: the hop failed
     int why;              // (uniform) 0 ok, 1 no candidate holds the tip, 2 nothing agreed on / solid behind it
-    uint64_t e_hi, e_lo;  // (uniform) the m new bases, first on top
+    uint64_t e_hi, e_lo;  // (uniform) the first min(m, 64) new bases, first on top
+    uint64_t f_hi, f_lo;  // (uniform) the bases of the levels 65 .. m (a hop's second stretch)
     Kmer X;               // (uniform) the new tip, walk strand
     uint32_t nc;          // (uniform) candidates found for the next hop (lanes < nc hold them)
     uint32_t used;        // (uniform) reads that held the tip
@@ -1109,9 +1115,9 @@ __device__ __forceinline__ void cons_pack(uint32_t base, bool on, uint32_t lane,
 // the caller stores it into L.cw[g][lane] once it has done its own work).  staged: L.cw[g] holds the words of THESE candidates.
 template <int MODE, bool SH = false>
 __device__ __forceinline__ void scout_cons(const SolidView &t, TeamLds &L, uint32_t g, const Kmer &X, int k, int min_cov, uint32_t &c_ptr,
-                                           uint32_t &c_del, uint32_t nc, uint32_t want, bool staged, ConsHop &R, uint64_t &word,
+                                           uint32_t &c_del, uint32_t nc, uint32_t want, bool staged, ConsHop &R, uint64_t &word, uint64_t &word2,
                                            unsigned long long &lookups, unsigned long long *tsc = nullptr)
-{
+{   // want <= 128: two stretches of 64 levels; word / word2: this lane's (and, for lanes < 32, a second) word of the next hop's pieces
     static_assert(MODE == KEY_PACKED, "the tip and its levels in 64-bit words");
 #ifdef MC_SCOUT_TIMING
     unsigned long long ts_ = __builtin_amdgcn_s_memrealtime();
@@ -1120,12 +1126,15 @@ __device__ __forceinline__ void scout_cons(const SolidView &t, TeamLds &L, uint3
 #endif
     const uint32_t lane = threadIdx.x & 63;
     uint64_t *cw = L.cw[g];
-    R.m = 0; R.why = 1; R.e_hi = R.e_lo = 0; R.X = X; R.nc = 0; R.used = 0;
-    word = 0;
+    R.m = 0; R.why = 1; R.e_hi = R.e_lo = 0; R.f_hi = R.f_lo = 0; R.X = X; R.nc = 0; R.used = 0;
+    word = 0; word2 = 0;
+    // staged word `lane` belongs to candidate cdA (its word wiA), staged word 64 + lane (lanes < 32) to cdB
+    const uint32_t cdA = lane / CONS_WORDS, wiA = lane - cdA * CONS_WORDS, cdB = (lane + 64u) / CONS_WORDS, wiB = lane + 64u - cdB * CONS_WORDS;
     if (!staged) {
-        const uint32_t cp = (uint32_t)__shfl((int)c_ptr, (int)(lane >> 3));
+        const uint32_t cpA = (uint32_t)__shfl((int)c_ptr, (int)cdA), cpB = (uint32_t)__shfl((int)c_ptr, (int)min(cdB, CONS_N - 1u));
         __builtin_amdgcn_wave_barrier();
-        cw[lane] = (lane >> 3) < nc ? cons_word_of(t, cp, lane & 7u) : 0ull;
+        cw[lane] = cdA < nc ? cons_word_of(t, cpA, wiA) : 0ull;
+        if (lane < 32u) cw[64u + lane] = cdB < nc ? cons_word_of(t, cpB, wiB) : 0ull;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
@@ -1170,23 +1179,28 @@ __device__ __forceinline__ void scout_cons(const SolidView &t, TeamLds &L, uint3
     // one that does not.
     uint32_t len = 0;
     uint64_t s_hi = 0, s_lo = 0;
-    {
-        if (lane < CONS_N && Qv != ~0u) {
+    // add: 0 for the levels 1 .. 64, 64 for the second stretch (65 .. 128); live: this lane's candidate takes part
+    auto cut = [&](uint32_t add, bool live, uint32_t &len_o, uint64_t &o_hi, uint64_t &o_lo) {
+        len_o = 0; o_hi = 0; o_lo = 0;
+        if (lane < CONS_N && Qv != ~0u && live) {
             const uint32_t Q = Qv & 0x7FFFFFFFu;
             const uint64_t *sw = cw + CONS_WORDS * lane;
             if (Qv >> 31) {
-                const uint32_t off0 = Q + (uint32_t)k - wbv, lim = min(CONS_WORDS * 32u, rb - wbv);
-                if (off0 < lim) { len = min(64u, lim - off0); s_hi = bases32(sw, off0); s_lo = bases32(sw, off0 + 32u); }
+                const uint32_t off0 = Q + (uint32_t)k - wbv + add, lim = min(CONS_WORDS * 32u, rb - wbv);
+                if (off0 < lim) { len_o = min(64u, lim - off0); o_hi = bases32(sw, off0); o_lo = bases32(sw, off0 + 32u); }
             } else {
                 const uint32_t a = Q - wbv;  // staged bases in front of the tip (fewer than 64 only at the very start of the store)
-                if (a >= 64u) { len = 64u; s_hi = rc64_pairs(bases32(sw, a - 32u)); s_lo = rc64_pairs(bases32(sw, a - 64u)); }
+                if (a >= 64u + add) { len_o = 64u; o_hi = rc64_pairs(bases32(sw, a - 32u - add)); o_lo = rc64_pairs(bases32(sw, a - 64u - add)); }
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if (lane < CONS_N) { L.cstr[g][lane][0] = s_hi; L.cstr[g][lane][1] = s_lo; L.cnd[g][lane] = len; }
+        if (lane < CONS_N) { L.cstr[g][lane][0] = o_hi; L.cstr[g][lane][1] = o_lo; L.cnd[g][lane] = len_o; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-    }
+    };
+    cut(0u, true, len, s_hi, s_lo);
+    uint32_t m1 = 0;            // levels of the second stretch
+    uint64_t f_hi = 0, f_lo = 0;
     uint32_t m0;
     uint64_t e_hi, e_lo;
 #if MC_CONS_PAIRS
@@ -1216,70 +1230,88 @@ __device__ __forceinline__ void scout_cons(const SolidView &t, TeamLds &L, uint3
         else if (m0 < 64u) e_lo &= ~0ull << (128u - 2u * m0);
     }
 #else
-    // ---- lane l votes on level l + 1: the candidates' bases there (4 bits each, 8: none) and a first count, four byte counters
-    uint32_t bb = 0, cnt = 0;
-    {
-        const uint64_t *col = &L.cstr[g][0][lane >> 5];
-        const uint32_t sh = 62u - 2u * (lane & 31u);
-        uint64_t wv_[CONS_N];
+    // ---- a stretch of 64 levels: lane l votes on level l + 1 of it -- the candidates' bases there (4 bits each, 8: none) and a first
+    // count, four byte counters.  v_hi:v_lo / vlen: lane i < CONS_N's candidate's bases for the stretch (cut above); alive_end: lane i <
+    // CONS_N: up to which level of the stretch its candidate is alive; returns the levels the stretch adds, their bases in o_hi:o_lo
+    uint32_t alive_end = 64u;
+    auto vote = [&](const uint64_t v_hi, const uint64_t v_lo, const uint32_t vlen, const uint32_t want_s, const bool single_s, uint64_t &o_hi, uint64_t &o_lo) -> uint32_t {
+        uint32_t bb = 0, cnt = 0;
+        {
+            const uint64_t *col = &L.cstr[g][0][lane >> 5];
+            const uint32_t sh = 62u - 2u * (lane & 31u);
+            uint64_t wv_[CONS_N];
 #pragma unroll
-        for (uint32_t i = 0; i < CONS_N; i++) wv_[i] = col[2u * i];  // (requested together)
+            for (uint32_t i = 0; i < CONS_N; i++) wv_[i] = col[2u * i];  // (requested together)
 #pragma unroll
-        for (uint32_t i = 0; i < CONS_N; i++) {
-            const uint32_t len_i = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)i);
-            const bool valid = lane < len_i;
-            const uint32_t b = (uint32_t)(wv_[i] >> sh) & 3u;
-            cnt += (valid ? 1u : 0u) << (8u * b);
-            bb |= (valid ? b : 8u) << (4u * i);
+            for (uint32_t i = 0; i < CONS_N; i++) {
+                const uint32_t len_i = (uint32_t)__builtin_amdgcn_readlane((int)vlen, (int)i);
+                const bool valid = lane < len_i;
+                const uint32_t b = (uint32_t)(wv_[i] >> sh) & 3u;
+                cnt += (valid ? 1u : 0u) << (8u * b);
+                bb |= (valid ? b : 8u) << (4u * i);
+            }
         }
-    }
-    uint32_t top, second;
-    uint32_t base = cons_top(cnt, top, second);
-    bool ok = top >= 1;
-    if (!single) {
-        // ---- up to which level is each read alive?  A read stops being alive at its first disagreement with the first count's
-        // winners that has a second one within the two levels behind it: a sequencing error is one lone disagreement, the end
-        // of a read (the store holds the next read's bases behind it) a run of them.  Lane i < CONS_N compares candidate i's 64
-        // bases with the winners all at once: a flag a level in the even bits (two bits a level, first level on top, so
-        // "behind" is to the right), levels it holds no base for flagged too
-        uint64_t p_hi, p_lo;
-        cons_pack(base, true, lane, p_hi, p_lo);
-        uint32_t end = 0;
-        if (lane < CONS_N) {
-            constexpr uint64_t EV = 0x5555555555555555ull;
-            const uint64_t x_hi = s_hi ^ p_hi, x_lo = s_lo ^ p_lo;
-            uint64_t d_hi = (x_hi | (x_hi >> 1)) & EV, d_lo = (x_lo | (x_lo >> 1)) & EV;
-            if (len < 32u) { d_hi |= EV >> (2u * len); d_lo = EV; }
-            else if (len < 64u) d_lo |= EV >> (2u * (len - 32u));
-            const uint64_t f_hi = d_hi & ((d_hi << 2) | (d_lo >> 62) | (d_hi << 4) | (d_lo >> 60)), f_lo = d_lo & ((d_lo << 2) | (d_lo << 4));
-            end = f_hi ? (uint32_t)__builtin_clzll(f_hi) >> 1 : (f_lo ? 32u + ((uint32_t)__builtin_clzll(f_lo) >> 1) : 64u);
-            end = min(end, len);
-        }
-        // ---- the count among the reads that are alive: the path goes on while two of them agree and no other base has as many votes
-        uint32_t cnt2 = 0;
+        uint32_t top, second;
+        uint32_t base = cons_top(cnt, top, second);
+        bool ok = top >= 1;
+        if (!single_s) {
+            // ---- up to which level is each read alive?  A read stops being alive at its first disagreement with the first count's
+            // winners that has a second one within the two levels behind it: a sequencing error is one lone disagreement, the end
+            // of a read (the store holds the next read's bases behind it) a run of them.  Lane i < CONS_N compares candidate i's 64
+            // bases with the winners all at once: a flag a level in the even bits (two bits a level, first level on top, so
+            // "behind" is to the right), levels it holds no base for flagged too
+            uint64_t p_hi, p_lo;
+            cons_pack(base, true, lane, p_hi, p_lo);
+            uint32_t end = 0;
+            if (lane < CONS_N) {
+                constexpr uint64_t EV = 0x5555555555555555ull;
+                const uint64_t x_hi = v_hi ^ p_hi, x_lo = v_lo ^ p_lo;
+                uint64_t d_hi = (x_hi | (x_hi >> 1)) & EV, d_lo = (x_lo | (x_lo >> 1)) & EV;
+                if (vlen < 32u) { d_hi |= EV >> (2u * vlen); d_lo = EV; }
+                else if (vlen < 64u) d_lo |= EV >> (2u * (vlen - 32u));
+                const uint64_t f_hi_ = d_hi & ((d_hi << 2) | (d_lo >> 62) | (d_hi << 4) | (d_lo >> 60)), f_lo_ = d_lo & ((d_lo << 2) | (d_lo << 4));
+                end = f_hi_ ? (uint32_t)__builtin_clzll(f_hi_) >> 1 : (f_lo_ ? 32u + ((uint32_t)__builtin_clzll(f_lo_) >> 1) : 64u);
+                end = min(end, vlen);
+            }
+            alive_end = end;
+            // ---- the count among the reads that are alive: the path goes on while two of them agree and no other base has as many votes
+            uint32_t cnt2 = 0;
 #pragma unroll
-        for (uint32_t i = 0; i < CONS_N; i++) {
-            const uint32_t end_i = (uint32_t)__builtin_amdgcn_readlane((int)end, (int)i);
-            cnt2 += (lane < end_i ? 1u : 0u) << (8u * ((bb >> (4u * i)) & 3u));
+            for (uint32_t i = 0; i < CONS_N; i++) {
+                const uint32_t end_i = (uint32_t)__builtin_amdgcn_readlane((int)end, (int)i);
+                cnt2 += (lane < end_i ? 1u : 0u) << (8u * ((bb >> (4u * i)) & 3u));
+            }
+            base = cons_top(cnt2, top, second);
+            ok = top >= 2 && top > second;
         }
-        base = cons_top(cnt2, top, second);
-        ok = top >= 2 && top > second;
-    }
-    {
-        const unsigned long long okm = __ballot(ok && lane < want);
-        m0 = okm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~okm);
-        if (m0 == 0) return;
-        cons_pack(base, lane < m0, lane, e_hi, e_lo);
+        const unsigned long long okm = __ballot(ok && lane < want_s);
+        const uint32_t ms = okm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~okm);
+        o_hi = 0; o_lo = 0;
+        if (ms) cons_pack(base, lane < ms, lane, o_hi, o_lo);
+        return ms;
+    };
+    m0 = vote(s_hi, s_lo, len, min(want, 64u), single, e_hi, e_lo);
+    if (m0 == 0) return;
+    // ---- the second stretch: the hop ran its 64 lanes out and the reads are still there -- the ones that were alive to the end of the
+    // first stretch vote on the levels 65 .. 128 from the bases behind, no round trip in between (the look-ups come once, at the end)
+    if (!single && m0 == 64u && want > 64u) {
+        uint32_t len2;
+        uint64_t t_hi, t_lo;
+        cut(64u, alive_end >= 64u, len2, t_hi, t_lo);
+        m1 = vote(t_hi, t_lo, len2, want - 64u, false, f_hi, f_lo);
     }
 #endif
     // the tip's k bases and the levels behind them, 32 bases a word: vertex j levels past the tip = bases [j, j + k) of it
     uint64_t *cs = L.cs[g];
     __builtin_amdgcn_wave_barrier();
+    const uint32_t mt = m0 + m1;  // the levels the votes added
     if (lane == 0) {
         cs[0] = (X.lo << (64u - sk2)) | (e_hi >> sk2);
         cs[1] = (e_hi << (64u - sk2)) | (e_lo >> sk2);
-        cs[2] = e_lo << (64u - sk2);
-        cs[3] = 0;
+        cs[2] = (e_lo << (64u - sk2)) | (f_hi >> sk2);
+        cs[3] = (f_hi << (64u - sk2)) | (f_lo >> sk2);
+        cs[4] = f_lo << (64u - sk2);
+        cs[5] = 0; cs[6] = 0;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1287,7 +1319,7 @@ __device__ __forceinline__ void scout_cons(const SolidView &t, TeamLds &L, uint3
     if (tsc) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); tsc[1] += n_ - ts_; ts_ = n_; }
 #endif
     // ---- the vertices that are looked up: lane l <-> level lo + l
-    const uint32_t lo = single || m0 <= CONS_TAIL ? 1u : m0 - CONS_TAIL + 1u, n_lk = m0 - lo + 1u;
+    const uint32_t lo = single || mt <= CONS_TAIL ? 1u : mt - CONS_TAIL + 1u, n_lk = mt - lo + 1u;
     const bool lk = lane < n_lk;
     const uint32_t j = lo + lane;
     const Kmer K{0, lk ? bases32(cs, j) >> (64u - sk2) : 0ull};
@@ -1378,11 +1410,19 @@ __device__ __forceinline__ void scout_cons(const SolidView &t, TeamLds &L, uint3
     __builtin_amdgcn_wave_barrier();
     c_ptr = lane < n_sel ? L.cnp[g][lane] : 0u;
     c_del = lane < n_sel ? L.cnd[g][lane] : 0u;
-    if ((lane >> 3) < n_sel) word = cons_word_of(t, L.cnp[g][lane >> 3], lane & 7u);
-    if (m < 32) { e_hi &= ~0ull << (64u - 2u * m); e_lo = 0; }
-    else if (m == 32) e_lo = 0;
-    else if (m < 64) e_lo &= ~0ull << (128u - 2u * m);
-    R.m = m; R.why = 0; R.e_hi = e_hi; R.e_lo = e_lo; R.nc = n_sel;
+    if (cdA < n_sel) word = cons_word_of(t, L.cnp[g][cdA], wiA);
+    if (lane < 32u && cdB < n_sel) word2 = cons_word_of(t, L.cnp[g][cdB], wiB);
+    {   // the bases of the levels that stay (the tail may have been cut back to the last solid vertex)
+        auto keep = [](uint64_t &hi, uint64_t &lo_, uint32_t n) {
+            if (n == 0) { hi = 0; lo_ = 0; }
+            else if (n < 32) { hi &= ~0ull << (64u - 2u * n); lo_ = 0; }
+            else if (n == 32) lo_ = 0;
+            else if (n < 64) lo_ &= ~0ull << (128u - 2u * n);
+        };
+        keep(e_hi, e_lo, min(m, 64u));
+        keep(f_hi, f_lo, m > 64u ? m - 64u : 0u);
+    }
+    R.m = m; R.why = 0; R.e_hi = e_hi; R.e_lo = e_lo; R.f_hi = f_hi; R.f_lo = f_lo; R.nc = n_sel;
     R.X = Kmer{0, bases32(cs, m) >> (64u - sk2)};
 #ifdef MC_SCOUT_TIMING
     if (tsc) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); tsc[4] += n_ - ts_; ts_ = n_; }
@@ -1447,8 +1487,8 @@ __device__ __forceinline__ void scout_companion(const BfsState &S, const SolidVi
                         uint32_t probe = seq;
                         if (lane == 0) probe = ld_u32(&box->req_seq) | (ld_u32(&box->quit) << 31);  // (used at the end of the hop)
                         ConsHop R;
-                        uint64_t word;
-                        scout_cons<MODE, SH>(t, L, wv, X, k, min_cov, c_ptr, c_del, nc, min(64u, budget - levels), staged, R, word, lookups, tsc);
+                        uint64_t word, word2;
+                        scout_cons<MODE, SH>(t, L, wv, X, k, min_cov, c_ptr, c_del, nc, min((uint32_t)MC_CONS_LEVELS, budget - levels), staged, R, word, word2, lookups, tsc);
                         if (tid == 0) iters++;
 #ifdef MC_SCOUT_TIMING
                         unsigned long long tq_ = __builtin_amdgcn_s_memrealtime();
@@ -1462,7 +1502,8 @@ __device__ __forceinline__ void scout_companion(const BfsState &S, const SolidVi
                             if (lane == 0) atomicAdd(&box->e_stuck, 1ull);
                             break;
                         }
-                        path_append(P, T, R.e_hi, R.e_lo, R.m, lane == 0);
+                        path_append(P, T, R.e_hi, R.e_lo, min(R.m, 64u), lane == 0);
+                        if (R.m > 64u) path_append(P, T, R.f_hi, R.f_lo, R.m - 64u, lane == 0);  // (the hop's second stretch)
                         levels += R.m;
                         X = R.X;
                         nc = R.nc;
@@ -1471,6 +1512,7 @@ __device__ __forceinline__ void scout_companion(const BfsState &S, const SolidVi
                         } else {  // the words around the next hop's candidates: asked for inside the hop, they have travelled meanwhile
                             __builtin_amdgcn_wave_barrier();
                             L.cw[wv][lane] = word;
+                            if (lane < 32u) L.cw[wv][64u + lane] = word2;
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                             __builtin_amdgcn_wave_barrier();
                             staged = true;
