@@ -342,7 +342,9 @@ typedef struct {
 int mc_get_stats(mc_ctx *ctx, mc_stats *out);
 int mc_reset_stats(mc_ctx *ctx);
 /* Gives the counting pipeline's scratch (the record / key streams of the last run: about 1.3 bytes per base counted) and
- * the idle blocks of the process-wide pools back to the driver; the table, the read store and the list of solid k-mers
+ * the idle blocks of the process-wide pools back to the driver -- and, on a context that counted hash keys as long records, the
+ * key streams of mc_finalize_counts' join (8 bytes a key, twice: 84 GB for configs[2]'s 4.58 G keys; a walk's check of its
+ * look-ups by key then sweeps the table instead) --; the table, the read store and the list of solid k-mers
  * stay.  For callers that need the device's memory between counting and what follows (the next counting call allocates
  * its scratch again).  No counterpart in the reference: the JVM's collector does this for BigLong2ShortHashMap's
  * transient arrays (itmo!/structures/map/BigLong2ShortHashMap.java:46-70). */
