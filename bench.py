@@ -292,7 +292,15 @@ def main():
                 rows = [r for r in csv.DictReader(l for l in open(pmc) if not l.startswith("#"))]
                 commit = next((l.split()[-1] for l in open(pmc) if l.startswith("# commit")), None)
                 fresh = None
-                if commit and os.path.isdir(os.path.join(ROOT, ".git")):
+                # (no .git on the GPU box -- the file also names a hash of the counting kernels' sources as they were measured)
+                measured = next((l.split()[2] for l in open(pmc) if l.startswith("# sources")), None)
+                if measured:
+                    import hashlib
+                    hh = hashlib.sha256()
+                    for src in ("count_pipeline.h", "kmer_device.h"):
+                        hh.update(open(os.path.join(ROOT, "metacherchant_amd", "csrc", src), "rb").read())
+                    fresh = hh.hexdigest()[:16] == measured
+                if fresh is None and commit and os.path.isdir(os.path.join(ROOT, ".git")):
                     try:
                         fresh = subprocess.run(["git", "-C", ROOT, "diff", "--quiet", commit, "--", "metacherchant_amd/csrc/count_pipeline.h",
                                                 "metacherchant_amd/csrc/kmer_device.h"], timeout=20).returncode == 0

@@ -31,6 +31,11 @@ import os
 with open("gpurun_out/pmc_summary.csv", "w") as f:
     # bench.py reports these bytes as roofline.traffic only while the counting kernels are unchanged since this commit
     f.write("# commit %s\n" % os.environ.get("MC_COMMIT", "unknown"))
+    import hashlib
+    hh = hashlib.sha256()
+    for src in ("count_pipeline.h", "kmer_device.h"):
+        hh.update(open(os.path.join("metacherchant_amd", "csrc", src), "rb").read())
+    f.write("# sources %s  (sha256[:16] of csrc/count_pipeline.h + csrc/kmer_device.h as measured: bench.py reports these bytes only while they are unchanged)\n" % hh.hexdigest()[:16])
     f.write("kernel,dispatch,FETCH_SIZE_KB,WRITE_SIZE_KB,fetch_GB_corrected_x2,write_GB\n")
     for k, d in out.items():
         name, n = k.rsplit("#", 1)
