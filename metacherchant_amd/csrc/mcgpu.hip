@@ -1412,7 +1412,8 @@ static void dup_arm(mc_ctx *c, double keys, uint32_t grid)
     const std::string keep = c->err;
     if (dup_small_bufs(c)) { c->err = keep; (void)hipGetLastError(); return; }
     const uint32_t nseg = grid + 1;  // (the last one: keys that enter the table outside the merge kernel)
-    const uint64_t cap = dup_cap(keys / ((double)DUP_B1 * (double)grid));
+    uint64_t cap = dup_cap(keys / ((double)DUP_B1 * (double)grid));
+    if (const char *e = getenv("MC_DUP_L1_SCALE")) cap = std::max<uint64_t>(4, (uint64_t)((double)cap * atof(e)));  // (tests: streams that overflow)
     if (D.l1_words < (uint64_t)DUP_B1 * nseg * cap) dup_make_room(c, (uint64_t)DUP_B1 * nseg * cap * 8);
     if (ensure_buf(c, &D.l1_keys, &D.l1_words, (uint64_t)DUP_B1 * nseg * cap) || ensure_buf(c, &D.l1_counts, &D.l1_counts_cap, (uint64_t)DUP_B1 * nseg)) {
         c->err = keep;
@@ -1503,6 +1504,8 @@ static int ensure_dups(mc_ctx *c)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     n_used = c->h_scratch[20];
     bool have_l1 = D.l1_armed && (uint32_t)c->h_scratch[21] == 0;
+    if (D.l1_armed && !have_l1 && getenv("MC_INGEST_DEBUG"))
+        fprintf(stderr, "[join] a segment of the merge kernel's key streams overflowed (the table holds %llu keys): the first level by a sweep\n", (unsigned long long)c->h_scratch[20]);
     D.l1_armed = false;  // (whatever happens next: the streams serve one join)
     if (n_used < 2) { D.checked = true; c->st.dup_keys = 0; return MC_OK; }
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
@@ -1573,6 +1576,8 @@ static int ensure_dups(mc_ctx *c)
         // more from a sweep, whose streams are sized by the number of keys the table holds
         if (attempt >= 1 || !have_l1)
             return fail(c, MC_EOVERFLOW, "internal: the key streams of the duplicate-key join overflowed (%llu keys)", n_used);
+        if (getenv("MC_INGEST_DEBUG")) fprintf(stderr, "[join] the merge kernel's key streams overflowed (sized for %.0f keys, the table holds %llu): once more from a sweep\n",
+                                               c->cfg.capacity_hint ? (double)c->cfg.capacity_hint : D.expected_keys, n_used);
         have_l1 = false;
     }
     if (n_listed) {

@@ -160,3 +160,26 @@ def test_per_window_form_merges_them_too(mc, monkeypatch, tmp_path, k):
     _check(ctx, t, k, pairs, contigs, genome, tmp_path, "k%d_perwindow" % k)
     assert ctx.stats().long_runs == 0 and ctx.stats().dup_keys == 0
     ctx.close()
+
+
+def test_key_streams_that_overflow_send_the_join_to_its_sweep(mc, monkeypatch, tmp_path, capfd):
+    """The merge kernel's key streams are sized by the capacity hint (a hint that falls short of the keys, at configs[2]'s size, makes
+    them overflow; MC_DUP_L1_SCALE plays that here): the join must notice and start again from a sweep of the table, whose streams
+    are sized by the number of keys the table really holds -- same results."""
+    monkeypatch.setenv("MC_COUNT_PATH", "partition")
+    monkeypatch.setenv("MC_DUP_L1_SCALE", "0.05")
+    monkeypatch.setenv("MC_INGEST_DEBUG", "1")
+    monkeypatch.delenv("MC_LONG_RECORDS", raising=False)
+    monkeypatch.delenv("MC_LONG_BINS", raising=False)
+    k = 47
+    pairs = [v for v in VECTORS if v["k"] == k]
+    genome, codes, offs, contigs = _planted(k, pairs, flip=True)
+    t, _ = oracle_table(codes, offs, k, po.KEY_POLY)
+    ctx = mc.Context(k, mc.KEY_POLY, 0, int(t.size() * 0.8))
+    ctx.set_coverage_hint(3)
+    ctx.add_reads_packed(po.pack(codes), offs)
+    _check(ctx, t, k, pairs, contigs, genome, tmp_path, "k47_short_hint")
+    st = ctx.stats()
+    assert st.long_runs == 1 and st.left_bins == 0 and st.dup_checks >= 1 and st.dup_keys >= len(pairs), (st.long_runs, st.left_bins, st.dup_checks, st.dup_keys)
+    ctx.close()
+    assert "[join] a segment of the merge kernel's key streams overflowed" in capfd.readouterr().err
