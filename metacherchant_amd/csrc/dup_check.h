@@ -10,11 +10,14 @@
 //             merge kernel itself while a region goes back to HBM (count_long.h k_p3_long: the keys are in LDS then, and a region's
 //             slots are in home-slot order, i.e. nearly in bucket order: runs of ~6 keys to consecutive addresses), or by a sweep of
 //             the table (k_dup_sweep: what a context falls back to).  A workgroup owns one segment of every bucket.
-//   level 2   k_dup_scatter: a bucket's keys, tile by tile through LDS, into F2 sub-buckets by the next bits.
-//   level 3   k_dup_find: a sub-bucket (a few thousand keys) goes into an LDS set with one compare-and-swap a key; a key that is
-//             there already is listed.
+//   level 2   k_dup_scatter: a bucket's keys, tile by tile through LDS, into F2 <= 1024 sub-buckets by the next bits; a workgroup
+//             (bucket, slice of its segments) owns its own segment of every sub-bucket: no global atomics.
+//   level 3   k_dup_find: a sub-bucket (~1 750 keys) goes into an LDS set of 32-bit fingerprints with one compare-and-swap a key; a
+//             key whose fingerprint is taken is looked at again (the sub-bucket is read once more, 7e-4 of them), and a key that
+//             really is there twice is listed.
 //
-// 8 bytes a key and level: 3.7 GB written + 7.4 GB read and written + 3.7 GB read for configs[2] scaled (458 M keys).  The list is
+// 8 bytes a key and level: 3.7 GB written (6.1 measured: runs of ~6 keys) + 3.7 GB read and 5.1 written + 3.8 GB read for configs[2]
+// scaled (458 M keys): +1.5 ms in the merge kernel, 2.8 + 1.8 ms for the two levels (profiles/r06_*).  The list is
 // empty in 994 runs of 1000 at that size; when it is not, mcgpu.hip (dup_fixup) sweeps the table once for the listed keys' slots,
 // writes the SUM of a key's counters into each of them -- so the walk, which comes by bases, and mc_get's sweep read the reference's
 // count wherever they look -- and remembers the slots: exports and "Hashtable size" count a key once, and the slots get their own
