@@ -274,6 +274,8 @@ def main():
             p3 = "k_p3_dedup" if dedup else "k_p3_merge"
             parts = {p1: st.p1_ms / launches, "k_sk2_scatter" if sk else "k_p2_scatter": st.p2_ms / launches,
                      p3: st.p3_ms / launches}
+            if world > 1 and st.binned_runs:  # the binned exchange: the senders did the first level (in `extract`, not in the counting run)
+                parts = {"k_sk2_scatter_staged<listed>": st.p2_ms / launches, p3: st.p3_ms / launches}
             if st.long_runs:  # polynomial keys, k > 32, as long records (csrc/count_long.h)
                 parts = {"k_skl_extract": st.p1_ms / launches, "k_sk2_scatter_compact<2,2>": st.p2_ms / launches, "k_p3_long": st.p3_ms / launches}
             pipeline = st.p3_ms > 0
@@ -369,6 +371,12 @@ def main():
             out["walk_fallback"] = info.get("walk_fallback")
             out["exchange_GB_per_step"] = round(sum(p["exchange_GB_sent"] for p in rank_phases), 4)
             out["exchange_chunks"] = sc.n_chunks
+            # the form the records travelled in: binned = every owner's records in the order of its run's level-1 buckets (include/mcgpu.h
+            # mc_extract_superkmers_binned_dev), the counting run starts at its second level; flat = 16-byte records in any order; keys
+            # (the walk's look-ahead: every rank's packed reads brought to the walking rank's store, every record with a pointer into it)
+            out["reads_gathered_for_the_walk"] = bool(sc.gather_reads)
+            out["exchange_form"] = ("binned (%d fine buckets; %d of %d counting runs from the second level)" % (sc.fine_buckets, st.binned_runs, st.count_launches)
+                                    if sc.fine_buckets else ("flat records" if sc.by_minimizer else "keys"))
             out["count_runs_per_step"] = sc.n_count_runs
             out["rank_phases_ms_per_step"] = rank_phases
     if world == 1 and args.config == 1 and not args.skip_config2 and rank == 0:

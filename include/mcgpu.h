@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define MC_ABI_VERSION 13
+#define MC_ABI_VERSION 14
 
 /* error codes */
 #define MC_OK 0
@@ -111,8 +111,24 @@ int mc_set_coverage_hint(mc_ctx *ctx, int min_cov);
  * sharded run whose reads the BFS rank cannot see.  mc_share_read_store(ctx, from): a BFS-only context built by
  * mc_solid_from_pairs_dev reads the store of `from`, the context of the same device that counted (or extracted) this
  * rank's reads and whose pointers the pairs carry; `from` must outlive the BFS calls on ctx (NULL detaches). */
-int mc_set_read_pointers(mc_ctx *ctx, int enable);
+int mc_set_read_pointers(mc_ctx *ctx, int mode);
 int mc_share_read_store(mc_ctx *ctx, mc_ctx *from);
+/* ... and for the ranks of a sharded run whose reads the BFS rank CAN see, because they are brought to it: with pointers from the
+ * walking rank's reads alone -- one read in eight at 8 GPUs -- the walk of 8 x configs[1] took 146 ms instead of 7.9 (its look-ahead
+ * had a 3.75-fold read set to follow).  mc_set_read_pointers' mode: 0 no pointers; 1 this context's own store (the default); 2 a
+ * store kept by another context: this one keeps nothing, but works out the pointers of the reads it extracts or counts as if
+ * they were appended to a store at mc_read_store_tell() -- the caller copies the words there (mc_read_store_import_dev on the
+ * context that keeps the store, at that position).  | MC_PTRS_ON_EVERY_RECORD: every record this context will be handed by
+ * mc_add_superkmers*_dev / mc_add_keys_dev carries a pointer (the merge kernel need not wait for a later copy that has one).
+ *   mc_read_store_seek    the next reads go (mode 1) or are deemed to go (mode 2) to position at_bases, a multiple of 32: ranks
+ *                         that share one store take disjoint stretches of it; reserve_bases (mode 1): room up to there
+ *   mc_read_store_tell    where the next reads will go
+ *   mc_read_store_import_dev  n_words packed words (32 bases each, as in mc_add_reads_packed_dev, with their pad word) of another
+ *                         rank's reads to position at_bases of this context's store */
+#define MC_PTRS_ON_EVERY_RECORD 0x10
+int mc_read_store_seek(mc_ctx *ctx, uint64_t at_bases, uint64_t reserve_bases);
+uint64_t mc_read_store_tell(mc_ctx *ctx);
+int mc_read_store_import_dev(mc_ctx *ctx, const uint64_t *d_words, uint64_t n_words, uint64_t at_bases);
 
 /* Use the caller's HIP stream (a hipStream_t passed as void*) for all work of this context
  * instead of the context's own stream.  NULL restores the own stream. */
@@ -254,6 +270,29 @@ int mc_extract_superkmers_dev(mc_ctx *ctx, const uint64_t *d_words, const uint64
                               uint64_t n_bases, uint32_t n_owners, uint64_t *d_records, uint32_t *d_bins,
                               uint64_t records_cap, uint64_t *owner_offsets);
 int mc_add_superkmers_dev(mc_ctx *ctx, const uint64_t *d_records, const uint32_t *d_bins, uint64_t n);
+/* The binned form of the same exchange: the sender also does the first level of the OWNER's counting run, so that the owner's run
+ * starts at its second level (the owner's pass that dealt flat received records to its level-1 buckets was 4.5 of the 14.4 ms a
+ * rank of 8 x configs[1] counted for; the sender's packing pass does the ordering instead).  Owner o's records
+ * d_records[owner_offsets[o] .. owner_offsets[o + 1]) come in the order of n_fine "fine buckets" of the records' bin words;
+ * d_fine_counts (device, n_owners x n_fine, written here) says how many records every (owner, fine bucket) cell holds, and
+ * owner_windows (host, n_owners) how many k-mer windows every owner's records hold.  What travels to owner o: its records, its
+ * pointers (if any) and its row of n_fine counts.
+ *   mc_superkmer_fine_buckets  the n_fine to extract with for n_owners owners whose tables are laid out like this context's (the
+ *                           level-1 buckets of its counting run: a function of the table's size); 0: no binned form here
+ *                           (tables without a second level, more than 16384 / n_owners buckets, MC_EXCHANGE_BINNED=0) -- use the flat form
+ *   mc_add_superkmers_binned_dev  what an owner received: n records in n_parts parts lying back to back (part p = records
+ *                           part_offsets[p] .. part_offsets[p + 1], part_offsets on the host, n_parts + 1 entries; a part is what one
+ *                           rank sent of one chunk), part p in the order of its d_part_counts[p * n_fine ..] (device) fine buckets;
+ *                           n_windows = the windows of all records (the senders' owner_windows, summed).  Same result as
+ *                           mc_add_superkmers_dev on the same records; counts that do not add up to a part's length are MC_EINVAL.
+ *                           Where this context's level-1 buckets are not unions of the fine buckets (its table grew to another
+ *                           bucket count), or the parts are more than 1024 x np1 / n_fine, the records are counted as a flat stream. */
+uint32_t mc_superkmer_fine_buckets(mc_ctx *ctx, uint32_t n_owners);
+int mc_extract_superkmers_binned_dev(mc_ctx *ctx, const uint64_t *d_words, const uint64_t *d_read_offsets, uint64_t n_reads,
+                                     uint64_t n_bases, uint32_t n_owners, uint32_t n_fine, uint64_t *d_records, uint32_t *d_bins,
+                                     uint64_t records_cap, uint32_t *d_fine_counts, uint64_t *owner_offsets, uint64_t *owner_windows);
+int mc_add_superkmers_binned_dev(mc_ctx *ctx, const uint64_t *d_records, const uint32_t *d_bins, uint64_t n, uint64_t n_windows,
+                                 uint32_t n_fine, uint32_t n_parts, const uint64_t *part_offsets, const uint32_t *d_part_counts);
 
 /* ---- the walk over several ranks' tables where they are.  After the exchange every rank's counting table holds the k-mers it
  * owns; instead of gathering the ones at or above --coverage into a second table on the rank that walks (mc_export_dev ->
@@ -338,6 +377,7 @@ typedef struct {
                                 a copy of the solid k-mers), 2 a batch of under 2^22 windows took the direct kernel, 3 nothing vouched for
                                 the table's size when a batch came (no capacity_hint that still holds, and the table not empty), 4 bins
                                 overflowed or the table had to grow, 5 more keys in several regions than the join's lists take */
+    uint64_t binned_runs;    /* mc_add_superkmers_binned_dev calls whose run started at the second level (the others counted a flat stream) */
 } mc_stats;
 int mc_get_stats(mc_ctx *ctx, mc_stats *out);
 int mc_reset_stats(mc_ctx *ctx);

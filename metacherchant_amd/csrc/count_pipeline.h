@@ -634,16 +634,42 @@ __device__ __forceinline__ uint64_t p1w_bits(uint64_t W0, uint64_t W1, uint64_t 
 // written.  The 16-byte and 4-byte stores of the two-array form reach HBM as two partly filled sectors per record (the lines
 // of 512 buckets x 1024 segments do not live in the L2 until they are full): 9.2 GB written for 2.7 GB on configs[1].
 constexpr uint32_t SKC_REL_BITS = 22;
-template <bool OWNERS, bool COMPACT = false>
+// BINNED (multi-GPU, with OWNERS): the records of owner o are dealt to `sub` buckets by the top of their bin word -- bucket
+// o * sub + mulhi32(bin, sub), np1 * sub buckets in all -- so that a second pass (k_sk2_scatter_staged<.., false, true>) can put
+// every owner's records in the order of the `fine` level-1 buckets of the OWNER's counting run (fine = a multiple of sub) and the
+// owner needs no first level of its own.  That pass writes to exact places: this kernel counts, besides, the records of every
+// (owner, fine bucket) cell and the windows of every owner -- in LDS, a row of np1 * fine counters a workgroup (fine_rows),
+// summed by k_skb_offsets.
+constexpr uint32_t SKB_MAX_CELLS = 16384;  // owners x fine buckets at most (64 KB of LDS beside the kernel's 62)
+template <bool ON> struct Sk1wFine { uint32_t h[ON ? SKB_MAX_CELLS : 1]; uint32_t win[ON ? PT_MAX_BUCKETS : 1]; };
+struct SkBinned { uint32_t sub, fine; uint32_t *fine_rows; unsigned long long *owner_windows; };
+template <bool OWNERS, bool COMPACT = false, bool BINNED = false>
 __global__ void __launch_bounds__(P1W_THREADS, MC_P1W_MIN_WAVES) k_sk1w_extract(
     const uint64_t *__restrict__ words, const uint64_t *__restrict__ offsets, uint64_t n_reads, uint64_t base_lo,
     uint64_t n_bases, uint64_t n_tiles, const uint32_t *__restrict__ first_read, int k, uint32_t np1, uint32_t *seg_counts,
-    uint64_t cap, uint4 *out_recs, uint32_t *out_ptrs, SkSpill sp, uint64_t ptr_base, uint32_t chunk_tiles = 0, uint32_t m2 = 0)
+    uint64_t cap, uint4 *out_recs, uint32_t *out_ptrs, SkSpill sp, uint64_t ptr_base, uint32_t chunk_tiles = 0, uint32_t m2 = 0,
+    SkBinned bn = SkBinned{1, 1, nullptr, nullptr})
 {
     static_assert(!(OWNERS && COMPACT), "the compact form is for the single-GPU pipeline");
+    static_assert(!BINNED || OWNERS, "fine buckets are the owners' business");
     __shared__ Sk1wLds L;
+    __shared__ Sk1wFine<BINNED> F;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     for (uint32_t i = tid; i < PT_MAX_BUCKETS1_SK; i += P1W_THREADS) L.wcur[i] = 0;
+    if (BINNED) {
+        for (uint32_t i = tid; i < np1 * bn.fine; i += P1W_THREADS) F.h[i] = 0;
+        for (uint32_t i = tid; i < np1; i += P1W_THREADS) F.win[i] = 0;
+    }
+    // bucket of a record (and, BINNED, its cell and its owner's windows counted)
+    auto bucket_of = [&](uint32_t hsel, uint32_t bin, uint32_t n_win) -> uint32_t {
+        if (BINNED) {
+            const uint32_t o = sk_owner(hsel, np1);
+            atomicAdd(&F.h[o * bn.fine + mulhi32(bin, bn.fine)], 1u);
+            atomicAdd(&F.win[o], n_win);
+            return o * bn.sub + mulhi32(bin, bn.sub);
+        }
+        return OWNERS ? sk_owner(hsel, np1) : mulhi32(bin, np1);
+    };
     uint32_t *starts = L.starts[wv];
     uint32_t *brkw = L.brk[wv];
     uint8_t *brkb = reinterpret_cast<uint8_t *>(brkw);
@@ -848,7 +874,7 @@ __global__ void __launch_bounds__(P1W_THREADS, MC_P1W_MIN_WAVES) k_sk1w_extract(
                 hi |= (uint64_t)(n - 1) << 60;
                 const uint32_t hsel = hst[wi];
                 const uint32_t bin = sk_bin(hsel);
-                const uint32_t d = OWNERS ? sk_owner(hsel, np1) : mulhi32(bin, np1);
+                const uint32_t d = bucket_of(hsel, bin, n);
                 uint4 rec;
                 rec.x = bin; rec.y = tail; rec.z = (uint32_t)hi; rec.w = (uint32_t)(hi >> 32);
                 const uint64_t dst = atomicAdd(&L.wcur[d], 1u);
@@ -892,7 +918,7 @@ __global__ void __launch_bounds__(P1W_THREADS, MC_P1W_MIN_WAVES) k_sk1w_extract(
 #pragma unroll
             for (int qq = 1; qq < PT_ITEMS; qq++) hsel = j == (uint32_t)qq ? hmin[qq] : hsel;
             const uint32_t bin = sk_bin(hsel);
-            const uint32_t d = OWNERS ? sk_owner(hsel, np1) : mulhi32(bin, np1);
+            const uint32_t d = bucket_of(hsel, bin, n);
             uint4 rec;
             rec.x = bin; rec.y = tail; rec.z = (uint32_t)hi; rec.w = (uint32_t)(hi >> 32);
             const uint64_t dst = atomicAdd(&L.wcur[d], 1u);
@@ -913,8 +939,81 @@ __global__ void __launch_bounds__(P1W_THREADS, MC_P1W_MIN_WAVES) k_sk1w_extract(
 #endif
     }
     __syncthreads();
-    for (uint32_t d = tid; d < np1; d += P1W_THREADS)  // how much of its segment of every bucket this workgroup filled
+    const uint32_t n_buckets = BINNED ? np1 * bn.sub : np1;
+    for (uint32_t d = tid; d < n_buckets; d += P1W_THREADS)  // how much of its segment of every bucket this workgroup filled
         seg_counts[(uint64_t)d * gridDim.x + blockIdx.x] = (uint32_t)min((uint64_t)L.wcur[d], cap);
+    if (BINNED) {
+        for (uint32_t i = tid; i < np1 * bn.fine; i += P1W_THREADS) bn.fine_rows[(uint64_t)blockIdx.x * (np1 * bn.fine) + i] = F.h[i];
+        for (uint32_t i = tid; i < np1; i += P1W_THREADS) if (F.win[i]) atomicAdd(&bn.owner_windows[i], (unsigned long long)F.win[i]);
+    }
+}
+
+// BINNED, after the first level.  k_skb_colsum: cell[i] (zeroed by the caller) = records of (owner, fine bucket) cell i over all
+// workgroups' rows -- blockIdx.y takes a stretch of rows.  k_skb_offsets (one workgroup): cell_start[i] = records in the cells
+// before i (owners ascending, fine buckets ascending inside an owner: the order of the packed stream), owner_off[o] = where owner
+// o's records start, owner_off[n_owners] = all of them.
+__global__ void __launch_bounds__(256) k_skb_colsum(const uint32_t *__restrict__ fine_rows, uint32_t n_rows, uint32_t n, uint32_t *cell)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t per = (n_rows + gridDim.y - 1) / gridDim.y, r0 = blockIdx.y * per, r1 = min(n_rows, r0 + per);
+    uint32_t v = 0;
+    for (uint32_t r = r0; r < r1; r++) v += fine_rows[(uint64_t)r * n + i];
+    if (v) atomicAdd(&cell[i], v);
+}
+__global__ void __launch_bounds__(1024) k_skb_offsets(const uint32_t *__restrict__ cell, uint32_t n_owners, uint32_t fine,
+                                                      unsigned long long *cell_start, unsigned long long *owner_off)
+{
+    __shared__ unsigned long long part[1024];
+    const uint32_t tid = threadIdx.x, n = n_owners * fine;
+    const uint32_t per = (n + 1023) / 1024, lo = min(n, tid * per), hi = min(n, lo + per);
+    unsigned long long sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += cell[i];
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long acc = 0;
+        for (uint32_t i = 0; i < 1024; i++) { const unsigned long long v = part[i]; part[i] = acc; acc += v; }
+        owner_off[n_owners] = acc;
+    }
+    __syncthreads();
+    unsigned long long acc = part[tid];
+    for (uint32_t i = lo; i < hi; i++) {
+        cell_start[i] = acc;
+        if (i % fine == 0) owner_off[i / fine] = acc;
+        acc += cell[i];
+    }
+}
+
+// The receiving side of a binned exchange: part p (what one rank sent of one chunk: part_off[p] onwards in the receive buffer, in the
+// order of `fine` buckets with part_counts[p * fine + f] records each) becomes r = fine / np1 segments of every level-1 bucket of this
+// rank's counting run -- segment p * r + f % r of bucket f / r (mulhi32(bin, fine) / r = mulhi32(bin, np1) when np1 divides fine).
+// One workgroup a part.
+__global__ void __launch_bounds__(1024) k_skb_segments(const unsigned long long *__restrict__ part_off, const uint32_t *__restrict__ part_counts,
+                                                       uint32_t fine, uint32_t r, uint32_t nseg, uint32_t *seg_counts, unsigned long long *seg_start,
+                                                       unsigned long long *bad)
+{   // *bad: parts whose counts do not add up to their length (the second level would read past them)
+    __shared__ unsigned long long part[1024];
+    const uint32_t tid = threadIdx.x, p = blockIdx.x;
+    const uint32_t *cnt = part_counts + (uint64_t)p * fine;
+    const uint32_t per = (fine + 1023) / 1024, lo = min(fine, tid * per), hi = min(fine, lo + per);
+    unsigned long long sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += cnt[i];
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long acc = part_off[p];
+        for (uint32_t i = 0; i < 1024; i++) { const unsigned long long v = part[i]; part[i] = acc; acc += v; }
+        if (acc != part_off[p + 1]) atomicAdd(bad, 1ull);
+    }
+    __syncthreads();
+    unsigned long long acc = part[tid];
+    for (uint32_t f = lo; f < hi; f++) {
+        const uint64_t at = (uint64_t)(f / r) * nseg + (uint64_t)p * r + f % r;
+        seg_counts[at] = cnt[f];
+        seg_start[at] = acc;
+        acc += cnt[f];
+    }
 }
 
 // Multi-GPU split: packs the (owner, segment) pieces k_sk1_extract<true> filled into one stream ordered by
@@ -1124,23 +1223,34 @@ __device__ __forceinline__ uint4 as_uint4(v4u v) { return make_uint4(v.x, v.y, v
 #ifndef MC_SK2_ITEMS
 #define MC_SK2_ITEMS 4   // records per thread and tile: 4096-record tiles, 104 KB of LDS, one workgroup per CU (2: 2.6 ms, 4: 2.3, 5: 2.3, 6: 2.5; unstaged 2.9-3.0)
 #endif
-template <int ITEMS>
+// IN_LISTED (the receiving side of a binned exchange, mcgpu.hip mc_add_superkmers_binned_dev): segment sg of a bucket starts at record
+// in_start[bucket * nseg_in + sg] of in_recs / in_ptrs -- the pieces of what the other ranks sent, each in the order of the fine
+// buckets -- instead of at (bucket * nseg_in + sg) * seg_cap1; and what leaves is the compact form's unit, the read pointer in the
+// record's first word (the bin word has served once the leaf is known) -- out_ptrs is not written.
+// OUT_LISTED (the sending side, mc_extract_superkmers_binned_dev): the buckets are (owner, coarse bucket) pairs -- bucket = owner *
+// np1 + coarse --, the leaves the m2 fine buckets inside a coarse one, and leaf dd of a bucket goes to out_start[bucket * m2 + dd]
+// onwards, an exact place (k_skb_offsets): no capacity, nothing spilled, no fill levels written.
+template <int ITEMS, bool IN_LISTED, bool OUT_LISTED>
 struct Sk2sLds {
     uint4 rec[PT_THREADS * ITEMS];
-    uint32_t ptr[PT_THREADS * ITEMS];
+    uint32_t ptr[IN_LISTED ? 1 : PT_THREADS * ITEMS];
     uint16_t leaf[PT_THREADS * ITEMS];
     uint32_t cnt[PT_MAX_LEAVES2], wcur[PT_MAX_LEAVES2], off[PT_MAX_LEAVES2];
     uint32_t seg_prefix[P1W_SEGMENTS + 1];
     uint32_t wave_tot[PT_THREADS / 64];
     uint32_t tile_seg;
+    unsigned long long seg_at[IN_LISTED ? P1W_SEGMENTS : 1];
+    unsigned long long out_at[OUT_LISTED ? PT_MAX_LEAVES2 : 1];
 };
-template <int ITEMS>
+template <int ITEMS, bool IN_LISTED = false, bool OUT_LISTED = false>
 __global__ void __launch_bounds__(PT_THREADS) k_sk2_scatter_staged(const uint4 *__restrict__ in_recs, const uint32_t *__restrict__ in_ptrs,
                                                                    uint64_t seg_cap1, const uint32_t *__restrict__ seg_counts1,
                                                                    uint32_t n_buckets1, uint32_t np1, uint32_t m2, uint32_t *leaf_counts,
-                                                                   uint64_t cap2, uint4 *out_recs, uint32_t *out_ptrs, SkSpill sp, uint32_t nseg_in)
+                                                                   uint64_t cap2, uint4 *out_recs, uint32_t *out_ptrs, SkSpill sp, uint32_t nseg_in,
+                                                                   const unsigned long long *__restrict__ in_start = nullptr,
+                                                                   const unsigned long long *__restrict__ out_start = nullptr)
 {
-    __shared__ Sk2sLds<ITEMS> L;
+    __shared__ Sk2sLds<ITEMS, IN_LISTED, OUT_LISTED> L;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     constexpr uint32_t TILE = PT_THREADS * ITEMS;
     auto block_excl = [&](uint32_t c, uint32_t *total) -> uint32_t {  // exclusive scan of one value per thread
@@ -1171,7 +1281,10 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk2_scatter_staged(const uint4 *
             const uint32_t ex = block_excl(c, &total);
             if (tid < nseg_in) L.seg_prefix[tid] = ex;
             if (tid == 0) L.seg_prefix[nseg_in] = total;
+            if (IN_LISTED) if (tid < nseg_in) L.seg_at[tid] = in_start[(uint64_t)bucket * nseg_in + tid];
+            if (OUT_LISTED) if (tid < m2) L.out_at[tid] = out_start[(uint64_t)bucket * m2 + tid];
         }
+        const uint32_t bdig = OUT_LISTED ? bucket % np1 : bucket;  // (the bucket's digit of the bin word)
         __syncthreads();
         for (uint32_t first = 0; first < total; first += TILE) {
             if (tid == 0) {  // segment of the tile's first record: largest sg with seg_prefix[sg] <= first
@@ -1193,7 +1306,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk2_scatter_staged(const uint4 *
                 have[j] = e < total;
                 if (have[j]) {
                     while (e >= L.seg_prefix[sg + 1]) sg++;
-                    const uint64_t at = ((uint64_t)bucket * nseg_in + sg) * seg_cap1 + (e - L.seg_prefix[sg]);
+                    const uint64_t at = (IN_LISTED ? (uint64_t)L.seg_at[sg] : ((uint64_t)bucket * nseg_in + sg) * seg_cap1) + (e - L.seg_prefix[sg]);
                     rec[j] = ld_v4u(&in_recs[at]);
                     ptr[j] = in_ptrs[at];
                 }
@@ -1201,7 +1314,8 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk2_scatter_staged(const uint4 *
 #pragma unroll
             for (int j = 0; j < ITEMS; j++)
                 if (have[j]) {
-                    d[j] = mulhi32(rec[j].x, np1 * m2) - bucket * m2;
+                    d[j] = mulhi32(rec[j].x, np1 * m2) - bdig * m2;
+                    if (IN_LISTED) rec[j].x = ptr[j];
                     rank[j] = atomicAdd(&L.cnt[d[j]], 1u);
                 }
             __syncthreads();
@@ -1216,7 +1330,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk2_scatter_staged(const uint4 *
                 if (have[j]) {
                     const uint32_t at = L.off[d[j]] + rank[j];
                     st_v4u(&L.rec[at], rec[j]);
-                    L.ptr[at] = ptr[j];
+                    if (!IN_LISTED) L.ptr[at] = ptr[j];
                     L.leaf[at] = (uint16_t)d[j];
                 }
             __syncthreads();
@@ -1224,10 +1338,16 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk2_scatter_staged(const uint4 *
             for (uint32_t i = tid; i < n_tile; i += PT_THREADS) {
                 const uint32_t dd = L.leaf[i];
                 const uint64_t dst = (uint64_t)L.wcur[dd] + (i - L.off[dd]);
-                if (dst < cap2) {
+                if (OUT_LISTED) {
+                    const uint64_t at = (uint64_t)L.out_at[dd] + dst;
+                    if (at < cap2) {  // (here: the room of the caller's buffer; the host reports what did not fit)
+                        st_v4u(&out_recs[at], ld_v4u(&L.rec[i]));
+                        out_ptrs[at] = L.ptr[i];
+                    }
+                } else if (dst < cap2) {
                     const uint64_t at = ((uint64_t)bucket * m2 + dd) * cap2 + dst;
                     st_v4u(&out_recs[at], ld_v4u(&L.rec[i]));
-                    out_ptrs[at] = L.ptr[i];
+                    if (!IN_LISTED) out_ptrs[at] = L.ptr[i];
                 } else {
                     sk_spill_push(sp, L.rec[i]);
                 }
@@ -1236,7 +1356,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_sk2_scatter_staged(const uint4 *
             if (tid < m2) { L.wcur[tid] += L.cnt[tid]; L.cnt[tid] = 0; }
         }
         __syncthreads();
-        if (tid < m2) leaf_counts[(uint64_t)bucket * m2 + tid] = min(L.wcur[tid], (uint32_t)cap2);
+        if (!OUT_LISTED) if (tid < m2) leaf_counts[(uint64_t)bucket * m2 + tid] = min(L.wcur[tid], (uint32_t)cap2);
     }
 }
 

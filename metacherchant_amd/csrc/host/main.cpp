@@ -452,6 +452,7 @@ int run(const Options &o)
     constexpr size_t CHUNK_JOBS = 256;
     const size_t calcs_per_chunk = std::max<size_t>(1, CHUNK_JOBS / dirs.size());
     double bfs_ms = 0, out_ms = 0;
+    unsigned long long bfs_rounds = 0, bfs_levels = 0;  // (metrics.json: how well the walks' look-ahead did -- levels per verification round)
     auto ms_between = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     for (size_t c0 = 0; c0 < calcs.size(); c0 += calcs_per_chunk) {
         const size_t c1 = std::min(calcs.size(), c0 + calcs_per_chunk);
@@ -478,6 +479,7 @@ int run(const Options &o)
         if (!jobs.empty()) E.bfs_batch(jobs.data(), (uint32_t)jobs.size(), o.coverage, o.maxkmers, o.maxradius, res.data());
         const auto tb1 = std::chrono::steady_clock::now();
         bfs_ms += ms_between(tb0, tb1);
+        for (const mc_bfs_result &r : res) { bfs_rounds += r.rounds; bfs_levels += r.levels; }
 
         size_t j = 0;
         for (size_t c = c0; c < c1; c++) {
@@ -517,9 +519,9 @@ int run(const Options &o)
     char buf[512];
     snprintf(buf, sizeof buf,
              "{\"windows\": %llu, \"distinct_kmers\": %llu, \"load_and_count_ms\": %.3f, \"count_kernel_ms\": %.3f, "
-             "\"bfs_ms\": %.3f, \"output_ms\": %.3f, \"table_bytes\": %llu}\n",
+             "\"bfs_ms\": %.3f, \"output_ms\": %.3f, \"table_bytes\": %llu, \"binned_runs\": %llu, \"bfs_levels\": %llu, \"bfs_rounds\": %llu}\n",
              (unsigned long long)stt.windows, (unsigned long long)n_distinct, ms(t0, t1), stt.count_total_ms, bfs_ms,
-             out_ms, (unsigned long long)stt.table_bytes);
+             out_ms, (unsigned long long)stt.table_bytes, (unsigned long long)stt.binned_runs, bfs_levels, bfs_rounds);  // (binned_runs: --devices, counting runs fed by the binned exchange)
     write_file(wd + "/metrics.json", buf);
     write_file(wd + "/SUCCESS", "");
     return 0;

@@ -230,6 +230,13 @@ struct mc_ctx {
     uint64_t *rs_words = nullptr;
     uint64_t rs_cap_words = 0, rs_bases = 0;
     bool rs_enabled = true;
+    // mc_set_read_pointers' other modes.  rs_virtual: this context keeps no store, but the reads it extracts or counts sit in ANOTHER
+    // context's store (the walking rank's, mc_read_store_import_dev) from rs_bases on: their pointers are worked out as if they were
+    // appended here, and only the bookkeeping is done.  all_ptrs: every record mc_add_superkmers*_dev is handed carries a pointer.
+    // rs_hi_bases: how far the store is filled by imports (a real store; never below what rs_bases has reached).
+    bool rs_virtual = false, all_ptrs = false;
+    uint64_t rs_hi_bases = 0;
+    uint64_t rs_end() const { return std::max(rs_bases, rs_hi_bases); }
     mc_ctx *rs_from = nullptr;
     uint64_t cur_ptr_base = ~0ull;  // store position of base 0 of the batch being counted (~0: no pointers for it)
     uint32_t ptr_tries = 1;         // count_pipeline.h k_p3_merge: 16 while the records of other ranks (no pointers) are merged
@@ -314,8 +321,15 @@ struct mc_ctx {
         uint32_t *cursors1 = nullptr, *seg_counts1 = nullptr, *cursors2 = nullptr, *leaf_state = nullptr, *leaf_new = nullptr, *flags = nullptr;  // cursors1: owner cursors (multi-GPU split); cursors2: leaf fill levels; flags: [0] spill lost, [1] any leaf failed, [2] a segment of the solid list overflowed
         unsigned long long *spill_count = nullptr;
         uint64_t a_cap = 0, b_cap = 0, spill_cap = 0, tiles1_cap = 0, leaves_cap = 0, segs1_cap = 0, a_hints_cap = 0, b_hints_cap = 0, cursors2_cap = 0;
+        // the binned exchange (mc_extract_superkmers_binned_dev / mc_add_superkmers_binned_dev): every first-level workgroup's row of
+        // (owner, fine bucket) counters; where every cell starts in the packed stream; where every listed segment of the second level starts
+        uint32_t *skb_rows = nullptr;
+        unsigned long long *skb_cell_start = nullptr, *skb_seg_start = nullptr, *skb_small = nullptr;  // skb_small: owner offsets / windows / part offsets / a flag
+        uint64_t skb_rows_cap = 0, skb_cell_start_cap = 0, skb_seg_start_cap = 0, skb_small_cap = 0;
         void release(int dev)
         {   // (the large streams go to g_scratch_pool: ensure_buf took them from there)
+            g_scratch_pool.put(dev, skb_rows, skb_rows_cap * 4); g_scratch_pool.put(dev, skb_cell_start, skb_cell_start_cap * 8);
+            g_scratch_pool.put(dev, skb_seg_start, skb_seg_start_cap * 8); g_scratch_pool.put(dev, skb_small, skb_small_cap * 8);
             g_scratch_pool.put(dev, a_keys, a_cap * 8); g_scratch_pool.put(dev, b_keys, b_cap * 8); (void)hipFree(spill_keys);
             g_scratch_pool.put(dev, a_recs, a_recs_cap * sizeof(uint4)); g_scratch_pool.put(dev, b_recs, b_recs_cap * sizeof(uint4));
             (void)hipFree(spill_recs); (void)hipFree(solid_cursors); (void)hipFree(emit_counts);
@@ -388,8 +402,8 @@ struct mc_ctx {
         t.empty_cnt = d_ctr + 1;
         t.fatal = d_fatal;
         const mc_ctx *rs = rs_from ? rs_from : this;
-        t.reads = rs->rs_bases ? rs->rs_words : nullptr;
-        t.reads_bases = rs->rs_bases;
+        t.reads = rs->rs_end() && rs->rs_words ? rs->rs_words : nullptr;
+        t.reads_bases = rs->rs_words ? rs->rs_end() : 0;
         t.shards = d_shards;
         t.n_shards = d_shards ? (uint32_t)h_shards.size() : 0u;
         t.owner_mm_k = shard_owner_mm_k;
@@ -1609,6 +1623,11 @@ struct PipePlan {
     uint64_t pos0 = 0;
     bool guessed = false;  // no capacity hint vouches for the table's size: pipe_finish merges a sample of the leaves first
     bool lng = false;      // long records (count_long.h): two 16-byte words a record in every stream
+    // listed: there is no first level -- the records lie in the caller's buffer (in_recs / in_ptrs) in pieces that are in level-1 bucket
+    // order already (the binned exchange), and the second level reads segment sg of a bucket from pipe.skb_seg_start[bucket * nseg1 + sg]
+    bool listed = false;
+    const uint4 *in_recs = nullptr;
+    const uint32_t *in_ptrs = nullptr;
     SpillView sp{};
     SkSpill sks{};
 };
@@ -1633,12 +1652,63 @@ __global__ void __launch_bounds__(256) k_pipe_reset(uint32_t *seg_counts1, uint6
     if (flags && t < 6) flags[t] = 0;
 }
 
+// How a table of c->n_regions regions splits into level-1 buckets and leaves (records: the super-k-mer pipeline; else keys): *n_leaves
+// leaves of 2^*g regions each, *np1 level-1 buckets.  Returns what is wrong, or null.
+static const char *plan_levels(const mc_ctx *c, bool records, uint64_t *n_leaves_out, uint32_t *g_out, uint64_t *np1_out)
+{
+    // leaves: the regions themselves up to 2^20 of them (2^18 when keys travel, not records), else 2^g regions per leaf;
+    // level-1 buckets: up to 512, each of m2 <= 1024 (512) leaves (regions_for made the numbers divide)
+    uint64_t n_leaves = c->n_regions;
+    uint32_t g = 0;
+    // (2^20 leaves at most in either form: a leaf that covers 2^g regions is swept 2^(g+1) times by the merge kernel -- with 2^18
+    // leaves the 137 GB table of configs[2] had g = 3, and two thirds of that run were those sweeps)
+    const uint32_t max_b2 = records ? PT_MAX_LEAVES2 : PT_MAX_BUCKETS_KEYS;  // (super-k-mer records: k_sk2_scatter; keys: k_p2_scatter)
+    const uint32_t max_b1_big = records ? PT_MAX_BUCKETS1_SK : PT_MAX_BUCKETS_KEYS;  // (1024 level-1 buckets only when 512 do not do)
+    while (n_leaves > (uint64_t)max_b1_big * max_b2) { n_leaves >>= 1; g++; }
+    if ((n_leaves << g) != c->n_regions) return "the table's regions do not split into leaves";
+    if (n_leaves < 4) return "partitioned counting needs at least 4 table regions";
+    // (512 level-1 buckets while 512 x max_b2 leaves do, then 1024, then -- super-k-mer records only -- 2048)
+    uint64_t np1 = PT_MAX_BUCKETS;
+    while (np1 < max_b1_big && n_leaves > np1 * max_b2) np1 *= 2;
+    np1 = std::min<uint64_t>(n_leaves, np1);
+    if (records) if (const char *e = getenv("MC_SK_B1")) np1 = std::min<uint64_t>(n_leaves, std::min<uint64_t>(std::max<uint64_t>(strtoull(e, nullptr, 10), 1), max_b1_big));  // (tuning runs)
+    while (n_leaves % np1) np1--;  // (a power of two, or 512 dividing a multiple of 512)
+    if (n_leaves / np1 > max_b2) return "the leaves do not fit two scatter levels";
+    *n_leaves_out = n_leaves; *g_out = g; *np1_out = np1;
+    return nullptr;
+}
+
+// Makes sure the table can take a batch of wb key occurrences: with a capacity hint that still holds the table was sized for
+// it; without one assume every eighth occurrence is a new key at most.  Either way the merge kernel
+// reports regions that would overflow and the table is grown then.
+static int pipe_reserve(mc_ctx *c, uint64_t wb, bool *hint_holds_out)
+{
+    unsigned long long used;
+    uint32_t fatal;
+    int rc = read_counters(c, &used, &fatal);
+    if (rc) return rc;
+    if (fatal) return fail(c, MC_EOVERFLOW, "a k-mer table region filled up (hash skew)");
+    c->n_used_host = used;
+    const bool hint_holds = c->cfg.capacity_hint && used < c->cfg.capacity_hint;
+    if (!hint_holds && c->n_slots() < wb / 4) {
+        const uint64_t want = regions_for(c, (uint64_t)(((double)used + (double)wb / 8.0) / 0.5));
+        if (want > c->n_regions) {
+            rc = table_grow(c, want);
+            if (rc) return rc;
+        }
+    }
+    *hint_holds_out = hint_holds;
+    return MC_OK;
+}
+
 // Table capacity check, scratch buffers and cursors for one run of the partitioned pipeline over
 // `wb` key occurrences.  n_records != 0: they travel as (an estimated) n_records super-k-mer records.
 static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records = 0, uint32_t nseg1 = PT_SEGMENTS, uint32_t pieces = 1,
-                        bool level2_only = false, uint64_t compact_tiles = 0, bool lng = false)
-{
+                        bool level2_only = false, uint64_t compact_tiles = 0, bool lng = false, bool listed = false)
+{   // listed: PipePlan::listed -- no first-level streams (the solid list alone may want pipe.a_recs), the caller has filled
+    // pipe.seg_counts1 (np1 x nseg1 fill levels) and pipe.skb_seg_start already
     pl->lng = lng;
+    pl->listed = listed;
     const uint64_t rw = lng ? 2 : 1;  // 16-byte words a record   // compact_tiles != 0: the caller's level-1 kernel is k_sk1w_extract over this many tiles in one piece and can write the compact
     // form: taken up when the rest of the run allows it (a second level through the staged kernel, one region per leaf, segments
     // short enough for 22-bit positions)   // level2_only: the level-1 scatter has run and the table has since been replaced by one of another size (pipe_resize_by_sample):
@@ -1649,44 +1719,15 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
     mc_ctx::Pipe &P = c->pipe;
     c->solid_list_fresh = false;  // the pipeline buffers are about to be reused
     c->dup.l2_valid = false;      // (... and with them what the key join left there)
-    // Make sure the table can take the batch: with a capacity hint that still holds the table was sized for
-    // it; without one assume every eighth occurrence is a new key at most.  Either way the merge kernel
-    // reports regions that would overflow and the table is grown then.
     if (!level2_only) {
-        unsigned long long used;
-        uint32_t fatal;
-        int rc = read_counters(c, &used, &fatal);
+        bool hint_holds;
+        int rc = pipe_reserve(c, wb, &hint_holds);
         if (rc) return rc;
-        if (fatal) return fail(c, MC_EOVERFLOW, "a k-mer table region filled up (hash skew)");
-        c->n_used_host = used;
-        const bool hint_holds = c->cfg.capacity_hint && used < c->cfg.capacity_hint;
         pl->guessed = !hint_holds;
-        if (!hint_holds && c->n_slots() < wb / 4) {
-            const uint64_t want = regions_for(c, (uint64_t)(((double)used + (double)wb / 8.0) / 0.5));
-            if (want > c->n_regions) {
-                rc = table_grow(c, want);
-                if (rc) return rc;
-            }
-        }
     }
-    // leaves: the regions themselves up to 2^20 of them (2^18 when keys travel, not records), else 2^g regions per leaf;
-    // level-1 buckets: up to 512, each of m2 <= 1024 (512) leaves (regions_for made the numbers divide)
-    uint64_t n_leaves = c->n_regions;
-    uint32_t g = 0;
-    // (2^20 leaves at most in either form: a leaf that covers 2^g regions is swept 2^(g+1) times by the merge kernel -- with 2^18
-    // leaves the 137 GB table of configs[2] had g = 3, and two thirds of that run were those sweeps)
-    const uint32_t max_b2 = n_records ? PT_MAX_LEAVES2 : PT_MAX_BUCKETS_KEYS;  // (super-k-mer records: k_sk2_scatter; keys: k_p2_scatter)
-    const uint32_t max_b1_big = n_records ? PT_MAX_BUCKETS1_SK : PT_MAX_BUCKETS_KEYS;  // (1024 level-1 buckets only when 512 do not do)
-    while (n_leaves > (uint64_t)max_b1_big * max_b2) { n_leaves >>= 1; g++; }
-    if ((n_leaves << g) != c->n_regions) return fail(c, MC_EINVAL, "internal: %llu table regions do not split into leaves", (unsigned long long)c->n_regions);
-    if (n_leaves < 4) return fail(c, MC_EINVAL, "internal: partitioned counting needs at least 4 table regions");
-    // (512 level-1 buckets while 512 x max_b2 leaves do, then 1024, then -- super-k-mer records only -- 2048)
-    uint64_t np1 = PT_MAX_BUCKETS;
-    while (np1 < max_b1_big && n_leaves > np1 * max_b2) np1 *= 2;
-    np1 = std::min<uint64_t>(n_leaves, np1);
-    if (n_records) if (const char *e = getenv("MC_SK_B1")) np1 = std::min<uint64_t>(n_leaves, std::min<uint64_t>(strtoull(e, nullptr, 10), max_b1_big));  // (tuning runs)
-    while (n_leaves % np1) np1--;  // (a power of two, or 512 dividing a multiple of 512)
-    if (n_leaves / np1 > max_b2) return fail(c, MC_EINVAL, "internal: %llu leaves do not fit two scatter levels", (unsigned long long)n_leaves);
+    uint64_t n_leaves, np1;
+    uint32_t g;
+    if (const char *why = plan_levels(c, n_records != 0, &n_leaves, &g, &np1)) return fail(c, MC_EINVAL, "internal: %s (%llu table regions)", why, (unsigned long long)c->n_regions);
     pl->b1 = (uint32_t)np1;               // level-1 buckets
     pl->b2 = (uint32_t)(n_leaves / np1);  // leaves per bucket; 1: the level-1 buckets already are the leaves, no P2
     pl->g = g;
@@ -1709,6 +1750,7 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
         if (lng) pl->compact = compact_tiles && pl->sk && pl->b2 > 1 && pl->b2 <= 1024 && g == 0 && pieces == 1 && chunk * P1L_TILE < (1ull << 32) &&
                                !(pl->guessed && !c->virgin);
         pl->chunk_tiles = pl->compact ? (uint32_t)chunk : 0;
+        if (listed) pl->compact = true;  // (the listed second level leaves the pointer in the record's first word too: no pointer arrays behind it)
     }
     const uint64_t units = (pl->sk ? n_records : wb) / pieces + (pieces > 1 ? 1024 : 0);  // records in the streams (of one piece)
     // (long records into 2^20 leaves and more -- configs[2] at full size, where the table leaves the streams 130 GB --: tighter streams)
@@ -1721,14 +1763,15 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
     pl->cap2 = (uint64_t)(mean_leaf * 1.15 + sig2 * std::sqrt(mean_leaf) + 64.0);  // (a spilled record also costs the solid list, P3Emit)
     if (const char *e = getenv("MC_CAP2")) { const long v = atol(e); if (v >= 64) pl->cap2 = (uint64_t)v; }  // (tuning runs)
     pl->spill_cap = pl->sk ? std::max<uint64_t>(units * pieces / 16, 1u << 16) : std::max<uint64_t>(wb / 64, 1u << 20);
-    if (pl->np1 * nseg1 * pl->cap1 >= 0xFFFFFFFFull || (uint64_t)pl->b2 * pl->cap2 * pieces >= 0xFFFFFFFFull)
+    if ((!listed && pl->np1 * nseg1 * pl->cap1 >= 0xFFFFFFFFull) || (uint64_t)pl->b2 * pl->cap2 * pieces >= 0xFFFFFFFFull)
         return fail(c, MC_EINVAL, "internal: partitioned batch too large for 32-bit bucket indices");
     // (np1, n_leaves as computed above)
     int rc;
     uint64_t dummy;
 #define ENSURE(ptr, capvar, need) do { rc = ensure_buf(c, &(ptr), &(capvar), (need)); if (rc) return rc; } while (0)
     if (pl->sk) {
-        if (!level2_only) ENSURE(P.a_recs, P.a_recs_cap, np1 * nseg1 * pl->cap1 * pieces * rw);
+        if (!level2_only && !listed) ENSURE(P.a_recs, P.a_recs_cap, np1 * nseg1 * pl->cap1 * pieces * rw);
+        if (listed && c->want_list) ENSURE(P.a_recs, P.a_recs_cap, units + units / 4);  // (the solid list's room, as a first level would have left it)
         // (long records into a table nothing vouches for: the second level's buffer first serves as the sample's scratch set, 64 MB)
         if (pl->b2 > 1) ENSURE(P.b_recs, P.b_recs_cap, std::max<uint64_t>(n_leaves * pl->cap2 * pieces * rw, lng && pl->guessed ? (1ull << 22) : 0));
         if (!level2_only) ENSURE(P.spill_recs, P.spill_recs_cap, pl->spill_cap * rw);
@@ -1738,7 +1781,7 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
         { uint64_t cap = P.spill_cap; ENSURE(P.spill_keys, cap, pl->spill_cap); dummy = P.spill_cap; ENSURE(P.spill_hints, dummy, pl->spill_cap); P.spill_cap = cap; }
     }
     if (!pl->compact && !lng) {  // (the compact form keeps the read pointers inside the records)
-        if (!level2_only) ENSURE(P.a_hints, P.a_hints_cap, np1 * nseg1 * pl->cap1 * pieces);
+        if (!level2_only && !listed) ENSURE(P.a_hints, P.a_hints_cap, np1 * nseg1 * pl->cap1 * pieces);
         ENSURE(P.b_hints, P.b_hints_cap, n_leaves * pl->cap2 * pieces);
     }
     if (!level2_only) ENSURE(P.seg_counts1, P.segs1_cap, np1 * nseg1 * pieces);
@@ -1750,7 +1793,7 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
         P.spill_count = reinterpret_cast<unsigned long long *>(P.flags + 4);
     }
     // (one launch clears all five: a fill each, 10 us apart, was 60 us in front of every run)
-    hipLaunchKernelGGL(k_pipe_reset, dim3(256), dim3(256), 0, c->stream, P.seg_counts1, level2_only ? 0 : np1 * nseg1 * pieces, P.cursors2, n_leaves * pieces,
+    hipLaunchKernelGGL(k_pipe_reset, dim3(256), dim3(256), 0, c->stream, P.seg_counts1, level2_only || listed ? 0 : np1 * nseg1 * pieces, P.cursors2, n_leaves * pieces,
                        P.leaf_state, P.leaf_new, n_leaves, level2_only ? nullptr : P.flags);
     HIPCHK(c, hipGetLastError());
     pl->sp = SpillView{P.spill_keys, P.spill_hints, P.spill_count, pl->spill_cap, P.flags};
@@ -1950,10 +1993,13 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
             hipLaunchKernelGGL((k_sk2_scatter_compact<2, 2>), dim3((unsigned)np1), dim3(PT_THREADS), 0, c->stream, P.a_recs, pl.cap1,
                                P.seg_counts1, (uint32_t)np1, pl.b2, P.cursors2, pl.cap2, P.b_recs, pl.sks, pl.nseg1, c->cur_ptr_base, pl.pos0,
                                (uint64_t)pl.chunk_tiles * P1L_TILE);
-        else if (pl.sk && pl.compact)
+        else if (pl.sk && pl.compact && !pl.listed)
             hipLaunchKernelGGL(k_sk2_scatter_compact<MC_SK2C_ITEMS>, dim3((unsigned)np1), dim3(PT_THREADS), 0, c->stream, P.a_recs, pl.cap1,
                                P.seg_counts1, (uint32_t)np1, pl.b2, P.cursors2, pl.cap2, P.b_recs, pl.sks, pl.nseg1, c->cur_ptr_base, pl.pos0,
                                (uint64_t)pl.chunk_tiles * P1W_TILE);
+        else if (pl.listed)
+            hipLaunchKernelGGL((k_sk2_scatter_staged<MC_SK2_ITEMS, true, false>), dim3((unsigned)np1), dim3(PT_THREADS), 0, c->stream, pl.in_recs, pl.in_ptrs, (uint64_t)0,
+                               P.seg_counts1, (uint32_t)np1, pl.b1, pl.b2, P.cursors2, pl.cap2, P.b_recs, nullptr, pl.sks, pl.nseg1, P.skb_seg_start, nullptr);
         else if (pl.sk && staged && pl.pieces == 1)
             hipLaunchKernelGGL(k_sk2_scatter_staged<MC_SK2_ITEMS>, dim3((unsigned)np1), dim3(PT_THREADS), 0, c->stream, P.a_recs, P.a_hints, pl.cap1,
                                P.seg_counts1, (uint32_t)np1, pl.b1, pl.b2, P.cursors2, pl.cap2, P.b_recs, P.b_hints, pl.sks, pl.nseg1);
@@ -2494,6 +2540,23 @@ static int add_keys_partitioned(mc_ctx *c, const uint64_t *d_keys, const uint32_
     return MC_OK;
 }
 
+// a stream of records through the direct kernel (what the partitioned runs fall back on when their streams overflow)
+static int add_records_direct(mc_ctx *c, const uint4 *d_recs, const uint32_t *d_bins, uint64_t n)
+{
+    c->solid_tracked = false;
+    c->solid_list_fresh = false;
+    for (uint64_t i = 0; i < n;) {
+        uint64_t allowed;
+        int rc = table_reserve(c, (n - i) * SK_MAX_WINDOWS, &allowed);
+        if (rc) return rc;
+        const uint64_t m = std::min<uint64_t>(std::max<uint64_t>(allowed / SK_MAX_WINDOWS, 1), n - i);
+        hipLaunchKernelGGL(k_sk_add_records, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, d_recs + i, d_bins + i, m, c->cfg.k, c->view(), 0u, c->d_ctr + 6);
+        HIPCHK(c, hipGetLastError());
+        i += m;
+    }
+    return MC_OK;
+}
+
 // A flat stream of super-k-mer records (+ bin words): what a rank owns after the multi-GPU exchange.
 static int add_records_partitioned(mc_ctx *c, const uint4 *d_recs, const uint32_t *d_bins, uint64_t n)
 {
@@ -2515,19 +2578,53 @@ static int add_records_partitioned(mc_ctx *c, const uint4 *d_recs, const uint32_
     if (rc) return rc;
     rc = pipe_finish(c, pl, ms1);
     if (rc != 1) return rc;
-    // (the buckets overflowed) the direct kernel instead
-    c->solid_tracked = false;
-    c->solid_list_fresh = false;
-    for (uint64_t i = 0; i < n;) {
-        uint64_t allowed;
-        rc = table_reserve(c, (n - i) * SK_MAX_WINDOWS, &allowed);
+    return add_records_direct(c, d_recs, d_bins, n);  // (the buckets overflowed)
+}
+
+// Records that arrive in level-1 bucket order already (the binned exchange, include/mcgpu.h mc_add_superkmers_binned_dev): part p of
+// the buffer -- records part_off[p] .. part_off[p + 1] -- holds part_counts[p * fine + f] records of fine bucket f = mulhi32(bin word,
+// fine), f ascending.  Where this table's level-1 buckets are unions of fine buckets the run starts at the second level, every part
+// r = fine / np1 segments of every bucket; returns 2 where they are not (or the table has no second level, or the parts are too
+// many): the caller counts the records as a flat stream.
+static int add_records_binned(mc_ctx *c, const uint4 *d_recs, const uint32_t *d_ptrs, uint64_t n, uint64_t n_windows, uint32_t fine, uint32_t n_parts,
+                              const uint64_t *part_off, const uint32_t *d_part_counts)
+{
+    mc_ctx::Pipe &P = c->pipe;
+    {   // (the table may grow for the batch -- a context without a hint --: before the plan is looked at, as pipe_prepare would)
+        bool hint_holds;
+        int rc = pipe_reserve(c, n_windows, &hint_holds);
         if (rc) return rc;
-        const uint64_t m = std::min<uint64_t>(std::max<uint64_t>(allowed / SK_MAX_WINDOWS, 1), n - i);
-        hipLaunchKernelGGL(k_sk_add_records, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, d_recs + i, d_bins + i, m, c->cfg.k, c->view(), 0u, c->d_ctr + 6);
-        HIPCHK(c, hipGetLastError());
-        i += m;
     }
-    return MC_OK;
+    uint64_t n_leaves, np1;
+    uint32_t g;
+    if (plan_levels(c, true, &n_leaves, &g, &np1)) return 2;
+    if (n_leaves / np1 <= 1 || fine % np1 || n >= (1ull << 31)) return 2;
+    const uint64_t r = fine / np1, nseg = (uint64_t)n_parts * r;
+    if (nseg > (uint64_t)P1W_SEGMENTS || nseg == 0) return 2;
+    int rc = ensure_buf(c, &P.seg_counts1, &P.segs1_cap, np1 * nseg);
+    if (!rc) rc = ensure_buf(c, &P.skb_seg_start, &P.skb_seg_start_cap, np1 * nseg);
+    if (!rc) rc = ensure_buf(c, &P.skb_small, &P.skb_small_cap, (uint64_t)P1W_SEGMENTS + 2 * PT_MAX_BUCKETS + 8);
+    if (rc) return rc;
+    // (the parts' starts go up through the context's pinned words; the kernel checks every part's counts against its length)
+    std::vector<unsigned long long> po(part_off, part_off + n_parts + 1);
+    po.push_back(0);  // [n_parts + 1]: the "counts do not add up" flag
+    HIPCHK(c, hipMemcpyAsync(P.skb_small, po.data(), po.size() * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_skb_segments, dim3(n_parts), dim3(1024), 0, c->stream, P.skb_small, d_part_counts, fine, (uint32_t)r, (uint32_t)nseg, P.seg_counts1,
+                       P.skb_seg_start, P.skb_small + n_parts + 1);
+    HIPCHK(c, hipGetLastError());
+    unsigned long long bad = 0;
+    HIPCHK(c, hipMemcpyAsync(&bad, P.skb_small + n_parts + 1, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // (po must outlive its copy, and nothing may read by counts that do not add up)
+    if (bad) return fail(c, MC_EINVAL, "mc_add_superkmers_binned_dev: the fine-bucket counts of %llu part(s) do not add up to the parts' lengths", bad);
+    PipePlan pl;
+    rc = pipe_prepare(c, n_windows, &pl, n, (uint32_t)nseg, 1, false, 0, false, true);
+    if (rc) return rc;
+    if (pl.np1 != np1 || pl.b2 <= 1) return fail(c, MC_EINVAL, "internal: the plan of a binned run changed under it");
+    pl.in_recs = d_recs;
+    pl.in_ptrs = d_ptrs;
+    rc = pipe_finish(c, pl, 0.0);
+    if (rc != 1) return rc;
+    return add_records_direct(c, d_recs, d_ptrs, n);  // (the leaves' streams overflowed)
 }
 
 // Appends the packed bases [first_off, last_off) of a batch (word-aligned copy from the batch's own buffer) to the read
@@ -2535,7 +2632,7 @@ static int add_records_partitioned(mc_ctx *c, const uint4 *d_recs, const uint32_
 // already sits in the store from word `in_place` on (mc_add_reads_packed uploads straight into it).
 static int rs_reserve(mc_ctx *c, uint64_t more_words)
 {
-    const uint64_t used = c->rs_bases / 32, need = used + more_words + 2;
+    const uint64_t used = c->rs_words ? c->rs_end() / 32 : 0, need = std::max(c->rs_bases / 32 + more_words, used) + 2;  // (used: what must survive a move)
     if (need <= c->rs_cap_words) return MC_OK;
     uint64_t cap = std::max<uint64_t>(c->rs_cap_words * 2, std::max<uint64_t>(need, 1ull << 20));
     // (from the process-wide pool of large blocks, like the pipeline's scratch: a context's read store handed back with
@@ -2561,10 +2658,12 @@ static int rs_reserve(mc_ctx *c, uint64_t more_words)
 static int rs_append(mc_ctx *c, const uint64_t *d_words, uint64_t first_off, uint64_t last_off, int64_t in_place = -1, bool side = false)
 {
     c->cur_ptr_base = ~0ull;
-    if (!c->rs_enabled || last_off <= first_off) return MC_OK;
+    if ((!c->rs_enabled && !c->rs_virtual) || last_off <= first_off) return MC_OK;
     const uint64_t w0 = first_off / 32, w1 = (last_off + 31) / 32;  // words [w0, w1) hold the batch (+ a pad word behind)
     uint64_t at = c->rs_bases / 32;
-    if (in_place >= 0) {
+    if (c->rs_virtual) {
+        // (the words themselves travel to the context that keeps the store: mc_read_store_import_dev there, at rs_bases as it is now)
+    } else if (in_place >= 0) {
         at = (uint64_t)in_place;
     } else {
         int rc = rs_reserve(c, w1 - w0 + 1);
@@ -2843,6 +2942,7 @@ int mc_clear(mc_ctx *c)
         c->d_shards = nullptr; c->h_shards.clear(); c->shard_owner_mm_k = 0;
     }
     c->rs_bases = 0;  // (slots that pointed into the read store go with the table)
+    c->rs_hi_bases = 0;
     HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, 9 * sizeof(unsigned long long), c->stream));  // (counters and the fatal flag: one fill)
     c->n_used_host = 0;
     c->finalized = false;
@@ -2865,11 +2965,63 @@ int mc_set_coverage_hint(mc_ctx *c, int min_cov)
     return MC_OK;
 }
 
-int mc_set_read_pointers(mc_ctx *c, int enable)
+int mc_set_read_pointers(mc_ctx *c, int mode)
 {
     if (!c) return MC_EINVAL;
     std::lock_guard<std::mutex> g(c->mu);
-    c->rs_enabled = enable != 0;
+    const int m = mode & 0xF;
+    if (m > 2 || (mode & ~(0xF | MC_PTRS_ON_EVERY_RECORD))) return fail(c, MC_EINVAL, "mc_set_read_pointers: mode %d", mode);
+    c->rs_enabled = m == 1;
+    c->rs_virtual = m == 2;
+    c->all_ptrs = (mode & MC_PTRS_ON_EVERY_RECORD) != 0;
+    return MC_OK;
+}
+
+int mc_read_store_seek(mc_ctx *c, uint64_t at_bases, uint64_t reserve_bases)
+{
+    if (!c) return MC_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (at_bases % 32) return fail(c, MC_EINVAL, "mc_read_store_seek: positions are whole words (multiples of 32 bases)");
+    if (!c->rs_enabled && !c->rs_virtual) return fail(c, MC_ESTATE, "mc_read_store_seek: this context keeps no read pointers");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (c->rs_enabled) {
+        c->rs_hi_bases = c->rs_end();  // (what lies below stays readable)
+        c->rs_bases = at_bases;
+        const uint64_t want = std::max(reserve_bases, at_bases) / 32 + 2;
+        if (want > c->rs_cap_words) {
+            int rc = rs_reserve(c, want - at_bases / 32);
+            if (rc) return rc;
+        }
+    } else {
+        c->rs_bases = at_bases;
+    }
+    return MC_OK;
+}
+
+uint64_t mc_read_store_tell(mc_ctx *c)
+{
+    if (!c) return 0;
+    std::lock_guard<std::mutex> g(c->mu);
+    return c->rs_bases;
+}
+
+int mc_read_store_import_dev(mc_ctx *c, const uint64_t *d_words, uint64_t n_words, uint64_t at_bases)
+{
+    if (!c) return MC_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->rs_enabled) return fail(c, MC_ESTATE, "mc_read_store_import_dev: this context keeps no read store");
+    if (at_bases % 32 || (!d_words && n_words)) return fail(c, MC_EINVAL, "mc_read_store_import_dev: bad argument");
+    if (n_words == 0) return MC_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const uint64_t at = at_bases / 32;
+    if (at + n_words + 1 > c->rs_cap_words) {  // (mc_read_store_seek's reserve_bases is what makes this rare: a move copies the store)
+        const uint64_t fill = c->rs_bases / 32;
+        int rc = rs_reserve(c, at + n_words + 1 > fill ? at + n_words + 1 - fill : 0);
+        if (rc) return rc;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->rs_words + at, d_words, n_words * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // (the caller's buffer may go as soon as this returns)
+    c->rs_hi_bases = std::max(c->rs_hi_bases, (at + n_words) * 32);
     return MC_OK;
 }
 
@@ -3814,6 +3966,145 @@ int mc_extract_superkmers_dev(mc_ctx *c, const uint64_t *d_words, const uint64_t
     return MC_OK;
 }
 
+// fine buckets of a binned exchange for n_owners owners whose tables are laid out like this context's (0: no binned form), and the
+// coarse buckets an owner's records are dealt to by the first level (*sub)
+static uint32_t skb_fine_buckets(const mc_ctx *c, uint32_t n_owners, uint32_t *sub)
+{
+    static const bool off = [] { const char *e = getenv("MC_EXCHANGE_BINNED"); return e && !strcmp(e, "0"); }();
+    if (off || !c->sk_form || !c->mm_k || n_owners == 0 || n_owners > PT_MAX_BUCKETS) return 0;
+    uint64_t n_leaves, np1;
+    uint32_t g;
+    if (plan_levels(c, true, &n_leaves, &g, &np1)) return 0;
+    if (n_leaves / np1 <= 1 || (uint64_t)n_owners * np1 > SKB_MAX_CELLS) return 0;
+    uint32_t sb = 1;  // about 512 first-level buckets in all (what k_sk1w_extract keeps open on one GPU), a power of two that divides np1
+    while ((uint64_t)n_owners * sb * 2 <= PT_MAX_BUCKETS && np1 % (sb * 2) == 0) sb *= 2;
+    if (np1 / sb > PT_MAX_LEAVES2 || (uint64_t)n_owners * sb > PT_MAX_BUCKETS1_SK) return 0;
+    if (sub) *sub = sb;
+    return (uint32_t)np1;
+}
+
+uint32_t mc_superkmer_fine_buckets(mc_ctx *c, uint32_t n_owners)
+{
+    if (!c) return 0;
+    std::lock_guard<std::mutex> g(c->mu);
+    return skb_fine_buckets(c, n_owners, nullptr);
+}
+
+int mc_extract_superkmers_binned_dev(mc_ctx *c, const uint64_t *d_words, const uint64_t *d_off, uint64_t n_reads, uint64_t n_bases,
+                                     uint32_t n_owners, uint32_t n_fine, uint64_t *d_recs, uint32_t *d_ptrs, uint64_t cap,
+                                     uint32_t *d_fine_counts, uint64_t *owner_offsets, uint64_t *owner_windows)
+{
+    if (!c) return MC_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->sk_form) return fail(c, MC_ESTATE, "mc_extract_superkmers_binned_dev: this context does not count through super-k-mers (mc_superkmer_capacity() == 0)");
+    if (!owner_offsets || !owner_windows || !d_recs || !d_ptrs || !d_fine_counts || n_owners == 0 || n_owners > PT_MAX_BUCKETS)
+        return fail(c, MC_EINVAL, "mc_extract_superkmers_binned_dev: bad argument");
+    // the coarse buckets of the first level: a power of two that divides n_fine, about 512 buckets in all
+    uint32_t sub = 1;
+    while ((uint64_t)n_owners * sub * 2 <= PT_MAX_BUCKETS && n_fine % (sub * 2) == 0) sub *= 2;
+    if (n_fine == 0 || (uint64_t)n_owners * n_fine > SKB_MAX_CELLS || n_fine / sub > PT_MAX_LEAVES2 || (uint64_t)n_owners * sub > PT_MAX_BUCKETS1_SK)
+        return fail(c, MC_EINVAL, "mc_extract_superkmers_binned_dev: %u fine buckets for %u owners (mc_superkmer_fine_buckets says how many)", n_fine, n_owners);
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    for (uint32_t o = 0; o <= n_owners; o++) owner_offsets[o] = 0;
+    for (uint32_t o = 0; o < n_owners; o++) owner_windows[o] = 0;
+    const uint64_t n_cells = (uint64_t)n_owners * n_fine;
+    HIPCHK(c, hipMemsetAsync(d_fine_counts, 0, n_cells * sizeof(uint32_t), c->stream));
+    if (n_reads == 0) return MC_OK;
+    mc_ctx::Pipe &P = c->pipe;
+    uint64_t first_off = 0, last_off = 0;
+    HIPCHK(c, hipMemcpyAsync(&first_off, d_off, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&last_off, d_off + n_reads, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (last_off != n_bases)
+        return fail(c, MC_EINVAL, "mc_extract_superkmers_binned_dev: read_offsets[n_reads]=%llu but n_bases=%llu",
+                    (unsigned long long)last_off, (unsigned long long)n_bases);
+    {
+        const int64_t in_store = c->extract_in_store;  // (mc_group: tokenised on this device, in the store already)
+        c->extract_in_store = -1;
+        int rrc = rs_append(c, d_words, first_off, last_off, in_store);
+        if (rrc) return rrc;
+    }
+    c->solid_list_fresh = false;  // (the pieces go into pipe.a_recs: mc_extract_superkmers_dev says what that ends)
+    const uint64_t bound = sk_records_bound(c, n_bases - first_off, n_reads);
+    const uint32_t nseg = P1W_SEGMENTS, n_buckets = n_owners * sub;
+    uint64_t seg_cap = (uint64_t)((double)bound / (double)n_buckets / (double)nseg * 1.25) + 64;
+    {   // a workgroup (= segment) takes whole tiles, one per wave and round: with few tiles some segments get more than others, or any at all
+        const uint64_t n_waves = (uint64_t)nseg * P1W_WAVES;
+        const uint64_t tiles = (last_off - first_off + P1W_TILE - 1) / P1W_TILE + 1, per_wg = (tiles + n_waves - 1) / n_waves * P1W_WAVES;
+        const double per_tile = (double)bound / (double)std::max<uint64_t>(tiles - 1, 1);
+        seg_cap = std::max<uint64_t>(seg_cap, (uint64_t)((double)per_wg * per_tile / (double)n_buckets * 1.3) + 64);
+    }
+    if ((uint64_t)n_buckets * nseg * seg_cap >= 0xFFFFFFFFull)
+        return fail(c, MC_EINVAL, "mc_extract_superkmers_binned_dev: batch too large (split the reads)");
+    const uint64_t n_tiles_abs = (last_off + P1W_TILE - 1) / P1W_TILE;
+    int rc = ensure_buf(c, &P.tile_first, &P.tiles1_cap, n_tiles_abs);
+    if (!rc) rc = ensure_buf(c, &P.a_recs, &P.a_recs_cap, (uint64_t)n_buckets * nseg * seg_cap);
+    if (!rc) rc = ensure_buf(c, &P.a_hints, &P.a_hints_cap, (uint64_t)n_buckets * nseg * seg_cap);
+    if (!rc) rc = ensure_buf(c, &P.seg_counts1, &P.segs1_cap, (uint64_t)n_buckets * nseg);
+    if (!rc) rc = ensure_buf(c, &P.skb_rows, &P.skb_rows_cap, (uint64_t)nseg * n_cells);
+    if (!rc) rc = ensure_buf(c, &P.skb_cell_start, &P.skb_cell_start_cap, n_cells);
+    if (!rc) rc = ensure_buf(c, &P.skb_small, &P.skb_small_cap, (uint64_t)P1W_SEGMENTS + 2 * PT_MAX_BUCKETS + 8);
+    if (rc) return rc;
+    if (!P.flags) {  // four flags and, behind them, the spill counter: cleared by one fill, read by one copy
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&P.flags), 4 * sizeof(uint32_t) + sizeof(unsigned long long)));
+        P.spill_count = reinterpret_cast<unsigned long long *>(P.flags + 4);
+    }
+    HIPCHK(c, hipMemsetAsync(P.flags, 0, 4 * sizeof(uint32_t) + sizeof(unsigned long long), c->stream));
+    unsigned long long *d_owner = P.skb_small, *d_win = P.skb_small + n_owners + 1;  // owner offsets (n_owners + 1), owner windows (n_owners)
+    HIPCHK(c, hipMemsetAsync(d_win, 0, n_owners * sizeof(unsigned long long), c->stream));
+    const SkSpill none{nullptr, P.spill_count, 0, P.flags};  // no spill list: an overflow is reported
+    launch_tile_first(c, d_off, n_reads, n_tiles_abs, P.tile_first, P1W_TILE);
+    hipLaunchKernelGGL((k_sk1w_extract<true, false, true>), dim3(nseg), dim3(P1W_THREADS), 0, c->stream, d_words, d_off, n_reads, first_off,
+                       last_off, n_tiles_abs, P.tile_first, c->cfg.k, n_owners, P.seg_counts1, seg_cap, P.a_recs, P.a_hints, none, c->cur_ptr_base,
+                       0u, 0u, SkBinned{sub, n_fine, P.skb_rows, d_win});
+    hipLaunchKernelGGL(k_skb_colsum, dim3((unsigned)((n_cells + 255) / 256), 16), dim3(256), 0, c->stream, P.skb_rows, nseg, (uint32_t)n_cells, d_fine_counts);
+    hipLaunchKernelGGL(k_skb_offsets, dim3(1), dim3(1024), 0, c->stream, d_fine_counts, n_owners, n_fine, P.skb_cell_start, d_owner);
+    // every (owner, coarse bucket)'s segments into the owner's fine buckets, at their exact places in the caller's buffer
+    hipLaunchKernelGGL((k_sk2_scatter_staged<MC_SK2_ITEMS, false, true>), dim3(n_buckets), dim3(PT_THREADS), 0, c->stream, P.a_recs, P.a_hints, seg_cap,
+                       P.seg_counts1, n_buckets, sub, n_fine / sub, nullptr, cap, reinterpret_cast<uint4 *>(d_recs), d_ptrs, none, nseg, nullptr, P.skb_cell_start);
+    HIPCHK(c, hipGetLastError());
+    std::vector<unsigned long long> h(2 * n_owners + 1);
+    uint32_t lost = 0;
+    HIPCHK(c, hipMemcpyAsync(h.data(), d_owner, (2 * n_owners + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&lost, P.flags, sizeof lost, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (lost) return fail(c, MC_EOVERFLOW, "mc_extract_superkmers_binned_dev: more super-k-mers than expected (unusually short runs); use mc_extract_keys_dev");
+    if (h[n_owners] > cap)
+        return fail(c, MC_EINVAL, "mc_extract_superkmers_binned_dev: %llu records but capacity %llu", h[n_owners], (unsigned long long)cap);
+    for (uint32_t o = 0; o <= n_owners; o++) owner_offsets[o] = h[o];
+    for (uint32_t o = 0; o < n_owners; o++) owner_windows[o] = h[n_owners + 1 + o];
+    return MC_OK;
+}
+
+static int add_superkmers_locked(mc_ctx *c, const uint64_t *d_recs, const uint32_t *d_bins, uint64_t n);
+
+int mc_add_superkmers_binned_dev(mc_ctx *c, const uint64_t *d_recs, const uint32_t *d_ptrs, uint64_t n, uint64_t n_windows, uint32_t n_fine,
+                                 uint32_t n_parts, const uint64_t *part_offsets, const uint32_t *d_part_counts)
+{
+    if (!c) return MC_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->sk_form) return fail(c, MC_ESTATE, "mc_add_superkmers_binned_dev: this context does not count through super-k-mers");
+    if (n && (!d_recs || !d_ptrs || !part_offsets || !d_part_counts || n_parts == 0 || n_fine == 0)) return fail(c, MC_EINVAL, "mc_add_superkmers_binned_dev: bad argument");
+    if (n) {
+        bool ok = part_offsets[0] == 0 && part_offsets[n_parts] == n;
+        for (uint32_t p = 0; p < n_parts && ok; p++) ok = part_offsets[p] <= part_offsets[p + 1];
+        if (!ok) return fail(c, MC_EINVAL, "mc_add_superkmers_binned_dev: the parts must lie back to back over the %llu records", (unsigned long long)n);
+    }
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (n && c->mm_k) {
+        c->ptr_tries = c->all_ptrs ? 1 : 16;  // (records of ranks that keep no read store carry no pointer)
+        int rc = add_records_binned(c, reinterpret_cast<const uint4 *>(d_recs), d_ptrs, n, n_windows, n_fine, n_parts, part_offsets, d_part_counts);
+        if (rc != 2) {
+            if (rc) return rc;
+            c->st.binned_runs++;
+            counts_changed(c);
+            c->solid_cov = -1; c->solid_external = false;
+            return MC_OK;
+        }
+    }
+    return add_superkmers_locked(c, d_recs, d_ptrs, n);  // (this table's buckets are not unions of the fine ones: records are records in any order)
+}
+
 int mc_add_superkmers_dev(mc_ctx *c, const uint64_t *d_recs, const uint32_t *d_bins, uint64_t n)
 {
     if (!c) return MC_EINVAL;
@@ -3821,7 +4112,12 @@ int mc_add_superkmers_dev(mc_ctx *c, const uint64_t *d_recs, const uint32_t *d_b
     if (!c->sk_form) return fail(c, MC_ESTATE, "mc_add_superkmers_dev: this context does not count through super-k-mers");
     if ((!d_recs || !d_bins) && n) return fail(c, MC_EINVAL, "mc_add_superkmers_dev: null pointer");
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    c->ptr_tries = 16;  // (records of ranks that keep no read store carry no pointer)
+    return add_superkmers_locked(c, d_recs, d_bins, n);
+}
+
+static int add_superkmers_locked(mc_ctx *c, const uint64_t *d_recs, const uint32_t *d_bins, uint64_t n)
+{
+    c->ptr_tries = c->all_ptrs ? 1 : 16;  // (records of ranks that keep no read store carry no pointer)
     if (!c->mm_k) {  // the context gave up minimizer bins (to_hash_regions): the records are expanded by the direct kernel
         c->solid_tracked = false;
         c->solid_list_fresh = false;
@@ -5098,6 +5394,7 @@ struct mc_group {
     bool use_rccl = false;
     std::vector<ncclComm_t> comm;
     bool peer_all = true;       // every pair of distinct devices has peer access (else HIP stages those copies through the host)
+    bool gather_reads = false;  // every device's reads are brought to the first device's store, and every record carries a pointer into it
 };
 
 namespace {
@@ -5163,7 +5460,13 @@ int mc_group_create(const mc_config *cfg, const int32_t *devices, uint32_t n_dev
         const int rc = mc_create(&c, &x);
         if (rc) { mc_group_destroy(g); return rc; }
         g->ctx.push_back(x);
-        if (r > 0) (void)mc_set_read_pointers(x, 0);  // (the BFS device cannot see this one's reads)
+        // The BFS device reads its look-ahead from ITS store: the other devices' reads are brought there (group_import_reads; a file's
+        // reads are tokenised there in the first place) and every device works its pointers out as if its reads sat in that store
+        // -- a walk that had only the first device's reads to follow took 20 times as long at 8 devices (include/mcgpu.h
+        // mc_set_read_pointers).  MC_EXCHANGE_GATHER_READS=0: the other devices' records carry no pointers.
+        static const bool gather = [] { const char *e = getenv("MC_EXCHANGE_GATHER_READS"); return !(e && !strcmp(e, "0")); }();
+        g->gather_reads = gather && n_devices > 1;
+        if (n_devices > 1) (void)mc_set_read_pointers(x, g->gather_reads ? ((r == 0 ? 1 : 2) | MC_PTRS_ON_EVERY_RECORD) : (r == 0 ? 1 : 0));
     }
     // peer access between every pair of different devices (already enabled: fine).  A pair without it still works -- HIP
     // stages such copies through the host -- but at a fraction of the xGMI rate: say so once.
@@ -5228,12 +5531,30 @@ namespace {
 struct GroupRank {
     DevBuf<uint64_t> dw, doff, send, recv;   // reads uploaded here (host batches); what goes out (records: 2 words each, or keys) and what came in
     DevBuf<uint32_t> send_p, recv_p;         // the read pointers that travel with them
+    DevBuf<uint32_t> fc, recv_fc;            // binned records: a row of fine-bucket counts for every owner; the rows every source sent me
     std::vector<uint64_t> owner_off;         // owner o's piece of `send` = [owner_off[o], owner_off[o + 1])
+    std::vector<uint64_t> owner_win;         // binned records: the windows of owner o's piece
     uint64_t n_recv = 0;
     const uint64_t *d_words = nullptr, *d_off = nullptr;  // the share: d_off[0 .. n_reads] index bases of d_words
     uint64_t n_reads = 0, n_bases = 0, windows = 0;       // n_bases = d_off[n_reads]; windows: k-mer occurrences, or an upper bound
     int64_t in_store = -1;                                // >= 0: the share sits in this device's read store from that word on
 };
+
+// n_words packed words of device `from`'s reads to word `at_word` of the first device's read store (where that device's pointers lead)
+int group_import_reads(mc_group *g, size_t from, const uint64_t *src, uint64_t n_words, uint64_t at_word)
+{
+    mc_ctx *c0 = g->ctx[0];
+    std::lock_guard<std::mutex> g0(c0->mu);
+    if (hipSetDevice(c0->cfg.device) != hipSuccess) return MC_EHIP;
+    if (at_word + n_words + 1 > c0->rs_cap_words) {
+        const uint64_t fill = c0->rs_bases / 32;
+        int rc = rs_reserve(c0, at_word + n_words + 1 > fill ? at_word + n_words + 1 - fill : 0);
+        if (rc) return rc;
+    }
+    if (peer_copy(c0->rs_words + at_word, c0, src, g->ctx[from], n_words * 8, c0->stream) != hipSuccess || hipStreamSynchronize(c0->stream) != hipSuccess) return MC_EHIP;
+    c0->rs_hi_bases = std::max(c0->rs_hi_bases, (at_word + n_words) * 32);
+    return MC_OK;
+}
 
 // every device: its share -> records (keys) bucketed by owner; the exchange; every device counts what it owns
 int group_exchange_count(mc_group *g, std::vector<GroupRank> &R)
@@ -5241,18 +5562,33 @@ int group_exchange_count(mc_group *g, std::vector<GroupRank> &R)
     const size_t W = g->ctx.size();
     const bool sk = g->ctx[0]->sk_form;
     bool sk_batch = sk;  // this batch travels as super-k-mer records (false: as keys)
+    // the binned form of the record exchange (include/mcgpu.h mc_extract_superkmers_binned_dev) where every device's table is laid
+    // out for the same level-1 buckets: the sender orders an owner's records by them, and the owner's run starts at its second level
+    uint32_t fine = 0;
+    if (sk) {
+        fine = mc_superkmer_fine_buckets(g->ctx[0], (uint32_t)W);
+        for (size_t r = 1; r < W && fine; r++) if (mc_superkmer_fine_buckets(g->ctx[r], (uint32_t)W) != fine) fine = 0;
+    }
     auto extract = [&](size_t r, bool as_records) -> int {
         mc_ctx *c = g->ctx[r];
         GroupRank &X = R[r];
         X.owner_off.assign(W + 1, 0);
-        if (X.n_reads == 0 || X.windows == 0) return MC_OK;
+        X.owner_win.assign(W, 0);
         if (hipSetDevice(c->cfg.device) != hipSuccess) return MC_EHIP;
+        if (as_records && fine && X.fc.alloc((uint64_t)W * fine) != hipSuccess) return MC_ENOMEM;
+        if (X.n_reads == 0 || X.windows == 0) {  // (a rank without reads still sends its rows: zeros)
+            if (as_records && fine && (hipMemsetAsync(X.fc.p, 0, (uint64_t)W * fine * 4, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)) return MC_EHIP;
+            return MC_OK;
+        }
         X.send.reset();
         X.send_p.reset();
         c->extract_in_store = X.in_store;
         if (as_records) {
             const uint64_t cap = mc_superkmer_capacity(c, X.windows, X.n_reads);
             if (X.send.alloc(cap * 2) != hipSuccess || X.send_p.alloc(cap) != hipSuccess) return MC_ENOMEM;
+            if (fine)
+                return mc_extract_superkmers_binned_dev(c, X.d_words, X.d_off, X.n_reads, X.n_bases, (uint32_t)W, fine, X.send.p, X.send_p.p, cap, X.fc.p,
+                                                        X.owner_off.data(), X.owner_win.data());
             return mc_extract_superkmers_dev(c, X.d_words, X.d_off, X.n_reads, X.n_bases, (uint32_t)W, X.send.p, X.send_p.p, cap, X.owner_off.data());
         }
         if (X.send.alloc(X.windows) != hipSuccess || X.send_p.alloc(X.windows) != hipSuccess) return MC_ENOMEM;
@@ -5263,8 +5599,11 @@ int group_exchange_count(mc_group *g, std::vector<GroupRank> &R)
         return mc_extract_keys_dev(c, X.d_words, X.d_off, X.n_reads, X.n_bases, (uint32_t)W, reinterpret_cast<int64_t *>(X.send.p), X.send_p.p, X.windows,
                                    X.owner_off.data());
     };
+    std::vector<uint64_t> fill(W, 0);  // (where every device's reads go, or are deemed to go, in the shared store: a second extraction starts there again)
+    if (g->gather_reads) for (size_t r = 0; r < W; r++) fill[r] = mc_read_store_tell(g->ctx[r]);
     int rc = per_rank(W, [&](size_t r) -> int { return extract(r, sk); });
     if (rc == MC_EOVERFLOW && sk) {
+        if (g->gather_reads) for (size_t r = 0; r < W; r++) (void)mc_read_store_seek(g->ctx[r], fill[r], 0);
         // an owner's piece overflowed (reads of low complexity share one minimizer, hence one owner): this batch travels as
         // keys instead, on every rank alike -- one record per window, counted per owner first and then packed (no piece to
         // overflow), and dealt to the SAME owners: those of the keys' minimizers
@@ -5279,6 +5618,7 @@ int group_exchange_count(mc_group *g, std::vector<GroupRank> &R)
     }
     // ---- the exchange: owner d receives its piece of every rank's output, all pairs at once
     const size_t unit = sk_batch ? 16 : 8;
+    const bool binned = sk_batch && fine != 0;
     if (g->use_rccl) {
         // RCCL: every device's receive buffer first, then ONE group of sends and receives over all pairs (what an all-to-all
         // with per-pair counts is), each communicator's calls on its own context's stream
@@ -5288,6 +5628,7 @@ int group_exchange_count(mc_group *g, std::vector<GroupRank> &R)
             uint64_t total = 0;
             for (size_t r = 0; r < W; r++) total += R[r].owner_off[d + 1] - R[r].owner_off[d];
             R[d].n_recv = total;
+            if (binned && R[d].recv_fc.alloc((uint64_t)W * fine) != hipSuccess) return MC_ENOMEM;
             if (total == 0) return MC_OK;
             return R[d].recv.alloc(total * (sk_batch ? 2 : 1)) == hipSuccess && R[d].recv_p.alloc(total) == hipSuccess ? MC_OK : MC_ENOMEM;
         });
@@ -5299,12 +5640,17 @@ int group_exchange_count(mc_group *g, std::vector<GroupRank> &R)
         for (size_t r = 0; r < W && nr == ncclSuccess; r++)       // source
             for (size_t d = 0; d < W && nr == ncclSuccess; d++) {  // owner
                 const uint64_t o0 = R[r].owner_off[d], m = R[r].owner_off[d + 1] - o0;
+                if (binned) {  // source r's row of counts for owner d
+                    nr = g_rccl.Send(R[r].fc.p + d * fine, (size_t)fine * 4, ncclUint8, (int)d, g->comm[r], g->ctx[r]->stream);
+                    if (nr == ncclSuccess) nr = g_rccl.Recv(R[d].recv_fc.p + r * fine, (size_t)fine * 4, ncclUint8, (int)r, g->comm[d], g->ctx[d]->stream);
+                    if (nr != ncclSuccess) break;
+                }
                 if (m == 0) continue;
                 nr = g_rccl.Send(reinterpret_cast<const char *>(R[r].send.p) + o0 * unit, m * unit, ncclUint8, (int)d, g->comm[r], g->ctx[r]->stream);
                 if (nr == ncclSuccess) nr = g_rccl.Recv(reinterpret_cast<char *>(R[d].recv.p) + at[d] * unit, m * unit, ncclUint8, (int)r, g->comm[d], g->ctx[d]->stream);
                 // (read pointers lead into the FIRST device's read store, the one the walk reads: the other devices keep none, and the
                 // zeros they used to send -- a fifth of their bytes -- are filled in where they arrive)
-                if (r == 0) {
+                if (r == 0 || g->gather_reads) {  // (gather_reads: every device's reads are in that store, every record brings its pointer)
                     if (nr == ncclSuccess) nr = g_rccl.Send(R[r].send_p.p + o0, m * 4, ncclUint8, (int)d, g->comm[r], g->ctx[r]->stream);
                     if (nr == ncclSuccess) nr = g_rccl.Recv(R[d].recv_p.p + at[d], m * 4, ncclUint8, (int)r, g->comm[d], g->ctx[d]->stream);
                 } else {
@@ -5334,12 +5680,14 @@ int group_exchange_count(mc_group *g, std::vector<GroupRank> &R)
         R[d].n_recv = total;
         if (total == 0) return MC_OK;
         if (R[d].recv.alloc(total * (sk_batch ? 2 : 1)) != hipSuccess || R[d].recv_p.alloc(total) != hipSuccess) return MC_ENOMEM;
+        if (binned && R[d].recv_fc.alloc((uint64_t)W * fine) != hipSuccess) return MC_ENOMEM;
         uint64_t at = 0;
         for (size_t r = 0; r < W; r++) {
             const uint64_t o0 = R[r].owner_off[d], m = R[r].owner_off[d + 1] - o0;
+            if (binned && peer_copy(R[d].recv_fc.p + r * fine, c, R[r].fc.p + d * fine, g->ctx[r], (size_t)fine * 4, c->stream) != hipSuccess) return MC_EHIP;
             // (pointers: from the first device only -- they lead into its read store; the others' would be zeros)
             if (peer_copy(reinterpret_cast<char *>(R[d].recv.p) + at * unit, c, reinterpret_cast<const char *>(R[r].send.p) + o0 * unit, g->ctx[r], m * unit, c->stream) != hipSuccess ||
-                (r == 0 ? peer_copy(R[d].recv_p.p + at, c, R[r].send_p.p + o0, g->ctx[r], m * 4, c->stream)
+                (r == 0 || g->gather_reads ? peer_copy(R[d].recv_p.p + at, c, R[r].send_p.p + o0, g->ctx[r], m * 4, c->stream)
                         : (m ? hipMemsetAsync(R[d].recv_p.p + at, 0, m * 4, c->stream) : hipSuccess)) != hipSuccess)
                 return MC_EHIP;
             at += m;
@@ -5350,6 +5698,15 @@ int group_exchange_count(mc_group *g, std::vector<GroupRank> &R)
     // ---- every device counts what it owns
     rc = per_rank(W, [&](size_t d) -> int {
         if (R[d].n_recv == 0) return MC_OK;
+        if (binned) {  // every source's piece is a part, in the order the pieces were received
+            std::vector<uint64_t> part_off(W + 1, 0);
+            uint64_t windows = 0;
+            for (size_t r = 0; r < W; r++) {
+                part_off[r + 1] = part_off[r] + (R[r].owner_off[d + 1] - R[r].owner_off[d]);
+                windows += R[r].owner_win[d];
+            }
+            return mc_add_superkmers_binned_dev(g->ctx[d], R[d].recv.p, R[d].recv_p.p, R[d].n_recv, windows, fine, (uint32_t)W, part_off.data(), R[d].recv_fc.p);
+        }
         return sk_batch ? mc_add_superkmers_dev(g->ctx[d], R[d].recv.p, R[d].recv_p.p, R[d].n_recv)
                   : mc_add_keys_dev(g->ctx[d], reinterpret_cast<const int64_t *>(R[d].recv.p), R[d].recv_p.p, R[d].n_recv);
     });
@@ -5392,7 +5749,33 @@ int group_add_host_batch(mc_group *g, const uint64_t *words, const uint64_t *off
         for (mc_ctx *c : g->ctx) if (!c->err.empty()) return gfail(g, rc, c->err);
         return gfail(g, rc, "mc_group_add_reads_packed: the reads did not reach the devices");
     }
-    return group_exchange_count(g, R);
+    uint64_t end_word = 0;
+    if (g->gather_reads) {
+        // the shares one behind the other in the first device's store: its own where its extraction will append it, the others'
+        // copied there from their devices; every other device is told where its share sits (its pointers lead there)
+        mc_ctx *c0 = g->ctx[0];
+        uint64_t at = 0;
+        {
+            std::lock_guard<std::mutex> g0(c0->mu);
+            at = c0->rs_end() / 32;
+        }
+        std::vector<uint64_t> pos(W + 1, at);
+        for (size_t r = 0; r < W; r++) pos[r + 1] = pos[r] + (R[r].n_reads ? (R[r].n_bases + 31) / 32 + 1 : 0);
+        end_word = pos[W];
+        if ((rc = mc_read_store_seek(c0, pos[0] * 32, end_word * 32 + 64)) != MC_OK) return gfail(g, rc, c0->err);
+        rc = per_rank(W, [&](size_t r) -> int {
+            if (r == 0 || R[r].n_reads == 0) return MC_OK;
+            int x = group_import_reads(g, r, R[r].dw.p, (R[r].n_bases + 31) / 32 + 1, pos[r]);
+            return x ? x : mc_read_store_seek(g->ctx[r], pos[r] * 32, 0);
+        });
+        if (rc) {
+            for (mc_ctx *c : g->ctx) if (!c->err.empty()) return gfail(g, rc, c->err);
+            return gfail(g, rc, "mc_group_add_reads_packed: the reads did not reach the first device's store");
+        }
+    }
+    rc = group_exchange_count(g, R);
+    if (g->gather_reads && rc == MC_OK && (rc = mc_read_store_seek(g->ctx[0], end_word * 32, 0)) != MC_OK) return gfail(g, rc, g->ctx[0]->err);  // (the next batch goes behind all of them)
+    return rc;
 }
 }  // namespace
 
@@ -5493,6 +5876,9 @@ int mc_group_add_reads_file(mc_group *g, const char *path, uint64_t *n_reads)
                         return MC_EHIP;
                     X.d_words = X.dw.p - w0;
                     X.d_off = X.doff.p;
+                    // (the share sits in the first device's store: batch position p is store position base_word * 32 + p, which is
+                    // what this device's pointers come to when its -- deemed -- fill stands at the share's first word)
+                    if (g->gather_reads) return mc_read_store_seek(c, (base_word + cut_off[r] / 32) * 32, 0);
                     return MC_OK;
                 });
                 if (frc) return gfail(g, frc, "mc_group_add_reads_file: the shares did not reach the devices");
@@ -5622,6 +6008,7 @@ int mc_group_get_stats(mc_group *g, mc_stats *out)
         t.grows += s.grows; t.spill_keys += s.spill_keys; t.solid_kmers += s.solid_kmers; t.solid_sweeps += s.solid_sweeps;
         t.solid_list_builds += s.solid_list_builds;
         t.long_runs += s.long_runs;
+        t.binned_runs += s.binned_runs;
         t.dup_keys += s.dup_keys; t.dup_checks += s.dup_checks; t.dup_ms = std::max(t.dup_ms, s.dup_ms); t.dup_unchecked |= s.dup_unchecked;
         t.left_bins = std::max(t.left_bins, s.left_bins);
         t.count_ms = std::max(t.count_ms, s.count_ms); t.count_total_ms = std::max(t.count_total_ms, s.count_total_ms);

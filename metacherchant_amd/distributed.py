@@ -38,8 +38,19 @@ class ShardedCounter:
         # Read pointers (include/mcgpu.h mc_set_read_pointers): the BFS rank walks with look-ahead read from ITS OWN
         # reads, so only its records carry pointers; the other ranks keep no read store and send zeros.
         self.bfs_rank = bfs_rank
-        if self.world > 1 and bfs_rank is not None and self.rank != bfs_rank and hasattr(ctx, "set_read_pointers"):
-            ctx.set_read_pointers(False)
+        # ... but a walk whose look-ahead has one read in W to follow is slow (8 x configs[1]: 146 ms against 7.9 with all of them):
+        # the other ranks' packed reads are brought to the walking rank's store (2 bits a base, chunk by chunk beside the
+        # records: a tenth of their bytes), every rank works out the pointers of its reads as if they sat there, and every
+        # record carries one (MC_EXCHANGE_GATHER_READS=0: the old way, pointers from the walking rank's reads alone).
+        self.gather_reads = (self.world > 1 and bfs_rank is not None and hasattr(ctx, "read_store_seek")
+                             and os.environ.get("MC_EXCHANGE_GATHER_READS", "1") != "0")
+        self._store_fill = 0  # words of the shared store handed out so far (the same number on every rank)
+        self._reads_pending = []  # (handle, the sender's words, what the walking rank will import) of the chunks' read transfers
+        if self.world > 1 and bfs_rank is not None and hasattr(ctx, "set_read_pointers"):
+            if self.gather_reads:
+                ctx.set_read_pointers((1 if self.rank == bfs_rank else 2) | 0x10)
+            elif self.rank != bfs_rank:
+                ctx.set_read_pointers(False)
         # A rank's reads are exchanged in chunks of at most this many reads (MC_EXCHANGE_CHUNK_READS): what bounds the memory of
         # one extraction whatever the size of the rank's share (configs[3]: 125 M reads a rank; DESIGN.md section 6 has the
         # budget); see add_reads_dev for what happens to the chunks.
@@ -54,6 +65,7 @@ class ShardedCounter:
         self.n_count_runs = 0
         self.pool_rows = 0  # rows of the one receive buffer of the last add_reads_dev call that made one (tests)
         self.pool_slack = float(os.environ.get("MC_EXCHANGE_POOL_SLACK", 1.12))  # the one receive buffer: the first chunk's records x chunks x this
+        self.fine_buckets = 0   # fine buckets of the binned record exchange of the last add_reads_dev call (0: the flat form ran)
         self.n_pool_misses = 0  # chunks that did not fit it any more (they get tensors of their own; the tests look at it)
         # where a rank's time goes, as its host sees it (seconds, summed over add_reads_dev calls until reset_phases): `extract`
         # = mc_extract_*_dev (synchronous), `exchange_wait` = waiting for transfers that the next chunk's extraction did not
@@ -62,8 +74,10 @@ class ShardedCounter:
 
     def clear(self):
         """empties the sharded table (every rank calls it): the context's mc_clear, and the table may then be fed in either form"""
+        self._import_reads()  # (transfers still running finish first)
         self.ctx.clear()
         self._fed = False
+        self._store_fill = 0
 
     def reset_phases(self):
         for key in self.phase_s:
@@ -91,9 +105,18 @@ class ShardedCounter:
         want = max(1, -(-int(n_reads) // self.chunk_reads))
         if n_reads >= self.min_chunk_share:
             want = max(want, self.min_chunks)
-        nc = torch.tensor([want], dtype=torch.int64, device=self.device)
+        sk = hasattr(ctx, "superkmer_capacity") and ctx.superkmer_capacity(max(int(max_windows), 1), max(int(n_reads), 1)) != 0
+        # The binned form of the record exchange (include/mcgpu.h mc_extract_superkmers_binned_dev): the sender puts every owner's
+        # records in the order of the level-1 buckets of the owner's counting run, which then starts at its second level.  The
+        # bucket count comes from the table's layout; every rank must use the same one (the counts travel as rows of that length),
+        # so the ranks agree on it -- in the all-reduce they need anyway -- and take the flat form when they differ.
+        f_mine = int(ctx.superkmer_fine_buckets(W)) if sk and hasattr(ctx, "superkmer_fine_buckets") else 0
+        nc = torch.tensor([want, f_mine, -f_mine], dtype=torch.int64, device=self.device)
         dist.all_reduce(nc, op=dist.ReduceOp.MAX, group=self.group)
-        n_chunks = int(nc.item())
+        nc = [int(x) for x in nc.cpu().tolist()]
+        n_chunks = nc[0]
+        fine = nc[1] if nc[1] == -nc[2] else 0
+        self.fine_buckets = fine  # (of the last call; 0: flat records or keys)
         self.n_chunks = n_chunks  # (of the last call: the tests look at it)
         bounds = [n_reads * c // n_chunks for c in range(n_chunks + 1)]
         if n_chunks > 1:  # the chunk boundaries' base offsets in one copy
@@ -101,7 +124,6 @@ class ShardedCounter:
             base_at = [0] + [int(x) for x in d_offsets[idx].cpu().tolist()] + [int(n_bases)]
         else:
             base_at = [0, int(n_bases)]
-        sk = hasattr(ctx, "superkmer_capacity") and ctx.superkmer_capacity(max(int(max_windows), 1), max(int(n_reads), 1)) != 0
         # (records are dealt to the owners of their minimizers, keys to the owners of their own hashes: a table fed in both
         # forms would hold a k-mer on two ranks, and attach_shards could name only one rule -- ADVICE r4)
         if getattr(self, "_fed", False) and self.by_minimizer != sk:
@@ -109,10 +131,19 @@ class ShardedCounter:
                 "super-k-mer records" if self.by_minimizer else "keys", "super-k-mer records" if sk else "keys"))
         self.by_minimizer = sk
         self._fed = True
+        if self.gather_reads:
+            # every rank's stretch of the walking rank's store for this call: its words, a pad word a chunk, a spare -- one all-gather
+            mine = torch.tensor([(int(n_bases) + 31) // 32 + 2 * n_chunks + 2], dtype=torch.int64, device=self.device)
+            sizes = torch.empty(W, dtype=torch.int64, device=self.device)
+            dist.all_gather_into_tensor(sizes, mine, group=self.group)
+            sizes = [int(x) for x in sizes.cpu().tolist()]
+            at = self._store_fill + sum(sizes[:self.rank])
+            self._store_fill += sum(sizes)
+            ctx.read_store_seek(32 * at, 32 * self._store_fill if self.rank == self.bfs_rank else 0)
         # Read pointers travel only FROM the rank that walks (they lead into its read store; the others keep none and used to
         # send an array of zeros: a fifth of the bytes of seven ranks out of eight)
-        with_ptrs = self.bfs_rank is None or self.rank == self.bfs_rank
-        ptr_sources = list(range(W)) if self.bfs_rank is None else [self.bfs_rank]
+        with_ptrs = self.bfs_rank is None or self.rank == self.bfs_rank or self.gather_reads
+        ptr_sources = list(range(W)) if self.bfs_rank is None or self.gather_reads else [self.bfs_rank]
         pending = []  # per chunk: [handles, send buffers (kept alive while the transfers run), received payload, received pointers, n]
         self.n_count_runs = 0
         # What arrives is received straight into ONE buffer sized from the first chunk (x chunks left, + 12 %), so that the
@@ -140,6 +171,7 @@ class ShardedCounter:
                 torch.cuda.synchronize(self.device)
             self.phase_s["exchange_wait"] += time.perf_counter() - t_w
             n_all = sum(x[4] for x in pending)
+            binned = [x[6] for x in pending]
             in_pool = pool["recv"] is not None and all(x[5] for x in pending)
             if len(pending) == 1:
                 recv, recv_p = pending[0][2], pending[0][3]
@@ -152,7 +184,13 @@ class ShardedCounter:
             pool["at"] = 0
             t_c = time.perf_counter()
             # (a rank that received nothing still calls: the context must know its pipeline buffers were reused, mcgpu.hip)
-            if sk:
+            if sk and fine and n_all:
+                # every (chunk, source) is a part in fine-bucket order; the parts lie back to back as they were received
+                lens = [n for b in binned for n in b[0]]
+                part_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+                part_counts = torch.cat([b[1] for b in binned]) if len(binned) > 1 else binned[0][1]
+                ctx.add_superkmers_binned_dev(recv, recv_p, n_all, sum(b[2] for b in binned), fine, part_off, part_counts)
+            elif sk:
                 ctx.add_superkmers_dev(recv, recv_p, n_all)
             else:
                 ctx.add_keys_dev(recv, n_all, recv_p)
@@ -164,24 +202,27 @@ class ShardedCounter:
             nb = base_at[c + 1] - base_at[c]
             # (offsets are absolute in the rank's buffer: a chunk is the reads [a, b) with the bases up to base_at[c + 1])
             pending.append(self._exchange_chunk(sk, d_words, d_offsets[a:], b - a, base_at[c + 1], nb if sk else min(int(max_windows), nb),
-                                                with_ptrs, ptr_sources, pool, n_chunks - c))
+                                                with_ptrs, ptr_sources, pool, n_chunks - c, fine, base_at[c]))
             if len(pending) >= 2:
                 settle(pending[-2])  # (its transfers had this chunk's extraction to travel in)
             # what is held: the received payloads, and the send buffers of the chunk whose transfers are still running
-            kept = sum(x[4] * ((16 if sk else 8) + 4) for x in pending) + sum(t.numel() * t.element_size() for x in pending if x[1] for t in x[1])
+            kept = sum(x[4] * ((16 if sk else 8) + 4) for x in pending) + sum(t.numel() * t.element_size() for x in pending if x[1] for t in x[1] if t is not None)
             if (self.count_every and len(pending) >= self.count_every) or kept >= self.keep_bytes:
                 count_pending()
         count_pending()
 
-    def _counts(self, send_counts):
-        """The one host round trip of an exchange: what every rank will send me."""
+    def _counts(self, send_counts, send_windows, reads_words, reads_at):
+        """The one host round trip of an exchange: what every rank will send me -- records (keys); the windows they hold (binned
+        form); and, to the walking rank, how many words of packed reads and where in its store they belong."""
         W = self.world
-        sc = torch.tensor(send_counts, dtype=torch.int64, device=self.device)
-        rc = torch.empty(W, dtype=torch.int64, device=self.device)
+        rows = [[int(send_counts[o]), int(send_windows[o]), int(reads_words) if o == self.bfs_rank else 0, int(reads_at)] for o in range(W)]
+        sc = torch.tensor(rows, dtype=torch.int64, device=self.device)
+        rc = torch.empty((W, 4), dtype=torch.int64, device=self.device)
         dist.all_to_all_single(rc, sc, group=self.group)
-        return [int(x) for x in rc.cpu().tolist()]
+        rc = rc.cpu().tolist()
+        return [int(x[0]) for x in rc], sum(int(x[1]) for x in rc), [int(x[2]) for x in rc], [int(x[3]) for x in rc]
 
-    def _exchange_chunk(self, sk, d_words, d_offsets, n_reads, n_bases_end, room, with_ptrs, ptr_sources, pool, chunks_left):
+    def _exchange_chunk(self, sk, d_words, d_offsets, n_reads, n_bases_end, room, with_ptrs, ptr_sources, pool, chunks_left, fine=0, n_bases_start=0):
         """One chunk: extract (super-k-mer records of 16 bytes for packed keys, k >= 23 -- a seventh of the bytes of one key
         per window --, else keys), one exchange of the counts, then the payload and the read pointers as asynchronous
         all-to-alls.  Returns (handles, send buffers, received payload, received pointers, n received): the caller waits."""
@@ -194,8 +235,22 @@ class ShardedCounter:
             send = torch.empty(cap, dtype=torch.int64, device=self.device)
         send_p = torch.empty(cap, dtype=torch.int32, device=self.device)          # the read pointers (of the records' first windows)
         t_e = time.perf_counter()
+        binned = sk and fine
+        fc = None
+        win = np.zeros(W, dtype=np.uint64)
+        if binned:  # a row of `fine` counts for every owner: how its records split into fine buckets
+            fc = (torch.empty if n_reads else torch.zeros)((W, fine), dtype=torch.int32, device=self.device)
+        # the chunk's packed reads: words [w0, w1] of this rank's buffer (the pad word behind them included), deemed to sit at
+        # reads_at in the walking rank's store -- where the extraction below works its pointers out for
+        reads_words, reads_at, w0 = 0, 0, 0
+        if self.gather_reads and n_reads and self.rank != self.bfs_rank:
+            w0 = int(n_bases_start) // 32
+            reads_words = (int(n_bases_end) + 31) // 32 - w0 + 1
+            reads_at = ctx.read_store_tell()
         if n_reads:
-            if sk:
+            if binned:
+                off, win = ctx.extract_superkmers_binned_dev(d_words, d_offsets, n_reads, n_bases_end, W, fine, send, send_p, cap, fc)
+            elif sk:
                 off = ctx.extract_superkmers_dev(d_words, d_offsets, n_reads, n_bases_end, W, send, send_p, cap)
             else:
                 off = ctx.extract_keys_dev(d_words, d_offsets, n_reads, n_bases_end, W, send, cap, send_p)
@@ -203,7 +258,7 @@ class ShardedCounter:
             off = np.zeros(W + 1, dtype=np.uint64)
         self.phase_s["extract"] += time.perf_counter() - t_e
         send_counts = [int(off[o + 1] - off[o]) for o in range(W)]
-        recv_counts = self._counts(send_counts)
+        recv_counts, recv_windows, reads_in, reads_in_at = self._counts(send_counts, [int(x) for x in win], reads_words, reads_at)
         n_recv, n_send = sum(recv_counts), int(off[W])
         # pointers: only the ranks in ptr_sources send theirs; what comes from the others is zero (no pointer)
         all_send = len(ptr_sources) == W
@@ -248,10 +303,49 @@ class ShardedCounter:
                                              input_split_sizes=p_send, group=self.group, async_op=True))
             ptr_bytes = 4 * (n_send - send_counts[self.rank]) if with_ptrs else 0
         self.bytes_sent += (16 if sk else 8) * (n_send - send_counts[self.rank]) + ptr_bytes
-        return [hs, (send, send_p), recv, recv_p, n_recv, in_pool]
+        if self.gather_reads:
+            # the packed reads, to the walking rank alone: an all-to-all in which nobody else receives.  Nothing needs them before
+            # the walk: the transfer is waited for in finalize(), behind the counting run (_import_reads).
+            is_dst = self.rank == self.bfs_rank
+            got = torch.empty(max(sum(reads_in), 1), dtype=torch.int64, device=self.device) if is_dst else torch.empty(1, dtype=torch.int64, device=self.device)
+            src = d_words[w0:w0 + reads_words]
+            h = dist.all_to_all_single(got[:sum(reads_in) if is_dst else 0], src, output_split_sizes=reads_in if is_dst else [0] * W,
+                                       input_split_sizes=[reads_words if o == self.bfs_rank else 0 for o in range(W)], group=self.group, async_op=True)
+            self.bytes_sent += 8 * reads_words
+            imports, at = [], 0
+            if is_dst:
+                for r in range(W):
+                    if reads_in[r]:
+                        imports.append((got[at:at + reads_in[r]], reads_in[r], reads_in_at[r]))
+                    at += reads_in[r]
+            self._reads_pending.append((h, src, imports))
+        info = None
+        if binned:  # the counts: row r of what arrives is source r's row for me
+            recv_fc = torch.empty((W, fine), dtype=torch.int32, device=self.device)
+            hs.append(dist.all_to_all_single(recv_fc, fc, group=self.group, async_op=True))
+            self.bytes_sent += 4 * fine * (W - 1)
+            info = (recv_counts, recv_fc, recv_windows)
+        return [hs, (send, send_p, fc), recv, recv_p, n_recv, in_pool, info]
+
+    def _import_reads(self):
+        """the other ranks' packed reads into the walking rank's store, where their records' pointers lead (every rank calls: the
+        senders let go of their buffers)"""
+        if not self._reads_pending:
+            return
+        t_w = time.perf_counter()
+        for h, _, _ in self._reads_pending:
+            h.wait()
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)  # (the context copies on its own stream)
+        self.phase_s["exchange_wait"] += time.perf_counter() - t_w
+        for _, _, imports in self._reads_pending:
+            for words, n_words, at_bases in imports:
+                self.ctx.read_store_import_dev(words, n_words, at_bases)
+        self._reads_pending = []
 
     def finalize(self):
         """Local distinct keys; the sum over ranks is the table size (owners are disjoint)."""
+        self._import_reads()
         n = self.ctx.finalize()
         if self.world == 1:
             return n
@@ -269,6 +363,7 @@ class ShardedCounter:
         ctx, W = self.ctx, self.world
         if W == 1:
             return True
+        self._import_reads()
         if self.attach_ok is False:
             return False
         mine = torch.frombuffer(bytearray(ctx.shard_export()), dtype=torch.uint8).to(self.device)

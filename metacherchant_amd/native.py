@@ -56,7 +56,8 @@ class Stats(C.Structure):
                 ("grows", C.c_uint64), ("p1_ms", C.c_double), ("p2_ms", C.c_double), ("p3_ms", C.c_double),
                 ("spill_keys", C.c_uint64), ("solid_kmers", C.c_uint64), ("solid_sweeps", C.c_uint64),
                 ("solid_list_builds", C.c_uint64), ("long_runs", C.c_uint64), ("dup_keys", C.c_uint64),
-                ("dup_checks", C.c_uint64), ("dup_ms", C.c_double), ("dup_unchecked", C.c_uint64), ("left_bins", C.c_uint64)]
+                ("dup_checks", C.c_uint64), ("dup_ms", C.c_double), ("dup_unchecked", C.c_uint64), ("left_bins", C.c_uint64),
+                ("binned_runs", C.c_uint64)]
 
 
 # every symbol include/mcgpu.h declares; tests check that the library exports all of them
@@ -65,7 +66,9 @@ EXPORTS = [
     "mc_add_reads_packed_dev", "mc_add_reads_file", "mc_finalize_counts", "mc_get", "mc_get_dev", "mc_kmer_keys", "mc_bfs", "mc_bfs_batch",
     "mc_bfs_result_free", "mc_export", "mc_export_dev", "mc_add_pairs_dev", "mc_solid_from_pairs_dev", "mc_save_kmers", "mc_load_kmers", "mc_key_owner", "mc_extract_keys_dev",
     "mc_group_create", "mc_group_destroy", "mc_group_last_error", "mc_group_set_coverage_hint", "mc_group_add_reads_packed", "mc_group_add_reads_file",
-    "mc_group_finalize_counts", "mc_group_bfs_batch", "mc_group_get_stats", "mc_add_keys_dev", "mc_superkmer_capacity", "mc_extract_superkmers_dev", "mc_add_superkmers_dev", "mc_get_stats", "mc_reset_stats", "mc_trim", "mc_synth_reads_dev", "mc_synth_genome",
+    "mc_group_finalize_counts", "mc_group_bfs_batch", "mc_group_get_stats", "mc_add_keys_dev", "mc_superkmer_capacity", "mc_extract_superkmers_dev", "mc_add_superkmers_dev",
+    "mc_superkmer_fine_buckets", "mc_extract_superkmers_binned_dev", "mc_add_superkmers_binned_dev",
+    "mc_read_store_seek", "mc_read_store_tell", "mc_read_store_import_dev", "mc_get_stats", "mc_reset_stats", "mc_trim", "mc_synth_reads_dev", "mc_synth_genome",
     "mc_shard_export", "mc_shard_attach", "mc_shard_detach",
 ]
 
@@ -131,6 +134,14 @@ def load():
     L.mc_superkmer_capacity.restype = u64
     L.mc_extract_superkmers_dev.argtypes = [vp, vp, vp, u64, u64, C.c_uint32, vp, vp, u64, u64p]
     L.mc_add_superkmers_dev.argtypes = [vp, vp, vp, u64]
+    L.mc_read_store_seek.argtypes = [vp, u64, u64]
+    L.mc_read_store_tell.argtypes = [vp]
+    L.mc_read_store_tell.restype = u64
+    L.mc_read_store_import_dev.argtypes = [vp, vp, u64, u64]
+    L.mc_superkmer_fine_buckets.argtypes = [vp, C.c_uint32]
+    L.mc_superkmer_fine_buckets.restype = C.c_uint32
+    L.mc_extract_superkmers_binned_dev.argtypes = [vp, vp, vp, u64, u64, C.c_uint32, C.c_uint32, vp, vp, u64, vp, u64p, u64p]
+    L.mc_add_superkmers_binned_dev.argtypes = [vp, vp, vp, u64, u64, C.c_uint32, C.c_uint32, u64p, vp]
     L.mc_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.mc_reset_stats.argtypes = [vp]
     L.mc_trim.argtypes = [vp]
@@ -200,9 +211,21 @@ class Context:
         """mc_set_coverage_hint: counting keeps #(count >= min_cov) current, BFS set-up skips a table sweep."""
         self._chk(self._L.mc_set_coverage_hint(self._h, int(min_cov)))
 
-    def set_read_pointers(self, enable):
-        """mc_set_read_pointers: keep (1) or stop keeping (0) the reads and the slots' pointers into them."""
-        self._chk(self._L.mc_set_read_pointers(self._h, 1 if enable else 0))
+    PTRS_NONE, PTRS_OWN_STORE, PTRS_STORE_ELSEWHERE, PTRS_ON_EVERY_RECORD = 0, 1, 2, 0x10
+
+    def set_read_pointers(self, mode):
+        """mc_set_read_pointers: False / 0 no pointers, True / 1 this context's own read store, 2 a store kept by another context
+        (read_store_tell / read_store_import_dev); | PTRS_ON_EVERY_RECORD: every record it is handed carries a pointer."""
+        self._chk(self._L.mc_set_read_pointers(self._h, int(mode)))
+
+    def read_store_seek(self, at_bases, reserve_bases=0):
+        self._chk(self._L.mc_read_store_seek(self._h, int(at_bases), int(reserve_bases)))
+
+    def read_store_tell(self):
+        return int(self._L.mc_read_store_tell(self._h))
+
+    def read_store_import_dev(self, d_words, n_words, at_bases):
+        self._chk(self._L.mc_read_store_import_dev(self._h, _dptr(d_words), int(n_words), int(at_bases)))
 
     def share_read_store(self, other):
         """mc_share_read_store: this (BFS-only) context reads its look-ahead from `other`'s read store."""
@@ -361,6 +384,26 @@ class Context:
 
     def add_superkmers_dev(self, d_recs, d_bins, n):
         self._chk(self._L.mc_add_superkmers_dev(self._h, _dptr(d_recs), _dptr(d_bins), n))
+
+    # ---- the binned form of the exchange (include/mcgpu.h mc_extract_superkmers_binned_dev): the sender does the owner's first level
+    def superkmer_fine_buckets(self, n_owners):
+        """fine buckets to extract with for n_owners owners laid out like this context; 0: use the flat form"""
+        return int(self._L.mc_superkmer_fine_buckets(self._h, int(n_owners)))
+
+    def extract_superkmers_binned_dev(self, d_words, d_offsets, n_reads, n_bases, n_owners, n_fine, d_recs, d_bins, cap, d_fine_counts):
+        """as extract_superkmers_dev; d_fine_counts: int32 tensor of n_owners x n_fine entries (written).  Returns (owner offsets,
+        windows of every owner's records)."""
+        off = np.zeros(n_owners + 1, dtype=np.uint64)
+        win = np.zeros(n_owners, dtype=np.uint64)
+        self._chk(self._L.mc_extract_superkmers_binned_dev(self._h, _dptr(d_words), _dptr(d_offsets), n_reads, n_bases, n_owners, n_fine,
+                                                           _dptr(d_recs), _dptr(d_bins), cap, _dptr(d_fine_counts), _p(off, C.c_uint64), _p(win, C.c_uint64)))
+        return off, win
+
+    def add_superkmers_binned_dev(self, d_recs, d_bins, n, n_windows, n_fine, part_offsets, d_part_counts):
+        """part_offsets: n_parts + 1 record offsets (host); d_part_counts: int32 tensor of n_parts x n_fine entries"""
+        po = np.ascontiguousarray(part_offsets, dtype=np.uint64)
+        self._chk(self._L.mc_add_superkmers_binned_dev(self._h, _dptr(d_recs), _dptr(d_bins), n, int(n_windows), n_fine, len(po) - 1,
+                                                       _p(po, C.c_uint64), _dptr(d_part_counts)))
 
     # ---- the walk over several ranks' tables in place (include/mcgpu.h mc_shard_*)
     SHARD_HANDLE_BYTES = 128

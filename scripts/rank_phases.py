@@ -29,6 +29,8 @@ ap.add_argument("--chunk", type=int, default=32 << 20, help="reads per exchange 
 ap.add_argument("--min-chunks", type=int, default=4, help="chunks at least (MC_EXCHANGE_MIN_CHUNKS: transfers overlap the next chunk's extraction)")
 ap.add_argument("--count-every", type=int, default=0, help="chunks per counting run (MC_EXCHANGE_COUNT_EVERY; 0: one run for all)")
 ap.add_argument("--keep-gb", type=float, default=12.0, help="received records kept at most before a counting run takes them (MC_EXCHANGE_KEEP_GB)")
+ap.add_argument("--flat", action="store_true", help="the flat form of the record exchange (mc_extract_superkmers_dev / mc_add_superkmers_dev) instead of the binned one")
+ap.add_argument("--own-ptrs-only", action="store_true", help="MC_EXCHANGE_GATHER_READS=0: only the walking rank's reads are in its store -- the records of one read in W keep their pointers (default: every rank's packed reads are brought there, distributed.py, and every record carries one)")
 ap.add_argument("--check", action="store_true", help="--shard: sampled loci and the walk against the oracle (replays the read generator on the host)")
 args = ap.parse_args()
 W = args.owners
@@ -60,6 +62,8 @@ windows_total = R * (L - k + 1)
 est_distinct = int(contigs * clen + windows_total * (1.0 - (1.0 - err / 10000.0) ** k))
 ctx = m.Context(k, m.KEY_PACKED, 0, est_distinct + (1 << 20))
 ctx.set_coverage_hint(cov)
+if not args.own_ptrs_only:  # (as ShardedCounter sets it on the walking rank: the store holds every rank's reads, every record brings a pointer)
+    ctx.set_read_pointers(1 | 0x10)
 print("table for %.0f M expected keys: %.1f GB in use; %d chunks of <= %d reads" % (est_distinct / 1e6, used(), n_chunks, chunk_max), flush=True)
 d_words = torch.empty((chunk_max * L + 31) // 32 + 1, dtype=torch.int64, device=dev)
 d_off = torch.empty(chunk_max + 1, dtype=torch.int64, device=dev)
@@ -78,8 +82,9 @@ for rep in range(1 if args.shard else 3):
     ms_ext = ms_add = 0.0
     n_rec = 0
     peak = used()
-    kept, kept_p = [], []
+    kept, kept_p, kept_fc, kept_len, kept_win = [], [], [], [], []
     runs = 0
+    fine = 0 if args.flat else ctx.superkmer_fine_buckets(W)  # the binned form of the exchange where the table has a second level
 
     def count_kept():
         global ms_add, peak, runs
@@ -91,7 +96,14 @@ for rep in range(1 if args.shard else 3):
         kept.clear()
         kept_p.clear()
         peak = max(peak, used())
-        _, ms = timed(lambda: ctx.add_superkmers_dev(recv, recv_p, nr))
+        if fine:  # every (chunk, owner) piece is a part in fine-bucket order, as if W ranks had sent them
+            part_off = np.concatenate([[0], np.cumsum(kept_len)]).astype(np.uint64)
+            fc_all = torch.cat(kept_fc)
+            n_win = sum(kept_win)
+            kept_fc.clear(); kept_len.clear(); kept_win.clear()
+            _, ms = timed(lambda: ctx.add_superkmers_binned_dev(recv, recv_p, nr, n_win, fine, part_off, fc_all))
+        else:
+            _, ms = timed(lambda: ctx.add_superkmers_dev(recv, recv_p, nr))
         ms_add += ms
         runs += 1
         peak = max(peak, used())
@@ -104,14 +116,29 @@ for rep in range(1 if args.shard else 3):
         cap = ctx.superkmer_capacity(n * (L - k + 1), n)
         send = torch.empty((cap, 2), dtype=torch.int64, device=dev)
         send_b = torch.empty(cap, dtype=torch.int32, device=dev)
-        off, ms = timed(lambda: ctx.extract_superkmers_dev(d_words, d_off, n, n * L, W, send, send_b, cap))
+        if fine:
+            fc = torch.empty((W, fine), dtype=torch.int32, device=dev)
+            (off, win), ms = timed(lambda: ctx.extract_superkmers_binned_dev(d_words, d_off, n, n * L, W, fine, send, send_b, cap, fc))
+            kept_fc.append(fc)
+            kept_len.extend(int(off[o + 1] - off[o]) for o in range(W))
+            kept_win.append(int(win.sum()))
+        else:
+            off, ms = timed(lambda: ctx.extract_superkmers_dev(d_words, d_off, n, n * L, W, send, send_b, cap))
         ms_ext += ms
         nr = int(off[W])
         n_rec += nr
         # (a rank receives about what it sends: its own records stand in for the received ones, in buffers of their own; the
         # pointers of 7 ranks out of 8 do not travel -- zeros where they arrive)
         kept.append(send[:nr].clone())
-        kept_p.append(send_b[:nr].clone())
+        ptrs = send_b[:nr].clone()
+        if args.own_ptrs_only and nr:
+            # what a rank receives when the other ranks' reads stay where they are: records of ALL ranks' reads, of which only the
+            # walking rank's carry pointers -- the records of the chunk's first eighth of reads keep theirs (exact pointers:
+            # position + 1), the others arrive with none
+            pz = ptrs.to(torch.int64) & 0xFFFFFFFF
+            base = int(pz[pz > 0].min())
+            ptrs[pz > base + (n * L) // W] = 0
+        kept_p.append(ptrs)
         peak = max(peak, used())
         if args.shard:
             print("  reads %d..%d: extract %.1f ms so far (%d records, send buffers %.1f GB); %.1f GB in use" % (
@@ -126,9 +153,9 @@ for rep in range(1 if args.shard else 3):
     st = ctx.stats()
     reached = sum(len(r["lo"]) for r in res if r is not None)
     tot = ms_ext + ms_add + ms_fin + ms_bfs
-    print("owners %d, %d reads in %d chunks: extract %.2f (%d records, %.2f GB to send as 16-byte records%s) | count in %d run(s) %.2f | finalize %.2f (%d distinct) | "
+    print("owners %d, %s exchange, %d reads in %d chunks: extract %.2f (%d records, %.2f GB to send as 16-byte records%s) | count in %d run(s) %.2f | finalize %.2f (%d distinct) | "
           "walk in place %.2f (%d reached; rank 0 only) | sum %.2f ms (every rank: %.2f) | table %.1f GB, grows %d, handed on / spilled %d | peak device memory %.1f GB" % (
-              W, R, n_chunks, ms_ext, n_rec, n_rec * 16 / 1e9, ", + 4-byte pointers from the walking rank", runs, ms_add, ms_fin, nd, ms_bfs, reached, tot,
+              W, ("binned (%d fine buckets, %d binned runs)" % (fine, st.binned_runs)) if fine else "flat", R, n_chunks, ms_ext, n_rec, n_rec * 16 / 1e9, ", + 4-byte pointers from the walking rank", runs, ms_add, ms_fin, nd, ms_bfs, reached, tot,
               ms_ext + ms_add + ms_fin, st.table_bytes / 1e9, st.grows, st.spill_keys, peak), flush=True)
     if not args.shard and rep == 2:
         # the same reads on one GPU, whole step (what bench.py times at N = 1), for the ratio

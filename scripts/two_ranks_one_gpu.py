@@ -78,15 +78,34 @@ def _worker(rank, world, port, k, q):
         # the BFS-only context holds no counts of its own (mc_solid_from_pairs_dev): what it knows shows in the walks
         seed = genome[min(30000, clen // 3):min(30000, clen // 3) + 300]
         shi, slo = seed_windows(seed, k)
+        rounds = {}
         for d in (1, -1, 0):
             got = solid.bfs(shi, slo, d, cov, 20000, -1)
             want = po.bfs(t, k, mode, [seed], d, cov, 20000, -1)
             assert (got is None) == (want is None)
             if got is None:
                 continue
+            rounds[d] = (got["rounds"], got["levels"])
             assert np.array_equal(got["lo"], want["lo"]) and np.array_equal(got["dist"], want["dist"])
             assert np.array_equal(got["cov"], want["cov"]) and np.array_equal(got["hi"], want["hi"])
-        q.put(("ok", total, n_solid, sc.bytes_sent, sc.n_chunks, ctx.superkmer_capacity(1000, 10) > 0))
+        if in_place and sc.gather_reads and VARIANT and VARIANT % 2 == 0 and rounds and mode == m.KEY_PACKED:
+            # The other rank's packed reads were brought to this rank's store and its records' pointers lead there: the walk's
+            # look-ahead is as good as one context's over all the reads -- about as many verification rounds for the same levels.
+            # (Pointers that led anywhere else would only cost rounds, never a result: this is where it would show.)
+            one = m.Context(k, mode, 0, 0)
+            if hint:
+                one.set_coverage_hint(cov)
+            one.add_reads_packed(po.pack(reads), off)
+            one.finalize()
+            for d, (r_sh, lv) in rounds.items():
+                ref = one.bfs(shi, slo, d, cov, 20000, -1)
+                assert ref["levels"] == lv
+                print("walk %d: %d levels, %d rounds over two ranks' tables, %d in one context" % (d, lv, r_sh, ref["rounds"]), flush=True)
+                assert r_sh <= 1.5 * ref["rounds"] + 16, (d, lv, r_sh, ref["rounds"])
+            one.close()
+        if sc.fine_buckets:  # the binned form of the record exchange: every counting run of this rank started at its second level
+            assert ctx.stats().binned_runs == sc.n_count_runs > 0, (ctx.stats().binned_runs, sc.n_count_runs)
+        q.put(("ok", total, n_solid, sc.bytes_sent, sc.n_chunks, "fine buckets: %d" % sc.fine_buckets, ctx.superkmer_capacity(1000, 10) > 0))
     if in_place:
         sc.walk_done(dst=0)
     dist.barrier()

@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported(lib):
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     assert sorted(native.EXPORTS) == names  # the Python binding tracks the header
-    assert lib.mc_abi_version() == 13
+    assert lib.mc_abi_version() == 14
 
 
 def test_host_only_entry_points_work_without_gpu(lib):

@@ -18,9 +18,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 class OracleBackedContext:
     """Implements the Context methods distributed.py uses, on CPU tensors, with oracle/ functions."""
 
-    def __init__(self, k, mode, records=False, rank=0):
+    def __init__(self, k, mode, records=False, rank=0, binned=False):
         from oracle import pyoracle as po
         self.po, self.k, self.mode = po, k, mode
+        self.binned = binned    # ... whose exchange has the binned form (fine buckets), as tables with a second level have
+        self.n_binned_runs = 0
+        self.ptr_mode, self.fill, self.seeks, self.imports = 1, 0, [], []
         self.t = po.Table()
         self.records = records  # stand in for a context that splits reads into super-k-mer records
         self.rank = rank        # stamped into what this context extracts, so that the receiver can tell the sources apart
@@ -43,8 +46,67 @@ class OracleBackedContext:
         # its records bring theirs (5), everybody else's arrive with none
         src = (d_recs[:n, 1] - 7) // 16
         assert bool(((d_recs[:n, 1] - 7) % 16 == 0).all())
-        assert bool((d_bins[:n][src == 0] == 5).all()) and bool((d_bins[:n][src != 0] == 0).all())
+        if self.ptr_mode & 0x10:  # (the reads of every rank are in the walking rank's store: every record brings its pointer)
+            assert bool((d_bins[:n] == 5).all())
+        else:
+            assert bool((d_bins[:n][src == 0] == 5).all()) and bool((d_bins[:n][src != 0] == 0).all())
         self.add_keys_dev(d_recs[:n, 0].contiguous(), n)
+
+    # the shared read store (ShardedCounter.gather_reads): pointers = where the walking rank's store holds the read, the words follow
+    def set_read_pointers(self, mode):
+        self.ptr_mode = int(mode)
+
+    def read_store_seek(self, at_bases, reserve_bases=0):
+        assert at_bases % 32 == 0
+        self.fill = at_bases
+        self.seeks.append(at_bases)
+
+    def read_store_tell(self):
+        return self.fill
+
+    def read_store_import_dev(self, d_words, n_words, at_bases):
+        assert (self.ptr_mode & 0xF) == 1 and at_bases % 32 == 0 and d_words.shape[0] == n_words
+        self.imports.append((at_bases, d_words.numpy().copy().view(np.uint64)))
+
+    def _append(self, d_off, n_reads, n_bases):
+        """what mc_extract_*_dev does to the (real or deemed) store: the chunk's whole words behind the fill"""
+        first = int(d_off.numpy().view(np.uint64)[0])
+        self.fill += 32 * ((n_bases + 31) // 32 - first // 32)
+
+    # the binned form: fine bucket of a record = a function of its key; an owner's records in bucket order, a row of counts beside them
+    FINE = 8
+
+    def superkmer_fine_buckets(self, n_owners):
+        return self.FINE if self.records and self.binned else 0
+
+    @staticmethod
+    def _fine_of(keys, fine):
+        return ((keys.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(40)).astype(np.int64) % fine
+
+    def extract_superkmers_binned_dev(self, d_words, d_off, n_reads, n_bases, n_owners, n_fine, d_recs, d_bins, cap, d_fine_counts):
+        assert n_fine == self.FINE and d_fine_counts.shape == (n_owners, n_fine) and d_fine_counts.dtype == torch.int32
+        out = self.extract_superkmers_dev(d_words, d_off, n_reads, n_bases, n_owners, d_recs, d_bins, cap)
+        win = np.zeros(n_owners, dtype=np.uint64)
+        for o in range(n_owners):
+            a, b = int(out[o]), int(out[o + 1])
+            keys = d_recs[a:b, 0].numpy().copy()
+            f = self._fine_of(keys, n_fine)
+            order = np.argsort(f, kind="stable")
+            d_recs[a:b, 0] = torch.from_numpy(keys[order])
+            d_fine_counts[o] = torch.from_numpy(np.bincount(f, minlength=n_fine).astype(np.int32))
+            win[o] = b - a  # (one window a record here)
+        return out, win
+
+    def add_superkmers_binned_dev(self, d_recs, d_bins, n, n_windows, n_fine, part_offsets, d_part_counts):
+        po = [int(x) for x in part_offsets]
+        assert po[0] == 0 and po[-1] == n and n_windows == n and d_part_counts.shape == (len(po) - 1, n_fine)
+        for p in range(len(po) - 1):  # every part in fine-bucket order, its row of counts beside it
+            keys = d_recs[po[p]:po[p + 1], 0].numpy()
+            f = self._fine_of(keys, n_fine)
+            assert bool((np.diff(f) >= 0).all())
+            assert np.array_equal(np.bincount(f, minlength=n_fine), d_part_counts[p].numpy())
+        self.n_binned_runs += 1
+        self.add_superkmers_dev(d_recs, d_bins, n)
 
     def add_reads_packed_dev(self, d_words, d_off, n_reads, n_bases):
         self.t.count_reads_packed(d_words.numpy().view(np.uint64), d_off.numpy().view(np.uint64), self.k, self.mode)
@@ -66,6 +128,8 @@ class OracleBackedContext:
         from metacherchant_amd import native
         keys = self._keys(d_words, d_off, n_reads)
         assert int(d_off.numpy().view(np.uint64)[n_reads]) == n_bases
+        if n_reads:
+            self._append(d_off, n_reads, n_bases)
         owners = np.array([native.key_owner(int(x), n_owners) for x in keys], dtype=np.int64)
         order = np.argsort(owners, kind="stable")
         out = np.zeros(n_owners + 1, dtype=np.uint64)
@@ -106,7 +170,9 @@ class OracleBackedContext:
         return n
 
 
-def _worker(rank, world, port, k, mode, reads, L, n_reads, min_cov, q, records=False, chunk_reads=0, share0=None, count_every=0, pool_slack=None, keep_gb=None):
+def _worker(rank, world, port, k, mode, reads, L, n_reads, min_cov, q, records=False, chunk_reads=0, share0=None, count_every=0, pool_slack=None, keep_gb=None,
+            binned=False):
+    # binned: the contexts offer the binned form of the record exchange ("rank0": only rank 0's does -- the ranks must settle on the flat form)
     # chunk_reads: MC_EXCHANGE_CHUNK_READS (0: the default, one chunk here); share0: reads of rank 0 (None: equal shares)
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -129,10 +195,26 @@ def _worker(rank, world, port, k, mode, reads, L, n_reads, min_cov, q, records=F
         mine = reads[lo * L:hi * L]
         words = torch.from_numpy(po.pack(mine).view(np.int64))
         off = torch.from_numpy((np.arange(hi - lo + 1, dtype=np.uint64) * L).view(np.int64))
-        ctx = OracleBackedContext(k, mode, records, rank)
+        ctx = OracleBackedContext(k, mode, records, rank, binned=(binned is True) or (binned == "rank0" and rank == 0))
         sc = ShardedCounter(ctx, torch.device("cpu"))
         sc.add_reads_dev(words, off, hi - lo, (hi - lo) * L, (hi - lo) * (L - k + 1))
-        total = sc.finalize()
+        total = sc.finalize()  # (... where the walking rank takes the other ranks' reads into its store)
+        if sc.gather_reads:
+            # the other rank's packed reads went to rank 0's store: every chunk's words (pad word included) to where that rank's
+            # context deemed them -- stretches that follow one another from the position the ranks agreed on
+            other = split_reads(n_reads, world, 1) if share0 is None else (share0, n_reads)
+            theirs = po.pack(reads[other[0] * L:other[1] * L])
+            if rank == 0:
+                assert ctx.ptr_mode == 0x11 and len(ctx.seeks) == 1 and ctx.seeks[0] == 0
+                at = 32 * ((hi - lo) * L // 32 + 1 + 2 * sc.n_chunks + 2)  # behind rank 0's own stretch (its words, two a chunk, a spare)
+                for where, w in sorted(ctx.imports, key=lambda x: x[0]):
+                    assert where == at, (where, at)
+                    hit = [i for i in range(len(theirs) - len(w) + 1) if theirs[i] == w[0] and np.array_equal(theirs[i:i + len(w)], w)]
+                    assert hit, "an imported stretch is not a piece of the other rank's packed reads"
+                    at += 32 * (len(w) - 1)
+                assert sum(len(w) - 1 for _, w in ctx.imports) >= len(theirs) - 1 or other[1] == other[0]
+            else:
+                assert ctx.ptr_mode == 0x12 and not ctx.imports and len(ctx.seeks) == 1 and ctx.seeks[0] > 0
         solid = OracleBackedContext(k, mode)
         n_solid = sc.gather_solid(solid, min_cov, dst=0)
         own_keys = ctx.t.dump()[0]
@@ -140,7 +222,7 @@ def _worker(rank, world, port, k, mode, reads, L, n_reads, min_cov, q, records=F
         assert all(native.key_owner(int(x), world) == rank for x in own_keys[:500])
         if rank == 0:
             sk, scnt = solid.t.dump()
-            q.put((total, n_solid, sk, scnt, sc.bytes_sent, sc.n_chunks, sc.n_count_runs, sc.n_pool_misses, sc.pool_rows))
+            q.put((total, n_solid, sk, scnt, sc.bytes_sent, sc.n_chunks, sc.n_count_runs, sc.n_pool_misses, sc.pool_rows, ctx.n_binned_runs, sc.fine_buckets))
     finally:
         dist.destroy_process_group()
 
@@ -192,11 +274,16 @@ def _free_port():
 # with shares so unequal that rank 1 (6, 2 and 0 reads) has chunks without a read while rank 0 still sends
 # ... and the last two with a receive buffer half of what arrives (the chunks that do not fit get tensors of their own, and the
 # counting run's input is put together after all)
-@pytest.mark.parametrize("k,mode,records,chunk_reads,share0,count_every,pool_slack", [
-    (31, 0, False, 0, None, 0, None), (35, 1, False, 0, None, 0, None), (31, 0, True, 0, None, 0, None),
-    (31, 0, True, 64, 294, 0, None), (27, 0, True, 50, 298, 0, None), (33, 1, False, 64, 300, 0, None), (31, 0, True, 64, 294, 2, None),
-    (31, 0, True, 64, 294, 0, 0.5), (33, 1, False, 64, 300, 0, 0.5)])
-def test_sharded_count_equals_single_table(k, mode, records, chunk_reads, share0, count_every, pool_slack):
+# binned: the record exchange in its binned form (every owner's records in fine-bucket order, a row of counts beside them: the stand-in
+# checks order and counts of every part it is handed) -- one chunk, five chunks with one run, with a run every two chunks, with a
+# receive buffer too small; "rank0": only one rank's table offers it, and both must take the flat form
+@pytest.mark.parametrize("k,mode,records,chunk_reads,share0,count_every,pool_slack,binned", [
+    (31, 0, False, 0, None, 0, None, False), (35, 1, False, 0, None, 0, None, False), (31, 0, True, 0, None, 0, None, False),
+    (31, 0, True, 64, 294, 0, None, False), (27, 0, True, 50, 298, 0, None, False), (33, 1, False, 64, 300, 0, None, False), (31, 0, True, 64, 294, 2, None, False),
+    (31, 0, True, 64, 294, 0, 0.5, False), (33, 1, False, 64, 300, 0, 0.5, False),
+    (31, 0, True, 0, None, 0, None, True), (31, 0, True, 64, 294, 0, None, True), (27, 0, True, 50, 298, 2, None, True), (31, 0, True, 64, 294, 0, 0.5, True),
+    (31, 0, True, 64, 294, 0, None, "rank0")])
+def test_sharded_count_equals_single_table(k, mode, records, chunk_reads, share0, count_every, pool_slack, binned):
     from metacherchant_amd import build
     build.build_lib()  # key_owner comes from the C ABI (host function, no GPU needed)
     from oracle import pyoracle as po
@@ -208,10 +295,11 @@ def test_sharded_count_equals_single_table(k, mode, records, chunk_reads, share0
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, k, mode, reads, L, n_reads, min_cov, q, records, chunk_reads, share0, count_every, pool_slack)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, k, mode, reads, L, n_reads, min_cov, q, records, chunk_reads, share0, count_every, pool_slack, None, binned))
+             for r in range(2)]
     for p in procs:
         p.start()
-    total, n_solid, sk, scnt, sent, n_chunks, runs, pool_misses, _ = q.get(timeout=120)
+    total, n_solid, sk, scnt, sent, n_chunks, runs, pool_misses, _, binned_runs, fine = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -225,6 +313,7 @@ def test_sharded_count_equals_single_table(k, mode, records, chunk_reads, share0
     # however many chunks travelled: ONE counting run (a run rewrites the rank's whole table), unless the memory bound asks for more
     assert runs == (1 if not count_every else -(-n_chunks // count_every))
     assert (pool_misses > 0) == (pool_slack is not None)  # (every chunk of a run lands in the one buffer unless it was made too small)
+    assert (binned_runs, fine) == ((runs, OracleBackedContext.FINE) if binned is True else (0, 0))  # every run binned, or none
 
 
 def test_receive_pool_holds_what_may_gather_between_counting_runs():
@@ -247,7 +336,7 @@ def test_receive_pool_holds_what_may_gather_between_counting_runs():
         procs = [ctx.Process(target=_worker, args=(r, 2, port, k, 0, reads, L, n_reads, min_cov, q, True, 64, 294, count_every, None, keep_gb)) for r in range(2)]
         for p in procs:
             p.start()
-        total, n_solid, sk, scnt, sent, n_chunks, runs, pool_misses, pool_rows = q.get(timeout=120)
+        total, n_solid, sk, scnt, sent, n_chunks, runs, pool_misses, pool_rows, _, _ = q.get(timeout=120)
         for p in procs:
             p.join(timeout=60)
             assert p.exitcode == 0

@@ -396,6 +396,19 @@ def test_cli_several_devices_equal_one(cli, tmp_path, devices, k, extra, env):
         assert len(lines) == 2 and all(int(l.split(" reads in ")[1].split()[0]) >= 2 for l in lines), outs["many"][1][-2000:]
     size_line = [l for l in outs["one"][1].splitlines() if "Hashtable size" in l][0].split("Hashtable size")[1]
     assert ("Hashtable size" + size_line) in outs["many"][1]  # owners are disjoint: the shards add up to the one table
+    # packed k-mers of 23 bases and more travel as super-k-mer records in the binned form (include/mcgpu.h
+    # mc_extract_superkmers_binned_dev): the devices' counting runs start at their second level
+    import json
+    metrics = json.load(open(str(tmp_path / "wd_many" / "metrics.json")))
+    assert (metrics["binned_runs"] > 0) == (23 <= k <= 31), metrics
+    # every device's reads sit in the first device's store and its records' pointers lead there (mc_set_read_pointers mode 2): the
+    # walk's look-ahead does as well as one device's over all the reads -- about as many verification rounds for the same levels
+    one = json.load(open(str(tmp_path / "wd_one" / "metrics.json")))
+    # (with pointers from the first device's reads alone these walks took 2.2 to 3.4 times the rounds; the rounds of a walk vary a
+    # little from run to run -- scouts and verifier race --, and for hash keys, which travel as one key a window and leave their
+    # pointers by another rule, by more: checked for packed keys)
+    assert metrics["bfs_levels"] == one["bfs_levels"], (metrics, one)
+    assert hashed or metrics["bfs_rounds"] <= 2 * one["bfs_rounds"] + 32, (metrics, one)
     kw = {}
     it = iter(extra)
     for a in it:

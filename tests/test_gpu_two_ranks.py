@@ -24,6 +24,8 @@ def test_two_ranks_on_one_gpu(k, records, walk):
     assert "'ok'" in line
     assert line.rstrip(")").endswith("True" if records else "False")  # which form of the exchange ran
     assert ", 5, " in line  # ... in five chunks, rank 1 with three reads in all (scripts/two_ranks_one_gpu.py)
+    # records travel binned (the sender does the owner's first level; the script checks that every counting run started at its second)
+    assert ("fine buckets: 512" if records else "fine buckets: 0") in line
 
 
 def test_bench_multi_rank_path_on_one_gpu():
@@ -41,7 +43,9 @@ def test_bench_multi_rank_path_on_one_gpu():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["bfs"]["reached"] > 1000 and out["solid_kmers"] > 100000
-    assert out["roofline"]["kernel_ms"]["k_sk1_records"] > 0  # the super-k-mer form of the exchange ran
+    # the super-k-mer form of the exchange ran, binned: the counting runs had no first level of their own
+    assert out["exchange_form"].startswith("binned (512 fine buckets") and "k_sk1_records" not in out["roofline"]["kernel_ms"]
+    assert out["roofline"]["kernel_ms"]["k_sk2_scatter_staged<listed>"] > 0
     # the record says what ran: how many ranks the process group had, which walk, what travelled, what every rank did
     assert out["ranks_seen"] == 2 and out["backend"] == "gloo" and out["walk_mode"] == "in_place" and out["walk_fallback"] is None
     assert out["exchange_chunks"] >= 4 and out["count_runs_per_step"] == 1 and out["exchange_GB_per_step"] > 0
