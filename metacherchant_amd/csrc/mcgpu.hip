@@ -2616,6 +2616,15 @@ static int add_records_binned(mc_ctx *c, const uint4 *d_recs, const uint32_t *d_
     HIPCHK(c, hipMemcpyAsync(&bad, P.skb_small + n_parts + 1, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));  // (po must outlive its copy, and nothing may read by counts that do not add up)
     if (bad) return fail(c, MC_EINVAL, "mc_add_superkmers_binned_dev: the fine-bucket counts of %llu part(s) do not add up to the parts' lengths", bad);
+    if (!c->want_list && (P.a_recs || P.a_hints)) {
+        // This run has no first level: the extraction's first-level streams (a fifth of the table at configs[3]'s size) go back to the
+        // pool, where the second level's buffer -- about as large -- is taken from; the next extraction gets them back from there.
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        g_scratch_pool.put(c->cfg.device, P.a_recs, P.a_recs_cap * sizeof(uint4));
+        g_scratch_pool.put(c->cfg.device, P.a_hints, P.a_hints_cap * 4);
+        P.a_recs = nullptr; P.a_recs_cap = 0; P.a_hints = nullptr; P.a_hints_cap = 0;
+        c->solid_list_fresh = false;
+    }
     PipePlan pl;
     rc = pipe_prepare(c, n_windows, &pl, n, (uint32_t)nseg, 1, false, 0, false, true);
     if (rc) return rc;

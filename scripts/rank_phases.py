@@ -64,6 +64,8 @@ ctx = m.Context(k, m.KEY_PACKED, 0, est_distinct + (1 << 20))
 ctx.set_coverage_hint(cov)
 if not args.own_ptrs_only:  # (as ShardedCounter sets it on the walking rank: the store holds every rank's reads, every record brings a pointer)
     ctx.set_read_pointers(1 | 0x10)
+    if args.shard:  # ... and has room for them: W shares of packed reads (configs[3]: 8 x 4.7 GB), what the walking rank's memory must hold
+        ctx.read_store_seek(0, 32 * W * ((R * L + 31) // 32 + 2 * n_chunks + 2))
 print("table for %.0f M expected keys: %.1f GB in use; %d chunks of <= %d reads" % (est_distinct / 1e6, used(), n_chunks, chunk_max), flush=True)
 d_words = torch.empty((chunk_max * L + 31) // 32 + 1, dtype=torch.int64, device=dev)
 d_off = torch.empty(chunk_max + 1, dtype=torch.int64, device=dev)
@@ -77,12 +79,13 @@ for i in range(len(seed) - k + 1):
 hi, lo = np.zeros(len(sv), dtype=np.uint64), np.array(sv, dtype=np.uint64)
 jobs = [(hi, lo, -1), (hi, lo, 1)]
 
-for rep in range(1 if args.shard else 3):
+for rep in range(2 if args.shard else 3):  # (the first repetition pays for fresh device memory: 20 GB buffers zeroed by the driver)
     ctx.clear()
     ms_ext = ms_add = 0.0
     n_rec = 0
     peak = used()
     kept, kept_p, kept_fc, kept_len, kept_win = [], [], [], [], []
+    pool = {"recs": None, "ptrs": None, "at": 0}
     runs = 0
     fine = 0 if args.flat else ctx.superkmer_fine_buckets(W)  # the binned form of the exchange where the table has a second level
 
@@ -91,10 +94,14 @@ for rep in range(1 if args.shard else 3):
         if not kept:
             return
         nr = sum(x.shape[0] for x in kept)
-        recv = torch.cat(kept) if len(kept) > 1 else kept[0]
-        recv_p = torch.cat(kept_p) if len(kept_p) > 1 else kept_p[0]
+        if pool["recs"] is not None and pool["at"] == nr:  # (the chunks lie back to back in the one buffer: distributed.py's receive pool)
+            recv, recv_p = pool["recs"], pool["ptrs"]
+        else:
+            recv = torch.cat(kept) if len(kept) > 1 else kept[0]
+            recv_p = torch.cat(kept_p) if len(kept_p) > 1 else kept_p[0]
         kept.clear()
         kept_p.clear()
+        pool["at"] = 0
         peak = max(peak, used())
         if fine:  # every (chunk, owner) piece is a part in fine-bucket order, as if W ranks had sent them
             part_off = np.concatenate([[0], np.cumsum(kept_len)]).astype(np.uint64)
@@ -129,8 +136,22 @@ for rep in range(1 if args.shard else 3):
         n_rec += nr
         # (a rank receives about what it sends: its own records stand in for the received ones, in buffers of their own; the
         # pointers of 7 ranks out of 8 do not travel -- zeros where they arrive)
-        kept.append(send[:nr].clone())
-        ptrs = send_b[:nr].clone()
+        if pool["recs"] is None and n_chunks > 1:  # what may gather between counting runs, as ShardedCounter sizes its receive buffer
+            held = n_chunks if not args.count_every else min(n_chunks, args.count_every)
+            rows = int(min(nr * held * 1.12, args.keep_gb * 1e9 / 20 + nr * 1.12)) + 1024
+            pool["recs"] = torch.empty((rows, 2), dtype=torch.int64, device=dev)
+            pool["ptrs"] = torch.empty(rows, dtype=torch.int32, device=dev)
+        if pool["recs"] is not None and pool["at"] + nr <= pool["recs"].shape[0]:
+            a0 = pool["at"]
+            pool["recs"][a0:a0 + nr] = send[:nr]
+            pool["ptrs"][a0:a0 + nr] = send_b[:nr]
+            kept.append(pool["recs"][a0:a0 + nr])
+            ptrs = pool["ptrs"][a0:a0 + nr]
+            pool["at"] = a0 + nr
+        else:
+            kept.append(send[:nr].clone())
+            ptrs = send_b[:nr].clone()
+            pool["at"] = -1 << 60  # (this run's input is put together after all)
         if args.own_ptrs_only and nr:
             # what a rank receives when the other ranks' reads stay where they are: records of ALL ranks' reads, of which only the
             # walking rank's carry pointers -- the records of the chunk's first eighth of reads keep theirs (exact pointers:
@@ -144,6 +165,8 @@ for rep in range(1 if args.shard else 3):
             print("  reads %d..%d: extract %.1f ms so far (%d records, send buffers %.1f GB); %.1f GB in use" % (
                 first, first + n, ms_ext, nr, cap * 20 / 1e9, used()), flush=True)
         del send, send_b
+        if args.shard:
+            torch.cuda.empty_cache()  # (torch keeps freed blocks: "in use" below means the buffers that are held, as in distributed.py)
         if (args.count_every and len(kept) >= args.count_every) or sum(x.numel() * 8 for x in kept) + sum(x.numel() * 4 for x in kept_p) >= args.keep_gb * 1e9:
             count_kept()
     count_kept()
@@ -155,7 +178,7 @@ for rep in range(1 if args.shard else 3):
     tot = ms_ext + ms_add + ms_fin + ms_bfs
     print("owners %d, %s exchange, %d reads in %d chunks: extract %.2f (%d records, %.2f GB to send as 16-byte records%s) | count in %d run(s) %.2f | finalize %.2f (%d distinct) | "
           "walk in place %.2f (%d reached; rank 0 only) | sum %.2f ms (every rank: %.2f) | table %.1f GB, grows %d, handed on / spilled %d | peak device memory %.1f GB" % (
-              W, ("binned (%d fine buckets, %d binned runs)" % (fine, st.binned_runs)) if fine else "flat", R, n_chunks, ms_ext, n_rec, n_rec * 16 / 1e9, ", + 4-byte pointers from the walking rank", runs, ms_add, ms_fin, nd, ms_bfs, reached, tot,
+              W, ("binned (%d fine buckets, %d binned runs)" % (fine, st.binned_runs)) if fine else "flat", R, n_chunks, ms_ext, n_rec, n_rec * 16 / 1e9, (" + 4-byte pointers from the walking rank" if args.own_ptrs_only else " + %.2f GB of pointers + %.2f GB of packed reads to the walking rank" % (n_rec * 4 / 1e9, R * L / 4e9)), runs, ms_add, ms_fin, nd, ms_bfs, reached, tot,
               ms_ext + ms_add + ms_fin, st.table_bytes / 1e9, st.grows, st.spill_keys, peak), flush=True)
     if not args.shard and rep == 2:
         # the same reads on one GPU, whole step (what bench.py times at N = 1), for the ratio
