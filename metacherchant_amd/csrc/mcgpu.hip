@@ -6045,6 +6045,8 @@ int mc_group_bfs_batch(mc_group *g, const mc_bfs_job *jobs, uint32_t n_jobs, int
     static const bool want_gather = getenv("MC_GROUP_WALK") && !strcmp(getenv("MC_GROUP_WALK"), "gather");
     if (!want_gather && g->peer_all) {
         mc_ctx *c0 = g->ctx[0];
+        static const bool dbg = getenv("MC_INGEST_DEBUG") != nullptr;
+        const auto t_0 = std::chrono::steady_clock::now();
         if (g->dirty || !c0->d_shards) {
             std::vector<ShardWire> w(W);
             int grc = per_rank(W, [&](size_t r) -> int {
@@ -6061,7 +6063,10 @@ int mc_group_bfs_batch(mc_group *g, const mc_bfs_job *jobs, uint32_t n_jobs, int
             g->dirty = false;
             g->solid_cov = -1;
         }
+        const auto t_1 = std::chrono::steady_clock::now();
         const int rc = mc_bfs_batch(c0, jobs, n_jobs, min_cov, max_kmers, max_radius, out);
+        if (dbg) fprintf(stderr, "[walk] group: tables described and attached in %.2f ms, %u walk(s) in %.2f ms\n", std::chrono::duration<double, std::milli>(t_1 - t_0).count(),
+                         n_jobs, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_1).count());
         return rc ? gfail(g, rc, mc_last_error(c0)) : MC_OK;
     }
     if (g->dirty || g->solid_cov != min_cov) {
