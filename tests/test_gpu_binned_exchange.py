@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from oracle import pyoracle as po
-from tests.helpers import oracle_table, synth_case
+from tests.helpers import oracle_table, ragged_case, synth_case
 
 pytestmark = pytest.mark.gpu
 
@@ -151,6 +151,32 @@ def test_fine_buckets_that_are_not_the_tables_own(mc, scale, binned_runs):
         ctx = _count_owner(mc, torch, parts[w], k, hint, fine, True)
         ctx.finalize()
         assert ctx.stats().binned_runs == binned_runs
+        a, b = ctx.export(0)
+        ks.append(a)
+        cs.append(b)
+        ctx.close()
+    gk, gc = np.concatenate(ks), np.concatenate(cs)
+    o = np.argsort(gk, kind="stable")
+    assert np.array_equal(gk[o], ok) and np.array_equal(gc[o], oc)
+
+
+def test_ragged_reads_through_the_binned_exchange(mc):
+    """Reads of 0 .. 220 bases (shorter than k, one window, many): the same table as the oracle's, three owners, two senders, two chunks."""
+    import torch
+    rng = np.random.default_rng(5)
+    _, codes, offs = ragged_case(rng, 30000, max_len=220, genome_len=60000)
+    k, W, hint = 27, 3, 40_000_000
+    t, _ = oracle_table(codes, offs, k, po.KEY_PACKED)
+    ok, oc = t.dump()
+    probe = mc.Context(k, mc.KEY_PACKED, 0, hint)
+    fine = probe.superkmer_fine_buckets(W)
+    probe.close()
+    parts = _extract_all(mc, torch, 2, 2, W, fine, k, hint, codes, offs, binned=True)
+    ks, cs = [], []
+    for w in range(W):
+        ctx = _count_owner(mc, torch, parts[w], k, hint, fine, True)
+        ctx.finalize()
+        assert ctx.stats().binned_runs == 1
         a, b = ctx.export(0)
         ks.append(a)
         cs.append(b)
