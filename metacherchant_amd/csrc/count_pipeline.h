@@ -1390,8 +1390,10 @@ template <int ITEMS, int RW = 1>
 __global__ void __launch_bounds__(PT_THREADS, ITEMS * RW <= 3 ? 8 : 4) k_sk2_scatter_compact(const uint4 *__restrict__ in_recs, uint64_t seg_cap1,
                                                                        const uint32_t *__restrict__ seg_counts1, uint32_t n_buckets1, uint32_t m2,
                                                                        uint32_t *leaf_counts, uint64_t cap2, uint4 *out_recs, SkSpill sp,
-                                                                       uint32_t nseg_in, uint64_t ptr_base, uint64_t pos0, uint64_t seg_bases)
-{
+                                                                       uint32_t nseg_in, uint64_t ptr_base, uint64_t pos0, uint64_t seg_bases, uint32_t leaf_shift = 0)
+{   // leaf_shift (RW == 1): the records carry the leaf of a bucket of 2^10 leaves whatever the table -- the ten bits of the bin word
+    // below the bucket's -- and this table, of a power of two of regions, has 2^(10 - leaf_shift) of them a bucket (a context without
+    // a capacity hint: the table is sized between the two levels, mcgpu.hip pipe_resize_by_sample)
     __shared__ Sk2cLds<ITEMS, RW> L;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     constexpr uint32_t TILE = PT_THREADS * ITEMS;
@@ -1458,7 +1460,7 @@ __global__ void __launch_bounds__(PT_THREADS, ITEMS * RW <= 3 ? 8 : 4) k_sk2_sca
                 if (dr[j] != NONE) {
                     // (long records: the bin word's top 24 bits sit in the second word above the window count -- the leaf is worked out here,
                     // for the table as it is now --, the position has the first word to itself)
-                    const uint32_t dj = RW == 2 ? mulhi32(rec[j].y & 0xFFFFFF00u, n_buckets1 * m2) - bucket * m2 : rec[j].x >> SKC_REL_BITS;
+                    const uint32_t dj = RW == 2 ? mulhi32(rec[j].y & 0xFFFFFF00u, n_buckets1 * m2) - bucket * m2 : (rec[j].x >> SKC_REL_BITS) >> leaf_shift;
                     if (RW == 2) rec[j].y &= 0xFFu;
                     const uint64_t pos = pos0 + (uint64_t)dr[j] * seg_bases + (RW == 2 ? rec[j].x : rec[j].x & ((1u << SKC_REL_BITS) - 1u));
                     rec[j].x = ptr_base == ~0ull ? 0u : ptr_encode(ptr_base + pos);

@@ -235,6 +235,7 @@ struct mc_ctx {
     // appended here, and only the bookkeeping is done.  all_ptrs: every record mc_add_superkmers*_dev is handed carries a pointer.
     // rs_hi_bases: how far the store is filled by imports (a real store; never below what rs_bases has reached).
     bool rs_virtual = false, all_ptrs = false;
+    bool no_vleaf = false;  // (add_reads_partitioned: this batch's sample asked for a table beyond 2^19 regions; the first level runs again in the two-array form)
     uint64_t rs_hi_bases = 0;
     uint64_t rs_end() const { return std::max(rs_bases, rs_hi_bases); }
     mc_ctx *rs_from = nullptr;
@@ -1622,6 +1623,10 @@ struct PipePlan {
     uint32_t chunk_tiles = 0;
     uint64_t pos0 = 0;
     bool guessed = false;  // no capacity hint vouches for the table's size: pipe_finish merges a sample of the leaves first
+    // vleaf: compact records written before the table's size is known (a first batch without a hint): their leaf field holds the TEN
+    // bits of the bin word below the level-1 bucket's -- 2^10 leaves a bucket whatever the table --, the table is then given a power
+    // of two of regions (pipe_resize_by_sample) and the second level drops the bits it does not need
+    bool vleaf = false;
     bool lng = false;      // long records (count_long.h): two 16-byte words a record in every stream
     // listed: there is no first level -- the records lie in the caller's buffer (in_recs / in_ptrs) in pieces that are in level-1 bucket
     // order already (the binned exchange), and the second level reads segment sg of a bucket from pipe.skb_seg_start[bucket * nseg1 + sg]
@@ -1745,6 +1750,24 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
         // are those of the table the first level saw)
         pl->compact = compact_tiles && compact_on && staged && pl->sk && pl->b2 > 1 && pl->b2 <= (1u << (32 - SKC_REL_BITS)) && g == 0 && pieces == 1 &&
                       chunk * P1W_TILE <= (1ull << SKC_REL_BITS) && !(pl->guessed && c->virgin);
+        // ... unless the table can be given a power of two of regions once the batch's size is known: 512 buckets of 2 .. 1024 leaves
+        static const bool vleaf_on = [] { const char *e = getenv("MC_SK_VLEAF"); return !(e && !strcmp(e, "0")); }();
+        pl->vleaf = false;
+        if (!pl->compact && !lng && vleaf_on && !c->no_vleaf && compact_tiles && compact_on && staged && pl->sk && g == 0 && pieces == 1 && chunk * P1W_TILE <= (1ull << SKC_REL_BITS) &&
+            pl->guessed && c->virgin && c->mm_k > 0 && np1 == PT_MAX_BUCKETS && c->n_regions <= (uint64_t)PT_MAX_BUCKETS * 1024) {
+            uint64_t r2 = 2 * PT_MAX_BUCKETS;
+            while (r2 < c->n_regions) r2 *= 2;
+            if (r2 != c->n_regions) {  // (a virgin table: nothing to move)
+                table_release(c, c->slots, c->slots_bytes);
+                c->slots = nullptr;
+                int rc = table_alloc(c, r2);
+                if (rc) return rc;
+                n_leaves = r2;
+                pl->b2 = (uint32_t)(n_leaves / np1);
+                pl->n_leaves = n_leaves;
+            }
+            pl->compact = pl->vleaf = true;
+        }
         // (long records keep the leaf in their second word: 32 bits of position)
         // (... and the bin word, so the table may still be replaced between the levels: a virgin table without a hint qualifies)
         if (lng) pl->compact = compact_tiles && pl->sk && pl->b2 > 1 && pl->b2 <= 1024 && g == 0 && pieces == 1 && chunk * P1L_TILE < (1ull << 32) &&
@@ -1876,7 +1899,17 @@ static int pipe_resize_by_sample(mc_ctx *c, PipePlan &pl, uint64_t n_records)
     const double est = (double)c->h_scratch[24] * (double)pl.np1 * 1.1 + 1024.0;
     c->dup.expected_keys = est;  // (what the key streams of dup_check.h are sized by in a context without a hint)
     if (est > 0.45 * (double)SET_SLOTS * (double)pl.np1) return MC_OK;  // (the scratch set was too full to count in: the old way)
-    const uint64_t want = regions_for(c, mm_slots_for(c, est, 0.36));
+    uint64_t want = regions_for(c, mm_slots_for(c, est, 0.36));
+    if (pl.vleaf) {
+        // a power of two of regions: the smaller of the two around `want` while it keeps the table under load 0.45 (0.36 x 1.25),
+        // else the larger (load 0.23 at least); beyond 2^19 regions the records' ten leaf bits do not reach: the caller runs the
+        // first level again in the two-array form
+        uint64_t p2 = 2 * PT_MAX_BUCKETS;
+        while (p2 * 2 <= want) p2 *= 2;
+        if (est > 0.45 * (double)(p2 << c->sb)) p2 *= 2;
+        if (p2 > (uint64_t)PT_MAX_BUCKETS * 1024) return 5;
+        want = p2;
+    }
     if (pl.lng && est > 0.40 * (double)(want << c->sb)) return 4;  // (hash keys need their bins roomy, mc_create: the caller takes the per-window form)
     if (pl.lng && want <= c->n_regions) { pl.guessed = false; return MC_OK; }  // (the table it was created with holds the batch)
     static const bool dbg = getenv("MC_INGEST_DEBUG") != nullptr;
@@ -1996,7 +2029,7 @@ static int pipe_finish(mc_ctx *c, PipePlan &pl, double ms1, bool p2_done = false
         else if (pl.sk && pl.compact && !pl.listed)
             hipLaunchKernelGGL(k_sk2_scatter_compact<MC_SK2C_ITEMS>, dim3((unsigned)np1), dim3(PT_THREADS), 0, c->stream, P.a_recs, pl.cap1,
                                P.seg_counts1, (uint32_t)np1, pl.b2, P.cursors2, pl.cap2, P.b_recs, pl.sks, pl.nseg1, c->cur_ptr_base, pl.pos0,
-                               (uint64_t)pl.chunk_tiles * P1W_TILE);
+                               (uint64_t)pl.chunk_tiles * P1W_TILE, pl.vleaf ? 10u - (uint32_t)__builtin_ctz(pl.b2) : 0u);
         else if (pl.listed)
             hipLaunchKernelGGL((k_sk2_scatter_staged<MC_SK2_ITEMS, true, false>), dim3((unsigned)np1), dim3(PT_THREADS), 0, c->stream, pl.in_recs, pl.in_ptrs, (uint64_t)0,
                                P.seg_counts1, (uint32_t)np1, pl.b1, pl.b2, P.cursors2, pl.cap2, P.b_recs, nullptr, pl.sks, pl.nseg1, P.skb_seg_start, nullptr);
@@ -2474,11 +2507,11 @@ static int add_reads_partitioned_once(mc_ctx *c, const uint64_t *d_words, const 
         if (pl.sk && pl.compact) {
             pl.pos0 = base0 / P1W_TILE * P1W_TILE;
             if (getenv("MC_INGEST_DEBUG"))
-                fprintf(stderr, "[count] compact records: %u buckets x %u leaves, %u tiles a segment from base %llu\n", pl.b1, pl.b2, pl.chunk_tiles,
-                        (unsigned long long)pl.pos0);
+                fprintf(stderr, "[count] compact records: %u buckets x %u leaves%s, %u tiles a segment from base %llu\n", pl.b1, pl.vleaf ? 1024u : pl.b2,
+                        pl.vleaf ? " (whatever the table: it is sized behind the first level)" : "", pl.chunk_tiles, (unsigned long long)pl.pos0);
             hipLaunchKernelGGL((k_sk1w_extract<false, true>), dim3(P1W_SEGMENTS), dim3(P1W_THREADS), 0, c->stream, d_words, offs, nr, base0, end_abs,
                                n_tiles_abs, P.tile_first, c->cfg.k, pl.b1, P.seg_counts1, pl.cap1, P.a_recs, nullptr, pl.sks, c->cur_ptr_base,
-                               pl.chunk_tiles, pl.b2);
+                               pl.chunk_tiles, pl.vleaf ? 1024u : pl.b2);
         }
         else if (pl.sk)
             hipLaunchKernelGGL(k_sk1w_extract<false>, dim3(P1W_SEGMENTS), dim3(P1W_THREADS), 0, c->stream, d_words, offs, nr, base0, end_abs,
@@ -2488,6 +2521,13 @@ static int add_reads_partitioned_once(mc_ctx *c, const uint64_t *d_words, const 
                             P.a_hints, pl.sp, 0, nullptr);
         HIPCHK(c, hipGetLastError());
         rc = pipe_resize_by_sample(c, pl, n_records);
+        if (rc == 5 && !c->no_vleaf) {  // (the batch wants a table beyond the reach of the records' leaf bits: once more, the two-array way)
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            c->no_vleaf = true;
+            rc = add_reads_partitioned(c, d_words, d_off, r0, r1, base0, end_abs, wb);
+            c->no_vleaf = false;
+            return rc;
+        }
         if (rc) return rc;
         rc = pipe_finish(c, pl, ms1, false, 0, true, true);
     }
