@@ -1751,7 +1751,8 @@ static int pipe_prepare(mc_ctx *c, uint64_t wb, PipePlan *pl, uint64_t n_records
         pl->compact = compact_tiles && compact_on && staged && pl->sk && pl->b2 > 1 && pl->b2 <= (1u << (32 - SKC_REL_BITS)) && g == 0 && pieces == 1 &&
                       chunk * P1W_TILE <= (1ull << SKC_REL_BITS) && !(pl->guessed && c->virgin);
         // ... unless the table can be given a power of two of regions once the batch's size is known: 512 buckets of 2 .. 1024 leaves
-        static const bool vleaf_on = [] { const char *e = getenv("MC_SK_VLEAF"); return !(e && !strcmp(e, "0")); }();
+        const char *ve = getenv("MC_SK_VLEAF");  // (read on every run: the tests switch it)
+        const bool vleaf_on = !(ve && !strcmp(ve, "0"));
         pl->vleaf = false;
         if (!pl->compact && !lng && vleaf_on && !c->no_vleaf && compact_tiles && compact_on && staged && pl->sk && g == 0 && pieces == 1 && chunk * P1W_TILE <= (1ull << SKC_REL_BITS) &&
             pl->guessed && c->virgin && c->mm_k > 0 && np1 == PT_MAX_BUCKETS && c->n_regions <= (uint64_t)PT_MAX_BUCKETS * 1024) {
@@ -1907,7 +1908,9 @@ static int pipe_resize_by_sample(mc_ctx *c, PipePlan &pl, uint64_t n_records)
         uint64_t p2 = 2 * PT_MAX_BUCKETS;
         while (p2 * 2 <= want) p2 *= 2;
         if (est > 0.45 * (double)(p2 << c->sb)) p2 *= 2;
-        if (p2 > (uint64_t)PT_MAX_BUCKETS * 1024) return 5;
+        uint64_t reach = (uint64_t)PT_MAX_BUCKETS * 1024;
+        if (const char *e = getenv("MC_SK_VLEAF_MAX_REGIONS")) if (*e) reach = std::min<uint64_t>(reach, strtoull(e, nullptr, 10));  // (tests: the way back at a small size)
+        if (p2 > reach) return 5;
         want = p2;
     }
     if (pl.lng && est > 0.40 * (double)(want << c->sb)) return 4;  // (hash keys need their bins roomy, mc_create: the caller takes the per-window form)
@@ -2523,6 +2526,7 @@ static int add_reads_partitioned_once(mc_ctx *c, const uint64_t *d_words, const 
         rc = pipe_resize_by_sample(c, pl, n_records);
         if (rc == 5 && !c->no_vleaf) {  // (the batch wants a table beyond the reach of the records' leaf bits: once more, the two-array way)
             HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (getenv("MC_INGEST_DEBUG")) fprintf(stderr, "[count] the batch wants a table beyond the reach of its records' ten leaf bits: the first level again, two arrays\n");
             c->no_vleaf = true;
             rc = add_reads_partitioned(c, d_words, d_off, r0, r1, base0, end_abs, wb);
             c->no_vleaf = false;

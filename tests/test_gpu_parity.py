@@ -292,6 +292,52 @@ def test_compact_records_of_the_counting_pipeline(mc, monkeypatch, capfd):
         ctx.close()
 
 
+@pytest.mark.parametrize("mode", ["vleaf", "two_arrays", "beyond_reach"])
+def test_first_batch_without_a_hint_sizes_its_table_behind_compact_records(mc, monkeypatch, capfd, mode):
+    """No capacity hint, an empty table: the first level writes compact records whose leaf field is the ten bits of the bin word below the
+    level-1 bucket's (1024 leaves a bucket, whatever the table), the sample of the first bucket then makes a table of a power of two
+    of regions and the second level keeps the bits that table needs (mcgpu.hip PipePlan::vleaf).  Same pairs, same walk as the oracle
+    and as the two-array form (MC_SK_VLEAF=0); and where the wanted table lies beyond the reach of the ten bits
+    (MC_SK_VLEAF_MAX_REGIONS plays that at a small size) the first level runs again the two-array way."""
+    monkeypatch.delenv("MC_COUNT_PATH", raising=False)
+    monkeypatch.setenv("MC_INGEST_DEBUG", "1")
+    if mode == "two_arrays":
+        monkeypatch.setenv("MC_SK_VLEAF", "0")
+    if mode == "beyond_reach":
+        monkeypatch.setenv("MC_SK_VLEAF_MAX_REGIONS", "512")
+    genome, reads, off = synth_case(4, 500000, 320000, 150, 100)  # (38 M windows: enough records for the sample's scratch set)
+    t, _ = oracle_table(reads, off, 31, po.KEY_PACKED)
+    ok, oc = t.dump()
+    seed = genome[10000:10500]
+    hi, lo = seed_windows(seed, 31)
+    ctx = mc.Context(31, mc.KEY_PACKED, 0, 0)
+    ctx.set_coverage_hint(5)
+    capfd.readouterr()
+    ctx.add_reads_packed(po.pack(reads), off)
+    assert ctx.finalize() == t.size()
+    err = capfd.readouterr().err
+    n_v = err.count("(whatever the table: it is sized behind the first level)")
+    assert n_v == (0 if mode == "two_arrays" else 1), err
+    st = ctx.stats()
+    regions = st.table_bytes // (4096 * 16)
+    if mode == "vleaf":
+        assert regions & (regions - 1) == 0 and 0.2 < len(ok) / (regions * 4096) < 0.5, (regions, len(ok))  # (a power of two, load 0.23 .. 0.45 if the sample is right)
+    assert ("the first level again, two arrays" in err) == (mode == "beyond_reach"), err
+    gk, gc = ctx.export(1)
+    assert np.array_equal(gk, ok) and np.array_equal(gc, oc)
+    got = ctx.bfs(hi, lo, 1, 5, 3000, -1)
+    assert_bfs_equal(got, po.bfs(t, 31, po.KEY_PACKED, [seed], 1, 5, 3000, -1))
+    assert got["rounds"] * 4 < got["levels"]  # (the read pointers made the trip)
+    # a second batch into the same table (no longer empty: the ordinary plan)
+    ctx.add_reads_packed(po.pack(reads[:off[30000]]), off[:30001])
+    t.count_reads(reads[:off[30000]], off[:30001], 31, po.KEY_PACKED)
+    ok, oc = t.dump()
+    assert ctx.finalize() == t.size()
+    gk, gc = ctx.export(1)
+    assert np.array_equal(gk, ok) and np.array_equal(gc, oc)
+    ctx.close()
+
+
 def test_capacity_hint_a_quarter_of_what_the_reads_hold(mc, monkeypatch):
     """A capacity hint vouches for the table's size, so the pipeline merges into it without sampling -- and finds most regions
     full: leaves hand occurrences on to the next regions, the direct kernel that drains that list parks what finds no room in
