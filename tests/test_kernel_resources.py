@@ -66,3 +66,17 @@ def test_the_long_record_kernels_fit_two_workgroups_a_cu(tmp_path):
         assert r["private_segment_fixed_size"] == 0 and r["vgpr_spill_count"] == 0, (name, r)
         if "k_p3_long" in name:
             assert 2 * r["group_segment_fixed_size"] <= 160 * 1024 and r["vgpr_count"] <= 128, (name, r)
+
+
+def test_the_binned_exchange_kernels_use_no_scratch_and_fit_a_cu(tmp_path):
+    """The multi-GPU record exchange in its binned form (count_pipeline.h): the first level with its 64 KB histogram of (owner, fine bucket)
+    cells beside the 62 KB it has anyway, and the staged second level in its three forms -- segments where the first level left them,
+    segments where they were received (`in listed`), exact output places (`out listed`) -- one workgroup of 1024 threads a CU each."""
+    kernels = _kernel_notes(tmp_path)
+    staged = {n: r for n, r in kernels.items() if "k_sk2_scatter_stagedILi" in n}
+    assert len(staged) == 3, sorted(staged)
+    binned = {n: r for n, r in kernels.items() if "k_sk1w_extractILb1ELb0ELb1E" in n}
+    assert len(binned) == 1, sorted(kernels)
+    for name, r in list(staged.items()) + list(binned.items()) + [(n, r) for n, r in kernels.items() if "k_skb_" in n]:
+        assert r["private_segment_fixed_size"] == 0 and r["vgpr_spill_count"] == 0, (name, r)
+        assert r["group_segment_fixed_size"] <= 160 * 1024 and r["vgpr_count"] <= 128, (name, r)
