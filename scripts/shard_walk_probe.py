@@ -67,6 +67,13 @@ for rep in range(4):
     res, ms = timed(lambda: ctxs[0].bfs_batch(jobs, cov, 100000, -1))
     print("walk over %d owners' tables in place: %.2f ms (%d reached, %d + %d rounds, %d + %d levels); %d distinct k-mers in all" % (
         W, ms, sum(len(r["lo"]) for r in res), res[0]["rounds"], res[1]["rounds"], res[0]["levels"], res[1]["levels"], total), flush=True)
+# a step of a sharded run attaches anew (the tables changed): what the first walk behind an attachment costs
+exports = [c.shard_export() for c in ctxs]
+for rep in range(3):
+    ctxs[0].shard_detach()
+    _, ms_a = timed(lambda: ctxs[0].shard_attach(exports, 0, True))
+    res, ms = timed(lambda: ctxs[0].bfs_batch(jobs, cov, 100000, -1))
+    print("attached again in %.2f ms, the walk behind it: %.2f ms" % (ms_a, ms), flush=True)
 ctxs[0].shard_detach()
 reached = [r["lo"].copy() for r in res]
 for c in ctxs[1:]:
